@@ -1,0 +1,218 @@
+/*
+ * samtools_amd.h -- C-ABI of the MI355X-native mpileup/depth engine.
+ *
+ * This is the drop-in boundary for the samtools pileup hot path
+ * (BASELINE.json north_star).  Plain C, plain pointers
+ * and sizes, no torch / C++ types.  The functions below replace, in bulk
+ * ("window at a time") form, what the reference does one column at a time:
+ *
+ *   reference interface (file:line)                      replaced by
+ *   ---------------------------------------------------  ---------------------------
+ *   mplp_func read callback        bam_plcmd.c:400-461    sta_stage_window + prep/BAQ kernels
+ *   bam_mplp_init/_auto/...        bam_plcmd.c:581-607    sta_mpileup_plan / sta_mpileup_emit
+ *   bam_mplp_set_maxcnt            bam_plcmd.c:597        sta_mplp_params.max_depth
+ *   bam_mplp_init_overlaps         bam_plcmd.c:586        STA_MPLP_SMART_OVERLAPS
+ *   sam_prob_realn (BAQ)           bam_plcmd.c:451        STA_MPLP_REALN / STA_MPLP_REDO_BAQ
+ *   mpileup() column loop+format   bam_plcmd.c:607-868    sta_mpileup_emit (text on device)
+ *   pileup_seq                     bam_plcmd.c:54-169     sta_mpileup_emit
+ *   print_empty_pileup             bam_plcmd.c:372-398    sta_mpileup_emit with params.all
+ *   mplp_get_ref                   bam_plcmd.c:289-352    sta_set_reference
+ *   add_depth / incr_hist[_qual]   bam2depth.c:165-477    sta_depth_plan / sta_depth_emit
+ *   fastdepth_core merge + -s hash bam2depth.c:486-699    sta_depth_plan (per-file read sets)
+ *   bed_overlap                    bedidx.c:159-197       sta_window.bed_* (merged intervals)
+ *   bam_mpileup / main_depth (CLI) bam_plcmd.c:1075, bam2depth.c:732   sta_main_mpileup / sta_main_depth
+ *
+ * The per-column callback surface (bam_plp_* / bam_mplp_* / bam_plbuf_*) is
+ * declared in samtools_amd_plp.h.
+ *
+ * Threading: one engine is used from one host thread (like bam_mplp_t).
+ * Errors: functions return 0 on success, negative on failure; the message is
+ * available from sta_last_error().  There is NO CPU fallback: every compute
+ * entry point fails with STA_ERR_NO_DEVICE if no HIP device is usable.
+ */
+#ifndef SAMTOOLS_AMD_H
+#define SAMTOOLS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STA_OK 0
+#define STA_ERR_NO_DEVICE (-2)
+#define STA_ERR_HIP (-3)
+#define STA_ERR_ARG (-4)
+#define STA_ERR_UNSORTED (-5)
+#define STA_ERR_UNSUPPORTED (-6)
+#define STA_ERR_IO (-7)
+
+/* mplp_conf_t.flag bits, same values as bam_plcmd.c:173-201 */
+#define STA_MPLP_NO_ORPHAN       (1 << 3)
+#define STA_MPLP_REALN           (1 << 4)
+#define STA_MPLP_REDO_BAQ        (1 << 6)
+#define STA_MPLP_ILLUMINA13      (1 << 7)
+#define STA_MPLP_SMART_OVERLAPS  (1 << 10)
+#define STA_MPLP_PRINT_MAPQ_CHAR (1 << 11)
+#define STA_MPLP_PRINT_QPOS      (1 << 12)
+#define STA_MPLP_PRINT_QNAME     (1 << 13)
+#define STA_MPLP_PRINT_FLAG      (1 << 14)
+#define STA_MPLP_PRINT_RNAME     (1 << 15)
+#define STA_MPLP_PRINT_POS       (1 << 16)
+#define STA_MPLP_PRINT_MAPQ      (1 << 17)
+#define STA_MPLP_PRINT_RNEXT     (1 << 19)
+#define STA_MPLP_PRINT_PNEXT     (1 << 20)
+#define STA_MPLP_PRINT_RLEN      (1 << 24)
+#define STA_MPLP_PRINT_QPOS5     (1 << 26)
+
+/* per-read aux summary bits (sta_reads.aux) computed while decoding */
+#define STA_AUX_HAS_BQ   1   /* BQ:Z present (and usable)         */
+#define STA_AUX_HAS_ZQ   2   /* ZQ:Z present                      */
+#define STA_AUX_SKIP     4   /* excluded by -G read-group list    */
+
+/* where the arrays of a sta_reads / sta_window live */
+#define STA_MEM_HOST   0     /* engine copies them to HBM (pinned staging) */
+#define STA_MEM_DEVICE 1     /* already resident in HBM; used in place     */
+
+/*
+ * Pre-decoded alignment records of ONE input file for ONE window, structure
+ * of arrays, sorted by pos (file order preserved among equal pos).  Record
+ * field meaning follows bam1_core_t.
+ *
+ *  pos[i]        0-based leftmost coordinate MINUS window origin (int32)
+ *  cig_off[i]    index of read i's first op in cigar[]; cig_off[n] = total ops
+ *  base_off8[i]  (offset of read i's first base)/8 in qual[]/bq[]; the 4-bit
+ *                packed sequence starts at seq[base_off8[i]*4].  Every read's
+ *                base run is padded to a multiple of 8 bases.
+ *  name_off[i]   offset of read i's qname in names[]; name_off[n] = total
+ */
+typedef struct sta_reads {
+    int64_t n_reads;
+    const int32_t *pos;
+    const uint16_t *flag;
+    const uint8_t *mapq;
+    const uint8_t *aux;
+    const int32_t *l_qseq;
+    const uint32_t *cig_off;     /* n_reads + 1 */
+    const uint32_t *base_off8;   /* n_reads */
+    const int32_t *mtid;
+    const int64_t *mpos;         /* absolute mate position (bam1_core_t.mpos) */
+    const int32_t *isize;        /* clamped to int32 */
+    const uint32_t *name_off;    /* n_reads + 1 */
+    const uint32_t *cigar;       /* len<<4|op, op in MIDNSHP=XB */
+    const uint8_t *seq;          /* 4-bit packed, high nibble first */
+    const uint8_t *qual;         /* Phred, 0xff = absent */
+    const uint8_t *bq;           /* optional BQ:Z values ('@' = 64 where absent), NULL if no read has one */
+    const char *names;           /* NUL-terminated qnames */
+    uint64_t n_cigar_total, n_bases_total /* padded */, n_name_bytes;
+} sta_reads;
+
+/* One window of reference columns on one contig, with every read (of every
+ * input file) whose reference span can touch it. */
+typedef struct sta_window {
+    int32_t tid;
+    int64_t origin;              /* absolute coordinate of relative column 0 */
+    int32_t col_beg, col_end;    /* relative columns to produce: [col_beg, col_end) */
+    const char *tname;           /* contig name (host pointer, always) */
+    int64_t tlen;                /* contig length from the header */
+    int32_t n_files;
+    const sta_reads *files;      /* host array of n_files descriptors */
+    int32_t mem;                 /* STA_MEM_HOST or STA_MEM_DEVICE: where files[].arrays live */
+    /* -l/-b BED: merged, sorted, disjoint intervals of this contig (absolute, host pointers) */
+    int32_t has_bed;
+    int64_t n_bed;
+    const int64_t *bed_beg, *bed_end;
+    /* -r region clip (absolute, half open); has_reg = 0 for none */
+    int32_t has_reg;
+    int64_t reg_beg, reg_end;
+} sta_window;
+
+/* subset of mplp_conf_t (bam_plcmd.c:206-216) the device path consumes */
+typedef struct sta_mplp_params {
+    int32_t min_mq, min_baseQ, capQ_thres, max_depth;
+    int32_t all, rev_del;
+    int32_t rflag_require, rflag_filter;
+    int32_t flag;                /* STA_MPLP_* */
+    int32_t no_ins, no_del, no_ends;
+    int32_t has_fai;             /* a FASTA was given with -f (BAQ/ref column need it) */
+} sta_mplp_params;
+
+/* subset of depth_opt (bam2depth.c:72-86) */
+typedef struct sta_depth_params {
+    int32_t flag, incl_flag, require_flag;
+    int32_t min_qual, min_mqual, min_len;
+    int32_t skip_del, all_pos, remove_overlaps;
+} sta_depth_params;
+
+/* what a plan call learned about the window */
+typedef struct sta_plan_info {
+    uint64_t out_bytes;          /* text bytes the emit call will produce          */
+    uint64_t n_lines;            /* output rows                                    */
+    uint64_t n_data_cols;        /* columns with >=1 read (mpileup) / covered (depth) */
+    uint64_t n_kept_reads;       /* reads that passed the read-level filters       */
+    uint64_t piled_bases;        /* sum of reference span of kept reads in-window  */
+    uint64_t n_maxcnt_dropped;   /* reads dropped by the -d cap                    */
+} sta_plan_info;
+
+typedef struct sta_engine sta_engine;
+
+/* ---- engine ---- */
+int sta_engine_create(sta_engine **out, int device, void *hip_stream);
+void sta_engine_destroy(sta_engine *e);
+const char *sta_last_error(const sta_engine *e);
+/* number of usable HIP devices (0 when there is none); never throws */
+int sta_device_count(void);
+const char *sta_version(void);
+
+/* ---- reference sequence (mplp_get_ref) ---- */
+/* Copies contig `tid` (raw FASTA characters) to HBM; kept until replaced or
+ * sta_clear_references().  mem selects host or device source pointer. */
+int sta_set_reference(sta_engine *e, int32_t tid, const char *seq, int64_t len, int32_t mem);
+void sta_clear_references(sta_engine *e);
+
+/* ---- staging ---- */
+/* Makes `w` the current window: uploads (STA_MEM_HOST) or adopts
+ * (STA_MEM_DEVICE) the read arrays.  Asynchronous on the engine stream. */
+int sta_stage_window(sta_engine *e, const sta_window *w);
+
+/* ---- mpileup ---- */
+/* Runs read prep (filters, reference span), quality prep (-6, BQ tags), BAQ,
+ * -d cap, mate-overlap resolution and the per-column measuring pass; returns
+ * sizes.  Synchronises the stream. */
+int sta_mpileup_plan(sta_engine *e, const sta_mplp_params *p, sta_plan_info *info);
+/* Writes the pileup text of the planned window into dev_out (device pointer,
+ * capacity >= out_bytes); dev_out == NULL uses an engine-owned buffer that
+ * sta_fetch_output() copies back.  Asynchronous on the engine stream. */
+int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity);
+
+/* ---- depth ---- */
+int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info);
+int sta_depth_emit(sta_engine *e, void *dev_out, uint64_t capacity);
+/* binary per-column counts of the planned window: int32 [n_files][col_end-col_beg]
+ * (device pointer owned by the engine, valid until the next plan call) */
+const int32_t *sta_depth_counts_dev(sta_engine *e);
+
+/* ---- results ---- */
+int sta_fetch_output(sta_engine *e, char *host_out, uint64_t n);   /* D2H + sync */
+int sta_sync(sta_engine *e);
+
+/* ---- measurement support (bench.py) ---- */
+/* When enabled, every kernel launch is bracketed by HIP events on the engine
+ * stream and accumulated per kernel name. */
+void sta_profile_enable(sta_engine *e, int on);
+void sta_profile_reset(sta_engine *e);
+/* Copies up to cap entries; returns the number of distinct kernels. */
+typedef struct sta_kernel_time { char name[48]; uint64_t launches; double total_ms; } sta_kernel_time;
+int sta_profile_get(sta_engine *e, sta_kernel_time *out, int cap);
+
+/* ---- samtools-compatible command drivers (host side, C++) ---- */
+/* argv[0] = "mpileup" / "depth"; same options, stdout/stderr text and exit
+ * status as the reference sub-commands (bamtk.c:248,270 would dispatch here). */
+int sta_main_mpileup(int argc, char **argv);
+int sta_main_depth(int argc, char **argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,233 @@
+"""ctypes mirror of include/samtools_amd.h (structures, constants, prototypes)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libsamtools_amd.so")
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        "samtools_amd: %s is missing -- build it with `make -C samtools_amd/csrc` "
+        "(or __graft_entry__.build()); the engine has no Python/CPU fallback" % _LIB_PATH)
+
+lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+
+STA_OK = 0
+STA_ERR_NO_DEVICE = -2
+STA_MEM_HOST = 0
+STA_MEM_DEVICE = 1
+
+
+class MPLP:
+    NO_ORPHAN = 1 << 3
+    REALN = 1 << 4
+    REDO_BAQ = 1 << 6
+    ILLUMINA13 = 1 << 7
+    SMART_OVERLAPS = 1 << 10
+    PRINT_MAPQ_CHAR = 1 << 11
+    PRINT_QPOS = 1 << 12
+    PRINT_QNAME = 1 << 13
+    PRINT_FLAG = 1 << 14
+    PRINT_RNAME = 1 << 15
+    PRINT_POS = 1 << 16
+    PRINT_MAPQ = 1 << 17
+    PRINT_PNEXT = 1 << 20
+    PRINT_RLEN = 1 << 24
+    PRINT_QPOS5 = 1 << 26
+    DEFAULT = NO_ORPHAN | REALN | SMART_OVERLAPS
+
+
+class Reads(C.Structure):
+    """sta_reads: pointers are raw addresses (host or device, see Window.mem)."""
+    _fields_ = [
+        ("n_reads", C.c_int64),
+        ("pos", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p), ("aux", C.c_void_p),
+        ("l_qseq", C.c_void_p), ("cig_off", C.c_void_p), ("base_off8", C.c_void_p), ("mtid", C.c_void_p),
+        ("mpos", C.c_void_p), ("isize", C.c_void_p), ("name_off", C.c_void_p), ("cigar", C.c_void_p),
+        ("seq", C.c_void_p), ("qual", C.c_void_p), ("bq", C.c_void_p), ("names", C.c_void_p),
+        ("n_cigar_total", C.c_uint64), ("n_bases_total", C.c_uint64), ("n_name_bytes", C.c_uint64),
+    ]
+
+
+class Window(C.Structure):
+    _fields_ = [
+        ("tid", C.c_int32), ("origin", C.c_int64), ("col_beg", C.c_int32), ("col_end", C.c_int32),
+        ("tname", C.c_char_p), ("tlen", C.c_int64),
+        ("n_files", C.c_int32), ("files", C.POINTER(Reads)), ("mem", C.c_int32),
+        ("has_bed", C.c_int32), ("n_bed", C.c_int64), ("bed_beg", C.c_void_p), ("bed_end", C.c_void_p),
+        ("has_reg", C.c_int32), ("reg_beg", C.c_int64), ("reg_end", C.c_int64),
+    ]
+
+
+class MplpParams(C.Structure):
+    _fields_ = [
+        ("min_mq", C.c_int32), ("min_baseQ", C.c_int32), ("capQ_thres", C.c_int32), ("max_depth", C.c_int32),
+        ("all", C.c_int32), ("rev_del", C.c_int32), ("rflag_require", C.c_int32), ("rflag_filter", C.c_int32),
+        ("flag", C.c_int32), ("no_ins", C.c_int32), ("no_del", C.c_int32), ("no_ends", C.c_int32),
+        ("has_fai", C.c_int32),
+    ]
+
+    @classmethod
+    def defaults(cls):
+        """bam_mpileup() defaults (bam_plcmd.c:1083-1094)."""
+        return cls(min_mq=0, min_baseQ=13, capQ_thres=0, max_depth=8000, all=0, rev_del=0, rflag_require=0,
+                   rflag_filter=4 | 256 | 512 | 1024, flag=MPLP.DEFAULT, no_ins=0, no_del=0, no_ends=0, has_fai=0)
+
+
+class DepthParams(C.Structure):
+    _fields_ = [
+        ("flag", C.c_int32), ("incl_flag", C.c_int32), ("require_flag", C.c_int32),
+        ("min_qual", C.c_int32), ("min_mqual", C.c_int32), ("min_len", C.c_int32),
+        ("skip_del", C.c_int32), ("all_pos", C.c_int32), ("remove_overlaps", C.c_int32),
+    ]
+
+    @classmethod
+    def defaults(cls):
+        """main_depth() defaults (bam2depth.c:740-754)."""
+        return cls(flag=4 | 256 | 1024 | 512, incl_flag=0, require_flag=0, min_qual=0, min_mqual=0, min_len=0,
+                   skip_del=1, all_pos=0, remove_overlaps=0)
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("out_bytes", C.c_uint64), ("n_lines", C.c_uint64), ("n_data_cols", C.c_uint64),
+                ("n_kept_reads", C.c_uint64), ("piled_bases", C.c_uint64), ("n_maxcnt_dropped", C.c_uint64)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+_P = C.c_void_p
+_PROTOS = {
+    "sta_engine_create": (C.c_int, [C.POINTER(_P), C.c_int, _P]),
+    "sta_engine_destroy": (None, [_P]),
+    "sta_last_error": (C.c_char_p, [_P]),
+    "sta_device_count": (C.c_int, []),
+    "sta_version": (C.c_char_p, []),
+    "sta_set_reference": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int32]),
+    "sta_clear_references": (None, [_P]),
+    "sta_stage_window": (C.c_int, [_P, C.POINTER(Window)]),
+    "sta_mpileup_plan": (C.c_int, [_P, C.POINTER(MplpParams), C.POINTER(PlanInfo)]),
+    "sta_mpileup_emit": (C.c_int, [_P, _P, C.c_uint64]),
+    "sta_depth_plan": (C.c_int, [_P, C.POINTER(DepthParams), C.POINTER(PlanInfo)]),
+    "sta_depth_emit": (C.c_int, [_P, _P, C.c_uint64]),
+    "sta_depth_counts_dev": (_P, [_P]),
+    "sta_fetch_output": (C.c_int, [_P, _P, C.c_uint64]),
+    "sta_sync": (C.c_int, [_P]),
+    "sta_profile_enable": (None, [_P, C.c_int]),
+    "sta_profile_reset": (None, [_P]),
+    "sta_profile_get": (C.c_int, [_P, C.POINTER(KernelTime), C.c_int]),
+    "sta_main_mpileup": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "sta_main_depth": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+}
+EXPORTED_SYMBOLS = sorted(_PROTOS)
+for _name, (_res, _args) in _PROTOS.items():
+    _f = getattr(lib, _name)   # AttributeError here = the library does not export what the header declares
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def device_count():
+    return int(lib.sta_device_count())
+
+
+def version():
+    return lib.sta_version().decode()
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _argv(args):
+    arr = (C.c_char_p * (len(args) + 1))()
+    for i, a in enumerate(args):
+        arr[i] = a.encode()
+    return arr
+
+
+def main_mpileup(args):
+    """Run the `mpileup` driver in-process; args excludes the sub-command name."""
+    a = ["mpileup"] + list(args)
+    return lib.sta_main_mpileup(len(a), _argv(a))
+
+
+def main_depth(args):
+    a = ["depth"] + list(args)
+    return lib.sta_main_depth(len(a), _argv(a))
+
+
+class Engine:
+    """Owns one sta_engine.  `stream` is a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = _P()
+        rc = lib.sta_engine_create(C.byref(self._h), int(device), _P(stream or 0))
+        if rc == STA_ERR_NO_DEVICE:
+            raise EngineError("no usable HIP device %d (the engine has no CPU fallback)" % device)
+        if rc != STA_OK:
+            raise EngineError("sta_engine_create failed: %d" % rc)
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            lib.sta_engine_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != STA_OK:
+            raise EngineError("%s failed (%d): %s" % (what, rc, lib.sta_last_error(self._h).decode()))
+
+    def set_reference(self, tid, ptr, length, mem=STA_MEM_HOST):
+        self._chk(lib.sta_set_reference(self._h, tid, _P(ptr), length, mem), "sta_set_reference")
+
+    def clear_references(self):
+        lib.sta_clear_references(self._h)
+
+    def stage_window(self, window):
+        self._keep = [window]
+        self._chk(lib.sta_stage_window(self._h, C.byref(window)), "sta_stage_window")
+
+    def mpileup_plan(self, params):
+        info = PlanInfo()
+        self._chk(lib.sta_mpileup_plan(self._h, C.byref(params), C.byref(info)), "sta_mpileup_plan")
+        return info
+
+    def mpileup_emit(self, dev_ptr=None, capacity=0):
+        self._chk(lib.sta_mpileup_emit(self._h, _P(dev_ptr or 0), capacity), "sta_mpileup_emit")
+
+    def depth_plan(self, params):
+        info = PlanInfo()
+        self._chk(lib.sta_depth_plan(self._h, C.byref(params), C.byref(info)), "sta_depth_plan")
+        return info
+
+    def depth_emit(self, dev_ptr=None, capacity=0):
+        self._chk(lib.sta_depth_emit(self._h, _P(dev_ptr or 0), capacity), "sta_depth_emit")
+
+    def depth_counts_ptr(self):
+        return lib.sta_depth_counts_dev(self._h)
+
+    def fetch_output(self, nbytes):
+        buf = C.create_string_buffer(int(nbytes) if nbytes else 1)
+        self._chk(lib.sta_fetch_output(self._h, C.cast(buf, _P), int(nbytes)), "sta_fetch_output")
+        return buf.raw[:int(nbytes)]
+
+    def sync(self):
+        self._chk(lib.sta_sync(self._h), "sta_sync")
+
+    def profile(self, on=True):
+        lib.sta_profile_enable(self._h, 1 if on else 0)
+
+    def profile_reset(self):
+        lib.sta_profile_reset(self._h)
+
+    def profile_get(self):
+        arr = (KernelTime * 64)()
+        n = lib.sta_profile_get(self._h, arr, 64)
+        return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(min(n, 64))}

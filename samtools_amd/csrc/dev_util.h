@@ -1,0 +1,99 @@
+// dev_util.h -- small device helpers shared by the kernels (gfx950, wave64).
+#pragma once
+#include "sta_dev.h"
+
+#define WAVE 64
+
+#define BAM_FPAIRED 1
+#define BAM_FPROPER_PAIR 2
+#define BAM_FUNMAP 4
+#define BAM_FMUNMAP 8
+#define BAM_FREVERSE 16
+
+enum { CG_M = 0, CG_I, CG_D, CG_N, CG_S, CG_H, CG_P, CG_EQ, CG_X, CG_B };
+
+__device__ __forceinline__ bool cg_is_refop(int op) { return (0x18Du >> op) & 1; }   // M D N = X  -> bits 0,2,3,7,8
+__device__ __forceinline__ bool cg_is_mop(int op) { return (0x181u >> op) & 1; }     // M = X
+__device__ __forceinline__ bool cg_is_qop(int op) { return op == CG_I || op == CG_S; }
+
+__device__ __forceinline__ int dec_digits(unsigned long long v)
+{
+    int n = 1;
+    while (v >= 10) { v /= 10; ++n; }
+    return n;
+}
+__device__ __forceinline__ int dec_digits_u32(uint32_t v)
+{
+    return 1 + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u)
+             + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
+}
+
+// merged, sorted, disjoint intervals: does [beg,end) overlap any?  (bedidx.c:159-197 semantics)
+__device__ __forceinline__ bool bed_overlap_dev(const int64_t *bbeg, const int64_t *bend, int64_t n, int64_t beg, int64_t end)
+{
+    // first interval with bend > beg
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (bend[mid] > beg) hi = mid; else lo = mid + 1;
+    }
+    return lo < n && bbeg[lo] < end;
+}
+
+// seq_nt16_table restricted to what FASTA text can hold (hts.c)
+__device__ __forceinline__ int nt16_from_char(unsigned char c)
+{
+    switch (c) {
+    case '=': return 0;
+    case 'A': case 'a': return 1;
+    case 'C': case 'c': return 2;
+    case 'M': case 'm': return 3;
+    case 'G': case 'g': return 4;
+    case 'R': case 'r': return 5;
+    case 'S': case 's': return 6;
+    case 'V': case 'v': return 7;
+    case 'T': case 't': return 8;
+    case 'W': case 'w': return 9;
+    case 'Y': case 'y': return 10;
+    case 'H': case 'h': return 11;
+    case 'K': case 'k': return 12;
+    case 'D': case 'd': return 13;
+    case 'B': case 'b': return 14;
+    case '0': return 1;
+    case '1': return 2;
+    case '2': return 4;
+    case '3': return 8;
+    default: return 15;
+    }
+}
+
+__device__ __forceinline__ int seq_nib(const uint8_t *seq, uint64_t seq_byte0, int i)
+{
+    return (seq[seq_byte0 + (uint64_t)(i >> 1)] >> ((~i & 1) << 2)) & 0xf;
+}
+
+__device__ __forceinline__ char lower_c(char c) { return (c >= 'A' && c <= 'Z') ? (char)(c + 32) : c; }
+__device__ __forceinline__ char upper_c(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+
+// wave-cooperative search on a non-decreasing int32 array: first index in [0,n) with a[i] > key
+// (a "64-ary" search: every step the 64 lanes probe 64 evenly spaced points)
+__device__ __forceinline__ int64_t wave_upper_bound(const int32_t *a, int64_t n, int32_t key)
+{
+    int lane = threadIdx.x & (WAVE - 1);
+    int64_t lo = 0, hi = n;          // answer in [lo, hi]
+    while (hi - lo > 0) {
+        int64_t span = hi - lo;
+        int64_t step = (span + WAVE - 1) / WAVE;
+        int64_t idx = lo + (int64_t)lane * step;
+        bool gt = (idx < hi) ? (a[idx] > key) : true;
+        unsigned long long m = __ballot(gt);
+        int first = m ? __ffsll((long long)m) - 1 : WAVE;   // first lane whose probe is > key
+        // answer lies in (probe[first-1], probe[first]]
+        int64_t nlo = first == 0 ? lo : lo + (int64_t)(first - 1) * step + 1;
+        int64_t nhi = lo + (int64_t)first * step;
+        if (nhi > hi) nhi = hi;
+        if (step == 1) { lo = nhi; hi = nhi; break; }
+        lo = nlo; hi = nhi;
+    }
+    return lo;
+}

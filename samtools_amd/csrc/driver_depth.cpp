@@ -1,0 +1,240 @@
+// driver_depth.cpp -- `samtools depth` command driver on top of the device engine.
+//
+// Mirrors main_depth()/fastdepth_core() of the reference (bam2depth.c:732-1006, :486-699): same
+// options, same rows.  The N-file merge by (tid,pos) (:578-596) becomes "every window receives the
+// reads of every file", the ring histogram + row flushing (:209-477) becomes the difference /
+// scan / format kernels of the engine, and the -a/-aa zero_region() calls (:88-118, :246-287) are
+// restated per contig below.
+#include "host_io.h"
+#include "host_stage.h"
+#include "host_pump.h"
+#include <getopt.h>
+#include <cstdio>
+#include <cstring>
+#include <cerrno>
+#include <climits>
+
+using namespace sta;
+
+namespace {
+
+struct DRunner {
+    sta_depth_params p{};
+    sta_engine *eng = nullptr;
+    std::vector<std::unique_ptr<AlnReader>> readers;
+    const Header *h = nullptr;
+    FILE *out = stdout;
+    std::unique_ptr<Bed> bed;
+    bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
+    int64_t window_cols = 1 << 20, max_reads = 4 << 20;
+    std::vector<StagedFile> staged;
+    std::vector<char> text;
+
+    int run_window(int tid, int64_t cb, int64_t ce, const std::vector<std::vector<const Rec *>> *reads, int all_mode,
+                   bool write, uint64_t *n_kept)
+    {
+        if (ce <= cb) { if (n_kept) *n_kept = 0; return 0; }
+        size_t nf = readers.size();
+        staged.resize(nf);
+        std::vector<sta_reads> views(nf);
+        for (size_t f = 0; f < nf; ++f) {
+            staged[f].clear();
+            if (reads) for (const Rec *r : (*reads)[f]) staged[f].add(*r, cb, nullptr);
+            staged[f].finish();
+            views[f] = staged[f].view();
+        }
+        sta_window w; memset(&w, 0, sizeof w);
+        w.tid = tid; w.origin = cb; w.col_beg = 0; w.col_end = (int32_t)(ce - cb);
+        w.tname = h->names[(size_t)tid].c_str(); w.tlen = h->lens[(size_t)tid];
+        w.n_files = (int32_t)nf; w.files = views.data(); w.mem = STA_MEM_HOST;
+        const Bed::Ivals *iv = bed ? bed->get(h->names[(size_t)tid]) : nullptr;
+        static const int64_t none = 0;
+        if (bed) { w.has_bed = 1; w.n_bed = iv ? (int64_t)iv->beg.size() : 0; w.bed_beg = iv ? iv->beg.data() : &none; w.bed_end = iv ? iv->end.data() : &none; }
+        if (sta_stage_window(eng, &w) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
+        sta_depth_params pp = p;
+        pp.all_pos = all_mode;
+        sta_plan_info info;
+        if (sta_depth_plan(eng, &pp, &info) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
+        if (n_kept) *n_kept = info.n_kept_reads;
+        if (!write || info.out_bytes == 0) return 0;
+        if (sta_depth_emit(eng, nullptr, 0) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
+        text.resize((size_t)info.out_bytes);
+        if (sta_fetch_output(eng, text.data(), info.out_bytes) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
+        if (fwrite(text.data(), 1, text.size(), out) != text.size()) return -1;
+        return 0;
+    }
+
+    int run_empty(int tid, int64_t a, int64_t b)      // zero_region
+    {
+        while (a < b) {
+            int64_t e = std::min(b, a + window_cols);
+            if (run_window(tid, a, e, nullptr, 1, true, nullptr) < 0) return -1;
+            a = e;
+        }
+        return 0;
+    }
+
+    // mode 0: covered rows only; 1: -a (zero rows once a read of this contig passed the filters); 2: always
+    int process_tid(Pump &pump, int tid, int mode)
+    {
+        int64_t tlen = h->lens[(size_t)tid];
+        int64_t lo = has_reg ? beg0 : 0;
+        int64_t hi_all = has_reg ? std::min(end0, tlen) : tlen;
+        bool started = mode == 2;
+        int64_t cursor = started ? lo : std::max(lo, pump.next_pos(tid));
+        std::vector<std::vector<const Rec *>> reads;
+        for (;;) {
+            bool more = pump.next_pos(tid) != INT64_MAX;
+            if (!more && !pump.has_carry()) break;
+            if (!started && !pump.has_carry()) cursor = std::max(cursor, pump.next_pos(tid));
+            int64_t ce_target = cursor + window_cols;
+            if (has_reg) ce_target = std::min(ce_target, end0);
+            if (ce_target <= cursor) { pump.fill(tid, cursor, INT64_MAX, reads); pump.drop_tid_carry(); break; }
+            int64_t ce = pump.fill(tid, cursor, ce_target, reads);
+            if (pump.error()) return -1;
+            if (pump.next_pos(tid) == INT64_MAX) {
+                int64_t me = pump.carry_max_end();
+                if (me != INT64_MIN) ce = std::min(ce, std::max(me, cursor));
+            }
+            if (ce > cursor) {
+                uint64_t n_kept = 0;
+                if (mode == 1 && !started) {
+                    if (run_window(tid, cursor, ce, &reads, 0, false, &n_kept) < 0) return -1;
+                    if (n_kept) {
+                        started = true;
+                        if (run_empty(tid, lo, cursor) < 0) return -1;
+                        if (run_window(tid, cursor, ce, &reads, 1, true, &n_kept) < 0) return -1;
+                    }
+                } else if (run_window(tid, cursor, ce, &reads, started ? 1 : 0, true, &n_kept) < 0) return -1;
+            }
+            pump.retire(ce);
+            cursor = std::max(cursor, ce);
+        }
+        pump.drop_tid_carry();
+        if (started && run_empty(tid, cursor, hi_all) < 0) return -1;
+        return 0;
+    }
+
+    int run()
+    {
+        PumpConfig pc; pc.window_cols = window_cols; pc.max_reads = max_reads; pc.use_endpos = true;
+        Pump pump(readers, pc);
+        const int all = p.all_pos;
+        // with a region every -a/-aa run prints the whole region of tid0 (bam2depth.c:267-270)
+        const int mode = has_reg ? (all ? 2 : 0) : (all >= 2 ? 2 : all);
+        int next_full = 0; bool did_tid0 = false;
+        for (;;) {
+            int tid = pump.next_tid();
+            if (pump.error()) break;
+            if (all >= 2 && !has_reg) {
+                int upto = tid < 0 ? h->nref() : tid;
+                for (int t = next_full; t < upto; ++t) if (run_empty(t, 0, h->lens[(size_t)t]) < 0) return 1;
+                next_full = tid < 0 ? h->nref() : tid + 1;
+            }
+            if (tid < 0) break;
+            if (has_reg && tid == tid0) did_tid0 = true;
+            if (process_tid(pump, tid, mode) < 0) { if (pump.error()) break; return 1; }
+        }
+        if (pump.error()) {
+            fflush(out);
+            if (pump.error() == -2) fprintf(stderr, "samtools depth: Data is not position sorted\n");
+            else fprintf(stderr, "samtools depth: %s\n", pump.error_text());
+            return 1;
+        }
+        if (all && has_reg && !did_tid0)
+            if (run_empty(tid0, beg0, std::min(end0, h->lens[(size_t)tid0])) < 0) return 1;
+        return 0;
+    }
+};
+
+void usage_exit(FILE *fp)
+{
+    fprintf(fp, "Usage: samtools depth [options] in.bam [in.bam ...]\n"
+                "(MI355X engine; options as samtools 1.23.1 depth except -X and CRAM input)\n");
+}
+
+}  // namespace
+
+extern "C" int sta_main_depth(int argc, char **argv)
+{
+    DRunner run;
+    sta_depth_params &opt = run.p;
+    opt.flag = 4 | 256 | 1024 | 512;
+    opt.skip_del = 1;
+    std::string file_list, out_file, reg;
+    bool header = false;
+    if (const char *e = getenv("STA_WINDOW_COLS")) run.window_cols = std::max<long long>(1, atoll(e));
+    if (const char *e = getenv("STA_WINDOW_READS")) run.max_reads = std::max<long long>(1, atoll(e));
+
+    static const struct option lopts[] = {
+        { "min-MQ", required_argument, NULL, 'Q' }, { "min-mq", required_argument, NULL, 'Q' },
+        { "min-BQ", required_argument, NULL, 'q' }, { "min-bq", required_argument, NULL, 'q' },
+        { "excl-flags", required_argument, NULL, 'G' }, { "incl-flags", required_argument, NULL, 1 },
+        { "require-flags", required_argument, NULL, 2 }, { "threads", required_argument, NULL, '@' },
+        { NULL, 0, NULL, 0 } };
+    optind = 1;
+    int c, tmp;
+    while ((c = getopt_long(argc, argv, "@:q:Q:JHd:m:l:g:G:o:ar:Xf:b:s", lopts, NULL)) >= 0) {
+        switch (c) {
+        case 'a': opt.all_pos++; break;
+        case 'b':
+            run.bed = Bed::load(optarg);
+            if (!run.bed) { fprintf(stderr, "samtools depth: Could not read file \"%s\"\n", optarg); return 1; }
+            break;
+        case 'f': file_list = optarg; break;
+        case 'd': case 'm': case '@': break;
+        case 'g': tmp = str2flag(optarg); if (tmp < 0) { fprintf(stderr, "samtools depth: Unknown flag '%s'\n", optarg); return 1; } opt.flag &= ~tmp; break;
+        case 'G': tmp = str2flag(optarg); if (tmp < 0) { fprintf(stderr, "samtools depth: Unknown flag '%s'\n", optarg); return 1; } opt.flag |= tmp; break;
+        case 1: tmp = str2flag(optarg); if (tmp < 0) { fprintf(stderr, "samtools depth: Unknown flag '%s'\n", optarg); return 1; } opt.incl_flag |= tmp; break;
+        case 2: tmp = str2flag(optarg); if (tmp < 0) { fprintf(stderr, "samtools depth: Unknown flag '%s'\n", optarg); return 1; } opt.require_flag |= tmp; break;
+        case 'l': opt.min_len = atoi(optarg); break;
+        case 'H': header = true; break;
+        case 'q': opt.min_qual = atoi(optarg); break;
+        case 'Q': opt.min_mqual = atoi(optarg); break;
+        case 'J': opt.skip_del = 0; break;
+        case 'o': if (out_file.empty()) out_file = optarg; break;
+        case 'r': reg = optarg; break;
+        case 's': opt.remove_overlaps = 1; break;
+        case 'X': fprintf(stderr, "samtools depth: -X is not supported by the MI355X engine\n"); return 1;
+        default: usage_exit(stderr); return 1;
+        }
+    }
+    if (argc < optind + 1 && file_list.empty()) { usage_exit(argc == optind ? stdout : stderr); return argc == optind ? 0 : 1; }
+    std::vector<std::string> fns;
+    if (!file_list.empty()) { if (!read_file_list(file_list, &fns)) return 1; }
+    else for (int i = optind; i < argc; ++i) fns.push_back(argv[i]);
+
+    for (auto &fn : fns) {
+        std::string err;
+        auto r = AlnReader::open(fn, &err);
+        if (!r) { fprintf(stderr, "samtools depth: Cannot open input file \"%s\": %s\n", fn.c_str(), strerror(errno ? errno : ENOENT)); return 1; }
+        run.readers.push_back(std::move(r));
+    }
+    run.h = &run.readers[0]->header();
+    if (!reg.empty()) {
+        for (size_t i = 0; i < run.readers.size(); ++i) {
+            int t; int64_t b, e;
+            if (!parse_region(run.readers[i]->header(), reg, &t, &b, &e)) { fprintf(stderr, "samtools depth: cannot parse region \"%s\"\n", reg.c_str()); return 1; }
+            run.readers[i]->set_region(t, b, e);
+            if (i == 0) { run.has_reg = true; run.tid0 = t; run.beg0 = b; run.end0 = e; }
+        }
+    }
+    if (!out_file.empty()) {
+        run.out = fopen(out_file.c_str(), "w");
+        if (!run.out) { fprintf(stderr, "samtools depth: Cannot open \"%s\" for writing.\n", out_file.c_str()); return 1; }
+    }
+    if (header) {
+        fprintf(run.out, "#CHROM\tPOS");
+        for (auto &fn : fns) fprintf(run.out, "\t%s", fn.c_str());
+        fputc('\n', run.out);
+    }
+    if (sta_engine_create(&run.eng, 0, nullptr) != STA_OK) {
+        fprintf(stderr, "samtools depth: no usable HIP device (the MI355X engine has no CPU fallback)\n");
+        return 1;
+    }
+    int ret = run.run();
+    fflush(run.out);
+    if (run.out != stdout) fclose(run.out);
+    sta_engine_destroy(run.eng);
+    return ret;
+}

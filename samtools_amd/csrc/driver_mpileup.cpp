@@ -1,0 +1,377 @@
+// driver_mpileup.cpp -- `samtools mpileup` command driver on top of the device engine.
+//
+// Mirrors bam_mpileup()/mpileup() of the reference (bam_plcmd.c:1075-1272, :470-934): same options,
+// same stdout text, same mandatory stderr line and exit status.  What differs is the execution
+// model: instead of asking the iterator for one column at a time, the driver cuts each contig into
+// windows, stages every read that can touch a window (host_pump + host_stage), and the engine
+// produces the window's text on the GPU (include/samtools_amd.h).  The -a/-aa bookkeeping of
+// mpileup() (:610-660, :880-910) is restated at window granularity below.
+#include "host_io.h"
+#include "host_stage.h"
+#include "host_pump.h"
+#include <getopt.h>
+#include <cstdio>
+#include <cstring>
+#include <cerrno>
+#include <climits>
+#include <set>
+
+using namespace sta;
+
+namespace {
+
+struct Conf {
+    sta_mplp_params p{};
+    std::string reg, fai_fname, output_fname;
+    std::unique_ptr<Fasta> fai;
+    std::unique_ptr<Bed> bed;
+    std::set<std::string> rg_excl; bool has_rg_excl = false;
+    int64_t window_cols = 1 << 20, max_reads = 4 << 20;
+};
+
+// sample.c:79-122 (bam_smpl_add): number of distinct samples for "[mpileup] N samples in M input files"
+struct Samples {
+    std::set<std::string> rg, sm;
+    void add_pair(const std::string &k, const std::string &v) { if (rg.count(k)) return; rg.insert(k); sm.insert(v); }
+    void add(const std::string &fn, const std::string *txt)
+    {
+        if (!txt) { add_pair(fn, fn); return; }
+        size_t p = 0; int n = 0; std::string first_sm; bool have_first = false;
+        for (;;) {
+            size_t q = txt->find("@RG", p);
+            if (q == std::string::npos) break;
+            p = q + 3;
+            size_t qi = txt->find("\tID:", p), ri = txt->find("\tSM:", p);
+            if (qi == std::string::npos || ri == std::string::npos) break;
+            qi += 4; ri += 4;
+            size_t qe = txt->find_first_of("\t\n", qi), re = txt->find_first_of("\t\n", ri);
+            std::string id = txt->substr(qi, qe == std::string::npos ? std::string::npos : qe - qi);
+            std::string smv = txt->substr(ri, re == std::string::npos ? std::string::npos : re - ri);
+            add_pair(fn + "/" + id, smv);
+            if (!have_first) { first_sm = smv; have_first = true; }
+            p = std::max(qi, ri);
+            ++n;
+        }
+        if (n == 0) add_pair(fn, fn);
+        else if (n == 1 && have_first) add_pair(fn, first_sm);
+    }
+};
+
+struct Runner {
+    Conf &conf;
+    sta_engine *eng = nullptr;
+    std::vector<std::unique_ptr<AlnReader>> readers;
+    const Header *h = nullptr;
+    FILE *out = stdout;
+    bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
+    std::vector<StagedFile> staged;
+    std::vector<char> text;
+    int loaded_ref_tid = -2;
+
+    explicit Runner(Conf &c) : conf(c) {}
+
+    int set_ref(int tid)
+    {
+        if (!conf.fai || tid == loaded_ref_tid) return 0;
+        sta_clear_references(eng);
+        loaded_ref_tid = tid;
+        const std::string *s = conf.fai->fetch(h->names[(size_t)tid]);
+        if (!s) return 0;
+        return sta_set_reference(eng, tid, s->data(), (int64_t)s->size(), STA_MEM_HOST);
+    }
+
+    // run one window; all_mode overrides conf.p.all.  Returns <0 on error; n_data receives the data column count.
+    int run_window(int tid, int64_t cb, int64_t ce, const std::vector<std::vector<const Rec *>> *reads, int all_mode,
+                   bool write, uint64_t *n_data)
+    {
+        if (ce <= cb) { if (n_data) *n_data = 0; return 0; }
+        if (set_ref(tid) < 0) return -1;
+        size_t nf = readers.size();
+        staged.resize(nf);
+        std::vector<sta_reads> views(nf);
+        for (size_t f = 0; f < nf; ++f) {
+            staged[f].clear();
+            if (reads) for (const Rec *r : (*reads)[f]) staged[f].add(*r, cb, conf.has_rg_excl ? &conf.rg_excl : nullptr);
+            staged[f].finish();
+            views[f] = staged[f].view();
+        }
+        sta_window w; memset(&w, 0, sizeof w);
+        w.tid = tid; w.origin = cb; w.col_beg = 0; w.col_end = (int32_t)(ce - cb);
+        w.tname = h->names[(size_t)tid].c_str(); w.tlen = h->lens[(size_t)tid];
+        w.n_files = (int32_t)nf; w.files = views.data(); w.mem = STA_MEM_HOST;
+        const Bed::Ivals *iv = conf.bed ? conf.bed->get(h->names[(size_t)tid]) : nullptr;
+        static const int64_t none = 0;
+        if (conf.bed) { w.has_bed = 1; w.n_bed = iv ? (int64_t)iv->beg.size() : 0; w.bed_beg = iv ? iv->beg.data() : &none; w.bed_end = iv ? iv->end.data() : &none; }
+        if (has_reg) { w.has_reg = 1; w.reg_beg = beg0; w.reg_end = end0; }
+        if (sta_stage_window(eng, &w) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
+        sta_mplp_params p = conf.p;
+        p.all = all_mode;
+        sta_plan_info info;
+        if (sta_mpileup_plan(eng, &p, &info) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
+        if (n_data) *n_data = info.n_data_cols;
+        if (!write || info.out_bytes == 0) return 0;
+        if (sta_mpileup_emit(eng, nullptr, 0) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
+        text.resize((size_t)info.out_bytes);
+        if (sta_fetch_output(eng, text.data(), info.out_bytes) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
+        if (fwrite(text.data(), 1, text.size(), out) != text.size()) { fprintf(stderr, "Failed to write pileup data.\n"); return -1; }
+        return 0;
+    }
+
+    // zero-depth rows for [a,b) of a contig (print_empty_pileup), produced by read-less windows
+    int run_empty(int tid, int64_t a, int64_t b)
+    {
+        while (a < b) {
+            int64_t e = std::min(b, a + conf.window_cols);
+            if (run_window(tid, a, e, nullptr, 1, true, nullptr) < 0) return -1;
+            a = e;
+        }
+        return 0;
+    }
+
+    // One contig.  mode 0: only covered columns (no -a); 1: -a, zero-depth rows once the contig has shown a
+    // data column; 2: -aa, always.  Equivalent to mpileup()'s last_tid/last_pos bookkeeping (:610-660,
+    // :880-910): every contig that prints anything prints its whole [lo, hi_all) range, in contig order.
+    int process_tid(Pump &pump, int tid, int mode)
+    {
+        int64_t tlen = h->lens[(size_t)tid];
+        int64_t lo = has_reg ? beg0 : 0;
+        int64_t hi_all = has_reg ? std::min(end0, tlen) : tlen;
+        bool started = mode == 2;
+        int64_t cursor = started ? lo : std::max(lo, pump.next_pos(tid));
+        std::vector<std::vector<const Rec *>> reads;
+        for (;;) {
+            bool more = pump.next_pos(tid) != INT64_MAX;
+            if (!more && !pump.has_carry()) break;
+            if (!started && !pump.has_carry()) cursor = std::max(cursor, pump.next_pos(tid));   // skip uncovered gap
+            int64_t ce_target = cursor + conf.window_cols;
+            if (has_reg) ce_target = std::min(ce_target, end0);
+            if (ce_target <= cursor) {              // past the region end: drain the rest of this contig
+                pump.fill(tid, cursor, INT64_MAX, reads);
+                pump.drop_tid_carry();
+                break;
+            }
+            int64_t ce = pump.fill(tid, cursor, ce_target, reads);
+            if (pump.error()) return -1;
+            if (pump.next_pos(tid) == INT64_MAX) {  // last reads of the contig: stop where they stop
+                int64_t me = pump.carry_max_end();
+                if (me != INT64_MIN) ce = std::min(ce, std::max(me, cursor));
+            }
+            if (ce > cursor) {
+                uint64_t n_data = 0;
+                if (mode == 1 && !started) {
+                    if (run_window(tid, cursor, ce, &reads, 0, false, &n_data) < 0) return -1;
+                    if (n_data) {
+                        started = true;
+                        if (run_empty(tid, lo, cursor) < 0) return -1;
+                        if (run_window(tid, cursor, ce, &reads, 1, true, &n_data) < 0) return -1;
+                    }
+                } else if (run_window(tid, cursor, ce, &reads, started ? 1 : 0, true, &n_data) < 0) return -1;
+            }
+            pump.retire(ce);
+            cursor = std::max(cursor, ce);
+        }
+        pump.drop_tid_carry();
+        if (started && run_empty(tid, cursor, hi_all) < 0) return -1;
+        return 0;
+    }
+
+    int run()
+    {
+        PumpConfig pc; pc.window_cols = conf.window_cols; pc.max_reads = conf.max_reads; pc.use_endpos = false;
+        Pump pump(readers, pc);
+        const int all = conf.p.all;
+        const int mode = all >= 2 ? 2 : all;
+        int next_full = 0;               // -aa without region: contigs below this index are done
+        bool did_tid0 = false;
+        for (;;) {
+            int tid = pump.next_tid();
+            if (pump.error()) break;
+            if (all >= 2 && !has_reg) {
+                int upto = tid < 0 ? h->nref() : tid;
+                for (int t = next_full; t < upto; ++t) if (run_empty(t, 0, h->lens[(size_t)t]) < 0) return 1;
+                next_full = tid < 0 ? h->nref() : tid + 1;
+            }
+            if (tid < 0) break;
+            if (has_reg && tid == tid0) did_tid0 = true;
+            if (process_tid(pump, tid, mode) < 0) { if (pump.error()) break; return 1; }
+        }
+        if (pump.error()) {
+            fflush(out);
+            fprintf(stderr, "samtools mpileup: %s\n", pump.error_text());
+            fprintf(stderr, "samtools mpileup: error reading from input file\n");
+            return 1;
+        }
+        if (all >= 2 && has_reg && !did_tid0)
+            if (run_empty(tid0, beg0, std::min(end0, h->lens[(size_t)tid0])) < 0) return 1;
+        return 0;
+    }
+};
+
+void usage(FILE *fp)
+{
+    fprintf(fp, "\nUsage: samtools mpileup [options] in1.bam [in2.bam [...]]\n"
+                "(MI355X engine; options as samtools 1.23.1 mpileup except -M, -C, -X and CRAM input)\n");
+}
+
+}  // namespace
+
+extern "C" int sta_main_mpileup(int argc, char **argv)
+{
+    Conf conf;
+    sta_mplp_params &mp = conf.p;
+    mp.min_baseQ = 13; mp.capQ_thres = 0; mp.max_depth = 8000;
+    mp.flag = STA_MPLP_NO_ORPHAN | STA_MPLP_REALN | STA_MPLP_SMART_OVERLAPS;
+    mp.rflag_filter = 4 | 256 | 512 | 1024;
+    int use_orphan = 0;
+    std::string file_list;
+    bool ignore_rg = false;
+    if (const char *e = getenv("STA_WINDOW_COLS")) conf.window_cols = std::max<long long>(1, atoll(e));
+    if (const char *e = getenv("STA_WINDOW_READS")) conf.max_reads = std::max<long long>(1, atoll(e));
+
+    static const struct option lopts[] = {
+        { "rf", required_argument, NULL, 1 }, { "ff", required_argument, NULL, 2 },
+        { "incl-flags", required_argument, NULL, 1 }, { "excl-flags", required_argument, NULL, 2 },
+        { "output", required_argument, NULL, 3 },
+        { "output-QNAME", no_argument, NULL, 5 }, { "output-qname", no_argument, NULL, 5 },
+        { "illumina1.3+", no_argument, NULL, '6' }, { "count-orphans", no_argument, NULL, 'A' },
+        { "bam-list", required_argument, NULL, 'b' },
+        { "no-BAQ", no_argument, NULL, 'B' }, { "no-baq", no_argument, NULL, 'B' },
+        { "adjust-MQ", required_argument, NULL, 'C' }, { "adjust-mq", required_argument, NULL, 'C' },
+        { "max-depth", required_argument, NULL, 'd' },
+        { "redo-BAQ", no_argument, NULL, 'E' }, { "redo-baq", no_argument, NULL, 'E' },
+        { "fasta-ref", required_argument, NULL, 'f' }, { "reference", required_argument, NULL, 'f' },
+        { "exclude-RG", required_argument, NULL, 'G' }, { "exclude-rg", required_argument, NULL, 'G' },
+        { "positions", required_argument, NULL, 'l' }, { "region", required_argument, NULL, 'r' },
+        { "ignore-RG", no_argument, NULL, 'R' }, { "ignore-rg", no_argument, NULL, 'R' },
+        { "min-MQ", required_argument, NULL, 'q' }, { "min-mq", required_argument, NULL, 'q' },
+        { "min-BQ", required_argument, NULL, 'Q' }, { "min-bq", required_argument, NULL, 'Q' },
+        { "ignore-overlaps-removal", no_argument, NULL, 'x' }, { "disable-overlap-removal", no_argument, NULL, 'x' },
+        { "output-mods", no_argument, NULL, 'M' },
+        { "output-BP", no_argument, NULL, 'O' }, { "output-bp", no_argument, NULL, 'O' },
+        { "output-BP-5", no_argument, NULL, 14 }, { "output-bp-5", no_argument, NULL, 14 },
+        { "output-MQ", no_argument, NULL, 's' }, { "output-mq", no_argument, NULL, 's' },
+        { "customized-index", no_argument, NULL, 'X' },
+        { "reverse-del", no_argument, NULL, 6 }, { "output-extra", required_argument, NULL, 7 },
+        { "output-sep", required_argument, NULL, 8 }, { "output-empty", required_argument, NULL, 9 },
+        { "no-output-ins", no_argument, NULL, 10 }, { "no-output-ins-mods", no_argument, NULL, 11 },
+        { "no-output-del", no_argument, NULL, 12 }, { "no-output-ends", no_argument, NULL, 13 },
+        { NULL, 0, NULL, 0 } };
+
+    optind = 1;
+    int c;
+    while ((c = getopt_long(argc, argv, "Af:r:l:q:Q:RC:Bd:b:o:EG:6OsxXaM", lopts, NULL)) >= 0) {
+        switch (c) {
+        case 'x': mp.flag &= ~STA_MPLP_SMART_OVERLAPS; break;
+        case 1: mp.rflag_require = str2flag(optarg); if (mp.rflag_require < 0) { fprintf(stderr, "Could not parse --rf %s\n", optarg); return 1; } break;
+        case 2: mp.rflag_filter = str2flag(optarg); if (mp.rflag_filter < 0) { fprintf(stderr, "Could not parse --ff %s\n", optarg); return 1; } break;
+        case 3: case 'o': conf.output_fname = optarg; break;
+        case 5: mp.flag |= STA_MPLP_PRINT_QNAME; break;
+        case 6: mp.rev_del = 1; break;
+        case 7: {
+            // build_auxlist (bam_plcmd.c:240-287): column names the device path can print; tags are not supported
+            static const struct { const char *n; int f; } cols[] = {
+                { "QNAME", STA_MPLP_PRINT_QNAME }, { "FLAG", STA_MPLP_PRINT_FLAG }, { "RNAME", STA_MPLP_PRINT_RNAME },
+                { "POS", STA_MPLP_PRINT_POS }, { "MAPQ", STA_MPLP_PRINT_MAPQ }, { "RNEXT", 1 << 19 },
+                { "PNEXT", STA_MPLP_PRINT_PNEXT }, { "RLEN", STA_MPLP_PRINT_RLEN } };
+            std::string s = optarg; size_t p = 0;
+            while (p <= s.size()) {
+                size_t e = s.find(',', p); if (e == std::string::npos) e = s.size();
+                std::string tag = s.substr(p, e - p);
+                bool hit = false;
+                for (auto &cn : cols) if (tag == cn.n) { mp.flag |= cn.f; hit = true; }
+                if (!hit && !tag.empty()) { fprintf(stderr, "samtools mpileup: --output-extra %s is not supported by the MI355X engine\n", tag.c_str()); return 1; }
+                p = e + 1;
+            }
+            break;
+        }
+        case 8: case 9: fprintf(stderr, "samtools mpileup: --output-sep/--output-empty need tag columns, which the MI355X engine does not support\n"); return 1;
+        case 10: mp.no_ins++; break;
+        case 11: break;
+        case 12: mp.no_del++; break;
+        case 13: mp.no_ends = 1; break;
+        case 'f':
+            conf.fai = Fasta::load(optarg);
+            if (!conf.fai) { fprintf(stderr, "[E::fai_load] failed to load %s\n", optarg); return 1; }
+            conf.fai_fname = optarg; mp.has_fai = 1;
+            break;
+        case 'd': mp.max_depth = atoi(optarg); break;
+        case 'r': conf.reg = optarg; break;
+        case 'l':
+            conf.bed = Bed::load(optarg);
+            if (!conf.bed) { fprintf(stderr, "samtools mpileup: Could not read file \"%s\"\n", optarg); return 1; }
+            break;
+        case 'B': mp.flag &= ~STA_MPLP_REALN; break;
+        case 'X': fprintf(stderr, "samtools mpileup: -X is not supported by the MI355X engine\n"); return 1;
+        case 'E': mp.flag |= STA_MPLP_REDO_BAQ; break;
+        case '6': mp.flag |= STA_MPLP_ILLUMINA13; break;
+        case 'R': ignore_rg = true; break;
+        case 's': mp.flag |= STA_MPLP_PRINT_MAPQ_CHAR; break;
+        case 'O': mp.flag |= STA_MPLP_PRINT_QPOS; break;
+        case 14: mp.flag |= STA_MPLP_PRINT_QPOS5; break;
+        case 'M': fprintf(stderr, "samtools mpileup: -M/--output-mods is not supported by the MI355X engine\n"); return 1;
+        case 'C': mp.capQ_thres = atoi(optarg); break;
+        case 'q': mp.min_mq = atoi(optarg); break;
+        case 'Q': mp.min_baseQ = atoi(optarg); break;
+        case 'b': file_list = optarg; break;
+        case 'A': use_orphan = 1; break;
+        case 'G': {
+            conf.has_rg_excl = true;
+            FILE *fp = fopen(optarg, "r");
+            if (!fp) { fprintf(stderr, "[%s] Fail to open file %s. Continue anyway.\n", "bam_mpileup", optarg); break; }
+            char buf[1024];
+            while (fscanf(fp, "%1023s", buf) > 0) conf.rg_excl.insert(buf);
+            fclose(fp);
+            break;
+        }
+        case 'a': mp.all++; break;
+        default: usage(stderr); return 1;
+        }
+    }
+    if (!(mp.flag & STA_MPLP_REALN) && (mp.flag & STA_MPLP_REDO_BAQ)) { fprintf(stderr, "Error: The -B option cannot be combined with -E\n"); return 1; }
+    if (use_orphan) mp.flag &= ~STA_MPLP_NO_ORPHAN;
+    if (argc == 1) { usage(stderr); return 1; }
+    std::vector<std::string> fns;
+    if (!file_list.empty()) { if (!read_file_list(file_list, &fns)) { fprintf(stderr, "No files read from %s\n", file_list.c_str()); return 1; } }
+    else for (int i = optind; i < argc; ++i) fns.push_back(argv[i]);
+    if (fns.empty()) { fprintf(stderr, "[mpileup] no input file/data given\n"); return 1; }
+
+    Runner run(conf);
+    Samples sm;
+    for (auto &fn : fns) {
+        std::string err;
+        auto r = AlnReader::open(fn, &err);
+        if (!r) { fprintf(stderr, "[mpileup] failed to open %s: %s\n", fn.c_str(), strerror(errno ? errno : ENOENT)); return 1; }
+        sm.add(fn, ignore_rg ? nullptr : &r->header().text);
+        run.readers.push_back(std::move(r));
+    }
+    run.h = &run.readers[0]->header();
+    if (!conf.reg.empty()) {
+        for (size_t i = 0; i < run.readers.size(); ++i) {
+            int t; int64_t b, e;
+            if (!parse_region(run.readers[i]->header(), conf.reg, &t, &b, &e)) {
+                fprintf(stderr, "[E::mpileup] fail to parse region '%s' with %s\n", conf.reg.c_str(), fns[i].c_str());
+                return 1;
+            }
+            run.readers[i]->set_region(t, b, e);
+            if (i == 0) { run.has_reg = true; run.tid0 = t; run.beg0 = b; run.end0 = e; }
+        }
+    }
+    fprintf(stderr, "[mpileup] %d samples in %d input files\n", (int)sm.sm.size(), (int)fns.size());
+    if (!conf.output_fname.empty()) {
+        run.out = fopen(conf.output_fname.c_str(), "w");
+        if (!run.out) { fprintf(stderr, "[mpileup] failed to write to %s: %s\n", conf.output_fname.c_str(), strerror(errno)); return 1; }
+    }
+    if (!mp.max_depth) { mp.max_depth = INT_MAX; fprintf(stderr, "[mpileup] Max depth set to maximum value (%d)\n", INT_MAX); }
+    else if ((long long)mp.max_depth * (long long)fns.size() > 1 << 20) fprintf(stderr, "[mpileup] Combined max depth is above 1M. Potential memory hog!\n");
+
+    int rc = sta_engine_create(&run.eng, 0, nullptr);
+    if (rc != STA_OK) {
+        fprintf(stderr, "samtools mpileup: no usable HIP device (the MI355X engine has no CPU fallback)\n");
+        return 1;
+    }
+    int ret = run.run();
+    fflush(run.out);
+    if (run.out != stdout) fclose(run.out);
+    sta_engine_destroy(run.eng);
+    return ret;
+}

@@ -1,0 +1,567 @@
+// engine.cpp -- C-ABI engine: HBM staging, workspace, kernel pipeline orchestration.
+// Implements include/samtools_amd.h (the bulk replacement for the bam_mplp_* / add_depth hot
+// loops; see that header for the reference file:line map).  No CPU compute fallback exists here:
+// without a usable HIP device every entry point returns STA_ERR_NO_DEVICE.
+#include "sta_dev.h"
+#include <string>
+#include <vector>
+#include <map>
+#include <cstring>
+#include <cstdio>
+#include <climits>
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (p) { hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + (n >> 3) + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct FileBufs {
+    // staged input copies (only used with STA_MEM_HOST)
+    DevBuf pos, flag, mapq, aux, lq, cig_off, base_off8, mtid, mpos, isize, name_off, cigar, seq, qual, bq, names;
+    // workspace
+    DevBuf qual_work, end, maxend, info, clip, chain;
+    void release()
+    {
+        DevBuf *all[] = { &pos, &flag, &mapq, &aux, &lq, &cig_off, &base_off8, &mtid, &mpos, &isize, &name_off, &cigar,
+                          &seq, &qual, &bq, &names, &qual_work, &end, &maxend, &info, &clip, &chain };
+        for (DevBuf *b : all) b->release();
+    }
+};
+
+struct RefSeq { DevBuf buf; int64_t len = 0; bool external = false; const char *ext = nullptr; };
+
+struct ProfEntry { uint64_t launches = 0; double ms = 0; };
+struct ProfPending { std::string name; hipEvent_t a, b; };
+
+}  // namespace
+
+struct sta_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<int32_t, RefSeq> refs;
+    // current window
+    bool staged = false;
+    sta_window win{};
+    std::string tname;
+    std::vector<FileBufs> fb;
+    std::vector<StaReadsDev> files_h;
+    std::vector<int32_t> min_pos, max_pos_hint;
+    DevBuf files_d, tname_d, bed_d, line_len, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch;
+    StaWinDev wd{};
+    // plan state
+    int planned = 0;   // 1 mpileup, 2 depth
+    sta_mplp_params mp{};
+    sta_depth_params dp{};
+    StaCounters ctr_h{};
+    uint64_t out_bytes = 0;
+    uint32_t lds_cap = 0;
+    void *last_out = nullptr;
+    // profiling
+    bool prof_on = false;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<ProfPending> pending;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int fail(sta_engine *e, int code, const std::string &msg)
+{
+    if (e) e->err = msg;
+    return code;
+}
+int hipfail(sta_engine *e, hipError_t r, const char *what)
+{
+    return fail(e, STA_ERR_HIP, std::string(what) + ": " + hipGetErrorString(r));
+}
+#define HIPCHK(call) do { hipError_t r_ = (call); if (r_ != hipSuccess) return hipfail(e, r_, #call); } while (0)
+
+hipEvent_t get_event(sta_engine *e)
+{
+    if (!e->ev_pool.empty()) { hipEvent_t ev = e->ev_pool.back(); e->ev_pool.pop_back(); return ev; }
+    hipEvent_t ev; hipEventCreate(&ev); return ev;
+}
+struct ProfScope {
+    sta_engine *e; const char *name; hipEvent_t a{}, b{};
+    ProfScope(sta_engine *e_, const char *n) : e(e_), name(n)
+    {
+        if (e->prof_on) { a = get_event(e); b = get_event(e); hipEventRecord(a, e->stream); }
+    }
+    ~ProfScope()
+    {
+        if (e->prof_on) { hipEventRecord(b, e->stream); e->pending.push_back(ProfPending{ name, a, b }); }
+    }
+};
+void prof_drain(sta_engine *e)
+{
+    for (auto &p : e->pending) {
+        float ms = 0;
+        hipEventSynchronize(p.b);
+        hipEventElapsedTime(&ms, p.a, p.b);
+        ProfEntry &pe = e->prof[p.name];
+        pe.launches++; pe.ms += ms;
+        e->ev_pool.push_back(p.a); e->ev_pool.push_back(p.b);
+    }
+    e->pending.clear();
+}
+
+template <class T>
+int upload(sta_engine *e, DevBuf &b, const T *src, size_t n, const T **dev_out, int mem)
+{
+    if (mem == STA_MEM_DEVICE) { *dev_out = src; return 0; }
+    if (n == 0 || src == nullptr) { if (b.ensure(16)) return fail(e, STA_ERR_HIP, "hipMalloc failed"); *dev_out = src ? (const T *)b.p : nullptr; return 0; }
+    if (b.ensure(n * sizeof(T) + 16)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+    HIPCHK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, e->stream));
+    *dev_out = (const T *)b.p;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sta_version(void) { return "samtools_amd 0.1 (MI355X/gfx950 mpileup+depth engine; samtools 1.23.1 semantics)"; }
+
+int sta_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sta_engine_create(sta_engine **out, int device, void *hip_stream)
+{
+    if (!out) return STA_ERR_ARG;
+    *out = nullptr;
+    int n = sta_device_count();
+    if (n <= 0 || device < 0 || device >= n) return STA_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return STA_ERR_NO_DEVICE;
+    sta_engine *e = new sta_engine();
+    e->device = device;
+    e->stream = (hipStream_t)hip_stream;   // nullptr = default stream
+    *out = e;
+    return STA_OK;
+}
+
+void sta_engine_destroy(sta_engine *e)
+{
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    for (auto &f : e->fb) f.release();
+    for (auto &r : e->refs) r.second.buf.release();
+    DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->offs, &e->scan_tmp, &e->counters, &e->table,
+                      &e->out, &e->diff, &e->maxcnt_scratch, &e->baq_scratch };
+    for (DevBuf *b : all) b->release();
+    for (auto &p : e->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto ev : e->ev_pool) hipEventDestroy(ev);
+    delete e;
+}
+
+const char *sta_last_error(const sta_engine *e) { return e ? e->err.c_str() : "no engine"; }
+
+int sta_set_reference(sta_engine *e, int32_t tid, const char *seq, int64_t len, int32_t mem)
+{
+    if (!e || len < 0) return STA_ERR_ARG;
+    hipSetDevice(e->device);
+    RefSeq &r = e->refs[tid];
+    r.len = len;
+    if (mem == STA_MEM_DEVICE) { r.external = true; r.ext = seq; return STA_OK; }
+    r.external = false;
+    if (r.buf.ensure((size_t)len + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(reference) failed");
+    if (len) HIPCHK(hipMemcpyAsync(r.buf.p, seq, (size_t)len, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return STA_OK;
+}
+
+void sta_clear_references(sta_engine *e)
+{
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    for (auto &r : e->refs) r.second.buf.release();
+    e->refs.clear();
+}
+
+int sta_stage_window(sta_engine *e, const sta_window *w)
+{
+    if (!e || !w || w->n_files < 0 || w->col_end < w->col_beg) return fail(e, STA_ERR_ARG, "bad window");
+    hipSetDevice(e->device);
+    e->staged = false; e->planned = 0;
+    e->win = *w;
+    e->tname = w->tname ? w->tname : "";
+    if (e->fb.size() < (size_t)w->n_files) e->fb.resize((size_t)w->n_files);
+    e->files_h.assign((size_t)w->n_files, StaReadsDev{});
+    for (int f = 0; f < w->n_files; ++f) {
+        const sta_reads &r = w->files[f];
+        FileBufs &b = e->fb[(size_t)f];
+        StaReadsDev &d = e->files_h[(size_t)f];
+        size_t n = (size_t)r.n_reads;
+        d.n = r.n_reads;
+        d.n_bases_total = r.n_bases_total;
+        int rc = 0, mem = w->mem;
+        rc |= upload(e, b.pos, r.pos, n, &d.pos, mem);
+        rc |= upload(e, b.flag, r.flag, n, &d.flag, mem);
+        rc |= upload(e, b.mapq, r.mapq, n, &d.mapq, mem);
+        rc |= upload(e, b.aux, r.aux, n, &d.aux, mem);
+        rc |= upload(e, b.lq, r.l_qseq, n, &d.l_qseq, mem);
+        rc |= upload(e, b.cig_off, r.cig_off, n + 1, &d.cig_off, mem);
+        rc |= upload(e, b.base_off8, r.base_off8, n, &d.base_off8, mem);
+        rc |= upload(e, b.mtid, r.mtid, n, &d.mtid, mem);
+        rc |= upload(e, b.mpos, r.mpos, n, &d.mpos, mem);
+        rc |= upload(e, b.isize, r.isize, n, &d.isize, mem);
+        rc |= upload(e, b.name_off, r.name_off, n + 1, &d.name_off, mem);
+        rc |= upload(e, b.cigar, r.cigar, (size_t)r.n_cigar_total, &d.cigar, mem);
+        rc |= upload(e, b.seq, r.seq, (size_t)(r.n_bases_total / 2), &d.seq, mem);
+        rc |= upload(e, b.qual, r.qual, (size_t)r.n_bases_total, &d.qual_in, mem);
+        if (r.bq) rc |= upload(e, b.bq, r.bq, (size_t)r.n_bases_total, &d.bq, mem); else d.bq = nullptr;
+        rc |= upload(e, b.names, r.names, (size_t)r.n_name_bytes, &d.names, mem);
+        if (rc) return rc;
+        // workspace
+        if (b.end.ensure(n * 4 + 16) || b.maxend.ensure(n * 4 + 16) || b.info.ensure(n * 4 + 16) || b.clip.ensure(n * 4 + 16)
+            || b.chain.ensure(n * 4 + 16))
+            return fail(e, STA_ERR_HIP, "hipMalloc(workspace) failed");
+        d.end = (int32_t *)b.end.p; d.maxend = (int32_t *)b.maxend.p; d.info = (uint32_t *)b.info.p; d.clip = (int32_t *)b.clip.p;
+        d.qual = const_cast<uint8_t *>(d.qual_in);
+    }
+    // window constants
+    StaWinDev &wd = e->wd;
+    wd = StaWinDev{};
+    wd.col_beg = w->col_beg; wd.col_end = w->col_end; wd.origin = w->origin; wd.tid = w->tid; wd.tlen = w->tlen;
+    wd.nfiles = w->n_files;
+    if (e->tname_d.ensure(e->tname.size() + 16)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+    if (!e->tname.empty()) HIPCHK(hipMemcpyAsync(e->tname_d.p, e->tname.data(), e->tname.size(), hipMemcpyHostToDevice, e->stream));
+    wd.tname = (const char *)e->tname_d.p; wd.tname_len = (int32_t)e->tname.size();
+    wd.has_bed = w->has_bed; wd.n_bed = w->has_bed ? w->n_bed : 0;
+    if (w->has_bed) {
+        size_t nb = (size_t)w->n_bed;
+        if (e->bed_d.ensure(nb * 16 + 32)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+        if (nb) {
+            HIPCHK(hipMemcpyAsync(e->bed_d.p, w->bed_beg, nb * 8, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync((char *)e->bed_d.p + nb * 8, w->bed_end, nb * 8, hipMemcpyHostToDevice, e->stream));
+        }
+        wd.bed_beg = (const int64_t *)e->bed_d.p; wd.bed_end = wd.bed_beg + nb;
+    }
+    wd.has_reg = w->has_reg; wd.reg_beg = w->reg_beg; wd.reg_end = w->reg_end;
+    auto it = e->refs.find(w->tid);
+    if (it != e->refs.end()) { wd.ref = it->second.external ? it->second.ext : (const char *)it->second.buf.p; wd.ref_len = it->second.len; }
+    else { wd.ref = nullptr; wd.ref_len = 0; }
+    int64_t ncols = (int64_t)w->col_end - w->col_beg;
+    if (e->line_len.ensure((size_t)(ncols + 1) * 4 + 16) || e->offs.ensure((size_t)(ncols + 2) * 8 + 16)
+        || e->scan_tmp.ensure(sta_scan_tmp_bytes(ncols > 0 ? ncols : 1) + 64) || e->counters.ensure(sizeof(StaCounters)))
+        return fail(e, STA_ERR_HIP, "hipMalloc(column workspace) failed");
+    e->staged = true;
+    return STA_OK;
+}
+
+static int push_files(sta_engine *e)
+{
+    size_t bytes = e->files_h.size() * sizeof(StaReadsDev);
+    if (e->files_d.ensure(bytes + 16)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+    if (bytes) HIPCHK(hipMemcpyAsync(e->files_d.p, e->files_h.data(), bytes, hipMemcpyHostToDevice, e->stream));
+    e->wd.files = (const StaReadsDev *)e->files_d.p;
+    return STA_OK;
+}
+
+static int finish_plan(sta_engine *e, int64_t ncols, sta_plan_info *info)
+{
+    {
+        ProfScope ps(e, "len_scan");
+        sta_launch_len_scan(e->stream, (const uint32_t *)e->line_len.p, (uint64_t *)e->offs.p, ncols, e->scan_tmp.p, e->scan_tmp.cap);
+    }
+    {
+        ProfScope ps(e, "wave_bytes_max");
+        sta_launch_wave_bytes_max(e->stream, (const uint64_t *)e->offs.p, ncols, (StaCounters *)e->counters.p);
+    }
+    uint64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&total, (const uint64_t *)e->offs.p + (ncols > 0 ? ncols : 0), 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return hipfail(e, le, "kernel launch");
+    e->out_bytes = total;
+    uint64_t mw = e->ctr_h.max_wave_bytes;
+    uint32_t cap = (uint32_t)((mw + 255) & ~255ull);
+    if (cap < 1024) cap = 1024;
+    if (cap > 65536 - 64) cap = 65536 - 64;
+    e->lds_cap = cap;
+    if (info) {
+        info->out_bytes = total; info->n_lines = e->ctr_h.n_lines; info->n_data_cols = e->ctr_h.n_data_cols;
+        info->n_kept_reads = e->ctr_h.n_kept; info->piled_bases = e->ctr_h.piled_bases; info->n_maxcnt_dropped = e->ctr_h.n_dropped;
+    }
+    return STA_OK;
+}
+
+static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_maxcnt)
+{
+    hipStream_t s = e->stream;
+    StaCounters *ctr = (StaCounters *)e->counters.p;
+    HIPCHK(hipMemsetAsync(ctr, 0, sizeof(StaCounters), s));
+    const int nf = (int)e->files_h.size();
+    bool has_ref = e->wd.ref != nullptr;
+    bool realn = (p->flag & STA_MPLP_REALN) && has_ref;
+    bool redo = (p->flag & STA_MPLP_REDO_BAQ) != 0;
+    bool olap = (p->flag & STA_MPLP_SMART_OVERLAPS) != 0;
+    bool illum = (p->flag & STA_MPLP_ILLUMINA13) != 0;
+    // working quality pool needed?
+    for (int f = 0; f < nf; ++f) {
+        StaReadsDev &d = e->files_h[(size_t)f];
+        bool tag_bq = realn && !redo && d.bq != nullptr;
+        bool need = illum || realn || olap;
+        if (need && d.n_bases_total) {
+            FileBufs &b = e->fb[(size_t)f];
+            if (b.qual_work.ensure((size_t)d.n_bases_total + 32)) return fail(e, STA_ERR_HIP, "hipMalloc(qual) failed");
+            d.qual = (uint8_t *)b.qual_work.p;
+            StaReadsDev tmp = d;
+            if (!tag_bq) tmp.bq = nullptr;
+            ProfScope ps(e, "qual_prep");
+            sta_launch_qual_prep(s, tmp, illum ? 1 : 0);
+        } else d.qual = const_cast<uint8_t *>(d.qual_in);
+    }
+    int rc = push_files(e);
+    if (rc) return rc;
+    {
+        ProfScope ps(e, "prep_reads");
+        sta_launch_prep_reads(s, e->wd, e->files_h.data(), nf, *p, ctr);
+    }
+    if (realn) {
+        for (int f = 0; f < nf; ++f) {
+            StaReadsDev &d = e->files_h[(size_t)f];
+            if (!d.n) continue;
+            // geometry bounds of the reads that need BAQ (written by k_prep_reads)
+            StaCounters c{};
+            HIPCHK(hipMemcpyAsync(&c, ctr, sizeof(c), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (!c.n_baq) break;
+            size_t need = sta_baq_scratch_bytes(d.n, (int)c.max_lq, (int)c.max_bw);
+            if (e->baq_scratch.ensure(need + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ scratch) failed");
+            ProfScope ps(e, "baq");
+            sta_launch_baq(s, d, e->wd, redo ? 1 : 0, e->baq_scratch.p, need, (int)c.max_lq, (int)c.max_bw);
+        }
+    }
+    if (do_maxcnt) {
+        // exact replay of the -d cap, one file at a time (rare path)
+        for (int f = 0; f < nf; ++f) {
+            StaReadsDev &d = e->files_h[(size_t)f];
+            if (!d.n) continue;
+            // span of read ends relative to the smallest start: computed on the host from the staged window bounds
+            int32_t lo = e->min_pos[(size_t)f], hi = e->max_pos_hint[(size_t)f];
+            int64_t span = (int64_t)hi - lo + 2;
+            if (e->maxcnt_scratch.ensure((size_t)(span + 4) * 4)) return fail(e, STA_ERR_HIP, "hipMalloc(maxcnt) failed");
+            ProfScope ps(e, "maxcnt_serial");
+            sta_launch_maxcnt(s, d, p->max_depth, lo, (int32_t)span, (int32_t *)e->maxcnt_scratch.p, ctr);
+        }
+    }
+    for (int f = 0; f < nf; ++f) {
+        StaReadsDev &d = e->files_h[(size_t)f];
+        if (!d.n) continue;
+        if (e->scan_tmp.ensure(sta_scan_tmp_bytes(d.n) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+        ProfScope ps(e, "maxend_scan");
+        sta_launch_maxend_scan(s, d, e->scan_tmp.p, e->scan_tmp.cap);
+    }
+    if (!do_maxcnt && p->max_depth > 0 && p->max_depth < INT_MAX) {
+        for (int f = 0; f < nf; ++f) {
+            ProfScope ps(e, "maxcnt_detect");
+            sta_launch_maxcnt_detect(s, e->files_h[(size_t)f], p->max_depth, ctr);
+        }
+    }
+    if (olap) {
+        for (int f = 0; f < nf; ++f) {
+            StaReadsDev &d = e->files_h[(size_t)f];
+            if (!d.n) continue;
+            size_t slots = sta_overlap_table_slots(d.n);
+            if (e->table.ensure(sta_overlap_table_bytes(slots) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(name table) failed");
+            ProfScope ps(e, "overlap");
+            sta_launch_overlap(s, d, e->wd.origin, e->wd.tid, e->table.p, slots, (int32_t *)e->fb[(size_t)f].chain.p, ctr);
+        }
+    }
+    {
+        ProfScope ps(e, "mplp_len");
+        sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, ctr);
+    }
+    return STA_OK;
+}
+
+int sta_mpileup_plan(sta_engine *e, const sta_mplp_params *p, sta_plan_info *info)
+{
+    if (!e || !p) return STA_ERR_ARG;
+    if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
+    hipSetDevice(e->device);
+    if (p->capQ_thres > 10) return fail(e, STA_ERR_UNSUPPORTED, "-C/--adjust-MQ is not supported by the device path");
+    if (p->flag & (1 << 19)) return fail(e, STA_ERR_UNSUPPORTED, "--output-extra RNEXT is not supported by the device path");
+    e->mp = *p;
+    int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
+    // host-side bounds for the (rare) exact -d replay
+    e->min_pos.assign(e->files_h.size(), 0); e->max_pos_hint.assign(e->files_h.size(), 0);
+    int rc = mpileup_pipeline(e, p, false);
+    if (rc) return rc;
+    rc = finish_plan(e, ncols, info);
+    if (rc) return rc;
+    if (e->ctr_h.maxcnt_flag) {
+        // The cap may trigger somewhere in this window: find the coordinate span of the reads, then
+        // re-run the pipeline with the exact replay inserted.
+        for (size_t f = 0; f < e->files_h.size(); ++f) {
+            StaReadsDev &d = e->files_h[f];
+            if (!d.n) continue;
+            int32_t first = 0, lastmax = 0;
+            HIPCHK(hipMemcpy(&first, d.pos, 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&lastmax, d.maxend + (d.n - 1), 4, hipMemcpyDeviceToHost));
+            int32_t lastpos = 0;
+            HIPCHK(hipMemcpy(&lastpos, d.pos + (d.n - 1), 4, hipMemcpyDeviceToHost));
+            e->min_pos[f] = first;
+            e->max_pos_hint[f] = lastmax > lastpos ? lastmax : lastpos;
+        }
+        rc = mpileup_pipeline(e, p, true);
+        if (rc) return rc;
+        rc = finish_plan(e, ncols, info);
+        if (rc) return rc;
+    }
+    e->planned = 1;
+    return STA_OK;
+}
+
+static int emit_common(sta_engine *e, void *dev_out, uint64_t capacity, char **out)
+{
+    if (dev_out) {
+        if (capacity < e->out_bytes) return fail(e, STA_ERR_ARG, "output buffer too small");
+        *out = (char *)dev_out;
+    } else {
+        if (e->out.ensure((size_t)e->out_bytes + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(output) failed");
+        *out = (char *)e->out.p;
+    }
+    e->last_out = *out;
+    return STA_OK;
+}
+
+int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
+{
+    if (!e) return STA_ERR_ARG;
+    if (e->planned != 1) return fail(e, STA_ERR_ARG, "sta_mpileup_plan has not run for this window");
+    hipSetDevice(e->device);
+    char *out = nullptr;
+    int rc = emit_common(e, dev_out, capacity, &out);
+    if (rc) return rc;
+    if (e->out_bytes == 0) return STA_OK;
+    ProfScope ps(e, "mplp_emit");
+    sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, out, e->lds_cap);
+    return STA_OK;
+}
+
+int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info)
+{
+    if (!e || !p) return STA_ERR_ARG;
+    if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
+    hipSetDevice(e->device);
+    e->dp = *p;
+    hipStream_t s = e->stream;
+    StaCounters *ctr = (StaCounters *)e->counters.p;
+    HIPCHK(hipMemsetAsync(ctr, 0, sizeof(StaCounters), s));
+    const int nf = (int)e->files_h.size();
+    int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
+    for (auto &d : e->files_h) d.qual = const_cast<uint8_t *>(d.qual_in);
+    int rc = push_files(e);
+    if (rc) return rc;
+    {
+        ProfScope ps(e, "prep_reads_depth");
+        sta_launch_prep_reads_depth(s, e->wd, e->files_h.data(), nf, *p, ctr);
+    }
+    if (p->remove_overlaps) {
+        for (int f = 0; f < nf; ++f) {
+            StaReadsDev &d = e->files_h[(size_t)f];
+            if (!d.n) continue;
+            size_t slots = sta_overlap_table_slots(d.n);
+            if (e->table.ensure(sta_overlap_table_bytes(slots) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(name table) failed");
+            ProfScope ps(e, "depth_pair");
+            sta_launch_depth_pair(s, d, e->wd.origin, e->wd.tid, e->table.p, slots, (int32_t *)e->fb[(size_t)f].chain.p, ctr);
+        }
+    }
+    size_t drows = (size_t)(nf + 1) * (size_t)(ncols + 1);
+    if (e->diff.ensure(drows * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(depth rows) failed");
+    HIPCHK(hipMemsetAsync(e->diff.p, 0, drows * 4, s));
+    {
+        ProfScope ps(e, "depth_count");
+        sta_launch_depth_count(s, e->wd, e->files_h.data(), nf, *p, (int32_t *)e->diff.p);
+    }
+    {
+        ProfScope ps(e, "depth_scan");
+        sta_launch_depth_scan(s, (int32_t *)e->diff.p, nf + 1, ncols, e->scan_tmp.p, e->scan_tmp.cap);
+    }
+    {
+        ProfScope ps(e, "depth_len");
+        sta_launch_depth_len(s, e->wd, *p, (const int32_t *)e->diff.p, (uint32_t *)e->line_len.p, ctr);
+    }
+    rc = finish_plan(e, ncols, info);
+    if (rc) return rc;
+    e->planned = 2;
+    return STA_OK;
+}
+
+int sta_depth_emit(sta_engine *e, void *dev_out, uint64_t capacity)
+{
+    if (!e) return STA_ERR_ARG;
+    if (e->planned != 2) return fail(e, STA_ERR_ARG, "sta_depth_plan has not run for this window");
+    hipSetDevice(e->device);
+    char *out = nullptr;
+    int rc = emit_common(e, dev_out, capacity, &out);
+    if (rc) return rc;
+    if (e->out_bytes == 0) return STA_OK;
+    ProfScope ps(e, "depth_emit");
+    sta_launch_depth_emit(e->stream, e->wd, e->dp, (const int32_t *)e->diff.p, (const uint64_t *)e->offs.p, out, e->lds_cap);
+    return STA_OK;
+}
+
+const int32_t *sta_depth_counts_dev(sta_engine *e) { return e && e->planned == 2 ? (const int32_t *)e->diff.p : nullptr; }
+
+int sta_fetch_output(sta_engine *e, char *host_out, uint64_t n)
+{
+    if (!e || (!host_out && n)) return STA_ERR_ARG;
+    hipSetDevice(e->device);
+    if (n > e->out_bytes) return fail(e, STA_ERR_ARG, "fetch larger than output");
+    if (n) HIPCHK(hipMemcpyAsync(host_out, e->last_out, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return hipfail(e, le, "emit kernel");
+    return STA_OK;
+}
+
+int sta_sync(sta_engine *e)
+{
+    if (!e) return STA_ERR_ARG;
+    hipSetDevice(e->device);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return STA_OK;
+}
+
+void sta_profile_enable(sta_engine *e, int on) { if (e) e->prof_on = on != 0; }
+void sta_profile_reset(sta_engine *e) { if (e) { prof_drain(e); e->prof.clear(); } }
+int sta_profile_get(sta_engine *e, sta_kernel_time *out, int cap)
+{
+    if (!e) return 0;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    prof_drain(e);
+    int i = 0;
+    for (auto &kv : e->prof) {
+        if (i < cap && out) {
+            std::memset(&out[i], 0, sizeof(out[i]));
+            std::snprintf(out[i].name, sizeof(out[i].name), "%s", kv.first.c_str());
+            out[i].launches = kv.second.launches; out[i].total_ms = kv.second.ms;
+        }
+        ++i;
+    }
+    return i;
+}
+
+}  // extern "C"

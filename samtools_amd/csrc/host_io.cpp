@@ -1,0 +1,417 @@
+// host_io.cpp -- SAM/BAM/FASTA/BED decoding for the drivers (see host_io.h).
+#include "host_io.h"
+#include <zlib.h>
+#include <cstring>
+#include <cstdlib>
+#include <cstdio>
+#include <cctype>
+#include <algorithm>
+#include <fstream>
+
+namespace sta {
+
+namespace {
+// seq_nt16_table (hts.c): IUPAC character -> 4-bit code, everything else 15
+struct Nt16 {
+    uint8_t t[256];
+    Nt16()
+    {
+        memset(t, 15, sizeof t);
+        const char *codes = "=ACMGRSVTWYHKDBN";
+        for (int i = 0; i < 16; ++i) { t[(unsigned char)codes[i]] = (uint8_t)i; t[(unsigned char)tolower(codes[i])] = (uint8_t)i; }
+        t['0'] = 1; t['1'] = 2; t['2'] = 4; t['3'] = 8;
+    }
+};
+const Nt16 g_nt16;
+
+inline bool is_refop(int op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+}  // namespace
+
+struct AlnReader::Impl {
+    gzFile fp = nullptr;
+    bool is_bam = false;
+    std::vector<uint8_t> buf; size_t bp = 0, bl = 0; bool eof = false;
+    std::string line; bool have_line = false;
+    std::vector<uint8_t> blk;
+
+    bool fill()
+    {
+        if (eof) return false;
+        if (buf.empty()) buf.resize(1 << 18);
+        int n = gzread(fp, buf.data(), (unsigned)buf.size());
+        if (n <= 0) { eof = true; bp = bl = 0; return false; }
+        bp = 0; bl = (size_t)n;
+        return true;
+    }
+    size_t read(void *dst, size_t n)
+    {
+        uint8_t *d = (uint8_t *)dst; size_t got = 0;
+        while (got < n) {
+            if (bp >= bl && !fill()) break;
+            size_t k = std::min(bl - bp, n - got);
+            memcpy(d + got, buf.data() + bp, k);
+            bp += k; got += k;
+        }
+        return got;
+    }
+    bool getline(std::string &s)
+    {
+        s.clear();
+        bool any = false;
+        for (;;) {
+            if (bp >= bl && !fill()) break;
+            any = true;
+            uint8_t *b = buf.data() + bp;
+            uint8_t *nl = (uint8_t *)memchr(b, '\n', bl - bp);
+            if (nl) {
+                s.append((char *)b, (size_t)(nl - b));
+                bp += (size_t)(nl - b) + 1;
+                if (!s.empty() && s.back() == '\r') s.pop_back();
+                return true;
+            }
+            s.append((char *)b, bl - bp);
+            bp = bl;
+        }
+        return any;
+    }
+};
+
+AlnReader::~AlnReader()
+{
+    if (p_) { if (p_->fp) gzclose(p_->fp); delete p_; }
+}
+
+static void header_from_text(Header &h, bool add_refs)
+{
+    size_t p = 0;
+    while (p < h.text.size()) {
+        size_t e = h.text.find('\n', p);
+        if (e == std::string::npos) e = h.text.size();
+        if (e - p >= 3 && h.text.compare(p, 3, "@SQ") == 0) {
+            std::string sn; int64_t ln = 0;
+            size_t q = p + 3;
+            while (q < e) {
+                if (h.text[q] == '\t') { ++q; continue; }
+                size_t f = q;
+                while (q < e && h.text[q] != '\t') ++q;
+                if (q - f >= 3 && h.text[f + 2] == ':') {
+                    if (h.text[f] == 'S' && h.text[f + 1] == 'N') sn = h.text.substr(f + 3, q - f - 3);
+                    else if (h.text[f] == 'L' && h.text[f + 1] == 'N') ln = strtoll(h.text.c_str() + f + 3, nullptr, 10);
+                }
+            }
+            if (!sn.empty()) {
+                if (add_refs) { h.index[sn] = (int)h.names.size(); h.names.push_back(sn); h.lens.push_back(ln); }
+                else { int t = h.tid(sn); if (t >= 0 && ln > h.lens[(size_t)t]) h.lens[(size_t)t] = ln; }   // long references
+            }
+        }
+        p = e + 1;
+    }
+}
+
+std::unique_ptr<AlnReader> AlnReader::open(const std::string &path, std::string *err)
+{
+    std::unique_ptr<AlnReader> r(new AlnReader());
+    r->p_ = new Impl();
+    Impl &im = *r->p_;
+    im.fp = path == "-" ? gzdopen(fileno(stdin), "rb") : gzopen(path.c_str(), "rb");
+    if (!im.fp) { if (err) *err = "failed to open " + path; return nullptr; }
+    gzbuffer(im.fp, 1 << 18);
+    im.fill();
+    if (im.bl >= 4 && memcmp(im.buf.data(), "BAM\1", 4) == 0) {
+        im.is_bam = true; im.bp = 4;
+        int32_t l_text = 0, n_ref = 0;
+        if (im.read(&l_text, 4) != 4 || l_text < 0) { if (err) *err = "truncated BAM header"; return nullptr; }
+        r->hdr_.text.resize((size_t)l_text);
+        if (im.read(&r->hdr_.text[0], (size_t)l_text) != (size_t)l_text) { if (err) *err = "truncated BAM header"; return nullptr; }
+        while (!r->hdr_.text.empty() && r->hdr_.text.back() == '\0') r->hdr_.text.pop_back();
+        if (im.read(&n_ref, 4) != 4) { if (err) *err = "truncated BAM header"; return nullptr; }
+        for (int i = 0; i < n_ref; ++i) {
+            int32_t l_name = 0, l_ref = 0;
+            if (im.read(&l_name, 4) != 4) return nullptr;
+            std::string nm((size_t)l_name, '\0');
+            if (im.read(&nm[0], (size_t)l_name) != (size_t)l_name) return nullptr;
+            while (!nm.empty() && nm.back() == '\0') nm.pop_back();
+            if (im.read(&l_ref, 4) != 4) return nullptr;
+            r->hdr_.index[nm] = (int)r->hdr_.names.size();
+            r->hdr_.names.push_back(nm); r->hdr_.lens.push_back(l_ref);
+        }
+        header_from_text(r->hdr_, false);
+    } else {
+        while (im.getline(im.line)) {
+            if (im.line.empty()) continue;
+            if (im.line[0] != '@') { im.have_line = true; break; }
+            r->hdr_.text += im.line; r->hdr_.text += '\n';
+        }
+        header_from_text(r->hdr_, true);
+    }
+    return r;
+}
+
+static void finish_rec(Rec &r)
+{
+    r.rlen = 0;
+    for (uint32_t c : r.cigar) if (is_refop((int)(c & 0xf))) r.rlen += (c >> 4);
+}
+
+static int parse_sam(const Header &h, std::string &line, Rec &r)
+{
+    char *f[11]; size_t fl[11]; int nf = 0;
+    char *p = &line[0], *e = p + line.size();
+    while (nf < 11) {
+        char *t = (char *)memchr(p, '\t', (size_t)(e - p));
+        f[nf] = p; fl[nf] = t ? (size_t)(t - p) : (size_t)(e - p); ++nf;
+        if (!t) { p = e; break; }
+        p = t + 1;
+    }
+    if (nf < 11) return -2;
+    char *aux = p;
+    for (int i = 0; i < 11; ++i) f[i][fl[i]] = 0;
+    r.qname.assign(f[0], fl[0]);
+    r.flag = (uint16_t)strtol(f[1], nullptr, 0);
+    r.tid = (fl[2] == 1 && f[2][0] == '*') ? -1 : h.tid(f[2]);
+    r.pos = strtoll(f[3], nullptr, 10) - 1;
+    r.mapq = (uint8_t)strtol(f[4], nullptr, 10);
+    r.cigar.clear();
+    if (!(fl[5] == 1 && f[5][0] == '*')) {
+        char *c = f[5];
+        while (*c) {
+            char *q; unsigned long len = strtoul(c, &q, 10);
+            const char *ops = "MIDNSHP=XB"; const char *o = *q ? strchr(ops, *q) : nullptr;
+            if (!o) return -2;
+            r.cigar.push_back((uint32_t)(len << 4 | (unsigned)(o - ops)));
+            c = q + 1;
+        }
+    }
+    if (fl[6] == 1 && f[6][0] == '=') r.mtid = r.tid;
+    else if (fl[6] == 1 && f[6][0] == '*') r.mtid = -1;
+    else r.mtid = h.tid(f[6]);
+    r.mpos = strtoll(f[7], nullptr, 10) - 1;
+    r.isize = strtoll(f[8], nullptr, 10);
+    size_t l = (fl[9] == 1 && f[9][0] == '*') ? 0 : fl[9];
+    r.l_qseq = (int32_t)l;
+    r.seq.assign((l + 1) / 2, 0);
+    for (size_t i = 0; i < l; ++i) r.seq[i >> 1] |= (uint8_t)(g_nt16.t[(unsigned char)f[9][i]] << ((~i & 1) << 2));
+    r.qual.resize(l);
+    if (fl[10] == 1 && f[10][0] == '*') std::fill(r.qual.begin(), r.qual.end(), 0xff);
+    else { if (fl[10] != l) return -2; for (size_t i = 0; i < l; ++i) r.qual[i] = (uint8_t)(f[10][i] - 33); }
+    r.has_bq = r.has_zq = false; r.bq.clear(); r.rg.clear();
+    while (aux < e) {
+        char *t = (char *)memchr(aux, '\t', (size_t)(e - aux));
+        size_t n = t ? (size_t)(t - aux) : (size_t)(e - aux);
+        if (n >= 5 && aux[2] == ':' && aux[4] == ':' && aux[3] == 'Z') {
+            if (aux[0] == 'R' && aux[1] == 'G') r.rg.assign(aux + 5, n - 5);
+            else if (aux[0] == 'B' && aux[1] == 'Q') { r.has_bq = true; r.bq.assign(aux + 5, aux + n); }
+            else if (aux[0] == 'Z' && aux[1] == 'Q') r.has_zq = true;
+        }
+        if (!t) break;
+        aux = t + 1;
+    }
+    finish_rec(r);
+    return 1;
+}
+
+static int aux_size(int t) { switch (t) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; case 'd': return 8; } return 0; }
+
+static int parse_bam(AlnReader::Impl &im, Rec &r);
+
+int AlnReader::next_raw(Rec &r)
+{
+    Impl &im = *p_;
+    if (im.is_bam) return parse_bam(im, r);
+    if (im.have_line) im.have_line = false;
+    else { do { if (!im.getline(im.line)) return 0; } while (im.line.empty()); }
+    return parse_sam(hdr_, im.line, r);
+}
+
+static int parse_bam(AlnReader::Impl &im, Rec &r)
+{
+    int32_t bs = 0;
+    size_t n = im.read(&bs, 4);
+    if (n == 0) return 0;
+    if (n != 4 || bs < 32) return -2;
+    if (im.blk.size() < (size_t)bs) im.blk.resize((size_t)bs * 2);
+    if (im.read(im.blk.data(), (size_t)bs) != (size_t)bs) return -2;
+    const uint8_t *b = im.blk.data();
+    int32_t refID, pos, l_seq, nref, npos, tlen; uint16_t n_cig, flag;
+    memcpy(&refID, b, 4); memcpy(&pos, b + 4, 4);
+    uint8_t l_rn = b[8]; r.mapq = b[9];
+    memcpy(&n_cig, b + 12, 2); memcpy(&flag, b + 14, 2); memcpy(&l_seq, b + 16, 4);
+    memcpy(&nref, b + 20, 4); memcpy(&npos, b + 24, 4); memcpy(&tlen, b + 28, 4);
+    size_t need = 32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    if ((size_t)bs < need || l_seq < 0) return -2;
+    size_t o = 32;
+    r.qname.assign((const char *)b + o, l_rn ? l_rn - 1u : 0u); o += l_rn;
+    r.cigar.resize(n_cig); if (n_cig) memcpy(r.cigar.data(), b + o, 4 * (size_t)n_cig); o += 4 * (size_t)n_cig;
+    r.seq.assign(b + o, b + o + ((size_t)l_seq + 1) / 2); o += ((size_t)l_seq + 1) / 2;
+    r.qual.assign(b + o, b + o + (size_t)l_seq); o += (size_t)l_seq;
+    r.tid = refID; r.pos = pos; r.flag = flag; r.mtid = nref; r.mpos = npos; r.isize = tlen; r.l_qseq = l_seq;
+    r.has_bq = r.has_zq = false; r.bq.clear(); r.rg.clear();
+    const uint8_t *p = b + o, *e = b + bs;
+    while (p + 3 <= e) {
+        int t = p[2]; const uint8_t *tag = p; p += 3;
+        if (t == 'Z' || t == 'H') {
+            const uint8_t *s = p; while (p < e && *p) ++p;
+            if (t == 'Z') {
+                if (tag[0] == 'R' && tag[1] == 'G') r.rg.assign((const char *)s, (size_t)(p - s));
+                else if (tag[0] == 'B' && tag[1] == 'Q') { r.has_bq = true; r.bq.assign(s, p); }
+                else if (tag[0] == 'Z' && tag[1] == 'Q') r.has_zq = true;
+            }
+            ++p;
+        } else if (t == 'B') {
+            if (p + 5 > e) break;
+            int sz = aux_size(p[0]); uint32_t cnt; memcpy(&cnt, p + 1, 4);
+            p += 5 + (size_t)sz * cnt;
+        } else { int sz = aux_size(t); if (!sz) break; p += sz; }
+    }
+    finish_rec(r);
+    return 1;
+}
+
+int AlnReader::next(Rec &r)
+{
+    for (;;) {
+        int ret = next_raw(r);
+        if (ret <= 0) return ret;
+        if (has_reg_) {
+            if (r.tid != rtid_ || r.pos >= rend_ || r.endpos() <= rbeg_) continue;
+        }
+        return 1;
+    }
+}
+
+bool parse_region(const Header &h, const std::string &reg, int *tid, int64_t *beg, int64_t *end)
+{
+    *beg = 0; *end = INT64_MAX;
+    int t = h.tid(reg);
+    if (t >= 0) { *tid = t; return true; }
+    size_t colon = reg.rfind(':');
+    if (colon == std::string::npos) return false;
+    t = h.tid(reg.substr(0, colon));
+    if (t < 0) return false;
+    std::string num;
+    for (size_t i = colon + 1; i < reg.size(); ++i) if (reg[i] != ',') num += reg[i];
+    char *q;
+    long long b = strtoll(num.c_str(), &q, 10);
+    if (q == num.c_str()) { if (*q == '-') b = 1; else return false; }
+    long long e = INT64_MAX;
+    if (*q == '-') { if (q[1]) e = strtoll(q + 1, nullptr, 10); }
+    else if (*q) return false;
+    *tid = t; *beg = b > 0 ? b - 1 : 0; *end = e;
+    return *beg < *end;
+}
+
+std::unique_ptr<Fasta> Fasta::load(const std::string &path)
+{
+    gzFile fp = gzopen(path.c_str(), "rb");
+    if (!fp) return nullptr;
+    gzbuffer(fp, 1 << 18);
+    std::unique_ptr<Fasta> fa(new Fasta());
+    std::vector<char> buf(1 << 18);
+    std::string name; bool in_name = false, bol = true;
+    int n;
+    while ((n = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) {
+        for (int i = 0; i < n; ++i) {
+            char c = buf[(size_t)i];
+            if (in_name) {
+                if (c == '\n') {
+                    in_name = false; bol = true;
+                    size_t k = 0; while (k < name.size() && !isspace((unsigned char)name[k])) ++k;
+                    name.resize(k);
+                    fa->idx_[name] = fa->seqs_.size();
+                    fa->seqs_.emplace_back();
+                } else name += c;
+                continue;
+            }
+            if (bol && c == '>') { in_name = true; name.clear(); continue; }
+            if (c == '\n') { bol = true; continue; }
+            bol = false;
+            if (!isgraph((unsigned char)c) || fa->seqs_.empty()) continue;
+            fa->seqs_.back() += c;
+        }
+    }
+    gzclose(fp);
+    return fa;
+}
+
+std::unique_ptr<Bed> Bed::load(const std::string &path)
+{
+    gzFile fp = gzopen(path.c_str(), "rb");
+    if (!fp) return nullptr;
+    std::unique_ptr<Bed> b(new Bed());
+    std::unordered_map<std::string, std::vector<std::pair<int64_t, int64_t>>> raw;
+    std::vector<char> line(1 << 16);
+    while (gzgets(fp, line.data(), (int)line.size())) {
+        char *ref = line.data();
+        size_t l = strlen(ref);
+        while (l && (ref[l - 1] == '\n' || ref[l - 1] == '\r')) ref[--l] = 0;
+        while (*ref && isspace((unsigned char)*ref)) ++ref;
+        if (!*ref || *ref == '#') continue;
+        char *re = ref; while (*re && !isspace((unsigned char)*re)) ++re;
+        unsigned long long beg = 0, end = 0; int num = 0;
+        if (*re) { *re = 0; num = sscanf(re + 1, "%llu %llu", &beg, &end); }
+        if (num == 1) end = beg--;
+        if (num < 1 || end < beg) {
+            if (!strcmp(ref, "browser") || !strcmp(ref, "track")) continue;
+            fprintf(stderr, "[bed_read] Parse error reading \"%s\"\n", path.c_str());
+            gzclose(fp);
+            return nullptr;
+        }
+        raw[ref].emplace_back((int64_t)beg, (int64_t)end);
+    }
+    gzclose(fp);
+    for (auto &kv : raw) {
+        auto &v = kv.second;
+        std::sort(v.begin(), v.end());
+        Ivals iv;
+        for (auto &pr : v) {
+            if (pr.second <= pr.first) continue;     // empty interval never overlaps anything
+            if (!iv.beg.empty() && pr.first <= iv.end.back()) { if (pr.second > iv.end.back()) iv.end.back() = pr.second; }
+            else { iv.beg.push_back(pr.first); iv.end.push_back(pr.second); }
+        }
+        b->m_[kv.first] = std::move(iv);
+    }
+    return b;
+}
+
+bool Bed::overlap(const std::string &chr, int64_t beg, int64_t end) const
+{
+    const Ivals *iv = get(chr);
+    if (!iv) return false;
+    size_t i = (size_t)(std::upper_bound(iv->end.begin(), iv->end.end(), beg) - iv->end.begin());
+    return i < iv->beg.size() && iv->beg[i] < end;
+}
+
+int str2flag(const char *s)
+{
+    char *end;
+    long v = strtol(s, &end, 0);
+    if (end != s && *end == 0) return v < 0 ? -1 : (int)v;
+    static const struct { const char *n; int f; } names[] = {
+        { "PAIRED", 1 }, { "PROPER_PAIR", 2 }, { "UNMAP", 4 }, { "MUNMAP", 8 }, { "REVERSE", 16 }, { "MREVERSE", 32 },
+        { "READ1", 64 }, { "READ2", 128 }, { "SECONDARY", 256 }, { "QCFAIL", 512 }, { "DUP", 1024 }, { "SUPPLEMENTARY", 2048 } };
+    int flag = 0;
+    const char *p = s;
+    while (*p) {
+        const char *e = p; while (*e && *e != ',') ++e;
+        bool hit = false;
+        for (auto &nm : names)
+            if (strlen(nm.n) == (size_t)(e - p) && strncasecmp(p, nm.n, (size_t)(e - p)) == 0) { flag |= nm.f; hit = true; break; }
+        if (!hit) return -1;
+        p = *e ? e + 1 : e;
+    }
+    return flag;
+}
+
+bool read_file_list(const std::string &path, std::vector<std::string> *out)
+{
+    std::ifstream in(path);
+    if (!in) return false;
+    std::string l;
+    while (std::getline(in, l)) {
+        while (!l.empty() && isspace((unsigned char)l.back())) l.pop_back();
+        if (!l.empty()) out->push_back(l);
+    }
+    return !out->empty();
+}
+
+}  // namespace sta

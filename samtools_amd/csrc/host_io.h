@@ -1,0 +1,86 @@
+// host_io.h -- host-side input decoding for the samtools-amd drivers (C++).
+// Stands where HTSlib's sam_open/sam_hdr_read/sam_read1/sam_itr_next, faidx and samtools'
+// bedidx.c stand for the reference drivers (bam_plcmd.c:500-569, bam2depth.c:926-976).
+// Records are decoded straight into the fields the staging layer needs.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <unordered_map>
+#include <memory>
+
+namespace sta {
+
+struct Header {
+    std::vector<std::string> names;
+    std::vector<int64_t> lens;
+    std::string text;
+    std::unordered_map<std::string, int> index;
+    int tid(const std::string &n) const { auto it = index.find(n); return it == index.end() ? -1 : it->second; }
+    int nref() const { return (int)names.size(); }
+};
+
+struct Rec {
+    int32_t tid = -1, mtid = -1;
+    int64_t pos = 0, mpos = 0, isize = 0;
+    uint16_t flag = 0;
+    uint8_t mapq = 0;
+    int32_t l_qseq = 0;
+    std::string qname;
+    std::vector<uint32_t> cigar;
+    std::vector<uint8_t> seq;    // 4-bit packed
+    std::vector<uint8_t> qual;
+    std::vector<uint8_t> bq;     // BQ:Z bytes (empty if absent)
+    bool has_bq = false, has_zq = false;
+    std::string rg;              // RG:Z value ("" if absent)
+    int64_t rlen = 0;            // reference span (bam_cigar2rlen)
+    int64_t end() const { return pos + rlen; }
+    int64_t endpos() const { int64_t l = (flag & 4) ? 0 : rlen; return pos + (l > 0 ? l : 1); }   // bam_endpos
+};
+
+class AlnReader {
+public:
+    static std::unique_ptr<AlnReader> open(const std::string &path, std::string *err);
+    ~AlnReader();
+    const Header &header() const { return hdr_; }
+    void set_region(int tid, int64_t beg, int64_t end) { has_reg_ = true; rtid_ = tid; rbeg_ = beg; rend_ = end; }
+    // 1 = record, 0 = EOF, <0 = error
+    int next(Rec &r);
+    struct Impl;
+private:
+    AlnReader() = default;
+    Impl *p_ = nullptr;
+    Header hdr_;
+    bool has_reg_ = false; int rtid_ = 0; int64_t rbeg_ = 0, rend_ = 0;
+    int next_raw(Rec &r);
+};
+
+// hts_parse_reg-like ("chr", "chr:beg", "chr:beg-end", thousands commas); 0-based half open
+bool parse_region(const Header &h, const std::string &reg, int *tid, int64_t *beg, int64_t *end);
+
+// whole-file FASTA (faidx stand-in)
+class Fasta {
+public:
+    static std::unique_ptr<Fasta> load(const std::string &path);
+    const std::string *fetch(const std::string &name) const { auto it = idx_.find(name); return it == idx_.end() ? nullptr : &seqs_[it->second]; }
+private:
+    std::vector<std::string> seqs_;
+    std::unordered_map<std::string, size_t> idx_;
+};
+
+// BED / position list (bedidx.c:258-364), kept as merged disjoint sorted intervals per contig:
+// the overlap predicate of bed_overlap() (bedidx.c:159-197) is preserved by merging.
+class Bed {
+public:
+    static std::unique_ptr<Bed> load(const std::string &path);
+    struct Ivals { std::vector<int64_t> beg, end; };
+    const Ivals *get(const std::string &chr) const { auto it = m_.find(chr); return it == m_.end() ? nullptr : &it->second; }
+    bool overlap(const std::string &chr, int64_t beg, int64_t end) const;
+private:
+    std::unordered_map<std::string, Ivals> m_;
+};
+
+int str2flag(const char *s);   // bam_str2flag
+bool read_file_list(const std::string &path, std::vector<std::string> *out);   // bam_plcmd.c:944-999
+
+}  // namespace sta

@@ -1,0 +1,106 @@
+// host_pump.cpp -- see host_pump.h
+#include "host_pump.h"
+#include <algorithm>
+#include <climits>
+
+namespace sta {
+
+Pump::Pump(std::vector<std::unique_ptr<AlnReader>> &readers, const PumpConfig &cfg) : rd_(readers), cfg_(cfg)
+{
+    size_t n = rd_.size();
+    pend_.resize(n); has_pend_.assign(n, 0); eof_.assign(n, 0); carry_.resize(n);
+    last_pos_.assign(n, -1); last_tid_.assign(n, -1);
+    for (size_t f = 0; f < n; ++f) advance(f);
+}
+
+void Pump::advance(size_t f)
+{
+    has_pend_[f] = 0;
+    if (eof_[f]) return;
+    for (;;) {
+        int r = rd_[f]->next(pend_[f]);
+        if (r == 0) { eof_[f] = 1; return; }
+        if (r < 0) { eof_[f] = 1; err_ = -1; errtxt_ = "error reading from input file"; return; }
+        if (pend_[f].tid < 0) continue;              // unplaced reads never reach the engines
+        if (!(pend_[f].flag & 4)) {
+            if (pend_[f].tid < last_tid_[f] || (pend_[f].tid == last_tid_[f] && pend_[f].pos < last_pos_[f])) {
+                eof_[f] = 1; err_ = -2; errtxt_ = "the input is not position sorted";
+                return;
+            }
+            last_tid_[f] = pend_[f].tid; last_pos_[f] = pend_[f].pos;
+        } else if (pend_[f].tid < last_tid_[f] || (pend_[f].tid == last_tid_[f] && pend_[f].pos < last_pos_[f])) {
+            continue;                                  // out-of-order unmapped-flagged record: filtered anyway
+        }
+        has_pend_[f] = 1;
+        return;
+    }
+}
+
+int Pump::next_tid()
+{
+    int best = INT_MAX;
+    for (size_t f = 0; f < rd_.size(); ++f) {
+        if (has_pend_[f]) best = std::min(best, (int)pend_[f].tid);
+        if (!carry_[f].empty()) best = std::min(best, (int)carry_[f].front().tid);
+    }
+    return best == INT_MAX ? -1 : best;
+}
+
+int64_t Pump::next_pos(int tid)
+{
+    int64_t best = INT64_MAX;
+    for (size_t f = 0; f < rd_.size(); ++f)
+        if (has_pend_[f] && pend_[f].tid == tid) best = std::min(best, pend_[f].pos);
+    return best;
+}
+
+bool Pump::has_carry() const
+{
+    for (auto &c : carry_) if (!c.empty()) return true;
+    return false;
+}
+
+int64_t Pump::carry_max_end() const
+{
+    int64_t m = INT64_MIN;
+    for (auto &c : carry_) for (auto &r : c) m = std::max(m, span_end(r));
+    return m;
+}
+
+int64_t Pump::fill(int tid, int64_t cb, int64_t ce_target, std::vector<std::vector<const Rec *>> &reads)
+{
+    size_t n = rd_.size();
+    int64_t ce = ce_target;
+    for (size_t f = 0; f < n; ++f) {
+        int64_t count = 0;
+        while (has_pend_[f] && pend_[f].tid == tid && pend_[f].pos < ce) {
+            int64_t p = pend_[f].pos;
+            carry_[f].push_back(std::move(pend_[f]));
+            advance(f);
+            if (++count >= cfg_.max_reads && f == 0) {
+                // cut the window after this start position (all reads sharing it stay together)
+                while (has_pend_[f] && pend_[f].tid == tid && pend_[f].pos == p) { carry_[f].push_back(std::move(pend_[f])); advance(f); }
+                if (p + 1 > cb) ce = std::min(ce, p + 1);
+                break;
+            }
+        }
+    }
+    reads.assign(n, {});
+    for (size_t f = 0; f < n; ++f) {
+        reads[f].reserve(carry_[f].size());
+        for (auto &r : carry_[f]) reads[f].push_back(&r);
+    }
+    return ce;
+}
+
+void Pump::retire(int64_t ce)
+{
+    for (auto &c : carry_) {
+        auto it = std::remove_if(c.begin(), c.end(), [&](const Rec &r) { return span_end(r) <= ce; });
+        c.erase(it, c.end());
+    }
+}
+
+void Pump::drop_tid_carry() { for (auto &c : carry_) c.clear(); }
+
+}  // namespace sta

@@ -1,0 +1,49 @@
+// host_pump.h -- streams position-sorted records of N input files into column windows.
+// Host-side counterpart of the reference's "pull reads while they can still touch the current
+// column" loop (bam_mplp64_auto -> mplp_func, bam_plcmd.c:607; fastdepth_core merge,
+// bam2depth.c:578-663), restated for window-at-a-time processing on the device: a window
+// [cb, ce) of one contig receives every read whose span can touch it, i.e. the reads carried over
+// from the previous window plus all unread records that start before ce.
+#pragma once
+#include "host_io.h"
+#include "host_stage.h"
+#include <deque>
+#include <functional>
+
+namespace sta {
+
+struct PumpConfig {
+    int64_t window_cols = 1 << 20;     // target columns per window
+    int64_t max_reads = 4 << 20;       // soft cap of new reads per file per window
+    bool use_endpos = false;           // carry criterion: bam_endpos (depth) instead of pos + rlen (mpileup)
+};
+
+class Pump {
+public:
+    Pump(std::vector<std::unique_ptr<AlnReader>> &readers, const PumpConfig &cfg);
+    // smallest tid that still has unread records (or carried reads); -1 when everything is consumed
+    int next_tid();
+    // position of the first unread record on `tid` over all files (INT64_MAX if none)
+    int64_t next_pos(int tid);
+    bool has_carry() const;
+    int64_t carry_max_end() const;
+    // Consume records of `tid` starting before `ce_target` (possibly fewer: the read cap may cut the
+    // window short) and return the actual window end.  reads[f] = carried + new records of file f.
+    int64_t fill(int tid, int64_t cb, int64_t ce_target, std::vector<std::vector<const Rec *>> &reads);
+    // After the window [cb, ce) was processed: keep only reads that extend beyond ce.
+    void retire(int64_t ce);
+    void drop_tid_carry();             // forget carried reads when leaving a contig
+    int error() const { return err_; }   // <0 after a decode error or unsorted input
+    const char *error_text() const { return errtxt_.c_str(); }
+private:
+    std::vector<std::unique_ptr<AlnReader>> &rd_;
+    PumpConfig cfg_;
+    std::vector<Rec> pend_; std::vector<char> has_pend_, eof_;
+    std::vector<std::deque<Rec>> carry_;
+    std::vector<int64_t> last_pos_; std::vector<int> last_tid_;
+    int err_ = 0; std::string errtxt_;
+    void advance(size_t f);
+    int64_t span_end(const Rec &r) const { return cfg_.use_endpos ? r.endpos() : r.end(); }
+};
+
+}  // namespace sta

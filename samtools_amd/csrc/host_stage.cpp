@@ -1,0 +1,70 @@
+// host_stage.cpp -- see host_stage.h
+#include "host_stage.h"
+#include <cstring>
+#include <climits>
+
+namespace sta {
+
+void StagedFile::clear()
+{
+    pos.clear(); l_qseq.clear(); mtid.clear(); isize.clear(); flag.clear(); mapq.clear(); aux.clear();
+    cig_off.clear(); base_off8.clear(); name_off.clear(); cigar.clear(); mpos.clear();
+    seq.clear(); qual.clear(); bq.clear(); names.clear();
+    any_bq = false;
+}
+
+void StagedFile::add(const Rec &r, int64_t origin, const std::set<std::string> *rg_excl)
+{
+    pos.push_back((int32_t)(r.pos - origin));
+    flag.push_back(r.flag);
+    mapq.push_back(r.mapq);
+    uint8_t a = 0;
+    bool bq_ok = r.has_bq && (int32_t)r.bq.size() >= r.l_qseq;
+    if (bq_ok) a |= STA_AUX_HAS_BQ;
+    if (r.has_zq) a |= STA_AUX_HAS_ZQ;
+    if (rg_excl && !r.rg.empty() && rg_excl->count(r.rg)) a |= STA_AUX_SKIP;
+    aux.push_back(a);
+    l_qseq.push_back(r.l_qseq);
+    cig_off.push_back((uint32_t)cigar.size());
+    cigar.insert(cigar.end(), r.cigar.begin(), r.cigar.end());
+    // bases: padded to a multiple of 8 so that seq offset = qual offset / 2 stays whole
+    size_t b0 = qual.size();
+    base_off8.push_back((uint32_t)(b0 >> 3));
+    size_t padded = ((size_t)r.l_qseq + 7) & ~(size_t)7;
+    qual.resize(b0 + padded, 0);
+    if (r.l_qseq) memcpy(&qual[b0], r.qual.data(), (size_t)r.l_qseq);
+    seq.resize((b0 + padded) / 2, 0);
+    if (r.l_qseq) memcpy(&seq[b0 / 2], r.seq.data(), ((size_t)r.l_qseq + 1) / 2);
+    bq.resize(b0 + padded, 64);               // '@' = "no adjustment"
+    if (bq_ok) { memcpy(&bq[b0], r.bq.data(), (size_t)r.l_qseq); any_bq = true; }
+    mtid.push_back(r.mtid);
+    mpos.push_back(r.mpos);
+    int64_t is = r.isize;
+    if (is > INT32_MAX) is = INT32_MAX;
+    if (is < -INT32_MAX) is = -INT32_MAX;
+    isize.push_back((int32_t)is);
+    name_off.push_back((uint32_t)names.size());
+    names.insert(names.end(), r.qname.begin(), r.qname.end());
+    names.push_back('\0');
+}
+
+void StagedFile::finish()
+{
+    cig_off.push_back((uint32_t)cigar.size());
+    name_off.push_back((uint32_t)names.size());
+}
+
+sta_reads StagedFile::view() const
+{
+    sta_reads v;
+    memset(&v, 0, sizeof v);
+    v.n_reads = n();
+    v.pos = pos.data(); v.flag = flag.data(); v.mapq = mapq.data(); v.aux = aux.data(); v.l_qseq = l_qseq.data();
+    v.cig_off = cig_off.data(); v.base_off8 = base_off8.data(); v.mtid = mtid.data(); v.mpos = mpos.data();
+    v.isize = isize.data(); v.name_off = name_off.data(); v.cigar = cigar.data(); v.seq = seq.data(); v.qual = qual.data();
+    v.bq = any_bq ? bq.data() : nullptr; v.names = names.data();
+    v.n_cigar_total = cigar.size(); v.n_bases_total = qual.size(); v.n_name_bytes = names.size();
+    return v;
+}
+
+}  // namespace sta

@@ -1,0 +1,28 @@
+// host_stage.h -- builds the structure-of-arrays staging buffers (sta_reads) from decoded records.
+// This is the "C host code stages pre-decoded BAM records" half of the boundary (BASELINE.json
+// north_star); the arrays are what sta_stage_window() copies to HBM.
+#pragma once
+#include "host_io.h"
+#include "../../include/samtools_amd.h"
+#include <set>
+
+namespace sta {
+
+struct StagedFile {
+    std::vector<int32_t> pos, l_qseq, mtid, isize;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq, aux;
+    std::vector<uint32_t> cig_off, base_off8, name_off, cigar;
+    std::vector<int64_t> mpos;
+    std::vector<uint8_t> seq, qual, bq;
+    std::vector<char> names;
+    bool any_bq = false;
+    void clear();
+    // origin: absolute coordinate of relative 0; rg_excl: -G read groups to drop (may be null)
+    void add(const Rec &r, int64_t origin, const std::set<std::string> *rg_excl);
+    void finish();                 // closes the offset arrays
+    sta_reads view() const;        // pointers into this object (valid until the next add/clear)
+    int64_t n() const { return (int64_t)pos.size(); }
+};
+
+}  // namespace sta

@@ -1,0 +1,401 @@
+// kernels_common.hip -- read preparation, quality preparation and scans (gfx950).
+//
+// k_prep_reads      : mplp_func read-level filters (bam_plcmd.c:413-458) + reference span
+//                     (bam_cigar2rlen) + overlap eligibility (HTSlib overlap_push conditions,
+//                     SURVEY.md A.3) for every staged read; one thread per read, SoA loads coalesce.
+// k_prep_reads_depth: fastdepth_core read filters (bam2depth.c:552-571) + qlen_used (:124-159).
+// k_qual_prep       : -6 shift (bam_plcmd.c:428-433) and BQ:Z tag application (realn.c, A.4) as one
+//                     elementwise pass over the quality pool, 16 B per lane.
+// scans             : three-phase block scans (reduce / scan of block sums / rescan), wave64 shuffles.
+#include "dev_util.h"
+
+// ------------------------------------------------------------------------------------------------
+struct PrepArgs {
+    int32_t min_mq, rflag_require, rflag_filter, flag, all;
+};
+
+__global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, PrepArgs P, StaCounters *ctr)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long piled = 0; unsigned kept = 0;
+    if (i < R.n) {
+        int32_t pos = R.pos[i];
+        uint32_t flag = R.flag[i];
+        uint32_t c0 = R.cig_off[i], c1 = R.cig_off[i + 1];
+        int32_t rlen = 0;
+        bool has_m = false, has_n = false;
+        for (uint32_t k = c0; k < c1; ++k) {
+            uint32_t c = R.cigar[k];
+            int op = c & 0xf;
+            if (cg_is_refop(op)) rlen += (int32_t)(c >> 4);
+            has_m |= cg_is_mop(op);
+            has_n |= (op == CG_N);
+        }
+        int32_t end = pos + rlen;
+        int32_t lq = R.l_qseq[i];
+        uint32_t aux = R.aux[i];
+        uint32_t mapq = R.mapq[i];
+        int64_t apos = W.origin + pos;
+        bool pushed = !(flag & BAM_FUNMAP);
+        if (P.rflag_require && !(P.rflag_require & flag)) pushed = false;
+        if (P.rflag_filter && (P.rflag_filter & flag)) pushed = false;
+        if (pushed && W.has_bed && P.all == 0) {
+            int64_t endpos = apos + (rlen > 0 ? rlen : 1);
+            pushed = bed_overlap_dev(W.bed_beg, W.bed_end, W.n_bed, apos, endpos);
+        }
+        if (aux & STA_AUX_SKIP) pushed = false;
+        bool has_ref = W.ref != nullptr;
+        if (has_ref && W.ref_len <= apos) pushed = false;   // "Skipping because ... is outside of ..."
+        if ((int32_t)mapq < P.min_mq) pushed = false;
+        else if ((P.flag & STA_MPLP_NO_ORPHAN) && (flag & BAM_FPAIRED) && !(flag & BAM_FPROPER_PAIR)) pushed = false;
+
+        bool keep = pushed && rlen > 0;
+        bool simple = (c1 - c0 == 1) && cg_is_mop(R.cigar[c0] & 0xf);
+        uint32_t info = (pushed ? RI_PUSHED : 0) | (keep ? RI_KEEP : 0) | (simple ? RI_SIMPLE : 0)
+                      | ((flag & BAM_FREVERSE) ? RI_REV : 0) | (mapq << RI_MAPQ_SHIFT);
+        // overlap_push eligibility
+        if (keep && (P.flag & STA_MPLP_SMART_OVERLAPS) && !(flag & BAM_FMUNMAP) && (flag & BAM_FPROPER_PAIR)) {
+            int32_t mtid = R.mtid[i];
+            int64_t mpos = R.mpos[i];
+            long long isz = R.isize[i]; if (isz < 0) isz = -isz;
+            bool no = (mtid >= 0 && mtid != W.tid) || (isz >= 2ll * lq && mpos >= W.origin + end);
+            if (!no) info |= RI_OLAP_EL;
+        }
+        // BAQ needed? (realn.c early returns, A.4)
+        if (pushed && (P.flag & STA_MPLP_REALN) && has_ref && lq > 0 && has_m && !has_n) {
+            bool redo = (P.flag & STA_MPLP_REDO_BAQ) != 0;
+            bool q_absent = R.qual_in[(uint64_t)R.base_off8[i] << 3] == 0xff;
+            if (!q_absent && !(aux & STA_AUX_HAS_ZQ) && (redo || !(aux & STA_AUX_HAS_BQ))) {
+                info |= RI_BAQ;
+                // band width of realn.c: 7, or |ref extent - query extent of the M ops| + 3 when larger
+                long long x = 0, y = 0, xb = -1, xe = -1, yb = -1, ye = -1;
+                for (uint32_t k = c0; k < c1; ++k) {
+                    uint32_t c = R.cigar[k]; int op = c & 0xf; long long l = c >> 4;
+                    if (cg_is_mop(op)) { if (yb < 0) yb = y; if (xb < 0) xb = x; ye = y + l; xe = x + l; x += l; y += l; }
+                    else if (op == CG_S || op == CG_I) y += l;
+                    else if (op == CG_D) x += l;
+                }
+                long long d = (xe - xb) - (ye - yb); if (d < 0) d = -d;
+                int bw = d > 7 ? (int)d + 3 : 7;
+                int dl = (int)((xe - xb + (lq - (ye - yb)) + bw) - lq); if (dl < 0) dl = -dl;   // |l_ref - l_query| upper bound
+                if (dl > bw) bw = dl;
+                atomicMax(&ctr->max_lq, (unsigned long long)lq);
+                atomicMax(&ctr->max_bw, (unsigned long long)bw);
+                atomicAdd(&ctr->n_baq, 1ull);
+            }
+            // both BQ and ZQ without redo: ZQ is dropped and BQ applied by k_qual_prep
+        }
+        R.end[i] = end;
+        R.info[i] = info;
+        if (keep) {
+            kept = 1;
+            int32_t a = pos > W.col_beg ? pos : W.col_beg, b = end < W.col_end ? end : W.col_end;
+            if (b > a) piled = (unsigned long long)(b - a);
+        }
+    }
+    // wave reduce then one atomic per wave
+    for (int o = 32; o; o >>= 1) { piled += __shfl_down(piled, o); kept += __shfl_down(kept, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (piled) atomicAdd(&ctr->piled_bases, piled);
+        if (kept) atomicAdd(&ctr->n_kept, (unsigned long long)kept);
+    }
+}
+
+void sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
+                           const sta_mplp_params &p, StaCounters *ctr)
+{
+    PrepArgs a{ p.min_mq, p.rflag_require, p.rflag_filter, p.flag, p.all };
+    for (int f = 0; f < nfiles; ++f) {
+        const StaReadsDev &R = files_host[f];
+        if (R.n == 0) continue;
+        int64_t nb = (R.n + 255) / 256;
+        hipLaunchKernelGGL(k_prep_reads, dim3((unsigned)nb), dim3(256), 0, s, R, w, a, ctr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct PrepDepthArgs { int32_t flag, incl_flag, require_flag, min_mqual, min_len; };
+
+__global__ void __launch_bounds__(256) k_prep_reads_depth(StaReadsDev R, StaWinDev W, PrepDepthArgs P, StaCounters *ctr)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long piled = 0; unsigned kept = 0;
+    if (i < R.n) {
+        int32_t pos = R.pos[i];
+        uint32_t flag = R.flag[i];
+        uint32_t c0 = R.cig_off[i], c1 = R.cig_off[i + 1];
+        int32_t rlen = 0;
+        int64_t qused = 0;
+        for (uint32_t k = c0; k < c1; ++k) {
+            uint32_t c = R.cigar[k];
+            int op = c & 0xf;
+            if (cg_is_refop(op)) rlen += (int32_t)(c >> 4);
+            if (op == CG_M || op == CG_I || op == CG_EQ || op == CG_X) qused += (c >> 4);
+        }
+        int32_t lq = R.l_qseq[i];
+        bool ok = true;
+        if (flag & P.flag) ok = false;
+        if (P.incl_flag && (flag & P.incl_flag) == 0) ok = false;
+        if ((flag & P.require_flag) != (uint32_t)P.require_flag) ok = false;
+        if ((int32_t)R.mapq[i] < P.min_mqual) ok = false;
+        if (ok && P.min_len) {
+            // qlen_used (bam2depth.c:124-159)
+            int64_t l;
+            if (lq) {
+                l = lq;
+                uint32_t kl, kr;
+                for (kl = c0; kl < c1; kl++) { if ((R.cigar[kl] & 0xf) == CG_S) l -= (R.cigar[kl] >> 4); else break; }
+                for (kr = c1; kr > kl + 1; kr--) { if ((R.cigar[kr - 1] & 0xf) == CG_S) l -= (R.cigar[kr - 1] >> 4); else break; }
+            } else l = qused;
+            if (l < P.min_len) ok = false;
+        }
+        // bam_endpos: pos + max(rlen,1) (unmapped-flagged reads count as length 1)
+        int32_t span = (flag & BAM_FUNMAP) ? 0 : rlen;
+        int32_t end = pos + (span > 0 ? span : 1);
+        R.end[i] = end;
+        R.info[i] = (ok ? (RI_PUSHED | RI_KEEP) : 0) | ((flag & BAM_FREVERSE) ? RI_REV : 0);
+        R.clip[i] = 0;
+        if (ok) {
+            kept = 1;
+            int32_t a = pos > W.col_beg ? pos : W.col_beg, b = end < W.col_end ? end : W.col_end;
+            if (b > a) piled = (unsigned long long)(b - a);
+        }
+    }
+    for (int o = 32; o; o >>= 1) { piled += __shfl_down(piled, o); kept += __shfl_down(kept, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (piled) atomicAdd(&ctr->piled_bases, piled);
+        if (kept) atomicAdd(&ctr->n_kept, (unsigned long long)kept);
+    }
+}
+
+void sta_launch_prep_reads_depth(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
+                                 const sta_depth_params &p, StaCounters *ctr)
+{
+    PrepDepthArgs a{ p.flag, p.incl_flag, p.require_flag, p.min_mqual, p.min_len };
+    for (int f = 0; f < nfiles; ++f) {
+        const StaReadsDev &R = files_host[f];
+        if (R.n == 0) continue;
+        int64_t nb = (R.n + 255) / 256;
+        hipLaunchKernelGGL(k_prep_reads_depth, dim3((unsigned)nb), dim3(256), 0, s, R, w, a, ctr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Working-quality pool = f(input pool): 16 bytes per lane, fully coalesced.
+__global__ void __launch_bounds__(256) k_qual_prep(const uint8_t *__restrict__ qin, const uint8_t *__restrict__ bq,
+                                                   uint8_t *__restrict__ qout, uint64_t nbytes, int illumina13)
+{
+    uint64_t n16 = nbytes >> 4;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        uint4 v = reinterpret_cast<const uint4 *>(qin)[i];
+        uint4 b = bq ? reinterpret_cast<const uint4 *>(bq)[i] : make_uint4(0, 0, 0, 0);
+        uint32_t w[4] = { v.x, v.y, v.z, v.w }, bb[4] = { b.x, b.y, b.z, b.w };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t q = (w[j] >> (8 * k)) & 0xff;
+                if (illumina13) q = q > 31 ? q - 31 : 0;
+                if (bq) {
+                    uint32_t t = (bb[j] >> (8 * k)) & 0xff;
+                    q = (q + 64 < t) ? 0 : (q - (t - 64)) & 0xff;
+                }
+                o |= q << (8 * k);
+            }
+            w[j] = o;
+        }
+        reinterpret_cast<uint4 *>(qout)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    // tail (pool is padded to 8 bases per read, so at most 8 trailing bytes)
+    if (blockIdx.x == 0 && threadIdx.x < (nbytes & 15)) {
+        uint64_t i = (n16 << 4) + threadIdx.x;
+        uint32_t q = qin[i];
+        if (illumina13) q = q > 31 ? q - 31 : 0;
+        if (bq) { uint32_t t = bq[i]; q = (q + 64 < t) ? 0 : (q - (t - 64)) & 0xff; }
+        qout[i] = (uint8_t)q;
+    }
+}
+
+void sta_launch_qual_prep(hipStream_t s, const StaReadsDev &r, int illumina13)
+{
+    if (r.n_bases_total == 0) return;
+    uint64_t n16 = r.n_bases_total >> 4;
+    uint64_t nb = (n16 + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(k_qual_prep, dim3((unsigned)nb), dim3(256), 0, s, r.qual_in, r.bq, r.qual, r.n_bases_total, illumina13);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic three-phase scan.  TILE elements per 256-thread block.
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+
+struct OpSumU64 { typedef unsigned long long T; static __device__ T id() { return 0; } static __device__ T f(T a, T b) { return a + b; } };
+struct OpMaxI32 { typedef int T; static __device__ T id() { return INT32_MIN; } static __device__ T f(T a, T b) { return a > b ? a : b; } };
+struct OpSumI32 { typedef int T; static __device__ T id() { return 0; } static __device__ T f(T a, T b) { return a + b; } };
+
+template <class Op> __device__ typename Op::T block_scan_incl(typename Op::T v, typename Op::T *wave_tot /*LDS[5]*/, typename Op::T &block_total)
+{
+    typedef typename Op::T T;
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        T u = __shfl_up(v, o);
+        if (lane >= o) v = Op::f(u, v);
+    }
+    if (lane == 63) wave_tot[wid] = v;
+    __syncthreads();
+    T pre = Op::id();
+    for (int w = 0; w < wid; ++w) pre = Op::f(pre, wave_tot[w]);
+    T tot = Op::id();
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) tot = Op::f(tot, wave_tot[w]);
+    block_total = tot;
+    __syncthreads();
+    return Op::f(pre, v);
+}
+
+// Loader functors turn input element i into Op::T
+struct LoadU32 { const uint32_t *p; __device__ unsigned long long operator()(int64_t i) const { return p[i]; } };
+struct LoadI32 { const int32_t *p; __device__ int operator()(int64_t i) const { return p[i]; } };
+struct LoadKeptEnd { const int32_t *end; const uint32_t *info;
+    __device__ int operator()(int64_t i) const { return (info[i] & RI_KEEP) ? end[i] : INT32_MIN; } };
+
+template <class Op, class Load> __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_reduce(Load ld, int64_t n, typename Op::T *block_sums)
+{
+    typedef typename Op::T T;
+    __shared__ T wt[SCAN_BLOCK / 64];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    T acc = Op::id();
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) if (base + j < n) acc = Op::f(acc, ld(base + j));
+    T tot;
+    block_scan_incl<Op>(acc, wt, tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of block sums in place; total stored at [nb]
+template <class Op> __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_sums(typename Op::T *block_sums, int64_t nb)
+{
+    typedef typename Op::T T;
+    __shared__ T wt[SCAN_BLOCK / 64];
+    T carry = Op::id();
+    for (int64_t b0 = 0; b0 < nb; b0 += SCAN_BLOCK) {
+        int64_t i = b0 + threadIdx.x;
+        T v = i < nb ? block_sums[i] : Op::id();
+        T tot;
+        T inc = block_scan_incl<Op>(v, wt, tot);
+        // exclusive = carry (+) (inc without v) -> recompute from neighbours: use shuffle of inc
+        T prev = __shfl_up(inc, 1);
+        int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        __shared__ T last_of_wave[SCAN_BLOCK / 64];
+        if (lane == 63) last_of_wave[wid] = inc;
+        __syncthreads();
+        T ex = lane ? prev : (wid ? last_of_wave[wid - 1] : Op::id());
+        if (i < nb) block_sums[i] = Op::f(carry, ex);
+        carry = Op::f(carry, tot);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[nb] = carry;
+}
+
+template <class Op, class Load, class Tout, bool EXCL> __global__ void __launch_bounds__(SCAN_BLOCK)
+k_scan_apply(Load ld, int64_t n, const typename Op::T *block_sums, Tout *out)
+{
+    typedef typename Op::T T;
+    __shared__ T wt[SCAN_BLOCK / 64];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    T v[SCAN_ITEMS];
+    T acc = Op::id();
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) { v[j] = (base + j < n) ? ld(base + j) : Op::id(); acc = Op::f(acc, v[j]); }
+    T tot;
+    T inc = block_scan_incl<Op>(acc, wt, tot);
+    // exclusive prefix of this thread = block prefix (+) (inclusive scan of previous thread)
+    T prev = __shfl_up(inc, 1);
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ T last_of_wave[SCAN_BLOCK / 64];
+    if (lane == 63) last_of_wave[wid] = inc;
+    __syncthreads();
+    T ex = lane ? prev : (wid ? last_of_wave[wid - 1] : Op::id());
+    T run = Op::f(block_sums[blockIdx.x], ex);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (base + j < n) {
+            if (EXCL) { out[base + j] = (Tout)run; run = Op::f(run, v[j]); }
+            else { run = Op::f(run, v[j]); out[base + j] = (Tout)run; }
+        }
+    }
+    if (EXCL && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        // grand total at out[n]
+        out[n] = (Tout)block_sums[gridDim.x];
+    }
+}
+
+size_t sta_scan_tmp_bytes(int64_t n)
+{
+    int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    return (size_t)(nb + 2) * sizeof(unsigned long long);
+}
+
+template <class Op, class Load, class Tout, bool EXCL>
+static void run_scan(hipStream_t s, Load ld, int64_t n, Tout *out, void *tmp)
+{
+    typedef typename Op::T T;
+    if (n <= 0) {
+        return;
+    }
+    int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    T *sums = reinterpret_cast<T *>(tmp);
+    hipLaunchKernelGGL((k_scan_reduce<Op, Load>), dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, ld, n, sums);
+    hipLaunchKernelGGL((k_scan_sums<Op>), dim3(1), dim3(SCAN_BLOCK), 0, s, sums, nb);
+    hipLaunchKernelGGL((k_scan_apply<Op, Load, Tout, EXCL>), dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, ld, n, sums, out);
+}
+
+void sta_launch_maxend_scan(hipStream_t s, const StaReadsDev &r, void *tmp, size_t)
+{
+    LoadKeptEnd ld{ r.end, r.info };
+    run_scan<OpMaxI32, LoadKeptEnd, int32_t, false>(s, ld, r.n, r.maxend, tmp);
+}
+
+__global__ void k_set_u64(uint64_t *p, uint64_t v) { *p = v; }
+
+void sta_launch_len_scan(hipStream_t s, const uint32_t *len, uint64_t *offs, int64_t n, void *tmp, size_t)
+{
+    if (n <= 0) { hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, s, offs, (uint64_t)0); return; }
+    LoadU32 ld{ len };
+    run_scan<OpSumU64, LoadU32, uint64_t, true>(s, ld, n, offs, tmp);
+}
+
+// depth: in-place inclusive prefix sum of each row of diff[nrows][ncols+1] over the first ncols entries
+void sta_launch_depth_scan(hipStream_t s, int32_t *diff, int nrows, int64_t ncols, void *tmp, size_t)
+{
+    for (int r = 0; r < nrows; ++r) {
+        int32_t *row = diff + (int64_t)r * (ncols + 1);
+        LoadI32 ld{ row };
+        run_scan<OpSumI32, LoadI32, int32_t, false>(s, ld, ncols, row, tmp);
+    }
+}
+
+// max over waves (64 columns) of the output bytes a wave must stage -> sizes the emit kernels' LDS
+__global__ void __launch_bounds__(256) k_wave_bytes_max(const uint64_t *offs, int64_t ncols, StaCounters *ctr)
+{
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t nw = (ncols + 63) / 64;
+    unsigned long long b = 0;
+    if (w < nw) {
+        int64_t c0 = w * 64, c1 = c0 + 64 < ncols ? c0 + 64 : ncols;
+        b = offs[c1] - offs[c0];
+    }
+    for (int o = 32; o; o >>= 1) { unsigned long long u = __shfl_down(b, o); b = u > b ? u : b; }
+    if ((threadIdx.x & 63) == 0 && b) atomicMax(&ctr->max_wave_bytes, b);
+}
+
+void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, int64_t ncols, StaCounters *ctr)
+{
+    int64_t nw = (ncols + 63) / 64;
+    if (nw <= 0) return;
+    hipLaunchKernelGGL(k_wave_bytes_max, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, offs, ncols, ctr);
+}

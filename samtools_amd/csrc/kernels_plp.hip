@@ -1,0 +1,469 @@
+// kernels_plp.hip -- the mpileup column kernels (gfx950, wave64).
+//
+// Replaces the reference's per-column hot loops: HTSlib bam_plp64_next + resolve_cigar2
+// (callers bam_plcmd.c:607) and samtools' mpileup()/pileup_seq() text assembly
+// (bam_plcmd.c:54-169, :663-868), plus print_empty_pileup (:372-398).
+//
+// Layout of the work: one wavefront owns 64 consecutive reference columns, one lane per column.
+// The reads that can touch those columns form a contiguous index range of the position-sorted
+// read arrays, found with a wave-cooperative 64-ary search on `maxend` (prefix max of read ends)
+// and `pos`.  The wave then walks that range *uniformly* (read metadata becomes scalar loads);
+// each lane tests coverage of its own column, resolves its CIGAR position, applies the base
+// quality filter and appends its token.  Because reads are walked in file order and every lane
+// appends to its own line, the reference's "column entries in file order" rule holds by
+// construction, with no sort.
+//
+//  k_mplp_len  : measuring pass -> bytes of every output line (0 = column not printed)
+//  (scan)      : exclusive scan of line lengths -> line offsets
+//  k_mplp_emit : writes the text.  A wave's lines are contiguous in the output, so they are
+//                assembled in LDS and flushed with coalesced 16-byte stores; a wave whose
+//                lines exceed the LDS slice falls back to direct global byte stores.
+#include "dev_util.h"
+
+struct MplpDevPar {
+    int32_t min_baseQ, all, rev_del, flag, no_ins, no_del, no_ends;
+    int64_t tlen;
+};
+
+__constant__ char c_nt_lc[17] = ",acmgrsvtwyhkdbn";
+__constant__ char c_nt_uc[17] = ".ACMGRSVTWYHKDBN";
+__constant__ char c_nt16_str[17] = "=ACMGRSVTWYHKDBN";
+
+#define EXTRA_MASK (STA_MPLP_PRINT_MAPQ_CHAR | STA_MPLP_PRINT_QPOS | STA_MPLP_PRINT_QNAME | STA_MPLP_PRINT_FLAG | \
+                    STA_MPLP_PRINT_RNAME | STA_MPLP_PRINT_POS | STA_MPLP_PRINT_MAPQ | STA_MPLP_PRINT_PNEXT | \
+                    STA_MPLP_PRINT_RLEN | STA_MPLP_PRINT_QPOS5)
+
+extern __shared__ __attribute__((aligned(16))) char lds_text[];
+
+// ---- byte sink: LDS slice of this wave, or global memory ----
+template <bool LDS> struct Sink {
+    uint32_t cur;        // LDS: offset into lds_text; global: unused
+    char *g;             // global cursor
+    __device__ __forceinline__ void put(char c)
+    {
+        if (LDS) lds_text[cur++] = c;
+        else *g++ = c;
+    }
+    __device__ __forceinline__ void put_dec(long long v)
+    {
+        if (v < 0) { put('-'); v = -v; }
+        unsigned long long u = (unsigned long long)v;
+        int n = dec_digits(u);
+        if (LDS) {
+            uint32_t e = cur + n;
+            for (uint32_t q = e; q > cur;) { lds_text[--q] = (char)('0' + u % 10); u /= 10; }
+            cur = e;
+        } else {
+            char *e = g + n;
+            for (char *q = e; q > g;) { *--q = (char)('0' + u % 10); u /= 10; }
+            g = e;
+        }
+    }
+};
+
+struct Resolved {
+    int qpos, indel, k;
+    bool is_del, is_refskip;
+};
+
+// stateless equivalent of HTSlib resolve_cigar2 for (read, column p) -- SURVEY.md A.2
+__device__ __forceinline__ Resolved resolve_general(const uint32_t *cig, int n, int rpos, int p)
+{
+    Resolved r;
+    int x = rpos, y = 0, k = 0, op = 0, l = 0;
+    for (k = 0; k < n; ++k) {
+        uint32_t c = cig[k];
+        op = c & 0xf; l = (int)(c >> 4);
+        if (cg_is_refop(op)) {
+            if (p < x + l) break;
+            if (cg_is_mop(op)) y += l;
+            x += l;
+        } else if (cg_is_qop(op)) y += l;
+    }
+    r.k = k; r.indel = 0; r.is_del = false; r.is_refskip = false;
+    if (x + l - 1 == p && k + 1 < n) {
+        int op2 = cig[k + 1] & 0xf, l2 = (int)(cig[k + 1] >> 4);
+        if (op2 == CG_D && op != CG_D) {
+            r.indel = -l2;
+            for (int j = k + 2; j < n; ++j) {
+                if ((cig[j] & 0xf) == CG_D) r.indel -= (int)(cig[j] >> 4); else break;
+            }
+        } else if (op2 == CG_I) {
+            r.indel = l2;
+            for (int j = k + 2; j < n; ++j) {
+                int o = cig[j] & 0xf;
+                if (o == CG_I) r.indel += (int)(cig[j] >> 4);
+                else if (o != CG_P) break;
+            }
+        } else if (op2 == CG_P && k + 2 < n) {
+            int l3 = 0;
+            for (int j = k + 2; j < n; ++j) {
+                int o = cig[j] & 0xf;
+                if (o == CG_I) l3 += (int)(cig[j] >> 4);
+                else if (cg_is_refop(o)) break;
+            }
+            if (l3 > 0) r.indel = l3;
+        }
+    }
+    if (cg_is_mop(op)) r.qpos = y + (p - x);
+    else { r.is_del = true; r.qpos = y; r.is_refskip = (op == CG_N); }
+    return r;
+}
+
+// bam_plp_insertion: total length (I+P run after op k) and the D that may follow it
+__device__ __forceinline__ void insertion_shape(const uint32_t *cig, int n, int k, int &ins_total, int &del_after)
+{
+    ins_total = 0; del_after = 0;
+    int j = k + 1;
+    for (; j < n; ++j) {
+        int o = cig[j] & 0xf;
+        if (o == CG_I || o == CG_P) ins_total += (int)(cig[j] >> 4); else break;
+    }
+    if (j < n && (cig[j] & 0xf) == CG_D) del_after = (int)(cig[j] >> 4);
+}
+
+// One (read, column) entry after filtering: everything pileup_seq / the extra columns need.
+struct Entry {
+    int64_t r;           // read index
+    int rpos, rend, lq;
+    uint32_t info;
+    uint64_t boff;       // base offset (bytes into qual; /2 into seq)
+    Resolved rs;
+};
+
+__device__ __forceinline__ int token_len(const StaReadsDev &R, const MplpDevPar &P, const Entry &e, int p)
+{
+    int len = 1;
+    if (!P.no_ends) len += (p == e.rpos ? 2 : 0) + (p == e.rend - 1 ? 1 : 0);
+    if (e.rs.indel != 0) {
+        int del_len = -e.rs.indel;
+        if (e.rs.indel > 0) {
+            const uint32_t *cig = R.cigar + R.cig_off[e.r];
+            int n = (int)(R.cig_off[e.r + 1] - R.cig_off[e.r]);
+            int ins_total;
+            insertion_shape(cig, n, e.rs.k, ins_total, del_len);
+            if (P.no_ins < 2) len += 1 + dec_digits_u32((uint32_t)ins_total);
+            if (!P.no_ins) len += ins_total;
+        }
+        if (del_len > 0) {
+            if (P.no_del < 2) len += 1 + dec_digits_u32((uint32_t)del_len);
+            if (!P.no_del) len += del_len;
+        }
+    }
+    return len;
+}
+
+template <bool LDS>
+__device__ __forceinline__ void token_write(const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, const Entry &e, int p, Sink<LDS> &s)
+{
+    bool rev = (e.info & RI_REV) != 0;
+    int64_t apos = W.origin + p;
+    if (!P.no_ends && p == e.rpos) {
+        int mq = (int)((e.info >> RI_MAPQ_SHIFT) & 0xff);
+        s.put('^');
+        s.put((char)(mq > 93 ? 126 : mq + 33));
+    }
+    if (!e.rs.is_del) {
+        int c = e.rs.qpos < e.lq ? seq_nib(R.seq, e.boff >> 1, e.rs.qpos) : 15;
+        if (W.ref) {
+            int rb = apos < W.ref_len ? nt16_from_char((unsigned char)W.ref[apos]) : 15;
+            if (c == rb) c = 0;
+        }
+        s.put(rev ? c_nt_lc[c] : c_nt_uc[c]);
+    } else {
+        s.put(e.rs.is_refskip ? (rev ? '<' : '>') : ((rev && P.rev_del) ? '#' : '*'));
+    }
+    if (e.rs.indel != 0) {
+        int del_len = -e.rs.indel;
+        if (e.rs.indel > 0) {
+            const uint32_t *cig = R.cigar + R.cig_off[e.r];
+            int n = (int)(R.cig_off[e.r + 1] - R.cig_off[e.r]);
+            int ins_total;
+            insertion_shape(cig, n, e.rs.k, ins_total, del_len);
+            if (P.no_ins < 2) { s.put('+'); s.put_dec(ins_total); }
+            if (!P.no_ins) {
+                char pad = (rev && P.rev_del) ? '#' : '*';
+                int j = 1;
+                for (int kk = e.rs.k + 1; kk < n; ++kk) {
+                    int o = cig[kk] & 0xf, l = (int)(cig[kk] >> 4);
+                    if (o == CG_P) { for (int t = 0; t < l; ++t) s.put(pad); }
+                    else if (o == CG_I) {
+                        for (int t = 0; t < l; ++t, ++j) {
+                            int qi = e.rs.qpos + j - (e.rs.is_del ? 1 : 0);
+                            char ch = qi < e.lq ? c_nt16_str[seq_nib(R.seq, e.boff >> 1, qi)] : 'N';
+                            s.put(rev ? lower_c(ch) : upper_c(ch));
+                        }
+                    } else break;
+                }
+            }
+        }
+        if (del_len > 0) {
+            if (P.no_del < 2) { s.put('-'); s.put_dec(del_len); }
+            if (!P.no_del) {
+                for (int j = 1; j <= del_len; ++j) {
+                    // reference: (ref && (int)pos+j < ref_len) ? ref[pos+j] : 'N'   (bam_plcmd.c:158)
+                    char c = (W.ref && (int64_t)((int)apos + j) < W.ref_len) ? W.ref[apos + j] : 'N';
+                    s.put(rev ? lower_c(c) : upper_c(c));
+                }
+            }
+        }
+    }
+    if (!P.no_ends && p == e.rend - 1) s.put('$');
+}
+
+// extra per-read columns (bam_plcmd.c:727-796)
+__device__ __forceinline__ long long extra_value(const StaReadsDev &R, const StaWinDev &W, int kind, const Entry &e)
+{
+    switch (kind) {
+    case STA_MPLP_PRINT_QPOS: return e.rs.qpos + 1;
+    case STA_MPLP_PRINT_QPOS5: return (e.info & RI_REV) ? e.lq - e.rs.qpos + (e.rs.is_del ? 1 : 0) : e.rs.qpos + 1;
+    case STA_MPLP_PRINT_FLAG: return R.flag[e.r];
+    case STA_MPLP_PRINT_POS: return W.origin + e.rpos + 1;
+    case STA_MPLP_PRINT_MAPQ: return (e.info >> RI_MAPQ_SHIFT) & 0xff;
+    case STA_MPLP_PRINT_PNEXT: return R.mpos[e.r] + 1;
+    case STA_MPLP_PRINT_RLEN: return e.lq;
+    }
+    return 0;
+}
+__device__ __forceinline__ int extra_len(const StaReadsDev &R, const StaWinDev &W, int kind, const Entry &e)
+{
+    if (kind == STA_MPLP_PRINT_MAPQ_CHAR) return 1;
+    if (kind == STA_MPLP_PRINT_QNAME) return (int)(R.name_off[e.r + 1] - R.name_off[e.r]) - 1;
+    if (kind == STA_MPLP_PRINT_RNAME) return W.tname_len;
+    long long v = extra_value(R, W, kind, e);
+    return (v < 0 ? 1 : 0) + dec_digits((unsigned long long)(v < 0 ? -v : v));
+}
+template <bool LDS>
+__device__ __forceinline__ void extra_write(const StaReadsDev &R, const StaWinDev &W, int kind, const Entry &e, Sink<LDS> &s)
+{
+    if (kind == STA_MPLP_PRINT_MAPQ_CHAR) {
+        int c = (int)((e.info >> RI_MAPQ_SHIFT) & 0xff) + 33;
+        s.put((char)(c > 126 ? 126 : c));
+    } else if (kind == STA_MPLP_PRINT_QNAME) {
+        const char *nm = R.names + R.name_off[e.r];
+        int l = (int)(R.name_off[e.r + 1] - R.name_off[e.r]) - 1;
+        for (int t = 0; t < l; ++t) s.put(nm[t]);
+    } else if (kind == STA_MPLP_PRINT_RNAME) {
+        for (int t = 0; t < W.tname_len; ++t) s.put(W.tname[t]);
+    } else s.put_dec(extra_value(R, W, kind, e));
+}
+
+// ---- the uniform walk over one file's candidate reads ----
+// MODE 0: measure (n_plp, cnt, seq_len, extras_len)   MODE 1: count only (n_plp, cnt)
+// MODE 2: write seq tokens   MODE 3: write qual chars   MODE 4: write one extra column `kind`
+struct Acc { uint32_t n_plp, cnt, seq_len, extras_len; };
+
+template <int MODE, bool LDS>
+__device__ __forceinline__ void file_pass(const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int p, bool active,
+                                          int64_t rlo, int64_t rhi, int kind, Acc &acc, Sink<LDS> &s)
+{
+    uint32_t nw = 0;    // entries written so far (for the ',' separators)
+    for (int64_t r = rlo; r < rhi; ++r) {
+        uint32_t info = R.info[r];
+        if (!(info & RI_KEEP)) continue;
+        int rpos = R.pos[r], rend = R.end[r];
+        bool cov = active && rpos <= p && p < rend;
+        if (__ballot(cov) == 0) continue;
+        if (!cov) continue;
+        Entry e;
+        e.r = r; e.rpos = rpos; e.rend = rend; e.info = info;
+        e.lq = R.l_qseq[r];
+        e.boff = (uint64_t)R.base_off8[r] << 3;
+        if (info & RI_SIMPLE) { e.rs.qpos = p - rpos; e.rs.indel = 0; e.rs.k = 0; e.rs.is_del = false; e.rs.is_refskip = false; }
+        else e.rs = resolve_general(R.cigar + R.cig_off[r], (int)(R.cig_off[r + 1] - R.cig_off[r]), rpos, p);
+        if (MODE <= 1) acc.n_plp++;
+        int c = e.rs.qpos < e.lq ? R.qual[e.boff + (uint64_t)e.rs.qpos] : 0;
+        if (c < P.min_baseQ) continue;
+        if (MODE == 0) {
+            acc.cnt++;
+            acc.seq_len += (uint32_t)token_len(R, P, e, p);
+            uint32_t ex = (uint32_t)P.flag & EXTRA_MASK;
+            while (ex) {
+                int kd = (int)(ex & (~ex + 1)); ex &= ex - 1;
+                acc.extras_len += (uint32_t)extra_len(R, W, kd, e);
+            }
+        } else if (MODE == 1) {
+            acc.cnt++;
+        } else if (MODE == 2) {
+            token_write<LDS>(R, W, P, e, p, s);
+        } else if (MODE == 3) {
+            s.put((char)(c + 33 < 126 ? c + 33 : 126));
+        } else {
+            if (nw > 0 && kind != STA_MPLP_PRINT_MAPQ_CHAR) s.put(',');
+            extra_write<LDS>(R, W, kind, e, s);
+        }
+        nw++;
+    }
+}
+
+__device__ __forceinline__ void wave_read_range(const StaReadsDev &R, int p0, int p1 /*last col*/, int64_t &rlo, int64_t &rhi)
+{
+    if (R.n == 0) { rlo = rhi = 0; return; }
+    rlo = wave_upper_bound(R.maxend, R.n, p0);      // first read with an end beyond the first column
+    rhi = wave_upper_bound(R.pos, R.n, p1);         // first read starting beyond the last column
+    if (rlo > rhi) rlo = rhi;
+}
+
+// bytes of "\t cnt \t seq \t qual [\t extra]*" for one file
+__device__ __forceinline__ uint32_t file_text_len(const MplpDevPar &P, const Acc &a)
+{
+    uint32_t n_extra = (uint32_t)__popc((uint32_t)P.flag & EXTRA_MASK);
+    uint32_t len = 1 + (uint32_t)dec_digits_u32(a.cnt) + 1 + (a.seq_len ? a.seq_len : 1) + 1 + (a.cnt ? a.cnt : 1);
+    if (n_extra) {
+        // every extra column: '\t' + (fields + separators, or '*')
+        uint32_t n_sep_cols = n_extra - ((P.flag & STA_MPLP_PRINT_MAPQ_CHAR) ? 1u : 0u);
+        if (a.cnt) len += n_extra + a.extras_len + n_sep_cols * (a.cnt - 1);
+        else len += 2 * n_extra;
+    }
+    return len;
+}
+
+__device__ __forceinline__ bool column_selected(const StaWinDev &W, int64_t apos)
+{
+    if (W.has_reg && (apos < W.reg_beg || apos >= W.reg_end)) return false;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_mplp_len(StaWinDev W, MplpDevPar P, uint32_t *line_len, StaCounters *ctr)
+{
+    int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    int lane = threadIdx.x & 63;
+    int64_t ncols = (int64_t)W.col_end - W.col_beg;
+    int64_t c0 = (int64_t)wave * 64;
+    if (c0 >= ncols) return;
+    int p0 = W.col_beg + (int)c0;
+    int p = p0 + lane;
+    bool active = p < W.col_end;
+    int plast = p0 + 63 < W.col_end ? p0 + 63 : W.col_end - 1;
+    int64_t apos = W.origin + p;
+
+    uint32_t total = 0; bool any = false;
+    Sink<false> dummy; dummy.g = nullptr; dummy.cur = 0;
+    for (int f = 0; f < W.nfiles; ++f) {
+        const StaReadsDev &R = W.files[f];
+        int64_t rlo, rhi;
+        wave_read_range(R, p0, plast, rlo, rhi);
+        Acc a{ 0, 0, 0, 0 };
+        file_pass<0, false>(R, W, P, p, active, rlo, rhi, 0, a, dummy);
+        any |= a.n_plp > 0;
+        total += file_text_len(P, a);
+    }
+    bool in_reg = active && column_selected(W, apos);
+    bool data = in_reg && any;
+    bool exists = in_reg && (any || (P.all && apos < P.tlen));
+    if (exists && W.has_bed) exists = bed_overlap_dev(W.bed_beg, W.bed_end, W.n_bed, apos, apos + 1);
+    uint32_t len = 0;
+    if (exists) len = (uint32_t)W.tname_len + 1 + (uint32_t)dec_digits((unsigned long long)(apos + 1)) + 1 + 1 + total + 1;
+    if (active) line_len[c0 + lane] = len;
+    unsigned long long mdata = __ballot(data), mex = __ballot(exists);
+    if (lane == 0) {
+        if (mdata) atomicAdd(&ctr->n_data_cols, (unsigned long long)__popcll(mdata));
+        if (mex) atomicAdd(&ctr->n_lines, (unsigned long long)__popcll(mex));
+    }
+}
+
+template <bool LDS>
+__device__ __forceinline__ void emit_column(const StaWinDev &W, const MplpDevPar &P, int p0, int plast, int p, bool exists, Sink<LDS> &s)
+{
+    int64_t apos = W.origin + p;
+    if (exists) {
+        for (int t = 0; t < W.tname_len; ++t) s.put(W.tname[t]);
+        s.put('\t');
+        s.put_dec(apos + 1);
+        s.put('\t');
+        s.put((W.ref && apos < W.ref_len) ? W.ref[apos] : 'N');
+    }
+    for (int f = 0; f < W.nfiles; ++f) {
+        const StaReadsDev &R = W.files[f];
+        int64_t rlo, rhi;
+        wave_read_range(R, p0, plast, rlo, rhi);
+        Acc a{ 0, 0, 0, 0 };
+        file_pass<1, LDS>(R, W, P, p, exists, rlo, rhi, 0, a, s);
+        if (exists) { s.put('\t'); s.put_dec(a.cnt); s.put('\t'); }
+        // seq
+        file_pass<2, LDS>(R, W, P, p, exists && a.cnt, rlo, rhi, 0, a, s);
+        // a column whose tokens are all empty cannot happen (every token has >= 1 char)
+        if (exists) { if (!a.cnt) s.put('*'); s.put('\t'); }
+        file_pass<3, LDS>(R, W, P, p, exists && a.cnt, rlo, rhi, 0, a, s);
+        if (exists && !a.cnt) s.put('*');
+        uint32_t ex = (uint32_t)P.flag & EXTRA_MASK;
+        while (ex) {
+            int kd = (int)(ex & (~ex + 1)); ex &= ex - 1;
+            if (exists) s.put('\t');
+            file_pass<4, LDS>(R, W, P, p, exists && a.cnt, rlo, rhi, kd, a, s);
+            if (exists && !a.cnt) s.put('*');
+        }
+    }
+    if (exists) s.put('\n');
+}
+
+__global__ void __launch_bounds__(256) k_mplp_emit(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, char *out, uint32_t lds_cap)
+{
+    int wid = threadIdx.x >> 6;
+    int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    int lane = threadIdx.x & 63;
+    int64_t ncols = (int64_t)W.col_end - W.col_beg;
+    int64_t c0 = (int64_t)wave * 64;
+    if (c0 >= ncols) return;
+    int64_t c1 = c0 + 64 < ncols ? c0 + 64 : ncols;
+    int p0 = W.col_beg + (int)c0;
+    int p = p0 + lane;
+    bool active = p < W.col_end;
+    int plast = W.col_beg + (int)c1 - 1;
+    uint64_t o0 = offs[c0], o1 = offs[c1];
+    uint64_t my0 = active ? offs[c0 + lane] : o1;
+    uint64_t my1 = active ? offs[c0 + lane + 1] : o1;
+    bool exists = my1 > my0;
+    uint64_t wbytes = o1 - o0;
+    if (wbytes == 0) return;
+    if (wbytes <= lds_cap) {
+        uint32_t slice = (lds_cap + 16 + 15) & ~15u;
+        uint32_t base = (uint32_t)wid * slice;
+        uint32_t mis = (uint32_t)((uintptr_t)(out + o0) & 15);
+        Sink<true> s; s.g = nullptr; s.cur = base + mis + (uint32_t)(my0 - o0);
+        emit_column<true>(W, P, p0, plast, p, exists, s);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // flush: LDS offset == global address (mod 16)
+        char *dst = out + o0;
+        uint32_t n = (uint32_t)wbytes;
+        uint32_t head = mis ? 16 - mis : 0; if (head > n) head = n;
+        if ((uint32_t)lane < head) dst[lane] = lds_text[base + mis + lane];
+        uint32_t body = (n - head) >> 4;
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(lds_text + base + mis + head);
+        uint4 *dst4 = reinterpret_cast<uint4 *>(dst + head);
+        for (uint32_t i = lane; i < body; i += 64) dst4[i] = src4[i];
+        uint32_t done = head + (body << 4);
+        if (done + lane < n) dst[done + lane] = lds_text[base + mis + done + lane];
+    } else {
+        Sink<false> s; s.cur = 0; s.g = out + my0;
+        emit_column<false>(W, P, p0, plast, p, exists, s);
+    }
+}
+
+static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
+{
+    MplpDevPar d;
+    d.min_baseQ = p.min_baseQ; d.all = p.all; d.rev_del = p.rev_del; d.flag = p.flag;
+    d.no_ins = p.no_ins; d.no_del = p.no_del; d.no_ends = p.no_ends; d.tlen = tlen;
+    return d;
+}
+
+// tlen travels in StaWinDev.reg_* style fields? no: we pass it through ref_len-independent P.tlen
+void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, StaCounters *ctr)
+{
+    int64_t ncols = (int64_t)w.col_end - w.col_beg;
+    if (ncols <= 0) return;
+    int64_t nb = (ncols + 255) / 256;
+    hipLaunchKernelGGL(k_mplp_len, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, ctr);
+}
+
+void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, char *out, uint32_t lds_cap)
+{
+    int64_t ncols = (int64_t)w.col_end - w.col_beg;
+    if (ncols <= 0) return;
+    int64_t nb = (ncols + 255) / 256;
+    uint32_t slice = (lds_cap + 16 + 15) & ~15u;
+    hipLaunchKernelGGL(k_mplp_emit, dim3((unsigned)nb), dim3(256), 4 * slice, s, w, make_par(p, w.tlen), offs, out, lds_cap);
+}

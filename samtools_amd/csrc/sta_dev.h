@@ -1,0 +1,102 @@
+// sta_dev.h -- internal device-side view of a staged window and kernel launchers.
+// Not part of the C-ABI (include/samtools_amd.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/samtools_amd.h"
+
+// per-read packed info word produced by k_prep_reads
+#define RI_PUSHED   0x1u    // passed mplp_func filters -> reaches bam_plp_push
+#define RI_KEEP     0x2u    // in the pileup: pushed, reference span > 0, not dropped by -d cap
+#define RI_SIMPLE   0x4u    // CIGAR is a single M/=/X op
+#define RI_REV      0x8u
+#define RI_OLAP_EL  0x10u   // eligible for mate-overlap hashing (overlap_push conditions)
+#define RI_BAQ      0x20u   // BAQ must be computed for this read
+#define RI_MAPQ_SHIFT 8     // bits 8..15: mapping quality after -C
+
+// one input file's reads as the kernels see them (all device pointers)
+struct StaReadsDev {
+    int64_t n;
+    const int32_t *pos;
+    const uint16_t *flag;
+    const uint8_t *mapq;
+    const uint8_t *aux;
+    const int32_t *l_qseq;
+    const uint32_t *cig_off;
+    const uint32_t *base_off8;
+    const int32_t *mtid;
+    const int64_t *mpos;
+    const int32_t *isize;
+    const uint32_t *name_off;
+    const uint32_t *cigar;
+    const uint8_t *seq;
+    const uint8_t *qual_in;
+    const uint8_t *bq;
+    const char *names;
+    uint64_t n_bases_total;
+    // engine workspace
+    uint8_t *qual;        // working qualities (== qual_in when nothing rewrites them)
+    int32_t *end;         // pos + reference span
+    int32_t *maxend;      // inclusive prefix max of `end` over RI_KEEP reads
+    uint32_t *info;       // RI_*
+    int32_t *clip;        // depth -s: columns below this are not counted (0 = none)
+};
+
+// window constants shared by the column kernels
+struct StaWinDev {
+    int32_t col_beg, col_end;
+    int64_t origin;
+    int32_t tid;
+    int64_t tlen;
+    int32_t nfiles;
+    const StaReadsDev *files;       // device array
+    const char *ref;                // contig sequence indexed by absolute position (or nullptr)
+    int64_t ref_len;
+    const char *tname; int32_t tname_len;
+    int32_t has_bed; int64_t n_bed; const int64_t *bed_beg, *bed_end;
+    int32_t has_reg; int64_t reg_beg, reg_end;
+};
+
+struct StaCounters {          // device-side reduction targets, zeroed per plan
+    unsigned long long n_lines, n_data_cols, n_kept, piled_bases, n_dropped, max_wave_bytes, n_anom, maxcnt_flag, max_lq, max_bw, n_baq;
+};
+
+// ---- launchers (defined in the .hip files) ----
+void sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
+                           const sta_mplp_params &p, StaCounters *ctr);
+void sta_launch_prep_reads_depth(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
+                                 const sta_depth_params &p, StaCounters *ctr);
+void sta_launch_qual_prep(hipStream_t s, const StaReadsDev &r, int illumina13);
+void sta_launch_maxend_scan(hipStream_t s, const StaReadsDev &r, void *tmp, size_t tmp_bytes);
+size_t sta_scan_tmp_bytes(int64_t n);
+// exclusive scan of u32 lengths into u64 offsets (offs has n+1 entries)
+void sta_launch_len_scan(hipStream_t s, const uint32_t *len, uint64_t *offs, int64_t n, void *tmp, size_t tmp_bytes);
+void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, StaCounters *ctr);
+void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs,
+                          char *out, uint32_t lds_cap);
+void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, int64_t ncols, StaCounters *ctr);
+
+// overlap (mate) resolution
+size_t sta_overlap_table_slots(int64_t n_reads);
+size_t sta_overlap_table_bytes(size_t slots);
+void sta_launch_overlap(hipStream_t s, const StaReadsDev &r, int64_t origin, int32_t tid, void *table, size_t slots,
+                        int32_t *chain_next, StaCounters *ctr);
+// -d cap
+void sta_launch_maxcnt_detect(hipStream_t s, const StaReadsDev &r, int maxcnt, StaCounters *ctr);
+void sta_launch_maxcnt(hipStream_t s, const StaReadsDev &r, int maxcnt, int32_t col_lo, int32_t ncols_span,
+                       int32_t *scratch, StaCounters *ctr);
+// BAQ
+size_t sta_baq_scratch_bytes(int64_t n_reads, int max_lq, int max_bw);
+void sta_launch_baq(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int redo, void *scratch, size_t scratch_bytes,
+                    int lq_max, int bw_max);
+
+// depth
+void sta_launch_depth_count(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
+                            const sta_depth_params &p, int32_t *diff /*[(nfiles+1)][ncols+1]*/);
+void sta_launch_depth_scan(hipStream_t s, int32_t *diff, int nrows, int64_t ncols, void *tmp, size_t tmp_bytes);
+void sta_launch_depth_len(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, const int32_t *counts,
+                          uint32_t *line_len, StaCounters *ctr);
+void sta_launch_depth_emit(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, const int32_t *counts,
+                           const uint64_t *offs, char *out, uint32_t lds_cap);
+void sta_launch_depth_pair(hipStream_t s, const StaReadsDev &r, int64_t origin, int32_t tid, void *table, size_t slots,
+                           int32_t *chain_next, StaCounters *ctr);

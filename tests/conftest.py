@@ -1,0 +1,32 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_bin():
+    """CPU oracle (test infrastructure only); built on demand with gcc."""
+    exe = os.path.join(REPO, "oracle", "_build", "oracle_samtools")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(REPO, "oracle")], check=True, stdout=subprocess.DEVNULL)
+    return exe
+
+
+@pytest.fixture(scope="session")
+def product_bin():
+    """samtools-amd CLI (HIP engine).  Must already be built in-tree (see __graft_entry__.build)."""
+    exe = os.path.join(REPO, "samtools_amd", "bin", "samtools-amd")
+    if not os.path.exists(exe):
+        pytest.fail("samtools_amd/bin/samtools-amd is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    return exe

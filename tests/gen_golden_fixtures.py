@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Copy the reference's own golden vectors for the mpileup/depth path into tests/golden/.
+
+/root/reference does not exist on the GPU box, so the small input fixtures and the
+expected outputs of every reproducible case in tests/regcases.py are committed under
+tests/golden/ (data files only -- no reference source code).  Expected outputs larger
+than 16 KiB are stored gzip-compressed.  Run from the repo root in the build container:
+
+    python tests/gen_golden_fixtures.py
+
+Sources: /root/reference/test/mpileup/{*.sam,*.bam,*.fa,regions,xx.bed*,expected/*.out},
+/root/reference/test/dat/{mpileup.*,view.001.sam}, /root/reference/test/large_pos/*.
+"""
+import gzip
+import os
+import re
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import regcases  # noqa: E402
+
+REF = "/root/reference/test"
+OUT = os.path.join(HERE, "golden")
+
+
+def copy(src, dst, gz_over=None):
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    if gz_over is not None and os.path.getsize(src) > gz_over:
+        with open(src, "rb") as fi, gzip.GzipFile(dst + ".gz", "wb", mtime=0) as fo:
+            shutil.copyfileobj(fi, fo)
+    else:
+        shutil.copyfile(src, dst)
+
+
+def tokens_to_files(argstr, workdir):
+    out = []
+    for a in argstr.split():
+        for part in re.split(r"[,:]", a):
+            p = os.path.normpath(os.path.join(workdir, part))
+            if os.path.isfile(p):
+                out.append(p)
+    return out
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not present; fixtures are already committed")
+    inputs = set()
+    for exp, args, post in regcases.MPILEUP + regcases.DEPTH + regcases.EXPECTED_FAIL:
+        inputs.update(tokens_to_files(args, os.path.join(REF, "mpileup")))
+        src = os.path.join(REF, "mpileup", "expected", exp)
+        if post == "gz1":
+            copy(src + ".f3-6.gz", os.path.join(OUT, "mpileup", "expected", exp + ".f3-6.gz"))
+        else:
+            copy(src, os.path.join(OUT, "mpileup", "expected", exp), gz_over=16384)
+    for exp, args, post in regcases.TESTPL:
+        inputs.update(tokens_to_files(args, REF))
+        copy(os.path.join(REF, exp), os.path.join(OUT, exp), gz_over=16384)
+    copy(os.path.join(REF, "dat", "mpileup.err.1"), os.path.join(OUT, "dat", "mpileup.err.1"))
+    for p in sorted(inputs):
+        rel = os.path.relpath(p, REF)
+        copy(p, os.path.join(OUT, rel))
+    # mpileup.reg:89 -- read groups of mpileup.1.bam except ERR013140
+    d = gzip.open(os.path.join(REF, "mpileup", "mpileup.1.bam")).read()
+    rgs = sorted(set(m.group(1).decode() for m in re.finditer(rb"RGZ([A-Z0-9]+)", d)))
+    with open(os.path.join(OUT, "mpileup", "35.rg.txt"), "w") as fh:
+        for r in rgs:
+            if r != "ERR013140":
+                fh.write(r + "\n")
+    total = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(OUT) for f in fs)
+    print("golden fixtures: %.1f MiB under %s" % (total / 2 ** 20, OUT))
+
+
+if __name__ == "__main__":
+    main()

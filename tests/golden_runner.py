@@ -65,8 +65,23 @@ def read_expected(path, post):
     if post == "gz1":
         with gzip.open(path + ".f3-6.gz", "rt") as fh:
             return fh.read()
-    with open(path) as fh:
+    if not os.path.exists(path) and os.path.exists(path + ".gz"):
+        with gzip.open(path + ".gz", "rt", encoding="latin1") as fh:
+            return fh.read()
+    with open(path, encoding="latin1") as fh:
         return fh.read()
+
+
+GOLDEN = os.path.join(HERE, "golden")
+ORACLE = os.path.join(REPO, "oracle", "_build", "oracle_samtools")
+PRODUCT = os.path.join(REPO, "samtools_amd", "bin", "samtools-amd")
+
+
+def case_paths(group, exp):
+    """(workdir, expected_path) for a regcases entry of the given group."""
+    if group == "testpl":
+        return GOLDEN, os.path.join(GOLDEN, exp)
+    return os.path.join(GOLDEN, "mpileup"), os.path.join(GOLDEN, "mpileup", "expected", exp)
 
 
 def run_case(binary, workdir, expected_path, argstr, post, env=None, timeout=600):

@@ -1,0 +1,148 @@
+"""Deterministic synthetic aligned reads: used by the tests, smoke() and bench.py.
+
+One generator feeds both sides of every parity test: `synth_reads` returns the structure-of-arrays
+staging layout of include/samtools_amd.h (numpy), `write_sam` writes the very same reads as SAM
+text for the CLIs (engine and oracle).  Not product code."""
+import os
+
+import numpy as np
+
+NT16 = {"A": 1, "C": 2, "G": 4, "T": 8, "N": 15}
+CODE2CHR = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
+QUAL_SET = np.array([2, 11, 25, 37], dtype=np.uint8)
+QUAL_P = np.array([0.02, 0.05, 0.13, 0.80])
+
+
+def synth_ref(n, seed=1):
+    rng = np.random.default_rng(seed)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)]
+
+
+def synth_reads(ref, depth=30, read_len=150, seed=42, paired=False, sub_rate=0.001, indel_rate=0.005,
+                mapq=60, origin=0):
+    """Returns a dict with the sta_reads arrays for ONE file covering the whole of `ref`.
+
+    ref: uint8 array of ASCII bases (contig of length len(ref)); reads lie fully inside it."""
+    rng = np.random.default_rng(seed)
+    n_ref = len(ref)
+    L = read_len
+    n_reads = max(1, int(depth * n_ref / L))
+    if paired:
+        n_pairs = max(1, n_reads // 2)
+        isz = np.maximum(np.rint(rng.normal(300, 30, n_pairs)).astype(np.int64), L)
+        isz = np.minimum(isz, n_ref)
+        s = rng.integers(0, np.maximum(n_ref - isz + 1, 1))
+        left = s
+        right = s + isz - L
+        orient = rng.integers(0, 2, n_pairs)          # 0: read1 left/fwd (99/147), 1: read1 right/rev (83/163)
+        pos = np.concatenate([left, right])
+        flag = np.concatenate([np.where(orient == 0, 99, 163), np.where(orient == 0, 147, 83)]).astype(np.uint16)
+        mpos = np.concatenate([right, left])
+        tlen = np.concatenate([isz, -isz])
+        pair_id = np.concatenate([np.arange(n_pairs), np.arange(n_pairs)])
+        n_reads = 2 * n_pairs
+    else:
+        pos = rng.integers(0, n_ref - L + 1, n_reads)
+        flag = np.where(rng.integers(0, 2, n_reads) == 1, 16, 0).astype(np.uint16)
+        mpos = np.full(n_reads, -1, dtype=np.int64)
+        tlen = np.zeros(n_reads, dtype=np.int64)
+        pair_id = np.arange(n_reads)
+    order = np.argsort(pos, kind="stable")
+    pos, flag, mpos, tlen, pair_id = pos[order], flag[order], mpos[order], tlen[order], pair_id[order]
+
+    # bases: reference + substitutions
+    idx = pos[:, None] + np.arange(L)[None, :]
+    bases = ref[idx].copy()                                  # ASCII
+    sub = rng.random(bases.shape) < sub_rate
+    if sub.any():
+        alt = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(sub.sum()))]
+        bases[sub] = alt
+    quals = QUAL_SET[rng.choice(4, size=bases.shape, p=QUAL_P)]
+
+    # CIGARs: default <L>M; a few reads carry one 1-3 bp insertion or deletion
+    cig_n = np.ones(n_reads, dtype=np.int64)
+    has_indel = rng.random(n_reads) < indel_rate
+    cigars = {}
+    for r in np.nonzero(has_indel)[0]:
+        k = int(rng.integers(1, 4))
+        at = int(rng.integers(10, L - 10 - k))
+        if rng.integers(0, 2) == 0 or pos[r] + L + k > n_ref:
+            # insertion: query keeps L bases, k of them inserted -> reference span L-k
+            cigars[int(r)] = [(at, 0), (k, 1), (L - at - k, 0)]
+            bases[r, at + k:] = ref[pos[r] + at: pos[r] + L - k]
+            bases[r, at:at + k] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, k)]
+        else:
+            cigars[int(r)] = [(at, 0), (k, 2), (L - at, 0)]
+            bases[r, at:] = ref[pos[r] + at + k: pos[r] + L + k]
+        cig_n[r] = 3
+    cig_off = np.zeros(n_reads + 1, dtype=np.uint32)
+    np.cumsum(cig_n, out=cig_off[1:])
+    cigar = np.full(int(cig_off[-1]), (L << 4) | 0, dtype=np.uint32)
+    for r, ops in cigars.items():
+        o = int(cig_off[r])
+        for j, (ln, op) in enumerate(ops):
+            cigar[o + j] = (ln << 4) | op
+
+    Lp = (L + 7) & ~7
+    qual_pool = np.zeros((n_reads, Lp), dtype=np.uint8)
+    qual_pool[:, :L] = quals
+    code = np.zeros(256, dtype=np.uint8) + 15
+    for ch, v in NT16.items():
+        code[ord(ch)] = v
+    codes = np.zeros((n_reads, Lp), dtype=np.uint8)
+    codes[:, :L] = code[bases]
+    seq_pool = ((codes[:, 0::2] << 4) | codes[:, 1::2]).astype(np.uint8)
+    base_off8 = (np.arange(n_reads, dtype=np.uint64) * (Lp >> 3)).astype(np.uint32)
+
+    names = [("r%d" % p).encode() + b"\0" for p in pair_id]
+    name_len = np.fromiter((len(x) for x in names), dtype=np.int64, count=n_reads)
+    name_off = np.zeros(n_reads + 1, dtype=np.uint32)
+    np.cumsum(name_len, out=name_off[1:])
+    names_pool = np.frombuffer(b"".join(names), dtype=np.uint8)
+
+    return {
+        "n": n_reads, "L": L,
+        "pos": (pos - origin).astype(np.int32), "flag": flag, "mapq": np.full(n_reads, mapq, dtype=np.uint8),
+        "aux": np.zeros(n_reads, dtype=np.uint8), "l_qseq": np.full(n_reads, L, dtype=np.int32),
+        "cig_off": cig_off, "base_off8": base_off8,
+        "mtid": np.where(mpos >= 0, 0, -1).astype(np.int32) if paired else np.full(n_reads, -1, dtype=np.int32),
+        "mpos": mpos.astype(np.int64), "isize": tlen.astype(np.int32), "name_off": name_off,
+        "cigar": cigar, "seq": np.ascontiguousarray(seq_pool).reshape(-1), "qual": qual_pool.reshape(-1),
+        "names": names_pool,
+        "_bases": bases, "_quals": quals, "_abs_pos": pos,
+    }
+
+
+def cigar_str(rd, r):
+    ops = rd["cigar"][int(rd["cig_off"][r]):int(rd["cig_off"][r + 1])]
+    return "".join("%d%s" % (int(c) >> 4, "MIDNSHP=XB"[int(c) & 15]) for c in ops)
+
+
+def write_sam(path, rd, ref_name, ref_len):
+    with open(path, "w") as fh:
+        fh.write("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n" % (ref_name, ref_len))
+        names = rd["names"].tobytes().split(b"\0")
+        for r in range(rd["n"]):
+            mp = int(rd["mpos"][r])
+            fh.write("%s\t%d\t%s\t%d\t%d\t%s\t%s\t%d\t%d\t%s\t%s\n" % (
+                names[r].decode(), int(rd["flag"][r]), ref_name, int(rd["_abs_pos"][r]) + 1, int(rd["mapq"][r]),
+                cigar_str(rd, r), "=" if mp >= 0 else "*", mp + 1, int(rd["isize"][r]),
+                rd["_bases"][r].tobytes().decode(), (rd["_quals"][r] + 33).astype(np.uint8).tobytes().decode()))
+
+
+def write_fasta(path, name, ref):
+    with open(path, "w") as fh:
+        fh.write(">%s\n" % name)
+        s = ref.tobytes().decode()
+        for i in range(0, len(s), 60):
+            fh.write(s[i:i + 60] + "\n")
+
+
+def write_synth_sam(outdir, n_ref=20000, depth=20, read_len=100, seed=7, paired=True, name="chrS", **kw):
+    ref = synth_ref(n_ref, seed=1)
+    rd = synth_reads(ref, depth=depth, read_len=read_len, seed=seed, paired=paired, **kw)
+    sam = os.path.join(outdir, "synth.sam")
+    fa = os.path.join(outdir, "synth.fa")
+    write_sam(sam, rd, name, n_ref)
+    write_fasta(fa, name, ref)
+    return sam, fa

@@ -1,0 +1,45 @@
+"""Engine vs CPU oracle on seeded synthetic reads (SURVEY.md 8d generator), through both CLIs.
+Covers the bench configurations at sizes the oracle finishes in seconds.  Needs a GPU: -m gpu."""
+import os
+import subprocess
+
+import pytest
+
+from synth import write_synth_sam
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    # (id, generator kwargs, argv template)
+    ("mpileup30_noref", dict(n_ref=60000, depth=30, read_len=150, seed=42, paired=False), ["mpileup", "{sam}"]),
+    ("mpileup30_B", dict(n_ref=60000, depth=30, read_len=150, seed=43, paired=False), ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
+    ("mpileup30_baq", dict(n_ref=30000, depth=30, read_len=150, seed=44, paired=False), ["mpileup", "-f", "{fa}", "{sam}"]),
+    ("mpileup30_pairs_olap", dict(n_ref=60000, depth=30, read_len=150, seed=45, paired=True), ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
+    ("mpileup_EA_pairs", dict(n_ref=30000, depth=30, read_len=150, seed=46, paired=True), ["mpileup", "-E", "-A", "-f", "{fa}", "{sam}"]),
+    ("mpileup300", dict(n_ref=8000, depth=300, read_len=150, seed=47, paired=False), ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
+    ("mpileup_sO", dict(n_ref=20000, depth=25, read_len=100, seed=48, paired=True), ["mpileup", "-s", "-O", "--output-BP-5", "--output-QNAME", "-Q0", "{sam}"]),
+    ("mpileup_a", dict(n_ref=5000, depth=3, read_len=50, seed=49, paired=False), ["mpileup", "-a", "-f", "{fa}", "{sam}"]),
+    ("depth30", dict(n_ref=60000, depth=30, read_len=150, seed=50, paired=False), ["depth", "{sam}"]),
+    ("depth30_a", dict(n_ref=60000, depth=30, read_len=150, seed=51, paired=False), ["depth", "-a", "{sam}"]),
+    ("depth_q20", dict(n_ref=60000, depth=30, read_len=150, seed=52, paired=False), ["depth", "-q", "20", "{sam}"]),
+    ("depth_s_J", dict(n_ref=40000, depth=30, read_len=150, seed=53, paired=True, indel_rate=0.05), ["depth", "-s", "-J", "{sam}"]),
+]
+
+
+@pytest.mark.parametrize("cid,gen,argv", CONFIGS, ids=[c[0] for c in CONFIGS])
+@pytest.mark.parametrize("window_cols", [None, 1000])
+def test_engine_equals_oracle_on_synthetic(tmp_path, oracle_bin, product_bin, cid, gen, argv, window_cols):
+    sam, fa = write_synth_sam(str(tmp_path), **gen)
+    args = [a.format(sam=sam, fa=fa) for a in argv]
+    want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    env = dict(os.environ)
+    if window_cols:
+        env["STA_WINDOW_COLS"] = str(window_cols)
+    got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert got.returncode == 0, got.stderr.decode()[-500:]
+    if got.stdout != want:
+        g, w = got.stdout.split(b"\n"), want.split(b"\n")
+        for i, (a, b) in enumerate(zip(g, w)):
+            if a != b:
+                pytest.fail("line %d differs\n got: %r\nwant: %r" % (i + 1, a[:300], b[:300]))
+        pytest.fail("line count differs: got %d want %d" % (len(g), len(w)))

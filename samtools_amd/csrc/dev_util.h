@@ -75,6 +75,45 @@ __device__ __forceinline__ int seq_nib(const uint8_t *seq, uint64_t seq_byte0, i
 __device__ __forceinline__ char lower_c(char c) { return (c >= 'A' && c <= 'Z') ? (char)(c + 32) : c; }
 __device__ __forceinline__ char upper_c(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
 
+// BAQ window geometry of realn.c: reference window [xb, xe) and the band width that
+// probaln_glocal ends up using.  Shared by k_prep_reads (scratch sizing) and k_baq.
+struct BaqGeo { long long xb, xe; int bw, l_ref; bool ok; };
+__device__ __forceinline__ BaqGeo baq_geometry(const uint32_t *cigar, int n_cigar, long long rpos, int lq,
+                                                const char *ref, long long ref_len)
+{
+    BaqGeo g; g.ok = false; g.bw = 7; g.l_ref = 0; g.xb = g.xe = -1;
+    long long x = rpos, xb = -1, xe = -1; int y = 0, yb = -1, ye = -1;
+    for (int k = 0; k < n_cigar; ++k) {
+        int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
+        if (cg_is_mop(op)) {
+            if (yb < 0) yb = y;
+            if (xb < 0) xb = x;
+            ye = y + l; xe = x + l;
+            x += l; y += l;
+        } else if (op == CG_S || op == CG_I) y += l;
+        else if (op == CG_D) x += l;
+    }
+    if (xb < 0) return g;
+    int bw = 7;
+    long long d = (xe - xb) - (ye - yb); if (d < 0) d = -d;
+    if (d > bw) bw = (int)d + 3;
+    xb -= yb + bw / 2; if (xb < 0) xb = 0;
+    xe += lq - ye + bw / 2;
+    if (xe - xb - lq > bw) { xb += (xe - xb - lq - bw) / 2; xe -= (xe - xb - lq - bw) / 2; }
+    (void)ref;                      // the staged contig has an explicit length and no NUL bytes
+    if (xe > ref_len) xe = ref_len > xb ? ref_len : xb;
+    int l_ref = (int)(xe - xb);
+    g.xb = xb; g.xe = xe; g.l_ref = l_ref;
+    // probaln_glocal: bw = min(max(l_ref, l_query), bw); bw = max(bw, |l_ref - l_query|)
+    int b2 = l_ref > lq ? l_ref : lq;
+    if (b2 > bw) b2 = bw;
+    int dd = l_ref - lq; if (dd < 0) dd = -dd;
+    if (b2 < dd) b2 = dd;
+    g.bw = b2;
+    g.ok = l_ref > 0 && lq > 0;
+    return g;
+}
+
 // wave-cooperative search on a non-decreasing int32 array: first index in [0,n) with a[i] > key
 // (a "64-ary" search: every step the 64 lanes probe 64 evenly spaced points)
 __device__ __forceinline__ int64_t wave_upper_bound(const int32_t *a, int64_t n, int32_t key)

@@ -344,6 +344,7 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             StaCounters c{};
             HIPCHK(hipMemcpyAsync(&c, ctr, sizeof(c), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] file %d: n_baq=%llu max_lq=%llu max_bw=%llu kept=%llu\n", f, c.n_baq, c.max_lq, c.max_bw, c.n_kept);
             if (!c.n_baq) break;
             size_t need = sta_baq_scratch_bytes(d.n, (int)c.max_lq, (int)c.max_bw);
             if (e->baq_scratch.ensure(need + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ scratch) failed");

@@ -77,7 +77,7 @@ int64_t Pump::fill(int tid, int64_t cb, int64_t ce_target, std::vector<std::vect
             int64_t p = pend_[f].pos;
             carry_[f].push_back(std::move(pend_[f]));
             advance(f);
-            if (++count >= cfg_.max_reads && f == 0) {
+            if (++count >= cfg_.max_reads && f == 0 && p >= cb) {
                 // cut the window after this start position (all reads sharing it stay together)
                 while (has_pend_[f] && pend_[f].tid == tid && pend_[f].pos == p) { carry_[f].push_back(std::move(pend_[f])); advance(f); }
                 if (p + 1 > cb) ce = std::min(ce, p + 1);

@@ -46,41 +46,16 @@ __global__ void __launch_bounds__(64) k_baq(StaReadsDev R, StaWinDev W, BaqTable
     uint8_t *qual = R.qual + boff;
     long long rpos = W.origin + R.pos[r];
 
-    // alignment extent (realn.c)
-    long long x = rpos; int y = 0, yb = -1, ye = -1; long long xb = -1, xe = -1;
-    for (int k = 0; k < n_cigar; ++k) {
-        int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
-        if (cg_is_mop(op)) {
-            if (yb < 0) yb = y;
-            if (xb < 0) xb = x;
-            ye = y + l; xe = x + l;
-            x += l; y += l;
-        } else if (op == CG_S || op == CG_I) y += l;
-        else if (op == CG_D) x += l;
-    }
-    int bw = 7;
-    {
-        long long d = (xe - xb) - (ye - yb); if (d < 0) d = -d;
-        if (d > bw) bw = (int)d + 3;
-    }
-    xb -= yb + bw / 2; if (xb < 0) xb = 0;
-    xe += lq - ye + bw / 2;
-    if (xe - xb - lq > bw) { xb += (xe - xb - lq - bw) / 2; xe -= (xe - xb - lq - bw) / 2; }
-    for (long long i = xb; i < xe; ++i) if (i >= W.ref_len || W.ref[i] == '\0') { xe = i; break; }
-    int l_ref = (int)(xe - xb), l_query = lq;
-    if (l_ref <= 0 || l_query <= 0) return;    // probaln_glocal returns 0: qualities unchanged
-
-    // probaln_glocal
+    BaqGeo g = baq_geometry(cigar, n_cigar, rpos, lq, W.ref, W.ref_len);
+    if (!g.ok) return;                          // probaln_glocal returns 0: qualities unchanged
+    long long xb = g.xb;
+    int l_ref = g.l_ref, l_query = lq, bw = g.bw;
     const char *ref = W.ref + xb;               // ref[k-1] -> code
 #define REFC(k1) nt16_int_dev(nt16_from_char((unsigned char)ref[(k1)]))
 #define QRYC(i1) nt16_int_dev(seq_nib(R.seq, boff >> 1, (i1)))
-    int cbw = bw;
-    bw = l_ref > l_query ? l_ref : l_query;
-    if (bw > cbw) bw = cbw;
-    { int d = l_ref - l_query; if (d < 0) d = -d; if (bw < d) bw = d; }
     int bw2 = bw * 2 + 1;
     int i_dim = bw2 * 3 + 6;
-    if (i_dim > idim_max || l_query > lq_max) return;   // cannot happen: sizes come from the same formulae
+    if (i_dim > idim_max || l_query > lq_max) return;   // cannot happen: sizes come from the same function
 
     size_t wave_base = (size_t)(t >> 6) * 64 * dbl_per_read;
     double *fS = scratch + wave_base + lane;                                  // f[(row*idim_max + u)*64]

@@ -67,18 +67,8 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
             bool q_absent = R.qual_in[(uint64_t)R.base_off8[i] << 3] == 0xff;
             if (!q_absent && !(aux & STA_AUX_HAS_ZQ) && (redo || !(aux & STA_AUX_HAS_BQ))) {
                 info |= RI_BAQ;
-                // band width of realn.c: 7, or |ref extent - query extent of the M ops| + 3 when larger
-                long long x = 0, y = 0, xb = -1, xe = -1, yb = -1, ye = -1;
-                for (uint32_t k = c0; k < c1; ++k) {
-                    uint32_t c = R.cigar[k]; int op = c & 0xf; long long l = c >> 4;
-                    if (cg_is_mop(op)) { if (yb < 0) yb = y; if (xb < 0) xb = x; ye = y + l; xe = x + l; x += l; y += l; }
-                    else if (op == CG_S || op == CG_I) y += l;
-                    else if (op == CG_D) x += l;
-                }
-                long long d = (xe - xb) - (ye - yb); if (d < 0) d = -d;
-                int bw = d > 7 ? (int)d + 3 : 7;
-                int dl = (int)((xe - xb + (lq - (ye - yb)) + bw) - lq); if (dl < 0) dl = -dl;   // |l_ref - l_query| upper bound
-                if (dl > bw) bw = dl;
+                BaqGeo g = baq_geometry(R.cigar + c0, (int)(c1 - c0), apos, lq, W.ref, W.ref_len);
+                int bw = g.bw;
                 atomicMax(&ctr->max_lq, (unsigned long long)lq);
                 atomicMax(&ctr->max_bw, (unsigned long long)bw);
                 atomicAdd(&ctr->n_baq, 1ull);

@@ -463,7 +463,10 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
-    int64_t nb = (ncols + 255) / 256;
     uint32_t slice = (lds_cap + 16 + 15) & ~15u;
-    hipLaunchKernelGGL(k_mplp_emit, dim3((unsigned)nb), dim3(256), 4 * slice, s, w, make_par(p, w.tlen), offs, out, lds_cap);
+    // waves per workgroup so that the workgroup's LDS (one slice per wave) stays within 64 KiB
+    int wpb = 4 * slice <= 65536 ? 4 : (2 * slice <= 65536 ? 2 : 1);
+    int64_t nwaves = (ncols + 63) / 64;
+    int64_t nb = (nwaves + wpb - 1) / wpb;
+    hipLaunchKernelGGL(k_mplp_emit, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, make_par(p, w.tlen), offs, out, lds_cap);
 }

@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- Mbases piled / s of the MI355X mpileup/depth engine (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one window of synthetic, position-sorted reads that is
+already resident in HBM: read filters -> quality prep -> BAQ -> overlap -> per-column measure ->
+scan -> pileup text, all through the C-ABI (include/samtools_amd.h).  At N > 1 every rank owns a
+different window (reference positions shard into independent windows: weak scaling) and the
+per-window text is gathered on rank 0 with one RCCL gather inside the timed step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mpileup30|mpileup30_B|mpileup300|depth30]
+
+Launched by the driver for N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+Prints ONE JSON line on rank 0.  The CPU oracle appears only in the cpu_baseline leg (rank 0, N=1).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+WORKLOADS = {
+    # name: (kind, depth, default window columns, algorithmic bytes per piled base, cli args)
+    "mpileup30": ("mpileup", 30, 4 << 20, 4.3, ["mpileup", "-f", "{fa}", "{sam}"]),
+    "mpileup30_B": ("mpileup", 30, 4 << 20, 4.3, ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
+    "mpileup300": ("mpileup", 300, 1 << 19, 3.75, ["mpileup", "-f", "{fa}", "{sam}"]),
+    "depth30": ("depth", 30, 8 << 20, 0.21, ["depth", "-a", "{sam}"]),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="mpileup30", choices=sorted(WORKLOADS))
+    ap.add_argument("--cols", type=int, default=0, help="window columns per GPU per step (0 = workload default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cols", type=int, default=0)
+    return ap.parse_args()
+
+
+def build_window(torch, np, sa, rd, ref_t, n_cols, dev):
+    """numpy SoA -> device tensors -> sta_window (STA_MEM_DEVICE)."""
+    keep = {}
+    def up(name):
+        arr = rd[name]
+        if arr.dtype == np.uint32: arr = arr.view(np.int32)
+        elif arr.dtype == np.uint16: arr = arr.view(np.int16)
+        elif arr.dtype == np.uint64: arr = arr.view(np.int64)
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+        keep[name] = t
+        return t.data_ptr()
+    reads = sa.Reads()
+    reads.n_reads = rd["n"]
+    for f in ("pos", "flag", "mapq", "aux", "l_qseq", "cig_off", "base_off8", "mtid", "mpos", "isize", "name_off",
+              "cigar", "seq", "qual", "names"):
+        setattr(reads, f, up(f))
+    reads.bq = None
+    reads.n_cigar_total = len(rd["cigar"])
+    reads.n_bases_total = len(rd["qual"])
+    reads.n_name_bytes = len(rd["names"])
+    files = (sa.Reads * 1)(reads)
+    w = sa.Window()
+    w.tid = 0; w.origin = 0; w.col_beg = 0; w.col_end = n_cols
+    w.tname = b"chrS"; w.tlen = n_cols
+    w.n_files = 1; w.files = files; w.mem = 1
+    w.has_bed = 0; w.has_reg = 0
+    keep["files"] = files
+    in_bytes = sum(int(rd[f].nbytes) for f in ("pos", "flag", "mapq", "aux", "l_qseq", "cig_off", "base_off8", "mtid",
+                                                 "mpos", "isize", "name_off", "cigar", "seq", "qual")) + n_cols
+    return w, keep, in_bytes
+
+
+def cpu_baseline(wl, sample_cols):
+    """Oracle (plain-C restatement, kind='port') timed single-threaded on a bounded sample of the same workload."""
+    from synth import synth_ref, synth_reads, write_sam, write_fasta
+    kind, depth, _, _, argv = WORKLOADS[wl]
+    oracle = os.path.join(REPO, "oracle", "_build", "oracle_samtools")
+    if not os.path.exists(oracle):
+        return None
+    ref = synth_ref(sample_cols, seed=1)
+    rd = synth_reads(ref, depth=depth, read_len=150, seed=42)
+    with tempfile.TemporaryDirectory() as tmp:
+        sam, fa = os.path.join(tmp, "s.sam"), os.path.join(tmp, "s.fa")
+        write_sam(sam, rd, "chrS", sample_cols)
+        write_fasta(fa, "chrS", ref)
+        args = [a.format(sam=sam, fa=fa) for a in argv]
+        t0 = time.perf_counter()
+        with open(os.devnull, "wb") as dn:
+            subprocess.run([oracle] + args, stdout=dn, stderr=dn, check=True)
+        dt = time.perf_counter() - t0
+    bases = int(rd["n"]) * 150
+    return {"value": bases / dt / 1e6, "unit": "Mbases/s", "cores": 1, "kind": "port",
+            "sample": "%s on %d synthetic reads (%d Mbases, %d columns, SAM text input, output to /dev/null), %.1f s wall, "
+                      "oracle restatement (not the upstream binary: HTSlib is absent)" % (
+                          " ".join(argv[:-1]).replace("{fa}", "ref.fa"), rd["n"], bases // 1000000, sample_cols, dt)}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import samtools_amd as sa
+    from synth import synth_ref, synth_reads
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    kind, depth, def_cols, alg_bytes_per_base, _ = WORKLOADS[a.workload]
+    n_cols = a.cols or def_cols
+    # every rank generates its own window (different seed): reference windows are independent shards
+    ref = synth_ref(n_cols, seed=1 + rank)
+    rd = synth_reads(ref, depth=depth, read_len=150, seed=42 + rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = sa.Engine(local, stream)
+    ref_t = torch.from_numpy(ref.copy()).to(dev)
+    eng.set_reference(0, ref_t.data_ptr(), n_cols, 1)
+    w, keep, in_bytes = build_window(torch, np, sa, rd, ref_t, n_cols, dev)
+    if kind == "mpileup":
+        par = sa.MplpParams.defaults()
+        par.has_fai = 1
+        if a.workload.endswith("_B"):
+            par.flag &= ~sa.MPLP.REALN
+    else:
+        par = sa.DepthParams.defaults()
+        par.all_pos = 1
+
+    def plan():
+        eng.stage_window(w)
+        return eng.mpileup_plan(par) if kind == "mpileup" else eng.depth_plan(par)
+
+    info = plan()
+    out_bytes = int(info.out_bytes)
+    piled = int(info.piled_bases)
+    cap = out_bytes + 4096
+    out_t = torch.empty(cap, dtype=torch.uint8, device=dev)
+    gather_list = None
+    if dist is not None:
+        caps = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(caps, torch.tensor([cap], dtype=torch.int64, device=dev))
+        cap = int(max(int(c.item()) for c in caps))
+        out_t = torch.empty(cap, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            gather_list = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+
+    def step():
+        plan()
+        if kind == "mpileup":
+            eng.mpileup_emit(out_t.data_ptr(), cap)
+        else:
+            eng.depth_emit(out_t.data_ptr(), cap)
+        if dist is not None:
+            # the single collective of the path: per-window column text -> rank 0 over RCCL/xGMI
+            dist.gather(out_t, gather_list, dst=0)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    eng.profile(True)
+    eng.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_get()
+    eng.profile(False)
+
+    tt = torch.tensor([dt, float(piled)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_all, piled_all = float(tmax[0].item()), float(tsum[1].item())
+    else:
+        dt_all, piled_all = dt, float(piled)
+
+    if rank == 0:
+        # correctness spot check of what was just timed: line count and final newline
+        head = bytes(out_t[:min(out_bytes, 1 << 16)].cpu().numpy().tobytes())
+        assert out_bytes == 0 or head.count(b"\n") > 0
+        value = piled_all * a.steps / dt_all / 1e6
+        # dominant kernel by accumulated HIP-event time (rank 0)
+        dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, 0.0))
+        dom_name, (dom_launches, dom_ms) = dom
+        launches_per_step = max(1, dom_launches // max(1, a.steps))
+        avg_ms = dom_ms / max(1, dom_launches)
+        alg_bytes_per_launch = alg_bytes_per_base * piled / launches_per_step
+        achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        res = {
+            "metric": "Mbases piled/s (mpileup, 30x 150bp)" if a.workload.startswith("mpileup30") else "Mbases piled/s (%s)" % a.workload,
+            "value": value, "unit": "Mbases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt_all / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/f64" if (kind == "mpileup" and not a.workload.endswith("_B")) else "u8",
+            "data": "synthetic",
+            "config": {"workload": a.workload, "command": " ".join(WORKLOADS[a.workload][4][:-1]).replace("{fa}", "ref.fa"),
+                       "read_len": 150, "depth": depth, "window_cols_per_gpu": n_cols, "reads_per_gpu": int(rd["n"]),
+                       "piled_bases_per_gpu_step": piled, "out_bytes_per_gpu_step": out_bytes,
+                       "staged_in_bytes_per_gpu": in_bytes, "parallelism": "window-sharded x%d, 1 RCCL gather" % world},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_unit": alg_bytes_per_base, "units_per_launch": piled / launches_per_step,
+                         "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step},
+            "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            sample = a.cpu_sample_cols or (1000000 if kind == "mpileup" and not a.workload.endswith("_B") else 2000000)
+            if depth >= 300:
+                sample //= 10
+            cb = cpu_baseline(a.workload, sample)
+            if cb:
+                res["cpu_baseline"] = cb
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -136,3 +136,30 @@ __device__ __forceinline__ int64_t wave_upper_bound(const int32_t *a, int64_t n,
     }
     return lo;
 }
+
+
+// Block-wide reduction of N per-thread values followed by ONE global atomic per value and block
+// (sum for k < NSUM, max for the rest).  Keeps contended device atomics off the per-wave path: a
+// counter word sustains only ~90 atomics/us, so one atomic per wave (65k+ waves) costs milliseconds.
+template <int N, int NSUM>
+__device__ __forceinline__ void block_reduce_atomic(unsigned long long (&v)[N], unsigned long long *const (&dst)[N])
+{
+    __shared__ unsigned long long red_[16][N];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        unsigned long long x = v[k];
+        for (int o = 32; o; o >>= 1) {
+            unsigned long long y = __shfl_down(x, o);
+            x = k < NSUM ? x + y : (y > x ? y : x);
+        }
+        if (lane == 0) red_[wid][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        const int k = threadIdx.x;
+        unsigned long long x = red_[0][k];
+        for (int w = 1; w < nw; ++w) { unsigned long long y = red_[w][k]; x = k < NSUM ? x + y : (y > x ? y : x); }
+        if (x) { if (k < NSUM) atomicAdd(dst[k], x); else atomicMax(dst[k], x); }
+    }
+}

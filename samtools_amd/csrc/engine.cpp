@@ -58,7 +58,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch;
     StaWinDev wd{};
     // plan state
     int planned = 0;   // 1 mpileup, 2 depth
@@ -162,7 +162,7 @@ void sta_engine_destroy(sta_engine *e)
     hipStreamSynchronize(e->stream);
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
-    DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->offs, &e->scan_tmp, &e->counters, &e->table,
+    DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->offs, &e->scan_tmp, &e->counters, &e->table,
                       &e->out, &e->diff, &e->maxcnt_scratch, &e->baq_scratch };
     for (DevBuf *b : all) b->release();
     for (auto &p : e->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -233,7 +233,7 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
         if (b.end.ensure(n * 4 + 16) || b.maxend.ensure(n * 4 + 16) || b.info.ensure(n * 4 + 16) || b.clip.ensure(n * 4 + 16)
             || b.chain.ensure(n * 4 + 16))
             return fail(e, STA_ERR_HIP, "hipMalloc(workspace) failed");
-        d.end = (int32_t *)b.end.p; d.maxend = (int32_t *)b.maxend.p; d.info = (uint32_t *)b.info.p; d.clip = (int32_t *)b.clip.p;
+        d.end = (int32_t *)b.end.p; d.maxend = (int32_t *)b.maxend.p; d.info = (uint32_t *)b.info.p; d.clip = (int32_t *)b.clip.p; d.chain = (int32_t *)b.chain.p;
         d.qual = const_cast<uint8_t *>(d.qual_in);
     }
     // window constants
@@ -282,8 +282,8 @@ static int finish_plan(sta_engine *e, int64_t ncols, sta_plan_info *info)
         sta_launch_len_scan(e->stream, (const uint32_t *)e->line_len.p, (uint64_t *)e->offs.p, ncols, e->scan_tmp.p, e->scan_tmp.cap);
     }
     {
-        ProfScope ps(e, "wave_bytes_max");
-        sta_launch_wave_bytes_max(e->stream, (const uint64_t *)e->offs.p, ncols, (StaCounters *)e->counters.p);
+        ProfScope ps(e, "col_stats");
+        sta_launch_wave_bytes_max(e->stream, (const uint64_t *)e->offs.p, (const uint32_t *)e->line_len.p, ncols, (StaCounters *)e->counters.p);
     }
     uint64_t total = 0;
     HIPCHK(hipMemcpyAsync(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
@@ -337,19 +337,46 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
         sta_launch_prep_reads(s, e->wd, e->files_h.data(), nf, *p, ctr);
     }
     if (realn) {
-        for (int f = 0; f < nf; ++f) {
+        // geometry bounds of the reads that need BAQ (written by k_prep_reads; maxima over all files)
+        StaCounters c{};
+        HIPCHK(hipMemcpyAsync(&c, ctr, sizeof(c), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] n_baq=%llu (fast %llu, lq<=%llu) slow: max_lq=%llu max_bw=%llu kept=%llu\n", c.n_baq, c.n_baq_fast, c.max_lq_fast, c.max_lq, c.max_bw, c.n_kept);
+        if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] bw8=%llu general=%llu\n", c.n_baq_bw8, c.n_baq_general);
+        for (int f = 0; f < nf && c.n_baq; ++f) {
             StaReadsDev &d = e->files_h[(size_t)f];
             if (!d.n) continue;
-            // geometry bounds of the reads that need BAQ (written by k_prep_reads)
-            StaCounters c{};
-            HIPCHK(hipMemcpyAsync(&c, ctr, sizeof(c), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] file %d: n_baq=%llu max_lq=%llu max_bw=%llu kept=%llu\n", f, c.n_baq, c.max_lq, c.max_bw, c.n_kept);
-            if (!c.n_baq) break;
-            size_t need = sta_baq_scratch_bytes(d.n, (int)c.max_lq, (int)c.max_bw);
-            if (e->baq_scratch.ensure(need + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ scratch) failed");
-            ProfScope ps(e, "baq");
-            sta_launch_baq(s, d, e->wd, redo ? 1 : 0, e->baq_scratch.p, need, (int)c.max_lq, (int)c.max_bw);
+            int32_t n_list = 0;
+            if (c.n_baq > c.n_baq_fast) {
+                HIPCHK(hipMemcpyAsync(&n_list, d.chain, 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+            }
+            if (c.n_baq_fast || c.n_baq_bw8) {
+                // band-in-registers kernels: groups of 64 reads, one scratch slot (forward rows) per group in flight
+                int gpl = 0;
+                size_t need = sta_baq_band_scratch_bytes(d.n, (int)c.max_lq_fast, &gpl);
+                if (e->baq_scratch.ensure(need + 64)) {
+                    // not enough free HBM for the one-launch slab: fall back to a 4 GiB slab (more, smaller launches)
+                    (void)hipGetLastError();
+                    setenv("STA_BAQ_SLAB_GIB", "4", 1);
+                    need = sta_baq_band_scratch_bytes(d.n, (int)c.max_lq_fast, &gpl);
+                    if (e->baq_scratch.ensure(need + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ scratch) failed");
+                }
+                if (c.n_baq_fast) {
+                    ProfScope ps(e, "baq");
+                    sta_launch_baq_band(s, d, e->wd, e->baq_scratch.p, (int)c.max_lq_fast, gpl, 7, d.n, 0);
+                }
+                if (c.n_baq_bw8 && n_list) {
+                    ProfScope ps(e, "baq_bw8");
+                    sta_launch_baq_band(s, d, e->wd, e->baq_scratch.p, (int)c.max_lq_fast, gpl, 8, n_list, 1);
+                }
+            }
+            if (c.n_baq_general && n_list) {
+                size_t need = sta_baq_scratch_bytes(d.n, (int)c.max_lq, (int)c.max_bw);
+                if (e->baq_scratch.ensure(need + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ scratch) failed");
+                ProfScope ps(e, "baq_general");
+                sta_launch_baq(s, d, e->wd, redo ? 1 : 0, e->baq_scratch.p, need, (int)c.max_lq, (int)c.max_bw, n_list);
+            }
         }
     }
     if (do_maxcnt) {
@@ -389,8 +416,10 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
         }
     }
     {
+        int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
+        if (e->colinfo.ensure((size_t)(ncols > 0 ? ncols : 1) * (size_t)(nf > 0 ? nf : 1) * 8 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(column info) failed");
         ProfScope ps(e, "mplp_len");
-        sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, ctr);
+        sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr);
     }
     return STA_OK;
 }
@@ -456,7 +485,7 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     if (rc) return rc;
     if (e->out_bytes == 0) return STA_OK;
     ProfScope ps(e, "mplp_emit");
-    sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, out, e->lds_cap);
+    sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap);
     return STA_OK;
 }
 

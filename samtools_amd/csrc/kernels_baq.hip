@@ -12,6 +12,7 @@
 // keeps only two rolling rows.  Reads are processed in chunks sized to the scratch budget.
 #include "dev_util.h"
 #include <math.h>
+#include <cstdlib>
 
 #define EI .25
 #define EM .33333333333
@@ -35,9 +36,9 @@ __global__ void __launch_bounds__(64) k_baq(StaReadsDev R, StaWinDev W, BaqTable
     int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
     int lane = threadIdx.x;
     if (t >= count) return;
-    int64_t r = first + t;
+    int64_t r = R.chain[1 + first + t];        // compact list of the reads the band-7 kernel does not take
     uint32_t info = R.info[r];
-    if (!(info & RI_BAQ)) return;
+    if (!(info & RI_BAQ_SLOW) || ((info >> RI_BAQ_BW_SHIFT) & 31) != 0) return;   // band-8 reads share the list but have their own kernel
 
     const uint32_t *cigar = R.cigar + R.cig_off[r];
     int n_cigar = (int)(R.cig_off[r + 1] - R.cig_off[r]);
@@ -261,13 +262,13 @@ static BaqTables g_tables;
 static bool g_tables_init = false;
 
 void sta_launch_baq(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int redo, void *scratch, size_t scratch_bytes,
-                         int lq_max, int bw_max)
+                         int lq_max, int bw_max, int64_t n_slow)
 {
     if (!g_tables_init) {
         for (int i = 0; i < 256; ++i) g_tables.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
         g_tables_init = true;
     }
-    if (r.n == 0 || lq_max <= 0) return;
+    if (r.n == 0 || lq_max <= 0 || n_slow <= 0) return;
     int idim_max = (bw_max * 2 + 1) * 3 + 6;
     size_t dbl_per_read = (size_t)(lq_max + 1) * idim_max + (size_t)2 * idim_max + (size_t)(lq_max + 2);
     size_t bytes_per_read = dbl_per_read * 8 + (size_t)lq_max * 5;
@@ -278,10 +279,382 @@ void sta_launch_baq(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int
     double *dscr = (double *)scratch;
     int32_t *state_s = (int32_t *)(dscr + chunk * dbl_per_read);
     uint8_t *q_s = (uint8_t *)(state_s + chunk * (size_t)lq_max);
-    for (int64_t first = 0; first < r.n; first += (int64_t)chunk) {
-        int64_t count = r.n - first < (int64_t)chunk ? r.n - first : (int64_t)chunk;
+    for (int64_t first = 0; first < n_slow; first += (int64_t)chunk) {
+        int64_t count = n_slow - first < (int64_t)chunk ? n_slow - first : (int64_t)chunk;
         unsigned nb = (unsigned)((count + 63) / 64);
         hipLaunchKernelGGL(k_baq, dim3(nb), dim3(64), 0, s, r, w, g_tables, redo, first, count, dscr, dbl_per_read, idim_max, lq_max,
                            state_s, q_s);
     }
+}
+
+// ================================================================================================
+// Band-in-registers kernels: the common case.  realn.c picks bw = 7 unless the alignment's net
+// indel is large, and probaln_glocal widens it to |l_ref - l_query| (8 for reads with a 2-3 bp
+// deletion), so BW = 7 and BW = 8 cover nearly every read; the rest go to k_baq above.
+// One lane per read as above, but the band lives in registers in diagonal-relative coordinates
+//     j = k - i + BW   (k = 1-based reference index, i = query row, 0 <= j < NB = 2*BW+1)
+//     (i-1,k-1) -> j      (i-1,k) -> j+1      (i,k-1) -> j-1
+// so every row update is a fully unrolled, statically indexed sweep over NB x {M,I,D} doubles and
+// the only bulk memory traffic is ONE coalesced store (forward kernel) and ONE coalesced load
+// (backward kernel) per (row, M/I cell): 2*NB doubles per row per read, laid out
+// [row][cell][lane] inside the wave's scratch slot (512 B per wave access).  The backward kernel
+// keeps its row in registers too (the backward D state is only a running scalar).  Cells outside
+// 1 <= k <= l_ref are held at exactly 0.0 (the reference never touches them: calloc), which keeps
+// every sum bit-identical because x + 0.0 == x for the non-negative values involved.
+// Per-row inputs (quality, query base, new reference base) are fetched two rows ahead and
+// converted (LDS tables) one row ahead, so no row waits on memory.
+// Arithmetic order is the reference's; the file is built with -ffp-contract=off.
+
+__device__ __forceinline__ double emis_sel(int rc, int qyc, double ematch, double e_lo)
+{
+    // rc: reference code 0..3, 4 = ambiguous, 7 = outside the reference window
+    double e = (rc == qyc) ? ematch : e_lo;
+    double hi = (rc == 7) ? 0. : 1.;
+    return rc > 3 ? hi : e;
+}
+#define FLD(w, j) ((int)((uint32_t)((w) >> (3 * (j))) & 7u))
+
+struct BaqRd {           // what both kernels need to know about one read
+    const uint32_t *cigar; int n_cigar, lq, l_ref;
+    uint8_t *qual; const uint8_t *seq; const char *ref;
+    long long rpos, xb;
+};
+__device__ __forceinline__ BaqRd baq_rd(const StaReadsDev &R, const StaWinDev &W, int64_t r)
+{
+    BaqRd d;
+    d.cigar = R.cigar + R.cig_off[r];
+    d.n_cigar = (int)(R.cig_off[r + 1] - R.cig_off[r]);
+    d.lq = R.l_qseq[r];
+    uint64_t boff = (uint64_t)R.base_off8[r] << 3;
+    d.qual = R.qual + boff;
+    d.seq = R.seq + (boff >> 1);
+    d.rpos = W.origin + R.pos[r];
+    BaqGeo g = baq_geometry(d.cigar, d.n_cigar, d.rpos, d.lq, W.ref, W.ref_len);
+    d.xb = g.xb; d.l_ref = g.l_ref;
+    d.ref = W.ref + g.xb;
+    return d;
+}
+struct BaqPar { double m0, m1, m2, m3, m4, m6, m8, sM, sI, bM, bI, eim1, eim4; };
+__device__ __forceinline__ BaqPar baq_par(int lq, int l_ref)
+{
+    BaqPar p;
+    const float cd = 0.001f, ce = 0.1f;     // probaln_par_t { float d, e; int bw; }
+    p.sM = p.sI = 1. / (2 * lq + 2);
+    p.m0 = (1 - cd - cd) * (1 - p.sM); p.m1 = p.m2 = cd * (1 - p.sM);
+    p.m3 = (1 - ce) * (1 - p.sI); p.m4 = ce * (1 - p.sI);
+    p.m6 = 1 - ce; p.m8 = ce;
+    p.bM = (1 - cd) / l_ref; p.bI = cd / l_ref;
+    p.eim1 = EI * p.m1; p.eim4 = EI * p.m4;
+    return p;
+}
+
+#define RCODE(idx) (((idx) >= 0 && (idx) < l_ref) ? (int)refc[(unsigned char)ref[(idx)]] : 7)
+#define RRAW(idx) (((idx) >= 0 && (idx) < l_ref) ? (int)(unsigned char)ref[(idx)] : 256)
+#define RCONV(raw) ((raw) < 256 ? (int)refc[(raw)] : 7)
+#define SEQB(i0) ((int)seq[(i0) >> 1])
+#define QCONV(sb, i0) nt16_int_dev(((sb) >> ((~(i0) & 1) << 2)) & 0xf)
+
+// which lane handles which read: direct (group of 64 consecutive reads) or through the list in `chain`
+__device__ __forceinline__ int64_t baq_pick(const StaReadsDev &R, int64_t g, int lane, int use_list, int bw)
+{
+    int64_t r;
+    if (use_list) {
+        int64_t t = g * 64 + lane;
+        if (t >= R.chain[0]) return -1;
+        r = R.chain[1 + t];
+    } else {
+        r = g * 64 + lane;
+        if (r >= R.n) return -1;
+    }
+    uint32_t info = R.info[r];
+    if (!(info & RI_BAQ) || (int)((info >> RI_BAQ_BW_SHIFT) & 31) != bw) return -1;
+    if (((info & RI_BAQ_SLOW) != 0) != (use_list != 0)) return -1;
+    return r;
+}
+
+template <int BW>
+__global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
+                                                 double *scratch, size_t slot_dbl, int lq_cap)
+{
+    constexpr int NB = 2 * BW + 1;
+    __shared__ float q2p[256];
+    __shared__ uint8_t refc[256];
+    q2p[threadIdx.x] = T.q2p[threadIdx.x];
+    refc[threadIdx.x] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)threadIdx.x));
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t gl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // group within this launch == scratch slot
+    if (gl >= ngroups) return;
+    const int64_t r = baq_pick(R, g0 + gl, lane, use_list, BW);
+    if (r < 0) return;
+    double *slot = scratch + (size_t)gl * slot_dbl;
+    double *F = slot + lane;
+    double *S = slot + (size_t)lq_cap * (2 * NB) * 64 + lane;
+#define Frow(i, c) F[((size_t)((i) - 1) * (2 * NB) + (c)) * 64]
+    const BaqRd d = baq_rd(R, W, r);
+    const int lq = d.lq, l_ref = d.l_ref;
+    const uint8_t *qual = d.qual, *seq = d.seq; const char *ref = d.ref;
+    const BaqPar p = baq_par(lq, l_ref);
+
+    double M[NB], I[NB], D[NB];
+    uint64_t rw = 0;                 // 3-bit field j = code of reference index (i - BW - 1 + j) for the current row i
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rw |= (uint64_t)RCODE(j - BW) << (3 * j);
+
+    S[0] = 1.;
+    {   // row 1: k = j - BW + 1
+        int qy = QCONV(SEQB(0), 0);
+        double q0 = q2p[qual[0]];
+        double ematch = 1. - q0, e_lo = qy > 3 ? 1. : q0 * EM;
+        int qyc = qy > 3 ? 9 : qy;
+        double sum = 0.;
+        const double eibi = EI * p.bI;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int rc = FLD(rw, j);
+            double e = emis_sel(rc, qyc, ematch, e_lo);
+            double a = e * p.bM;
+            double b2 = rc == 7 ? 0. : eibi;
+            M[j] = a; I[j] = b2; D[j] = 0.;
+            sum += a + b2;
+        }
+        S[64] = sum;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { M[j] /= sum; I[j] /= sum; }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { Frow(1, 2 * j) = M[j]; Frow(1, 2 * j + 1) = I[j]; }
+    }
+    // software pipeline of the per-row inputs: raw bytes two rows ahead, converted one row ahead
+    int c_sb = 0, c_rc = 7;                   // converted, for the next row
+    float c_qf = 0.f;
+    int r_q = 0, r_sb = 0, r_rr = 256;        // raw, for the row after
+    if (lq >= 2) { c_qf = q2p[qual[1]]; c_sb = SEQB(1); c_rc = RCODE(2 + BW - 1); }
+    if (lq >= 3) { r_q = qual[2]; r_sb = SEQB(2); r_rr = RRAW(3 + BW - 1); }
+#pragma unroll 1
+    for (int i = 2; i <= lq; ++i) {
+        const float qf = c_qf; const int sb = c_sb; const int nrc = c_rc;
+        // convert what was fetched during the previous row, fetch for row i+2
+        c_qf = q2p[r_q]; c_sb = r_sb; c_rc = RCONV(r_rr);
+        if (i + 2 <= lq) { r_q = qual[i + 1]; r_sb = SEQB(i + 1); r_rr = RRAW(i + 2 + BW - 1); }
+        rw = (rw >> 3) | ((uint64_t)nrc << (3 * (NB - 1)));
+        const int qy = QCONV(sb, i - 1);
+        const double qli = qf;
+        const double ematch = 1. - qli, e_lo = qy > 3 ? 1. : qli * EM;
+        const int qyc = qy > 3 ? 9 : qy;
+        double sum = 0., pm = 0., pd = 0.;    // pm, pd: this row's M and D at j-1
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int rc = FLD(rw, j);
+            double e = emis_sel(rc, qyc, ematch, e_lo);
+            double fm = e * (p.m0 * M[j] + p.m3 * I[j] + p.m6 * D[j]);
+            double fi = (j + 1 < NB) ? EI * (p.m1 * M[j + 1] + p.m4 * I[j + 1]) : 0.;
+            double fd = p.m2 * pm + p.m8 * pd;
+            fd = rc == 7 ? 0. : fd;
+            M[j] = fm; I[j] = fi; D[j] = fd;
+            sum += fm + fi + fd;
+            pm = fm; pd = fd;
+        }
+        S[(size_t)i * 64] = sum;
+        double inv = 1. / sum;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { M[j] *= inv; I[j] *= inv; D[j] *= inv; }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { Frow(i, 2 * j) = M[j]; Frow(i, 2 * j + 1) = I[j]; }
+    }
+    {   // s[l_query+1]
+        double sum = 0.;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) sum += M[j] * p.sM + I[j] * p.sI;
+        S[(size_t)(lq + 1) * 64] = sum;
+    }
+#undef Frow
+}
+
+template <int BW>
+__global__ void __launch_bounds__(256) k_baq_bwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
+                                                 double *scratch, size_t slot_dbl, int lq_cap)
+{
+    constexpr int NB = 2 * BW + 1;
+    __shared__ float q2p[256];
+    __shared__ uint8_t refc[256];
+    q2p[threadIdx.x] = T.q2p[threadIdx.x];
+    refc[threadIdx.x] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)threadIdx.x));
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t gl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gl >= ngroups) return;
+    const int64_t r = baq_pick(R, g0 + gl, lane, use_list, BW);
+    if (r < 0) return;
+    double *slot = scratch + (size_t)gl * slot_dbl;
+    const double *F = slot + lane;
+    const double *S = slot + (size_t)lq_cap * (2 * NB) * 64 + lane;
+    int32_t *P = reinterpret_cast<int32_t *>(slot + (size_t)lq_cap * (2 * NB) * 64 + (size_t)(lq_cap + 2) * 64) + lane;
+#define Frow(i, c) F[((size_t)((i) - 1) * (2 * NB) + (c)) * 64]
+    const BaqRd d = baq_rd(R, W, r);
+    const int lq = d.lq, l_ref = d.l_ref;
+    uint8_t *qual = d.qual; const uint8_t *seq = d.seq; const char *ref = d.ref;
+    const BaqPar p = baq_par(lq, l_ref);
+
+    // row lq: field j = code(lq - BW - 1 + j); it doubles as the backward word of row lq-1
+    uint64_t rw = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rw |= (uint64_t)RCODE(lq - BW - 1 + j) << (3 * j);
+    double bMr[NB], bIr[NB];
+    {
+        double sl = S[(size_t)lq * 64], sl1 = S[(size_t)(lq + 1) * 64];
+        double vM = p.sM / sl / sl1, vI = p.sI / sl / sl1;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            bool valid = FLD(rw, j) != 7;             // row lq: 1 <= k <= l_ref
+            bMr[j] = valid ? vM : 0.; bIr[j] = valid ? vI : 0.;
+        }
+    }
+    // pipeline: row i needs qual[i], seq(i), S[i], code(i - BW) (all for i < lq)
+    float c_qf = 0.f; int c_sb = 0, c_rc = 7; double c_s = 1.;
+    int r_q = 0, r_sb = 0, r_rr = 256; double r_s = 1.;
+    if (lq >= 2) { int i = lq - 1; c_qf = q2p[qual[i]]; c_sb = SEQB(i); c_s = S[(size_t)i * 64]; }
+    if (lq >= 3) { int i = lq - 2; r_q = qual[i]; r_sb = SEQB(i); r_s = S[(size_t)i * 64]; r_rr = RRAW(i - BW); }
+#pragma unroll 1
+    for (int i = lq; i >= 1; --i) {
+        // forward row i for the MAP step: issued first so the loads fly during the row update
+        double fM[NB], fI[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { fM[j] = Frow(i, 2 * j); fI[j] = Frow(i, 2 * j + 1); }
+        if (i < lq) {
+            const float qf = c_qf; const int sb = c_sb; const int nrc = c_rc; const double si = c_s;
+            c_qf = q2p[r_q]; c_sb = r_sb; c_rc = RCONV(r_rr); c_s = r_s;
+            if (i - 2 >= 1) { int i2 = i - 2; r_q = qual[i2]; r_sb = SEQB(i2); r_s = S[(size_t)i2 * 64]; r_rr = RRAW(i2 - BW); }
+            if (i < lq - 1) rw = (rw << 3) | (uint64_t)nrc;
+            const int qy = QCONV(sb, i);
+            const double qli1 = qf;
+            const double ematch = 1. - qli1, e_lo = qy > 3 ? 1. : qli1 * EM;
+            const int qyc = qy > 3 ? 9 : qy;
+            const double yv = i > 1 ? 1. : 0.;
+            double dnext = 0.;
+#pragma unroll
+            for (int j = NB - 1; j >= 0; --j) {
+                int rc = FLD(rw, j);
+                double e = emis_sel(rc, qyc, ematch, e_lo) * bMr[j];     // rc == 7 <=> k >= l_ref: e = 0 * b
+                double bi1 = j > 0 ? bIr[j - 1] : 0.;
+                double bm = e * p.m0 + p.eim1 * bi1 + p.m2 * dnext;
+                double bi_ = e * p.m3 + p.eim4 * bi1;
+                double bd = (e * p.m6 + p.m8 * dnext) * yv;
+                bMr[j] = bm; bIr[j] = bi_;
+                dnext = bd;
+            }
+            double ys = 1. / si;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { bMr[j] *= ys; bIr[j] *= ys; }
+            if (i <= BW) {            // cells with k < 1 do not exist in the reference: keep them at zero
+#pragma unroll
+                for (int j = 0; j < BW; ++j) if (j < BW + 1 - i) { bMr[j] = 0.; bIr[j] = 0.; }
+            }
+        }
+        // MAP for row i
+        double sum = 0., max = 0.;
+        int max_k = -1;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double z;
+            z = fM[j] * bMr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 0; } sum += z;
+            z = fI[j] * bIr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 1; } sum += z;
+        }
+        max /= sum;
+        double v = -4.343 * log(1. - max) + .499;
+        int kq = (v >= 2147483648.0 || v < -2147483648.0 || v != v) ? INT32_MIN : (int)v;
+        P[(size_t)(i - 1) * 64] = (int32_t)(((uint32_t)max_k << 8) | (uint32_t)(uint8_t)(kq > 100 ? 99 : kq));
+    }
+
+    /*** realn.c, extended BAQ: bq = min(running max from the left, from the right) inside each M block; apply ***/
+    {
+        long long xx = d.rpos; int yy = 0;
+        for (int c = 0; c < d.n_cigar; ++c) {
+            int op = d.cigar[c] & 0xf, l = (int)(d.cigar[c] >> 4);
+            if (cg_is_mop(op)) {
+                if (l > lq - yy) l = lq - yy;
+                if (l > 0) {
+                    int run = 0;
+                    for (int i = yy; i < yy + l; ++i) {
+                        int32_t pk = P[(size_t)i * 64];
+                        int st = pk >> 8;
+                        int b = ((st & 3) != 0 || (long long)(st >> 2) != xx - d.xb + (i - yy)) ? 0 : (pk & 0xff);
+                        run = b > run ? b : run;
+                        P[(size_t)i * 64] = (b << 8) | run;        // raw bq, left running max
+                    }
+                    run = 0;
+                    for (int i = yy + l - 1; i >= yy; --i) {
+                        int32_t pk = P[(size_t)i * 64];
+                        int b = pk >> 8, left = pk & 0xff;
+                        run = b > run ? b : run;
+                        int bqv = left < run ? left : run;
+                        int q0 = qual[i];
+                        int tag = 64 + (q0 <= bqv ? 0 : q0 - bqv);
+                        qual[i] = (uint8_t)(q0 - (tag - 64));
+                    }
+                }
+                xx += l; yy += l;
+            } else if (op == CG_S || op == CG_I) {
+                if (l > lq - yy) l = lq - yy;
+                yy += l;
+            } else if (op == CG_D) xx += l;
+        }
+    }
+#undef Frow
+}
+
+static size_t baq_slot_dbl(int lq_cap, int bw)
+{
+    int nb = 2 * bw + 1;
+    return (size_t)lq_cap * (2 * nb) * 64 + (size_t)(lq_cap + 2) * 64 + (size_t)(lq_cap + 1) / 2 * 64;
+}
+
+size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_launch)
+{
+    int64_t ngroups = (n_reads + 63) / 64;
+    // One launch per pass over ALL groups when the slab fits (no partially filled last round of waves);
+    // 288 GB of HBM makes a tens-of-GiB slab affordable.  STA_BAQ_SLAB_GIB bounds it (default 48).
+    int64_t gpl = ngroups;
+    const char *ev = getenv("STA_BAQ_GROUPS");
+    if (ev && atoi(ev) > 0) gpl = atoi(ev);
+    size_t slab_gib = 48;
+    const char *es = getenv("STA_BAQ_SLAB_GIB");
+    if (es && atoi(es) > 0) slab_gib = (size_t)atoi(es);
+    size_t slot = baq_slot_dbl(lq_cap, 8) * 8;
+    if ((size_t)gpl * slot > (slab_gib << 30)) {
+        // split into equal chunks that are multiples of 6144 groups (LCM of the 3072 / 2048 resident waves of the two kernels)
+        int64_t fit = (int64_t)((slab_gib << 30) / slot);
+        int64_t nchunk = (gpl + fit - 1) / fit;
+        gpl = (ngroups + nchunk - 1) / nchunk;
+        if (gpl > 6144) gpl = (gpl + 6143) / 6144 * 6144;
+        while (gpl > 4 && (size_t)gpl * slot > (slab_gib << 30)) gpl -= gpl > 6144 ? 6144 : gpl / 2;
+    }
+    if (gpl > ngroups) gpl = ngroups;
+    if (gpl < 1) gpl = 1;
+    if (groups_per_launch) *groups_per_launch = (int)gpl;
+    return (size_t)gpl * slot;
+}
+
+template <int BW>
+static void run_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int gpl, int64_t n_items, int use_list)
+{
+    int64_t ngroups = (n_items + 63) / 64;
+    size_t slot = baq_slot_dbl(lq_cap, BW);
+    for (int64_t g0 = 0; g0 < ngroups; g0 += gpl) {
+        int64_t ng = ngroups - g0 < gpl ? ngroups - g0 : gpl;
+        unsigned nb = (unsigned)((ng + 3) / 4);
+        hipLaunchKernelGGL(k_baq_fwd<BW>, dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap);
+        hipLaunchKernelGGL(k_baq_bwd<BW>, dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap);
+    }
+}
+
+void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int gpl, int bw,
+                         int64_t n_items, int use_list)
+{
+    if (!g_tables_init) {
+        for (int i = 0; i < 256; ++i) g_tables.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
+        g_tables_init = true;
+    }
+    if (r.n == 0 || lq_cap <= 0 || gpl <= 0 || n_items <= 0) return;
+    if (bw == 7) run_band<7>(s, r, w, scratch, lq_cap, gpl, n_items, use_list);
+    else if (bw == 8) run_band<8>(s, r, w, scratch, lq_cap, gpl, n_items, use_list);
 }

@@ -8,16 +8,18 @@
 //                     elementwise pass over the quality pool, 16 B per lane.
 // scans             : three-phase block scans (reduce / scan of block sums / rescan), wave64 shuffles.
 #include "dev_util.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 struct PrepArgs {
-    int32_t min_mq, rflag_require, rflag_filter, flag, all;
+    int32_t min_mq, rflag_require, rflag_filter, flag, all, baq_force_slow;
 };
 
 __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, PrepArgs P, StaCounters *ctr)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long piled = 0; unsigned kept = 0;
+    unsigned long long c_baq = 0, c_fast = 0, c_bw8 = 0, c_gen = 0, m_lqf = 0, m_lq = 0, m_bw = 0;
     if (i < R.n) {
         int32_t pos = R.pos[i];
         uint32_t flag = R.flag[i];
@@ -50,7 +52,7 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
         else if ((P.flag & STA_MPLP_NO_ORPHAN) && (flag & BAM_FPAIRED) && !(flag & BAM_FPROPER_PAIR)) pushed = false;
 
         bool keep = pushed && rlen > 0;
-        bool simple = (c1 - c0 == 1) && cg_is_mop(R.cigar[c0] & 0xf);
+        bool simple = (c1 - c0 == 1) && cg_is_mop(R.cigar[c0] & 0xf) && lq == rlen;   // one M op covering the whole query
         uint32_t info = (pushed ? RI_PUSHED : 0) | (keep ? RI_KEEP : 0) | (simple ? RI_SIMPLE : 0)
                       | ((flag & BAM_FREVERSE) ? RI_REV : 0) | (mapq << RI_MAPQ_SHIFT);
         // overlap_push eligibility
@@ -66,12 +68,26 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
             bool redo = (P.flag & STA_MPLP_REDO_BAQ) != 0;
             bool q_absent = R.qual_in[(uint64_t)R.base_off8[i] << 3] == 0xff;
             if (!q_absent && !(aux & STA_AUX_HAS_ZQ) && (redo || !(aux & STA_AUX_HAS_BQ))) {
-                info |= RI_BAQ;
                 BaqGeo g = baq_geometry(R.cigar + c0, (int)(c1 - c0), apos, lq, W.ref, W.ref_len);
-                int bw = g.bw;
-                atomicMax(&ctr->max_lq, (unsigned long long)lq);
-                atomicMax(&ctr->max_bw, (unsigned long long)bw);
-                atomicAdd(&ctr->n_baq, 1ull);
+                if (g.ok) {         // !ok: probaln_glocal returns 0 and the qualities stay as they are
+                    info |= RI_BAQ;
+                    c_baq = 1;
+                    bool band = (g.bw == 7 || g.bw == 8) && lq <= STA_BAQ7_LQ_MAX && !P.baq_force_slow;
+                    if (band) {
+                        info |= (uint32_t)g.bw << RI_BAQ_BW_SHIFT;
+                        m_lqf = (unsigned long long)lq;
+                    } else {
+                        m_lq = (unsigned long long)lq;
+                        m_bw = (unsigned long long)g.bw;
+                    }
+                    if (band && g.bw == 7) c_fast = 1;
+                    else {
+                        if (band) c_bw8 = 1; else c_gen = 1;
+                        info |= RI_BAQ_SLOW;
+                        int slot = atomicAdd(&R.chain[0], 1);
+                        R.chain[1 + slot] = (int32_t)i;
+                    }
+                }
             }
             // both BQ and ZQ without redo: ZQ is dropped and BQ applied by k_qual_prep
         }
@@ -83,22 +99,22 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
             if (b > a) piled = (unsigned long long)(b - a);
         }
     }
-    // wave reduce then one atomic per wave
-    for (int o = 32; o; o >>= 1) { piled += __shfl_down(piled, o); kept += __shfl_down(kept, o); }
-    if ((threadIdx.x & 63) == 0) {
-        if (piled) atomicAdd(&ctr->piled_bases, piled);
-        if (kept) atomicAdd(&ctr->n_kept, (unsigned long long)kept);
-    }
+    // block reduce, then one atomic per counter and block
+    unsigned long long v[9] = { piled, kept, c_baq, c_fast, c_bw8, c_gen, m_lqf, m_lq, m_bw };
+    unsigned long long *const dst[9] = { &ctr->piled_bases, &ctr->n_kept, &ctr->n_baq, &ctr->n_baq_fast, &ctr->n_baq_bw8, &ctr->n_baq_general,
+                                         &ctr->max_lq_fast, &ctr->max_lq, &ctr->max_bw };
+    block_reduce_atomic<9, 6>(v, dst);
 }
 
 void sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
                            const sta_mplp_params &p, StaCounters *ctr)
 {
-    PrepArgs a{ p.min_mq, p.rflag_require, p.rflag_filter, p.flag, p.all };
+    PrepArgs a{ p.min_mq, p.rflag_require, p.rflag_filter, p.flag, p.all, getenv("STA_BAQ_FORCE_SLOW") ? 1 : 0 };
     for (int f = 0; f < nfiles; ++f) {
         const StaReadsDev &R = files_host[f];
         if (R.n == 0) continue;
         int64_t nb = (R.n + 255) / 256;
+        hipMemsetAsync(R.chain, 0, 4, s);
         hipLaunchKernelGGL(k_prep_reads, dim3((unsigned)nb), dim3(256), 0, s, R, w, a, ctr);
     }
 }
@@ -151,11 +167,9 @@ __global__ void __launch_bounds__(256) k_prep_reads_depth(StaReadsDev R, StaWinD
             if (b > a) piled = (unsigned long long)(b - a);
         }
     }
-    for (int o = 32; o; o >>= 1) { piled += __shfl_down(piled, o); kept += __shfl_down(kept, o); }
-    if ((threadIdx.x & 63) == 0) {
-        if (piled) atomicAdd(&ctr->piled_bases, piled);
-        if (kept) atomicAdd(&ctr->n_kept, (unsigned long long)kept);
-    }
+    unsigned long long v[2] = { piled, kept };
+    unsigned long long *const dst[2] = { &ctr->piled_bases, &ctr->n_kept };
+    block_reduce_atomic<2, 2>(v, dst);
 }
 
 void sta_launch_prep_reads_depth(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
@@ -248,7 +262,7 @@ template <class Op> __device__ typename Op::T block_scan_incl(typename Op::T v, 
 }
 
 // Loader functors turn input element i into Op::T
-struct LoadU32 { const uint32_t *p; __device__ unsigned long long operator()(int64_t i) const { return p[i]; } };
+struct LoadU32 { const uint32_t *p; __device__ unsigned long long operator()(int64_t i) const { return p[i] & 0x7fffffffu; } };   // bit 31 of a line length = "column has data"
 struct LoadI32 { const int32_t *p; __device__ int operator()(int64_t i) const { return p[i]; } };
 struct LoadKeptEnd { const int32_t *end; const uint32_t *info;
     __device__ int operator()(int64_t i) const { return (info[i] & RI_KEEP) ? end[i] : INT32_MIN; } };
@@ -369,23 +383,33 @@ void sta_launch_depth_scan(hipStream_t s, int32_t *diff, int nrows, int64_t ncol
     }
 }
 
-// max over waves (64 columns) of the output bytes a wave must stage -> sizes the emit kernels' LDS
-__global__ void __launch_bounds__(256) k_wave_bytes_max(const uint64_t *offs, int64_t ncols, StaCounters *ctr)
+// Column statistics after the scan: max over waves (64 columns) of the output bytes a wave must stage
+// (sizes the emit kernels' LDS), number of output rows, number of columns with data.  Grid-stride,
+// block-reduced: a few thousand atomics in total.
+__global__ void __launch_bounds__(256) k_col_stats(const uint64_t *offs, const uint32_t *line_len, int64_t ncols, StaCounters *ctr)
 {
-    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t nw = (ncols + 63) / 64;
-    unsigned long long b = 0;
-    if (w < nw) {
-        int64_t c0 = w * 64, c1 = c0 + 64 < ncols ? c0 + 64 : ncols;
-        b = offs[c1] - offs[c0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long lines = 0, data = 0, mx = 0;
+    for (int64_t c = tid; c < ncols; c += stride) {
+        uint32_t u = line_len[c];
+        lines += (u & 0x7fffffffu) != 0;
+        data += u >> 31;
     }
-    for (int o = 32; o; o >>= 1) { unsigned long long u = __shfl_down(b, o); b = u > b ? u : b; }
-    if ((threadIdx.x & 63) == 0 && b) atomicMax(&ctr->max_wave_bytes, b);
+    const int64_t nw = (ncols + 63) / 64;
+    for (int64_t w = tid; w < nw; w += stride) {
+        int64_t c0 = w * 64, c1 = c0 + 64 < ncols ? c0 + 64 : ncols;
+        unsigned long long b = offs[c1] - offs[c0];
+        mx = b > mx ? b : mx;
+    }
+    unsigned long long v[3] = { lines, data, mx };
+    unsigned long long *const dst[3] = { &ctr->n_lines, &ctr->n_data_cols, &ctr->max_wave_bytes };
+    block_reduce_atomic<3, 2>(v, dst);
 }
 
-void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, int64_t ncols, StaCounters *ctr)
+void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, const uint32_t *line_len, int64_t ncols, StaCounters *ctr)
 {
-    int64_t nw = (ncols + 63) / 64;
-    if (nw <= 0) return;
-    hipLaunchKernelGGL(k_wave_bytes_max, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, offs, ncols, ctr);
+    if (ncols <= 0) return;
+    int64_t nb = (ncols + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_col_stats, dim3((unsigned)nb), dim3(256), 0, s, offs, line_len, ncols, ctr);
 }

@@ -107,13 +107,9 @@ __global__ void __launch_bounds__(256) k_depth_len(StaWinDev W, DepthDevPar P, c
             for (int f = 0; f < W.nfiles; ++f)
                 len += 1 + (uint32_t)dec_digits_u32((uint32_t)counts[(int64_t)f * (ncols + 1) + c]);
         }
-        line_len[c] = len;
+        line_len[c] = len | (covered ? 0x80000000u : 0u);     // rows / covered columns are counted by k_col_stats
     }
-    unsigned long long mc = __ballot(covered), me = __ballot(ex);
-    if ((threadIdx.x & 63) == 0) {
-        if (mc) atomicAdd(&ctr->n_data_cols, (unsigned long long)__popcll(mc));
-        if (me) atomicAdd(&ctr->n_lines, (unsigned long long)__popcll(me));
-    }
+    (void)ctr;
 }
 
 void sta_launch_depth_len(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, const int32_t *counts,

@@ -354,12 +354,8 @@ __global__ void __launch_bounds__(256) k_mplp_len(StaWinDev W, MplpDevPar P, uin
     if (exists && W.has_bed) exists = bed_overlap_dev(W.bed_beg, W.bed_end, W.n_bed, apos, apos + 1);
     uint32_t len = 0;
     if (exists) len = (uint32_t)W.tname_len + 1 + (uint32_t)dec_digits((unsigned long long)(apos + 1)) + 1 + 1 + total + 1;
-    if (active) line_len[c0 + lane] = len;
-    unsigned long long mdata = __ballot(data), mex = __ballot(exists);
-    if (lane == 0) {
-        if (mdata) atomicAdd(&ctr->n_data_cols, (unsigned long long)__popcll(mdata));
-        if (mex) atomicAdd(&ctr->n_lines, (unsigned long long)__popcll(mex));
-    }
+    if (active) line_len[c0 + lane] = len | (data ? 0x80000000u : 0u);     // rows / data columns are counted by k_col_stats
+    (void)ctr;
 }
 
 template <bool LDS>
@@ -442,6 +438,234 @@ __global__ void __launch_bounds__(256) k_mplp_emit(StaWinDev W, MplpDevPar P, co
     }
 }
 
+
+// ================================================================================================
+// Fast column kernels (no --output-extra / -O / -s columns): same column-per-lane layout, but
+//  * read metadata is fetched 64 reads at a time with coalesced vector loads and broadcast with
+//    v_readlane, so the walk issues no dependent scalar loads;
+//  * only reads that can touch the wave's 64 columns are visited (ballot of a per-lane test);
+//  * four reads are in flight at once (their quality / base bytes are loaded before any is used);
+//  * the measuring pass stores (count, seq bytes) per column and file, so the emit pass walks the
+//    reads ONCE and writes the base string and the quality string at two cursors.
+// Non-simple reads (indels, clips, pads, ref skips) take the generic per-entry path inline.
+
+__device__ __forceinline__ int rl_i(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+__device__ __forceinline__ uint32_t rl_u(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
+
+// "=ACMGRSV" / "TWYHKDBN" with '.' in place of '=' (a base equal to the reference, or '=' in the read)
+__device__ __forceinline__ char base_char_fast(int c, bool rev)
+{
+    const unsigned long long lo = 0x565352474D43412EULL, hi = 0x4E42444B48595754ULL;
+    unsigned long long t = (c & 8) ? hi : lo;
+    int ch = (int)((t >> ((c & 7) << 3)) & 0xff);
+    if (rev) ch = c == 0 ? ',' : (ch | 0x20);
+    return (char)ch;
+}
+
+template <bool EMIT, bool LDS>
+__device__ __forceinline__ void fast_walk(const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int p0, int plast,
+                                          int p, bool active, int rbcode, int64_t rlo, int64_t rhi,
+                                          uint32_t &n_plp, uint32_t &cnt, uint32_t &seq_len, Sink<LDS> &ss, Sink<LDS> &sq)
+{
+    const int lane = threadIdx.x & 63;
+    const bool ends = !P.no_ends;
+    for (int64_t b0 = rlo; b0 < rhi; b0 += 64) {
+        const int64_t ri = b0 + lane;
+        const bool ok = ri < rhi;
+        const uint32_t v_info = ok ? R.info[ri] : 0u;
+        const int v_pos = ok ? R.pos[ri] : 0;
+        const int v_end = ok ? R.end[ri] : 0;
+        const uint32_t v_b8 = ok ? R.base_off8[ri] : 0u;
+        unsigned long long live = __ballot(ok && (v_info & RI_KEEP) && v_end > p0 && v_pos <= plast);
+        while (live) {
+            bool valid[4], cov[4];
+            uint32_t info[4], b8[4];
+            int rpos[4], rend[4], jx[4], qv[4], sv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                valid[k] = live != 0;
+                int j = valid[k] ? __ffsll((long long)live) - 1 : 0;
+                if (valid[k]) live &= live - 1;
+                jx[k] = j;
+                info[k] = rl_u(v_info, j); rpos[k] = rl_i(v_pos, j); rend[k] = rl_i(v_end, j); b8[k] = rl_u(v_b8, j);
+                cov[k] = valid[k] && active && p >= rpos[k] && p < rend[k];
+                qv[k] = 0; sv[k] = 0;
+                if (cov[k] && (info[k] & RI_SIMPLE)) {
+                    uint64_t boff = (uint64_t)b8[k] << 3;
+                    int qpos = p - rpos[k];
+                    qv[k] = R.qual[boff + (uint64_t)qpos];
+                    if (EMIT) sv[k] = R.seq[(boff >> 1) + (uint64_t)(qpos >> 1)];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!valid[k]) continue;
+                if (info[k] & RI_SIMPLE) {
+                    if (cov[k]) {
+                        if (!EMIT) n_plp++;
+                        if (qv[k] >= P.min_baseQ) {
+                            bool head = ends && p == rpos[k], tail = ends && p == rend[k] - 1;
+                            if (!EMIT) {
+                                cnt++;
+                                seq_len += 1u + (head ? 2u : 0u) + (tail ? 1u : 0u);
+                            } else {
+                                bool rev = (info[k] & RI_REV) != 0;
+                                if (head) {
+                                    int mq = (int)((info[k] >> RI_MAPQ_SHIFT) & 0xff);
+                                    ss.put('^'); ss.put((char)(mq > 93 ? 126 : mq + 33));
+                                }
+                                int qpos = p - rpos[k];
+                                int c = (sv[k] >> ((~qpos & 1) << 2)) & 0xf;
+                                if (c == rbcode) c = 0;
+                                ss.put(base_char_fast(c, rev));
+                                if (tail) ss.put('$');
+                                sq.put((char)(qv[k] + 33 < 126 ? qv[k] + 33 : 126));
+                            }
+                        }
+                    }
+                } else {
+                    // generic entry (uniform branch: the read is the same for every lane)
+                    if (__ballot(cov[k]) == 0) continue;
+                    if (cov[k]) {
+                        Entry e;
+                        e.r = b0 + jx[k]; e.rpos = rpos[k]; e.rend = rend[k]; e.info = info[k];
+                        e.lq = R.l_qseq[e.r];
+                        e.boff = (uint64_t)b8[k] << 3;
+                        e.rs = resolve_general(R.cigar + R.cig_off[e.r], (int)(R.cig_off[e.r + 1] - R.cig_off[e.r]), e.rpos, p);
+                        if (!EMIT) n_plp++;
+                        int c = e.rs.qpos < e.lq ? R.qual[e.boff + (uint64_t)e.rs.qpos] : 0;
+                        if (c >= P.min_baseQ) {
+                            if (!EMIT) { cnt++; seq_len += (uint32_t)token_len(R, P, e, p); }
+                            else {
+                                token_write<LDS>(R, W, P, e, p, ss);
+                                sq.put((char)(c + 33 < 126 ? c + 33 : 126));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mplp_len_fast(StaWinDev W, MplpDevPar P, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr)
+{
+    int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    int lane = threadIdx.x & 63;
+    int64_t ncols = (int64_t)W.col_end - W.col_beg;
+    int64_t c0 = (int64_t)wave * 64;
+    if (c0 >= ncols) return;
+    int p0 = W.col_beg + (int)c0;
+    int p = p0 + lane;
+    bool active = p < W.col_end;
+    int plast = p0 + 63 < W.col_end ? p0 + 63 : W.col_end - 1;
+    int64_t apos = W.origin + p;
+
+    uint32_t total = 0; bool any = false;
+    Sink<false> d1, d2; d1.g = d2.g = nullptr; d1.cur = d2.cur = 0;
+    for (int f = 0; f < W.nfiles; ++f) {
+        const StaReadsDev &R = W.files[f];
+        int64_t rlo, rhi;
+        wave_read_range(R, p0, plast, rlo, rhi);
+        uint32_t n_plp = 0, cnt = 0, seq_len = 0;
+        fast_walk<false, false>(R, W, P, p0, plast, p, active, -1, rlo, rhi, n_plp, cnt, seq_len, d1, d2);
+        any |= n_plp > 0;
+        total += 1 + (uint32_t)dec_digits_u32(cnt) + 1 + (seq_len ? seq_len : 1) + 1 + (cnt ? cnt : 1);
+        if (active) colinfo[(int64_t)f * ncols + c0 + lane] = make_uint2(cnt, seq_len);
+    }
+    bool in_reg = active && column_selected(W, apos);
+    bool data = in_reg && any;
+    bool exists = in_reg && (any || (P.all && apos < P.tlen));
+    if (exists && W.has_bed) exists = bed_overlap_dev(W.bed_beg, W.bed_end, W.n_bed, apos, apos + 1);
+    uint32_t len = 0;
+    if (exists) len = (uint32_t)W.tname_len + 1 + (uint32_t)dec_digits((unsigned long long)(apos + 1)) + 1 + 1 + total + 1;
+    if (active) line_len[c0 + lane] = len | (data ? 0x80000000u : 0u);     // rows / data columns are counted by k_col_stats
+    (void)ctr;
+}
+
+template <bool LDS>
+__device__ __forceinline__ void emit_column_fast(const StaWinDev &W, const MplpDevPar &P, const uint2 *colinfo, int64_t ncols, int64_t col,
+                                                 int p0, int plast, int p, bool exists, Sink<LDS> &s)
+{
+    int64_t apos = W.origin + p;
+    int rbcode = -1;
+    if (exists) {
+        for (int t = 0; t < W.tname_len; ++t) s.put(W.tname[t]);
+        s.put('\t');
+        s.put_dec(apos + 1);
+        s.put('\t');
+        char rc = (W.ref && apos < W.ref_len) ? W.ref[apos] : 'N';
+        s.put(rc);
+        if (W.ref) rbcode = apos < W.ref_len ? nt16_from_char((unsigned char)rc) : 15;
+    }
+    for (int f = 0; f < W.nfiles; ++f) {
+        const StaReadsDev &R = W.files[f];
+        int64_t rlo, rhi;
+        wave_read_range(R, p0, plast, rlo, rhi);
+        uint2 ci = exists ? colinfo[(int64_t)f * ncols + col] : make_uint2(0, 0);
+        uint32_t cnt = ci.x, seq_len = ci.y;
+        Sink<LDS> ss = s, sq = s;
+        if (exists) {
+            s.put('\t'); s.put_dec(cnt); s.put('\t');
+            ss = s;
+            uint32_t sl = seq_len ? seq_len : 1;
+            sq = s; sq.cur += sl + 1; sq.g += sl + 1;
+            if (!cnt) { ss.put('*'); sq.put('*'); ss = s; sq = s; sq.cur += sl + 1; sq.g += sl + 1; }
+            // the tab between the two strings
+            Sink<LDS> st = s; st.cur += sl; st.g += sl; st.put('\t');
+            s.cur += sl + 1 + (cnt ? cnt : 1); s.g += sl + 1 + (cnt ? cnt : 1);
+        }
+        uint32_t d0 = 0, d1 = 0, d2 = 0;
+        fast_walk<true, LDS>(R, W, P, p0, plast, p, exists && cnt, rbcode, rlo, rhi, d0, d1, d2, ss, sq);
+    }
+    if (exists) s.put('\n');
+}
+
+__global__ void __launch_bounds__(256) k_mplp_emit_fast(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
+                                                        char *out, uint32_t lds_cap)
+{
+    int wid = threadIdx.x >> 6;
+    int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    int lane = threadIdx.x & 63;
+    int64_t ncols = (int64_t)W.col_end - W.col_beg;
+    int64_t c0 = (int64_t)wave * 64;
+    if (c0 >= ncols) return;
+    int64_t c1 = c0 + 64 < ncols ? c0 + 64 : ncols;
+    int p0 = W.col_beg + (int)c0;
+    int p = p0 + lane;
+    bool active = p < W.col_end;
+    int plast = W.col_beg + (int)c1 - 1;
+    uint64_t o0 = offs[c0], o1 = offs[c1];
+    uint64_t my0 = active ? offs[c0 + lane] : o1;
+    uint64_t my1 = active ? offs[c0 + lane + 1] : o1;
+    bool exists = my1 > my0;
+    uint64_t wbytes = o1 - o0;
+    if (wbytes == 0) return;
+    if (wbytes <= lds_cap) {
+        uint32_t slice = (lds_cap + 16 + 15) & ~15u;
+        uint32_t base = (uint32_t)wid * slice;
+        uint32_t mis = (uint32_t)((uintptr_t)(out + o0) & 15);
+        Sink<true> s; s.g = nullptr; s.cur = base + mis + (uint32_t)(my0 - o0);
+        emit_column_fast<true>(W, P, colinfo, ncols, c0 + lane, p0, plast, p, exists, s);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        char *dst = out + o0;
+        uint32_t n = (uint32_t)wbytes;
+        uint32_t head = mis ? 16 - mis : 0; if (head > n) head = n;
+        if ((uint32_t)lane < head) dst[lane] = lds_text[base + mis + lane];
+        uint32_t body = (n - head) >> 4;
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(lds_text + base + mis + head);
+        uint4 *dst4 = reinterpret_cast<uint4 *>(dst + head);
+        for (uint32_t i = lane; i < body; i += 64) dst4[i] = src4[i];
+        uint32_t done = head + (body << 4);
+        if (done + lane < n) dst[done + lane] = lds_text[base + mis + done + lane];
+    } else {
+        Sink<false> s; s.cur = 0; s.g = out + my0;
+        emit_column_fast<false>(W, P, colinfo, ncols, c0 + lane, p0, plast, p, exists, s);
+    }
+}
+
 static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
 {
     MplpDevPar d;
@@ -451,15 +675,20 @@ static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
 }
 
 // tlen travels in StaWinDev.reg_* style fields? no: we pass it through ref_len-independent P.tlen
-void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, StaCounters *ctr)
+void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
     int64_t nb = (ncols + 255) / 256;
+    if (!((uint32_t)p.flag & EXTRA_MASK) && colinfo) {
+        hipLaunchKernelGGL(k_mplp_len_fast, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, colinfo, ctr);
+        return;
+    }
     hipLaunchKernelGGL(k_mplp_len, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, ctr);
 }
 
-void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, char *out, uint32_t lds_cap)
+void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
+                          char *out, uint32_t lds_cap)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
@@ -468,5 +697,9 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
     int wpb = 4 * slice <= 65536 ? 4 : (2 * slice <= 65536 ? 2 : 1);
     int64_t nwaves = (ncols + 63) / 64;
     int64_t nb = (nwaves + wpb - 1) / wpb;
+    if (!((uint32_t)p.flag & EXTRA_MASK) && colinfo) {
+        hipLaunchKernelGGL(k_mplp_emit_fast, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, make_par(p, w.tlen), offs, colinfo, out, lds_cap);
+        return;
+    }
     hipLaunchKernelGGL(k_mplp_emit, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, make_par(p, w.tlen), offs, out, lds_cap);
 }

@@ -12,6 +12,8 @@
 #define RI_REV      0x8u
 #define RI_OLAP_EL  0x10u   // eligible for mate-overlap hashing (overlap_push conditions)
 #define RI_BAQ      0x20u   // BAQ must be computed for this read
+#define RI_BAQ_SLOW 0x40u   // ... by the general-band kernel (band width != 7 or very long read); listed in `chain`
+#define RI_BAQ_BW_SHIFT 16  // bits 16..20: band width handled by a band-in-registers BAQ kernel (7 or 8), 0 = general kernel
 #define RI_MAPQ_SHIFT 8     // bits 8..15: mapping quality after -C
 
 // one input file's reads as the kernels see them (all device pointers)
@@ -40,6 +42,7 @@ struct StaReadsDev {
     int32_t *maxend;      // inclusive prefix max of `end` over RI_KEEP reads
     uint32_t *info;       // RI_*
     int32_t *clip;        // depth -s: columns below this are not counted (0 = none)
+    int32_t *chain;       // n+4 ints: BAQ slow-read list ([0] = count, then read indices) until the overlap pass reuses it as hash chains
 };
 
 // window constants shared by the column kernels
@@ -58,7 +61,7 @@ struct StaWinDev {
 };
 
 struct StaCounters {          // device-side reduction targets, zeroed per plan
-    unsigned long long n_lines, n_data_cols, n_kept, piled_bases, n_dropped, max_wave_bytes, n_anom, maxcnt_flag, max_lq, max_bw, n_baq;
+    unsigned long long n_lines, n_data_cols, n_kept, piled_bases, n_dropped, max_wave_bytes, n_anom, maxcnt_flag, max_lq, max_bw, n_baq, max_lq_fast, n_baq_fast, n_baq_bw8, n_baq_general;
 };
 
 // ---- launchers (defined in the .hip files) ----
@@ -71,10 +74,11 @@ void sta_launch_maxend_scan(hipStream_t s, const StaReadsDev &r, void *tmp, size
 size_t sta_scan_tmp_bytes(int64_t n);
 // exclusive scan of u32 lengths into u64 offsets (offs has n+1 entries)
 void sta_launch_len_scan(hipStream_t s, const uint32_t *len, uint64_t *offs, int64_t n, void *tmp, size_t tmp_bytes);
-void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, StaCounters *ctr);
-void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs,
+void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo /*[nfiles][ncols] (count, seq bytes)*/,
+                         StaCounters *ctr);
+void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
                           char *out, uint32_t lds_cap);
-void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, int64_t ncols, StaCounters *ctr);
+void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, const uint32_t *line_len, int64_t ncols, StaCounters *ctr);
 
 // overlap (mate) resolution
 size_t sta_overlap_table_slots(int64_t n_reads);
@@ -88,7 +92,12 @@ void sta_launch_maxcnt(hipStream_t s, const StaReadsDev &r, int maxcnt, int32_t 
 // BAQ
 size_t sta_baq_scratch_bytes(int64_t n_reads, int max_lq, int max_bw);
 void sta_launch_baq(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int redo, void *scratch, size_t scratch_bytes,
-                    int lq_max, int bw_max);
+                    int lq_max, int bw_max, int64_t n_slow);
+// band-in-registers kernels (band width 7: reads taken directly; 8: through the list in `chain`)
+#define STA_BAQ7_LQ_MAX 2048
+size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_launch);
+void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int groups_per_launch,
+                         int bw, int64_t n_items, int use_list);
 
 // depth
 void sta_launch_depth_count(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,

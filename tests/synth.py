@@ -19,7 +19,7 @@ def synth_ref(n, seed=1):
 
 
 def synth_reads(ref, depth=30, read_len=150, seed=42, paired=False, sub_rate=0.001, indel_rate=0.005,
-                mapq=60, origin=0):
+                mapq=60, origin=0, max_indel=3):
     """Returns a dict with the sta_reads arrays for ONE file covering the whole of `ref`.
 
     ref: uint8 array of ASCII bases (contig of length len(ref)); reads lie fully inside it."""
@@ -64,7 +64,7 @@ def synth_reads(ref, depth=30, read_len=150, seed=42, paired=False, sub_rate=0.0
     has_indel = rng.random(n_reads) < indel_rate
     cigars = {}
     for r in np.nonzero(has_indel)[0]:
-        k = int(rng.integers(1, 4))
+        k = int(rng.integers(1, max_indel + 1))
         at = int(rng.integers(10, L - 10 - k))
         if rng.integers(0, 2) == 0 or pos[r] + L + k > n_ref:
             # insertion: query keeps L bases, k of them inserted -> reference span L-k

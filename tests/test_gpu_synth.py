@@ -14,6 +14,7 @@ CONFIGS = [
     ("mpileup30_noref", dict(n_ref=60000, depth=30, read_len=150, seed=42, paired=False), ["mpileup", "{sam}"]),
     ("mpileup30_B", dict(n_ref=60000, depth=30, read_len=150, seed=43, paired=False), ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
     ("mpileup30_baq", dict(n_ref=30000, depth=30, read_len=150, seed=44, paired=False), ["mpileup", "-f", "{fa}", "{sam}"]),
+    ("mpileup_baq_indels", dict(n_ref=20000, depth=30, read_len=150, seed=54, paired=False, indel_rate=0.3, max_indel=14), ["mpileup", "-f", "{fa}", "{sam}"]),
     ("mpileup30_pairs_olap", dict(n_ref=60000, depth=30, read_len=150, seed=45, paired=True), ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
     ("mpileup_EA_pairs", dict(n_ref=30000, depth=30, read_len=150, seed=46, paired=True), ["mpileup", "-E", "-A", "-f", "{fa}", "{sam}"]),
     ("mpileup300", dict(n_ref=8000, depth=300, read_len=150, seed=47, paired=False), ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
@@ -43,3 +44,16 @@ def test_engine_equals_oracle_on_synthetic(tmp_path, oracle_bin, product_bin, ci
             if a != b:
                 pytest.fail("line %d differs\n got: %r\nwant: %r" % (i + 1, a[:300], b[:300]))
         pytest.fail("line count differs: got %d want %d" % (len(g), len(w)))
+
+
+@pytest.mark.parametrize("force_slow", ["0", "1"])
+def test_baq_kernels_agree_with_oracle(tmp_path, oracle_bin, product_bin, force_slow):
+    """The band-in-registers BAQ kernels (bw 7/8) and the general-band kernel must both reproduce the oracle:
+    STA_BAQ_FORCE_SLOW=1 routes every read through the general kernel."""
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=12000, depth=40, read_len=120, seed=61, paired=True, indel_rate=0.2, max_indel=10)
+    args = ["mpileup", "-E", "-f", fa, sam]
+    want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    env = dict(os.environ, STA_BAQ_FORCE_SLOW=force_slow) if force_slow == "1" else dict(os.environ)
+    got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert got.returncode == 0, got.stderr.decode()[-500:]
+    assert got.stdout == want

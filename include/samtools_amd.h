@@ -186,6 +186,24 @@ int sta_mpileup_plan(sta_engine *e, const sta_mplp_params *p, sta_plan_info *inf
  * sta_fetch_output() copies back.  Asynchronous on the engine stream. */
 int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity);
 
+/* ---- binary per-column pileup entries (the bam_plp_* / bam_mplp_* surface is built on these; see
+ *      samtools_amd_plp.h).  One input file per window.  Replaces bam_plp_push's admission rules
+ *      (unmapped reads dropped, -d cap, mate-overlap resolution) + bam_plp64_next/resolve_cigar2. ---- */
+typedef struct sta_plp_entry {
+    int32_t read;      /* index into the staged reads of the window                      */
+    int32_t qpos;      /* bam_pileup1_t.qpos                                             */
+    int32_t indel;     /* bam_pileup1_t.indel                                            */
+    uint32_t bits;     /* 1 is_del, 2 is_head, 4 is_tail, 8 is_refskip, bits >> 4 = cigar_ind */
+} sta_plp_entry;
+/* info->out_bytes = 16 * entries, n_lines = columns with >= 1 entry */
+int sta_plp_plan(sta_engine *e, int32_t max_depth, int32_t overlaps, sta_plan_info *info);
+int sta_plp_emit(sta_engine *e, void *dev_entries, uint64_t capacity);     /* NULL: engine buffer, read with sta_fetch_output */
+/* first n (<= columns + 1) exclusive column offsets of the planned window (bytes for text plans, entries for sta_plp_plan) */
+int sta_fetch_col_offsets(sta_engine *e, uint64_t *host_offs, uint64_t n);
+/* per-read state after a plan: info words (bit 1 = read is in the pileup) and the working quality
+ * pool (mate-overlap / BAQ adjusted), laid out like sta_reads.qual.  Either pointer may be NULL. */
+int sta_fetch_read_state(sta_engine *e, int32_t file, uint32_t *host_info, uint8_t *host_qual);
+
 /* ---- depth ---- */
 int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info);
 int sta_depth_emit(sta_engine *e, void *dev_out, uint64_t capacity);

@@ -61,7 +61,8 @@ struct sta_engine {
     DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch;
     StaWinDev wd{};
     // plan state
-    int planned = 0;   // 1 mpileup, 2 depth
+    int planned = 0;   // 1 mpileup, 2 depth, 3 plp entries
+    bool plp_mode = false;
     sta_mplp_params mp{};
     sta_depth_params dp{};
     StaCounters ctr_h{};
@@ -415,7 +416,10 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             sta_launch_overlap(s, d, e->wd.origin, e->wd.tid, e->table.p, slots, (int32_t *)e->fb[(size_t)f].chain.p, ctr);
         }
     }
-    {
+    if (e->plp_mode) {
+        ProfScope ps(e, "plp_count");
+        sta_launch_plp_count(s, e->wd, (uint32_t *)e->line_len.p);
+    } else {
         int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
         if (e->colinfo.ensure((size_t)(ncols > 0 ? ncols : 1) * (size_t)(nf > 0 ? nf : 1) * 8 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(column info) failed");
         ProfScope ps(e, "mplp_len");
@@ -486,6 +490,84 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     if (e->out_bytes == 0) return STA_OK;
     ProfScope ps(e, "mplp_emit");
     sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap);
+    return STA_OK;
+}
+
+/* ---- binary per-column entries (bam_plp_* surface) ---- */
+int sta_plp_plan(sta_engine *e, int32_t max_depth, int32_t overlaps, sta_plan_info *info)
+{
+    if (!e) return STA_ERR_ARG;
+    if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
+    if (e->files_h.size() != 1) return fail(e, STA_ERR_ARG, "the pileup-entry path takes one input file per window");
+    hipSetDevice(e->device);
+    sta_mplp_params p; memset(&p, 0, sizeof p);
+    p.max_depth = max_depth;
+    p.flag = overlaps ? STA_MPLP_SMART_OVERLAPS : 0;     // bam_plp_push drops unmapped reads only; callers filter in their callback
+    e->mp = p;
+    // the reference (if one was set for another use of this engine) must not trigger the "read beyond the FASTA" filter
+    const char *saved_ref = e->wd.ref; int64_t saved_len = e->wd.ref_len;
+    e->wd.ref = nullptr; e->wd.ref_len = 0;
+    int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
+    e->min_pos.assign(e->files_h.size(), 0); e->max_pos_hint.assign(e->files_h.size(), 0);
+    e->plp_mode = true;
+    int rc = mpileup_pipeline(e, &p, false);
+    if (!rc) rc = finish_plan(e, ncols, info);
+    if (!rc && e->ctr_h.maxcnt_flag) {
+        StaReadsDev &d = e->files_h[0];
+        if (d.n) {
+            int32_t first = 0, lastmax = 0, lastpos = 0;
+            HIPCHK(hipMemcpy(&first, d.pos, 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&lastmax, d.maxend + (d.n - 1), 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&lastpos, d.pos + (d.n - 1), 4, hipMemcpyDeviceToHost));
+            e->min_pos[0] = first; e->max_pos_hint[0] = lastmax > lastpos ? lastmax : lastpos;
+        }
+        rc = mpileup_pipeline(e, &p, true);
+        if (!rc) rc = finish_plan(e, ncols, info);
+    }
+    e->plp_mode = false;
+    e->wd.ref = saved_ref; e->wd.ref_len = saved_len;
+    if (rc) return rc;
+    e->out_bytes *= 16;                                   // offsets were scanned in entries
+    if (info) info->out_bytes = e->out_bytes;
+    e->planned = 3;
+    return STA_OK;
+}
+
+int sta_plp_emit(sta_engine *e, void *dev_entries, uint64_t capacity)
+{
+    if (!e) return STA_ERR_ARG;
+    if (e->planned != 3) return fail(e, STA_ERR_ARG, "sta_plp_plan has not run for this window");
+    hipSetDevice(e->device);
+    char *out = nullptr;
+    int rc = emit_common(e, dev_entries, capacity, &out);
+    if (rc) return rc;
+    if (e->out_bytes == 0) return STA_OK;
+    ProfScope ps(e, "plp_fill");
+    sta_launch_plp_fill(e->stream, e->wd, (const uint64_t *)e->offs.p, out);
+    return STA_OK;
+}
+
+int sta_fetch_col_offsets(sta_engine *e, uint64_t *host_offs, uint64_t n)
+{
+    if (!e || !host_offs) return STA_ERR_ARG;
+    if (!e->planned) return fail(e, STA_ERR_ARG, "no planned window");
+    hipSetDevice(e->device);
+    uint64_t ncols = (uint64_t)((int64_t)e->wd.col_end - e->wd.col_beg);
+    if (n > ncols + 1) return fail(e, STA_ERR_ARG, "more offsets requested than columns + 1");
+    HIPCHK(hipMemcpyAsync(host_offs, e->offs.p, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return STA_OK;
+}
+
+int sta_fetch_read_state(sta_engine *e, int32_t file, uint32_t *host_info, uint8_t *host_qual)
+{
+    if (!e || file < 0 || (size_t)file >= e->files_h.size()) return STA_ERR_ARG;
+    if (!e->planned) return fail(e, STA_ERR_ARG, "no planned window");
+    hipSetDevice(e->device);
+    StaReadsDev &d = e->files_h[(size_t)file];
+    if (host_info && d.n) HIPCHK(hipMemcpyAsync(host_info, d.info, (size_t)d.n * 4, hipMemcpyDeviceToHost, e->stream));
+    if (host_qual && d.n_bases_total) HIPCHK(hipMemcpyAsync(host_qual, d.qual, (size_t)d.n_bases_total, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return STA_OK;
 }
 

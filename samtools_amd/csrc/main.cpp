@@ -1,17 +1,19 @@
 // main.cpp -- `samtools-amd` command: the two sub-commands of the hot path, dispatched the way
 // bamtk.c:248,270 dispatches them in the reference.
 #include "../../include/samtools_amd.h"
+extern "C" int sta_main_plpdump(int argc, char **argv);   // diagnostic client of the bam_plp_* surface (driver_plpdump.cpp)
 #include <cstdio>
 #include <cstring>
 
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        fprintf(stderr, "Usage: samtools-amd <mpileup|depth> [options]\n%s\n", sta_version());
+        fprintf(stderr, "Usage: samtools-amd <mpileup|depth|plpdump> [options]\n%s\n", sta_version());
         return 1;
     }
     if (strcmp(argv[1], "mpileup") == 0) return sta_main_mpileup(argc - 1, argv + 1);
     if (strcmp(argv[1], "depth") == 0) return sta_main_depth(argc - 1, argv + 1);
+    if (strcmp(argv[1], "plpdump") == 0) return sta_main_plpdump(argc - 1, argv + 1);
     fprintf(stderr, "[main] unrecognized command '%s'\n", argv[1]);
     return 1;
 }

@@ -80,6 +80,10 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
                           char *out, uint32_t lds_cap);
 void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, const uint32_t *line_len, int64_t ncols, StaCounters *ctr);
 
+// binary per-column entries for the bam_plp_* surface (kernels_plpapi.hip)
+void sta_launch_plp_count(hipStream_t s, const StaWinDev &w, uint32_t *line_len);
+void sta_launch_plp_fill(hipStream_t s, const StaWinDev &w, const uint64_t *offs, void *entries);
+
 // overlap (mate) resolution
 size_t sta_overlap_table_slots(int64_t n_reads);
 size_t sta_overlap_table_bytes(size_t slots);

@@ -1,0 +1,64 @@
+"""Window sharding across the GPUs of one node (BASELINE.json north_star).
+
+Reference positions split into non-overlapping windows; every rank (one process per GPU) runs the
+whole hot path on its own windows and the per-window pileup text is collected on rank 0 with ONE
+gather per step (RCCL over xGMI when the backend is "nccl", gloo in the CPU tests).  The reference's
+own precedent for position sharding is bam_consensus.c:2759-2790 (span jobs) and bedcov.c:297-308
+(per-interval iterators).  Nothing here computes pileups: it only decides who owns which columns
+and moves finished text.
+"""
+from typing import List, Sequence, Tuple
+
+
+def plan_windows(contig_lengths: Sequence[int], window_cols: int) -> List[Tuple[int, int, int]]:
+    """All windows (tid, beg, end) of a genome in output order (contig order, then position)."""
+    out = []
+    for tid, n in enumerate(contig_lengths):
+        beg = 0
+        while beg < n:
+            end = min(n, beg + window_cols)
+            out.append((tid, beg, end))
+            beg = end
+    return out
+
+
+def windows_of_rank(windows: Sequence[Tuple[int, int, int]], rank: int, world: int) -> List[int]:
+    """Indices of the windows rank `rank` owns: contiguous blocks (so a rank's text is one contiguous
+    piece of the final output), sizes differing by at most one window."""
+    n = len(windows)
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return list(range(lo, hi))
+
+
+def halo_columns(max_ref_span: int) -> int:
+    """Reads starting up to this many columns before a window can still touch it or rewrite (through
+    mate-overlap resolution) the qualities of a read that does: 2 x the longest reference span."""
+    return 2 * int(max_ref_span)
+
+
+def gather_text(local, dst: int = 0, group=None):
+    """Collect every rank's byte tensor (uint8, 1-D, on the backend's device) on `dst` in rank order.
+
+    One size all_gather (8 bytes per rank) and ONE gather of the text, padded to the largest piece.
+    Returns the list of per-rank tensors on `dst` (trimmed to their true sizes), None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    buf = local
+    if local.numel() != cap:
+        buf = torch.zeros(cap, dtype=torch.uint8, device=local.device)
+        buf[:local.numel()] = local
+    recv = [torch.empty(cap, dtype=torch.uint8, device=local.device) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return [r[:s] for r, s in zip(recv, sizes)]

@@ -1,0 +1,70 @@
+"""Multi-rank path on CPU: window ownership and the one-gather collection of per-window text
+(samtools_amd/shard.py), world_size 2 over gloo.  The engine itself is not called here (no GPU):
+each rank fabricates the text its windows would produce, and rank 0 must reassemble the exact
+single-process output."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from samtools_amd import shard  # noqa: E402
+
+
+def fake_window_text(tid, beg, end):
+    # variable-length rows, like pileup text
+    return b"".join(b"chr%d\t%d\t%s\n" % (tid, p + 1, b"." * (p % 7)) for p in range(beg, end))
+
+
+def _worker(rank, world, port, contigs, wcols, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wins = shard.plan_windows(contigs, wcols)
+    mine = shard.windows_of_rank(wins, rank, world)
+    text = b"".join(fake_window_text(*wins[i]) for i in mine)
+    local = torch.frombuffer(bytearray(text), dtype=torch.uint8) if text else torch.zeros(0, dtype=torch.uint8)
+    parts = shard.gather_text(local, dst=0)
+    if rank == 0:
+        q.put(b"".join(bytes(p.numpy().tobytes()) for p in parts))
+    else:
+        assert parts is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize("contigs,wcols", [([1000, 37, 512], 128), ([90], 100), ([300, 300], 64)])
+def test_two_ranks_reassemble_single_process_output(contigs, wcols):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, contigs, wcols, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = b"".join(fake_window_text(*w) for w in shard.plan_windows(contigs, wcols))
+    assert got == want
+
+
+def test_window_ownership_is_a_partition():
+    wins = shard.plan_windows([1000, 1, 999, 4096], 256)
+    for world in (1, 2, 3, 8):
+        owned = [i for r in range(world) for i in shard.windows_of_rank(wins, r, world)]
+        assert owned == list(range(len(wins)))          # every window exactly once, in output order
+        sizes = [len(shard.windows_of_rank(wins, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+    assert shard.halo_columns(151) == 302

@@ -35,6 +35,19 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
+def alg_bytes_per_base(kernel, wl_bytes_per_base, band_cells=15):
+    """Algorithmic HBM bytes per piled base for the kernels that can dominate a step.
+
+    BAQ forward/backward: the (M, I) part of every forward row -- 2 * band_cells doubles per query base -- is written once
+    by the forward kernel and read once by the backward/MAP kernel; inputs (quality, packed base, reference base) add ~2.5 B.
+    Pileup kernels: SURVEY.md 8d figure for the whole measure+emit pair (4.3 B/base at 30x), attributed to the emit kernel."""
+    if kernel in ("baq_fwd", "baq_bwd"):
+        return 2 * band_cells * 8 + 2.5
+    if kernel == "mplp_len":
+        return 1.0 + 12.0 / 30.0
+    return wl_bytes_per_base
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,7 +136,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    kind, depth, def_cols, alg_bytes_per_base, _ = WORKLOADS[a.workload]
+    kind, depth, def_cols, alg_bytes_per_base_wl, _ = WORKLOADS[a.workload]
     n_cols = a.cols or def_cols
     # every rank generates its own window (different seed): reference windows are independent shards
     ref = synth_ref(n_cols, seed=1 + rank)
@@ -151,14 +164,7 @@ def main():
     piled = int(info.piled_bases)
     cap = out_bytes + 4096
     out_t = torch.empty(cap, dtype=torch.uint8, device=dev)
-    gather_list = None
-    if dist is not None:
-        caps = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(caps, torch.tensor([cap], dtype=torch.int64, device=dev))
-        cap = int(max(int(c.item()) for c in caps))
-        out_t = torch.empty(cap, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            gather_list = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+    from samtools_amd import shard
 
     def step():
         plan()
@@ -168,7 +174,8 @@ def main():
             eng.depth_emit(out_t.data_ptr(), cap)
         if dist is not None:
             # the single collective of the path: per-window column text -> rank 0 over RCCL/xGMI
-            dist.gather(out_t, gather_list, dst=0)
+            # (one 8-byte size all-gather + one gather of the text; samtools_amd/shard.py)
+            shard.gather_text(out_t[:out_bytes], dst=0)
 
     for _ in range(a.warmup):
         step()
@@ -205,12 +212,33 @@ def main():
         assert out_bytes == 0 or head.count(b"\n") > 0
         value = piled_all * a.steps / dt_all / 1e6
         # dominant kernel by accumulated HIP-event time (rank 0)
-        dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, 0.0))
-        dom_name, (dom_launches, dom_ms) = dom
-        launches_per_step = max(1, dom_launches // max(1, a.steps))
-        avg_ms = dom_ms / max(1, dom_launches)
-        alg_bytes_per_launch = alg_bytes_per_base * piled / launches_per_step
-        achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        def roof(name):
+            launches, ms = prof[name]
+            per_step = max(1, launches // max(1, a.steps))
+            avg_ms = ms / max(1, launches)
+            bpb = alg_bytes_per_base(name, alg_bytes_per_base_wl)
+            per_launch = bpb * piled / per_step
+            ach = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": traffic_of(name, per_step), "alg_bytes_per_unit": bpb, "units_per_launch": piled / per_step,
+                    "avg_launch_ms": avg_ms, "launches_per_step": per_step}
+
+        pmc = {}
+        pmc_path = os.path.join(REPO, "profiles", "r01_%s_pmc_traffic.json" % a.workload)
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+        KNAME = {"baq_fwd": "void k_baq_fwd<7>", "baq_bwd": "void k_baq_bwd<7>", "mplp_emit": "k_mplp_emit_fast", "mplp_len": "k_mplp_len_fast",
+                 "depth_emit": "k_depth_emit", "depth_len": "k_depth_len", "depth_count": "k_depth_count"}
+
+        def traffic_of(name, per_step):
+            """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE + WRITE_SIZE, KB);
+            measured at the default window size only (null otherwise).  Counter calibration: DESIGN.md section 5."""
+            ent = pmc.get(KNAME.get(name, name))
+            if not ent or a.cols or "FETCH_SIZE" not in ent or "WRITE_SIZE" not in ent:
+                return None
+            return (ent["FETCH_SIZE"]["per_launch"] + ent["WRITE_SIZE"]["per_launch"]) * 1024.0
+
+        dom_name = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
         res = {
             "metric": "Mbases piled/s (mpileup, 30x 150bp)" if a.workload.startswith("mpileup30") else "Mbases piled/s (%s)" % a.workload,
             "value": value, "unit": "Mbases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -221,12 +249,14 @@ def main():
                        "read_len": 150, "depth": depth, "window_cols_per_gpu": n_cols, "reads_per_gpu": int(rd["n"]),
                        "piled_bases_per_gpu_step": piled, "out_bytes_per_gpu_step": out_bytes,
                        "staged_in_bytes_per_gpu": in_bytes, "parallelism": "window-sharded x%d, 1 RCCL gather" % world},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "alg_bytes_per_unit": alg_bytes_per_base, "units_per_launch": piled / launches_per_step,
-                         "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step},
+            "roofline": roof(dom_name) if dom_name else None,
             "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
         }
+        emit_name = "mplp_emit" if kind == "mpileup" else "depth_emit"
+        if emit_name in prof and emit_name != dom_name:
+            res["roofline_pileup"] = roof(emit_name)
+        # whole-step algorithmic rate (every kernel of the step, SURVEY.md 8d bytes): the number to compare with 8 TB/s end to end
+        res["step_alg_GBps"] = alg_bytes_per_base_wl * piled_all / (dt_all / a.steps) / 1e9 / max(1, world)
         if world == 1 and not a.no_cpu_baseline:
             sample = a.cpu_sample_cols or (1000000 if kind == "mpileup" and not a.workload.endswith("_B") else 2000000)
             if depth >= 300:

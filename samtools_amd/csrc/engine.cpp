@@ -363,13 +363,17 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                     need = sta_baq_band_scratch_bytes(d.n, (int)c.max_lq_fast, &gpl);
                     if (e->baq_scratch.ensure(need + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ scratch) failed");
                 }
-                if (c.n_baq_fast) {
-                    ProfScope ps(e, "baq");
-                    sta_launch_baq_band(s, d, e->wd, e->baq_scratch.p, (int)c.max_lq_fast, gpl, 7, d.n, 0);
-                }
-                if (c.n_baq_bw8 && n_list) {
-                    ProfScope ps(e, "baq_bw8");
-                    sta_launch_baq_band(s, d, e->wd, e->baq_scratch.p, (int)c.max_lq_fast, gpl, 8, n_list, 1);
+                for (int cls = 0; cls < 2; ++cls) {
+                    // class 0: band width 7, reads taken in place; class 1: band width 8, through the list
+                    int64_t items = cls == 0 ? (c.n_baq_fast ? d.n : 0) : (c.n_baq_bw8 ? (int64_t)n_list : 0);
+                    int64_t ngroups = (items + 63) / 64;
+                    for (int64_t g0 = 0; g0 < ngroups; g0 += gpl) {
+                        int64_t ng = ngroups - g0 < gpl ? ngroups - g0 : gpl;
+                        for (int pass = 0; pass < 2; ++pass) {
+                            ProfScope ps(e, cls == 0 ? (pass ? "baq_bwd" : "baq_fwd") : (pass ? "baq8_bwd" : "baq8_fwd"));
+                            sta_launch_baq_band(s, d, e->wd, e->baq_scratch.p, (int)c.max_lq_fast, cls == 0 ? 7 : 8, g0, ng, cls, pass);
+                        }
+                    }
                 }
             }
             if (c.n_baq_general && n_list) {

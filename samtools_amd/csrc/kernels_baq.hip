@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
 #pragma unroll
         for (int j = 0; j < NB; ++j) { M[j] /= sum; I[j] /= sum; }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { Frow(1, 2 * j) = M[j]; Frow(1, 2 * j + 1) = I[j]; }
+        for (int j = 0; j < NB; ++j) { __builtin_nontemporal_store(M[j], &Frow(1, 2 * j)); __builtin_nontemporal_store(I[j], &Frow(1, 2 * j + 1)); }
     }
     // software pipeline of the per-row inputs: raw bytes two rows ahead, converted one row ahead
     int c_sb = 0, c_rc = 7;                   // converted, for the next row
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
 #pragma unroll
         for (int j = 0; j < NB; ++j) { M[j] *= inv; I[j] *= inv; D[j] *= inv; }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { Frow(i, 2 * j) = M[j]; Frow(i, 2 * j + 1) = I[j]; }
+        for (int j = 0; j < NB; ++j) { __builtin_nontemporal_store(M[j], &Frow(i, 2 * j)); __builtin_nontemporal_store(I[j], &Frow(i, 2 * j + 1)); }
     }
     {   // s[l_query+1]
         double sum = 0.;
@@ -470,8 +470,11 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
 #undef Frow
 }
 
+#ifndef BAQ_PREFETCH_F
+#define BAQ_PREFETCH_F 1
+#endif
 template <int BW>
-__global__ void __launch_bounds__(256) k_baq_bwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
+__global__ void __launch_bounds__(256, BAQ_PREFETCH_F ? 2 : 3) k_baq_bwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
                                                  double *scratch, size_t slot_dbl, int lq_cap)
 {
     constexpr int NB = 2 * BW + 1;
@@ -516,10 +519,13 @@ __global__ void __launch_bounds__(256) k_baq_bwd(StaReadsDev R, StaWinDev W, Baq
     if (lq >= 3) { int i = lq - 2; r_q = qual[i]; r_sb = SEQB(i); r_s = S[(size_t)i * 64]; r_rr = RRAW(i - BW); }
 #pragma unroll 1
     for (int i = lq; i >= 1; --i) {
-        // forward row i for the MAP step: issued first so the loads fly during the row update
+        // forward row i for the MAP step.  BAQ_PREFETCH_F: issue the loads first so they fly during the row update
+        // (costs 4*NB VGPRs: 2 waves/SIMD); otherwise load at the MAP step and rely on 3 waves/SIMD to hide the latency.
         double fM[NB], fI[NB];
+#if BAQ_PREFETCH_F
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { fM[j] = Frow(i, 2 * j); fI[j] = Frow(i, 2 * j + 1); }
+        for (int j = 0; j < NB; ++j) { fM[j] = __builtin_nontemporal_load(&Frow(i, 2 * j)); fI[j] = __builtin_nontemporal_load(&Frow(i, 2 * j + 1)); }
+#endif
         if (i < lq) {
             const float qf = c_qf; const int sb = c_sb; const int nrc = c_rc; const double si = c_s;
             c_qf = q2p[r_q]; c_sb = r_sb; c_rc = RCONV(r_rr); c_s = r_s;
@@ -551,6 +557,10 @@ __global__ void __launch_bounds__(256) k_baq_bwd(StaReadsDev R, StaWinDev W, Baq
             }
         }
         // MAP for row i
+#if !BAQ_PREFETCH_F
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { fM[j] = __builtin_nontemporal_load(&Frow(i, 2 * j)); fI[j] = __builtin_nontemporal_load(&Frow(i, 2 * j + 1)); }
+#endif
         double sum = 0., max = 0.;
         int max_k = -1;
 #pragma unroll
@@ -602,6 +612,305 @@ __global__ void __launch_bounds__(256) k_baq_bwd(StaReadsDev R, StaWinDev W, Baq
 #undef Frow
 }
 
+// ================================================================================================
+// Checkpointed variant (opt-in with STA_BAQ_CHECKPOINT=1; measured slower on MI355X): the forward kernel stores only every C-th row (M, I and D: the
+// full state), and the backward kernel re-computes the C rows of a block from the checkpoint below
+// it, keeping their (M, I) cells in REGISTERS (one wave per SIMD, up to 512 VGPRs) while it walks the
+// block backwards.  HBM stream per query base: 3*NB*8/C bytes written + read (90 B at BW 7, C 4)
+// instead of 2*NB*8 (240 B) -- the fp64 work grows by one extra forward pass, which the kernel pair
+// has headroom for (it was bound by the scratch stream).  Same arithmetic, same order, same results.
+//
+// Block word: reference codes for indices a-BW .. a+C+BW-1 of a block of rows a+1..a+C in ONE 64-bit
+// word (3 bits per code); the forward word of row a+1+c is (word >> 3c), the backward word of that
+// row is (word >> 3(c+1)), and the next lower block's word is (word << 3C) | C new codes.
+
+template <int BW>
+__device__ __forceinline__ double baq_row1(double (&M)[2 * BW + 1], double (&I)[2 * BW + 1], double (&D)[2 * BW + 1], uint64_t rw, int qy, double q0, const BaqPar &p)
+{
+    constexpr int NB = 2 * BW + 1;
+    const double ematch = 1. - q0, e_lo = qy > 3 ? 1. : q0 * EM;
+    const int qyc = qy > 3 ? 9 : qy;
+    double sum = 0.;
+    const double eibi = EI * p.bI;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int rc = FLD(rw, j);
+        double e = emis_sel(rc, qyc, ematch, e_lo);
+        double a = e * p.bM;
+        double b2 = rc == 7 ? 0. : eibi;
+        M[j] = a; I[j] = b2; D[j] = 0.;
+        sum += a + b2;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { M[j] /= sum; I[j] /= sum; }
+    return sum;
+}
+
+template <int BW>
+__device__ __forceinline__ double baq_fwd_row(double (&M)[2 * BW + 1], double (&I)[2 * BW + 1], double (&D)[2 * BW + 1], uint64_t rw, int qy, double qli, const BaqPar &p)
+{
+    constexpr int NB = 2 * BW + 1;
+    const double ematch = 1. - qli, e_lo = qy > 3 ? 1. : qli * EM;
+    const int qyc = qy > 3 ? 9 : qy;
+    double sum = 0., pm = 0., pd = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int rc = FLD(rw, j);
+        double e = emis_sel(rc, qyc, ematch, e_lo);
+        double fm = e * (p.m0 * M[j] + p.m3 * I[j] + p.m6 * D[j]);
+        double fi = (j + 1 < NB) ? EI * (p.m1 * M[j + 1] + p.m4 * I[j + 1]) : 0.;
+        double fd = p.m2 * pm + p.m8 * pd;
+        fd = rc == 7 ? 0. : fd;
+        M[j] = fm; I[j] = fi; D[j] = fd;
+        sum += fm + fi + fd;
+        pm = fm; pd = fd;
+    }
+    const double inv = 1. / sum;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { M[j] *= inv; I[j] *= inv; D[j] *= inv; }
+    return sum;
+}
+
+template <int BW, int C>
+__global__ void __launch_bounds__(256) k_baq_ck_fwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
+                                                    double *scratch, size_t slot_dbl, int lq_cap)
+{
+    constexpr int NB = 2 * BW + 1;
+    __shared__ float q2p[256];
+    __shared__ uint8_t refc[256];
+    q2p[threadIdx.x] = T.q2p[threadIdx.x];
+    refc[threadIdx.x] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)threadIdx.x));
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t gl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gl >= ngroups) return;
+    const int64_t r = baq_pick(R, g0 + gl, lane, use_list, BW);
+    if (r < 0) return;
+    double *CK = scratch + (size_t)gl * slot_dbl + lane;          // CK[((t-1)*3NB + cell)*64], checkpoint after row t*C
+    const BaqRd d = baq_rd(R, W, r);
+    const int lq = d.lq, l_ref = d.l_ref;
+    const uint8_t *qual = d.qual, *seq = d.seq; const char *ref = d.ref;
+    const BaqPar p = baq_par(lq, l_ref);
+
+    double M[NB], I[NB], D[NB];
+    uint64_t rw = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rw |= (uint64_t)RCODE(j - BW) << (3 * j);
+    baq_row1<BW>(M, I, D, rw, QCONV(SEQB(0), 0), (double)q2p[qual[0]], p);
+    int c_sb = 0, c_rc = 7; float c_qf = 0.f;
+    int r_q = 0, r_sb = 0, r_rr = 256;
+    if (lq >= 2) { c_qf = q2p[qual[1]]; c_sb = SEQB(1); c_rc = RCODE(2 + BW - 1); }
+    if (lq >= 3) { r_q = qual[2]; r_sb = SEQB(2); r_rr = RRAW(3 + BW - 1); }
+#pragma unroll 1
+    for (int i = 2; i <= lq; ++i) {
+        const float qf = c_qf; const int sb = c_sb; const int nrc = c_rc;
+        c_qf = q2p[r_q]; c_sb = r_sb; c_rc = RCONV(r_rr);
+        if (i + 2 <= lq) { r_q = qual[i + 1]; r_sb = SEQB(i + 1); r_rr = RRAW(i + 2 + BW - 1); }
+        rw = (rw >> 3) | ((uint64_t)nrc << (3 * (NB - 1)));
+        baq_fwd_row<BW>(M, I, D, rw, QCONV(sb, i - 1), (double)qf, p);
+        if (i % C == 0 && i < lq) {
+            double *ck = CK + (size_t)(i / C - 1) * (3 * NB) * 64;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { ck[(size_t)(3 * j) * 64] = M[j]; ck[(size_t)(3 * j + 1) * 64] = I[j]; ck[(size_t)(3 * j + 2) * 64] = D[j]; }
+        }
+    }
+}
+
+template <int BW, int C>
+__global__ void __launch_bounds__(256) k_baq_ck_bwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
+                                                    double *scratch, size_t slot_dbl, int lq_cap)
+{
+    constexpr int NB = 2 * BW + 1;
+    constexpr int NF = NB + C;                 // fields of a block word
+    __shared__ float q2p[256];
+    __shared__ uint8_t refc[256];
+    q2p[threadIdx.x] = T.q2p[threadIdx.x];
+    refc[threadIdx.x] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)threadIdx.x));
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t gl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gl >= ngroups) return;
+    const int64_t r = baq_pick(R, g0 + gl, lane, use_list, BW);
+    if (r < 0) return;
+    const double *CK = scratch + (size_t)gl * slot_dbl + lane;
+    const int nck_cap = (lq_cap - 1) / C;
+    int32_t *P = reinterpret_cast<int32_t *>(scratch + (size_t)gl * slot_dbl + (size_t)nck_cap * (3 * NB) * 64) + lane;
+    const BaqRd d = baq_rd(R, W, r);
+    const int lq = d.lq, l_ref = d.l_ref;
+    uint8_t *qual = d.qual; const uint8_t *seq = d.seq; const char *ref = d.ref;
+    const BaqPar p = baq_par(lq, l_ref);
+
+    double M[NB], I[NB], D[NB];                // forward state while a block is re-computed
+    double sM_[C][NB], sI_[C][NB], Sb[C];      // the block's forward rows (M, I) and their scaling sums
+    double bMr[NB], bIr[NB];                   // backward row
+    int t = (lq - 1) / C;                      // top block: rows a+1 .. lq, a = t*C
+    int a = t * C;
+    // block word of the top block
+    uint64_t bw_ = 0;
+#pragma unroll
+    for (int g = 0; g < NF; ++g) bw_ |= (uint64_t)RCODE(a - BW + g) << (3 * g);
+    // inputs of the top block's rows (row a+1+c: quality / base of query index a+c), raw
+    int rq[C], rsb[C], rnew[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { rq[c] = 0; rsb[c] = 0; rnew[c] = 256; if (a + c < lq) { rq[c] = qual[a + c]; rsb[c] = SEQB(a + c); } }
+    if (t >= 1) {
+        const double *ck = CK + (size_t)(t - 1) * (3 * NB) * 64;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { M[j] = ck[(size_t)(3 * j) * 64]; I[j] = ck[(size_t)(3 * j + 1) * 64]; D[j] = ck[(size_t)(3 * j + 2) * 64]; }
+    }
+    float carry_qf = 0.f; int carry_qy = 4;    // inputs of the first row of the block above (row a+C+1): backward row a+C needs them
+#pragma unroll 1
+    for (; t >= 0; --t) {
+        a = t * C;
+        // convert this block's inputs
+        float inq[C]; int inqy[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { inq[c] = q2p[rq[c]]; inqy[c] = QCONV(rsb[c], a + c); }
+        /*** re-compute rows a+1 .. a+C ***/
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int row = a + 1 + c;
+            if (row <= lq) {
+                const uint64_t rw = bw_ >> (3 * c);
+                double sum;
+                if (c == 0 && a == 0) sum = baq_row1<BW>(M, I, D, rw, inqy[0], (double)inq[0], p);
+                else sum = baq_fwd_row<BW>(M, I, D, rw, inqy[c], (double)inq[c], p);
+                Sb[c] = sum;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { sM_[c][j] = M[j]; sI_[c][j] = I[j]; }
+            }
+        }
+        if (a + C >= lq) {
+            // top block: s[lq+1] from row lq (still in M, I), then the backward row of lq
+            double sum = 0.;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) sum += M[j] * p.sM + I[j] * p.sI;
+            const int ctop = lq - a - 1;
+            double sl = Sb[0];
+#pragma unroll
+            for (int c = 1; c < C; ++c) if (c == ctop) sl = Sb[c];
+            const double vM = p.sM / sl / sum, vI = p.sI / sl / sum;
+            const uint64_t rwl = bw_ >> (3 * ctop);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                bool valid = FLD(rwl, j) != 7;
+                bMr[j] = valid ? vM : 0.; bIr[j] = valid ? vI : 0.;
+            }
+        }
+        /*** fetch for the block below while this block walks backwards: its checkpoint into M/I/D, its raw inputs ***/
+        const float first_qf = inq[0]; const int first_qy = inqy[0];
+        if (t >= 1) {
+            const int a2 = a - C;
+            if (t >= 2) {
+                const double *ck = CK + (size_t)(t - 2) * (3 * NB) * 64;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { M[j] = ck[(size_t)(3 * j) * 64]; I[j] = ck[(size_t)(3 * j + 1) * 64]; D[j] = ck[(size_t)(3 * j + 2) * 64]; }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) { rq[c] = qual[a2 + c]; rsb[c] = SEQB(a2 + c); rnew[c] = RRAW(a2 - BW + c); }
+        }
+        /*** backward rows a+C .. a+1 with MAP ***/
+#pragma unroll
+        for (int c = C - 1; c >= 0; --c) {
+            const int i = a + 1 + c;
+            if (i <= lq) {
+                if (i < lq) {
+                    const float qf = (c + 1 < C) ? inq[c + 1 < C ? c + 1 : 0] : carry_qf;
+                    const int qy = (c + 1 < C) ? inqy[c + 1 < C ? c + 1 : 0] : carry_qy;
+                    const uint64_t rw = bw_ >> (3 * (c + 1));
+                    const double qli1 = qf;
+                    const double ematch = 1. - qli1, e_lo = qy > 3 ? 1. : qli1 * EM;
+                    const int qyc = qy > 3 ? 9 : qy;
+                    const double yv = i > 1 ? 1. : 0.;
+                    double dnext = 0.;
+#pragma unroll
+                    for (int j = NB - 1; j >= 0; --j) {
+                        int rc = FLD(rw, j);
+                        double e = emis_sel(rc, qyc, ematch, e_lo) * bMr[j];
+                        double bi1 = j > 0 ? bIr[j - 1] : 0.;
+                        double bm = e * p.m0 + p.eim1 * bi1 + p.m2 * dnext;
+                        double bi_ = e * p.m3 + p.eim4 * bi1;
+                        double bd = (e * p.m6 + p.m8 * dnext) * yv;
+                        bMr[j] = bm; bIr[j] = bi_;
+                        dnext = bd;
+                    }
+                    const double ys = 1. / Sb[c];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) { bMr[j] *= ys; bIr[j] *= ys; }
+                    if (i <= BW) {
+#pragma unroll
+                        for (int j = 0; j < BW; ++j) if (j < BW + 1 - i) { bMr[j] = 0.; bIr[j] = 0.; }
+                    }
+                }
+                double sum = 0., max = 0.;
+                int max_k = -1;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    double z;
+                    z = sM_[c][j] * bMr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 0; } sum += z;
+                    z = sI_[c][j] * bIr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 1; } sum += z;
+                }
+                max /= sum;
+                double v = -4.343 * log(1. - max) + .499;
+                int kq = (v >= 2147483648.0 || v < -2147483648.0 || v != v) ? INT32_MIN : (int)v;
+                P[(size_t)(i - 1) * 64] = (int32_t)(((uint32_t)max_k << 8) | (uint32_t)(uint8_t)(kq > 100 ? 99 : kq));
+            }
+        }
+        carry_qf = first_qf; carry_qy = first_qy;
+        // block word of the block below: shift up by C fields, C new codes at the bottom
+        if (t >= 1) {
+            uint64_t nw = bw_ << (3 * C);
+#pragma unroll
+            for (int c = 0; c < C; ++c) nw |= (uint64_t)RCONV(rnew[c]) << (3 * c);
+            bw_ = nw;
+        }
+    }
+
+    /*** realn.c, extended BAQ ***/
+    {
+        long long xx = d.rpos; int yy = 0;
+        for (int c = 0; c < d.n_cigar; ++c) {
+            int op = d.cigar[c] & 0xf, l = (int)(d.cigar[c] >> 4);
+            if (cg_is_mop(op)) {
+                if (l > lq - yy) l = lq - yy;
+                if (l > 0) {
+                    int run = 0;
+                    for (int i = yy; i < yy + l; ++i) {
+                        int32_t pk = P[(size_t)i * 64];
+                        int st = pk >> 8;
+                        int b = ((st & 3) != 0 || (long long)(st >> 2) != xx - d.xb + (i - yy)) ? 0 : (pk & 0xff);
+                        run = b > run ? b : run;
+                        P[(size_t)i * 64] = (b << 8) | run;
+                    }
+                    run = 0;
+                    for (int i = yy + l - 1; i >= yy; --i) {
+                        int32_t pk = P[(size_t)i * 64];
+                        int b = pk >> 8, left = pk & 0xff;
+                        run = b > run ? b : run;
+                        int bqv = left < run ? left : run;
+                        int q0 = qual[i];
+                        int tag = 64 + (q0 <= bqv ? 0 : q0 - bqv);
+                        qual[i] = (uint8_t)(q0 - (tag - 64));
+                    }
+                }
+                xx += l; yy += l;
+            } else if (op == CG_S || op == CG_I) {
+                if (l > lq - yy) l = lq - yy;
+                yy += l;
+            } else if (op == CG_D) xx += l;
+        }
+    }
+}
+
+static bool baq_use_ck() { const char *e = getenv("STA_BAQ_CHECKPOINT"); return e && atoi(e) > 0; }
+
+static size_t baq_ck_slot_dbl(int lq_cap, int bw, int c)
+{
+    int nb = 2 * bw + 1;
+    size_t nck = (size_t)((lq_cap - 1) / c);
+    return nck * (3 * nb) * 64 + (size_t)(lq_cap + 1) / 2 * 64;
+}
+
 static size_t baq_slot_dbl(int lq_cap, int bw)
 {
     int nb = 2 * bw + 1;
@@ -620,6 +929,7 @@ size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_l
     const char *es = getenv("STA_BAQ_SLAB_GIB");
     if (es && atoi(es) > 0) slab_gib = (size_t)atoi(es);
     size_t slot = baq_slot_dbl(lq_cap, 8) * 8;
+    if (baq_use_ck()) { size_t a = baq_ck_slot_dbl(lq_cap, 7, 4), b = baq_ck_slot_dbl(lq_cap, 8, 3); slot = (a > b ? a : b) * 8; }
     if ((size_t)gpl * slot > (slab_gib << 30)) {
         // split into equal chunks that are multiples of 6144 groups (LCM of the 3072 / 2048 resident waves of the two kernels)
         int64_t fit = (int64_t)((slab_gib << 30) / slot);
@@ -635,26 +945,35 @@ size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_l
 }
 
 template <int BW>
-static void run_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int gpl, int64_t n_items, int use_list)
+static void run_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int64_t g0, int64_t ng, int use_list, int pass)
 {
-    int64_t ngroups = (n_items + 63) / 64;
-    size_t slot = baq_slot_dbl(lq_cap, BW);
-    for (int64_t g0 = 0; g0 < ngroups; g0 += gpl) {
-        int64_t ng = ngroups - g0 < gpl ? ngroups - g0 : gpl;
-        unsigned nb = (unsigned)((ng + 3) / 4);
-        hipLaunchKernelGGL(k_baq_fwd<BW>, dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap);
-        hipLaunchKernelGGL(k_baq_bwd<BW>, dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap);
+    unsigned nb = (unsigned)((ng + 3) / 4);
+    if (baq_use_ck()) {
+        constexpr int C = BW == 7 ? 4 : 3;
+        size_t cslot = baq_ck_slot_dbl(lq_cap, BW, C);
+        if (pass == 0)
+            hipLaunchKernelGGL((k_baq_ck_fwd<BW, C>), dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, cslot, lq_cap);
+        else
+            hipLaunchKernelGGL((k_baq_ck_bwd<BW, C>), dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, cslot, lq_cap);
+        return;
     }
+    size_t slot = baq_slot_dbl(lq_cap, BW);
+    if (pass == 0)
+        hipLaunchKernelGGL(k_baq_fwd<BW>, dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap);
+    else
+        hipLaunchKernelGGL(k_baq_bwd<BW>, dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap);
 }
 
-void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int gpl, int bw,
-                         int64_t n_items, int use_list)
+// One pass (0 = forward, 1 = backward + MAP + apply) over groups [g0, g0 + ng) of 64 reads; the engine calls the two passes
+// chunk by chunk (a chunk = what fits the scratch slab) so that each launch can be timed on its own.
+void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw,
+                         int64_t g0, int64_t ng, int use_list, int pass)
 {
     if (!g_tables_init) {
         for (int i = 0; i < 256; ++i) g_tables.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
         g_tables_init = true;
     }
-    if (r.n == 0 || lq_cap <= 0 || gpl <= 0 || n_items <= 0) return;
-    if (bw == 7) run_band<7>(s, r, w, scratch, lq_cap, gpl, n_items, use_list);
-    else if (bw == 8) run_band<8>(s, r, w, scratch, lq_cap, gpl, n_items, use_list);
+    if (r.n == 0 || lq_cap <= 0 || ng <= 0) return;
+    if (bw == 7) run_band<7>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass);
+    else if (bw == 8) run_band<8>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass);
 }

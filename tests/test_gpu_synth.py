@@ -46,14 +46,18 @@ def test_engine_equals_oracle_on_synthetic(tmp_path, oracle_bin, product_bin, ci
         pytest.fail("line count differs: got %d want %d" % (len(g), len(w)))
 
 
-@pytest.mark.parametrize("force_slow", ["0", "1"])
+@pytest.mark.parametrize("force_slow", ["0", "1", "checkpoint"])
 def test_baq_kernels_agree_with_oracle(tmp_path, oracle_bin, product_bin, force_slow):
-    """The band-in-registers BAQ kernels (bw 7/8) and the general-band kernel must both reproduce the oracle:
-    STA_BAQ_FORCE_SLOW=1 routes every read through the general kernel."""
+    """The band-in-registers BAQ kernels (bw 7/8, default), their checkpoint-and-recompute variant
+    (STA_BAQ_CHECKPOINT=1) and the general-band kernel (STA_BAQ_FORCE_SLOW=1) must all reproduce the oracle."""
     sam, fa = write_synth_sam(str(tmp_path), n_ref=12000, depth=40, read_len=120, seed=61, paired=True, indel_rate=0.2, max_indel=10)
     args = ["mpileup", "-E", "-f", fa, sam]
     want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
-    env = dict(os.environ, STA_BAQ_FORCE_SLOW=force_slow) if force_slow == "1" else dict(os.environ)
+    env = dict(os.environ)
+    if force_slow == "1":
+        env["STA_BAQ_FORCE_SLOW"] = "1"
+    elif force_slow == "checkpoint":
+        env["STA_BAQ_CHECKPOINT"] = "1"
     got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert got.returncode == 0, got.stderr.decode()[-500:]
     assert got.stdout == want

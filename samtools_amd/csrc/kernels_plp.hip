@@ -501,27 +501,44 @@ __device__ __forceinline__ void fast_walk(const StaReadsDev &R, const StaWinDev 
             for (int k = 0; k < 4; ++k) {
                 if (!valid[k]) continue;
                 if (info[k] & RI_SIMPLE) {
-                    if (cov[k]) {
-                        if (!EMIT) n_plp++;
-                        if (qv[k] >= P.min_baseQ) {
-                            bool head = ends && p == rpos[k], tail = ends && p == rend[k] - 1;
-                            if (!EMIT) {
-                                cnt++;
-                                seq_len += 1u + (head ? 2u : 0u) + (tail ? 1u : 0u);
-                            } else {
-                                bool rev = (info[k] & RI_REV) != 0;
-                                if (head) {
-                                    int mq = (int)((info[k] >> RI_MAPQ_SHIFT) & 0xff);
-                                    ss.put('^'); ss.put((char)(mq > 93 ? 126 : mq + 33));
-                                }
-                                int qpos = p - rpos[k];
-                                int c = (sv[k] >> ((~qpos & 1) << 2)) & 0xf;
-                                if (c == rbcode) c = 0;
-                                ss.put(base_char_fast(c, rev));
-                                if (tail) ss.put('$');
-                                sq.put((char)(qv[k] + 33 < 126 ? qv[k] + 33 : 126));
-                            }
+                    // branch-free: every lane runs the same code; a lane that has nothing to add writes at its cursor
+                    // without advancing it (the byte is overwritten by its next real write, or by the separator that
+                    // emit_column_fast puts there after the walk)
+                    const bool pass = cov[k] && qv[k] >= P.min_baseQ;
+                    const bool head = pass && ends && p == rpos[k], tail = pass && ends && p == rend[k] - 1;
+                    if (!EMIT) {
+                        n_plp += cov[k] ? 1u : 0u;
+                        cnt += pass ? 1u : 0u;
+                        seq_len += (pass ? 1u : 0u) + (head ? 2u : 0u) + (tail ? 1u : 0u);
+                    } else if (LDS) {
+                        const bool rev = (info[k] & RI_REV) != 0;
+                        const int mq = (int)((info[k] >> RI_MAPQ_SHIFT) & 0xff);
+                        const int qpos = p - rpos[k];
+                        int c = (sv[k] >> ((~qpos & 1) << 2)) & 0xf;
+                        if (c == rbcode) c = 0;
+                        uint32_t cur = ss.cur;
+                        lds_text[cur] = '^';
+                        lds_text[cur + (head ? 1u : 0u)] = (char)(mq > 93 ? 126 : mq + 33);
+                        cur += head ? 2u : 0u;
+                        lds_text[cur] = base_char_fast(c, rev);
+                        cur += pass ? 1u : 0u;
+                        lds_text[cur] = '$';
+                        cur += tail ? 1u : 0u;
+                        ss.cur = cur;
+                        lds_text[sq.cur] = (char)(qv[k] + 33 < 126 ? qv[k] + 33 : 126);
+                        sq.cur += pass ? 1u : 0u;
+                    } else if (pass) {
+                        bool rev = (info[k] & RI_REV) != 0;
+                        if (head) {
+                            int mq = (int)((info[k] >> RI_MAPQ_SHIFT) & 0xff);
+                            ss.put('^'); ss.put((char)(mq > 93 ? 126 : mq + 33));
                         }
+                        int qpos = p - rpos[k];
+                        int c = (sv[k] >> ((~qpos & 1) << 2)) & 0xf;
+                        if (c == rbcode) c = 0;
+                        ss.put(base_char_fast(c, rev));
+                        if (tail) ss.put('$');
+                        sq.put((char)(qv[k] + 33 < 126 ? qv[k] + 33 : 126));
                     }
                 } else {
                     // generic entry (uniform branch: the read is the same for every lane)
@@ -585,7 +602,7 @@ __global__ void __launch_bounds__(256) k_mplp_len_fast(StaWinDev W, MplpDevPar P
 
 template <bool LDS>
 __device__ __forceinline__ void emit_column_fast(const StaWinDev &W, const MplpDevPar &P, const uint2 *colinfo, int64_t ncols, int64_t col,
-                                                 int p0, int plast, int p, bool exists, Sink<LDS> &s)
+                                                 int p0, int plast, int p, bool exists, Sink<LDS> &s, uint32_t dump)
 {
     int64_t apos = W.origin + p;
     int rbcode = -1;
@@ -605,18 +622,23 @@ __device__ __forceinline__ void emit_column_fast(const StaWinDev &W, const MplpD
         uint2 ci = exists ? colinfo[(int64_t)f * ncols + col] : make_uint2(0, 0);
         uint32_t cnt = ci.x, seq_len = ci.y;
         Sink<LDS> ss = s, sq = s;
+        uint32_t sl = seq_len ? seq_len : 1;
         if (exists) {
             s.put('\t'); s.put_dec(cnt); s.put('\t');
             ss = s;
-            uint32_t sl = seq_len ? seq_len : 1;
             sq = s; sq.cur += sl + 1; sq.g += sl + 1;
-            if (!cnt) { ss.put('*'); sq.put('*'); ss = s; sq = s; sq.cur += sl + 1; sq.g += sl + 1; }
-            // the tab between the two strings
-            Sink<LDS> st = s; st.cur += sl; st.g += sl; st.put('\t');
+        }
+        const bool walk = exists && cnt;
+        if (LDS && !walk) ss.cur = sq.cur = dump;       // lanes without entries: predicated writes land in the wave's dump bytes
+        uint32_t d0 = 0, d1 = 0, d2 = 0;
+        fast_walk<true, LDS>(R, W, P, p0, plast, p, walk, rbcode, rlo, rhi, d0, d1, d2, ss, sq);
+        if (exists) {
+            // separators and the '*' placeholders go in AFTER the walk (its last predicated write may sit on them)
+            Sink<LDS> st = s;
+            if (!cnt) { st.put('*'); st.put('\t'); st.put('*'); }
+            else { st.cur += sl; st.g += sl; st.put('\t'); }
             s.cur += sl + 1 + (cnt ? cnt : 1); s.g += sl + 1 + (cnt ? cnt : 1);
         }
-        uint32_t d0 = 0, d1 = 0, d2 = 0;
-        fast_walk<true, LDS>(R, W, P, p0, plast, p, exists && cnt, rbcode, rlo, rhi, d0, d1, d2, ss, sq);
     }
     if (exists) s.put('\n');
 }
@@ -642,11 +664,11 @@ __global__ void __launch_bounds__(256) k_mplp_emit_fast(StaWinDev W, MplpDevPar 
     uint64_t wbytes = o1 - o0;
     if (wbytes == 0) return;
     if (wbytes <= lds_cap) {
-        uint32_t slice = (lds_cap + 16 + 15) & ~15u;
+        uint32_t slice = (lds_cap + 48 + 15) & ~15u;       // text (+ up to 15 alignment bytes) + 16 dump bytes for predicated writes
         uint32_t base = (uint32_t)wid * slice;
         uint32_t mis = (uint32_t)((uintptr_t)(out + o0) & 15);
         Sink<true> s; s.g = nullptr; s.cur = base + mis + (uint32_t)(my0 - o0);
-        emit_column_fast<true>(W, P, colinfo, ncols, c0 + lane, p0, plast, p, exists, s);
+        emit_column_fast<true>(W, P, colinfo, ncols, c0 + lane, p0, plast, p, exists, s, base + slice - 8);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -662,7 +684,7 @@ __global__ void __launch_bounds__(256) k_mplp_emit_fast(StaWinDev W, MplpDevPar 
         if (done + lane < n) dst[done + lane] = lds_text[base + mis + done + lane];
     } else {
         Sink<false> s; s.cur = 0; s.g = out + my0;
-        emit_column_fast<false>(W, P, colinfo, ncols, c0 + lane, p0, plast, p, exists, s);
+        emit_column_fast<false>(W, P, colinfo, ncols, c0 + lane, p0, plast, p, exists, s, 0);
     }
 }
 
@@ -698,7 +720,10 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
     int64_t nwaves = (ncols + 63) / 64;
     int64_t nb = (nwaves + wpb - 1) / wpb;
     if (!((uint32_t)p.flag & EXTRA_MASK) && colinfo) {
-        hipLaunchKernelGGL(k_mplp_emit_fast, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, make_par(p, w.tlen), offs, colinfo, out, lds_cap);
+        uint32_t fslice = (lds_cap + 48 + 15) & ~15u;      // must match k_mplp_emit_fast
+        int fw = 4 * fslice <= 65536 ? 4 : (2 * fslice <= 65536 ? 2 : 1);
+        int64_t fnb = (nwaves + fw - 1) / fw;
+        hipLaunchKernelGGL(k_mplp_emit_fast, dim3((unsigned)fnb), dim3(64 * fw), (size_t)fw * fslice, s, w, make_par(p, w.tlen), offs, colinfo, out, lds_cap);
         return;
     }
     hipLaunchKernelGGL(k_mplp_emit, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, make_par(p, w.tlen), offs, out, lds_cap);

@@ -28,6 +28,17 @@ struct MplpDevPar {
 __constant__ char c_nt_lc[17] = ",acmgrsvtwyhkdbn";
 __constant__ char c_nt_uc[17] = ".ACMGRSVTWYHKDBN";
 __constant__ char c_nt16_str[17] = "=ACMGRSVTWYHKDBN";
+// seq_nt16_table (hts.c): character -> 4-bit code, 15 for anything else (a table: the switch in nt16_from_char costs ~300
+// scalar instructions of exec-mask juggling per wave when every lane holds a different character)
+__constant__ unsigned char c_nt16_of_char[256] = {
+    15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15,
+    15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15,  1, 2, 4, 8, 15,15,15,15, 15,15,15,15, 15, 0,15,15,
+    15, 1,14, 2, 13,15,15, 4, 11,15,15,12, 15, 3,15,15, 15,15, 5, 6,  8,15, 7, 9, 15,10,15,15, 15,15,15,15,
+    15, 1,14, 2, 13,15,15, 4, 11,15,15,12, 15, 3,15,15, 15,15, 5, 6,  8,15, 7, 9, 15,10,15,15, 15,15,15,15,
+    15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15,
+    15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15,
+    15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15,
+    15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15 };
 
 #define EXTRA_MASK (STA_MPLP_PRINT_MAPQ_CHAR | STA_MPLP_PRINT_QPOS | STA_MPLP_PRINT_QNAME | STA_MPLP_PRINT_FLAG | \
                     STA_MPLP_PRINT_RNAME | STA_MPLP_PRINT_POS | STA_MPLP_PRINT_MAPQ | STA_MPLP_PRINT_PNEXT | \
@@ -449,6 +460,10 @@ __global__ void __launch_bounds__(256) k_mplp_emit(StaWinDev W, MplpDevPar P, co
 //    reads ONCE and writes the base string and the quality string at two cursors.
 // Non-simple reads (indels, clips, pads, ref skips) take the generic per-entry path inline.
 
+// Pointers that reach a kernel through W.files[] (a struct read from memory) are "generic" to the compiler, which then
+// emits flat_load (slower, and it couples vmcnt with lgkmcnt).  They always point to HBM: say so.
+#define GPTR(T, p) ((const __attribute__((address_space(1))) T *)(p))
+
 __device__ __forceinline__ int rl_i(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
 __device__ __forceinline__ uint32_t rl_u(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
 
@@ -469,13 +484,15 @@ __device__ __forceinline__ void fast_walk(const StaReadsDev &R, const StaWinDev 
 {
     const int lane = threadIdx.x & 63;
     const bool ends = !P.no_ends;
+    const auto g_info = GPTR(uint32_t, R.info); const auto g_pos = GPTR(int32_t, R.pos); const auto g_end = GPTR(int32_t, R.end);
+    const auto g_b8 = GPTR(uint32_t, R.base_off8); const auto g_qual = GPTR(uint8_t, R.qual); const auto g_seq = GPTR(uint8_t, R.seq);
     for (int64_t b0 = rlo; b0 < rhi; b0 += 64) {
         const int64_t ri = b0 + lane;
         const bool ok = ri < rhi;
-        const uint32_t v_info = ok ? R.info[ri] : 0u;
-        const int v_pos = ok ? R.pos[ri] : 0;
-        const int v_end = ok ? R.end[ri] : 0;
-        const uint32_t v_b8 = ok ? R.base_off8[ri] : 0u;
+        const uint32_t v_info = ok ? g_info[ri] : 0u;
+        const int v_pos = ok ? g_pos[ri] : 0;
+        const int v_end = ok ? g_end[ri] : 0;
+        const uint32_t v_b8 = ok ? g_b8[ri] : 0u;
         unsigned long long live = __ballot(ok && (v_info & RI_KEEP) && v_end > p0 && v_pos <= plast);
         while (live) {
             bool valid[4], cov[4];
@@ -493,8 +510,8 @@ __device__ __forceinline__ void fast_walk(const StaReadsDev &R, const StaWinDev 
                 if (cov[k] && (info[k] & RI_SIMPLE)) {
                     uint64_t boff = (uint64_t)b8[k] << 3;
                     int qpos = p - rpos[k];
-                    qv[k] = R.qual[boff + (uint64_t)qpos];
-                    if (EMIT) sv[k] = R.seq[(boff >> 1) + (uint64_t)(qpos >> 1)];
+                    qv[k] = g_qual[boff + (uint64_t)qpos];
+                    if (EMIT) sv[k] = g_seq[(boff >> 1) + (uint64_t)(qpos >> 1)];
                 }
             }
 #pragma unroll
@@ -613,7 +630,7 @@ __device__ __forceinline__ void emit_column_fast(const StaWinDev &W, const MplpD
         s.put('\t');
         char rc = (W.ref && apos < W.ref_len) ? W.ref[apos] : 'N';
         s.put(rc);
-        if (W.ref) rbcode = apos < W.ref_len ? nt16_from_char((unsigned char)rc) : 15;
+        if (W.ref) rbcode = apos < W.ref_len ? (int)c_nt16_of_char[(unsigned char)rc] : 15;
     }
     for (int f = 0; f < W.nfiles; ++f) {
         const StaReadsDev &R = W.files[f];

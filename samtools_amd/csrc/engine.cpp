@@ -49,6 +49,10 @@ struct ProfPending { std::string name; hipEvent_t a, b; };
 struct sta_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;        // second stream: the few band-8 BAQ groups run beside the band-7 kernels
+    hipEvent_t side_done = nullptr;
+    hipStream_t pipe_stream = nullptr; // BAQ forward/backward software pipeline
+    std::vector<hipEvent_t> pipe_ev;
     std::string err;
     std::map<int32_t, RefSeq> refs;
     // current window
@@ -58,7 +62,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch, baq_scratch2;
     StaWinDev wd{};
     // plan state
     int planned = 0;   // 1 mpileup, 2 depth, 3 plp entries
@@ -95,14 +99,14 @@ hipEvent_t get_event(sta_engine *e)
     hipEvent_t ev; hipEventCreate(&ev); return ev;
 }
 struct ProfScope {
-    sta_engine *e; const char *name; hipEvent_t a{}, b{};
-    ProfScope(sta_engine *e_, const char *n) : e(e_), name(n)
+    sta_engine *e; const char *name; hipEvent_t a{}, b{}; hipStream_t st;
+    ProfScope(sta_engine *e_, const char *n, hipStream_t on = nullptr, bool use_on = false) : e(e_), name(n), st(use_on ? on : e_->stream)
     {
-        if (e->prof_on) { a = get_event(e); b = get_event(e); hipEventRecord(a, e->stream); }
+        if (e->prof_on) { a = get_event(e); b = get_event(e); hipEventRecord(a, st); }
     }
     ~ProfScope()
     {
-        if (e->prof_on) { hipEventRecord(b, e->stream); e->pending.push_back(ProfPending{ name, a, b }); }
+        if (e->prof_on) { hipEventRecord(b, st); e->pending.push_back(ProfPending{ name, a, b }); }
     }
 };
 void prof_drain(sta_engine *e)
@@ -164,8 +168,12 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->maxcnt_scratch, &e->baq_scratch };
+                      &e->out, &e->diff, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2 };
     for (DevBuf *b : all) b->release();
+    if (e->side) hipStreamDestroy(e->side);
+    if (e->pipe_stream) hipStreamDestroy(e->pipe_stream);
+    for (auto ev : e->pipe_ev) hipEventDestroy(ev);
+    if (e->side_done) hipEventDestroy(e->side_done);
     for (auto &p : e->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     delete e;
@@ -363,18 +371,73 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                     need = sta_baq_band_scratch_bytes(d.n, (int)c.max_lq_fast, &gpl);
                     if (e->baq_scratch.ensure(need + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ scratch) failed");
                 }
-                for (int cls = 0; cls < 2; ++cls) {
-                    // class 0: band width 7, reads taken in place; class 1: band width 8, through the list
-                    int64_t items = cls == 0 ? (c.n_baq_fast ? d.n : 0) : (c.n_baq_bw8 ? (int64_t)n_list : 0);
-                    int64_t ngroups = (items + 63) / 64;
-                    for (int64_t g0 = 0; g0 < ngroups; g0 += gpl) {
-                        int64_t ng = ngroups - g0 < gpl ? ngroups - g0 : gpl;
-                        for (int pass = 0; pass < 2; ++pass) {
-                            ProfScope ps(e, cls == 0 ? (pass ? "baq_bwd" : "baq_fwd") : (pass ? "baq8_bwd" : "baq8_fwd"));
-                            sta_launch_baq_band(s, d, e->wd, e->baq_scratch.p, (int)c.max_lq_fast, cls == 0 ? 7 : 8, g0, ng, cls, pass);
+                // class 1 (band width 8, through the list: a few dozen groups, latency bound) runs on a side stream beside
+                // class 0 (band width 7, reads in place) when both exist; the stream was synchronised above, so the side
+                // stream may start at once, and the main stream waits for it before the qualities are used
+                const size_t slot_bytes = need / (size_t)(gpl > 0 ? gpl : 1);
+                const int64_t groups8 = c.n_baq_bw8 ? ((int64_t)n_list + 63) / 64 : 0;
+                bool side = c.n_baq_fast && groups8 > 0 && groups8 <= 4096 && !getenv("STA_BAQ_NO_SIDE_STREAM");
+                char *side_scratch = nullptr;
+                if (side) {
+                    size_t extra = (size_t)groups8 * slot_bytes;
+                    if (e->baq_scratch2.ensure(extra + 64)) { (void)hipGetLastError(); side = false; }
+                    else side_scratch = (char *)e->baq_scratch2.p;
+                    if (side && !e->side) {
+                        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->side_done, hipEventDisableTiming) != hipSuccess) {
+                            (void)hipGetLastError(); side = false;
                         }
                     }
                 }
+                for (int cls = 1; cls >= 0; --cls) {
+                    // class 0: band width 7, reads taken in place; class 1: band width 8, through the list
+                    int64_t items = cls == 0 ? (c.n_baq_fast ? d.n : 0) : (c.n_baq_bw8 ? (int64_t)n_list : 0);
+                    int64_t ngroups = (items + 63) / 64;
+                    const bool on_side = side && cls == 1;
+                    hipStream_t st = on_side ? e->side : s;
+                    // class 0 can be software-pipelined over two streams (STA_BAQ_PIPE_GROUPS=n: the backward kernel of chunk k,
+                    // read bound, beside the forward kernel of chunk k+1, write bound).  Off by default: measured 10-20 %
+                    // SLOWER on MI355X (16.3 ms -> 18.0-20.0 ms per step at n = 3072..768), the two kernels only share the chip.
+                    int64_t pipe = 0;
+                    if (cls == 0 && ngroups <= gpl) {
+                        const char *ev = getenv("STA_BAQ_PIPE_GROUPS");
+                        pipe = ev ? atoll(ev) : 0;
+                        if (pipe <= 0 || ngroups < 2 * pipe) pipe = 0;
+                        if (pipe && !e->pipe_stream) {
+                            if (hipStreamCreateWithFlags(&e->pipe_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); pipe = 0; }
+                        }
+                    }
+                    if (pipe) {
+                        int64_t nchunk = (ngroups + pipe - 1) / pipe;
+                        while ((int64_t)e->pipe_ev.size() < nchunk + 1) {
+                            hipEvent_t ev; if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(e, STA_ERR_HIP, "hipEventCreate failed");
+                            e->pipe_ev.push_back(ev);
+                        }
+                        hipEvent_t t0{}, t1{};
+                        if (e->prof_on) { t0 = get_event(e); t1 = get_event(e); hipEventRecord(t0, s); }
+                        for (int64_t k = 0; k < nchunk; ++k) {
+                            int64_t g0 = k * pipe, ng = ngroups - g0 < pipe ? ngroups - g0 : pipe;
+                            const size_t off = (size_t)g0 * slot_bytes;
+                            sta_launch_baq_band(s, d, e->wd, (char *)e->baq_scratch.p + off, (int)c.max_lq_fast, 7, g0, ng, 0, 0);
+                            HIPCHK(hipEventRecord(e->pipe_ev[(size_t)k], s));
+                            HIPCHK(hipStreamWaitEvent(e->pipe_stream, e->pipe_ev[(size_t)k], 0));
+                            sta_launch_baq_band(e->pipe_stream, d, e->wd, (char *)e->baq_scratch.p + off, (int)c.max_lq_fast, 7, g0, ng, 0, 1);
+                        }
+                        HIPCHK(hipEventRecord(e->pipe_ev[(size_t)nchunk], e->pipe_stream));
+                        HIPCHK(hipStreamWaitEvent(s, e->pipe_ev[(size_t)nchunk], 0));
+                        if (e->prof_on) { hipEventRecord(t1, s); e->pending.push_back(ProfPending{ "baq_fwd+bwd_pipelined", t0, t1 }); }
+                        continue;
+                    }
+                    int64_t step = on_side ? ngroups : gpl;
+                    for (int64_t g0 = 0; g0 < ngroups; g0 += step) {
+                        int64_t ng = ngroups - g0 < step ? ngroups - g0 : step;
+                        for (int pass = 0; pass < 2; ++pass) {
+                            ProfScope ps(e, cls == 0 ? (pass ? "baq_bwd" : "baq_fwd") : (pass ? "baq8_bwd" : "baq8_fwd"), st, true);
+                            sta_launch_baq_band(st, d, e->wd, on_side ? (void *)side_scratch : e->baq_scratch.p, (int)c.max_lq_fast, cls == 0 ? 7 : 8, g0, ng, cls, pass);
+                        }
+                    }
+                    if (on_side) HIPCHK(hipEventRecord(e->side_done, e->side));
+                }
+                if (side) HIPCHK(hipStreamWaitEvent(s, e->side_done, 0));
             }
             if (c.n_baq_general && n_list) {
                 size_t need = sta_baq_scratch_bytes(d.n, (int)c.max_lq, (int)c.max_bw);

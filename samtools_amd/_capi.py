@@ -117,6 +117,10 @@ _PROTOS = {
     "sta_profile_enable": (None, [_P, C.c_int]),
     "sta_profile_reset": (None, [_P]),
     "sta_profile_get": (C.c_int, [_P, C.POINTER(KernelTime), C.c_int]),
+    "sta_plp_plan": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(PlanInfo)]),
+    "sta_plp_emit": (C.c_int, [_P, _P, C.c_uint64]),
+    "sta_fetch_col_offsets": (C.c_int, [_P, _P, C.c_uint64]),
+    "sta_fetch_read_state": (C.c_int, [_P, C.c_int32, _P, _P]),
     "sta_main_mpileup": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_main_depth": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
 }

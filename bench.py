@@ -162,23 +162,47 @@ def main():
     info = plan()
     out_bytes = int(info.out_bytes)
     piled = int(info.piled_bases)
-    cap = out_bytes + 4096
-    out_t = torch.empty(cap, dtype=torch.uint8, device=dev)
     from samtools_amd import shard
+    sizes = recv = None
+    cap = out_bytes + 4096
+    if dist is not None:
+        sizes = shard.exchange_sizes(out_bytes, dev)      # once: the synthetic window is the same every step
+        cap = max(sizes) + 4096                            # every rank's buffers can be sent padded to the largest piece
+    out_t = torch.empty(cap, dtype=torch.uint8, device=dev)
+
+    # N > 1: the text of step k is gathered on rank 0 (ONE RCCL gather per step) while step k+1 computes: two output
+    # buffers, asynchronous gather on RCCL's own stream, sizes exchanged once (the synthetic window is the same every step)
+    n_buf = 2 if dist is not None else 1
+    out_bufs = [out_t] + [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(n_buf - 1)]
+    pending = [None] * n_buf
+    if dist is not None and rank == 0:
+        recv = [[torch.empty(max(sizes), dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(n_buf)]
+    step_no = [0]
 
     def step():
+        i = step_no[0] % n_buf
+        step_no[0] += 1
+        if pending[i] is not None:
+            pending[i].wait()              # the buffer's previous gather must have left it
+            pending[i] = None
         plan()
         if kind == "mpileup":
-            eng.mpileup_emit(out_t.data_ptr(), cap)
+            eng.mpileup_emit(out_bufs[i].data_ptr(), cap)
         else:
-            eng.depth_emit(out_t.data_ptr(), cap)
+            eng.depth_emit(out_bufs[i].data_ptr(), cap)
         if dist is not None:
-            # the single collective of the path: per-window column text -> rank 0 over RCCL/xGMI
-            # (one 8-byte size all-gather + one gather of the text; samtools_amd/shard.py)
-            shard.gather_text(out_t[:out_bytes], dst=0)
+            # the single collective of the path: per-window column text -> rank 0 over RCCL/xGMI (samtools_amd/shard.py)
+            pending[i] = shard.gather_text(out_bufs[i], dst=0, sizes=sizes, recv=recv[i] if recv else None, async_op=True)
+
+    def drain():
+        for i in range(n_buf):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
 
     for _ in range(a.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -188,6 +212,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    drain()                                # every gather of the timed steps has completed inside the timed region
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -38,27 +38,61 @@ def halo_columns(max_ref_span: int) -> int:
     return 2 * int(max_ref_span)
 
 
-def gather_text(local, dst: int = 0, group=None):
+def exchange_sizes(n_local: int, device, group=None) -> List[int]:
+    """Every rank's text size (one 8-byte all_gather)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    n = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    return [int(s.item()) for s in sizes]
+
+
+class PendingGather:
+    """An in-flight gather: wait() returns the per-rank byte tensors on the destination rank (None elsewhere)."""
+
+    def __init__(self, work, recv, sizes):
+        self._work, self._recv, self._sizes = work, recv, sizes
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        if self._recv is None:
+            return None
+        return [r[:s] for r, s in zip(self._recv, self._sizes)]
+
+
+def gather_text(local, dst: int = 0, group=None, sizes: Sequence[int] = None, recv=None, async_op: bool = False):
     """Collect every rank's byte tensor (uint8, 1-D, on the backend's device) on `dst` in rank order.
 
-    One size all_gather (8 bytes per rank) and ONE gather of the text, padded to the largest piece.
-    Returns the list of per-rank tensors on `dst` (trimmed to their true sizes), None elsewhere."""
+    ONE gather of the text, padded to the largest piece; when `sizes` (every rank's byte count) is not supplied it is
+    obtained with one 8-byte all_gather first.  `local` may be longer than its entry in `sizes` (a reusable buffer).
+    `recv` optionally supplies the destination's receive buffers (world tensors of >= max(sizes) bytes) so that a
+    steady-state loop allocates nothing.  With async_op=True a PendingGather is returned at once: the copy runs on
+    the backend's own stream and overlaps whatever the caller launches next (the next window's kernels)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        sizes = exchange_sizes(local.numel(), local.device, group)
+    sizes = [int(x) for x in sizes]
     cap = max(max(sizes), 1)
-    buf = local
-    if local.numel() != cap:
+    if local.numel() >= cap:
+        buf = local[:cap]
+    else:
         buf = torch.zeros(cap, dtype=torch.uint8, device=local.device)
         buf[:local.numel()] = local
-    recv = [torch.empty(cap, dtype=torch.uint8, device=local.device) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, recv, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return [r[:s] for r, s in zip(recv, sizes)]
+    if rank == dst:
+        if recv is None:
+            recv = [torch.empty(cap, dtype=torch.uint8, device=local.device) for _ in range(world)]
+        recv = [r[:cap] for r in recv]
+    else:
+        recv = None
+    work = dist.gather(buf, recv, dst=dst, group=group, async_op=async_op)
+    pending = PendingGather(work if async_op else None, recv, sizes)
+    return pending if async_op else pending.wait()

@@ -30,10 +30,19 @@ def _worker(rank, world, port, contigs, wcols, q):
     text = b"".join(fake_window_text(*wins[i]) for i in mine)
     local = torch.frombuffer(bytearray(text), dtype=torch.uint8) if text else torch.zeros(0, dtype=torch.uint8)
     parts = shard.gather_text(local, dst=0)
+    # the steady-state form bench.py uses: sizes exchanged once, reusable padded buffers, asynchronous gather
+    sizes = shard.exchange_sizes(local.numel(), local.device)
+    cap = max(max(sizes), 1)
+    padded = torch.zeros(cap + 5, dtype=torch.uint8)
+    padded[:local.numel()] = local
+    recv = [torch.empty(cap, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+    pend = [shard.gather_text(padded, dst=0, sizes=sizes, recv=recv, async_op=True) for _ in range(2)]
+    parts2 = [p.wait() for p in pend][-1]
     if rank == 0:
+        assert [bytes(p.numpy().tobytes()) for p in parts] == [bytes(p.numpy().tobytes()) for p in parts2]
         q.put(b"".join(bytes(p.numpy().tobytes()) for p in parts))
     else:
-        assert parts is None
+        assert parts is None and parts2 is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -313,6 +313,9 @@ __device__ __forceinline__ double emis_sel(int rc, int qyc, double ematch, doubl
     return rc > 3 ? hi : e;
 }
 #define FLD(w, j) ((int)((uint32_t)((w) >> (3 * (j))) & 7u))
+// (M, I) of one band cell travel together: 16 bytes per lane and store (the forward kernel is store-ISSUE bound, so half as
+// many, twice as wide stores; 1 KiB per wave access)
+typedef double baq_d2 __attribute__((ext_vector_type(2)));
 
 struct BaqRd {           // what both kernels need to know about one read
     const uint32_t *cigar; int n_cigar, lq, l_ref;
@@ -388,9 +391,9 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
     const int64_t r = baq_pick(R, g0 + gl, lane, use_list, BW);
     if (r < 0) return;
     double *slot = scratch + (size_t)gl * slot_dbl;
-    double *F = slot + lane;
+    baq_d2 *F = reinterpret_cast<baq_d2 *>(slot) + lane;
     double *S = slot + (size_t)lq_cap * (2 * NB) * 64 + lane;
-#define Frow(i, c) F[((size_t)((i) - 1) * (2 * NB) + (c)) * 64]
+#define Fcell(i, j) F[((size_t)((i) - 1) * NB + (j)) * 64]
     const BaqRd d = baq_rd(R, W, r);
     const int lq = d.lq, l_ref = d.l_ref;
     const uint8_t *qual = d.qual, *seq = d.seq; const char *ref = d.ref;
@@ -422,7 +425,7 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
 #pragma unroll
         for (int j = 0; j < NB; ++j) { M[j] /= sum; I[j] /= sum; }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { __builtin_nontemporal_store(M[j], &Frow(1, 2 * j)); __builtin_nontemporal_store(I[j], &Frow(1, 2 * j + 1)); }
+        for (int j = 0; j < NB; ++j) { baq_d2 v = { M[j], I[j] }; __builtin_nontemporal_store(v, &Fcell(1, j)); }
     }
     // software pipeline of the per-row inputs: raw bytes two rows ahead, converted one row ahead
     int c_sb = 0, c_rc = 7;                   // converted, for the next row
@@ -459,7 +462,7 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
 #pragma unroll
         for (int j = 0; j < NB; ++j) { M[j] *= inv; I[j] *= inv; D[j] *= inv; }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { __builtin_nontemporal_store(M[j], &Frow(i, 2 * j)); __builtin_nontemporal_store(I[j], &Frow(i, 2 * j + 1)); }
+        for (int j = 0; j < NB; ++j) { baq_d2 v = { M[j], I[j] }; __builtin_nontemporal_store(v, &Fcell(i, j)); }
     }
     {   // s[l_query+1]
         double sum = 0.;
@@ -467,7 +470,7 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
         for (int j = 0; j < NB; ++j) sum += M[j] * p.sM + I[j] * p.sI;
         S[(size_t)(lq + 1) * 64] = sum;
     }
-#undef Frow
+#undef Fcell
 }
 
 #ifndef BAQ_PREFETCH_F
@@ -489,10 +492,10 @@ __global__ void __launch_bounds__(256, BAQ_PREFETCH_F ? 2 : 3) k_baq_bwd(StaRead
     const int64_t r = baq_pick(R, g0 + gl, lane, use_list, BW);
     if (r < 0) return;
     double *slot = scratch + (size_t)gl * slot_dbl;
-    const double *F = slot + lane;
+    const baq_d2 *F = reinterpret_cast<const baq_d2 *>(slot) + lane;
     const double *S = slot + (size_t)lq_cap * (2 * NB) * 64 + lane;
     int32_t *P = reinterpret_cast<int32_t *>(slot + (size_t)lq_cap * (2 * NB) * 64 + (size_t)(lq_cap + 2) * 64) + lane;
-#define Frow(i, c) F[((size_t)((i) - 1) * (2 * NB) + (c)) * 64]
+#define Fcell(i, j) F[((size_t)((i) - 1) * NB + (j)) * 64]
     const BaqRd d = baq_rd(R, W, r);
     const int lq = d.lq, l_ref = d.l_ref;
     uint8_t *qual = d.qual; const uint8_t *seq = d.seq; const char *ref = d.ref;
@@ -524,7 +527,7 @@ __global__ void __launch_bounds__(256, BAQ_PREFETCH_F ? 2 : 3) k_baq_bwd(StaRead
         double fM[NB], fI[NB];
 #if BAQ_PREFETCH_F
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { fM[j] = __builtin_nontemporal_load(&Frow(i, 2 * j)); fI[j] = __builtin_nontemporal_load(&Frow(i, 2 * j + 1)); }
+        for (int j = 0; j < NB; ++j) { baq_d2 v = __builtin_nontemporal_load(&Fcell(i, j)); fM[j] = v.x; fI[j] = v.y; }
 #endif
         if (i < lq) {
             const float qf = c_qf; const int sb = c_sb; const int nrc = c_rc; const double si = c_s;
@@ -559,7 +562,7 @@ __global__ void __launch_bounds__(256, BAQ_PREFETCH_F ? 2 : 3) k_baq_bwd(StaRead
         // MAP for row i
 #if !BAQ_PREFETCH_F
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { fM[j] = __builtin_nontemporal_load(&Frow(i, 2 * j)); fI[j] = __builtin_nontemporal_load(&Frow(i, 2 * j + 1)); }
+        for (int j = 0; j < NB; ++j) { baq_d2 v = __builtin_nontemporal_load(&Fcell(i, j)); fM[j] = v.x; fI[j] = v.y; }
 #endif
         double sum = 0., max = 0.;
         int max_k = -1;
@@ -609,7 +612,7 @@ __global__ void __launch_bounds__(256, BAQ_PREFETCH_F ? 2 : 3) k_baq_bwd(StaRead
             } else if (op == CG_D) xx += l;
         }
     }
-#undef Frow
+#undef Fcell
 }
 
 // ================================================================================================

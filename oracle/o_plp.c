@@ -118,6 +118,7 @@ struct oplp {
     oplp_auto_f func;
     void *data;
     ohash_t *overlaps;
+    int (*construct)(void *data, const orec_t *b, void *cd);   /* bam_plp_constructor hook (cd is not modelled: NULL) */
 };
 
 /* ---- cigar_iref2iseq_set / _next (Appendix A.3.1) ---- */
@@ -429,6 +430,7 @@ int oplp_push(oplp_t *iter, const orec_t *b)
         iter->max_tid = b->tid; iter->max_pos = iter->tail->beg;
         if (iter->tail->end > iter->pos || iter->tail->b.tid > iter->tid) {
             lbnode_t *next = mp_alloc(&iter->mp);
+            if (iter->construct && iter->construct(iter->data, &iter->tail->b, NULL) < 0) { mp_free(&iter->mp, next); iter->error = 1; return -1; }
             if (overlap_push(iter, iter->tail) < 0) {
                 mp_free(&iter->mp, next);
                 iter->error = 1; return -1;
@@ -541,6 +543,11 @@ void omplp_destroy(omplp_t *iter)
 void omplp_set_maxcnt(omplp_t *iter, int maxcnt)
 {
     for (int i = 0; i < iter->n; ++i) iter->iter[i]->maxcnt = maxcnt;
+}
+void oplp_constructor(oplp_t *iter, int (*func)(void *data, const orec_t *b, void *cd)) { iter->construct = func; }
+void omplp_constructor(omplp_t *iter, int (*func)(void *data, const orec_t *b, void *cd))
+{
+    for (int i = 0; i < iter->n; ++i) iter->iter[i]->construct = func;
 }
 int omplp_init_overlaps(omplp_t *iter)
 {

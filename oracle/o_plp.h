@@ -35,6 +35,9 @@ omplp_t *omplp_init(int n, oplp_auto_f func, void **data);
 void omplp_destroy(omplp_t *iter);
 void omplp_set_maxcnt(omplp_t *iter, int maxcnt);
 int omplp_init_overlaps(omplp_t *iter);
+/* bam_plp_constructor / bam_mplp_constructor: called when a read enters the pileup (cd is passed as NULL) */
+void oplp_constructor(oplp_t *iter, int (*func)(void *data, const orec_t *b, void *cd));
+void omplp_constructor(omplp_t *iter, int (*func)(void *data, const orec_t *b, void *cd));
 int omplp_auto(omplp_t *iter, int *tid, hpos_t *pos, int *n_plp, const opileup1_t **plp);
 
 /* bam_plp_insertion: inserted sequence following p (pads as '*'); returns

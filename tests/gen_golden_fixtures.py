@@ -8,7 +8,7 @@ than 16 KiB are stored gzip-compressed.  Run from the repo root in the build con
 
     python tests/gen_golden_fixtures.py
 
-Sources: /root/reference/test/mpileup/{*.sam,*.bam,*.fa,regions,xx.bed*,expected/*.out},
+Sources: /root/reference/test/bedcov/* (copied whole), /root/reference/test/mpileup/{*.sam,*.bam,*.fa,regions,xx.bed*,expected/*.out},
 /root/reference/test/dat/{mpileup.*,view.001.sam}, /root/reference/test/large_pos/*.
 """
 import gzip
@@ -47,6 +47,8 @@ def tokens_to_files(argstr, workdir):
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures are already committed")
+    for f in os.listdir(os.path.join(REF, "bedcov")):
+        copy(os.path.join(REF, "bedcov", f), os.path.join(OUT, "bedcov", f))
     inputs = set()
     for exp, args, post in regcases.MPILEUP + regcases.DEPTH + regcases.EXPECTED_FAIL:
         inputs.update(tokens_to_files(args, os.path.join(REF, "mpileup")))

@@ -6,6 +6,7 @@
 #include "../../include/samtools_amd.h"
 #include "../../include/samtools_amd_plp.h"
 #include "host_io.h"
+#include "bam1_from_rec.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,33 +20,13 @@ namespace {
 
 struct Src { std::unique_ptr<AlnReader> rd; Rec rec; };
 
-void rec_to_bam(const Rec &r, bam1_t *b)
-{
-    size_t lqn = r.qname.size() + 1;
-    size_t pad = (4 - (lqn & 3)) & 3;
-    size_t need = lqn + pad + r.cigar.size() * 4 + ((size_t)r.l_qseq + 1) / 2 + (size_t)r.l_qseq;
-    if (b->m_data < need) { b->data = (uint8_t *)realloc(b->data, need); b->m_data = (uint32_t)need; }
-    b->l_data = (int)need;
-    b->core.pos = r.pos; b->core.tid = r.tid; b->core.bin = 0; b->core.qual = r.mapq; b->core.l_extranul = (uint8_t)pad;
-    b->core.flag = r.flag; b->core.l_qname = (uint16_t)(lqn + pad); b->core.n_cigar = (uint32_t)r.cigar.size();
-    b->core.l_qseq = r.l_qseq; b->core.mtid = r.mtid; b->core.mpos = r.mpos; b->core.isize = r.isize;
-    uint8_t *p = b->data;
-    memcpy(p, r.qname.c_str(), lqn); p += lqn;
-    memset(p, 0, pad); p += pad;
-    if (!r.cigar.empty()) memcpy(p, r.cigar.data(), r.cigar.size() * 4);
-    p += r.cigar.size() * 4;
-    if (r.l_qseq) memcpy(p, r.seq.data(), ((size_t)r.l_qseq + 1) / 2);
-    p += ((size_t)r.l_qseq + 1) / 2;
-    if (r.l_qseq) memcpy(p, r.qual.data(), (size_t)r.l_qseq);
-}
-
 int read_cb(void *data, bam1_t *b)
 {
     Src *s = (Src *)data;
     int ret = s->rd->next(s->rec);
     if (ret == 0) return -1;
     if (ret < 0) return -2;
-    rec_to_bam(s->rec, b);
+    rec_to_bam1(s->rec, b);
     return 0;
 }
 

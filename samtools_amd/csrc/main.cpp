@@ -3,19 +3,21 @@
 #include "../../include/samtools_amd.h"
 extern "C" int sta_main_plpdump(int argc, char **argv);   // diagnostic client of the bam_plp_* surface (driver_plpdump.cpp)
 extern "C" int sta_main_bedcov(int argc, char **argv);    // bedcov.c column loop on the engine iterator (driver_bedcov.cpp)
+extern "C" int sta_main_coverage(int argc, char **argv);  // coverage.c tabular loop on the engine iterator (driver_coverage.cpp)
 #include <cstdio>
 #include <cstring>
 
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        fprintf(stderr, "Usage: samtools-amd <mpileup|depth|bedcov|plpdump> [options]\n%s\n", sta_version());
+        fprintf(stderr, "Usage: samtools-amd <mpileup|depth|bedcov|coverage|plpdump> [options]\n%s\n", sta_version());
         return 1;
     }
     if (strcmp(argv[1], "mpileup") == 0) return sta_main_mpileup(argc - 1, argv + 1);
     if (strcmp(argv[1], "depth") == 0) return sta_main_depth(argc - 1, argv + 1);
     if (strcmp(argv[1], "plpdump") == 0) return sta_main_plpdump(argc - 1, argv + 1);
     if (strcmp(argv[1], "bedcov") == 0) return sta_main_bedcov(argc - 1, argv + 1);
+    if (strcmp(argv[1], "coverage") == 0) return sta_main_coverage(argc - 1, argv + 1);
     fprintf(stderr, "[main] unrecognized command '%s'\n", argv[1]);
     return 1;
 }

@@ -8,7 +8,7 @@ than 16 KiB are stored gzip-compressed.  Run from the repo root in the build con
 
     python tests/gen_golden_fixtures.py
 
-Sources: /root/reference/test/bedcov/* (copied whole), /root/reference/test/mpileup/{*.sam,*.bam,*.fa,regions,xx.bed*,expected/*.out},
+Sources: /root/reference/test/bedcov/* and test/coverage/* (+ test/dat/sample.sam) copied whole, /root/reference/test/mpileup/{*.sam,*.bam,*.fa,regions,xx.bed*,expected/*.out},
 /root/reference/test/dat/{mpileup.*,view.001.sam}, /root/reference/test/large_pos/*.
 """
 import gzip
@@ -49,6 +49,9 @@ def main():
         sys.exit("reference tree not present; fixtures are already committed")
     for f in os.listdir(os.path.join(REF, "bedcov")):
         copy(os.path.join(REF, "bedcov", f), os.path.join(OUT, "bedcov", f))
+    for f in os.listdir(os.path.join(REF, "coverage")):
+        copy(os.path.join(REF, "coverage", f), os.path.join(OUT, "coverage", f))
+    copy(os.path.join(REF, "dat", "sample.sam"), os.path.join(OUT, "coverage", "sample.sam"))
     inputs = set()
     for exp, args, post in regcases.MPILEUP + regcases.DEPTH + regcases.EXPECTED_FAIL:
         inputs.update(tokens_to_files(args, os.path.join(REF, "mpileup")))

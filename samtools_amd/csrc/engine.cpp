@@ -447,6 +447,13 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             }
         }
     }
+    if (has_ref && p->capQ_thres > 10) {
+        // -C: after BAQ (it reads the adjusted qualities), before anything that looks at KEEP or the mapping quality
+        for (int f = 0; f < nf; ++f) {
+            ProfScope ps(e, "cap_mapq");
+            sta_launch_cap_mapq(s, e->files_h[(size_t)f], e->wd, p->capQ_thres, p->min_mq, ctr);
+        }
+    }
     if (do_maxcnt) {
         // exact replay of the -d cap, one file at a time (rare path)
         for (int f = 0; f < nf; ++f) {
@@ -500,7 +507,6 @@ int sta_mpileup_plan(sta_engine *e, const sta_mplp_params *p, sta_plan_info *inf
     if (!e || !p) return STA_ERR_ARG;
     if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
     hipSetDevice(e->device);
-    if (p->capQ_thres > 10) return fail(e, STA_ERR_UNSUPPORTED, "-C/--adjust-MQ is not supported by the device path");
     if (p->flag & (1 << 19)) return fail(e, STA_ERR_UNSUPPORTED, "--output-extra RNEXT is not supported by the device path");
     e->mp = *p;
     int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;

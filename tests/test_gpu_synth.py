@@ -61,3 +61,19 @@ def test_baq_kernels_agree_with_oracle(tmp_path, oracle_bin, product_bin, force_
     got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert got.returncode == 0, got.stderr.decode()[-500:]
     assert got.stdout == want
+
+
+@pytest.mark.parametrize("extra", [[], ["-q", "25"], ["-B"], ["-s", "--output-MQ"]])
+def test_adjust_mq_equals_oracle(tmp_path, oracle_bin, product_bin, extra):
+    """-C / --adjust-MQ (HTSlib sam_cap_mapq after BAQ; no reference golden uses it, so the oracle restatement is the
+    only checker): mismatch-rich synthetic reads and the reference's real-data fixture with soft clips."""
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=15000, depth=30, read_len=100, seed=81, paired=True, sub_rate=0.03, indel_rate=0.05)
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dat")
+    for args in (["mpileup", "-C", "50"] + extra + ["-f", fa, sam],
+                 ["mpileup", "-C", "40"] + extra + ["-f", os.path.join(g, "mpileup.ref.fa"), os.path.join(g, "mpileup.1.sam")]):
+        want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert got.returncode == 0, got.stderr.decode()[-500:]
+        assert got.stdout == want, args
+        assert want != subprocess.run([oracle_bin] + [a for a in args if a not in ("-C", "50", "40")], stdout=subprocess.PIPE,
+                                      stderr=subprocess.DEVNULL, check=True).stdout      # -C changes something in this data

@@ -61,7 +61,7 @@ extern "C" {
 #define STA_MPLP_PRINT_RNAME     (1 << 15)
 #define STA_MPLP_PRINT_POS       (1 << 16)
 #define STA_MPLP_PRINT_MAPQ      (1 << 17)
-#define STA_MPLP_PRINT_RNEXT     (1 << 19)
+#define STA_MPLP_PRINT_RNEXT     (1 << 19)   /* text comes from sta_reads.xcol_* column 0 */
 #define STA_MPLP_PRINT_PNEXT     (1 << 20)
 #define STA_MPLP_PRINT_RLEN      (1 << 24)
 #define STA_MPLP_PRINT_QPOS5     (1 << 26)
@@ -106,6 +106,13 @@ typedef struct sta_reads {
     const uint8_t *bq;           /* optional BQ:Z values ('@' = 64 where absent), NULL if no read has one */
     const char *names;           /* NUL-terminated qnames */
     uint64_t n_cigar_total, n_bases_total /* padded */, n_name_bytes;
+    /* optional host-formatted text columns (--output-extra RNEXT and aux tags, bam_plcmd.c:779-784,:798-852): n_xcols
+     * columns per read; the text of (read i, column c) is xcol_text[xcol_off[i*n_xcols+c] .. xcol_off[i*n_xcols+c+1]).
+     * Column 0 is RNEXT when STA_MPLP_PRINT_RNEXT is set, the tags follow in --output-extra order.  n_xcols = 0: none. */
+    int32_t n_xcols;
+    const uint32_t *xcol_off;    /* n_reads * n_xcols + 1 */
+    const char *xcol_text;
+    uint64_t n_xcol_bytes;
 } sta_reads;
 
 /* One window of reference columns on one contig, with every read (of every
@@ -136,6 +143,8 @@ typedef struct sta_mplp_params {
     int32_t flag;                /* STA_MPLP_* */
     int32_t no_ins, no_del, no_ends;
     int32_t has_fai;             /* a FASTA was given with -f (BAQ/ref column need it) */
+    int32_t n_tags;              /* aux-tag columns after the fixed extra columns (text staged in sta_reads.xcol_*) */
+    int32_t tag_sep;             /* --output-sep character between the entries of a tag column (',' by default) */
 } sta_mplp_params;
 
 /* subset of depth_opt (bam2depth.c:72-86) */

@@ -26,6 +26,7 @@ struct Conf {
     std::unique_ptr<Fasta> fai;
     std::unique_ptr<Bed> bed;
     std::set<std::string> rg_excl; bool has_rg_excl = false;
+    std::vector<std::string> tags; char sep = ',', empty = '*';      // --output-extra aux tags, --output-sep, --output-empty
     int64_t window_cols = 1 << 20, max_reads = 4 << 20;
 };
 
@@ -91,7 +92,8 @@ struct Runner {
         std::vector<sta_reads> views(nf);
         for (size_t f = 0; f < nf; ++f) {
             staged[f].clear();
-            if (reads) for (const Rec *r : (*reads)[f]) staged[f].add(*r, cb, conf.has_rg_excl ? &conf.rg_excl : nullptr);
+            XcolSpec xs; xs.rnext = (conf.p.flag & STA_MPLP_PRINT_RNEXT) != 0; xs.hdr = &readers[f]->header(); xs.n_tags = (int)conf.tags.size(); xs.empty = conf.empty;
+            if (reads) for (const Rec *r : (*reads)[f]) staged[f].add(*r, cb, conf.has_rg_excl ? &conf.rg_excl : nullptr, xs.n_cols() ? &xs : nullptr);
             staged[f].finish();
             views[f] = staged[f].view();
         }
@@ -210,7 +212,7 @@ struct Runner {
 void usage(FILE *fp)
 {
     fprintf(fp, "\nUsage: samtools mpileup [options] in1.bam [in2.bam [...]]\n"
-                "(MI355X engine; options as samtools 1.23.1 mpileup except -M, -C, -X and CRAM input)\n");
+                "(MI355X engine; options as samtools 1.23.1 mpileup except -M, -X and CRAM input)\n");
 }
 
 }  // namespace
@@ -271,7 +273,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
             // build_auxlist (bam_plcmd.c:240-287): column names the device path can print; tags are not supported
             static const struct { const char *n; int f; } cols[] = {
                 { "QNAME", STA_MPLP_PRINT_QNAME }, { "FLAG", STA_MPLP_PRINT_FLAG }, { "RNAME", STA_MPLP_PRINT_RNAME },
-                { "POS", STA_MPLP_PRINT_POS }, { "MAPQ", STA_MPLP_PRINT_MAPQ }, { "RNEXT", 1 << 19 },
+                { "POS", STA_MPLP_PRINT_POS }, { "MAPQ", STA_MPLP_PRINT_MAPQ }, { "RNEXT", STA_MPLP_PRINT_RNEXT },
                 { "PNEXT", STA_MPLP_PRINT_PNEXT }, { "RLEN", STA_MPLP_PRINT_RLEN } };
             std::string s = optarg; size_t p = 0;
             while (p <= s.size()) {
@@ -279,12 +281,17 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
                 std::string tag = s.substr(p, e - p);
                 bool hit = false;
                 for (auto &cn : cols) if (tag == cn.n) { mp.flag |= cn.f; hit = true; }
-                if (!hit && !tag.empty()) { fprintf(stderr, "samtools mpileup: --output-extra %s is not supported by the MI355X engine\n", tag.c_str()); return 1; }
+                // build_auxlist (bam_plcmd.c:270-282): anything else with two characters is an aux tag
+                if (!hit && !tag.empty()) {
+                    if (tag.size() != 2) fprintf(stderr, "[build_auxlist] tag '%s' has more than two characters or not supported\n", tag.c_str());
+                    else conf.tags.push_back(tag);
+                }
                 p = e + 1;
             }
             break;
         }
-        case 8: case 9: fprintf(stderr, "samtools mpileup: --output-sep/--output-empty need tag columns, which the MI355X engine does not support\n"); return 1;
+        case 8: conf.sep = optarg[0]; break;
+        case 9: conf.empty = optarg[0]; break;
         case 10: mp.no_ins++; break;
         case 11: break;
         case 12: mp.no_del++; break;
@@ -335,6 +342,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     else for (int i = optind; i < argc; ++i) fns.push_back(argv[i]);
     if (fns.empty()) { fprintf(stderr, "[mpileup] no input file/data given\n"); return 1; }
 
+    mp.n_tags = (int32_t)conf.tags.size(); mp.tag_sep = conf.sep;
     Runner run(conf);
     Samples sm;
     for (auto &fn : fns) {
@@ -342,6 +350,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
         auto r = AlnReader::open(fn, &err);
         if (!r) { fprintf(stderr, "[mpileup] failed to open %s: %s\n", fn.c_str(), strerror(errno ? errno : ENOENT)); return 1; }
         sm.add(fn, ignore_rg ? nullptr : &r->header().text);
+        if (!conf.tags.empty()) r->set_wanted_tags(conf.tags);
         run.readers.push_back(std::move(r));
     }
     run.h = &run.readers[0]->header();

@@ -28,13 +28,13 @@ struct DevBuf {
 
 struct FileBufs {
     // staged input copies (only used with STA_MEM_HOST)
-    DevBuf pos, flag, mapq, aux, lq, cig_off, base_off8, mtid, mpos, isize, name_off, cigar, seq, qual, bq, names;
+    DevBuf pos, flag, mapq, aux, lq, cig_off, base_off8, mtid, mpos, isize, name_off, cigar, seq, qual, bq, names, xoff, xtext;
     // workspace
     DevBuf qual_work, end, maxend, info, clip, chain;
     void release()
     {
         DevBuf *all[] = { &pos, &flag, &mapq, &aux, &lq, &cig_off, &base_off8, &mtid, &mpos, &isize, &name_off, &cigar,
-                          &seq, &qual, &bq, &names, &qual_work, &end, &maxend, &info, &clip, &chain };
+                          &seq, &qual, &bq, &names, &xoff, &xtext, &qual_work, &end, &maxend, &info, &clip, &chain };
         for (DevBuf *b : all) b->release();
     }
 };
@@ -237,6 +237,12 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
         rc |= upload(e, b.qual, r.qual, (size_t)r.n_bases_total, &d.qual_in, mem);
         if (r.bq) rc |= upload(e, b.bq, r.bq, (size_t)r.n_bases_total, &d.bq, mem); else d.bq = nullptr;
         rc |= upload(e, b.names, r.names, (size_t)r.n_name_bytes, &d.names, mem);
+        d.n_xcols = r.n_xcols > 0 && r.xcol_off && r.xcol_text ? r.n_xcols : 0;
+        d.xcol_off = nullptr; d.xcol_text = nullptr;
+        if (d.n_xcols) {
+            rc |= upload(e, b.xoff, r.xcol_off, n * (size_t)d.n_xcols + 1, &d.xcol_off, mem);
+            rc |= upload(e, b.xtext, r.xcol_text, (size_t)r.n_xcol_bytes, &d.xcol_text, mem);
+        }
         if (rc) return rc;
         // workspace
         if (b.end.ensure(n * 4 + 16) || b.maxend.ensure(n * 4 + 16) || b.info.ensure(n * 4 + 16) || b.clip.ensure(n * 4 + 16)
@@ -507,7 +513,11 @@ int sta_mpileup_plan(sta_engine *e, const sta_mplp_params *p, sta_plan_info *inf
     if (!e || !p) return STA_ERR_ARG;
     if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
     hipSetDevice(e->device);
-    if (p->flag & (1 << 19)) return fail(e, STA_ERR_UNSUPPORTED, "--output-extra RNEXT is not supported by the device path");
+    {
+        int need_x = ((p->flag & STA_MPLP_PRINT_RNEXT) ? 1 : 0) + (p->n_tags > 0 ? p->n_tags : 0);
+        for (auto &d : e->files_h)
+            if (need_x && d.n && d.n_xcols != need_x) return fail(e, STA_ERR_ARG, "RNEXT / tag columns requested but sta_reads.xcol_* does not hold them");
+    }
     e->mp = *p;
     int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
     // host-side bounds for the (rare) exact -d replay

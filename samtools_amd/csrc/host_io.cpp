@@ -28,6 +28,8 @@ inline bool is_refop(int op) { return op == 0 || op == 2 || op == 3 || op == 7 |
 }  // namespace
 
 struct AlnReader::Impl {
+    std::vector<std::string> want;   // aux tags to format (--output-extra)
+
     gzFile fp = nullptr;
     bool is_bam = false;
     std::vector<uint8_t> buf; size_t bp = 0, bl = 0; bool eof = false;
@@ -153,7 +155,9 @@ static void finish_rec(Rec &r)
     for (uint32_t c : r.cigar) if (is_refop((int)(c & 0xf))) r.rlen += (c >> 4);
 }
 
-static int parse_sam(const Header &h, std::string &line, Rec &r)
+static void tag_from_sam(const char *val, size_t n, char type, std::string &out);
+
+static int parse_sam(const Header &h, std::string &line, Rec &r, const std::vector<std::string> *want)
 {
     char *f[11]; size_t fl[11]; int nf = 0;
     char *p = &line[0], *e = p + line.size();
@@ -195,9 +199,13 @@ static int parse_sam(const Header &h, std::string &line, Rec &r)
     if (fl[10] == 1 && f[10][0] == '*') std::fill(r.qual.begin(), r.qual.end(), 0xff);
     else { if (fl[10] != l) return -2; for (size_t i = 0; i < l; ++i) r.qual[i] = (uint8_t)(f[10][i] - 33); }
     r.has_bq = r.has_zq = false; r.bq.clear(); r.rg.clear();
+    if (want) { r.tagtext.assign(want->size(), std::string()); r.tag_has.assign(want->size(), 0); }
     while (aux < e) {
         char *t = (char *)memchr(aux, '\t', (size_t)(e - aux));
         size_t n = t ? (size_t)(t - aux) : (size_t)(e - aux);
+        if (want && n >= 5 && aux[2] == ':' && aux[4] == ':')
+            for (size_t w = 0; w < want->size(); ++w)
+                if (!r.tag_has[w] && (*want)[w][0] == aux[0] && (*want)[w][1] == aux[1]) { r.tag_has[w] = 1; tag_from_sam(aux + 5, n - 5, aux[3], r.tagtext[w]); }
         if (n >= 5 && aux[2] == ':' && aux[4] == ':' && aux[3] == 'Z') {
             if (aux[0] == 'R' && aux[1] == 'G') r.rg.assign(aux + 5, n - 5);
             else if (aux[0] == 'B' && aux[1] == 'Q') { r.has_bq = true; r.bq.assign(aux + 5, aux + n); }
@@ -210,6 +218,16 @@ static int parse_sam(const Header &h, std::string &line, Rec &r)
     return 1;
 }
 
+// text of one aux value the way mpileup prints it (bam_plcmd.c:811-850): Z/H as is, integers in decimal, floats with %g
+// (HTSlib's kputd is approximated by %g, as in the oracle), A as the character, anything else (B arrays) as '*'
+static void tag_from_sam(const char *val, size_t n, char type, std::string &out)
+{
+    if (type == 'Z' || type == 'H' || type == 'A') out.assign(val, n);
+    else if (type == 'i') { char b[32]; snprintf(b, sizeof b, "%lld", strtoll(std::string(val, n).c_str(), nullptr, 10)); out = b; }
+    else if (type == 'f') { char b[64]; snprintf(b, sizeof b, "%g", (double)strtof(std::string(val, n).c_str(), nullptr)); out = b; }
+    else out = "*";
+}
+
 static int aux_size(int t) { switch (t) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; case 'd': return 8; } return 0; }
 
 static int parse_bam(AlnReader::Impl &im, Rec &r);
@@ -220,7 +238,7 @@ int AlnReader::next_raw(Rec &r)
     if (im.is_bam) return parse_bam(im, r);
     if (im.have_line) im.have_line = false;
     else { do { if (!im.getline(im.line)) return 0; } while (im.line.empty()); }
-    return parse_sam(hdr_, im.line, r);
+    return parse_sam(hdr_, im.line, r, im.want.empty() ? nullptr : &im.want);
 }
 
 static int parse_bam(AlnReader::Impl &im, Rec &r)
@@ -247,8 +265,28 @@ static int parse_bam(AlnReader::Impl &im, Rec &r)
     r.tid = refID; r.pos = pos; r.flag = flag; r.mtid = nref; r.mpos = npos; r.isize = tlen; r.l_qseq = l_seq;
     r.has_bq = r.has_zq = false; r.bq.clear(); r.rg.clear();
     const uint8_t *p = b + o, *e = b + bs;
+    const bool want = !im.want.empty();
+    if (want) { r.tagtext.assign(im.want.size(), std::string()); r.tag_has.assign(im.want.size(), 0); }
     while (p + 3 <= e) {
         int t = p[2]; const uint8_t *tag = p; p += 3;
+        if (want)
+            for (size_t w = 0; w < im.want.size(); ++w)
+                if (!r.tag_has[w] && im.want[w][0] == (char)tag[0] && im.want[w][1] == (char)tag[1]) {
+                    r.tag_has[w] = 1;
+                    std::string &out = r.tagtext[w];
+                    char nb[64];
+                    if (t == 'Z' || t == 'H') { const uint8_t *q = p; while (q < e && *q) ++q; out.assign((const char *)p, (size_t)(q - p)); }
+                    else if (t == 'A') out.assign(1, (char)p[0]);
+                    else if (t == 'c') { snprintf(nb, sizeof nb, "%d", (int)(int8_t)p[0]); out = nb; }
+                    else if (t == 'C') { snprintf(nb, sizeof nb, "%d", (int)p[0]); out = nb; }
+                    else if (t == 's') { int16_t v; memcpy(&v, p, 2); snprintf(nb, sizeof nb, "%d", (int)v); out = nb; }
+                    else if (t == 'S') { uint16_t v; memcpy(&v, p, 2); snprintf(nb, sizeof nb, "%d", (int)v); out = nb; }
+                    else if (t == 'i') { int32_t v; memcpy(&v, p, 4); snprintf(nb, sizeof nb, "%d", v); out = nb; }
+                    else if (t == 'I') { uint32_t v; memcpy(&v, p, 4); snprintf(nb, sizeof nb, "%u", v); out = nb; }
+                    else if (t == 'f') { float v; memcpy(&v, p, 4); snprintf(nb, sizeof nb, "%g", (double)v); out = nb; }
+                    else if (t == 'd') { double v; memcpy(&v, p, 8); snprintf(nb, sizeof nb, "%g", v); out = nb; }
+                    else out = "*";
+                }
         if (t == 'Z' || t == 'H') {
             const uint8_t *s = p; while (p < e && *p) ++p;
             if (t == 'Z') {
@@ -266,6 +304,8 @@ static int parse_bam(AlnReader::Impl &im, Rec &r)
     finish_rec(r);
     return 1;
 }
+
+void AlnReader::set_wanted_tags(const std::vector<std::string> &tags) { p_->want = tags; }
 
 int AlnReader::next(Rec &r)
 {

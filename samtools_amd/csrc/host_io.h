@@ -33,6 +33,9 @@ struct Rec {
     std::vector<uint8_t> bq;     // BQ:Z bytes (empty if absent)
     bool has_bq = false, has_zq = false;
     std::string rg;              // RG:Z value ("" if absent)
+    // --output-extra aux tags: text of every wanted tag as mpileup prints it (bam_plcmd.c:811-850); tag_has[i] = 0 if absent
+    std::vector<std::string> tagtext;
+    std::vector<char> tag_has;
     int64_t rlen = 0;            // reference span (bam_cigar2rlen)
     int64_t end() const { return pos + rlen; }
     int64_t endpos() const { int64_t l = (flag & 4) ? 0 : rlen; return pos + (l > 0 ? l : 1); }   // bam_endpos
@@ -44,6 +47,8 @@ public:
     ~AlnReader();
     const Header &header() const { return hdr_; }
     void set_region(int tid, int64_t beg, int64_t end) { has_reg_ = true; rtid_ = tid; rbeg_ = beg; rend_ = end; }
+    // two-character aux tags whose values next() should format into Rec::tagtext (in this order)
+    void set_wanted_tags(const std::vector<std::string> &tags);
     // 1 = record, 0 = EOF, <0 = error
     int next(Rec &r);
     struct Impl;

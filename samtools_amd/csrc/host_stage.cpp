@@ -10,11 +10,25 @@ void StagedFile::clear()
     pos.clear(); l_qseq.clear(); mtid.clear(); isize.clear(); flag.clear(); mapq.clear(); aux.clear();
     cig_off.clear(); base_off8.clear(); name_off.clear(); cigar.clear(); mpos.clear();
     seq.clear(); qual.clear(); bq.clear(); names.clear();
+    xcol_off.clear(); xcol_text.clear(); n_xcols = 0;
     any_bq = false;
 }
 
-void StagedFile::add(const Rec &r, int64_t origin, const std::set<std::string> *rg_excl)
+void StagedFile::add(const Rec &r, int64_t origin, const std::set<std::string> *rg_excl, const XcolSpec *xs)
 {
+    if (xs && xs->n_cols() > 0) {
+        n_xcols = xs->n_cols();
+        if (xs->rnext) {
+            xcol_off.push_back((uint32_t)xcol_text.size());
+            if (r.mtid >= 0 && xs->hdr && r.mtid < xs->hdr->nref()) { const std::string &nm = xs->hdr->names[(size_t)r.mtid]; xcol_text.insert(xcol_text.end(), nm.begin(), nm.end()); }
+            else xcol_text.push_back('*');
+        }
+        for (int t = 0; t < xs->n_tags; ++t) {
+            xcol_off.push_back((uint32_t)xcol_text.size());
+            if ((size_t)t < r.tag_has.size() && r.tag_has[(size_t)t]) xcol_text.insert(xcol_text.end(), r.tagtext[(size_t)t].begin(), r.tagtext[(size_t)t].end());
+            else xcol_text.push_back(xs->empty);
+        }
+    }
     pos.push_back((int32_t)(r.pos - origin));
     flag.push_back(r.flag);
     mapq.push_back(r.mapq);
@@ -52,6 +66,7 @@ void StagedFile::finish()
 {
     cig_off.push_back((uint32_t)cigar.size());
     name_off.push_back((uint32_t)names.size());
+    if (n_xcols) xcol_off.push_back((uint32_t)xcol_text.size());
 }
 
 sta_reads StagedFile::view() const
@@ -64,6 +79,7 @@ sta_reads StagedFile::view() const
     v.isize = isize.data(); v.name_off = name_off.data(); v.cigar = cigar.data(); v.seq = seq.data(); v.qual = qual.data();
     v.bq = any_bq ? bq.data() : nullptr; v.names = names.data();
     v.n_cigar_total = cigar.size(); v.n_bases_total = qual.size(); v.n_name_bytes = names.size();
+    if (n_xcols) { v.n_xcols = n_xcols; v.xcol_off = xcol_off.data(); v.xcol_text = xcol_text.data(); v.n_xcol_bytes = xcol_text.size(); }
     return v;
 }
 

@@ -8,6 +8,15 @@
 
 namespace sta {
 
+// what the host formats per read for --output-extra (RNEXT first, then the aux tags)
+struct XcolSpec {
+    bool rnext = false;
+    const Header *hdr = nullptr;     // contig names for RNEXT
+    int n_tags = 0;
+    char empty = '*';                // --output-empty: printed for a read without the tag
+    int n_cols() const { return (rnext ? 1 : 0) + n_tags; }
+};
+
 struct StagedFile {
     std::vector<int32_t> pos, l_qseq, mtid, isize;
     std::vector<uint16_t> flag;
@@ -16,10 +25,11 @@ struct StagedFile {
     std::vector<int64_t> mpos;
     std::vector<uint8_t> seq, qual, bq;
     std::vector<char> names;
+    std::vector<uint32_t> xcol_off; std::vector<char> xcol_text; int n_xcols = 0;
     bool any_bq = false;
     void clear();
     // origin: absolute coordinate of relative 0; rg_excl: -G read groups to drop (may be null)
-    void add(const Rec &r, int64_t origin, const std::set<std::string> *rg_excl);
+    void add(const Rec &r, int64_t origin, const std::set<std::string> *rg_excl, const XcolSpec *xs = nullptr);
     void finish();                 // closes the offset arrays
     sta_reads view() const;        // pointers into this object (valid until the next add/clear)
     int64_t n() const { return (int64_t)pos.size(); }

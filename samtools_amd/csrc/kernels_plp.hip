@@ -22,8 +22,10 @@
 
 struct MplpDevPar {
     int32_t min_baseQ, all, rev_del, flag, no_ins, no_del, no_ends;
+    int32_t n_tags, tag_sep;
     int64_t tlen;
 };
+#define TAGKIND (1 << 28)       // file_pass "kind" of tag column t is TAGKIND + t
 
 __constant__ char c_nt_lc[17] = ",acmgrsvtwyhkdbn";
 __constant__ char c_nt_uc[17] = ".ACMGRSVTWYHKDBN";
@@ -41,7 +43,7 @@ __constant__ unsigned char c_nt16_of_char[256] = {
     15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15 };
 
 #define EXTRA_MASK (STA_MPLP_PRINT_MAPQ_CHAR | STA_MPLP_PRINT_QPOS | STA_MPLP_PRINT_QNAME | STA_MPLP_PRINT_FLAG | \
-                    STA_MPLP_PRINT_RNAME | STA_MPLP_PRINT_POS | STA_MPLP_PRINT_MAPQ | STA_MPLP_PRINT_PNEXT | \
+                    STA_MPLP_PRINT_RNAME | STA_MPLP_PRINT_POS | STA_MPLP_PRINT_MAPQ | STA_MPLP_PRINT_RNEXT | STA_MPLP_PRINT_PNEXT | \
                     STA_MPLP_PRINT_RLEN | STA_MPLP_PRINT_QPOS5)
 
 extern __shared__ __attribute__((aligned(16))) char lds_text[];
@@ -236,8 +238,18 @@ __device__ __forceinline__ long long extra_value(const StaReadsDev &R, const Sta
     }
     return 0;
 }
-__device__ __forceinline__ int extra_len(const StaReadsDev &R, const StaWinDev &W, int kind, const Entry &e)
+// host-formatted text column: RNEXT is column 0 when requested, tag t is column (RNEXT ? 1 : 0) + t
+__device__ __forceinline__ int xcol_index(const MplpDevPar &P, int kind)
 {
+    int rn = (P.flag & STA_MPLP_PRINT_RNEXT) ? 1 : 0;
+    return kind == STA_MPLP_PRINT_RNEXT ? 0 : rn + (kind - TAGKIND);
+}
+__device__ __forceinline__ int extra_len(const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int kind, const Entry &e)
+{
+    if (kind == STA_MPLP_PRINT_RNEXT || kind >= TAGKIND) {
+        const uint32_t *o = R.xcol_off + (uint64_t)e.r * (uint64_t)R.n_xcols + (uint64_t)xcol_index(P, kind);
+        return (int)(o[1] - o[0]);
+    }
     if (kind == STA_MPLP_PRINT_MAPQ_CHAR) return 1;
     if (kind == STA_MPLP_PRINT_QNAME) return (int)(R.name_off[e.r + 1] - R.name_off[e.r]) - 1;
     if (kind == STA_MPLP_PRINT_RNAME) return W.tname_len;
@@ -245,9 +257,12 @@ __device__ __forceinline__ int extra_len(const StaReadsDev &R, const StaWinDev &
     return (v < 0 ? 1 : 0) + dec_digits((unsigned long long)(v < 0 ? -v : v));
 }
 template <bool LDS>
-__device__ __forceinline__ void extra_write(const StaReadsDev &R, const StaWinDev &W, int kind, const Entry &e, Sink<LDS> &s)
+__device__ __forceinline__ void extra_write(const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int kind, const Entry &e, Sink<LDS> &s)
 {
-    if (kind == STA_MPLP_PRINT_MAPQ_CHAR) {
+    if (kind == STA_MPLP_PRINT_RNEXT || kind >= TAGKIND) {
+        const uint32_t *o = R.xcol_off + (uint64_t)e.r * (uint64_t)R.n_xcols + (uint64_t)xcol_index(P, kind);
+        for (uint32_t t = o[0]; t < o[1]; ++t) s.put(R.xcol_text[t]);
+    } else if (kind == STA_MPLP_PRINT_MAPQ_CHAR) {
         int c = (int)((e.info >> RI_MAPQ_SHIFT) & 0xff) + 33;
         s.put((char)(c > 126 ? 126 : c));
     } else if (kind == STA_MPLP_PRINT_QNAME) {
@@ -291,8 +306,9 @@ __device__ __forceinline__ void file_pass(const StaReadsDev &R, const StaWinDev 
             uint32_t ex = (uint32_t)P.flag & EXTRA_MASK;
             while (ex) {
                 int kd = (int)(ex & (~ex + 1)); ex &= ex - 1;
-                acc.extras_len += (uint32_t)extra_len(R, W, kd, e);
+                acc.extras_len += (uint32_t)extra_len(R, W, P, kd, e);
             }
+            for (int t = 0; t < P.n_tags; ++t) acc.extras_len += (uint32_t)extra_len(R, W, P, TAGKIND + t, e);
         } else if (MODE == 1) {
             acc.cnt++;
         } else if (MODE == 2) {
@@ -300,8 +316,8 @@ __device__ __forceinline__ void file_pass(const StaReadsDev &R, const StaWinDev 
         } else if (MODE == 3) {
             s.put((char)(c + 33 < 126 ? c + 33 : 126));
         } else {
-            if (nw > 0 && kind != STA_MPLP_PRINT_MAPQ_CHAR) s.put(',');
-            extra_write<LDS>(R, W, kind, e, s);
+            if (nw > 0 && kind != STA_MPLP_PRINT_MAPQ_CHAR) s.put(kind >= TAGKIND ? (char)P.tag_sep : ',');
+            extra_write<LDS>(R, W, P, kind, e, s);
         }
         nw++;
     }
@@ -318,7 +334,7 @@ __device__ __forceinline__ void wave_read_range(const StaReadsDev &R, int p0, in
 // bytes of "\t cnt \t seq \t qual [\t extra]*" for one file
 __device__ __forceinline__ uint32_t file_text_len(const MplpDevPar &P, const Acc &a)
 {
-    uint32_t n_extra = (uint32_t)__popc((uint32_t)P.flag & EXTRA_MASK);
+    uint32_t n_extra = (uint32_t)__popc((uint32_t)P.flag & EXTRA_MASK) + (uint32_t)P.n_tags;
     uint32_t len = 1 + (uint32_t)dec_digits_u32(a.cnt) + 1 + (a.seq_len ? a.seq_len : 1) + 1 + (a.cnt ? a.cnt : 1);
     if (n_extra) {
         // every extra column: '\t' + (fields + separators, or '*')
@@ -398,6 +414,11 @@ __device__ __forceinline__ void emit_column(const StaWinDev &W, const MplpDevPar
             int kd = (int)(ex & (~ex + 1)); ex &= ex - 1;
             if (exists) s.put('\t');
             file_pass<4, LDS>(R, W, P, p, exists && a.cnt, rlo, rhi, kd, a, s);
+            if (exists && !a.cnt) s.put('*');
+        }
+        for (int t = 0; t < P.n_tags; ++t) {           // aux-tag columns, in --output-extra order (bam_plcmd.c:798-852)
+            if (exists) s.put('\t');
+            file_pass<4, LDS>(R, W, P, p, exists && a.cnt, rlo, rhi, TAGKIND + t, a, s);
             if (exists && !a.cnt) s.put('*');
         }
     }
@@ -710,6 +731,7 @@ static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
     MplpDevPar d;
     d.min_baseQ = p.min_baseQ; d.all = p.all; d.rev_del = p.rev_del; d.flag = p.flag;
     d.no_ins = p.no_ins; d.no_del = p.no_del; d.no_ends = p.no_ends; d.tlen = tlen;
+    d.n_tags = p.n_tags > 0 ? p.n_tags : 0; d.tag_sep = p.tag_sep ? p.tag_sep : ',';
     return d;
 }
 
@@ -719,7 +741,7 @@ void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_param
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
     int64_t nb = (ncols + 255) / 256;
-    if (!((uint32_t)p.flag & EXTRA_MASK) && colinfo) {
+    if (!((uint32_t)p.flag & EXTRA_MASK) && p.n_tags <= 0 && colinfo) {
         hipLaunchKernelGGL(k_mplp_len_fast, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, colinfo, ctr);
         return;
     }
@@ -736,7 +758,7 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
     int wpb = 4 * slice <= 65536 ? 4 : (2 * slice <= 65536 ? 2 : 1);
     int64_t nwaves = (ncols + 63) / 64;
     int64_t nb = (nwaves + wpb - 1) / wpb;
-    if (!((uint32_t)p.flag & EXTRA_MASK) && colinfo) {
+    if (!((uint32_t)p.flag & EXTRA_MASK) && p.n_tags <= 0 && colinfo) {
         uint32_t fslice = (lds_cap + 48 + 15) & ~15u;      // must match k_mplp_emit_fast
         int fw = 4 * fslice <= 65536 ? 4 : (2 * fslice <= 65536 ? 2 : 1);
         int64_t fnb = (nwaves + fw - 1) / fw;

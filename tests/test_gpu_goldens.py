@@ -10,7 +10,7 @@ from golden_runner import case_paths, first_diff, run_case
 pytestmark = pytest.mark.gpu
 
 # cases the device path declares unsupported (documented in DESIGN.md): tag columns of --output-extra
-UNSUPPORTED = {"79.out"}
+UNSUPPORTED = set()
 CASES = [("reg", c) for c in regcases.MPILEUP + regcases.DEPTH if c[0] not in UNSUPPORTED] + \
         [("testpl", c) for c in regcases.TESTPL]
 IDS = ["%s::%s" % (c[0], c[1][:60]) for _, c in CASES]

@@ -77,3 +77,22 @@ def test_adjust_mq_equals_oracle(tmp_path, oracle_bin, product_bin, extra):
         assert got.stdout == want, args
         assert want != subprocess.run([oracle_bin] + [a for a in args if a not in ("-C", "50", "40")], stdout=subprocess.PIPE,
                                       stderr=subprocess.DEVNULL, check=True).stdout      # -C changes something in this data
+
+
+def test_output_extra_tags_and_rnext_equal_oracle(tmp_path, oracle_bin, product_bin):
+    """--output-extra with aux tags (host-formatted text columns), RNEXT, --output-sep / --output-empty: BAM and SAM inputs
+    of the reference's fixtures plus synthetic pairs (no tags at all: every entry prints the --output-empty character)."""
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=8000, depth=20, read_len=100, seed=91, paired=True)
+    cases = [
+        ["mpileup", "--output-extra", "NM,RG,FLAG,RNEXT,XT,MD", os.path.join(g, "mpileup", "mpileup.1.bam")],
+        ["mpileup", "-s", "--output-extra", "RNEXT,PNEXT,AS,XS,NM", "--output-sep", ";", "--output-empty", "-", "-a", os.path.join(g, "dat", "mpileup.1.sam")],
+        ["mpileup", "--output-extra", "QNAME,RNEXT,ZZ", "--output-empty", "?", "-f", fa, sam],
+        ["mpileup", "--output-extra", "RNEXT", "-Q", "0", os.path.join(g, "mpileup", "mpileup.1.bam"), os.path.join(g, "mpileup", "mpileup.2.bam")],
+    ]
+    for args in cases:
+        want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert got.returncode == 0, got.stderr.decode()[-500:]
+        assert got.stdout == want, args
+        assert len(want) > 1000

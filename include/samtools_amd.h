@@ -13,6 +13,8 @@
  *   bam_mplp_set_maxcnt            bam_plcmd.c:597        sta_mplp_params.max_depth
  *   bam_mplp_init_overlaps         bam_plcmd.c:586        STA_MPLP_SMART_OVERLAPS
  *   sam_prob_realn (BAQ)           bam_plcmd.c:451        STA_MPLP_REALN / STA_MPLP_REDO_BAQ
+ *   sam_cap_mapq (-C)              bam_plcmd.c:453-457    sta_mplp_params.capQ_thres
+ *   --output-extra tags / RNEXT    bam_plcmd.c:779-852    sta_reads.xcol_* + sta_mplp_params.n_tags
  *   mpileup() column loop+format   bam_plcmd.c:607-868    sta_mpileup_emit (text on device)
  *   pileup_seq                     bam_plcmd.c:54-169     sta_mpileup_emit
  *   print_empty_pileup             bam_plcmd.c:372-398    sta_mpileup_emit with params.all

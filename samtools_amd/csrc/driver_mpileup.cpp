@@ -270,7 +270,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
         case 5: mp.flag |= STA_MPLP_PRINT_QNAME; break;
         case 6: mp.rev_del = 1; break;
         case 7: {
-            // build_auxlist (bam_plcmd.c:240-287): column names the device path can print; tags are not supported
+            // build_auxlist (bam_plcmd.c:240-287): fixed column names set flag bits, any other two-character name is an aux tag
             static const struct { const char *n; int f; } cols[] = {
                 { "QNAME", STA_MPLP_PRINT_QNAME }, { "FLAG", STA_MPLP_PRINT_FLAG }, { "RNAME", STA_MPLP_PRINT_RNAME },
                 { "POS", STA_MPLP_PRINT_POS }, { "MAPQ", STA_MPLP_PRINT_MAPQ }, { "RNEXT", STA_MPLP_PRINT_RNEXT },

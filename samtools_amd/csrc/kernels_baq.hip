@@ -250,7 +250,6 @@ __global__ void __launch_bounds__(64) k_baq(StaReadsDev R, StaWinDev W, BaqTable
 }
 
 // scratch sizing: the engine passes n_reads only; geometry bounds come from the staged window
-static const int BAQ_LQ_MAX_DEFAULT = 0;
 
 size_t sta_baq_scratch_bytes(int64_t n_reads, int max_lq, int max_bw)
 {

@@ -735,7 +735,6 @@ static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
     return d;
 }
 
-// tlen travels in StaWinDev.reg_* style fields? no: we pass it through ref_len-independent P.tlen
 void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;

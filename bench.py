@@ -288,7 +288,11 @@ def main():
         # whole-step algorithmic rate (every kernel of the step, SURVEY.md 8d bytes): the number to compare with 8 TB/s end to end
         res["step_alg_GBps"] = alg_bytes_per_base_wl * piled_all / (dt_all / a.steps) / 1e9 / max(1, world)
         if world == 1 and not a.no_cpu_baseline:
-            sample = a.cpu_sample_cols or (1000000 if kind == "mpileup" and not a.workload.endswith("_B") else 2000000)
+            # bounded sample: BAQ runs at ~6 Mbases/s on one core, so 2 M columns (400 k reads, 60 Mbases) is ~10 s of CPU work;
+            # the other workloads keep the same sample (the oracle needs 0.2-0.7 s there: generating and writing the SAM text
+            # in Python costs far more than the run, so a bigger sample would only slow the bench down)
+            sample = 2000000
+            sample = a.cpu_sample_cols or sample
             if depth >= 300:
                 sample //= 10
             cb = cpu_baseline(a.workload, sample)

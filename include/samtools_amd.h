@@ -147,6 +147,7 @@ typedef struct sta_mplp_params {
     int32_t has_fai;             /* a FASTA was given with -f (BAQ/ref column need it) */
     int32_t n_tags;              /* aux-tag columns after the fixed extra columns (text staged in sta_reads.xcol_*) */
     int32_t tag_sep;             /* --output-sep character between the entries of a tag column (',' by default) */
+    int32_t min_qlen;            /* coverage -l: drop reads whose bam_cigar2qlen is smaller (0 = off) */
 } sta_mplp_params;
 
 /* subset of depth_opt (bam2depth.c:72-86) */
@@ -214,6 +215,22 @@ int sta_fetch_col_offsets(sta_engine *e, uint64_t *host_offs, uint64_t n);
 /* per-read state after a plan: info words (bit 1 = read is in the pileup) and the working quality
  * pool (mate-overlap / BAQ adjusted), laid out like sta_reads.qual.  Either pointer may be NULL. */
 int sta_fetch_read_state(sta_engine *e, int32_t file, uint32_t *host_info, uint8_t *host_qual);
+
+/* ---- coverage / bedcov: per-window column reductions (coverage.c:621-672, bedcov.c:316-333) ---- */
+typedef struct sta_cov_params {
+    int32_t mode;                /* 0 coverage, 1 bedcov */
+    int32_t min_baseQ;           /* coverage -Q */
+    int32_t min_depth;           /* coverage --min-depth (>= 1) / bedcov -d (-1 = off) */
+    int32_t skip_dn;             /* bedcov -j */
+    int32_t max_depth;           /* iterator depth cap (bam_mplp_set_maxcnt) */
+    int32_t min_mq, rflag_require, rflag_filter, min_qlen;     /* read filters of the commands' read_bam callbacks */
+} sta_cov_params;
+typedef struct sta_cov_totals {  /* coverage: sums over the window's columns (and all files) */
+    uint64_t n_covered_bases, summed_coverage, summed_baseQ, quality_bases, missing_qual;
+} sta_cov_totals;
+/* per_file: [n_files][2] = {sum of per-column depth, columns at or above min_depth} (bedcov); may be NULL for coverage.
+ * info->n_kept_reads = reads that entered the pileup (bedcov -c).  Synchronises the stream. */
+int sta_cov_plan(sta_engine *e, const sta_cov_params *p, sta_cov_totals *totals, uint64_t *per_file, sta_plan_info *info);
 
 /* ---- depth ---- */
 int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info);

@@ -138,6 +138,48 @@ __device__ __forceinline__ int64_t wave_upper_bound(const int32_t *a, int64_t n,
 }
 
 
+// stateless HTSlib resolve_cigar2 for one (read, column) -- SURVEY.md A.2 (shared by the entry and coverage kernels)
+__device__ __forceinline__ void plp_resolve(const uint32_t *cig, int n, int rpos, int p, int &qpos, int &indel, int &k_out,
+                                            bool &is_del, bool &is_refskip)
+{
+    int x = rpos, y = 0, k = 0, op = 0, l = 0;
+    for (k = 0; k < n; ++k) {
+        uint32_t c = cig[k];
+        op = c & 0xf; l = (int)(c >> 4);
+        if (cg_is_refop(op)) {
+            if (p < x + l) break;
+            if (cg_is_mop(op)) y += l;
+            x += l;
+        } else if (cg_is_qop(op)) y += l;
+    }
+    k_out = k; indel = 0; is_del = false; is_refskip = false;
+    if (x + l - 1 == p && k + 1 < n) {
+        int op2 = cig[k + 1] & 0xf, l2 = (int)(cig[k + 1] >> 4);
+        if (op2 == CG_D && op != CG_D) {
+            indel = -l2;
+            for (int j = k + 2; j < n; ++j) { if ((cig[j] & 0xf) == CG_D) indel -= (int)(cig[j] >> 4); else break; }
+        } else if (op2 == CG_I) {
+            indel = l2;
+            for (int j = k + 2; j < n; ++j) {
+                int o = cig[j] & 0xf;
+                if (o == CG_I) indel += (int)(cig[j] >> 4);
+                else if (o != CG_P) break;
+            }
+        } else if (op2 == CG_P && k + 2 < n) {
+            int l3 = 0;
+            for (int j = k + 2; j < n; ++j) {
+                int o = cig[j] & 0xf;
+                if (o == CG_I) l3 += (int)(cig[j] >> 4);
+                else if (cg_is_refop(o)) break;
+            }
+            if (l3 > 0) indel = l3;
+        }
+    }
+    if (cg_is_mop(op)) qpos = y + (p - x);
+    else { is_del = true; qpos = y; is_refskip = (op == CG_N); }
+}
+
+
 // Block-wide reduction of N per-thread values followed by ONE global atomic per value and block
 // (sum for k < NSUM, max for the rest).  Keeps contended device atomics off the per-wave path: a
 // counter word sustains only ~90 atomics/us, so one atomic per wave (65k+ waves) costs milliseconds.

@@ -62,7 +62,7 @@ void output_header(FILE *fp, const char *hdr, int fields, int n, char **fn, int 
 
 }  // namespace
 
-extern "C" int sta_main_bedcov(int argc, char **argv)
+extern "C" int sta_main_bedcov_iter(int argc, char **argv)
 {
     int c, status = 0, min_mapQ = 0, skip_DN = 0, do_rcount = 0, tflags, min_depth = -1, max_depth = INT_MAX, print_header = 0, hdr = 0;
     uint32_t flags = 4 | 256 | 512 | 1024;

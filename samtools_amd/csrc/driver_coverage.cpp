@@ -75,7 +75,7 @@ void print_tabular_line(FILE *out, const Header &h, const std::vector<stats_aux_
 
 }  // namespace
 
-extern "C" int sta_main_coverage(int argc, char **argv)
+extern "C" int sta_main_coverage_iter(int argc, char **argv)
 {
     int c, i, max_depth = 1000000, opt_min_baseQ = 0, opt_min_mapQ = 0, opt_min_len = 0, mindepth = 1, print_value_warning = 0;
     int fail_flags = 4 | 256 | 512 | 1024, required_flags = 0;

@@ -62,11 +62,12 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch, baq_scratch2;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out;
     StaWinDev wd{};
     // plan state
     int planned = 0;   // 1 mpileup, 2 depth, 3 plp entries
     bool plp_mode = false;
+    bool cov_mode = false;          // coverage / bedcov: the pipeline stops before the per-column text measuring pass
     sta_mplp_params mp{};
     sta_depth_params dp{};
     StaCounters ctr_h{};
@@ -168,7 +169,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2 };
+                      &e->out, &e->diff, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
     if (e->pipe_stream) hipStreamDestroy(e->pipe_stream);
@@ -496,6 +497,7 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             sta_launch_overlap(s, d, e->wd.origin, e->wd.tid, e->table.p, slots, (int32_t *)e->fb[(size_t)f].chain.p, ctr);
         }
     }
+    if (e->cov_mode) return STA_OK;
     if (e->plp_mode) {
         ProfScope ps(e, "plp_count");
         sta_launch_plp_count(s, e->wd, (uint32_t *)e->line_len.p);
@@ -651,6 +653,59 @@ int sta_fetch_read_state(sta_engine *e, int32_t file, uint32_t *host_info, uint8
     if (host_info && d.n) HIPCHK(hipMemcpyAsync(host_info, d.info, (size_t)d.n * 4, hipMemcpyDeviceToHost, e->stream));
     if (host_qual && d.n_bases_total) HIPCHK(hipMemcpyAsync(host_qual, d.qual, (size_t)d.n_bases_total, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return STA_OK;
+}
+
+int sta_cov_plan(sta_engine *e, const sta_cov_params *cp, sta_cov_totals *totals, uint64_t *per_file, sta_plan_info *info)
+{
+    if (!e || !cp) return STA_ERR_ARG;
+    if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
+    hipSetDevice(e->device);
+    sta_mplp_params p; memset(&p, 0, sizeof p);
+    p.max_depth = cp->max_depth; p.min_mq = cp->min_mq; p.rflag_require = cp->rflag_require; p.rflag_filter = cp->rflag_filter; p.min_qlen = cp->min_qlen;
+    e->mp = p;
+    const char *saved_ref = e->wd.ref; int64_t saved_len = e->wd.ref_len;
+    e->wd.ref = nullptr; e->wd.ref_len = 0;
+    e->min_pos.assign(e->files_h.size(), 0); e->max_pos_hint.assign(e->files_h.size(), 0);
+    const size_t nf = e->files_h.size();
+    if (e->cov_out.ensure((5 + nf * 2) * 8 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+    e->cov_mode = true;
+    int rc = mpileup_pipeline(e, &p, false);
+    if (!rc) { hipError_t r_ = hipStreamSynchronize(e->stream); if (r_ != hipSuccess) rc = hipfail(e, r_, "sync"); }
+    if (!rc) {
+        HIPCHK(hipMemcpy(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost));
+        if (e->ctr_h.maxcnt_flag) {
+            for (size_t f = 0; f < nf; ++f) {
+                StaReadsDev &d = e->files_h[f];
+                if (!d.n) continue;
+                int32_t first = 0, lastmax = 0, lastpos = 0;
+                HIPCHK(hipMemcpy(&first, d.pos, 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(&lastmax, d.maxend + (d.n - 1), 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(&lastpos, d.pos + (d.n - 1), 4, hipMemcpyDeviceToHost));
+                e->min_pos[f] = first; e->max_pos_hint[f] = lastmax > lastpos ? lastmax : lastpos;
+            }
+            rc = mpileup_pipeline(e, &p, true);
+        }
+    }
+    e->cov_mode = false;
+    e->wd.ref = saved_ref; e->wd.ref_len = saved_len;
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(e->cov_out.p, 0, (5 + nf * 2) * 8, e->stream));
+    {
+        ProfScope ps(e, "cov_cols");
+        sta_launch_cov_cols(e->stream, e->wd, cp->mode, cp->min_baseQ, cp->min_depth, cp->skip_dn, (unsigned long long *)e->cov_out.p,
+                            (unsigned long long *)e->cov_out.p + 5);
+    }
+    std::vector<uint64_t> host(5 + nf * 2);
+    HIPCHK(hipMemcpyAsync(host.data(), e->cov_out.p, host.size() * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return hipfail(e, le, "coverage kernels");
+    if (totals) { totals->n_covered_bases = host[0]; totals->summed_coverage = host[1]; totals->summed_baseQ = host[2]; totals->quality_bases = host[3]; totals->missing_qual = host[4]; }
+    if (per_file) for (size_t i = 0; i < nf * 2; ++i) per_file[i] = host[5 + i];
+    if (info) { memset(info, 0, sizeof *info); info->n_kept_reads = e->ctr_h.n_kept; info->piled_bases = e->ctr_h.piled_bases; info->n_maxcnt_dropped = e->ctr_h.n_dropped; }
+    e->planned = 4;      // read state can be fetched; there is nothing to emit
     return STA_OK;
 }
 

@@ -315,6 +315,7 @@ int AlnReader::next(Rec &r)
         if (has_reg_) {
             if (r.tid != rtid_ || r.pos >= rend_ || r.endpos() <= rbeg_) continue;
         }
+        if (on_record) on_record(r);
         return 1;
     }
 }

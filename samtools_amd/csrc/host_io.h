@@ -8,6 +8,7 @@
 #include <vector>
 #include <unordered_map>
 #include <memory>
+#include <functional>
 
 namespace sta {
 
@@ -49,6 +50,8 @@ public:
     void set_region(int tid, int64_t beg, int64_t end) { has_reg_ = true; rtid_ = tid; rbeg_ = beg; rend_ = end; }
     // two-character aux tags whose values next() should format into Rec::tagtext (in this order)
     void set_wanted_tags(const std::vector<std::string> &tags);
+    // called for every record next() returns (read-level statistics of `coverage`: coverage.c:182-196 counts in its callback)
+    std::function<void(const Rec &)> on_record;
     // 1 = record, 0 = EOF, <0 = error
     int next(Rec &r);
     struct Impl;

@@ -12,7 +12,7 @@
 
 // ------------------------------------------------------------------------------------------------
 struct PrepArgs {
-    int32_t min_mq, rflag_require, rflag_filter, flag, all, baq_force_slow;
+    int32_t min_mq, rflag_require, rflag_filter, flag, all, baq_force_slow, min_qlen;
 };
 
 __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, PrepArgs P, StaCounters *ctr)
@@ -48,6 +48,12 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
         if (aux & STA_AUX_SKIP) pushed = false;
         bool has_ref = W.ref != nullptr;
         if (has_ref && W.ref_len <= apos) pushed = false;   // "Skipping because ... is outside of ..."
+        if (P.min_qlen) {
+            // coverage -l: bam_cigar2qlen (coverage.c:189)
+            int32_t ql = 0;
+            for (uint32_t k = c0; k < c1; ++k) { int op = R.cigar[k] & 0xf; if (op == CG_M || op == CG_I || op == CG_S || op == CG_EQ || op == CG_X) ql += (int32_t)(R.cigar[k] >> 4); }
+            if (ql < P.min_qlen) pushed = false;
+        }
         if ((int32_t)mapq < P.min_mq) pushed = false;
         else if ((P.flag & STA_MPLP_NO_ORPHAN) && (flag & BAM_FPAIRED) && !(flag & BAM_FPROPER_PAIR)) pushed = false;
 
@@ -109,7 +115,7 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
 void sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
                            const sta_mplp_params &p, StaCounters *ctr)
 {
-    PrepArgs a{ p.min_mq, p.rflag_require, p.rflag_filter, p.flag, p.all, getenv("STA_BAQ_FORCE_SLOW") ? 1 : 0 };
+    PrepArgs a{ p.min_mq, p.rflag_require, p.rflag_filter, p.flag, p.all, getenv("STA_BAQ_FORCE_SLOW") ? 1 : 0, p.min_qlen };
     for (int f = 0; f < nfiles; ++f) {
         const StaReadsDev &R = files_host[f];
         if (R.n == 0) continue;

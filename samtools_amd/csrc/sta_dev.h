@@ -86,6 +86,10 @@ void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, const uint32
 void sta_launch_plp_count(hipStream_t s, const StaWinDev &w, uint32_t *line_len);
 void sta_launch_plp_fill(hipStream_t s, const StaWinDev &w, const uint64_t *offs, void *entries);
 
+// coverage / bedcov column reductions (kernels_cov.hip)
+void sta_launch_cov_cols(hipStream_t s, const StaWinDev &w, int mode, int min_baseQ, int min_depth, int skip_dn,
+                         unsigned long long *totals /*[5]*/, unsigned long long *per_file /*[nfiles][2]*/);
+
 // overlap (mate) resolution
 size_t sta_overlap_table_slots(int64_t n_reads);
 size_t sta_overlap_table_bytes(size_t slots);

@@ -16,8 +16,9 @@ CASES = [
 ]
 
 
-def run(exe, args, cwd):
-    p = subprocess.run([exe, "bedcov"] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+def run(exe, args, cwd, iterator=False):
+    env = dict(os.environ, STA_COV_ITERATOR="1") if iterator else None      # reference loop on the bam_mplp_* surface instead of k_cov_cols
+    p = subprocess.run([exe, "bedcov"] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert p.returncode == 0, p.stderr.decode()[-400:]
     return p.stdout
 
@@ -50,15 +51,20 @@ def test_oracle_bedcov_header_cases(oracle_bin, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("iterator", [False, True], ids=["device_reduction", "iterator_loop"])
 @pytest.mark.parametrize("exp,args", CASES, ids=[c[0] for c in CASES])
-def test_engine_bedcov_matches_reference_golden(product_bin, exp, args):
-    assert run(product_bin, args, G) == open(os.path.join(G, exp), "rb").read()
+def test_engine_bedcov_matches_reference_golden(product_bin, exp, args, iterator):
+    assert run(product_bin, args, G, iterator) == open(os.path.join(G, exp), "rb").read()
 
 
 @pytest.mark.gpu
-def test_engine_bedcov_header_and_depth_columns(product_bin, oracle_bin, tmp_path):
+@pytest.mark.parametrize("iterator", [False, True], ids=["device_reduction", "iterator_loop"])
+def test_engine_bedcov_header_and_depth_columns(product_bin, oracle_bin, tmp_path, iterator):
     for args, want in header_cases(tmp_path):
-        assert run(product_bin, args, G) == want
+        assert run(product_bin, args, G, iterator) == want
     # options without a reference golden: engine vs oracle
-    for args in (["-d", "20", "-c", "bedcov_gG.bed", "bedcov.bam"], ["-Q", "30", "-j", "-d", "5", "bedcov_gG.bed", "bedcov.bam", "bedcov.bam"]):
-        assert run(product_bin, args, G) == run(oracle_bin, args, G)
+    big = os.path.join(os.path.dirname(G), "mpileup", "mpileup.1.bam")
+    bed = tmp_path / "b.bed"; bed.write_text("17\t100\t2000\tx\n17\t3000\t3000\n17\t150\t160\n17\t4000\t9000\n")
+    for args in (["-d", "20", "-c", "bedcov_gG.bed", "bedcov.bam"], ["-Q", "30", "-j", "-d", "5", "bedcov_gG.bed", "bedcov.bam", "bedcov.bam"],
+                 ["-c", "-d", "0", str(bed), big], ["-j", "-Q", "20", "-g", "1024", str(bed), big, big]):
+        assert run(product_bin, args, G, iterator) == run(oracle_bin, args, G), args

@@ -19,8 +19,9 @@ def cases(tmp_path):
             ("5.expected", ["--min-depth", "4", s, s1])]
 
 
-def run(exe, args):
-    p = subprocess.run([exe, "coverage"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+def run(exe, args, iterator=False):
+    env = dict(os.environ, STA_COV_ITERATOR="1") if iterator else None      # reference loop on the bam_mplp_* surface instead of k_cov_cols
+    p = subprocess.run([exe, "coverage"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert p.returncode == 0, p.stderr.decode()[-400:]
     return p.stdout
 
@@ -31,10 +32,13 @@ def test_oracle_coverage_matches_reference_goldens(oracle_bin, tmp_path):
 
 
 @pytest.mark.gpu
-def test_engine_coverage_matches_reference_goldens(product_bin, oracle_bin, tmp_path):
+@pytest.mark.parametrize("iterator", [False, True], ids=["device_reduction", "iterator_loop"])
+def test_engine_coverage_matches_reference_goldens(product_bin, oracle_bin, tmp_path, iterator):
     for exp, args in cases(tmp_path):
-        assert run(product_bin, args) == open(os.path.join(G, exp), "rb").read(), exp
+        assert run(product_bin, args, iterator) == open(os.path.join(G, exp), "rb").read(), exp
     # options without a golden: engine vs oracle (region, flags, read length, header off) on a bigger file
     big = os.path.join(os.path.dirname(G), "dat", "mpileup.1.sam")
-    for args in (["-r", "17:200-900", big], ["-H", "--ff", "UNMAP,DUP", "-l", "50", "-Q", "20", big], ["-q", "30", "-d", "10", big]):
-        assert run(product_bin, args) == run(oracle_bin, args), args
+    three = [os.path.join(os.path.dirname(G), "dat", "mpileup.%d.sam" % k) for k in (1, 2, 3)]
+    for args in (["-r", "17:200-900", big], ["-H", "--ff", "UNMAP,DUP", "-l", "50", "-Q", "20", big], ["-q", "30", "-d", "10", big],
+                 ["--min-depth", "40", "-Q", "30"] + three, ["-r", "17:4100-4200", big]):
+        assert run(product_bin, args, iterator) == run(oracle_bin, args), args

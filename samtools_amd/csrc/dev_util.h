@@ -138,6 +138,33 @@ __device__ __forceinline__ int64_t wave_upper_bound(const int32_t *a, int64_t n,
 }
 
 
+// a read reached bam_plp_push and was not dropped by the -d cap (it moved the iterator's max_pos)
+__device__ __forceinline__ bool read_advances_iterator(const StaReadsDev &R, int64_t j)
+{
+    uint32_t info = R.info[j];
+    bool dropped = (info & RI_PUSHED) && !(info & RI_KEEP) && R.end[j] > R.pos[j];
+    return (info & RI_PUSHED) && !dropped;
+}
+
+// Quality a deletion / ref-skip placeholder of read r shows at column p (bam_plcmd.c:676-679 reads qual[qpos] of the NEXT base).
+// HTSlib resolves a mate pair when the second mate is pushed, and a column is handed out as soon as some read starting
+// beyond it has been pushed -- so a column before the mate's start sees the resolved quality only if the mate itself is
+// that first read.  Everything else about the overlap pass is order independent; this is the one place where it is not.
+__device__ __forceinline__ int placeholder_qual(const StaReadsDev &R, int64_t r, int qpos, int lq, uint64_t boff, int p)
+{
+    if (qpos >= lq) return 0;
+    int q = R.qual[boff + (uint64_t)qpos];
+    if (!R.fix_y || R.fix_y[r] != qpos) return q;
+    const int64_t mate = R.fix_mate[r];
+    if (p >= R.pos[mate]) return q;
+    // first read (file order) starting beyond p that advances the iterator
+    int64_t lo = 0, hi = R.n;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (R.pos[mid] > p) hi = mid; else lo = mid + 1; }
+    int64_t j = lo;
+    while (j < R.n && !read_advances_iterator(R, j)) ++j;
+    return j == mate ? q : (int)R.fix_q[r];
+}
+
 // stateless HTSlib resolve_cigar2 for one (read, column) -- SURVEY.md A.2 (shared by the entry and coverage kernels)
 __device__ __forceinline__ void plp_resolve(const uint32_t *cig, int n, int rpos, int p, int &qpos, int &indel, int &k_out,
                                             bool &is_del, bool &is_refskip)

@@ -30,11 +30,11 @@ struct FileBufs {
     // staged input copies (only used with STA_MEM_HOST)
     DevBuf pos, flag, mapq, aux, lq, cig_off, base_off8, mtid, mpos, isize, name_off, cigar, seq, qual, bq, names, xoff, xtext;
     // workspace
-    DevBuf qual_work, end, maxend, info, clip, chain;
+    DevBuf qual_work, end, maxend, info, clip, chain, fix_y, fix_mate, fix_q;
     void release()
     {
         DevBuf *all[] = { &pos, &flag, &mapq, &aux, &lq, &cig_off, &base_off8, &mtid, &mpos, &isize, &name_off, &cigar,
-                          &seq, &qual, &bq, &names, &xoff, &xtext, &qual_work, &end, &maxend, &info, &clip, &chain };
+                          &seq, &qual, &bq, &names, &xoff, &xtext, &qual_work, &end, &maxend, &info, &clip, &chain, &fix_y, &fix_mate, &fix_q };
         for (DevBuf *b : all) b->release();
     }
 };
@@ -345,6 +345,14 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             ProfScope ps(e, "qual_prep");
             sta_launch_qual_prep(s, tmp, illum ? 1 : 0);
         } else d.qual = const_cast<uint8_t *>(d.qual_in);
+        d.fix_y = nullptr; d.fix_mate = nullptr; d.fix_q = nullptr;
+        if (olap && d.n) {
+            FileBufs &b = e->fb[(size_t)f];
+            if (b.fix_y.ensure((size_t)d.n * 4 + 16) || b.fix_mate.ensure((size_t)d.n * 4 + 16) || b.fix_q.ensure((size_t)d.n + 16))
+                return fail(e, STA_ERR_HIP, "hipMalloc(overlap fix-up) failed");
+            d.fix_y = (int32_t *)b.fix_y.p; d.fix_mate = (int32_t *)b.fix_mate.p; d.fix_q = (uint8_t *)b.fix_q.p;
+            HIPCHK(hipMemsetAsync(d.fix_y, 0xff, (size_t)d.n * 4, s));
+        }
     }
     int rc = push_files(e);
     if (rc) return rc;

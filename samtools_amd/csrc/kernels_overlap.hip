@@ -130,6 +130,22 @@ __device__ void tweak_overlap(const StaReadsDev &R, int64_t ia, int64_t ib)
     wa.cig = wa.cig0 = R.cigar + R.cig_off[ia]; wa.cig_max = R.cigar + R.cig_off[ia + 1];
     wb.cig = wb.cig0 = R.cigar + R.cig_off[ib]; wb.cig_max = R.cigar + R.cig_off[ib + 1];
     long long iref = bpos;
+    if (R.fix_y && bpos > apos) {
+        // does a deletion / ref-skip run of a cover the column just before the mate starts?  Its placeholders look at the
+        // quality of the next query base, which the resolution below may rewrite (placeholder_qual in dev_util.h)
+        long long x = apos; int y = 0;
+        for (const uint32_t *c = wa.cig; c < wa.cig_max; ++c) {
+            int op = *c & 0xf; long long l = *c >> 4;
+            if (cg_is_refop(op)) {
+                if (bpos - 1 < x + l) {
+                    if ((op == CG_D || op == CG_N) && y < alq) { R.fix_y[ia] = y; R.fix_q[ia] = a_qual[y]; R.fix_mate[ia] = (int32_t)ib; }
+                    break;
+                }
+                if (cg_is_mop(op)) y += (int)l;
+                x += l;
+            } else if (cg_is_qop(op)) y += (int)l;
+        }
+    }
     int a_ret = iref2iseq_set(wa, iref - apos);
     if (a_ret < 0) return;
     int b_ret = iref2iseq_set(wb, iref - bpos);

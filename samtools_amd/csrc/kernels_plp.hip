@@ -298,7 +298,7 @@ __device__ __forceinline__ void file_pass(const StaReadsDev &R, const StaWinDev 
         if (info & RI_SIMPLE) { e.rs.qpos = p - rpos; e.rs.indel = 0; e.rs.k = 0; e.rs.is_del = false; e.rs.is_refskip = false; }
         else e.rs = resolve_general(R.cigar + R.cig_off[r], (int)(R.cig_off[r + 1] - R.cig_off[r]), rpos, p);
         if (MODE <= 1) acc.n_plp++;
-        int c = e.rs.qpos < e.lq ? R.qual[e.boff + (uint64_t)e.rs.qpos] : 0;
+        int c = e.rs.is_del ? placeholder_qual(R, r, e.rs.qpos, e.lq, e.boff, p) : (e.rs.qpos < e.lq ? R.qual[e.boff + (uint64_t)e.rs.qpos] : 0);
         if (c < P.min_baseQ) continue;
         if (MODE == 0) {
             acc.cnt++;
@@ -588,7 +588,7 @@ __device__ __forceinline__ void fast_walk(const StaReadsDev &R, const StaWinDev 
                         e.boff = (uint64_t)b8[k] << 3;
                         e.rs = resolve_general(R.cigar + R.cig_off[e.r], (int)(R.cig_off[e.r + 1] - R.cig_off[e.r]), e.rpos, p);
                         if (!EMIT) n_plp++;
-                        int c = e.rs.qpos < e.lq ? R.qual[e.boff + (uint64_t)e.rs.qpos] : 0;
+                        int c = e.rs.is_del ? placeholder_qual(R, e.r, e.rs.qpos, e.lq, e.boff, p) : (e.rs.qpos < e.lq ? R.qual[e.boff + (uint64_t)e.rs.qpos] : 0);
                         if (c >= P.min_baseQ) {
                             if (!EMIT) { cnt++; seq_len += (uint32_t)token_len(R, P, e, p); }
                             else {

@@ -43,6 +43,10 @@ struct StaReadsDev {
     int32_t *maxend;      // inclusive prefix max of `end` over RI_KEEP reads
     uint32_t *info;       // RI_*
     int32_t *clip;        // depth -s: columns below this are not counted (0 = none)
+    // mate-overlap visibility fix-up (see placeholder_qual in dev_util.h): for a read whose deletion / ref-skip run straddles
+    // the start of its mate, the query index the run's placeholders look at (-1 = none), that base's quality BEFORE the
+    // pair was resolved, and the mate's read index.  NULL when overlaps are off.
+    int32_t *fix_y, *fix_mate; uint8_t *fix_q;
     int32_t *chain;       // n+4 ints: BAQ slow-read list ([0] = count, then read indices) until the overlap pass reuses it as hash chains
 };
 

@@ -14,6 +14,7 @@ CONFIGS = [
     ("mpileup30_noref", dict(n_ref=60000, depth=30, read_len=150, seed=42, paired=False), ["mpileup", "{sam}"]),
     ("mpileup30_B", dict(n_ref=60000, depth=30, read_len=150, seed=43, paired=False), ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
     ("mpileup30_baq", dict(n_ref=30000, depth=30, read_len=150, seed=44, paired=False), ["mpileup", "-f", "{fa}", "{sam}"]),
+    ("mpileup30_baq_100k_reads", dict(n_ref=500000, depth=30, read_len=150, seed=55, paired=True), ["mpileup", "-f", "{fa}", "{sam}"]),
     ("mpileup_baq_indels", dict(n_ref=20000, depth=30, read_len=150, seed=54, paired=False, indel_rate=0.3, max_indel=14), ["mpileup", "-f", "{fa}", "{sam}"]),
     ("mpileup30_pairs_olap", dict(n_ref=60000, depth=30, read_len=150, seed=45, paired=True), ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
     ("mpileup_EA_pairs", dict(n_ref=30000, depth=30, read_len=150, seed=46, paired=True), ["mpileup", "-E", "-A", "-f", "{fa}", "{sam}"]),

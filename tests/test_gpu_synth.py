@@ -97,3 +97,39 @@ def test_output_extra_tags_and_rnext_equal_oracle(tmp_path, oracle_bin, product_
         assert got.returncode == 0, got.stderr.decode()[-500:]
         assert got.stdout == want, args
         assert len(want) > 1000
+
+
+def test_overlap_placeholder_sees_resolved_quality_only_if_mate_triggers_column(tmp_path, oracle_bin, product_bin):
+    """HTSlib resolves a mate pair when the second mate is PUSHED; a column is handed out as soon as a read starting
+    beyond it has been pushed.  A deletion placeholder shows the quality of the next base, which may lie in the overlap:
+    columns before the mate's start see the resolved value only when the mate itself is the first read beyond the column.
+    Hand-made pairs: deletion / ref skip ending exactly at the mate's start, with and without other reads starting in
+    between, several names (the keeper of a pair is chosen by a hash of the name), default and 30-column windows."""
+    import re
+
+    def sam(name, cigar, extra_reads):
+        qlen = sum(int(n) for n, op in re.findall(r"(\d+)([MIDNS=X])", cigar) if op in "MIS=X")
+        a_q = ("5" * 50 + "&" + "5" * 40)[:qlen]      # base 50 (the first one after the deletion) has quality 5
+        lines = ["@HD\tVN:1.6\tSO:coordinate", "@SQ\tSN:c\tLN:1000",
+                 "%s\t99\tc\t101\t60\t%s\t=\t153\t122\t%s\t%s" % (name, cigar, "A" * qlen, a_q)]
+        for pos in extra_reads:
+            lines.append("x%d\t0\tc\t%d\t60\t30M\t*\t0\t0\t%s\t%s" % (pos, pos, "C" * 30, "I" * 30))
+        lines.append("%s\t147\tc\t153\t60\t70M\t=\t101\t-122\t%s\t%s" % (name, "A" * 70, "?" * 70))
+        return "\n".join(lines) + "\n"
+
+    n = 0
+    for name in ("p1", "p2", "q7"):
+        for extra in ([], [152], [153], [151, 152], [140]):
+            for cig in ("50M2D20M", "50M2N20M", "49M1D1N1D20M", "50M4D18M"):
+                path = tmp_path / ("t%d.sam" % n); n += 1
+                path.write_text(sam(name, cig, extra))
+                for env_extra in ({}, {"STA_WINDOW_COLS": "30"}):
+                    args = ["mpileup", "-Q", "0", str(path)]
+                    want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+                    got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env_extra))
+                    assert got.returncode == 0, got.stderr.decode()[-300:]
+                    assert got.stdout == want, (name, extra, cig, env_extra)
+    # the data really exercises both outcomes (resolved and unresolved placeholder qualities)
+    a = subprocess.run([oracle_bin, "mpileup", "-Q", "0", str(tmp_path / "t0.sam")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    b = subprocess.run([oracle_bin, "mpileup", "-Q", "0", str(tmp_path / "t4.sam")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    assert [l for l in a.split(b"\n") if l.startswith(b"c\t151\t")] != [l for l in b.split(b"\n") if l.startswith(b"c\t151\t")]

@@ -215,6 +215,11 @@ int sta_fetch_col_offsets(sta_engine *e, uint64_t *host_offs, uint64_t n);
 /* per-read state after a plan: info words (bit 1 = read is in the pileup) and the working quality
  * pool (mate-overlap / BAQ adjusted), laid out like sta_reads.qual.  Either pointer may be NULL. */
 int sta_fetch_read_state(sta_engine *e, int32_t file, uint32_t *host_info, uint8_t *host_qual);
+/* mate-overlap visibility records of the last plan (one per read; fix_y[i] = -1: none): the query index whose quality a
+ * deletion / ref-skip placeholder of read i shows, that quality before the pair was resolved, and the mate's read index.
+ * HTSlib resolves a pair when the second mate is pushed, so columns handed out earlier still see the old value
+ * (DESIGN.md section 2); the iterator surface uses these to present b->qual[] as of each column. */
+int sta_fetch_overlap_fixups(sta_engine *e, int32_t file, int32_t *fix_y, int32_t *fix_mate, uint8_t *fix_q);
 
 /* ---- coverage / bedcov: per-window column reductions (coverage.c:621-672, bedcov.c:316-333) ---- */
 typedef struct sta_cov_params {

@@ -717,6 +717,21 @@ int sta_cov_plan(sta_engine *e, const sta_cov_params *cp, sta_cov_totals *totals
     return STA_OK;
 }
 
+int sta_fetch_overlap_fixups(sta_engine *e, int32_t file, int32_t *fix_y, int32_t *fix_mate, uint8_t *fix_q)
+{
+    if (!e || file < 0 || (size_t)file >= e->files_h.size() || !fix_y || !fix_mate || !fix_q) return STA_ERR_ARG;
+    if (!e->planned) return fail(e, STA_ERR_ARG, "no planned window");
+    hipSetDevice(e->device);
+    StaReadsDev &d = e->files_h[(size_t)file];
+    if (!d.n) return STA_OK;
+    if (!d.fix_y) { for (int64_t i = 0; i < d.n; ++i) fix_y[i] = -1; return STA_OK; }
+    HIPCHK(hipMemcpyAsync(fix_y, d.fix_y, (size_t)d.n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(fix_mate, d.fix_mate, (size_t)d.n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(fix_q, d.fix_q, (size_t)d.n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return STA_OK;
+}
+
 int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info)
 {
     if (!e || !p) return STA_ERR_ARG;

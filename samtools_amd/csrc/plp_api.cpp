@@ -158,6 +158,10 @@ struct sta_bam_plp {
     std::vector<uint8_t> qpool;
     std::vector<LiveRead *> win_reads;
     std::vector<bam_pileup1_t> plp;
+    // mate-overlap resolution becomes visible in b->qual[] at the column HTSlib would have applied it (push order)
+    struct Pending { int64_t vis_col; LiveRead *r; int32_t y; uint8_t q_new; };
+    std::vector<Pending> pend_vis; size_t pend_next = 0;
+    std::vector<int32_t> fix_y, fix_mate; std::vector<uint8_t> fix_q;
     Soa soa;
     bam1_t tmp;                        // caller-owned record the callback fills
 
@@ -282,15 +286,42 @@ int build_window(sta_bam_plp *it)
         fprintf(stderr, "[E::bam_plp] %s\n", sta_last_error(it->eng));
         it->error = 1; return ST_ERR;
     }
+    it->pend_vis.clear(); it->pend_next = 0;
+    if (it->overlaps) {
+        const size_t nr = it->win_reads.size();
+        it->fix_y.assign(nr, -1); it->fix_mate.assign(nr, 0); it->fix_q.assign(nr, 0);
+        if (sta_fetch_overlap_fixups(it->eng, 0, it->fix_y.data(), it->fix_mate.data(), it->fix_q.data()) != STA_OK) {
+            fprintf(stderr, "[E::bam_plp] %s\n", sta_last_error(it->eng));
+            it->error = 1; return ST_ERR;
+        }
+    }
     for (size_t i = 0; i < it->win_reads.size(); ++i) {
         LiveRead *r = it->win_reads[i];
-        if (it->overlaps && r->b.core.l_qseq > 0)
-            memcpy(bam_get_qual(&r->b), &it->qpool[(size_t)it->soa.base_off8[i] << 3], (size_t)r->b.core.l_qseq);
+        if (it->overlaps && r->b.core.l_qseq > 0) {
+            uint8_t *q = bam_get_qual(&r->b);
+            memcpy(q, &it->qpool[(size_t)it->soa.base_off8[i] << 3], (size_t)r->b.core.l_qseq);
+            const int32_t y = it->fix_y[i];
+            if (y >= 0 && y < r->b.core.l_qseq && q[y] != it->fix_q[i]) {
+                // the pair was resolved when the mate was pushed; columns handed out before that still show the old value.
+                // They are the columns below the start of the last read that advanced the iterator before the mate.
+                const size_t m = (size_t)it->fix_mate[i];
+                int64_t vis = it->win_reads[m]->b.core.pos;
+                for (size_t j = m; j-- > 0;) {
+                    const uint32_t inf = it->info[j];
+                    const LiveRead *rj = it->win_reads[j];
+                    const bool dropped = (inf & 1u) && !(inf & 2u) && ref_span(&rj->b) > 0;      // pushed, but removed by the -d cap
+                    if ((inf & 1u) && !dropped) { vis = rj->b.core.pos; break; }
+                }
+                it->pend_vis.push_back(sta_bam_plp::Pending{ vis, r, y, q[y] });
+                q[y] = it->fix_q[i];
+            }
+        }
         if ((it->info[i] & 2u) && !r->constructed) {          // read entered the pileup: constructor hook
             r->constructed = true;
             if (it->ctor) it->ctor(it->data, &r->b, &r->cd);
         }
     }
+    std::sort(it->pend_vis.begin(), it->pend_vis.end(), [](const sta_bam_plp::Pending &a, const sta_bam_plp::Pending &b) { return a.vis_col < b.vis_col; });
     return ST_OK;
 }
 
@@ -304,6 +335,10 @@ const bam_pileup1_t *next64(sta_bam_plp *it, int *tid, hts_pos_t *pos, int *n_pl
                 const int64_t c = it->cur++;
                 const uint64_t a = it->offs[(size_t)c], b = it->offs[(size_t)c + 1];
                 if (b == a) continue;
+                while (it->pend_next < it->pend_vis.size() && it->pend_vis[it->pend_next].vis_col <= it->cb + c) {
+                    const auto &pv = it->pend_vis[it->pend_next++];
+                    bam_get_qual(&pv.r->b)[pv.y] = pv.q_new;
+                }
                 it->plp.resize((size_t)(b - a));
                 for (uint64_t k = a; k < b; ++k) {
                     const sta_plp_entry &e = it->ent[(size_t)k];

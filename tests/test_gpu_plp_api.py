@@ -73,3 +73,11 @@ def test_plp_surface_max_depth_cap(oracle_bin, product_bin):
     """bam_plp_set_maxcnt: reads arriving at a start position once more than maxcnt are live are dropped (47.out rule)."""
     run_both(oracle_bin, product_bin, ["-d", "8500", os.path.join(G, "mpileup", "deep.sam")], {})
     run_both(oracle_bin, product_bin, ["-x", "-d", "20", os.path.join(G, "dat", "mpileup.1.sam")], {})
+
+
+def test_plp_surface_overlap_visibility_at_scale(tmp_path, oracle_bin, product_bin):
+    """150 000 columns of 30x pairs with frequent indels: b->qual[] of every entry must be what HTSlib would show AT THAT
+    COLUMN (a pair is resolved when its second mate is pushed; deletion placeholders before the mate's start can tell)."""
+    sam, _ = write_synth_sam(str(tmp_path), n_ref=150000, depth=30, read_len=150, seed=106, paired=True, indel_rate=0.1, max_indel=7)
+    run_both(oracle_bin, product_bin, [sam], {})
+    run_both(oracle_bin, product_bin, [sam], {"STA_PLP_BATCH": "3000"})

@@ -72,6 +72,8 @@ extern "C" {
 #define STA_AUX_HAS_BQ   1   /* BQ:Z present (and usable)         */
 #define STA_AUX_HAS_ZQ   2   /* ZQ:Z present                      */
 #define STA_AUX_SKIP     4   /* excluded by -G read-group list    */
+#define STA_AUX_ACCEPTED 8   /* carried over from an earlier window of the same iterator, where the -d cap (bam_plp_push)
+                              * already accepted it: the cap is not re-tested, the read still counts as live */
 
 /* where the arrays of a sta_reads / sta_window live */
 #define STA_MEM_HOST   0     /* engine copies them to HBM (pinned staging) */

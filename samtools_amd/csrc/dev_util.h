@@ -231,4 +231,5 @@ __device__ __forceinline__ void block_reduce_atomic(unsigned long long (&v)[N], 
         for (int w = 1; w < nw; ++w) { unsigned long long y = red_[w][k]; x = k < NSUM ? x + y : (y > x ? y : x); }
         if (x) { if (k < NSUM) atomicAdd(dst[k], x); else atomicMax(dst[k], x); }
     }
+    __syncthreads();      // the staging array is reused by the next call in the same kernel (k_cov_cols calls this per file)
 }

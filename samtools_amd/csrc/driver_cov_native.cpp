@@ -84,6 +84,14 @@ int cov_run_tid(sta_engine *eng, Pump &pump, std::vector<std::unique_ptr<AlnRead
                     for (size_t i = 0; i < info.size(); ++i)
                         if ((info[i] & 2u) && (first || staged[f].pos[i] >= 0)) acc.kept[f]++;
                 }
+            if (pi.n_maxcnt_dropped)
+                for (size_t f = 0; f < nf; ++f) {
+                    info.resize((size_t)staged[f].n());
+                    if (info.empty() || sta_fetch_read_state(eng, (int32_t)f, info.data(), nullptr) != STA_OK) continue;
+                    std::vector<char> dr(info.size());
+                    for (size_t i = 0; i < info.size(); ++i) dr[i] = (info[i] & 1u) && !(info[i] & 2u) && reads[f][i]->rlen > 0;
+                    pump.drop(f, dr);          // reads the depth cap removed never come back (bam_plp_push did not store them)
+                }
             first = false;
         }
         pump.retire(ce);

@@ -67,6 +67,7 @@ struct Runner {
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
     std::vector<StagedFile> staged;
     std::vector<char> text;
+    std::vector<std::vector<char>> cap_dropped;      // per file: reads of the last window that the -d cap dropped
     int loaded_ref_tid = -2;
 
     explicit Runner(Conf &c) : conf(c) {}
@@ -111,6 +112,20 @@ struct Runner {
         sta_plan_info info;
         if (sta_mpileup_plan(eng, &p, &info) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
         if (n_data) *n_data = info.n_data_cols;
+        cap_dropped.assign(nf, {});
+        if (info.n_maxcnt_dropped && reads) {
+            // the cap removed reads from the iterator: they must not be carried into the next window (bam_plp_push never
+            // stored them); info bit 0 = reached bam_plp_push, bit 1 = in the pileup
+            std::vector<uint32_t> inf;
+            for (size_t f = 0; f < nf; ++f) {
+                inf.resize((size_t)staged[f].n());
+                if (inf.empty()) continue;
+                if (sta_fetch_read_state(eng, (int32_t)f, inf.data(), nullptr) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
+                cap_dropped[f].assign(inf.size(), 0);
+                for (size_t i = 0; i < inf.size(); ++i)
+                    cap_dropped[f][i] = (inf[i] & 1u) && !(inf[i] & 2u) && (*reads)[f][i]->rlen > 0;
+            }
+        }
         if (!write || info.out_bytes == 0) return 0;
         if (sta_mpileup_emit(eng, nullptr, 0) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
         text.resize((size_t)info.out_bytes);
@@ -169,6 +184,8 @@ struct Runner {
                     }
                 } else if (run_window(tid, cursor, ce, &reads, started ? 1 : 0, true, &n_data) < 0) return -1;
             }
+            for (size_t f = 0; f < cap_dropped.size(); ++f) if (!cap_dropped[f].empty()) pump.drop(f, cap_dropped[f]);
+            cap_dropped.clear();
             pump.retire(ce);
             cursor = std::max(cursor, ce);
         }

@@ -38,6 +38,7 @@ struct Rec {
     std::vector<std::string> tagtext;
     std::vector<char> tag_has;
     int64_t rlen = 0;            // reference span (bam_cigar2rlen)
+    bool accepted = false;       // carried from an earlier window whose -d replay kept it (STA_AUX_ACCEPTED when re-staged)
     int64_t end() const { return pos + rlen; }
     int64_t endpos() const { int64_t l = (flag & 4) ? 0 : rlen; return pos + (l > 0 ? l : 1); }   // bam_endpos
 };

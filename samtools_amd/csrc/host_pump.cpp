@@ -93,11 +93,20 @@ int64_t Pump::fill(int tid, int64_t cb, int64_t ce_target, std::vector<std::vect
     return ce;
 }
 
+void Pump::drop(size_t f, const std::vector<char> &dropped)
+{
+    std::deque<Rec> keep;
+    size_t i = 0;
+    for (auto &r : carry_[f]) { if (!(i < dropped.size() && dropped[i])) keep.push_back(std::move(r)); ++i; }
+    carry_[f].swap(keep);
+}
+
 void Pump::retire(int64_t ce)
 {
     for (auto &c : carry_) {
         auto it = std::remove_if(c.begin(), c.end(), [&](const Rec &r) { return span_end(r) <= ce; });
         c.erase(it, c.end());
+        for (auto &r : c) r.accepted = true;       // what stays was accepted by this window's -d replay
     }
 }
 

@@ -32,6 +32,9 @@ public:
     int64_t fill(int tid, int64_t cb, int64_t ce_target, std::vector<std::vector<const Rec *>> &reads);
     // After the window [cb, ce) was processed: keep only reads that extend beyond ce.
     void retire(int64_t ce);
+    // before retire(): reads of file f (indexed as fill() returned them) that the -d cap dropped in this window leave the
+    // iterator for good, exactly as bam_plp_push never stored them
+    void drop(size_t f, const std::vector<char> &dropped);
     void drop_tid_carry();             // forget carried reads when leaving a contig
     int error() const { return err_; }   // <0 after a decode error or unsorted input
     const char *error_text() const { return errtxt_.c_str(); }

@@ -37,6 +37,7 @@ void StagedFile::add(const Rec &r, int64_t origin, const std::set<std::string> *
     if (bq_ok) a |= STA_AUX_HAS_BQ;
     if (r.has_zq) a |= STA_AUX_HAS_ZQ;
     if (rg_excl && !r.rg.empty() && rg_excl->count(r.rg)) a |= STA_AUX_SKIP;
+    if (r.accepted) a |= STA_AUX_ACCEPTED;
     aux.push_back(a);
     l_qseq.push_back(r.l_qseq);
     cig_off.push_back((uint32_t)cigar.size());

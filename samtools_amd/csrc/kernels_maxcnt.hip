@@ -7,7 +7,9 @@
 // order-dependent recurrence, but it can only trigger where more than maxcnt-1 reads are stacked,
 // so: k_maxcnt_detect bounds the stack height of every read with one binary search on `maxend`
 // (parallel, cheap) and raises a flag; only flagged windows run k_maxcnt_serial, a single-lane
-// exact replay (still on the device -- there is no host fallback).
+// exact replay (still on the device -- there is no host fallback).  Across windows the host keeps the
+// iterator's state consistent: reads the cap dropped are not carried into the next window, and carried
+// reads arrive flagged STA_AUX_ACCEPTED (they count as live but are never re-tested).
 #include "dev_util.h"
 
 __global__ void __launch_bounds__(256) k_maxcnt_detect(StaReadsDev R, int maxcnt, StaCounters *ctr)
@@ -40,7 +42,7 @@ __global__ void k_maxcnt_serial(StaReadsDev R, int maxcnt, int32_t col_lo, int32
             for (int32_t c = retired + 1; c <= p - 1; ++c) { if (c - col_lo >= 0 && c - col_lo <= span) live -= hist[c - col_lo]; }
             if (p - 1 > retired) retired = p - 1;
             cur_p = p;
-        } else if (live + 1 > (long long)maxcnt) {
+        } else if (!(R.aux[i] & STA_AUX_ACCEPTED) && live + 1 > (long long)maxcnt) {
             if (info & RI_KEEP) { R.info[i] = info & ~(RI_KEEP | RI_OLAP_EL); dropped++; }
             else R.info[i] = info & ~RI_PUSHED;      // zero-span read that would have been dropped: no effect
             continue;

@@ -24,6 +24,8 @@ struct LiveRead {
     bam1_t b;
     int64_t end = 0;                 // bam_endpos: pos + max(reference span, 1)
     bool constructed = false;
+    bool accepted = false;           // carried from an earlier window whose -d replay kept it
+    bool cap_dropped = false;        // removed by the -d cap in the window just processed
     bam_pileup_cd cd;
     std::vector<uint8_t> orig_qual;  // qualities as pushed (mate-overlap resolution restarts from these in every window)
 };
@@ -80,7 +82,7 @@ struct Soa {
         pos.push_back((int32_t)(b->core.pos - origin));
         flag.push_back(b->core.flag);
         mapq.push_back(b->core.qual);
-        aux.push_back(0);
+        aux.push_back(r.accepted ? STA_AUX_ACCEPTED : 0);
         int32_t lq = b->core.l_qseq;
         l_qseq.push_back(lq);
         cig_off.push_back((uint32_t)cigar.size());
@@ -207,10 +209,10 @@ void retire(sta_bam_plp *it)
     // reads that cannot reach a column >= ce leave the iterator (destructor hook, like bam_plp_next's mp_free)
     std::deque<LiveRead *> keep;
     for (LiveRead *r : it->live) {
-        if (r->end <= it->ce) {
+        if (r->end <= it->ce || r->cap_dropped) {
             if (r->constructed && it->dtor) it->dtor(it->data, &r->b, &r->cd);
             free_read(r);
-        } else keep.push_back(r);
+        } else { r->accepted = true; keep.push_back(r); }
     }
     it->live.swap(keep);
     it->prev_tid = it->win_tid; it->prev_ce = it->ce;
@@ -316,6 +318,7 @@ int build_window(sta_bam_plp *it)
                 q[y] = it->fix_q[i];
             }
         }
+        r->cap_dropped = (it->info[i] & 1u) && !(it->info[i] & 2u) && ref_span(&r->b) > 0;      // bam_plp_push never stored it
         if ((it->info[i] & 2u) && !r->constructed) {          // read entered the pileup: constructor hook
             r->constructed = true;
             if (it->ctor) it->ctor(it->data, &r->b, &r->cd);

@@ -66,5 +66,6 @@ def test_engine_bedcov_header_and_depth_columns(product_bin, oracle_bin, tmp_pat
     big = os.path.join(os.path.dirname(G), "mpileup", "mpileup.1.bam")
     bed = tmp_path / "b.bed"; bed.write_text("17\t100\t2000\tx\n17\t3000\t3000\n17\t150\t160\n17\t4000\t9000\n")
     for args in (["-d", "20", "-c", "bedcov_gG.bed", "bedcov.bam"], ["-Q", "30", "-j", "-d", "5", "bedcov_gG.bed", "bedcov.bam", "bedcov.bam"],
-                 ["-c", "-d", "0", str(bed), big], ["-j", "-Q", "20", "-g", "1024", str(bed), big, big]):
+                 ["-c", "-d", "0", str(bed), big], ["-j", "-Q", "20", "-g", "1024", str(bed), big, big],
+                 ["-j", "-d", "20", "-c", str(bed), big, os.path.join(os.path.dirname(G), "mpileup", "mpileup.2.bam"), big]):
         assert run(product_bin, args, G, iterator) == run(oracle_bin, args, G), args

@@ -133,3 +133,18 @@ def test_overlap_placeholder_sees_resolved_quality_only_if_mate_triggers_column(
     a = subprocess.run([oracle_bin, "mpileup", "-Q", "0", str(tmp_path / "t0.sam")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
     b = subprocess.run([oracle_bin, "mpileup", "-Q", "0", str(tmp_path / "t4.sam")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
     assert [l for l in a.split(b"\n") if l.startswith(b"c\t151\t")] != [l for l in b.split(b"\n") if l.startswith(b"c\t151\t")]
+
+
+@pytest.mark.parametrize("window", [None, "3000", "700"])
+def test_depth_cap_is_exact_across_windows(tmp_path, oracle_bin, product_bin, window):
+    """-d / bam_mplp_set_maxcnt is order dependent (live-node count when a read arrives): reads it drops must stay out of
+    later windows and reads it kept must not be re-tested there (STA_AUX_ACCEPTED).  400x pairs, cap 50 and 120."""
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=12000, depth=400, read_len=150, seed=204, paired=True, indel_rate=0.03)
+    env = dict(os.environ)
+    if window:
+        env["STA_WINDOW_COLS"] = window; env["STA_PLP_BATCH"] = window
+    for args in (["mpileup", "-B", "-d", "50", "-f", fa, sam], ["mpileup", "-d", "120", "-f", fa, sam], ["plpdump", "-d", "100", sam]):
+        want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert got.returncode == 0, got.stderr.decode()[-300:]
+        assert got.stdout == want, args

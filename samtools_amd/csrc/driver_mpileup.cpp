@@ -69,6 +69,7 @@ struct Runner {
     std::vector<char> text;
     std::vector<std::vector<char>> cap_dropped;      // per file: reads of the last window that the -d cap dropped
     int loaded_ref_tid = -2;
+    int64_t loaded_ref_len = INT64_MAX;               // length of the loaded FASTA contig (INT64_MAX: none, no length filter)
 
     explicit Runner(Conf &c) : conf(c) {}
 
@@ -77,8 +78,10 @@ struct Runner {
         if (!conf.fai || tid == loaded_ref_tid) return 0;
         sta_clear_references(eng);
         loaded_ref_tid = tid;
+        loaded_ref_len = INT64_MAX;
         const std::string *s = conf.fai->fetch(h->names[(size_t)tid]);
         if (!s) return 0;
+        loaded_ref_len = (int64_t)s->size();
         return sta_set_reference(eng, tid, s->data(), (int64_t)s->size(), STA_MEM_HOST);
     }
 
@@ -151,6 +154,7 @@ struct Runner {
     int process_tid(Pump &pump, int tid, int mode)
     {
         int64_t tlen = h->lens[(size_t)tid];
+        if (set_ref(tid) < 0) return -1;            // also tells the pump's lookahead the FASTA length of this contig
         int64_t lo = has_reg ? beg0 : 0;
         int64_t hi_all = has_reg ? std::min(end0, tlen) : tlen;
         bool started = mode == 2;
@@ -159,7 +163,7 @@ struct Runner {
         for (;;) {
             bool more = pump.next_pos(tid) != INT64_MAX;
             if (!more && !pump.has_carry()) break;
-            if (!started && !pump.has_carry()) cursor = std::max(cursor, pump.next_pos(tid));   // skip uncovered gap
+            if (!started) cursor = std::max(cursor, std::min(pump.carry_next_covered(cursor), pump.next_pos(tid)));   // skip uncovered gap
             int64_t ce_target = cursor + conf.window_cols;
             if (has_reg) ce_target = std::min(ce_target, end0);
             if (ce_target <= cursor) {              // past the region end: drain the rest of this contig
@@ -197,6 +201,23 @@ struct Runner {
     int run()
     {
         PumpConfig pc; pc.window_cols = conf.window_cols; pc.max_reads = conf.max_reads; pc.use_endpos = false;
+        if (conf.p.flag & STA_MPLP_SMART_OVERLAPS) {
+            pc.keep_mates = true;
+            // host-side "this record certainly reaches bam_plp_push" (subset of k_prep_reads' filters: whatever needs the
+            // device's view -- BED, -C, contig length -- answers "not sure" and the lookahead just runs on)
+            const sta_mplp_params pp = conf.p;
+            const bool unsure = conf.bed || conf.has_rg_excl || pp.capQ_thres > 0 || pp.min_qlen > 0;
+            pc.surely_pushed = [this, pp, unsure](const Rec &r) {
+                if (unsure || (r.flag & 4)) return false;
+                if (r.tid != loaded_ref_tid && conf.fai) return false;
+                if (r.pos >= loaded_ref_len) return false;
+                if (pp.rflag_require && !(pp.rflag_require & r.flag)) return false;
+                if (pp.rflag_filter && (pp.rflag_filter & r.flag)) return false;
+                if ((int)r.mapq < pp.min_mq) return false;
+                if ((pp.flag & STA_MPLP_NO_ORPHAN) && (r.flag & 1) && !(r.flag & 2)) return false;
+                return true;
+            };
+        }
         Pump pump(readers, pc);
         const int all = conf.p.all;
         const int mode = all >= 2 ? 2 : all;

@@ -60,6 +60,13 @@ bool Pump::has_carry() const
     return false;
 }
 
+int64_t Pump::carry_next_covered(int64_t cursor) const
+{
+    int64_t best = INT64_MAX;
+    for (auto &c : carry_) for (auto &r : c) if (span_end(r) > cursor) best = std::min(best, std::max(r.pos, cursor));
+    return best;
+}
+
 int64_t Pump::carry_max_end() const
 {
     int64_t m = INT64_MIN;
@@ -85,6 +92,20 @@ int64_t Pump::fill(int tid, int64_t cb, int64_t ce_target, std::vector<std::vect
             }
         }
     }
+    if (cfg_.surely_pushed) {
+        for (size_t f = 0; f < n; ++f) {
+            // the iterators of different files advance independently (bam_mplp_*): lookahead is per file
+            int64_t me = INT64_MIN;
+            for (auto &r : carry_[f]) me = std::max(me, span_end(r));
+            bool sure = false;
+            for (auto &r : carry_[f]) if (r.pos >= ce && cfg_.surely_pushed(r)) { sure = true; break; }   // cut windows
+            while (!sure && has_pend_[f] && pend_[f].tid == tid && pend_[f].pos < me) {
+                sure = cfg_.surely_pushed(pend_[f]);
+                carry_[f].push_back(std::move(pend_[f]));
+                advance(f);
+            }
+        }
+    }
     reads.assign(n, {});
     for (size_t f = 0; f < n; ++f) {
         reads[f].reserve(carry_[f].size());
@@ -104,8 +125,22 @@ void Pump::drop(size_t f, const std::vector<char> &dropped)
 void Pump::retire(int64_t ce)
 {
     for (auto &c : carry_) {
-        auto it = std::remove_if(c.begin(), c.end(), [&](const Rec &r) { return span_end(r) <= ce; });
-        c.erase(it, c.end());
+        std::vector<const Rec *> stay;
+        if (cfg_.keep_mates)
+            for (auto &r : c) if (span_end(r) > ce && (r.flag & 1) && (r.flag & 2) && !(r.flag & 8)) stay.push_back(&r);
+        auto mate_stays = [&](const Rec &r) {
+            if (!(r.flag & 1) || !(r.flag & 2) || (r.flag & 8) || r.mtid != r.tid) return false;
+            auto lo = std::lower_bound(stay.begin(), stay.end(), r.mpos, [](const Rec *s, int64_t p) { return s->pos < p; });   // carry is position sorted
+            for (; lo != stay.end() && (*lo)->pos == r.mpos; ++lo) if (*lo != &r && (*lo)->qname == r.qname) return true;
+            return false;
+        };
+        std::vector<char> gone(c.size(), 0);       // decided before anything moves: `stay` points into c
+        size_t i = 0;
+        for (auto &r : c) { gone[i++] = span_end(r) <= ce && !(!stay.empty() && mate_stays(r)); }
+        std::deque<Rec> keep;
+        i = 0;
+        for (auto &r : c) { if (!gone[i++]) keep.push_back(std::move(r)); }
+        c.swap(keep);
         for (auto &r : c) r.accepted = true;       // what stays was accepted by this window's -d replay
     }
 }

@@ -16,6 +16,17 @@ struct PumpConfig {
     int64_t window_cols = 1 << 20;     // target columns per window
     int64_t max_reads = 4 << 20;       // soft cap of new reads per file per window
     bool use_endpos = false;           // carry criterion: bam_endpos (depth) instead of pos + rlen (mpileup)
+    // Mate-overlap lookahead (mpileup): HTSlib hands out column c once a read starting beyond c was pushed, and a pair is
+    // resolved when its second mate is pushed -- so a window must also stage the reads that start at or after its end,
+    // up to the first one that certainly reaches bam_plp_push (the trigger of the window's last columns), as far as
+    // they can still be the mate of a staged read (start < largest staged end).  They add no columns to this window
+    // and simply stay carried for the next one.  Empty function = no lookahead (depth, coverage).
+    std::function<bool(const Rec &)> surely_pushed;
+    // Mate overlaps again: every window re-derives the resolved qualities from the records as read, so a read that can no
+    // longer touch a column must still be staged for as long as its mate can -- HTSlib's resolution may rewrite bases of
+    // the later mate beyond the earlier mate's end (the deletion branch of tweak_overlap_quality), and those stay visible
+    // after the earlier mate has left the pileup.
+    bool keep_mates = false;
 };
 
 class Pump {
@@ -26,6 +37,8 @@ public:
     // position of the first unread record on `tid` over all files (INT64_MAX if none)
     int64_t next_pos(int tid);
     bool has_carry() const;
+    // first column >= cursor that a carried read can touch (INT64_MAX if none)
+    int64_t carry_next_covered(int64_t cursor) const;
     int64_t carry_max_end() const;
     // Consume records of `tid` starting before `ce_target` (possibly fewer: the read cap may cut the
     // window short) and return the actual window end.  reads[f] = carried + new records of file f.

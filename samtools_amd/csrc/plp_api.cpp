@@ -26,6 +26,7 @@ struct LiveRead {
     bool constructed = false;
     bool accepted = false;           // carried from an earlier window whose -d replay kept it
     bool cap_dropped = false;        // removed by the -d cap in the window just processed
+    bool ghost = false;              // left the pileup (destructor done) but still staged: its mate is live (overlap resolution)
     bam_pileup_cd cd;
     std::vector<uint8_t> orig_qual;  // qualities as pushed (mate-overlap resolution restarts from these in every window)
 };
@@ -208,10 +209,25 @@ void retire(sta_bam_plp *it)
 {
     // reads that cannot reach a column >= ce leave the iterator (destructor hook, like bam_plp_next's mp_free)
     std::deque<LiveRead *> keep;
+    // Overlap resolution is re-derived from the pushed qualities in every window, and HTSlib may rewrite bases of one mate
+    // beyond the other mate's end (deletion branch of tweak_overlap_quality): a read whose mate stays is kept staged as a
+    // "ghost" -- destructor hook fired, no columns -- until the mate leaves too.
+    std::vector<const LiveRead *> stay;
+    if (it->overlaps)
+        for (const LiveRead *r : it->live)
+            if (r->end > it->ce && !r->cap_dropped && (r->b.core.flag & 1) && (r->b.core.flag & 2) && !(r->b.core.flag & 8)) stay.push_back(r);
+    auto mate_stays = [&](const LiveRead *r) {
+        const auto &c = r->b.core;
+        if (!(c.flag & 1) || !(c.flag & 2) || (c.flag & 8) || c.mtid != c.tid) return false;
+        for (const LiveRead *s : stay) if (s != r && s->b.core.pos == c.mpos && !strcmp(bam_get_qname(&s->b), bam_get_qname(&r->b))) return true;
+        return false;
+    };
     for (LiveRead *r : it->live) {
         if (r->end <= it->ce || r->cap_dropped) {
             if (r->constructed && it->dtor) it->dtor(it->data, &r->b, &r->cd);
-            free_read(r);
+            r->constructed = false;
+            if (!r->cap_dropped && !stay.empty() && mate_stays(r)) { r->ghost = true; r->accepted = true; keep.push_back(r); }
+            else free_read(r);
         } else { r->accepted = true; keep.push_back(r); }
     }
     it->live.swap(keep);
@@ -261,6 +277,15 @@ int build_window(sta_bam_plp *it)
     }
     it->soa.clear();
     it->win_reads.assign(it->live.begin(), it->live.end());
+    // Mate overlaps: HTSlib resolves a pair when its second mate is pushed, and the record that bounds this window (peek)
+    // is the push that releases the window's last columns -- if it is the mate of a staged read, those columns already
+    // see the resolved quality.  So peek is staged too (it has no column here) whenever it can overlap a staged read.
+    LiveRead *lookahead = nullptr;
+    if (it->overlaps && it->peek && it->peek->b.core.tid == tid) {
+        int64_t max_end = INT64_MIN;
+        for (LiveRead *r : it->live) max_end = std::max(max_end, r->end);
+        if (it->peek->b.core.pos < max_end) { lookahead = it->peek; it->win_reads.push_back(lookahead); }
+    }
     // reads starting at or beyond ce have no column here; they are staged anyway (they are few) to keep indices simple
     for (LiveRead *r : it->win_reads) {
         if (it->overlaps && r->orig_qual.empty() && r->b.core.l_qseq > 0)
@@ -319,11 +344,12 @@ int build_window(sta_bam_plp *it)
             }
         }
         r->cap_dropped = (it->info[i] & 1u) && !(it->info[i] & 2u) && ref_span(&r->b) > 0;      // bam_plp_push never stored it
-        if ((it->info[i] & 2u) && !r->constructed) {          // read entered the pileup: constructor hook
+        if ((it->info[i] & 2u) && !r->constructed && !r->ghost) {          // read entered the pileup: constructor hook
             r->constructed = true;
             if (it->ctor) it->ctor(it->data, &r->b, &r->cd);
         }
     }
+    if (lookahead) lookahead->cap_dropped = false;       // it is a new read of the next window, tested there
     std::sort(it->pend_vis.begin(), it->pend_vis.end(), [](const sta_bam_plp::Pending &a, const sta_bam_plp::Pending &b) { return a.vis_col < b.vis_col; });
     return ST_OK;
 }

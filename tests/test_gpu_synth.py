@@ -148,3 +148,80 @@ def test_depth_cap_is_exact_across_windows(tmp_path, oracle_bin, product_bin, wi
         got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert got.returncode == 0, got.stderr.decode()[-300:]
         assert got.stdout == want, args
+
+
+def test_overlap_placeholder_with_mate_beyond_window_end(tmp_path, oracle_bin, product_bin):
+    """Same corner as above, across a window boundary: the deletion / ref skip straddles the end of a window and the mate
+    starts in the next one.  The window must still see the mate (host_pump lookahead, plp_api peek staging), because the
+    mate is the push that releases the window's last columns.  Window ends swept over the whole run."""
+    def sam(skip, extra):
+        qlen = 70
+        a_q = ("5" * 50 + "&" + "5" * 40)[:qlen]
+        mate = 101 + 50 + skip
+        lines = ["@HD\tVN:1.6\tSO:coordinate", "@SQ\tSN:c\tLN:2000",
+                 "p1\t99\tc\t101\t60\t50M%dN20M\t=\t%d\t%d\t%s\t%s" % (skip, mate, 50 + skip + 70, "A" * qlen, a_q)]
+        for pos in extra:
+            lines.append("x%d\t4\tc\t%d\t0\t*\t*\t0\t0\t%s\t%s" % (pos, pos, "C" * 30, "I" * 30))       # filtered: never pushed
+        lines.append("p1\t147\tc\t%d\t60\t70M\t=\t101\t%d\t%s\t%s" % (mate, -(50 + skip + 70), "A" * 70, "?" * 70))
+        return "\n".join(lines) + "\n"
+
+    n = 0
+    for skip in (40, 200):
+        for extra in ([], [120, 160]):
+            path = tmp_path / ("w%d.sam" % n); n += 1
+            path.write_text(sam(skip, extra))
+            for args in (["mpileup", "-Q", "0", str(path)], ["mpileup", str(path)], ["plpdump", "-x", str(path)]):
+                want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+                for w in ("25", "60", "77", "100", "130", "190", "250"):
+                    got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                         env=dict(os.environ, STA_WINDOW_COLS=w, STA_PLP_BATCH="1"))
+                    assert got.returncode == 0, got.stderr.decode()[-300:]
+                    assert got.stdout == want, (skip, extra, args[:2], w)
+
+
+@pytest.mark.parametrize("seed", [1, 7])
+def test_engine_equals_oracle_on_messy_multicontig_input(tmp_path, oracle_bin, product_bin, seed):
+    """tests/synth_rich.py: clips, long ref skips, pads, =/X, every flag, mates on other contigs, unmapped mates, repeated
+    names, missing SEQ/QUAL, RG/NM tags over three contigs; default and 900-column windows (scripts/hunt3.py in small)."""
+    from synth_rich import write_rich_sam
+    sam, fa = write_rich_sam(str(tmp_path), seed=seed, n_templates=2500)
+    bed = tmp_path / "r.bed"; bed.write_text("c1\t100\t9000\nc1\t9500\t9600\nc2\t0\t4000\tname\nc3\t20000\t44000\n")
+    cases = [["mpileup", "-f", fa, sam], ["mpileup", "-B", "-Q", "0", "-s", "-O", "--output-extra", "FLAG,RNEXT,NM,RG", "-f", fa, sam],
+             ["mpileup", "-B", "-l", str(bed), "-a", sam], ["mpileup", "-r", "c3:1000-30000", "-d", "15", "-f", fa, sam],
+             ["mpileup", "-C", "50", "-f", fa, sam], ["depth", "-a", "-s", "-J", sam], ["plpdump", "-x", sam], ["plpdump", "-d", "12", sam],
+             ["coverage", sam], ["bedcov", "-j", "-d", "8", "-c", str(bed), sam]]
+    for args in cases:
+        want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        for envx in ({}, {"STA_WINDOW_COLS": "900", "STA_PLP_BATCH": "700"}):
+            got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **envx))
+            assert got.returncode == 0, got.stderr.decode()[-300:]
+            assert got.stdout == want, (args[:3], envx)
+
+
+def test_overlap_rewrites_beyond_first_mates_end_survive_window_changes(tmp_path, oracle_bin, product_bin):
+    """HTSlib's tweak_overlap_quality has a deletion branch that rewrites bases of the later mate BEYOND the earlier mate's
+    end (earlier mate sits after a deletion, later mate jumps ahead over a ref skip).  Every window re-derives the
+    resolution from the pushed records, so the earlier mate has to stay staged while the later one is live
+    (Pump::retire keep_mates, plp_api ghosts)."""
+    lines = ["@HD\tVN:1.6\tSO:coordinate", "@SQ\tSN:c\tLN:2000"]
+    for k, (name, off) in enumerate((("p1", 0), ("p2", 300), ("q7", 600), ("zz9", 900))):
+        a, b = 101 + off, 121 + off
+        lines.append("%s\t99\tc\t%d\t60\t20M4D30M\t=\t%d\t120\t%s\t%s" % (name, a, b, "A" * 50, "F" * 50))
+        lines.append("x%d\t0\tc\t%d\t60\t30M\t*\t0\t0\t%s\t%s" % (k, a + 5, "C" * 30, "I" * 30))
+        lines.append("%s\t147\tc\t%d\t60\t10M60N30M\t=\t%d\t-120\t%s\t%s" % (name, b, a, "A" * 40, "".join(chr(40 + i) for i in range(40))))
+    path = tmp_path / "q.sam"; path.write_text("\n".join(lines) + "\n")
+    outs = set()
+    for args in (["mpileup", "-Q", "0", str(path)], ["mpileup", str(path)], ["plpdump", "-x", str(path)]):
+        want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        outs.add(want)
+        for w in (None, "20", "33", "57", "64", "90", "150"):
+            env = dict(os.environ)
+            if w: env.update(STA_WINDOW_COLS=w, STA_PLP_BATCH="1")
+            got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert got.returncode == 0, got.stderr.decode()[-300:]
+            assert got.stdout == want, (args[:2], w)
+    # the data does hit the branch: without overlap resolution the later mate's first bases after the skip keep their quality
+    raw = subprocess.run([oracle_bin, "mpileup", "-Q", "0", "-x", str(path)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    res = subprocess.run([oracle_bin, "mpileup", "-Q", "0", str(path)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    pick = lambda t: [l for l in t.split(b"\n") if l.startswith(b"c\t191\t")]
+    assert pick(raw) != pick(res)

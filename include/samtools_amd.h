@@ -265,6 +265,14 @@ int sta_profile_get(sta_engine *e, sta_kernel_time *out, int cap);
 int sta_main_mpileup(int argc, char **argv);
 int sta_main_depth(int argc, char **argv);
 
+/* ---- host input plumbing (needs no device) ----
+ * The drivers' SAM / BAM reader (stands where sam_open / sam_read1 stand for bam_plcmd.c:500-569): BGZF blocks are inflated
+ * by `threads` workers and records are parsed one batch ahead of the consumer.  sta_io_scan decodes a whole file through it
+ * and returns the record count and an order-dependent checksum over every decoded field (threads <= 0: the drivers'
+ * default, $STA_IO_THREADS or 4; 1 worker is still a separate thread).  stage != 0 additionally pushes the records through
+ * the drivers' window pump and SoA stager (what runs between the reader and sta_stage_window).  Returns 0, or <0 on error. */
+int sta_io_scan(const char *path, int threads, int stage, uint64_t *n_records, uint64_t *checksum);
+
 #ifdef __cplusplus
 }
 #endif

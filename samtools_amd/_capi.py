@@ -124,6 +124,7 @@ _PROTOS = {
     "sta_fetch_read_state": (C.c_int, [_P, C.c_int32, _P, _P]),
     "sta_main_mpileup": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_main_depth": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "sta_io_scan": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 EXPORTED_SYMBOLS = sorted(_PROTOS)
 for _name, (_res, _args) in _PROTOS.items():
@@ -160,6 +161,15 @@ def main_mpileup(args):
 def main_depth(args):
     a = ["depth"] + list(args)
     return lib.sta_main_depth(len(a), _argv(a))
+
+
+def io_scan(path, threads=0, stage=False):
+    """(records, checksum) of a SAM/BAM file decoded by the drivers' reader; needs no device."""
+    n, h = C.c_uint64(0), C.c_uint64(0)
+    rc = lib.sta_io_scan(os.fsencode(path), int(threads), 1 if stage else 0, C.byref(n), C.byref(h))
+    if rc != 0:
+        raise RuntimeError("sta_io_scan(%s) failed: %d" % (path, rc))
+    return n.value, h.value
 
 
 class Engine:

@@ -1,0 +1,234 @@
+// host_bgzf.cpp -- see host_bgzf.h
+#include "host_bgzf.h"
+#include <zlib.h>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace sta {
+
+int io_default_threads()
+{
+    if (const char *e = getenv("STA_IO_THREADS")) { int v = atoi(e); if (v > 0) return v > 64 ? 64 : v; }
+    return 4;
+}
+
+namespace {
+
+// ---- zlib gzread on the caller's thread (plain text, ordinary gzip, stdin) ----
+class GzSource : public ByteSource {
+public:
+    explicit GzSource(gzFile f) : fp_(f) { gzbuffer(fp_, 1 << 18); }
+    ~GzSource() override { if (fp_) gzclose(fp_); }
+    size_t read(void *dst, size_t n) override
+    {
+        size_t got = 0;
+        while (got < n && !eof_) {
+            unsigned want = (unsigned)std::min<size_t>(n - got, 1u << 30);
+            int k = gzread(fp_, (char *)dst + got, want);
+            if (k < 0) { bad_ = true; eof_ = true; break; }
+            if (k == 0) { eof_ = true; break; }
+            got += (size_t)k;
+        }
+        return got;
+    }
+    bool failed() const override { return bad_; }
+private:
+    gzFile fp_; bool eof_ = false, bad_ = false;
+};
+
+// ---- BGZF: one I/O thread cuts blocks, workers inflate, the consumer takes them in file order ----
+class BgzfSource : public ByteSource {
+    enum { EMPTY = 0, QUEUED = 1, DONE = 2 };
+    struct Slot {
+        std::vector<uint8_t> comp, out;
+        uint32_t clen = 0, olen = 0, crc = 0, isize = 0;
+        int state = EMPTY;
+        bool bad = false;
+    };
+public:
+    BgzfSource(FILE *fp, int threads) : fp_(fp)
+    {
+        if (threads < 1) threads = 1;
+        slots_.resize((size_t)threads * 8 + 8);
+        for (auto &s : slots_) { s.comp.resize(1 << 16); s.out.resize(1 << 16); }
+        io_ = std::thread([this] { io_loop(); });
+        for (int i = 0; i < threads; ++i) workers_.emplace_back([this] { work_loop(); });
+    }
+    ~BgzfSource() override
+    {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_free_.notify_all(); cv_work_.notify_all(); cv_done_.notify_all();
+        if (io_.joinable()) io_.join();
+        for (auto &t : workers_) if (t.joinable()) t.join();
+        if (fp_) fclose(fp_);
+    }
+    size_t read(void *dst, size_t n) override
+    {
+        size_t got = 0;
+        while (got < n) {
+            if (cur_ && cur_off_ < cur_->olen) {
+                size_t k = std::min<size_t>(cur_->olen - cur_off_, n - got);
+                memcpy((char *)dst + got, cur_->out.data() + cur_off_, k);
+                cur_off_ += (uint32_t)k; got += k;
+                continue;
+            }
+            if (!advance()) break;
+        }
+        return got;
+    }
+    bool failed() const override { return bad_; }
+private:
+    FILE *fp_;
+    std::vector<Slot> slots_;
+    std::mutex m_;
+    std::condition_variable cv_free_, cv_work_, cv_done_;
+    std::deque<uint64_t> work_;
+    uint64_t n_cut_ = 0, n_taken_ = 0;     // blocks handed to the pool / returned by the consumer (guarded by m_)
+    bool stop_ = false, io_eof_ = false, io_bad_ = false;
+    std::thread io_; std::vector<std::thread> workers_;
+    Slot *cur_ = nullptr; uint32_t cur_off_ = 0; bool bad_ = false, end_ = false;
+
+    // release the current block and wait for the next one in file order
+    bool advance()
+    {
+        if (end_) return false;
+        std::unique_lock<std::mutex> lk(m_);
+        if (cur_) { cur_->state = EMPTY; cur_ = nullptr; ++n_taken_; cv_free_.notify_one(); }
+        for (;;) {
+            if (n_taken_ < n_cut_) {
+                Slot &s = slots_[(size_t)(n_taken_ % slots_.size())];
+                if (s.state == DONE) {
+                    if (s.bad) { bad_ = true; end_ = true; return false; }
+                    cur_ = &s; cur_off_ = 0;
+                    return true;
+                }
+            } else if (io_eof_) {
+                if (io_bad_) bad_ = true;
+                end_ = true;
+                return false;
+            }
+            cv_done_.wait(lk);
+        }
+    }
+
+    void io_loop()
+    {
+        for (;;) {
+            Slot *s;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_free_.wait(lk, [this] { return stop_ || n_cut_ - n_taken_ < slots_.size(); });
+                if (stop_) return;
+                s = &slots_[(size_t)(n_cut_ % slots_.size())];
+            }
+            // SAM spec 4.1: 12 fixed bytes, XLEN, extra subfields (BC carries BSIZE = total block size - 1), deflate data, CRC32, ISIZE
+            uint8_t h[12];
+            size_t k = fread(h, 1, 12, fp_);
+            bool eof = k == 0, bad = false;
+            uint32_t bsize = 0, xlen = 0;
+            if (!eof) {
+                if (k != 12 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) bad = true;
+                else {
+                    xlen = h[10] | (uint32_t)h[11] << 8;
+                    uint8_t x[65536];
+                    if (fread(x, 1, xlen, fp_) != xlen) bad = true;
+                    else {
+                        bool found = false;
+                        for (uint32_t o = 0; o + 4 <= xlen;) {
+                            uint32_t sl = x[o + 2] | (uint32_t)x[o + 3] << 8;
+                            if (x[o] == 'B' && x[o + 1] == 'C' && sl == 2 && o + 6 <= xlen) { bsize = (x[o + 4] | (uint32_t)x[o + 5] << 8) + 1u; found = true; }
+                            o += 4 + sl;
+                        }
+                        if (!found || bsize < 12 + xlen + 8) bad = true;
+                    }
+                }
+                if (!bad) {
+                    uint32_t rest = bsize - 12 - xlen;            // deflate data + CRC32 + ISIZE (the 12 fixed bytes include XLEN)
+                    if (rest < 8 || rest > s->comp.size() + 8) bad = true;
+                    else {
+                        s->clen = rest - 8;
+                        uint8_t tail[8];
+                        if (fread(s->comp.data(), 1, s->clen, fp_) != s->clen || fread(tail, 1, 8, fp_) != 8) bad = true;
+                        else { memcpy(&s->crc, tail, 4); memcpy(&s->isize, tail + 4, 4); if (s->isize > s->out.size()) bad = true; }
+                    }
+                }
+            }
+            std::lock_guard<std::mutex> g(m_);
+            if (eof || bad) { io_eof_ = true; io_bad_ = bad; cv_done_.notify_all(); return; }
+            s->state = QUEUED; s->bad = false;
+            work_.push_back(n_cut_++);
+            cv_work_.notify_one();
+        }
+    }
+
+    void work_loop()
+    {
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) return;
+        for (;;) {
+            Slot *s;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_work_.wait(lk, [this] { return stop_ || !work_.empty(); });
+                if (stop_) break;
+                s = &slots_[(size_t)(work_.front() % slots_.size())];
+                work_.pop_front();
+            }
+            bool bad = false;
+            inflateReset(&zs);
+            zs.next_in = s->comp.data(); zs.avail_in = s->clen;
+            zs.next_out = s->out.data(); zs.avail_out = (uInt)s->out.size();
+            int rc = inflate(&zs, Z_FINISH);
+            s->olen = (uint32_t)(s->out.size() - zs.avail_out);
+            if (rc != Z_STREAM_END || s->olen != s->isize) bad = true;
+            else if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), s->out.data(), s->olen) != s->crc) bad = true;
+            std::lock_guard<std::mutex> g(m_);
+            s->bad = bad; s->state = DONE;
+            cv_done_.notify_all();
+        }
+        inflateEnd(&zs);
+    }
+};
+
+bool looks_like_bgzf(const uint8_t *h, size_t n)
+{
+    if (n < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+    uint32_t xlen = h[10] | (uint32_t)h[11] << 8;
+    for (uint32_t o = 0; o + 4 <= xlen && 12 + o + 4 <= n;) {
+        uint32_t sl = h[12 + o + 2] | (uint32_t)h[12 + o + 3] << 8;
+        if (h[12 + o] == 'B' && h[12 + o + 1] == 'C' && sl == 2) return true;
+        o += 4 + sl;
+    }
+    return false;
+}
+
+}  // namespace
+
+std::unique_ptr<ByteSource> ByteSource::open(const std::string &path, int threads, std::string *err)
+{
+    if (threads <= 0) threads = io_default_threads();
+    if (path != "-") {
+        FILE *fp = fopen(path.c_str(), "rb");
+        if (!fp) { if (err) *err = "failed to open " + path; return nullptr; }
+        uint8_t h[64];
+        size_t n = fread(h, 1, sizeof h, fp);
+        if (looks_like_bgzf(h, n)) {
+            if (fseek(fp, 0, SEEK_SET) == 0) {
+                setvbuf(fp, nullptr, _IOFBF, 1 << 20);
+                return std::unique_ptr<ByteSource>(new BgzfSource(fp, threads));
+            }
+        }
+        fclose(fp);
+    }
+    gzFile g = path == "-" ? gzdopen(fileno(stdin), "rb") : gzopen(path.c_str(), "rb");
+    if (!g) { if (err) *err = "failed to open " + path; return nullptr; }
+    return std::unique_ptr<ByteSource>(new GzSource(g));
+}
+
+}  // namespace sta

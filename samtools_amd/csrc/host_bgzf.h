@@ -1,0 +1,27 @@
+// host_bgzf.h -- byte sources for the drivers' SAM/BAM reader.
+// Stands where HTSlib's bgzf.c (absent from the reference tree; SAM spec section 4.1 is the format) stands for
+// sam_open/sam_read1: a BGZF file is a series of <=64 KiB gzip members whose extra field "BC" carries the
+// compressed block size, so blocks can be cut on the host by one I/O thread and inflated by a pool of workers
+// (host inflate is the end-to-end limiter either side of the pileup engine).
+// Anything that is not BGZF (plain text, ordinary gzip, stdin) goes through zlib's gzread on the caller's thread.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+
+namespace sta {
+
+class ByteSource {
+public:
+    virtual ~ByteSource() {}
+    // up to n bytes; fewer only at end of data or on error
+    virtual size_t read(void *dst, size_t n) = 0;
+    virtual bool failed() const = 0;
+    // threads <= 0: $STA_IO_THREADS or 4
+    static std::unique_ptr<ByteSource> open(const std::string &path, int threads, std::string *err);
+};
+
+int io_default_threads();
+
+}  // namespace sta

@@ -1,5 +1,10 @@
 // host_io.cpp -- SAM/BAM/FASTA/BED decoding for the drivers (see host_io.h).
 #include "host_io.h"
+#include "host_bgzf.h"
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <zlib.h>
 #include <cstring>
 #include <cstdlib>
@@ -30,19 +35,31 @@ inline bool is_refop(int op) { return op == 0 || op == 2 || op == 3 || op == 7 |
 struct AlnReader::Impl {
     std::vector<std::string> want;   // aux tags to format (--output-extra)
 
-    gzFile fp = nullptr;
+    std::unique_ptr<ByteSource> src;
     bool is_bam = false;
     std::vector<uint8_t> buf; size_t bp = 0, bl = 0; bool eof = false;
     std::string line; bool have_line = false;
     std::vector<uint8_t> blk;
 
+    // ---- parse-ahead: a background thread decodes records into batches, next() hands them out in order ----
+    struct Batch { std::vector<Rec> r; size_t n = 0; };
+    static constexpr size_t BATCH = 2048, DEPTH = 4;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv_ready, cv_spare;
+    std::deque<Batch> ready;
+    std::vector<Batch> spare;
+    bool started = false, stop = false, done = false;
+    int final_status = 0;            // what next() returns once the batches are drained: 0 = EOF, <0 = error
+    Batch cur; size_t cur_i = 0;
+
     bool fill()
     {
         if (eof) return false;
         if (buf.empty()) buf.resize(1 << 18);
-        int n = gzread(fp, buf.data(), (unsigned)buf.size());
-        if (n <= 0) { eof = true; bp = bl = 0; return false; }
-        bp = 0; bl = (size_t)n;
+        size_t n = src->read(buf.data(), buf.size());
+        if (n == 0) { eof = true; bp = bl = 0; return false; }
+        bp = 0; bl = n;
         return true;
     }
     size_t read(void *dst, size_t n)
@@ -76,11 +93,18 @@ struct AlnReader::Impl {
         }
         return any;
     }
+    void shutdown()
+    {
+        if (!started) return;
+        { std::lock_guard<std::mutex> g(m); stop = true; }
+        cv_spare.notify_all(); cv_ready.notify_all();
+        if (th.joinable()) th.join();
+    }
 };
 
 AlnReader::~AlnReader()
 {
-    if (p_) { if (p_->fp) gzclose(p_->fp); delete p_; }
+    if (p_) { p_->shutdown(); delete p_; }
 }
 
 static void header_from_text(Header &h, bool add_refs)
@@ -110,14 +134,13 @@ static void header_from_text(Header &h, bool add_refs)
     }
 }
 
-std::unique_ptr<AlnReader> AlnReader::open(const std::string &path, std::string *err)
+std::unique_ptr<AlnReader> AlnReader::open(const std::string &path, std::string *err, int threads)
 {
     std::unique_ptr<AlnReader> r(new AlnReader());
     r->p_ = new Impl();
     Impl &im = *r->p_;
-    im.fp = path == "-" ? gzdopen(fileno(stdin), "rb") : gzopen(path.c_str(), "rb");
-    if (!im.fp) { if (err) *err = "failed to open " + path; return nullptr; }
-    gzbuffer(im.fp, 1 << 18);
+    im.src = ByteSource::open(path, threads, err);
+    if (!im.src) return nullptr;
     im.fill();
     if (im.bl >= 4 && memcmp(im.buf.data(), "BAM\1", 4) == 0) {
         im.is_bam = true; im.bp = 4;
@@ -307,16 +330,54 @@ static int parse_bam(AlnReader::Impl &im, Rec &r)
 
 void AlnReader::set_wanted_tags(const std::vector<std::string> &tags) { p_->want = tags; }
 
+// parser thread: decode + region filter, one batch at a time
+void AlnReader::parse_ahead()
+{
+    Impl &im = *p_;
+    for (;;) {
+        Impl::Batch b;
+        {
+            std::unique_lock<std::mutex> lk(im.m);
+            im.cv_spare.wait(lk, [&] { return im.stop || !im.spare.empty() || im.ready.size() < Impl::DEPTH; });
+            if (im.stop) return;
+            if (!im.spare.empty()) { b = std::move(im.spare.back()); im.spare.pop_back(); }
+        }
+        if (b.r.size() < Impl::BATCH) b.r.resize(Impl::BATCH);
+        b.n = 0;
+        int status = 1;
+        while (b.n < Impl::BATCH) {
+            Rec &r = b.r[b.n];
+            status = next_raw(r);
+            if (status <= 0) break;
+            if (has_reg_ && (r.tid != rtid_ || r.pos >= rend_ || r.endpos() <= rbeg_)) continue;
+            r.accepted = false;
+            ++b.n;
+        }
+        if (status < 0 || im.src->failed()) status = status < 0 ? status : -1;
+        std::lock_guard<std::mutex> g(im.m);
+        if (b.n) im.ready.push_back(std::move(b));
+        if (status <= 0) { im.final_status = status; im.done = true; im.cv_ready.notify_all(); return; }
+        im.cv_ready.notify_one();
+    }
+}
+
 int AlnReader::next(Rec &r)
 {
+    Impl &im = *p_;
+    if (!im.started) { im.started = true; im.th = std::thread([this] { parse_ahead(); }); }
     for (;;) {
-        int ret = next_raw(r);
-        if (ret <= 0) return ret;
-        if (has_reg_) {
-            if (r.tid != rtid_ || r.pos >= rend_ || r.endpos() <= rbeg_) continue;
+        if (im.cur_i < im.cur.n) {
+            std::swap(r, im.cur.r[im.cur_i++]);       // the consumer's old buffers go back into the batch for reuse
+            if (on_record) on_record(r);
+            return 1;
         }
-        if (on_record) on_record(r);
-        return 1;
+        std::unique_lock<std::mutex> lk(im.m);
+        if (!im.cur.r.empty()) { im.cur.n = 0; im.spare.push_back(std::move(im.cur)); im.cur = Impl::Batch(); im.cv_spare.notify_one(); }
+        im.cur_i = 0;
+        im.cv_ready.wait(lk, [&] { return !im.ready.empty() || im.done; });
+        if (im.ready.empty()) return im.final_status;
+        im.cur = std::move(im.ready.front()); im.ready.pop_front();
+        im.cv_spare.notify_one();
     }
 }
 

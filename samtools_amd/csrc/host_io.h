@@ -45,7 +45,8 @@ struct Rec {
 
 class AlnReader {
 public:
-    static std::unique_ptr<AlnReader> open(const std::string &path, std::string *err);
+    // threads: BGZF inflate workers (<= 0: $STA_IO_THREADS or 4); records are parsed one batch ahead on a further thread
+    static std::unique_ptr<AlnReader> open(const std::string &path, std::string *err, int threads = 0);
     ~AlnReader();
     const Header &header() const { return hdr_; }
     void set_region(int tid, int64_t beg, int64_t end) { has_reg_ = true; rtid_ = tid; rbeg_ = beg; rend_ = end; }
@@ -62,6 +63,7 @@ private:
     Header hdr_;
     bool has_reg_ = false; int rtid_ = 0; int64_t rbeg_ = 0, rend_ = 0;
     int next_raw(Rec &r);
+    void parse_ahead();
 };
 
 // hts_parse_reg-like ("chr", "chr:beg", "chr:beg-end", thousands commas); 0-based half open

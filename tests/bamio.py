@@ -1,0 +1,96 @@
+"""Minimal SAM -> BAM (BGZF) writer for tests and host-I/O benchmarks (SAM spec v1 sections 4.1-4.2).
+Not a general converter: what the synthetic generators and the reference's test SAMs contain."""
+import struct
+import zlib
+
+_NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+_OPS = {c: i for i, c in enumerate("MIDNSHP=XB")}
+_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def _reg2bin(beg, end):
+    end -= 1
+    if beg >> 14 == end >> 14: return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17: return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20: return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23: return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26: return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def _aux(field):
+    tag, typ, val = field[:2], field[3], field[5:]
+    t = tag.encode()
+    if typ == "A": return t + b"A" + val.encode()[:1]
+    if typ == "i":
+        v = int(val)
+        for code, fmt, lo, hi in (("C", "<B", 0, 255), ("c", "<b", -128, 127), ("S", "<H", 0, 65535), ("s", "<h", -32768, 32767),
+                                  ("I", "<I", 0, 2 ** 32 - 1), ("i", "<i", -2 ** 31, 2 ** 31 - 1)):
+            if lo <= v <= hi: return t + code.encode() + struct.pack(fmt, v)
+        raise ValueError(field)
+    if typ == "f": return t + b"f" + struct.pack("<f", float(val))
+    if typ in "ZH": return t + typ.encode() + val.encode() + b"\0"
+    if typ == "B":
+        sub = val[0]; items = [x for x in val[2:].split(",") if x]
+        fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]
+        conv = float if sub == "f" else int
+        return t + b"B" + sub.encode() + struct.pack("<I", len(items)) + b"".join(struct.pack("<" + fmt, conv(x)) for x in items)
+    raise ValueError(field)
+
+
+def _bgzf_block(data, level):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = c.compress(data) + c.flush()
+    bsize = len(comp) + 25
+    return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + comp
+            + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+
+
+def sam_to_bam(sam_path, bam_path, level=1, block=0xff00):
+    """block: payload bytes per BGZF block (small values make many-block files for the threaded reader tests)."""
+    header, names, lens, recs = [], [], [], []
+    with open(sam_path) as fh:
+        for line in fh:
+            line = line.rstrip("\n")
+            if not line: continue
+            if line[0] == "@":
+                header.append(line)
+                if line.startswith("@SQ"):
+                    d = dict(f.split(":", 1) for f in line.split("\t")[1:] if ":" in f)
+                    names.append(d["SN"]); lens.append(int(d["LN"]))
+                continue
+            recs.append(line)
+    tid = {n: i for i, n in enumerate(names)}
+    text = ("\n".join(header) + "\n").encode() if header else b""
+    out = [b"BAM\1", struct.pack("<i", len(text)), text, struct.pack("<i", len(names))]
+    for n, l in zip(names, lens):
+        nb = n.encode() + b"\0"
+        out.append(struct.pack("<i", len(nb)) + nb + struct.pack("<i", min(l, 2 ** 31 - 1)))
+    for line in recs:
+        f = line.split("\t")
+        qn = f[0].encode() + b"\0"
+        flag = int(f[1], 0); ref = -1 if f[2] == "*" else tid[f[2]]; pos = int(f[3]) - 1; mapq = int(f[4])
+        cig = []
+        if f[5] != "*":
+            num = ""
+            for ch in f[5]:
+                if ch.isdigit(): num += ch
+                else: cig.append(int(num) << 4 | _OPS[ch]); num = ""
+        mref = ref if f[6] == "=" else (-1 if f[6] == "*" else tid[f[6]])
+        mpos = int(f[7]) - 1; tlen = int(f[8])
+        seq = "" if f[9] == "*" else f[9]
+        l = len(seq)
+        sb = bytearray((l + 1) // 2)
+        for i, ch in enumerate(seq): sb[i >> 1] |= _NT16.get(ch.upper(), 15) << (4 if i % 2 == 0 else 0)
+        qb = b"\xff" * l if f[10] == "*" else bytes(ord(ch) - 33 for ch in f[10])
+        rlen = sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3, 7, 8))
+        end = pos + (rlen if rlen > 0 and not (flag & 4) else 1)
+        body = (struct.pack("<iiBBHHHiiii", ref, pos, len(qn), mapq, _reg2bin(max(pos, 0), max(end, 1)), len(cig), flag, l, mref, mpos, tlen)
+                + qn + b"".join(struct.pack("<I", c) for c in cig) + bytes(sb) + qb + b"".join(_aux(a) for a in f[11:]))
+        out.append(struct.pack("<i", len(body)) + body)
+    raw = b"".join(out)
+    with open(bam_path, "wb") as fo:
+        for o in range(0, len(raw), block):
+            fo.write(_bgzf_block(raw[o:o + block], level))
+        fo.write(_EOF)
+    return bam_path

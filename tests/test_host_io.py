@@ -1,0 +1,83 @@
+"""Host input plumbing (no GPU): the drivers' SAM/BAM reader -- threaded BGZF inflate + parse-ahead -- decodes the same records
+whatever the thread count, block size or container (SAM text vs BAM), and reports damaged input instead of truncating.
+sta_io_scan folds every decoded field into an order-dependent checksum; stage=True also runs the window pump + SoA stager."""
+import gzip
+import os
+
+import pytest
+
+from bamio import sam_to_bam
+from synth import write_synth_sam
+from synth_rich import write_rich_sam
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from samtools_amd import _capi
+    return _capi
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("hostio"))
+    sam, _ = write_synth_sam(d, n_ref=60000, depth=30, read_len=150, seed=11, paired=True, indel_rate=0.02)
+    rich, _ = write_rich_sam(d, seed=3, n_templates=1500)
+    return d, sam, rich
+
+
+def test_bam_writer_matches_a_samtools_written_bam(tmp_path):
+    """tests/bamio.py is pinned on a SAM/BAM pair the reference's test suite ships: same decompressed bytes."""
+    want = gzip.open(os.path.join(GOLD, "mpileup", "ce#5b.bam")).read()
+    out = sam_to_bam(os.path.join(GOLD, "mpileup", "ce#5b.sam"), str(tmp_path / "x.bam"))
+    assert gzip.open(out).read() == want
+
+
+@pytest.mark.parametrize("which", ["synth", "rich"])
+def test_same_records_from_sam_and_bam_any_threads_any_block_size(capi, files, which):
+    d, sam, rich = files
+    src = sam if which == "synth" else rich
+    ref = capi.io_scan(src, 1, False)
+    ref_staged = capi.io_scan(src, 1, True)
+    assert ref[0] > 1000
+    for block in (0xff00, 4096, 700):
+        bam = sam_to_bam(src, os.path.join(d, "%s_%d.bam" % (which, block)), level=1, block=block)
+        for threads in (1, 3, 8):
+            assert capi.io_scan(bam, threads, False) == ref, (block, threads)
+        assert capi.io_scan(bam, 4, True) == ref_staged, block
+    # ordinary gzip of the SAM text (not BGZF) goes through the single-thread path
+    gz = os.path.join(d, which + ".sam.gz")
+    with open(src, "rb") as fi, gzip.open(gz, "wb", compresslevel=1) as fo:
+        fo.write(fi.read())
+    assert capi.io_scan(gz, 4, False) == ref
+
+
+def test_reference_fixture_bams_decode_identically_with_one_and_many_workers(capi):
+    n = 0
+    for sub in ("mpileup", "bedcov"):
+        for fn in sorted(os.listdir(os.path.join(GOLD, sub))):
+            if fn.endswith(".bam"):
+                p = os.path.join(GOLD, sub, fn)
+                assert capi.io_scan(p, 1, False) == capi.io_scan(p, 6, False), fn
+                n += 1
+    assert n >= 15
+
+
+def test_damaged_and_truncated_bgzf_is_an_error_not_a_short_read(capi, files):
+    d, sam, _ = files
+    bam = sam_to_bam(sam, os.path.join(d, "dmg.bam"), level=1, block=8192)
+    raw = bytearray(open(bam, "rb").read())
+    good = capi.io_scan(bam, 4, False)
+    # flip a byte inside the deflate data of a block in the middle: CRC / inflate must notice
+    bad = bytearray(raw); bad[len(bad) // 2] ^= 0x5a
+    p = os.path.join(d, "dmg1.bam"); open(p, "wb").write(bad)
+    with pytest.raises(RuntimeError):
+        capi.io_scan(p, 4, False)
+    # cut in the middle of a block
+    p = os.path.join(d, "dmg2.bam"); open(p, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(RuntimeError):
+        capi.io_scan(p, 4, False)
+    # a missing EOF marker block alone is tolerated (samtools only warns)
+    p = os.path.join(d, "noeof.bam"); open(p, "wb").write(raw[:-28])
+    assert capi.io_scan(p, 4, False) == good

@@ -22,6 +22,9 @@
  *   add_depth / incr_hist[_qual]   bam2depth.c:165-477    sta_depth_plan / sta_depth_emit
  *   fastdepth_core merge + -s hash bam2depth.c:486-699    sta_depth_plan (per-file read sets)
  *   bed_overlap                    bedidx.c:159-197       sta_window.bed_* (merged intervals)
+ *   coverage / bedcov column loops coverage.c:621-672, bedcov.c:316-333   sta_cov_plan
+ *   bcf_call_init / bcf_call_glfgen bam2bcf.c:38-48,65-123 sta_glf_plan (+ sta_glf_consensus, bam_tview.c:194-212)
+ *   sam_open / sam_read1 (host)    bam_plcmd.c:500-569    sta_io_scan exercises the drivers' reader (BGZF worker pool)
  *   bam_mpileup / main_depth (CLI) bam_plcmd.c:1075, bam2depth.c:732   sta_main_mpileup / sta_main_depth
  *
  * The per-column callback surface (bam_plp_* / bam_mplp_* / bam_plbuf_*) is
@@ -239,6 +242,30 @@ typedef struct sta_cov_totals {  /* coverage: sums over the window's columns (an
  * info->n_kept_reads = reads that entered the pileup (bedcov -c).  Synchronises the stream. */
 int sta_cov_plan(sta_engine *e, const sta_cov_params *p, sta_cov_totals *totals, uint64_t *per_file, sta_plan_info *info);
 
+/* ---- per-column genotype-likelihood packer (bcf_call_init / bcf_call_glfgen, bam2bcf.c:38-48,65-123; errmod_cal in
+ * HTSlib; the consensus call of bam_tview.c:194-212).  Columns come from the plain iterator (no filters, no overlaps), as
+ * tview drives it through bam_lplbuf.  The reference FASTA set with sta_set_reference supplies the column's base ('N' if
+ * none).  Columns with more than 255 counted bases are flagged: HTSlib subsamples them with its process-wide random stream,
+ * the engine keeps the first 255 in pileup order. ---- */
+typedef struct sta_glf_params {
+    int32_t min_baseQ;           /* bcf_call_init(theta, min_baseQ): tview passes 13 */
+    int32_t max_depth;           /* iterator depth cap (8000 = bam_plp default) */
+    double theta;                /* <= 0: 0.83 (CALL_DEFTHETA); errmod_init(1 - theta) */
+} sta_glf_params;
+#define STA_GLF_CUT 1            /* sta_glf_col.flags: more than 255 counted bases */
+typedef struct sta_glf_col {     /* what bcf_call_glfgen returns for one column of one file */
+    int32_t n_plp;               /* entries the iterator handed over (0 = the iterator would not have returned the column) */
+    int32_t n;                   /* return value: bases that passed the filters */
+    int32_t flags;
+    float qsum[4];               /* bcf_callret1_t (bam2bcf.h:41-46) */
+    float p[25];
+} sta_glf_col;
+/* plans and runs the window: info->out_bytes = (col_end - col_beg) * n_files * sizeof(sta_glf_col), laid out [column][file];
+ * read them back with sta_fetch_output */
+int sta_glf_plan(sta_engine *e, const sta_glf_params *p, sta_plan_info *info);
+/* bam_tview.c:194-212: consensus character (",ACMGRSVTWYHKDBN" alphabet) and its quality for one column */
+int sta_glf_consensus(const sta_glf_col *c, char ref_base, char *call_char);
+
 /* ---- depth ---- */
 int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info);
 int sta_depth_emit(sta_engine *e, void *dev_out, uint64_t capacity);
@@ -264,6 +291,8 @@ int sta_profile_get(sta_engine *e, sta_kernel_time *out, int cap);
  * status as the reference sub-commands (bamtk.c:248,270 would dispatch here). */
 int sta_main_mpileup(int argc, char **argv);
 int sta_main_depth(int argc, char **argv);
+/* `glf [-Q min_baseQ] [-t theta] [-f ref.fa] in.bam`: one text line per column (what tests diff against the oracle) */
+int sta_main_glf(int argc, char **argv);
 
 /* ---- host input plumbing (needs no device) ----
  * The drivers' SAM / BAM reader (stands where sam_open / sam_read1 stand for bam_plcmd.c:500-569): BGZF blocks are inflated

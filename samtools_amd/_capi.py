@@ -94,6 +94,14 @@ class PlanInfo(C.Structure):
                 ("n_kept_reads", C.c_uint64), ("piled_bases", C.c_uint64), ("n_maxcnt_dropped", C.c_uint64)]
 
 
+class GlfParams(C.Structure):
+    _fields_ = [("min_baseQ", C.c_int32), ("max_depth", C.c_int32), ("theta", C.c_double)]
+
+
+class GlfCol(C.Structure):
+    _fields_ = [("n_plp", C.c_int32), ("n", C.c_int32), ("flags", C.c_int32), ("qsum", C.c_float * 4), ("p", C.c_float * 25)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -124,6 +132,9 @@ _PROTOS = {
     "sta_fetch_read_state": (C.c_int, [_P, C.c_int32, _P, _P]),
     "sta_main_mpileup": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_main_depth": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "sta_glf_plan": (C.c_int, [_P, C.POINTER(GlfParams), C.POINTER(PlanInfo)]),
+    "sta_glf_consensus": (C.c_int, [C.POINTER(GlfCol), C.c_char, C.c_char_p]),
+    "sta_main_glf": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_io_scan": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 EXPORTED_SYMBOLS = sorted(_PROTOS)

@@ -3,12 +3,14 @@
 // loops; see that header for the reference file:line map).  No CPU compute fallback exists here:
 // without a usable HIP device every entry point returns STA_ERR_NO_DEVICE.
 #include "sta_dev.h"
+#include "glf_tables.h"
 #include <string>
 #include <vector>
 #include <map>
 #include <cstring>
 #include <cstdio>
 #include <climits>
+#include <cctype>
 
 namespace {
 
@@ -62,7 +64,8 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab;
+    double glf_depcorr = -1.0;      // theta the coefficient block in glf_tab was computed for
     StaWinDev wd{};
     // plan state
     int planned = 0;   // 1 mpileup, 2 depth, 3 plp entries
@@ -169,7 +172,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out };
+                      &e->out, &e->diff, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
     if (e->pipe_stream) hipStreamDestroy(e->pipe_stream);
@@ -715,6 +718,89 @@ int sta_cov_plan(sta_engine *e, const sta_cov_params *cp, sta_cov_totals *totals
     if (info) { memset(info, 0, sizeof *info); info->n_kept_reads = e->ctr_h.n_kept; info->piled_bases = e->ctr_h.piled_bases; info->n_maxcnt_dropped = e->ctr_h.n_dropped; }
     e->planned = 4;      // read state can be fetched; there is nothing to emit
     return STA_OK;
+}
+
+// row a14: bcf_call_glfgen over every column of the staged window (kernels_glf.hip)
+int sta_glf_plan(sta_engine *e, const sta_glf_params *gp, sta_plan_info *info)
+{
+    if (!e || !gp) return STA_ERR_ARG;
+    if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
+    hipSetDevice(e->device);
+    const double theta = gp->theta <= 0. ? 0.83 : gp->theta;
+    const double depcorr = 1. - theta;
+    if (e->glf_depcorr != depcorr) {
+        std::vector<double> t;
+        sta::glf_tables(depcorr, t);
+        if (e->glf_tab.ensure(t.size() * 8)) return fail(e, STA_ERR_HIP, "hipMalloc(glf tables) failed");
+        HIPCHK(hipMemcpy(e->glf_tab.p, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+        e->glf_depcorr = depcorr;
+    }
+    sta_mplp_params p; memset(&p, 0, sizeof p);
+    p.max_depth = gp->max_depth > 0 ? gp->max_depth : 8000;
+    e->mp = p;
+    const char *saved_ref = e->wd.ref; int64_t saved_len = e->wd.ref_len;
+    e->wd.ref = nullptr; e->wd.ref_len = 0;          // the plain iterator has no contig-length filter and no BAQ
+    e->min_pos.assign(e->files_h.size(), 0); e->max_pos_hint.assign(e->files_h.size(), 0);
+    const size_t nf = e->files_h.size();
+    e->cov_mode = true;
+    int rc = mpileup_pipeline(e, &p, false);
+    if (!rc) { hipError_t r_ = hipStreamSynchronize(e->stream); if (r_ != hipSuccess) rc = hipfail(e, r_, "sync"); }
+    if (!rc) {
+        HIPCHK(hipMemcpy(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost));
+        if (e->ctr_h.maxcnt_flag) {
+            for (size_t f = 0; f < nf; ++f) {
+                StaReadsDev &d = e->files_h[f];
+                if (!d.n) continue;
+                int32_t first = 0, lastmax = 0, lastpos = 0;
+                HIPCHK(hipMemcpy(&first, d.pos, 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(&lastmax, d.maxend + (d.n - 1), 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(&lastpos, d.pos + (d.n - 1), 4, hipMemcpyDeviceToHost));
+                e->min_pos[f] = first; e->max_pos_hint[f] = lastmax > lastpos ? lastmax : lastpos;
+            }
+            rc = mpileup_pipeline(e, &p, true);
+        }
+    }
+    e->cov_mode = false;
+    e->wd.ref = saved_ref; e->wd.ref_len = saved_len;
+    if (rc) return rc;
+    const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
+    const uint64_t bytes = (uint64_t)(ncols > 0 ? ncols : 0) * nf * sizeof(sta_glf_col);
+    if (e->out.ensure(bytes + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(output) failed");
+    {
+        ProfScope ps(e, "glf_cols");
+        const double *t = (const double *)e->glf_tab.p;
+        sta_launch_glf_cols(e->stream, e->wd, gp->min_baseQ, 60, saved_ref, saved_len, t + sta::GLF_FK_OFF, t + sta::GLF_BETA_OFF, t + sta::GLF_LHET_OFF, e->out.p);
+    }
+    HIPCHK(hipMemcpyAsync(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return hipfail(e, le, "glf kernels");
+    e->out_bytes = bytes; e->last_out = e->out.p;
+    if (info) { memset(info, 0, sizeof *info); info->out_bytes = bytes; info->n_kept_reads = e->ctr_h.n_kept; info->piled_bases = e->ctr_h.piled_bases; info->n_maxcnt_dropped = e->ctr_h.n_dropped; }
+    e->planned = 4;
+    return STA_OK;
+}
+
+// bam_tview.c:194-212
+int sta_glf_consensus(const sta_glf_col *c, char ref_base, char *call_char)
+{
+    if (!c) return -1;
+    int qsum[4], a1, a2, tmp;
+    double p[3], prior = 30;
+    unsigned call;
+    for (int i = 0; i < 4; ++i) qsum[i] = ((int)c->qsum[i]) << 2 | i;
+    for (int i = 1; i < 4; ++i)
+        for (int j = i; j > 0 && qsum[j] > qsum[j - 1]; --j) tmp = qsum[j], qsum[j] = qsum[j - 1], qsum[j - 1] = tmp;
+    a1 = qsum[0] & 3; a2 = qsum[1] & 3;
+    p[0] = c->p[a1 * 5 + a1]; p[1] = c->p[a1 * 5 + a2] + prior; p[2] = c->p[a2 * 5 + a2];
+    const int rb = toupper((unsigned char)ref_base);
+    if ("ACGT"[a1] != rb) p[0] += prior + 3;
+    if ("ACGT"[a2] != rb) p[2] += prior + 3;
+    if (p[0] < p[1] && p[0] < p[2]) call = (1u << a1) << 16 | (unsigned)(int)((p[1] < p[2] ? p[1] : p[2]) - p[0] + .499);
+    else if (p[2] < p[1] && p[2] < p[0]) call = (1u << a2) << 16 | (unsigned)(int)((p[0] < p[1] ? p[0] : p[1]) - p[2] + .499);
+    else call = (1u << a1 | 1u << a2) << 16 | (unsigned)(int)((p[0] < p[2] ? p[0] : p[2]) - p[1] + .499);
+    if (call_char) *call_char = ",ACMGRSVTWYHKDBN"[call >> 16 & 0xf];
+    return (int)(call & 0xffff);
 }
 
 int sta_fetch_overlap_fixups(sta_engine *e, int32_t file, int32_t *fix_y, int32_t *fix_mate, uint8_t *fix_q)

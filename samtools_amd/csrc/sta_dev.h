@@ -91,6 +91,8 @@ void sta_launch_plp_count(hipStream_t s, const StaWinDev &w, uint32_t *line_len)
 void sta_launch_plp_fill(hipStream_t s, const StaWinDev &w, const uint64_t *offs, void *entries);
 
 // coverage / bedcov column reductions (kernels_cov.hip)
+void sta_launch_glf_cols(hipStream_t s, const StaWinDev &w, int min_baseQ, int capQ, const char *ref, int64_t ref_len,
+                         const double *fk, const double *beta, const double *lhet, void *out);
 void sta_launch_cov_cols(hipStream_t s, const StaWinDev &w, int mode, int min_baseQ, int min_depth, int skip_dn,
                          unsigned long long *totals /*[5]*/, unsigned long long *per_file /*[nfiles][2]*/);
 

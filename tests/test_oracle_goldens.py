@@ -3,6 +3,8 @@
 Every reproducible `P` line of test/mpileup/mpileup.reg and depth.reg, the
 test.pl mpileup cases and the large-position depth cases must match byte for
 byte.  Runs on CPU (no GPU needed)."""
+import os
+
 import pytest
 
 import regcases
@@ -27,3 +29,35 @@ def test_oracle_mandatory_stderr_line(oracle_bin):
         argv = expand_args(regcases.TESTPL[0][1], GOLDEN, tmp)
         p = subprocess.run([oracle_bin] + argv, cwd=GOLDEN, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.stderr.decode() == open(os.path.join(GOLDEN, "dat", "mpileup.err.1")).read()
+
+
+def tview_consensus_from_glf(glf_text, tview_expected):
+    """Rebuild tview's consensus row (third line of `samtools tview -d T -p CHROMOSOME_I:10000000000`, test/test.pl:2910)
+    from `glf` output: reference-row '*' marks an insertion column (blank in the consensus row), other columns are
+    consecutive positions starting at the requested one; uncovered positions stay blank."""
+    calls = {}
+    for line in glf_text.split("\n"):
+        if line:
+            f = line.split("\t")
+            calls[int(f[1])] = f[7]
+    rows = tview_expected.split("\n")
+    ref_row, want = rows[1], rows[2]
+    pos, got = 10000000000, ""
+    for ch in ref_row:
+        if ch == "*":
+            got += " "
+        else:
+            got += calls.get(pos, " ")
+            pos += 1
+    return got, want.ljust(len(ref_row))
+
+
+def test_oracle_glfgen_reproduces_tview_consensus_line(oracle_bin):
+    """Row a14 (bcf_call_glfgen + errmod_cal + tview's call): the only reference golden that depends on it is the consensus
+    line of test/large_pos/tview.expected.out -- 78 characters, one of them a heterozygous call."""
+    import subprocess
+    gold = os.path.join(os.path.dirname(__file__), "golden", "large_pos")
+    out = subprocess.run([oracle_bin, "glf", os.path.join(gold, "longref.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    got, want = tview_consensus_from_glf(out.stdout.decode(), open(os.path.join(gold, "tview.expected.out")).read())
+    assert got == want
+    assert "K" in want

@@ -2,6 +2,7 @@
 import os, subprocess, sys, time
 sys.path.insert(0, "tests")
 from synth_rich import write_rich_sam
+from bamio import sam_to_bam
 out = "/tmp/hunt3"; os.makedirs(out, exist_ok=True)
 seeds = [int(x) for x in sys.argv[1:]] or [1, 2]
 for seed in seeds:
@@ -13,6 +14,7 @@ for seed in seeds:
     with open(sam_q, "w") as fo:
         for l in open(sam):
             if l[0] == "@" or l.split("\t")[9] != "*": fo.write(l)
+    bam = sam_to_bam(sam, os.path.join(out, "rich_%d.bam" % seed), level=1, block=20000)      # engine reads BAM (threaded BGZF), oracle the SAM text
     bed = os.path.join(out, "r%d.bed" % seed)
     with open(bed, "w") as f:
         f.write("c1\t100\t9000\nc1\t9500\t9600\nc2\t0\t4000\tname\nc3\t20000\t44000\n")
@@ -23,6 +25,7 @@ for seed in seeds:
         ["mpileup", "-G", os.path.join(out, "rg.txt"), "-C", "50", "-f", fa, sam],
         ["depth", sam], ["depth", "-a", "-s", "-J", sam, sam2], ["depth", "-aa", "-q", "10", "-Q", "5", "-l", "60", sam_q], ["depth", "-b", bed, "-g", "0x400", "-G", "16", sam], ["depth", "-r", "c2", "-a", sam],
         ["plpdump", sam], ["plpdump", "-x", sam, sam2], ["plpdump", "-p", sam], ["plpdump", "-d", "12", sam],
+        ["glf", "-f", fa, sam], ["glf", "-Q", "3", sam],
         ["coverage", sam, sam2], ["coverage", "-r", "c3:5000-20000", "-Q", "10", "-q", "5", "-l", "60", sam], ["bedcov", "-j", "-d", "8", "-c", bed, sam, sam2], ["bedcov", "-Q", "20", "-g", "1024", bed, sam],
     ]
     open(os.path.join(out, "rg.txt"), "w").write("g2\n")
@@ -30,7 +33,8 @@ for seed in seeds:
         o = subprocess.run(["oracle/_build/oracle_samtools"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         want = o.stdout.split(b"\n")
         for envx in ({}, {"STA_WINDOW_COLS": "900", "STA_PLP_BATCH": "700"}):
-            p = subprocess.run(["samtools_amd/bin/samtools-amd"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **envx))
+            eargs = [bam if (a == sam and envx) else a for a in args]
+            p = subprocess.run(["samtools_amd/bin/samtools-amd"] + eargs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **envx))
             got = p.stdout.split(b"\n")
             nd = [i for i, (x, y) in enumerate(zip(got, want)) if x != y]
             ok = p.returncode == o.returncode and len(got) == len(want) and not nd

@@ -24,6 +24,7 @@
  *   bed_overlap                    bedidx.c:159-197       sta_window.bed_* (merged intervals)
  *   coverage / bedcov column loops coverage.c:621-672, bedcov.c:316-333   sta_cov_plan
  *   bcf_call_init / bcf_call_glfgen bam2bcf.c:38-48,65-123 sta_glf_plan (+ sta_glf_consensus, bam_tview.c:194-212)
+ *   bam_fillmd1_core + BAQ tag     bam_md.c:64-224,474-479 sta_calmd_plan / sta_fetch_calmd
  *   sam_open / sam_read1 (host)    bam_plcmd.c:500-569    sta_io_scan exercises the drivers' reader (BGZF worker pool)
  *   bam_mpileup / main_depth (CLI) bam_plcmd.c:1075, bam2depth.c:732   sta_main_mpileup / sta_main_depth
  *
@@ -266,6 +267,25 @@ int sta_glf_plan(sta_engine *e, const sta_glf_params *p, sta_plan_info *info);
 /* bam_tview.c:194-212: consensus character (",ACMGRSVTWYHKDBN" alphabet) and its quality for one column */
 int sta_glf_consensus(const sta_glf_col *c, char ref_base, char *call_char);
 
+/* ---- calmd's per-record arithmetic: MD / NM recomputation (bam_fillmd1_core, bam_md.c:64-224) and the BAQ tag writer
+ * (sam_prob_realn call, bam_md.c:474-479).  Works on file 0 of the staged window (records are independent: the window is only
+ * the coordinate frame; the contig set with sta_set_reference is the FASTA calmd was given). ---- */
+#define STA_CALMD_REALN     1    /* -r: run BAQ */
+#define STA_CALMD_APPLY     2    /* -A: BAQ changes the qualities (tag ZQ:Z) instead of only writing BQ:Z */
+#define STA_CALMD_EXTENDED  4    /* -E */
+#define STA_CALMD_USE_EQUAL 8    /* -e: matching bases become '=' */
+#define STA_CALMD_BIN_QUAL  16   /* -q */
+typedef struct sta_calmd_params { int32_t flag; int32_t max_nm; /* -n, 0 = off */ } sta_calmd_params;
+#define STA_CALMD_HAS_MD    1    /* state[]: NM / MD are valid (mapped record with a sequence on a contig that has a reference) */
+#define STA_CALMD_NEW_TAG   2    /*          BAQ was computed: tag[] holds the BQ:Z (or, with -A, ZQ:Z) string               */
+#define STA_CALMD_BQ_TO_ZQ  4    /*          an existing BQ:Z was applied to the qualities (realn.c renames it ZQ:Z)          */
+/* info->out_bytes = bytes of MD text */
+int sta_calmd_plan(sta_engine *e, const sta_calmd_params *p, sta_plan_info *info);
+/* Results of the planned window (any pointer may be NULL): nm[n]; md_off[n+1] into md_text; state[n]; the quality, 4-bit
+ * sequence and tag pools in the staged layout (sta_reads.base_off8; seq at half the byte offset). */
+int sta_fetch_calmd(sta_engine *e, int32_t *nm, uint64_t *md_off, char *md_text, uint8_t *state, uint8_t *qual_pool,
+                    uint8_t *seq_pool, uint8_t *tag_pool);
+
 /* ---- depth ---- */
 int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info);
 int sta_depth_emit(sta_engine *e, void *dev_out, uint64_t capacity);
@@ -293,6 +313,8 @@ int sta_main_mpileup(int argc, char **argv);
 int sta_main_depth(int argc, char **argv);
 /* `glf [-Q min_baseQ] [-t theta] [-f ref.fa] in.bam`: one text line per column (what tests diff against the oracle) */
 int sta_main_glf(int argc, char **argv);
+/* `calmd [-erAEq] [-n max_nm] in.bam ref.fa`: dumps the record fields calmd changes (not a SAM writer) */
+int sta_main_calmd(int argc, char **argv);
 
 /* ---- host input plumbing (needs no device) ----
  * The drivers' SAM / BAM reader (stands where sam_open / sam_read1 stand for bam_plcmd.c:500-569): BGZF blocks are inflated

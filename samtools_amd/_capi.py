@@ -94,6 +94,10 @@ class PlanInfo(C.Structure):
                 ("n_kept_reads", C.c_uint64), ("piled_bases", C.c_uint64), ("n_maxcnt_dropped", C.c_uint64)]
 
 
+class CalmdParams(C.Structure):
+    _fields_ = [("flag", C.c_int32), ("max_nm", C.c_int32)]
+
+
 class GlfParams(C.Structure):
     _fields_ = [("min_baseQ", C.c_int32), ("max_depth", C.c_int32), ("theta", C.c_double)]
 
@@ -134,6 +138,9 @@ _PROTOS = {
     "sta_main_depth": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_glf_plan": (C.c_int, [_P, C.POINTER(GlfParams), C.POINTER(PlanInfo)]),
     "sta_glf_consensus": (C.c_int, [C.POINTER(GlfCol), C.c_char, C.c_char_p]),
+    "sta_calmd_plan": (C.c_int, [_P, C.POINTER(CalmdParams), C.POINTER(PlanInfo)]),
+    "sta_fetch_calmd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "sta_main_calmd": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_main_glf": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_io_scan": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }

@@ -135,7 +135,7 @@ extern "C" int sta_main_bedcov_iter(int argc, char **argv)
             aux[(size_t)i].min_mapQ = min_mapQ; aux[(size_t)i].flags = flags; aux[(size_t)i].rcnt = 0;
             data[(size_t)i] = &aux[(size_t)i];
         }
-        // ---- from here on: bedcov.c:303-352 verbatim in structure, on the engine's iterator ----
+        // ---- from here on: the column loop of bedcov.c:303-352 restated on the engine's iterator (HTSlib names via STA_PLP_DROPIN) ----
         bam_mplp_t mplp = bam_mplp_init(n, read_bam, data.data());
         bam_mplp_set_maxcnt(mplp, min_depth > max_depth ? min_depth : max_depth);
         std::fill(cnt.begin(), cnt.end(), 0); std::fill(pcov.begin(), pcov.end(), 0);

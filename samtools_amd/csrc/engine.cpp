@@ -64,7 +64,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     double glf_depcorr = -1.0;      // theta the coefficient block in glf_tab was computed for
     StaWinDev wd{};
     // plan state
@@ -172,7 +172,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab };
+                      &e->out, &e->diff, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
     if (e->pipe_stream) hipStreamDestroy(e->pipe_stream);
@@ -274,6 +274,7 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
         wd.bed_beg = (const int64_t *)e->bed_d.p; wd.bed_end = wd.bed_beg + nb;
     }
     wd.has_reg = w->has_reg; wd.reg_beg = w->reg_beg; wd.reg_end = w->reg_end;
+    wd.baq_plain = 0;
     auto it = e->refs.find(w->tid);
     if (it != e->refs.end()) { wd.ref = it->second.external ? it->second.ext : (const char *)it->second.buf.p; wd.ref_len = it->second.len; }
     else { wd.ref = nullptr; wd.ref_len = 0; }
@@ -778,6 +779,86 @@ int sta_glf_plan(sta_engine *e, const sta_glf_params *gp, sta_plan_info *info)
     e->out_bytes = bytes; e->last_out = e->out.p;
     if (info) { memset(info, 0, sizeof *info); info->out_bytes = bytes; info->n_kept_reads = e->ctr_h.n_kept; info->piled_bases = e->ctr_h.piled_bases; info->n_maxcnt_dropped = e->ctr_h.n_dropped; }
     e->planned = 4;
+    return STA_OK;
+}
+
+// 8(f) row 3: calmd's per-record arithmetic (kernels_md.hip) on file 0 of the staged window
+int sta_calmd_plan(sta_engine *e, const sta_calmd_params *cp, sta_plan_info *info)
+{
+    if (!e || !cp) return STA_ERR_ARG;
+    if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
+    if (e->files_h.size() != 1) return fail(e, STA_ERR_ARG, "calmd works on one input file");
+    hipSetDevice(e->device);
+    const bool realn = (cp->flag & STA_CALMD_REALN) != 0, apply = (cp->flag & STA_CALMD_APPLY) != 0;
+    if (realn && !e->wd.ref) return fail(e, STA_ERR_ARG, "calmd -r needs the reference of the contig");
+    sta_mplp_params p; memset(&p, 0, sizeof p);
+    p.flag = realn ? STA_MPLP_REALN : 0;
+    e->mp = p;
+    e->min_pos.assign(1, 0); e->max_pos_hint.assign(1, 0);
+    StaReadsDev &d = e->files_h[0];
+    const uint8_t *saved_bq = d.bq;
+    if (!apply) d.bq = nullptr;                  // without -A an existing BQ:Z is left alone (and still blocks a recomputation)
+    e->wd.baq_plain = (cp->flag & STA_CALMD_EXTENDED) ? 0 : 1;
+    e->cov_mode = true;
+    int rc = mpileup_pipeline(e, &p, false);
+    e->cov_mode = false;
+    e->wd.baq_plain = 0;
+    if (rc) { d.bq = saved_bq; return rc; }
+    hipStream_t s = e->stream;
+    const size_t n = (size_t)d.n, nb = (size_t)d.n_bases_total;
+    if (e->md_nm.ensure(n * 4 + 16) || e->md_len.ensure(n * 4 + 16) || e->md_state.ensure(n + 16) || e->md_tag.ensure(nb + 16)
+        || e->md_seq.ensure(nb / 2 + 16) || e->offs.ensure((n + 2) * 8 + 16) || e->scan_tmp.ensure(sta_scan_tmp_bytes((int64_t)n) + 64))
+        return fail(e, STA_ERR_HIP, "hipMalloc failed");
+    HIPCHK(hipMemsetAsync(e->md_state.p, 0, n + 1, s));
+    HIPCHK(hipMemsetAsync(e->md_tag.p, 0, nb + 1, s));
+    if (nb) HIPCHK(hipMemcpyAsync(e->md_seq.p, d.seq, nb / 2, hipMemcpyDeviceToDevice, s));
+    if (!realn && d.qual == d.qual_in && ((cp->flag & STA_CALMD_BIN_QUAL) || cp->max_nm > 0) && nb) {
+        // -q / -n rewrite qualities: they need the working copy the BAQ path would have made
+        FileBufs &b = e->fb[0];
+        if (b.qual_work.ensure(nb + 32)) return fail(e, STA_ERR_HIP, "hipMalloc(qual) failed");
+        HIPCHK(hipMemcpyAsync(b.qual_work.p, d.qual_in, nb, hipMemcpyDeviceToDevice, s));
+        d.qual = (uint8_t *)b.qual_work.p;
+    }
+    if (n) {
+        if (realn) { ProfScope ps(e, "calmd_tag"); sta_launch_calmd_tag(s, d, apply ? 1 : 0, (uint8_t *)e->md_tag.p, (uint8_t *)e->md_state.p); }
+        { ProfScope ps(e, "md_len"); sta_launch_md_len(s, d, e->wd, (int32_t *)e->md_nm.p, (uint32_t *)e->md_len.p, (uint8_t *)e->md_state.p); }
+        { ProfScope ps(e, "len_scan"); sta_launch_len_scan(s, (const uint32_t *)e->md_len.p, (uint64_t *)e->offs.p, (int64_t)n, e->scan_tmp.p, e->scan_tmp.cap); }
+    }
+    uint64_t total = 0;
+    if (n) HIPCHK(hipMemcpyAsync(&total, (uint64_t *)e->offs.p + n, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (e->out.ensure((size_t)total + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(output) failed");
+    if (n) {
+        ProfScope ps(e, "md_emit");
+        sta_launch_md_emit(s, d, e->wd, (cp->flag & STA_CALMD_USE_EQUAL) ? 1 : 0, (cp->flag & STA_CALMD_BIN_QUAL) ? 1 : 0, cp->max_nm,
+                           (const int32_t *)e->md_nm.p, (const uint64_t *)e->offs.p, (char *)e->out.p, (uint8_t *)e->md_seq.p);
+    }
+    d.bq = saved_bq;
+    HIPCHK(hipStreamSynchronize(s));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return hipfail(e, le, "calmd kernels");
+    e->out_bytes = total; e->last_out = e->out.p;
+    if (info) { memset(info, 0, sizeof *info); info->out_bytes = total; }
+    e->planned = 6;
+    return STA_OK;
+}
+
+int sta_fetch_calmd(sta_engine *e, int32_t *nm, uint64_t *md_off, char *md_text, uint8_t *state, uint8_t *qual_pool, uint8_t *seq_pool, uint8_t *tag_pool)
+{
+    if (!e) return STA_ERR_ARG;
+    if (e->planned != 6) return fail(e, STA_ERR_ARG, "no planned calmd window");
+    hipSetDevice(e->device);
+    StaReadsDev &d = e->files_h[0];
+    const size_t n = (size_t)d.n, nb = (size_t)d.n_bases_total;
+    hipStream_t s = e->stream;
+    if (nm && n) HIPCHK(hipMemcpyAsync(nm, e->md_nm.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (md_off) { if (n) HIPCHK(hipMemcpyAsync(md_off, e->offs.p, (n + 1) * 8, hipMemcpyDeviceToHost, s)); else md_off[0] = 0; }
+    if (md_text && e->out_bytes) HIPCHK(hipMemcpyAsync(md_text, e->out.p, (size_t)e->out_bytes, hipMemcpyDeviceToHost, s));
+    if (state && n) HIPCHK(hipMemcpyAsync(state, e->md_state.p, n, hipMemcpyDeviceToHost, s));
+    if (qual_pool && nb) HIPCHK(hipMemcpyAsync(qual_pool, d.qual, nb, hipMemcpyDeviceToHost, s));
+    if (seq_pool && nb) HIPCHK(hipMemcpyAsync(seq_pool, e->md_seq.p, nb / 2, hipMemcpyDeviceToHost, s));
+    if (tag_pool && nb) HIPCHK(hipMemcpyAsync(tag_pool, e->md_tag.p, nb, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return STA_OK;
 }
 

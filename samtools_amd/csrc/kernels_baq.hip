@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(64) k_baq(StaReadsDev R, StaWinDev W, BaqTable
                         int b = state[(size_t)i * 64];
                         run = b > run ? b : run;                    // rght[i]
                         int left = qq[(size_t)i * 64];
-                        int bqv = left < run ? left : run;
+                        int bqv = W.baq_plain ? b : (left < run ? left : run);    // plain (calmd -r without -E): min(qual, q) per base
                         int q0 = qual[i];
                         int tag = 64 + (q0 <= bqv ? 0 : q0 - bqv);  // bq[i] as stored in ZQ
                         qual[i] = (uint8_t)(q0 - (tag - 64));
@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(256, BAQ_PREFETCH_F ? 2 : 3) k_baq_bwd(StaRead
                         int32_t pk = P[(size_t)i * 64];
                         int b = pk >> 8, left = pk & 0xff;
                         run = b > run ? b : run;
-                        int bqv = left < run ? left : run;
+                        int bqv = W.baq_plain ? b : (left < run ? left : run);    // plain (calmd -r without -E): min(qual, q) per base
                         int q0 = qual[i];
                         int tag = 64 + (q0 <= bqv ? 0 : q0 - bqv);
                         qual[i] = (uint8_t)(q0 - (tag - 64));
@@ -889,7 +889,7 @@ __global__ void __launch_bounds__(256) k_baq_ck_bwd(StaReadsDev R, StaWinDev W, 
                         int32_t pk = P[(size_t)i * 64];
                         int b = pk >> 8, left = pk & 0xff;
                         run = b > run ? b : run;
-                        int bqv = left < run ? left : run;
+                        int bqv = W.baq_plain ? b : (left < run ? left : run);    // plain (calmd -r without -E): min(qual, q) per base
                         int q0 = qual[i];
                         int tag = 64 + (q0 <= bqv ? 0 : q0 - bqv);
                         qual[i] = (uint8_t)(q0 - (tag - 64));

@@ -63,6 +63,7 @@ struct StaWinDev {
     const char *tname; int32_t tname_len;
     int32_t has_bed; int64_t n_bed; const int64_t *bed_beg, *bed_end;
     int32_t has_reg; int64_t reg_beg, reg_end;
+    int32_t baq_plain;              // 0: extended BAQ (what mpileup always asks for, realn.c flag bit 2); 1: per-base BAQ (calmd -r without -E)
 };
 
 struct StaCounters {          // device-side reduction targets, zeroed per plan
@@ -93,6 +94,10 @@ void sta_launch_plp_fill(hipStream_t s, const StaWinDev &w, const uint64_t *offs
 // coverage / bedcov column reductions (kernels_cov.hip)
 void sta_launch_glf_cols(hipStream_t s, const StaWinDev &w, int min_baseQ, int capQ, const char *ref, int64_t ref_len,
                          const double *fk, const double *beta, const double *lhet, void *out);
+void sta_launch_calmd_tag(hipStream_t s, const StaReadsDev &r, int apply, uint8_t *tag_pool, uint8_t *state);
+void sta_launch_md_len(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int32_t *nm, uint32_t *md_len, uint8_t *state);
+void sta_launch_md_emit(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int use_equal, int bin_qual, int max_nm,
+                        const int32_t *nm, const uint64_t *md_off, char *md_text, uint8_t *seq_work);
 void sta_launch_cov_cols(hipStream_t s, const StaWinDev &w, int mode, int min_baseQ, int min_depth, int skip_dn,
                          unsigned long long *totals /*[5]*/, unsigned long long *per_file /*[nfiles][2]*/);
 

@@ -61,3 +61,26 @@ def test_oracle_glfgen_reproduces_tview_consensus_line(oracle_bin):
     got, want = tview_consensus_from_glf(out.stdout.decode(), open(os.path.join(gold, "tview.expected.out")).read())
     assert got == want
     assert "K" in want
+
+
+@pytest.mark.parametrize("n", ["1", "2", "3"])
+def test_oracle_calmd_recomputes_the_md_and_nm_tags_the_reference_inputs_carry(oracle_bin, n):
+    """8(f) row 3 (bam_fillmd1_core): test/dat/mpileup.{1,2,3}.sam carry MD:Z / NM:i written by the aligner against
+    test/dat/mpileup.ref.fa, the very pair the reference's calmd test runs on (test/test.pl:3652-3661, which only checks the
+    container magic).  Recomputed values must equal the stored ones (MD compared case-insensitively, as bam_md.c:182-190 does)."""
+    import subprocess
+    dat = os.path.join(os.path.dirname(__file__), "golden", "dat")
+    sam = os.path.join(dat, "mpileup.%s.sam" % n)
+    out = subprocess.run([oracle_bin, "calmd", sam, os.path.join(dat, "mpileup.ref.fa")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    recs = [l.rstrip("\n").split("\t") for l in open(sam) if not l.startswith("@")]
+    lines = [l.split("\t") for l in out.stdout.decode().split("\n") if l]
+    assert len(lines) == len(recs)
+    checked = 0
+    for got, rec in zip(lines, recs):
+        tags = {t[:2]: t[5:] for t in rec[11:]}
+        assert got[0] == rec[0] and got[1] == rec[1]
+        if "MD" in tags and got[6] != "*":
+            assert got[6].upper() == tags["MD"].upper(), rec[0]
+            assert int(got[5]) == int(tags["NM"]), rec[0]
+            checked += 1
+    assert checked >= 230

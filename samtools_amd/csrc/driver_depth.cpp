@@ -28,7 +28,7 @@ struct DRunner {
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
     int64_t window_cols = 1 << 20, max_reads = 4 << 20;
     std::vector<StagedFile> staged;
-    std::vector<char> text;
+    pvector<char> text;                 // page-locked: the D2H copy of the text lands here
 
     int run_window(int tid, int64_t cb, int64_t ce, const std::vector<std::vector<const Rec *>> *reads, int all_mode,
                    bool write, uint64_t *n_kept)

@@ -66,7 +66,7 @@ struct Runner {
     FILE *out = stdout;
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
     std::vector<StagedFile> staged;
-    std::vector<char> text;
+    pvector<char> text;                 // page-locked: the D2H copy of the text lands here
     std::vector<std::vector<char>> cap_dropped;      // per file: reads of the last window that the -d cap dropped
     int loaded_ref_tid = -2;
     int64_t loaded_ref_len = INT64_MAX;               // length of the loaded FASTA contig (INT64_MAX: none, no length filter)

@@ -1,0 +1,27 @@
+// host_pinned.h -- page-locked host memory for the staging pools and the fetched text (BASELINE.json north_star: "stages
+// pre-decoded BAM records into pinned ... buffers").  hipMemcpyAsync from pageable memory goes through the runtime's own
+// bounce buffer (~10 GB/s and synchronous); from pinned memory it is a direct DMA at PCIe rate.  The vectors are reused
+// across windows, so the (slow) hipHostMalloc calls happen only while the pools grow.  Without a usable device (host-only
+// tools and tests: sta_io_scan) the allocator falls back to malloc.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace sta {
+
+void *pinned_alloc(size_t bytes);      // never returns nullptr (throws std::bad_alloc)
+void pinned_free(void *p) noexcept;
+
+template <class T> struct PinnedAlloc {
+    typedef T value_type;
+    PinnedAlloc() noexcept {}
+    template <class U> PinnedAlloc(const PinnedAlloc<U> &) noexcept {}
+    T *allocate(size_t n) { return static_cast<T *>(pinned_alloc(n * sizeof(T))); }
+    void deallocate(T *p, size_t) noexcept { pinned_free(p); }
+    template <class U> bool operator==(const PinnedAlloc<U> &) const noexcept { return true; }
+    template <class U> bool operator!=(const PinnedAlloc<U> &) const noexcept { return false; }
+};
+template <class T> using pvector = std::vector<T, PinnedAlloc<T>>;
+
+}  // namespace sta

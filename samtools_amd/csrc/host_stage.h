@@ -3,6 +3,7 @@
 // north_star); the arrays are what sta_stage_window() copies to HBM.
 #pragma once
 #include "host_io.h"
+#include "host_pinned.h"
 #include "../../include/samtools_amd.h"
 #include <set>
 
@@ -18,14 +19,15 @@ struct XcolSpec {
 };
 
 struct StagedFile {
-    std::vector<int32_t> pos, l_qseq, mtid, isize;
-    std::vector<uint16_t> flag;
-    std::vector<uint8_t> mapq, aux;
-    std::vector<uint32_t> cig_off, base_off8, name_off, cigar;
-    std::vector<int64_t> mpos;
-    std::vector<uint8_t> seq, qual, bq;
-    std::vector<char> names;
-    std::vector<uint32_t> xcol_off; std::vector<char> xcol_text; int n_xcols = 0;
+    // page-locked (host_pinned.h): sta_stage_window copies straight out of these
+    pvector<int32_t> pos, l_qseq, mtid, isize;
+    pvector<uint16_t> flag;
+    pvector<uint8_t> mapq, aux;
+    pvector<uint32_t> cig_off, base_off8, name_off, cigar;
+    pvector<int64_t> mpos;
+    pvector<uint8_t> seq, qual, bq;
+    pvector<char> names;
+    pvector<uint32_t> xcol_off; pvector<char> xcol_text; int n_xcols = 0;
     bool any_bq = false;
     void clear();
     // origin: absolute coordinate of relative 0; rg_excl: -G read groups to drop (may be null)

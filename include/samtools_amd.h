@@ -321,7 +321,9 @@ int sta_main_calmd(int argc, char **argv);
  * by `threads` workers and records are parsed one batch ahead of the consumer.  sta_io_scan decodes a whole file through it
  * and returns the record count and an order-dependent checksum over every decoded field (threads <= 0: the drivers'
  * default, $STA_IO_THREADS or 4; 1 worker is still a separate thread).  stage != 0 additionally pushes the records through
- * the drivers' window pump and SoA stager (what runs between the reader and sta_stage_window).  Returns 0, or <0 on error. */
+ * the drivers' window pump and SoA stager (what runs between the reader and sta_stage_window) and checksums every staged
+ * window: 1 = one decoded record at a time (host_pump.h), 2 = chunk slices decoded on `threads` parser threads
+ * (host_chunk.h); both lanes must give the same checksum.  Returns 0, or <0 on error. */
 int sta_io_scan(const char *path, int threads, int stage, uint64_t *n_records, uint64_t *checksum);
 
 #ifdef __cplusplus

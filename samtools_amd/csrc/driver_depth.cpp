@@ -8,6 +8,9 @@
 #include "host_io.h"
 #include "host_stage.h"
 #include "host_pump.h"
+#include "host_chunk.h"
+#include "host_bgzf.h"
+#include <cstdlib>
 #include <getopt.h>
 #include <cstdio>
 #include <cstring>
@@ -27,22 +30,18 @@ struct DRunner {
     std::unique_ptr<Bed> bed;
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
     int64_t window_cols = 1 << 20, max_reads = 4 << 20;
-    std::vector<StagedFile> staged;
+    std::vector<StagedFile> staged;     // the window the pump staged last
+    std::vector<StagedFile> no_reads;   // read-less windows leave `staged` alone
     pvector<char> text;                 // page-locked: the D2H copy of the text lands here
 
-    int run_window(int tid, int64_t cb, int64_t ce, const std::vector<std::vector<const Rec *>> *reads, int all_mode,
-                   bool write, uint64_t *n_kept)
+    // one window over what the pump staged (have_reads) or over no reads at all (zero rows)
+    int run_window(int tid, int64_t cb, int64_t ce, bool have_reads, int all_mode, bool write, uint64_t *n_kept)
     {
         if (ce <= cb) { if (n_kept) *n_kept = 0; return 0; }
         size_t nf = readers.size();
-        staged.resize(nf);
         std::vector<sta_reads> views(nf);
-        for (size_t f = 0; f < nf; ++f) {
-            staged[f].clear();
-            if (reads) for (const Rec *r : (*reads)[f]) staged[f].add(*r, cb, nullptr);
-            staged[f].finish();
-            views[f] = staged[f].view();
-        }
+        if (!have_reads && no_reads.size() != nf) { no_reads.assign(nf, StagedFile()); for (auto &e : no_reads) e.finish(); }
+        for (size_t f = 0; f < nf; ++f) views[f] = have_reads ? staged[f].view() : no_reads[f].view();
         sta_window w; memset(&w, 0, sizeof w);
         w.tid = tid; w.origin = cb; w.col_beg = 0; w.col_end = (int32_t)(ce - cb);
         w.tname = h->names[(size_t)tid].c_str(); w.tlen = h->lens[(size_t)tid];
@@ -68,29 +67,28 @@ struct DRunner {
     {
         while (a < b) {
             int64_t e = std::min(b, a + window_cols);
-            if (run_window(tid, a, e, nullptr, 1, true, nullptr) < 0) return -1;
+            if (run_window(tid, a, e, false, 1, true, nullptr) < 0) return -1;
             a = e;
         }
         return 0;
     }
 
     // mode 0: covered rows only; 1: -a (zero rows once a read of this contig passed the filters); 2: always
-    int process_tid(Pump &pump, int tid, int mode)
+    int process_tid(WindowSource &pump, int tid, int mode)
     {
         int64_t tlen = h->lens[(size_t)tid];
         int64_t lo = has_reg ? beg0 : 0;
         int64_t hi_all = has_reg ? std::min(end0, tlen) : tlen;
         bool started = mode == 2;
         int64_t cursor = started ? lo : std::max(lo, pump.next_pos(tid));
-        std::vector<std::vector<const Rec *>> reads;
         for (;;) {
             bool more = pump.next_pos(tid) != INT64_MAX;
             if (!more && !pump.has_carry()) break;
             if (!started && !pump.has_carry()) cursor = std::max(cursor, pump.next_pos(tid));
             int64_t ce_target = cursor + window_cols;
             if (has_reg) ce_target = std::min(ce_target, end0);
-            if (ce_target <= cursor) { pump.fill(tid, cursor, INT64_MAX, reads); pump.drop_tid_carry(); break; }
-            int64_t ce = pump.fill(tid, cursor, ce_target, reads);
+            if (ce_target <= cursor) { pump.fill_staged(tid, cursor, INT64_MAX, staged); pump.drop_tid_carry(); break; }
+            int64_t ce = pump.fill_staged(tid, cursor, ce_target, staged);
             if (pump.error()) return -1;
             if (pump.next_pos(tid) == INT64_MAX) {
                 int64_t me = pump.carry_max_end();
@@ -99,13 +97,13 @@ struct DRunner {
             if (ce > cursor) {
                 uint64_t n_kept = 0;
                 if (mode == 1 && !started) {
-                    if (run_window(tid, cursor, ce, &reads, 0, false, &n_kept) < 0) return -1;
+                    if (run_window(tid, cursor, ce, true, 0, false, &n_kept) < 0) return -1;
                     if (n_kept) {
                         started = true;
                         if (run_empty(tid, lo, cursor) < 0) return -1;
-                        if (run_window(tid, cursor, ce, &reads, 1, true, &n_kept) < 0) return -1;
+                        if (run_window(tid, cursor, ce, true, 1, true, &n_kept) < 0) return -1;
                     }
-                } else if (run_window(tid, cursor, ce, &reads, started ? 1 : 0, true, &n_kept) < 0) return -1;
+                } else if (run_window(tid, cursor, ce, true, started ? 1 : 0, true, &n_kept) < 0) return -1;
             }
             pump.retire(ce);
             cursor = std::max(cursor, ce);
@@ -118,7 +116,11 @@ struct DRunner {
     int run()
     {
         PumpConfig pc; pc.window_cols = window_cols; pc.max_reads = max_reads; pc.use_endpos = true;
-        Pump pump(readers, pc);
+        const char *lane = getenv("STA_IO_LANE");
+        std::unique_ptr<WindowSource> src;
+        if (lane && !strcmp(lane, "rec")) src.reset(new Pump(readers, pc));          // record-at-a-time lane
+        else src.reset(new ChunkPump(readers, pc, io_default_threads()));           // chunk slices decoded on several threads
+        WindowSource &pump = *src;
         const int all = p.all_pos;
         // with a region every -a/-aa run prints the whole region of tid0 (bam2depth.c:267-270)
         const int mode = has_reg ? (all ? 2 : 0) : (all >= 2 ? 2 : all);

@@ -9,6 +9,8 @@
 #include "host_io.h"
 #include "host_stage.h"
 #include "host_pump.h"
+#include "host_chunk.h"
+#include "host_bgzf.h"
 #include <getopt.h>
 #include <cstdio>
 #include <cstring>
@@ -65,7 +67,8 @@ struct Runner {
     const Header *h = nullptr;
     FILE *out = stdout;
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
-    std::vector<StagedFile> staged;
+    std::vector<StagedFile> staged;                   // the window the pump staged last
+    std::vector<StagedFile> no_reads;                 // read-less windows (zero-depth rows) leave `staged` alone
     pvector<char> text;                 // page-locked: the D2H copy of the text lands here
     std::vector<std::vector<char>> cap_dropped;      // per file: reads of the last window that the -d cap dropped
     int loaded_ref_tid = -2;
@@ -85,22 +88,16 @@ struct Runner {
         return sta_set_reference(eng, tid, s->data(), (int64_t)s->size(), STA_MEM_HOST);
     }
 
-    // run one window; all_mode overrides conf.p.all.  Returns <0 on error; n_data receives the data column count.
-    int run_window(int tid, int64_t cb, int64_t ce, const std::vector<std::vector<const Rec *>> *reads, int all_mode,
-                   bool write, uint64_t *n_data)
+    // run one window over what the pump staged (have_reads) or over no reads at all; all_mode overrides conf.p.all.
+    // Returns <0 on error; n_data receives the data column count.
+    int run_window(int tid, int64_t cb, int64_t ce, WindowSource *pump, bool have_reads, int all_mode, bool write, uint64_t *n_data)
     {
         if (ce <= cb) { if (n_data) *n_data = 0; return 0; }
         if (set_ref(tid) < 0) return -1;
         size_t nf = readers.size();
-        staged.resize(nf);
         std::vector<sta_reads> views(nf);
-        for (size_t f = 0; f < nf; ++f) {
-            staged[f].clear();
-            XcolSpec xs; xs.rnext = (conf.p.flag & STA_MPLP_PRINT_RNEXT) != 0; xs.hdr = &readers[f]->header(); xs.n_tags = (int)conf.tags.size(); xs.empty = conf.empty;
-            if (reads) for (const Rec *r : (*reads)[f]) staged[f].add(*r, cb, conf.has_rg_excl ? &conf.rg_excl : nullptr, xs.n_cols() ? &xs : nullptr);
-            staged[f].finish();
-            views[f] = staged[f].view();
-        }
+        if (!have_reads && no_reads.size() != nf) { no_reads.assign(nf, StagedFile()); for (auto &e : no_reads) e.finish(); }
+        for (size_t f = 0; f < nf; ++f) views[f] = have_reads ? staged[f].view() : no_reads[f].view();
         sta_window w; memset(&w, 0, sizeof w);
         w.tid = tid; w.origin = cb; w.col_beg = 0; w.col_end = (int32_t)(ce - cb);
         w.tname = h->names[(size_t)tid].c_str(); w.tlen = h->lens[(size_t)tid];
@@ -116,7 +113,7 @@ struct Runner {
         if (sta_mpileup_plan(eng, &p, &info) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
         if (n_data) *n_data = info.n_data_cols;
         cap_dropped.assign(nf, {});
-        if (info.n_maxcnt_dropped && reads) {
+        if (info.n_maxcnt_dropped && have_reads && pump) {
             // the cap removed reads from the iterator: they must not be carried into the next window (bam_plp_push never
             // stored them); info bit 0 = reached bam_plp_push, bit 1 = in the pileup
             std::vector<uint32_t> inf;
@@ -126,7 +123,7 @@ struct Runner {
                 if (sta_fetch_read_state(eng, (int32_t)f, inf.data(), nullptr) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
                 cap_dropped[f].assign(inf.size(), 0);
                 for (size_t i = 0; i < inf.size(); ++i)
-                    cap_dropped[f][i] = (inf[i] & 1u) && !(inf[i] & 2u) && (*reads)[f][i]->rlen > 0;
+                    cap_dropped[f][i] = (inf[i] & 1u) && !(inf[i] & 2u) && pump->staged_has_span(f, i);
             }
         }
         if (!write || info.out_bytes == 0) return 0;
@@ -142,7 +139,7 @@ struct Runner {
     {
         while (a < b) {
             int64_t e = std::min(b, a + conf.window_cols);
-            if (run_window(tid, a, e, nullptr, 1, true, nullptr) < 0) return -1;
+            if (run_window(tid, a, e, nullptr, false, 1, true, nullptr) < 0) return -1;
             a = e;
         }
         return 0;
@@ -151,7 +148,7 @@ struct Runner {
     // One contig.  mode 0: only covered columns (no -a); 1: -a, zero-depth rows once the contig has shown a
     // data column; 2: -aa, always.  Equivalent to mpileup()'s last_tid/last_pos bookkeeping (:610-660,
     // :880-910): every contig that prints anything prints its whole [lo, hi_all) range, in contig order.
-    int process_tid(Pump &pump, int tid, int mode)
+    int process_tid(WindowSource &pump, int tid, int mode)
     {
         int64_t tlen = h->lens[(size_t)tid];
         if (set_ref(tid) < 0) return -1;            // also tells the pump's lookahead the FASTA length of this contig
@@ -159,7 +156,6 @@ struct Runner {
         int64_t hi_all = has_reg ? std::min(end0, tlen) : tlen;
         bool started = mode == 2;
         int64_t cursor = started ? lo : std::max(lo, pump.next_pos(tid));
-        std::vector<std::vector<const Rec *>> reads;
         for (;;) {
             bool more = pump.next_pos(tid) != INT64_MAX;
             if (!more && !pump.has_carry()) break;
@@ -167,11 +163,11 @@ struct Runner {
             int64_t ce_target = cursor + conf.window_cols;
             if (has_reg) ce_target = std::min(ce_target, end0);
             if (ce_target <= cursor) {              // past the region end: drain the rest of this contig
-                pump.fill(tid, cursor, INT64_MAX, reads);
+                pump.fill_staged(tid, cursor, INT64_MAX, staged);
                 pump.drop_tid_carry();
                 break;
             }
-            int64_t ce = pump.fill(tid, cursor, ce_target, reads);
+            int64_t ce = pump.fill_staged(tid, cursor, ce_target, staged);
             if (pump.error()) return -1;
             if (pump.next_pos(tid) == INT64_MAX) {  // last reads of the contig: stop where they stop
                 int64_t me = pump.carry_max_end();
@@ -180,13 +176,13 @@ struct Runner {
             if (ce > cursor) {
                 uint64_t n_data = 0;
                 if (mode == 1 && !started) {
-                    if (run_window(tid, cursor, ce, &reads, 0, false, &n_data) < 0) return -1;
+                    if (run_window(tid, cursor, ce, &pump, true, 0, false, &n_data) < 0) return -1;
                     if (n_data) {
                         started = true;
                         if (run_empty(tid, lo, cursor) < 0) return -1;
-                        if (run_window(tid, cursor, ce, &reads, 1, true, &n_data) < 0) return -1;
+                        if (run_window(tid, cursor, ce, &pump, true, 1, true, &n_data) < 0) return -1;
                     }
-                } else if (run_window(tid, cursor, ce, &reads, started ? 1 : 0, true, &n_data) < 0) return -1;
+                } else if (run_window(tid, cursor, ce, &pump, true, started ? 1 : 0, true, &n_data) < 0) return -1;
             }
             for (size_t f = 0; f < cap_dropped.size(); ++f) if (!cap_dropped[f].empty()) pump.drop(f, cap_dropped[f]);
             cap_dropped.clear();
@@ -218,7 +214,16 @@ struct Runner {
                 return true;
             };
         }
-        Pump pump(readers, pc);
+        // input lane: chunk slices decoded on several threads, unless per-record host formatting is needed
+        // (--output-extra tags / RNEXT, -G) or STA_IO_LANE=rec asks for the record-at-a-time lane
+        pc.rg_excl = conf.has_rg_excl ? &conf.rg_excl : nullptr;
+        pc.xs_rnext = (conf.p.flag & STA_MPLP_PRINT_RNEXT) != 0; pc.xs_n_tags = (int)conf.tags.size(); pc.xs_empty = conf.empty;
+        const char *lane = getenv("STA_IO_LANE");
+        const bool chunked = !pc.rg_excl && !pc.xs_rnext && !pc.xs_n_tags && !(lane && !strcmp(lane, "rec"));
+        std::unique_ptr<WindowSource> src;
+        if (chunked) src.reset(new ChunkPump(readers, pc, io_default_threads()));
+        else src.reset(new Pump(readers, pc));
+        WindowSource &pump = *src;
         const int all = conf.p.all;
         const int mode = all >= 2 ? 2 : all;
         int next_full = 0;               // -aa without region: contigs below this index are done

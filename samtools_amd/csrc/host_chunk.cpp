@@ -1,0 +1,328 @@
+// host_chunk.cpp -- see host_chunk.h
+#include "host_chunk.h"
+#include <algorithm>
+#include <climits>
+#include <cstring>
+
+namespace sta {
+
+// ------------------------------------------------------------------------------------------------ Chunk
+void Chunk::append(const Rec &r)
+{
+    if (cig_off.empty()) { cig_off.push_back(0); base_off8.push_back(0); name_off.push_back(0); }
+    tid.push_back(r.tid); pos.push_back(r.pos); flag.push_back(r.flag); mapq.push_back(r.mapq);
+    l_qseq.push_back(r.l_qseq); mtid.push_back(r.mtid); mpos.push_back(r.mpos); isize.push_back(r.isize);
+    rlen.push_back((int32_t)std::min<int64_t>(r.rlen, INT32_MAX));
+    const bool bq_ok = r.has_bq && (int32_t)r.bq.size() >= r.l_qseq;
+    aux.push_back((uint8_t)((bq_ok ? STA_AUX_HAS_BQ : 0) | (r.has_zq ? STA_AUX_HAS_ZQ : 0)));
+    cigar.insert(cigar.end(), r.cigar.begin(), r.cigar.end());
+    const size_t b0 = qual.size(), padded = ((size_t)r.l_qseq + 7) & ~(size_t)7;
+    qual.resize(b0 + padded, 0);
+    if (r.l_qseq) memcpy(&qual[b0], r.qual.data(), (size_t)r.l_qseq);
+    seq.resize((b0 + padded) / 2, 0);
+    if (r.l_qseq) memcpy(&seq[b0 / 2], r.seq.data(), ((size_t)r.l_qseq + 1) / 2);
+    if (bq_ok && !has_bq_pool) { has_bq_pool = true; bq.assign(b0, 64); }
+    if (has_bq_pool) { bq.resize(b0 + padded, 64); if (bq_ok) memcpy(&bq[b0], r.bq.data(), (size_t)r.l_qseq); }
+    names.insert(names.end(), r.qname.begin(), r.qname.end());
+    names.push_back('\0');
+    cig_off.push_back((uint32_t)cigar.size());
+    base_off8.push_back((uint32_t)(qual.size() >> 3));
+    name_off.push_back((uint32_t)names.size());
+}
+
+void Chunk::close()
+{
+    if (cig_off.empty()) { cig_off.push_back(0); base_off8.push_back(0); name_off.push_back(0); }
+}
+
+void Chunk::to_rec(int64_t i, Rec &r) const
+{
+    const size_t k = (size_t)i;
+    r = Rec();
+    r.tid = tid[k]; r.mtid = mtid[k]; r.pos = pos[k]; r.mpos = mpos[k]; r.isize = isize[k];
+    r.flag = flag[k]; r.mapq = mapq[k]; r.l_qseq = l_qseq[k]; r.rlen = rlen[k];
+    r.qname.assign(names.data() + name_off[k]);
+    r.cigar.assign(cigar.begin() + cig_off[k], cigar.begin() + cig_off[k + 1]);
+    const size_t b0 = (size_t)base_off8[k] << 3, l = (size_t)l_qseq[k];
+    r.seq.assign(seq.begin() + (long)(b0 / 2), seq.begin() + (long)(b0 / 2 + (l + 1) / 2));
+    r.qual.assign(qual.begin() + (long)b0, qual.begin() + (long)(b0 + l));
+    r.has_bq = (aux[k] & STA_AUX_HAS_BQ) != 0; r.has_zq = (aux[k] & STA_AUX_HAS_ZQ) != 0;
+    if (r.has_bq) r.bq.assign(bq.begin() + (long)b0, bq.begin() + (long)(b0 + l));
+}
+
+// ------------------------------------------------------------------------------------------------ ChunkReader
+static constexpr size_t GROUP_BYTES = 1 << 20;
+
+ChunkReader::ChunkReader(AlnReader *rd, int threads) : rd_(rd)
+{
+    if (threads < 1) threads = 1;
+    max_ahead_ = (size_t)threads * 2 + 2;
+    for (int i = 0; i < threads; ++i) th_.emplace_back([this] { work(); });
+}
+
+ChunkReader::~ChunkReader()
+{
+    { std::lock_guard<std::mutex> g(out_m_); stop_ = true; }
+    cv_room_.notify_all(); cv_out_.notify_all();
+    for (auto &t : th_) if (t.joinable()) t.join();
+}
+
+void ChunkReader::work()
+{
+    std::vector<uint8_t> raw;
+    Rec r; std::string scratch;
+    for (;;) {
+        uint64_t seq;
+        {
+            // room first (bounded read-ahead), then the next group under the I/O lock: groups are cut strictly in file order
+            std::unique_lock<std::mutex> lk(out_m_);
+            cv_room_.wait(lk, [this] { return stop_ || next_in_ - next_out_ < max_ahead_; });
+            if (stop_) return;
+        }
+        int64_t nrec = 0;
+        {
+            std::lock_guard<std::mutex> g(io_m_);
+            if (io_end_.load()) return;
+            int st = rd_->raw_group(raw, GROUP_BYTES, &nrec);
+            if (st <= 0) {
+                std::lock_guard<std::mutex> g2(out_m_);
+                io_status_.store(st); io_end_.store(true);
+                cv_out_.notify_all();
+                return;
+            }
+            std::lock_guard<std::mutex> g2(out_m_);
+            seq = next_in_++;
+        }
+        auto c = std::make_shared<Chunk>();
+        size_t o = 0; bool bad = false;
+        while (o < raw.size()) {
+            size_t used = 0;
+            int st = rd_->parse_raw(raw.data() + o, raw.size() - o, &used, r, scratch);
+            if (st <= 0) { bad = true; break; }
+            o += used;
+            r.rlen = 0;
+            for (uint32_t cg : r.cigar) { int op = (int)(cg & 0xf); if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) r.rlen += (cg >> 4); }
+            if (!rd_->in_region(r)) continue;
+            c->append(r);
+        }
+        c->close();
+        std::lock_guard<std::mutex> g(out_m_);
+        if (bad && seq < bad_seq_) bad_seq_ = seq;
+        done_[seq] = std::move(c);
+        cv_out_.notify_all();
+    }
+}
+
+std::shared_ptr<Chunk> ChunkReader::next()
+{
+    std::unique_lock<std::mutex> lk(out_m_);
+    for (;;) {
+        auto it = done_.find(next_out_);
+        if (it != done_.end()) {
+            std::shared_ptr<Chunk> c = std::move(it->second);
+            done_.erase(it);
+            const bool bad = next_out_ >= bad_seq_;
+            ++next_out_;
+            cv_room_.notify_all();
+            if (bad) { status_ = -2; return nullptr; }       // records before the malformed one in that group are dropped too
+            return c;
+        }
+        if (io_end_.load() && next_out_ >= next_in_) { const int st = io_status_.load(); status_ = st < 0 ? st : 0; return nullptr; }
+        cv_out_.wait_for(lk, std::chrono::milliseconds(50));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ChunkPump
+ChunkPump::ChunkPump(std::vector<std::unique_ptr<AlnReader>> &readers, const PumpConfig &cfg, int threads) : cfg_(cfg)
+{
+    f_.resize(readers.size());
+    for (size_t i = 0; i < readers.size(); ++i) f_[i].rd.reset(new ChunkReader(readers[i].get(), threads));
+}
+
+bool ChunkPump::settle(File &f)
+{
+    for (;;) {
+        if (f.eof) return false;
+        if (!f.cur || f.idx >= f.cur->n()) {
+            f.cur = f.rd->next(); f.idx = 0;
+            if (!f.cur) {
+                f.eof = true;
+                if (f.rd->status() < 0 && !err_) { err_ = -1; errtxt_ = "error reading from input file"; }
+                return false;
+            }
+            continue;
+        }
+        const Chunk &c = *f.cur; const size_t k = (size_t)f.idx;
+        if (c.tid[k] < 0) { ++f.idx; continue; }                    // unplaced reads never reach the engines
+        const bool before = c.tid[k] < f.last_tid || (c.tid[k] == f.last_tid && c.pos[k] < f.last_pos);
+        if (!(c.flag[k] & 4)) {
+            if (before) { f.eof = true; err_ = -2; errtxt_ = "the input is not position sorted"; return false; }
+            f.last_tid = c.tid[k]; f.last_pos = c.pos[k];
+        } else if (before) { ++f.idx; continue; }                  // out-of-order unmapped-flagged record: filtered anyway
+        return true;
+    }
+}
+
+int ChunkPump::next_tid()
+{
+    int best = INT_MAX;
+    for (auto &f : f_) {
+        if (settle(f)) best = std::min(best, (int)f.cur->tid[(size_t)f.idx]);
+        if (!f.carry.empty()) best = std::min(best, (int)f.carry.front().tid);
+    }
+    return best == INT_MAX ? -1 : best;
+}
+
+int64_t ChunkPump::next_pos(int tid)
+{
+    int64_t best = INT64_MAX;
+    for (auto &f : f_) if (settle(f) && f.cur->tid[(size_t)f.idx] == tid) best = std::min(best, f.cur->pos[(size_t)f.idx]);
+    return best;
+}
+
+bool ChunkPump::has_carry() const
+{
+    for (auto &f : f_) if (!f.carry.empty()) return true;
+    return false;
+}
+
+int64_t ChunkPump::carry_next_covered(int64_t cursor) const
+{
+    int64_t best = INT64_MAX;
+    for (auto &f : f_) for (auto &r : f.carry) if (span_end(r) > cursor) best = std::min(best, std::max(r.pos, cursor));
+    return best;
+}
+
+int64_t ChunkPump::carry_max_end() const
+{
+    int64_t m = INT64_MIN;
+    for (auto &f : f_) {
+        for (auto &r : f.carry) m = std::max(m, span_end(r));
+        for (auto &g : f.fresh) for (int64_t i = g.i0; i < g.i1; ++i) m = std::max(m, span_end(*g.c, i));
+    }
+    return m;
+}
+
+int64_t ChunkPump::fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged)
+{
+    int64_t ce = ce_target;
+    auto take = [](File &f) {
+        // append the settled record to the window's slices
+        if (!f.fresh.empty() && f.fresh.back().c == f.cur && f.fresh.back().i1 == f.idx) f.fresh.back().i1++;
+        else f.fresh.push_back(Range{ f.cur, f.idx, f.idx + 1 });
+        ++f.idx;
+    };
+    for (size_t fi = 0; fi < f_.size(); ++fi) {
+        File &f = f_[fi];
+        f.fresh.clear(); f.dropped.clear();
+        int64_t count = 0;
+        while (settle(f) && f.cur->tid[(size_t)f.idx] == tid && f.cur->pos[(size_t)f.idx] < ce) {
+            const int64_t p = f.cur->pos[(size_t)f.idx];
+            take(f);
+            if (++count >= cfg_.max_reads && fi == 0 && p >= cb) {
+                // cut the window after this start position (all reads sharing it stay together)
+                while (settle(f) && f.cur->tid[(size_t)f.idx] == tid && f.cur->pos[(size_t)f.idx] == p) take(f);
+                if (p + 1 > cb) ce = std::min(ce, p + 1);
+                break;
+            }
+        }
+    }
+    if (cfg_.surely_pushed) {
+        Rec probe;
+        for (auto &f : f_) {
+            int64_t me = INT64_MIN;
+            for (auto &r : f.carry) me = std::max(me, span_end(r));
+            for (auto &g : f.fresh) for (int64_t i = g.i0; i < g.i1; ++i) me = std::max(me, span_end(*g.c, i));
+            bool sure = false;
+            for (auto &r : f.carry) if (r.pos >= ce && cfg_.surely_pushed(r)) { sure = true; break; }
+            while (!sure && settle(f) && f.cur->tid[(size_t)f.idx] == tid && f.cur->pos[(size_t)f.idx] < me) {
+                const size_t k = (size_t)f.idx;
+                probe.tid = f.cur->tid[k]; probe.pos = f.cur->pos[k]; probe.flag = f.cur->flag[k]; probe.mapq = f.cur->mapq[k];
+                sure = cfg_.surely_pushed(probe);
+                take(f);
+            }
+        }
+    }
+    staged.resize(f_.size());
+    for (size_t fi = 0; fi < f_.size(); ++fi) {
+        File &f = f_[fi];
+        StagedFile &s = staged[fi];
+        s.clear();
+        for (auto &r : f.carry) s.add(r, cb, nullptr);
+        f.n_carry_staged = f.carry.size();
+        for (auto &g : f.fresh) s.add_range(*g.c, g.i0, g.i1, cb);
+        s.finish();
+    }
+    return ce;
+}
+
+bool ChunkPump::staged_has_span(size_t fi, size_t i) const
+{
+    if (fi >= f_.size()) return false;
+    const File &f = f_[fi];
+    if (i < f.n_carry_staged) return i < f.carry.size() && f.carry[i].rlen > 0;
+    int64_t k = (int64_t)(i - f.n_carry_staged);
+    for (auto &g : f.fresh) { if (k < g.i1 - g.i0) return g.c->rlen[(size_t)(g.i0 + k)] > 0; k -= g.i1 - g.i0; }
+    return false;
+}
+
+void ChunkPump::drop(size_t fi, const std::vector<char> &dropped)
+{
+    File &f = f_[fi];
+    f.dropped = dropped;             // consulted by retire() for the window's new reads
+    std::deque<Rec> keep;
+    size_t i = 0;
+    for (auto &r : f.carry) { if (!(i < dropped.size() && dropped[i])) keep.push_back(std::move(r)); ++i; }
+    // (n_carry_staged keeps the ORIGINAL count: `dropped` is indexed in staged order)
+    f.carry.swap(keep);
+}
+
+void ChunkPump::retire(int64_t ce)
+{
+    struct Stay { int64_t pos; const char *qname; };
+    auto paired_ok = [](unsigned flag) { return (flag & 1) && (flag & 2) && !(flag & 8); };
+    for (auto &f : f_) {
+        auto is_dropped = [&](size_t staged_index) { return staged_index < f.dropped.size() && f.dropped[staged_index]; };
+        // pass 1: who stays because its span reaches beyond ce (position sorted: carried reads first, then the new ones)
+        std::vector<Stay> stay;
+        if (cfg_.keep_mates) {
+            for (auto &r : f.carry) if (span_end(r) > ce && paired_ok(r.flag)) stay.push_back(Stay{ r.pos, r.qname.c_str() });
+            size_t si = f.n_carry_staged;
+            for (auto &g : f.fresh)
+                for (int64_t i = g.i0; i < g.i1; ++i, ++si)
+                    if (!is_dropped(si) && span_end(*g.c, i) > ce && paired_ok(g.c->flag[(size_t)i]))
+                        stay.push_back(Stay{ g.c->pos[(size_t)i], g.c->names.data() + g.c->name_off[(size_t)i] });
+        }
+        auto mate_stays = [&](unsigned flag, int32_t tid, int32_t mtid, int64_t mpos, const char *qname) {
+            if (stay.empty() || !paired_ok(flag) || mtid != tid) return false;
+            auto lo = std::lower_bound(stay.begin(), stay.end(), mpos, [](const Stay &s, int64_t p) { return s.pos < p; });
+            for (; lo != stay.end() && lo->pos == mpos; ++lo) if (lo->qname != qname && !strcmp(lo->qname, qname)) return true;
+            return false;
+        };
+        // pass 2: decide for the carried reads before anything moves (`stay` points into them), then keep / materialise
+        std::vector<char> keepc(f.carry.size(), 0);
+        { size_t i = 0; for (auto &r : f.carry) keepc[i++] = span_end(r) > ce || mate_stays(r.flag, r.tid, r.mtid, r.mpos, r.qname.c_str()); }
+        std::vector<std::pair<const Chunk *, int64_t>> fresh_keep;
+        size_t si = f.n_carry_staged;
+        for (auto &g : f.fresh)
+            for (int64_t i = g.i0; i < g.i1; ++i, ++si) {
+                if (is_dropped(si)) continue;
+                const size_t k = (size_t)i;
+                if (span_end(*g.c, i) > ce || mate_stays(g.c->flag[k], g.c->tid[k], g.c->mtid[k], g.c->mpos[k], g.c->names.data() + g.c->name_off[k]))
+                    fresh_keep.emplace_back(g.c.get(), i);
+            }
+        std::deque<Rec> keep;
+        { size_t i = 0; for (auto &r : f.carry) { if (keepc[i++]) keep.push_back(std::move(r)); } }
+        for (auto &pr : fresh_keep) { keep.emplace_back(); pr.first->to_rec(pr.second, keep.back()); }
+        f.carry.swap(keep);
+        for (auto &r : f.carry) r.accepted = true;      // what stays was accepted by this window's -d replay
+        f.fresh.clear(); f.dropped.clear(); f.n_carry_staged = 0;
+    }
+}
+
+void ChunkPump::drop_tid_carry()
+{
+    for (auto &f : f_) { f.carry.clear(); f.fresh.clear(); f.dropped.clear(); f.n_carry_staged = 0; }
+}
+
+}  // namespace sta

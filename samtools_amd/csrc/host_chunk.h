@@ -1,0 +1,99 @@
+// host_chunk.h -- the drivers' fast input lane: records are decoded on several threads straight into structure-of-arrays
+// chunks whose pools have the staging layout, so that a window is assembled by concatenating chunk slices (bulk copies +
+// offset rebasing) instead of one decoded record at a time.  Same role as host_pump.h (the reference's "pull reads while they
+// can still touch the column" loop, bam_plcmd.c:607 / bam2depth.c:578-663), same window semantics -- host_scan.cpp checks that
+// both lanes stage byte-identical windows -- but per-record work is left only for the few reads that straddle a window end.
+// Used when no per-record host formatting is asked for (no --output-extra tags / RNEXT, no -G read-group list).
+#pragma once
+#include "host_io.h"
+#include "host_pump.h"
+#include "host_stage.h"
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+namespace sta {
+
+// consecutive records of one file in file order; pools laid out like StagedFile's (8-padded bases, NUL-terminated names)
+struct Chunk {
+    std::vector<int32_t> tid, l_qseq, mtid, rlen;
+    std::vector<int64_t> pos, mpos, isize;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq, aux;               // aux: STA_AUX_HAS_BQ / STA_AUX_HAS_ZQ
+    std::vector<uint32_t> cig_off, base_off8, name_off;      // n + 1 entries each
+    std::vector<uint32_t> cigar;
+    std::vector<uint8_t> seq, qual, bq;           // bq maintained only once some record carries BQ:Z
+    bool has_bq_pool = false;
+    std::vector<char> names;
+    int64_t n() const { return (int64_t)pos.size(); }
+    int64_t end(int64_t i) const { return pos[(size_t)i] + rlen[(size_t)i]; }
+    int64_t endpos(int64_t i) const { int64_t l = (flag[(size_t)i] & 4) ? 0 : rlen[(size_t)i]; return pos[(size_t)i] + (l > 0 ? l : 1); }
+    void append(const Rec &r);
+    void close();                                 // final offset entries
+    void to_rec(int64_t i, Rec &r) const;         // materialise one record (reads that stay carried across windows)
+};
+
+// decodes one input on `threads` parser threads; chunks come out in file order
+class ChunkReader {
+public:
+    ChunkReader(AlnReader *rd, int threads);
+    ~ChunkReader();
+    // next chunk in file order; nullptr at end of data or after an error (status() tells which)
+    std::shared_ptr<Chunk> next();
+    int status() const { return status_; }        // 0 = fine / clean end, <0 = decode error
+private:
+    AlnReader *rd_;
+    std::vector<std::thread> th_;
+    std::mutex io_m_, out_m_;
+    std::condition_variable cv_out_, cv_room_;
+    std::map<uint64_t, std::shared_ptr<Chunk>> done_;
+    uint64_t next_in_ = 0, next_out_ = 0;
+    std::atomic<bool> io_end_{ false }; std::atomic<int> io_status_{ 0 };
+    bool stop_ = false;
+    int status_ = 0;
+    uint64_t bad_seq_ = UINT64_MAX;               // first group that failed to parse
+    size_t max_ahead_;
+    void work();
+};
+
+// window source over chunked readers
+class ChunkPump : public WindowSource {
+public:
+    ChunkPump(std::vector<std::unique_ptr<AlnReader>> &readers, const PumpConfig &cfg, int threads);
+    int next_tid() override;
+    int64_t next_pos(int tid) override;
+    bool has_carry() const override;
+    int64_t carry_next_covered(int64_t cursor) const override;
+    int64_t carry_max_end() const override;
+    int64_t fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged) override;
+    bool staged_has_span(size_t f, size_t i) const override;
+    void drop(size_t f, const std::vector<char> &dropped) override;
+    void retire(int64_t ce) override;
+    void drop_tid_carry() override;
+    int error() const override { return err_; }
+    const char *error_text() const override { return errtxt_.c_str(); }
+private:
+    struct Range { std::shared_ptr<Chunk> c; int64_t i0, i1; };
+    struct File {
+        std::unique_ptr<ChunkReader> rd;
+        std::shared_ptr<Chunk> cur; int64_t idx = 0;      // next unread record
+        bool eof = false;
+        int64_t last_pos = -1; int last_tid = -1;
+        std::deque<Rec> carry;                            // reads carried from earlier windows (materialised)
+        std::vector<Range> fresh;                         // the current window's new reads, as chunk slices
+        size_t n_carry_staged = 0;                        // carried reads at the front of the staged order
+        std::vector<char> dropped;                        // per staged read: removed by the -d cap in this window
+    };
+    PumpConfig cfg_;
+    std::vector<File> f_;
+    int err_ = 0; std::string errtxt_;
+    bool settle(File &f);                                 // positions f.cur/f.idx on the next usable record; false at end
+    int64_t span_end(const Chunk &c, int64_t i) const { return cfg_.use_endpos ? c.endpos(i) : c.end(i); }
+    int64_t span_end(const Rec &r) const { return cfg_.use_endpos ? r.endpos() : r.end(); }
+};
+
+}  // namespace sta

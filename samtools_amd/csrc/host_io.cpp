@@ -264,6 +264,8 @@ int AlnReader::next_raw(Rec &r)
     return parse_sam(hdr_, im.line, r, im.want.empty() ? nullptr : &im.want);
 }
 
+static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::string> &wanted, Rec &r);
+
 static int parse_bam(AlnReader::Impl &im, Rec &r)
 {
     int32_t bs = 0;
@@ -272,7 +274,12 @@ static int parse_bam(AlnReader::Impl &im, Rec &r)
     if (n != 4 || bs < 32) return -2;
     if (im.blk.size() < (size_t)bs) im.blk.resize((size_t)bs * 2);
     if (im.read(im.blk.data(), (size_t)bs) != (size_t)bs) return -2;
-    const uint8_t *b = im.blk.data();
+    return parse_bam_mem(im.blk.data(), bs, im.want, r);
+}
+
+// one BAM alignment record (SAM spec 4.2) of bs bytes, block_size prefix already consumed
+static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::string> &wanted, Rec &r)
+{
     int32_t refID, pos, l_seq, nref, npos, tlen; uint16_t n_cig, flag;
     memcpy(&refID, b, 4); memcpy(&pos, b + 4, 4);
     uint8_t l_rn = b[8]; r.mapq = b[9];
@@ -288,13 +295,13 @@ static int parse_bam(AlnReader::Impl &im, Rec &r)
     r.tid = refID; r.pos = pos; r.flag = flag; r.mtid = nref; r.mpos = npos; r.isize = tlen; r.l_qseq = l_seq;
     r.has_bq = r.has_zq = false; r.bq.clear(); r.rg.clear();
     const uint8_t *p = b + o, *e = b + bs;
-    const bool want = !im.want.empty();
-    if (want) { r.tagtext.assign(im.want.size(), std::string()); r.tag_has.assign(im.want.size(), 0); }
+    const bool want = !wanted.empty();
+    if (want) { r.tagtext.assign(wanted.size(), std::string()); r.tag_has.assign(wanted.size(), 0); }
     while (p + 3 <= e) {
         int t = p[2]; const uint8_t *tag = p; p += 3;
         if (want)
-            for (size_t w = 0; w < im.want.size(); ++w)
-                if (!r.tag_has[w] && im.want[w][0] == (char)tag[0] && im.want[w][1] == (char)tag[1]) {
+            for (size_t w = 0; w < wanted.size(); ++w)
+                if (!r.tag_has[w] && wanted[w][0] == (char)tag[0] && wanted[w][1] == (char)tag[1]) {
                     r.tag_has[w] = 1;
                     std::string &out = r.tagtext[w];
                     char nb[64];
@@ -326,6 +333,60 @@ static int parse_bam(AlnReader::Impl &im, Rec &r)
     }
     finish_rec(r);
     return 1;
+}
+
+// ---- raw record groups for the chunked reader (host_chunk.cpp): whole BAM records (with their block_size prefix) or whole
+// SAM lines ('\n' terminated), about `target` bytes per call; appended to `out`.  Not to be mixed with next().
+int AlnReader::raw_group(std::vector<uint8_t> &out, size_t target, int64_t *n_records)
+{
+    Impl &im = *p_;
+    int64_t nrec = 0;
+    out.clear();
+    if (im.is_bam) {
+        while (out.size() < target) {
+            int32_t bs = 0;
+            size_t n = im.read(&bs, 4);
+            if (n == 0) break;
+            if (n != 4 || bs < 32) return -2;
+            size_t o = out.size();
+            out.resize(o + 4 + (size_t)bs);
+            memcpy(&out[o], &bs, 4);
+            if (im.read(&out[o + 4], (size_t)bs) != (size_t)bs) return -2;
+            ++nrec;
+        }
+    } else {
+        while (out.size() < target) {
+            if (im.have_line) im.have_line = false;
+            else if (!im.getline(im.line)) break;
+            if (im.line.empty()) continue;
+            out.insert(out.end(), im.line.begin(), im.line.end());
+            out.push_back('\n');
+            ++nrec;
+        }
+    }
+    if (im.src->failed()) return -1;
+    if (n_records) *n_records = nrec;
+    return nrec ? 1 : 0;
+}
+
+bool AlnReader::is_bam() const { return p_->is_bam; }
+
+// parses one record of a group returned by raw_group(); *used = bytes consumed.  1 = record, <0 = malformed
+int AlnReader::parse_raw(const uint8_t *p, size_t avail, size_t *used, Rec &r, std::string &scratch) const
+{
+    const Impl &im = *p_;
+    if (im.is_bam) {
+        if (avail < 4) return -2;
+        int32_t bs; memcpy(&bs, p, 4);
+        if (bs < 32 || (size_t)bs + 4 > avail) return -2;
+        *used = (size_t)bs + 4;
+        return parse_bam_mem(p + 4, bs, im.want, r);
+    }
+    const uint8_t *nl = (const uint8_t *)memchr(p, '\n', avail);
+    if (!nl) return -2;
+    scratch.assign((const char *)p, (size_t)(nl - p));
+    *used = (size_t)(nl - p) + 1;
+    return parse_sam(hdr_, scratch, r, im.want.empty() ? nullptr : &im.want);
 }
 
 void AlnReader::set_wanted_tags(const std::vector<std::string> &tags) { p_->want = tags; }

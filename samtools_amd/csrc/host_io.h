@@ -56,6 +56,13 @@ public:
     std::function<void(const Rec &)> on_record;
     // 1 = record, 0 = EOF, <0 = error
     int next(Rec &r);
+    // chunked access (host_chunk.h): raw_group() cuts the byte stream into groups of whole records on one thread (1 = group,
+    // 0 = end of data, <0 = error), parse_raw() decodes one record of a group and may run on any number of threads at once.
+    int raw_group(std::vector<uint8_t> &out, size_t target, int64_t *n_records);
+    int parse_raw(const uint8_t *p, size_t avail, size_t *used, Rec &r, std::string &scratch) const;
+    bool is_bam() const;
+    bool has_region() const { return has_reg_; }
+    bool in_region(const Rec &r) const { return !has_reg_ || !(r.tid != rtid_ || r.pos >= rend_ || r.endpos() <= rbeg_); }
     struct Impl;
 private:
     AlnReader() = default;

@@ -114,6 +114,19 @@ int64_t Pump::fill(int tid, int64_t cb, int64_t ce_target, std::vector<std::vect
     return ce;
 }
 
+int64_t Pump::fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged)
+{
+    int64_t ce = fill(tid, cb, ce_target, last_);
+    staged.resize(rd_.size());
+    for (size_t f = 0; f < rd_.size(); ++f) {
+        XcolSpec xs; xs.rnext = cfg_.xs_rnext; xs.hdr = &rd_[f]->header(); xs.n_tags = cfg_.xs_n_tags; xs.empty = cfg_.xs_empty;
+        staged[f].clear();
+        for (const Rec *r : last_[f]) staged[f].add(*r, cb, cfg_.rg_excl, xs.n_cols() ? &xs : nullptr);
+        staged[f].finish();
+    }
+    return ce;
+}
+
 void Pump::drop(size_t f, const std::vector<char> &dropped)
 {
     std::deque<Rec> keep;

@@ -9,6 +9,7 @@
 #include "host_stage.h"
 #include <deque>
 #include <functional>
+#include <set>
 
 namespace sta {
 
@@ -27,30 +28,56 @@ struct PumpConfig {
     // the later mate beyond the earlier mate's end (the deletion branch of tweak_overlap_quality), and those stay visible
     // after the earlier mate has left the pileup.
     bool keep_mates = false;
+    // staging options of fill_staged(): -G read groups to mark STA_AUX_SKIP, --output-extra columns formatted on the host
+    const std::set<std::string> *rg_excl = nullptr;
+    bool xs_rnext = false; int xs_n_tags = 0; char xs_empty = '*';
 };
 
-class Pump {
+// What the window loops of the drivers need from an input lane (Pump below: one decoded record at a time; ChunkPump in
+// host_chunk.h: chunk slices).  A window [cb, ce) of one contig receives every read whose span can touch it.
+class WindowSource {
+public:
+    virtual ~WindowSource() {}
+    virtual int next_tid() = 0;                            // smallest tid with unread or carried reads; -1 at the end
+    virtual int64_t next_pos(int tid) = 0;                 // first unread position on tid (INT64_MAX if none)
+    virtual bool has_carry() const = 0;
+    virtual int64_t carry_next_covered(int64_t cursor) const = 0;
+    virtual int64_t carry_max_end() const = 0;
+    // consume the records of `tid` starting before ce_target (the read cap may cut the window short) and stage them,
+    // carried reads first, relative to cb; returns the actual window end
+    virtual int64_t fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged) = 0;
+    virtual bool staged_has_span(size_t f, size_t i) const = 0;      // reference span > 0 of the i-th staged read of file f
+    virtual void drop(size_t f, const std::vector<char> &dropped) = 0;
+    virtual void retire(int64_t ce) = 0;
+    virtual void drop_tid_carry() = 0;
+    virtual int error() const = 0;
+    virtual const char *error_text() const = 0;
+};
+
+class Pump : public WindowSource {
 public:
     Pump(std::vector<std::unique_ptr<AlnReader>> &readers, const PumpConfig &cfg);
     // smallest tid that still has unread records (or carried reads); -1 when everything is consumed
-    int next_tid();
+    int next_tid() override;
     // position of the first unread record on `tid` over all files (INT64_MAX if none)
-    int64_t next_pos(int tid);
-    bool has_carry() const;
+    int64_t next_pos(int tid) override;
+    bool has_carry() const override;
     // first column >= cursor that a carried read can touch (INT64_MAX if none)
-    int64_t carry_next_covered(int64_t cursor) const;
-    int64_t carry_max_end() const;
+    int64_t carry_next_covered(int64_t cursor) const override;
+    int64_t carry_max_end() const override;
     // Consume records of `tid` starting before `ce_target` (possibly fewer: the read cap may cut the
     // window short) and return the actual window end.  reads[f] = carried + new records of file f.
     int64_t fill(int tid, int64_t cb, int64_t ce_target, std::vector<std::vector<const Rec *>> &reads);
     // After the window [cb, ce) was processed: keep only reads that extend beyond ce.
-    void retire(int64_t ce);
+    int64_t fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged) override;
+    bool staged_has_span(size_t f, size_t i) const override { return f < last_.size() && i < last_[f].size() && last_[f][i]->rlen > 0; }
+    void retire(int64_t ce) override;
     // before retire(): reads of file f (indexed as fill() returned them) that the -d cap dropped in this window leave the
     // iterator for good, exactly as bam_plp_push never stored them
-    void drop(size_t f, const std::vector<char> &dropped);
-    void drop_tid_carry();             // forget carried reads when leaving a contig
-    int error() const { return err_; }   // <0 after a decode error or unsorted input
-    const char *error_text() const { return errtxt_.c_str(); }
+    void drop(size_t f, const std::vector<char> &dropped) override;
+    void drop_tid_carry() override;    // forget carried reads when leaving a contig
+    int error() const override { return err_; }   // <0 after a decode error or unsorted input
+    const char *error_text() const override { return errtxt_.c_str(); }
 private:
     std::vector<std::unique_ptr<AlnReader>> &rd_;
     PumpConfig cfg_;
@@ -58,6 +85,7 @@ private:
     std::vector<std::deque<Rec>> carry_;
     std::vector<int64_t> last_pos_; std::vector<int> last_tid_;
     int err_ = 0; std::string errtxt_;
+    std::vector<std::vector<const Rec *>> last_;      // reads of the window fill_staged() staged last
     void advance(size_t f);
     int64_t span_end(const Rec &r) const { return cfg_.use_endpos ? r.endpos() : r.end(); }
 };

@@ -4,6 +4,9 @@
 #include "host_io.h"
 #include "host_pump.h"
 #include "host_stage.h"
+#include "host_chunk.h"
+#include "host_bgzf.h"
+#include <cstdlib>
 #include <climits>
 
 using namespace sta;
@@ -37,28 +40,57 @@ extern "C" int sta_io_scan(const char *path, int threads, int stage, uint64_t *n
         while ((st = readers[0]->next(r)) > 0) { fold(f, r); ++n; }
         if (st < 0) return -2;
     } else {
-        // what driver_mpileup does between the reader and sta_stage_window, minus the device
+        // what driver_mpileup does between the reader and sta_stage_window, minus the device: stage 1 = one decoded record
+        // at a time (Pump), stage 2 = chunk slices (ChunkPump); both must stage byte-identical windows.  The overlap
+        // lookahead and mate keeping of the mpileup driver are switched on so that they are part of the comparison.
         PumpConfig pc; pc.window_cols = 1 << 20;
-        Pump pump(readers, pc);
-        std::vector<std::vector<const Rec *>> reads;
-        StagedFile sf;
+        if (const char *e = getenv("STA_WINDOW_COLS")) pc.window_cols = std::max<long long>(1, atoll(e));
+        if (const char *e = getenv("STA_WINDOW_READS")) pc.max_reads = std::max<long long>(1, atoll(e));
+        pc.keep_mates = true;
+        pc.surely_pushed = [](const Rec &r) { return !(r.flag & 0x704) && r.mapq >= 1; };
+        std::unique_ptr<WindowSource> src;
+        if (stage == 2) src.reset(new ChunkPump(readers, pc, threads > 0 ? threads : io_default_threads()));
+        else src.reset(new Pump(readers, pc));
+        WindowSource &pump = *src;
+        std::vector<StagedFile> staged;
         for (;;) {
             int tid = pump.next_tid();
             if (pump.error() || tid < 0) break;
             int64_t cursor = pump.next_pos(tid);
             for (;;) {
                 if (pump.next_pos(tid) == INT64_MAX && !pump.has_carry()) break;
-                if (!pump.has_carry()) cursor = std::max(cursor, pump.next_pos(tid));
-                int64_t ce = pump.fill(tid, cursor, cursor + pc.window_cols, reads);
+                cursor = std::max(cursor, std::min(pump.carry_next_covered(cursor), pump.next_pos(tid)));
+                int64_t ce = pump.fill_staged(tid, cursor, cursor + pc.window_cols, staged);
                 if (pump.error()) break;
-                sf.clear();
-                for (const Rec *r : reads[0]) { if (r->pos >= cursor) ++n; sf.add(*r, cursor, nullptr, nullptr); }
-                sf.finish();
-                f.u64((uint64_t)sf.n()); f.bytes(sf.pos.data(), sf.pos.size() * 4); f.bytes(sf.cigar.data(), sf.cigar.size() * 4);
-                f.bytes(sf.qual.data(), sf.qual.size()); f.bytes(sf.seq.data(), sf.seq.size()); f.bytes(sf.names.data(), sf.names.size());
+                if (pump.next_pos(tid) == INT64_MAX) {
+                    int64_t me = pump.carry_max_end();
+                    if (me != INT64_MIN) ce = std::min(ce, std::max(me, cursor));
+                }
+                const StagedFile &sf = staged[0];
+                for (size_t i = 0; i < sf.pos.size(); ++i) if (sf.pos[i] >= 0 && !(sf.aux[i] & STA_AUX_ACCEPTED)) ++n;
+                static const bool nosum = getenv("STA_SCAN_NOSUM") != nullptr;     // timing runs: skip the (byte-serial) checksum
+                f.u64((uint64_t)tid); f.u64((uint64_t)cursor); f.u64((uint64_t)ce); f.u64((uint64_t)sf.n());
+                if (!nosum) {
+                f.bytes(sf.pos.data(), sf.pos.size() * 4); f.bytes(sf.flag.data(), sf.flag.size() * 2); f.bytes(sf.mapq.data(), sf.mapq.size());
+                f.bytes(sf.aux.data(), sf.aux.size()); f.bytes(sf.l_qseq.data(), sf.l_qseq.size() * 4); f.bytes(sf.mtid.data(), sf.mtid.size() * 4);
+                f.bytes(sf.mpos.data(), sf.mpos.size() * 8); f.bytes(sf.isize.data(), sf.isize.size() * 4);
+                f.bytes(sf.cig_off.data(), sf.cig_off.size() * 4); f.bytes(sf.base_off8.data(), sf.base_off8.size() * 4); f.bytes(sf.name_off.data(), sf.name_off.size() * 4);
+                f.bytes(sf.cigar.data(), sf.cigar.size() * 4); f.bytes(sf.qual.data(), sf.qual.size()); f.bytes(sf.seq.data(), sf.seq.size());
+                f.bytes(sf.names.data(), sf.names.size()); f.u64(sf.any_bq); if (sf.any_bq) f.bytes(sf.bq.data(), sf.bq.size());
+                uint64_t spans = 0;
+                for (size_t i = 0; i < sf.pos.size(); ++i) spans = spans * 3 + (pump.staged_has_span(0, i) ? 1 : 0);
+                f.u64(spans);
+                }
+                // pretend the depth cap removed every 97th read with a span, so that drop() is part of the comparison
+                if (getenv("STA_SCAN_DROP")) {
+                    std::vector<char> dr(sf.pos.size(), 0);
+                    for (size_t i = 0; i < dr.size(); ++i) dr[i] = (i % 97 == 96) && !(sf.aux[i] & STA_AUX_ACCEPTED) && pump.staged_has_span(0, i);
+                    pump.drop(0, dr);
+                }
                 pump.retire(ce);
-                cursor = ce;
+                cursor = std::max(cursor, ce);
             }
+            if (pump.error()) break;
             pump.drop_tid_carry();
         }
         if (pump.error()) return -2;

@@ -1,5 +1,6 @@
 // host_stage.cpp -- see host_stage.h
 #include "host_stage.h"
+#include "host_chunk.h"
 #include <cstring>
 #include <climits>
 
@@ -61,6 +62,41 @@ void StagedFile::add(const Rec &r, int64_t origin, const std::set<std::string> *
     name_off.push_back((uint32_t)names.size());
     names.insert(names.end(), r.qname.begin(), r.qname.end());
     names.push_back('\0');
+}
+
+void StagedFile::add_range(const Chunk &c, int64_t i0, int64_t i1, int64_t origin)
+{
+    if (i1 <= i0) return;
+    const size_t a = (size_t)i0, b = (size_t)i1, m = b - a, n0 = pos.size();
+    pos.resize(n0 + m); isize.resize(n0 + m);
+    for (size_t k = 0; k < m; ++k) pos[n0 + k] = (int32_t)(c.pos[a + k] - origin);
+    for (size_t k = 0; k < m; ++k) {
+        int64_t is = c.isize[a + k];
+        isize[n0 + k] = (int32_t)(is > INT32_MAX ? INT32_MAX : is < -INT32_MAX ? -INT32_MAX : is);
+    }
+    flag.insert(flag.end(), c.flag.begin() + i0, c.flag.begin() + i1);
+    mapq.insert(mapq.end(), c.mapq.begin() + i0, c.mapq.begin() + i1);
+    aux.insert(aux.end(), c.aux.begin() + i0, c.aux.begin() + i1);
+    l_qseq.insert(l_qseq.end(), c.l_qseq.begin() + i0, c.l_qseq.begin() + i1);
+    mtid.insert(mtid.end(), c.mtid.begin() + i0, c.mtid.begin() + i1);
+    mpos.insert(mpos.end(), c.mpos.begin() + i0, c.mpos.begin() + i1);
+    // pools: the slice [first offset of i0, first offset of i1) of every pool, then offsets shifted by (new base - old base)
+    const uint32_t cg0 = c.cig_off[a], cg1 = c.cig_off[b], b0 = c.base_off8[a], b1 = c.base_off8[b], nm0 = c.name_off[a], nm1 = c.name_off[b];
+    const uint32_t cg_base = (uint32_t)cigar.size(), q_base8 = (uint32_t)(qual.size() >> 3), nm_base = (uint32_t)names.size();
+    cigar.insert(cigar.end(), c.cigar.begin() + cg0, c.cigar.begin() + cg1);
+    qual.insert(qual.end(), c.qual.begin() + ((size_t)b0 << 3), c.qual.begin() + ((size_t)b1 << 3));
+    seq.insert(seq.end(), c.seq.begin() + ((size_t)b0 << 2), c.seq.begin() + ((size_t)b1 << 2));
+    if (c.has_bq_pool) {
+        bq.insert(bq.end(), c.bq.begin() + ((size_t)b0 << 3), c.bq.begin() + ((size_t)b1 << 3));
+        if (!any_bq) for (size_t k = a; k < b; ++k) if (c.aux[k] & STA_AUX_HAS_BQ) { any_bq = true; break; }
+    } else bq.resize(qual.size(), 64);
+    names.insert(names.end(), c.names.begin() + nm0, c.names.begin() + nm1);
+    cig_off.resize(n0 + m); base_off8.resize(n0 + m); name_off.resize(n0 + m);
+    for (size_t k = 0; k < m; ++k) {
+        cig_off[n0 + k] = c.cig_off[a + k] - cg0 + cg_base;
+        base_off8[n0 + k] = c.base_off8[a + k] - b0 + q_base8;
+        name_off[n0 + k] = c.name_off[a + k] - nm0 + nm_base;
+    }
 }
 
 void StagedFile::finish()

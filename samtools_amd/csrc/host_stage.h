@@ -18,6 +18,8 @@ struct XcolSpec {
     int n_cols() const { return (rnext ? 1 : 0) + n_tags; }
 };
 
+struct Chunk;       // host_chunk.h
+
 struct StagedFile {
     // page-locked (host_pinned.h): sta_stage_window copies straight out of these
     pvector<int32_t> pos, l_qseq, mtid, isize;
@@ -32,6 +34,9 @@ struct StagedFile {
     void clear();
     // origin: absolute coordinate of relative 0; rg_excl: -G read groups to drop (may be null)
     void add(const Rec &r, int64_t origin, const std::set<std::string> *rg_excl, const XcolSpec *xs = nullptr);
+    // bulk form of add() for records [i0, i1) of a decoded chunk (no read-group list, no extra columns): pool slices are
+    // copied whole and the offsets rebased
+    void add_range(const Chunk &c, int64_t i0, int64_t i1, int64_t origin);
     void finish();                 // closes the offset arrays
     sta_reads view() const;        // pointers into this object (valid until the next add/clear)
     int64_t n() const { return (int64_t)pos.size(); }

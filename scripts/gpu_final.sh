@@ -17,3 +17,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_B -o $TAG -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --workload mpileup30_B > $R/gpurun_out/final/prof_B.log 2>&1
 cd $R
 TAG=$TAG bash scripts/gpu_pmc.sh mpileup30 > gpurun_out/final/pmc.log 2>&1; tail -8 gpurun_out/final/pmc.log
+timeout 300 python scripts/e2e_cli.py 2000000 > gpurun_out/final/e2e.log 2>&1; tail -4 gpurun_out/final/e2e.log

@@ -81,3 +81,66 @@ def test_damaged_and_truncated_bgzf_is_an_error_not_a_short_read(capi, files):
     # a missing EOF marker block alone is tolerated (samtools only warns)
     p = os.path.join(d, "noeof.bam"); open(p, "wb").write(raw[:-28])
     assert capi.io_scan(p, 4, False) == good
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+WINDOWS = [{}, {"STA_WINDOW_COLS": "900"}, {"STA_WINDOW_COLS": "211", "STA_SCAN_DROP": "1"}, {"STA_WINDOW_COLS": "5000", "STA_WINDOW_READS": "50"},
+           {"STA_WINDOW_COLS": "64", "STA_WINDOW_READS": "7", "STA_SCAN_DROP": "1"}]
+
+
+@pytest.mark.parametrize("which", ["synth", "rich"])
+def test_chunk_lane_stages_the_same_windows_as_the_record_lane(capi, files, which):
+    """host_chunk.h (records decoded on several threads into SoA chunks, windows = slice concatenations) against
+    host_pump.h (one decoded record at a time): every staged array of every window, the window bounds, which reads have a
+    reference span, with the mpileup driver's overlap lookahead / mate keeping switched on, tiny windows, read-cap cuts and
+    simulated -d drops."""
+    d, sam, rich = files
+    src = sam if which == "synth" else rich
+    bam = sam_to_bam(src, os.path.join(d, which + "_lane.bam"), level=1, block=3000)
+    for env in WINDOWS:
+        ref = _with_env(env, lambda: capi.io_scan(src, 2, 1))
+        for path, threads in ((src, 1), (src, 5), (bam, 3)):
+            got = _with_env(env, lambda: capi.io_scan(path, threads, 2))
+            assert got == ref, (env, os.path.basename(path), threads)
+    assert _with_env(WINDOWS[1], lambda: capi.io_scan(src, 2, 1)) != _with_env(WINDOWS[0], lambda: capi.io_scan(src, 2, 1))
+
+
+def test_chunk_lane_on_the_reference_fixture_bams(capi):
+    for sub in ("mpileup", "bedcov"):
+        for fn in sorted(os.listdir(os.path.join(GOLD, sub))):
+            if fn.endswith(".bam"):
+                p = os.path.join(GOLD, sub, fn)
+                for env in ({}, {"STA_WINDOW_COLS": "100"}):
+                    a = _with_env(env, lambda: capi.io_scan(p, 2, 1))
+                    b = _with_env(env, lambda: capi.io_scan(p, 4, 2))
+                    assert a == b, (fn, env)
+
+
+def test_chunk_lane_reports_unsorted_and_damaged_input(capi, files):
+    d, sam, _ = files
+    lines = open(sam).read().split("\n")
+    hdr = [l for l in lines if l.startswith("@")]
+    recs = [l for l in lines if l and not l.startswith("@")]
+    recs[10], recs[400] = recs[400], recs[10]
+    bad = os.path.join(d, "unsorted.sam")
+    open(bad, "w").write("\n".join(hdr + recs) + "\n")
+    for stage in (1, 2):
+        with pytest.raises(RuntimeError):
+            capi.io_scan(bad, 3, stage)
+    bam = sam_to_bam(sam, os.path.join(d, "dmg_lane.bam"), level=1, block=8192)
+    raw = bytearray(open(bam, "rb").read()); raw[len(raw) // 2] ^= 0x5a
+    p = os.path.join(d, "dmg_lane2.bam"); open(p, "wb").write(raw)
+    with pytest.raises(RuntimeError):
+        capi.io_scan(p, 3, 2)

@@ -12,6 +12,7 @@
 #include "host_chunk.h"
 #include "host_bgzf.h"
 #include <getopt.h>
+#include <ctime>
 #include <cstdio>
 #include <cstring>
 #include <cerrno>
@@ -60,7 +61,17 @@ struct Samples {
     }
 };
 
+// STA_DRIVER_TIMING=1: cumulative wall time per driver phase on stderr at exit (where an end-to-end run spends its time)
+struct PhaseClock {
+    const bool on = getenv("STA_DRIVER_TIMING") != nullptr;
+    double t[8] = { 0 }; const char *name[8] = { "fill+stage", "set_ref", "stage_window", "plan", "emit", "fetch", "fwrite", "retire" };
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+    struct Scope { PhaseClock &c; int k; double t0; Scope(PhaseClock &c_, int k_) : c(c_), k(k_), t0(c_.on ? now() : 0) {} ~Scope() { if (c.on) c.t[k] += now() - t0; } };
+    ~PhaseClock() { if (on) { fprintf(stderr, "[driver timing]"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.3f s", name[i], t[i]); fprintf(stderr, "\n"); } }
+};
+
 struct Runner {
+    PhaseClock clk;
     Conf &conf;
     sta_engine *eng = nullptr;
     std::vector<std::unique_ptr<AlnReader>> readers;
@@ -93,7 +104,7 @@ struct Runner {
     int run_window(int tid, int64_t cb, int64_t ce, WindowSource *pump, bool have_reads, int all_mode, bool write, uint64_t *n_data)
     {
         if (ce <= cb) { if (n_data) *n_data = 0; return 0; }
-        if (set_ref(tid) < 0) return -1;
+        { PhaseClock::Scope ps(clk, 1); if (set_ref(tid) < 0) return -1; }
         size_t nf = readers.size();
         std::vector<sta_reads> views(nf);
         if (!have_reads && no_reads.size() != nf) { no_reads.assign(nf, StagedFile()); for (auto &e : no_reads) e.finish(); }
@@ -106,11 +117,11 @@ struct Runner {
         static const int64_t none = 0;
         if (conf.bed) { w.has_bed = 1; w.n_bed = iv ? (int64_t)iv->beg.size() : 0; w.bed_beg = iv ? iv->beg.data() : &none; w.bed_end = iv ? iv->end.data() : &none; }
         if (has_reg) { w.has_reg = 1; w.reg_beg = beg0; w.reg_end = end0; }
-        if (sta_stage_window(eng, &w) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
+        { PhaseClock::Scope ps(clk, 2); if (sta_stage_window(eng, &w) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; } }
         sta_mplp_params p = conf.p;
         p.all = all_mode;
         sta_plan_info info;
-        if (sta_mpileup_plan(eng, &p, &info) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
+        { PhaseClock::Scope ps(clk, 3); if (sta_mpileup_plan(eng, &p, &info) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; } }
         if (n_data) *n_data = info.n_data_cols;
         cap_dropped.assign(nf, {});
         if (info.n_maxcnt_dropped && have_reads && pump) {
@@ -127,10 +138,10 @@ struct Runner {
             }
         }
         if (!write || info.out_bytes == 0) return 0;
-        if (sta_mpileup_emit(eng, nullptr, 0) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
-        text.resize((size_t)info.out_bytes);
-        if (sta_fetch_output(eng, text.data(), info.out_bytes) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
-        if (fwrite(text.data(), 1, text.size(), out) != text.size()) { fprintf(stderr, "Failed to write pileup data.\n"); return -1; }
+        { PhaseClock::Scope ps(clk, 4); if (sta_mpileup_emit(eng, nullptr, 0) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; } }
+        { PhaseClock::Scope ps(clk, 5); text.resize((size_t)info.out_bytes);
+          if (sta_fetch_output(eng, text.data(), info.out_bytes) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; } }
+        { PhaseClock::Scope ps(clk, 6); if (fwrite(text.data(), 1, text.size(), out) != text.size()) { fprintf(stderr, "Failed to write pileup data.\n"); return -1; } }
         return 0;
     }
 
@@ -167,7 +178,8 @@ struct Runner {
                 pump.drop_tid_carry();
                 break;
             }
-            int64_t ce = pump.fill_staged(tid, cursor, ce_target, staged);
+            int64_t ce;
+            { PhaseClock::Scope ps(clk, 0); ce = pump.fill_staged(tid, cursor, ce_target, staged); }
             if (pump.error()) return -1;
             if (pump.next_pos(tid) == INT64_MAX) {  // last reads of the contig: stop where they stop
                 int64_t me = pump.carry_max_end();
@@ -186,7 +198,7 @@ struct Runner {
             }
             for (size_t f = 0; f < cap_dropped.size(); ++f) if (!cap_dropped[f].empty()) pump.drop(f, cap_dropped[f]);
             cap_dropped.clear();
-            pump.retire(ce);
+            { PhaseClock::Scope ps(clk, 7); pump.retire(ce); }
             cursor = std::max(cursor, ce);
         }
         pump.drop_tid_carry();

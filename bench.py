@@ -7,7 +7,7 @@ scan -> pileup text, all through the C-ABI (include/samtools_amd.h).  At N > 1 e
 different window (reference positions shard into independent windows: weak scaling) and the
 per-window text is gathered on rank 0 with one RCCL gather inside the timed step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mpileup30|mpileup30_B|mpileup300|depth30]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mpileup30|mpileup30_B|mpileup300|depth30|glf30|calmd30]
 
 Launched by the driver for N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
 Prints ONE JSON line on rank 0.  The CPU oracle appears only in the cpu_baseline leg (rank 0, N=1).
@@ -31,6 +31,9 @@ WORKLOADS = {
     "mpileup30_B": ("mpileup", 30, 4 << 20, 4.3, ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
     "mpileup300": ("mpileup", 300, 1 << 19, 3.75, ["mpileup", "-f", "{fa}", "{sam}"]),
     "depth30": ("depth", 30, 8 << 20, 0.21, ["depth", "-a", "{sam}"]),
+    # rows widened into after the pileup path; single GPU, results stay on the device
+    "glf30": ("glf", 30, 4 << 20, 1.5 + 128.0 / 30.0, ["glf", "-f", "{fa}", "{sam}"]),
+    "calmd30": ("calmd", 30, 4 << 20, 4.0, ["calmd", "-r", "{sam}", "{fa}"]),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
@@ -114,7 +117,7 @@ def cpu_baseline(wl, sample_cols):
     return {"value": bases / dt / 1e6, "unit": "Mbases/s", "cores": 1, "kind": "port",
             "sample": "%s on %d synthetic reads (%d Mbases, %d columns, SAM text input, output to /dev/null), %.1f s wall, "
                       "oracle restatement (not the upstream binary: HTSlib is absent)" % (
-                          " ".join(argv[:-1]).replace("{fa}", "ref.fa"), rd["n"], bases // 1000000, sample_cols, dt)}
+                          " ".join(x for x in argv if x != "{sam}").replace("{fa}", "ref.fa"), rd["n"], bases // 1000000, sample_cols, dt)}
 
 
 def main():
@@ -151,17 +154,23 @@ def main():
         par.has_fai = 1
         if a.workload.endswith("_B"):
             par.flag &= ~sa.MPLP.REALN
-    else:
+    elif kind == "depth":
         par = sa.DepthParams.defaults()
         par.all_pos = 1
+    elif world > 1:
+        raise SystemExit("workload %s is a single-GPU measurement" % a.workload)
 
     def plan():
         eng.stage_window(w)
+        if kind == "glf":
+            return eng.glf_plan()
+        if kind == "calmd":
+            return eng.calmd_plan(flag=1)          # -r: BAQ (plain mode) + tag, then MD / NM
         return eng.mpileup_plan(par) if kind == "mpileup" else eng.depth_plan(par)
 
     info = plan()
     out_bytes = int(info.out_bytes)
-    piled = int(info.piled_bases)
+    piled = int(info.piled_bases) or int(rd["n"]) * 150      # (the calmd plan reports no pileup counters: every base is aligned)
     from samtools_amd import shard
     sizes = recv = None
     cap = out_bytes + 4096
@@ -188,7 +197,7 @@ def main():
         plan()
         if kind == "mpileup":
             eng.mpileup_emit(out_bufs[i].data_ptr(), cap)
-        else:
+        elif kind == "depth":
             eng.depth_emit(out_bufs[i].data_ptr(), cap)
         if dist is not None:
             # the single collective of the path: per-window column text -> rank 0 over RCCL/xGMI (samtools_amd/shard.py)
@@ -233,8 +242,9 @@ def main():
 
     if rank == 0:
         # correctness spot check of what was just timed: line count and final newline
-        head = bytes(out_t[:min(out_bytes, 1 << 16)].cpu().numpy().tobytes())
-        assert out_bytes == 0 or head.count(b"\n") > 0
+        if kind in ("mpileup", "depth"):
+            head = bytes(out_t[:min(out_bytes, 1 << 16)].cpu().numpy().tobytes())
+            assert out_bytes == 0 or head.count(b"\n") > 0
         value = piled_all * a.steps / dt_all / 1e6
         # dominant kernel by accumulated HIP-event time (rank 0)
         def roof(name):
@@ -273,16 +283,16 @@ def main():
             "metric": "Mbases piled/s (mpileup, 30x 150bp)" if a.workload.startswith("mpileup30") else "Mbases piled/s (%s)" % a.workload,
             "value": value, "unit": "Mbases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt_all / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8/f64" if (kind == "mpileup" and not a.workload.endswith("_B")) else "u8",
+            "vs_baseline": None, "dtype": "u8/f64" if ((kind == "mpileup" and not a.workload.endswith("_B")) or kind in ("glf", "calmd")) else "u8",
             "data": "synthetic",
-            "config": {"workload": a.workload, "command": " ".join(WORKLOADS[a.workload][4][:-1]).replace("{fa}", "ref.fa"),
+            "config": {"workload": a.workload, "command": " ".join(x for x in WORKLOADS[a.workload][4] if x != "{sam}").replace("{fa}", "ref.fa"),
                        "read_len": 150, "depth": depth, "window_cols_per_gpu": n_cols, "reads_per_gpu": int(rd["n"]),
                        "piled_bases_per_gpu_step": piled, "out_bytes_per_gpu_step": out_bytes,
                        "staged_in_bytes_per_gpu": in_bytes, "parallelism": "window-sharded x%d, 1 RCCL gather" % world},
             "roofline": roof(dom_name) if dom_name else None,
             "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
         }
-        emit_name = "mplp_emit" if kind == "mpileup" else "depth_emit"
+        emit_name = {"mpileup": "mplp_emit", "depth": "depth_emit", "glf": "glf_cols", "calmd": "md_emit"}[kind]
         if emit_name in prof and emit_name != dom_name:
             res["roofline_pileup"] = roof(emit_name)
         # whole-step algorithmic rate (every kernel of the step, SURVEY.md 8d bytes): the number to compare with 8 TB/s end to end

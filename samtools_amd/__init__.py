@@ -11,6 +11,9 @@ from ._capi import (  # noqa: F401
     KernelTime,
     MplpParams,
     DepthParams,
+    GlfParams,
+    GlfCol,
+    CalmdParams,
     PlanInfo,
     Reads,
     Window,
@@ -24,6 +27,6 @@ from ._capi import (  # noqa: F401
 )
 
 __all__ = [
-    "Engine", "EngineError", "KernelTime", "MplpParams", "DepthParams", "PlanInfo", "Reads", "Window",
+    "Engine", "EngineError", "KernelTime", "MplpParams", "DepthParams", "GlfParams", "GlfCol", "CalmdParams", "PlanInfo", "Reads", "Window",
     "device_count", "lib", "main_depth", "main_mpileup", "version", "MPLP", "EXPORTED_SYMBOLS",
 ]

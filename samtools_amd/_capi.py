@@ -244,6 +244,18 @@ class Engine:
     def depth_emit(self, dev_ptr=None, capacity=0):
         self._chk(lib.sta_depth_emit(self._h, _P(dev_ptr or 0), capacity), "sta_depth_emit")
 
+    def glf_plan(self, min_baseQ=13, max_depth=8000, theta=0.83):
+        """bcf_call_glfgen over every column of the staged window; results via fetch_output (GlfCol[col][file])."""
+        info, p = PlanInfo(), GlfParams(min_baseQ, max_depth, theta)
+        self._chk(lib.sta_glf_plan(self._h, C.byref(p), C.byref(info)), "sta_glf_plan")
+        return info
+
+    def calmd_plan(self, flag=0, max_nm=0):
+        """calmd's MD / NM / BAQ-tag arithmetic on file 0 of the staged window; info.out_bytes = MD text bytes."""
+        info, p = PlanInfo(), CalmdParams(flag, max_nm)
+        self._chk(lib.sta_calmd_plan(self._h, C.byref(p), C.byref(info)), "sta_calmd_plan")
+        return info
+
     def depth_counts_ptr(self):
         return lib.sta_depth_counts_dev(self._h)
 

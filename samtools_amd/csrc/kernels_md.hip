@@ -13,26 +13,30 @@
 
 struct MdPar { int32_t use_equal, bin_qual, max_nm, apply; };
 
+// one wave per 64 consecutive records, the lanes stride over the bases of one record at a time (coalesced byte streams)
 __global__ void __launch_bounds__(256) k_calmd_tag(StaReadsDev R, MdPar P, uint8_t *tag_pool, uint8_t *state)
 {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R.n) return;
-    const uint32_t info = R.info[r], aux = R.aux[r];
-    uint8_t st = 0;
-    if (info & RI_BAQ) {
-        st |= 2;
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(int64_t)63;
+    for (int j = 0; j < 64; ++j) {
+        const int64_t r = r0 + j;
+        if (r >= R.n) break;
+        const uint32_t info = R.info[r], aux = R.aux[r];
         const uint64_t boff = (uint64_t)R.base_off8[r] << 3;
         const int lq = R.l_qseq[r];
-        for (int i = 0; i < lq; ++i) {
-            const uint8_t q0 = R.qual_in[boff + i], q1 = R.qual[boff + i];
-            tag_pool[boff + i] = (uint8_t)(64 + (q0 - q1));
-            if (!P.apply) R.qual[boff + i] = q0;
+        uint8_t st = 0;
+        if (info & RI_BAQ) {
+            st |= 2;
+            for (int i = lane; i < lq; i += 64) {
+                const uint8_t q0 = R.qual_in[boff + i], q1 = R.qual[boff + i];
+                tag_pool[boff + i] = (uint8_t)(64 + (q0 - q1));
+                if (!P.apply) R.qual[boff + i] = q0;
+            }
+        } else if (P.apply && (aux & STA_AUX_HAS_BQ) && R.bq && !(R.flag[r] & BAM_FUNMAP) && lq > 0 && R.qual_in[boff] != 0xff) {
+            st |= 4;                   // an existing BQ:Z was applied by k_qual_prep (realn.c renames it ZQ:Z)
         }
-    } else if (P.apply && (aux & STA_AUX_HAS_BQ) && R.bq && !(R.flag[r] & BAM_FUNMAP) && R.l_qseq[r] > 0
-               && R.qual_in[(uint64_t)R.base_off8[r] << 3] != 0xff) {
-        st |= 4;                   // an existing BQ:Z was applied by k_qual_prep (realn.c renames it ZQ:Z)
+        if (lane == 0) state[r] = st;
     }
-    state[r] = st;
 }
 
 // shared walk of bam_md.c:89-124; EMIT = write the string, otherwise only measure

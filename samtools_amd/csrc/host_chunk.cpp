@@ -128,7 +128,7 @@ std::shared_ptr<Chunk> ChunkReader::next()
             return c;
         }
         if (io_end_.load() && next_out_ >= next_in_) { const int st = io_status_.load(); status_ = st < 0 ? st : 0; return nullptr; }
-        cv_out_.wait_for(lk, std::chrono::milliseconds(50));
+        cv_out_.wait(lk);
     }
 }
 

@@ -319,6 +319,7 @@ int sta_main_calmd(int argc, char **argv);
 /* ---- host input plumbing (needs no device) ----
  * The drivers' SAM / BAM reader (stands where sam_open / sam_read1 stand for bam_plcmd.c:500-569): BGZF blocks are inflated
  * by `threads` workers and records are parsed one batch ahead of the consumer.  sta_io_scan decodes a whole file through it
+ * (`path` may hold several paths separated by '\n': the drivers' multi-file windows)
  * and returns the record count and an order-dependent checksum over every decoded field (threads <= 0: the drivers'
  * default, $STA_IO_THREADS or 4; 1 worker is still a separate thread).  stage != 0 additionally pushes the records through
  * the drivers' window pump and SoA stager (what runs between the reader and sta_stage_window) and checksums every staged

@@ -185,6 +185,8 @@ def io_scan(path, threads=0, stage=False):
     """(records, checksum) of a SAM/BAM file decoded by the drivers' reader; needs no device.
     stage: False/0 = records only, True/1 = + window pump and stager (record lane), 2 = chunk lane."""
     n, h = C.c_uint64(0), C.c_uint64(0)
+    if isinstance(path, (list, tuple)):
+        path = "\n".join(path)          # several inputs = the drivers' multi-file windows
     rc = lib.sta_io_scan(os.fsencode(path), int(threads), int(stage), C.byref(n), C.byref(h))
     if rc != 0:
         raise RuntimeError("sta_io_scan(%s) failed: %d" % (path, rc))

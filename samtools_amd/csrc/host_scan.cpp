@@ -32,13 +32,25 @@ extern "C" int sta_io_scan(const char *path, int threads, int stage, uint64_t *n
     if (!path) return -1;
     std::string err;
     std::vector<std::unique_ptr<AlnReader>> readers;
-    readers.push_back(AlnReader::open(path, &err, threads));
-    if (!readers[0]) return -1;
+    {
+        // several inputs (the drivers' multi-file windows): paths separated by '\n'
+        std::string all(path);
+        size_t a = 0;
+        while (a <= all.size()) {
+            size_t b = all.find('\n', a);
+            if (b == std::string::npos) b = all.size();
+            if (b > a) { readers.push_back(AlnReader::open(all.substr(a, b - a), &err, threads)); if (!readers.back()) return -1; }
+            a = b + 1;
+        }
+        if (readers.empty()) return -1;
+    }
     Fnv f; uint64_t n = 0;
     if (!stage) {
-        Rec r; int st;
-        while ((st = readers[0]->next(r)) > 0) { fold(f, r); ++n; }
-        if (st < 0) return -2;
+        for (auto &rd : readers) {
+            Rec r; int st;
+            while ((st = rd->next(r)) > 0) { fold(f, r); ++n; }
+            if (st < 0) return -2;
+        }
     } else {
         // what driver_mpileup does between the reader and sta_stage_window, minus the device: stage 1 = one decoded record
         // at a time (Pump), stage 2 = chunk slices (ChunkPump); both must stage byte-identical windows.  The overlap
@@ -66,27 +78,31 @@ extern "C" int sta_io_scan(const char *path, int threads, int stage, uint64_t *n
                     int64_t me = pump.carry_max_end();
                     if (me != INT64_MIN) ce = std::min(ce, std::max(me, cursor));
                 }
-                const StagedFile &sf = staged[0];
-                for (size_t i = 0; i < sf.pos.size(); ++i) if (sf.pos[i] >= 0 && !(sf.aux[i] & STA_AUX_ACCEPTED)) ++n;
                 static const bool nosum = getenv("STA_SCAN_NOSUM") != nullptr;     // timing runs: skip the (byte-serial) checksum
-                f.u64((uint64_t)tid); f.u64((uint64_t)cursor); f.u64((uint64_t)ce); f.u64((uint64_t)sf.n());
-                if (!nosum) {
-                f.bytes(sf.pos.data(), sf.pos.size() * 4); f.bytes(sf.flag.data(), sf.flag.size() * 2); f.bytes(sf.mapq.data(), sf.mapq.size());
-                f.bytes(sf.aux.data(), sf.aux.size()); f.bytes(sf.l_qseq.data(), sf.l_qseq.size() * 4); f.bytes(sf.mtid.data(), sf.mtid.size() * 4);
-                f.bytes(sf.mpos.data(), sf.mpos.size() * 8); f.bytes(sf.isize.data(), sf.isize.size() * 4);
-                f.bytes(sf.cig_off.data(), sf.cig_off.size() * 4); f.bytes(sf.base_off8.data(), sf.base_off8.size() * 4); f.bytes(sf.name_off.data(), sf.name_off.size() * 4);
-                f.bytes(sf.cigar.data(), sf.cigar.size() * 4); f.bytes(sf.qual.data(), sf.qual.size()); f.bytes(sf.seq.data(), sf.seq.size());
-                f.bytes(sf.names.data(), sf.names.size()); f.u64(sf.any_bq); if (sf.any_bq) f.bytes(sf.bq.data(), sf.bq.size());
-                uint64_t spans = 0;
-                for (size_t i = 0; i < sf.pos.size(); ++i) spans = spans * 3 + (pump.staged_has_span(0, i) ? 1 : 0);
-                f.u64(spans);
+                f.u64((uint64_t)tid); f.u64((uint64_t)cursor); f.u64((uint64_t)ce);
+                for (size_t fi = 0; fi < staged.size(); ++fi) {
+                    const StagedFile &sf = staged[fi];
+                    for (size_t i = 0; i < sf.pos.size(); ++i) if (sf.pos[i] >= 0 && !(sf.aux[i] & STA_AUX_ACCEPTED)) ++n;
+                    f.u64((uint64_t)sf.n());
+                    if (nosum) continue;
+                    f.bytes(sf.pos.data(), sf.pos.size() * 4); f.bytes(sf.flag.data(), sf.flag.size() * 2); f.bytes(sf.mapq.data(), sf.mapq.size());
+                    f.bytes(sf.aux.data(), sf.aux.size()); f.bytes(sf.l_qseq.data(), sf.l_qseq.size() * 4); f.bytes(sf.mtid.data(), sf.mtid.size() * 4);
+                    f.bytes(sf.mpos.data(), sf.mpos.size() * 8); f.bytes(sf.isize.data(), sf.isize.size() * 4);
+                    f.bytes(sf.cig_off.data(), sf.cig_off.size() * 4); f.bytes(sf.base_off8.data(), sf.base_off8.size() * 4); f.bytes(sf.name_off.data(), sf.name_off.size() * 4);
+                    f.bytes(sf.cigar.data(), sf.cigar.size() * 4); f.bytes(sf.qual.data(), sf.qual.size()); f.bytes(sf.seq.data(), sf.seq.size());
+                    f.bytes(sf.names.data(), sf.names.size()); f.u64(sf.any_bq); if (sf.any_bq) f.bytes(sf.bq.data(), sf.bq.size());
+                    uint64_t spans = 0;
+                    for (size_t i = 0; i < sf.pos.size(); ++i) spans = spans * 3 + (pump.staged_has_span(fi, i) ? 1 : 0);
+                    f.u64(spans);
                 }
                 // pretend the depth cap removed every 97th read with a span, so that drop() is part of the comparison
-                if (getenv("STA_SCAN_DROP")) {
-                    std::vector<char> dr(sf.pos.size(), 0);
-                    for (size_t i = 0; i < dr.size(); ++i) dr[i] = (i % 97 == 96) && !(sf.aux[i] & STA_AUX_ACCEPTED) && pump.staged_has_span(0, i);
-                    pump.drop(0, dr);
-                }
+                if (getenv("STA_SCAN_DROP"))
+                    for (size_t fi = 0; fi < staged.size(); ++fi) {
+                        const StagedFile &sf = staged[fi];
+                        std::vector<char> dr(sf.pos.size(), 0);
+                        for (size_t i = 0; i < dr.size(); ++i) dr[i] = (i % 97 == 96) && !(sf.aux[i] & STA_AUX_ACCEPTED) && pump.staged_has_span(fi, i);
+                        pump.drop(fi, dr);
+                    }
                 pump.retire(ce);
                 cursor = std::max(cursor, ce);
             }

@@ -144,3 +144,16 @@ def test_chunk_lane_reports_unsorted_and_damaged_input(capi, files):
     p = os.path.join(d, "dmg_lane2.bam"); open(p, "wb").write(raw)
     with pytest.raises(RuntimeError):
         capi.io_scan(p, 3, 2)
+
+
+def test_chunk_lane_with_several_input_files(capi, files, tmp_path):
+    """Multi-file windows (bam_mplp_* style: every window receives the reads of every file; the read cap of file 0 cuts the
+    window for all of them): both lanes, mixed SAM / BAM inputs."""
+    d, sam, rich = files
+    other, _ = write_synth_sam(str(tmp_path), n_ref=60000, depth=12, read_len=100, seed=12, paired=True)
+    bam = sam_to_bam(other, os.path.join(d, "other.bam"), level=1, block=4000)
+    for env in WINDOWS:
+        ref = _with_env(env, lambda: capi.io_scan([sam, other, sam], 2, 1))
+        assert _with_env(env, lambda: capi.io_scan([sam, bam, sam], 4, 2)) == ref, env
+        assert _with_env(env, lambda: capi.io_scan([sam, other, sam], 1, 2)) == ref, env
+    assert capi.io_scan([sam, other], 2, 1) != capi.io_scan([other, sam], 2, 1)

@@ -34,7 +34,13 @@ def windows_of_rank(windows: Sequence[Tuple[int, int, int]], rank: int, world: i
 
 def halo_columns(max_ref_span: int) -> int:
     """Reads starting up to this many columns before a window can still touch it or rewrite (through
-    mate-overlap resolution) the qualities of a read that does: 2 x the longest reference span."""
+    mate-overlap resolution) the qualities of a read that does: 2 x the longest reference span.
+
+    Two refinements found with long ref skips (host_pump.h): a shard must also receive (i) the earlier
+    mate of every read that is live in it, even when that mate ends before the shard starts (HTSlib may rewrite bases of
+    the later mate beyond the earlier mate's end), and (ii) the records after its last column up to the first one that is
+    certainly pushed (it releases the shard's last columns and may be an overlap mate).  The drivers' pumps implement both;
+    a region-restricted reader per rank must widen its query accordingly."""
     return 2 * int(max_ref_span)
 
 

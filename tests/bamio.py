@@ -94,3 +94,29 @@ def sam_to_bam(sam_path, bam_path, level=1, block=0xff00):
             fo.write(_bgzf_block(raw[o:o + block], level))
         fo.write(_EOF)
     return bam_path
+
+
+def bam_filter(src, dst, require=0, exclude=0, level=1):
+    """`samtools view -b -f require -F exclude` for tests: copies the header and the records whose FLAG passes."""
+    import gzip
+    raw = gzip.open(src).read()
+    l_text = struct.unpack("<i", raw[4:8])[0]
+    o = 8 + l_text
+    n_ref = struct.unpack("<i", raw[o:o + 4])[0]
+    o += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack("<i", raw[o:o + 4])[0]
+        o += 4 + l_name + 4
+    out = [raw[:o]]
+    while o < len(raw):
+        bs = struct.unpack("<i", raw[o:o + 4])[0]
+        flag = struct.unpack("<H", raw[o + 4 + 14:o + 4 + 16])[0]
+        if (flag & require) == require and not (flag & exclude):
+            out.append(raw[o:o + 4 + bs])
+        o += 4 + bs
+    data = b"".join(out)
+    with open(dst, "wb") as fo:
+        for k in range(0, len(data), 0xff00):
+            fo.write(_bgzf_block(data[k:k + 0xff00], level))
+        fo.write(_EOF)
+    return dst

@@ -157,3 +157,21 @@ def test_chunk_lane_with_several_input_files(capi, files, tmp_path):
         assert _with_env(env, lambda: capi.io_scan([sam, bam, sam], 4, 2)) == ref, env
         assert _with_env(env, lambda: capi.io_scan([sam, other, sam], 1, 2)) == ref, env
     assert capi.io_scan([sam, other], 2, 1) != capi.io_scan([other, sam], 2, 1)
+
+
+def test_both_lanes_read_standard_input(files):
+    """`-` = stdin (what `samtools view ... | samtools mpileup -` relies on, mpileup.reg:102-105): goes through gzread on the
+    caller's thread; records and staged windows must equal those of the file."""
+    import subprocess
+    import sys
+    d, sam, _ = files
+    bam = sam_to_bam(sam, os.path.join(d, "stdin.bam"), level=1, block=6000)
+    code = ("import sys; sys.path.insert(0, %r); from samtools_amd import _capi; "
+            "print(_capi.io_scan('-', 3, int(sys.argv[1])))" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from samtools_amd import _capi
+    for stage in (0, 1, 2):
+        want = str(_capi.io_scan(sam, 3, stage))
+        for path in (sam, bam):
+            with open(path, "rb") as fh:
+                got = subprocess.run([sys.executable, "-c", code, str(stage)], stdin=fh, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+            assert got.stdout.decode().strip() == want, (stage, os.path.basename(path))

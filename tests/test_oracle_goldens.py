@@ -84,3 +84,18 @@ def test_oracle_calmd_recomputes_the_md_and_nm_tags_the_reference_inputs_carry(o
             assert int(got[5]) == int(tags["NM"]), rec[0]
             checked += 1
     assert checked >= 230
+
+
+@pytest.mark.parametrize("exp,require,exclude", [("44.out", 16, 0), ("46.out", 0, 16)])
+def test_oracle_reads_a_filtered_bam_from_stdin(oracle_bin, tmp_path, exp, require, exclude):
+    """mpileup.reg:102,104 (43.out, 45.out): `samtools view -h -f 16 | samtools mpileup -x -`.  The expected files are byte
+    for byte 44.out / 46.out; `view` is emulated by tests/bamio.py (flag filter on the BAM records), the pipe is real."""
+    import gzip
+    import subprocess
+    from bamio import bam_filter
+    gold = os.path.join(os.path.dirname(__file__), "golden", "mpileup")
+    src = bam_filter(os.path.join(gold, "mpileup.1.bam"), str(tmp_path / "f.bam"), require, exclude)
+    want = gzip.open(os.path.join(gold, "expected", exp + ".gz")).read()
+    with open(src, "rb") as fh:
+        out = subprocess.run([oracle_bin, "mpileup", "-x", "-"], stdin=fh, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    assert out.stdout == want

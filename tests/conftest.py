@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The C-ABI library is built in-tree by __graft_entry__.build(); a fresh checkout that runs the tests first gets it built
+    here (hipcc cross-compiles gfx950 without a GPU).  Nothing is built when the artefacts are already there."""
+    lib = os.path.join(REPO, "samtools_amd", "lib", "libsamtools_amd.so")
+    exe = os.path.join(REPO, "samtools_amd", "bin", "samtools-amd")
+    if os.path.exists(lib) and os.path.exists(exe):
+        return
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        return          # the tests that need the library will say so
+    subprocess.run(["make", "-j8", "-C", os.path.join(REPO, "samtools_amd", "csrc")], check=False, stdout=subprocess.DEVNULL)
+
+
 @pytest.fixture(scope="session")
 def oracle_bin():
     """CPU oracle (test infrastructure only); built on demand with gcc."""

@@ -119,7 +119,7 @@ struct DRunner {
         const char *lane = getenv("STA_IO_LANE");
         std::unique_ptr<WindowSource> src;
         if (lane && !strcmp(lane, "rec")) src.reset(new Pump(readers, pc));          // record-at-a-time lane
-        else src.reset(new ChunkPump(readers, pc, io_default_threads()));           // chunk slices decoded on several threads
+        else src.reset(new ChunkPump(readers, pc, io_threads_per_input((int)readers.size())));           // chunk slices decoded on several threads
         WindowSource &pump = *src;
         const int all = p.all_pos;
         // with a region every -a/-aa run prints the whole region of tid0 (bam2depth.c:267-270)
@@ -208,7 +208,7 @@ extern "C" int sta_main_depth(int argc, char **argv)
 
     for (auto &fn : fns) {
         std::string err;
-        auto r = AlnReader::open(fn, &err);
+        auto r = AlnReader::open(fn, &err, io_threads_per_input((int)fns.size()));
         if (!r) { fprintf(stderr, "samtools depth: Cannot open input file \"%s\": %s\n", fn.c_str(), strerror(errno ? errno : ENOENT)); return 1; }
         run.readers.push_back(std::move(r));
     }

@@ -233,7 +233,7 @@ struct Runner {
         const char *lane = getenv("STA_IO_LANE");
         const bool chunked = !pc.rg_excl && !pc.xs_rnext && !pc.xs_n_tags && !(lane && !strcmp(lane, "rec"));
         std::unique_ptr<WindowSource> src;
-        if (chunked) src.reset(new ChunkPump(readers, pc, io_default_threads()));
+        if (chunked) src.reset(new ChunkPump(readers, pc, io_threads_per_input((int)readers.size())));
         else src.reset(new Pump(readers, pc));
         WindowSource &pump = *src;
         const int all = conf.p.all;
@@ -402,7 +402,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     Samples sm;
     for (auto &fn : fns) {
         std::string err;
-        auto r = AlnReader::open(fn, &err);
+        auto r = AlnReader::open(fn, &err, io_threads_per_input((int)fns.size()));
         if (!r) { fprintf(stderr, "[mpileup] failed to open %s: %s\n", fn.c_str(), strerror(errno ? errno : ENOENT)); return 1; }
         sm.add(fn, ignore_rg ? nullptr : &r->header().text);
         if (!conf.tags.empty()) r->set_wanted_tags(conf.tags);

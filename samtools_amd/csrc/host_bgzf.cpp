@@ -18,6 +18,14 @@ int io_default_threads()
     return 4;
 }
 
+int io_threads_per_input(int n_inputs)
+{
+    const int t = io_default_threads();
+    if (n_inputs <= 2) return t;
+    const int share = (2 * t + n_inputs - 1) / n_inputs;
+    return share < 1 ? 1 : share;
+}
+
 namespace {
 
 // ---- zlib gzread on the caller's thread (plain text, ordinary gzip, stdin) ----

@@ -23,5 +23,8 @@ public:
 };
 
 int io_default_threads();
+// per-input worker count when a command reads n_inputs files at once: the default is shared out (at least 1 each), so that
+// a hundred-file mpileup does not start a thousand threads
+int io_threads_per_input(int n_inputs);
 
 }  // namespace sta

@@ -65,6 +65,7 @@ struct sta_engine {
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
     DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    int baq_slab_gib_cap = 0;       // 0 = default; 4 after a one-launch BAQ slab could not be allocated
     double glf_depcorr = -1.0;      // theta the coefficient block in glf_tab was computed for
     StaWinDev wd{};
     // plan state
@@ -382,12 +383,12 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             if (c.n_baq_fast || c.n_baq_bw8) {
                 // band-in-registers kernels: groups of 64 reads, one scratch slot (forward rows) per group in flight
                 int gpl = 0;
-                size_t need = sta_baq_band_scratch_bytes(d.n, (int)c.max_lq_fast, &gpl);
+                size_t need = sta_baq_band_scratch_bytes(d.n, (int)c.max_lq_fast, &gpl, e->baq_slab_gib_cap);
                 if (e->baq_scratch.ensure(need + 64)) {
-                    // not enough free HBM for the one-launch slab: fall back to a 4 GiB slab (more, smaller launches)
+                    // not enough free HBM for the one-launch slab: this engine falls back to a 4 GiB slab (more, smaller launches)
                     (void)hipGetLastError();
-                    setenv("STA_BAQ_SLAB_GIB", "4", 1);
-                    need = sta_baq_band_scratch_bytes(d.n, (int)c.max_lq_fast, &gpl);
+                    e->baq_slab_gib_cap = 4;
+                    need = sta_baq_band_scratch_bytes(d.n, (int)c.max_lq_fast, &gpl, e->baq_slab_gib_cap);
                     if (e->baq_scratch.ensure(need + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ scratch) failed");
                 }
                 // class 1 (band width 8, through the list: a few dozen groups, latency bound) runs on a side stream beside

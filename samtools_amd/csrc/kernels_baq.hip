@@ -919,7 +919,7 @@ static size_t baq_slot_dbl(int lq_cap, int bw)
     return (size_t)lq_cap * (2 * nb) * 64 + (size_t)(lq_cap + 2) * 64 + (size_t)(lq_cap + 1) / 2 * 64;
 }
 
-size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_launch)
+size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_launch, int slab_gib_cap)
 {
     int64_t ngroups = (n_reads + 63) / 64;
     // One launch per pass over ALL groups when the slab fits (no partially filled last round of waves);
@@ -930,6 +930,7 @@ size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_l
     size_t slab_gib = 48;
     const char *es = getenv("STA_BAQ_SLAB_GIB");
     if (es && atoi(es) > 0) slab_gib = (size_t)atoi(es);
+    if (slab_gib_cap > 0 && (size_t)slab_gib_cap < slab_gib) slab_gib = (size_t)slab_gib_cap;     // the engine's fallback after a failed allocation
     size_t slot = baq_slot_dbl(lq_cap, 8) * 8;
     if (baq_use_ck()) { size_t a = baq_ck_slot_dbl(lq_cap, 7, 4), b = baq_ck_slot_dbl(lq_cap, 8, 3); slot = (a > b ? a : b) * 8; }
     if ((size_t)gpl * slot > (slab_gib << 30)) {

@@ -116,7 +116,7 @@ void sta_launch_baq(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int
                     int lq_max, int bw_max, int64_t n_slow);
 // band-in-registers kernels (band width 7: reads taken directly; 8: through the list in `chain`)
 #define STA_BAQ7_LQ_MAX 2048
-size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_launch);
+size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_launch, int slab_gib_cap /* 0 = $STA_BAQ_SLAB_GIB or 48 */);
 void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw,
                          int64_t g0, int64_t ng, int use_list, int pass /*0 forward, 1 backward*/);
 

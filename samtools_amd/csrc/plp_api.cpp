@@ -15,6 +15,7 @@
 #include <cstring>
 #include <deque>
 #include <vector>
+#include <mutex>
 
 namespace {
 
@@ -128,8 +129,10 @@ struct Soa {
 const int64_t MAX_WINDOW_COLS = (int64_t)1 << 24;
 
 // Engines (HBM workspace, streams) are expensive to create; callers like bedcov create one iterator per BED interval,
-// so finished iterators park their engine here.  Single-threaded by contract, like the HTSlib iterator.
+// so finished iterators park their engine here.  An iterator is single-threaded by contract, like the HTSlib one;
+// different iterators may live on different threads, hence the lock around the pool.
 std::vector<sta_engine *> g_engine_pool;
+std::mutex g_engine_pool_m;                    // iterators may live on different threads
 enum { ST_OK = 0, ST_NEED_MORE = 1, ST_END = 2, ST_ERR = -1 };
 
 }  // namespace
@@ -268,7 +271,7 @@ int build_window(sta_bam_plp *it)
     it->have_win = true;
     if (ce <= cb) return ST_OK;
 
-    if (!it->eng && !g_engine_pool.empty()) { it->eng = g_engine_pool.back(); g_engine_pool.pop_back(); }
+    if (!it->eng) { std::lock_guard<std::mutex> g(g_engine_pool_m); if (!g_engine_pool.empty()) { it->eng = g_engine_pool.back(); g_engine_pool.pop_back(); } }
     if (!it->eng) {
         if (sta_engine_create(&it->eng, 0, nullptr) != STA_OK) {
             fprintf(stderr, "[E::bam_plp] no usable HIP device (the MI355X engine has no CPU fallback)\n");
@@ -416,6 +419,7 @@ void sta_bam_plp_destroy(sta_bam_plp_t it)
     clear_reads(it);
     free(it->tmp.data);
     if (it->eng) {
+        std::unique_lock<std::mutex> g(g_engine_pool_m);
         if (g_engine_pool.size() < 8) g_engine_pool.push_back(it->eng);
         else sta_engine_destroy(it->eng);
     }

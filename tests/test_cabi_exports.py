@@ -55,3 +55,56 @@ def test_no_device_fails_loudly():
     h = ctypes.c_void_p()
     assert lib.sta_engine_create(ctypes.byref(h), 0, None) == -2
     assert not h.value
+
+
+def test_iterator_structs_have_htslib_layout(tmp_path):
+    """The drop-in header declares bam1_t / bam_pileup1_t itself when htslib/sam.h is not included first: the layouts must
+    be HTSlib's (>= 1.10, LP64) or a caller compiled against HTSlib would read garbage."""
+    src = tmp_path / "layout.c"
+    src.write_text(r'''
+#include <stddef.h>
+#include "samtools_amd.h"
+#include "samtools_amd_plp.h"
+_Static_assert(sizeof(hts_pos_t) == 8, "hts_pos_t");
+_Static_assert(sizeof(bam1_core_t) == 48, "bam1_core_t size");
+_Static_assert(offsetof(bam1_core_t, pos) == 0 && offsetof(bam1_core_t, tid) == 8 && offsetof(bam1_core_t, bin) == 12, "core head");
+_Static_assert(offsetof(bam1_core_t, qual) == 14 && offsetof(bam1_core_t, l_extranul) == 15 && offsetof(bam1_core_t, flag) == 16, "core mid");
+_Static_assert(offsetof(bam1_core_t, l_qname) == 18 && offsetof(bam1_core_t, n_cigar) == 20 && offsetof(bam1_core_t, l_qseq) == 24, "core lens");
+_Static_assert(offsetof(bam1_core_t, mtid) == 28 && offsetof(bam1_core_t, mpos) == 32 && offsetof(bam1_core_t, isize) == 40, "core mate");
+_Static_assert(sizeof(bam1_t) == 80, "bam1_t size");
+_Static_assert(offsetof(bam1_t, core) == 0 && offsetof(bam1_t, id) == 48 && offsetof(bam1_t, data) == 56, "bam1_t head");
+_Static_assert(offsetof(bam1_t, l_data) == 64 && offsetof(bam1_t, m_data) == 68, "bam1_t tail");
+_Static_assert(sizeof(bam_pileup_cd) == 8, "bam_pileup_cd");
+_Static_assert(sizeof(bam_pileup1_t) == 40, "bam_pileup1_t size");
+_Static_assert(offsetof(bam_pileup1_t, b) == 0 && offsetof(bam_pileup1_t, qpos) == 8 && offsetof(bam_pileup1_t, indel) == 12, "plp head");
+_Static_assert(offsetof(bam_pileup1_t, level) == 16 && offsetof(bam_pileup1_t, cd) == 24 && offsetof(bam_pileup1_t, cigar_ind) == 32, "plp tail");
+_Static_assert(sizeof(kstring_t) == 24, "kstring_t");
+_Static_assert(sizeof(sta_plp_entry) == 16, "sta_plp_entry");
+_Static_assert(sizeof(sta_glf_col) == 128, "sta_glf_col");
+int main(void) { return 0; }
+''')
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-I", INC, str(src)], check=True)
+
+
+def test_ctypes_mirror_matches_the_header(tmp_path):
+    """samtools_amd/_capi.py restates the header's structures by hand: sizes and a few field offsets must agree with what a C
+    compiler sees (catches a forgotten field on either side without needing a GPU)."""
+    import sys
+    sys.path.insert(0, REPO)
+    from samtools_amd import _capi
+    names = [("sta_reads", _capi.Reads), ("sta_window", _capi.Window), ("sta_mplp_params", _capi.MplpParams),
+             ("sta_depth_params", _capi.DepthParams), ("sta_plan_info", _capi.PlanInfo), ("sta_kernel_time", _capi.KernelTime),
+             ("sta_glf_params", _capi.GlfParams), ("sta_glf_col", _capi.GlfCol), ("sta_calmd_params", _capi.CalmdParams)]
+    src = tmp_path / "sz.c"
+    body = "".join('printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n, _ in names)
+    body += 'printf("off_window_files %zu\\n", offsetof(sta_window, files));\nprintf("off_mplp_flag %zu\\n", offsetof(sta_mplp_params, flag));\n'
+    body += 'printf("off_reads_xcol_off %zu\\n", offsetof(sta_reads, xcol_off));\n'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "samtools_amd.h"\nint main(void) {\n' + body + "return 0; }\n")
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c11", "-I", INC, str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], stdout=subprocess.PIPE, check=True).stdout.decode().split("\n") if l)
+    for n, cls in names:
+        assert int(out[n]) == ctypes.sizeof(cls), n
+    assert int(out["off_window_files"]) == _capi.Window.files.offset
+    assert int(out["off_mplp_flag"]) == _capi.MplpParams.flag.offset
+    assert int(out["off_reads_xcol_off"]) == _capi.Reads.xcol_off.offset

@@ -108,3 +108,24 @@ def test_ctypes_mirror_matches_the_header(tmp_path):
     assert int(out["off_window_files"]) == _capi.Window.files.offset
     assert int(out["off_mplp_flag"]) == _capi.MplpParams.flag.offset
     assert int(out["off_reads_xcol_off"]) == _capi.Reads.xcol_off.offset
+
+
+def test_every_subcommand_refuses_to_compute_without_a_device(tmp_path):
+    """No CPU fallback anywhere: on a machine without a HIP device every sub-command of the CLI must exit non-zero, print
+    nothing on stdout and say why.  (Skipped on the GPU box, where the -m gpu tests run the same commands for real.)"""
+    lib = ctypes.CDLL(LIB)
+    lib.sta_device_count.restype = ctypes.c_int
+    if lib.sta_device_count() > 0:
+        import pytest
+        pytest.skip("a HIP device is present")
+    exe = os.path.join(REPO, "samtools_amd", "bin", "samtools-amd")
+    gold = os.path.join(REPO, "tests", "golden")
+    sam, fa = os.path.join(gold, "mpileup", "mp_D.sam"), os.path.join(gold, "mpileup", "mp.fa")
+    cases = [["mpileup", sam], ["mpileup", "-f", fa, sam], ["depth", "-a", sam], ["plpdump", sam], ["coverage", sam], ["glf", sam],
+             ["calmd", "-r", sam, fa], ["bedcov", os.path.join(gold, "bedcov", "bedcov.bed"), os.path.join(gold, "bedcov", "bedcov.bam")]]
+    for env_extra in ({}, {"STA_COV_ITERATOR": "1"}):
+        for args in cases:
+            p = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env_extra))
+            assert p.returncode != 0, args
+            assert p.stdout == b"", args
+            assert b"HIP device" in p.stderr, (args, p.stderr[-200:])

@@ -129,3 +129,23 @@ def test_every_subcommand_refuses_to_compute_without_a_device(tmp_path):
             assert p.returncode != 0, args
             assert p.stdout == b"", args
             assert b"HIP device" in p.stderr, (args, p.stderr[-200:])
+
+
+def test_product_sources_never_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing under samtools_amd/ or include/ may include, link, import or execute it
+    (only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() use it, as the checker)."""
+    import re
+    bad = []
+    roots = [os.path.join(REPO, "samtools_amd"), INC]
+    for root in roots:
+        for dp, _, fs in os.walk(root):
+            for fn in fs:
+                if not fn.endswith((".cpp", ".hip", ".h", ".py", "Makefile")):
+                    continue
+                text = open(os.path.join(dp, fn), errors="replace").read()
+                if re.search(r"oracle/|oracle_samtools|o_plp\.h|o_common\.h|import\s+oracle|from\s+oracle", text):
+                    bad.append(os.path.relpath(os.path.join(dp, fn), REPO))
+    assert not bad, bad
+    # and the library does not link it
+    out = subprocess.run(["ldd", LIB], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert "oracle" not in out

@@ -321,7 +321,7 @@ int sta_main_calmd(int argc, char **argv);
  * by `threads` workers and records are parsed one batch ahead of the consumer.  sta_io_scan decodes a whole file through it
  * (`path` may hold several paths separated by '\n': the drivers' multi-file windows)
  * and returns the record count and an order-dependent checksum over every decoded field (threads <= 0: the drivers'
- * default, $STA_IO_THREADS or 4; 1 worker is still a separate thread).  stage != 0 additionally pushes the records through
+ * default, $STA_IO_THREADS or 4..8 depending on the machine; 1 worker is still a separate thread).  stage != 0 additionally pushes the records through
  * the drivers' window pump and SoA stager (what runs between the reader and sta_stage_window) and checksums every staged
  * window: 1 = one decoded record at a time (host_pump.h), 2 = chunk slices decoded on `threads` parser threads
  * (host_chunk.h); both lanes must give the same checksum.  Returns 0, or <0 on error. */

@@ -15,7 +15,10 @@ namespace sta {
 int io_default_threads()
 {
     if (const char *e = getenv("STA_IO_THREADS")) { int v = atoi(e); if (v > 0) return v > 64 ? 64 : v; }
-    return 4;
+    // half the hardware threads, between 4 and 8: inflate and parse stop scaling there
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int v = (int)(hw / 2);
+    return v < 4 ? 4 : v > 8 ? 8 : v;
 }
 
 int io_threads_per_input(int n_inputs)

@@ -18,7 +18,7 @@ public:
     // up to n bytes; fewer only at end of data or on error
     virtual size_t read(void *dst, size_t n) = 0;
     virtual bool failed() const = 0;
-    // threads <= 0: $STA_IO_THREADS or 4
+    // threads <= 0: $STA_IO_THREADS, else 4..8 depending on the machine
     static std::unique_ptr<ByteSource> open(const std::string &path, int threads, std::string *err);
 };
 

@@ -45,7 +45,7 @@ struct Rec {
 
 class AlnReader {
 public:
-    // threads: BGZF inflate workers (<= 0: $STA_IO_THREADS or 4); records are parsed one batch ahead on a further thread
+    // threads: BGZF inflate workers (<= 0: $STA_IO_THREADS, else 4..8 depending on the machine); records are parsed one batch ahead on a further thread
     static std::unique_ptr<AlnReader> open(const std::string &path, std::string *err, int threads = 0);
     ~AlnReader();
     const Header &header() const { return hdr_; }

@@ -3,19 +3,27 @@
 
 One "step" = one pass of the hot path over one window of synthetic, position-sorted reads that is
 already resident in HBM: read filters -> quality prep -> BAQ -> overlap -> per-column measure ->
-scan -> pileup text, all through the C-ABI (include/samtools_amd.h).  At N > 1 every rank owns a
-different window (reference positions shard into independent windows: weak scaling) and the
-per-window text is gathered on rank 0 with one RCCL gather inside the timed step.
+scan -> pileup text, all through the C-ABI (include/samtools_amd.h).
+
+N > 1 (launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`):
+ONE sorted input is generated identically on every rank, its reference columns are split into N contiguous
+blocks, every rank stages the reads that can touch its block plus the mate halo and piles ONLY
+its own columns, and the per-block text is collected on rank 0 with one size all-gather + one variable-size
+gather over RCCL (samtools_amd/shard.py) inside the timed step.  Per-GPU work is fixed as N grows (the input
+has N x the single-GPU window): weak scaling.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mpileup30|mpileup30_B|mpileup300|depth30|glf30|calmd30]
+                    [--verify] [--no-pmc] [--no-cpu-baseline]
 
-Launched by the driver for N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
-Prints ONE JSON line on rank 0.  The CPU oracle appears only in the cpu_baseline leg (rank 0, N=1).
+Prints ONE JSON line on rank 0.  The CPU oracle appears only as the checker / cpu_baseline leg (rank 0).
 """
 import argparse
-import ctypes as C
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -26,29 +34,22 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
 WORKLOADS = {
-    # name: (kind, depth, default window columns, algorithmic bytes per piled base, cli args)
-    "mpileup30": ("mpileup", 30, 4 << 20, 4.3, ["mpileup", "-f", "{fa}", "{sam}"]),
+    # name: (kind, depth, default window columns per GPU, algorithmic HBM bytes per piled base, cli args)
+    "mpileup30": ("mpileup", 30, 4 << 20, 4.3 + 1.0, ["mpileup", "-f", "{fa}", "{sam}"]),       # + ~1 B/base of reference window for BAQ
     "mpileup30_B": ("mpileup", 30, 4 << 20, 4.3, ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
-    "mpileup300": ("mpileup", 300, 1 << 19, 3.75, ["mpileup", "-f", "{fa}", "{sam}"]),
+    "mpileup300": ("mpileup", 300, 1 << 19, 3.75 + 1.0, ["mpileup", "-f", "{fa}", "{sam}"]),
+    "mpileup300_B": ("mpileup", 300, 1 << 19, 3.75, ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
     "depth30": ("depth", 30, 8 << 20, 0.21, ["depth", "-a", "{sam}"]),
     # rows widened into after the pileup path; single GPU, results stay on the device
     "glf30": ("glf", 30, 4 << 20, 1.5 + 128.0 / 30.0, ["glf", "-f", "{fa}", "{sam}"]),
     "calmd30": ("calmd", 30, 4 << 20, 4.0, ["calmd", "-r", "{sam}", "{fa}"]),
 }
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E
-
-
-def alg_bytes_per_base(kernel, wl_bytes_per_base, band_cells=15):
-    """Algorithmic HBM bytes per piled base for the kernels that can dominate a step.
-
-    BAQ forward/backward: the (M, I) part of every forward row -- 2 * band_cells doubles per query base -- is written once
-    by the forward kernel and read once by the backward/MAP kernel; inputs (quality, packed base, reference base) add ~2.5 B.
-    Pileup kernels: SURVEY.md 8d figure for the whole measure+emit pair (4.3 B/base at 30x), attributed to the emit kernel."""
-    if kernel in ("baq_fwd", "baq_bwd"):
-        return 2 * band_cells * 8 + 2.5
-    if kernel == "mplp_len":
-        return 1.0 + 12.0 / 30.0
-    return wl_bytes_per_base
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec); ~6.3 TB/s is what a streaming copy reaches
+# fp64 vector ALU without fused multiply-add (BAQ must round like the CPU: -ffp-contract=off): 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz
+FP64_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+# BAQ arithmetic per band cell (kernels_baq.hip): forward M 6 + I 4 + D 3 + row sum 3 + scaling 3 = 19 fp64 operations,
+# backward M 6 + I 3 + D 4 + scaling 2 + MAP 6 = 21; 2*7+1 = 15 band cells per query base
+BAQ_FP64_OPS_PER_BASE = {"baq_fwd": 19 * 15, "baq_bwd": 21 * 15}
 
 
 def parse():
@@ -60,19 +61,22 @@ def parse():
     ap.add_argument("--cols", type=int, default=0, help="window columns per GPU per step (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cols", type=int, default=0)
+    ap.add_argument("--verify", action="store_true",
+                    help="hash the text of the timed window and compare it with the oracle's text for the same seeds (adds ~20-40 s of CPU work)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-run one step under rocprofv3 --pmc for roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def build_window(torch, np, sa, rd, ref_t, n_cols, dev):
-    """numpy SoA -> device tensors -> sta_window (STA_MEM_DEVICE)."""
-    keep = {}
+def upload_reads(torch, np, sa, rd, dev, keep):
+    """numpy SoA -> device tensors -> sta_reads descriptor (STA_MEM_DEVICE)."""
     def up(name):
         arr = rd[name]
         if arr.dtype == np.uint32: arr = arr.view(np.int32)
         elif arr.dtype == np.uint16: arr = arr.view(np.int16)
         elif arr.dtype == np.uint64: arr = arr.view(np.int64)
-        t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
-        keep[name] = t
+        t = torch.from_numpy(np.ascontiguousarray(arr).copy()).to(dev)
+        keep.append(t)
         return t.data_ptr()
     reads = sa.Reads()
     reads.n_reads = rd["n"]
@@ -83,41 +87,118 @@ def build_window(torch, np, sa, rd, ref_t, n_cols, dev):
     reads.n_cigar_total = len(rd["cigar"])
     reads.n_bases_total = len(rd["qual"])
     reads.n_name_bytes = len(rd["names"])
+    return reads
+
+
+def build_window(torch, np, sa, rd, n_cols, dev, origin=0, col_beg=0, col_end=None, tlen=None):
+    keep = []
+    reads = upload_reads(torch, np, sa, rd, dev, keep)
     files = (sa.Reads * 1)(reads)
     w = sa.Window()
-    w.tid = 0; w.origin = 0; w.col_beg = 0; w.col_end = n_cols
-    w.tname = b"chrS"; w.tlen = n_cols
+    w.tid = 0; w.origin = origin; w.col_beg = col_beg; w.col_end = n_cols if col_end is None else col_end
+    w.tname = b"chrS"; w.tlen = n_cols if tlen is None else tlen
     w.n_files = 1; w.files = files; w.mem = 1
     w.has_bed = 0; w.has_reg = 0
-    keep["files"] = files
+    keep.append(files)
     in_bytes = sum(int(rd[f].nbytes) for f in ("pos", "flag", "mapq", "aux", "l_qseq", "cig_off", "base_off8", "mtid",
-                                                 "mpos", "isize", "name_off", "cigar", "seq", "qual")) + n_cols
+                                                 "mpos", "isize", "name_off", "cigar", "seq", "qual")) + (w.col_end - w.col_beg)
     return w, keep, in_bytes
 
 
-def cpu_baseline(wl, sample_cols):
-    """Oracle (plain-C restatement, kind='port') timed single-threaded on a bounded sample of the same workload."""
+def slice_reads(np, rd, lo, hi, origin):
+    """reads [lo, hi) of a generated set as their own sta_reads arrays, positions relative to `origin` (a rank's block + halo)."""
+    out = {"n": hi - lo, "L": rd["L"]}
+    for f in ("flag", "mapq", "aux", "l_qseq", "mtid", "mpos", "isize"):
+        out[f] = rd[f][lo:hi]
+    out["pos"] = (rd["_abs_pos"][lo:hi] - origin).astype(np.int32)
+    c0, c1 = int(rd["cig_off"][lo]), int(rd["cig_off"][hi])
+    out["cig_off"] = (rd["cig_off"][lo:hi + 1] - c0).astype(np.uint32)
+    out["cigar"] = rd["cigar"][c0:c1]
+    b0 = int(rd["base_off8"][lo]) if hi > lo else 0
+    b1 = (int(rd["base_off8"][hi]) if hi < rd["n"] else len(rd["qual"]) // 8) if hi > lo else 0
+    out["base_off8"] = (rd["base_off8"][lo:hi] - b0).astype(np.uint32)
+    out["qual"] = rd["qual"][b0 * 8:b1 * 8]
+    out["seq"] = rd["seq"][b0 * 4:b1 * 4]
+    n0, n1 = int(rd["name_off"][lo]), int(rd["name_off"][hi])
+    out["name_off"] = (rd["name_off"][lo:hi + 1] - n0).astype(np.uint32)
+    out["names"] = rd["names"][n0:n1]
+    return out
+
+
+def oracle_text_hash(wl, n_cols, seed_ref=1, seed_reads=42, save_to=None):
+    """The checker: the oracle's text for the synthetic window (same generator, same seeds) -> sha256, bytes, wall time."""
     from synth import synth_ref, synth_reads, write_sam, write_fasta
     kind, depth, _, _, argv = WORKLOADS[wl]
     oracle = os.path.join(REPO, "oracle", "_build", "oracle_samtools")
     if not os.path.exists(oracle):
         return None
-    ref = synth_ref(sample_cols, seed=1)
-    rd = synth_reads(ref, depth=depth, read_len=150, seed=42)
+    ref = synth_ref(n_cols, seed=seed_ref)
+    rd = synth_reads(ref, depth=depth, read_len=150, seed=seed_reads)
     with tempfile.TemporaryDirectory() as tmp:
         sam, fa = os.path.join(tmp, "s.sam"), os.path.join(tmp, "s.fa")
-        write_sam(sam, rd, "chrS", sample_cols)
+        write_sam(sam, rd, "chrS", n_cols)
         write_fasta(fa, "chrS", ref)
         args = [a.format(sam=sam, fa=fa) for a in argv]
+        h = hashlib.sha256()
+        n = 0
         t0 = time.perf_counter()
         with open(os.devnull, "wb") as dn:
-            subprocess.run([oracle] + args, stdout=dn, stderr=dn, check=True)
+            p = subprocess.Popen([oracle] + args, stdout=subprocess.PIPE, stderr=dn)
+            fh = open(save_to, "wb") if save_to else None
+            while True:
+                b = p.stdout.read(1 << 22)
+                if not b:
+                    break
+                h.update(b); n += len(b)
+                if fh: fh.write(b)
+            if fh: fh.close()
+            if p.wait() != 0:
+                raise RuntimeError("oracle failed on the %s sample" % wl)
         dt = time.perf_counter() - t0
-    bases = int(rd["n"]) * 150
-    return {"value": bases / dt / 1e6, "unit": "Mbases/s", "cores": 1, "kind": "port",
-            "sample": "%s on %d synthetic reads (%d Mbases, %d columns, SAM text input, output to /dev/null), %.1f s wall, "
-                      "oracle restatement (not the upstream binary: HTSlib is absent)" % (
-                          " ".join(x for x in argv if x != "{sam}").replace("{fa}", "ref.fa"), rd["n"], bases // 1000000, sample_cols, dt)}
+    return {"sha256": h.hexdigest(), "bytes": n, "seconds": dt, "n_reads": int(rd["n"]), "bases": int(rd["n"]) * 150,
+            "argv": " ".join(x for x in argv if x != "{sam}").replace("{fa}", "ref.fa"), "ref": ref, "rd": rd}
+
+
+def collect_pmc(a, kernels):
+    """roofline.traffic measured on THIS box: one step of the same workload under `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (separate passes: both do not fit the TCC slots; MI355X_MICROARCH.md 'rocprofv3 PMC slots').
+    Returns {kernel: {"FETCH_SIZE": KB per launch, "WRITE_SIZE": KB per launch}} or None."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    out = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="sta_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", a.workload, "--steps", "1", "--warmup", "0",
+               "--no-cpu-baseline", "--no-pmc"] + (["--cols", str(a.cols)] if a.cols else [])
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            agg = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != ctr:
+                        continue
+                    k = row["Kernel_Name"].split("(")[0]
+                    e = agg.setdefault(k, [0, 0.0])
+                    e[0] += 1; e[1] += float(row["Counter_Value"])
+            for k, (n, v) in agg.items():
+                out.setdefault(k, {})[ctr] = v / max(n, 1)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out or None
+
+
+KNAME = {"baq_fwd": "void k_baq_fwd<7>", "baq_bwd": "void k_baq_bwd<7>", "mplp_emit": "k_mplp_emit_fast", "mplp_len": "k_mplp_len_fast",
+         "mplp_fused": "k_mplp_fused", "depth_emit": "k_depth_emit", "depth_len": "k_depth_len", "depth_count": "k_depth_count",
+         "depth_fused": "k_depth_fused", "glf_cols": "k_glf_cols"}
+# gfx950: FETCH_SIZE tallies a 16-byte-per-lane streaming read at half its bytes (MI355X_MICROARCH.md, HBM); these kernels read that way
+FETCH_X2 = {"baq_bwd"}
 
 
 def main():
@@ -130,6 +211,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks for the 1-GPU box: STA_BENCH_ONE_DEVICE=1 puts every rank on device 0, STA_BENCH_BACKEND=gloo replaces RCCL
+    if os.environ.get("STA_BENCH_ONE_DEVICE"):
+        local = 0
+    backend = os.environ.get("STA_BENCH_BACKEND", "nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -137,18 +222,31 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
-    kind, depth, def_cols, alg_bytes_per_base_wl, _ = WORKLOADS[a.workload]
-    n_cols = a.cols or def_cols
-    # every rank generates its own window (different seed): reference windows are independent shards
-    ref = synth_ref(n_cols, seed=1 + rank)
-    rd = synth_reads(ref, depth=depth, read_len=150, seed=42 + rank)
+    kind, depth, def_cols, alg_bpb, _ = WORKLOADS[a.workload]
+    cols_per_gpu = a.cols or def_cols
+    n_cols = cols_per_gpu * world
+    from samtools_amd import shard
+    # ONE input for the whole job (same seeds on every rank); rank r owns columns [blk_beg, blk_end)
+    ref = synth_ref(n_cols, seed=1)
+    rd_all = synth_reads(ref, depth=depth, read_len=150, seed=42)
+    blk_beg, blk_end = shard.block_of(rank, world, n_cols)
+    if world > 1:
+        # reads that can touch the block plus the mate halo (reads starting up to 2 x the longest span before it)
+        lo, hi = shard.read_range(rd_all["_abs_pos"], blk_beg, blk_end, halo=shard.halo_columns(150 + 3))
+        origin = max(0, blk_beg - shard.halo_columns(150 + 3))
+        rd = slice_reads(np, rd_all, lo, hi, origin)
+    else:
+        origin, rd = 0, rd_all
     stream = torch.cuda.current_stream().cuda_stream
     eng = sa.Engine(local, stream)
     ref_t = torch.from_numpy(ref.copy()).to(dev)
     eng.set_reference(0, ref_t.data_ptr(), n_cols, 1)
-    w, keep, in_bytes = build_window(torch, np, sa, rd, ref_t, n_cols, dev)
+    w, keep, in_bytes = build_window(torch, np, sa, rd, n_cols, dev, origin=origin, col_beg=blk_beg - origin, col_end=blk_end - origin, tlen=n_cols)
     if kind == "mpileup":
         par = sa.MplpParams.defaults()
         par.has_fai = 1
@@ -171,28 +269,28 @@ def main():
     info = plan()
     out_bytes = int(info.out_bytes)
     piled = int(info.piled_bases) or int(rd["n"]) * 150      # (the calmd plan reports no pileup counters: every base is aligned)
-    from samtools_amd import shard
-    sizes = recv = None
+    # (piled_bases counts only the columns this rank owns: k_prep_reads clips every read to [col_beg, col_end))
+    sizes = None
     cap = out_bytes + 4096
     if dist is not None:
-        sizes = shard.exchange_sizes(out_bytes, dev)      # once: the synthetic window is the same every step
-        cap = max(sizes) + 4096                            # every rank's buffers can be sent padded to the largest piece
+        sizes = shard.exchange_sizes(out_bytes, dev if backend == "nccl" else torch.device("cpu"))      # once: the synthetic window is the same every step
     out_t = torch.empty(cap, dtype=torch.uint8, device=dev)
 
-    # N > 1: the text of step k is gathered on rank 0 (ONE RCCL gather per step) while step k+1 computes: two output
-    # buffers, asynchronous gather on RCCL's own stream, sizes exchanged once (the synthetic window is the same every step)
+    # N > 1: the text of step k is gathered on rank 0 (ONE variable-size RCCL gather per step) while step k+1 computes:
+    # two output buffers, the gather runs asynchronously on RCCL's stream
     n_buf = 2 if dist is not None else 1
     out_bufs = [out_t] + [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(n_buf - 1)]
     pending = [None] * n_buf
+    recv = None
     if dist is not None and rank == 0:
-        recv = [[torch.empty(max(sizes), dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(n_buf)]
+        recv = [torch.empty(sum(sizes), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
     step_no = [0]
 
     def step():
         i = step_no[0] % n_buf
         step_no[0] += 1
         if pending[i] is not None:
-            pending[i].wait()              # the buffer's previous gather must have left it
+            shard.wait_all(pending[i])     # the buffer's previous gather must have left it
             pending[i] = None
         plan()
         if kind == "mpileup":
@@ -200,15 +298,18 @@ def main():
         elif kind == "depth":
             eng.depth_emit(out_bufs[i].data_ptr(), cap)
         if dist is not None:
-            # the single collective of the path: per-window column text -> rank 0 over RCCL/xGMI (samtools_amd/shard.py)
-            pending[i] = shard.gather_text(out_bufs[i], dst=0, sizes=sizes, recv=recv[i] if recv else None, async_op=True)
+            # the single collective of the path: per-block column text -> rank 0 over RCCL/xGMI, true sizes (samtools_amd/shard.py)
+            pending[i] = shard.gather_text_v(out_bufs[i], out_bytes, dst=0, sizes=sizes, recv=recv[i] if recv else None)
 
     def drain():
         for i in range(n_buf):
             if pending[i] is not None:
-                pending[i].wait()
+                shard.wait_all(pending[i])
                 pending[i] = None
 
+    if a.pmc_child:
+        step(); torch.cuda.synchronize()
+        return
     for _ in range(a.warmup):
         step()
     drain()
@@ -230,7 +331,7 @@ def main():
     prof = eng.profile_get()
     eng.profile(False)
 
-    tt = torch.tensor([dt, float(piled)], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt, float(piled)], dtype=torch.float64, device=dev if backend == "nccl" else torch.device("cpu"))
     if dist is not None:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -241,44 +342,62 @@ def main():
         dt_all, piled_all = dt, float(piled)
 
     if rank == 0:
-        # correctness spot check of what was just timed: line count and final newline
+        last = (step_no[0] - 1) % n_buf
+        timed_sha = None
         if kind in ("mpileup", "depth"):
-            head = bytes(out_t[:min(out_bytes, 1 << 16)].cpu().numpy().tobytes())
-            assert out_bytes == 0 or head.count(b"\n") > 0
+            # what was just timed: the whole text (all ranks' blocks at N > 1), hashed
+            src = recv[last][:sum(sizes)] if recv else out_bufs[last][:out_bytes]
+            timed_sha = hashlib.sha256(src.cpu().numpy().tobytes()).hexdigest()
         value = piled_all * a.steps / dt_all / 1e6
-        # dominant kernel by accumulated HIP-event time (rank 0)
+        pmc, pmc_src = None, None
+        if world == 1 and not a.no_pmc:
+            pmc = collect_pmc(a, prof)
+            pmc_src = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes) of one step of this command on this GPU"
+        if pmc is None and not a.cols:
+            for tag in ("r02", "r01"):
+                pth = os.path.join(REPO, "profiles", "%s_%s_pmc_traffic.json" % (tag, a.workload))
+                if os.path.exists(pth):
+                    raw = json.load(open(pth))
+                    pmc = {k: {c: v[c]["per_launch"] for c in v} for k, v in raw.items()}
+                    pmc_src = "recorded: profiles/%s (not measured in this run)" % os.path.basename(pth)
+                    break
+
+        def traffic_of(name):
+            ent = (pmc or {}).get(KNAME.get(name, name))
+            if not ent or "FETCH_SIZE" not in ent or "WRITE_SIZE" not in ent:
+                return None
+            return (ent["FETCH_SIZE"] * (2.0 if name in FETCH_X2 else 1.0) + ent["WRITE_SIZE"]) * 1024.0
+
         def roof(name):
+            """SURVEY.md 8(d) roofline of one kernel: the path's algorithmic bytes per piled base (each staged byte read once, each
+            output byte written once) x the bases one launch processes / the kernel's average launch time, against 8 TB/s."""
             launches, ms = prof[name]
             per_step = max(1, launches // max(1, a.steps))
             avg_ms = ms / max(1, launches)
-            bpb = alg_bytes_per_base(name, alg_bytes_per_base_wl)
-            per_launch = bpb * piled / per_step
-            ach = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic_of(name, per_step), "alg_bytes_per_unit": bpb, "units_per_launch": piled / per_step,
-                    "avg_launch_ms": avg_ms, "launches_per_step": per_step}
+            units = piled / per_step
+            ach = alg_bpb * units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            tr = traffic_of(name)
+            r = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                 "traffic": tr, "traffic_source": pmc_src if tr is not None else None,
+                 "alg_bytes_per_unit": alg_bpb, "units_per_launch": units, "avg_launch_ms": avg_ms, "launches_per_step": per_step}
+            if name in BAQ_FP64_OPS_PER_BASE:
+                # BAQ is fp64 work (SURVEY.md 8d: "flops, not bytes, then dominate BAQ (report separately)")
+                ops = BAQ_FP64_OPS_PER_BASE[name] * units
+                tops = ops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+                r["fp64"] = {"ops_per_unit": BAQ_FP64_OPS_PER_BASE[name], "achieved": tops, "peak": FP64_PEAK_TOPS, "unit": "Tflop/s (no FMA)",
+                             "frac": tops / FP64_PEAK_TOPS}
+                # the forward-row scratch stream the kernel pair moves through HBM: implementation traffic, reported as DRAM utilisation
+                sb = float(os.environ.get("STA_BAQ_STREAM_BPB", "0")) or eng_baq_stream_bpb
+                r["dram_util"] = {"stream_bytes_per_unit": sb, "achieved": sb * units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+                r["dram_util"]["frac"] = r["dram_util"]["achieved"] / HBM_PEAK_GBS
+            return r
 
-        pmc = {}
-        pmc_path = os.path.join(REPO, "profiles", "r01_%s_pmc_traffic.json" % a.workload)
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-        KNAME = {"baq_fwd": "void k_baq_fwd<7>", "baq_bwd": "void k_baq_bwd<7>", "mplp_emit": "k_mplp_emit_fast", "mplp_len": "k_mplp_len_fast",
-                 "depth_emit": "k_depth_emit", "depth_len": "k_depth_len", "depth_count": "k_depth_count"}
-
-        def traffic_of(name, per_step):
-            """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE + WRITE_SIZE, KB);
-            measured at the default window size only (null otherwise).  Counter calibration: DESIGN.md section 5."""
-            ent = pmc.get(KNAME.get(name, name))
-            if not ent or a.cols or "FETCH_SIZE" not in ent or "WRITE_SIZE" not in ent:
-                return None
-            # gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts a 16-byte-per-lane streaming read at
-            # half its bytes; k_baq_bwd reads its forward rows that way (its ~30.2 GB of rows show up as ~16.6 GB)
-            fetch_corr = 2.0 if name == "baq_bwd" else 1.0
-            return (ent["FETCH_SIZE"]["per_launch"] * fetch_corr + ent["WRITE_SIZE"]["per_launch"]) * 1024.0
-
+        # forward rows streamed per query base by the BAQ pair (2 doubles per band cell and stored row, see kernels_baq.hip)
+        eng_baq_stream_bpb = float(sa.baq_stream_bytes_per_base()) if hasattr(sa, "baq_stream_bytes_per_base") else 240.0
         # kernels on the side stream (band-8 BAQ groups) overlap the main ones: they cannot be "the" dominant kernel
-        main = {k: v for k, v in prof.items() if not k.startswith("baq8")}
-        dom_name = max(main.items(), key=lambda kv: kv[1][1])[0] if main else None
+        main_k = {k: v for k, v in prof.items() if not k.startswith("baq8")}
+        dom_name = max(main_k.items(), key=lambda kv: kv[1][1])[0] if main_k else None
         res = {
             "metric": "Mbases piled/s (mpileup, 30x 150bp)" if a.workload.startswith("mpileup30") else "Mbases piled/s (%s)" % a.workload,
             "value": value, "unit": "Mbases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -286,29 +405,56 @@ def main():
             "vs_baseline": None, "dtype": "u8/f64" if ((kind == "mpileup" and not a.workload.endswith("_B")) or kind in ("glf", "calmd")) else "u8",
             "data": "synthetic",
             "config": {"workload": a.workload, "command": " ".join(x for x in WORKLOADS[a.workload][4] if x != "{sam}").replace("{fa}", "ref.fa"),
-                       "read_len": 150, "depth": depth, "window_cols_per_gpu": n_cols, "reads_per_gpu": int(rd["n"]),
+                       "read_len": 150, "depth": depth, "window_cols_per_gpu": cols_per_gpu, "input_cols": n_cols, "reads_per_gpu": int(rd["n"]),
                        "piled_bases_per_gpu_step": piled, "out_bytes_per_gpu_step": out_bytes,
-                       "staged_in_bytes_per_gpu": in_bytes, "parallelism": "window-sharded x%d, 1 RCCL gather" % world},
+                       "staged_in_bytes_per_gpu": in_bytes,
+                       "parallelism": "one sorted input, reference columns sharded x%d (+ mate halo), 1 variable-size RCCL gather" % world},
             "roofline": roof(dom_name) if dom_name else None,
             "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
         }
-        emit_name = {"mpileup": "mplp_emit", "depth": "depth_emit", "glf": "glf_cols", "calmd": "md_emit"}[kind]
-        if emit_name in prof and emit_name != dom_name:
+        emit_name = next((k for k in ({"mpileup": ["mplp_fused", "mplp_emit"], "depth": ["depth_fused", "depth_emit"], "glf": ["glf_cols"], "calmd": ["md_emit"]}[kind]) if k in prof), None)
+        if emit_name and emit_name != dom_name:
             res["roofline_pileup"] = roof(emit_name)
-        # whole-step algorithmic rate (every kernel of the step, SURVEY.md 8d bytes): the number to compare with 8 TB/s end to end
-        res["step_alg_GBps"] = alg_bytes_per_base_wl * piled_all / (dt_all / a.steps) / 1e9 / max(1, world)
+        # whole step against the same roof: every kernel of the step, SURVEY.md 8d bytes
+        res["roofline_step"] = {"bound": "hbm", "achieved": alg_bpb * piled_all / (dt_all / a.steps) / 1e9 / max(1, world), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s per GPU", "alg_bytes_per_unit": alg_bpb}
+        res["roofline_step"]["frac"] = res["roofline_step"]["achieved"] / HBM_PEAK_GBS
+        res["output_sha256"] = timed_sha
+        if kind in ("mpileup", "depth") and a.verify:
+            # the timed window itself, byte for byte (hash of the whole text) against the oracle on the same seeds
+            o = oracle_text_hash(a.workload, n_cols)
+            res["verify"] = {"oracle_sha256": o["sha256"] if o else None, "identical": bool(o and o["sha256"] == timed_sha),
+                             "bytes": o["bytes"] if o else None, "oracle_seconds": o["seconds"] if o else None}
+            if not res["verify"]["identical"]:
+                print(json.dumps(res))
+                raise SystemExit("bench.py --verify: the timed text differs from the oracle's")
         if world == 1 and not a.no_cpu_baseline:
             # bounded sample: BAQ runs at ~6 Mbases/s on one core, so 2 M columns (400 k reads, 60 Mbases) is ~10 s of CPU work;
             # the other workloads keep the same sample (the oracle needs 0.2-0.7 s there: generating and writing the SAM text
             # in Python costs far more than the run, so a bigger sample would only slow the bench down)
-            sample = 2000000
-            sample = a.cpu_sample_cols or sample
+            sample = a.cpu_sample_cols or 2000000
             if depth >= 300:
                 sample //= 10
-            cb = cpu_baseline(a.workload, sample)
-            if cb:
-                res["cpu_baseline"] = cb
+            o = oracle_text_hash(a.workload, sample)
+            if o:
+                res["cpu_baseline"] = {
+                    "value": o["bases"] / o["seconds"] / 1e6, "unit": "Mbases/s", "cores": 1, "kind": "port",
+                    "sample": "%s on %d synthetic reads (%d Mbases, %d columns, SAM text input, text hashed not stored), %.1f s wall, "
+                              "oracle restatement (not the upstream binary: HTSlib is absent)" % (o["argv"], o["n_reads"], o["bases"] // 1000000, sample, o["seconds"])}
+                if kind in ("mpileup", "depth"):
+                    # the same sample through the engine: byte parity of every default bench run (the oracle is only the checker)
+                    ref_s = torch.from_numpy(o["ref"].copy()).to(dev)
+                    eng.set_reference(0, ref_s.data_ptr(), sample, 1)
+                    ws, keep_s, _ = build_window(torch, np, sa, o["rd"], sample, dev)
+                    eng.stage_window(ws)
+                    inf = eng.mpileup_plan(par) if kind == "mpileup" else eng.depth_plan(par)
+                    (eng.mpileup_emit if kind == "mpileup" else eng.depth_emit)()
+                    got = eng.fetch_output(int(inf.out_bytes))
+                    res["parity_check"] = {"sample_cols": sample, "bytes": len(got), "engine_sha256": hashlib.sha256(got).hexdigest(),
+                                           "oracle_sha256": o["sha256"], "identical": hashlib.sha256(got).hexdigest() == o["sha256"]}
         print(json.dumps(res))
+        if res.get("parity_check") and not res["parity_check"]["identical"]:
+            raise SystemExit("bench.py: the engine's text for the CPU-baseline sample differs from the oracle's")
     if dist is not None:
         dist.destroy_process_group()
 

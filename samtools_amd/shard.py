@@ -1,12 +1,23 @@
-"""Window sharding across the GPUs of one node (BASELINE.json north_star).
+"""Reference-column sharding across the GPUs of one node (BASELINE.json north_star).
 
-Reference positions split into non-overlapping windows; every rank (one process per GPU) runs the
-whole hot path on its own windows and the per-window pileup text is collected on rank 0 with ONE
-gather per step (RCCL over xGMI when the backend is "nccl", gloo in the CPU tests).  The reference's
-own precedent for position sharding is bam_consensus.c:2759-2790 (span jobs) and bedcov.c:297-308
-(per-interval iterators).  Nothing here computes pileups: it only decides who owns which columns
-and moves finished text.
+Reference positions split into non-overlapping column blocks; every rank (one process per GPU) runs the
+whole hot path on its own block and the per-block pileup text is collected on rank 0 with ONE gather per
+step: an 8-byte size all-gather plus grouped point-to-point transfers of exactly the bytes each rank
+produced (ncclGroupStart / ncclSend / ncclRecv over xGMI when the backend is "nccl" = RCCL, gloo in the
+CPU tests).  The reference's own precedent for position sharding is the span-job loop of
+bam_consensus.c:2759-2810 and the per-interval iterators of bedcov.c:297-308; what a rank must read
+besides the reads that touch its block (the halo) follows host_pump.h.
+
+Two layers use this module:
+  * bench.py --gpus N: ONE device-resident input, each rank piles its block (`block_of`, `read_range`);
+  * `python -m samtools_amd.shard mpileup|depth <args>` under torchrun: the product drivers
+    (sta_main_mpileup / sta_main_depth) run with STA_SHARD=rank/world, which restricts a rank to its block
+    of the (region-clipped) genome, and the text is gathered and written by rank 0 (`run_sharded_cli`).
+Nothing here computes pileups: it only decides who owns which columns and moves finished text.
 """
+import os
+import sys
+import tempfile
 from typing import List, Sequence, Tuple
 
 
@@ -32,16 +43,28 @@ def windows_of_rank(windows: Sequence[Tuple[int, int, int]], rank: int, world: i
     return list(range(lo, hi))
 
 
-def halo_columns(max_ref_span: int) -> int:
-    """Reads starting up to this many columns before a window can still touch it or rewrite (through
-    mate-overlap resolution) the qualities of a read that does: 2 x the longest reference span.
+def block_of(rank: int, world: int, n_cols: int) -> Tuple[int, int]:
+    """Columns [beg, end) of a linear coordinate space of n_cols that rank `rank` owns: equal contiguous blocks
+    (the same rule the C drivers apply to STA_SHARD=rank/world, driver_shard.h)."""
+    beg = n_cols * rank // world
+    end = n_cols * (rank + 1) // world
+    return beg, end
 
-    Two refinements found with long ref skips (host_pump.h): a shard must also receive (i) the earlier
-    mate of every read that is live in it, even when that mate ends before the shard starts (HTSlib may rewrite bases of
-    the later mate beyond the earlier mate's end), and (ii) the records after its last column up to the first one that is
-    certainly pushed (it releases the shard's last columns and may be an overlap mate).  The drivers' pumps implement both;
-    a region-restricted reader per rank must widen its query accordingly."""
+
+def halo_columns(max_ref_span: int) -> int:
+    """Reads starting up to this many columns before (or after) a block can still touch it, rewrite -- through
+    mate-overlap resolution -- the qualities of a read that does, or be the push that releases the block's last
+    columns: 2 x the longest reference span (host_pump.h keep_mates / surely_pushed)."""
     return 2 * int(max_ref_span)
+
+
+def read_range(abs_pos, blk_beg: int, blk_end: int, halo: int) -> Tuple[int, int]:
+    """Index range [lo, hi) of the position-sorted reads a rank stages for block [blk_beg, blk_end): everything starting
+    inside the block or within `halo` columns of either side."""
+    import numpy as np
+    lo = int(np.searchsorted(abs_pos, blk_beg - halo, side="left"))
+    hi = int(np.searchsorted(abs_pos, blk_end + halo, side="left"))
+    return lo, hi
 
 
 def exchange_sizes(n_local: int, device, group=None) -> List[int]:
@@ -56,49 +79,132 @@ def exchange_sizes(n_local: int, device, group=None) -> List[int]:
     return [int(s.item()) for s in sizes]
 
 
-class PendingGather:
-    """An in-flight gather: wait() returns the per-rank byte tensors on the destination rank (None elsewhere)."""
-
-    def __init__(self, work, recv, sizes):
-        self._work, self._recv, self._sizes = work, recv, sizes
-
-    def wait(self):
-        if self._work is not None:
-            self._work.wait()
-            self._work = None
-        if self._recv is None:
-            return None
-        return [r[:s] for r, s in zip(self._recv, self._sizes)]
+def wait_all(works) -> None:
+    for w in works or ():
+        w.wait()
 
 
-def gather_text(local, dst: int = 0, group=None, sizes: Sequence[int] = None, recv=None, async_op: bool = False):
-    """Collect every rank's byte tensor (uint8, 1-D, on the backend's device) on `dst` in rank order.
-
-    ONE gather of the text, padded to the largest piece; when `sizes` (every rank's byte count) is not supplied it is
-    obtained with one 8-byte all_gather first.  `local` may be longer than its entry in `sizes` (a reusable buffer).
-    `recv` optionally supplies the destination's receive buffers (world tensors of >= max(sizes) bytes) so that a
-    steady-state loop allocates nothing.  With async_op=True a PendingGather is returned at once: the copy runs on
-    the backend's own stream and overlaps whatever the caller launches next (the next window's kernels)."""
+def gather_text_v(local, n_local: int, dst: int = 0, group=None, sizes: Sequence[int] = None, recv=None):
+    """Variable-size gather of byte tensors onto `dst`, nothing padded: `dst` posts one receive per peer straight into
+    its slice of ONE contiguous buffer (rank order = output order) and every other rank posts one send of exactly its
+    n_local bytes; the operations are issued as one group (dist.batch_isend_irecv -> ncclGroupStart/End on RCCL).
+    Returns the list of in-flight works (wait with wait_all); on `dst`, `recv` (world-total bytes, allocated here when
+    None) holds the concatenated text once they completed -- read it as recv[:sum(sizes)].  dst's own piece is copied
+    locally."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if sizes is None:
-        sizes = exchange_sizes(local.numel(), local.device, group)
+        sizes = exchange_sizes(n_local, local.device, group)
     sizes = [int(x) for x in sizes]
-    cap = max(max(sizes), 1)
-    if local.numel() >= cap:
-        buf = local[:cap]
-    else:
-        buf = torch.zeros(cap, dtype=torch.uint8, device=local.device)
-        buf[:local.numel()] = local
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # the 1-GPU test box: several ranks share one device and talk over gloo, which moves host memory
+        host = local[:sizes[rank]].cpu()
+        works = gather_text_v(host, sizes[rank], dst=dst, group=group, sizes=sizes)
+        wait_all(works)
+        if rank == dst:
+            if recv is None:
+                recv = torch.empty(max(sum(sizes), 1), dtype=torch.uint8, device=local.device)
+            recv[:sum(sizes)].copy_(gather_text_v.last_recv[:sum(sizes)])
+            gather_text_v.last_recv = recv
+        return []
+    ops = []
     if rank == dst:
         if recv is None:
-            recv = [torch.empty(cap, dtype=torch.uint8, device=local.device) for _ in range(world)]
-        recv = [r[:cap] for r in recv]
-    else:
-        recv = None
-    work = dist.gather(buf, recv, dst=dst, group=group, async_op=async_op)
-    pending = PendingGather(work if async_op else None, recv, sizes)
-    return pending if async_op else pending.wait()
+            recv = torch.empty(max(sum(sizes), 1), dtype=torch.uint8, device=local.device)
+        off = 0
+        for r in range(world):
+            piece = recv[off:off + sizes[r]]
+            if r == rank:
+                piece.copy_(local[:sizes[r]])
+            elif sizes[r]:
+                ops.append(dist.P2POp(dist.irecv, piece, r, group))
+            off += sizes[r]
+    elif sizes[rank]:
+        ops.append(dist.P2POp(dist.isend, local[:sizes[rank]], dst, group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    gather_text_v.last_recv = recv if rank == dst else None
+    return works
+
+
+def gather_text(local, dst: int = 0, group=None, sizes: Sequence[int] = None):
+    """Blocking form: every rank's byte tensor on `dst`, in rank order, as one contiguous tensor (None elsewhere)."""
+    import torch.distributed as dist
+
+    if sizes is None:
+        sizes = exchange_sizes(local.numel(), local.device, group)
+    works = gather_text_v(local, local.numel(), dst=dst, group=group, sizes=sizes)
+    wait_all(works)
+    if dist.get_rank(group) != dst:
+        return None
+    return gather_text_v.last_recv[:sum(sizes)]
+
+
+def run_sharded_cli(argv: Sequence[str], out=None) -> int:
+    """`mpileup ...` / `depth ...` across the ranks of the current process group: every rank runs the product driver
+    restricted to its block (STA_SHARD), rank 0 writes the concatenated text to `out` (default stdout, or the -o file
+    the command names).  Returns the worst exit status over the ranks."""
+    import torch
+    import torch.distributed as dist
+    from . import _capi
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sub, args = argv[0], list(argv[1:])
+    if sub not in ("mpileup", "depth"):
+        raise SystemExit("samtools_amd.shard: only mpileup and depth shard over reference columns")
+    # the command's own -o/--output is where rank 0 finally writes; every rank's block goes to a private file first
+    final = None
+    for k in range(len(args) - 1):
+        if args[k] in ("-o", "--output"):
+            final = args[k + 1]
+            del args[k:k + 2]
+            break
+    use_cuda = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    with tempfile.TemporaryDirectory() as tmp:
+        part = os.path.join(tmp, "part.%d" % rank)
+        os.environ["STA_SHARD"] = "%d/%d" % (rank, world)
+        try:
+            rc = (_capi.main_mpileup if sub == "mpileup" else _capi.main_depth)(args + ["-o", part])
+        finally:
+            os.environ.pop("STA_SHARD", None)
+        data = open(part, "rb").read() if os.path.exists(part) else b""
+    local = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev) if data else torch.zeros(0, dtype=torch.uint8, device=dev)
+    rcs = torch.tensor([rc], dtype=torch.int64, device=dev)
+    dist.all_reduce(rcs, op=dist.ReduceOp.MAX)
+    whole = gather_text(local, dst=0)
+    if rank == 0:
+        buf = whole.cpu().numpy().tobytes()
+        if out is not None:
+            out.write(buf)
+        elif final:
+            with open(final, "wb") as fh:
+                fh.write(buf)
+        else:
+            sys.stdout.buffer.write(buf)
+            sys.stdout.buffer.flush()
+    return int(rcs.item())
+
+
+def main() -> int:
+    """torchrun entry: python -m torch.distributed.run --nproc-per-node N -m samtools_amd.shard mpileup -f ref.fa in.bam"""
+    import torch
+    import torch.distributed as dist
+
+    backend = os.environ.get("STA_SHARD_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        # one process per GPU; STA_SHARD_ONE_DEVICE=1 puts every rank on device 0 (the 1-GPU test box)
+        local = 0 if os.environ.get("STA_SHARD_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        os.environ["STA_DEVICE"] = str(local)
+    dist.init_process_group(backend)
+    try:
+        return run_sharded_cli(sys.argv[1:])
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    sys.exit(main())

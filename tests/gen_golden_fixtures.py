@@ -9,7 +9,7 @@ than 16 KiB are stored gzip-compressed.  Run from the repo root in the build con
     python tests/gen_golden_fixtures.py
 
 Sources: /root/reference/test/bedcov/* and test/coverage/* (+ test/dat/sample.sam) copied whole, /root/reference/test/mpileup/{*.sam,*.bam,*.fa,regions,xx.bed*,expected/*.out},
-/root/reference/test/dat/{mpileup.*,view.001.sam}, /root/reference/test/large_pos/*.
+/root/reference/test/dat/{mpileup.*,view.001.sam}, /root/reference/test/large_pos/*, /root/reference/examples/{ex1.sam.gz,ex1.fa}.
 """
 import gzip
 import os
@@ -71,6 +71,9 @@ def main():
     copy(os.path.join(REF, "mpileup", "ce#5b.sam"), os.path.join(OUT, "mpileup", "ce#5b.sam"))
     # the only reference test output that depends on bcf_call_glfgen / errmod_cal (row a14): tview's consensus line
     copy(os.path.join(REF, "large_pos", "tview.expected.out"), os.path.join(OUT, "large_pos", "tview.expected.out"))
+    # BASELINE.json configs[0]: examples/ex1.sam.gz (headerless SAM, @SQ comes from the FASTA index) + ex1.fa
+    for f in ("ex1.sam.gz", "ex1.fa"):
+        copy(os.path.join(os.path.dirname(REF), "examples", f), os.path.join(OUT, "examples", f))
     # mpileup.reg:89 -- read groups of mpileup.1.bam except ERR013140
     d = gzip.open(os.path.join(REF, "mpileup", "mpileup.1.bam")).read()
     rgs = sorted(set(m.group(1).decode() for m in re.finditer(rb"RGZ([A-Z0-9]+)", d)))

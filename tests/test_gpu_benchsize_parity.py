@@ -1,0 +1,136 @@
+"""Byte parity at the configurations bench.py measures.
+
+The engine runs the exact window bench.py times (same generator, same seeds, device-resident arrays through the
+C-ABI) and the sha256 of its text must equal the oracle's for the same reads:
+  * mpileup30     4 194 304 columns, 838 860 reads, BAQ on  (~20-40 s of oracle)
+  * mpileup300    524 288 columns, 1 048 576 reads, BAQ on  (the deep-column emit path + BAQ together)
+  * depth30       8 388 608 columns, -a
+  * engine paths that only an environment variable reaches: chunked BAQ slab (STA_BAQ_SLAB_GIB=1), no side stream
+    for the band-8 groups (STA_BAQ_NO_SIDE_STREAM=1), at 786 432 columns
+  * BASELINE.json configs[0]: examples/ex1.sam.gz (headerless, @SQ from the FASTA) + ex1.fa, SAM and BAM input.
+Needs a GPU: -m gpu.  The oracle is only the checker."""
+import gzip
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def _engine_sha(wl, n_cols, env=None):
+    """sha256 of the engine's text for bench.py's window of workload `wl` (seeds 1 / 42)."""
+    import numpy as np
+    import torch
+    import samtools_amd as sa
+    import bench
+    from synth import synth_ref, synth_reads
+    kind, depth, _, _, _ = bench.WORKLOADS[wl]
+    dev = torch.device("cuda", 0)
+    ref = synth_ref(n_cols, seed=1)
+    rd = synth_reads(ref, depth=depth, read_len=150, seed=42)
+    saved = {}
+    for k, v in (env or {}).items():
+        saved[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        eng = sa.Engine(0, torch.cuda.current_stream().cuda_stream)
+        ref_t = torch.from_numpy(ref.copy()).to(dev)
+        eng.set_reference(0, ref_t.data_ptr(), n_cols, 1)
+        w, keep, _ = bench.build_window(torch, np, sa, rd, n_cols, dev)
+        eng.stage_window(w)
+        if kind == "mpileup":
+            par = sa.MplpParams.defaults(); par.has_fai = 1
+            if wl.endswith("_B"):
+                par.flag &= ~sa.MPLP.REALN
+            info = eng.mpileup_plan(par)
+            out = torch.empty(int(info.out_bytes) + 64, dtype=torch.uint8, device=dev)
+            eng.mpileup_emit(out.data_ptr(), out.numel())
+        else:
+            par = sa.DepthParams.defaults(); par.all_pos = 1
+            info = eng.depth_plan(par)
+            out = torch.empty(int(info.out_bytes) + 64, dtype=torch.uint8, device=dev)
+            eng.depth_emit(out.data_ptr(), out.numel())
+        eng.sync()
+        text = out[:int(info.out_bytes)].cpu().numpy().tobytes()
+        eng.close()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return hashlib.sha256(text).hexdigest(), len(text), int(info.piled_bases)
+
+
+_oracle_cache = {}
+
+
+def _oracle(wl, n_cols):
+    import bench
+    key = (wl, n_cols)
+    if key not in _oracle_cache:
+        o = bench.oracle_text_hash(wl, n_cols)
+        assert o is not None, "oracle binary missing (make -C oracle)"
+        _oracle_cache[key] = (o["sha256"], o["bytes"], o["bases"])
+    return _oracle_cache[key]
+
+
+@pytest.mark.parametrize("wl", ["mpileup30", "mpileup300", "depth30", "mpileup30_B", "mpileup300_B"])
+def test_bench_window_text_is_byte_identical_to_the_oracle(wl):
+    import bench
+    n_cols = bench.WORKLOADS[wl][2]
+    want_sha, want_n, _ = _oracle(wl, n_cols)
+    got_sha, got_n, piled = _engine_sha(wl, n_cols)
+    assert got_n == want_n
+    assert got_sha == want_sha
+    assert piled > 0
+
+
+@pytest.mark.parametrize("env", [{"STA_BAQ_SLAB_GIB": "1"}, {"STA_BAQ_NO_SIDE_STREAM": "1"}, {"STA_BAQ_SLAB_GIB": "1", "STA_BAQ_NO_SIDE_STREAM": "1"}],
+                         ids=["slab1g", "noside", "slab1g_noside"])
+def test_env_only_engine_paths(env):
+    n_cols = 3 << 18      # 786 432 columns: 157 286 reads, a 6.4 GB one-launch slab -> 7 chunks under STA_BAQ_SLAB_GIB=1
+    want_sha, want_n, _ = _oracle("mpileup30", n_cols)
+    got_sha, got_n, _ = _engine_sha("mpileup30", n_cols, env)
+    assert (got_n, got_sha) == (want_n, want_sha)
+
+
+def _ex1(tmp_path):
+    """configs[0]: examples/ex1.sam.gz has no header; `samtools view -bt ex1.fa.fai` takes @SQ from the FASTA index."""
+    from bamio import sam_to_bam
+    gold = os.path.join(HERE, "golden", "examples")
+    fa = os.path.join(gold, "ex1.fa")
+    names, lens = [], []
+    for line in open(fa):
+        if line.startswith(">"):
+            names.append(line[1:].split()[0]); lens.append(0)
+        else:
+            lens[-1] += len(line.strip())
+    sam = str(tmp_path / "ex1.sam")
+    with open(sam, "w") as fh:
+        fh.write("@HD\tVN:1.6\tSO:coordinate\n")
+        for n, l in zip(names, lens):
+            fh.write("@SQ\tSN:%s\tLN:%d\n" % (n, l))
+        fh.write(gzip.open(os.path.join(gold, "ex1.sam.gz"), "rt").read())
+    bam = str(tmp_path / "ex1.bam")
+    sam_to_bam(sam, bam)
+    return sam, bam, fa
+
+
+@pytest.mark.parametrize("opts", [[], ["-B"], ["-E", "-A"], ["-a"], ["-r", "seq2:100-900"]], ids=["default", "B", "EA", "a", "region"])
+def test_config0_ex1(tmp_path, oracle_bin, product_bin, opts):
+    sam, bam, fa = _ex1(tmp_path)
+    want = subprocess.run([oracle_bin, "mpileup"] + opts + ["-f", fa, sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    assert want.count(b"\n") > 1000
+    for inp in (sam, bam):
+        got = subprocess.run([product_bin, "mpileup"] + opts + ["-f", fa, inp], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert got.returncode == 0, got.stderr.decode()[-400:]
+        assert got.stdout == want
+    d_want = subprocess.run([oracle_bin, "depth", "-a", sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    d_got = subprocess.run([product_bin, "depth", "-a", bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert d_got.returncode == 0 and d_got.stdout == d_want

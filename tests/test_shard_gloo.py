@@ -29,20 +29,23 @@ def _worker(rank, world, port, contigs, wcols, q):
     mine = shard.windows_of_rank(wins, rank, world)
     text = b"".join(fake_window_text(*wins[i]) for i in mine)
     local = torch.frombuffer(bytearray(text), dtype=torch.uint8) if text else torch.zeros(0, dtype=torch.uint8)
-    parts = shard.gather_text(local, dst=0)
-    # the steady-state form bench.py uses: sizes exchanged once, reusable padded buffers, asynchronous gather
+    whole = shard.gather_text(local, dst=0)
+    # the steady-state form bench.py uses: sizes exchanged once, a reusable (larger) send buffer, one reusable receive buffer,
+    # grouped point-to-point transfers of the TRUE sizes (nothing padded), two gathers in flight
     sizes = shard.exchange_sizes(local.numel(), local.device)
-    cap = max(max(sizes), 1)
-    padded = torch.zeros(cap + 5, dtype=torch.uint8)
+    padded = torch.zeros(local.numel() + 5, dtype=torch.uint8)
     padded[:local.numel()] = local
-    recv = [torch.empty(cap, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
-    pend = [shard.gather_text(padded, dst=0, sizes=sizes, recv=recv, async_op=True) for _ in range(2)]
-    parts2 = [p.wait() for p in pend][-1]
+    recv = [torch.empty(max(sum(sizes), 1), dtype=torch.uint8) for _ in range(2)] if rank == 0 else [None, None]
+    pend = [shard.gather_text_v(padded, local.numel(), dst=0, sizes=sizes, recv=recv[k]) for k in range(2)]
+    for p in pend:
+        shard.wait_all(p)
     if rank == 0:
-        assert [bytes(p.numpy().tobytes()) for p in parts] == [bytes(p.numpy().tobytes()) for p in parts2]
-        q.put(b"".join(bytes(p.numpy().tobytes()) for p in parts))
+        assert sum(sizes) == whole.numel()
+        for k in range(2):
+            assert bytes(recv[k][:sum(sizes)].numpy().tobytes()) == bytes(whole.numpy().tobytes())
+        q.put(bytes(whole.numpy().tobytes()))
     else:
-        assert parts is None and parts2 is None
+        assert whole is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,3 +80,17 @@ def test_window_ownership_is_a_partition():
         sizes = [len(shard.windows_of_rank(wins, r, world)) for r in range(world)]
         assert max(sizes) - min(sizes) <= 1
     assert shard.halo_columns(151) == 302
+
+
+def test_blocks_partition_the_columns_and_read_ranges_cover_them():
+    import numpy as np
+    rng = np.random.default_rng(5)
+    pos = np.sort(rng.integers(0, 100000, 5000))
+    for world in (1, 2, 3, 8):
+        blocks = [shard.block_of(r, world, 100003) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == 100003
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+        for b, e in blocks:
+            lo, hi = shard.read_range(pos, b, e, halo=300)
+            assert np.all(pos[lo:hi] >= b - 300) and np.all(pos[lo:hi] < e + 300)
+            assert (lo == 0 or pos[lo - 1] < b - 300) and (hi == len(pos) or pos[hi] >= e + 300)

@@ -217,7 +217,7 @@ extern "C" int sta_main_coverage(int argc, char **argv)
     cp.min_mq = opt_min_mapQ; cp.rflag_require = required_flags; cp.rflag_filter = fail_flags; cp.min_qlen = opt_min_len;
     int64_t window_cols = 1 << 22;
     if (const char *e = getenv("STA_WINDOW_COLS")) window_cols = std::max<long long>(1, atoll(e));
-    PumpConfig pc; pc.window_cols = window_cols; pc.max_reads = 4 << 20; pc.use_endpos = false;
+    PumpConfig pc; pc.window_cols = window_cols; pc.max_reads = 4 << 20; pc.use_endpos = false; pc.nref_limit = readers[0]->header().nref();
     Pump pump(readers, pc);
     int status = 0, last_tid = -1;
     bool warn = false;
@@ -340,7 +340,7 @@ extern "C" int sta_main_bedcov(int argc, char **argv)
             readers.push_back(std::move(r));
         }
         CovAccum acc((size_t)n);
-        PumpConfig pc; pc.window_cols = 1 << 22; pc.max_reads = 4 << 20; pc.use_endpos = false;
+        PumpConfig pc; pc.window_cols = 1 << 22; pc.max_reads = 4 << 20; pc.use_endpos = false; pc.nref_limit = h0.nref();
         Pump pump(readers, pc);
         int t0 = pump.next_tid();
         if (!pump.error() && t0 == tid && end > beg) {

@@ -41,7 +41,7 @@ extern "C" int sta_main_glf(int argc, char **argv)
     if (sta_engine_create(&eng, 0, nullptr) != STA_OK) { fprintf(stderr, "samtools glf: no usable HIP device\n"); return 2; }
     int64_t window_cols = 1 << 20;
     if (const char *e = getenv("STA_WINDOW_COLS")) window_cols = std::max<long long>(1, atoll(e));
-    PumpConfig pc; pc.window_cols = window_cols; pc.use_endpos = false;
+    PumpConfig pc; pc.window_cols = window_cols; pc.use_endpos = false; pc.nref_limit = readers[0]->header().nref();
     Pump pump(readers, pc);
     StagedFile staged;
     std::vector<std::vector<const Rec *>> reads;

@@ -523,6 +523,48 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
     return STA_OK;
 }
 
+// Restores the engine's pipeline mode and reference view on every exit path of a plan that borrows mpileup_pipeline()
+// (the binary-entry, coverage and glf plans run it without a reference and stop it early): an early HIP-error return
+// must not leave a pooled engine in the wrong mode.
+struct ModeGuard {
+    sta_engine *e; const char *ref; int64_t len;
+    ModeGuard(sta_engine *e_, bool plp, bool cov) : e(e_), ref(e_->wd.ref), len(e_->wd.ref_len)
+    {
+        e->plp_mode = plp; e->cov_mode = cov;
+        e->wd.ref = nullptr; e->wd.ref_len = 0;      // the plain iterator has no contig-length filter and no BAQ
+    }
+    ~ModeGuard() { e->plp_mode = false; e->cov_mode = false; e->wd.ref = ref; e->wd.ref_len = len; }
+};
+
+// coordinate span of the staged reads, for the exact -d replay (rare path: only after the detector fired)
+static int maxcnt_bounds(sta_engine *e)
+{
+    for (size_t f = 0; f < e->files_h.size(); ++f) {
+        StaReadsDev &d = e->files_h[f];
+        if (!d.n) continue;
+        int32_t first = 0, lastmax = 0, lastpos = 0;
+        HIPCHK(hipMemcpy(&first, d.pos, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&lastmax, d.maxend + (d.n - 1), 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&lastpos, d.pos + (d.n - 1), 4, hipMemcpyDeviceToHost));
+        e->min_pos[f] = first;
+        e->max_pos_hint[f] = lastmax > lastpos ? lastmax : lastpos;
+    }
+    return STA_OK;
+}
+
+// pipeline without the text measuring pass (cov_mode), re-run with the exact -d replay when the detector asks for it
+static int counting_pipeline(sta_engine *e, const sta_mplp_params *p)
+{
+    int rc = mpileup_pipeline(e, p, false);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost));
+    if (!e->ctr_h.maxcnt_flag) return STA_OK;
+    rc = maxcnt_bounds(e);
+    if (rc) return rc;
+    return mpileup_pipeline(e, p, true);
+}
+
 int sta_mpileup_plan(sta_engine *e, const sta_mplp_params *p, sta_plan_info *info)
 {
     if (!e || !p) return STA_ERR_ARG;
@@ -544,17 +586,8 @@ int sta_mpileup_plan(sta_engine *e, const sta_mplp_params *p, sta_plan_info *inf
     if (e->ctr_h.maxcnt_flag) {
         // The cap may trigger somewhere in this window: find the coordinate span of the reads, then
         // re-run the pipeline with the exact replay inserted.
-        for (size_t f = 0; f < e->files_h.size(); ++f) {
-            StaReadsDev &d = e->files_h[f];
-            if (!d.n) continue;
-            int32_t first = 0, lastmax = 0;
-            HIPCHK(hipMemcpy(&first, d.pos, 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(&lastmax, d.maxend + (d.n - 1), 4, hipMemcpyDeviceToHost));
-            int32_t lastpos = 0;
-            HIPCHK(hipMemcpy(&lastpos, d.pos + (d.n - 1), 4, hipMemcpyDeviceToHost));
-            e->min_pos[f] = first;
-            e->max_pos_hint[f] = lastmax > lastpos ? lastmax : lastpos;
-        }
+        rc = maxcnt_bounds(e);
+        if (rc) return rc;
         rc = mpileup_pipeline(e, p, true);
         if (rc) return rc;
         rc = finish_plan(e, ncols, info);
@@ -602,28 +635,20 @@ int sta_plp_plan(sta_engine *e, int32_t max_depth, int32_t overlaps, sta_plan_in
     p.max_depth = max_depth;
     p.flag = overlaps ? STA_MPLP_SMART_OVERLAPS : 0;     // bam_plp_push drops unmapped reads only; callers filter in their callback
     e->mp = p;
-    // the reference (if one was set for another use of this engine) must not trigger the "read beyond the FASTA" filter
-    const char *saved_ref = e->wd.ref; int64_t saved_len = e->wd.ref_len;
-    e->wd.ref = nullptr; e->wd.ref_len = 0;
     int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
     e->min_pos.assign(e->files_h.size(), 0); e->max_pos_hint.assign(e->files_h.size(), 0);
-    e->plp_mode = true;
-    int rc = mpileup_pipeline(e, &p, false);
-    if (!rc) rc = finish_plan(e, ncols, info);
-    if (!rc && e->ctr_h.maxcnt_flag) {
-        StaReadsDev &d = e->files_h[0];
-        if (d.n) {
-            int32_t first = 0, lastmax = 0, lastpos = 0;
-            HIPCHK(hipMemcpy(&first, d.pos, 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(&lastmax, d.maxend + (d.n - 1), 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(&lastpos, d.pos + (d.n - 1), 4, hipMemcpyDeviceToHost));
-            e->min_pos[0] = first; e->max_pos_hint[0] = lastmax > lastpos ? lastmax : lastpos;
-        }
-        rc = mpileup_pipeline(e, &p, true);
+    int rc;
+    {
+        // no reference here: one set for another use of this engine must not trigger the "read beyond the FASTA" filter
+        ModeGuard guard(e, true, false);
+        rc = mpileup_pipeline(e, &p, false);
         if (!rc) rc = finish_plan(e, ncols, info);
+        if (!rc && e->ctr_h.maxcnt_flag) {
+            rc = maxcnt_bounds(e);
+            if (!rc) rc = mpileup_pipeline(e, &p, true);
+            if (!rc) rc = finish_plan(e, ncols, info);
+        }
     }
-    e->plp_mode = false;
-    e->wd.ref = saved_ref; e->wd.ref_len = saved_len;
     if (rc) return rc;
     e->out_bytes *= 16;                                   // offsets were scanned in entries
     if (info) info->out_bytes = e->out_bytes;
@@ -677,32 +702,14 @@ int sta_cov_plan(sta_engine *e, const sta_cov_params *cp, sta_cov_totals *totals
     sta_mplp_params p; memset(&p, 0, sizeof p);
     p.max_depth = cp->max_depth; p.min_mq = cp->min_mq; p.rflag_require = cp->rflag_require; p.rflag_filter = cp->rflag_filter; p.min_qlen = cp->min_qlen;
     e->mp = p;
-    const char *saved_ref = e->wd.ref; int64_t saved_len = e->wd.ref_len;
-    e->wd.ref = nullptr; e->wd.ref_len = 0;
     e->min_pos.assign(e->files_h.size(), 0); e->max_pos_hint.assign(e->files_h.size(), 0);
     const size_t nf = e->files_h.size();
     if (e->cov_out.ensure((5 + nf * 2) * 8 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
-    e->cov_mode = true;
-    int rc = mpileup_pipeline(e, &p, false);
-    if (!rc) { hipError_t r_ = hipStreamSynchronize(e->stream); if (r_ != hipSuccess) rc = hipfail(e, r_, "sync"); }
-    if (!rc) {
-        HIPCHK(hipMemcpy(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost));
-        if (e->ctr_h.maxcnt_flag) {
-            for (size_t f = 0; f < nf; ++f) {
-                StaReadsDev &d = e->files_h[f];
-                if (!d.n) continue;
-                int32_t first = 0, lastmax = 0, lastpos = 0;
-                HIPCHK(hipMemcpy(&first, d.pos, 4, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(&lastmax, d.maxend + (d.n - 1), 4, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(&lastpos, d.pos + (d.n - 1), 4, hipMemcpyDeviceToHost));
-                e->min_pos[f] = first; e->max_pos_hint[f] = lastmax > lastpos ? lastmax : lastpos;
-            }
-            rc = mpileup_pipeline(e, &p, true);
-        }
+    {
+        ModeGuard guard(e, false, true);
+        int rc = counting_pipeline(e, &p);
+        if (rc) return rc;
     }
-    e->cov_mode = false;
-    e->wd.ref = saved_ref; e->wd.ref_len = saved_len;
-    if (rc) return rc;
     HIPCHK(hipMemsetAsync(e->cov_out.p, 0, (5 + nf * 2) * 8, e->stream));
     {
         ProfScope ps(e, "cov_cols");
@@ -740,31 +747,14 @@ int sta_glf_plan(sta_engine *e, const sta_glf_params *gp, sta_plan_info *info)
     sta_mplp_params p; memset(&p, 0, sizeof p);
     p.max_depth = gp->max_depth > 0 ? gp->max_depth : 8000;
     e->mp = p;
-    const char *saved_ref = e->wd.ref; int64_t saved_len = e->wd.ref_len;
-    e->wd.ref = nullptr; e->wd.ref_len = 0;          // the plain iterator has no contig-length filter and no BAQ
+    const char *saved_ref = e->wd.ref; const int64_t saved_len = e->wd.ref_len;     // the column's reference base for k_glf_cols
     e->min_pos.assign(e->files_h.size(), 0); e->max_pos_hint.assign(e->files_h.size(), 0);
     const size_t nf = e->files_h.size();
-    e->cov_mode = true;
-    int rc = mpileup_pipeline(e, &p, false);
-    if (!rc) { hipError_t r_ = hipStreamSynchronize(e->stream); if (r_ != hipSuccess) rc = hipfail(e, r_, "sync"); }
-    if (!rc) {
-        HIPCHK(hipMemcpy(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost));
-        if (e->ctr_h.maxcnt_flag) {
-            for (size_t f = 0; f < nf; ++f) {
-                StaReadsDev &d = e->files_h[f];
-                if (!d.n) continue;
-                int32_t first = 0, lastmax = 0, lastpos = 0;
-                HIPCHK(hipMemcpy(&first, d.pos, 4, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(&lastmax, d.maxend + (d.n - 1), 4, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(&lastpos, d.pos + (d.n - 1), 4, hipMemcpyDeviceToHost));
-                e->min_pos[f] = first; e->max_pos_hint[f] = lastmax > lastpos ? lastmax : lastpos;
-            }
-            rc = mpileup_pipeline(e, &p, true);
-        }
+    {
+        ModeGuard guard(e, false, true);
+        int rc = counting_pipeline(e, &p);
+        if (rc) return rc;
     }
-    e->cov_mode = false;
-    e->wd.ref = saved_ref; e->wd.ref_len = saved_len;
-    if (rc) return rc;
     const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
     const uint64_t bytes = (uint64_t)(ncols > 0 ? ncols : 0) * nf * sizeof(sta_glf_col);
     if (e->out.ensure(bytes + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(output) failed");

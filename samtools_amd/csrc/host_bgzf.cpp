@@ -227,14 +227,11 @@ std::unique_ptr<ByteSource> ByteSource::open(const std::string &path, int thread
     if (path != "-") {
         FILE *fp = fopen(path.c_str(), "rb");
         if (!fp) { if (err) *err = "failed to open " + path; return nullptr; }
+        setvbuf(fp, nullptr, _IOFBF, 1 << 20);      // before any other operation on the stream (ISO C 7.21.5.6)
         uint8_t h[64];
         size_t n = fread(h, 1, sizeof h, fp);
-        if (looks_like_bgzf(h, n)) {
-            if (fseek(fp, 0, SEEK_SET) == 0) {
-                setvbuf(fp, nullptr, _IOFBF, 1 << 20);
-                return std::unique_ptr<ByteSource>(new BgzfSource(fp, threads));
-            }
-        }
+        if (looks_like_bgzf(h, n) && fseek(fp, 0, SEEK_SET) == 0)
+            return std::unique_ptr<ByteSource>(new BgzfSource(fp, threads));
         fclose(fp);
     }
     gzFile g = path == "-" ? gzdopen(fileno(stdin), "rb") : gzopen(path.c_str(), "rb");

@@ -154,6 +154,7 @@ bool ChunkPump::settle(File &f)
         }
         const Chunk &c = *f.cur; const size_t k = (size_t)f.idx;
         if (c.tid[k] < 0) { ++f.idx; continue; }                    // unplaced reads never reach the engines
+        if (c.tid[k] >= cfg_.nref_limit) { f.eof = true; err_ = -3; errtxt_ = "a record names a reference sequence that is not in the first input's header"; return false; }
         const bool before = c.tid[k] < f.last_tid || (c.tid[k] == f.last_tid && c.pos[k] < f.last_pos);
         if (!(c.flag[k] & 4)) {
             if (before) { f.eof = true; err_ = -2; errtxt_ = "the input is not position sorted"; return false; }

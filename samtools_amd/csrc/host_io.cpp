@@ -1,5 +1,6 @@
 // host_io.cpp -- SAM/BAM/FASTA/BED decoding for the drivers (see host_io.h).
 #include "host_io.h"
+#include <climits>
 #include "host_bgzf.h"
 #include <condition_variable>
 #include <deque>
@@ -40,6 +41,7 @@ struct AlnReader::Impl {
     std::vector<uint8_t> buf; size_t bp = 0, bl = 0; bool eof = false;
     std::string line; bool have_line = false;
     std::vector<uint8_t> blk;
+    int32_t n_ref = INT32_MAX;       // BAM: references in the header (records naming a refID beyond it are malformed)
 
     // ---- parse-ahead: a background thread decodes records into batches, next() hands them out in order ----
     struct Batch { std::vector<Rec> r; size_t n = 0; };
@@ -150,9 +152,12 @@ std::unique_ptr<AlnReader> AlnReader::open(const std::string &path, std::string 
         if (im.read(&r->hdr_.text[0], (size_t)l_text) != (size_t)l_text) { if (err) *err = "truncated BAM header"; return nullptr; }
         while (!r->hdr_.text.empty() && r->hdr_.text.back() == '\0') r->hdr_.text.pop_back();
         if (im.read(&n_ref, 4) != 4) { if (err) *err = "truncated BAM header"; return nullptr; }
+        if (n_ref < 0) { if (err) *err = "invalid BAM header (negative n_ref)"; return nullptr; }
+        im.n_ref = n_ref;
         for (int i = 0; i < n_ref; ++i) {
             int32_t l_name = 0, l_ref = 0;
             if (im.read(&l_name, 4) != 4) return nullptr;
+            if (l_name <= 0 || l_name > (1 << 20)) { if (err) *err = "invalid BAM header (reference name length)"; return nullptr; }
             std::string nm((size_t)l_name, '\0');
             if (im.read(&nm[0], (size_t)l_name) != (size_t)l_name) return nullptr;
             while (!nm.empty() && nm.back() == '\0') nm.pop_back();
@@ -264,7 +269,7 @@ int AlnReader::next_raw(Rec &r)
     return parse_sam(hdr_, im.line, r, im.want.empty() ? nullptr : &im.want);
 }
 
-static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::string> &wanted, Rec &r);
+static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::string> &wanted, Rec &r, int32_t n_ref);
 
 static int parse_bam(AlnReader::Impl &im, Rec &r)
 {
@@ -274,11 +279,11 @@ static int parse_bam(AlnReader::Impl &im, Rec &r)
     if (n != 4 || bs < 32) return -2;
     if (im.blk.size() < (size_t)bs) im.blk.resize((size_t)bs * 2);
     if (im.read(im.blk.data(), (size_t)bs) != (size_t)bs) return -2;
-    return parse_bam_mem(im.blk.data(), bs, im.want, r);
+    return parse_bam_mem(im.blk.data(), bs, im.want, r, im.n_ref);
 }
 
 // one BAM alignment record (SAM spec 4.2) of bs bytes, block_size prefix already consumed
-static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::string> &wanted, Rec &r)
+static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::string> &wanted, Rec &r, int32_t n_ref)
 {
     int32_t refID, pos, l_seq, nref, npos, tlen; uint16_t n_cig, flag;
     memcpy(&refID, b, 4); memcpy(&pos, b + 4, 4);
@@ -287,6 +292,8 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
     memcpy(&nref, b + 20, 4); memcpy(&npos, b + 24, 4); memcpy(&tlen, b + 28, 4);
     size_t need = 32 + (size_t)l_rn + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
     if ((size_t)bs < need || l_seq < 0) return -2;
+    // sam.c bam_read1: ids beyond the header are an error, not data
+    if (refID < -1 || refID >= n_ref || nref < -1 || nref >= n_ref) return -2;
     size_t o = 32;
     r.qname.assign((const char *)b + o, l_rn ? l_rn - 1u : 0u); o += l_rn;
     r.cigar.resize(n_cig); if (n_cig) memcpy(r.cigar.data(), b + o, 4 * (size_t)n_cig); o += 4 * (size_t)n_cig;
@@ -297,15 +304,33 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
     const uint8_t *p = b + o, *e = b + bs;
     const bool want = !wanted.empty();
     if (want) { r.tagtext.assign(wanted.size(), std::string()); r.tag_has.assign(wanted.size(), 0); }
+    const uint8_t *cg = nullptr; uint32_t cg_n = 0;          // CG:B,I: the real CIGAR of a read with more than 65535 operations
     while (p + 3 <= e) {
         int t = p[2]; const uint8_t *tag = p; p += 3;
+        // size of the value, checked against the record end before anything is read (a truncated field is a malformed record)
+        size_t vlen;
+        if (t == 'Z' || t == 'H') {
+            const uint8_t *q = (const uint8_t *)memchr(p, 0, (size_t)(e - p));
+            if (!q) return -2;
+            vlen = (size_t)(q - p) + 1;
+        } else if (t == 'B') {
+            if (p + 5 > e) return -2;
+            int sz = aux_size(p[0]); uint32_t cnt; memcpy(&cnt, p + 1, 4);
+            if (!sz || (uint64_t)sz * cnt > (uint64_t)(e - p - 5)) return -2;
+            vlen = 5 + (size_t)sz * cnt;
+            if (tag[0] == 'C' && tag[1] == 'G' && p[0] == 'I') { cg = p + 5; cg_n = cnt; }
+        } else {
+            int sz = aux_size(t);
+            if (!sz || p + sz > e) return -2;
+            vlen = (size_t)sz;
+        }
         if (want)
             for (size_t w = 0; w < wanted.size(); ++w)
                 if (!r.tag_has[w] && wanted[w][0] == (char)tag[0] && wanted[w][1] == (char)tag[1]) {
                     r.tag_has[w] = 1;
                     std::string &out = r.tagtext[w];
                     char nb[64];
-                    if (t == 'Z' || t == 'H') { const uint8_t *q = p; while (q < e && *q) ++q; out.assign((const char *)p, (size_t)(q - p)); }
+                    if (t == 'Z' || t == 'H') out.assign((const char *)p, vlen - 1);
                     else if (t == 'A') out.assign(1, (char)p[0]);
                     else if (t == 'c') { snprintf(nb, sizeof nb, "%d", (int)(int8_t)p[0]); out = nb; }
                     else if (t == 'C') { snprintf(nb, sizeof nb, "%d", (int)p[0]); out = nb; }
@@ -317,19 +342,18 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
                     else if (t == 'd') { double v; memcpy(&v, p, 8); snprintf(nb, sizeof nb, "%g", v); out = nb; }
                     else out = "*";
                 }
-        if (t == 'Z' || t == 'H') {
-            const uint8_t *s = p; while (p < e && *p) ++p;
-            if (t == 'Z') {
-                if (tag[0] == 'R' && tag[1] == 'G') r.rg.assign((const char *)s, (size_t)(p - s));
-                else if (tag[0] == 'B' && tag[1] == 'Q') { r.has_bq = true; r.bq.assign(s, p); }
-                else if (tag[0] == 'Z' && tag[1] == 'Q') r.has_zq = true;
-            }
-            ++p;
-        } else if (t == 'B') {
-            if (p + 5 > e) break;
-            int sz = aux_size(p[0]); uint32_t cnt; memcpy(&cnt, p + 1, 4);
-            p += 5 + (size_t)sz * cnt;
-        } else { int sz = aux_size(t); if (!sz) break; p += sz; }
+        if (t == 'Z') {
+            if (tag[0] == 'R' && tag[1] == 'G') r.rg.assign((const char *)p, vlen - 1);
+            else if (tag[0] == 'B' && tag[1] == 'Q') { r.has_bq = true; r.bq.assign(p, p + vlen - 1); }
+            else if (tag[0] == 'Z' && tag[1] == 'Q') r.has_zq = true;
+        }
+        p += vlen;
+    }
+    // SAM spec 4.2.2 / sam.c bam_tag2cigar: a CIGAR of more than 65535 operations is stored in CG:B,I and the record carries
+    // the placeholder <l_seq>S<ref span>N
+    if (cg && n_cig == 2 && (r.cigar[0] & 0xf) == 4 && (int64_t)(r.cigar[0] >> 4) == (int64_t)l_seq && (r.cigar[1] & 0xf) == 3) {
+        r.cigar.resize(cg_n);
+        if (cg_n) memcpy(r.cigar.data(), cg, 4 * (size_t)cg_n);
     }
     finish_rec(r);
     return 1;
@@ -380,7 +404,7 @@ int AlnReader::parse_raw(const uint8_t *p, size_t avail, size_t *used, Rec &r, s
         int32_t bs; memcpy(&bs, p, 4);
         if (bs < 32 || (size_t)bs + 4 > avail) return -2;
         *used = (size_t)bs + 4;
-        return parse_bam_mem(p + 4, bs, im.want, r);
+        return parse_bam_mem(p + 4, bs, im.want, r, im.n_ref);
     }
     const uint8_t *nl = (const uint8_t *)memchr(p, '\n', avail);
     if (!nl) return -2;

@@ -22,6 +22,7 @@ void Pump::advance(size_t f)
         if (r == 0) { eof_[f] = 1; return; }
         if (r < 0) { eof_[f] = 1; err_ = -1; errtxt_ = "error reading from input file"; return; }
         if (pend_[f].tid < 0) continue;              // unplaced reads never reach the engines
+        if (pend_[f].tid >= cfg_.nref_limit) { eof_[f] = 1; err_ = -3; errtxt_ = "a record names a reference sequence that is not in the first input's header"; return; }
         if (!(pend_[f].flag & 4)) {
             if (pend_[f].tid < last_tid_[f] || (pend_[f].tid == last_tid_[f] && pend_[f].pos < last_pos_[f])) {
                 eof_[f] = 1; err_ = -2; errtxt_ = "the input is not position sorted";

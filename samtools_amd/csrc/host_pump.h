@@ -31,6 +31,9 @@ struct PumpConfig {
     // staging options of fill_staged(): -G read groups to mark STA_AUX_SKIP, --output-extra columns formatted on the host
     const std::set<std::string> *rg_excl = nullptr;
     bool xs_rnext = false; int xs_n_tags = 0; char xs_empty = '*';
+    // contigs of the header the driver prints from (the first input's): a record of any input naming a later one is an error
+    // instead of an out-of-range name / length lookup
+    int nref_limit = INT32_MAX;
 };
 
 // What the window loops of the drivers need from an input lane (Pump below: one decoded record at a time; ChunkPump in

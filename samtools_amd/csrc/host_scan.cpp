@@ -55,7 +55,7 @@ extern "C" int sta_io_scan(const char *path, int threads, int stage, uint64_t *n
         // what driver_mpileup does between the reader and sta_stage_window, minus the device: stage 1 = one decoded record
         // at a time (Pump), stage 2 = chunk slices (ChunkPump); both must stage byte-identical windows.  The overlap
         // lookahead and mate keeping of the mpileup driver are switched on so that they are part of the comparison.
-        PumpConfig pc; pc.window_cols = 1 << 20;
+        PumpConfig pc; pc.window_cols = 1 << 20; pc.nref_limit = readers[0]->header().nref();
         if (const char *e = getenv("STA_WINDOW_COLS")) pc.window_cols = std::max<long long>(1, atoll(e));
         if (const char *e = getenv("STA_WINDOW_READS")) pc.max_reads = std::max<long long>(1, atoll(e));
         pc.keep_mates = true;

@@ -419,8 +419,9 @@ void sta_bam_plp_destroy(sta_bam_plp_t it)
     clear_reads(it);
     free(it->tmp.data);
     if (it->eng) {
+        // an engine that reported an error is not reused by a later iterator
         std::unique_lock<std::mutex> g(g_engine_pool_m);
-        if (g_engine_pool.size() < 8) g_engine_pool.push_back(it->eng);
+        if (!it->error && g_engine_pool.size() < 8) g_engine_pool.push_back(it->eng);
         else sta_engine_destroy(it->eng);
     }
     delete it;

@@ -13,7 +13,7 @@
  *   bam_plbuf.c:40-69        (bam_plbuf_* wrapper)               bam_plp_init, bam_plp_push, bam_plp64_next,
  *                                                                bam_plp_reset, bam_plp_destroy
  *   bedcov.c:303-335, coverage.c:572-589, cut_target.c:223-248   bam_mplp_init/_auto, bam_plp_init/_auto, set_maxcnt
- *   bam_plcmd.c:119, bam_tview.c:223,255                         bam_plp_insertion
+ *   bam_plcmd.c:119, bam_tview.c:223,255                         bam_plp_insertion_mod, bam_plp_insertion
  *   bam_plbuf.h:45-51                                            bam_plbuf_init/_push/_reset/_destroy
  *
  * Every symbol is exported with an `sta_` prefix so that the library can be loaded next to a real
@@ -79,6 +79,7 @@ typedef struct bam_pileup1_t {
 } bam_pileup1_t;
 
 typedef struct kstring_t { size_t l, m; char *s; } kstring_t;
+typedef struct hts_base_mod_state hts_base_mod_state;      /* HTSlib's MM/ML parser state: opaque here */
 
 #define bam_get_qname(b) ((char *)(b)->data)
 #define bam_get_cigar(b) ((uint32_t *)((b)->data + (b)->core.l_qname))
@@ -108,6 +109,9 @@ void sta_bam_plp_constructor(sta_bam_plp_t iter, int (*func)(void *data, const b
 void sta_bam_plp_destructor(sta_bam_plp_t iter, int (*func)(void *data, const bam1_t *b, bam_pileup_cd *cd));
 /* inserted sequence after p (pads as '*'), returns its length incl. pads or <0; *del_len = deletion that follows it */
 int sta_bam_plp_insertion(const bam_pileup1_t *p, kstring_t *ins, int *del_len);
+/* the form bam_plcmd.c:119 calls: m == NULL (no --output-mods) is bam_plp_insertion; a non-NULL HTSlib state cannot be
+ * interpreted by this library and yields the plain inserted bases */
+int sta_bam_plp_insertion_mod(const bam_pileup1_t *p, hts_base_mod_state *m, kstring_t *ins, int *del_len);
 
 /* ---- multi-file iterator (HTSlib bam_mplp_*) ---- */
 sta_bam_mplp_t sta_bam_mplp_init(int n, sta_bam_plp_auto_f func, void **data);
@@ -150,6 +154,7 @@ void sta_bam_plp_set_batch(sta_bam_plp_t iter, int n_records);
 #define bam_plp_constructor sta_bam_plp_constructor
 #define bam_plp_destructor sta_bam_plp_destructor
 #define bam_plp_insertion sta_bam_plp_insertion
+#define bam_plp_insertion_mod sta_bam_plp_insertion_mod
 #define bam_mplp_init sta_bam_mplp_init
 #define bam_mplp_destroy sta_bam_mplp_destroy
 #define bam_mplp_set_maxcnt sta_bam_mplp_set_maxcnt

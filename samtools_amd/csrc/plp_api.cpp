@@ -521,6 +521,15 @@ int sta_bam_plp_insertion(const bam_pileup1_t *p, kstring_t *ins, int *del_len)
     return indel;
 }
 
+// bam_plcmd.c:119 calls the _mod form; with no modification state (m == NULL, i.e. without --output-mods) HTSlib's
+// bam_plp_insertion_mod is bam_plp_insertion.  A non-NULL state belongs to HTSlib's MM/ML parser (hts_base_mod_state is its
+// opaque type): this library cannot interpret it, so the inserted bases are returned without modification annotations.
+int sta_bam_plp_insertion_mod(const bam_pileup1_t *p, hts_base_mod_state *m, kstring_t *ins, int *del_len)
+{
+    (void)m;
+    return sta_bam_plp_insertion(p, ins, del_len);
+}
+
 }  // extern "C"
 
 // ---- multi-file iterator ----

@@ -1,0 +1,16 @@
+"""Builds tests/cabi/plp_client.c -- a plain-C99 client that sees nothing but include/samtools_amd_plp.h and the shared
+library -- exactly the way a samtools source file would be switched over: STA_PLP_DROPIN + -lsamtools_amd."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def build_client(outdir):
+    exe = os.path.join(str(outdir), "plp_client")
+    lib = os.path.join(REPO, "samtools_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O2", "-DSTA_PLP_DROPIN",
+                    "-I", os.path.join(REPO, "include"), os.path.join(HERE, "cabi", "plp_client.c"),
+                    "-L", lib, "-lsamtools_amd", "-Wl,-rpath," + lib, "-o", exe], check=True)
+    return exe

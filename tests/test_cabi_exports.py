@@ -149,3 +149,22 @@ def test_product_sources_never_touch_the_oracle():
     # and the library does not link it
     out = subprocess.run(["ldd", LIB], stdout=subprocess.PIPE, check=True).stdout.decode()
     assert "oracle" not in out
+
+
+def test_external_c99_client_builds_against_the_public_header_only(tmp_path):
+    """tests/cabi/plp_client.c includes nothing of ours but include/samtools_amd_plp.h, uses the unprefixed HTSlib names
+    (STA_PLP_DROPIN) and links -lsamtools_amd: it must build as pedantic C99 and, without a device, fail loudly."""
+    from cabi_client import build_client
+    exe = build_client(tmp_path)
+    src = open(os.path.join(REPO, "tests", "cabi", "plp_client.c")).read()
+    incs = re.findall(r'#include\s+"([^"]+)"', src)
+    assert incs == ["samtools_amd_plp.h"], incs
+    needed = subprocess.run(["readelf", "-d", exe], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert "libsamtools_amd.so" in needed
+    lib = ctypes.CDLL(LIB)
+    lib.sta_device_count.restype = ctypes.c_int
+    if lib.sta_device_count() > 0:
+        return
+    for mode in ([], ["-p"]):
+        p = subprocess.run([exe] + mode + [os.path.join(REPO, "tests", "golden", "mpileup", "mp_D.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode != 0 and p.stdout == b"" and b"HIP device" in p.stderr

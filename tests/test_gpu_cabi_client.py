@@ -1,0 +1,54 @@
+"""The drop-in boundary exercised from OUTSIDE the library: tests/cabi/plp_client.c is plain C99, built
+with `gcc -std=c99 -DSTA_PLP_DROPIN -Iinclude ... -lsamtools_amd` (no private headers), written like the reference's own
+small pileup clients (bedcov.c:303-335 pull loop, bam_plbuf.c:40-69 push loop, bam_plcmd.c:119 bam_plp_insertion_mod).
+Every bam_pileup1_t field of every column it is handed must equal the oracle's restated HTSlib iterator.  -m gpu."""
+import os
+import subprocess
+
+import pytest
+
+from cabi_client import build_client
+from synth import write_synth_sam
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SAMS = {
+    "mpileup1": [os.path.join(G, "dat", "mpileup.1.sam")],
+    "three_files": [os.path.join(G, "dat", "mpileup.%d.sam" % i) for i in (1, 2, 3)],
+    "overlap50": [os.path.join(G, "mpileup", "overlap50.sam")],
+    "mp_D": [os.path.join(G, "mpileup", "mp_D.sam")], "mp_DI": [os.path.join(G, "mpileup", "mp_DI.sam")],
+    "mp_I": [os.path.join(G, "mpileup", "mp_I.sam")], "mp_ID": [os.path.join(G, "mpileup", "mp_ID.sam")],
+    "mp_N2": [os.path.join(G, "mpileup", "mp_N2.sam")], "mp_P": [os.path.join(G, "mpileup", "mp_P.sam")],
+    "depth3": [os.path.join(G, "mpileup", "xx#depth3.sam")],
+}
+
+
+@pytest.fixture(scope="module")
+def client(tmp_path_factory):
+    return build_client(tmp_path_factory.mktemp("cabi"))
+
+
+def _diff(oracle_bin, client, args, env=None):
+    want = subprocess.run([oracle_bin, "plpdump"] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    got = subprocess.run([client] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
+    assert got.returncode == 0, got.stderr.decode()[-500:]
+    if got.stdout != want:
+        for i, (a, b) in enumerate(zip(got.stdout.split(b"\n"), want.split(b"\n"))):
+            assert a == b, "column record %d differs\n got: %r\nwant: %r" % (i + 1, a[:300], b[:300])
+        assert len(got.stdout) == len(want)
+    assert len(want) > 0
+
+
+@pytest.mark.parametrize("mode", [[], ["-x"], ["-p"]], ids=["pull", "pull_no_overlaps", "push_plbuf"])
+@pytest.mark.parametrize("name", sorted(SAMS))
+def test_external_client_sees_htslib_columns(oracle_bin, client, name, mode):
+    files = SAMS[name][:1] if "-p" in mode else SAMS[name]
+    _diff(oracle_bin, client, mode + files)
+
+
+def test_external_client_depth_cap_and_window_sizes(tmp_path, oracle_bin, client):
+    _diff(oracle_bin, client, ["-x", "-d", "20", os.path.join(G, "dat", "mpileup.1.sam")])
+    sam, _ = write_synth_sam(str(tmp_path), n_ref=15000, depth=30, read_len=150, seed=72, paired=True, indel_rate=0.1, max_indel=6)
+    for batch in ("40", "3000", None):
+        _diff(oracle_bin, client, [sam], {"STA_PLP_BATCH": batch} if batch else None)

@@ -125,20 +125,19 @@ def slice_reads(np, rd, lo, hi, origin):
     return out
 
 
-def oracle_text_hash(wl, n_cols, seed_ref=1, seed_reads=42, save_to=None):
-    """The checker: the oracle's text for the synthetic window (same generator, same seeds) -> sha256, bytes, wall time."""
-    from synth import synth_ref, synth_reads, write_sam, write_fasta
+def oracle_text_hash(wl, n_cols, seed_ref=1, seed_reads=42, save_to=None, inputs=None):
+    """The checker: the oracle's text for the synthetic window (same generator, same seeds) -> sha256, bytes, wall time.
+    inputs: optional dict from synth_inputs() so that several workloads of one shape share the generated reads and SAM text."""
     kind, depth, _, _, argv = WORKLOADS[wl]
     oracle = os.path.join(REPO, "oracle", "_build", "oracle_samtools")
     if not os.path.exists(oracle):
         return None
-    ref = synth_ref(n_cols, seed=seed_ref)
-    rd = synth_reads(ref, depth=depth, read_len=150, seed=seed_reads)
-    with tempfile.TemporaryDirectory() as tmp:
-        sam, fa = os.path.join(tmp, "s.sam"), os.path.join(tmp, "s.fa")
-        write_sam(sam, rd, "chrS", n_cols)
-        write_fasta(fa, "chrS", ref)
-        args = [a.format(sam=sam, fa=fa) for a in argv]
+    own = inputs is None
+    if own:
+        inputs = synth_inputs(depth, n_cols, seed_ref, seed_reads)
+    try:
+        rd = inputs["rd"]
+        args = [a.format(sam=inputs["sam"], fa=inputs["fa"]) for a in argv]
         h = hashlib.sha256()
         n = 0
         t0 = time.perf_counter()
@@ -155,8 +154,23 @@ def oracle_text_hash(wl, n_cols, seed_ref=1, seed_reads=42, save_to=None):
             if p.wait() != 0:
                 raise RuntimeError("oracle failed on the %s sample" % wl)
         dt = time.perf_counter() - t0
-    return {"sha256": h.hexdigest(), "bytes": n, "seconds": dt, "n_reads": int(rd["n"]), "bases": int(rd["n"]) * 150,
-            "argv": " ".join(x for x in argv if x != "{sam}").replace("{fa}", "ref.fa"), "ref": ref, "rd": rd}
+        return {"sha256": h.hexdigest(), "bytes": n, "seconds": dt, "n_reads": int(rd["n"]), "bases": int(rd["n"]) * 150,
+                "argv": " ".join(x for x in argv if x != "{sam}").replace("{fa}", "ref.fa"), "ref": inputs["ref"], "rd": rd}
+    finally:
+        if own:
+            shutil.rmtree(inputs["dir"], ignore_errors=True)
+
+
+def synth_inputs(depth, n_cols, seed_ref=1, seed_reads=42):
+    """bench.py's synthetic window as numpy arrays AND as the SAM / FASTA files the oracle reads (caller removes ['dir'])."""
+    from synth import synth_ref, synth_reads, write_sam, write_fasta
+    ref = synth_ref(n_cols, seed=seed_ref)
+    rd = synth_reads(ref, depth=depth, read_len=150, seed=seed_reads)
+    d = tempfile.mkdtemp(prefix="sta_bench_")
+    sam, fa = os.path.join(d, "s.sam"), os.path.join(d, "s.fa")
+    write_sam(sam, rd, "chrS", n_cols)
+    write_fasta(fa, "chrS", ref)
+    return {"ref": ref, "rd": rd, "sam": sam, "fa": fa, "dir": d}
 
 
 def collect_pmc(a, kernels):

@@ -57,7 +57,13 @@ def synth_reads(ref, depth=30, read_len=150, seed=42, paired=False, sub_rate=0.0
     if sub.any():
         alt = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(sub.sum()))]
         bases[sub] = alt
-    quals = QUAL_SET[rng.choice(4, size=bases.shape, p=QUAL_P)]
+    # == QUAL_SET[rng.choice(4, size=bases.shape, p=QUAL_P)] bit for bit (Generator.choice draws one uniform per element and
+    # searches the cumulative distribution), five times faster at bench sizes
+    cdf = QUAL_P.cumsum(); cdf /= cdf[-1]
+    u = rng.random(bases.shape)
+    qi = (u >= cdf[0]).astype(np.uint8); qi += u >= cdf[1]; qi += u >= cdf[2]
+    quals = QUAL_SET[qi]
+    del u, qi
 
     # CIGARs: default <L>M; a few reads carry one 1-3 bp insertion or deletion
     cig_n = np.ones(n_reads, dtype=np.int64)

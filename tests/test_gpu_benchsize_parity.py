@@ -22,17 +22,33 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 
 
+_inputs = {}
+
+
+def _shape(wl, n_cols):
+    """generated once per (depth, columns): the numpy arrays for the engine, the SAM / FASTA for the oracle"""
+    import atexit
+    import shutil
+    import bench
+    key = (bench.WORKLOADS[wl][1], n_cols)
+    if key not in _inputs:
+        for k in list(_inputs):                       # one shape at a time: these are hundreds of MB each
+            shutil.rmtree(_inputs.pop(k)["dir"], ignore_errors=True)
+        _inputs[key] = bench.synth_inputs(key[0], n_cols)
+        atexit.register(shutil.rmtree, _inputs[key]["dir"], True)
+    return _inputs[key]
+
+
 def _engine_sha(wl, n_cols, env=None):
     """sha256 of the engine's text for bench.py's window of workload `wl` (seeds 1 / 42)."""
     import numpy as np
     import torch
     import samtools_amd as sa
     import bench
-    from synth import synth_ref, synth_reads
-    kind, depth, _, _, _ = bench.WORKLOADS[wl]
+    kind = bench.WORKLOADS[wl][0]
     dev = torch.device("cuda", 0)
-    ref = synth_ref(n_cols, seed=1)
-    rd = synth_reads(ref, depth=depth, read_len=150, seed=42)
+    inp = _shape(wl, n_cols)
+    ref, rd = inp["ref"], inp["rd"]
     saved = {}
     for k, v in (env or {}).items():
         saved[k] = os.environ.get(k)
@@ -74,13 +90,13 @@ def _oracle(wl, n_cols):
     import bench
     key = (wl, n_cols)
     if key not in _oracle_cache:
-        o = bench.oracle_text_hash(wl, n_cols)
+        o = bench.oracle_text_hash(wl, n_cols, inputs=_shape(wl, n_cols))
         assert o is not None, "oracle binary missing (make -C oracle)"
         _oracle_cache[key] = (o["sha256"], o["bytes"], o["bases"])
     return _oracle_cache[key]
 
 
-@pytest.mark.parametrize("wl", ["mpileup30", "mpileup300", "depth30", "mpileup30_B", "mpileup300_B"])
+@pytest.mark.parametrize("wl", ["mpileup30", "mpileup30_B", "mpileup300", "mpileup300_B", "depth30"])
 def test_bench_window_text_is_byte_identical_to_the_oracle(wl):
     import bench
     n_cols = bench.WORKLOADS[wl][2]
@@ -126,7 +142,7 @@ def _ex1(tmp_path):
 def test_config0_ex1(tmp_path, oracle_bin, product_bin, opts):
     sam, bam, fa = _ex1(tmp_path)
     want = subprocess.run([oracle_bin, "mpileup"] + opts + ["-f", fa, sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
-    assert want.count(b"\n") > 1000
+    assert want.count(b"\n") > 500
     for inp in (sam, bam):
         got = subprocess.run([product_bin, "mpileup"] + opts + ["-f", fa, inp], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert got.returncode == 0, got.stderr.decode()[-400:]

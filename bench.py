@@ -306,11 +306,14 @@ def main():
         if pending[i] is not None:
             shard.wait_all(pending[i])     # the buffer's previous gather must have left it
             pending[i] = None
-        plan()
         if kind == "mpileup":
-            eng.mpileup_emit(out_bufs[i].data_ptr(), cap)
+            eng.stage_window(w)
+            eng.mpileup_run(par, out_bufs[i].data_ptr(), cap)       # plan + emit: the text lands in the caller's buffer
         elif kind == "depth":
-            eng.depth_emit(out_bufs[i].data_ptr(), cap)
+            eng.stage_window(w)
+            eng.depth_run(par, out_bufs[i].data_ptr(), cap)
+        else:
+            plan()
         if dist is not None:
             # the single collective of the path: per-block column text -> rank 0 over RCCL/xGMI, true sizes (samtools_amd/shard.py)
             pending[i] = shard.gather_text_v(out_bufs[i], out_bytes, dst=0, sizes=sizes, recv=recv[i] if recv else None)

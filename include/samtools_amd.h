@@ -15,7 +15,7 @@
  *   sam_prob_realn (BAQ)           bam_plcmd.c:451        STA_MPLP_REALN / STA_MPLP_REDO_BAQ
  *   sam_cap_mapq (-C)              bam_plcmd.c:453-457    sta_mplp_params.capQ_thres
  *   --output-extra tags / RNEXT    bam_plcmd.c:779-852    sta_reads.xcol_* + sta_mplp_params.n_tags
- *   mpileup() column loop+format   bam_plcmd.c:607-868    sta_mpileup_emit (text on device)
+ *   mpileup() column loop+format   bam_plcmd.c:607-868    sta_mpileup_emit / sta_mpileup_run (text on device)
  *   pileup_seq                     bam_plcmd.c:54-169     sta_mpileup_emit
  *   print_empty_pileup             bam_plcmd.c:372-398    sta_mpileup_emit with params.all
  *   mplp_get_ref                   bam_plcmd.c:289-352    sta_set_reference
@@ -203,6 +203,12 @@ int sta_mpileup_plan(sta_engine *e, const sta_mplp_params *p, sta_plan_info *inf
  * capacity >= out_bytes); dev_out == NULL uses an engine-owned buffer that
  * sta_fetch_output() copies back.  Asynchronous on the engine stream. */
 int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity);
+/* Plan and emit in one call (one kernel measures the lines, places them with a decoupled look-back and writes them): the
+ * staged window's text goes to dev_out (device pointer; an exact size is not known in advance, so the capacity must cover
+ * the text -- too small is STA_ERR_ARG and sta_last_error() names the size) or, with dev_out == NULL, to an engine-owned
+ * buffer that grows as needed (read it with sta_fetch_output).  info receives the same counters as sta_mpileup_plan.
+ * Synchronises the stream. */
+int sta_mpileup_run(sta_engine *e, const sta_mplp_params *p, void *dev_out, uint64_t capacity, sta_plan_info *info);
 
 /* ---- binary per-column pileup entries (the bam_plp_* / bam_mplp_* surface is built on these; see
  *      samtools_amd_plp.h).  One input file per window.  Replaces bam_plp_push's admission rules
@@ -289,6 +295,8 @@ int sta_fetch_calmd(sta_engine *e, int32_t *nm, uint64_t *md_off, char *md_text,
 /* ---- depth ---- */
 int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info);
 int sta_depth_emit(sta_engine *e, void *dev_out, uint64_t capacity);
+/* plan + emit in one call (same contract as sta_mpileup_run) */
+int sta_depth_run(sta_engine *e, const sta_depth_params *p, void *dev_out, uint64_t capacity, sta_plan_info *info);
 /* binary per-column counts of the planned window: int32 [n_files][col_end-col_beg]
  * (device pointer owned by the engine, valid until the next plan call) */
 const int32_t *sta_depth_counts_dev(sta_engine *e);

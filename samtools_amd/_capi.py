@@ -122,8 +122,10 @@ _PROTOS = {
     "sta_stage_window": (C.c_int, [_P, C.POINTER(Window)]),
     "sta_mpileup_plan": (C.c_int, [_P, C.POINTER(MplpParams), C.POINTER(PlanInfo)]),
     "sta_mpileup_emit": (C.c_int, [_P, _P, C.c_uint64]),
+    "sta_mpileup_run": (C.c_int, [_P, C.POINTER(MplpParams), _P, C.c_uint64, C.POINTER(PlanInfo)]),
     "sta_depth_plan": (C.c_int, [_P, C.POINTER(DepthParams), C.POINTER(PlanInfo)]),
     "sta_depth_emit": (C.c_int, [_P, _P, C.c_uint64]),
+    "sta_depth_run": (C.c_int, [_P, C.POINTER(DepthParams), _P, C.c_uint64, C.POINTER(PlanInfo)]),
     "sta_depth_counts_dev": (_P, [_P]),
     "sta_fetch_output": (C.c_int, [_P, _P, C.c_uint64]),
     "sta_sync": (C.c_int, [_P]),
@@ -238,9 +240,20 @@ class Engine:
     def mpileup_emit(self, dev_ptr=None, capacity=0):
         self._chk(lib.sta_mpileup_emit(self._h, _P(dev_ptr or 0), capacity), "sta_mpileup_emit")
 
+    def mpileup_run(self, params, dev_ptr=None, capacity=0):
+        """plan + emit in one call (single-pass kernel); text in dev_ptr, or in the engine's buffer when None"""
+        info = PlanInfo()
+        self._chk(lib.sta_mpileup_run(self._h, C.byref(params), _P(dev_ptr or 0), capacity, C.byref(info)), "sta_mpileup_run")
+        return info
+
     def depth_plan(self, params):
         info = PlanInfo()
         self._chk(lib.sta_depth_plan(self._h, C.byref(params), C.byref(info)), "sta_depth_plan")
+        return info
+
+    def depth_run(self, params, dev_ptr=None, capacity=0):
+        info = PlanInfo()
+        self._chk(lib.sta_depth_run(self._h, C.byref(params), _P(dev_ptr or 0), capacity, C.byref(info)), "sta_depth_run")
         return info
 
     def depth_emit(self, dev_ptr=None, capacity=0):

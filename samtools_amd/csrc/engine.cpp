@@ -64,7 +64,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     int baq_slab_gib_cap = 0;       // 0 = default; 4 after a one-launch BAQ slab could not be allocated
     double glf_depcorr = -1.0;      // theta the coefficient block in glf_tab was computed for
     StaWinDev wd{};
@@ -78,6 +78,7 @@ struct sta_engine {
     uint64_t out_bytes = 0;
     uint32_t lds_cap = 0;
     void *last_out = nullptr;
+    bool fused = false;             // the planned window's text was produced by the single-pass kernel (into e->out unless run() was given a buffer)
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;
@@ -173,7 +174,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq };
+                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
     if (e->pipe_stream) hipStreamDestroy(e->pipe_stream);
@@ -213,7 +214,7 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
 {
     if (!e || !w || w->n_files < 0 || w->col_end < w->col_beg) return fail(e, STA_ERR_ARG, "bad window");
     hipSetDevice(e->device);
-    e->staged = false; e->planned = 0;
+    e->staged = false; e->planned = 0; e->fused = false;
     e->win = *w;
     e->tname = w->tname ? w->tname : "";
     if (e->fb.size() < (size_t)w->n_files) e->fb.resize((size_t)w->n_files);
@@ -517,6 +518,7 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
     } else {
         int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
         if (e->colinfo.ensure((size_t)(ncols > 0 ? ncols : 1) * (size_t)(nf > 0 ? nf : 1) * 8 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(column info) failed");
+        if (e->fused) return STA_OK;                // the single-pass kernel measures and writes in one launch (fused_text)
         ProfScope ps(e, "mplp_len");
         sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr);
     }
@@ -565,6 +567,82 @@ static int counting_pipeline(sta_engine *e, const sta_mplp_params *p)
     return mpileup_pipeline(e, p, true);
 }
 
+// ---- single-pass text path (k_mplp_fused): measure + offsets + text in one launch ----
+static bool fused_enabled(const sta_mplp_params *p)
+{
+    static const bool legacy = getenv("STA_MPLP_LEGACY") != nullptr;
+    return !legacy && sta_mplp_has_fast_path(*p);
+}
+static uint32_t fused_lbuf()
+{
+    static const uint32_t v = [] { const char *e = getenv("STA_MPLP_LBUF"); long x = e ? atol(e) : 0; return (uint32_t)(x >= 512 && x <= 150000 ? x : 8192); }();
+    return v;
+}
+// one launch into out[0, cap); the window totals land in StaCounters (out_bytes, n_lines, n_data_cols, overflow)
+static int fused_launch(sta_engine *e, const sta_mplp_params *p, char *out, uint64_t cap)
+{
+    const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
+    if (ncols <= 0) return STA_OK;
+    if (e->fused_status.ensure(sta_mplp_fused_status_bytes(ncols) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(look-back status) failed");
+    StaCounters *ctr = (StaCounters *)e->counters.p;
+    HIPCHK(hipMemsetAsync(&ctr->out_bytes, 0, 16, e->stream));              // out_bytes, overflow
+    ProfScope ps(e, "mplp_fused");
+    sta_launch_mplp_fused(e->stream, e->wd, *p, e->fused_status.p, (uint2 *)e->colinfo.p, out, cap, ctr, fused_lbuf());
+    return STA_OK;
+}
+static int fused_finish(sta_engine *e, sta_plan_info *info)
+{
+    HIPCHK(hipMemcpyAsync(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return hipfail(e, le, "kernel launch");
+    e->out_bytes = e->ctr_h.out_bytes;
+    if (info) {
+        info->out_bytes = e->out_bytes; info->n_lines = e->ctr_h.n_lines; info->n_data_cols = e->ctr_h.n_data_cols;
+        info->n_kept_reads = e->ctr_h.n_kept; info->piled_bases = e->ctr_h.piled_bases; info->n_maxcnt_dropped = e->ctr_h.n_dropped;
+    }
+    return STA_OK;
+}
+// pipeline + single-pass text into `out` (NULL: the engine's own buffer, grown to fit; a caller's buffer that is too small is an error)
+static int fused_text(sta_engine *e, const sta_mplp_params *p, char *out, uint64_t cap, sta_plan_info *info)
+{
+    const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
+    e->min_pos.assign(e->files_h.size(), 0); e->max_pos_hint.assign(e->files_h.size(), 0);
+    int rc = mpileup_pipeline(e, p, false);
+    if (rc) return rc;
+    const bool own = out == nullptr;
+    if (own) {
+        // a guess that holds for ordinary data: 2 bytes of text per staged base (+ marks) and the fixed part of every line; the
+        // kernel keeps counting when the buffer is too small, so a wrong guess costs one more launch, not a wrong answer
+        uint64_t guess = (uint64_t)(ncols > 0 ? ncols : 0) * (uint64_t)(e->tname.size() + 28 + 12 * e->files_h.size()) + 4096;
+        for (auto &d : e->files_h) guess += d.n_bases_total * 5 / 2 + (uint64_t)d.n * 8;
+        if (e->out.ensure((size_t)guess)) return fail(e, STA_ERR_HIP, "hipMalloc(output) failed");
+        out = (char *)e->out.p; cap = e->out.cap;
+    }
+    rc = fused_launch(e, p, out, cap);
+    if (!rc) rc = fused_finish(e, info);
+    if (rc) return rc;
+    if (e->ctr_h.maxcnt_flag) {
+        // the -d cap may trigger in this window: exact replay, then the text again
+        rc = maxcnt_bounds(e);
+        if (!rc) rc = mpileup_pipeline(e, p, true);
+        if (!rc) rc = fused_launch(e, p, out, cap);
+        if (!rc) rc = fused_finish(e, info);
+        if (rc) return rc;
+    }
+    if (e->ctr_h.overflow) {
+        if (!own) return fail(e, STA_ERR_ARG, "output buffer too small (" + std::to_string(e->out_bytes) + " bytes needed)");
+        if (e->out.ensure((size_t)e->out_bytes + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(output) failed");
+        out = (char *)e->out.p; cap = e->out.cap;
+        rc = fused_launch(e, p, out, cap);
+        if (!rc) rc = fused_finish(e, info);
+        if (rc) return rc;
+        if (e->ctr_h.overflow) return fail(e, STA_ERR_HIP, "single-pass emit overflowed twice");
+    }
+    e->last_out = out;
+    return STA_OK;
+}
+
 int sta_mpileup_plan(sta_engine *e, const sta_mplp_params *p, sta_plan_info *info)
 {
     if (!e || !p) return STA_ERR_ARG;
@@ -577,6 +655,14 @@ int sta_mpileup_plan(sta_engine *e, const sta_mplp_params *p, sta_plan_info *inf
     }
     e->mp = *p;
     int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
+    e->fused = fused_enabled(p);
+    if (e->fused) {
+        // the text is produced right away, into the engine's buffer; sta_mpileup_emit hands it over
+        int rc = fused_text(e, p, nullptr, 0, info);
+        if (rc) { e->fused = false; return rc; }
+        e->planned = 1;
+        return STA_OK;
+    }
     // host-side bounds for the (rare) exact -d replay
     e->min_pos.assign(e->files_h.size(), 0); e->max_pos_hint.assign(e->files_h.size(), 0);
     int rc = mpileup_pipeline(e, p, false);
@@ -615,12 +701,42 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     if (!e) return STA_ERR_ARG;
     if (e->planned != 1) return fail(e, STA_ERR_ARG, "sta_mpileup_plan has not run for this window");
     hipSetDevice(e->device);
+    if (e->fused) {
+        // the single-pass kernel already wrote the text (engine buffer): a caller's buffer gets a device-to-device copy
+        if (dev_out && dev_out != e->last_out) {
+            if (capacity < e->out_bytes) return fail(e, STA_ERR_ARG, "output buffer too small");
+            if (e->out_bytes) HIPCHK(hipMemcpyAsync(dev_out, e->last_out, (size_t)e->out_bytes, hipMemcpyDeviceToDevice, e->stream));
+            e->last_out = dev_out;
+        }
+        return STA_OK;
+    }
     char *out = nullptr;
     int rc = emit_common(e, dev_out, capacity, &out);
     if (rc) return rc;
     if (e->out_bytes == 0) return STA_OK;
     ProfScope ps(e, "mplp_emit");
     sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap);
+    return STA_OK;
+}
+
+/* plan + emit in one call: the whole window's text into dev_out (NULL: engine buffer, read with sta_fetch_output) */
+int sta_mpileup_run(sta_engine *e, const sta_mplp_params *p, void *dev_out, uint64_t capacity, sta_plan_info *info)
+{
+    if (!e || !p) return STA_ERR_ARG;
+    if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
+    hipSetDevice(e->device);
+    if (!fused_enabled(p)) {
+        // per-read text columns (--output-extra, -O, -s): measuring pass + scan + generic emit kernel
+        sta_plan_info tmp;
+        int rc = sta_mpileup_plan(e, p, info ? info : &tmp);
+        if (rc) return rc;
+        return sta_mpileup_emit(e, dev_out, capacity);
+    }
+    e->mp = *p;
+    e->fused = true;
+    int rc = fused_text(e, p, (char *)dev_out, capacity, info);
+    if (rc) { e->fused = false; e->planned = 0; return rc; }
+    e->planned = 1;
     return STA_OK;
 }
 
@@ -890,17 +1006,15 @@ int sta_fetch_overlap_fixups(sta_engine *e, int32_t file, int32_t *fix_y, int32_
     return STA_OK;
 }
 
-int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info)
+// depth: read filters (+ -s mate clip) -> prefix max of read ends -> ONE kernel that counts every column, places the rows with a
+// decoupled look-back and writes them (k_depth_fused).  out == NULL: the engine's own buffer.
+static int depth_text(sta_engine *e, const sta_depth_params *p, char *out, uint64_t cap, sta_plan_info *info)
 {
-    if (!e || !p) return STA_ERR_ARG;
-    if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
-    hipSetDevice(e->device);
-    e->dp = *p;
     hipStream_t s = e->stream;
     StaCounters *ctr = (StaCounters *)e->counters.p;
     HIPCHK(hipMemsetAsync(ctr, 0, sizeof(StaCounters), s));
     const int nf = (int)e->files_h.size();
-    int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
+    const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
     for (auto &d : e->files_h) d.qual = const_cast<uint8_t *>(d.qual_in);
     int rc = push_files(e);
     if (rc) return rc;
@@ -918,22 +1032,46 @@ int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info
             sta_launch_depth_pair(s, d, e->wd.origin, e->wd.tid, e->table.p, slots, (int32_t *)e->fb[(size_t)f].chain.p, ctr);
         }
     }
-    size_t drows = (size_t)(nf + 1) * (size_t)(ncols + 1);
+    for (int f = 0; f < nf; ++f) {
+        StaReadsDev &d = e->files_h[(size_t)f];
+        if (!d.n) continue;
+        if (e->scan_tmp.ensure(sta_scan_tmp_bytes(d.n) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+        ProfScope ps(e, "maxend_scan");
+        sta_launch_maxend_scan(s, d, e->scan_tmp.p, e->scan_tmp.cap);
+    }
+    const size_t drows = (size_t)(nf + 1) * (size_t)(ncols + 1);
     if (e->diff.ensure(drows * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(depth rows) failed");
-    HIPCHK(hipMemsetAsync(e->diff.p, 0, drows * 4, s));
-    {
-        ProfScope ps(e, "depth_count");
-        sta_launch_depth_count(s, e->wd, e->files_h.data(), nf, *p, (int32_t *)e->diff.p);
+    if (e->fused_status.ensure(sta_depth_fused_status_bytes(ncols) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(look-back status) failed");
+    const bool own = out == nullptr;
+    if (own) {
+        const uint64_t guess = (uint64_t)(ncols > 0 ? ncols : 0) * (uint64_t)(e->tname.size() + 14 + 12 * (size_t)nf) + 4096;
+        if (e->out.ensure((size_t)guess)) return fail(e, STA_ERR_HIP, "hipMalloc(output) failed");
+        out = (char *)e->out.p; cap = e->out.cap;
     }
-    {
-        ProfScope ps(e, "depth_scan");
-        sta_launch_depth_scan(s, (int32_t *)e->diff.p, nf + 1, ncols, e->scan_tmp.p, e->scan_tmp.cap);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (ncols > 0) {
+            HIPCHK(hipMemsetAsync(&ctr->out_bytes, 0, 16, s));
+            ProfScope ps(e, "depth_fused");
+            sta_launch_depth_fused(s, e->wd, *p, e->fused_status.p, (int32_t *)e->diff.p, out, cap, ctr, 4096);
+        }
+        rc = fused_finish(e, info);
+        if (rc) return rc;
+        if (!e->ctr_h.overflow) break;
+        if (!own || attempt) return fail(e, STA_ERR_ARG, "output buffer too small (" + std::to_string(e->out_bytes) + " bytes needed)");
+        if (e->out.ensure((size_t)e->out_bytes + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(output) failed");
+        out = (char *)e->out.p; cap = e->out.cap;
     }
-    {
-        ProfScope ps(e, "depth_len");
-        sta_launch_depth_len(s, e->wd, *p, (const int32_t *)e->diff.p, (uint32_t *)e->line_len.p, ctr);
-    }
-    rc = finish_plan(e, ncols, info);
+    e->last_out = out;
+    return STA_OK;
+}
+
+int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info)
+{
+    if (!e || !p) return STA_ERR_ARG;
+    if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
+    hipSetDevice(e->device);
+    e->dp = *p;
+    int rc = depth_text(e, p, nullptr, 0, info);
     if (rc) return rc;
     e->planned = 2;
     return STA_OK;
@@ -944,12 +1082,25 @@ int sta_depth_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     if (!e) return STA_ERR_ARG;
     if (e->planned != 2) return fail(e, STA_ERR_ARG, "sta_depth_plan has not run for this window");
     hipSetDevice(e->device);
-    char *out = nullptr;
-    int rc = emit_common(e, dev_out, capacity, &out);
-    if (rc) return rc;
-    if (e->out_bytes == 0) return STA_OK;
-    ProfScope ps(e, "depth_emit");
-    sta_launch_depth_emit(e->stream, e->wd, e->dp, (const int32_t *)e->diff.p, (const uint64_t *)e->offs.p, out, e->lds_cap);
+    // the rows were written by the plan (engine buffer): a caller's buffer gets a device-to-device copy
+    if (dev_out && dev_out != e->last_out) {
+        if (capacity < e->out_bytes) return fail(e, STA_ERR_ARG, "output buffer too small");
+        if (e->out_bytes) HIPCHK(hipMemcpyAsync(dev_out, e->last_out, (size_t)e->out_bytes, hipMemcpyDeviceToDevice, e->stream));
+        e->last_out = dev_out;
+    }
+    return STA_OK;
+}
+
+/* plan + emit in one call; see sta_mpileup_run */
+int sta_depth_run(sta_engine *e, const sta_depth_params *p, void *dev_out, uint64_t capacity, sta_plan_info *info)
+{
+    if (!e || !p) return STA_ERR_ARG;
+    if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
+    hipSetDevice(e->device);
+    e->dp = *p;
+    int rc = depth_text(e, p, (char *)dev_out, capacity, info);
+    if (rc) { e->planned = 0; return rc; }
+    e->planned = 2;
     return STA_OK;
 }
 

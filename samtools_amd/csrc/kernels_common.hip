@@ -17,10 +17,11 @@ struct PrepArgs {
 
 __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, PrepArgs P, StaCounters *ctr)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long piled = 0; unsigned kept = 0;
+    // grid-stride over the reads: the counters are reduced ONCE per block at the end (a counter word sustains only ~90
+    // atomics/us, so one reduction per 256 reads cost more than the reads themselves)
+    unsigned long long piled = 0, kept = 0;
     unsigned long long c_baq = 0, c_fast = 0, c_bw8 = 0, c_gen = 0, m_lqf = 0, m_lq = 0, m_bw = 0;
-    if (i < R.n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R.n; i += (int64_t)gridDim.x * blockDim.x) {
         int32_t pos = R.pos[i];
         uint32_t flag = R.flag[i];
         uint32_t c0 = R.cig_off[i], c1 = R.cig_off[i + 1];
@@ -77,18 +78,18 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
                 BaqGeo g = baq_geometry(R.cigar + c0, (int)(c1 - c0), apos, lq, W.ref, W.ref_len);
                 if (g.ok) {         // !ok: probaln_glocal returns 0 and the qualities stay as they are
                     info |= RI_BAQ;
-                    c_baq = 1;
+                    c_baq += 1;
                     bool band = (g.bw == 7 || g.bw == 8) && lq <= STA_BAQ7_LQ_MAX && !P.baq_force_slow;
                     if (band) {
                         info |= (uint32_t)g.bw << RI_BAQ_BW_SHIFT;
-                        m_lqf = (unsigned long long)lq;
+                        if ((unsigned long long)lq > m_lqf) m_lqf = (unsigned long long)lq;
                     } else {
-                        m_lq = (unsigned long long)lq;
-                        m_bw = (unsigned long long)g.bw;
+                        if ((unsigned long long)lq > m_lq) m_lq = (unsigned long long)lq;
+                        if ((unsigned long long)g.bw > m_bw) m_bw = (unsigned long long)g.bw;
                     }
-                    if (band && g.bw == 7) c_fast = 1;
+                    if (band && g.bw == 7) c_fast += 1;
                     else {
-                        if (band) c_bw8 = 1; else c_gen = 1;
+                        if (band) c_bw8 += 1; else c_gen += 1;
                         info |= RI_BAQ_SLOW;
                         int slot = atomicAdd(&R.chain[0], 1);
                         R.chain[1 + slot] = (int32_t)i;
@@ -100,9 +101,9 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
         R.end[i] = end;
         R.info[i] = info;
         if (keep) {
-            kept = 1;
+            kept += 1;
             int32_t a = pos > W.col_beg ? pos : W.col_beg, b = end < W.col_end ? end : W.col_end;
-            if (b > a) piled = (unsigned long long)(b - a);
+            if (b > a) piled += (unsigned long long)(b - a);
         }
     }
     // block reduce, then one atomic per counter and block
@@ -120,6 +121,7 @@ void sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev 
         const StaReadsDev &R = files_host[f];
         if (R.n == 0) continue;
         int64_t nb = (R.n + 255) / 256;
+        if (nb > 2048) nb = 2048;
         hipMemsetAsync(R.chain, 0, 4, s);
         hipLaunchKernelGGL(k_prep_reads, dim3((unsigned)nb), dim3(256), 0, s, R, w, a, ctr);
     }
@@ -210,9 +212,8 @@ struct PrepDepthArgs { int32_t flag, incl_flag, require_flag, min_mqual, min_len
 
 __global__ void __launch_bounds__(256) k_prep_reads_depth(StaReadsDev R, StaWinDev W, PrepDepthArgs P, StaCounters *ctr)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long piled = 0; unsigned kept = 0;
-    if (i < R.n) {
+    unsigned long long piled = 0, kept = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R.n; i += (int64_t)gridDim.x * blockDim.x) {
         int32_t pos = R.pos[i];
         uint32_t flag = R.flag[i];
         uint32_t c0 = R.cig_off[i], c1 = R.cig_off[i + 1];
@@ -244,13 +245,18 @@ __global__ void __launch_bounds__(256) k_prep_reads_depth(StaReadsDev R, StaWinD
         // bam_endpos: pos + max(rlen,1) (unmapped-flagged reads count as length 1)
         int32_t span = (flag & BAM_FUNMAP) ? 0 : rlen;
         int32_t end = pos + (span > 0 ? span : 1);
-        R.end[i] = end;
-        R.info[i] = (ok ? (RI_PUSHED | RI_KEEP) : 0) | ((flag & BAM_FREVERSE) ? RI_REV : 0);
+        // the column walker finds a read through [pos, R.end): the CIGAR's own reach, which is longer than bam_endpos for an
+        // unmapped-flagged record that still carries a CIGAR (add_depth counts along the CIGAR whatever the flag says);
+        // RI_UNMAP_SPAN keeps the "row is covered" span at bam_endpos for those
+        const int32_t cig_end = pos + (rlen > 0 ? rlen : 1);
+        const bool simple = (c1 - c0 == 1) && cg_is_mop(R.cigar[c0] & 0xf) && lq == rlen && !(flag & BAM_FUNMAP);
+        R.end[i] = cig_end;
+        R.info[i] = (ok ? (RI_PUSHED | RI_KEEP) : 0) | ((flag & BAM_FREVERSE) ? RI_REV : 0) | (simple ? RI_SIMPLE : 0) | (cig_end != end ? RI_UNMAP_SPAN : 0);
         R.clip[i] = 0;
         if (ok) {
-            kept = 1;
+            kept += 1;
             int32_t a = pos > W.col_beg ? pos : W.col_beg, b = end < W.col_end ? end : W.col_end;
-            if (b > a) piled = (unsigned long long)(b - a);
+            if (b > a) piled += (unsigned long long)(b - a);
         }
     }
     unsigned long long v[2] = { piled, kept };
@@ -266,6 +272,7 @@ void sta_launch_prep_reads_depth(hipStream_t s, const StaWinDev &w, const StaRea
         const StaReadsDev &R = files_host[f];
         if (R.n == 0) continue;
         int64_t nb = (R.n + 255) / 256;
+        if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(k_prep_reads_depth, dim3((unsigned)nb), dim3(256), 0, s, R, w, a, ctr);
     }
 }

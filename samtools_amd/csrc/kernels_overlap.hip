@@ -248,7 +248,8 @@ __global__ void __launch_bounds__(256) k_name_groups(StaReadsDev R, int64_t orig
                 holder = -1;
             }
         } else {
-            long long endpos = origin + R.end[x];
+            // bam_endpos (R.end is the CIGAR's reach; an unmapped-flagged record counts as one column, see k_prep_reads_depth)
+            long long endpos = origin + ((R.info[x] & RI_UNMAP_SPAN) ? R.pos[x] + 1 : R.end[x]);
             if (holder < 0) {
                 long long mpos = R.mpos[x];
                 if (mpos == -1 || (R.mtid[x] == tid && mpos <= endpos)) { holder = x; holder_end = endpos; }

@@ -12,6 +12,7 @@
 #define RI_REV      0x8u
 #define RI_OLAP_EL  0x10u   // eligible for mate-overlap hashing (overlap_push conditions)
 #define RI_BAQ      0x20u   // BAQ must be computed for this read
+#define RI_UNMAP_SPAN 0x80u // depth: R.end is the CIGAR's reach, the covered span (bam_endpos) is one column
 #define RI_BAQ_SLOW 0x40u   // ... by the general-band kernel (band width != 7 or very long read); listed in `chain`
 #define RI_BAQ_BW_SHIFT 16  // bits 16..20: band width handled by a band-in-registers BAQ kernel (7 or 8), 0 = general kernel
 #define RI_MAPQ_SHIFT 8     // bits 8..15: mapping quality after -C
@@ -68,6 +69,7 @@ struct StaWinDev {
 
 struct StaCounters {          // device-side reduction targets, zeroed per plan
     unsigned long long n_lines, n_data_cols, n_kept, piled_bases, n_dropped, max_wave_bytes, n_anom, maxcnt_flag, max_lq, max_bw, n_baq, max_lq_fast, n_baq_fast, n_baq_bw8, n_baq_general;
+    unsigned long long out_bytes, overflow;      // single-pass kernels: total text bytes of the window; set when the output buffer was too small
 };
 
 // ---- launchers (defined in the .hip files) ----
@@ -85,6 +87,11 @@ void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_param
                          StaCounters *ctr);
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
                           char *out, uint32_t lds_cap);
+// single-pass measure + look-back + emit (kernels_plp.hip): `status` = sta_mplp_fused_status_bytes(ncols) bytes of scratch
+size_t sta_mplp_fused_status_bytes(int64_t ncols);
+bool sta_mplp_has_fast_path(const sta_mplp_params &p);
+void sta_launch_mplp_fused(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, void *status, uint2 *colinfo, char *out,
+                           uint64_t capacity, StaCounters *ctr, uint32_t lbuf);
 void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, const uint32_t *line_len, int64_t ncols, StaCounters *ctr);
 
 // binary per-column entries for the bam_plp_* surface (kernels_plpapi.hip)
@@ -128,5 +135,8 @@ void sta_launch_depth_len(hipStream_t s, const StaWinDev &w, const sta_depth_par
                           uint32_t *line_len, StaCounters *ctr);
 void sta_launch_depth_emit(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, const int32_t *counts,
                            const uint64_t *offs, char *out, uint32_t lds_cap);
+size_t sta_depth_fused_status_bytes(int64_t ncols);
+void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, void *status, int32_t *counts, char *out,
+                            uint64_t capacity, StaCounters *ctr, uint32_t lbuf);
 void sta_launch_depth_pair(hipStream_t s, const StaReadsDev &r, int64_t origin, int32_t tid, void *table, size_t slots,
                            int32_t *chain_next, StaCounters *ctr);

@@ -64,7 +64,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, fused_status, giant, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     int baq_slab_gib_cap = 0;       // 0 = default; 4 after a one-launch BAQ slab could not be allocated
     double glf_depcorr = -1.0;      // theta the coefficient block in glf_tab was computed for
     StaWinDev wd{};
@@ -174,7 +174,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq };
+                      &e->out, &e->diff, &e->fused_status, &e->giant, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
     if (e->pipe_stream) hipStreamDestroy(e->pipe_stream);
@@ -532,7 +532,7 @@ struct ModeGuard {
     sta_engine *e; const char *ref; int64_t len;
     ModeGuard(sta_engine *e_, bool plp, bool cov) : e(e_), ref(e_->wd.ref), len(e_->wd.ref_len)
     {
-        e->plp_mode = plp; e->cov_mode = cov;
+        e->plp_mode = plp; e->cov_mode = cov; e->fused = false;
         e->wd.ref = nullptr; e->wd.ref_len = 0;      // the plain iterator has no contig-length filter and no BAQ
     }
     ~ModeGuard() { e->plp_mode = false; e->cov_mode = false; e->wd.ref = ref; e->wd.ref_len = len; }
@@ -575,7 +575,7 @@ static bool fused_enabled(const sta_mplp_params *p)
 }
 static uint32_t fused_lbuf()
 {
-    static const uint32_t v = [] { const char *e = getenv("STA_MPLP_LBUF"); long x = e ? atol(e) : 0; return (uint32_t)(x >= 512 && x <= 150000 ? x : 8192); }();
+    static const uint32_t v = [] { const char *e = getenv("STA_MPLP_LBUF"); long x = e ? atol(e) : 0; return (uint32_t)(x >= 512 && x <= 11000 ? x : 8192); }();     // 4 waves x (5 KB + buffer) must stay within the default 64 KiB of dynamic LDS
     return v;
 }
 // one launch into out[0, cap); the window totals land in StaCounters (out_bytes, n_lines, n_data_cols, overflow)
@@ -584,10 +584,12 @@ static int fused_launch(sta_engine *e, const sta_mplp_params *p, char *out, uint
     const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
     if (ncols <= 0) return STA_OK;
     if (e->fused_status.ensure(sta_mplp_fused_status_bytes(ncols) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(look-back status) failed");
+    if (e->giant.ensure((size_t)((ncols + 63) / 64) * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(wave list) failed");
     StaCounters *ctr = (StaCounters *)e->counters.p;
-    HIPCHK(hipMemsetAsync(&ctr->out_bytes, 0, 16, e->stream));              // out_bytes, overflow
+    HIPCHK(hipMemsetAsync(&ctr->out_bytes, 0, 24, e->stream));              // out_bytes, overflow, n_giant
     ProfScope ps(e, "mplp_fused");
-    sta_launch_mplp_fused(e->stream, e->wd, *p, e->fused_status.p, (uint2 *)e->colinfo.p, out, cap, ctr, fused_lbuf());
+    sta_launch_mplp_fused(e->stream, e->wd, *p, e->fused_status.p, (uint2 *)e->colinfo.p, out, cap, ctr, fused_lbuf(), (uint32_t *)e->giant.p,
+                          (unsigned long long *)e->offs.p);
     return STA_OK;
 }
 static int fused_finish(sta_engine *e, sta_plan_info *info)
@@ -638,6 +640,12 @@ static int fused_text(sta_engine *e, const sta_mplp_params *p, char *out, uint64
         if (!rc) rc = fused_finish(e, info);
         if (rc) return rc;
         if (e->ctr_h.overflow) return fail(e, STA_ERR_HIP, "single-pass emit overflowed twice");
+    }
+    if (e->ctr_h.n_giant) {
+        // lines longer than the fused kernel's LDS line buffer (columns thousands of reads deep): written by the follow-up kernel
+        ProfScope ps(e, "mplp_emit_listed");
+        sta_launch_mplp_emit_listed(e->stream, e->wd, *p, (const unsigned long long *)e->offs.p, (const uint2 *)e->colinfo.p, out,
+                                    (const uint32_t *)e->giant.p, e->ctr_h.n_giant);
     }
     e->last_out = out;
     return STA_OK;
@@ -898,6 +906,7 @@ int sta_calmd_plan(sta_engine *e, const sta_calmd_params *cp, sta_plan_info *inf
     hipSetDevice(e->device);
     const bool realn = (cp->flag & STA_CALMD_REALN) != 0, apply = (cp->flag & STA_CALMD_APPLY) != 0;
     if (realn && !e->wd.ref) return fail(e, STA_ERR_ARG, "calmd -r needs the reference of the contig");
+    e->fused = false;
     sta_mplp_params p; memset(&p, 0, sizeof p);
     p.flag = realn ? STA_MPLP_REALN : 0;
     e->mp = p;

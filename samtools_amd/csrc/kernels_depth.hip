@@ -8,6 +8,7 @@
 // counts, and the rows are formatted to text by one wave per 64 columns (LDS staged, coalesced
 // flush) exactly like the mpileup emitter.
 #include "dev_util.h"
+#include <cstdlib>
 #include "dev_lookback.h"
 
 extern __shared__ __attribute__((aligned(16))) char lds_dtext[];
@@ -203,7 +204,7 @@ struct DepthFusedArgs {
     char *out; unsigned long long capacity;
     int32_t *counts;
     StaCounters *ctr;
-    uint32_t lbuf, per_wave, n_tiles;
+    uint32_t lbuf, per_wave, n_tiles, tiles_per_batch;
     int32_t has_clip;
 };
 
@@ -289,96 +290,128 @@ __device__ __forceinline__ void depth_read_range(const StaReadsDev &R, int p0, i
     rhi = wave_upper_bound(R.pos, R.n, p1);
     if (rlo > rhi) rlo = rhi;
 }
+// the next tile's range from the previous one's: both bounds only move forward (see wave_read_range_next in kernels_plp.hip)
+__device__ __forceinline__ void depth_read_range_next(const StaReadsDev &R, int p0, int p1, int64_t &rlo, int64_t &rhi, bool have_prev)
+{
+    if (R.n == 0) { rlo = rhi = 0; return; }
+    if (!have_prev) { depth_read_range(R, p0, p1, rlo, rhi); return; }
+    const int lane = threadIdx.x & 63;
+    bool found = false;
+    for (int it = 0; it < 3 && !found; ++it) {
+        const int64_t idx = rlo + lane;
+        const unsigned long long m = __ballot(idx < R.n ? R.maxend[idx] > p0 : true);
+        if (m) { rlo += __ffsll((long long)m) - 1; found = true; } else rlo += 64;
+    }
+    if (!found) rlo = wave_upper_bound(R.maxend, R.n, p0);
+    if (rlo > R.n) rlo = R.n;
+    found = false;
+    for (int it = 0; it < 3 && !found; ++it) {
+        const int64_t idx = rhi + lane;
+        const unsigned long long m = __ballot(idx < R.n ? R.pos[idx] > p1 : true);
+        if (m) { rhi += __ffsll((long long)m) - 1; found = true; } else rhi += 64;
+    }
+    if (!found) rhi = wave_upper_bound(R.pos, R.n, p1);
+    if (rhi > R.n) rhi = R.n;
+    if (rlo > rhi) rlo = rhi;
+}
 
 __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P, DepthFusedArgs A)
 {
-    __shared__ unsigned int s_tile;
+    __shared__ unsigned int s_batch;
     __shared__ unsigned long long s_wtot[4][2];
     __shared__ unsigned long long s_base[2];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) s_tile = atomicAdd(A.ticket, 1u);
+    if (threadIdx.x == 0) s_batch = atomicAdd(A.ticket, 1u);      // one ticket per batch of consecutive tiles (dev_lookback.h)
     __syncthreads();
-    const unsigned int tile = s_tile;
+    const unsigned int batch = s_batch;
     const int64_t ncols = (int64_t)W.col_end - W.col_beg;
-    const int64_t c0 = ((int64_t)tile * 4 + wid) * 64;
-    const bool wave_on = c0 < ncols;
-    const int p0 = W.col_beg + (int)(wave_on ? c0 : 0);
-    const int p = p0 + lane;
-    const bool active = wave_on && p < W.col_end;
-    const int plast = p0 + 63 < W.col_end ? p0 + 63 : W.col_end - 1;
-    const int64_t apos = W.origin + p;
-    const int64_t col = c0 + lane;
     const uint32_t lb = (uint32_t)wid * A.per_wave;
+    int64_t rlo1 = 0, rhi1 = 0; bool have_range = false;
 
-    // ---- COUNT ----
-    uint32_t len = 0; bool covered = false, exists = false;
-    if (wave_on) {
-        uint32_t cover = 0, digits = 0;
-        for (int f = 0; f < W.nfiles; ++f) {
-            const StaReadsDev &R = W.files[f];
-            int64_t rlo, rhi;
-            depth_read_range(R, p0, plast, rlo, rhi);
-            uint32_t cnt = 0;
-            depth_walk(R, P, A.has_clip, p0, plast, p, active, rlo, rhi, cnt, cover);
-            if (active) A.counts[(int64_t)f * (ncols + 1) + col] = (int32_t)cnt;
-            digits += 1 + (uint32_t)dec_digits_u32(cnt);
+    for (unsigned ti = 0; ti < A.tiles_per_batch; ++ti) {
+        const unsigned int tile = batch * A.tiles_per_batch + ti;
+        if (tile >= A.n_tiles) break;
+        __syncthreads();
+        const int64_t c0 = ((int64_t)tile * 4 + wid) * 64;
+        const bool wave_on = c0 < ncols;
+        const int p0 = W.col_beg + (int)(wave_on ? c0 : 0);
+        const int p = p0 + lane;
+        const bool active = wave_on && p < W.col_end;
+        const int plast = p0 + 63 < W.col_end ? p0 + 63 : W.col_end - 1;
+        const int64_t apos = W.origin + p;
+        const int64_t col = c0 + lane;
+
+        // ---- COUNT ----
+        uint32_t len = 0; bool covered = false, exists = false;
+        if (wave_on) {
+            uint32_t cover = 0, digits = 0;
+            for (int f = 0; f < W.nfiles; ++f) {
+                const StaReadsDev &R = W.files[f];
+                int64_t rlo, rhi;
+                if (W.nfiles == 1) { depth_read_range_next(R, p0, plast, rlo1, rhi1, have_range); have_range = true; rlo = rlo1; rhi = rhi1; }
+                else depth_read_range(R, p0, plast, rlo, rhi);
+                uint32_t cnt = 0;
+                depth_walk(R, P, A.has_clip, p0, plast, p, active, rlo, rhi, cnt, cover);
+                if (active) A.counts[(int64_t)f * (ncols + 1) + col] = (int32_t)cnt;
+                digits += 1 + (uint32_t)dec_digits_u32(cnt);
+            }
+            if (active) A.counts[(int64_t)W.nfiles * (ncols + 1) + col] = (int32_t)cover;
+            covered = active && cover > 0;
+            exists = active && (covered || (P.all_pos && apos < W.tlen));
+            if (exists && W.has_bed) exists = bed_overlap_dev(W.bed_beg, W.bed_end, W.n_bed, apos, apos + 1);
+            if (exists) len = (uint32_t)W.tname_len + 1 + (uint32_t)dec_digits((unsigned long long)(apos + 1)) + digits + 1;
         }
-        if (active) A.counts[(int64_t)W.nfiles * (ncols + 1) + col] = (int32_t)cover;
-        covered = active && cover > 0;
-        exists = active && (covered || (P.all_pos && apos < W.tlen));
-        if (exists && W.has_bed) exists = bed_overlap_dev(W.bed_beg, W.bed_end, W.n_bed, apos, apos + 1);
-        if (exists) len = (uint32_t)W.tname_len + 1 + (uint32_t)dec_digits((unsigned long long)(apos + 1)) + digits + 1;
-    }
-    uint32_t incl = len;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-    const uint32_t excl = incl - len;
-    const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    const unsigned long long n_rows = (unsigned long long)__popcll(__ballot(exists)), n_cov = (unsigned long long)__popcll(__ballot(covered));
-    if (lane == 0) { s_wtot[wid][0] = wave_total; s_wtot[wid][1] = (n_rows << 31) | n_cov; }
-    __syncthreads();
-    if (wid == 0) {
-        const unsigned long long agg0 = s_wtot[0][0] + s_wtot[1][0] + s_wtot[2][0] + s_wtot[3][0];
-        const unsigned long long agg1 = s_wtot[0][1] + s_wtot[1][1] + s_wtot[2][1] + s_wtot[3][1];
-        unsigned long long ex0, ex1;
-        tile_lookback(A.status, tile, agg0, agg1, ex0, ex1);
-        if (lane == 0) {
-            s_base[0] = ex0; s_base[1] = agg0;
-            if (tile + 1 == A.n_tiles) {
-                A.ctr->out_bytes = ex0 + agg0;
-                A.ctr->n_lines = (ex1 + agg1) >> 31;
-                A.ctr->n_data_cols = (ex1 + agg1) & 0x7fffffffull;
+        uint32_t incl = len;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+        const uint32_t excl = incl - len;
+        const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const unsigned long long n_rows = (unsigned long long)__popcll(__ballot(exists)), n_cov = (unsigned long long)__popcll(__ballot(covered));
+        if (lane == 0) { s_wtot[wid][0] = wave_total; s_wtot[wid][1] = (n_rows << 31) | n_cov; }
+        __syncthreads();
+        if (wid == 0) {
+            const unsigned long long agg0 = s_wtot[0][0] + s_wtot[1][0] + s_wtot[2][0] + s_wtot[3][0];
+            const unsigned long long agg1 = s_wtot[0][1] + s_wtot[1][1] + s_wtot[2][1] + s_wtot[3][1];
+            unsigned long long ex0, ex1;
+            tile_lookback(A.status, tile, agg0, agg1, ex0, ex1);
+            if (lane == 0) {
+                s_base[0] = ex0; s_base[1] = agg0;
+                if (tile + 1 == A.n_tiles) {
+                    A.ctr->out_bytes = ex0 + agg0;
+                    A.ctr->n_lines = (ex1 + agg1) >> 31;
+                    A.ctr->n_data_cols = (ex1 + agg1) & 0x7fffffffull;
+                }
             }
         }
-    }
-    __syncthreads();
-    const unsigned long long wg_off = s_base[0], wg_bytes = s_base[1];
-    if (wg_off + wg_bytes > A.capacity) { if (threadIdx.x == 0) A.ctr->overflow = 1; return; }
-    if (!wave_on || wave_total == 0) return;
-    unsigned long long wave_off = wg_off;
-    for (int w = 0; w < wid; ++w) wave_off += s_wtot[w][0];
+        __syncthreads();
+        const unsigned long long wg_off = s_base[0], wg_bytes = s_base[1];
+        if (wg_off + wg_bytes > A.capacity) { if (threadIdx.x == 0) A.ctr->overflow = 1; continue; }
+        if (!wave_on || wave_total == 0) continue;
+        unsigned long long wave_off = wg_off;
+        for (int w = 0; w < wid; ++w) wave_off += s_wtot[w][0];
 
-    // ---- EMIT: rows into the wave's LDS line buffer (rounds of consecutive rows when many input files make them long) ----
-    int a = 0;
-    while (a < 64) {
-        const uint32_t start = (uint32_t)__shfl((int)excl, a);
-        const bool fits = lane >= a && incl - start <= A.lbuf;
-        const int nb = __popcll(__ballot(fits));
-        if (nb == 0) {
-            if (lane == a && exists) { DSink<false> s; s.cur = 0; s.g = A.out + wave_off + excl; depth_row_write<false>(W, A.counts, ncols, col, s); }
-            a += 1;
-            continue;
+        // ---- EMIT: rows into the wave's LDS line buffer (rounds of consecutive rows when many input files make them long) ----
+        int a = 0;
+        while (a < 64) {
+            const uint32_t start = (uint32_t)__shfl((int)excl, a);
+            const bool fits = lane >= a && incl - start <= A.lbuf;
+            const int nb = __popcll(__ballot(fits));
+            if (nb == 0) {
+                if (lane == a && exists) { DSink<false> s; s.cur = 0; s.g = A.out + wave_off + excl; depth_row_write<false>(W, A.counts, ncols, col, s); }
+                a += 1;
+                continue;
+            }
+            const int b = a + nb;
+            const uint32_t rbytes = (uint32_t)__shfl((int)incl, b - 1) - start;
+            if (rbytes) {
+                char *dst = A.out + wave_off + start;
+                const uint32_t mis = (uint32_t)((uintptr_t)dst & 15);
+                wave_lds_sync();
+                if (lane >= a && lane < b && exists) { DSink<true> s; s.g = nullptr; s.cur = lb + mis + (excl - start); depth_row_write<true>(W, A.counts, ncols, col, s); }
+                wave_lds_sync();
+                wave_flush_text(lds_dtext + lb + mis, dst, rbytes);
+            }
+            a = b;
         }
-        const int b = a + nb;
-        const uint32_t rbytes = (uint32_t)__shfl((int)incl, b - 1) - start;
-        if (rbytes) {
-            char *dst = A.out + wave_off + start;
-            const uint32_t mis = (uint32_t)((uintptr_t)dst & 15);
-            wave_lds_sync();
-            if (lane >= a && lane < b && exists) { DSink<true> s; s.g = nullptr; s.cur = lb + mis + (excl - start); depth_row_write<true>(W, A.counts, ncols, col, s); }
-            wave_lds_sync();
-            wave_flush_text(lds_dtext + lb + mis, dst, rbytes);
-        }
-        a = b;
     }
 }
 
@@ -398,5 +431,8 @@ void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_p
     a.lbuf = lbuf; a.per_wave = ((lbuf + 16 + 15) & ~15u) + 16; a.n_tiles = (uint32_t)n_tiles;
     a.has_clip = p.remove_overlaps ? 1 : 0;
     DepthDevPar d{ p.min_qual, p.skip_del, p.all_pos };
-    hipLaunchKernelGGL(k_depth_fused, dim3((unsigned)n_tiles), dim3(256), (size_t)4 * a.per_wave, s, w, d, a);
+    int64_t tpb = 1;      // consecutive tiles per workgroup serialise the look-back chain (measured: 400x slower); kept as an experiment knob
+    { static const char *ev = getenv("STA_FUSED_TPB"); if (ev && atoi(ev) > 0) tpb = atoi(ev); }
+    a.tiles_per_batch = (uint32_t)tpb;
+    hipLaunchKernelGGL(k_depth_fused, dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), (size_t)4 * a.per_wave, s, w, d, a);
 }

@@ -203,11 +203,9 @@ int sta_mpileup_plan(sta_engine *e, const sta_mplp_params *p, sta_plan_info *inf
  * capacity >= out_bytes); dev_out == NULL uses an engine-owned buffer that
  * sta_fetch_output() copies back.  Asynchronous on the engine stream. */
 int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity);
-/* Plan and emit in one call (one kernel measures the lines, places them with a decoupled look-back and writes them): the
- * staged window's text goes to dev_out (device pointer; an exact size is not known in advance, so the capacity must cover
- * the text -- too small is STA_ERR_ARG and sta_last_error() names the size) or, with dev_out == NULL, to an engine-owned
- * buffer that grows as needed (read it with sta_fetch_output).  info receives the same counters as sta_mpileup_plan.
- * Synchronises the stream. */
+/* Plan and emit in one call: the staged window's text goes to dev_out (device pointer; the exact size is only known once
+ * the window is planned, so a capacity that turns out too small is STA_ERR_ARG) or, with dev_out == NULL, to an engine-owned
+ * buffer (read it with sta_fetch_output).  info receives the same counters as sta_mpileup_plan.  Synchronises the stream. */
 int sta_mpileup_run(sta_engine *e, const sta_mplp_params *p, void *dev_out, uint64_t capacity, sta_plan_info *info);
 
 /* ---- binary per-column pileup entries (the bam_plp_* / bam_mplp_* surface is built on these; see

@@ -64,7 +64,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, fused_status, giant, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     int baq_slab_gib_cap = 0;       // 0 = default; 4 after a one-launch BAQ slab could not be allocated
     double glf_depcorr = -1.0;      // theta the coefficient block in glf_tab was computed for
     StaWinDev wd{};
@@ -78,7 +78,6 @@ struct sta_engine {
     uint64_t out_bytes = 0;
     uint32_t lds_cap = 0;
     void *last_out = nullptr;
-    bool fused = false;             // the planned window's text was produced by the single-pass kernel (into e->out unless run() was given a buffer)
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;
@@ -174,7 +173,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->fused_status, &e->giant, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq };
+                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
     if (e->pipe_stream) hipStreamDestroy(e->pipe_stream);
@@ -214,7 +213,7 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
 {
     if (!e || !w || w->n_files < 0 || w->col_end < w->col_beg) return fail(e, STA_ERR_ARG, "bad window");
     hipSetDevice(e->device);
-    e->staged = false; e->planned = 0; e->fused = false;
+    e->staged = false; e->planned = 0;
     e->win = *w;
     e->tname = w->tname ? w->tname : "";
     if (e->fb.size() < (size_t)w->n_files) e->fb.resize((size_t)w->n_files);
@@ -318,6 +317,7 @@ static int finish_plan(sta_engine *e, int64_t ncols, sta_plan_info *info)
     uint32_t cap = (uint32_t)((mw + 255) & ~255ull);
     if (cap < 1024) cap = 1024;
     if (cap > 65536 - 64) cap = 65536 - 64;
+    if (getenv("STA_EMIT_LDS_CAP")) cap = (uint32_t)atoi(getenv("STA_EMIT_LDS_CAP"));      // experiment: waves above the cap write straight to global memory
     e->lds_cap = cap;
     if (info) {
         info->out_bytes = total; info->n_lines = e->ctr_h.n_lines; info->n_data_cols = e->ctr_h.n_data_cols;
@@ -518,7 +518,6 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
     } else {
         int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
         if (e->colinfo.ensure((size_t)(ncols > 0 ? ncols : 1) * (size_t)(nf > 0 ? nf : 1) * 8 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(column info) failed");
-        if (e->fused) return STA_OK;                // the single-pass kernel measures and writes in one launch (fused_text)
         ProfScope ps(e, "mplp_len");
         sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr);
     }
@@ -532,7 +531,7 @@ struct ModeGuard {
     sta_engine *e; const char *ref; int64_t len;
     ModeGuard(sta_engine *e_, bool plp, bool cov) : e(e_), ref(e_->wd.ref), len(e_->wd.ref_len)
     {
-        e->plp_mode = plp; e->cov_mode = cov; e->fused = false;
+        e->plp_mode = plp; e->cov_mode = cov;
         e->wd.ref = nullptr; e->wd.ref_len = 0;      // the plain iterator has no contig-length filter and no BAQ
     }
     ~ModeGuard() { e->plp_mode = false; e->cov_mode = false; e->wd.ref = ref; e->wd.ref_len = len; }
@@ -567,31 +566,7 @@ static int counting_pipeline(sta_engine *e, const sta_mplp_params *p)
     return mpileup_pipeline(e, p, true);
 }
 
-// ---- single-pass text path (k_mplp_fused): measure + offsets + text in one launch ----
-static bool fused_enabled(const sta_mplp_params *p)
-{
-    static const bool legacy = getenv("STA_MPLP_LEGACY") != nullptr;
-    return !legacy && sta_mplp_has_fast_path(*p);
-}
-static uint32_t fused_lbuf()
-{
-    static const uint32_t v = [] { const char *e = getenv("STA_MPLP_LBUF"); long x = e ? atol(e) : 0; return (uint32_t)(x >= 512 && x <= 11000 ? x : 8192); }();     // 4 waves x (5 KB + buffer) must stay within the default 64 KiB of dynamic LDS
-    return v;
-}
-// one launch into out[0, cap); the window totals land in StaCounters (out_bytes, n_lines, n_data_cols, overflow)
-static int fused_launch(sta_engine *e, const sta_mplp_params *p, char *out, uint64_t cap)
-{
-    const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
-    if (ncols <= 0) return STA_OK;
-    if (e->fused_status.ensure(sta_mplp_fused_status_bytes(ncols) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(look-back status) failed");
-    if (e->giant.ensure((size_t)((ncols + 63) / 64) * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(wave list) failed");
-    StaCounters *ctr = (StaCounters *)e->counters.p;
-    HIPCHK(hipMemsetAsync(&ctr->out_bytes, 0, 24, e->stream));              // out_bytes, overflow, n_giant
-    ProfScope ps(e, "mplp_fused");
-    sta_launch_mplp_fused(e->stream, e->wd, *p, e->fused_status.p, (uint2 *)e->colinfo.p, out, cap, ctr, fused_lbuf(), (uint32_t *)e->giant.p,
-                          (unsigned long long *)e->offs.p);
-    return STA_OK;
-}
+// totals of a single-pass kernel (k_depth_fused): counters -> host, one synchronisation
 static int fused_finish(sta_engine *e, sta_plan_info *info)
 {
     HIPCHK(hipMemcpyAsync(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
@@ -603,51 +578,6 @@ static int fused_finish(sta_engine *e, sta_plan_info *info)
         info->out_bytes = e->out_bytes; info->n_lines = e->ctr_h.n_lines; info->n_data_cols = e->ctr_h.n_data_cols;
         info->n_kept_reads = e->ctr_h.n_kept; info->piled_bases = e->ctr_h.piled_bases; info->n_maxcnt_dropped = e->ctr_h.n_dropped;
     }
-    return STA_OK;
-}
-// pipeline + single-pass text into `out` (NULL: the engine's own buffer, grown to fit; a caller's buffer that is too small is an error)
-static int fused_text(sta_engine *e, const sta_mplp_params *p, char *out, uint64_t cap, sta_plan_info *info)
-{
-    const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
-    e->min_pos.assign(e->files_h.size(), 0); e->max_pos_hint.assign(e->files_h.size(), 0);
-    int rc = mpileup_pipeline(e, p, false);
-    if (rc) return rc;
-    const bool own = out == nullptr;
-    if (own) {
-        // a guess that holds for ordinary data: 2 bytes of text per staged base (+ marks) and the fixed part of every line; the
-        // kernel keeps counting when the buffer is too small, so a wrong guess costs one more launch, not a wrong answer
-        uint64_t guess = (uint64_t)(ncols > 0 ? ncols : 0) * (uint64_t)(e->tname.size() + 28 + 12 * e->files_h.size()) + 4096;
-        for (auto &d : e->files_h) guess += d.n_bases_total * 5 / 2 + (uint64_t)d.n * 8;
-        if (e->out.ensure((size_t)guess)) return fail(e, STA_ERR_HIP, "hipMalloc(output) failed");
-        out = (char *)e->out.p; cap = e->out.cap;
-    }
-    rc = fused_launch(e, p, out, cap);
-    if (!rc) rc = fused_finish(e, info);
-    if (rc) return rc;
-    if (e->ctr_h.maxcnt_flag) {
-        // the -d cap may trigger in this window: exact replay, then the text again
-        rc = maxcnt_bounds(e);
-        if (!rc) rc = mpileup_pipeline(e, p, true);
-        if (!rc) rc = fused_launch(e, p, out, cap);
-        if (!rc) rc = fused_finish(e, info);
-        if (rc) return rc;
-    }
-    if (e->ctr_h.overflow) {
-        if (!own) return fail(e, STA_ERR_ARG, "output buffer too small (" + std::to_string(e->out_bytes) + " bytes needed)");
-        if (e->out.ensure((size_t)e->out_bytes + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(output) failed");
-        out = (char *)e->out.p; cap = e->out.cap;
-        rc = fused_launch(e, p, out, cap);
-        if (!rc) rc = fused_finish(e, info);
-        if (rc) return rc;
-        if (e->ctr_h.overflow) return fail(e, STA_ERR_HIP, "single-pass emit overflowed twice");
-    }
-    if (e->ctr_h.n_giant) {
-        // lines longer than the fused kernel's LDS line buffer (columns thousands of reads deep): written by the follow-up kernel
-        ProfScope ps(e, "mplp_emit_listed");
-        sta_launch_mplp_emit_listed(e->stream, e->wd, *p, (const unsigned long long *)e->offs.p, (const uint2 *)e->colinfo.p, out,
-                                    (const uint32_t *)e->giant.p, e->ctr_h.n_giant);
-    }
-    e->last_out = out;
     return STA_OK;
 }
 
@@ -663,14 +593,6 @@ int sta_mpileup_plan(sta_engine *e, const sta_mplp_params *p, sta_plan_info *inf
     }
     e->mp = *p;
     int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
-    e->fused = fused_enabled(p);
-    if (e->fused) {
-        // the text is produced right away, into the engine's buffer; sta_mpileup_emit hands it over
-        int rc = fused_text(e, p, nullptr, 0, info);
-        if (rc) { e->fused = false; return rc; }
-        e->planned = 1;
-        return STA_OK;
-    }
     // host-side bounds for the (rare) exact -d replay
     e->min_pos.assign(e->files_h.size(), 0); e->max_pos_hint.assign(e->files_h.size(), 0);
     int rc = mpileup_pipeline(e, p, false);
@@ -709,15 +631,6 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     if (!e) return STA_ERR_ARG;
     if (e->planned != 1) return fail(e, STA_ERR_ARG, "sta_mpileup_plan has not run for this window");
     hipSetDevice(e->device);
-    if (e->fused) {
-        // the single-pass kernel already wrote the text (engine buffer): a caller's buffer gets a device-to-device copy
-        if (dev_out && dev_out != e->last_out) {
-            if (capacity < e->out_bytes) return fail(e, STA_ERR_ARG, "output buffer too small");
-            if (e->out_bytes) HIPCHK(hipMemcpyAsync(dev_out, e->last_out, (size_t)e->out_bytes, hipMemcpyDeviceToDevice, e->stream));
-            e->last_out = dev_out;
-        }
-        return STA_OK;
-    }
     char *out = nullptr;
     int rc = emit_common(e, dev_out, capacity, &out);
     if (rc) return rc;
@@ -730,22 +643,10 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
 /* plan + emit in one call: the whole window's text into dev_out (NULL: engine buffer, read with sta_fetch_output) */
 int sta_mpileup_run(sta_engine *e, const sta_mplp_params *p, void *dev_out, uint64_t capacity, sta_plan_info *info)
 {
-    if (!e || !p) return STA_ERR_ARG;
-    if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
-    hipSetDevice(e->device);
-    if (!fused_enabled(p)) {
-        // per-read text columns (--output-extra, -O, -s): measuring pass + scan + generic emit kernel
-        sta_plan_info tmp;
-        int rc = sta_mpileup_plan(e, p, info ? info : &tmp);
-        if (rc) return rc;
-        return sta_mpileup_emit(e, dev_out, capacity);
-    }
-    e->mp = *p;
-    e->fused = true;
-    int rc = fused_text(e, p, (char *)dev_out, capacity, info);
-    if (rc) { e->fused = false; e->planned = 0; return rc; }
-    e->planned = 1;
-    return STA_OK;
+    sta_plan_info tmp;
+    int rc = sta_mpileup_plan(e, p, info ? info : &tmp);
+    if (rc) return rc;
+    return sta_mpileup_emit(e, dev_out, capacity);
 }
 
 /* ---- binary per-column entries (bam_plp_* surface) ---- */
@@ -906,7 +807,6 @@ int sta_calmd_plan(sta_engine *e, const sta_calmd_params *cp, sta_plan_info *inf
     hipSetDevice(e->device);
     const bool realn = (cp->flag & STA_CALMD_REALN) != 0, apply = (cp->flag & STA_CALMD_APPLY) != 0;
     if (realn && !e->wd.ref) return fail(e, STA_ERR_ARG, "calmd -r needs the reference of the contig");
-    e->fused = false;
     sta_mplp_params p; memset(&p, 0, sizeof p);
     p.flag = realn ? STA_MPLP_REALN : 0;
     e->mp = p;

@@ -466,16 +466,6 @@ void sta_launch_len_scan(hipStream_t s, const uint32_t *len, uint64_t *offs, int
     run_scan<OpSumU64, LoadU32, uint64_t, true>(s, ld, n, offs, tmp);
 }
 
-// depth: in-place inclusive prefix sum of each row of diff[nrows][ncols+1] over the first ncols entries
-void sta_launch_depth_scan(hipStream_t s, int32_t *diff, int nrows, int64_t ncols, void *tmp, size_t)
-{
-    for (int r = 0; r < nrows; ++r) {
-        int32_t *row = diff + (int64_t)r * (ncols + 1);
-        LoadI32 ld{ row };
-        run_scan<OpSumI32, LoadI32, int32_t, false>(s, ld, ncols, row, tmp);
-    }
-}
-
 // Column statistics after the scan: max over waves (64 columns) of the output bytes a wave must stage
 // (sizes the emit kernels' LDS), number of output rows, number of columns with data.  Grid-stride,
 // block-reduced: a few thousand atomics in total.

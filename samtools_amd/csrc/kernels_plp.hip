@@ -20,7 +20,6 @@
 //                lines exceed the LDS slice falls back to direct global byte stores.
 #include "dev_util.h"
 #include <cstdlib>
-#include "dev_lookback.h"
 
 struct MplpDevPar {
     int32_t min_baseQ, all, rev_del, flag, no_ins, no_del, no_ends;
@@ -330,32 +329,6 @@ __device__ __forceinline__ void wave_read_range(const StaReadsDev &R, int p0, in
     if (R.n == 0) { rlo = rhi = 0; return; }
     rlo = wave_upper_bound(R.maxend, R.n, p0);      // first read with an end beyond the first column
     rhi = wave_upper_bound(R.pos, R.n, p1);         // first read starting beyond the last column
-    if (rlo > rhi) rlo = rhi;
-}
-
-// The next wave tile's range from the previous one's (tiles are visited left to right, so both bounds only move forward): one
-// coalesced 64-entry probe per bound in the common case instead of two 64-ary searches of ~4 dependent loads each.
-__device__ __forceinline__ void wave_read_range_next(const StaReadsDev &R, int p0, int p1, int64_t &rlo, int64_t &rhi, bool have_prev)
-{
-    if (R.n == 0) { rlo = rhi = 0; return; }
-    if (!have_prev) { wave_read_range(R, p0, p1, rlo, rhi); return; }
-    const int lane = threadIdx.x & 63;
-    bool found = false;
-    for (int it = 0; it < 3 && !found; ++it) {
-        const int64_t idx = rlo + lane;
-        const unsigned long long m = __ballot(idx < R.n ? R.maxend[idx] > p0 : true);
-        if (m) { rlo += __ffsll((long long)m) - 1; found = true; } else rlo += 64;
-    }
-    if (!found) rlo = wave_upper_bound(R.maxend, R.n, p0);
-    if (rlo > R.n) rlo = R.n;
-    found = false;
-    for (int it = 0; it < 3 && !found; ++it) {
-        const int64_t idx = rhi + lane;
-        const unsigned long long m = __ballot(idx < R.n ? R.pos[idx] > p1 : true);
-        if (m) { rhi += __ffsll((long long)m) - 1; found = true; } else rhi += 64;
-    }
-    if (!found) rhi = wave_upper_bound(R.pos, R.n, p1);
-    if (rhi > R.n) rhi = R.n;
     if (rlo > rhi) rlo = rhi;
 }
 
@@ -755,417 +728,6 @@ __global__ void __launch_bounds__(256) k_mplp_emit_fast(StaWinDev W, MplpDevPar 
 }
 
 
-// ================================================================================================
-// Single-pass column kernel: measuring pass, offsets and text in ONE launch (no k_mplp_len / scan / k_col_stats launches,
-// no host round trip between "how long are the lines" and "write them").
-//
-//  * A workgroup takes a ticket (tile = 256 consecutive columns, one wave per 64) -- tiles are handed out in start order,
-//    so a tile only ever waits for tiles that are already running.
-//  * COUNT pass: every wave walks its candidate reads and counts, per column, the entries, the entries that pass -Q and
-//    the base-string bytes; line lengths -> wave / workgroup totals.
-//  * Decoupled look-back over the tiles' status words ({flag, bytes} and {flag, rows, data columns}, each ONE 8-byte word
-//    written with a device-scope store, so the value IS the flag: no fence pairs) gives the tile's byte offset in the
-//    output; the last tile leaves the window totals in StaCounters.
-//  * EMIT pass: the wave walks the same reads again and builds its lines in its LDS line buffer at their final relative
-//    positions, then flushes with coalesced 16-byte stores.  A wave whose text exceeds the line buffer emits it in rounds
-//    of consecutive columns (deep columns: 300x needs ~40 KB per 64 columns); a single line longer than the buffer is
-//    written straight to global memory.  LDS per wave is therefore a constant, whatever the depth.
-//
-// The walk itself is restructured for throughput: the candidate reads' metadata is loaded 64 at a time, the live ones are
-// compacted, and their bases are converted READ-MAJOR -- 16 lanes per read, 4 columns per lane, one 4-byte load of
-// qualities and one of packed bases per lane -- into a small LDS tile (one byte of quality-character + pass flag and one
-// byte of base code per (read, column)).  The column-major pass then costs one LDS byte read per (read, lane) instead of
-// per-lane global byte loads and the per-read address arithmetic.  Reads that are not a single M run take the generic
-// per-entry path (resolve_general / token_len / token_write), as in k_mplp_emit_fast.
-
-#define FT_ROWS 32                       // reads per LDS tile
-#define FT_META 1024                     // 4 arrays x 64 x 4 bytes of compacted read metadata
-#define FT_TILE (2 * 64 * FT_ROWS)
-
-struct FusedArgs {
-    unsigned long long *status;          // 2 words per tile, zeroed before the launch
-    unsigned int *ticket;                // zeroed before the launch
-    char *out; unsigned long long capacity;
-    uint2 *colinfo;                      // [nfiles][ncols] (count, seq bytes) when the window has more than one input file
-    StaCounters *ctr;
-    uint32_t lbuf;                       // line-buffer bytes per wave
-    uint32_t per_wave;                   // LDS bytes per wave (metadata + tile + line buffer slice)
-    uint32_t n_tiles;
-    uint32_t tiles_per_batch;            // consecutive tiles one workgroup (one ticket) works through
-    // waves holding a line longer than the line buffer: their wave index goes to giant[ctr->n_giant++], the per-column
-    // offsets to offs[] and (one input file) the per-column counts to colinfo_one[]; k_mplp_emit_listed writes them
-    uint32_t *giant; unsigned long long *offs; uint2 *colinfo_one;
-};
-
-typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-
-// MODE 0: count (n_plp, cnt, seq_len)   MODE 1: write base string at ss and quality string at sq
-//
-// Tile layout: tq32[(row / 4) * 64 + column] packs the quality bytes of FOUR consecutive reads for one column into one dword
-// (byte row & 3), tc32 likewise the base codes -- the column pass fetches four reads with one LDS load per array and lane.
-// (one instance serves both passes -- `emit` is wave-uniform -- so that the kernel's code stays small: the conversion and the
-// generic-entry path appear once)
-__device__ __forceinline__ void fused_walk(const bool emit, const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int p0, int plast, int p, bool active,
-                                           int rbcode, int64_t rlo, int64_t rhi, char *wl, uint32_t &n_plp, uint32_t &cnt, uint32_t &seq_len,
-                                           Sink<true> &ss, Sink<true> &sq)
-{
-    const int lane = threadIdx.x & 63;
-    const bool ends = !P.no_ends;
-    const auto g_info = GPTR(uint32_t, R.info); const auto g_pos = GPTR(int32_t, R.pos); const auto g_end = GPTR(int32_t, R.end);
-    const auto g_b8 = GPTR(uint32_t, R.base_off8); const auto g_qual = GPTR(uint8_t, R.qual); const auto g_seq = GPTR(uint8_t, R.seq);
-    uint32_t *m_info = reinterpret_cast<uint32_t *>(wl); int32_t *m_pos = reinterpret_cast<int32_t *>(wl + 256);
-    int32_t *m_end = reinterpret_cast<int32_t *>(wl + 512); uint32_t *m_b8 = reinterpret_cast<uint32_t *>(wl + 768);
-    uint8_t *tq = reinterpret_cast<uint8_t *>(wl + FT_META), *tc = tq + 64 * FT_ROWS;
-    const uint32_t *tq32 = reinterpret_cast<const uint32_t *>(tq), *tc32 = reinterpret_cast<const uint32_t *>(tc);
-    const int grp = lane >> 4, t4 = (lane & 15) << 2;
-    const uint64_t qual_bytes = R.n_bases_total, seq_bytes = R.n_bases_total >> 1;
-    constexpr int NSTEP = FT_ROWS / 4;
-    for (int64_t b0 = rlo; b0 < rhi; b0 += 64) {
-        const int64_t ri = b0 + lane;
-        const bool ok = ri < rhi;
-        const uint32_t v_info = ok ? g_info[ri] : 0u;
-        const int v_pos = ok ? g_pos[ri] : 0;
-        const int v_end = ok ? g_end[ri] : 0;
-        const uint32_t v_b8 = ok ? g_b8[ri] : 0u;
-        const bool lv = ok && (v_info & RI_KEEP) && v_end > p0 && v_pos <= plast;
-        const unsigned long long live = __ballot(lv);
-        if (!live) continue;
-        const int nlive = __popcll(live);
-        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-        wave_lds_sync();                                 // the previous batch's tile / metadata readers are done
-        if (lv) { m_info[rank] = (v_info & 0x00ffffffu) | ((uint32_t)lane << 24); m_pos[rank] = v_pos; m_end[rank] = v_end; m_b8[rank] = v_b8; }
-        wave_lds_sync();
-        // compacted copies: lane k holds live read k (lanes >= nlive hold stale words that are never selected)
-        const uint32_t c_info = m_info[lane]; const int c_pos = m_pos[lane], c_end = m_end[lane]; const uint32_t c_b8 = m_b8[lane];
-        for (int t0 = 0; t0 < nlive; t0 += FT_ROWS) {
-            const int nt = nlive - t0 < FT_ROWS ? nlive - t0 : FT_ROWS;
-            if (t0) wave_lds_sync();                     // the previous tile's column pass is done
-            // ---- read-major conversion: 4 reads per step, 16 lanes per read, 4 columns per lane.  All loads of the tile are
-            //      issued before the first one is used (one exposed memory latency per tile, not per step) ----
-            uint32_t qd[NSTEP], sd[NSTEP];
-#pragma unroll
-            for (int u = 0; u < NSTEP; ++u) {
-                qd[u] = 0; sd[u] = 0;
-                const int row = 4 * u + grp;
-                if (row < nt) {
-                    const int src = t0 + row;
-                    if (m_info[src] & RI_SIMPLE) {
-                        const int rpos = m_pos[src], rl = m_end[src] - rpos;
-                        const int qpos0 = p0 + t4 - rpos;
-                        if (qpos0 > -4 && qpos0 < rl) {
-                            const uint64_t boff = (uint64_t)m_b8[src] << 3;
-                            const int ld = qpos0 < 0 ? 0 : qpos0;
-                            const uint64_t qa = boff + (uint64_t)ld, sa = (boff >> 1) + (uint64_t)(ld >> 1);
-                            if (qa + 4 <= qual_bytes) qd[u] = *reinterpret_cast<const __attribute__((address_space(1))) u32_unaligned *>(g_qual + qa);
-                            else { for (int k = 0; k < 4; ++k) if (qa + (uint64_t)k < qual_bytes) qd[u] |= (uint32_t)g_qual[qa + k] << (8 * k); }
-                            if (sa + 4 <= seq_bytes) sd[u] = *reinterpret_cast<const __attribute__((address_space(1))) u32_unaligned *>(g_seq + sa);
-                            else { for (int k = 0; k < 4; ++k) if (sa + (uint64_t)k < seq_bytes) sd[u] |= (uint32_t)g_seq[sa + k] << (8 * k); }
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < NSTEP; ++u) {
-                const int row = 4 * u + grp;
-                if (row < nt) {
-                    const int src = t0 + row;
-                    if (m_info[src] & RI_SIMPLE) {
-                        const int rpos = m_pos[src], rl = m_end[src] - rpos;
-                        const int qpos0 = p0 + t4 - rpos;
-                        const int ld = qpos0 < 0 ? 0 : qpos0;
-                        const bool any_valid = qpos0 > -4 && qpos0 < rl;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int qpos = qpos0 + k;
-                            const bool valid = any_valid && qpos >= 0 && qpos < rl;
-                            const int q = (int)((qd[u] >> (8 * ((qpos - ld) & 3))) & 0xffu);
-                            const int n = qpos - (ld & ~1);                    // nibble index inside sd (high nibble first)
-                            const uint32_t c = (sd[u] >> (8 * ((n >> 1) & 3) + ((n & 1) ? 0 : 4))) & 0xfu;
-                            int qc = q + 33; qc = qc > 126 ? 126 : qc;
-                            qc |= q >= P.min_baseQ ? 0x80 : 0;
-                            const int at = ((u * 64 + t4 + k) << 2) + grp;
-                            tq[at] = (uint8_t)(valid ? qc : 0);
-                            tc[at] = (uint8_t)c;
-                        }
-                    }
-                }
-            }
-            wave_lds_sync();
-            // ---- column-major pass: one lane per column, reads in file order, four reads per LDS load ----
-            uint32_t nq4 = tq32[lane], nc4 = tc32[lane];
-            for (int u = 0; 4 * u < nt; ++u) {
-                const uint32_t q4 = nq4, c4 = nc4;
-                if (4 * (u + 1) < nt) { nq4 = tq32[(u + 1) * 64 + lane]; nc4 = tc32[(u + 1) * 64 + lane]; }   // next group: in flight during this one
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int row = 4 * u + k;
-                    if (row >= nt) break;
-                    const int j = t0 + row;
-                    const uint32_t info = rl_u(c_info, j);
-                    const int rpos = rl_i(c_pos, j), rend = rl_i(c_end, j);
-                    if (info & RI_SIMPLE) {
-                        const uint32_t qb = (q4 >> (8 * k)) & 0xffu;
-                        const bool pass = (qb & 0x80u) && active;
-                        if (!emit) {
-                            const bool cov = qb != 0 && active;
-                            n_plp += cov ? 1u : 0u;
-                            cnt += pass ? 1u : 0u;
-                            seq_len += pass ? 1u : 0u;
-                            // head / tail marks: only when the read starts / ends inside this wave's 64 columns (uniform branches)
-                            if (ends && rpos >= p0 && rpos <= plast) seq_len += (pass && p == rpos) ? 2u : 0u;
-                            if (ends && rend - 1 >= p0 && rend - 1 <= plast) seq_len += (pass && p == rend - 1) ? 1u : 0u;
-                        } else {
-                            const bool rev = (info & RI_REV) != 0;
-                            int c = (int)((c4 >> (8 * k)) & 0xffu);
-                            if (c == rbcode) c = 0;
-                            const char ch = base_char_fast(c, rev);
-                            const char qch = (char)(qb & 0x7fu);
-                            const bool head_here = ends && rpos >= p0 && rpos <= plast, tail_here = ends && rend - 1 >= p0 && rend - 1 <= plast;
-                            const int mq = (int)((info >> RI_MAPQ_SHIFT) & 0xff);
-                            // branch-free appends: a lane with nothing to add writes at its cursor without advancing it (the byte is
-                            // overwritten by its next real write or by the separator fused_emit_lines puts there after the walk)
-                            uint32_t cur = ss.cur;
-                            if (head_here) {
-                                const bool head = pass && p == rpos;
-                                lds_text[cur] = '^';
-                                lds_text[cur + (head ? 1u : 0u)] = (char)(mq > 93 ? 126 : mq + 33);
-                                cur += head ? 2u : 0u;
-                            }
-                            lds_text[cur] = ch;
-                            cur += pass ? 1u : 0u;
-                            if (tail_here) {
-                                const bool tail = pass && p == rend - 1;
-                                lds_text[cur] = '$';
-                                cur += tail ? 1u : 0u;
-                            }
-                            ss.cur = cur;
-                            lds_text[sq.cur] = qch;
-                            sq.cur += pass ? 1u : 0u;
-                        }
-                    } else {
-                        // generic entry (uniform branch: the read is the same for every lane)
-                        const bool cov = active && p >= rpos && p < rend;
-                        if (__ballot(cov) == 0) continue;
-                        if (cov) {
-                            Entry e;
-                            e.r = b0 + (int64_t)(info >> 24); e.rpos = rpos; e.rend = rend; e.info = info & 0x00ffffffu;
-                            e.lq = R.l_qseq[e.r];
-                            e.boff = (uint64_t)rl_u(c_b8, j) << 3;
-                            e.rs = resolve_general(R.cigar + R.cig_off[e.r], (int)(R.cig_off[e.r + 1] - R.cig_off[e.r]), e.rpos, p);
-                            if (!emit) n_plp++;
-                            int c = e.rs.is_del ? placeholder_qual(R, e.r, e.rs.qpos, e.lq, e.boff, p) : (e.rs.qpos < e.lq ? R.qual[e.boff + (uint64_t)e.rs.qpos] : 0);
-                            if (c >= P.min_baseQ) {
-                                if (!emit) { cnt++; seq_len += (uint32_t)token_len(R, P, e, p); }
-                                else {
-                                    token_write<true>(R, W, P, e, p, ss);
-                                    sq.put((char)(c + 33 < 126 ? c + 33 : 126));
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-// the lines of the wave's columns (lanes with `mine`), each at s (LDS: final position inside the wave's line buffer; global: final
-// address).  Mirrors emit_column_fast; (count, base-string bytes) per file come from the COUNT pass: registers for one input file,
-// colinfo otherwise.
-__device__ __forceinline__ void fused_emit_lines(const StaWinDev &W, const MplpDevPar &P, const uint2 *colinfo, int64_t ncols, int64_t col,
-                                                 int p0, int plast, int p, bool mine, uint32_t cnt0, uint32_t sl0, char *wl, Sink<true> &s, uint32_t dump,
-                                                 int64_t rlo1, int64_t rhi1)
-{
-    const int64_t apos = W.origin + p;
-    int rbcode = -1;
-    if (mine) {
-        for (int t = 0; t < W.tname_len; ++t) s.put(W.tname[t]);
-        s.put('\t');
-        s.put_dec(apos + 1);
-        s.put('\t');
-        const char rc = (W.ref && apos < W.ref_len) ? W.ref[apos] : 'N';
-        s.put(rc);
-        if (W.ref) rbcode = apos < W.ref_len ? (int)c_nt16_of_char[(unsigned char)rc] : 15;
-    }
-    for (int f = 0; f < W.nfiles; ++f) {
-        const StaReadsDev &R = W.files[f];
-        int64_t rlo = rlo1, rhi = rhi1;                      // the COUNT pass's range when the window has one input file
-        if (W.nfiles > 1) wave_read_range(R, p0, plast, rlo, rhi);
-        uint32_t cnt = cnt0, seq_len = sl0;
-        if (colinfo) { const uint2 ci = mine ? colinfo[(int64_t)f * ncols + col] : make_uint2(0, 0); cnt = ci.x; seq_len = ci.y; }
-        if (!mine) { cnt = 0; seq_len = 0; }
-        Sink<true> ss = s, sq = s;
-        const uint32_t sl = seq_len ? seq_len : 1;
-        if (mine) {
-            s.put('\t'); s.put_dec(cnt); s.put('\t');
-            ss = s;
-            sq = s; sq.cur += sl + 1; sq.g += sl + 1;
-        }
-        const bool walk = mine && cnt;
-        if (!walk) ss.cur = sq.cur = dump;     // lanes without entries: predicated writes land in the wave's dump bytes
-        uint32_t d0 = 0, d1 = 0, d2 = 0;
-        fused_walk(true, R, W, P, p0, plast, p, walk, rbcode, rlo, rhi, wl, d0, d1, d2, ss, sq);
-        if (mine) {
-            // separators and the '*' placeholders go in AFTER the walk (its last predicated write may sit on them)
-            Sink<true> st = s;
-            if (!cnt) { st.put('*'); st.put('\t'); st.put('*'); }
-            else { st.cur += sl; st.g += sl; st.put('\t'); }
-            s.cur += sl + 1 + (cnt ? cnt : 1); s.g += sl + 1 + (cnt ? cnt : 1);
-        }
-    }
-    if (mine) s.put('\n');
-}
-
-__global__ void __launch_bounds__(256) k_mplp_fused(StaWinDev W, MplpDevPar P, FusedArgs A)
-{
-    __shared__ unsigned int s_batch;
-    __shared__ unsigned long long s_wtot[4][2];
-    __shared__ unsigned long long s_base[2];
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // one ticket per BATCH of consecutive tiles (a ticket word sustains ~90 atomics/us: one per tile would cost more than the
-    // tiles); batches are handed out in start order, so a tile only ever waits for tiles that are already running
-    if (threadIdx.x == 0) s_batch = atomicAdd(A.ticket, 1u);
-    __syncthreads();
-    const unsigned int batch = s_batch;
-    const int64_t ncols = (int64_t)W.col_end - W.col_beg;
-    char *wl = lds_text + (size_t)wid * A.per_wave;
-    const uint32_t lb = (uint32_t)wid * A.per_wave + FT_META + FT_TILE;          // line buffer: index into lds_text
-    const uint32_t dump = lb + ((A.lbuf + 16 + 15) & ~15u);                      // 16 bytes behind the text area (+ alignment slack)
-    const uint2 *ci = A.colinfo;
-    int64_t rlo1 = 0, rhi1 = 0; bool have_range = false;                         // single input file: the wave's read range moves forward tile by tile
-
-    for (unsigned ti = 0; ti < A.tiles_per_batch; ++ti) {
-        const unsigned int tile = batch * A.tiles_per_batch + ti;
-        if (tile >= A.n_tiles) break;
-        __syncthreads();                                     // every wave is done with the previous tile's shared words
-        const int64_t c0 = ((int64_t)tile * 4 + wid) * 64;
-        const bool wave_on = c0 < ncols;
-        const int p0 = W.col_beg + (int)(wave_on ? c0 : 0);
-        const int p = p0 + lane;
-        const bool active = wave_on && p < W.col_end;
-        const int plast = p0 + 63 < W.col_end ? p0 + 63 : W.col_end - 1;
-        const int64_t apos = W.origin + p;
-
-        // ---- COUNT ----
-        uint32_t total = 0, cnt0 = 0, sl0 = 0; bool any = false;
-        if (wave_on) {
-            Sink<true> d1, d2; d1.g = d2.g = nullptr; d1.cur = d2.cur = 0;
-            for (int f = 0; f < W.nfiles; ++f) {
-                const StaReadsDev &R = W.files[f];
-                int64_t rlo, rhi;
-                if (W.nfiles == 1) { wave_read_range_next(R, p0, plast, rlo1, rhi1, have_range); have_range = true; rlo = rlo1; rhi = rhi1; }
-                else wave_read_range(R, p0, plast, rlo, rhi);
-                uint32_t n_plp = 0, cnt = 0, seq_len = 0;
-                fused_walk(false, R, W, P, p0, plast, p, active, -1, rlo, rhi, wl, n_plp, cnt, seq_len, d1, d2);
-                any |= n_plp > 0;
-                total += 1 + (uint32_t)dec_digits_u32(cnt) + 1 + (seq_len ? seq_len : 1) + 1 + (cnt ? cnt : 1);
-                if (A.colinfo) { if (active) A.colinfo[(int64_t)f * ncols + c0 + lane] = make_uint2(cnt, seq_len); }
-                else { cnt0 = cnt; sl0 = seq_len; }
-            }
-        }
-        const bool in_reg = active && column_selected(W, apos);
-        const bool data = in_reg && any;
-        bool exists = in_reg && (any || (P.all && apos < P.tlen));
-        if (exists && W.has_bed) exists = bed_overlap_dev(W.bed_beg, W.bed_end, W.n_bed, apos, apos + 1);
-        uint32_t len = 0;
-        if (exists) len = (uint32_t)W.tname_len + 1 + (uint32_t)dec_digits((unsigned long long)(apos + 1)) + 1 + 1 + total + 1;
-        // offsets inside the wave
-        uint32_t incl = len;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-        const uint32_t excl = incl - len;
-        const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        const unsigned long long n_rows = (unsigned long long)__popcll(__ballot(exists)), n_data = (unsigned long long)__popcll(__ballot(data));
-        if (lane == 0) { s_wtot[wid][0] = wave_total; s_wtot[wid][1] = (n_rows << 31) | n_data; }
-        __syncthreads();
-
-        // ---- decoupled look-back (wave 0) ----
-        if (wid == 0) {
-            const unsigned long long agg0 = s_wtot[0][0] + s_wtot[1][0] + s_wtot[2][0] + s_wtot[3][0];
-            const unsigned long long agg1 = s_wtot[0][1] + s_wtot[1][1] + s_wtot[2][1] + s_wtot[3][1];
-            unsigned long long ex0, ex1;
-            tile_lookback(A.status, tile, agg0, agg1, ex0, ex1);
-            if (lane == 0) {
-                s_base[0] = ex0; s_base[1] = agg0;
-                if (tile + 1 == A.n_tiles) {
-                    A.ctr->out_bytes = ex0 + agg0;
-                    A.ctr->n_lines = (ex1 + agg1) >> 31;
-                    A.ctr->n_data_cols = (ex1 + agg1) & 0x7fffffffull;
-                }
-            }
-        }
-        __syncthreads();
-        const unsigned long long wg_off = s_base[0], wg_bytes = s_base[1];
-        if (wg_off + wg_bytes > A.capacity) { if (threadIdx.x == 0) A.ctr->overflow = 1; continue; }    // counted, not written: the host retries with room
-        if (!wave_on || wave_total == 0) continue;
-        unsigned long long wave_off = wg_off;
-        for (int w = 0; w < wid; ++w) wave_off += s_wtot[w][0];
-
-        // ---- EMIT, in rounds of consecutive columns that fit the line buffer ----
-        int a = 0; bool listed = false;
-        while (a < 64) {
-            const uint32_t start = (uint32_t)__shfl((int)excl, a);
-            const bool fits = lane >= a && incl - start <= A.lbuf;
-            const int nb = __popcll(__ballot(fits));                             // line ends are monotone: the fitting lanes are a .. a+nb-1
-            if (nb == 0) {
-                // One line longer than the whole buffer (thousands of reads deep): this wave's columns go on the list of the
-                // follow-up kernel, which writes such lines straight to global memory (k_mplp_emit_listed) from the offsets and
-                // per-column counts left here.  Rare; the rest of the wave is still written below.
-                if (!listed) {
-                    listed = true;
-                    if (active) {
-                        A.offs[c0 + lane] = wave_off + excl;
-                        if (!ci) A.colinfo_one[c0 + lane] = make_uint2(cnt0, sl0);
-                    }
-                    if (lane == 0) {
-                        A.offs[c0 + 64 < ncols ? c0 + 64 : ncols] = wave_off + wave_total;
-                        const unsigned long long k = atomicAdd(&A.ctr->n_giant, 1ull);
-                        A.giant[k] = (uint32_t)(c0 >> 6);
-                    }
-                }
-                a += 1;
-                continue;
-            }
-            const int b = a + nb;
-            const uint32_t rbytes = (uint32_t)__shfl((int)incl, b - 1) - start;
-            if (rbytes) {
-                char *dst = A.out + wave_off + start;
-                const uint32_t mis = (uint32_t)((uintptr_t)dst & 15);
-                const bool mine = lane >= a && lane < b && exists;
-                Sink<true> s; s.g = nullptr; s.cur = lb + mis + (excl - start);
-                wave_lds_sync();                                                 // the previous round's flush has read the buffer
-                fused_emit_lines(W, P, ci, ncols, c0 + lane, p0, plast, p, mine, cnt0, sl0, wl, s, dump, rlo1, rhi1);
-                wave_lds_sync();
-                wave_flush_text(lds_text + lb + mis, dst, rbytes);              // LDS offset == global address (mod 16)
-            }
-            a = b;
-        }
-    }
-}
-
-// The waves k_mplp_fused put on its list (a line longer than its LDS line buffer): every line of such a wave is written
-// straight to global memory at the offsets the fused kernel left in offs[] (lines the fused kernel already wrote are simply
-// written again with the same bytes).
-__global__ void __launch_bounds__(256) k_mplp_emit_listed(StaWinDev W, MplpDevPar P, const unsigned long long *__restrict__ offs, const uint2 *__restrict__ colinfo,
-                                                          char *out, const uint32_t *__restrict__ list, unsigned long long n_list)
-{
-    const unsigned long long li = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (li >= n_list) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t ncols = (int64_t)W.col_end - W.col_beg;
-    const int64_t c0 = (int64_t)list[li] * 64;
-    const int64_t c1 = c0 + 64 < ncols ? c0 + 64 : ncols;
-    const int p0 = W.col_beg + (int)c0;
-    const int p = p0 + lane;
-    const bool active = p < W.col_end;
-    const int plast = W.col_beg + (int)c1 - 1;
-    const unsigned long long o1 = offs[c1];
-    const unsigned long long my0 = active ? offs[c0 + lane] : o1;
-    const unsigned long long my1 = active ? (lane == 63 || c0 + lane + 1 == c1 ? o1 : offs[c0 + lane + 1]) : o1;
-    const bool exists = my1 > my0;
-    Sink<false> s; s.cur = 0; s.g = out + my0;
-    emit_column_fast<false>(W, P, colinfo, ncols, c0 + lane, p0, plast, p, exists, s, 0);
-}
-
 static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
 {
     MplpDevPar d;
@@ -1207,42 +769,5 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
     hipLaunchKernelGGL(k_mplp_emit, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, make_par(p, w.tlen), offs, out, lds_cap);
 }
 
-// LDS per wave of k_mplp_fused for a line buffer of `lbuf` bytes
-static uint32_t fused_per_wave(uint32_t lbuf) { return FT_META + FT_TILE + ((lbuf + 16 + 15) & ~15u) + 16; }
-
-size_t sta_mplp_fused_status_bytes(int64_t ncols)
-{
-    int64_t n_tiles = (ncols + 255) / 256;
-    return (size_t)n_tiles * 16 + 16;          // 2 words per tile + the ticket
-}
-
-void sta_launch_mplp_fused(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, void *status, uint2 *colinfo, char *out,
-                           uint64_t capacity, StaCounters *ctr, uint32_t lbuf, uint32_t *giant, unsigned long long *offs)
-{
-    int64_t ncols = (int64_t)w.col_end - w.col_beg;
-    if (ncols <= 0) return;
-    const int64_t n_tiles = (ncols + 255) / 256;
-    hipMemsetAsync(status, 0, sta_mplp_fused_status_bytes(ncols), s);
-    FusedArgs a;
-    a.status = (unsigned long long *)status;
-    a.ticket = (unsigned int *)((char *)status + (size_t)n_tiles * 16);
-    a.out = out; a.capacity = capacity; a.colinfo = w.nfiles > 1 ? colinfo : nullptr; a.ctr = ctr;
-    a.lbuf = lbuf; a.per_wave = fused_per_wave(lbuf); a.n_tiles = (uint32_t)n_tiles;
-    a.giant = giant; a.offs = offs; a.colinfo_one = colinfo;
-    // enough batches to keep every CU busy through the tail (~768 workgroups are resident), as few tickets as that allows
-    int64_t tpb = 1;      // consecutive tiles per workgroup serialise the look-back chain (measured: 400x slower); kept as an experiment knob
-    { static const char *ev = getenv("STA_FUSED_TPB"); if (ev && atoi(ev) > 0) tpb = atoi(ev); }
-    a.tiles_per_batch = (uint32_t)tpb;
-    const int64_t n_batches = (n_tiles + tpb - 1) / tpb;
-    hipLaunchKernelGGL(k_mplp_fused, dim3((unsigned)n_batches), dim3(256), (size_t)4 * a.per_wave, s, w, make_par(p, w.tlen), a);
-}
-
-void sta_launch_mplp_emit_listed(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const unsigned long long *offs, const uint2 *colinfo,
-                                 char *out, const uint32_t *list, uint64_t n_list)
-{
-    if (!n_list) return;
-    hipLaunchKernelGGL(k_mplp_emit_listed, dim3((unsigned)((n_list + 3) / 4)), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, out, list, (unsigned long long)n_list);
-}
-
-// no --output-extra / -O / -s columns: the window can take the single-pass kernel
+// no --output-extra / -O / -s columns: the window takes the fast kernel pair
 bool sta_mplp_has_fast_path(const sta_mplp_params &p) { return !((uint32_t)p.flag & EXTRA_MASK) && p.n_tags <= 0; }

@@ -70,7 +70,6 @@ struct StaWinDev {
 struct StaCounters {          // device-side reduction targets, zeroed per plan
     unsigned long long n_lines, n_data_cols, n_kept, piled_bases, n_dropped, max_wave_bytes, n_anom, maxcnt_flag, max_lq, max_bw, n_baq, max_lq_fast, n_baq_fast, n_baq_bw8, n_baq_general;
     unsigned long long out_bytes, overflow;      // single-pass kernels: total text bytes of the window; set when the output buffer was too small
-    unsigned long long n_giant;                  // k_mplp_fused: waves with a line longer than the LDS line buffer (written by k_mplp_emit_listed)
 };
 
 // ---- launchers (defined in the .hip files) ----
@@ -88,14 +87,7 @@ void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_param
                          StaCounters *ctr);
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
                           char *out, uint32_t lds_cap);
-// single-pass measure + look-back + emit (kernels_plp.hip): `status` = sta_mplp_fused_status_bytes(ncols) bytes of scratch
-size_t sta_mplp_fused_status_bytes(int64_t ncols);
 bool sta_mplp_has_fast_path(const sta_mplp_params &p);
-void sta_launch_mplp_fused(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, void *status, uint2 *colinfo, char *out,
-                           uint64_t capacity, StaCounters *ctr, uint32_t lbuf, uint32_t *giant /*[waves]*/, unsigned long long *offs /*[ncols + 1]*/);
-// follow-up for the waves the fused kernel listed (ctr->n_giant of them): lines longer than its LDS line buffer
-void sta_launch_mplp_emit_listed(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const unsigned long long *offs, const uint2 *colinfo,
-                                 char *out, const uint32_t *list, uint64_t n_list);
 void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, const uint32_t *line_len, int64_t ncols, StaCounters *ctr);
 
 // binary per-column entries for the bam_plp_* surface (kernels_plpapi.hip)
@@ -132,13 +124,6 @@ void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
                          int64_t g0, int64_t ng, int use_list, int pass /*0 forward, 1 backward*/);
 
 // depth
-void sta_launch_depth_count(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
-                            const sta_depth_params &p, int32_t *diff /*[(nfiles+1)][ncols+1]*/);
-void sta_launch_depth_scan(hipStream_t s, int32_t *diff, int nrows, int64_t ncols, void *tmp, size_t tmp_bytes);
-void sta_launch_depth_len(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, const int32_t *counts,
-                          uint32_t *line_len, StaCounters *ctr);
-void sta_launch_depth_emit(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, const int32_t *counts,
-                           const uint64_t *offs, char *out, uint32_t lds_cap);
 size_t sta_depth_fused_status_bytes(int64_t ncols);
 void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, void *status, int32_t *counts, char *out,
                             uint64_t capacity, StaCounters *ctr, uint32_t lbuf);

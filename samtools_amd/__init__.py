@@ -18,6 +18,7 @@ from ._capi import (  # noqa: F401
     Reads,
     Window,
     device_count,
+    baq_stream_bytes_per_base,
     lib,
     main_depth,
     main_mpileup,

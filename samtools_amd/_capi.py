@@ -153,6 +153,13 @@ for _name, (_res, _args) in _PROTOS.items():
     _f.argtypes = _args
 
 
+def baq_stream_bytes_per_base():
+    """forward-row bytes the band-7 BAQ kernel pair streams through HBM per query base (written once, read once)"""
+    f = lib.sta_baq_stream_bytes_per_base
+    f.restype = C.c_double
+    return float(f())
+
+
 def device_count():
     return int(lib.sta_device_count())
 

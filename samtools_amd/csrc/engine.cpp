@@ -53,8 +53,6 @@ struct sta_engine {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;        // second stream: the few band-8 BAQ groups run beside the band-7 kernels
     hipEvent_t side_done = nullptr;
-    hipStream_t pipe_stream = nullptr; // BAQ forward/backward software pipeline
-    std::vector<hipEvent_t> pipe_ev;
     std::string err;
     std::map<int32_t, RefSeq> refs;
     // current window
@@ -176,8 +174,6 @@ void sta_engine_destroy(sta_engine *e)
                       &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
-    if (e->pipe_stream) hipStreamDestroy(e->pipe_stream);
-    for (auto ev : e->pipe_ev) hipEventDestroy(ev);
     if (e->side_done) hipEventDestroy(e->side_done);
     for (auto &p : e->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
@@ -415,39 +411,6 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                     int64_t ngroups = (items + 63) / 64;
                     const bool on_side = side && cls == 1;
                     hipStream_t st = on_side ? e->side : s;
-                    // class 0 can be software-pipelined over two streams (STA_BAQ_PIPE_GROUPS=n: the backward kernel of chunk k,
-                    // read bound, beside the forward kernel of chunk k+1, write bound).  Off by default: measured 10-20 %
-                    // SLOWER on MI355X (16.3 ms -> 18.0-20.0 ms per step at n = 3072..768), the two kernels only share the chip.
-                    int64_t pipe = 0;
-                    if (cls == 0 && ngroups <= gpl) {
-                        const char *ev = getenv("STA_BAQ_PIPE_GROUPS");
-                        pipe = ev ? atoll(ev) : 0;
-                        if (pipe <= 0 || ngroups < 2 * pipe) pipe = 0;
-                        if (pipe && !e->pipe_stream) {
-                            if (hipStreamCreateWithFlags(&e->pipe_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); pipe = 0; }
-                        }
-                    }
-                    if (pipe) {
-                        int64_t nchunk = (ngroups + pipe - 1) / pipe;
-                        while ((int64_t)e->pipe_ev.size() < nchunk + 1) {
-                            hipEvent_t ev; if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(e, STA_ERR_HIP, "hipEventCreate failed");
-                            e->pipe_ev.push_back(ev);
-                        }
-                        hipEvent_t t0{}, t1{};
-                        if (e->prof_on) { t0 = get_event(e); t1 = get_event(e); hipEventRecord(t0, s); }
-                        for (int64_t k = 0; k < nchunk; ++k) {
-                            int64_t g0 = k * pipe, ng = ngroups - g0 < pipe ? ngroups - g0 : pipe;
-                            const size_t off = (size_t)g0 * slot_bytes;
-                            sta_launch_baq_band(s, d, e->wd, (char *)e->baq_scratch.p + off, (int)c.max_lq_fast, 7, g0, ng, 0, 0);
-                            HIPCHK(hipEventRecord(e->pipe_ev[(size_t)k], s));
-                            HIPCHK(hipStreamWaitEvent(e->pipe_stream, e->pipe_ev[(size_t)k], 0));
-                            sta_launch_baq_band(e->pipe_stream, d, e->wd, (char *)e->baq_scratch.p + off, (int)c.max_lq_fast, 7, g0, ng, 0, 1);
-                        }
-                        HIPCHK(hipEventRecord(e->pipe_ev[(size_t)nchunk], e->pipe_stream));
-                        HIPCHK(hipStreamWaitEvent(s, e->pipe_ev[(size_t)nchunk], 0));
-                        if (e->prof_on) { hipEventRecord(t1, s); e->pending.push_back(ProfPending{ "baq_fwd+bwd_pipelined", t0, t1 }); }
-                        continue;
-                    }
                     int64_t step = on_side ? ngroups : gpl;
                     for (int64_t g0 = 0; g0 < ngroups; g0 += step) {
                         int64_t ng = ngroups - g0 < step ? ngroups - g0 : step;

@@ -13,6 +13,7 @@
 #include "dev_util.h"
 #include <math.h>
 #include <cstdlib>
+#include <algorithm>
 
 #define EI .25
 #define EM .33333333333
@@ -374,7 +375,18 @@ __device__ __forceinline__ int64_t baq_pick(const StaReadsDev &R, int64_t g, int
     return r;
 }
 
-template <int BW>
+// ---- scratch layout of one group (64 reads = one wave), in "lane rows" of 64 doubles (512 B) ----
+// Forward rows.  DEC (band width 7): the I state is stored only for ODD rows; an even row's I is a function of the row below it,
+//     I[i][j] = (EI * (m1 * M[i-1][j+1] + m4 * I[i-1][j+1])) * (1 / s[i]),
+// which the backward kernel re-evaluates with the forward kernel's operations in the forward kernel's order, so the stream is
+// 3 * NB doubles per row PAIR instead of 4 * NB (-25 %).  Pair t = (i - 1) / 2 starts at lane row t * 3NB: the odd row's cells are
+// (M, I) pairs of 16 bytes per lane (two lane rows per cell), the even row's are 8-byte M values after them.
+// Without DEC every row stores (M, I) pairs: row i at lane row (i - 1) * 2NB.
+// After the rows: s[0 .. lq_cap + 1] (one lane row each), then -- only when the per-row states do not fit LDS -- one int32 per row.
+template <int NB, bool DEC> __host__ __device__ constexpr size_t baq_rows_lr(int lq_cap) { return DEC ? (size_t)((lq_cap + 1) / 2) * (3 * NB) : (size_t)lq_cap * (2 * NB); }
+#define BAQ_LDS_ROWS_MAX 256          // per-row state bytes live in LDS up to this read length (16 KB per wave)
+
+template <int BW, bool DEC>
 __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
                                                  double *scratch, size_t slot_dbl, int lq_cap)
 {
@@ -390,9 +402,9 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
     const int64_t r = baq_pick(R, g0 + gl, lane, use_list, BW);
     if (r < 0) return;
     double *slot = scratch + (size_t)gl * slot_dbl;
-    baq_d2 *F = reinterpret_cast<baq_d2 *>(slot) + lane;
-    double *S = slot + (size_t)lq_cap * (2 * NB) * 64 + lane;
-#define Fcell(i, j) F[((size_t)((i) - 1) * NB + (j)) * 64]
+    baq_d2 *F2 = reinterpret_cast<baq_d2 *>(slot) + lane;
+    double *F1 = slot + lane;
+    double *S = slot + baq_rows_lr<NB, DEC>(lq_cap) * 64 + lane;
     const BaqRd d = baq_rd(R, W, r);
     const int lq = d.lq, l_ref = d.l_ref;
     const uint8_t *qual = d.qual, *seq = d.seq; const char *ref = d.ref;
@@ -424,7 +436,7 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
 #pragma unroll
         for (int j = 0; j < NB; ++j) { M[j] /= sum; I[j] /= sum; }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { baq_d2 v = { M[j], I[j] }; __builtin_nontemporal_store(v, &Fcell(1, j)); }
+        for (int j = 0; j < NB; ++j) { baq_d2 v = { M[j], I[j] }; __builtin_nontemporal_store(v, &F2[(size_t)(DEC ? 2 * j : j) * (DEC ? 32 : 64)]); }
     }
     // software pipeline of the per-row inputs: raw bytes two rows ahead, converted one row ahead
     int c_sb = 0, c_rc = 7;                   // converted, for the next row
@@ -460,8 +472,19 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
         double inv = 1. / sum;
 #pragma unroll
         for (int j = 0; j < NB; ++j) { M[j] *= inv; I[j] *= inv; D[j] *= inv; }
+        if (DEC) {
+            const size_t t = (size_t)((i - 1) >> 1) * (3 * NB);
+            if (i & 1) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { baq_d2 v = { M[j], I[j] }; __builtin_nontemporal_store(v, &Fcell(i, j)); }
+                for (int j = 0; j < NB; ++j) { baq_d2 v = { M[j], I[j] }; __builtin_nontemporal_store(v, &F2[(t + 2 * j) * 32]); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) __builtin_nontemporal_store(M[j], &F1[(t + 2 * NB + j) * 64]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { baq_d2 v = { M[j], I[j] }; __builtin_nontemporal_store(v, &F2[((size_t)(i - 1) * NB + j) * 64]); }
+        }
     }
     {   // s[l_query+1]
         double sum = 0.;
@@ -469,17 +492,33 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
         for (int j = 0; j < NB; ++j) sum += M[j] * p.sM + I[j] * p.sI;
         S[(size_t)(lq + 1) * 64] = sum;
     }
-#undef Fcell
 }
 
-#ifndef BAQ_PREFETCH_F
-#define BAQ_PREFETCH_F 1
-#endif
-template <int BW>
-__global__ void __launch_bounds__(256, BAQ_PREFETCH_F ? 2 : 3) k_baq_bwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
-                                                 double *scratch, size_t slot_dbl, int lq_cap)
+// ---- backward + MAP + apply ----
+// Per-lane CIGAR cursor walking the query backwards: which operation covers query index q, and where it starts (realn.c's block
+// walk, evaluated on the fly so that the per-row MAP state never leaves the wave).
+struct BaqCur { int c; int ys, xs_off; int qlen; bool is_m; };      // op index, its first query index, its first reference index minus xb
+__device__ __forceinline__ void baq_cur_seek(BaqCur &cu, const uint32_t *cigar, int q)
+{
+    // move to earlier operations until the current one covers q (operations that consume no query base are stepped over)
+    while (cu.c > 0 && (q < cu.ys || cu.qlen == 0)) {
+        --cu.c;
+        const uint32_t w = cigar[cu.c];
+        const int op = w & 0xf, l = (int)(w >> 4);
+        const bool qop = cg_is_mop(op) || op == CG_I || op == CG_S, rop = cg_is_mop(op) || op == CG_D;   // (no N: such reads are never re-aligned)
+        cu.qlen = qop ? l : 0;
+        cu.is_m = cg_is_mop(op);
+        if (qop) cu.ys -= l;
+        if (rop) cu.xs_off -= l;
+    }
+}
+
+template <int BW, bool DEC, bool PLDS>
+__global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
+                                                    double *scratch, size_t slot_dbl, int lq_cap, int lds_rows)
 {
     constexpr int NB = 2 * BW + 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t baq_state[];        // PLDS: [wave][row][lane], one byte per row and read
     __shared__ float q2p[256];
     __shared__ uint8_t refc[256];
     q2p[threadIdx.x] = T.q2p[threadIdx.x];
@@ -491,22 +530,38 @@ __global__ void __launch_bounds__(256, BAQ_PREFETCH_F ? 2 : 3) k_baq_bwd(StaRead
     const int64_t r = baq_pick(R, g0 + gl, lane, use_list, BW);
     if (r < 0) return;
     double *slot = scratch + (size_t)gl * slot_dbl;
-    const baq_d2 *F = reinterpret_cast<const baq_d2 *>(slot) + lane;
-    const double *S = slot + (size_t)lq_cap * (2 * NB) * 64 + lane;
-    int32_t *P = reinterpret_cast<int32_t *>(slot + (size_t)lq_cap * (2 * NB) * 64 + (size_t)(lq_cap + 2) * 64) + lane;
-#define Fcell(i, j) F[((size_t)((i) - 1) * NB + (j)) * 64]
+    const baq_d2 *F2 = reinterpret_cast<const baq_d2 *>(slot) + lane;
+    const double *F1 = slot + lane;
+    const double *S = slot + baq_rows_lr<NB, DEC>(lq_cap) * 64 + lane;
+    // per-row MAP result b (0 unless the MAP state is M on the read's own diagonal): a byte in LDS, or an int in the scratch slot
+    uint8_t *Pl = baq_state + (size_t)(threadIdx.x >> 6) * (size_t)lds_rows * 64 + lane;
+    int32_t *Pg = reinterpret_cast<int32_t *>(slot + baq_rows_lr<NB, DEC>(lq_cap) * 64 + (size_t)(lq_cap + 2) * 64) + lane;
     const BaqRd d = baq_rd(R, W, r);
     const int lq = d.lq, l_ref = d.l_ref;
     uint8_t *qual = d.qual; const uint8_t *seq = d.seq; const char *ref = d.ref;
     const BaqPar p = baq_par(lq, l_ref);
+    const bool plain = W.baq_plain != 0;
+
+    // CIGAR cursor: starts behind the last operation
+    BaqCur cu; cu.c = d.n_cigar; cu.qlen = 0; cu.is_m = false;
+    {
+        int tq = 0; long long tx = d.rpos;
+        for (int c = 0; c < d.n_cigar; ++c) {
+            const int op = d.cigar[c] & 0xf, l = (int)(d.cigar[c] >> 4);
+            if (cg_is_mop(op)) { tq += l; tx += l; } else if (op == CG_I || op == CG_S) tq += l; else if (op == CG_D) tx += l;
+        }
+        cu.ys = tq; cu.xs_off = (int)(tx - d.xb);
+    }
+    int run_r = 0, run_c = -1;           // running maximum of b from the right inside the current M operation
 
     // row lq: field j = code(lq - BW - 1 + j); it doubles as the backward word of row lq-1
     uint64_t rw = 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) rw |= (uint64_t)RCODE(lq - BW - 1 + j) << (3 * j);
     double bMr[NB], bIr[NB];
+    const double s_top = S[(size_t)lq * 64];
     {
-        double sl = S[(size_t)lq * 64], sl1 = S[(size_t)(lq + 1) * 64];
+        double sl = s_top, sl1 = S[(size_t)(lq + 1) * 64];
         double vM = p.sM / sl / sl1, vI = p.sI / sl / sl1;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -519,357 +574,151 @@ __global__ void __launch_bounds__(256, BAQ_PREFETCH_F ? 2 : 3) k_baq_bwd(StaRead
     int r_q = 0, r_sb = 0, r_rr = 256; double r_s = 1.;
     if (lq >= 2) { int i = lq - 1; c_qf = q2p[qual[i]]; c_sb = SEQB(i); c_s = S[(size_t)i * 64]; }
     if (lq >= 3) { int i = lq - 2; r_q = qual[i]; r_sb = SEQB(i); r_s = S[(size_t)i * 64]; r_rr = RRAW(i - BW); }
+
+    // One row: backward update (b[i] from b[i+1]) unless i == lq, then the MAP step against the forward row.  Forward row of
+    // row i: (fM, fI) loaded, or -- EVEN row under DEC -- fM loaded and fI re-evaluated from the row below (Mp, Ip) and 1 / s[i].
+    double inv_i = 1. / s_top;
+#define BAQ_BWD_UPDATE(i)                                                                                                   \
+    if ((i) < lq) {                                                                                                         \
+        const float qf = c_qf; const int sb = c_sb; const int nrc = c_rc; const double si = c_s;                            \
+        c_qf = q2p[r_q]; c_sb = r_sb; c_rc = RCONV(r_rr); c_s = r_s;                                                        \
+        if ((i) - 2 >= 1) { int i2 = (i) - 2; r_q = qual[i2]; r_sb = SEQB(i2); r_s = S[(size_t)i2 * 64]; r_rr = RRAW(i2 - BW); } \
+        if ((i) < lq - 1) rw = (rw << 3) | (uint64_t)nrc;                                                                   \
+        const int qy = QCONV(sb, (i));                                                                                      \
+        const double qli1 = qf;                                                                                             \
+        const double ematch = 1. - qli1, e_lo = qy > 3 ? 1. : qli1 * EM;                                                    \
+        const int qyc = qy > 3 ? 9 : qy;                                                                                    \
+        const double yv = (i) > 1 ? 1. : 0.;                                                                                \
+        double dnext = 0.;                                                                                                  \
+        _Pragma("unroll")                                                                                                   \
+        for (int j = NB - 1; j >= 0; --j) {                                                                                 \
+            int rc = FLD(rw, j);                                                                                            \
+            double e = emis_sel(rc, qyc, ematch, e_lo) * bMr[j];     /* rc == 7 <=> k >= l_ref: e = 0 * b */                 \
+            double bi1 = j > 0 ? bIr[j - 1] : 0.;                                                                           \
+            double bm = e * p.m0 + p.eim1 * bi1 + p.m2 * dnext;                                                             \
+            double bi_ = e * p.m3 + p.eim4 * bi1;                                                                           \
+            double bd = (e * p.m6 + p.m8 * dnext) * yv;                                                                     \
+            bMr[j] = bm; bIr[j] = bi_;                                                                                      \
+            dnext = bd;                                                                                                     \
+        }                                                                                                                   \
+        inv_i = 1. / si;                                                                                                    \
+        _Pragma("unroll")                                                                                                   \
+        for (int j = 0; j < NB; ++j) { bMr[j] *= inv_i; bIr[j] *= inv_i; }                                                  \
+        if ((i) <= BW) {            /* cells with k < 1 do not exist in the reference: keep them at zero */                  \
+            _Pragma("unroll")                                                                                               \
+            for (int j = 0; j < BW; ++j) if (j < BW + 1 - (i)) { bMr[j] = 0.; bIr[j] = 0.; }                                \
+        }                                                                                                                   \
+    }
+    // MAP of row i given z-terms; then the per-row result: quality from the right-hand running maximum straight away (the
+    // left-hand one follows in the forward pass at the end), state byte kept for that pass
+#define BAQ_MAP_FINISH(i, sum, max, max_k)                                                                                  \
+    {                                                                                                                       \
+        double mx_ = (max) / (sum);                                                                                         \
+        double v = -4.343 * log(1. - mx_) + .499;                                                                           \
+        int kq = (v >= 2147483648.0 || v < -2147483648.0 || v != v) ? INT32_MIN : (int)v;                                   \
+        kq = (int)(uint8_t)(kq > 100 ? 99 : kq);                                                                            \
+        if (PLDS) {                                                                                                         \
+            const int q = (i) - 1;                                                                                          \
+            baq_cur_seek(cu, d.cigar, q);                                                                                   \
+            int b = 0;                                                                                                      \
+            const bool in_m = cu.is_m && q >= cu.ys && q < cu.ys + cu.qlen;                                                 \
+            if (in_m && ((max_k) & 3) == 0 && ((max_k) >> 2) == cu.xs_off + (q - cu.ys)) b = kq;                            \
+            Pl[(size_t)q * 64] = (uint8_t)b;                                                                                \
+            if (in_m) {                                                                                                     \
+                if (run_c != cu.c) { run_c = cu.c; run_r = 0; }                                                             \
+                run_r = b > run_r ? b : run_r;                                                                              \
+                const int q0 = qual[q];                                                                                     \
+                const int lim = plain ? b : run_r;                                                                          \
+                if (q0 > lim) qual[q] = (uint8_t)lim;                                                                       \
+            }                                                                                                               \
+        } else Pg[(size_t)((i) - 1) * 64] = (int32_t)(((uint32_t)(max_k) << 8) | (uint32_t)kq);                             \
+    }
+
+    int i = lq;
+    if (!DEC || (lq & 1)) {
+        // (without DEC: every row this way)  top row odd: a fully stored row on its own
 #pragma unroll 1
-    for (int i = lq; i >= 1; --i) {
-        // forward row i for the MAP step.  BAQ_PREFETCH_F: issue the loads first so they fly during the row update
-        // (costs 4*NB VGPRs: 2 waves/SIMD); otherwise load at the MAP step and rely on 3 waves/SIMD to hide the latency.
-        double fM[NB], fI[NB];
-#if BAQ_PREFETCH_F
-#pragma unroll
-        for (int j = 0; j < NB; ++j) { baq_d2 v = __builtin_nontemporal_load(&Fcell(i, j)); fM[j] = v.x; fI[j] = v.y; }
-#endif
-        if (i < lq) {
-            const float qf = c_qf; const int sb = c_sb; const int nrc = c_rc; const double si = c_s;
-            c_qf = q2p[r_q]; c_sb = r_sb; c_rc = RCONV(r_rr); c_s = r_s;
-            if (i - 2 >= 1) { int i2 = i - 2; r_q = qual[i2]; r_sb = SEQB(i2); r_s = S[(size_t)i2 * 64]; r_rr = RRAW(i2 - BW); }
-            if (i < lq - 1) rw = (rw << 3) | (uint64_t)nrc;
-            const int qy = QCONV(sb, i);
-            const double qli1 = qf;
-            const double ematch = 1. - qli1, e_lo = qy > 3 ? 1. : qli1 * EM;
-            const int qyc = qy > 3 ? 9 : qy;
-            const double yv = i > 1 ? 1. : 0.;
-            double dnext = 0.;
-#pragma unroll
-            for (int j = NB - 1; j >= 0; --j) {
-                int rc = FLD(rw, j);
-                double e = emis_sel(rc, qyc, ematch, e_lo) * bMr[j];     // rc == 7 <=> k >= l_ref: e = 0 * b
-                double bi1 = j > 0 ? bIr[j - 1] : 0.;
-                double bm = e * p.m0 + p.eim1 * bi1 + p.m2 * dnext;
-                double bi_ = e * p.m3 + p.eim4 * bi1;
-                double bd = (e * p.m6 + p.m8 * dnext) * yv;
-                bMr[j] = bm; bIr[j] = bi_;
-                dnext = bd;
-            }
-            double ys = 1. / si;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) { bMr[j] *= ys; bIr[j] *= ys; }
-            if (i <= BW) {            // cells with k < 1 do not exist in the reference: keep them at zero
-#pragma unroll
-                for (int j = 0; j < BW; ++j) if (j < BW + 1 - i) { bMr[j] = 0.; bIr[j] = 0.; }
-            }
-        }
-        // MAP for row i
-#if !BAQ_PREFETCH_F
-#pragma unroll
-        for (int j = 0; j < NB; ++j) { baq_d2 v = __builtin_nontemporal_load(&Fcell(i, j)); fM[j] = v.x; fI[j] = v.y; }
-#endif
-        double sum = 0., max = 0.;
-        int max_k = -1;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            double z;
-            z = fM[j] * bMr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 0; } sum += z;
-            z = fI[j] * bIr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 1; } sum += z;
-        }
-        max /= sum;
-        double v = -4.343 * log(1. - max) + .499;
-        int kq = (v >= 2147483648.0 || v < -2147483648.0 || v != v) ? INT32_MIN : (int)v;
-        P[(size_t)(i - 1) * 64] = (int32_t)(((uint32_t)max_k << 8) | (uint32_t)(uint8_t)(kq > 100 ? 99 : kq));
-    }
-
-    /*** realn.c, extended BAQ: bq = min(running max from the left, from the right) inside each M block; apply ***/
-    {
-        long long xx = d.rpos; int yy = 0;
-        for (int c = 0; c < d.n_cigar; ++c) {
-            int op = d.cigar[c] & 0xf, l = (int)(d.cigar[c] >> 4);
-            if (cg_is_mop(op)) {
-                if (l > lq - yy) l = lq - yy;
-                if (l > 0) {
-                    int run = 0;
-                    for (int i = yy; i < yy + l; ++i) {
-                        int32_t pk = P[(size_t)i * 64];
-                        int st = pk >> 8;
-                        int b = ((st & 3) != 0 || (long long)(st >> 2) != xx - d.xb + (i - yy)) ? 0 : (pk & 0xff);
-                        run = b > run ? b : run;
-                        P[(size_t)i * 64] = (b << 8) | run;        // raw bq, left running max
-                    }
-                    run = 0;
-                    for (int i = yy + l - 1; i >= yy; --i) {
-                        int32_t pk = P[(size_t)i * 64];
-                        int b = pk >> 8, left = pk & 0xff;
-                        run = b > run ? b : run;
-                        int bqv = W.baq_plain ? b : (left < run ? left : run);    // plain (calmd -r without -E): min(qual, q) per base
-                        int q0 = qual[i];
-                        int tag = 64 + (q0 <= bqv ? 0 : q0 - bqv);
-                        qual[i] = (uint8_t)(q0 - (tag - 64));
-                    }
-                }
-                xx += l; yy += l;
-            } else if (op == CG_S || op == CG_I) {
-                if (l > lq - yy) l = lq - yy;
-                yy += l;
-            } else if (op == CG_D) xx += l;
-        }
-    }
-#undef Fcell
-}
-
-// ================================================================================================
-// Checkpointed variant (opt-in with STA_BAQ_CHECKPOINT=1; measured slower on MI355X): the forward kernel stores only every C-th row (M, I and D: the
-// full state), and the backward kernel re-computes the C rows of a block from the checkpoint below
-// it, keeping their (M, I) cells in REGISTERS (one wave per SIMD, up to 512 VGPRs) while it walks the
-// block backwards.  HBM stream per query base: 3*NB*8/C bytes written + read (90 B at BW 7, C 4)
-// instead of 2*NB*8 (240 B) -- the fp64 work grows by one extra forward pass, which the kernel pair
-// has headroom for (it was bound by the scratch stream).  Same arithmetic, same order, same results.
-//
-// Block word: reference codes for indices a-BW .. a+C+BW-1 of a block of rows a+1..a+C in ONE 64-bit
-// word (3 bits per code); the forward word of row a+1+c is (word >> 3c), the backward word of that
-// row is (word >> 3(c+1)), and the next lower block's word is (word << 3C) | C new codes.
-
-template <int BW>
-__device__ __forceinline__ double baq_row1(double (&M)[2 * BW + 1], double (&I)[2 * BW + 1], double (&D)[2 * BW + 1], uint64_t rw, int qy, double q0, const BaqPar &p)
-{
-    constexpr int NB = 2 * BW + 1;
-    const double ematch = 1. - q0, e_lo = qy > 3 ? 1. : q0 * EM;
-    const int qyc = qy > 3 ? 9 : qy;
-    double sum = 0.;
-    const double eibi = EI * p.bI;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        int rc = FLD(rw, j);
-        double e = emis_sel(rc, qyc, ematch, e_lo);
-        double a = e * p.bM;
-        double b2 = rc == 7 ? 0. : eibi;
-        M[j] = a; I[j] = b2; D[j] = 0.;
-        sum += a + b2;
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) { M[j] /= sum; I[j] /= sum; }
-    return sum;
-}
-
-template <int BW>
-__device__ __forceinline__ double baq_fwd_row(double (&M)[2 * BW + 1], double (&I)[2 * BW + 1], double (&D)[2 * BW + 1], uint64_t rw, int qy, double qli, const BaqPar &p)
-{
-    constexpr int NB = 2 * BW + 1;
-    const double ematch = 1. - qli, e_lo = qy > 3 ? 1. : qli * EM;
-    const int qyc = qy > 3 ? 9 : qy;
-    double sum = 0., pm = 0., pd = 0.;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        int rc = FLD(rw, j);
-        double e = emis_sel(rc, qyc, ematch, e_lo);
-        double fm = e * (p.m0 * M[j] + p.m3 * I[j] + p.m6 * D[j]);
-        double fi = (j + 1 < NB) ? EI * (p.m1 * M[j + 1] + p.m4 * I[j + 1]) : 0.;
-        double fd = p.m2 * pm + p.m8 * pd;
-        fd = rc == 7 ? 0. : fd;
-        M[j] = fm; I[j] = fi; D[j] = fd;
-        sum += fm + fi + fd;
-        pm = fm; pd = fd;
-    }
-    const double inv = 1. / sum;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) { M[j] *= inv; I[j] *= inv; D[j] *= inv; }
-    return sum;
-}
-
-template <int BW, int C>
-__global__ void __launch_bounds__(256) k_baq_ck_fwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
-                                                    double *scratch, size_t slot_dbl, int lq_cap)
-{
-    constexpr int NB = 2 * BW + 1;
-    __shared__ float q2p[256];
-    __shared__ uint8_t refc[256];
-    q2p[threadIdx.x] = T.q2p[threadIdx.x];
-    refc[threadIdx.x] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)threadIdx.x));
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int64_t gl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gl >= ngroups) return;
-    const int64_t r = baq_pick(R, g0 + gl, lane, use_list, BW);
-    if (r < 0) return;
-    double *CK = scratch + (size_t)gl * slot_dbl + lane;          // CK[((t-1)*3NB + cell)*64], checkpoint after row t*C
-    const BaqRd d = baq_rd(R, W, r);
-    const int lq = d.lq, l_ref = d.l_ref;
-    const uint8_t *qual = d.qual, *seq = d.seq; const char *ref = d.ref;
-    const BaqPar p = baq_par(lq, l_ref);
-
-    double M[NB], I[NB], D[NB];
-    uint64_t rw = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) rw |= (uint64_t)RCODE(j - BW) << (3 * j);
-    baq_row1<BW>(M, I, D, rw, QCONV(SEQB(0), 0), (double)q2p[qual[0]], p);
-    int c_sb = 0, c_rc = 7; float c_qf = 0.f;
-    int r_q = 0, r_sb = 0, r_rr = 256;
-    if (lq >= 2) { c_qf = q2p[qual[1]]; c_sb = SEQB(1); c_rc = RCODE(2 + BW - 1); }
-    if (lq >= 3) { r_q = qual[2]; r_sb = SEQB(2); r_rr = RRAW(3 + BW - 1); }
-#pragma unroll 1
-    for (int i = 2; i <= lq; ++i) {
-        const float qf = c_qf; const int sb = c_sb; const int nrc = c_rc;
-        c_qf = q2p[r_q]; c_sb = r_sb; c_rc = RCONV(r_rr);
-        if (i + 2 <= lq) { r_q = qual[i + 1]; r_sb = SEQB(i + 1); r_rr = RRAW(i + 2 + BW - 1); }
-        rw = (rw >> 3) | ((uint64_t)nrc << (3 * (NB - 1)));
-        baq_fwd_row<BW>(M, I, D, rw, QCONV(sb, i - 1), (double)qf, p);
-        if (i % C == 0 && i < lq) {
-            double *ck = CK + (size_t)(i / C - 1) * (3 * NB) * 64;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) { ck[(size_t)(3 * j) * 64] = M[j]; ck[(size_t)(3 * j + 1) * 64] = I[j]; ck[(size_t)(3 * j + 2) * 64] = D[j]; }
-        }
-    }
-}
-
-template <int BW, int C>
-__global__ void __launch_bounds__(256) k_baq_ck_bwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
-                                                    double *scratch, size_t slot_dbl, int lq_cap)
-{
-    constexpr int NB = 2 * BW + 1;
-    constexpr int NF = NB + C;                 // fields of a block word
-    __shared__ float q2p[256];
-    __shared__ uint8_t refc[256];
-    q2p[threadIdx.x] = T.q2p[threadIdx.x];
-    refc[threadIdx.x] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)threadIdx.x));
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int64_t gl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gl >= ngroups) return;
-    const int64_t r = baq_pick(R, g0 + gl, lane, use_list, BW);
-    if (r < 0) return;
-    const double *CK = scratch + (size_t)gl * slot_dbl + lane;
-    const int nck_cap = (lq_cap - 1) / C;
-    int32_t *P = reinterpret_cast<int32_t *>(scratch + (size_t)gl * slot_dbl + (size_t)nck_cap * (3 * NB) * 64) + lane;
-    const BaqRd d = baq_rd(R, W, r);
-    const int lq = d.lq, l_ref = d.l_ref;
-    uint8_t *qual = d.qual; const uint8_t *seq = d.seq; const char *ref = d.ref;
-    const BaqPar p = baq_par(lq, l_ref);
-
-    double M[NB], I[NB], D[NB];                // forward state while a block is re-computed
-    double sM_[C][NB], sI_[C][NB], Sb[C];      // the block's forward rows (M, I) and their scaling sums
-    double bMr[NB], bIr[NB];                   // backward row
-    int t = (lq - 1) / C;                      // top block: rows a+1 .. lq, a = t*C
-    int a = t * C;
-    // block word of the top block
-    uint64_t bw_ = 0;
-#pragma unroll
-    for (int g = 0; g < NF; ++g) bw_ |= (uint64_t)RCODE(a - BW + g) << (3 * g);
-    // inputs of the top block's rows (row a+1+c: quality / base of query index a+c), raw
-    int rq[C], rsb[C], rnew[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) { rq[c] = 0; rsb[c] = 0; rnew[c] = 256; if (a + c < lq) { rq[c] = qual[a + c]; rsb[c] = SEQB(a + c); } }
-    if (t >= 1) {
-        const double *ck = CK + (size_t)(t - 1) * (3 * NB) * 64;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) { M[j] = ck[(size_t)(3 * j) * 64]; I[j] = ck[(size_t)(3 * j + 1) * 64]; D[j] = ck[(size_t)(3 * j + 2) * 64]; }
-    }
-    float carry_qf = 0.f; int carry_qy = 4;    // inputs of the first row of the block above (row a+C+1): backward row a+C needs them
-#pragma unroll 1
-    for (; t >= 0; --t) {
-        a = t * C;
-        // convert this block's inputs
-        float inq[C]; int inqy[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) { inq[c] = q2p[rq[c]]; inqy[c] = QCONV(rsb[c], a + c); }
-        /*** re-compute rows a+1 .. a+C ***/
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int row = a + 1 + c;
-            if (row <= lq) {
-                const uint64_t rw = bw_ >> (3 * c);
-                double sum;
-                if (c == 0 && a == 0) sum = baq_row1<BW>(M, I, D, rw, inqy[0], (double)inq[0], p);
-                else sum = baq_fwd_row<BW>(M, I, D, rw, inqy[c], (double)inq[c], p);
-                Sb[c] = sum;
-#pragma unroll
-                for (int j = 0; j < NB; ++j) { sM_[c][j] = M[j]; sI_[c][j] = I[j]; }
-            }
-        }
-        if (a + C >= lq) {
-            // top block: s[lq+1] from row lq (still in M, I), then the backward row of lq
-            double sum = 0.;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) sum += M[j] * p.sM + I[j] * p.sI;
-            const int ctop = lq - a - 1;
-            double sl = Sb[0];
-#pragma unroll
-            for (int c = 1; c < C; ++c) if (c == ctop) sl = Sb[c];
-            const double vM = p.sM / sl / sum, vI = p.sI / sl / sum;
-            const uint64_t rwl = bw_ >> (3 * ctop);
+        for (; i >= 1; --i) {
+            double fM[NB], fI[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                bool valid = FLD(rwl, j) != 7;
-                bMr[j] = valid ? vM : 0.; bIr[j] = valid ? vI : 0.;
+                baq_d2 v = __builtin_nontemporal_load(DEC ? &F2[((size_t)((i - 1) >> 1) * (3 * NB) + 2 * j) * 32] : &F2[((size_t)(i - 1) * NB + j) * 64]);
+                fM[j] = v.x; fI[j] = v.y;
             }
-        }
-        /*** fetch for the block below while this block walks backwards: its checkpoint into M/I/D, its raw inputs ***/
-        const float first_qf = inq[0]; const int first_qy = inqy[0];
-        if (t >= 1) {
-            const int a2 = a - C;
-            if (t >= 2) {
-                const double *ck = CK + (size_t)(t - 2) * (3 * NB) * 64;
+            BAQ_BWD_UPDATE(i)
+            double sum = 0., max = 0.; int max_k = -1;
 #pragma unroll
-                for (int j = 0; j < NB; ++j) { M[j] = ck[(size_t)(3 * j) * 64]; I[j] = ck[(size_t)(3 * j + 1) * 64]; D[j] = ck[(size_t)(3 * j + 2) * 64]; }
+            for (int j = 0; j < NB; ++j) {
+                double z;
+                z = fM[j] * bMr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 0; } sum += z;
+                z = fI[j] * bIr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 1; } sum += z;
             }
-#pragma unroll
-            for (int c = 0; c < C; ++c) { rq[c] = qual[a2 + c]; rsb[c] = SEQB(a2 + c); rnew[c] = RRAW(a2 - BW + c); }
+            BAQ_MAP_FINISH(i, sum, max, max_k)
+            if (DEC) { --i; break; }
         }
-        /*** backward rows a+C .. a+1 with MAP ***/
+    }
+    if (DEC) {
+        // pairs (i even, i - 1 odd): M of the even row + the full odd row are fetched before the even row's update
+#pragma unroll 1
+        for (; i >= 2; i -= 2) {
+            const size_t t = (size_t)((i - 1) >> 1) * (3 * NB);
+            double fM[NB], Mp[NB], Ip[NB];
 #pragma unroll
-        for (int c = C - 1; c >= 0; --c) {
-            const int i = a + 1 + c;
-            if (i <= lq) {
-                if (i < lq) {
-                    const float qf = (c + 1 < C) ? inq[c + 1 < C ? c + 1 : 0] : carry_qf;
-                    const int qy = (c + 1 < C) ? inqy[c + 1 < C ? c + 1 : 0] : carry_qy;
-                    const uint64_t rw = bw_ >> (3 * (c + 1));
-                    const double qli1 = qf;
-                    const double ematch = 1. - qli1, e_lo = qy > 3 ? 1. : qli1 * EM;
-                    const int qyc = qy > 3 ? 9 : qy;
-                    const double yv = i > 1 ? 1. : 0.;
-                    double dnext = 0.;
+            for (int j = 0; j < NB; ++j) fM[j] = __builtin_nontemporal_load(&F1[(t + 2 * NB + j) * 64]);
 #pragma unroll
-                    for (int j = NB - 1; j >= 0; --j) {
-                        int rc = FLD(rw, j);
-                        double e = emis_sel(rc, qyc, ematch, e_lo) * bMr[j];
-                        double bi1 = j > 0 ? bIr[j - 1] : 0.;
-                        double bm = e * p.m0 + p.eim1 * bi1 + p.m2 * dnext;
-                        double bi_ = e * p.m3 + p.eim4 * bi1;
-                        double bd = (e * p.m6 + p.m8 * dnext) * yv;
-                        bMr[j] = bm; bIr[j] = bi_;
-                        dnext = bd;
-                    }
-                    const double ys = 1. / Sb[c];
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) { bMr[j] *= ys; bIr[j] *= ys; }
-                    if (i <= BW) {
-#pragma unroll
-                        for (int j = 0; j < BW; ++j) if (j < BW + 1 - i) { bMr[j] = 0.; bIr[j] = 0.; }
-                    }
-                }
-                double sum = 0., max = 0.;
-                int max_k = -1;
+            for (int j = 0; j < NB; ++j) { baq_d2 v = __builtin_nontemporal_load(&F2[(t + 2 * j) * 32]); Mp[j] = v.x; Ip[j] = v.y; }
+            BAQ_BWD_UPDATE(i)
+            {
+                double sum = 0., max = 0.; int max_k = -1;
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     double z;
-                    z = sM_[c][j] * bMr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 0; } sum += z;
-                    z = sI_[c][j] * bIr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 1; } sum += z;
+                    z = fM[j] * bMr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 0; } sum += z;
+                    const double fi = (j + 1 < NB) ? (EI * (p.m1 * Mp[j + 1] + p.m4 * Ip[j + 1])) * inv_i : 0.;     // the forward kernel's I[i][j]
+                    z = fi * bIr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 1; } sum += z;
                 }
-                max /= sum;
-                double v = -4.343 * log(1. - max) + .499;
-                int kq = (v >= 2147483648.0 || v < -2147483648.0 || v != v) ? INT32_MIN : (int)v;
-                P[(size_t)(i - 1) * 64] = (int32_t)(((uint32_t)max_k << 8) | (uint32_t)(uint8_t)(kq > 100 ? 99 : kq));
+                BAQ_MAP_FINISH(i, sum, max, max_k)
+            }
+            BAQ_BWD_UPDATE(i - 1)
+            {
+                double sum = 0., max = 0.; int max_k = -1;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    double z;
+                    z = Mp[j] * bMr[j]; if (z > max) { max = z; max_k = (i - 1 - BW - 1 + j) << 2 | 0; } sum += z;
+                    z = Ip[j] * bIr[j]; if (z > max) { max = z; max_k = (i - 1 - BW - 1 + j) << 2 | 1; } sum += z;
+                }
+                BAQ_MAP_FINISH(i - 1, sum, max, max_k)
             }
         }
-        carry_qf = first_qf; carry_qy = first_qy;
-        // block word of the block below: shift up by C fields, C new codes at the bottom
-        if (t >= 1) {
-            uint64_t nw = bw_ << (3 * C);
-#pragma unroll
-            for (int c = 0; c < C; ++c) nw |= (uint64_t)RCONV(rnew[c]) << (3 * c);
-            bw_ = nw;
-        }
     }
+#undef BAQ_BWD_UPDATE
+#undef BAQ_MAP_FINISH
 
-    /*** realn.c, extended BAQ ***/
-    {
+    /*** realn.c, extended BAQ: bq = min(running max from the left, from the right) inside each M block; qual = min(qual, bq) ***/
+    if (PLDS) {
+        // the right-hand maximum was applied row by row above; the left-hand one needs the forward direction
+        if (!plain) {
+            int yy = 0;
+            for (int c = 0; c < d.n_cigar; ++c) {
+                int op = d.cigar[c] & 0xf, l = (int)(d.cigar[c] >> 4);
+                if (cg_is_mop(op)) {
+                    if (l > lq - yy) l = lq - yy;
+                    int run = 0;
+                    for (int q = yy; q < yy + l; ++q) {
+                        const int b = Pl[(size_t)q * 64];
+                        run = b > run ? b : run;
+                        const int q0 = qual[q];
+                        if (q0 > run) qual[q] = (uint8_t)run;
+                    }
+                    yy += l;
+                } else if (op == CG_S || op == CG_I) {
+                    if (l > lq - yy) l = lq - yy;
+                    yy += l;
+                }
+            }
+        }
+    } else {
         long long xx = d.rpos; int yy = 0;
         for (int c = 0; c < d.n_cigar; ++c) {
             int op = d.cigar[c] & 0xf, l = (int)(d.cigar[c] >> 4);
@@ -877,22 +726,22 @@ __global__ void __launch_bounds__(256) k_baq_ck_bwd(StaReadsDev R, StaWinDev W, 
                 if (l > lq - yy) l = lq - yy;
                 if (l > 0) {
                     int run = 0;
-                    for (int i = yy; i < yy + l; ++i) {
-                        int32_t pk = P[(size_t)i * 64];
+                    for (int q = yy; q < yy + l; ++q) {
+                        int32_t pk = Pg[(size_t)q * 64];
                         int st = pk >> 8;
-                        int b = ((st & 3) != 0 || (long long)(st >> 2) != xx - d.xb + (i - yy)) ? 0 : (pk & 0xff);
+                        int b = ((st & 3) != 0 || (long long)(st >> 2) != xx - d.xb + (q - yy)) ? 0 : (pk & 0xff);
                         run = b > run ? b : run;
-                        P[(size_t)i * 64] = (b << 8) | run;
+                        Pg[(size_t)q * 64] = (b << 8) | run;        // raw bq, left running max
                     }
                     run = 0;
-                    for (int i = yy + l - 1; i >= yy; --i) {
-                        int32_t pk = P[(size_t)i * 64];
+                    for (int q = yy + l - 1; q >= yy; --q) {
+                        int32_t pk = Pg[(size_t)q * 64];
                         int b = pk >> 8, left = pk & 0xff;
                         run = b > run ? b : run;
-                        int bqv = W.baq_plain ? b : (left < run ? left : run);    // plain (calmd -r without -E): min(qual, q) per base
-                        int q0 = qual[i];
+                        int bqv = plain ? b : (left < run ? left : run);    // plain (calmd -r without -E): min(qual, q) per base
+                        int q0 = qual[q];
                         int tag = 64 + (q0 <= bqv ? 0 : q0 - bqv);
-                        qual[i] = (uint8_t)(q0 - (tag - 64));
+                        qual[q] = (uint8_t)(q0 - (tag - 64));
                     }
                 }
                 xx += l; yy += l;
@@ -904,20 +753,18 @@ __global__ void __launch_bounds__(256) k_baq_ck_bwd(StaReadsDev R, StaWinDev W, 
     }
 }
 
-static bool baq_use_ck() { const char *e = getenv("STA_BAQ_CHECKPOINT"); return e && atoi(e) > 0; }
-
-static size_t baq_ck_slot_dbl(int lq_cap, int bw, int c)
+template <int NB, bool DEC>
+static size_t baq_slot_dbl_t(int lq_cap)
 {
-    int nb = 2 * bw + 1;
-    size_t nck = (size_t)((lq_cap - 1) / c);
-    return nck * (3 * nb) * 64 + (size_t)(lq_cap + 1) / 2 * 64;
+    // forward rows + s[] + the per-row state ints of the fallback path (reads longer than BAQ_LDS_ROWS_MAX)
+    return baq_rows_lr<NB, DEC>(lq_cap) * 64 + (size_t)(lq_cap + 2) * 64 + (lq_cap > BAQ_LDS_ROWS_MAX ? (size_t)(lq_cap + 1) / 2 * 64 : 0);
 }
+// band width 7 stores I rows every second row (DEC), band width 8 (a few reads with a 2-3 bp deletion: it would not fit the register
+// file at two waves per SIMD) stores every row
+static size_t baq_slot_dbl(int lq_cap, int bw) { return bw == 7 ? baq_slot_dbl_t<15, true>(lq_cap) : baq_slot_dbl_t<17, false>(lq_cap); }
 
-static size_t baq_slot_dbl(int lq_cap, int bw)
-{
-    int nb = 2 * bw + 1;
-    return (size_t)lq_cap * (2 * nb) * 64 + (size_t)(lq_cap + 2) * 64 + (size_t)(lq_cap + 1) / 2 * 64;
-}
+// bytes of forward-row stream per query base of the band-7 kernel pair (written once, read once): what bench.py reports as DRAM traffic
+extern "C" double sta_baq_stream_bytes_per_base(void) { return 3 * 15 * 8 / 2.0; }
 
 size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_launch, int slab_gib_cap)
 {
@@ -931,8 +778,7 @@ size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_l
     const char *es = getenv("STA_BAQ_SLAB_GIB");
     if (es && atoi(es) > 0) slab_gib = (size_t)atoi(es);
     if (slab_gib_cap > 0 && (size_t)slab_gib_cap < slab_gib) slab_gib = (size_t)slab_gib_cap;     // the engine's fallback after a failed allocation
-    size_t slot = baq_slot_dbl(lq_cap, 8) * 8;
-    if (baq_use_ck()) { size_t a = baq_ck_slot_dbl(lq_cap, 7, 4), b = baq_ck_slot_dbl(lq_cap, 8, 3); slot = (a > b ? a : b) * 8; }
+    size_t slot = std::max(baq_slot_dbl(lq_cap, 8), baq_slot_dbl(lq_cap, 7)) * 8;
     if ((size_t)gpl * slot > (slab_gib << 30)) {
         // split into equal chunks that are multiples of 6144 groups (LCM of the 3072 / 2048 resident waves of the two kernels)
         int64_t fit = (int64_t)((slab_gib << 30) / slot);
@@ -947,24 +793,18 @@ size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_l
     return (size_t)gpl * slot;
 }
 
-template <int BW>
+template <int BW, bool DEC>
 static void run_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int64_t g0, int64_t ng, int use_list, int pass)
 {
     unsigned nb = (unsigned)((ng + 3) / 4);
-    if (baq_use_ck()) {
-        constexpr int C = BW == 7 ? 4 : 3;
-        size_t cslot = baq_ck_slot_dbl(lq_cap, BW, C);
-        if (pass == 0)
-            hipLaunchKernelGGL((k_baq_ck_fwd<BW, C>), dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, cslot, lq_cap);
-        else
-            hipLaunchKernelGGL((k_baq_ck_bwd<BW, C>), dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, cslot, lq_cap);
-        return;
-    }
-    size_t slot = baq_slot_dbl(lq_cap, BW);
-    if (pass == 0)
-        hipLaunchKernelGGL(k_baq_fwd<BW>, dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap);
-    else
-        hipLaunchKernelGGL(k_baq_bwd<BW>, dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap);
+    // the slot stride is the same for both band widths (the engine sizes one slab for either): the larger of the two layouts
+    size_t slot = std::max(baq_slot_dbl(lq_cap, 8), baq_slot_dbl(lq_cap, 7));
+    if (pass == 0) { hipLaunchKernelGGL((k_baq_fwd<BW, DEC>), dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap); return; }
+    if (lq_cap <= BAQ_LDS_ROWS_MAX) {
+        const int rows = (lq_cap + 3) & ~3;
+        hipLaunchKernelGGL((k_baq_bwd<BW, DEC, true>), dim3(nb), dim3(256), (size_t)4 * rows * 64, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap, rows);
+    } else
+        hipLaunchKernelGGL((k_baq_bwd<BW, DEC, false>), dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap, 0);
 }
 
 // One pass (0 = forward, 1 = backward + MAP + apply) over groups [g0, g0 + ng) of 64 reads; the engine calls the two passes
@@ -977,6 +817,6 @@ void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
         g_tables_init = true;
     }
     if (r.n == 0 || lq_cap <= 0 || ng <= 0) return;
-    if (bw == 7) run_band<7>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass);
-    else if (bw == 8) run_band<8>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass);
+    if (bw == 7) run_band<7, true>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass);
+    else if (bw == 8) run_band<8, false>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass);
 }

@@ -56,7 +56,7 @@ __device__ __forceinline__ void depth_row_write(const StaWinDev &W, const int32_
 // 64 column counts.  That is O(reads) work per sub-tile instead of O(reads x 64 columns).  The counts go to `counts`
 // ([nfiles + 1][ncols + 1] int32, last row = covering reads: sta_depth_counts_dev) and give the row lengths; ONE look-back per
 // workgroup places its text; EMIT re-reads the counts, formats the rows into the wave's LDS line buffer and flushes them.
-#define DF_SUB_DEFAULT 4
+#define DF_SUB_DEFAULT 8
 struct DepthFusedArgs {
     unsigned long long *status; unsigned int *ticket;
     char *out; unsigned long long capacity;

@@ -5,7 +5,7 @@ out = "gpurun_out/dbg"; os.makedirs(out, exist_ok=True)
 sam, fa = write_synth_sam(out, n_ref=500000, depth=30, read_len=150, seed=55, paired=True)
 args = ["mpileup", "-f", fa, sam]
 want = subprocess.run(["oracle/_build/oracle_samtools"] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.split(b"\n")
-for name, envx in (("default", {}), ("no_side", {"STA_BAQ_NO_SIDE_STREAM": "1"}), ("force_slow", {"STA_BAQ_FORCE_SLOW": "1"}), ("checkpoint", {"STA_BAQ_CHECKPOINT": "1"}), ("no_olap(-x)", {})):
+for name, envx in (("default", {}), ("no_side", {"STA_BAQ_NO_SIDE_STREAM": "1"}), ("force_slow", {"STA_BAQ_FORCE_SLOW": "1"}), ("no_olap(-x)", {})):
     env = dict(os.environ, STA_DEBUG="1"); env.update(envx)
     a = args if name != "no_olap(-x)" else ["mpileup", "-x", "-f", fa, sam]
     w = want if name != "no_olap(-x)" else subprocess.run(["oracle/_build/oracle_samtools"] + a, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.split(b"\n")

@@ -47,18 +47,18 @@ def test_engine_equals_oracle_on_synthetic(tmp_path, oracle_bin, product_bin, ci
         pytest.fail("line count differs: got %d want %d" % (len(g), len(w)))
 
 
-@pytest.mark.parametrize("force_slow", ["0", "1", "checkpoint"])
-def test_baq_kernels_agree_with_oracle(tmp_path, oracle_bin, product_bin, force_slow):
-    """The band-in-registers BAQ kernels (bw 7/8, default), their checkpoint-and-recompute variant
-    (STA_BAQ_CHECKPOINT=1) and the general-band kernel (STA_BAQ_FORCE_SLOW=1) must all reproduce the oracle."""
-    sam, fa = write_synth_sam(str(tmp_path), n_ref=12000, depth=40, read_len=120, seed=61, paired=True, indel_rate=0.2, max_indel=10)
-    args = ["mpileup", "-E", "-f", fa, sam]
+@pytest.mark.parametrize("mode", ["band_even", "band_odd", "long_reads", "general", "plain_E_off"])
+def test_baq_kernels_agree_with_oracle(tmp_path, oracle_bin, product_bin, mode):
+    """The band-in-registers BAQ kernels (band width 7 with I rows stored every second row, band width 8 with every row; per-row
+    MAP states in LDS) for even and odd read lengths, the same kernels with the states in the scratch slot (reads longer than
+    256 bases) and the general-band kernel (STA_BAQ_FORCE_SLOW=1) must all reproduce the oracle."""
+    read_len = {"band_even": 120, "band_odd": 121, "long_reads": 301, "general": 120, "plain_E_off": 150}[mode]
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=12000, depth=40, read_len=read_len, seed=61, paired=True, indel_rate=0.2, max_indel=10)
+    args = ["mpileup", "-f", fa, sam] if mode == "plain_E_off" else ["mpileup", "-E", "-f", fa, sam]
     want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
     env = dict(os.environ)
-    if force_slow == "1":
+    if mode == "general":
         env["STA_BAQ_FORCE_SLOW"] = "1"
-    elif force_slow == "checkpoint":
-        env["STA_BAQ_CHECKPOINT"] = "1"
     got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert got.returncode == 0, got.stderr.decode()[-500:]
     assert got.stdout == want

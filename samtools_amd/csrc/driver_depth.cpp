@@ -10,6 +10,7 @@
 #include "host_pump.h"
 #include "host_chunk.h"
 #include "host_bgzf.h"
+#include "driver_pipeline.h"
 #include <cstdlib>
 #include <getopt.h>
 #include <cstdio>
@@ -30,36 +31,32 @@ struct DRunner {
     std::unique_ptr<Bed> bed;
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
     int64_t window_cols = 1 << 20, max_reads = 4 << 20;
-    std::vector<StagedFile> staged;     // the window the pump staged last
-    std::vector<StagedFile> no_reads;   // read-less windows leave `staged` alone
-    pvector<char> text;                 // page-locked: the D2H copy of the text lands here
+    std::unique_ptr<WinPipe> pipe;      // producer (this thread) -> device thread -> writer thread (driver_pipeline.h)
+    std::vector<StagedFile> no_reads;   // read-less windows; device thread only
 
-    // one window over what the pump staged (have_reads) or over no reads at all (zero rows)
-    int run_window(int tid, int64_t cb, int64_t ce, bool have_reads, int all_mode, bool write, uint64_t *n_kept)
+    // device stage of one window (device thread): H2D, the depth kernels, D2H of the rows
+    int device_stage(WinJob &j)
     {
-        if (ce <= cb) { if (n_kept) *n_kept = 0; return 0; }
         size_t nf = readers.size();
         std::vector<sta_reads> views(nf);
-        if (!have_reads && no_reads.size() != nf) { no_reads.assign(nf, StagedFile()); for (auto &e : no_reads) e.finish(); }
-        for (size_t f = 0; f < nf; ++f) views[f] = have_reads ? staged[f].view() : no_reads[f].view();
+        if (!j.have_reads && no_reads.size() != nf) { no_reads.assign(nf, StagedFile()); for (auto &e : no_reads) e.finish(); }
+        for (size_t f = 0; f < nf; ++f) views[f] = j.have_reads ? j.staged[f].view() : no_reads[f].view();
         sta_window w; memset(&w, 0, sizeof w);
-        w.tid = tid; w.origin = cb; w.col_beg = 0; w.col_end = (int32_t)(ce - cb);
-        w.tname = h->names[(size_t)tid].c_str(); w.tlen = h->lens[(size_t)tid];
+        w.tid = j.tid; w.origin = j.cb; w.col_beg = 0; w.col_end = (int32_t)(j.ce - j.cb);
+        w.tname = h->names[(size_t)j.tid].c_str(); w.tlen = h->lens[(size_t)j.tid];
         w.n_files = (int32_t)nf; w.files = views.data(); w.mem = STA_MEM_HOST;
-        const Bed::Ivals *iv = bed ? bed->get(h->names[(size_t)tid]) : nullptr;
+        const Bed::Ivals *iv = bed ? bed->get(h->names[(size_t)j.tid]) : nullptr;
         static const int64_t none = 0;
         if (bed) { w.has_bed = 1; w.n_bed = iv ? (int64_t)iv->beg.size() : 0; w.bed_beg = iv ? iv->beg.data() : &none; w.bed_end = iv ? iv->end.data() : &none; }
         if (sta_stage_window(eng, &w) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
         sta_depth_params pp = p;
-        pp.all_pos = all_mode;
-        sta_plan_info info;
-        if (sta_depth_plan(eng, &pp, &info) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
-        if (n_kept) *n_kept = info.n_kept_reads;
-        if (!write || info.out_bytes == 0) return 0;
-        if (sta_depth_emit(eng, nullptr, 0) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
-        text.resize((size_t)info.out_bytes);
-        if (sta_fetch_output(eng, text.data(), info.out_bytes) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
-        if (fwrite(text.data(), 1, text.size(), out) != text.size()) return -1;
+        pp.all_pos = j.all_mode;
+        j.out_bytes = 0;
+        if (sta_depth_plan(eng, &pp, &j.info) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
+        if (!j.write || j.info.out_bytes == 0) return 0;
+        if (j.text.size() < (size_t)j.info.out_bytes) j.text.resize((size_t)j.info.out_bytes + (size_t)(j.info.out_bytes >> 3));
+        if (sta_fetch_output(eng, j.text.data(), j.info.out_bytes) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
+        j.out_bytes = j.info.out_bytes;
         return 0;
     }
 
@@ -67,7 +64,10 @@ struct DRunner {
     {
         while (a < b) {
             int64_t e = std::min(b, a + window_cols);
-            if (run_window(tid, a, e, false, 1, true, nullptr) < 0) return -1;
+            WinJob *j = pipe->acquire();
+            j->tid = tid; j->cb = a; j->ce = e; j->have_reads = false; j->all_mode = 1; j->write = true; j->hold = false;
+            pipe->submit(j);
+            if (pipe->error()) return -1;
             a = e;
         }
         return 0;
@@ -87,24 +87,34 @@ struct DRunner {
             if (!started && !pump.has_carry()) cursor = std::max(cursor, pump.next_pos(tid));
             int64_t ce_target = cursor + window_cols;
             if (has_reg) ce_target = std::min(ce_target, end0);
-            if (ce_target <= cursor) { pump.fill_staged(tid, cursor, INT64_MAX, staged); pump.drop_tid_carry(); break; }
-            int64_t ce = pump.fill_staged(tid, cursor, ce_target, staged);
-            if (pump.error()) return -1;
+            WinJob *j = pipe->acquire();
+            if (ce_target <= cursor) { pump.fill_staged(tid, cursor, INT64_MAX, j->staged); pipe->release(j); pump.drop_tid_carry(); break; }
+            int64_t ce;
+            { const double t0 = WinPipe::now(); ce = pump.fill_staged(tid, cursor, ce_target, j->staged); pipe->add_fill_time(WinPipe::now() - t0); }
+            if (pump.error()) { pipe->release(j); return -1; }
             if (pump.next_pos(tid) == INT64_MAX) {
                 int64_t me = pump.carry_max_end();
                 if (me != INT64_MIN) ce = std::min(ce, std::max(me, cursor));
             }
             if (ce > cursor) {
-                uint64_t n_kept = 0;
+                j->tid = tid; j->cb = cursor; j->ce = ce; j->have_reads = true; j->hold = false;
                 if (mode == 1 && !started) {
-                    if (run_window(tid, cursor, ce, true, 0, false, &n_kept) < 0) return -1;
-                    if (n_kept) {
+                    // -a: nothing of this contig is printed before a read of it is known to pass the filters
+                    j->all_mode = 0; j->write = false; j->hold = true;
+                    pipe->submit(j);
+                    if (pipe->wait(j) < 0) { pipe->release(j); return -1; }
+                    if (j->info.n_kept_reads) {
                         started = true;
-                        if (run_empty(tid, lo, cursor) < 0) return -1;
-                        if (run_window(tid, cursor, ce, true, 1, true, &n_kept) < 0) return -1;
-                    }
-                } else if (run_window(tid, cursor, ce, true, started ? 1 : 0, true, &n_kept) < 0) return -1;
-            }
+                        if (run_empty(tid, lo, cursor) < 0) { pipe->release(j); return -1; }
+                        j->all_mode = 1; j->write = true; j->hold = false;
+                        pipe->submit(j);
+                    } else pipe->release(j);
+                } else {
+                    j->all_mode = started ? 1 : 0; j->write = true;
+                    pipe->submit(j);
+                }
+            } else pipe->release(j);
+            if (pipe->error()) return -1;
             pump.retire(ce);
             cursor = std::max(cursor, ce);
         }
@@ -130,22 +140,23 @@ struct DRunner {
             if (pump.error()) break;
             if (all >= 2 && !has_reg) {
                 int upto = tid < 0 ? h->nref() : tid;
-                for (int t = next_full; t < upto; ++t) if (run_empty(t, 0, h->lens[(size_t)t]) < 0) return 1;
+                for (int t = next_full; t < upto; ++t) if (run_empty(t, 0, h->lens[(size_t)t]) < 0) { pipe->drain(); return 1; }
                 next_full = tid < 0 ? h->nref() : tid + 1;
             }
             if (tid < 0) break;
             if (has_reg && tid == tid0) did_tid0 = true;
-            if (process_tid(pump, tid, mode) < 0) { if (pump.error()) break; return 1; }
+            if (process_tid(pump, tid, mode) < 0) { if (pump.error()) break; pipe->drain(); return 1; }
         }
         if (pump.error()) {
+            pipe->drain();
             fflush(out);
             if (pump.error() == -2) fprintf(stderr, "samtools depth: Data is not position sorted\n");
             else fprintf(stderr, "samtools depth: %s\n", pump.error_text());
             return 1;
         }
         if (all && has_reg && !did_tid0)
-            if (run_empty(tid0, beg0, std::min(end0, h->lens[(size_t)tid0])) < 0) return 1;
-        return 0;
+            if (run_empty(tid0, beg0, std::min(end0, h->lens[(size_t)tid0])) < 0) { pipe->drain(); return 1; }
+        return pipe->drain() < 0 ? 1 : 0;
     }
 };
 
@@ -230,11 +241,18 @@ extern "C" int sta_main_depth(int argc, char **argv)
         for (auto &fn : fns) fprintf(run.out, "\t%s", fn.c_str());
         fputc('\n', run.out);
     }
-    if (sta_engine_create(&run.eng, 0, nullptr) != STA_OK) {
+    if (sta_engine_create(&run.eng, getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0, nullptr) != STA_OK) {
         fprintf(stderr, "samtools depth: no usable HIP device (the MI355X engine has no CPU fallback)\n");
         return 1;
     }
-    int ret = run.run();
+    fflush(run.out);                  // the header line: the writer thread owns the stream from here on
+    int ret;
+    {
+        const char *ns = getenv("STA_PIPE_SLOTS");
+        run.pipe.reset(new WinPipe(ns && atoi(ns) > 0 ? (size_t)atoi(ns) : 3, [&run](WinJob &j) { return run.device_stage(j); }, run.out, "samtools depth: failed to write the output\n"));
+        ret = run.run();
+        run.pipe.reset();
+    }
     fflush(run.out);
     if (run.out != stdout) fclose(run.out);
     sta_engine_destroy(run.eng);

@@ -11,6 +11,7 @@
 #include "host_pump.h"
 #include "host_chunk.h"
 #include "host_bgzf.h"
+#include "driver_pipeline.h"
 #include <getopt.h>
 #include <ctime>
 #include <cstdio>
@@ -61,87 +62,73 @@ struct Samples {
     }
 };
 
-// STA_DRIVER_TIMING=1: cumulative wall time per driver phase on stderr at exit (where an end-to-end run spends its time)
-struct PhaseClock {
-    const bool on = getenv("STA_DRIVER_TIMING") != nullptr;
-    double t[8] = { 0 }; const char *name[8] = { "fill+stage", "set_ref", "stage_window", "plan", "emit", "fetch", "fwrite", "retire" };
-    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
-    struct Scope { PhaseClock &c; int k; double t0; Scope(PhaseClock &c_, int k_) : c(c_), k(k_), t0(c_.on ? now() : 0) {} ~Scope() { if (c.on) c.t[k] += now() - t0; } };
-    ~PhaseClock() { if (on) { fprintf(stderr, "[driver timing]"); for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.3f s", name[i], t[i]); fprintf(stderr, "\n"); } }
-};
-
 struct Runner {
-    PhaseClock clk;
     Conf &conf;
     sta_engine *eng = nullptr;
     std::vector<std::unique_ptr<AlnReader>> readers;
     const Header *h = nullptr;
     FILE *out = stdout;
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
-    std::vector<StagedFile> staged;                   // the window the pump staged last
-    std::vector<StagedFile> no_reads;                 // read-less windows (zero-depth rows) leave `staged` alone
-    pvector<char> text;                 // page-locked: the D2H copy of the text lands here
+    std::unique_ptr<WinPipe> pipe;                    // producer (this thread) -> device thread -> writer thread
+    std::vector<StagedFile> no_reads;                 // read-less windows (zero-depth rows); device thread only
     std::vector<std::vector<char>> cap_dropped;      // per file: reads of the last window that the -d cap dropped
+    // host side of mplp_get_ref (the pump's lookahead asks which contig's FASTA is "loaded" and how long it is); producer thread
     int loaded_ref_tid = -2;
-    int64_t loaded_ref_len = INT64_MAX;               // length of the loaded FASTA contig (INT64_MAX: none, no length filter)
+    int64_t loaded_ref_len = INT64_MAX;               // length of the FASTA contig (INT64_MAX: none, no length filter)
+    int dev_ref_tid = -2;                             // contig whose sequence is in HBM; device thread only
 
     explicit Runner(Conf &c) : conf(c) {}
 
-    int set_ref(int tid)
+    void host_ref(int tid)
     {
-        if (!conf.fai || tid == loaded_ref_tid) return 0;
-        sta_clear_references(eng);
+        if (!conf.fai || tid == loaded_ref_tid) return;
         loaded_ref_tid = tid;
-        loaded_ref_len = INT64_MAX;
         const std::string *s = conf.fai->fetch(h->names[(size_t)tid]);
-        if (!s) return 0;
-        loaded_ref_len = (int64_t)s->size();
-        return sta_set_reference(eng, tid, s->data(), (int64_t)s->size(), STA_MEM_HOST);
+        loaded_ref_len = s ? (int64_t)s->size() : INT64_MAX;
     }
 
-    // run one window over what the pump staged (have_reads) or over no reads at all; all_mode overrides conf.p.all.
-    // Returns <0 on error; n_data receives the data column count.
-    int run_window(int tid, int64_t cb, int64_t ce, WindowSource *pump, bool have_reads, int all_mode, bool write, uint64_t *n_data)
+    // device stage of one window (device thread): reference, H2D, plan, emit, D2H of the text
+    int device_stage(WinJob &j)
     {
-        if (ce <= cb) { if (n_data) *n_data = 0; return 0; }
-        { PhaseClock::Scope ps(clk, 1); if (set_ref(tid) < 0) return -1; }
-        size_t nf = readers.size();
+        const size_t nf = readers.size();
+        if (conf.fai && j.tid != dev_ref_tid) {
+            sta_clear_references(eng);
+            dev_ref_tid = j.tid;
+            const std::string *s = conf.fai->fetch(h->names[(size_t)j.tid]);
+            if (s && sta_set_reference(eng, j.tid, s->data(), (int64_t)s->size(), STA_MEM_HOST) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
+        }
         std::vector<sta_reads> views(nf);
-        if (!have_reads && no_reads.size() != nf) { no_reads.assign(nf, StagedFile()); for (auto &e : no_reads) e.finish(); }
-        for (size_t f = 0; f < nf; ++f) views[f] = have_reads ? staged[f].view() : no_reads[f].view();
+        if (!j.have_reads && no_reads.size() != nf) { no_reads.assign(nf, StagedFile()); for (auto &e : no_reads) e.finish(); }
+        for (size_t f = 0; f < nf; ++f) views[f] = j.have_reads ? j.staged[f].view() : no_reads[f].view();
         sta_window w; memset(&w, 0, sizeof w);
-        w.tid = tid; w.origin = cb; w.col_beg = 0; w.col_end = (int32_t)(ce - cb);
-        w.tname = h->names[(size_t)tid].c_str(); w.tlen = h->lens[(size_t)tid];
+        w.tid = j.tid; w.origin = j.cb; w.col_beg = 0; w.col_end = (int32_t)(j.ce - j.cb);
+        w.tname = h->names[(size_t)j.tid].c_str(); w.tlen = h->lens[(size_t)j.tid];
         w.n_files = (int32_t)nf; w.files = views.data(); w.mem = STA_MEM_HOST;
-        const Bed::Ivals *iv = conf.bed ? conf.bed->get(h->names[(size_t)tid]) : nullptr;
+        const Bed::Ivals *iv = conf.bed ? conf.bed->get(h->names[(size_t)j.tid]) : nullptr;
         static const int64_t none = 0;
         if (conf.bed) { w.has_bed = 1; w.n_bed = iv ? (int64_t)iv->beg.size() : 0; w.bed_beg = iv ? iv->beg.data() : &none; w.bed_end = iv ? iv->end.data() : &none; }
         if (has_reg) { w.has_reg = 1; w.reg_beg = beg0; w.reg_end = end0; }
-        { PhaseClock::Scope ps(clk, 2); if (sta_stage_window(eng, &w) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; } }
+        if (sta_stage_window(eng, &w) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
         sta_mplp_params p = conf.p;
-        p.all = all_mode;
-        sta_plan_info info;
-        { PhaseClock::Scope ps(clk, 3); if (sta_mpileup_plan(eng, &p, &info) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; } }
-        if (n_data) *n_data = info.n_data_cols;
-        cap_dropped.assign(nf, {});
-        if (info.n_maxcnt_dropped && have_reads && pump) {
-            // the cap removed reads from the iterator: they must not be carried into the next window (bam_plp_push never
-            // stored them); info bit 0 = reached bam_plp_push, bit 1 = in the pileup
-            std::vector<uint32_t> inf;
+        p.all = j.all_mode;
+        if (sta_mpileup_plan(eng, &p, &j.info) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
+        j.out_bytes = 0;
+        j.read_info.clear();
+        if (j.info.n_maxcnt_dropped && j.have_reads) {
+            // the cap removed reads from the iterator: the producer takes them out of the pump (info bit 0 = reached bam_plp_push,
+            // bit 1 = in the pileup)
+            j.read_info.resize(nf);
             for (size_t f = 0; f < nf; ++f) {
-                inf.resize((size_t)staged[f].n());
-                if (inf.empty()) continue;
-                if (sta_fetch_read_state(eng, (int32_t)f, inf.data(), nullptr) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
-                cap_dropped[f].assign(inf.size(), 0);
-                for (size_t i = 0; i < inf.size(); ++i)
-                    cap_dropped[f][i] = (inf[i] & 1u) && !(inf[i] & 2u) && pump->staged_has_span(f, i);
+                j.read_info[f].resize((size_t)j.staged[f].n());
+                if (j.read_info[f].empty()) continue;
+                if (sta_fetch_read_state(eng, (int32_t)f, j.read_info[f].data(), nullptr) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
             }
         }
-        if (!write || info.out_bytes == 0) return 0;
-        { PhaseClock::Scope ps(clk, 4); if (sta_mpileup_emit(eng, nullptr, 0) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; } }
-        { PhaseClock::Scope ps(clk, 5); text.resize((size_t)info.out_bytes);
-          if (sta_fetch_output(eng, text.data(), info.out_bytes) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; } }
-        { PhaseClock::Scope ps(clk, 6); if (fwrite(text.data(), 1, text.size(), out) != text.size()) { fprintf(stderr, "Failed to write pileup data.\n"); return -1; } }
+        if (!j.write || j.info.out_bytes == 0) return 0;
+        if (sta_mpileup_emit(eng, nullptr, 0) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
+        if (j.text.size() < (size_t)j.info.out_bytes) j.text.resize((size_t)j.info.out_bytes + (size_t)(j.info.out_bytes >> 3));
+        if (sta_fetch_output(eng, j.text.data(), j.info.out_bytes) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
+        j.out_bytes = j.info.out_bytes;
         return 0;
     }
 
@@ -150,7 +137,10 @@ struct Runner {
     {
         while (a < b) {
             int64_t e = std::min(b, a + conf.window_cols);
-            if (run_window(tid, a, e, nullptr, false, 1, true, nullptr) < 0) return -1;
+            WinJob *j = pipe->acquire();
+            j->tid = tid; j->cb = a; j->ce = e; j->have_reads = false; j->all_mode = 1; j->write = true; j->hold = false;
+            pipe->submit(j);
+            if (pipe->error()) return -1;
             a = e;
         }
         return 0;
@@ -162,7 +152,7 @@ struct Runner {
     int process_tid(WindowSource &pump, int tid, int mode)
     {
         int64_t tlen = h->lens[(size_t)tid];
-        if (set_ref(tid) < 0) return -1;            // also tells the pump's lookahead the FASTA length of this contig
+        host_ref(tid);                               // tells the pump's lookahead the FASTA length of this contig
         int64_t lo = has_reg ? beg0 : 0;
         int64_t hi_all = has_reg ? std::min(end0, tlen) : tlen;
         bool started = mode == 2;
@@ -173,32 +163,58 @@ struct Runner {
             if (!started) cursor = std::max(cursor, std::min(pump.carry_next_covered(cursor), pump.next_pos(tid)));   // skip uncovered gap
             int64_t ce_target = cursor + conf.window_cols;
             if (has_reg) ce_target = std::min(ce_target, end0);
+            WinJob *j = pipe->acquire();
             if (ce_target <= cursor) {              // past the region end: drain the rest of this contig
-                pump.fill_staged(tid, cursor, INT64_MAX, staged);
+                pump.fill_staged(tid, cursor, INT64_MAX, j->staged);
+                pipe->release(j);
                 pump.drop_tid_carry();
                 break;
             }
             int64_t ce;
-            { PhaseClock::Scope ps(clk, 0); ce = pump.fill_staged(tid, cursor, ce_target, staged); }
-            if (pump.error()) return -1;
+            { const double t0 = WinPipe::now(); ce = pump.fill_staged(tid, cursor, ce_target, j->staged); pipe->add_fill_time(WinPipe::now() - t0); }
+            if (pump.error()) { pipe->release(j); return -1; }
             if (pump.next_pos(tid) == INT64_MAX) {  // last reads of the contig: stop where they stop
                 int64_t me = pump.carry_max_end();
                 if (me != INT64_MIN) ce = std::min(ce, std::max(me, cursor));
             }
+            cap_dropped.clear();
             if (ce > cursor) {
-                uint64_t n_data = 0;
+                j->tid = tid; j->cb = cursor; j->ce = ce; j->have_reads = true; j->hold = false;
+                // the next window depends on this one's result only if the -d cap can drop reads here (they leave the pump)
+                const bool lockstep = cap_may_trigger(j->staged, conf.p.max_depth);
+                bool waited = false;
                 if (mode == 1 && !started) {
-                    if (run_window(tid, cursor, ce, &pump, true, 0, false, &n_data) < 0) return -1;
-                    if (n_data) {
+                    // -a: nothing of this contig is printed before its first data column is known
+                    j->all_mode = 0; j->write = false; j->hold = true;
+                    pipe->submit(j);
+                    if (pipe->wait(j) < 0) { pipe->release(j); return -1; }
+                    waited = true;
+                    if (j->info.n_data_cols) {
                         started = true;
-                        if (run_empty(tid, lo, cursor) < 0) return -1;
-                        if (run_window(tid, cursor, ce, &pump, true, 1, true, &n_data) < 0) return -1;
+                        if (run_empty(tid, lo, cursor) < 0) { pipe->release(j); return -1; }
+                        j->all_mode = 1; j->write = true; j->hold = false;
+                        pipe->submit(j);
+                        if (pipe->wait(j) < 0) return -1;
+                    } else pipe->release(j);                        // no column to print (the slot's read_info stays readable below)
+                } else {
+                    j->all_mode = started ? 1 : 0; j->write = true;
+                    pipe->submit(j);
+                    if (lockstep) { if (pipe->wait(j) < 0) return -1; waited = true; }
+                }
+                if (waited && !j->read_info.empty()) {
+                    // reads the cap removed must not be carried into the next window (bam_plp_push never stored them)
+                    cap_dropped.assign(readers.size(), {});
+                    for (size_t f = 0; f < j->read_info.size(); ++f) {
+                        const std::vector<uint32_t> &inf = j->read_info[f];
+                        cap_dropped[f].assign(inf.size(), 0);
+                        for (size_t i = 0; i < inf.size(); ++i) cap_dropped[f][i] = (inf[i] & 1u) && !(inf[i] & 2u) && pump.staged_has_span(f, i);
                     }
-                } else if (run_window(tid, cursor, ce, &pump, true, started ? 1 : 0, true, &n_data) < 0) return -1;
-            }
+                }
+            } else pipe->release(j);
+            if (pipe->error()) return -1;
             for (size_t f = 0; f < cap_dropped.size(); ++f) if (!cap_dropped[f].empty()) pump.drop(f, cap_dropped[f]);
             cap_dropped.clear();
-            { PhaseClock::Scope ps(clk, 7); pump.retire(ce); }
+            pump.retire(ce);
             cursor = std::max(cursor, ce);
         }
         pump.drop_tid_carry();
@@ -245,22 +261,23 @@ struct Runner {
             if (pump.error()) break;
             if (all >= 2 && !has_reg) {
                 int upto = tid < 0 ? h->nref() : tid;
-                for (int t = next_full; t < upto; ++t) if (run_empty(t, 0, h->lens[(size_t)t]) < 0) return 1;
+                for (int t = next_full; t < upto; ++t) if (run_empty(t, 0, h->lens[(size_t)t]) < 0) { pipe->drain(); return 1; }
                 next_full = tid < 0 ? h->nref() : tid + 1;
             }
             if (tid < 0) break;
             if (has_reg && tid == tid0) did_tid0 = true;
-            if (process_tid(pump, tid, mode) < 0) { if (pump.error()) break; return 1; }
+            if (process_tid(pump, tid, mode) < 0) { if (pump.error()) break; pipe->drain(); return 1; }
         }
         if (pump.error()) {
+            pipe->drain();
             fflush(out);
             fprintf(stderr, "samtools mpileup: %s\n", pump.error_text());
             fprintf(stderr, "samtools mpileup: error reading from input file\n");
             return 1;
         }
         if (all >= 2 && has_reg && !did_tid0)
-            if (run_empty(tid0, beg0, std::min(end0, h->lens[(size_t)tid0])) < 0) return 1;
-        return 0;
+            if (run_empty(tid0, beg0, std::min(end0, h->lens[(size_t)tid0])) < 0) { pipe->drain(); return 1; }
+        return pipe->drain() < 0 ? 1 : 0;
     }
 };
 
@@ -428,12 +445,18 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     if (!mp.max_depth) { mp.max_depth = INT_MAX; fprintf(stderr, "[mpileup] Max depth set to maximum value (%d)\n", INT_MAX); }
     else if ((long long)mp.max_depth * (long long)fns.size() > 1 << 20) fprintf(stderr, "[mpileup] Combined max depth is above 1M. Potential memory hog!\n");
 
-    int rc = sta_engine_create(&run.eng, 0, nullptr);
+    int rc = sta_engine_create(&run.eng, getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0, nullptr);
     if (rc != STA_OK) {
         fprintf(stderr, "samtools mpileup: no usable HIP device (the MI355X engine has no CPU fallback)\n");
         return 1;
     }
-    int ret = run.run();
+    int ret;
+    {
+        const char *ns = getenv("STA_PIPE_SLOTS");
+        run.pipe.reset(new WinPipe(ns && atoi(ns) > 0 ? (size_t)atoi(ns) : 3, [&run](WinJob &j) { return run.device_stage(j); }, run.out, "Failed to write pileup data.\n"));
+        ret = run.run();
+        run.pipe.reset();                 // joins the device and writer threads (everything is written)
+    }
     fflush(run.out);
     if (run.out != stdout) fclose(run.out);
     sta_engine_destroy(run.eng);

@@ -1,0 +1,182 @@
+// driver_pipeline.h -- the drivers' three-stage window pipeline.
+//
+// The reference's column loop is strictly serial: pull records, pile one column, print it (bam_plcmd.c:607-868,
+// bam2depth.c:578-699).  Here a window is a job that moves through three stages on three threads,
+//     producer (the driver's own thread): pump.fill_staged() -> the job's staging arrays (page-locked)
+//     device thread                     : reference upload, sta_stage_window (H2D), plan + emit kernels, D2H of the text
+//     writer thread                     : fwrite of the text, in submission order
+// so that staging window k+1, computing window k and writing window k-1 overlap.  Jobs live in a small ring of slots (each
+// owns its staging arrays and its text buffer); the engine is only ever touched by the device thread, the pump only by the
+// producer.  The producer can wait for a job's device stage when the NEXT window depends on its result (the -d cap dropped
+// reads; `-a` still waiting for the contig's first data column) -- everything else runs ahead.
+#pragma once
+#include "host_stage.h"
+#include "../../include/samtools_amd.h"
+#include <condition_variable>
+#include <cstdio>
+#include <ctime>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace sta {
+
+struct WinJob {
+    // set by the producer
+    int tid = -1; int64_t cb = 0, ce = 0;
+    bool have_reads = false;             // false: a read-less window (zero-depth rows): `staged` is ignored
+    int all_mode = 0; bool write = true;
+    bool hold = false;                   // the producer will submit this job again (same staged reads): the slot is not recycled
+    std::vector<StagedFile> staged;
+    // set by the device stage
+    pvector<char> text; uint64_t out_bytes = 0;
+    sta_plan_info info{};
+    std::vector<std::vector<uint32_t>> read_info;      // per file: engine info words, fetched only when the -d cap dropped reads
+    int rc = 0;
+    // pipeline state
+    int state = 0;                       // 0 free / with the producer, 1 queued for the device, 2 device done, 3 written
+};
+
+class WinPipe {
+public:
+    WinPipe(size_t n_slots, std::function<int(WinJob &)> device_fn, FILE *out, const char *write_error_text)
+        : fn_(std::move(device_fn)), out_(out), werr_(write_error_text), slots_(n_slots)
+    {
+        timing_ = getenv("STA_DRIVER_TIMING") != nullptr;
+        t0_ = now();
+        dev_ = std::thread([this] { device_loop(); });
+        wr_ = std::thread([this] { writer_loop(); });
+    }
+    ~WinPipe()
+    {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        if (dev_.joinable()) dev_.join();
+        if (wr_.joinable()) wr_.join();
+        if (timing_)
+            fprintf(stderr, "[driver timing] wall %.3f s | producer: fill+stage %.3f s, waiting for a slot %.3f s, waiting for results %.3f s | "
+                            "device thread busy %.3f s | writer busy %.3f s | %llu windows\n",
+                    now() - t0_, t_fill_, t_slot_, t_wait_, t_dev_, t_wr_, (unsigned long long)n_jobs_);
+    }
+    // a slot the producer may fill (blocks while all are in flight)
+    WinJob *acquire()
+    {
+        const double a = now();
+        std::unique_lock<std::mutex> lk(m_);
+        WinJob *j = nullptr;
+        cv_.wait(lk, [&] { for (auto &s : slots_) if (s.state == 0 && !s.hold) { j = &s; return true; } return false; });
+        j->state = -1;                    // with the producer
+        t_slot_ += now() - a;
+        return j;
+    }
+    void release(WinJob *j) { std::lock_guard<std::mutex> g(m_); j->state = 0; j->hold = false; cv_.notify_all(); }   // not submitted after all
+    void submit(WinJob *j)
+    {
+        { std::lock_guard<std::mutex> g(m_); j->state = 1; j->rc = 0; order_.push_back(j); devq_.push_back(j); ++n_jobs_; }
+        cv_.notify_all();
+    }
+    // device stage of j finished (plan info, text in j->text): returns its rc.  A held job is waited for until the writer has
+    // passed it too, so that the producer may submit it again.
+    int wait(WinJob *j)
+    {
+        const double a = now();
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return j->hold ? j->state == 3 : (j->state >= 2 || j->state == 0); });
+        t_wait_ += now() - a;
+        return j->rc;
+    }
+    // every submitted job written; returns the first error (<0) or 0
+    int drain()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return order_.empty(); });
+        return err_;
+    }
+    int error() { std::lock_guard<std::mutex> g(m_); return err_; }
+    void add_fill_time(double s) { t_fill_ += s; }
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
+private:
+    void device_loop()
+    {
+        for (;;) {
+            WinJob *j = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || !devq_.empty(); });
+                if (devq_.empty()) return;
+                j = devq_.front(); devq_.pop_front();
+            }
+            const double a = now();
+            int rc = err_ ? err_ : fn_(*j);          // after an error the remaining jobs only drain
+            t_dev_ += now() - a;
+            { std::lock_guard<std::mutex> g(m_); j->rc = rc; if (rc < 0 && !err_) err_ = rc; j->state = 2; }
+            cv_.notify_all();
+        }
+    }
+    void writer_loop()
+    {
+        for (;;) {
+            WinJob *j = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return (stop_ && order_.empty()) || (!order_.empty() && order_.front()->state == 2); });
+                if (order_.empty()) return;
+                j = order_.front();
+            }
+            const double a = now();
+            int rc = 0;
+            if (j->rc >= 0 && j->write && j->out_bytes && !err_) {
+                if (fwrite(j->text.data(), 1, (size_t)j->out_bytes, out_) != (size_t)j->out_bytes) { fprintf(stderr, "%s", werr_); rc = -1; }
+            }
+            t_wr_ += now() - a;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (rc < 0 && !err_) err_ = rc;
+                order_.pop_front();
+                j->state = j->hold ? 3 : 0;       // a held job stays with the producer (it waits for state >= 2 and submits again)
+            }
+            cv_.notify_all();
+        }
+    }
+
+    std::function<int(WinJob &)> fn_;
+    FILE *out_; const char *werr_;
+    std::deque<WinJob> slots_;
+    std::deque<WinJob *> devq_, order_;
+    std::mutex m_; std::condition_variable cv_;
+    std::thread dev_, wr_;
+    bool stop_ = false; int err_ = 0;
+    bool timing_ = false; double t0_ = 0, t_fill_ = 0, t_slot_ = 0, t_wait_ = 0, t_dev_ = 0, t_wr_ = 0; unsigned long long n_jobs_ = 0;
+};
+
+// Can the -d cap (bam_plp_push: a read is dropped when more than max_depth reads are live at its start) possibly trigger for these
+// staged reads?  Conservative host-side bound: at a read's start at most the reads starting within the longest reference span
+// before it are live.  False for ordinary depths, so that the producer need not wait for the device's verdict.
+inline bool cap_may_trigger(const std::vector<StagedFile> &staged, int64_t max_depth)
+{
+    if (max_depth <= 0 || max_depth >= INT32_MAX) return false;
+    for (const StagedFile &f : staged) {
+        const int64_t n = f.n();
+        if (n <= max_depth) continue;
+        int64_t span_max = 1;
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t span = 0;
+            for (uint32_t k = f.cig_off[(size_t)i]; k < f.cig_off[(size_t)i + 1]; ++k) {
+                const uint32_t c = f.cigar[k]; const int op = (int)(c & 0xf);
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += (int64_t)(c >> 4);
+            }
+            if (span > span_max) span_max = span;
+        }
+        int64_t lo = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            while (f.pos[(size_t)lo] <= f.pos[(size_t)i] - span_max) ++lo;
+            if (i - lo + 1 > max_depth) return true;
+        }
+    }
+    return false;
+}
+
+}  // namespace sta

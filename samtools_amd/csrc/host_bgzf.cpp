@@ -15,8 +15,10 @@ namespace sta {
 int io_default_threads()
 {
     if (const char *e = getenv("STA_IO_THREADS")) { int v = atoi(e); if (v > 0) return v > 64 ? 64 : v; }
-    // half the hardware threads, between 4 and 8: inflate and parse stop scaling there
+    // half the hardware threads, between 4 and 8, on an ordinary host; a quarter (up to 24) on a many-core GPU node, where the
+    // inflate workers and the chunk parsers keep scaling (profiles/r02_e2e_cli.log)
     const unsigned hw = std::thread::hardware_concurrency();
+    if (hw >= 48) { const int q = (int)(hw / 4); return q > 24 ? 24 : q; }
     const int v = (int)(hw / 2);
     return v < 4 ? 4 : v > 8 ? 8 : v;
 }

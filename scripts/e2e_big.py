@@ -1,0 +1,128 @@
+"""End-to-end CLI timing (BAM file -> text) on >= 1 Gbase of synthetic 30x 150 bp reads (SURVEY.md 8d config 3 shape:
+several contigs), samtools-amd vs the CPU oracle.  Host decode, staging, PCIe and the output stream are all included --
+this is NOT bench.py's HBM-resident number.
+
+    python scripts/e2e_big.py [contigs=8] [columns_per_contig=4375000] [outdir=/dev/shm/sta_e2e]
+
+The input is generated in parallel (one process per contig), BGZF level 1.  Output goes to /dev/null for the timings; one
+extra run per command writes to a file and is compared (sha256) with the oracle's text (`mpileup -f` on one contig only:
+the oracle needs ~20 s per 125 Mbases there).  STA_DRIVER_TIMING=1 gives the per-thread phase table of the window pipeline."""
+import hashlib
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+n_contigs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+cols = int(sys.argv[2]) if len(sys.argv) > 2 else 4375000
+out = sys.argv[3] if len(sys.argv) > 3 else "/dev/shm/sta_e2e"
+os.makedirs(out, exist_ok=True)
+ENG = os.path.join(REPO, "samtools_amd", "bin", "samtools-amd")
+ORA = os.path.join(REPO, "oracle", "_build", "oracle_samtools")
+
+
+def make_contig(i):
+    import numpy as np
+    from synth import synth_ref, synth_reads, cigar_str
+    from bamio import bam_record_bytes, bgzf_compress
+    name = "chr%d" % (i + 1)
+    ref = synth_ref(cols, seed=1 + i)
+    rd = synth_reads(ref, depth=30, read_len=150, seed=42 + i)
+    tid = {"chr%d" % (k + 1): k for k in range(n_contigs)}
+    names = rd["names"].tobytes().split(b"\0")
+    recs = []
+    for r in range(rd["n"]):
+        line = "%s_%d\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s" % (
+            names[r].decode(), i, int(rd["flag"][r]), name, int(rd["_abs_pos"][r]) + 1, int(rd["mapq"][r]), cigar_str(rd, r),
+            rd["_bases"][r].tobytes().decode(), (rd["_quals"][r] + 33).astype(np.uint8).tobytes().decode())
+        recs.append(bam_record_bytes(line, tid))
+    comp = bgzf_compress(b"".join(recs), level=1)
+    part = os.path.join(out, "part%d.bgzf" % i)
+    with open(part, "wb") as fh:
+        fh.write(comp)
+    s = ref.tobytes().decode()
+    fa = ">%s\n" % name + "\n".join(s[k:k + 60] for k in range(0, len(s), 60)) + "\n"
+    with open(os.path.join(out, "part%d.fa" % i), "w") as fh:
+        fh.write(fa)
+    return int(rd["n"])
+
+
+def timed(cmd, env=None, stdout=None):
+    t0 = time.perf_counter()
+    with open(os.devnull, "wb") as dn:
+        p = subprocess.run(cmd, stdout=stdout or dn, stderr=subprocess.PIPE, env=env)
+    dt = time.perf_counter() - t0
+    if p.returncode != 0:
+        raise SystemExit("%s failed: %s" % (" ".join(cmd[:3]), p.stderr.decode()[-400:]))
+    return dt, p.stderr.decode()
+
+
+def sha_of(cmd, env=None):
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+    h = hashlib.sha256(); n = 0
+    while True:
+        b = p.stdout.read(1 << 22)
+        if not b:
+            break
+        h.update(b); n += len(b)
+    if p.wait() != 0:
+        raise SystemExit("failed: " + " ".join(cmd[:3]))
+    return h.hexdigest(), n
+
+
+def main():
+    from bamio import bam_header_bytes, bgzf_compress, _EOF
+    bam, fa = os.path.join(out, "big.bam"), os.path.join(out, "big.fa")
+    t0 = time.perf_counter()
+    if not os.path.exists(bam):
+        with mp.Pool(min(n_contigs, 16)) as pool:
+            counts = pool.map(make_contig, range(n_contigs))
+        names = ["chr%d" % (k + 1) for k in range(n_contigs)]
+        hdr = ["@HD\tVN:1.6\tSO:coordinate"] + ["@SQ\tSN:%s\tLN:%d" % (n, cols) for n in names]
+        with open(bam, "wb") as fo:
+            fo.write(bgzf_compress(bam_header_bytes(hdr, names, [cols] * n_contigs)))
+            for i in range(n_contigs):
+                fo.write(open(os.path.join(out, "part%d.bgzf" % i), "rb").read())
+                os.unlink(os.path.join(out, "part%d.bgzf" % i))
+            fo.write(_EOF)
+        with open(fa, "w") as fo:
+            for i in range(n_contigs):
+                fo.write(open(os.path.join(out, "part%d.fa" % i)).read())
+                os.unlink(os.path.join(out, "part%d.fa" % i))
+        n_reads = sum(counts)
+        open(os.path.join(out, "n_reads"), "w").write(str(n_reads))
+    n_reads = int(open(os.path.join(out, "n_reads")).read())
+    mb = n_reads * 150 / 1e6
+    print("input: %d contigs x %d columns, %d reads = %.0f Mbases piled, BAM %.0f MB (generated in %.0f s), host cores %d"
+          % (n_contigs, cols, n_reads, mb, os.path.getsize(bam) / 1e6, time.perf_counter() - t0, os.cpu_count()))
+    t_start, _ = timed([ENG, "depth", os.path.join(REPO, "tests", "golden", "mpileup", "mp_D.sam")])
+    print("engine start-up (tiny input): %.2f s" % t_start)
+    cmds = [("depth -a", ["depth", "-a", bam]), ("mpileup -B -f", ["mpileup", "-B", "-f", fa, bam]), ("mpileup -f", ["mpileup", "-f", fa, bam])]
+    for name, args in cmds:
+        best, best_err = 1e9, ""
+        for thr in (os.environ.get("E2E_THREADS", "8,16,24").split(",")):
+            env = dict(os.environ, STA_IO_THREADS=thr, STA_DRIVER_TIMING="1")
+            dt, err = timed([ENG] + args, env=env)
+            line = [l for l in err.split("\n") if l.startswith("[driver timing]")]
+            print("  %-14s io_threads=%-3s %.2f s  %.0f Mbases/s   %s" % (name, thr, dt, mb / dt, line[0] if line else ""))
+            if dt < best:
+                best, best_err = dt, thr
+        print("%-14s best %.2f s = %.0f Mbases/s (io_threads=%s; %.0f net of start-up)" % (name, best, mb / best, best_err, mb / max(best - t_start, 1e-3)))
+    # the oracle on the same file (single thread); mpileup -f only on the first contig (x n_contigs = the whole file)
+    for name, args, scale in (("depth -a", ["depth", "-a", bam], 1), ("mpileup -B -f", ["mpileup", "-B", "-f", fa, bam], 1),
+                              ("mpileup -f (chr1 only)", ["mpileup", "-f", fa, "-r", "chr1", bam], n_contigs)):
+        dt, _ = timed([ORA] + args)
+        print("oracle %-24s %.2f s -> %.1f Mbases/s single thread" % (name, dt, mb / scale / dt))
+    # byte parity of what was just timed
+    for name, args in (("depth -a", ["depth", "-a", bam]), ("mpileup -B -f", ["mpileup", "-B", "-f", fa, bam]), ("mpileup -f -r chr2", ["mpileup", "-f", fa, "-r", "chr2", bam])):
+        a, na = sha_of([ENG] + args)
+        b, nb = sha_of([ORA] + args)
+        print("parity %-20s engine %d bytes, oracle %d bytes: %s" % (name, na, nb, "IDENTICAL" if a == b else "DIFFERENT"))
+
+
+if __name__ == "__main__":
+    main()

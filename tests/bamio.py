@@ -46,6 +46,45 @@ def _bgzf_block(data, level):
             + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
 
 
+def bam_header_bytes(header_lines, names, lens):
+    text = ("\n".join(header_lines) + "\n").encode() if header_lines else b""
+    out = [b"BAM\1", struct.pack("<i", len(text)), text, struct.pack("<i", len(names))]
+    for n, l in zip(names, lens):
+        nb = n.encode() + b"\0"
+        out.append(struct.pack("<i", len(nb)) + nb + struct.pack("<i", min(l, 2 ** 31 - 1)))
+    return b"".join(out)
+
+
+def bam_record_bytes(line, tid):
+    """one SAM text line -> one BAM alignment record (block_size prefix included); tid: reference name -> id"""
+    f = line.split("\t")
+    qn = f[0].encode() + b"\0"
+    flag = int(f[1], 0); ref = -1 if f[2] == "*" else tid[f[2]]; pos = int(f[3]) - 1; mapq = int(f[4])
+    cig = []
+    if f[5] != "*":
+        num = ""
+        for ch in f[5]:
+            if ch.isdigit(): num += ch
+            else: cig.append(int(num) << 4 | _OPS[ch]); num = ""
+    mref = ref if f[6] == "=" else (-1 if f[6] == "*" else tid[f[6]])
+    mpos = int(f[7]) - 1; tlen = int(f[8])
+    seq = "" if f[9] == "*" else f[9]
+    l = len(seq)
+    sb = bytearray((l + 1) // 2)
+    for i, ch in enumerate(seq): sb[i >> 1] |= _NT16.get(ch.upper(), 15) << (4 if i % 2 == 0 else 0)
+    qb = b"\xff" * l if f[10] == "*" else bytes(ord(ch) - 33 for ch in f[10])
+    rlen = sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3, 7, 8))
+    end = pos + (rlen if rlen > 0 and not (flag & 4) else 1)
+    body = (struct.pack("<iiBBHHHiiii", ref, pos, len(qn), mapq, _reg2bin(max(pos, 0), max(end, 1)), len(cig), flag, l, mref, mpos, tlen)
+            + qn + b"".join(struct.pack("<I", c) for c in cig) + bytes(sb) + qb + b"".join(_aux(a) for a in f[11:]))
+    return struct.pack("<i", len(body)) + body
+
+
+def bgzf_compress(raw, level=1, block=0xff00):
+    """raw bytes -> concatenated BGZF blocks (no EOF marker)"""
+    return b"".join(_bgzf_block(raw[o:o + block], level) for o in range(0, len(raw), block))
+
+
 def sam_to_bam(sam_path, bam_path, level=1, block=0xff00):
     """block: payload bytes per BGZF block (small values make many-block files for the threaded reader tests)."""
     header, names, lens, recs = [], [], [], []
@@ -61,34 +100,7 @@ def sam_to_bam(sam_path, bam_path, level=1, block=0xff00):
                 continue
             recs.append(line)
     tid = {n: i for i, n in enumerate(names)}
-    text = ("\n".join(header) + "\n").encode() if header else b""
-    out = [b"BAM\1", struct.pack("<i", len(text)), text, struct.pack("<i", len(names))]
-    for n, l in zip(names, lens):
-        nb = n.encode() + b"\0"
-        out.append(struct.pack("<i", len(nb)) + nb + struct.pack("<i", min(l, 2 ** 31 - 1)))
-    for line in recs:
-        f = line.split("\t")
-        qn = f[0].encode() + b"\0"
-        flag = int(f[1], 0); ref = -1 if f[2] == "*" else tid[f[2]]; pos = int(f[3]) - 1; mapq = int(f[4])
-        cig = []
-        if f[5] != "*":
-            num = ""
-            for ch in f[5]:
-                if ch.isdigit(): num += ch
-                else: cig.append(int(num) << 4 | _OPS[ch]); num = ""
-        mref = ref if f[6] == "=" else (-1 if f[6] == "*" else tid[f[6]])
-        mpos = int(f[7]) - 1; tlen = int(f[8])
-        seq = "" if f[9] == "*" else f[9]
-        l = len(seq)
-        sb = bytearray((l + 1) // 2)
-        for i, ch in enumerate(seq): sb[i >> 1] |= _NT16.get(ch.upper(), 15) << (4 if i % 2 == 0 else 0)
-        qb = b"\xff" * l if f[10] == "*" else bytes(ord(ch) - 33 for ch in f[10])
-        rlen = sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3, 7, 8))
-        end = pos + (rlen if rlen > 0 and not (flag & 4) else 1)
-        body = (struct.pack("<iiBBHHHiiii", ref, pos, len(qn), mapq, _reg2bin(max(pos, 0), max(end, 1)), len(cig), flag, l, mref, mpos, tlen)
-                + qn + b"".join(struct.pack("<I", c) for c in cig) + bytes(sb) + qb + b"".join(_aux(a) for a in f[11:]))
-        out.append(struct.pack("<i", len(body)) + body)
-    raw = b"".join(out)
+    raw = bam_header_bytes(header, names, lens) + b"".join(bam_record_bytes(line, tid) for line in recs)
     with open(bam_path, "wb") as fo:
         for o in range(0, len(raw), block):
             fo.write(_bgzf_block(raw[o:o + block], level))

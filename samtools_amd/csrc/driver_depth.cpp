@@ -11,6 +11,7 @@
 #include "host_chunk.h"
 #include "host_bgzf.h"
 #include "driver_pipeline.h"
+#include "driver_shard.h"
 #include <cstdlib>
 #include <getopt.h>
 #include <cstdio>
@@ -33,6 +34,13 @@ struct DRunner {
     int64_t window_cols = 1 << 20, max_reads = 4 << 20;
     std::unique_ptr<WinPipe> pipe;      // producer (this thread) -> device thread -> writer thread (driver_pipeline.h)
     std::vector<StagedFile> no_reads;   // read-less windows; device thread only
+    Shard shard;                        // STA_SHARD=rank/world: this rank's block of the columns (driver_shard.h)
+    std::vector<int64_t> lin0;          // linear coordinate of every contig's first column (no region)
+
+    void owned(int tid, int64_t lo, int64_t hi, int64_t *pb, int64_t *pe) const
+    {
+        shard.clip(!shard.on ? 0 : (has_reg ? -beg0 : lin0[(size_t)tid]), lo, hi, pb, pe);
+    }
 
     // device stage of one window (device thread): H2D, the depth kernels, D2H of the rows
     int device_stage(WinJob &j)
@@ -62,6 +70,7 @@ struct DRunner {
 
     int run_empty(int tid, int64_t a, int64_t b)      // zero_region
     {
+        owned(tid, a, b, &a, &b);
         while (a < b) {
             int64_t e = std::min(b, a + window_cols);
             WinJob *j = pipe->acquire();
@@ -79,16 +88,26 @@ struct DRunner {
         int64_t tlen = h->lens[(size_t)tid];
         int64_t lo = has_reg ? beg0 : 0;
         int64_t hi_all = has_reg ? std::min(end0, tlen) : tlen;
+        int64_t stop = has_reg ? end0 : INT64_MAX;       // no window reaches beyond this column
+        if (shard.on) {
+            // this rank's part of the contig: walk up to it with the pump's own bookkeeping (no staging, no device)
+            int64_t pb, pe;
+            owned(tid, lo, hi_all, &pb, &pe);
+            if (pe <= pb) { pump.skip_to(tid, lo, INT64_MAX, window_cols); pump.drop_tid_carry(); return pump.error() ? -1 : 0; }
+            if (pb > lo) pump.skip_to(tid, lo, pb, window_cols);
+            if (pump.error()) return -1;
+            lo = pb; hi_all = pe; stop = std::min(stop, pe);
+        }
         bool started = mode == 2;
-        int64_t cursor = started ? lo : std::max(lo, pump.next_pos(tid));
+        // (a block that starts inside the contig starts at its first column: carried reads may cover it)
+        int64_t cursor = (started || shard.on) ? lo : std::max(lo, pump.next_pos(tid));
         for (;;) {
             bool more = pump.next_pos(tid) != INT64_MAX;
             if (!more && !pump.has_carry()) break;
             if (!started && !pump.has_carry()) cursor = std::max(cursor, pump.next_pos(tid));
-            int64_t ce_target = cursor + window_cols;
-            if (has_reg) ce_target = std::min(ce_target, end0);
+            int64_t ce_target = std::min(cursor + window_cols, stop);
+            if (ce_target <= cursor) { pump.skip_to(tid, cursor, INT64_MAX, window_cols); pump.drop_tid_carry(); break; }
             WinJob *j = pipe->acquire();
-            if (ce_target <= cursor) { pump.fill_staged(tid, cursor, INT64_MAX, j->staged); pipe->release(j); pump.drop_tid_carry(); break; }
             int64_t ce;
             { const double t0 = WinPipe::now(); ce = pump.fill_staged(tid, cursor, ce_target, j->staged); pipe->add_fill_time(WinPipe::now() - t0); }
             if (pump.error()) { pipe->release(j); return -1; }
@@ -134,6 +153,13 @@ struct DRunner {
         const int all = p.all_pos;
         // with a region every -a/-aa run prints the whole region of tid0 (bam2depth.c:267-270)
         const int mode = has_reg ? (all ? 2 : 0) : (all >= 2 ? 2 : all);
+        shard = Shard::from_env();
+        if (shard.on) {
+            if (mode == 1) { fprintf(stderr, "samtools depth: a sharded run (STA_SHARD) supports no single -a: whether a contig is printed depends on every block; use -aa or no -a\n"); return 1; }
+            lin0.assign((size_t)h->nref() + 1, 0);
+            for (int t = 0; t < h->nref(); ++t) lin0[(size_t)t + 1] = lin0[(size_t)t] + h->lens[(size_t)t];
+            shard.set_total(has_reg ? std::max<int64_t>(0, std::min(end0, h->lens[(size_t)tid0]) - beg0) : lin0[(size_t)h->nref()]);
+        }
         int next_full = 0; bool did_tid0 = false;
         for (;;) {
             int tid = pump.next_tid();
@@ -236,7 +262,7 @@ extern "C" int sta_main_depth(int argc, char **argv)
         run.out = fopen(out_file.c_str(), "w");
         if (!run.out) { fprintf(stderr, "samtools depth: Cannot open \"%s\" for writing.\n", out_file.c_str()); return 1; }
     }
-    if (header) {
+    if (header && Shard::from_env().rank == 0) {          // (a sharded run: the header line belongs to the first block)
         fprintf(run.out, "#CHROM\tPOS");
         for (auto &fn : fns) fprintf(run.out, "\t%s", fn.c_str());
         fputc('\n', run.out);

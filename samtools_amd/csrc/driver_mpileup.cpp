@@ -12,6 +12,7 @@
 #include "host_chunk.h"
 #include "host_bgzf.h"
 #include "driver_pipeline.h"
+#include "driver_shard.h"
 #include <getopt.h>
 #include <ctime>
 #include <cstdio>
@@ -76,6 +77,8 @@ struct Runner {
     int loaded_ref_tid = -2;
     int64_t loaded_ref_len = INT64_MAX;               // length of the FASTA contig (INT64_MAX: none, no length filter)
     int dev_ref_tid = -2;                             // contig whose sequence is in HBM; device thread only
+    Shard shard;                                      // STA_SHARD=rank/world: this rank's block of the columns (driver_shard.h)
+    std::vector<int64_t> lin0;                        // linear coordinate of every contig's first column (no region)
 
     explicit Runner(Conf &c) : conf(c) {}
 
@@ -132,9 +135,16 @@ struct Runner {
         return 0;
     }
 
+    // the part of [lo, hi) of contig tid this rank prints (everything without STA_SHARD)
+    void owned(int tid, int64_t lo, int64_t hi, int64_t *pb, int64_t *pe) const
+    {
+        shard.clip(!shard.on ? 0 : (has_reg ? -beg0 : lin0[(size_t)tid]), lo, hi, pb, pe);
+    }
+
     // zero-depth rows for [a,b) of a contig (print_empty_pileup), produced by read-less windows
     int run_empty(int tid, int64_t a, int64_t b)
     {
+        owned(tid, a, b, &a, &b);
         while (a < b) {
             int64_t e = std::min(b, a + conf.window_cols);
             WinJob *j = pipe->acquire();
@@ -155,21 +165,31 @@ struct Runner {
         host_ref(tid);                               // tells the pump's lookahead the FASTA length of this contig
         int64_t lo = has_reg ? beg0 : 0;
         int64_t hi_all = has_reg ? std::min(end0, tlen) : tlen;
+        int64_t stop = has_reg ? end0 : INT64_MAX;       // no window reaches beyond this column
+        if (shard.on) {
+            // this rank's part of the contig: walk up to it with the pump's own bookkeeping (no staging, no device), so that the
+            // first window inherits exactly the reads the unsharded run carries there
+            int64_t pb, pe;
+            owned(tid, lo, hi_all, &pb, &pe);
+            if (pe <= pb) { pump.skip_to(tid, lo, INT64_MAX, conf.window_cols); pump.drop_tid_carry(); return pump.error() ? -1 : 0; }
+            if (pb > lo) pump.skip_to(tid, lo, pb, conf.window_cols);
+            if (pump.error()) return -1;
+            lo = pb; hi_all = pe; stop = std::min(stop, pe);
+        }
         bool started = mode == 2;
-        int64_t cursor = started ? lo : std::max(lo, pump.next_pos(tid));
+        // (a block that starts inside the contig starts at its first column: carried reads may cover it)
+        int64_t cursor = (started || shard.on) ? lo : std::max(lo, pump.next_pos(tid));
         for (;;) {
             bool more = pump.next_pos(tid) != INT64_MAX;
             if (!more && !pump.has_carry()) break;
             if (!started) cursor = std::max(cursor, std::min(pump.carry_next_covered(cursor), pump.next_pos(tid)));   // skip uncovered gap
-            int64_t ce_target = cursor + conf.window_cols;
-            if (has_reg) ce_target = std::min(ce_target, end0);
-            WinJob *j = pipe->acquire();
-            if (ce_target <= cursor) {              // past the region end: drain the rest of this contig
-                pump.fill_staged(tid, cursor, INT64_MAX, j->staged);
-                pipe->release(j);
+            int64_t ce_target = std::min(cursor + conf.window_cols, stop);
+            if (ce_target <= cursor) {              // past the region / block end: pass over the rest of this contig
+                pump.skip_to(tid, cursor, INT64_MAX, conf.window_cols);
                 pump.drop_tid_carry();
                 break;
             }
+            WinJob *j = pipe->acquire();
             int64_t ce;
             { const double t0 = WinPipe::now(); ce = pump.fill_staged(tid, cursor, ce_target, j->staged); pipe->add_fill_time(WinPipe::now() - t0); }
             if (pump.error()) { pipe->release(j); return -1; }
@@ -182,6 +202,12 @@ struct Runner {
                 j->tid = tid; j->cb = cursor; j->ce = ce; j->have_reads = true; j->hold = false;
                 // the next window depends on this one's result only if the -d cap can drop reads here (they leave the pump)
                 const bool lockstep = cap_may_trigger(j->staged, conf.p.max_depth);
+                if (lockstep && shard.on) {
+                    pipe->release(j);
+                    fprintf(stderr, "samtools mpileup: the -d depth cap can trigger near %s:%lld, which couples this block to its predecessors; run unsharded or raise -d\n",
+                            h->names[(size_t)tid].c_str(), (long long)cursor + 1);
+                    return -1;
+                }
                 bool waited = false;
                 if (mode == 1 && !started) {
                     // -a: nothing of this contig is printed before its first data column is known
@@ -254,6 +280,13 @@ struct Runner {
         WindowSource &pump = *src;
         const int all = conf.p.all;
         const int mode = all >= 2 ? 2 : all;
+        shard = Shard::from_env();
+        if (shard.on) {
+            if (mode == 1) { fprintf(stderr, "samtools mpileup: a sharded run (STA_SHARD) supports no single -a: whether a contig is printed depends on every block; use -aa or no -a\n"); return 1; }
+            lin0.assign((size_t)h->nref() + 1, 0);
+            for (int t = 0; t < h->nref(); ++t) lin0[(size_t)t + 1] = lin0[(size_t)t] + h->lens[(size_t)t];
+            shard.set_total(has_reg ? std::max<int64_t>(0, std::min(end0, h->lens[(size_t)tid0]) - beg0) : lin0[(size_t)h->nref()]);
+        }
         int next_full = 0;               // -aa without region: contigs below this index are done
         bool did_tid0 = false;
         for (;;) {

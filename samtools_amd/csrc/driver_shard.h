@@ -1,0 +1,60 @@
+// driver_shard.h -- a rank's block of reference columns in a sharded run of `mpileup` / `depth`.
+//
+// STA_SHARD=rank/world restricts the driver to one contiguous block of the linear coordinate space it would otherwise print:
+// the -r region if there is one, else all contigs of the header laid end to end.  Blocks are equal (`n * rank / world`, the
+// rule of samtools_amd/shard.py block_of) unless STA_SHARD_CUTS="c1,c2,..." (world - 1 increasing cut coordinates; tests
+// sweep them through mate overlaps).  The concatenation of the ranks' outputs in rank order is the unsharded output: a rank
+// walks the input up to its block with the pump's own window bookkeeping (WindowSource::skip_to), so the reads it carries
+// into its first window -- spanning reads, overlap mates -- are exactly those the unsharded run carries there, and windows
+// never depend on where they are cut.  The reference's precedent for splitting by position is the region job loop of
+// bam_consensus.c:2759-2810 and the region iterators of bam_plcmd.c:550.  State that crosses blocks is refused instead of
+// approximated: `-a` (one -a prints a contig only once it has shown data somewhere) and a -d cap that can actually trigger.
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace sta {
+
+struct Shard {
+    bool on = false; int rank = 0, world = 1;
+    std::vector<int64_t> cuts;           // world - 1 cut coordinates (optional)
+    int64_t B = 0, E = INT64_MAX;        // this rank's block in linear coordinates, set by set_total()
+
+    static Shard from_env()
+    {
+        Shard s;
+        const char *e = getenv("STA_SHARD");
+        if (!e || !*e) return s;
+        int r = 0, w = 0;
+        if (sscanf(e, "%d/%d", &r, &w) != 2 || w < 1 || r < 0 || r >= w) return s;
+        s.on = w > 1; s.rank = r; s.world = w;
+        if (const char *c = getenv("STA_SHARD_CUTS")) {
+            while (*c) { char *q; long long v = strtoll(c, &q, 10); if (q == c) break; s.cuts.push_back(v); c = *q == ',' ? q + 1 : q; }
+            if ((int)s.cuts.size() != w - 1) s.cuts.clear();
+        }
+        return s;
+    }
+    void set_total(int64_t total)
+    {
+        if (!on) { B = 0; E = INT64_MAX; return; }
+        if (!cuts.empty()) { B = rank ? cuts[(size_t)rank - 1] : 0; E = rank + 1 < world ? cuts[(size_t)rank] : total; }
+        else { B = (int64_t)((__int128)total * rank / world); E = (int64_t)((__int128)total * (rank + 1) / world); }
+        if (B < 0) B = 0;
+        if (E > total) E = total;
+        if (E < B) E = B;
+    }
+    // the part of columns [a, b) of a contig that this rank owns; col0_lin = linear coordinate of the contig's column 0
+    // (cumulative contig lengths without a region; -region_begin with one, so that the region's first column is linear 0)
+    void clip(int64_t col0_lin, int64_t a, int64_t b, int64_t *pb, int64_t *pe) const
+    {
+        if (!on) { *pb = a; *pe = b; return; }
+        const int64_t cb = B - col0_lin, ce = E - col0_lin;
+        *pb = a > cb ? a : cb;
+        *pe = b < ce ? b : ce;
+        if (*pe < *pb) *pe = *pb;
+    }
+};
+
+}  // namespace sta

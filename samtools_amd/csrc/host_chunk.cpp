@@ -204,7 +204,7 @@ int64_t ChunkPump::carry_max_end() const
     return m;
 }
 
-int64_t ChunkPump::fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged)
+int64_t ChunkPump::fill_window(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> *staged_out)
 {
     int64_t ce = ce_target;
     auto take = [](File &f) {
@@ -244,6 +244,8 @@ int64_t ChunkPump::fill_staged(int tid, int64_t cb, int64_t ce_target, std::vect
             }
         }
     }
+    if (!staged_out) { for (auto &f : f_) f.n_carry_staged = f.carry.size(); return ce; }
+    std::vector<StagedFile> &staged = *staged_out;
     staged.resize(f_.size());
     for (size_t fi = 0; fi < f_.size(); ++fi) {
         File &f = f_[fi];

@@ -69,7 +69,8 @@ public:
     bool has_carry() const override;
     int64_t carry_next_covered(int64_t cursor) const override;
     int64_t carry_max_end() const override;
-    int64_t fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged) override;
+    int64_t fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged) override { return fill_window(tid, cb, ce_target, &staged); }
+    int64_t fill_unstaged(int tid, int64_t cb, int64_t ce_target) override { return fill_window(tid, cb, ce_target, nullptr); }
     bool staged_has_span(size_t f, size_t i) const override;
     void drop(size_t f, const std::vector<char> &dropped) override;
     void retire(int64_t ce) override;
@@ -91,6 +92,7 @@ private:
     PumpConfig cfg_;
     std::vector<File> f_;
     int err_ = 0; std::string errtxt_;
+    int64_t fill_window(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> *staged);     // staged == nullptr: bookkeeping only
     bool settle(File &f);                                 // positions f.cur/f.idx on the next usable record; false at end
     int64_t span_end(const Chunk &c, int64_t i) const { return cfg_.use_endpos ? c.endpos(i) : c.end(i); }
     int64_t span_end(const Rec &r) const { return cfg_.use_endpos ? r.endpos() : r.end(); }

@@ -49,6 +49,21 @@ public:
     // consume the records of `tid` starting before ce_target (the read cap may cut the window short) and stage them,
     // carried reads first, relative to cb; returns the actual window end
     virtual int64_t fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged) = 0;
+    // the same window bookkeeping without building the staging arrays: lets a driver pass over columns it does not own
+    // (a rank of a sharded run walking up to its block) with exactly the carry state the unsharded run would have there
+    virtual int64_t fill_unstaged(int tid, int64_t cb, int64_t ce_target) = 0;
+    // consume everything of `tid` before `pos` in steps of `step` columns (fill_unstaged + retire); returns pos
+    int64_t skip_to(int tid, int64_t from, int64_t pos, int64_t step)
+    {
+        int64_t cur = from;
+        while (cur < pos && !error()) {
+            if (next_pos(tid) == INT64_MAX && !has_carry()) break;
+            int64_t ce = fill_unstaged(tid, cur, pos - cur > step ? cur + step : pos);
+            retire(ce);
+            cur = ce > cur ? ce : cur + 1;
+        }
+        return pos;
+    }
     virtual bool staged_has_span(size_t f, size_t i) const = 0;      // reference span > 0 of the i-th staged read of file f
     virtual void drop(size_t f, const std::vector<char> &dropped) = 0;
     virtual void retire(int64_t ce) = 0;
@@ -73,6 +88,7 @@ public:
     int64_t fill(int tid, int64_t cb, int64_t ce_target, std::vector<std::vector<const Rec *>> &reads);
     // After the window [cb, ce) was processed: keep only reads that extend beyond ce.
     int64_t fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged) override;
+    int64_t fill_unstaged(int tid, int64_t cb, int64_t ce_target) override { return fill(tid, cb, ce_target, last_); }
     bool staged_has_span(size_t f, size_t i) const override { return f < last_.size() && i < last_[f].size() && last_[f][i]->rlen > 0; }
     void retire(int64_t ce) override;
     // before retire(): reads of file f (indexed as fill() returned them) that the -d cap dropped in this window leave the

@@ -1,0 +1,107 @@
+"""The product drivers sharded over reference columns: every rank runs sta_main_mpileup /
+sta_main_depth restricted to its block (STA_SHARD=rank/world) and the concatenation of the ranks' text in rank order must be the
+unsharded output, byte for byte -- with the block cuts swept through mate overlaps, long ref skips, contig boundaries and
+regions.  Part 1 runs the ranks one after the other (the cuts are what is under test); part 2 is the real thing: two processes
+on the one GPU of the test box under torch.distributed.run (gloo), text gathered by samtools_amd.shard.  -m gpu."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from synth import write_synth_sam
+from synth_rich import write_rich_sam
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(product_bin, args, env=None):
+    p = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    return p.stdout
+
+
+def _sharded(product_bin, args, world, cuts=None, env=None):
+    out = b""
+    for r in range(world):
+        e = dict(env or {}, STA_SHARD="%d/%d" % (r, world))
+        if cuts is not None:
+            e["STA_SHARD_CUTS"] = ",".join(str(c) for c in cuts)
+        out += _run(product_bin, args, e)
+    return out
+
+
+@pytest.fixture(scope="module")
+def pairs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("shard_pairs")
+    return write_synth_sam(str(d), n_ref=60000, depth=30, read_len=150, seed=23, paired=True, indel_rate=0.1, max_indel=7)
+
+
+@pytest.fixture(scope="module")
+def rich(tmp_path_factory):
+    d = tmp_path_factory.mktemp("shard_rich")
+    return write_rich_sam(str(d), seed=11, n_templates=6000)
+
+
+@pytest.mark.parametrize("cmd", [["mpileup", "-f", "{fa}"], ["mpileup", "-E", "-A", "-f", "{fa}"], ["mpileup", "-B", "-aa", "-f", "{fa}"], ["mpileup", "-x", "-B"],
+                                 ["depth"], ["depth", "-aa"], ["depth", "-s", "-J", "-q", "20"]], ids=lambda c: "_".join(x for x in c if not x.startswith("{")))
+def test_equal_blocks_reassemble_the_unsharded_output(product_bin, pairs, cmd):
+    sam, fa = pairs
+    args = [a.format(fa=fa) for a in cmd] + [sam]
+    want = _run(product_bin, args)
+    assert len(want) > 100000
+    for world in (2, 3, 8):
+        assert _sharded(product_bin, args, world) == want, "world %d" % world
+    # small windows inside the blocks as well
+    assert _sharded(product_bin, args, 3, env={"STA_WINDOW_COLS": "7000"}) == want
+
+
+def test_cuts_swept_through_mate_overlaps(product_bin, pairs):
+    """every cut position in a stretch of 400 columns (pairs overlap there in every phase), overlap resolution + BAQ on"""
+    sam, fa = pairs
+    args = ["mpileup", "-f", fa, sam]
+    want = _run(product_bin, args)
+    for cut in list(range(30000, 30400, 7)) + [1, 149, 150, 59999]:
+        assert _sharded(product_bin, args, 2, cuts=[cut]) == want, "cut %d" % cut
+
+
+@pytest.mark.parametrize("cmd", [["mpileup", "-f", "{fa}"], ["mpileup", "-aa", "-B", "-f", "{fa}"], ["depth", "-aa"], ["depth"]],
+                         ids=lambda c: "_".join(x for x in c if not x.startswith("{")))
+def test_messy_multi_contig_input(product_bin, rich, cmd):
+    """several contigs, long ref skips, clips, pads, every flag: blocks cut inside and between contigs"""
+    sam, fa = rich
+    args = [a.format(fa=fa) for a in cmd] + [sam]
+    want = _run(product_bin, args)
+    for world in (2, 5):
+        assert _sharded(product_bin, args, world) == want
+    for cuts in ([29999], [30000], [30001], [39000], [38999, 39001], [100, 83990]):
+        assert _sharded(product_bin, args, len(cuts) + 1, cuts=cuts) == want, cuts
+    # a region is its own coordinate space
+    rargs = args[:-1] + ["-r", "c3:5000-30000", sam]
+    rwant = _run(product_bin, rargs)
+    for world in (2, 3):
+        assert _sharded(product_bin, rargs, world) == rwant
+
+
+def test_state_that_crosses_blocks_is_refused(product_bin, pairs):
+    sam, fa = pairs
+    for args, msg in ((["mpileup", "-a", "-f", fa, sam], b"single -a"), (["depth", "-a", sam], b"single -a"), (["mpileup", "-d", "10", "-B", sam], b"depth cap")):
+        p = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, STA_SHARD="1/2"))
+        assert p.returncode != 0 and msg in p.stderr, (args, p.stderr[-200:])
+
+
+@pytest.mark.parametrize("cmd", [["mpileup", "-f", "{fa}"], ["depth", "-aa"]], ids=["mpileup", "depth"])
+def test_two_processes_one_gather(tmp_path, product_bin, pairs, cmd):
+    """python -m torch.distributed.run --nproc-per-node 2 -m samtools_amd.shard <command>: one process per rank (both on the
+    box's single GPU), text collected on rank 0 by the variable-size gather."""
+    sam, fa = pairs
+    args = [a.format(fa=fa) for a in cmd] + [sam]
+    want = _run(product_bin, args)
+    outp = str(tmp_path / "sharded.txt")
+    env = dict(os.environ, STA_SHARD_BACKEND="gloo", STA_SHARD_ONE_DEVICE="1", PYTHONPATH=REPO)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533" if cmd[0] == "mpileup" else "29534", "-m", "samtools_amd.shard"] + args + ["-o", outp],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=REPO)
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    assert open(outp, "rb").read() == want

@@ -15,6 +15,7 @@
  *   sam_prob_realn (BAQ)           bam_plcmd.c:451        STA_MPLP_REALN / STA_MPLP_REDO_BAQ
  *   sam_cap_mapq (-C)              bam_plcmd.c:453-457    sta_mplp_params.capQ_thres
  *   --output-extra tags / RNEXT    bam_plcmd.c:779-852    sta_reads.xcol_* + sta_mplp_params.n_tags
+ *   --output-mods (MM / ML)        bam_plcmd.c:86-109,356 sta_reads.mod_* + STA_MPLP_OUTPUT_MODS
  *   mpileup() column loop+format   bam_plcmd.c:607-868    sta_mpileup_emit / sta_mpileup_run (text on device)
  *   pileup_seq                     bam_plcmd.c:54-169     sta_mpileup_emit
  *   print_empty_pileup             bam_plcmd.c:372-398    sta_mpileup_emit with params.all
@@ -70,6 +71,7 @@ extern "C" {
 #define STA_MPLP_PRINT_RNEXT     (1 << 19)   /* text comes from sta_reads.xcol_* column 0 */
 #define STA_MPLP_PRINT_PNEXT     (1 << 20)
 #define STA_MPLP_PRINT_RLEN      (1 << 24)
+#define STA_MPLP_OUTPUT_MODS     (1 << 25)   /* -M / --output-mods: sta_reads.mod_* carries the text */
 #define STA_MPLP_PRINT_QPOS5     (1 << 26)
 
 /* per-read aux summary bits (sta_reads.aux) computed while decoding */
@@ -121,6 +123,15 @@ typedef struct sta_reads {
     const uint32_t *xcol_off;    /* n_reads * n_xcols + 1 */
     const char *xcol_text;
     uint64_t n_xcol_bytes;
+    /* optional base modifications for --output-mods (bam_plcmd.c:86-109 prints what HTSlib's bam_mods_at_qpos returns; here the
+     * MM / ML tags are evaluated on the host while staging): for every modified base of every read the text pileup_seq appends,
+     * e.g. "[+m128-h7]".  Entries of read i: mod_off[i] .. mod_off[i+1], sorted by mod_qpos (query position); text of entry e:
+     * mod_text[mod_toff[e] .. mod_toff[e+1]).  mod_off == NULL: none. */
+    const uint32_t *mod_off;     /* n_reads + 1 */
+    const uint32_t *mod_qpos;    /* n_mod_entries */
+    const uint32_t *mod_toff;    /* n_mod_entries + 1 */
+    const char *mod_text;
+    uint64_t n_mod_entries, n_mod_bytes;
 } sta_reads;
 
 /* One window of reference columns on one contig, with every read (of every
@@ -154,6 +165,7 @@ typedef struct sta_mplp_params {
     int32_t n_tags;              /* aux-tag columns after the fixed extra columns (text staged in sta_reads.xcol_*) */
     int32_t tag_sep;             /* --output-sep character between the entries of a tag column (',' by default) */
     int32_t min_qlen;            /* coverage -l: drop reads whose bam_cigar2qlen is smaller (0 = off) */
+    int32_t no_ins_mods;         /* --no-output-ins-mods: no modification text inside inserted sequences */
 } sta_mplp_params;
 
 /* subset of depth_opt (bam2depth.c:72-86) */

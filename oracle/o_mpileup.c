@@ -6,7 +6,7 @@
  * :400-461, mpileup :470-934, bam_mpileup option table :1075-1272, plus
  * sample.c:79-122 (sample counting for the mandatory stderr line).
  * Pinned by test/mpileup/mpileup.reg goldens (see tests/test_oracle_goldens.py).
- * Not supported (documented): -M/--output-mods (needs HTSlib MM/ML parser),
+ * -M/--output-mods: o_mods.c restates HTSlib's MM/ML parser (pinned on mp2.out / mp2-noins.out).  Not supported (documented):
  * CRAM input.
  */
 #include "o_plp.h"
@@ -168,11 +168,12 @@ static int mplp_func(void *data, orec_t *b)
 static inline int tolower_c(int c) { return (c >= 'A' && c <= 'Z') ? c + 32 : c; }
 static inline int toupper_c(int c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
 
-/* bam_plcmd.c:54-169 (base-mod branches omitted) */
+/* bam_plcmd.c:54-169; m = the read's base modifications with --output-mods (o_mods.c), else NULL */
 static int pileup_seq(ostr_t *ks_seq, const opileup1_t *p, hpos_t pos, hpos_t ref_len, const char *ref,
-                      ostr_t *ks_mod, int rev_del, int no_ins, int no_del, int no_ends)
+                      ostr_t *ks_mod, int rev_del, int no_ins, int no_ins_mods, int no_del, int no_ends, const omods_t *m)
 {
     int j;
+    no_ins_mods |= no_ins;
     if (!no_ends && p->is_head) {
         os_putc(ks_seq, '^');
         os_putc(ks_seq, p->b->mapq > 93 ? 126 : p->b->mapq + 33);
@@ -187,22 +188,31 @@ static int pileup_seq(ostr_t *ks_seq, const opileup1_t *p, hpos_t pos, hpos_t re
         }
         c = rec_is_rev(p->b) ? seq_nt_str_lc[c] : seq_nt_str_uc[c];
         os_putc(ks_seq, c);
+        if (m) omods_put(m, p->qpos, ks_seq);
     } else {
         os_putc(ks_seq, p->is_refskip ? (rec_is_rev(p->b) ? '<' : '>')
                                       : ((rec_is_rev(p->b) && rev_del) ? '#' : '*'));
     }
     int del_len = -p->indel;
     if (p->indel > 0) {
-        int len = oplp_insertion(p, ks_mod, &del_len);
+        int len = oplp_insertion_mod(p, m && !no_ins_mods ? m : NULL, ks_mod, &del_len);
         if (len < 0) return -1;
         if (no_ins < 2) { os_putc(ks_seq, '+'); os_putll(ks_seq, len); }
         if (!no_ins) {
+            int in_mod = 0;
             if (rec_is_rev(p->b)) {
                 char pad = rev_del ? '#' : '*';
-                for (j = 0; j < (int)ks_mod->l; j++)
-                    os_putc(ks_seq, ks_mod->s[j] != '*' ? tolower_c(ks_mod->s[j]) : pad);
+                for (j = 0; j < (int)ks_mod->l; j++) {
+                    if (ks_mod->s[j] == '[') in_mod = 1;
+                    else if (ks_mod->s[j] == ']') in_mod = 0;
+                    os_putc(ks_seq, ks_mod->s[j] != '*' ? (in_mod ? ks_mod->s[j] : tolower_c(ks_mod->s[j])) : pad);
+                }
             } else {
-                for (j = 0; j < (int)ks_mod->l; j++) os_putc(ks_seq, toupper_c(ks_mod->s[j]));
+                for (j = 0; j < (int)ks_mod->l; j++) {
+                    if (ks_mod->s[j] == '[') in_mod = 1;
+                    if (ks_mod->s[j] == ']') in_mod = 0;
+                    os_putc(ks_seq, in_mod ? ks_mod->s[j] : toupper_c(ks_mod->s[j]));
+                }
             }
         }
     }
@@ -409,7 +419,10 @@ static int mpileup(mplp_conf_t *conf, int nfn, char **fn)
                 const opileup1_t *p = plp[i] + j;
                 int c = p->qpos < p->b->l_qseq ? p->b->qual[p->qpos] : 0;
                 if (c >= conf->min_baseQ) {
-                    pileup_seq(&ks_seq, p, pos, ref_len, ref, &ks_mod, conf->rev_del, conf->no_ins, conf->no_del, conf->no_ends);
+                    omods_t mods; const omods_t *mp = NULL;
+                    if (conf->flag & MPLP_PRINT_MODS) { omods_parse(p->b, &mods); mp = &mods; }      /* (bam_plcmd.c:356-362 parses once per read; the result is the same) */
+                    pileup_seq(&ks_seq, p, pos, ref_len, ref, &ks_mod, conf->rev_del, conf->no_ins, conf->no_ins_mods, conf->no_del, conf->no_ends, mp);
+                    if (mp) omods_free(&mods);
                     os_putc(&ks_qual, c + 33 < 126 ? c + 33 : 126);
                     cnt++;
                 }
@@ -671,7 +684,7 @@ int o_main_mpileup(int argc, char *argv[])
         case 's': mplp.flag |= MPLP_PRINT_MAPQ_CHAR; break;
         case 'O': mplp.flag |= MPLP_PRINT_QPOS; break;
         case 14: mplp.flag |= MPLP_PRINT_QPOS5; break;
-        case 'M': fprintf(stderr, "oracle: -M/--output-mods not supported\n"); return 1;
+        case 'M': mplp.flag |= MPLP_PRINT_MODS; break;
         case 'C': mplp.capQ_thres = atoi(optarg); break;
         case 'q': mplp.min_mq = atoi(optarg); break;
         case 'Q': mplp.min_baseQ = atoi(optarg); break;

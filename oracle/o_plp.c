@@ -343,7 +343,9 @@ static int resolve_cigar2(opileup1_t *p, hpos_t pos, cstate_t *s)
 }
 
 /* bam_plp_insertion (Appendix A.2, last paragraph) */
-int oplp_insertion(const opileup1_t *p, ostr_t *ins, int *del_len)
+int oplp_insertion(const opileup1_t *p, ostr_t *ins, int *del_len) { return oplp_insertion_mod(p, NULL, ins, del_len); }
+
+int oplp_insertion_mod(const opileup1_t *p, const omods_t *m, ostr_t *ins, int *del_len)
 {
     int j, k, indel;
     os_clear(ins);
@@ -368,6 +370,7 @@ int oplp_insertion(const opileup1_t *p, ostr_t *ins, int *del_len)
             for (int c = 0; c < l; ++c, ++j) {
                 int qi = p->qpos + j - p->is_del;
                 os_putc(ins, qi < p->b->l_qseq ? nt16_str[rec_seqi(p->b->seq, qi)] : 'N');
+                if (m) omods_put(m, qi, ins);
             }
         } else break;
         k++;

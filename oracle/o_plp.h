@@ -47,4 +47,13 @@ int oplp_insertion(const opileup1_t *p, ostr_t *ins, int *del_len);
 /* realn.c / probaln.c restatement (o_baq.c) */
 int o_prob_realn(orec_t *b, const char *ref, hpos_t ref_len, int flag);
 
+/* ---- base modifications (o_mods.c): MM / ML tags of one record, grouped by query position ---- */
+typedef struct { int code; int strand; int qual; } omod1_t;     /* code: letter, or -ChEBI number; qual -1 = no ML value */
+typedef struct { int n, l; int *start; omod1_t *ent; } omods_t; /* start[q] .. start[q+1]: entries of query position q */
+int omods_parse(const orec_t *b, omods_t *m);
+void omods_free(omods_t *m);
+void omods_put(const omods_t *m, int qpos, ostr_t *out);
+/* bam_plp_insertion_mod: the inserted sequence with the modifications of every inserted base (m may be NULL) */
+int oplp_insertion_mod(const opileup1_t *p, const omods_t *m, ostr_t *ins, int *del_len);
+
 #endif

@@ -47,6 +47,8 @@ class Reads(C.Structure):
         ("seq", C.c_void_p), ("qual", C.c_void_p), ("bq", C.c_void_p), ("names", C.c_void_p),
         ("n_cigar_total", C.c_uint64), ("n_bases_total", C.c_uint64), ("n_name_bytes", C.c_uint64),
         ("n_xcols", C.c_int32), ("xcol_off", C.c_void_p), ("xcol_text", C.c_void_p), ("n_xcol_bytes", C.c_uint64),
+        ("mod_off", C.c_void_p), ("mod_qpos", C.c_void_p), ("mod_toff", C.c_void_p), ("mod_text", C.c_void_p),
+        ("n_mod_entries", C.c_uint64), ("n_mod_bytes", C.c_uint64),
     ]
 
 
@@ -65,14 +67,14 @@ class MplpParams(C.Structure):
         ("min_mq", C.c_int32), ("min_baseQ", C.c_int32), ("capQ_thres", C.c_int32), ("max_depth", C.c_int32),
         ("all", C.c_int32), ("rev_del", C.c_int32), ("rflag_require", C.c_int32), ("rflag_filter", C.c_int32),
         ("flag", C.c_int32), ("no_ins", C.c_int32), ("no_del", C.c_int32), ("no_ends", C.c_int32),
-        ("has_fai", C.c_int32), ("n_tags", C.c_int32), ("tag_sep", C.c_int32), ("min_qlen", C.c_int32),
+        ("has_fai", C.c_int32), ("n_tags", C.c_int32), ("tag_sep", C.c_int32), ("min_qlen", C.c_int32), ("no_ins_mods", C.c_int32),
     ]
 
     @classmethod
     def defaults(cls):
         """bam_mpileup() defaults (bam_plcmd.c:1083-1094)."""
         return cls(min_mq=0, min_baseQ=13, capQ_thres=0, max_depth=8000, all=0, rev_del=0, rflag_require=0,
-                   rflag_filter=4 | 256 | 512 | 1024, flag=MPLP.DEFAULT, no_ins=0, no_del=0, no_ends=0, has_fai=0, n_tags=0, tag_sep=ord(','), min_qlen=0)
+                   rflag_filter=4 | 256 | 512 | 1024, flag=MPLP.DEFAULT, no_ins=0, no_del=0, no_ends=0, has_fai=0, n_tags=0, tag_sep=ord(','), min_qlen=0, no_ins_mods=0)
 
 
 class DepthParams(C.Structure):

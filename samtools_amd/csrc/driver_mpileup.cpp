@@ -272,8 +272,9 @@ struct Runner {
         // (--output-extra tags / RNEXT, -G) or STA_IO_LANE=rec asks for the record-at-a-time lane
         pc.rg_excl = conf.has_rg_excl ? &conf.rg_excl : nullptr;
         pc.xs_rnext = (conf.p.flag & STA_MPLP_PRINT_RNEXT) != 0; pc.xs_n_tags = (int)conf.tags.size(); pc.xs_empty = conf.empty;
+        pc.xs_mods = (conf.p.flag & STA_MPLP_OUTPUT_MODS) != 0;          // MM / ML are evaluated per record while staging (host_mods.cpp)
         const char *lane = getenv("STA_IO_LANE");
-        const bool chunked = !pc.rg_excl && !pc.xs_rnext && !pc.xs_n_tags && !(lane && !strcmp(lane, "rec"));
+        const bool chunked = !pc.rg_excl && !pc.xs_rnext && !pc.xs_n_tags && !pc.xs_mods && !(lane && !strcmp(lane, "rec"));
         std::unique_ptr<WindowSource> src;
         if (chunked) src.reset(new ChunkPump(readers, pc, io_threads_per_input((int)readers.size())));
         else src.reset(new Pump(readers, pc));
@@ -317,7 +318,7 @@ struct Runner {
 void usage(FILE *fp)
 {
     fprintf(fp, "\nUsage: samtools mpileup [options] in1.bam [in2.bam [...]]\n"
-                "(MI355X engine; options as samtools 1.23.1 mpileup except -M, -X and CRAM input)\n");
+                "(MI355X engine; options as samtools 1.23.1 mpileup except -X and CRAM input)\n");
 }
 
 }  // namespace
@@ -398,7 +399,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
         case 8: conf.sep = optarg[0]; break;
         case 9: conf.empty = optarg[0]; break;
         case 10: mp.no_ins++; break;
-        case 11: break;
+        case 11: mp.no_ins_mods = 1; break;
         case 12: mp.no_del++; break;
         case 13: mp.no_ends = 1; break;
         case 'f':
@@ -420,7 +421,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
         case 's': mp.flag |= STA_MPLP_PRINT_MAPQ_CHAR; break;
         case 'O': mp.flag |= STA_MPLP_PRINT_QPOS; break;
         case 14: mp.flag |= STA_MPLP_PRINT_QPOS5; break;
-        case 'M': fprintf(stderr, "samtools mpileup: -M/--output-mods is not supported by the MI355X engine\n"); return 1;
+        case 'M': mp.flag |= STA_MPLP_OUTPUT_MODS; break;
         case 'C': mp.capQ_thres = atoi(optarg); break;
         case 'q': mp.min_mq = atoi(optarg); break;
         case 'Q': mp.min_baseQ = atoi(optarg); break;

@@ -30,13 +30,13 @@ struct DevBuf {
 
 struct FileBufs {
     // staged input copies (only used with STA_MEM_HOST)
-    DevBuf pos, flag, mapq, aux, lq, cig_off, base_off8, mtid, mpos, isize, name_off, cigar, seq, qual, bq, names, xoff, xtext;
+    DevBuf pos, flag, mapq, aux, lq, cig_off, base_off8, mtid, mpos, isize, name_off, cigar, seq, qual, bq, names, xoff, xtext, moff, mqpos, mtoff, mtext;
     // workspace
     DevBuf qual_work, end, maxend, info, clip, chain, fix_y, fix_mate, fix_q;
     void release()
     {
         DevBuf *all[] = { &pos, &flag, &mapq, &aux, &lq, &cig_off, &base_off8, &mtid, &mpos, &isize, &name_off, &cigar,
-                          &seq, &qual, &bq, &names, &xoff, &xtext, &qual_work, &end, &maxend, &info, &clip, &chain, &fix_y, &fix_mate, &fix_q };
+                          &seq, &qual, &bq, &names, &xoff, &xtext, &moff, &mqpos, &mtoff, &mtext, &qual_work, &end, &maxend, &info, &clip, &chain, &fix_y, &fix_mate, &fix_q };
         for (DevBuf *b : all) b->release();
     }
 };
@@ -243,6 +243,13 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
         if (d.n_xcols) {
             rc |= upload(e, b.xoff, r.xcol_off, n * (size_t)d.n_xcols + 1, &d.xcol_off, mem);
             rc |= upload(e, b.xtext, r.xcol_text, (size_t)r.n_xcol_bytes, &d.xcol_text, mem);
+        }
+        d.mod_off = nullptr; d.mod_qpos = nullptr; d.mod_toff = nullptr; d.mod_text = nullptr;
+        if (r.mod_off && r.mod_toff) {
+            rc |= upload(e, b.moff, r.mod_off, n + 1, &d.mod_off, mem);
+            rc |= upload(e, b.mqpos, r.mod_qpos, (size_t)r.n_mod_entries, &d.mod_qpos, mem);
+            rc |= upload(e, b.mtoff, r.mod_toff, (size_t)r.n_mod_entries + 1, &d.mod_toff, mem);
+            rc |= upload(e, b.mtext, r.mod_text, (size_t)r.n_mod_bytes, &d.mod_text, mem);
         }
         if (rc) return rc;
         // workspace

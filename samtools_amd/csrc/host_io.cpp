@@ -226,7 +226,7 @@ static int parse_sam(const Header &h, std::string &line, Rec &r, const std::vect
     r.qual.resize(l);
     if (fl[10] == 1 && f[10][0] == '*') std::fill(r.qual.begin(), r.qual.end(), 0xff);
     else { if (fl[10] != l) return -2; for (size_t i = 0; i < l; ++i) r.qual[i] = (uint8_t)(f[10][i] - 33); }
-    r.has_bq = r.has_zq = false; r.bq.clear(); r.rg.clear();
+    r.has_bq = r.has_zq = false; r.bq.clear(); r.rg.clear(); r.mm.clear(); r.ml.clear(); r.has_ml = false;
     if (want) { r.tagtext.assign(want->size(), std::string()); r.tag_has.assign(want->size(), 0); }
     while (aux < e) {
         char *t = (char *)memchr(aux, '\t', (size_t)(e - aux));
@@ -238,6 +238,13 @@ static int parse_sam(const Header &h, std::string &line, Rec &r, const std::vect
             if (aux[0] == 'R' && aux[1] == 'G') r.rg.assign(aux + 5, n - 5);
             else if (aux[0] == 'B' && aux[1] == 'Q') { r.has_bq = true; r.bq.assign(aux + 5, aux + n); }
             else if (aux[0] == 'Z' && aux[1] == 'Q') r.has_zq = true;
+            else if (aux[0] == 'M' && (aux[1] == 'M' || aux[1] == 'm')) r.mm.assign(aux + 5, n - 5);
+        }
+        if (n >= 7 && aux[2] == ':' && aux[3] == 'B' && aux[4] == ':' && aux[0] == 'M' && (aux[1] == 'L' || aux[1] == 'l') && (aux[5] == 'C' || aux[5] == 'c')) {
+            // ML:B:C,v,v,...
+            r.has_ml = true;
+            const char *q = aux + 6, *qe = aux + n;
+            while (q < qe) { if (*q == ',') { ++q; continue; } char *nx; long v = strtol(q, &nx, 10); if (nx == q) break; r.ml.push_back((uint8_t)v); q = nx; }
         }
         if (!t) break;
         aux = t + 1;
@@ -300,7 +307,7 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
     r.seq.assign(b + o, b + o + ((size_t)l_seq + 1) / 2); o += ((size_t)l_seq + 1) / 2;
     r.qual.assign(b + o, b + o + (size_t)l_seq); o += (size_t)l_seq;
     r.tid = refID; r.pos = pos; r.flag = flag; r.mtid = nref; r.mpos = npos; r.isize = tlen; r.l_qseq = l_seq;
-    r.has_bq = r.has_zq = false; r.bq.clear(); r.rg.clear();
+    r.has_bq = r.has_zq = false; r.bq.clear(); r.rg.clear(); r.mm.clear(); r.ml.clear(); r.has_ml = false;
     const uint8_t *p = b + o, *e = b + bs;
     const bool want = !wanted.empty();
     if (want) { r.tagtext.assign(wanted.size(), std::string()); r.tag_has.assign(wanted.size(), 0); }
@@ -319,6 +326,7 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
             if (!sz || (uint64_t)sz * cnt > (uint64_t)(e - p - 5)) return -2;
             vlen = 5 + (size_t)sz * cnt;
             if (tag[0] == 'C' && tag[1] == 'G' && p[0] == 'I') { cg = p + 5; cg_n = cnt; }
+            if (tag[0] == 'M' && (tag[1] == 'L' || tag[1] == 'l') && sz == 1) { r.has_ml = true; r.ml.assign(p + 5, p + 5 + cnt); }
         } else {
             int sz = aux_size(t);
             if (!sz || p + sz > e) return -2;
@@ -346,6 +354,7 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
             if (tag[0] == 'R' && tag[1] == 'G') r.rg.assign((const char *)p, vlen - 1);
             else if (tag[0] == 'B' && tag[1] == 'Q') { r.has_bq = true; r.bq.assign(p, p + vlen - 1); }
             else if (tag[0] == 'Z' && tag[1] == 'Q') r.has_zq = true;
+            else if (tag[0] == 'M' && (tag[1] == 'M' || tag[1] == 'm')) r.mm.assign((const char *)p, vlen - 1);
         }
         p += vlen;
     }

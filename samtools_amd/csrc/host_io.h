@@ -34,6 +34,8 @@ struct Rec {
     std::vector<uint8_t> bq;     // BQ:Z bytes (empty if absent)
     bool has_bq = false, has_zq = false;
     std::string rg;              // RG:Z value ("" if absent)
+    std::string mm;              // MM:Z / Mm:Z base-modification list ("" if absent) and its ML / Ml probabilities (--output-mods)
+    std::vector<uint8_t> ml; bool has_ml = false;
     // --output-extra aux tags: text of every wanted tag as mpileup prints it (bam_plcmd.c:811-850); tag_has[i] = 0 if absent
     std::vector<std::string> tagtext;
     std::vector<char> tag_has;

@@ -120,9 +120,9 @@ int64_t Pump::fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<St
     int64_t ce = fill(tid, cb, ce_target, last_);
     staged.resize(rd_.size());
     for (size_t f = 0; f < rd_.size(); ++f) {
-        XcolSpec xs; xs.rnext = cfg_.xs_rnext; xs.hdr = &rd_[f]->header(); xs.n_tags = cfg_.xs_n_tags; xs.empty = cfg_.xs_empty;
+        XcolSpec xs; xs.rnext = cfg_.xs_rnext; xs.hdr = &rd_[f]->header(); xs.n_tags = cfg_.xs_n_tags; xs.empty = cfg_.xs_empty; xs.mods = cfg_.xs_mods;
         staged[f].clear();
-        for (const Rec *r : last_[f]) staged[f].add(*r, cb, cfg_.rg_excl, xs.n_cols() ? &xs : nullptr);
+        for (const Rec *r : last_[f]) staged[f].add(*r, cb, cfg_.rg_excl, (xs.n_cols() || xs.mods) ? &xs : nullptr);
         staged[f].finish();
     }
     return ce;

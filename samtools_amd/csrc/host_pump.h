@@ -30,7 +30,7 @@ struct PumpConfig {
     bool keep_mates = false;
     // staging options of fill_staged(): -G read groups to mark STA_AUX_SKIP, --output-extra columns formatted on the host
     const std::set<std::string> *rg_excl = nullptr;
-    bool xs_rnext = false; int xs_n_tags = 0; char xs_empty = '*';
+    bool xs_rnext = false; int xs_n_tags = 0; char xs_empty = '*'; bool xs_mods = false;
     // contigs of the header the driver prints from (the first input's): a record of any input naming a later one is an error
     // instead of an out-of-range name / length lookup
     int nref_limit = INT32_MAX;

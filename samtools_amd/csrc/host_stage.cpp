@@ -12,6 +12,7 @@ void StagedFile::clear()
     cig_off.clear(); base_off8.clear(); name_off.clear(); cigar.clear(); mpos.clear();
     seq.clear(); qual.clear(); bq.clear(); names.clear();
     xcol_off.clear(); xcol_text.clear(); n_xcols = 0;
+    mod_off.clear(); mod_qpos.clear(); mod_toff.clear(); mod_text.clear(); with_mods = false;
     any_bq = false;
 }
 
@@ -29,6 +30,11 @@ void StagedFile::add(const Rec &r, int64_t origin, const std::set<std::string> *
             if ((size_t)t < r.tag_has.size() && r.tag_has[(size_t)t]) xcol_text.insert(xcol_text.end(), r.tagtext[(size_t)t].begin(), r.tagtext[(size_t)t].end());
             else xcol_text.push_back(xs->empty);
         }
+    }
+    if (xs && xs->mods) {
+        with_mods = true;
+        mod_off.push_back((uint32_t)mod_qpos.size());
+        format_base_mods(r, mod_qpos, mod_toff, mod_text);
     }
     pos.push_back((int32_t)(r.pos - origin));
     flag.push_back(r.flag);
@@ -104,6 +110,7 @@ void StagedFile::finish()
     cig_off.push_back((uint32_t)cigar.size());
     name_off.push_back((uint32_t)names.size());
     if (n_xcols) xcol_off.push_back((uint32_t)xcol_text.size());
+    if (with_mods) { mod_off.push_back((uint32_t)mod_qpos.size()); mod_toff.push_back((uint32_t)mod_text.size()); }
 }
 
 sta_reads StagedFile::view() const
@@ -117,6 +124,10 @@ sta_reads StagedFile::view() const
     v.bq = any_bq ? bq.data() : nullptr; v.names = names.data();
     v.n_cigar_total = cigar.size(); v.n_bases_total = qual.size(); v.n_name_bytes = names.size();
     if (n_xcols) { v.n_xcols = n_xcols; v.xcol_off = xcol_off.data(); v.xcol_text = xcol_text.data(); v.n_xcol_bytes = xcol_text.size(); }
+    if (with_mods && mod_off.size() == pos.size() + 1) {
+        v.mod_off = mod_off.data(); v.mod_qpos = mod_qpos.data(); v.mod_toff = mod_toff.data(); v.mod_text = mod_text.data();
+        v.n_mod_entries = mod_qpos.size(); v.n_mod_bytes = mod_text.size();
+    }
     return v;
 }
 

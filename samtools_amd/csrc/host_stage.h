@@ -15,10 +15,13 @@ struct XcolSpec {
     const Header *hdr = nullptr;     // contig names for RNEXT
     int n_tags = 0;
     char empty = '*';                // --output-empty: printed for a read without the tag
+    bool mods = false;               // --output-mods: stage the bracketed modification text of every modified base
     int n_cols() const { return (rnext ? 1 : 0) + n_tags; }
 };
 
 struct Chunk;       // host_chunk.h
+// appends the modified bases of one record (host_mods.cpp): query position, offset of its "[+m128]" text, the text
+void format_base_mods(const Rec &r, pvector<uint32_t> &qpos, pvector<uint32_t> &toff, pvector<char> &text);
 
 struct StagedFile {
     // page-locked (host_pinned.h): sta_stage_window copies straight out of these
@@ -30,6 +33,8 @@ struct StagedFile {
     pvector<uint8_t> seq, qual, bq;
     pvector<char> names;
     pvector<uint32_t> xcol_off; pvector<char> xcol_text; int n_xcols = 0;
+    // --output-mods (host_mods.cpp): entries of read i = mod_off[i] .. mod_off[i+1], sorted by query position
+    pvector<uint32_t> mod_off, mod_qpos, mod_toff; pvector<char> mod_text; bool with_mods = false;
     bool any_bq = false;
     void clear();
     // origin: absolute coordinate of relative 0; rg_excl: -G read groups to drop (may be null)

@@ -24,6 +24,7 @@
 struct MplpDevPar {
     int32_t min_baseQ, all, rev_del, flag, no_ins, no_del, no_ends;
     int32_t n_tags, tag_sep;
+    int32_t mods, no_ins_mods;       // --output-mods: append StaReadsDev.mod_* text to modified bases (and to inserted ones unless no_ins_mods)
     int64_t tlen;
 };
 #define TAGKIND (1 << 28)       // file_pass "kind" of tag column t is TAGKIND + t
@@ -124,6 +125,21 @@ __device__ __forceinline__ Resolved resolve_general(const uint32_t *cig, int n, 
     return r;
 }
 
+// --output-mods: the text HTSlib's bam_mods_at_qpos yields for query position qpos of read r ("[+m128]"), staged by the host
+// (host_mods.cpp); returns its length (0: the base is not modified) and where it starts
+__device__ __forceinline__ int mod_text_at(const StaReadsDev &R, int64_t r, int qpos, uint32_t &t0)
+{
+    if (!R.mod_off) return 0;
+    uint32_t lo = R.mod_off[r], hi = R.mod_off[r + 1];
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t q = R.mod_qpos[mid];
+        if (q == (uint32_t)qpos) { t0 = R.mod_toff[mid]; return (int)(R.mod_toff[mid + 1] - t0); }
+        if (q < (uint32_t)qpos) lo = mid + 1; else hi = mid;
+    }
+    return 0;
+}
+
 // bam_plp_insertion: total length (I+P run after op k) and the D that may follow it
 __device__ __forceinline__ void insertion_shape(const uint32_t *cig, int n, int k, int &ins_total, int &del_after)
 {
@@ -149,6 +165,8 @@ __device__ __forceinline__ int token_len(const StaReadsDev &R, const MplpDevPar 
 {
     int len = 1;
     if (!P.no_ends) len += (p == e.rpos ? 2 : 0) + (p == e.rend - 1 ? 1 : 0);
+    uint32_t mt0;
+    if (P.mods && !e.rs.is_del) len += mod_text_at(R, e.r, e.rs.qpos, mt0);
     if (e.rs.indel != 0) {
         int del_len = -e.rs.indel;
         if (e.rs.indel > 0) {
@@ -157,7 +175,18 @@ __device__ __forceinline__ int token_len(const StaReadsDev &R, const MplpDevPar 
             int ins_total;
             insertion_shape(cig, n, e.rs.k, ins_total, del_len);
             if (P.no_ins < 2) len += 1 + dec_digits_u32((uint32_t)ins_total);
-            if (!P.no_ins) len += ins_total;
+            if (!P.no_ins) {
+                len += ins_total;
+                if (P.mods && !P.no_ins_mods) {
+                    // modification text of the inserted bases (bam_plp_insertion_mod)
+                    int j = 1;
+                    for (int kk = e.rs.k + 1; kk < n; ++kk) {
+                        int o = cig[kk] & 0xf, l = (int)(cig[kk] >> 4);
+                        if (o == CG_I) { for (int t = 0; t < l; ++t, ++j) len += mod_text_at(R, e.r, e.rs.qpos + j - (e.rs.is_del ? 1 : 0), mt0); }
+                        else if (o != CG_P) break;
+                    }
+                }
+            }
         }
         if (del_len > 0) {
             if (P.no_del < 2) len += 1 + dec_digits_u32((uint32_t)del_len);
@@ -184,6 +213,7 @@ __device__ __forceinline__ void token_write(const StaReadsDev &R, const StaWinDe
             if (c == rb) c = 0;
         }
         s.put(rev ? c_nt_lc[c] : c_nt_uc[c]);
+        if (P.mods) { uint32_t t0; const int ml = mod_text_at(R, e.r, e.rs.qpos, t0); for (int t = 0; t < ml; ++t) s.put(R.mod_text[t0 + t]); }
     } else {
         s.put(e.rs.is_refskip ? (rev ? '<' : '>') : ((rev && P.rev_del) ? '#' : '*'));
     }
@@ -206,6 +236,7 @@ __device__ __forceinline__ void token_write(const StaReadsDev &R, const StaWinDe
                             int qi = e.rs.qpos + j - (e.rs.is_del ? 1 : 0);
                             char ch = qi < e.lq ? c_nt16_str[seq_nib(R.seq, e.boff >> 1, qi)] : 'N';
                             s.put(rev ? lower_c(ch) : upper_c(ch));
+                            if (P.mods && !P.no_ins_mods) { uint32_t t0; const int ml = mod_text_at(R, e.r, qi, t0); for (int t2 = 0; t2 < ml; ++t2) s.put(R.mod_text[t0 + t2]); }
                         }
                     } else break;
                 }
@@ -734,6 +765,7 @@ static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
     d.min_baseQ = p.min_baseQ; d.all = p.all; d.rev_del = p.rev_del; d.flag = p.flag;
     d.no_ins = p.no_ins; d.no_del = p.no_del; d.no_ends = p.no_ends; d.tlen = tlen;
     d.n_tags = p.n_tags > 0 ? p.n_tags : 0; d.tag_sep = p.tag_sep ? p.tag_sep : ',';
+    d.mods = (p.flag & STA_MPLP_OUTPUT_MODS) ? 1 : 0; d.no_ins_mods = (p.no_ins_mods || p.no_ins) ? 1 : 0;
     return d;
 }
 
@@ -742,7 +774,7 @@ void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_param
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
     int64_t nb = (ncols + 255) / 256;
-    if (!((uint32_t)p.flag & EXTRA_MASK) && p.n_tags <= 0 && colinfo) {
+    if (sta_mplp_has_fast_path(p) && colinfo) {
         hipLaunchKernelGGL(k_mplp_len_fast, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, colinfo, ctr);
         return;
     }
@@ -759,7 +791,7 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
     int wpb = 4 * slice <= 65536 ? 4 : (2 * slice <= 65536 ? 2 : 1);
     int64_t nwaves = (ncols + 63) / 64;
     int64_t nb = (nwaves + wpb - 1) / wpb;
-    if (!((uint32_t)p.flag & EXTRA_MASK) && p.n_tags <= 0 && colinfo) {
+    if (sta_mplp_has_fast_path(p) && colinfo) {
         uint32_t fslice = (lds_cap + 48 + 15) & ~15u;      // must match k_mplp_emit_fast
         int fw = 4 * fslice <= 65536 ? 4 : (2 * fslice <= 65536 ? 2 : 1);
         int64_t fnb = (nwaves + fw - 1) / fw;
@@ -770,4 +802,4 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
 }
 
 // no --output-extra / -O / -s columns: the window takes the fast kernel pair
-bool sta_mplp_has_fast_path(const sta_mplp_params &p) { return !((uint32_t)p.flag & EXTRA_MASK) && p.n_tags <= 0; }
+bool sta_mplp_has_fast_path(const sta_mplp_params &p) { return !((uint32_t)p.flag & (EXTRA_MASK | STA_MPLP_OUTPUT_MODS)) && p.n_tags <= 0; }

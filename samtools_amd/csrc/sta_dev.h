@@ -38,6 +38,7 @@ struct StaReadsDev {
     const char *names;
     uint64_t n_bases_total;
     int32_t n_xcols; const uint32_t *xcol_off; const char *xcol_text;     // host-formatted text columns (RNEXT, aux tags)
+    const uint32_t *mod_off, *mod_qpos, *mod_toff; const char *mod_text;  // --output-mods: per-read modification text (NULL: none)
     // engine workspace
     uint8_t *qual;        // working qualities (== qual_in when nothing rewrites them)
     int32_t *end;         // pos + reference span

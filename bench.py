@@ -208,11 +208,13 @@ def collect_pmc(a, kernels):
     return out or None
 
 
-KNAME = {"baq_fwd": "void k_baq_fwd<7>", "baq_bwd": "void k_baq_bwd<7>", "mplp_emit": "k_mplp_emit_fast", "mplp_len": "k_mplp_len_fast",
-         "mplp_fused": "k_mplp_fused", "depth_emit": "k_depth_emit", "depth_len": "k_depth_len", "depth_count": "k_depth_count",
+# engine kernel label -> prefix of the rocprofv3 kernel name
+KNAME = {"baq_fwd": "void k_baq_fwd<7", "baq_bwd": "void k_baq_bwd<7", "mplp_emit": "k_mplp_emit_fast", "mplp_len": "k_mplp_len_fast",
          "depth_fused": "k_depth_fused", "glf_cols": "k_glf_cols"}
-# gfx950: FETCH_SIZE tallies a 16-byte-per-lane streaming read at half its bytes (MI355X_MICROARCH.md, HBM); these kernels read that way
-FETCH_X2 = {"baq_bwd"}
+# gfx950: FETCH_SIZE tallies a 16-byte-per-lane streaming read at half its bytes (MI355X_MICROARCH.md, HBM).  k_baq_bwd reads two
+# thirds of its forward-row stream that way (the (M, I) pairs of the odd rows) and one third as 8-byte loads: the raw counter is
+# reported, and roofline.dram_util gives the stream the kernel must move by construction
+FETCH_X2 = set()
 
 
 def main():
@@ -380,7 +382,8 @@ def main():
                     break
 
         def traffic_of(name):
-            ent = (pmc or {}).get(KNAME.get(name, name))
+            pre = KNAME.get(name, name)
+            ent = next((v for k, v in (pmc or {}).items() if k.startswith(pre)), None)
             if not ent or "FETCH_SIZE" not in ent or "WRITE_SIZE" not in ent:
                 return None
             return (ent["FETCH_SIZE"] * (2.0 if name in FETCH_X2 else 1.0) + ent["WRITE_SIZE"]) * 1024.0

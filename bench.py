@@ -125,7 +125,7 @@ def slice_reads(np, rd, lo, hi, origin):
     return out
 
 
-def oracle_text_hash(wl, n_cols, seed_ref=1, seed_reads=42, save_to=None, inputs=None):
+def oracle_text_hash(wl, n_cols, seed_ref=1, seed_reads=42, save_to=None, inputs=None, chunk_cols=None):
     """The checker: the oracle's text for the synthetic window (same generator, same seeds) -> sha256, bytes, wall time.
     inputs: optional dict from synth_inputs() so that several workloads of one shape share the generated reads and SAM text."""
     kind, depth, _, _, argv = WORKLOADS[wl]
@@ -134,7 +134,7 @@ def oracle_text_hash(wl, n_cols, seed_ref=1, seed_reads=42, save_to=None, inputs
         return None
     own = inputs is None
     if own:
-        inputs = synth_inputs(depth, n_cols, seed_ref, seed_reads)
+        inputs = synth_inputs(depth, n_cols, seed_ref, seed_reads, chunk_cols)
     try:
         rd = inputs["rd"]
         args = [a.format(sam=inputs["sam"], fa=inputs["fa"]) for a in argv]
@@ -161,11 +161,12 @@ def oracle_text_hash(wl, n_cols, seed_ref=1, seed_reads=42, save_to=None, inputs
             shutil.rmtree(inputs["dir"], ignore_errors=True)
 
 
-def synth_inputs(depth, n_cols, seed_ref=1, seed_reads=42):
-    """bench.py's synthetic window as numpy arrays AND as the SAM / FASTA files the oracle reads (caller removes ['dir'])."""
-    from synth import synth_ref, synth_reads, write_sam, write_fasta
+def synth_inputs(depth, n_cols, seed_ref=1, seed_reads=42, chunk_cols=None):
+    """bench.py's synthetic window as numpy arrays AND as the SAM / FASTA files the oracle reads (caller removes ['dir']).
+    chunk_cols: the per-GPU window of a sharded run (the input is then assembled from pieces, tests/synth.py synth_chunked)."""
+    from synth import synth_ref, synth_chunked, write_sam, write_fasta
     ref = synth_ref(n_cols, seed=seed_ref)
-    rd = synth_reads(ref, depth=depth, read_len=150, seed=seed_reads)
+    rd = synth_chunked(ref, chunk_cols or n_cols, depth=depth, read_len=150, seed=seed_reads)
     d = tempfile.mkdtemp(prefix="sta_bench_")
     sam, fa = os.path.join(d, "s.sam"), os.path.join(d, "s.fa")
     write_sam(sam, rd, "chrS", n_cols)
@@ -222,7 +223,7 @@ def main():
     import numpy as np
     import torch
     import samtools_amd as sa
-    from synth import synth_ref, synth_reads
+    from synth import synth_ref, synth_chunked
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -247,9 +248,10 @@ def main():
     cols_per_gpu = a.cols or def_cols
     n_cols = cols_per_gpu * world
     from samtools_amd import shard
-    # ONE input for the whole job (same seeds on every rank); rank r owns columns [blk_beg, blk_end)
+    # ONE input for the whole job, the same on every rank: piece k = the reads starting in the k-th window of cols_per_gpu columns
+    # (seed 42 + k; they reach into the next window).  Rank r owns columns [blk_beg, blk_end) and only builds the pieces around them.
     ref = synth_ref(n_cols, seed=1)
-    rd_all = synth_reads(ref, depth=depth, read_len=150, seed=42)
+    rd_all = synth_chunked(ref, cols_per_gpu, depth=depth, read_len=150, seed=42, chunks=(rank - 1, rank, rank + 1))
     blk_beg, blk_end = shard.block_of(rank, world, n_cols)
     if world > 1:
         # reads that can touch the block plus the mate halo (reads starting up to 2 x the longest span before it)
@@ -442,7 +444,7 @@ def main():
         res["output_sha256"] = timed_sha
         if kind in ("mpileup", "depth") and a.verify:
             # the timed window itself, byte for byte (hash of the whole text) against the oracle on the same seeds
-            o = oracle_text_hash(a.workload, n_cols)
+            o = oracle_text_hash(a.workload, n_cols, chunk_cols=cols_per_gpu)
             res["verify"] = {"oracle_sha256": o["sha256"] if o else None, "identical": bool(o and o["sha256"] == timed_sha),
                              "bytes": o["bytes"] if o else None, "oracle_seconds": o["seconds"] if o else None}
             if not res["verify"]["identical"]:

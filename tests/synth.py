@@ -19,14 +19,17 @@ def synth_ref(n, seed=1):
 
 
 def synth_reads(ref, depth=30, read_len=150, seed=42, paired=False, sub_rate=0.001, indel_rate=0.005,
-                mapq=60, origin=0, max_indel=3):
+                mapq=60, origin=0, max_indel=3, start_span=None, n_reads=None):
     """Returns a dict with the sta_reads arrays for ONE file covering the whole of `ref`.
 
-    ref: uint8 array of ASCII bases (contig of length len(ref)); reads lie fully inside it."""
+    ref: uint8 array of ASCII bases (contig of length len(ref)); reads lie fully inside it.
+    start_span / n_reads (unpaired only): draw that many start positions from [0, start_span) instead of depth * len(ref) / L
+    of them from the whole of `ref` -- synth_chunked() builds long inputs out of such pieces."""
     rng = np.random.default_rng(seed)
     n_ref = len(ref)
     L = read_len
-    n_reads = max(1, int(depth * n_ref / L))
+    if n_reads is None:
+        n_reads = max(1, int(depth * n_ref / L))
     if paired:
         n_pairs = max(1, n_reads // 2)
         isz = np.maximum(np.rint(rng.normal(300, 30, n_pairs)).astype(np.int64), L)
@@ -42,7 +45,7 @@ def synth_reads(ref, depth=30, read_len=150, seed=42, paired=False, sub_rate=0.0
         pair_id = np.concatenate([np.arange(n_pairs), np.arange(n_pairs)])
         n_reads = 2 * n_pairs
     else:
-        pos = rng.integers(0, n_ref - L + 1, n_reads)
+        pos = rng.integers(0, n_ref - L + 1 if start_span is None else start_span, n_reads)
         flag = np.where(rng.integers(0, 2, n_reads) == 1, 16, 0).astype(np.uint16)
         mpos = np.full(n_reads, -1, dtype=np.int64)
         tlen = np.zeros(n_reads, dtype=np.int64)
@@ -152,3 +155,48 @@ def write_synth_sam(outdir, n_ref=20000, depth=20, read_len=100, seed=7, paired=
     write_sam(sam, rd, name, n_ref)
     write_fasta(fa, name, ref)
     return sam, fa
+
+
+_CONCAT = ("flag", "mapq", "aux", "l_qseq", "mtid", "mpos", "isize", "cigar", "seq", "qual", "names", "_bases", "_quals")
+
+
+def synth_chunked(ref, chunk_cols, depth=30, read_len=150, seed=42, chunks=None):
+    """ONE long sorted input assembled from pieces: piece k holds the reads STARTING in columns [k * chunk_cols, (k + 1) * chunk_cols)
+    (seed + k; they extend into the next piece's columns, so block cuts do split reads), generated independently so that a rank of
+    a sharded run only has to build the pieces around its block.  chunks = iterable of piece indices (None: all).  With one piece
+    covering the whole of `ref` the result is synth_reads(ref, seed=seed) itself.  Returns the merged dict (positions absolute)."""
+    n = len(ref)
+    L = read_len
+    n_chunks = (n + chunk_cols - 1) // chunk_cols
+    parts = []
+    for k in (range(n_chunks) if chunks is None else sorted(c for c in chunks if 0 <= c < n_chunks)):
+        c0 = k * chunk_cols
+        span = min(chunk_cols, n - L + 1 - c0)
+        if span <= 0:
+            continue
+        sub = ref[c0:min(n, c0 + span + L + 16)]
+        rd = synth_reads(sub, depth=depth, read_len=L, seed=seed + k, start_span=span,
+                         n_reads=max(1, int(depth * (n if n_chunks == 1 else min(chunk_cols, n - c0)) / L)))
+        rd["_abs_pos"] = rd["_abs_pos"] + c0
+        parts.append(rd)
+    if len(parts) == 1:
+        out = parts[0]
+        out["pos"] = out["_abs_pos"].astype(np.int32)
+        return out
+    out = {"n": sum(p["n"] for p in parts), "L": L}
+    for f in _CONCAT:
+        out[f] = np.concatenate([p[f] for p in parts])
+    out["_abs_pos"] = np.concatenate([p["_abs_pos"] for p in parts])
+    out["pos"] = out["_abs_pos"].astype(np.int32)
+    for f, pool, unit in (("cig_off", "cigar", 1), ("name_off", "names", 1)):
+        offs, base = [], 0
+        for p in parts:
+            offs.append(p[f][:-1].astype(np.int64) + base)
+            base += len(p[pool])
+        out[f] = np.concatenate(offs + [np.array([base], dtype=np.int64)]).astype(np.uint32)
+    offs, base = [], 0
+    for p in parts:
+        offs.append(p["base_off8"].astype(np.int64) + base)
+        base += len(p["qual"]) // 8
+    out["base_off8"] = np.concatenate(offs).astype(np.uint32)
+    return out

@@ -16,16 +16,18 @@ __device__ __forceinline__ bool cg_is_refop(int op) { return (0x18Du >> op) & 1;
 __device__ __forceinline__ bool cg_is_mop(int op) { return (0x181u >> op) & 1; }     // M = X
 __device__ __forceinline__ bool cg_is_qop(int op) { return op == CG_I || op == CG_S; }
 
-__device__ __forceinline__ int dec_digits(unsigned long long v)
-{
-    int n = 1;
-    while (v >= 10) { v /= 10; ++n; }
-    return n;
-}
 __device__ __forceinline__ int dec_digits_u32(uint32_t v)
 {
     return 1 + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u)
              + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
+}
+// (coordinates below 2^32 -- nearly always -- take the compare chain: a 64-bit divide per digit costs ~20 instructions)
+__device__ __forceinline__ int dec_digits(unsigned long long v)
+{
+    if (v <= 0xffffffffull) return dec_digits_u32((uint32_t)v);
+    int n = 1;
+    while (v >= 10) { v /= 10; ++n; }
+    return n;
 }
 
 // merged, sorted, disjoint intervals: does [beg,end) overlap any?  (bedidx.c:159-197 semantics)

@@ -931,7 +931,7 @@ static int depth_text(sta_engine *e, const sta_depth_params *p, char *out, uint6
         if (ncols > 0) {
             HIPCHK(hipMemsetAsync(&ctr->out_bytes, 0, 16, s));
             ProfScope ps(e, "depth_fused");
-            sta_launch_depth_fused(s, e->wd, *p, e->fused_status.p, (int32_t *)e->diff.p, out, cap, ctr, 4096);
+            sta_launch_depth_fused(s, e->wd, *p, e->fused_status.p, (int32_t *)e->diff.p, out, cap, ctr, 8192);
         }
         rc = fused_finish(e, info);
         if (rc) return rc;

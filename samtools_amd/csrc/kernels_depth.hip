@@ -28,7 +28,12 @@ template <bool LDS> struct DSink {
     __device__ __forceinline__ void put_dec(unsigned long long u)
     {
         int n = dec_digits(u);
-        if (LDS) { uint32_t e = cur + n; for (uint32_t q = e; q > cur;) { lds_dtext[--q] = (char)('0' + u % 10); u /= 10; } cur = e; }
+        if (LDS && u <= 0xffffffffull) {
+            uint32_t w = (uint32_t)u; const uint32_t e = cur + n;         // 32-bit digits: multiply-high + shift per digit
+            for (uint32_t q = e; q > cur;) { const uint32_t d = w / 10u; lds_dtext[--q] = (char)('0' + (w - d * 10u)); w = d; }
+            cur = e;
+        }
+        else if (LDS) { uint32_t e = cur + n; for (uint32_t q = e; q > cur;) { lds_dtext[--q] = (char)('0' + u % 10); u /= 10; } cur = e; }
         else { char *e = g + n; for (char *q = e; q > g;) { *--q = (char)('0' + u % 10); u /= 10; } g = e; }
     }
 };
@@ -49,35 +54,35 @@ __device__ __forceinline__ void depth_row_write(const StaWinDev &W, const int32_
 // ================================================================================================
 // Single-pass depth: per-column counts, row lengths, offsets (decoupled look-back, dev_lookback.h) and text in ONE launch.
 //
-// A workgroup takes one ticket for 4 x SUB x 64 consecutive columns (one wave per SUB x 64, walked as SUB sub-tiles
-// of 64 columns).  COUNT, per sub-tile: the reads that can touch it (contiguous index range, advanced from the previous
-// sub-tile's) are taken ONE LANE PER READ; every lane drops +1 / -1 difference marks for its read's counted runs into a
-// 65-entry LDS array (clipped to the sub-tile; a plain 150M read costs two LDS atomics), a wave scan turns the marks into the
-// 64 column counts.  That is O(reads) work per sub-tile instead of O(reads x 64 columns).  The counts go to `counts`
+// A workgroup takes one ticket for 4 x 512 consecutive columns; each of its waves owns 512 of them, EIGHT consecutive columns per
+// lane.  COUNT: the reads that can touch the wave's span (one contiguous index range) are taken ONE LANE PER READ; every lane drops
+// +1 / -1 difference marks for its read's counted runs into a 513-entry LDS array (clipped to the span; a plain 150M read costs two
+// LDS atomics); each lane then sums its eight entries and one wave scan turns the marks into the 512 column counts.  That is O(reads)
+// work instead of O(reads x columns / 64), and one memory round trip per phase for 512 columns.  The counts go to `counts`
 // ([nfiles + 1][ncols + 1] int32, last row = covering reads: sta_depth_counts_dev) and give the row lengths; ONE look-back per
-// workgroup places its text; EMIT re-reads the counts, formats the rows into the wave's LDS line buffer and flushes them.
-#define DF_SUB_DEFAULT 8
+// workgroup places its text; EMIT: every lane formats its eight rows back to back into the wave's LDS line buffer, 16-byte flush.
+#define DF_CPL 8                      // columns per lane
+#define DF_SPAN (64 * DF_CPL)         // columns per wave
 struct DepthFusedArgs {
     unsigned long long *status; unsigned int *ticket;
     char *out; unsigned long long capacity;
     int32_t *counts;
     StaCounters *ctr;
     uint32_t lbuf, per_wave, n_tiles;
-    int32_t sub;                          // sub-tiles of 64 columns per wave
     int32_t has_clip;
 };
 
 __device__ __forceinline__ void lds_mark(int *row, int a, int b, int p0)
 {
-    // [a, b) clipped to the sub-tile [p0, p0 + 64)
+    // [a, b) clipped to the wave's span [p0, p0 + DF_SPAN)
     a = a < p0 ? p0 : a;
-    b = b > p0 + 64 ? p0 + 64 : b;
+    b = b > p0 + DF_SPAN ? p0 + DF_SPAN : b;
     if (b <= a) return;
     atomicAdd(&row[a - p0], 1);
     atomicAdd(&row[b - p0], -1);
 }
 
-// difference marks of the reads [rlo, rhi) of file R for the sub-tile starting at p0 (bam2depth.c:396-424 rules: M/=/X counted
+// difference marks of the reads [rlo, rhi) of file R for the span starting at p0 (bam2depth.c:396-424 rules: M/=/X counted
 // under -q, D only with -J and judged by the quality of the next query base, N never; -s clips below `clip`)
 __device__ __forceinline__ void depth_marks(const StaReadsDev &R, const DepthDevPar &P, int has_clip, int p0, int plast,
                                             int64_t rlo, int64_t rhi, int *d_file, int *d_cover)
@@ -112,8 +117,8 @@ __device__ __forceinline__ void depth_marks(const StaReadsDev &R, const DepthDev
                 if (a < b) {
                     if (!P.min_qual) lds_mark(d_file, a, b, p0);
                     else {
-                        // run-length encode the passing bases inside the sub-tile
-                        const int32_t lo = a < p0 ? p0 : a, hi = b > p0 + 64 ? p0 + 64 : b;
+                        // run-length encode the passing bases inside the span
+                        const int32_t lo = a < p0 ? p0 : a, hi = b > p0 + DF_SPAN ? p0 + DF_SPAN : b;
                         int32_t run = -1;
                         for (int32_t x = lo; x < hi; ++x) {
                             const int q = spos + (x - i);
@@ -137,37 +142,31 @@ __device__ __forceinline__ void depth_read_range(const StaReadsDev &R, int p0, i
     rhi = wave_upper_bound(R.pos, R.n, p1);
     if (rlo > rhi) rlo = rhi;
 }
-// the next sub-tile's range from the previous one's: both bounds only move forward -- one coalesced 64-entry probe per bound
-// in the common case instead of two 64-ary searches of ~4 dependent loads each
-__device__ __forceinline__ void depth_read_range_next(const StaReadsDev &R, int p0, int p1, int64_t &rlo, int64_t &rhi, bool have_prev)
+
+__device__ __forceinline__ int wave_excl_scan_i32(int v, int &total)
 {
-    if (R.n == 0) { rlo = rhi = 0; return; }
-    if (!have_prev) { depth_read_range(R, p0, p1, rlo, rhi); return; }
     const int lane = threadIdx.x & 63;
-    bool found = false;
-    for (int it = 0; it < 3 && !found; ++it) {
-        const int64_t idx = rlo + lane;
-        const unsigned long long m = __ballot(idx < R.n ? R.maxend[idx] > p0 : true);
-        if (m) { rlo += __ffsll((long long)m) - 1; found = true; } else rlo += 64;
-    }
-    if (!found) rlo = wave_upper_bound(R.maxend, R.n, p0);
-    if (rlo > R.n) rlo = R.n;
-    found = false;
-    for (int it = 0; it < 3 && !found; ++it) {
-        const int64_t idx = rhi + lane;
-        const unsigned long long m = __ballot(idx < R.n ? R.pos[idx] > p1 : true);
-        if (m) { rhi += __ffsll((long long)m) - 1; found = true; } else rhi += 64;
-    }
-    if (!found) rhi = wave_upper_bound(R.pos, R.n, p1);
-    if (rhi > R.n) rhi = R.n;
-    if (rlo > rhi) rlo = rhi;
+    int x = v;
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+    total = __builtin_amdgcn_readlane(x, 63);
+    return x - v;
 }
 
-__device__ __forceinline__ int wave_incl_scan_i32(int v)
+// marks -> counts for the lane's DF_CPL consecutive columns (entries d[DF_CPL * lane ..]); written to the counts row
+__device__ __forceinline__ void depth_counts_from_marks(const int *d, int32_t *row, int64_t c0, int64_t ncols)
 {
     const int lane = threadIdx.x & 63;
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(v, o); if (lane >= o) v += y; }
-    return v;
+    int v[DF_CPL], sum = 0;
+#pragma unroll
+    for (int k = 0; k < DF_CPL; ++k) { v[k] = d[DF_CPL * lane + k]; sum += v[k]; }
+    int tot;
+    int run = wave_excl_scan_i32(sum, tot);
+#pragma unroll
+    for (int k = 0; k < DF_CPL; ++k) {
+        run += v[k];
+        const int64_t col = c0 + DF_CPL * lane + k;
+        if (col < ncols) row[col] = run;
+    }
 }
 
 // row length of column `col` from the stored counts (0: the row is not printed); `covered` = some read spans the column
@@ -189,50 +188,55 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
     __shared__ unsigned int s_tile;
     __shared__ unsigned long long s_wtot[4][2];
     __shared__ unsigned long long s_base[2];
-    __shared__ int s_diff[4][2][66];
+    __shared__ int s_diff[4][2][DF_SPAN + 4];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) s_tile = atomicAdd(A.ticket, 1u);          // tiles are handed out in start order (dev_lookback.h)
     __syncthreads();
     const unsigned int tile = s_tile;
     const int64_t ncols = (int64_t)W.col_end - W.col_beg;
-    const int64_t w0 = ((int64_t)tile * 4 + wid) * ((int64_t)A.sub * 64);    // this wave's first column
+    const int64_t c0 = ((int64_t)tile * 4 + wid) * DF_SPAN;          // this wave's first column
+    const bool wave_on = c0 < ncols;
     const uint32_t lb = (uint32_t)wid * A.per_wave;
     int *d_file = s_diff[wid][0], *d_cover = s_diff[wid][1];
 
-    // ---- COUNT: A.sub sub-tiles of 64 columns ----
-    unsigned long long wave_total = 0, n_rows = 0, n_cov = 0;
-    int64_t rlo1 = 0, rhi1 = 0; bool have_range = false;
-    for (int sub = 0; sub < A.sub; ++sub) {
-        const int64_t c0 = w0 + (int64_t)sub * 64;
-        if (c0 >= ncols) break;
+    // ---- COUNT ----
+    uint32_t len[DF_CPL]; uint32_t lane_len = 0;
+    unsigned long long n_rows = 0, n_cov = 0;
+#pragma unroll
+    for (int k = 0; k < DF_CPL; ++k) len[k] = 0;
+    if (wave_on) {
         const int p0 = W.col_beg + (int)c0;
-        const bool active = c0 + lane < ncols;
-        const int plast = p0 + 63 < W.col_end ? p0 + 63 : W.col_end - 1;
-        const int64_t col = c0 + lane;
-        d_cover[lane] = 0; if (lane == 0) d_cover[64] = 0;
+        const int plast = c0 + DF_SPAN < ncols ? p0 + DF_SPAN - 1 : W.col_end - 1;
+#pragma unroll
+        for (int k = 0; k < DF_CPL; ++k) d_cover[DF_CPL * lane + k] = 0;
+        if (lane == 0) d_cover[DF_SPAN] = 0;
         for (int f = 0; f < W.nfiles; ++f) {
             const StaReadsDev &R = W.files[f];
             int64_t rlo, rhi;
-            if (W.nfiles == 1) { depth_read_range_next(R, p0, plast, rlo1, rhi1, have_range); have_range = true; rlo = rlo1; rhi = rhi1; }
-            else depth_read_range(R, p0, plast, rlo, rhi);
-            d_file[lane] = 0; if (lane == 0) d_file[64] = 0;
+            depth_read_range(R, p0, plast, rlo, rhi);
+#pragma unroll
+            for (int k = 0; k < DF_CPL; ++k) d_file[DF_CPL * lane + k] = 0;
+            if (lane == 0) d_file[DF_SPAN] = 0;
             wave_lds_sync();
             depth_marks(R, P, A.has_clip, p0, plast, rlo, rhi, d_file, d_cover);
             wave_lds_sync();
-            const int cnt = wave_incl_scan_i32(d_file[lane]);
-            if (active) A.counts[(int64_t)f * (ncols + 1) + col] = cnt;
+            depth_counts_from_marks(d_file, A.counts + (int64_t)f * (ncols + 1), c0, ncols);
+            wave_lds_sync();                                         // d_file is zeroed again for the next file
         }
-        const int cover = wave_incl_scan_i32(d_cover[lane]);
-        if (active) A.counts[(int64_t)W.nfiles * (ncols + 1) + col] = cover;
-        wave_lds_sync();                                             // d_cover is zeroed again by the next sub-tile
-        bool covered;
-        const uint32_t len = depth_row_len(W, P, A.counts, ncols, col, active, covered);
-        unsigned long long t = len;
-        t = wave_sum_u64(t);
-        wave_total += t;
-        n_rows += (unsigned long long)__popcll(__ballot(len > 0));
-        n_cov += (unsigned long long)__popcll(__ballot(covered));
+        depth_counts_from_marks(d_cover, A.counts + (int64_t)W.nfiles * (ncols + 1), c0, ncols);
+#pragma unroll
+        for (int k = 0; k < DF_CPL; ++k) {
+            const int64_t col = c0 + DF_CPL * lane + k;
+            bool covered;
+            len[k] = depth_row_len(W, P, A.counts, ncols, col, col < ncols, covered);
+            lane_len += len[k];
+            n_rows += len[k] > 0; n_cov += covered;
+        }
     }
+    int wave_total_i;
+    const uint32_t lane_off = (uint32_t)wave_excl_scan_i32((int)lane_len, wave_total_i);
+    const uint32_t wave_total = (uint32_t)wave_total_i;
+    n_rows = wave_sum_u64(n_rows); n_cov = wave_sum_u64(n_cov);
     if (lane == 0) { s_wtot[wid][0] = wave_total; s_wtot[wid][1] = (n_rows << 31) | n_cov; }
     __syncthreads();
     if (wid == 0) {
@@ -252,63 +256,53 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
     __syncthreads();
     const unsigned long long wg_off = s_base[0], wg_bytes = s_base[1];
     if (wg_off + wg_bytes > A.capacity) { if (threadIdx.x == 0) A.ctr->overflow = 1; return; }     // counted, not written: the host retries with room
-    if (wave_total == 0) return;
+    if (!wave_on || wave_total == 0) return;
     unsigned long long off = wg_off;
     for (int w = 0; w < wid; ++w) off += s_wtot[w][0];
 
-    // ---- EMIT: rows of each sub-tile into the wave's LDS line buffer, flushed with 16-byte stores ----
-    for (int sub = 0; sub < A.sub; ++sub) {
-        const int64_t c0 = w0 + (int64_t)sub * 64;
-        if (c0 >= ncols) break;
-        const bool active = c0 + lane < ncols;
-        const int64_t col = c0 + lane;
-        bool covered;
-        const uint32_t len = depth_row_len(W, P, A.counts, ncols, col, active, covered);
-        uint32_t incl = len;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-        const uint32_t excl = incl - len;
-        const uint32_t sub_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        int a = 0;
-        while (a < 64 && sub_total) {
-            // rounds of consecutive rows that fit the line buffer (many input files make rows long)
-            const uint32_t start = (uint32_t)__shfl((int)excl, a);
-            const bool fits = lane >= a && incl - start <= A.lbuf;
-            const int nb = __popcll(__ballot(fits));
-            if (nb == 0) {
-                if (lane == a && len) { DSink<false> s; s.cur = 0; s.g = A.out + off + excl; depth_row_write<false>(W, A.counts, ncols, col, s); }
-                a += 1;
-                continue;
+    // ---- EMIT: every lane writes its rows back to back; rounds of consecutive lanes that fit the line buffer ----
+    const uint32_t lane_incl = lane_off + lane_len;
+    int a = 0;
+    while (a < 64) {
+        const uint32_t start = (uint32_t)__shfl((int)lane_off, a);
+        const bool fits = lane >= a && lane_incl - start <= A.lbuf;
+        const int nb = __popcll(__ballot(fits));
+        if (nb == 0) {
+            // one lane's rows alone exceed the buffer (hundreds of input files): straight to global memory
+            if (lane == a) {
+                DSink<false> s; s.cur = 0; s.g = A.out + off + lane_off;
+#pragma unroll
+                for (int k = 0; k < DF_CPL; ++k) if (len[k]) depth_row_write<false>(W, A.counts, ncols, c0 + DF_CPL * lane + k, s);
             }
-            const int b = a + nb;
-            const uint32_t rbytes = (uint32_t)__shfl((int)incl, b - 1) - start;
-            if (rbytes) {
-                char *dst = A.out + off + start;
-                const uint32_t mis = (uint32_t)((uintptr_t)dst & 15);
-                wave_lds_sync();
-                if (lane >= a && lane < b && len) { DSink<true> s; s.g = nullptr; s.cur = lb + mis + (excl - start); depth_row_write<true>(W, A.counts, ncols, col, s); }
-                wave_lds_sync();
-                wave_flush_text(lds_dtext + lb + mis, dst, rbytes);
-            }
-            a = b;
+            a += 1;
+            continue;
         }
-        off += sub_total;
+        const int b = a + nb;
+        const uint32_t rbytes = (uint32_t)__shfl((int)lane_incl, b - 1) - start;
+        if (rbytes) {
+            char *dst = A.out + off + start;
+            const uint32_t mis = (uint32_t)((uintptr_t)dst & 15);
+            wave_lds_sync();
+            if (lane >= a && lane < b) {
+                DSink<true> s; s.g = nullptr; s.cur = lb + mis + (lane_off - start);
+#pragma unroll
+                for (int k = 0; k < DF_CPL; ++k) if (len[k]) depth_row_write<true>(W, A.counts, ncols, c0 + DF_CPL * lane + k, s);
+            }
+            wave_lds_sync();
+            wave_flush_text(lds_dtext + lb + mis, dst, rbytes);
+        }
+        a = b;
     }
 }
 
-static int depth_sub()
-{
-    static const int v = [] { const char *e = getenv("STA_DEPTH_SUB"); int x = e ? atoi(e) : 0; return x >= 1 && x <= 64 ? x : DF_SUB_DEFAULT; }();
-    return v;
-}
-
-size_t sta_depth_fused_status_bytes(int64_t ncols) { const int64_t t = 256 * (int64_t)depth_sub(); return (size_t)((ncols + t - 1) / t) * 16 + 16; }
+size_t sta_depth_fused_status_bytes(int64_t ncols) { const int64_t t = 4 * DF_SPAN; return (size_t)((ncols + t - 1) / t) * 16 + 16; }
 
 void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, void *status, int32_t *counts, char *out,
                             uint64_t capacity, StaCounters *ctr, uint32_t lbuf)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
-    const int64_t tcols = 256 * (int64_t)depth_sub();
+    const int64_t tcols = 4 * DF_SPAN;
     const int64_t n_tiles = (ncols + tcols - 1) / tcols;
     hipMemsetAsync(status, 0, sta_depth_fused_status_bytes(ncols), s);
     DepthFusedArgs a;
@@ -316,7 +310,6 @@ void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_p
     a.ticket = (unsigned int *)((char *)status + (size_t)n_tiles * 16);
     a.out = out; a.capacity = capacity; a.counts = counts; a.ctr = ctr;
     a.lbuf = lbuf; a.per_wave = ((lbuf + 16 + 15) & ~15u) + 16; a.n_tiles = (uint32_t)n_tiles;
-    a.sub = depth_sub();
     a.has_clip = p.remove_overlaps ? 1 : 0;
     DepthDevPar d{ p.min_qual, p.skip_del, p.all_pos };
     hipLaunchKernelGGL(k_depth_fused, dim3((unsigned)n_tiles), dim3(256), (size_t)4 * a.per_wave, s, w, d, a);

@@ -21,10 +21,8 @@ __device__ __forceinline__ int dec_digits_u32(uint32_t v)
     return 1 + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u)
              + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
 }
-// (coordinates below 2^32 -- nearly always -- take the compare chain: a 64-bit divide per digit costs ~20 instructions)
 __device__ __forceinline__ int dec_digits(unsigned long long v)
 {
-    if (v <= 0xffffffffull) return dec_digits_u32((uint32_t)v);
     int n = 1;
     while (v >= 10) { v /= 10; ++n; }
     return n;

@@ -64,13 +64,7 @@ template <bool LDS> struct Sink {
         if (v < 0) { put('-'); v = -v; }
         unsigned long long u = (unsigned long long)v;
         int n = dec_digits(u);
-        if (LDS && u <= 0xffffffffull) {
-            // 32-bit digits: divide by a constant = multiply-high + shift (the 64-bit form is ~20 instructions per digit)
-            uint32_t w = (uint32_t)u;
-            const uint32_t e = cur + n;
-            for (uint32_t q = e; q > cur;) { const uint32_t d = w / 10u; lds_text[--q] = (char)('0' + (w - d * 10u)); w = d; }
-            cur = e;
-        } else if (LDS) {
+        if (LDS) {
             uint32_t e = cur + n;
             for (uint32_t q = e; q > cur;) { lds_text[--q] = (char)('0' + u % 10); u /= 10; }
             cur = e;

@@ -9,7 +9,8 @@ than 16 KiB are stored gzip-compressed.  Run from the repo root in the build con
     python tests/gen_golden_fixtures.py
 
 Sources: /root/reference/test/bedcov/* and test/coverage/* (+ test/dat/sample.sam) copied whole, /root/reference/test/mpileup/{*.sam,*.bam,*.fa,regions,xx.bed*,expected/*.out},
-/root/reference/test/dat/{mpileup.*,view.001.sam}, /root/reference/test/large_pos/*, /root/reference/examples/{ex1.sam.gz,ex1.fa}.
+/root/reference/test/dat/{mpileup.*,view.001.sam}, /root/reference/test/large_pos/*, /root/reference/examples/{ex1.sam.gz,ex1.fa},
+/root/reference/test/consensus/{*.sam,*.fa,*.fai,*.bed,expected/*.out}.
 """
 import gzip
 import os
@@ -74,6 +75,12 @@ def main():
     # BASELINE.json configs[0]: examples/ex1.sam.gz (headerless SAM, @SQ comes from the FASTA index) + ex1.fa
     for f in ("ex1.sam.gz", "ex1.fa"):
         copy(os.path.join(os.path.dirname(REF), "examples", f), os.path.join(OUT, "examples", f))
+    # consensus: test/consensus inputs + every expected file consensus.reg names
+    for f in os.listdir(os.path.join(REF, "consensus")):
+        if f.endswith((".sam", ".fa", ".fai", ".bed")):
+            copy(os.path.join(REF, "consensus", f), os.path.join(OUT, "consensus", f))
+    for exp, args, post in regcases.CONSENSUS:
+        copy(os.path.join(REF, "consensus", "expected", exp), os.path.join(OUT, "consensus", "expected", exp))
     # mpileup.reg:89 -- read groups of mpileup.1.bam except ERR013140
     d = gzip.open(os.path.join(REF, "mpileup", "mpileup.1.bam")).read()
     rgs = sorted(set(m.group(1).decode() for m in re.finditer(rb"RGZ([A-Z0-9]+)", d)))

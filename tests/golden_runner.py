@@ -81,6 +81,8 @@ def case_paths(group, exp):
     """(workdir, expected_path) for a regcases entry of the given group."""
     if group == "testpl":
         return GOLDEN, os.path.join(GOLDEN, exp)
+    if group == "consensus":
+        return os.path.join(GOLDEN, "consensus"), os.path.join(GOLDEN, "consensus", "expected", exp)
     return os.path.join(GOLDEN, "mpileup"), os.path.join(GOLDEN, "mpileup", "expected", exp)
 
 
@@ -89,9 +91,17 @@ def run_case(binary, workdir, expected_path, argstr, post, env=None, timeout=600
     with tempfile.TemporaryDirectory() as tmp:
         argv = expand_args(argstr, workdir, tmp)
         cmd = binary if isinstance(binary, list) else [binary]
+        if post == "outfile":
+            # consensus.reg:62-63 -- `-o cons.tmp; cat cons.tmp`: the -o / --output argument is redirected into tmp
+            argv = [os.path.join(tmp, a) if a == "cons.tmp" else a for a in argv]
         p = subprocess.run(cmd + argv, cwd=workdir, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            env=env, timeout=timeout)
-    got = postprocess(p.stdout.decode("latin1"), post)
+        out = p.stdout
+        if post == "outfile":
+            with open(os.path.join(tmp, "cons.tmp"), "rb") as fh:
+                out = out + fh.read()
+            post = None
+    got = postprocess(out.decode("latin1"), post)
     want = read_expected(expected_path, post)
     return got == want, got, want, p.stderr.decode("latin1")
 

@@ -1,8 +1,8 @@
 """Pins the CPU oracle against the reference's own golden vectors.
 
 Every reproducible `P` line of test/mpileup/mpileup.reg and depth.reg, the
-test.pl mpileup cases and the large-position depth cases must match byte for
-byte.  Runs on CPU (no GPU needed)."""
+test.pl mpileup cases, the large-position depth cases and every `P` line of
+test/consensus/consensus.reg must match byte for byte.  Runs on CPU (no GPU needed)."""
 import os
 
 import pytest
@@ -10,7 +10,8 @@ import pytest
 import regcases
 from golden_runner import case_paths, first_diff, run_case
 
-CASES = [("reg", c) for c in regcases.MPILEUP + regcases.DEPTH] + [("testpl", c) for c in regcases.TESTPL]
+CASES = ([("reg", c) for c in regcases.MPILEUP + regcases.DEPTH] + [("testpl", c) for c in regcases.TESTPL]
+         + [("consensus", c) for c in regcases.CONSENSUS])
 
 
 @pytest.mark.parametrize("group,case", CASES, ids=["%s::%s" % (c[0], c[1][:60]) for _, c in CASES])
@@ -99,3 +100,20 @@ def test_oracle_reads_a_filtered_bam_from_stdin(oracle_bin, tmp_path, exp, requi
     with open(src, "rb") as fh:
         out = subprocess.run([oracle_bin, "mpileup", "-x", "-"], stdin=fh, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
     assert out.stdout == want
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/bam_consensus_tab.h"), reason="reference tree only exists in the build container")
+def test_consensus_tables_are_the_documented_formulas():
+    """oracle/o_consensus.c and the product generate q2p[] / mqual_pow_1m[] with pow() from the formulas the reference header
+    documents (bam_consensus_tab.h:27-37) instead of carrying its 357 literals: the doubles must be the same bit for bit."""
+    import math
+    import re
+    s = open("/root/reference/bam_consensus_tab.h").read()
+
+    def table(name):
+        a = s.index(name)
+        return [float(x) for x in re.findall(r"[-+0-9.e]+", s[s.index("{", a) + 1:s.index("};", a)])]
+    q2p, mq = table("static double q2p[101]"), table("static double mqual_pow_1m[256]")
+    assert len(q2p) == 101 and len(mq) == 256
+    assert all(q2p[i] == math.pow(10, -i / 10.0) for i in range(101))
+    assert all(mq[i] == math.pow(10, -(i * .9) / 10.0) for i in range(255)) and mq[255] == mq[10]

@@ -28,6 +28,9 @@
  *   bam_fillmd1_core + BAQ tag     bam_md.c:64-224,474-479 sta_calmd_plan / sta_fetch_calmd
  *   sam_open / sam_read1 (host)    bam_plcmd.c:500-569    sta_io_scan exercises the drivers' reader (BGZF worker pool)
  *   bam_mpileup / main_depth (CLI) bam_plcmd.c:1075, bam2depth.c:732   sta_main_mpileup / sta_main_depth
+ *   pileup_loop + get_next_base    consensus_pileup.c:69-608            sta_consensus_run (columns incl. insertion columns)
+ *   nm_init / calculate_consensus_* / consensus_base   bam_consensus.c:1012-2183   sta_consensus_run
+ *   main_consensus (CLI)           bam_consensus.c:3149                 sta_main_consensus
  *
  * The per-column callback surface (bam_plp_* / bam_mplp_* / bam_plbuf_*) is
  * declared in samtools_amd_plp.h.
@@ -302,6 +305,39 @@ int sta_calmd_plan(sta_engine *e, const sta_calmd_params *p, sta_plan_info *info
 int sta_fetch_calmd(sta_engine *e, int32_t *nm, uint64_t *md_off, char *md_text, uint8_t *state, uint8_t *qual_pool,
                     uint8_t *seq_pool, uint8_t *tag_pool);
 
+/* ---- consensus: `samtools consensus`' own column iterator (consensus_pileup.c:69-608: one column per
+ * reference position plus one per inserted base, pads for the reads without the insertion) and its two callers, the
+ * frequency caller (bam_consensus.c:1907-2014) and the Bayesian one (:1258-1880 with the per-read preparation :1012-1206).
+ * Works on file 0 of the staged window.  The MD:Z text the Bayesian mode wants per read travels as text column 0 of
+ * sta_reads.xcol_* (n_xcols >= 1; "*" or empty = no tag). ---- */
+#define STA_CONS_SIMPLE    0     /* -m simple */
+#define STA_CONS_BAYES_116 1     /* -m bayesian_116 */
+#define STA_CONS_RECALL    2     /* -m bayesian (default) */
+#define STA_CONS_PRECISE   3     /* -m bayesian_p */
+#define STA_CONS_MIXED     4     /* -m bayesian_m */
+typedef struct sta_cons_params {    /* consensus_opts (bam_consensus.c:211-260), same names */
+    int32_t mode, use_qual, min_qual, adj_qual, use_mqual, nm_adjust, nm_halo, sc_cost, low_mqual, high_mqual, min_depth;
+    int32_t cons_cutoff, ambig, default_qual, excl_flags, incl_flags, min_mqual;
+    int32_t want_pileup;         /* also produce the per-column base / quality characters of `-f pileup` */
+    double scale_mqual, call_fract, het_fract, P_het, P_indel, het_scale, homopoly_fix, homopoly_redux;
+    int32_t qcal[3][101];        /* qcal_t smap / umap / omap (bam_consensus.c:191-195); identity = :flat */
+} sta_cons_params;
+typedef struct sta_cons_col {    /* one (position, nth) column */
+    int32_t depth;               /* reads in the column (0: the iterator has no such column) */
+    int32_t base;                /* consensus_base(): call character */
+    int32_t qual;                /*                   and its quality */
+} sta_cons_col;
+typedef struct sta_cons_info {
+    uint64_t n_cols;             /* (position, nth) columns of [col_beg, col_end), in order: position p has 1 + ins[p] of them */
+    uint64_t n_entries;          /* sum of depth over the columns */
+    uint64_t n_kept_reads;
+} sta_cons_info;
+/* runs the staged window.  Synchronises the stream. */
+int sta_consensus_run(sta_engine *e, const sta_cons_params *p, sta_cons_info *info);
+/* results of the last sta_consensus_run (any pointer may be NULL): ins[col_end - col_beg] = inserted columns after each
+ * position; cols[n_cols]; with want_pileup col_off[n_cols + 1] into seq_chars / qual_chars[n_entries] (pileup_t.base as
+ * `-f pileup` prints it: reverse-strand bases lower-cased, '#' for a reverse-strand pad; min(qual, 93) + '!'). */
+int sta_fetch_consensus(sta_engine *e, int32_t *ins, sta_cons_col *cols, uint64_t *col_off, char *seq_chars, char *qual_chars);
 /* ---- depth ---- */
 int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info);
 int sta_depth_emit(sta_engine *e, void *dev_out, uint64_t capacity);
@@ -333,6 +369,9 @@ int sta_main_depth(int argc, char **argv);
 int sta_main_glf(int argc, char **argv);
 /* `calmd [-erAEq] [-n max_nm] in.bam ref.fa`: dumps the record fields calmd changes (not a SAM writer) */
 int sta_main_calmd(int argc, char **argv);
+/* `consensus [options] in.bam`: options, text and exit status of `samtools consensus` (bam_consensus.c:3082-3593; -X presets
+ * and the named calibration tables other than :flat are not built) */
+int sta_main_consensus(int argc, char **argv);
 
 /* ---- host input plumbing (needs no device) ----
  * The drivers' SAM / BAM reader (stands where sam_open / sam_read1 stand for bam_plcmd.c:500-569): BGZF blocks are inflated

@@ -138,12 +138,13 @@ typedef struct cread {
     orec_t b;
 } cread_t;
 
-/* qual byte at index i, where i may run one past the array exactly as the reference's b_qual[seq_offset+1] can:
- * in a BAM record the byte after the qualities is the first aux byte. */
+/* qual byte at index i.  The reference reads b_qual[seq_offset+1] (and b_qual[seq_offset] for reads without SEQ) without a
+ * bounds check: exactly one past the array that is the first aux byte of the BAM record, further out it is undefined
+ * (whatever follows in memory) and reads as 0 here. */
 static inline int qual_at(const orec_t *b, int i)
 {
-    if (i < b->l_qseq) return b->qual[i];
-    return b->l_aux > 0 ? b->aux[0] : 0;
+    if (i >= 0 && i < b->l_qseq) return b->qual[i];
+    return i == b->l_qseq && b->l_aux > 0 ? b->aux[0] : 0;
 }
 
 static int take_op(cread_t *p)

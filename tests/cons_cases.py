@@ -1,0 +1,36 @@
+"""Inputs and option sets shared by the consensus tests (CPU harness: test_consensus_emul.py; device: test_gpu_consensus.py)."""
+import os
+
+from mdtag import add_md_tags
+from synth import write_synth_sam
+from synth_rich import write_rich_sam
+
+# every caller mode, every writer, the options that change what the device computes
+OPTION_SETS = [
+    ["-m", "simple"],
+    ["-m", "simple", "-f", "pileup"],
+    ["-m", "simple", "-f", "fastq", "-q", "-A", "-H", "0.3", "-c", "0.6", "--min-BQ", "8"],
+    ["-f", "fastq"],
+    ["-f", "pileup"],
+    ["-f", "pileup", "-A", "-a"],
+    ["-m", "bayesian_m", "-f", "pileup"],
+    ["-m", "bayesian_p", "-f", "fastq", "-aa", "-T", "{fa}", "--ref-qual", "7"],
+    ["-m", "bayesian_116", "-f", "pileup", "--show-del", "yes", "--show-ins", "no"],
+    ["-f", "pileup", "-p"],
+    ["-f", "fastq", "--homopoly-score", "0.3", "--homopoly-redux", "0.02", "--low-MQ", "5", "--scale-MQ", "1.5", "--het-scale", "0.37", "--mark-ins"],
+    ["-f", "fastq", "--no-use-MQ", "-q", "--min-BQ", "10", "-d", "3"],
+    ["-f", "pileup", "--no-adj-qual", "--no-adj-MQ", "--min-MQ", "20", "--ff", "0x704", "--NM-halo", "20", "--SC-cost", "30"],
+    ["-f", "fasta", "-l", "60", "-C", "25", "--P-het", "0.01", "--P-indel", "0.001"],
+]
+
+
+def make_inputs(tmpdir):
+    """[(sam, fasta)]: 30x pairs with many indels (no MD), the same with MD tags on two records out of three, and the messy
+    multi-contig set (clips, pads, ref skips, SEQ-less reads) with MD tags"""
+    d = str(tmpdir)
+    sam1, fa1 = write_synth_sam(d, n_ref=20000, depth=30, read_len=150, seed=5, paired=True, indel_rate=0.3, max_indel=7)
+    sam1md = add_md_tags(sam1, fa1, os.path.join(d, "pairs_md.sam"), every=1)
+    os.makedirs(os.path.join(d, "rich"), exist_ok=True)
+    sam2, fa2 = write_rich_sam(os.path.join(d, "rich"), seed=11, n_templates=3000)
+    sam2md = add_md_tags(sam2, fa2, os.path.join(d, "rich", "rich_md.sam"), every=3)
+    return [(sam1, fa1), (sam1md, fa1), (sam2md, fa2)]

@@ -43,6 +43,10 @@ WORKLOADS = {
     # rows widened into after the pileup path; single GPU, results stay on the device
     "glf30": ("glf", 30, 4 << 20, 1.5 + 128.0 / 30.0, ["glf", "-f", "{fa}", "{sam}"]),
     "calmd30": ("calmd", 30, 4 << 20, 4.0, ["calmd", "-r", "{sam}", "{fa}"]),
+    # `samtools consensus` columns (call + quality per column stay on the device).  Algorithmic bytes per piled
+    # base: seq 0.5 + qual 1 + per-read header ~0.2 + per-column result 12 B / depth 30 = 0.4
+    "consensus30": ("consensus", 30, 4 << 20, 2.1, ["consensus", "-f", "fastq", "{sam}"]),
+    "consensus30_simple": ("consensus", 30, 4 << 20, 2.1, ["consensus", "-m", "simple", "-f", "fastq", "{sam}"]),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec); ~6.3 TB/s is what a streaming copy reaches
 # fp64 vector ALU without fused multiply-add (BAQ must round like the CPU: -ffp-contract=off): 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz
@@ -211,7 +215,7 @@ def collect_pmc(a, kernels):
 
 # engine kernel label -> prefix of the rocprofv3 kernel name
 KNAME = {"baq_fwd": "void k_baq_fwd<7", "baq_bwd": "void k_baq_bwd<7", "mplp_emit": "k_mplp_emit_fast", "mplp_len": "k_mplp_len_fast",
-         "depth_fused": "k_depth_fused", "glf_cols": "k_glf_cols"}
+         "depth_fused": "k_depth_fused", "glf_cols": "k_glf_cols", "cons_col": "k_cons_col", "cons_walk": "k_cons_walk", "cons_read_a": "k_cons_read_a"}
 # gfx950: FETCH_SIZE tallies a 16-byte-per-lane streaming read at half its bytes (MI355X_MICROARCH.md, HBM).  k_baq_bwd reads two
 # thirds of its forward-row stream that way (the (M, I) pairs of the odd rows) and one third as 8-byte loads: the raw counter is
 # reported, and roofline.dram_util gives the stream the kernel must move by construction
@@ -276,8 +280,26 @@ def main():
     elif world > 1:
         raise SystemExit("workload %s is a single-GPU measurement" % a.workload)
 
+    cons_par = None
+    if kind == "consensus":
+        cons_par = sa.ConsParams.defaults()
+        if a.workload.endswith("_simple"):
+            cons_par.mode = 0
+        else:   # the Bayesian mode reads MD:Z from text column 0; the generated reads carry no tag ("*")
+            nrd = int(rd["n"])
+            xo = torch.arange(nrd + 1, dtype=torch.int32, device=dev); xt = torch.full((nrd + 1,), ord("*"), dtype=torch.uint8, device=dev)
+            keep += [xo, xt]
+            w.files[0].n_xcols = 1; w.files[0].xcol_off = xo.data_ptr(); w.files[0].xcol_text = xt.data_ptr(); w.files[0].n_xcol_bytes = nrd
+
+    class _ConsInfo:
+        out_bytes = 0; piled_bases = 0
+
     def plan():
         eng.stage_window(w)
+        if kind == "consensus":
+            ci = eng.consensus_run(cons_par)
+            r = _ConsInfo(); r.out_bytes = int(ci.n_cols) * 12; r.piled_bases = int(ci.n_entries)
+            return r
         if kind == "glf":
             return eng.glf_plan()
         if kind == "calmd":
@@ -424,7 +446,7 @@ def main():
             "metric": "Mbases piled/s (mpileup, 30x 150bp)" if a.workload.startswith("mpileup30") else "Mbases piled/s (%s)" % a.workload,
             "value": value, "unit": "Mbases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt_all / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8/f64" if ((kind == "mpileup" and not a.workload.endswith("_B")) or kind in ("glf", "calmd")) else "u8",
+            "vs_baseline": None, "dtype": "u8/f64" if ((kind == "mpileup" and not a.workload.endswith("_B")) or kind in ("glf", "calmd") or a.workload == "consensus30") else "u8",
             "data": "synthetic",
             "config": {"workload": a.workload, "command": " ".join(x for x in WORKLOADS[a.workload][4] if x != "{sam}").replace("{fa}", "ref.fa"),
                        "read_len": 150, "depth": depth, "window_cols_per_gpu": cols_per_gpu, "input_cols": n_cols, "reads_per_gpu": int(rd["n"]),

@@ -14,6 +14,9 @@ from ._capi import (  # noqa: F401
     GlfParams,
     GlfCol,
     CalmdParams,
+    ConsParams,
+    ConsCol,
+    ConsInfo,
     PlanInfo,
     Reads,
     Window,
@@ -28,6 +31,6 @@ from ._capi import (  # noqa: F401
 )
 
 __all__ = [
-    "Engine", "EngineError", "KernelTime", "MplpParams", "DepthParams", "GlfParams", "GlfCol", "CalmdParams", "PlanInfo", "Reads", "Window",
+    "Engine", "EngineError", "KernelTime", "MplpParams", "DepthParams", "GlfParams", "GlfCol", "CalmdParams", "ConsParams", "ConsCol", "ConsInfo", "PlanInfo", "Reads", "Window",
     "device_count", "lib", "main_depth", "main_mpileup", "version", "MPLP", "EXPORTED_SYMBOLS",
 ]

@@ -108,6 +108,35 @@ class GlfCol(C.Structure):
     _fields_ = [("n_plp", C.c_int32), ("n", C.c_int32), ("flags", C.c_int32), ("qsum", C.c_float * 4), ("p", C.c_float * 25)]
 
 
+class ConsParams(C.Structure):
+    """sta_cons_params: consensus_opts of `samtools consensus` (bam_consensus.c:211-260)"""
+    _fields_ = [(n, C.c_int32) for n in ("mode use_qual min_qual adj_qual use_mqual nm_adjust nm_halo sc_cost low_mqual high_mqual min_depth "
+                                          "cons_cutoff ambig default_qual excl_flags incl_flags min_mqual want_pileup").split()] \
+        + [(n, C.c_double) for n in "scale_mqual call_fract het_fract P_het P_indel het_scale homopoly_fix homopoly_redux".split()] \
+        + [("qcal", (C.c_int32 * 101) * 3)]
+
+    @classmethod
+    def defaults(cls, **kw):
+        """main_consensus's defaults (bam_consensus.c:3152-3194); keyword arguments override fields"""
+        p = cls(mode=2, adj_qual=1, use_mqual=1, scale_mqual=1.0, nm_adjust=1, nm_halo=50, sc_cost=60, low_mqual=1, high_mqual=60, min_depth=1,
+                call_fract=0.75, het_fract=0.5, cons_cutoff=10, default_qual=10, excl_flags=4 | 256 | 512 | 1024, P_het=1e-3, P_indel=2e-4,
+                het_scale=1.0, homopoly_redux=0.01)
+        for k in range(3):
+            for i in range(101):
+                p.qcal[k][i] = i
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+
+class ConsCol(C.Structure):
+    _fields_ = [("depth", C.c_int32), ("base", C.c_int32), ("qual", C.c_int32)]
+
+
+class ConsInfo(C.Structure):
+    _fields_ = [("n_cols", C.c_uint64), ("n_entries", C.c_uint64), ("n_kept_reads", C.c_uint64)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -146,6 +175,9 @@ _PROTOS = {
     "sta_fetch_calmd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "sta_main_calmd": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_main_glf": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "sta_consensus_run": (C.c_int, [_P, C.POINTER(ConsParams), C.POINTER(ConsInfo)]),
+    "sta_fetch_consensus": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "sta_main_consensus": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_io_scan": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 EXPORTED_SYMBOLS = sorted(_PROTOS)
@@ -273,6 +305,23 @@ class Engine:
         info, p = PlanInfo(), GlfParams(min_baseQ, max_depth, theta)
         self._chk(lib.sta_glf_plan(self._h, C.byref(p), C.byref(info)), "sta_glf_plan")
         return info
+
+    def consensus_run(self, params):
+        """`samtools consensus` columns of file 0 of the staged window (sta_consensus_run)"""
+        info = ConsInfo()
+        self._chk(lib.sta_consensus_run(self._h, C.byref(params), C.byref(info)), "sta_consensus_run")
+        return info
+
+    def fetch_consensus(self, n_positions, info, want_text=False):
+        """-> (ins[n_positions], cols[n_cols], col_off, seq_chars, qual_chars); the last three are None without want_text"""
+        ins = (C.c_int32 * max(1, n_positions))()
+        cols = (ConsCol * max(1, info.n_cols))()
+        off = (C.c_uint64 * (info.n_cols + 1))() if want_text else None
+        sq = C.create_string_buffer(max(1, info.n_entries)) if want_text else None
+        ql = C.create_string_buffer(max(1, info.n_entries)) if want_text else None
+        self._chk(lib.sta_fetch_consensus(self._h, C.cast(ins, _P), C.cast(cols, _P), C.cast(off, _P) if want_text else None,
+                                          C.cast(sq, _P) if want_text else None, C.cast(ql, _P) if want_text else None), "sta_fetch_consensus")
+        return ins, cols, off, sq, ql
 
     def calmd_plan(self, flag=0, max_nm=0):
         """calmd's MD / NM / BAQ-tag arithmetic on file 0 of the staged window; info.out_bytes = MD text bytes."""

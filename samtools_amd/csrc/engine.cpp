@@ -4,6 +4,10 @@
 // without a usable HIP device every entry point returns STA_ERR_NO_DEVICE.
 #include "sta_dev.h"
 #include "glf_tables.h"
+#include "cons_host.h"
+#include "cons_window.h"
+#include <memory>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include <map>
@@ -63,6 +67,10 @@ struct sta_engine {
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
     DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    // consensus
+    DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm;
+    sta_cons_params cons_p{}; bool cons_tab_ok = false;
+    cons::Win cons_w{}; uint64_t cons_ncols = 0, cons_nentries = 0; int64_t cons_W = 0; bool cons_text = false;
     int baq_slab_gib_cap = 0;       // 0 = default; 4 after a one-launch BAQ slab could not be allocated
     double glf_depcorr = -1.0;      // theta the coefficient block in glf_tab was computed for
     StaWinDev wd{};
@@ -171,7 +179,8 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq };
+                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
+                      &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
     if (e->side_done) hipEventDestroy(e->side_done);
@@ -765,6 +774,117 @@ int sta_glf_plan(sta_engine *e, const sta_glf_params *gp, sta_plan_info *info)
     e->out_bytes = bytes; e->last_out = e->out.p;
     if (info) { memset(info, 0, sizeof *info); info->out_bytes = bytes; info->n_kept_reads = e->ctr_h.n_kept; info->piled_bases = e->ctr_h.piled_bases; info->n_maxcnt_dropped = e->ctr_h.n_dropped; }
     e->planned = 4;
+    return STA_OK;
+}
+
+// `samtools consensus` on file 0 of the staged window (kernels_cons.hip; steps in cons_window.h)
+int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *info)
+{
+    if (!e || !cp) return STA_ERR_ARG;
+    if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
+    if (e->files_h.size() != 1) return fail(e, STA_ERR_ARG, "consensus works on one input file");
+    if (cp->mode < STA_CONS_SIMPLE || cp->mode > STA_CONS_MIXED) return fail(e, STA_ERR_ARG, "unknown consensus mode");
+    hipSetDevice(e->device);
+    hipStream_t s = e->stream;
+    // lookup tables: rebuilt only when a parameter they depend on changed
+    {
+        sta_cons_params a = *cp, b = e->cons_p; a.want_pileup = b.want_pileup = 0;
+        if (!e->cons_tab_ok || memcmp(&a, &b, sizeof a) != 0) {
+            std::unique_ptr<cons::Tables> t(new cons::Tables);
+            sta::cons_build_tables(*cp, *t);
+            if (e->cons_tab.ensure(sizeof(cons::Tables))) return fail(e, STA_ERR_HIP, "hipMalloc(consensus tables) failed");
+            HIPCHK(hipMemcpy(e->cons_tab.p, t.get(), sizeof(cons::Tables), hipMemcpyHostToDevice));
+            e->cons_p = *cp; e->cons_tab_ok = true;
+        }
+    }
+    const cons::Par o = sta::cons_par(*cp);
+    const cons::Tables *tab = (const cons::Tables *)e->cons_tab.p;
+    const StaReadsDev &d = e->files_h[0];
+    const int64_t n = d.n;
+    const int64_t W = (int64_t)e->wd.col_end - e->wd.col_beg;
+    if (W < 0) return fail(e, STA_ERR_ARG, "empty window");
+    const bool bayes_mq = o.mode != cons::MODE_SIMPLE && o.use_mqual;
+    if (bayes_mq && d.n_xcols < 1 && n > 0) return fail(e, STA_ERR_ARG, "the Bayesian mode reads MD:Z from text column 0 of sta_reads.xcol_*");
+    // workspace carve-up (one allocation): per-position and per-read arrays
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_ins = carve((size_t)(W + 1) * 4), o_len = carve((size_t)(W + 1) * 4), o_colbase = carve((size_t)(W + 2) * 8);
+    const size_t o_last = carve((size_t)n * 4), o_tail = carve((size_t)n * 4), o_keep = carve((size_t)n * 4), o_cs = carve((size_t)n * 4),
+                 o_ce = carve((size_t)n * 4), o_pmax = carve((size_t)n * 4), o_cnt = carve((size_t)n * 4), o_rowoff = carve((size_t)(n + 2) * 8), o_ctr = carve(64);
+    if (e->cons_ws.ensure(off + 256) || e->scan_tmp.ensure(sta_scan_tmp_bytes(std::max<int64_t>(std::max(W, n), 1) * 2) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(consensus workspace) failed");
+    char *ws = (char *)e->cons_ws.p;
+    cons::Win w; memset(&w, 0, sizeof w);
+    w.n_reads = n; w.pos = d.pos; w.flag = d.flag; w.mapq = d.mapq; w.l_qseq = d.l_qseq; w.cig_off = d.cig_off; w.base_off8 = d.base_off8;
+    w.cigar = d.cigar; w.seq = d.seq; w.qual_in = d.qual_in; w.n_xcols = d.n_xcols; w.xcol_off = d.xcol_off; w.xcol_text = d.xcol_text;
+    w.col_beg = e->wd.col_beg; w.col_end = e->wd.col_end;
+    w.ins = (uint32_t *)(ws + o_ins); w.colbase = (uint64_t *)(ws + o_colbase);
+    w.r_last = (int32_t *)(ws + o_last); w.r_tail = (int32_t *)(ws + o_tail); w.r_keep = (uint32_t *)(ws + o_keep);
+    w.cs = (int32_t *)(ws + o_cs); w.ce = (int32_t *)(ws + o_ce); w.pmax = (int32_t *)(ws + o_pmax); w.cnt = (uint32_t *)(ws + o_cnt);
+    w.rowoff = (uint64_t *)(ws + o_rowoff); w.counters = (unsigned long long *)(ws + o_ctr);
+    uint32_t *collen = (uint32_t *)(ws + o_len);
+    w.qual = const_cast<uint8_t *>(d.qual_in);
+    if (bayes_mq) {
+        const size_t nb = (size_t)d.n_bases_total;
+        if (e->cons_qwork.ensure(nb + 64) || e->cons_nm.ensure((nb + 8) * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(consensus per-base workspace) failed");
+        if (nb) HIPCHK(hipMemcpyAsync(e->cons_qwork.p, d.qual_in, nb, hipMemcpyDeviceToDevice, s));
+        w.qual = (uint8_t *)e->cons_qwork.p; w.nm = (int32_t *)e->cons_nm.p;
+    }
+    HIPCHK(hipMemsetAsync(w.ins, 0, (size_t)(W + 1) * 4, s));
+    HIPCHK(hipMemsetAsync(w.counters, 0, 64, s));
+    { ProfScope ps(e, "cons_read_a"); sta_launch_cons_read_a(s, w, o, tab); }
+    { ProfScope ps(e, "cons_scans");
+      sta_launch_cons_collen(s, w.ins, collen, W);
+      sta_launch_len_scan(s, collen, w.colbase, W, e->scan_tmp.p, e->scan_tmp.cap); }
+    { ProfScope ps(e, "cons_read_b"); sta_launch_cons_read_b(s, w); }
+    { ProfScope ps(e, "cons_scans");
+      sta_launch_len_scan(s, w.cnt, w.rowoff, n, e->scan_tmp.p, e->scan_tmp.cap);
+      if (n > 0) sta_launch_scan_max_i32(s, w.ce, w.pmax, n, e->scan_tmp.p); }
+    uint64_t n_entries = 0, n_cols = 0; unsigned long long ctr[2] = { 0, 0 };
+    HIPCHK(hipMemcpyAsync(&n_entries, w.rowoff + n, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&n_cols, w.colbase + W, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ctr, w.counters, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ctr[1]) return fail(e, STA_ERR_ARG, "a CIGAR holds an operation outside MIDNSHP=X");
+    if (e->cons_E.ensure((size_t)n_entries * 4 + 64) || (bayes_mq && e->cons_Enm.ensure((size_t)n_entries * 4 + 64)) || e->cons_cols.ensure((size_t)n_cols * sizeof(sta_cons_col) + 64)
+        || e->cons_depth.ensure((size_t)n_cols * 4 + 64))
+        return fail(e, STA_ERR_HIP, "hipMalloc(consensus entries) failed");
+    w.E = (uint32_t *)e->cons_E.p; w.Enm = bayes_mq ? (uint32_t *)e->cons_Enm.p : nullptr;
+    w.cols = (sta_cons_col *)e->cons_cols.p; w.depth = (uint32_t *)e->cons_depth.p;
+    { ProfScope ps(e, "cons_walk"); sta_launch_cons_walk(s, w, o); }
+    { ProfScope ps(e, "cons_col"); sta_launch_cons_col(s, w, o, tab, (int64_t)n_cols); }
+    e->cons_text = cp->want_pileup != 0;
+    if (e->cons_text) {
+        if (e->cons_coloff.ensure((size_t)(n_cols + 2) * 8 + 64) || e->cons_seq.ensure((size_t)n_entries + 64) || e->cons_qual.ensure((size_t)n_entries + 64)
+            || e->scan_tmp.ensure(sta_scan_tmp_bytes((int64_t)n_cols + 1) + 64))
+            return fail(e, STA_ERR_HIP, "hipMalloc(consensus text) failed");
+        w.col_off = (uint64_t *)e->cons_coloff.p; w.seq_chars = (char *)e->cons_seq.p; w.qual_chars = (char *)e->cons_qual.p;
+        { ProfScope ps(e, "cons_scans"); sta_launch_len_scan(s, w.depth, w.col_off, (int64_t)n_cols, e->scan_tmp.p, e->scan_tmp.cap); }
+        { ProfScope ps(e, "cons_text"); sta_launch_cons_text(s, w, (int64_t)n_cols); }
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return hipfail(e, le, "consensus kernels");
+    prof_drain(e);
+    e->cons_w = w; e->cons_ncols = n_cols; e->cons_nentries = n_entries; e->cons_W = W;
+    if (info) { info->n_cols = n_cols; info->n_entries = n_entries; info->n_kept_reads = ctr[0]; }
+    e->planned = 6;
+    return STA_OK;
+}
+
+int sta_fetch_consensus(sta_engine *e, int32_t *ins, sta_cons_col *cols, uint64_t *col_off, char *seq_chars, char *qual_chars)
+{
+    if (!e) return STA_ERR_ARG;
+    if (e->planned != 6) return fail(e, STA_ERR_ARG, "no consensus window was run");
+    if ((col_off || seq_chars || qual_chars) && !e->cons_text) return fail(e, STA_ERR_ARG, "the window was run without want_pileup");
+    hipSetDevice(e->device);
+    hipStream_t s = e->stream;
+    const cons::Win &w = e->cons_w;
+    if (ins && e->cons_W) HIPCHK(hipMemcpyAsync(ins, w.ins + 1, (size_t)e->cons_W * 4, hipMemcpyDeviceToHost, s));
+    if (cols && e->cons_ncols) HIPCHK(hipMemcpyAsync(cols, w.cols, (size_t)e->cons_ncols * sizeof(sta_cons_col), hipMemcpyDeviceToHost, s));
+    if (col_off) HIPCHK(hipMemcpyAsync(col_off, w.col_off, (size_t)(e->cons_ncols + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (seq_chars && e->cons_nentries) HIPCHK(hipMemcpyAsync(seq_chars, w.seq_chars, (size_t)e->cons_nentries, hipMemcpyDeviceToHost, s));
+    if (qual_chars && e->cons_nentries) HIPCHK(hipMemcpyAsync(qual_chars, w.qual_chars, (size_t)e->cons_nentries, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return STA_OK;
 }
 

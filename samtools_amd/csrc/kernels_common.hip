@@ -457,6 +457,13 @@ void sta_launch_maxend_scan(hipStream_t s, const StaReadsDev &r, void *tmp, size
     run_scan<OpMaxI32, LoadKeptEnd, int32_t, false>(s, ld, r.n, r.maxend, tmp);
 }
 
+// inclusive running maximum of an int32 array (consensus: last column of the reads so far)
+void sta_launch_scan_max_i32(hipStream_t s, const int32_t *in, int32_t *out, int64_t n, void *tmp)
+{
+    LoadI32 ld{ in };
+    run_scan<OpMaxI32, LoadI32, int32_t, false>(s, ld, n, out, tmp);
+}
+
 __global__ void k_set_u64(uint64_t *p, uint64_t v) { *p = v; }
 
 void sta_launch_len_scan(hipStream_t s, const uint32_t *len, uint64_t *offs, int64_t n, void *tmp, size_t)

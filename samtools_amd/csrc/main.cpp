@@ -10,11 +10,12 @@ extern "C" int sta_main_coverage(int argc, char **argv);  // coverage.c tabular 
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        fprintf(stderr, "Usage: samtools-amd <mpileup|depth|bedcov|coverage|plpdump|glf|calmd> [options]\n%s\n", sta_version());
+        fprintf(stderr, "Usage: samtools-amd <mpileup|depth|consensus|bedcov|coverage|plpdump|glf|calmd> [options]\n%s\n", sta_version());
         return 1;
     }
     if (strcmp(argv[1], "mpileup") == 0) return sta_main_mpileup(argc - 1, argv + 1);
     if (strcmp(argv[1], "depth") == 0) return sta_main_depth(argc - 1, argv + 1);
+    if (strcmp(argv[1], "consensus") == 0) return sta_main_consensus(argc - 1, argv + 1);
     if (strcmp(argv[1], "calmd") == 0) return sta_main_calmd(argc - 1, argv + 1);
     if (strcmp(argv[1], "glf") == 0) return sta_main_glf(argc - 1, argv + 1);
     if (strcmp(argv[1], "plpdump") == 0) return sta_main_plpdump(argc - 1, argv + 1);

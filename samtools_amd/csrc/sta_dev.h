@@ -82,6 +82,7 @@ void sta_launch_cap_mapq(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
 void sta_launch_qual_prep(hipStream_t s, const StaReadsDev &r, int illumina13);
 void sta_launch_maxend_scan(hipStream_t s, const StaReadsDev &r, void *tmp, size_t tmp_bytes);
 size_t sta_scan_tmp_bytes(int64_t n);
+void sta_launch_scan_max_i32(hipStream_t s, const int32_t *in, int32_t *out, int64_t n, void *tmp);
 // exclusive scan of u32 lengths into u64 offsets (offs has n+1 entries)
 void sta_launch_len_scan(hipStream_t s, const uint32_t *len, uint64_t *offs, int64_t n, void *tmp, size_t tmp_bytes);
 void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo /*[nfiles][ncols] (count, seq bytes)*/,
@@ -130,3 +131,12 @@ void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_p
                             uint64_t capacity, StaCounters *ctr, uint32_t lbuf);
 void sta_launch_depth_pair(hipStream_t s, const StaReadsDev &r, int64_t origin, int32_t tid, void *table, size_t slots,
                            int32_t *chain_next, StaCounters *ctr);
+
+// consensus (kernels_cons.hip; the window record and the step functions are in cons_window.h)
+namespace cons { struct Win; struct Par; struct Tables; }
+void sta_launch_cons_read_a(hipStream_t s, const cons::Win &w, const cons::Par &o, const cons::Tables *t);
+void sta_launch_cons_collen(hipStream_t s, const uint32_t *ins, uint32_t *len, int64_t W);
+void sta_launch_cons_read_b(hipStream_t s, const cons::Win &w);
+void sta_launch_cons_walk(hipStream_t s, const cons::Win &w, const cons::Par &o);
+void sta_launch_cons_col(hipStream_t s, const cons::Win &w, const cons::Par &o, const cons::Tables *t, int64_t n_cols);
+void sta_launch_cons_text(hipStream_t s, const cons::Win &w, int64_t n_cols);

@@ -94,7 +94,8 @@ def test_ctypes_mirror_matches_the_header(tmp_path):
     from samtools_amd import _capi
     names = [("sta_reads", _capi.Reads), ("sta_window", _capi.Window), ("sta_mplp_params", _capi.MplpParams),
              ("sta_depth_params", _capi.DepthParams), ("sta_plan_info", _capi.PlanInfo), ("sta_kernel_time", _capi.KernelTime),
-             ("sta_glf_params", _capi.GlfParams), ("sta_glf_col", _capi.GlfCol), ("sta_calmd_params", _capi.CalmdParams)]
+             ("sta_glf_params", _capi.GlfParams), ("sta_glf_col", _capi.GlfCol), ("sta_calmd_params", _capi.CalmdParams),
+             ("sta_cons_params", _capi.ConsParams), ("sta_cons_col", _capi.ConsCol), ("sta_cons_info", _capi.ConsInfo)]
     src = tmp_path / "sz.c"
     body = "".join('printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n, _ in names)
     body += 'printf("off_window_files %zu\\n", offsetof(sta_window, files));\nprintf("off_mplp_flag %zu\\n", offsetof(sta_mplp_params, flag));\n'
@@ -122,7 +123,7 @@ def test_every_subcommand_refuses_to_compute_without_a_device(tmp_path):
     gold = os.path.join(REPO, "tests", "golden")
     sam, fa = os.path.join(gold, "mpileup", "mp_D.sam"), os.path.join(gold, "mpileup", "mp.fa")
     cases = [["mpileup", sam], ["mpileup", "-f", fa, sam], ["depth", "-a", sam], ["plpdump", sam], ["coverage", sam], ["glf", sam],
-             ["calmd", "-r", sam, fa], ["bedcov", os.path.join(gold, "bedcov", "bedcov.bed"), os.path.join(gold, "bedcov", "bedcov.bam")]]
+             ["calmd", "-r", sam, fa], ["consensus", sam], ["consensus", "-m", "simple", "-f", "pileup", sam], ["bedcov", os.path.join(gold, "bedcov", "bedcov.bed"), os.path.join(gold, "bedcov", "bedcov.bam")]]
     for env_extra in ({}, {"STA_COV_ITERATOR": "1"}):
         for args in cases:
             p = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env_extra))

@@ -456,7 +456,7 @@ def main():
             "roofline": roof(dom_name) if dom_name else None,
             "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
         }
-        emit_name = next((k for k in ({"mpileup": ["mplp_fused", "mplp_emit"], "depth": ["depth_fused", "depth_emit"], "glf": ["glf_cols"], "calmd": ["md_emit"]}[kind]) if k in prof), None)
+        emit_name = next((k for k in ({"mpileup": ["mplp_fused", "mplp_emit"], "depth": ["depth_fused", "depth_emit"], "glf": ["glf_cols"], "calmd": ["md_emit"], "consensus": ["cons_col"]}[kind]) if k in prof), None)
         if emit_name and emit_name != dom_name:
             res["roofline_pileup"] = roof(emit_name)
         # whole step against the same roof: every kernel of the step, SURVEY.md 8d bytes

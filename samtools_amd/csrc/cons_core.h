@@ -380,37 +380,34 @@ struct Gap5Acc {
         const double oo = cp.poo[qual2] - xx, oM = cp.poM[qual2] - xx, ox = cp.pox[qual2] - xx;
         const double uu = cp.puu[qual2] - xx, um = cp.pum[qual2] - xx, mm = cp.pmm[qual2] - xx;
         if (base == 5) n_N++;
-        // genotype j = (a, c) over ACGT*: 0 AA 1 AC 2 AG 3 AT 4 A* 5 CC 6 CG 7 CT 8 C* 9 GG 10 GT 11 G* 12 TT 13 T* 14 **
-        if (base < 4) {
-            const int hom = base == 0 ? 0 : base == 1 ? 5 : base == 2 ? 9 : 12;
-            const int star = base == 0 ? 4 : base == 1 ? 8 : base == 2 ? 11 : 13;
-            S[hom] += MM;
-            S[star] += oM;
-            if (base != 0) S[4] += ox;
-            if (base != 1) S[8] += ox;
-            if (base != 2) S[11] += ox;
-            if (base != 3) S[13] += ox;
-            S[14] += oo;
-            // the three genotypes that pair this base with another one
-            if (base == 0) { S[1] += xM; S[2] += xM; S[3] += xM; }
-            else if (base == 1) { S[1] += xM; S[6] += xM; S[7] += xM; }
-            else if (base == 2) { S[2] += xM; S[6] += xM; S[10] += xM; }
-            else { S[3] += xM; S[7] += xM; S[10] += xM; }
-        } else if (base == 4) {
-            S[0] += uu; S[1] += uu; S[2] += uu; S[3] += uu; S[4] += um; S[5] += uu; S[6] += uu; S[7] += uu; S[8] += um;
-            S[9] += uu; S[10] += uu; S[11] += um; S[12] += uu; S[13] += um; S[14] += mm;
-        } else {
-            S[0] += MM; S[1] += MM; S[2] += MM; S[3] += MM; S[4] += oM; S[5] += MM; S[6] += MM; S[7] += MM; S[8] += oM;
-            S[9] += MM; S[10] += MM; S[11] += oM; S[12] += MM; S[13] += oM; S[14] += oo;
-        }
+        // genotype j = (a, c) over ACGT*: 0 AA 1 AC 2 AG 3 AT 4 A* 5 CC 6 CG 7 CT 8 C* 9 GG 10 GT 11 G* 12 TT 13 T* 14 **.
+        // Every genotype gets one addend per read; where the reference adds nothing (a called base against a genotype that
+        // does not hold it) the addend is +0.0, which leaves the sum bit-identical and keeps S[] in registers (no indexing).
+        const bool called = base < 4, star = base == 4;
+        const double other = called ? 0.0 : star ? uu : MM;              // genotypes of two bases, seen from a pad / an N
+        const double hA = base == 0 ? MM : other, hC = base == 1 ? MM : other, hG = base == 2 ? MM : other, hT = base == 3 ? MM : other;
+        const double xA = base == 0 ? xM : other, xC = base == 1 ? xM : other, xG = base == 2 ? xM : other, xT = base == 3 ? xM : other;
+        const double sx = called ? ox : star ? um : oM;                  // (base, *) genotypes that do not hold the called base
+        const double sA = base == 0 ? oM : sx, sC = base == 1 ? oM : sx, sG = base == 2 ? oM : sx, sT = base == 3 ? oM : sx;
+        S[0] += hA;
+        S[1] += base == 1 ? xC : xA;  S[2] += base == 2 ? xG : xA;  S[3] += base == 3 ? xT : xA;  S[4] += sA;
+        S[5] += hC;
+        S[6] += base == 2 ? xG : xC;  S[7] += base == 3 ? xT : xC;  S[8] += sC;
+        S[9] += hG;
+        S[10] += base == 3 ? xT : xG; S[11] += sG;
+        S[12] += hT; S[13] += sT;
+        S[14] += star ? mm : oo;
         depth++;
     }
     CONS_HD void finish(const Tables &t, const Probs &cp, Call &cons)
     {
         const double min_e_exp = -1021 * 0.693147180559945309417232121458 + 1;      // DBL_MIN_EXP * log(2) + 1
         const double DMAX = 1.7976931348623157e308, DMIN = 2.2250738585072014e-308;
-        double shift = -DMAX, mx = -DMAX, mx_het = -DMAX, norm[15], tot1 = 0, tot2 = 0;
+        double shift = -DMAX, mx = -DMAX, mx_het = -DMAX;
         int call = 0, het_call = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
         for (int j = 0; j < 15; ++j) {
             S[j] += cp.lprior15[j];
             if (shift < S[j]) shift = S[j];
@@ -418,26 +415,38 @@ struct Gap5Acc {
             if (!pure) { if (mx_het < S[j]) { mx_het = S[j]; het_call = j; } continue; }
             if (mx < S[j]) { mx = S[j]; call = j; }
         }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
         for (int j = 0; j < 15; ++j) {
             S[j] -= shift;
             const double e = fast_exp(t, S[j]);
             S[j] = S[j] > min_e_exp ? e : DMIN;
-            norm[j] = 0;
         }
+        // norm[m] = (sum of S before m, added up from 0) + (sum of S after m, added up from 14 down): the reference builds both
+        // running sums in one loop (bam_consensus.c:1739-1744); only the two called genotypes are needed
+        double tot1 = 0, tot2 = 0, Sc = 0, Sh = 0, P_c = 0, P_h = 0, Q_c = 0, Q_h = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
         for (int j = 0; j < 15; ++j) {
-            norm[j] += tot1; norm[14 - j] += tot2;
+            if (j == call) { P_c = tot1; Sc = S[j]; }
+            if (j == het_call) { P_h = tot1; Sh = S[j]; }
+            if (14 - j == call) Q_c = tot2;
+            if (14 - j == het_call) Q_h = tot2;
             tot1 += S[j]; tot2 += S[14 - j];
         }
+        double norm_c = P_c + Q_c, norm_h = P_h + Q_h;
         if (!depth || depth == n_N) { cons.call = 4; cons.het_call = 0; cons.het_logodd = 0; cons.phred = 0; cons.depth = 0; return; }
         cons.depth = depth;
-        if (norm[call] == 0) norm[call] = DMIN;
+        if (norm_c == 0) norm_c = DMIN;
         int ph;
-        if (S[call] == 1 && norm[call] < .01) ph = (int)(ph_log(norm[call]) + .5);
-        else ph = (int)(ph_log(1 - S[call] / (norm[call] + S[call])) + .5);
+        if (Sc == 1 && norm_c < .01) ph = (int)(ph_log(norm_c) + .5);
+        else ph = (int)(ph_log(1 - Sc / (norm_c + Sc)) + .5);
         cons.call = call == 0 ? 0 : call == 5 ? 1 : call == 9 ? 2 : call == 12 ? 3 : 4;          // pure genotypes only
         cons.phred = ph < 0 ? 0 : ph;
-        if (norm[het_call] == 0) norm[het_call] = DMIN;
-        ph = (int)(3.0103 * (fast_log2(S[het_call]) - fast_log2(norm[het_call])) + .5);
+        if (norm_h == 0) norm_h = DMIN;
+        ph = (int)(3.0103 * (fast_log2(Sh) - fast_log2(norm_h)) + .5);
         // index in the 5x5 matrix of the pair: rows 0 5 9 12 14 of the triangle start at 0 6 12 18 24
         cons.het_call = het_call < 5 ? het_call : het_call < 9 ? het_call + 1 : het_call < 12 ? het_call + 3 : het_call < 14 ? het_call + 6 : 24;
         cons.het_logodd = ph;

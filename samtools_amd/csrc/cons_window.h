@@ -7,7 +7,10 @@
 //   scan              colbase = exclusive sum of 1 + ins[1 ..]      (column index of (position, 0))
 //   step B  (read)    first / last column of the read inside the window, number of entries
 //   scans             rowoff = exclusive sum of entries; pmax = running max of last columns
-//   step W  (read)    the read's cursor walks its columns and writes one entry word (+ nm word) per column
+//   step W  (read)    reads with indels / skips / pads only: the read's cursor walks its columns and writes one entry word
+//                     (+ nm word) per column.  A read that is one aligned block between clips ("plain") stores nothing: what
+//                     it shows in a column follows from its start (plain_entry)
+//   step P  (position) colpos[column] = position, so that a column can place itself on a plain read
 //   step C  (column)  alive reads = [lo, hi) by two binary searches, gathered in file order -> call, quality, depth
 //   scan + step T     `-f pileup` only: base / quality characters of every column
 #pragma once
@@ -28,11 +31,13 @@ struct Win {
     int32_t *nm;                 // one word per staged base (Bayesian mode with mapping qualities), else null
     uint32_t *ins;               // [W + 1] inserted columns after positions col_beg - 1 (look-back, see step_walk) .. col_end - 1
     uint64_t *colbase;           // [W + 1]
-    int32_t *r_last, *r_tail; uint32_t *r_keep;
+    int32_t *r_last, *r_tail; uint32_t *r_keep;      // r_keep: 1 in the pileup, 2 reverse strand, 4 plain; r_tail of a plain read = its leading clip
+    int32_t *colpos;             // [n_cols] position (relative to the origin) of every column
+    int32_t *clist;              // reads that need the cursor walk
     int32_t *cs, *ce, *pmax; uint32_t *cnt; uint64_t *rowoff;
     uint32_t *E, *Enm;
     sta_cons_col *cols; uint32_t *depth; uint64_t *col_off; char *seq_chars, *qual_chars;
-    unsigned long long *counters;    // [0] kept reads, [1] bad CIGAR ops
+    unsigned long long *counters;    // [0] kept reads, [1] bad CIGAR ops, [2] reads on clist, [3] sum of column depths
 };
 
 CONS_HD ReadView view_of(const Win &w, int64_t r, bool working_qual)
@@ -46,35 +51,53 @@ CONS_HD ReadView view_of(const Win &w, int64_t r, bool working_qual)
     return v;
 }
 
-// AMAX(ptr, value): atomic max on the device, plain max in the harness; ADD likewise
-template <class AMAX, class ADD> CONS_HD void step_read_a(const Win &w, const Par &o, const Tables &t, int64_t r, AMAX amax, ADD add)
+CONS_HD void md_of(const Win &w, int64_t r, const char *&md, int &md_len)
+{
+    md = nullptr; md_len = 0;
+    if (w.n_xcols > 0) { const uint32_t a = w.xcol_off[r * w.n_xcols], b = w.xcol_off[r * w.n_xcols + 1]; md = w.xcol_text + a; md_len = (int)(b - a); }
+}
+
+// AMAX(ptr, value): atomic max on the device, plain max in the harness.  1 = the read is in the pileup, 0 = filtered,
+// -1 = its CIGAR holds an operation outside MIDNSHP=X
+template <class AMAX> CONS_HD int step_read_a(const Win &w, const Par &o, const Tables &t, int64_t r, AMAX amax, bool prepare_here)
 {
     w.r_keep[r] = 0; w.r_last[r] = w.pos[r] - 1; w.r_tail[r] = 0;
     const int fl = w.flag[r];
-    if (o.incl_flags && !(fl & o.incl_flags)) return;
-    if (o.excl_flags && (fl & o.excl_flags)) return;
-    if (w.mapq[r] < o.min_mqual) return;
-    if (fl & 4) return;
+    if (o.incl_flags && !(fl & o.incl_flags)) return 0;
+    if (o.excl_flags && (fl & o.excl_flags)) return 0;
+    if (w.mapq[r] < o.min_mqual) return 0;
+    if (fl & 4) return 0;
     const bool bayes_mq = o.mode != MODE_SIMPLE && o.use_mqual;
-    if (bayes_mq && w.l_qseq[r] <= 0) return;                      // nm_init: "discard"
+    if (bayes_mq && w.l_qseq[r] <= 0) return 0;                    // nm_init: "discard"
     ReadView v = view_of(w, r, false);
     const int32_t cb = w.col_beg, ce = w.col_end;
     uint32_t *ins = w.ins;
     Shape s = read_shape(v, [&](int32_t p, int32_t run) { if (p >= cb - 1 && p < ce) amax(&ins[p - (cb - 1)], (uint32_t)run); });
-    if (s.bad_op) { add(&w.counters[1], 1ull); return; }
-    if (s.last < v.start) return;                                  // no reference-consuming op: see DESIGN.md
-    if (bayes_mq) {
-        uint8_t *wq = w.qual + (size_t)w.base_off8[r] * 8;
-        const char *md = nullptr; int md_len = 0;
-        if (w.n_xcols > 0) { const uint32_t a = w.xcol_off[r * w.n_xcols], b = w.xcol_off[r * w.n_xcols + 1]; md = w.xcol_text + a; md_len = (int)(b - a); }
-        if (!read_prepare(o, t, v, wq, md, md_len, w.nm + (size_t)w.base_off8[r] * 8)) return;
+    if (s.bad_op) return -1;
+    if (s.last < v.start) return 0;                                // no reference-consuming op: see DESIGN.md
+    // plain: clips around exactly one M / = / X block
+    int32_t n_al = 0, lead = 0; bool plain = true;
+    for (int k = 0; k < v.n_cigar; ++k) {
+        const int op = (int)(v.cigar[k] & 15u); const int32_t len = (int32_t)(v.cigar[k] >> 4);
+        if (op == 0 || op == 7 || op == 8) { n_al++; if (len == 0) plain = false; }
+        else if (op == 4) { if (!n_al) lead += len; }
+        else if (op != 5) plain = false;
     }
-    w.r_keep[r] = 1 | ((fl & 16) ? 2u : 0u);
-    w.r_last[r] = s.last; w.r_tail[r] = s.tail_run;
-    add(&w.counters[0], 1ull);
+    plain = plain && n_al == 1;
+    // the per-read preparation (only l_qseq <= 0 makes it drop a read, and that was tested above) runs here in the harness
+    // and in its own LDS-staged kernel on the device
+    if (bayes_mq && prepare_here) {
+        const char *md = nullptr; int md_len = 0;
+        md_of(w, r, md, md_len);
+        read_prepare(o, t, v, w.qual + (size_t)w.base_off8[r] * 8, md, md_len, w.nm + (size_t)w.base_off8[r] * 8);
+    }
+    w.r_keep[r] = 1u | ((fl & 16) ? 2u : 0u) | (plain ? 4u : 0u);
+    w.r_last[r] = s.last; w.r_tail[r] = plain ? lead : s.tail_run;
+    return 1;
 }
 
-CONS_HD void step_read_b(const Win &w, int64_t r)
+// true: the read needs the cursor walk (goes on clist)
+CONS_HD bool step_read_b(const Win &w, int64_t r, uint32_t &alive /* columns the read is in */)
 {
     const int32_t W = w.col_end - w.col_beg;
     int32_t st = w.pos[r]; if (st < w.col_beg) st = w.col_beg; if (st > w.col_end) st = w.col_end;
@@ -82,9 +105,45 @@ CONS_HD void step_read_b(const Win &w, int64_t r)
     int32_t ce = cs - 1;
     if (w.r_keep[r] && w.pos[r] < w.col_end && w.r_last[r] >= w.col_beg) {
         const int32_t last = w.r_last[r];
-        ce = last < w.col_end ? (int32_t)w.colbase[last - w.col_beg] + w.r_tail[r] : (int32_t)w.colbase[W] - 1;
+        const int32_t tail = (w.r_keep[r] & 4u) ? 0 : w.r_tail[r];
+        ce = last < w.col_end ? (int32_t)w.colbase[last - w.col_beg] + tail : (int32_t)w.colbase[W] - 1;
     }
-    w.cs[r] = cs; w.ce[r] = ce; w.cnt[r] = (uint32_t)(ce - cs + 1);
+    alive = ce >= cs ? (uint32_t)(ce - cs + 1) : 0u;
+    const bool walk = ce >= cs && !(w.r_keep[r] & 4u);
+    w.cs[r] = cs; w.ce[r] = ce; w.cnt[r] = walk ? (uint32_t)(ce - cs + 1) : 0u;
+    return walk;
+}
+
+CONS_HD void step_colpos(const Win &w, int64_t i)               // i = position index inside the window
+{
+    const uint64_t c0 = w.colbase[i], c1 = w.colbase[i + 1];
+    for (uint64_t c = c0; c < c1; ++c) w.colpos[c] = w.col_beg + (int32_t)i;
+}
+
+// what a plain read shows in column ci: the base at its start-relative offset, or a pad opposite somebody else's insertion
+// (Cursor::step reduced to a single aligned block: no reference skips, no own insertions, the read ends on nth 0)
+CONS_HD uint32_t plain_entry(const Win &w, bool bayes_mq, bool working_qual, int64_t r, int32_t ci, uint32_t &nmw)
+{
+    const int32_t p = w.colpos[ci], nth = ci - (int32_t)w.colbase[p - w.col_beg];
+    const int32_t so = p - w.pos[r] + w.r_tail[r], lq = w.l_qseq[r];
+    const size_t pool = (size_t)w.base_off8[r] * 8;
+    const uint8_t *q = (working_qual ? w.qual : w.qual_in) + pool;
+    int base4, qual;
+    if (so < lq) { qual = q[so]; base4 = seqi(w.seq + pool / 2, so); } else { qual = 0xff; base4 = 15; }
+    if (nth > 0) {
+        base4 = 16;
+        if (so < lq) { const int q1 = so + 1 < lq ? q[so + 1] : 0; if (q1 < qual) qual = q1; } else qual = 0;
+    }
+    nmw = bayes_mq ? nm_word(w.nm + pool, lq, so) : 0u;
+    return (uint32_t)base4 | ((uint32_t)(qual & 255) << 5) | ((w.r_keep[r] & 2u) ? CONS_E_REV : 0u);
+}
+
+CONS_HD uint32_t entry_at(const Win &w, bool bayes_mq, bool working_qual, int64_t r, int32_t ci, uint32_t &nmw)
+{
+    if (w.r_keep[r] & 4u) return plain_entry(w, bayes_mq, working_qual, r, ci, nmw);
+    const uint64_t at = w.rowoff[r] + (uint32_t)(ci - w.cs[r]);
+    nmw = bayes_mq ? w.Enm[at] : 0u;
+    return w.E[at];
 }
 
 CONS_HD void step_walk(const Win &w, const Par &o, int64_t r)
@@ -140,27 +199,30 @@ CONS_HD int64_t lower_ge(const int32_t *key, int64_t n, int32_t c)
     return lo;
 }
 
-CONS_HD void step_col(const Win &w, const Par &o, const Tables &t, int64_t c)
+// KIND: 0 frequency caller, 1 one Bayesian parameter set, 2 both (mixed mode) -- separate instantiations keep the
+// accumulators of the modes that are not running out of the registers
+template <int KIND> CONS_HD void step_col(const Win &w, const Par &o, const Tables &t, int64_t c)
 {
     const int32_t ci = (int32_t)c;
     const int64_t hi = upper_le(w.cs, w.n_reads, ci), lo = lower_ge(w.pmax, w.n_reads, ci);
+    const bool bayes_mq = o.mode != MODE_SIMPLE && o.use_mqual, workq = bayes_mq && o.homopoly_on;
     int32_t td = 0;
     for (int64_t r = lo; r < hi; ++r) td += w.ce[r] >= ci;
     sta_cons_col out; out.depth = td; out.base = 'N'; out.qual = 0;
     w.depth[c] = (uint32_t)td;
     if (td == 0) { w.cols[c] = out; return; }
-    if (o.mode == MODE_SIMPLE) {
+    if (KIND == 0) {
         SimpleAcc acc; acc.init();
-        for (int64_t r = lo; r < hi; ++r) if (w.ce[r] >= ci) acc.add(o, w.E[w.rowoff[r] + (uint32_t)(ci - w.cs[r])]);
+        for (int64_t r = lo; r < hi; ++r) { if (w.ce[r] < ci) continue; uint32_t nmw; acc.add(o, entry_at(w, false, false, r, ci, nmw)); }
         int32_t q; out.base = acc.finish(o, q); out.qual = q;
     } else {
-        const bool mixed = o.mode == MODE_MIXED;
+        const bool mixed = KIND == 2;
         const Probs &cp1 = o.mode == MODE_PRECISE || mixed ? t.precise : t.recall;
-        Gap5Acc a1, a2; a1.init(); a2.init();
+        Gap5Acc a1, a2; a1.init(); if (mixed) a2.init();
         for (int64_t r = lo; r < hi; ++r) {
             if (w.ce[r] < ci) continue;
-            const uint64_t at = w.rowoff[r] + (uint32_t)(ci - w.cs[r]);
-            const uint32_t e = w.E[at], nmw = o.use_mqual ? w.Enm[at] : 0u;
+            uint32_t nmw;
+            const uint32_t e = entry_at(w, bayes_mq, workq, r, ci, nmw);
             const int q0 = w.l_qseq[r] > 0 ? w.qual_in[(size_t)w.base_off8[r] * 8] : 0;
             a1.add(o, t, cp1, e, nmw, w.mapq[r], q0, td);
             if (mixed) a2.add(o, t, t.recall, e, nmw, w.mapq[r], q0, td);
@@ -172,15 +234,19 @@ CONS_HD void step_col(const Win &w, const Par &o, const Tables &t, int64_t c)
     w.cols[c] = out;
 }
 
-CONS_HD void step_text(const Win &w, int64_t c)
+CONS_HD int col_kind(const Par &o) { return o.mode == MODE_SIMPLE ? 0 : o.mode == MODE_MIXED ? 2 : 1; }
+
+CONS_HD void step_text(const Win &w, const Par &o, int64_t c)
 {
     const int32_t ci = (int32_t)c;
     if (!w.depth[c]) return;
     const int64_t hi = upper_le(w.cs, w.n_reads, ci), lo = lower_ge(w.pmax, w.n_reads, ci);
+    const bool workq = o.mode != MODE_SIMPLE && o.use_mqual && o.homopoly_on;
     uint64_t at = w.col_off[c];
     for (int64_t r = lo; r < hi; ++r) {
         if (w.ce[r] < ci) continue;
-        const uint32_t e = w.E[w.rowoff[r] + (uint32_t)(ci - w.cs[r])];
+        uint32_t nmw;
+        const uint32_t e = entry_at(w, false, workq, r, ci, nmw);
         const int b4 = CONS_E_BASE4(e);
         char ch = (e & CONS_E_SKIPCOL) ? '.' : b4 >= 16 ? '*' : "NACMGRSVTWYHKDBN"[b4];
         if (e & CONS_E_REV) ch = ch == '*' ? '#' : (ch >= 'A' && ch <= 'Z' ? (char)(ch + 32) : ch);

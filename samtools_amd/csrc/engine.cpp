@@ -68,7 +68,7 @@ struct sta_engine {
     std::vector<int32_t> min_pos, max_pos_hint;
     DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
-    DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm;
+    DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
     cons::Win cons_w{}; uint64_t cons_ncols = 0, cons_nentries = 0; int64_t cons_W = 0; bool cons_text = false;
     int baq_slab_gib_cap = 0;       // 0 = default; 4 after a one-launch BAQ slab could not be allocated
@@ -180,7 +180,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->offs, &e->scan_tmp, &e->counters, &e->table,
                       &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
-                      &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm };
+                      &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
     if (e->side_done) hipEventDestroy(e->side_done);
@@ -810,7 +810,7 @@ int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *i
     auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
     const size_t o_ins = carve((size_t)(W + 1) * 4), o_len = carve((size_t)(W + 1) * 4), o_colbase = carve((size_t)(W + 2) * 8);
     const size_t o_last = carve((size_t)n * 4), o_tail = carve((size_t)n * 4), o_keep = carve((size_t)n * 4), o_cs = carve((size_t)n * 4),
-                 o_ce = carve((size_t)n * 4), o_pmax = carve((size_t)n * 4), o_cnt = carve((size_t)n * 4), o_rowoff = carve((size_t)(n + 2) * 8), o_ctr = carve(64);
+                 o_ce = carve((size_t)n * 4), o_pmax = carve((size_t)n * 4), o_cnt = carve((size_t)n * 4), o_rowoff = carve((size_t)(n + 2) * 8), o_clist = carve((size_t)n * 4), o_ctr = carve(64);
     if (e->cons_ws.ensure(off + 256) || e->scan_tmp.ensure(sta_scan_tmp_bytes(std::max<int64_t>(std::max(W, n), 1) * 2) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(consensus workspace) failed");
     char *ws = (char *)e->cons_ws.p;
     cons::Win w; memset(&w, 0, sizeof w);
@@ -820,7 +820,7 @@ int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *i
     w.ins = (uint32_t *)(ws + o_ins); w.colbase = (uint64_t *)(ws + o_colbase);
     w.r_last = (int32_t *)(ws + o_last); w.r_tail = (int32_t *)(ws + o_tail); w.r_keep = (uint32_t *)(ws + o_keep);
     w.cs = (int32_t *)(ws + o_cs); w.ce = (int32_t *)(ws + o_ce); w.pmax = (int32_t *)(ws + o_pmax); w.cnt = (uint32_t *)(ws + o_cnt);
-    w.rowoff = (uint64_t *)(ws + o_rowoff); w.counters = (unsigned long long *)(ws + o_ctr);
+    w.rowoff = (uint64_t *)(ws + o_rowoff); w.clist = (int32_t *)(ws + o_clist); w.counters = (unsigned long long *)(ws + o_ctr);
     uint32_t *collen = (uint32_t *)(ws + o_len);
     w.qual = const_cast<uint8_t *>(d.qual_in);
     if (bayes_mq) {
@@ -832,6 +832,7 @@ int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *i
     HIPCHK(hipMemsetAsync(w.ins, 0, (size_t)(W + 1) * 4, s));
     HIPCHK(hipMemsetAsync(w.counters, 0, 64, s));
     { ProfScope ps(e, "cons_read_a"); sta_launch_cons_read_a(s, w, o, tab); }
+    if (bayes_mq) { ProfScope ps(e, "cons_prepare"); sta_launch_cons_prepare(s, w, o, tab); }
     { ProfScope ps(e, "cons_scans");
       sta_launch_cons_collen(s, w.ins, collen, W);
       sta_launch_len_scan(s, collen, w.colbase, W, e->scan_tmp.p, e->scan_tmp.cap); }
@@ -839,34 +840,37 @@ int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *i
     { ProfScope ps(e, "cons_scans");
       sta_launch_len_scan(s, w.cnt, w.rowoff, n, e->scan_tmp.p, e->scan_tmp.cap);
       if (n > 0) sta_launch_scan_max_i32(s, w.ce, w.pmax, n, e->scan_tmp.p); }
-    uint64_t n_entries = 0, n_cols = 0; unsigned long long ctr[2] = { 0, 0 };
+    uint64_t n_entries = 0, n_cols = 0; unsigned long long ctr[4] = { 0, 0, 0, 0 };
     HIPCHK(hipMemcpyAsync(&n_entries, w.rowoff + n, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&n_cols, w.colbase + W, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(ctr, w.counters, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ctr, w.counters, 32, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (ctr[1]) return fail(e, STA_ERR_ARG, "a CIGAR holds an operation outside MIDNSHP=X");
     if (e->cons_E.ensure((size_t)n_entries * 4 + 64) || (bayes_mq && e->cons_Enm.ensure((size_t)n_entries * 4 + 64)) || e->cons_cols.ensure((size_t)n_cols * sizeof(sta_cons_col) + 64)
-        || e->cons_depth.ensure((size_t)n_cols * 4 + 64))
+        || e->cons_depth.ensure((size_t)n_cols * 4 + 64) || e->cons_colpos.ensure((size_t)n_cols * 4 + 64))
         return fail(e, STA_ERR_HIP, "hipMalloc(consensus entries) failed");
+    w.colpos = (int32_t *)e->cons_colpos.p;
+    const uint64_t sum_depth = ctr[3];
     w.E = (uint32_t *)e->cons_E.p; w.Enm = bayes_mq ? (uint32_t *)e->cons_Enm.p : nullptr;
     w.cols = (sta_cons_col *)e->cons_cols.p; w.depth = (uint32_t *)e->cons_depth.p;
-    { ProfScope ps(e, "cons_walk"); sta_launch_cons_walk(s, w, o); }
+    { ProfScope ps(e, "cons_colpos"); sta_launch_cons_colpos(s, w); }
+    { ProfScope ps(e, "cons_walk"); sta_launch_cons_walk(s, w, o, (int64_t)ctr[2]); }
     { ProfScope ps(e, "cons_col"); sta_launch_cons_col(s, w, o, tab, (int64_t)n_cols); }
     e->cons_text = cp->want_pileup != 0;
     if (e->cons_text) {
-        if (e->cons_coloff.ensure((size_t)(n_cols + 2) * 8 + 64) || e->cons_seq.ensure((size_t)n_entries + 64) || e->cons_qual.ensure((size_t)n_entries + 64)
+        if (e->cons_coloff.ensure((size_t)(n_cols + 2) * 8 + 64) || e->cons_seq.ensure((size_t)sum_depth + 64) || e->cons_qual.ensure((size_t)sum_depth + 64)
             || e->scan_tmp.ensure(sta_scan_tmp_bytes((int64_t)n_cols + 1) + 64))
             return fail(e, STA_ERR_HIP, "hipMalloc(consensus text) failed");
         w.col_off = (uint64_t *)e->cons_coloff.p; w.seq_chars = (char *)e->cons_seq.p; w.qual_chars = (char *)e->cons_qual.p;
         { ProfScope ps(e, "cons_scans"); sta_launch_len_scan(s, w.depth, w.col_off, (int64_t)n_cols, e->scan_tmp.p, e->scan_tmp.cap); }
-        { ProfScope ps(e, "cons_text"); sta_launch_cons_text(s, w, (int64_t)n_cols); }
+        { ProfScope ps(e, "cons_text"); sta_launch_cons_text(s, w, o, (int64_t)n_cols); }
     }
     HIPCHK(hipStreamSynchronize(s));
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "consensus kernels");
     prof_drain(e);
-    e->cons_w = w; e->cons_ncols = n_cols; e->cons_nentries = n_entries; e->cons_W = W;
-    if (info) { info->n_cols = n_cols; info->n_entries = n_entries; info->n_kept_reads = ctr[0]; }
+    e->cons_w = w; e->cons_ncols = n_cols; e->cons_nentries = sum_depth; e->cons_W = W;
+    if (info) { info->n_cols = n_cols; info->n_entries = sum_depth; info->n_kept_reads = ctr[0]; }
     e->planned = 6;
     return STA_OK;
 }

@@ -10,11 +10,71 @@
 
 using namespace cons;
 
+__device__ __forceinline__ unsigned long long wave_sum_ull(unsigned long long v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;       // lane 0 holds the sum
+}
+
 __global__ void __launch_bounds__(256) k_cons_read_a(Win w, Par o, const Tables *t)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= w.n_reads) return;
-    step_read_a(w, o, *t, r, [](uint32_t *p, uint32_t v) { atomicMax(p, v); }, [](unsigned long long *p, unsigned long long v) { atomicAdd(p, v); });
+    int code = 0;
+    if (r < w.n_reads) code = step_read_a(w, o, *t, r, [](uint32_t *p, uint32_t v) { atomicMax(p, v); }, false);
+    // one atomic per wave, not per read: a single counter word takes ~90 atomics per microsecond
+    const unsigned long long kept = __ballot(code > 0), bad = __ballot(code < 0);
+    if ((threadIdx.x & 63) == 0) {
+        if (kept) atomicAdd(&w.counters[0], (unsigned long long)__popcll(kept));
+        if (bad) atomicAdd(&w.counters[1], (unsigned long long)__popcll(bad));
+    }
+}
+
+// nm_init for the Bayesian mode: one wave per 64 consecutive reads.  A lane working through its own read touches its
+// qualities / bases / nm words byte by byte, several passes; straight from HBM that is 64 different cache lines per load
+// instruction.  The wave therefore copies the (contiguous) pool slice of its 64 reads into LDS with coalesced loads, every
+// lane runs read_prepare() on LDS, and the nm words (and rewritten qualities) go back with coalesced stores.
+#define PREP_CAP 10240                  // pool bytes of 64 reads the LDS slice holds (64 x 160)
+__global__ void __launch_bounds__(64) k_cons_prepare(Win w, Par o, const Tables *t)
+{
+    extern __shared__ unsigned char lds[];
+    uint8_t *lq = lds;                                   // PREP_CAP
+    uint8_t *ls = lds + PREP_CAP;                        // PREP_CAP / 2
+    int32_t *ln = (int32_t *)(lds + PREP_CAP + PREP_CAP / 2);      // PREP_CAP words
+    const int lane = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 64, r1 = r0 + 64 < w.n_reads ? r0 + 64 : w.n_reads;
+    const int64_t r = r0 + lane;
+    const int64_t first = (int64_t)w.base_off8[r0] * 8;
+    const int64_t end = (int64_t)w.base_off8[r1 - 1] * 8 + ((w.l_qseq[r1 - 1] + 7) & ~7);
+    const bool mine = r < r1 && (w.r_keep[r] & 1u);
+    const char *md = nullptr; int md_len = 0;
+    if (mine) md_of(w, r, md, md_len);
+    const int64_t B = end - first;
+    bool staged = B > 0 && B <= PREP_CAP;
+    if (staged) {
+        // every read of the slice must lie inside it, in order
+        const int64_t off = r < r1 ? (int64_t)w.base_off8[r] * 8 - first : 0;
+        const bool ok = r >= r1 || (off >= 0 && off + ((w.l_qseq[r] + 7) & ~7) <= B);
+        staged = __all(ok);
+    }
+    if (!staged) {
+        if (mine) { ReadView v = view_of(w, r, false); read_prepare(o, *t, v, w.qual + (size_t)w.base_off8[r] * 8, md, md_len, w.nm + (size_t)w.base_off8[r] * 8); }
+        return;
+    }
+    const uint32_t *gq = (const uint32_t *)(w.qual_in + first);          // pool offsets are multiples of 8
+    const uint32_t *gs = (const uint32_t *)(w.seq + first / 2);
+    for (int64_t i = lane; i < B / 4; i += 64) ((uint32_t *)lq)[i] = gq[i];
+    for (int64_t i = lane; i < B / 8; i += 64) ((uint32_t *)ls)[i] = gs[i];
+    __syncthreads();
+    if (mine) {
+        const int64_t off = (int64_t)w.base_off8[r] * 8 - first;
+        ReadView v = view_of(w, r, false);
+        v.seq = ls + off / 2; v.qual = lq + off;
+        read_prepare(o, *t, v, lq + off, md, md_len, ln + off);
+    }
+    __syncthreads();
+    int32_t *gn = w.nm + first;
+    for (int64_t i = lane; i < B; i += 64) gn[i] = ln[i];
+    if (o.homopoly_on) { uint32_t *gw = (uint32_t *)(w.qual + first); for (int64_t i = lane; i < B / 4; i += 64) gw[i] = ((uint32_t *)lq)[i]; }
 }
 
 // lengths for the column-index scan: position i of the window owns 1 + ins[i + 1] columns (ins[0] is the look-back position)
@@ -27,25 +87,41 @@ __global__ void __launch_bounds__(256) k_cons_collen(const uint32_t *ins, uint32
 __global__ void __launch_bounds__(256) k_cons_read_b(Win w)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < w.n_reads) step_read_b(w, r);
+    uint32_t alive = 0;
+    const bool walk = r < w.n_reads ? step_read_b(w, r, alive) : false;
+    // reads that need the cursor walk are appended to clist (any order), again one atomic per wave
+    const unsigned long long m = __ballot(walk);
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == 0 && m) base = atomicAdd(&w.counters[2], (unsigned long long)__popcll(m));
+    base = __shfl(base, 0);
+    if (walk) w.clist[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)r;
+    const unsigned long long tot = wave_sum_ull(alive);
+    if (lane == 0 && tot) atomicAdd(&w.counters[3], tot);
 }
 
-__global__ void __launch_bounds__(256) k_cons_walk(Win w, Par o)
+__global__ void __launch_bounds__(256) k_cons_colpos(Win w, int64_t W)
 {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < w.n_reads) step_walk(w, o, r);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W) step_colpos(w, i);
 }
 
-__global__ void __launch_bounds__(256) k_cons_col(Win w, Par o, const Tables *t, int64_t n_cols)
+__global__ void __launch_bounds__(256) k_cons_walk(Win w, Par o, int64_t n_list)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_list) step_walk(w, o, w.clist[k]);
+}
+
+template <int KIND> __global__ void __launch_bounds__(256) k_cons_col(Win w, Par o, const Tables *t, int64_t n_cols)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_cols) step_col(w, o, *t, c);
+    if (c < n_cols) step_col<KIND>(w, o, *t, c);
 }
 
-__global__ void __launch_bounds__(256) k_cons_text(Win w, int64_t n_cols)
+__global__ void __launch_bounds__(256) k_cons_text(Win w, Par o, int64_t n_cols)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_cols) step_text(w, c);
+    if (c < n_cols) step_text(w, o, c);
 }
 
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
@@ -53,6 +129,10 @@ static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256
 void sta_launch_cons_read_a(hipStream_t s, const Win &w, const Par &o, const Tables *t)
 {
     if (w.n_reads > 0) hipLaunchKernelGGL(k_cons_read_a, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, o, t);
+}
+void sta_launch_cons_prepare(hipStream_t s, const Win &w, const Par &o, const Tables *t)
+{
+    if (w.n_reads > 0) hipLaunchKernelGGL(k_cons_prepare, dim3((unsigned)((w.n_reads + 63) / 64)), dim3(64), PREP_CAP * 5 + PREP_CAP / 2, s, w, o, t);
 }
 void sta_launch_cons_collen(hipStream_t s, const uint32_t *ins, uint32_t *len, int64_t W)
 {
@@ -62,15 +142,24 @@ void sta_launch_cons_read_b(hipStream_t s, const Win &w)
 {
     if (w.n_reads > 0) hipLaunchKernelGGL(k_cons_read_b, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w);
 }
-void sta_launch_cons_walk(hipStream_t s, const Win &w, const Par &o)
+void sta_launch_cons_colpos(hipStream_t s, const Win &w)
 {
-    if (w.n_reads > 0) hipLaunchKernelGGL(k_cons_walk, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, o);
+    const int64_t W = (int64_t)w.col_end - w.col_beg;
+    if (W > 0) hipLaunchKernelGGL(k_cons_colpos, dim3(blocks_for(W)), dim3(256), 0, s, w, W);
+}
+void sta_launch_cons_walk(hipStream_t s, const Win &w, const Par &o, int64_t n_list)
+{
+    if (n_list > 0) hipLaunchKernelGGL(k_cons_walk, dim3(blocks_for(n_list)), dim3(256), 0, s, w, o, n_list);
 }
 void sta_launch_cons_col(hipStream_t s, const Win &w, const Par &o, const Tables *t, int64_t n_cols)
 {
-    if (n_cols > 0) hipLaunchKernelGGL(k_cons_col, dim3(blocks_for(n_cols)), dim3(256), 0, s, w, o, t, n_cols);
+    if (n_cols <= 0) return;
+    const int kind = col_kind(o);
+    if (kind == 0) hipLaunchKernelGGL(k_cons_col<0>, dim3(blocks_for(n_cols)), dim3(256), 0, s, w, o, t, n_cols);
+    else if (kind == 1) hipLaunchKernelGGL(k_cons_col<1>, dim3(blocks_for(n_cols)), dim3(256), 0, s, w, o, t, n_cols);
+    else hipLaunchKernelGGL(k_cons_col<2>, dim3(blocks_for(n_cols)), dim3(256), 0, s, w, o, t, n_cols);
 }
-void sta_launch_cons_text(hipStream_t s, const Win &w, int64_t n_cols)
+void sta_launch_cons_text(hipStream_t s, const Win &w, const Par &o, int64_t n_cols)
 {
-    if (n_cols > 0) hipLaunchKernelGGL(k_cons_text, dim3(blocks_for(n_cols)), dim3(256), 0, s, w, n_cols);
+    if (n_cols > 0) hipLaunchKernelGGL(k_cons_text, dim3(blocks_for(n_cols)), dim3(256), 0, s, w, o, n_cols);
 }

@@ -34,31 +34,35 @@ static int emul(const sta_window &w, const sta_cons_params &p, ConsWindowOut &ou
     d.ins = ins.data(); d.colbase = colbase.data(); d.r_last = r_last.data(); d.r_tail = r_tail.data(); d.r_keep = keep.data();
     d.cs = cs.data(); d.ce = ce.data(); d.pmax = pmax.data(); d.cnt = cnt.data(); d.rowoff = rowoff.data(); d.counters = counters;
     auto amax = [](uint32_t *q, uint32_t v) { if (*q < v) *q = v; };
-    auto add = [](unsigned long long *q, unsigned long long v) { *q += v; };
-    for (int64_t r = 0; r < n; ++r) cons::step_read_a(d, o, tab, r, amax, add);
+    for (int64_t r = 0; r < n; ++r) { const int code = cons::step_read_a(d, o, tab, r, amax, true); counters[code < 0 ? 1 : 0] += code != 0; }
     if (counters[1]) { err = "a CIGAR holds an operation outside MIDNSHP=X"; return -1; }
     colbase[0] = 0;
     for (int32_t i = 0; i < W; ++i) colbase[(size_t)i + 1] = colbase[(size_t)i] + 1 + ins[(size_t)i + 1];
-    for (int64_t r = 0; r < n; ++r) cons::step_read_b(d, r);
+    std::vector<int32_t> colpos(colbase[(size_t)W] + 1), clist;
+    d.colpos = colpos.data();
+    for (int32_t i = 0; i < W; ++i) cons::step_colpos(d, i);
+    uint64_t sum_depth = 0;
+    for (int64_t r = 0; r < n; ++r) { uint32_t alive; if (cons::step_read_b(d, r, alive)) clist.push_back((int32_t)r); sum_depth += alive; }
     rowoff[0] = 0;
     for (int64_t r = 0; r < n; ++r) { rowoff[(size_t)r + 1] = rowoff[(size_t)r] + cnt[(size_t)r]; pmax[(size_t)r] = r ? std::max(pmax[(size_t)r - 1], ce[(size_t)r]) : ce[(size_t)r]; }
     const uint64_t n_entries = rowoff[(size_t)n], n_cols = colbase[(size_t)W];
     std::vector<uint32_t> E(n_entries + 1), Enm(bayes_mq ? n_entries + 1 : 1), depth(n_cols + 1);
     d.E = E.data(); d.Enm = bayes_mq ? Enm.data() : nullptr;
-    for (int64_t r = 0; r < n; ++r) cons::step_walk(d, o, r);
+    for (int32_t r : clist) cons::step_walk(d, o, r);
     out.cols.assign(n_cols, sta_cons_col{ 0, 0, 0 });
     d.cols = out.cols.data(); d.depth = depth.data();
-    for (uint64_t c = 0; c < n_cols; ++c) cons::step_col(d, o, tab, (int64_t)c);
+    const int kind = cons::col_kind(o);
+    for (uint64_t c = 0; c < n_cols; ++c) { if (kind == 0) cons::step_col<0>(d, o, tab, (int64_t)c); else if (kind == 1) cons::step_col<1>(d, o, tab, (int64_t)c); else cons::step_col<2>(d, o, tab, (int64_t)c); }
     out.ins.assign(ins.begin() + 1, ins.end());
-    out.info.n_cols = n_cols; out.info.n_entries = n_entries; out.info.n_kept_reads = counters[0];
+    out.info.n_cols = n_cols; out.info.n_entries = sum_depth; out.info.n_kept_reads = counters[0];
     if (p.want_pileup) {
         out.col_off.resize(n_cols + 1);
         out.col_off[0] = 0;
         for (uint64_t c = 0; c < n_cols; ++c) out.col_off[c + 1] = out.col_off[c] + depth[c];
-        if (out.col_off[n_cols] != n_entries) { err = "column depths do not add up to the entries"; return -1; }
-        out.seq.assign(n_entries + 1, 0); out.qual.assign(n_entries + 1, 0);
+        if (out.col_off[n_cols] != sum_depth) { err = "column depths do not add up to the reads' columns"; return -1; }
+        out.seq.assign(sum_depth + 1, 0); out.qual.assign(sum_depth + 1, 0);
         d.col_off = out.col_off.data(); d.seq_chars = out.seq.data(); d.qual_chars = out.qual.data();
-        for (uint64_t c = 0; c < n_cols; ++c) cons::step_text(d, (int64_t)c);
+        for (uint64_t c = 0; c < n_cols; ++c) cons::step_text(d, o, (int64_t)c);
     }
     return 0;
 }

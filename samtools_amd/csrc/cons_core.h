@@ -205,6 +205,9 @@ CONS_HD double fast_exp(const Tables &t, double y)
     return t.e_tab[500 + (int)y];
 }
 
+struct Par; struct ReadView;
+CONS_HD void read_prepare_md(const Par &o, const ReadView &r, const char *md, int md_len, int32_t *nm);
+
 // ---- per-read preparation: nm[i] = homopolymer run << 24 | local edit cost; may rewrite the working qualities ----
 // md / md_len: the MD:Z text (md_len = 0 or text not starting with a digit: no tag).  Returns 0 if the read leaves the pileup.
 CONS_HD int read_prepare(const Par &o, const Tables &t, const ReadView &r, uint8_t *qual /* writable working copy */, const char *md, int md_len, int32_t *nm)
@@ -269,8 +272,47 @@ CONS_HD int read_prepare(const Par &o, const Tables &t, const ReadView &r, uint8
         for (int k = i; k < j; k++) { const int cur = nm[k] >> 24; nm[k] = ((poly > cur ? poly : cur) << 24) | (nm[k] & 0xffffff); }
         i = j - 1;
     }
-    if (md_len <= 0 || md[0] < '0' || md[0] > '9') return 1;
+    read_prepare_md(o, r, md, md_len, nm);
+    return 1;
+}
+
+// ---- the same preparation, one base at a time ----
+// With homopolymer fixing off and outside the samtools-1.16 mode (the defaults) the sequential loops of nm_init collapse:
+// polyl / polyr never move, so the "minimum quality of the run" a base is compared with is simply the previous base's
+// quality (the initial value for the first tested base, the last main-loop value for the final 8 bases), and the window
+// minimum qmin is not used at all.  That lets the device compute every base independently (lane per base, coalesced) instead
+// of one lane walking one read.  The MD / soft-clip costs are added afterwards by read_prepare_md().
+CONS_HD bool prepare_is_per_base(const Par &o) { return !o.homopoly_on && o.mode != MODE_BAYES_116; }
+
+CONS_HD int32_t prepare_base(const Par &o, const ReadView &r, int i)
+{
+    const int qlen = r.l_qseq;
+    const uint8_t *qual = r.qual, *seq = r.seq;
+    int adj = 0;
+    if (o.adj_qual && i >= 8) {
+        int qminp0 = qual[0];
+        if (qlen > 1 && seqi(seq, 1) == seqi(seq, 0) && qminp0 > qual[1]) qminp0 = qual[1];
+        int qminp;
+        if (qlen > 16) qminp = i < qlen - 8 ? (i == 8 ? qminp0 : qual[i - 1]) : qual[qlen - 9];
+        else qminp = qminp0;
+        const int tq = qual[i] / 3 + qminp;
+        adj = tq < qual[i] ? qual[i] - tq : 0;
+    }
+    const int base = seqi(seq, i);
+    int lo = i, hi = i;                                  // run of equal codes around i, searched no further than the cap needs
+    while (lo > 0 && i - lo < 101 && seqi(seq, lo - 1) == base) --lo;
+    while (hi + 1 < qlen && hi - lo < 101 && seqi(seq, hi + 1) == base) ++hi;
+    int poly = hi - lo; if (poly > 100) poly = 100;
+    return (poly << 24) | adj;
+}
+
+// soft-clip and MD mismatch costs on top of nm[] (the tail of nm_init, bam_consensus.c:1138-1203)
+CONS_HD void read_prepare_md(const Par &o, const ReadView &r, const char *md, int md_len, int32_t *nm)
+{
+    const int qlen = r.l_qseq;
+    if (qlen <= 0 || md_len <= 0 || md[0] < '0' || md[0] > '9') return;
     const int halo = o.nm_halo;
+    int i;
     const int op0 = (int)(r.cigar[0] & 15u), opn = (int)(r.cigar[r.n_cigar - 1] & 15u);
     if (op0 == 4 || (op0 == 5 && r.n_cigar > 1 && (int)(r.cigar[1] & 15u) == 4)) {
         for (i = 0; i < halo && i < qlen; i++) nm[i] += o.sc_cost;
@@ -295,7 +337,6 @@ CONS_HD int read_prepare(const Par &o, const Tables &t, const ReadView &r, uint8
         for (; i < pos + halo * 2 && i < qlen; i++) nm[i] += 5;
         m++;
     }
-    return 1;
 }
 
 // ---- frequency caller ----
@@ -344,15 +385,16 @@ struct Gap5Acc {
     double S[15];
     int32_t n_N, depth;
     CONS_HD void init() { for (int j = 0; j < 15; ++j) S[j] = 0; n_N = 0; depth = 0; }
-    // e: entry; nmw: nm word (0 when the read has none); mapq: mapping quality; q0: first quality byte of the read;
-    // td: number of reads alive in the column
-    CONS_HD void add(const Par &o, const Tables &t, const Probs &cp, uint32_t e, uint32_t nmw, int mapq, int q0, int td)
+    // e: entry; nmw: nm word (0 when the read has none); mapq: mapping quality; td: number of reads alive in the column
+    // q2p / mqpow: Tables::q2p and ::mqual_pow_1m (the device keeps them and cp in LDS); q0_absent: the read's first quality
+    // byte is 0xff
+    CONS_HD void add(const Par &o, const double *q2p, const double *mqpow, const Probs &cp, uint32_t e, uint32_t nmw, int mapq, bool q0_absent, int td)
     {
         const int pq = CONS_E_QUAL(e);
         if (pq < o.min_qual) return;
         if (e & CONS_E_REFSKIP) return;
         int qual = pq;
-        if (qual == 255 || (qual == 0 && q0 == 255)) qual = o.default_qual & 255;
+        if (qual == 255 || (qual == 0 && q0_absent)) qual = o.default_qual & 255;
         const int b4 = CONS_E_BASE4(e);
         // =ACM GRSV TWYH KDBN * -> A C G T * N
         const int base = b4 >= 16 ? 4 : (b4 == 1 ? 0 : b4 == 2 ? 1 : b4 == 4 ? 2 : b4 == 8 ? 3 : 5);
@@ -366,7 +408,7 @@ struct Gap5Acc {
             mqual *= o.scale_mqual;
             if (mqual < o.low_mqual) mqual = o.low_mqual;
             if (mqual > o.high_mqual) mqual = o.high_mqual;
-            const double P = t.q2p[qual > 100 ? 100 : qual], M = t.mqual_pow_1m[(int)mqual & 255];
+            const double P = q2p[qual > 100 ? 100 : qual], M = mqpow[(int)mqual & 255];
             qual = (int)ph_log(P + .75 * M - P * M) & 255;
         }
         if (qual < 1) qual = 1;

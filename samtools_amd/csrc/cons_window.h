@@ -19,6 +19,14 @@
 
 namespace cons {
 
+// what the column kernels need of a read, in one 32-byte record (two 16-byte loads instead of eight scattered ones)
+struct alignas(16) Meta {
+    int32_t cs, ce, pos, lead;   // first / last column in the window, leftmost coordinate, leading clip (plain reads)
+    uint32_t pool8, lq;          // base_off8, l_qseq
+    uint32_t bits;               // r_keep bits | mapq << 8 | (first quality byte == 0xff) << 16
+    uint32_t pad;
+};
+
 struct Win {
     int64_t n_reads;
     const int32_t *pos; const uint16_t *flag; const uint8_t *mapq; const int32_t *l_qseq;
@@ -34,6 +42,7 @@ struct Win {
     int32_t *r_last, *r_tail; uint32_t *r_keep;      // r_keep: 1 in the pileup, 2 reverse strand, 4 plain; r_tail of a plain read = its leading clip
     int32_t *colpos;             // [n_cols] position (relative to the origin) of every column
     int32_t *clist;              // reads that need the cursor walk
+    Meta *meta;
     int32_t *cs, *ce, *pmax; uint32_t *cnt; uint64_t *rowoff;
     uint32_t *E, *Enm;
     sta_cons_col *cols; uint32_t *depth; uint64_t *col_off; char *seq_chars, *qual_chars;
@@ -89,7 +98,11 @@ template <class AMAX> CONS_HD int step_read_a(const Win &w, const Par &o, const 
     if (bayes_mq && prepare_here) {
         const char *md = nullptr; int md_len = 0;
         md_of(w, r, md, md_len);
-        read_prepare(o, t, v, w.qual + (size_t)w.base_off8[r] * 8, md, md_len, w.nm + (size_t)w.base_off8[r] * 8);
+        int32_t *nm = w.nm + (size_t)w.base_off8[r] * 8;
+        if (prepare_is_per_base(o)) {                              // the formulation the device runs one lane per base
+            for (int i = 0; i < v.l_qseq; ++i) nm[i] = prepare_base(o, v, i);
+            read_prepare_md(o, v, md, md_len, nm);
+        } else read_prepare(o, t, v, w.qual + (size_t)w.base_off8[r] * 8, md, md_len, nm);
     }
     w.r_keep[r] = 1u | ((fl & 16) ? 2u : 0u) | (plain ? 4u : 0u);
     w.r_last[r] = s.last; w.r_tail[r] = plain ? lead : s.tail_run;
@@ -111,6 +124,10 @@ CONS_HD bool step_read_b(const Win &w, int64_t r, uint32_t &alive /* columns the
     alive = ce >= cs ? (uint32_t)(ce - cs + 1) : 0u;
     const bool walk = ce >= cs && !(w.r_keep[r] & 4u);
     w.cs[r] = cs; w.ce[r] = ce; w.cnt[r] = walk ? (uint32_t)(ce - cs + 1) : 0u;
+    Meta m; m.cs = cs; m.ce = ce; m.pos = w.pos[r]; m.lead = w.r_tail[r]; m.pool8 = w.base_off8[r]; m.lq = (uint32_t)w.l_qseq[r]; m.pad = 0;
+    const bool q0_absent = w.l_qseq[r] > 0 && w.qual_in[(size_t)w.base_off8[r] * 8] == 255;
+    m.bits = w.r_keep[r] | ((uint32_t)w.mapq[r] << 8) | (q0_absent ? 1u << 16 : 0u);
+    w.meta[r] = m;
     return walk;
 }
 
@@ -122,11 +139,11 @@ CONS_HD void step_colpos(const Win &w, int64_t i)               // i = position 
 
 // what a plain read shows in column ci: the base at its start-relative offset, or a pad opposite somebody else's insertion
 // (Cursor::step reduced to a single aligned block: no reference skips, no own insertions, the read ends on nth 0)
-CONS_HD uint32_t plain_entry(const Win &w, bool bayes_mq, bool working_qual, int64_t r, int32_t ci, uint32_t &nmw)
+CONS_HD uint32_t plain_entry(const Win &w, bool bayes_mq, bool working_qual, const Meta &m, int32_t ci, uint32_t &nmw)
 {
     const int32_t p = w.colpos[ci], nth = ci - (int32_t)w.colbase[p - w.col_beg];
-    const int32_t so = p - w.pos[r] + w.r_tail[r], lq = w.l_qseq[r];
-    const size_t pool = (size_t)w.base_off8[r] * 8;
+    const int32_t so = p - m.pos + m.lead, lq = (int32_t)m.lq;
+    const size_t pool = (size_t)m.pool8 * 8;
     const uint8_t *q = (working_qual ? w.qual : w.qual_in) + pool;
     int base4, qual;
     if (so < lq) { qual = q[so]; base4 = seqi(w.seq + pool / 2, so); } else { qual = 0xff; base4 = 15; }
@@ -135,13 +152,13 @@ CONS_HD uint32_t plain_entry(const Win &w, bool bayes_mq, bool working_qual, int
         if (so < lq) { const int q1 = so + 1 < lq ? q[so + 1] : 0; if (q1 < qual) qual = q1; } else qual = 0;
     }
     nmw = bayes_mq ? nm_word(w.nm + pool, lq, so) : 0u;
-    return (uint32_t)base4 | ((uint32_t)(qual & 255) << 5) | ((w.r_keep[r] & 2u) ? CONS_E_REV : 0u);
+    return (uint32_t)base4 | ((uint32_t)(qual & 255) << 5) | ((m.bits & 2u) ? CONS_E_REV : 0u);
 }
 
-CONS_HD uint32_t entry_at(const Win &w, bool bayes_mq, bool working_qual, int64_t r, int32_t ci, uint32_t &nmw)
+CONS_HD uint32_t entry_at(const Win &w, bool bayes_mq, bool working_qual, int64_t r, const Meta &m, int32_t ci, uint32_t &nmw)
 {
-    if (w.r_keep[r] & 4u) return plain_entry(w, bayes_mq, working_qual, r, ci, nmw);
-    const uint64_t at = w.rowoff[r] + (uint32_t)(ci - w.cs[r]);
+    if (m.bits & 4u) return plain_entry(w, bayes_mq, working_qual, m, ci, nmw);
+    const uint64_t at = w.rowoff[r] + (uint32_t)(ci - m.cs);
     nmw = bayes_mq ? w.Enm[at] : 0u;
     return w.E[at];
 }
@@ -201,7 +218,9 @@ CONS_HD int64_t lower_ge(const int32_t *key, int64_t n, int32_t c)
 
 // KIND: 0 frequency caller, 1 one Bayesian parameter set, 2 both (mixed mode) -- separate instantiations keep the
 // accumulators of the modes that are not running out of the registers
-template <int KIND> CONS_HD void step_col(const Win &w, const Par &o, const Tables &t, int64_t c)
+// cp1 (+ cp2 in the mixed mode), q2p, mqpow: the parameter sets and the two per-entry lookup tables of t, wherever the caller
+// keeps them (LDS copies on the device); t itself is only read once per column (fast_exp)
+template <int KIND> CONS_HD void step_col(const Win &w, const Par &o, const Tables &t, const Probs &cp1, const Probs &cp2, const double *q2p, const double *mqpow, int64_t c)
 {
     const int32_t ci = (int32_t)c;
     const int64_t hi = upper_le(w.cs, w.n_reads, ci), lo = lower_ge(w.pmax, w.n_reads, ci);
@@ -213,28 +232,34 @@ template <int KIND> CONS_HD void step_col(const Win &w, const Par &o, const Tabl
     if (td == 0) { w.cols[c] = out; return; }
     if (KIND == 0) {
         SimpleAcc acc; acc.init();
-        for (int64_t r = lo; r < hi; ++r) { if (w.ce[r] < ci) continue; uint32_t nmw; acc.add(o, entry_at(w, false, false, r, ci, nmw)); }
+        for (int64_t r = lo; r < hi; ++r) {
+            if (w.ce[r] < ci) continue;
+            const Meta m = w.meta[r];
+            uint32_t nmw; acc.add(o, entry_at(w, false, false, r, m, ci, nmw));
+        }
         int32_t q; out.base = acc.finish(o, q); out.qual = q;
     } else {
         const bool mixed = KIND == 2;
-        const Probs &cp1 = o.mode == MODE_PRECISE || mixed ? t.precise : t.recall;
         Gap5Acc a1, a2; a1.init(); if (mixed) a2.init();
         for (int64_t r = lo; r < hi; ++r) {
             if (w.ce[r] < ci) continue;
+            const Meta m = w.meta[r];
             uint32_t nmw;
-            const uint32_t e = entry_at(w, bayes_mq, workq, r, ci, nmw);
-            const int q0 = w.l_qseq[r] > 0 ? w.qual_in[(size_t)w.base_off8[r] * 8] : 0;
-            a1.add(o, t, cp1, e, nmw, w.mapq[r], q0, td);
-            if (mixed) a2.add(o, t, t.recall, e, nmw, w.mapq[r], q0, td);
+            const uint32_t e = entry_at(w, bayes_mq, workq, r, m, ci, nmw);
+            const int mapq = (int)((m.bits >> 8) & 255u); const bool q0a = (m.bits >> 16) & 1u;
+            a1.add(o, q2p, mqpow, cp1, e, nmw, mapq, q0a, td);
+            if (mixed) a2.add(o, q2p, mqpow, cp2, e, nmw, mapq, q0a, td);
         }
         Call c1; a1.finish(t, cp1, c1);
-        if (mixed) { Call c2; a2.finish(t, t.recall, c2); c1 = mix_calls(c1, c2); }
+        if (mixed) { Call c2; a2.finish(t, cp2, c2); c1 = mix_calls(c1, c2); }
         int32_t q; out.base = final_call(o, c1, q); out.qual = q;
     }
     w.cols[c] = out;
 }
 
 CONS_HD int col_kind(const Par &o) { return o.mode == MODE_SIMPLE ? 0 : o.mode == MODE_MIXED ? 2 : 1; }
+// first (or only) parameter set of the mode; the mixed mode's second one is always the recall set
+CONS_HD const Probs &first_probs(const Par &o, const Tables &t) { return o.mode == MODE_PRECISE || o.mode == MODE_MIXED ? t.precise : t.recall; }
 
 CONS_HD void step_text(const Win &w, const Par &o, int64_t c)
 {
@@ -246,7 +271,8 @@ CONS_HD void step_text(const Win &w, const Par &o, int64_t c)
     for (int64_t r = lo; r < hi; ++r) {
         if (w.ce[r] < ci) continue;
         uint32_t nmw;
-        const uint32_t e = entry_at(w, false, workq, r, ci, nmw);
+        const Meta m = w.meta[r];
+        const uint32_t e = entry_at(w, false, workq, r, m, ci, nmw);
         const int b4 = CONS_E_BASE4(e);
         char ch = (e & CONS_E_SKIPCOL) ? '.' : b4 >= 16 ? '*' : "NACMGRSVTWYHKDBN"[b4];
         if (e & CONS_E_REV) ch = ch == '*' ? '#' : (ch >= 'A' && ch <= 'Z' ? (char)(ch + 32) : ch);

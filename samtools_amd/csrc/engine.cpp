@@ -810,7 +810,7 @@ int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *i
     auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
     const size_t o_ins = carve((size_t)(W + 1) * 4), o_len = carve((size_t)(W + 1) * 4), o_colbase = carve((size_t)(W + 2) * 8);
     const size_t o_last = carve((size_t)n * 4), o_tail = carve((size_t)n * 4), o_keep = carve((size_t)n * 4), o_cs = carve((size_t)n * 4),
-                 o_ce = carve((size_t)n * 4), o_pmax = carve((size_t)n * 4), o_cnt = carve((size_t)n * 4), o_rowoff = carve((size_t)(n + 2) * 8), o_clist = carve((size_t)n * 4), o_ctr = carve(64);
+                 o_ce = carve((size_t)n * 4), o_pmax = carve((size_t)n * 4), o_cnt = carve((size_t)n * 4), o_rowoff = carve((size_t)(n + 2) * 8), o_clist = carve((size_t)n * 4), o_meta = carve((size_t)(n + 1) * sizeof(cons::Meta)), o_ctr = carve(64);
     if (e->cons_ws.ensure(off + 256) || e->scan_tmp.ensure(sta_scan_tmp_bytes(std::max<int64_t>(std::max(W, n), 1) * 2) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(consensus workspace) failed");
     char *ws = (char *)e->cons_ws.p;
     cons::Win w; memset(&w, 0, sizeof w);
@@ -820,7 +820,7 @@ int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *i
     w.ins = (uint32_t *)(ws + o_ins); w.colbase = (uint64_t *)(ws + o_colbase);
     w.r_last = (int32_t *)(ws + o_last); w.r_tail = (int32_t *)(ws + o_tail); w.r_keep = (uint32_t *)(ws + o_keep);
     w.cs = (int32_t *)(ws + o_cs); w.ce = (int32_t *)(ws + o_ce); w.pmax = (int32_t *)(ws + o_pmax); w.cnt = (uint32_t *)(ws + o_cnt);
-    w.rowoff = (uint64_t *)(ws + o_rowoff); w.clist = (int32_t *)(ws + o_clist); w.counters = (unsigned long long *)(ws + o_ctr);
+    w.rowoff = (uint64_t *)(ws + o_rowoff); w.clist = (int32_t *)(ws + o_clist); w.meta = (cons::Meta *)(ws + o_meta); w.counters = (unsigned long long *)(ws + o_ctr);
     uint32_t *collen = (uint32_t *)(ws + o_len);
     w.qual = const_cast<uint8_t *>(d.qual_in);
     if (bayes_mq) {

@@ -10,6 +10,8 @@
 
 using namespace cons;
 
+static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
 __device__ __forceinline__ unsigned long long wave_sum_ull(unsigned long long v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
@@ -77,6 +79,33 @@ __global__ void __launch_bounds__(64) k_cons_prepare(Win w, Par o, const Tables 
     if (o.homopoly_on) { uint32_t *gw = (uint32_t *)(w.qual + first); for (int64_t i = lane; i < B / 4; i += 64) gw[i] = ((uint32_t *)lq)[i]; }
 }
 
+// The default configuration (no homopolymer fixing, not the 1.16 mode) needs no sequential walk: prepare_base() gives the nm
+// word of one base from its neighbours.  A wave takes 16 consecutive reads and strides its lanes over each read's bases:
+// coalesced quality / sequence loads and nm stores, no LDS, full occupancy.
+__global__ void __launch_bounds__(256) k_cons_prepare_base(Win w, Par o)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    for (int k = 0; k < 16; ++k) {
+        const int64_t r = r0 + k;
+        if (r >= w.n_reads) break;
+        if (!(w.r_keep[r] & 1u)) continue;
+        const ReadView v = view_of(w, r, false);
+        int32_t *nm = w.nm + (size_t)w.base_off8[r] * 8;
+        for (int i = lane; i < v.l_qseq; i += 64) nm[i] = prepare_base(o, v, i);
+    }
+}
+// ... followed by the soft-clip / MD costs, one lane per read that carries an MD tag
+__global__ void __launch_bounds__(256) k_cons_prepare_md(Win w, Par o)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= w.n_reads || !(w.r_keep[r] & 1u)) return;
+    const char *md; int md_len;
+    md_of(w, r, md, md_len);
+    const ReadView v = view_of(w, r, false);
+    read_prepare_md(o, v, md, md_len, w.nm + (size_t)w.base_off8[r] * 8);
+}
+
 // lengths for the column-index scan: position i of the window owns 1 + ins[i + 1] columns (ins[0] is the look-back position)
 __global__ void __launch_bounds__(256) k_cons_collen(const uint32_t *ins, uint32_t *len, int64_t W)
 {
@@ -112,10 +141,28 @@ __global__ void __launch_bounds__(256) k_cons_walk(Win w, Par o, int64_t n_list)
     if (k < n_list) step_walk(w, o, w.clist[k]);
 }
 
+// The Bayesian caller looks up eleven table entries per read and column (q2p, mqual_pow_1m, nine log-probabilities): the
+// parameter set(s) and the two small tables are copied into LDS once per workgroup (10 KB, 18 KB in the mixed mode).
 template <int KIND> __global__ void __launch_bounds__(256) k_cons_col(Win w, Par o, const Tables *t, int64_t n_cols)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_cols) step_col<KIND>(w, o, *t, c);
+    if (KIND == 0) {
+        if (c < n_cols) step_col<0>(w, o, *t, t->recall, t->recall, t->q2p, t->mqual_pow_1m, c);
+        return;
+    }
+    __shared__ Probs s_cp1;
+    __shared__ Probs s_cp2[KIND == 2 ? 1 : 0 + (KIND == 2 ? 0 : 1)];      // one element either way; only filled in the mixed mode
+    __shared__ double s_q2p[101], s_mq[256];
+    {
+        const Probs &g1 = first_probs(o, *t);
+        const double *src = (const double *)&g1; double *dst = (double *)&s_cp1;
+        for (int i = threadIdx.x; i < (int)(sizeof(Probs) / 8); i += 256) dst[i] = src[i];
+        if (KIND == 2) { src = (const double *)&t->recall; dst = (double *)&s_cp2[0]; for (int i = threadIdx.x; i < (int)(sizeof(Probs) / 8); i += 256) dst[i] = src[i]; }
+        if (threadIdx.x < 101) s_q2p[threadIdx.x] = t->q2p[threadIdx.x];
+        s_mq[threadIdx.x] = t->mqual_pow_1m[threadIdx.x];
+    }
+    __syncthreads();
+    if (c < n_cols) step_col<KIND>(w, o, *t, s_cp1, s_cp2[0], s_q2p, s_mq, c);
 }
 
 __global__ void __launch_bounds__(256) k_cons_text(Win w, Par o, int64_t n_cols)
@@ -124,7 +171,6 @@ __global__ void __launch_bounds__(256) k_cons_text(Win w, Par o, int64_t n_cols)
     if (c < n_cols) step_text(w, o, c);
 }
 
-static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 void sta_launch_cons_read_a(hipStream_t s, const Win &w, const Par &o, const Tables *t)
 {
@@ -132,6 +178,11 @@ void sta_launch_cons_read_a(hipStream_t s, const Win &w, const Par &o, const Tab
 }
 void sta_launch_cons_prepare(hipStream_t s, const Win &w, const Par &o, const Tables *t)
 {
+    if (w.n_reads > 0 && prepare_is_per_base(o)) {
+        hipLaunchKernelGGL(k_cons_prepare_base, dim3((unsigned)((w.n_reads + 63) / 64)), dim3(256), 0, s, w, o);
+        hipLaunchKernelGGL(k_cons_prepare_md, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, o);
+        return;
+    }
     if (w.n_reads > 0) hipLaunchKernelGGL(k_cons_prepare, dim3((unsigned)((w.n_reads + 63) / 64)), dim3(64), PREP_CAP * 5 + PREP_CAP / 2, s, w, o, t);
 }
 void sta_launch_cons_collen(hipStream_t s, const uint32_t *ins, uint32_t *len, int64_t W)

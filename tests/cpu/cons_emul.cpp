@@ -39,6 +39,8 @@ static int emul(const sta_window &w, const sta_cons_params &p, ConsWindowOut &ou
     colbase[0] = 0;
     for (int32_t i = 0; i < W; ++i) colbase[(size_t)i + 1] = colbase[(size_t)i] + 1 + ins[(size_t)i + 1];
     std::vector<int32_t> colpos(colbase[(size_t)W] + 1), clist;
+    std::vector<cons::Meta> meta((size_t)n + 1);
+    d.meta = meta.data();
     d.colpos = colpos.data();
     for (int32_t i = 0; i < W; ++i) cons::step_colpos(d, i);
     uint64_t sum_depth = 0;
@@ -52,7 +54,12 @@ static int emul(const sta_window &w, const sta_cons_params &p, ConsWindowOut &ou
     out.cols.assign(n_cols, sta_cons_col{ 0, 0, 0 });
     d.cols = out.cols.data(); d.depth = depth.data();
     const int kind = cons::col_kind(o);
-    for (uint64_t c = 0; c < n_cols; ++c) { if (kind == 0) cons::step_col<0>(d, o, tab, (int64_t)c); else if (kind == 1) cons::step_col<1>(d, o, tab, (int64_t)c); else cons::step_col<2>(d, o, tab, (int64_t)c); }
+    const cons::Probs &cp1 = cons::first_probs(o, tab);
+    for (uint64_t c = 0; c < n_cols; ++c) {
+        if (kind == 0) cons::step_col<0>(d, o, tab, cp1, tab.recall, tab.q2p, tab.mqual_pow_1m, (int64_t)c);
+        else if (kind == 1) cons::step_col<1>(d, o, tab, cp1, tab.recall, tab.q2p, tab.mqual_pow_1m, (int64_t)c);
+        else cons::step_col<2>(d, o, tab, cp1, tab.recall, tab.q2p, tab.mqual_pow_1m, (int64_t)c);
+    }
     out.ins.assign(ins.begin() + 1, ins.end());
     out.info.n_cols = n_cols; out.info.n_entries = sum_depth; out.info.n_kept_reads = counters[0];
     if (p.want_pileup) {

@@ -216,44 +216,68 @@ CONS_HD int64_t lower_ge(const int32_t *key, int64_t n, int32_t c)
     return lo;
 }
 
+// One wave takes 64 consecutive columns [c0, c1].  The reads that can be alive in any of them are [lo, hi) (two binary
+// searches on wave-uniform keys), and every lane walks that same range: the per-read record is then a wave-uniform (scalar)
+// load and the alive test a compare, instead of every lane searching and gathering for itself.  Each lane still adds its own
+// alive reads in file order.  CONS_UNIFORM tells the device compiler the value is the same in every lane.
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define CONS_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
+#else
+#define CONS_UNIFORM(v) (v)
+#endif
+struct Span { int32_t lo, hi; };
+CONS_HD Span span_of(const Win &w, int32_t c0, int32_t c1)
+{
+    Span s;
+    s.lo = CONS_UNIFORM((int32_t)lower_ge(w.pmax, w.n_reads, CONS_UNIFORM(c0)));
+    s.hi = CONS_UNIFORM((int32_t)upper_le(w.cs, w.n_reads, CONS_UNIFORM(c1)));
+    return s;
+}
+
 // KIND: 0 frequency caller, 1 one Bayesian parameter set, 2 both (mixed mode) -- separate instantiations keep the
 // accumulators of the modes that are not running out of the registers
 // cp1 (+ cp2 in the mixed mode), q2p, mqpow: the parameter sets and the two per-entry lookup tables of t, wherever the caller
-// keeps them (LDS copies on the device); t itself is only read once per column (fast_exp)
-template <int KIND> CONS_HD void step_col(const Win &w, const Par &o, const Tables &t, const Probs &cp1, const Probs &cp2, const double *q2p, const double *mqpow, int64_t c)
+// keeps them (LDS copies on the device); t itself is only read once per column (fast_exp).  [c0, c1]: the wave's columns.
+template <int KIND> CONS_HD void step_col(const Win &w, const Par &o, const Tables &t, const Probs &cp1, const Probs &cp2, const double *q2p, const double *mqpow,
+                                          int64_t c, int32_t c0, int32_t c1)
 {
     const int32_t ci = (int32_t)c;
-    const int64_t hi = upper_le(w.cs, w.n_reads, ci), lo = lower_ge(w.pmax, w.n_reads, ci);
+    const Span sp = span_of(w, c0, c1);
     const bool bayes_mq = o.mode != MODE_SIMPLE && o.use_mqual, workq = bayes_mq && o.homopoly_on;
-    int32_t td = 0;
-    for (int64_t r = lo; r < hi; ++r) td += w.ce[r] >= ci;
-    sta_cons_col out; out.depth = td; out.base = 'N'; out.qual = 0;
-    w.depth[c] = (uint32_t)td;
-    if (td == 0) { w.cols[c] = out; return; }
+    sta_cons_col out; out.depth = 0; out.base = 'N'; out.qual = 0;
     if (KIND == 0) {
         SimpleAcc acc; acc.init();
-        for (int64_t r = lo; r < hi; ++r) {
-            if (w.ce[r] < ci) continue;
+        int32_t td = 0;
+        for (int32_t r = sp.lo; r < sp.hi; ++r) {
             const Meta m = w.meta[r];
+            if (m.cs > ci || m.ce < ci) continue;
+            ++td;
             uint32_t nmw; acc.add(o, entry_at(w, false, false, r, m, ci, nmw));
         }
-        int32_t q; out.base = acc.finish(o, q); out.qual = q;
+        out.depth = td;
+        if (td) { int32_t q; out.base = acc.finish(o, q); out.qual = q; }
     } else {
-        const bool mixed = KIND == 2;
-        Gap5Acc a1, a2; a1.init(); if (mixed) a2.init();
-        for (int64_t r = lo; r < hi; ++r) {
-            if (w.ce[r] < ci) continue;
-            const Meta m = w.meta[r];
-            uint32_t nmw;
-            const uint32_t e = entry_at(w, bayes_mq, workq, r, m, ci, nmw);
-            const int mapq = (int)((m.bits >> 8) & 255u); const bool q0a = (m.bits >> 16) & 1u;
-            a1.add(o, q2p, mqpow, cp1, e, nmw, mapq, q0a, td);
-            if (mixed) a2.add(o, q2p, mqpow, cp2, e, nmw, mapq, q0a, td);
+        int32_t td = 0;
+        for (int32_t r = sp.lo; r < sp.hi; ++r) { const Meta m = w.meta[r]; td += m.cs <= ci && m.ce >= ci; }
+        out.depth = td;
+        if (td) {
+            const bool mixed = KIND == 2;
+            Gap5Acc a1, a2; a1.init(); if (mixed) a2.init();
+            for (int32_t r = sp.lo; r < sp.hi; ++r) {
+                const Meta m = w.meta[r];
+                if (m.cs > ci || m.ce < ci) continue;
+                uint32_t nmw;
+                const uint32_t e = entry_at(w, bayes_mq, workq, r, m, ci, nmw);
+                const int mapq = (int)((m.bits >> 8) & 255u); const bool q0a = (m.bits >> 16) & 1u;
+                a1.add(o, q2p, mqpow, cp1, e, nmw, mapq, q0a, td);
+                if (mixed) a2.add(o, q2p, mqpow, cp2, e, nmw, mapq, q0a, td);
+            }
+            Call c1r; a1.finish(t, cp1, c1r);
+            if (mixed) { Call c2r; a2.finish(t, cp2, c2r); c1r = mix_calls(c1r, c2r); }
+            int32_t q; out.base = final_call(o, c1r, q); out.qual = q;
         }
-        Call c1; a1.finish(t, cp1, c1);
-        if (mixed) { Call c2; a2.finish(t, cp2, c2); c1 = mix_calls(c1, c2); }
-        int32_t q; out.base = final_call(o, c1, q); out.qual = q;
     }
+    w.depth[c] = (uint32_t)out.depth;
     w.cols[c] = out;
 }
 
@@ -261,17 +285,17 @@ CONS_HD int col_kind(const Par &o) { return o.mode == MODE_SIMPLE ? 0 : o.mode =
 // first (or only) parameter set of the mode; the mixed mode's second one is always the recall set
 CONS_HD const Probs &first_probs(const Par &o, const Tables &t) { return o.mode == MODE_PRECISE || o.mode == MODE_MIXED ? t.precise : t.recall; }
 
-CONS_HD void step_text(const Win &w, const Par &o, int64_t c)
+CONS_HD void step_text(const Win &w, const Par &o, int64_t c, int32_t c0, int32_t c1)
 {
     const int32_t ci = (int32_t)c;
+    const Span sp = span_of(w, c0, c1);
     if (!w.depth[c]) return;
-    const int64_t hi = upper_le(w.cs, w.n_reads, ci), lo = lower_ge(w.pmax, w.n_reads, ci);
     const bool workq = o.mode != MODE_SIMPLE && o.use_mqual && o.homopoly_on;
     uint64_t at = w.col_off[c];
-    for (int64_t r = lo; r < hi; ++r) {
-        if (w.ce[r] < ci) continue;
-        uint32_t nmw;
+    for (int32_t r = sp.lo; r < sp.hi; ++r) {
         const Meta m = w.meta[r];
+        if (m.cs > ci || m.ce < ci) continue;
+        uint32_t nmw;
         const uint32_t e = entry_at(w, false, workq, r, m, ci, nmw);
         const int b4 = CONS_E_BASE4(e);
         char ch = (e & CONS_E_SKIPCOL) ? '.' : b4 >= 16 ? '*' : "NACMGRSVTWYHKDBN"[b4];

@@ -7,6 +7,8 @@
 // the reference that this tree does not carry).
 #include "cons_host.h"
 #include "host_io.h"
+#include "host_bgzf.h"
+#include "host_chunk.h"
 #include "host_pump.h"
 #include "host_stage.h"
 #include <algorithm>
@@ -228,10 +230,15 @@ struct Runner {
         if (job.has_iter) readers[0]->set_region(job.iter_tid, job.iter_beg, job.iter_end);
         const Header &h = readers[0]->header();
         PumpConfig pc; pc.window_cols = window_cols; pc.use_endpos = false; pc.nref_limit = h.nref();
-        Pump pump(readers, pc);
-        XcolSpec xs; xs.n_tags = want_md ? 1 : 0; xs.empty = '*'; xs.hdr = &h;
-        StagedFile staged;
-        std::vector<std::vector<const Rec *>> reads;
+        pc.xs_n_tags = want_md ? 1 : 0; pc.xs_empty = '*';
+        // the drivers' input lanes (host_chunk.h: records parsed on several threads into chunk slices; host_pump.h: one record
+        // at a time, STA_INPUT_LANE=rec)
+        std::unique_ptr<WindowSource> src;
+        const char *lane = getenv("STA_INPUT_LANE");
+        if (lane && !strcmp(lane, "rec")) src.reset(new Pump(readers, pc));
+        else src.reset(new ChunkPump(readers, pc, io_default_threads()));
+        WindowSource &pump = *src;
+        std::vector<StagedFile> stagedv(1);
         ConsWindowOut out;
         for (;;) {
             const int tid = pump.next_tid();
@@ -244,17 +251,14 @@ struct Runner {
                 // alive at `cursor` they are not needed and the next window starts at the next read.
                 if (pump.has_carry() && pump.carry_max_end() <= cursor && pump.next_pos(tid) > cursor) pump.retire(cursor);
                 if (!pump.has_carry()) cursor = std::max(cursor, pump.next_pos(tid));
-                int64_t ce = pump.fill(tid, cursor, cursor + window_cols, reads);
+                int64_t ce = pump.fill_staged(tid, cursor, cursor + window_cols, stagedv);
                 if (pump.error()) break;
                 if (pump.next_pos(tid) == INT64_MAX) {
                     const int64_t me = pump.carry_max_end();
                     if (me != INT64_MIN) ce = std::min(ce, std::max(me, cursor));
                 }
                 if (ce > cursor) {
-                    staged.clear();
-                    for (const Rec *r : reads[0]) staged.add(*r, cursor, nullptr, want_md ? &xs : nullptr);
-                    staged.finish();
-                    sta_reads view = staged.view();
+                    sta_reads view = stagedv[0].view();
                     sta_window w; memset(&w, 0, sizeof w);
                     w.tid = tid; w.origin = cursor; w.col_beg = 0; w.col_end = (int32_t)(ce - cursor);
                     w.tname = h.names[(size_t)tid].c_str(); w.tlen = h.lens[(size_t)tid];

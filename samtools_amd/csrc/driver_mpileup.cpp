@@ -274,7 +274,7 @@ struct Runner {
         pc.xs_rnext = (conf.p.flag & STA_MPLP_PRINT_RNEXT) != 0; pc.xs_n_tags = (int)conf.tags.size(); pc.xs_empty = conf.empty;
         pc.xs_mods = (conf.p.flag & STA_MPLP_OUTPUT_MODS) != 0;          // MM / ML are evaluated per record while staging (host_mods.cpp)
         const char *lane = getenv("STA_IO_LANE");
-        const bool chunked = !pc.rg_excl && !pc.xs_rnext && !pc.xs_n_tags && !pc.xs_mods && !(lane && !strcmp(lane, "rec"));
+        const bool chunked = !pc.rg_excl && !pc.xs_rnext && !pc.xs_mods && !(lane && !strcmp(lane, "rec"));
         std::unique_ptr<WindowSource> src;
         if (chunked) src.reset(new ChunkPump(readers, pc, io_threads_per_input((int)readers.size())));
         else src.reset(new Pump(readers, pc));

@@ -68,7 +68,7 @@ struct sta_engine {
     std::vector<int32_t> min_pos, max_pos_hint;
     DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
-    DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos;
+    DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
     cons::Win cons_w{}; uint64_t cons_ncols = 0, cons_nentries = 0; int64_t cons_W = 0; bool cons_text = false;
     int baq_slab_gib_cap = 0;       // 0 = default; 4 after a one-launch BAQ slab could not be allocated
@@ -180,7 +180,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->offs, &e->scan_tmp, &e->counters, &e->table,
                       &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
-                      &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos };
+                      &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
     if (e->side_done) hipEventDestroy(e->side_done);
@@ -825,14 +825,14 @@ int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *i
     w.qual = const_cast<uint8_t *>(d.qual_in);
     if (bayes_mq) {
         const size_t nb = (size_t)d.n_bases_total;
-        if (e->cons_qwork.ensure(nb + 64) || e->cons_nm.ensure((nb + 8) * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(consensus per-base workspace) failed");
+        if (e->cons_qwork.ensure(nb + 64) || e->cons_nm.ensure((nb + 8) * 4 + 64) || e->cons_gran.ensure((nb / 8 + 2) * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(consensus per-base workspace) failed");
         if (nb) HIPCHK(hipMemcpyAsync(e->cons_qwork.p, d.qual_in, nb, hipMemcpyDeviceToDevice, s));
         w.qual = (uint8_t *)e->cons_qwork.p; w.nm = (int32_t *)e->cons_nm.p;
     }
     HIPCHK(hipMemsetAsync(w.ins, 0, (size_t)(W + 1) * 4, s));
     HIPCHK(hipMemsetAsync(w.counters, 0, 64, s));
     { ProfScope ps(e, "cons_read_a"); sta_launch_cons_read_a(s, w, o, tab); }
-    if (bayes_mq) { ProfScope ps(e, "cons_prepare"); sta_launch_cons_prepare(s, w, o, tab); }
+    if (bayes_mq) { ProfScope ps(e, "cons_prepare"); sta_launch_cons_prepare(s, w, o, tab, (int32_t *)e->cons_gran.p, (int64_t)d.n_bases_total); }
     { ProfScope ps(e, "cons_scans");
       sta_launch_cons_collen(s, w.ins, collen, W);
       sta_launch_len_scan(s, collen, w.colbase, W, e->scan_tmp.p, e->scan_tmp.cap); }

@@ -25,6 +25,15 @@ void Chunk::append(const Rec &r)
     if (has_bq_pool) { bq.resize(b0 + padded, 64); if (bq_ok) memcpy(&bq[b0], r.bq.data(), (size_t)r.l_qseq); }
     names.insert(names.end(), r.qname.begin(), r.qname.end());
     names.push_back('\0');
+    if (!r.tagtext.empty()) {
+        if (tag_off.empty()) { n_tags = (int)r.tagtext.size(); tag_off.push_back(0); }
+        for (size_t t = 0; t < r.tagtext.size(); ++t) {
+            const bool has = t < r.tag_has.size() && r.tag_has[t];
+            if (has) tag_text.insert(tag_text.end(), r.tagtext[t].begin(), r.tagtext[t].end());
+            tag_has.push_back((char)has);
+            tag_off.push_back((uint32_t)tag_text.size());
+        }
+    }
     cig_off.push_back((uint32_t)cigar.size());
     base_off8.push_back((uint32_t)(qual.size() >> 3));
     name_off.push_back((uint32_t)names.size());
@@ -48,6 +57,14 @@ void Chunk::to_rec(int64_t i, Rec &r) const
     r.qual.assign(qual.begin() + (long)b0, qual.begin() + (long)(b0 + l));
     r.has_bq = (aux[k] & STA_AUX_HAS_BQ) != 0; r.has_zq = (aux[k] & STA_AUX_HAS_ZQ) != 0;
     if (r.has_bq) r.bq.assign(bq.begin() + (long)b0, bq.begin() + (long)(b0 + l));
+    if (n_tags > 0) {
+        r.tagtext.assign((size_t)n_tags, std::string()); r.tag_has.assign((size_t)n_tags, 0);
+        for (int t = 0; t < n_tags; ++t) {
+            const size_t e = k * (size_t)n_tags + (size_t)t;
+            r.tag_has[(size_t)t] = tag_has[e];
+            r.tagtext[(size_t)t].assign(tag_text.data() + tag_off[e], tag_text.data() + tag_off[e + 1]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ ChunkReader
@@ -251,9 +268,11 @@ int64_t ChunkPump::fill_window(int tid, int64_t cb, int64_t ce_target, std::vect
         File &f = f_[fi];
         StagedFile &s = staged[fi];
         s.clear();
-        for (auto &r : f.carry) s.add(r, cb, nullptr);
+        XcolSpec xs; xs.n_tags = cfg_.xs_n_tags; xs.empty = cfg_.xs_empty;
+        const XcolSpec *xp = xs.n_tags > 0 ? &xs : nullptr;
+        for (auto &r : f.carry) s.add(r, cb, nullptr, xp);
         f.n_carry_staged = f.carry.size();
-        for (auto &g : f.fresh) s.add_range(*g.c, g.i0, g.i1, cb);
+        for (auto &g : f.fresh) s.add_range(*g.c, g.i0, g.i1, cb, xp);
         s.finish();
     }
     return ce;

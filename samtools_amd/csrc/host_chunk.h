@@ -3,7 +3,8 @@
 // offset rebasing) instead of one decoded record at a time.  Same role as host_pump.h (the reference's "pull reads while they
 // can still touch the column" loop, bam_plcmd.c:607 / bam2depth.c:578-663), same window semantics -- host_scan.cpp checks that
 // both lanes stage byte-identical windows -- but per-record work is left only for the few reads that straddle a window end.
-// Used when no per-record host formatting is asked for (no --output-extra tags / RNEXT, no -G read-group list).
+// Used when no per-record host formatting is asked for (no RNEXT column, no --output-mods, no -G read-group list); wanted aux
+// tags travel with the chunks as text.
 #pragma once
 #include "host_io.h"
 #include "host_pump.h"
@@ -29,6 +30,10 @@ struct Chunk {
     std::vector<uint8_t> seq, qual, bq;           // bq maintained only once some record carries BQ:Z
     bool has_bq_pool = false;
     std::vector<char> names;
+    // wanted aux tags (AlnReader::set_wanted_tags) as text, n_tags entries per record: the staging layer turns them into text
+    // columns (--output-extra tags of mpileup; MD:Z for the consensus path)
+    int n_tags = 0;
+    std::vector<uint32_t> tag_off; std::vector<char> tag_text, tag_has;
     int64_t n() const { return (int64_t)pos.size(); }
     int64_t end(int64_t i) const { return pos[(size_t)i] + rlen[(size_t)i]; }
     int64_t endpos(int64_t i) const { int64_t l = (flag[(size_t)i] & 4) ? 0 : rlen[(size_t)i]; return pos[(size_t)i] + (l > 0 ? l : 1); }

@@ -70,9 +70,19 @@ void StagedFile::add(const Rec &r, int64_t origin, const std::set<std::string> *
     names.push_back('\0');
 }
 
-void StagedFile::add_range(const Chunk &c, int64_t i0, int64_t i1, int64_t origin)
+void StagedFile::add_range(const Chunk &c, int64_t i0, int64_t i1, int64_t origin, const XcolSpec *xs)
 {
     if (i1 <= i0) return;
+    if (xs && xs->n_tags > 0) {
+        n_xcols = xs->n_tags;
+        for (int64_t i = i0; i < i1; ++i)
+            for (int t = 0; t < xs->n_tags; ++t) {
+                xcol_off.push_back((uint32_t)xcol_text.size());
+                const size_t e = (size_t)i * (size_t)c.n_tags + (size_t)t;
+                if (t < c.n_tags && c.tag_has[e]) xcol_text.insert(xcol_text.end(), c.tag_text.data() + c.tag_off[e], c.tag_text.data() + c.tag_off[e + 1]);
+                else xcol_text.push_back(xs->empty);
+            }
+    }
     const size_t a = (size_t)i0, b = (size_t)i1, m = b - a, n0 = pos.size();
     pos.resize(n0 + m); isize.resize(n0 + m);
     for (size_t k = 0; k < m; ++k) pos[n0 + k] = (int32_t)(c.pos[a + k] - origin);

@@ -39,9 +39,9 @@ struct StagedFile {
     void clear();
     // origin: absolute coordinate of relative 0; rg_excl: -G read groups to drop (may be null)
     void add(const Rec &r, int64_t origin, const std::set<std::string> *rg_excl, const XcolSpec *xs = nullptr);
-    // bulk form of add() for records [i0, i1) of a decoded chunk (no read-group list, no extra columns): pool slices are
-    // copied whole and the offsets rebased
-    void add_range(const Chunk &c, int64_t i0, int64_t i1, int64_t origin);
+    // bulk form of add() for records [i0, i1) of a decoded chunk (no read-group list, no RNEXT / modification columns): pool
+    // slices are copied whole and the offsets rebased; the chunk's aux-tag text becomes the tag columns
+    void add_range(const Chunk &c, int64_t i0, int64_t i1, int64_t origin, const XcolSpec *xs = nullptr);     // xs: tag columns only
     void finish();                 // closes the offset arrays
     sta_reads view() const;        // pointers into this object (valid until the next add/clear)
     int64_t n() const { return (int64_t)pos.size(); }

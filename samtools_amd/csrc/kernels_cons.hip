@@ -23,11 +23,19 @@ __global__ void __launch_bounds__(256) k_cons_read_a(Win w, Par o, const Tables 
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int code = 0;
     if (r < w.n_reads) code = step_read_a(w, o, *t, r, [](uint32_t *p, uint32_t v) { atomicMax(p, v); }, false);
-    // one atomic per wave, not per read: a single counter word takes ~90 atomics per microsecond
+    // one global atomic per workgroup, not per read: a single counter word takes ~90 atomics per microsecond
+    __shared__ unsigned int s_kept, s_bad;
+    if (threadIdx.x == 0) { s_kept = 0; s_bad = 0; }
+    __syncthreads();
     const unsigned long long kept = __ballot(code > 0), bad = __ballot(code < 0);
     if ((threadIdx.x & 63) == 0) {
-        if (kept) atomicAdd(&w.counters[0], (unsigned long long)__popcll(kept));
-        if (bad) atomicAdd(&w.counters[1], (unsigned long long)__popcll(bad));
+        if (kept) atomicAdd(&s_kept, (unsigned int)__popcll(kept));
+        if (bad) atomicAdd(&s_bad, (unsigned int)__popcll(bad));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_kept) atomicAdd(&w.counters[0], (unsigned long long)s_kept);
+        if (s_bad) atomicAdd(&w.counters[1], (unsigned long long)s_bad);
     }
 }
 
@@ -80,20 +88,26 @@ __global__ void __launch_bounds__(64) k_cons_prepare(Win w, Par o, const Tables 
 }
 
 // The default configuration (no homopolymer fixing, not the 1.16 mode) needs no sequential walk: prepare_base() gives the nm
-// word of one base from its neighbours.  A wave takes 16 consecutive reads and strides its lanes over each read's bases:
-// coalesced quality / sequence loads and nm stores, no LDS, full occupancy.
-__global__ void __launch_bounds__(256) k_cons_prepare_base(Win w, Par o)
+// word of one base from its neighbours.  One thread per staged base: k_cons_granules first notes, for every 8-base granule of
+// the pool (reads start on granule boundaries), which read it belongs to; k_cons_prepare_base then runs over the pool with
+// fully coalesced quality / sequence loads and nm stores and nothing sequential.
+__global__ void __launch_bounds__(256) k_cons_granules(Win w, int32_t *gran2read)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
-    for (int k = 0; k < 16; ++k) {
-        const int64_t r = r0 + k;
-        if (r >= w.n_reads) break;
-        if (!(w.r_keep[r] & 1u)) continue;
-        const ReadView v = view_of(w, r, false);
-        int32_t *nm = w.nm + (size_t)w.base_off8[r] * 8;
-        for (int i = lane; i < v.l_qseq; i += 64) nm[i] = prepare_base(o, v, i);
-    }
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= w.n_reads || !(w.r_keep[r] & 1u)) return;
+    const uint32_t g0 = w.base_off8[r], g1 = g0 + (uint32_t)((w.l_qseq[r] + 7) >> 3);
+    for (uint32_t g = g0; g < g1; ++g) gran2read[g] = (int32_t)r;
+}
+__global__ void __launch_bounds__(256) k_cons_prepare_base(Win w, Par o, const int32_t *gran2read, int64_t n_bases)
+{
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n_bases) return;
+    const int32_t r = gran2read[x >> 3];
+    if (r < 0) return;
+    const int i = (int)(x - (int64_t)w.base_off8[r] * 8);
+    if (i >= w.l_qseq[r]) return;                        // padding behind the read's last base
+    const ReadView v = view_of(w, r, false);
+    w.nm[x] = prepare_base(o, v, i);
 }
 // ... followed by the soft-clip / MD costs, one lane per read that carries an MD tag
 __global__ void __launch_bounds__(256) k_cons_prepare_md(Win w, Par o)
@@ -118,15 +132,24 @@ __global__ void __launch_bounds__(256) k_cons_read_b(Win w)
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t alive = 0;
     const bool walk = r < w.n_reads ? step_read_b(w, r, alive) : false;
-    // reads that need the cursor walk are appended to clist (any order), again one atomic per wave
+    // reads that need the cursor walk are appended to clist (any order): slots are handed out per workgroup
+    __shared__ unsigned int s_n[4];
+    __shared__ unsigned long long s_base, s_alive;
     const unsigned long long m = __ballot(walk);
-    const int lane = threadIdx.x & 63;
-    unsigned long long base = 0;
-    if (lane == 0 && m) base = atomicAdd(&w.counters[2], (unsigned long long)__popcll(m));
-    base = __shfl(base, 0);
-    if (walk) w.clist[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)r;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_alive = 0;
+    if (lane == 0) s_n[wid] = (unsigned int)__popcll(m);
+    __syncthreads();
     const unsigned long long tot = wave_sum_ull(alive);
-    if (lane == 0 && tot) atomicAdd(&w.counters[3], tot);
+    if (lane == 0 && tot) atomicAdd(&s_alive, tot);
+    if (threadIdx.x == 0) { const unsigned int all = s_n[0] + s_n[1] + s_n[2] + s_n[3]; s_base = all ? atomicAdd(&w.counters[2], (unsigned long long)all) : 0ull; }
+    __syncthreads();
+    if (walk) {
+        unsigned long long at = s_base;
+        for (int k = 0; k < wid; ++k) at += s_n[k];
+        w.clist[at + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)r;
+    }
+    if (threadIdx.x == 0 && s_alive) atomicAdd(&w.counters[3], s_alive);
 }
 
 __global__ void __launch_bounds__(256) k_cons_colpos(Win w, int64_t W)
@@ -146,8 +169,9 @@ __global__ void __launch_bounds__(256) k_cons_walk(Win w, Par o, int64_t n_list)
 template <int KIND> __global__ void __launch_bounds__(256) k_cons_col(Win w, Par o, const Tables *t, int64_t n_cols)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t c0 = (int32_t)(c & ~63ll), c1 = (int32_t)(c0 + 63 < n_cols ? c0 + 63 : n_cols - 1);      // this wave's columns
     if (KIND == 0) {
-        if (c < n_cols) step_col<0>(w, o, *t, t->recall, t->recall, t->q2p, t->mqual_pow_1m, c);
+        if (c < n_cols) step_col<0>(w, o, *t, t->recall, t->recall, t->q2p, t->mqual_pow_1m, c, c0, c1);
         return;
     }
     __shared__ Probs s_cp1;
@@ -162,13 +186,14 @@ template <int KIND> __global__ void __launch_bounds__(256) k_cons_col(Win w, Par
         s_mq[threadIdx.x] = t->mqual_pow_1m[threadIdx.x];
     }
     __syncthreads();
-    if (c < n_cols) step_col<KIND>(w, o, *t, s_cp1, s_cp2[0], s_q2p, s_mq, c);
+    if (c < n_cols) step_col<KIND>(w, o, *t, s_cp1, s_cp2[0], s_q2p, s_mq, c, c0, c1);
 }
 
 __global__ void __launch_bounds__(256) k_cons_text(Win w, Par o, int64_t n_cols)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_cols) step_text(w, o, c);
+    const int32_t c0 = (int32_t)(c & ~63ll), c1 = (int32_t)(c0 + 63 < n_cols ? c0 + 63 : n_cols - 1);
+    if (c < n_cols) step_text(w, o, c, c0, c1);
 }
 
 
@@ -176,10 +201,12 @@ void sta_launch_cons_read_a(hipStream_t s, const Win &w, const Par &o, const Tab
 {
     if (w.n_reads > 0) hipLaunchKernelGGL(k_cons_read_a, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, o, t);
 }
-void sta_launch_cons_prepare(hipStream_t s, const Win &w, const Par &o, const Tables *t)
+void sta_launch_cons_prepare(hipStream_t s, const Win &w, const Par &o, const Tables *t, int32_t *gran2read, int64_t n_bases)
 {
     if (w.n_reads > 0 && prepare_is_per_base(o)) {
-        hipLaunchKernelGGL(k_cons_prepare_base, dim3((unsigned)((w.n_reads + 63) / 64)), dim3(256), 0, s, w, o);
+        hipMemsetAsync(gran2read, 0xff, (size_t)((n_bases + 7) / 8) * 4, s);
+        hipLaunchKernelGGL(k_cons_granules, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, gran2read);
+        hipLaunchKernelGGL(k_cons_prepare_base, dim3(blocks_for(n_bases)), dim3(256), 0, s, w, o, gran2read, n_bases);
         hipLaunchKernelGGL(k_cons_prepare_md, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, o);
         return;
     }

@@ -6,6 +6,7 @@
 // without a device.
 #include "../../samtools_amd/csrc/cons_host.h"
 #include "../../samtools_amd/csrc/cons_window.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -55,10 +56,11 @@ static int emul(const sta_window &w, const sta_cons_params &p, ConsWindowOut &ou
     d.cols = out.cols.data(); d.depth = depth.data();
     const int kind = cons::col_kind(o);
     const cons::Probs &cp1 = cons::first_probs(o, tab);
-    for (uint64_t c = 0; c < n_cols; ++c) {
-        if (kind == 0) cons::step_col<0>(d, o, tab, cp1, tab.recall, tab.q2p, tab.mqual_pow_1m, (int64_t)c);
-        else if (kind == 1) cons::step_col<1>(d, o, tab, cp1, tab.recall, tab.q2p, tab.mqual_pow_1m, (int64_t)c);
-        else cons::step_col<2>(d, o, tab, cp1, tab.recall, tab.q2p, tab.mqual_pow_1m, (int64_t)c);
+    for (uint64_t c = 0; c < n_cols; ++c) {                      // 64-column spans, as the device's waves take them
+        const int32_t c0 = (int32_t)(c & ~63ull), c1 = (int32_t)std::min<uint64_t>(c0 + 63, n_cols - 1);
+        if (kind == 0) cons::step_col<0>(d, o, tab, cp1, tab.recall, tab.q2p, tab.mqual_pow_1m, (int64_t)c, c0, c1);
+        else if (kind == 1) cons::step_col<1>(d, o, tab, cp1, tab.recall, tab.q2p, tab.mqual_pow_1m, (int64_t)c, c0, c1);
+        else cons::step_col<2>(d, o, tab, cp1, tab.recall, tab.q2p, tab.mqual_pow_1m, (int64_t)c, c0, c1);
     }
     out.ins.assign(ins.begin() + 1, ins.end());
     out.info.n_cols = n_cols; out.info.n_entries = sum_depth; out.info.n_kept_reads = counters[0];
@@ -69,7 +71,7 @@ static int emul(const sta_window &w, const sta_cons_params &p, ConsWindowOut &ou
         if (out.col_off[n_cols] != sum_depth) { err = "column depths do not add up to the reads' columns"; return -1; }
         out.seq.assign(sum_depth + 1, 0); out.qual.assign(sum_depth + 1, 0);
         d.col_off = out.col_off.data(); d.seq_chars = out.seq.data(); d.qual_chars = out.qual.data();
-        for (uint64_t c = 0; c < n_cols; ++c) cons::step_text(d, o, (int64_t)c);
+        for (uint64_t c = 0; c < n_cols; ++c) { const int32_t c0 = (int32_t)(c & ~63ull); cons::step_text(d, o, (int64_t)c, c0, (int32_t)std::min<uint64_t>(c0 + 63, n_cols - 1)); }
     }
     return 0;
 }

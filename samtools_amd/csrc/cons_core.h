@@ -284,26 +284,65 @@ CONS_HD int read_prepare(const Par &o, const Tables &t, const ReadView &r, uint8
 // of one lane walking one read.  The MD / soft-clip costs are added afterwards by read_prepare_md().
 CONS_HD bool prepare_is_per_base(const Par &o) { return !o.homopoly_on && o.mode != MODE_BAYES_116; }
 
-CONS_HD int32_t prepare_base(const Par &o, const ReadView &r, int i)
+// nm words of the 8 bases i0 .. i0 + 7 (i0 a multiple of 8; rows of the staged pools are padded to 8 bases and start on 8-byte /
+// 4-byte boundaries).  Everything the 8 bases need is loaded up front with independent loads -- their qualities as one 64-bit
+// word, the packed sequence of bases i0 - 16 .. i0 + 23 as five 32-bit words -- and the per-base work runs on registers: the
+// first 12 neighbours either side of a base are compared without data-dependent control flow, only a longer homopolymer falls
+// into the loops, which search no further than the cap of 100 needs.
+CONS_HD void prepare_granule(const Par &o, const ReadView &r, int i0, int32_t out[8])
 {
     const int qlen = r.l_qseq;
     const uint8_t *qual = r.qual, *seq = r.seq;
-    int adj = 0;
-    if (o.adj_qual && i >= 8) {
-        int qminp0 = qual[0];
-        if (qlen > 1 && seqi(seq, 1) == seqi(seq, 0) && qminp0 > qual[1]) qminp0 = qual[1];
-        int qminp;
-        if (qlen > 16) qminp = i < qlen - 8 ? (i == 8 ? qminp0 : qual[i - 1]) : qual[qlen - 9];
-        else qminp = qminp0;
-        const int tq = qual[i] / 3 + qminp;
-        adj = tq < qual[i] ? qual[i] - tq : 0;
+    uint64_t q8; __builtin_memcpy(&q8, qual + i0, 8);
+    const int qprev = i0 > 0 ? qual[i0 - 1] : 0;
+    const int q0 = qual[0], q1 = qlen > 1 ? qual[1] : 0, s01 = seq[0];
+    const int qtail = qlen > 16 ? qual[qlen - 9] : 0;
+    const int n_words = (qlen + 7) >> 3, wc = i0 >> 3;
+    uint32_t wd[5];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 5; ++k) {
+        int wi = wc - 2 + k; if (wi < 0) wi = 0; if (wi > n_words - 1) wi = n_words - 1;
+        uint32_t x; __builtin_memcpy(&x, seq + (size_t)wi * 4, 4); wd[k] = x;
     }
-    const int base = seqi(seq, i);
-    int lo = i, hi = i;                                  // run of equal codes around i, searched no further than the cap needs
-    while (lo > 0 && i - lo < 101 && seqi(seq, lo - 1) == base) --lo;
-    while (hi + 1 < qlen && hi - lo < 101 && seqi(seq, hi + 1) == base) ++hi;
-    int poly = hi - lo; if (poly > 100) poly = 100;
-    return (poly << 24) | adj;
+    int qminp0 = q0;
+    if (qlen > 1 && (s01 >> 4) == (s01 & 15) && qminp0 > q1) qminp0 = q1;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int b = 0; b < 8; ++b) {
+        const int i = i0 + b;
+        if (i >= qlen) { out[b] = 0; continue; }
+        const int qi = (int)((q8 >> (8 * b)) & 255u), qim1 = b ? (int)((q8 >> (8 * (b - 1))) & 255u) : qprev;
+        int adj = 0;
+        if (o.adj_qual && i >= 8) {
+            int qminp;
+            if (qlen > 16) qminp = i < qlen - 8 ? (i == 8 ? qminp0 : qim1) : qtail;
+            else qminp = qminp0;
+            const int tq = qi / 3 + qminp;
+            adj = tq < qi ? qi - tq : 0;
+        }
+        // base t of a 32-bit word sits in byte t / 2, high nibble when t is even; rel = position inside the five words
+#define CONS_NIB(rel) ((int)((wd[(rel) >> 3] >> ((((rel) & 7) >> 1) * 8 + (((rel) & 1) ? 0 : 4))) & 15u))
+        const int base = CONS_NIB(16 + b);
+        int left = 0, right = 0;
+        bool okl = true, okr = true;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int d = 1; d <= 12; ++d) {
+            okl = okl && i - d >= 0 && CONS_NIB(16 + b - d) == base;
+            okr = okr && i + d < qlen && CONS_NIB(16 + b + d) == base;
+            left += okl; right += okr;
+        }
+#undef CONS_NIB
+        int lo = i - left, hi = i + right;
+        if (left == 12) while (lo > 0 && i - lo < 101 && seqi(seq, lo - 1) == base) --lo;
+        if (right == 12) while (hi + 1 < qlen && hi - lo < 101 && seqi(seq, hi + 1) == base) ++hi;
+        int poly = hi - lo; if (poly > 100) poly = 100;
+        out[b] = (poly << 24) | adj;
+    }
 }
 
 // soft-clip and MD mismatch costs on top of nm[] (the tail of nm_init, bam_consensus.c:1138-1203)

@@ -99,8 +99,8 @@ template <class AMAX> CONS_HD int step_read_a(const Win &w, const Par &o, const 
         const char *md = nullptr; int md_len = 0;
         md_of(w, r, md, md_len);
         int32_t *nm = w.nm + (size_t)w.base_off8[r] * 8;
-        if (prepare_is_per_base(o)) {                              // the formulation the device runs one lane per base
-            for (int i = 0; i < v.l_qseq; ++i) nm[i] = prepare_base(o, v, i);
+        if (prepare_is_per_base(o)) {                              // the formulation the device runs one lane per 8 bases
+            for (int i0 = 0; i0 < v.l_qseq; i0 += 8) prepare_granule(o, v, i0, nm + i0);
             read_prepare_md(o, v, md, md_len, nm);
         } else read_prepare(o, t, v, w.qual + (size_t)w.base_off8[r] * 8, md, md_len, nm);
     }

@@ -87,10 +87,10 @@ __global__ void __launch_bounds__(64) k_cons_prepare(Win w, Par o, const Tables 
     if (o.homopoly_on) { uint32_t *gw = (uint32_t *)(w.qual + first); for (int64_t i = lane; i < B / 4; i += 64) gw[i] = ((uint32_t *)lq)[i]; }
 }
 
-// The default configuration (no homopolymer fixing, not the 1.16 mode) needs no sequential walk: prepare_base() gives the nm
-// word of one base from its neighbours.  One thread per staged base: k_cons_granules first notes, for every 8-base granule of
-// the pool (reads start on granule boundaries), which read it belongs to; k_cons_prepare_base then runs over the pool with
-// fully coalesced quality / sequence loads and nm stores and nothing sequential.
+// The default configuration (no homopolymer fixing, not the 1.16 mode) needs no sequential walk: prepare_granule() gives the nm
+// words of 8 bases from their neighbourhood.  One thread per staged base: k_cons_granules first notes, for every 8-base granule of
+// the pool (reads start on granule boundaries), which read it belongs to; k_cons_prepare_base then runs over the pool, one
+// thread per granule, with nothing sequential between bases.
 __global__ void __launch_bounds__(256) k_cons_granules(Win w, int32_t *gran2read)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,16 +98,20 @@ __global__ void __launch_bounds__(256) k_cons_granules(Win w, int32_t *gran2read
     const uint32_t g0 = w.base_off8[r], g1 = g0 + (uint32_t)((w.l_qseq[r] + 7) >> 3);
     for (uint32_t g = g0; g < g1; ++g) gran2read[g] = (int32_t)r;
 }
-__global__ void __launch_bounds__(256) k_cons_prepare_base(Win w, Par o, const int32_t *gran2read, int64_t n_bases)
+__global__ void __launch_bounds__(256) k_cons_prepare_base(Win w, Par o, const int32_t *gran2read, int64_t n_gran)
 {
-    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= n_bases) return;
-    const int32_t r = gran2read[x >> 3];
+    // one thread per granule of 8 bases: the chain gran2read -> read record -> qualities is several dependent memory
+    // latencies deep, and a thread that stops after one base spends its whole life waiting on it
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_gran) return;
+    const int32_t r = gran2read[g];
     if (r < 0) return;
-    const int i = (int)(x - (int64_t)w.base_off8[r] * 8);
-    if (i >= w.l_qseq[r]) return;                        // padding behind the read's last base
+    const int i0 = (int)((g - (int64_t)w.base_off8[r]) * 8);
     const ReadView v = view_of(w, r, false);
-    w.nm[x] = prepare_base(o, v, i);
+    int32_t out[8];
+    prepare_granule(o, v, i0, out);
+    int4 *nm = (int4 *)(w.nm + g * 8);
+    nm[0] = make_int4(out[0], out[1], out[2], out[3]); nm[1] = make_int4(out[4], out[5], out[6], out[7]);
 }
 // ... followed by the soft-clip / MD costs, one lane per read that carries an MD tag
 __global__ void __launch_bounds__(256) k_cons_prepare_md(Win w, Par o)
@@ -206,7 +210,7 @@ void sta_launch_cons_prepare(hipStream_t s, const Win &w, const Par &o, const Ta
     if (w.n_reads > 0 && prepare_is_per_base(o)) {
         hipMemsetAsync(gran2read, 0xff, (size_t)((n_bases + 7) / 8) * 4, s);
         hipLaunchKernelGGL(k_cons_granules, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, gran2read);
-        hipLaunchKernelGGL(k_cons_prepare_base, dim3(blocks_for(n_bases)), dim3(256), 0, s, w, o, gran2read, n_bases);
+        hipLaunchKernelGGL(k_cons_prepare_base, dim3(blocks_for((n_bases + 7) / 8)), dim3(256), 0, s, w, o, gran2read, (n_bases + 7) / 8);
         hipLaunchKernelGGL(k_cons_prepare_md, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, o);
         return;
     }

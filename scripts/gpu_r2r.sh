@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r2r; mkdir -p $O
+(timeout 1200 python -m pytest tests/test_gpu_consensus.py -q -m gpu -n 12 -x > $O/pytest_cons.log 2>&1; echo "pytest rc=$?" >> $O/pytest_cons.log)
+tail -n 3 $O/pytest_cons.log
+for w in consensus30_simple consensus30; do
+timeout 400 python bench.py --workload $w --steps 10 --warmup 3 > $O/bench_$w.json 2> $O/bench_$w.err; tail -n 2 $O/bench_$w.err; python -c "
+import json; d=json.loads(open('$O/bench_$w.json').read()); print('$w', d['value'], d['ms_per_step'], d['kernels_ms_per_step'])"
+done
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_cons30 -- python $GRAFT_REPO_ROOT/bench.py --workload consensus30 --steps 10 --warmup 3 --no-cpu-baseline --no-pmc > /dev/null 2> $GRAFT_REPO_ROOT/$O/prof.err
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_cons30s -- python $GRAFT_REPO_ROOT/bench.py --workload consensus30_simple --steps 10 --warmup 3 --no-cpu-baseline --no-pmc > /dev/null 2>> $GRAFT_REPO_ROOT/$O/prof.err
+cd $GRAFT_REPO_ROOT; for d in prof_cons30 prof_cons30s; do find $O/$d -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -6 {}'; done
+timeout 900 python scripts/e2e_cons.py 2 4375000 /dev/shm/sta_e2e_cons > $O/e2e_cons.log 2>&1; cat $O/e2e_cons.log

@@ -496,6 +496,35 @@ def main():
                     got = eng.fetch_output(int(inf.out_bytes))
                     res["parity_check"] = {"sample_cols": sample, "bytes": len(got), "engine_sha256": hashlib.sha256(got).hexdigest(),
                                            "oracle_sha256": o["sha256"], "identical": hashlib.sha256(got).hexdigest() == o["sha256"]}
+                if kind == "consensus":
+                    # the same sample through the bulk entry: every column's (position, nth, depth, call, quality) against the rows
+                    # of the oracle's `-f pileup` output for the same options (the oracle is only the checker)
+                    ws, keep_s, _ = build_window(torch, np, sa, o["rd"], sample, dev)
+                    nrs = int(o["rd"]["n"])
+                    if cons_par.mode != 0:
+                        xo_s = torch.arange(nrs + 1, dtype=torch.int32, device=dev); xt_s = torch.full((nrs + 1,), ord("*"), dtype=torch.uint8, device=dev)
+                        keep_s += [xo_s, xt_s]
+                        ws.files[0].n_xcols = 1; ws.files[0].xcol_off = xo_s.data_ptr(); ws.files[0].xcol_text = xt_s.data_ptr(); ws.files[0].n_xcol_bytes = nrs
+                    eng.stage_window(ws)
+                    ci = eng.consensus_run(cons_par)
+                    ins, cols, _, _, _ = eng.fetch_consensus(sample, ci)
+                    ins = np.frombuffer(ins, dtype=np.int32, count=sample)
+                    cv = np.frombuffer(cols, dtype=np.int32, count=int(ci.n_cols) * 3).reshape(-1, 3)
+                    pos = np.repeat(np.arange(1, sample + 1, dtype=np.int64), ins + 1)
+                    first = np.cumsum(ins + 1) - (ins + 1)
+                    nth = np.arange(int(ci.n_cols), dtype=np.int64) - np.repeat(first, ins + 1)
+                    keepc = (cv[:, 0] > 0) & (cv[:, 1] != ord("*"))
+                    got_rows = np.stack([pos[keepc], nth[keepc], cv[keepc, 0], cv[keepc, 1], cv[keepc, 2]], axis=1)
+                    pargs = [x for x in WORKLOADS[a.workload][4] if x not in ("-f", "fastq")]
+                    inp = synth_inputs(depth, sample)
+                    try:
+                        pr = subprocess.run([os.path.join(REPO, "oracle", "_build", "oracle_samtools")] + [x.format(sam=inp["sam"], fa=inp["fa"]) for x in pargs[:-1]] + ["-f", "pileup", inp["sam"]],
+                                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+                    finally:
+                        shutil.rmtree(inp["dir"], ignore_errors=True)
+                    want_rows = np.array([[int(f[1]), int(f[2]), int(f[3]), ord(f[4]), int(f[5])] for f in (l.split("\t") for l in pr.stdout.decode().split("\n") if l)], dtype=np.int64)
+                    same = got_rows.shape == want_rows.shape and bool((got_rows == want_rows).all())
+                    res["parity_check"] = {"sample_cols": sample, "columns": int(got_rows.shape[0]), "what": "(position, nth, depth, call, quality) of every column vs the oracle's -f pileup rows", "identical": same}
         print(json.dumps(res))
         if res.get("parity_check") and not res["parity_check"]["identical"]:
             raise SystemExit("bench.py: the engine's text for the CPU-baseline sample differs from the oracle's")

@@ -329,7 +329,6 @@ static int finish_plan(sta_engine *e, int64_t ncols, sta_plan_info *info)
     uint32_t cap = (uint32_t)((mw + 255) & ~255ull);
     if (cap < 1024) cap = 1024;
     if (cap > 65536 - 64) cap = 65536 - 64;
-    if (getenv("STA_EMIT_LDS_CAP")) cap = (uint32_t)atoi(getenv("STA_EMIT_LDS_CAP"));      // experiment: waves above the cap write straight to global memory
     e->lds_cap = cap;
     if (info) {
         info->out_bytes = total; info->n_lines = e->ctr_h.n_lines; info->n_data_cols = e->ctr_h.n_data_cols;

@@ -338,6 +338,14 @@ int sta_consensus_run(sta_engine *e, const sta_cons_params *p, sta_cons_info *in
  * position; cols[n_cols]; with want_pileup col_off[n_cols + 1] into seq_chars / qual_chars[n_entries] (pileup_t.base as
  * `-f pileup` prints it: reverse-strand bases lower-cased, '#' for a reverse-strand pad; min(qual, 93) + '!'). */
 int sta_fetch_consensus(sta_engine *e, int32_t *ins, sta_cons_col *cols, uint64_t *col_off, char *seq_chars, char *qual_chars);
+/* The iterator half alone -- what pileup_loop() / get_next_base() hand to seq_column (consensus_pileup.c:69-608) -- for callers
+ * that keep their own per-column code (samtools_amd_cons.h builds pileup_loop on it).  No read filters besides the unmapped
+ * flag.  info->n_entries = entry words.  Per read i of the staged file: its first / last column index in the window
+ * (last < first: not in it) and entry_off[i]; its entry for column c is entries[entry_off[i] + c - first_col[i]]:
+ * bits 0-4 4-bit base code (16 = pad / deletion), 5-12 quality, 0x2000 ref_skip, 0x4000 reverse strand, 0x8000 the column
+ * lies in a reference skip (base '.'), 0x10000 padding; seq_offs[] = pileup_t.seq_offset of the same entry. */
+int sta_cons_entries_run(sta_engine *e, sta_cons_info *info);
+int sta_fetch_cons_entries(sta_engine *e, int32_t *ins, int32_t *first_col, int32_t *last_col, uint64_t *entry_off, uint32_t *entries, uint32_t *seq_offs);
 /* ---- depth ---- */
 int sta_depth_plan(sta_engine *e, const sta_depth_params *p, sta_plan_info *info);
 int sta_depth_emit(sta_engine *e, void *dev_out, uint64_t capacity);

@@ -26,7 +26,7 @@
 #include <zlib.h>
 #include "o_common.h"
 
-enum { FMT_FASTQ, FMT_FASTA, FMT_PILEUP };
+enum { FMT_FASTQ, FMT_FASTA, FMT_PILEUP, FMT_DUMP };       /* FMT_DUMP: every pileup_t field seq_column sees (for the pileup_loop() surface tests) */
 enum { MODE_SIMPLE, MODE_BAYES_116, MODE_RECALL, MODE_PRECISE, MODE_MIXED };
 
 typedef struct { int smap[101], umap[101], omap[101]; } qcal_t;
@@ -617,6 +617,16 @@ static int column_pileup(cctx_t *c, const cread_t *p, int depth, hpos_t pos, int
     return 0;
 }
 
+/* -f dump (not a samtools format): one row per column with what get_next_base left in every pileup_t */
+static int column_dump(cctx_t *c, const cread_t *p, int depth, hpos_t pos, int nth)
+{
+    fprintf(c->o->out, "%s\t%lld\t%d\t%d", c->o->h->name[p->b.tid], (long long)pos, nth, depth);
+    for (; p; p = p->next)
+        fprintf(c->o->out, "\t%c,%d,%d,%d,%d,%d,%d", p->base, p->qual, p->base4, p->ref_skip, p->is_rev, p->seq_off, p->padding);
+    fputc('\n', c->o->out);
+    return 0;
+}
+
 /* bam_consensus.c:2054-2075 */
 static void dump_fastq(const copts_t *o, const char *name, const ostr_t *seq, const ostr_t *qual)
 {
@@ -714,7 +724,7 @@ static int column_loop(cctx_t *c)
                 depth++;
             }
             tail = last ? last : head;
-            int v = o->fmt == FMT_PILEUP ? column_pileup(c, head, depth, col, nth) : column_fasta(c, head, depth, col, nth);
+            int v = o->fmt == FMT_DUMP ? column_dump(c, head, depth, col, nth) : o->fmt == FMT_PILEUP ? column_pileup(c, head, depth, col, nth) : column_fasta(c, head, depth, col, nth);
             for (p = dead; p; p = p->eofn) {
                 if (p->eofl) p->eofl->next = p->next; else head = p->next;
                 p->next = pool; pool = p;
@@ -888,7 +898,8 @@ static int run_serial(copts_t *o, const char *fn)
         rd_close(c.rd); c.rd = NULL;
         if (lr < 0) goto err;
 
-        if (o->fmt == FMT_PILEUP) {
+        if (o->fmt == FMT_DUMP) {
+        } else if (o->fmt == FMT_PILEUP) {
             if (o->all_bases) {
                 int tid = c.has_iter ? c.iter_tid : c.last_tid;
                 hpos_t len = tid >= 0 && tid < o->h->n_ref ? o->h->len[tid] : 0, pos = c.last_pos;
@@ -1039,6 +1050,7 @@ int o_main_consensus(int argc, char *argv[])
             if (!strcasecmp(optarg, "fasta")) o.fmt = FMT_FASTA;
             else if (!strcasecmp(optarg, "fastq")) o.fmt = FMT_FASTQ;
             else if (!strcasecmp(optarg, "pileup")) o.fmt = FMT_PILEUP;
+            else if (!strcasecmp(optarg, "dump")) o.fmt = FMT_DUMP;
             else { fprintf(stderr, "Unknown format %s\n", optarg); return 1; }
             break;
         case 'o': if (!(o.out = fopen(optarg, "w"))) { perror(optarg); return 1; } break;

@@ -178,6 +178,8 @@ _PROTOS = {
     "sta_consensus_run": (C.c_int, [_P, C.POINTER(ConsParams), C.POINTER(ConsInfo)]),
     "sta_fetch_consensus": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "sta_main_consensus": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "sta_cons_entries_run": (C.c_int, [_P, C.POINTER(ConsInfo)]),
+    "sta_fetch_cons_entries": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "sta_io_scan": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 EXPORTED_SYMBOLS = sorted(_PROTOS)

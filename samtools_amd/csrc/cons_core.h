@@ -56,6 +56,7 @@ struct Tables {
 #define CONS_E_REFSKIP 0x2000u       // pileup_t.ref_skip (also set on the bases either side of a reference skip)
 #define CONS_E_REV 0x4000u
 #define CONS_E_SKIPCOL 0x8000u       // the column lies inside an N operation: pileup_t.base == '.'
+#define CONS_E_PAD 0x10000u          // pileup_t.padding: the entry is a pad opposite another read's insertion
 #define CONS_NM_FLAT 0x80000000u     // nm word: index fell off the read, nm_local() does not divide by 10 and poly_len() is 0
 
 struct ReadView {
@@ -105,12 +106,12 @@ template <class F> CONS_HD Shape read_shape(const ReadView &r, F on_run)
 struct Cursor {
     int32_t pos;                 // reference position of the last consumed column (relative)
     int32_t nth, seq_off, cig_ind, cig_op, cig_len, eof, qual, base4;
-    bool ref_skip, skipcol;
+    bool ref_skip, skipcol, pad;
 
     CONS_HD void init(int32_t start)
     {
         pos = start - 1; nth = 0; seq_off = -1; cig_ind = 0; cig_op = -1; cig_len = 0; eof = 0; qual = 0; base4 = 0;
-        ref_skip = false; skipcol = false;
+        ref_skip = false; skipcol = false; pad = false;
     }
     CONS_HD bool take(const ReadView &r)
     {
@@ -146,9 +147,9 @@ struct Cursor {
             else if (op <= 8) break;
             else return -1;
         }
-        ref_skip = false; skipcol = false;
+        ref_skip = false; skipcol = false; pad = false;
         if (nth < n && op != 1) {                        // pad opposite somebody else's insertion
-            base4 = 16;
+            base4 = 16; pad = true;
             if (seq_off < r.l_qseq) { const int q = qat(r, seq_off + 1); if (q < qual) qual = q; }
             else qual = 0;
         } else if (op == 2 || op == 6) {
@@ -175,7 +176,7 @@ struct Cursor {
     }
     CONS_HD uint32_t entry(bool rev) const
     {
-        return (uint32_t)base4 | ((uint32_t)(qual & 255) << 5) | (ref_skip ? CONS_E_REFSKIP : 0u) | (rev ? CONS_E_REV : 0u) | (skipcol ? CONS_E_SKIPCOL : 0u);
+        return (uint32_t)base4 | ((uint32_t)(qual & 255) << 5) | (ref_skip ? CONS_E_REFSKIP : 0u) | (rev ? CONS_E_REV : 0u) | (skipcol ? CONS_E_SKIPCOL : 0u) | (pad ? CONS_E_PAD : 0u);
     }
 };
 

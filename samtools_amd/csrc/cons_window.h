@@ -68,7 +68,8 @@ CONS_HD void md_of(const Win &w, int64_t r, const char *&md, int &md_len)
 
 // AMAX(ptr, value): atomic max on the device, plain max in the harness.  1 = the read is in the pileup, 0 = filtered,
 // -1 = its CIGAR holds an operation outside MIDNSHP=X
-template <class AMAX> CONS_HD int step_read_a(const Win &w, const Par &o, const Tables &t, int64_t r, AMAX amax, bool prepare_here)
+// walk_all: every read gets stored entries (the iterator surface hands the entries themselves out), none counts as plain
+template <class AMAX> CONS_HD int step_read_a(const Win &w, const Par &o, const Tables &t, int64_t r, AMAX amax, bool prepare_here, bool walk_all = false)
 {
     w.r_keep[r] = 0; w.r_last[r] = w.pos[r] - 1; w.r_tail[r] = 0;
     const int fl = w.flag[r];
@@ -92,7 +93,7 @@ template <class AMAX> CONS_HD int step_read_a(const Win &w, const Par &o, const 
         else if (op == 4) { if (!n_al) lead += len; }
         else if (op != 5) plain = false;
     }
-    plain = plain && n_al == 1;
+    plain = plain && n_al == 1 && !walk_all;
     // the per-read preparation (only l_qseq <= 0 makes it drop a read, and that was tested above) runs here in the harness
     // and in its own LDS-staged kernel on the device
     if (bayes_mq && prepare_here) {
@@ -163,7 +164,8 @@ CONS_HD uint32_t entry_at(const Win &w, bool bayes_mq, bool working_qual, int64_
     return w.E[at];
 }
 
-CONS_HD void step_walk(const Win &w, const Par &o, int64_t r)
+// so_words: the second word of an entry is the query offset (pileup_t.seq_offset) instead of the nm word
+CONS_HD void step_walk(const Win &w, const Par &o, int64_t r, bool so_words = false)
 {
     const uint32_t cnt = w.cnt[r];
     if (!cnt) return;
@@ -171,7 +173,7 @@ CONS_HD void step_walk(const Win &w, const Par &o, int64_t r)
     ReadView v = view_of(w, r, bayes_mq && o.homopoly_on);
     const bool rev = (w.r_keep[r] & 2u) != 0;
     uint32_t *E = w.E + w.rowoff[r];
-    uint32_t *En = bayes_mq ? w.Enm + w.rowoff[r] : nullptr;
+    uint32_t *En = bayes_mq || so_words ? w.Enm + w.rowoff[r] : nullptr;
     const int32_t *nm = bayes_mq ? w.nm + (size_t)w.base_off8[r] * 8 : nullptr;
     const int32_t cs = w.cs[r];
     Cursor cur; cur.init(v.start);
@@ -191,7 +193,7 @@ CONS_HD void step_walk(const Win &w, const Par &o, int64_t r)
             if (cur.step(v, p, n, ins) <= 0) { done = true; break; }
             if (inw) {
                 k = (uint32_t)((int32_t)w.colbase[p - w.col_beg] + n - cs);
-                if (k < cnt) { E[k] = cur.entry(rev); if (En) En[k] = nm_word(nm, v.l_qseq, cur.seq_off); }
+                if (k < cnt) { E[k] = cur.entry(rev); if (En) En[k] = so_words ? (uint32_t)cur.seq_off : nm_word(nm, v.l_qseq, cur.seq_off); }
                 k++;
             }
             if (cur.eof == 1) { done = true; break; }

@@ -70,7 +70,7 @@ struct sta_engine {
     // consensus
     DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
-    cons::Win cons_w{}; uint64_t cons_ncols = 0, cons_nentries = 0; int64_t cons_W = 0; bool cons_text = false;
+    cons::Win cons_w{}; uint64_t cons_ncols = 0, cons_nentries = 0, cons_nstored = 0; int64_t cons_W = 0; bool cons_text = false, cons_walk_all = false;
     int baq_slab_gib_cap = 0;       // 0 = default; 4 after a one-launch BAQ slab could not be allocated
     double glf_depcorr = -1.0;      // theta the coefficient block in glf_tab was computed for
     StaWinDev wd{};
@@ -777,7 +777,20 @@ int sta_glf_plan(sta_engine *e, const sta_glf_params *gp, sta_plan_info *info)
 }
 
 // `samtools consensus` on file 0 of the staged window (kernels_cons.hip; steps in cons_window.h)
-int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *info)
+static int cons_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *info, bool walk_all);
+
+int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *info) { return cons_run(e, cp, info, false); }
+
+// the iterator half only (pileup_loop / get_next_base): every read's entries, no callers.  The caller's seq_fetch has done the
+// filtering, so only the unmapped flag is tested (consensus_pileup.c:341-349).
+int sta_cons_entries_run(sta_engine *e, sta_cons_info *info)
+{
+    sta_cons_params p; memset(&p, 0, sizeof p);
+    p.mode = STA_CONS_SIMPLE;
+    return cons_run(e, &p, info, true);
+}
+
+static int cons_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *info, bool walk_all)
 {
     if (!e || !cp) return STA_ERR_ARG;
     if (!e->staged) return fail(e, STA_ERR_ARG, "no staged window");
@@ -830,7 +843,7 @@ int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *i
     }
     HIPCHK(hipMemsetAsync(w.ins, 0, (size_t)(W + 1) * 4, s));
     HIPCHK(hipMemsetAsync(w.counters, 0, 64, s));
-    { ProfScope ps(e, "cons_read_a"); sta_launch_cons_read_a(s, w, o, tab); }
+    { ProfScope ps(e, "cons_read_a"); sta_launch_cons_read_a(s, w, o, tab, walk_all); }
     if (bayes_mq) { ProfScope ps(e, "cons_prepare"); sta_launch_cons_prepare(s, w, o, tab, (int32_t *)e->cons_gran.p, (int64_t)d.n_bases_total); }
     { ProfScope ps(e, "cons_scans");
       sta_launch_cons_collen(s, w.ins, collen, W);
@@ -845,17 +858,17 @@ int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *i
     HIPCHK(hipMemcpyAsync(ctr, w.counters, 32, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (ctr[1]) return fail(e, STA_ERR_ARG, "a CIGAR holds an operation outside MIDNSHP=X");
-    if (e->cons_E.ensure((size_t)n_entries * 4 + 64) || (bayes_mq && e->cons_Enm.ensure((size_t)n_entries * 4 + 64)) || e->cons_cols.ensure((size_t)n_cols * sizeof(sta_cons_col) + 64)
+    if (e->cons_E.ensure((size_t)n_entries * 4 + 64) || ((bayes_mq || walk_all) && e->cons_Enm.ensure((size_t)n_entries * 4 + 64)) || e->cons_cols.ensure((size_t)n_cols * sizeof(sta_cons_col) + 64)
         || e->cons_depth.ensure((size_t)n_cols * 4 + 64) || e->cons_colpos.ensure((size_t)n_cols * 4 + 64))
         return fail(e, STA_ERR_HIP, "hipMalloc(consensus entries) failed");
     w.colpos = (int32_t *)e->cons_colpos.p;
     const uint64_t sum_depth = ctr[3];
-    w.E = (uint32_t *)e->cons_E.p; w.Enm = bayes_mq ? (uint32_t *)e->cons_Enm.p : nullptr;
+    w.E = (uint32_t *)e->cons_E.p; w.Enm = bayes_mq || walk_all ? (uint32_t *)e->cons_Enm.p : nullptr;
     w.cols = (sta_cons_col *)e->cons_cols.p; w.depth = (uint32_t *)e->cons_depth.p;
     { ProfScope ps(e, "cons_colpos"); sta_launch_cons_colpos(s, w); }
-    { ProfScope ps(e, "cons_walk"); sta_launch_cons_walk(s, w, o, (int64_t)ctr[2]); }
-    { ProfScope ps(e, "cons_col"); sta_launch_cons_col(s, w, o, tab, (int64_t)n_cols); }
-    e->cons_text = cp->want_pileup != 0;
+    { ProfScope ps(e, "cons_walk"); sta_launch_cons_walk(s, w, o, (int64_t)ctr[2], walk_all); }
+    if (!walk_all) { ProfScope ps(e, "cons_col"); sta_launch_cons_col(s, w, o, tab, (int64_t)n_cols); }
+    e->cons_text = cp->want_pileup != 0 && !walk_all;
     if (e->cons_text) {
         if (e->cons_coloff.ensure((size_t)(n_cols + 2) * 8 + 64) || e->cons_seq.ensure((size_t)sum_depth + 64) || e->cons_qual.ensure((size_t)sum_depth + 64)
             || e->scan_tmp.ensure(sta_scan_tmp_bytes((int64_t)n_cols + 1) + 64))
@@ -868,16 +881,34 @@ int sta_consensus_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *i
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "consensus kernels");
     prof_drain(e);
-    e->cons_w = w; e->cons_ncols = n_cols; e->cons_nentries = sum_depth; e->cons_W = W;
+    e->cons_w = w; e->cons_ncols = n_cols; e->cons_nentries = sum_depth; e->cons_W = W; e->cons_walk_all = walk_all; e->cons_nstored = n_entries;
     if (info) { info->n_cols = n_cols; info->n_entries = sum_depth; info->n_kept_reads = ctr[0]; }
-    e->planned = 6;
+    e->planned = walk_all ? 7 : 8;
+    return STA_OK;
+}
+
+int sta_fetch_cons_entries(sta_engine *e, int32_t *ins, int32_t *first_col, int32_t *last_col, uint64_t *entry_off, uint32_t *entries, uint32_t *seq_offs)
+{
+    if (!e) return STA_ERR_ARG;
+    if (e->planned != 7) return fail(e, STA_ERR_ARG, "no consensus entries were computed");
+    hipSetDevice(e->device);
+    hipStream_t s = e->stream;
+    const cons::Win &w = e->cons_w;
+    const size_t n = (size_t)w.n_reads;
+    if (ins && e->cons_W) HIPCHK(hipMemcpyAsync(ins, w.ins + 1, (size_t)e->cons_W * 4, hipMemcpyDeviceToHost, s));
+    if (first_col && n) HIPCHK(hipMemcpyAsync(first_col, w.cs, n * 4, hipMemcpyDeviceToHost, s));
+    if (last_col && n) HIPCHK(hipMemcpyAsync(last_col, w.ce, n * 4, hipMemcpyDeviceToHost, s));
+    if (entry_off) HIPCHK(hipMemcpyAsync(entry_off, w.rowoff, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (entries && e->cons_nstored) HIPCHK(hipMemcpyAsync(entries, w.E, (size_t)e->cons_nstored * 4, hipMemcpyDeviceToHost, s));
+    if (seq_offs && e->cons_nstored) HIPCHK(hipMemcpyAsync(seq_offs, w.Enm, (size_t)e->cons_nstored * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return STA_OK;
 }
 
 int sta_fetch_consensus(sta_engine *e, int32_t *ins, sta_cons_col *cols, uint64_t *col_off, char *seq_chars, char *qual_chars)
 {
     if (!e) return STA_ERR_ARG;
-    if (e->planned != 6) return fail(e, STA_ERR_ARG, "no consensus window was run");
+    if (e->planned != 8) return fail(e, STA_ERR_ARG, "no consensus window was run");
     if ((col_off || seq_chars || qual_chars) && !e->cons_text) return fail(e, STA_ERR_ARG, "the window was run without want_pileup");
     hipSetDevice(e->device);
     hipStream_t s = e->stream;

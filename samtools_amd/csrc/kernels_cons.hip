@@ -18,11 +18,11 @@ __device__ __forceinline__ unsigned long long wave_sum_ull(unsigned long long v)
     return v;       // lane 0 holds the sum
 }
 
-__global__ void __launch_bounds__(256) k_cons_read_a(Win w, Par o, const Tables *t)
+__global__ void __launch_bounds__(256) k_cons_read_a(Win w, Par o, const Tables *t, int walk_all)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int code = 0;
-    if (r < w.n_reads) code = step_read_a(w, o, *t, r, [](uint32_t *p, uint32_t v) { atomicMax(p, v); }, false);
+    if (r < w.n_reads) code = step_read_a(w, o, *t, r, [](uint32_t *p, uint32_t v) { atomicMax(p, v); }, false, walk_all != 0);
     // one global atomic per workgroup, not per read: a single counter word takes ~90 atomics per microsecond
     __shared__ unsigned int s_kept, s_bad;
     if (threadIdx.x == 0) { s_kept = 0; s_bad = 0; }
@@ -162,10 +162,10 @@ __global__ void __launch_bounds__(256) k_cons_colpos(Win w, int64_t W)
     if (i < W) step_colpos(w, i);
 }
 
-__global__ void __launch_bounds__(256) k_cons_walk(Win w, Par o, int64_t n_list)
+__global__ void __launch_bounds__(256) k_cons_walk(Win w, Par o, int64_t n_list, int so_words)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_list) step_walk(w, o, w.clist[k]);
+    if (k < n_list) step_walk(w, o, w.clist[k], so_words != 0);
 }
 
 // The Bayesian caller looks up eleven table entries per read and column (q2p, mqual_pow_1m, nine log-probabilities): the
@@ -201,9 +201,9 @@ __global__ void __launch_bounds__(256) k_cons_text(Win w, Par o, int64_t n_cols)
 }
 
 
-void sta_launch_cons_read_a(hipStream_t s, const Win &w, const Par &o, const Tables *t)
+void sta_launch_cons_read_a(hipStream_t s, const Win &w, const Par &o, const Tables *t, bool walk_all)
 {
-    if (w.n_reads > 0) hipLaunchKernelGGL(k_cons_read_a, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, o, t);
+    if (w.n_reads > 0) hipLaunchKernelGGL(k_cons_read_a, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, o, t, walk_all ? 1 : 0);
 }
 void sta_launch_cons_prepare(hipStream_t s, const Win &w, const Par &o, const Tables *t, int32_t *gran2read, int64_t n_bases)
 {
@@ -229,9 +229,9 @@ void sta_launch_cons_colpos(hipStream_t s, const Win &w)
     const int64_t W = (int64_t)w.col_end - w.col_beg;
     if (W > 0) hipLaunchKernelGGL(k_cons_colpos, dim3(blocks_for(W)), dim3(256), 0, s, w, W);
 }
-void sta_launch_cons_walk(hipStream_t s, const Win &w, const Par &o, int64_t n_list)
+void sta_launch_cons_walk(hipStream_t s, const Win &w, const Par &o, int64_t n_list, bool so_words)
 {
-    if (n_list > 0) hipLaunchKernelGGL(k_cons_walk, dim3(blocks_for(n_list)), dim3(256), 0, s, w, o, n_list);
+    if (n_list > 0) hipLaunchKernelGGL(k_cons_walk, dim3(blocks_for(n_list)), dim3(256), 0, s, w, o, n_list, so_words ? 1 : 0);
 }
 void sta_launch_cons_col(hipStream_t s, const Win &w, const Par &o, const Tables *t, int64_t n_cols)
 {

@@ -134,11 +134,11 @@ void sta_launch_depth_pair(hipStream_t s, const StaReadsDev &r, int64_t origin, 
 
 // consensus (kernels_cons.hip; the window record and the step functions are in cons_window.h)
 namespace cons { struct Win; struct Par; struct Tables; }
-void sta_launch_cons_read_a(hipStream_t s, const cons::Win &w, const cons::Par &o, const cons::Tables *t);
+void sta_launch_cons_read_a(hipStream_t s, const cons::Win &w, const cons::Par &o, const cons::Tables *t, bool walk_all);
 void sta_launch_cons_prepare(hipStream_t s, const cons::Win &w, const cons::Par &o, const cons::Tables *t, int32_t *gran2read /* n_bases / 8 + 1 words */, int64_t n_bases);
 void sta_launch_cons_collen(hipStream_t s, const uint32_t *ins, uint32_t *len, int64_t W);
 void sta_launch_cons_read_b(hipStream_t s, const cons::Win &w);
 void sta_launch_cons_colpos(hipStream_t s, const cons::Win &w);
-void sta_launch_cons_walk(hipStream_t s, const cons::Win &w, const cons::Par &o, int64_t n_list);
+void sta_launch_cons_walk(hipStream_t s, const cons::Win &w, const cons::Par &o, int64_t n_list, bool so_words);
 void sta_launch_cons_col(hipStream_t s, const cons::Win &w, const cons::Par &o, const cons::Tables *t, int64_t n_cols);
 void sta_launch_cons_text(hipStream_t s, const cons::Win &w, const cons::Par &o, int64_t n_cols);

@@ -1,0 +1,174 @@
+/*
+ * cons_client.c -- an EXTERNAL client of the drop-in pileup_loop() surface: plain C99, built by the test with
+ *     gcc -std=c99 -DSTA_CONS_DROPIN -Iinclude tests/cabi/cons_client.c -Lsamtools_amd/lib -lsamtools_amd
+ * It includes nothing but the public header include/samtools_amd_cons.h and uses only the reference's own names (pileup_t,
+ * pileup_loop), i.e. it is written the way bam_consensus.c:2961-2972 drives the iterator: a seq_fetch callback that reads and
+ * filters records (readaln2, :2083-2103), a seq_init that attaches per-read client data (nm_init, :1012), a seq_column that
+ * looks at every pileup_t of the column (basic_pileup, :2191) and a seq_free (nm_free, :1208).
+ * As in plp_client.c the record source is a minimal SAM text parser, because HTSlib's sam_read1 is not in this tree.
+ *
+ *   cons_client [-s stop_after_columns] in.sam
+ * prints one row per column with the fields of every pileup_t, in the format of the oracle's `consensus -f dump`, then a
+ * line "# init N free N" on stderr.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "samtools_amd_cons.h"
+
+typedef struct {
+    FILE *fp;
+    char **names; int n_names;          /* @SQ SN: values, in header order = tid */
+    char *line; size_t cap;
+    int have_line;
+} src_t;
+
+static int tid_of(const src_t *s, const char *name)
+{
+    int i;
+    for (i = 0; i < s->n_names; ++i) if (strcmp(s->names[i], name) == 0) return i;
+    return -1;
+}
+
+static int open_src(src_t *s, const char *path)
+{
+    memset(s, 0, sizeof *s);
+    s->fp = fopen(path, "r");
+    if (!s->fp) return -1;
+    while (getline(&s->line, &s->cap, s->fp) > 0) {
+        if (s->line[0] != '@') { s->have_line = 1; break; }
+        if (strncmp(s->line, "@SQ", 3) == 0) {
+            char *p = strstr(s->line, "\tSN:");
+            if (p) {
+                char *e;
+                p += 4; e = p + strcspn(p, "\t\n");
+                s->names = (char **)realloc(s->names, sizeof(char *) * (size_t)(s->n_names + 1));
+                s->names[s->n_names] = (char *)malloc((size_t)(e - p) + 1);
+                memcpy(s->names[s->n_names], p, (size_t)(e - p)); s->names[s->n_names][e - p] = 0;
+                s->n_names++;
+            }
+        }
+    }
+    return 0;
+}
+
+static const char NT16[] = "=ACMGRSVTWYHKDBN";
+
+/* >= 0 ok, -1 EOF, < -1 error; fills the caller-owned record (what sam_read1 does for readaln2, bam_consensus.c:2083-2103) */
+static int read_rec(void *data, bam1_t *b)
+{
+    src_t *s = (src_t *)data;
+    char *f[11], *p;
+    int i, n_cig = 0;
+    size_t l_qn, pad, l_seq, need;
+    uint8_t *d;
+    if (s->have_line) s->have_line = 0;
+    else if (getline(&s->line, &s->cap, s->fp) <= 0) return -1;
+    p = s->line;
+    for (i = 0; i < 11; ++i) {
+        f[i] = p;
+        p += strcspn(p, "\t\n");
+        if (*p == 0 && i < 10) return -2;
+        if (*p) *p++ = 0;
+    }
+    if (strcmp(f[5], "*") != 0) for (p = f[5]; *p; ++p) if (*p < '0' || *p > '9') ++n_cig;
+    l_qn = strlen(f[0]) + 1; pad = (4 - (l_qn & 3)) & 3;
+    l_seq = strcmp(f[9], "*") == 0 ? 0 : strlen(f[9]);
+    need = l_qn + pad + 4 * (size_t)n_cig + (l_seq + 1) / 2 + l_seq;
+    if (b->m_data < need) { b->data = (uint8_t *)realloc(b->data, need); b->m_data = (uint32_t)need; }
+    b->l_data = (int)need;
+    b->core.tid = strcmp(f[2], "*") == 0 ? -1 : tid_of(s, f[2]);
+    b->core.pos = atoll(f[3]) - 1;
+    b->core.bin = 0; b->core.qual = (uint8_t)atoi(f[4]); b->core.l_extranul = (uint8_t)pad;
+    b->core.flag = (uint16_t)atoi(f[1]); b->core.l_qname = (uint16_t)(l_qn + pad); b->core.n_cigar = (uint32_t)n_cig;
+    b->core.l_qseq = (int32_t)l_seq;
+    b->core.mtid = strcmp(f[6], "=") == 0 ? b->core.tid : (strcmp(f[6], "*") == 0 ? -1 : tid_of(s, f[6]));
+    b->core.mpos = atoll(f[7]) - 1; b->core.isize = atoll(f[8]);
+    d = b->data;
+    memcpy(d, f[0], l_qn); memset(d + l_qn, 0, pad); d += l_qn + pad;
+    if (n_cig) {
+        uint32_t *cig = (uint32_t *)d;
+        for (p = f[5], i = 0; *p; ++i) {
+            char *q; unsigned long len = strtoul(p, &q, 10);
+            const char *ops = "MIDNSHP=XB", *o = strchr(ops, *q);
+            if (!o) return -2;
+            cig[i] = (uint32_t)(len << 4 | (unsigned long)(o - ops));
+            p = q + 1;
+        }
+        d += 4 * (size_t)n_cig;
+    }
+    memset(d, 0, (l_seq + 1) / 2);
+    for (i = 0; i < (int)l_seq; ++i) {
+        const char *o = strchr(NT16, f[9][i] >= 'a' && f[9][i] <= 'z' ? f[9][i] - 32 : f[9][i]);
+        d[i >> 1] |= (uint8_t)((o ? (int)(o - NT16) : 15) << ((~i & 1) << 2));
+    }
+    d += (l_seq + 1) / 2;
+    if (strcmp(f[10], "*") == 0) memset(d, 0xff, l_seq);
+    else { if (strlen(f[10]) != l_seq) return -2; for (i = 0; i < (int)l_seq; ++i) d[i] = (uint8_t)(f[10][i] - 33); }
+    return 0;
+}
+
+
+typedef struct { src_t src; long n_init, n_free, n_cols, stop_after; } client_t;
+
+/* readaln2: default exclusion flags of the command (UNMAP | SECONDARY | QCFAIL | DUP) */
+static int fetch_cb(void *cd, samFile *fp, sam_hdr_t *h, bam1_t *b)
+{
+    client_t *c = (client_t *)cd;
+    (void)fp; (void)h;
+    for (;;) {
+        int r = read_rec(&c->src, b);
+        if (r < 0) return r;
+        if (b->core.flag & (4 | 256 | 512 | 1024)) continue;
+        return r;
+    }
+}
+
+static int init_cb(void *cd, samFile *fp, sam_hdr_t *h, pileup_t *p)
+{
+    client_t *c = (client_t *)cd;
+    long *tag = (long *)malloc(sizeof(long));
+    (void)fp; (void)h;
+    if (!tag) return -1;
+    *tag = ++c->n_init;
+    p->cd = tag;
+    return 1;
+}
+
+static void free_cb(void *cd, samFile *fp, sam_hdr_t *h, pileup_t *p)
+{
+    client_t *c = (client_t *)cd;
+    (void)fp; (void)h;
+    if (p->cd) { c->n_free++; free(p->cd); p->cd = NULL; }
+}
+
+static int column_cb(void *cd, samFile *fp, sam_hdr_t *h, pileup_t *p, int depth, hts_pos_t pos, int nth, int is_insert)
+{
+    client_t *c = (client_t *)cd;
+    int n = 0;
+    (void)fp; (void)h; (void)is_insert;
+    printf("%s\t%lld\t%d\t%d", c->src.names[p->b.core.tid], (long long)pos, nth, depth);
+    for (; p; p = p->next, ++n) {
+        if (!p->cd || p->pos != pos || p->nth != nth) return -1;           /* client data attached; position fields filled */
+        if (p->b_qual != bam_get_qual(&p->b) || p->b_seq != bam_get_seq(&p->b)) return -1;
+        printf("\t%c,%d,%d,%d,%d,%d,%d", p->base, p->qual, p->base4, (int)p->ref_skip, p->b_is_rev, p->seq_offset, (int)p->padding);
+    }
+    putchar('\n');
+    if (n != depth) return -1;
+    if (c->stop_after > 0 && ++c->n_cols >= c->stop_after) return 1;     /* "early abort" of consensus_pileup.c:421-422 */
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    client_t c;
+    int a = 1, ret;
+    memset(&c, 0, sizeof c);
+    if (a + 1 < argc && !strcmp(argv[a], "-s")) { c.stop_after = atol(argv[a + 1]); a += 2; }
+    if (argc - a != 1) { fprintf(stderr, "usage: cons_client [-s stop_after_columns] in.sam\n"); return 2; }
+    if (open_src(&c.src, argv[a]) < 0) { fprintf(stderr, "cons_client: cannot open %s\n", argv[a]); return 2; }
+    ret = pileup_loop(NULL, NULL, fetch_cb, init_cb, column_cb, free_cb, &c);
+    fprintf(stderr, "# init %ld free %ld\n", c.n_init, c.n_free);
+    return ret == 0 ? 0 : 1;
+}

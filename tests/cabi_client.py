@@ -14,3 +14,13 @@ def build_client(outdir):
                     "-I", os.path.join(REPO, "include"), os.path.join(HERE, "cabi", "plp_client.c"),
                     "-L", lib, "-lsamtools_amd", "-Wl,-rpath," + lib, "-o", exe], check=True)
     return exe
+
+
+def build_cons_client(outdir):
+    """tests/cabi/cons_client.c: the same for the consensus iterator (include/samtools_amd_cons.h, STA_CONS_DROPIN: pileup_loop)"""
+    exe = os.path.join(str(outdir), "cons_client")
+    lib = os.path.join(REPO, "samtools_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O2", "-DSTA_CONS_DROPIN",
+                    "-I", os.path.join(REPO, "include"), os.path.join(HERE, "cabi", "cons_client.c"),
+                    "-L", lib, "-lsamtools_amd", "-Wl,-rpath," + lib, "-o", exe], check=True)
+    return exe

@@ -169,3 +169,17 @@ def test_external_c99_client_builds_against_the_public_header_only(tmp_path):
     for mode in ([], ["-p"]):
         p = subprocess.run([exe] + mode + [os.path.join(REPO, "tests", "golden", "mpileup", "mp_D.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert p.returncode != 0 and p.stdout == b"" and b"HIP device" in p.stderr
+
+
+def test_external_consensus_client_builds_against_the_public_header_only(tmp_path):
+    """tests/cabi/cons_client.c: a pedantic-C99 client of pileup_loop() under the reference's own names (STA_CONS_DROPIN)"""
+    from cabi_client import build_cons_client
+    exe = build_cons_client(tmp_path)
+    src = open(os.path.join(REPO, "tests", "cabi", "cons_client.c")).read()
+    assert re.findall(r'#include\s+"([^"]+)"', src) == ["samtools_amd_cons.h"]
+    lib = ctypes.CDLL(LIB)
+    lib.sta_device_count.restype = ctypes.c_int
+    if lib.sta_device_count() > 0:
+        return
+    p = subprocess.run([exe, os.path.join(REPO, "tests", "golden", "consensus", "consen1.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and p.stdout == b"" and b"HIP device" in p.stderr

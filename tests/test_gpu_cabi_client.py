@@ -7,7 +7,7 @@ import subprocess
 
 import pytest
 
-from cabi_client import build_client
+from cabi_client import build_client, build_cons_client
 from synth import write_synth_sam
 
 pytestmark = pytest.mark.gpu
@@ -52,3 +52,50 @@ def test_external_client_depth_cap_and_window_sizes(tmp_path, oracle_bin, client
     sam, _ = write_synth_sam(str(tmp_path), n_ref=15000, depth=30, read_len=150, seed=72, paired=True, indel_rate=0.1, max_indel=6)
     for batch in ("40", "3000", None):
         _diff(oracle_bin, client, [sam], {"STA_PLP_BATCH": batch} if batch else None)
+
+
+# ---- the consensus iterator: pileup_loop() (include/samtools_amd_cons.h) from an external C99 client ----
+
+@pytest.fixture(scope="module")
+def cons_client(tmp_path_factory):
+    return build_cons_client(tmp_path_factory.mktemp("cabi_cons"))
+
+
+def _cons_diff(oracle_bin, client, sam, env=None, extra=()):
+    want = subprocess.run([oracle_bin, "consensus", "-m", "simple", "-f", "dump", sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    got = subprocess.run([client] + list(extra) + [sam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
+    assert got.returncode == 0, got.stderr.decode()[-500:]
+    tally = [l for l in got.stderr.decode().split("\n") if l.startswith("# init")]
+    assert tally, got.stderr.decode()[-300:]
+    f = tally[0].split()
+    assert f[2] == f[4] and int(f[2]) > 0, tally          # every seq_init is matched by a seq_free
+    return got.stdout, want
+
+
+@pytest.mark.parametrize("name", ["consen1", "consen1b", "consen1c", "consen2", "consen3", "consen4"])
+def test_pileup_loop_client_sees_the_reference_columns(oracle_bin, cons_client, name):
+    """every pileup_t field of every column (insertion columns, pads, deletions) of the reference's consensus test inputs"""
+    got, want = _cons_diff(oracle_bin, cons_client, os.path.join(G, "consensus", name + ".sam"))
+    assert got == want
+
+
+def test_pileup_loop_client_on_synthetic_reads_and_small_batches(tmp_path, oracle_bin, cons_client):
+    from synth_rich import write_rich_sam
+    sam, _ = write_synth_sam(str(tmp_path), n_ref=15000, depth=30, read_len=150, seed=73, paired=True, indel_rate=0.3, max_indel=6)
+    os.makedirs(str(tmp_path / "rich"), exist_ok=True)
+    rich, _ = write_rich_sam(str(tmp_path / "rich"), seed=12, n_templates=1500)
+    for path in (sam, rich):
+        for batch in ("40", "3000", None):
+            got, want = _cons_diff(oracle_bin, cons_client, path, {"STA_PLP_BATCH": batch} if batch else None)
+            if got != want:
+                for i, (a, b) in enumerate(zip(got.split(b"\n"), want.split(b"\n"))):
+                    assert a == b, "%s batch %s: column record %d differs\n got: %r\nwant: %r" % (os.path.basename(path), batch, i + 1, a[:300], b[:300])
+                assert len(got) == len(want)
+            assert len(want) > 100000
+
+
+def test_pileup_loop_early_abort(tmp_path, oracle_bin, cons_client):
+    """seq_column returning 1 stops the loop (consensus_pileup.c:421-422): exactly the first 100 columns, every read freed"""
+    sam, _ = write_synth_sam(str(tmp_path), n_ref=5000, depth=20, read_len=100, seed=74, paired=False)
+    got, want = _cons_diff(oracle_bin, cons_client, sam, extra=("-s", "100"))
+    assert got == b"\n".join(want.split(b"\n")[:100]) + b"\n"

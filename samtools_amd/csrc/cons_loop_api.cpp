@@ -229,7 +229,8 @@ extern "C" int sta_pileup_loop(samFile *fp, sam_hdr_t *h,
                     const int v = seq_column(cd, fp, h, head, depth, (hts_pos_t)(cursor + (int64_t)pi + 1), nth, ins[pi] - nth);
                     size_t keep = 0;
                     for (size_t k : active) {
-                        if (last_col[k] == c) { reads[k].dead = true; if (seq_free) seq_free(cd, fp, h, reads[k].p); }
+                        // (a read that continues beyond the window also has the window's last column as its last_col)
+                        if (last_col[k] == c && reads[k].end <= we) { reads[k].dead = true; if (seq_free) seq_free(cd, fp, h, reads[k].p); }
                         else active[keep++] = k;
                     }
                     active.resize(keep);

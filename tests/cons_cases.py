@@ -5,6 +5,9 @@ from mdtag import add_md_tags
 from synth import write_synth_sam
 from synth_rich import write_rich_sam
 
+QCAL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "consensus_extra", "qcal.txt")
+LARGE_POS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_pos", "longref.sam")      # positions beyond 2^31
+
 # every caller mode, every writer, the options that change what the device computes
 OPTION_SETS = [
     ["-m", "simple"],
@@ -21,6 +24,8 @@ OPTION_SETS = [
     ["-f", "fastq", "--no-use-MQ", "-q", "--min-BQ", "10", "-d", "3"],
     ["-f", "pileup", "--no-adj-qual", "--no-adj-MQ", "--min-MQ", "20", "--ff", "0x704", "--NM-halo", "20", "--SC-cost", "30"],
     ["-f", "fasta", "-l", "60", "-C", "25", "--P-het", "0.01", "--P-indel", "0.001"],
+    ["-f", "pileup", "-t", QCAL],                       # --qual-calibration file (bam_consensus.c:674-738)
+    ["-m", "bayesian_m", "-f", "fastq", "-t", QCAL],
 ]
 
 

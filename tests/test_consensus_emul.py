@@ -9,7 +9,7 @@ import subprocess
 import pytest
 
 import regcases
-from cons_cases import OPTION_SETS, make_inputs
+from cons_cases import LARGE_POS, OPTION_SETS, make_inputs
 from golden_runner import case_paths, first_diff, run_case
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -51,3 +51,11 @@ def test_harness_matches_oracle_on_synthetic_inputs(emul_bin, oracle_bin, inputs
             rc2, got, err2 = _run(emul_bin, args, {"STA_WINDOW_COLS": wc})
             assert rc2 == 0, err2.decode()[-300:]
             assert got == want, "%s window %s: %s" % (os.path.basename(sam), wc, first_diff(got.decode("latin1"), want.decode("latin1")))
+
+
+def test_harness_positions_beyond_32_bits(emul_bin, oracle_bin):
+    for opts in (["-m", "simple", "-f", "pileup"], ["-f", "fastq"], ["-f", "pileup", "-r", "CHROMOSOME_I:10000000000-10000000050"]):
+        rc, want, err = _run(oracle_bin, opts + [LARGE_POS])
+        rc2, got, err2 = _run(emul_bin, opts + [LARGE_POS])
+        assert rc == 0 and rc2 == 0, (err, err2)
+        assert got == want and len(want) > 100, opts

@@ -8,7 +8,7 @@ import subprocess
 import pytest
 
 import regcases
-from cons_cases import OPTION_SETS, make_inputs
+from cons_cases import LARGE_POS, OPTION_SETS, make_inputs
 from golden_runner import case_paths, first_diff, run_case
 
 pytestmark = pytest.mark.gpu
@@ -42,6 +42,14 @@ def test_device_matches_oracle_on_synthetic_inputs(product_bin, oracle_bin, inpu
             rc2, got, err2 = _run(product_bin, args, {"STA_WINDOW_COLS": wc})
             assert rc2 == 0, err2.decode()[-300:]
             assert got == want, "%s window %s: %s" % (os.path.basename(sam), wc, first_diff(got.decode("latin1"), want.decode("latin1")))
+
+
+def test_device_positions_beyond_32_bits(product_bin, oracle_bin):
+    for opts in (["-m", "simple", "-f", "pileup"], ["-f", "fastq"], ["-f", "pileup", "-r", "CHROMOSOME_I:10000000000-10000000050"]):
+        rc, want, err = _run(oracle_bin, opts + [LARGE_POS])
+        rc2, got, err2 = _run(product_bin, opts + [LARGE_POS])
+        assert rc == 0 and rc2 == 0, (err, err2)
+        assert got == want and len(want) > 100, opts
 
 
 @pytest.mark.parametrize("mode", ["simple", "bayesian_no_mq", "bayesian"])

@@ -250,6 +250,7 @@ struct Runner {
                 // of that position decide one flag of the window's first column (cons_window.h step_walk).  When nothing is
                 // alive at `cursor` they are not needed and the next window starts at the next read.
                 if (pump.has_carry() && pump.carry_max_end() <= cursor && pump.next_pos(tid) > cursor) pump.retire(cursor);
+                if (pump.next_pos(tid) == INT64_MAX && !pump.has_carry()) break;
                 if (!pump.has_carry()) cursor = std::max(cursor, pump.next_pos(tid));
                 int64_t ce = pump.fill_staged(tid, cursor, cursor + window_cols, stagedv);
                 if (pump.error()) break;

@@ -93,6 +93,13 @@ struct sta_engine {
 
 namespace {
 
+// line-buffer bytes per wave of k_depth_fused: 64 rows at a time (experiment knob STA_DEPTH_LBUF)
+uint32_t depth_lbuf()
+{
+    static const uint32_t v = [] { const char *e = getenv("STA_DEPTH_LBUF"); int x = e ? atoi(e) : 2048; return (uint32_t)(x < 512 ? 512 : x > 32768 ? 32768 : x); }();
+    return v;
+}
+
 int fail(sta_engine *e, int code, const std::string &msg)
 {
     if (e) e->err = msg;
@@ -1085,7 +1092,7 @@ static int depth_text(sta_engine *e, const sta_depth_params *p, char *out, uint6
         if (ncols > 0) {
             HIPCHK(hipMemsetAsync(&ctr->out_bytes, 0, 16, s));
             ProfScope ps(e, "depth_fused");
-            sta_launch_depth_fused(s, e->wd, *p, e->fused_status.p, (int32_t *)e->diff.p, out, cap, ctr, 8192);
+            sta_launch_depth_fused(s, e->wd, *p, e->fused_status.p, (int32_t *)e->diff.p, out, cap, ctr, depth_lbuf());
         }
         rc = fused_finish(e, info);
         if (rc) return rc;

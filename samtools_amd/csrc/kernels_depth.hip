@@ -188,16 +188,22 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
     __shared__ unsigned int s_tile;
     __shared__ unsigned long long s_wtot[4][2];
     __shared__ unsigned long long s_base[2];
-    __shared__ int s_diff[4][2][DF_SPAN + 4];
+    __shared__ uint32_t s_len[4][DF_SPAN];
+    // the difference marks of the COUNT phase and the line buffers of the EMIT phase are never live at the same time (the
+    // look-back barrier lies between them): they share the dynamic LDS block, which keeps a workgroup at 16.5 KB
+    int *s_diff = reinterpret_cast<int *>(lds_dtext);                 // [4 waves][2][DF_SPAN + 4]
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) s_tile = atomicAdd(A.ticket, 1u);          // tiles are handed out in start order (dev_lookback.h)
-    __syncthreads();
-    const unsigned int tile = s_tile;
+    unsigned int tile;
+    if (A.ticket) {
+        if (threadIdx.x == 0) s_tile = atomicAdd(A.ticket, 1u);      // tiles are handed out in start order (dev_lookback.h)
+        __syncthreads();
+        tile = s_tile;
+    } else tile = blockIdx.x;
     const int64_t ncols = (int64_t)W.col_end - W.col_beg;
     const int64_t c0 = ((int64_t)tile * 4 + wid) * DF_SPAN;          // this wave's first column
     const bool wave_on = c0 < ncols;
     const uint32_t lb = (uint32_t)wid * A.per_wave;
-    int *d_file = s_diff[wid][0], *d_cover = s_diff[wid][1];
+    int *d_file = s_diff + (size_t)(wid * 2) * (DF_SPAN + 4), *d_cover = d_file + (DF_SPAN + 4);
 
     // ---- COUNT ----
     uint32_t len[DF_CPL]; uint32_t lane_len = 0;
@@ -234,7 +240,7 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
         }
     }
     int wave_total_i;
-    const uint32_t lane_off = (uint32_t)wave_excl_scan_i32((int)lane_len, wave_total_i);
+    (void)wave_excl_scan_i32((int)lane_len, wave_total_i);
     const uint32_t wave_total = (uint32_t)wave_total_i;
     n_rows = wave_sum_u64(n_rows); n_cov = wave_sum_u64(n_cov);
     if (lane == 0) { s_wtot[wid][0] = wave_total; s_wtot[wid][1] = (n_rows << 31) | n_cov; }
@@ -260,38 +266,35 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
     unsigned long long off = wg_off;
     for (int w = 0; w < wid; ++w) off += s_wtot[w][0];
 
-    // ---- EMIT: every lane writes its rows back to back; rounds of consecutive lanes that fit the line buffer ----
-    const uint32_t lane_incl = lane_off + lane_len;
-    int a = 0;
-    while (a < 64) {
-        const uint32_t start = (uint32_t)__shfl((int)lane_off, a);
-        const bool fits = lane >= a && lane_incl - start <= A.lbuf;
-        const int nb = __popcll(__ballot(fits));
-        if (nb == 0) {
-            // one lane's rows alone exceed the buffer (hundreds of input files): straight to global memory
-            if (lane == a) {
-                DSink<false> s; s.cur = 0; s.g = A.out + off + lane_off;
+    // ---- EMIT: 64 consecutive rows at a time, lane j formats row j of the group.  (A lane formatting its own 8 consecutive rows
+    // puts the lanes 8 x 16 = 128 bytes apart in the line buffer: with the usual 16-byte rows every byte store of the wave hit
+    // two LDS banks, 32-way conflicts, and the kernel was LDS-bound -- SQ_LDS_BANK_CONFLICT 118 M of 129 M active cycles.
+    // Neighbouring lanes now write neighbouring rows: 4-way.)  Row lengths travel through LDS in column order. ----
 #pragma unroll
-                for (int k = 0; k < DF_CPL; ++k) if (len[k]) depth_row_write<false>(W, A.counts, ncols, c0 + DF_CPL * lane + k, s);
-            }
-            a += 1;
-            continue;
-        }
-        const int b = a + nb;
-        const uint32_t rbytes = (uint32_t)__shfl((int)lane_incl, b - 1) - start;
-        if (rbytes) {
-            char *dst = A.out + off + start;
+    for (int k = 0; k < DF_CPL; ++k) s_len[wid][DF_CPL * lane + k] = len[k];
+    wave_lds_sync();
+    uint32_t gbase = 0;                                              // bytes of this wave's earlier groups
+    for (int k = 0; k < DF_CPL; ++k) {
+        const int m = k * 64 + lane;
+        const uint32_t l = s_len[wid][m];
+        int gtot_i;
+        const uint32_t ro = (uint32_t)wave_excl_scan_i32((int)l, gtot_i);
+        const uint32_t gtot = (uint32_t)gtot_i;
+        if (gtot == 0) continue;
+        char *dst = A.out + off + gbase;
+        const int64_t col = c0 + m;
+        if (gtot <= A.lbuf) {
             const uint32_t mis = (uint32_t)((uintptr_t)dst & 15);
             wave_lds_sync();
-            if (lane >= a && lane < b) {
-                DSink<true> s; s.g = nullptr; s.cur = lb + mis + (lane_off - start);
-#pragma unroll
-                for (int k = 0; k < DF_CPL; ++k) if (len[k]) depth_row_write<true>(W, A.counts, ncols, c0 + DF_CPL * lane + k, s);
-            }
+            if (l) { DSink<true> sk; sk.g = nullptr; sk.cur = lb + mis + ro; depth_row_write<true>(W, A.counts, ncols, col, sk); }
             wave_lds_sync();
-            wave_flush_text(lds_dtext + lb + mis, dst, rbytes);
+            wave_flush_text(lds_dtext + lb + mis, dst, gtot);
+        } else if (l) {
+            // the 64 rows exceed the line buffer (hundreds of input files): straight to global memory
+            DSink<false> sk; sk.cur = 0; sk.g = dst + ro;
+            depth_row_write<false>(W, A.counts, ncols, col, sk);
         }
-        a = b;
+        gbase += gtot;
     }
 }
 
@@ -312,5 +315,10 @@ void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_p
     a.lbuf = lbuf; a.per_wave = ((lbuf + 16 + 15) & ~15u) + 16; a.n_tiles = (uint32_t)n_tiles;
     a.has_clip = p.remove_overlaps ? 1 : 0;
     DepthDevPar d{ p.min_qual, p.skip_del, p.all_pos };
-    hipLaunchKernelGGL(k_depth_fused, dim3((unsigned)n_tiles), dim3(256), (size_t)4 * a.per_wave, s, w, d, a);
+    // STA_DEPTH_TICKET=0: tile = blockIdx.x (workgroups are dispatched in index order and never preempted, so a tile's
+    // predecessors are finished or running); the default ticket does not rely on that
+    static const bool use_ticket = !(getenv("STA_DEPTH_TICKET") && atoi(getenv("STA_DEPTH_TICKET")) == 0);
+    if (!use_ticket) a.ticket = nullptr;
+    const size_t marks = (size_t)4 * 2 * (DF_SPAN + 4) * sizeof(int), text = (size_t)4 * a.per_wave;
+    hipLaunchKernelGGL(k_depth_fused, dim3((unsigned)n_tiles), dim3(256), marks > text ? marks : text, s, w, d, a);
 }

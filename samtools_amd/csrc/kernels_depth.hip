@@ -22,12 +22,15 @@ __device__ __forceinline__ bool depth_row_exists(const StaWinDev &W, const Depth
     return ex;
 }
 
+// digits of a coordinate: nearly always below 2^32, where a compare chain replaces a loop of 64-bit divisions
+__device__ __forceinline__ int depth_dec_digits(unsigned long long u) { return u <= 0xffffffffull ? dec_digits_u32((uint32_t)u) : dec_digits(u); }
+
 template <bool LDS> struct DSink {
     uint32_t cur; char *g;
     __device__ __forceinline__ void put(char c) { if (LDS) lds_dtext[cur++] = c; else *g++ = c; }
     __device__ __forceinline__ void put_dec(unsigned long long u)
     {
-        int n = dec_digits(u);
+        int n = depth_dec_digits(u);
         if (LDS && u <= 0xffffffffull) {
             uint32_t w = (uint32_t)u; const uint32_t e = cur + n;         // 32-bit digits: multiply-high + shift per digit
             for (uint32_t q = e; q > cur;) { const uint32_t d = w / 10u; lds_dtext[--q] = (char)('0' + (w - d * 10u)); w = d; }
@@ -38,11 +41,21 @@ template <bool LDS> struct DSink {
     }
 };
 
+// the contig name, fetched once per wave (wave-uniform loads) instead of once per row: up to 16 characters in two registers
+struct DName { unsigned long long lo, hi; int len; };
+__device__ __forceinline__ DName depth_name(const StaWinDev &W)
+{
+    DName n; n.lo = 0; n.hi = 0; n.len = W.tname_len;
+    if (n.len <= 16) for (int t = 0; t < n.len; ++t) { const unsigned long long ch = (unsigned char)W.tname[t]; if (t < 8) n.lo |= ch << (8 * t); else n.hi |= ch << (8 * (t - 8)); }
+    return n;
+}
+
 template <bool LDS>
-__device__ __forceinline__ void depth_row_write(const StaWinDev &W, const int32_t *counts, int64_t ncols, int64_t c, DSink<LDS> &s)
+__device__ __forceinline__ void depth_row_write(const StaWinDev &W, const DName &nm, const int32_t *counts, int64_t ncols, int64_t c, DSink<LDS> &s)
 {
     int64_t apos = W.origin + W.col_beg + c;
-    for (int t = 0; t < W.tname_len; ++t) s.put(W.tname[t]);
+    if (nm.len <= 16) for (int t = 0; t < nm.len; ++t) s.put((char)((t < 8 ? nm.lo >> (8 * t) : nm.hi >> (8 * (t - 8))) & 0xff));
+    else for (int t = 0; t < W.tname_len; ++t) s.put(W.tname[t]);
     s.put('\t');
     s.put_dec((unsigned long long)(apos + 1));
     for (int f = 0; f < W.nfiles; ++f) { s.put('\t'); s.put_dec((uint32_t)counts[(int64_t)f * (ncols + 1) + c]); }
@@ -178,7 +191,7 @@ __device__ __forceinline__ uint32_t depth_row_len(const StaWinDev &W, const Dept
     const int64_t apos = W.origin + W.col_beg + col;
     bool ex = depth_row_exists(W, P, counts, ncols, col, apos, covered);
     if (!ex) return 0;
-    uint32_t len = (uint32_t)W.tname_len + 1 + (uint32_t)dec_digits((unsigned long long)(apos + 1)) + 1;
+    uint32_t len = (uint32_t)W.tname_len + 1 + (uint32_t)depth_dec_digits((unsigned long long)(apos + 1)) + 1;
     for (int f = 0; f < W.nfiles; ++f) len += 1 + (uint32_t)dec_digits_u32((uint32_t)counts[(int64_t)f * (ncols + 1) + col]);
     return len;
 }
@@ -273,6 +286,7 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
 #pragma unroll
     for (int k = 0; k < DF_CPL; ++k) s_len[wid][DF_CPL * lane + k] = len[k];
     wave_lds_sync();
+    const DName dname = depth_name(W);
     uint32_t gbase = 0;                                              // bytes of this wave's earlier groups
     for (int k = 0; k < DF_CPL; ++k) {
         const int m = k * 64 + lane;
@@ -286,13 +300,13 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
         if (gtot <= A.lbuf) {
             const uint32_t mis = (uint32_t)((uintptr_t)dst & 15);
             wave_lds_sync();
-            if (l) { DSink<true> sk; sk.g = nullptr; sk.cur = lb + mis + ro; depth_row_write<true>(W, A.counts, ncols, col, sk); }
+            if (l) { DSink<true> sk; sk.g = nullptr; sk.cur = lb + mis + ro; depth_row_write<true>(W, dname, A.counts, ncols, col, sk); }
             wave_lds_sync();
             wave_flush_text(lds_dtext + lb + mis, dst, gtot);
         } else if (l) {
             // the 64 rows exceed the line buffer (hundreds of input files): straight to global memory
             DSink<false> sk; sk.cur = 0; sk.g = dst + ro;
-            depth_row_write<false>(W, A.counts, ncols, col, sk);
+            depth_row_write<false>(W, dname, A.counts, ncols, col, sk);
         }
         gbase += gtot;
     }

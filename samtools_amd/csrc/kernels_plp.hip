@@ -587,13 +587,19 @@ __device__ __forceinline__ void fast_walk(const StaReadsDev &R, const StaWinDev 
                         int c = (sv[k] >> ((~qpos & 1) << 2)) & 0xf;
                         if (c == rbcode) c = 0;
                         uint32_t cur = ss.cur;
-                        lds_text[cur] = '^';
-                        lds_text[cur + (head ? 1u : 0u)] = (char)(mq > 93 ? 126 : mq + 33);
-                        cur += head ? 2u : 0u;
+                        // a read starts (ends) inside the wave's 64 columns in only ~30 % of the steps: the marker stores are
+                        // skipped by a wave-uniform branch otherwise (every LDS byte store of this kernel is bank-conflicted)
+                        if (__ballot(head)) {
+                            lds_text[cur] = '^';
+                            lds_text[cur + (head ? 1u : 0u)] = (char)(mq > 93 ? 126 : mq + 33);
+                            cur += head ? 2u : 0u;
+                        }
                         lds_text[cur] = base_char_fast(c, rev);
                         cur += pass ? 1u : 0u;
-                        lds_text[cur] = '$';
-                        cur += tail ? 1u : 0u;
+                        if (__ballot(tail)) {
+                            lds_text[cur] = '$';
+                            cur += tail ? 1u : 0u;
+                        }
                         ss.cur = cur;
                         lds_text[sq.cur] = (char)(qv[k] + 33 < 126 ? qv[k] + 33 : 126);
                         sq.cur += pass ? 1u : 0u;

@@ -309,6 +309,13 @@ CONS_HD void prepare_granule(const Par &o, const ReadView &r, int i0, int32_t ou
     }
     int qminp0 = q0;
     if (qlen > 1 && (s01 >> 4) == (s01 & 15) && qminp0 > q1) qminp0 = q1;
+    // the window as three little-endian numbers with base t of the window in bits 4t .. 4t+3 (the packed sequence holds the
+    // first base of a byte in its HIGH nibble: swap the nibbles of every byte)
+#define CONS_SWAPN(x) ((((x) & 0x0f0f0f0fu) << 4) | (((x) >> 4) & 0x0f0f0f0fu))
+    const uint64_t n0 = (uint64_t)CONS_SWAPN(wd[0]) | ((uint64_t)CONS_SWAPN(wd[1]) << 32);       // window bases 0 .. 15
+    const uint64_t n1 = (uint64_t)CONS_SWAPN(wd[2]) | ((uint64_t)CONS_SWAPN(wd[3]) << 32);       // 16 .. 31
+    const uint64_t n2 = (uint64_t)CONS_SWAPN(wd[4]);                                              // 32 .. 39
+#undef CONS_SWAPN
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -324,20 +331,25 @@ CONS_HD void prepare_granule(const Par &o, const ReadView &r, int i0, int32_t ou
             const int tq = qi / 3 + qminp;
             adj = tq < qi ? qi - tq : 0;
         }
-        // base t of a 32-bit word sits in byte t / 2, high nibble when t is even; rel = position inside the five words
-#define CONS_NIB(rel) ((int)((wd[(rel) >> 3] >> ((((rel) & 7) >> 1) * 8 + (((rel) & 1) ? 0 : 4))) & 15u))
-        const int base = CONS_NIB(16 + b);
-        int left = 0, right = 0;
-        bool okl = true, okr = true;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int d = 1; d <= 12; ++d) {
-            okl = okl && i - d >= 0 && CONS_NIB(16 + b - d) == base;
-            okr = okr && i + d < qlen && CONS_NIB(16 + b + d) == base;
-            left += okl; right += okr;
-        }
-#undef CONS_NIB
+        // run of equal codes around the base: XOR the window with the base in every nibble, mark the nibbles that differ, and
+        // count the clear ones next to the base with clz / ctz (12 either side; the window holds bases i0 - 16 .. i0 + 23)
+        const int rel = 16 + b;                                     // the base's nibble inside the window
+        const int base = (int)((rel < 16 ? n0 >> (4 * rel) : n1 >> (4 * (rel - 16))) & 15u);
+        const uint64_t rep = 0x1111111111111111ull * (uint64_t)base;
+        const uint64_t x0 = n0 ^ rep, x1 = n1 ^ rep, x2 = n2 ^ (uint32_t)rep;
+        const uint64_t d0 = (x0 | x0 >> 1 | x0 >> 2 | x0 >> 3) & 0x1111111111111111ull;      // bit 4k set: nibble k differs
+        const uint64_t d1 = (x1 | x1 >> 1 | x1 >> 2 | x1 >> 3) & 0x1111111111111111ull;
+        const uint64_t d2 = (x2 | x2 >> 1 | x2 >> 2 | x2 >> 3) & 0x11111111ull;
+        // left: nibbles rel-12 .. rel-1 (inside nibbles 4 .. 22 of the window), the nearest one in the top nibble of a 48-bit field
+        const int ls = 4 * (rel - 12);                              // 16 .. 44
+        const uint64_t lf = ((d0 >> ls) | (d1 << (64 - ls))) & 0xffffffffffffull;
+        int left = lf ? (int)(__builtin_clzll(lf << 16) >> 2) : 12;
+        // right: nibbles rel+1 .. rel+12 (inside 17 .. 35): bits 4(rel+1) .. of d1:d2 counted from nibble 16
+        const int rs = 4 * (rel + 1 - 16);                          // 4 .. 32
+        const uint64_t rf = ((d1 >> rs) | (rs ? d2 << (64 - rs) : 0ull)) & 0xffffffffffffull;
+        int right = rf ? (int)(__builtin_ctzll(rf) >> 2) : 12;
+        if (left > i) left = i;                                    // nibbles outside the read are not part of it
+        if (right > qlen - 1 - i) right = qlen - 1 - i;
         int lo = i - left, hi = i + right;
         if (left == 12) while (lo > 0 && i - lo < 101 && seqi(seq, lo - 1) == base) --lo;
         if (right == 12) while (hi + 1 < qlen && hi - lo < 101 && seqi(seq, hi + 1) == base) ++hi;

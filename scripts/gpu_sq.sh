@@ -16,6 +16,6 @@ for f in glob.glob("%s/gpurun_out/%s/p*/*counter_collection.csv" % (R, tag)):
         k = row["Kernel_Name"].split("(")[0]
         a = agg[k][row["Counter_Name"]]; a[0] += 1; a[1] += float(row["Counter_Value"])
 for k in agg:
-    if "mplp" in k or "baq" in k or "depth" in k:
+    if "k_" in k and "scan" not in k:
         print(k, {c: round(v[1]/v[0]) for c, v in sorted(agg[k].items())})
 PY

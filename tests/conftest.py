@@ -20,6 +20,9 @@ def pytest_sessionstart(session):
     lib = os.path.join(REPO, "samtools_amd", "lib", "libsamtools_amd.so")
     exe = os.path.join(REPO, "samtools_amd", "bin", "samtools-amd")
     if os.path.exists(lib) and os.path.exists(exe):
+        # the controlling process maps the in-tree library too (the xdist workers and the CLI sub-processes do the work): a
+        # missing or unloadable library fails the session here, not test by test
+        import samtools_amd  # noqa: F401
         return
     if not os.path.exists("/opt/rocm/bin/hipcc"):
         return          # the tests that need the library will say so

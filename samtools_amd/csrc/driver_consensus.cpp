@@ -459,7 +459,7 @@ int consensus_cli(int argc, char **argv, const ConsCompute &compute)
     std::unique_ptr<Fasta> fa;
     if (o.ref_fn && !(fa = Fasta::load(o.ref_fn))) { fprintf(stderr, "Failed to load fai for %s\n", o.ref_fn); return 1; }
     int64_t window_cols = 1 << 20;
-    if (const char *e = getenv("STA_WINDOW_COLS")) window_cols = std::max<long long>(1, atoll(e));
+    if (const char *e = getenv("STA_WINDOW_COLS")) window_cols = std::min<long long>(std::max<long long>(1, atoll(e)), 1 << 24);
     Runner run{ o, compute, fn, window_cols };
 
     struct Iv { int tid; int64_t beg, end; };

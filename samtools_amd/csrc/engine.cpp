@@ -865,6 +865,7 @@ static int cons_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *inf
     HIPCHK(hipMemcpyAsync(ctr, w.counters, 32, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (ctr[1]) return fail(e, STA_ERR_ARG, "a CIGAR holds an operation outside MIDNSHP=X");
+    if (n_cols > (uint64_t)INT32_MAX - 64 || n_entries > ((uint64_t)1 << 40)) return fail(e, STA_ERR_ARG, "consensus window too large: column indices are 32-bit (split the window)");
     if (e->cons_E.ensure((size_t)n_entries * 4 + 64) || ((bayes_mq || walk_all) && e->cons_Enm.ensure((size_t)n_entries * 4 + 64)) || e->cons_cols.ensure((size_t)n_cols * sizeof(sta_cons_col) + 64)
         || e->cons_depth.ensure((size_t)n_cols * 4 + 64) || e->cons_colpos.ensure((size_t)n_cols * 4 + 64))
         return fail(e, STA_ERR_HIP, "hipMalloc(consensus entries) failed");

@@ -1059,9 +1059,11 @@ static int depth_text(sta_engine *e, const sta_depth_params *p, char *out, uint6
     for (auto &d : e->files_h) d.qual = const_cast<uint8_t *>(d.qual_in);
     int rc = push_files(e);
     if (rc) return rc;
+    if (e->fused_status.ensure(sta_depth_fused_status_bytes(ncols) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(look-back status) failed");
+    bool status_zeroed;
     {
         ProfScope ps(e, "prep_reads_depth");
-        sta_launch_prep_reads_depth(s, e->wd, e->files_h.data(), nf, *p, ctr);
+        status_zeroed = sta_launch_prep_reads_depth(s, e->wd, e->files_h.data(), nf, *p, ctr, e->fused_status.p, sta_depth_fused_status_bytes(ncols));
     }
     if (p->remove_overlaps) {
         for (int f = 0; f < nf; ++f) {
@@ -1082,7 +1084,6 @@ static int depth_text(sta_engine *e, const sta_depth_params *p, char *out, uint6
     }
     const size_t drows = (size_t)(nf + 1) * (size_t)(ncols + 1);
     if (e->diff.ensure(drows * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(depth rows) failed");
-    if (e->fused_status.ensure(sta_depth_fused_status_bytes(ncols) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(look-back status) failed");
     const bool own = out == nullptr;
     if (own) {
         const uint64_t guess = (uint64_t)(ncols > 0 ? ncols : 0) * (uint64_t)(e->tname.size() + 14 + 12 * (size_t)nf) + 4096;
@@ -1091,9 +1092,9 @@ static int depth_text(sta_engine *e, const sta_depth_params *p, char *out, uint6
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (ncols > 0) {
-            HIPCHK(hipMemsetAsync(&ctr->out_bytes, 0, 16, s));
+            if (attempt) HIPCHK(hipMemsetAsync(&ctr->out_bytes, 0, 16, s));       // (the whole counter block was cleared before the first one)
             ProfScope ps(e, "depth_fused");
-            sta_launch_depth_fused(s, e->wd, *p, e->fused_status.p, (int32_t *)e->diff.p, out, cap, ctr, depth_lbuf());
+            sta_launch_depth_fused(s, e->wd, *p, e->fused_status.p, (int32_t *)e->diff.p, out, cap, ctr, depth_lbuf(), status_zeroed && !attempt);
         }
         rc = fused_finish(e, info);
         if (rc) return rc;

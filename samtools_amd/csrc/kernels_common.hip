@@ -210,8 +210,10 @@ void sta_launch_cap_mapq(hipStream_t s, const StaReadsDev &R, const StaWinDev &w
 // ------------------------------------------------------------------------------------------------
 struct PrepDepthArgs { int32_t flag, incl_flag, require_flag, min_mqual, min_len; };
 
-__global__ void __launch_bounds__(256) k_prep_reads_depth(StaReadsDev R, StaWinDev W, PrepDepthArgs P, StaCounters *ctr)
+__global__ void __launch_bounds__(256) k_prep_reads_depth(StaReadsDev R, StaWinDev W, PrepDepthArgs P, StaCounters *ctr, uint4 *zero, int64_t zero_n16)
 {
+    // (also clears the look-back status words of the depth kernel that follows: one small launch less per window)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n16; i += (int64_t)gridDim.x * blockDim.x) zero[i] = make_uint4(0, 0, 0, 0);
     unsigned long long piled = 0, kept = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R.n; i += (int64_t)gridDim.x * blockDim.x) {
         int32_t pos = R.pos[i];
@@ -264,17 +266,21 @@ __global__ void __launch_bounds__(256) k_prep_reads_depth(StaReadsDev R, StaWinD
     block_reduce_atomic<2, 2>(v, dst);
 }
 
-void sta_launch_prep_reads_depth(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
-                                 const sta_depth_params &p, StaCounters *ctr)
+bool sta_launch_prep_reads_depth(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
+                                 const sta_depth_params &p, StaCounters *ctr, void *zero, size_t zero_bytes)
 {
     PrepDepthArgs a{ p.flag, p.incl_flag, p.require_flag, p.min_mqual, p.min_len };
+    bool zeroed = false;                       // `zero` (16-byte aligned, a multiple of 16 bytes) is cleared by the first launch
     for (int f = 0; f < nfiles; ++f) {
         const StaReadsDev &R = files_host[f];
         if (R.n == 0) continue;
         int64_t nb = (R.n + 255) / 256;
         if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(k_prep_reads_depth, dim3((unsigned)nb), dim3(256), 0, s, R, w, a, ctr);
+        const bool z = !zeroed && zero && zero_bytes % 16 == 0;
+        hipLaunchKernelGGL(k_prep_reads_depth, dim3((unsigned)nb), dim3(256), 0, s, R, w, a, ctr, (uint4 *)(z ? zero : nullptr), (int64_t)(z ? zero_bytes / 16 : 0));
+        zeroed = zeroed || z;
     }
+    return zeroed;
 }
 
 // ------------------------------------------------------------------------------------------------

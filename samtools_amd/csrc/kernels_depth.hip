@@ -315,13 +315,13 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
 size_t sta_depth_fused_status_bytes(int64_t ncols) { const int64_t t = 4 * DF_SPAN; return (size_t)((ncols + t - 1) / t) * 16 + 16; }
 
 void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, void *status, int32_t *counts, char *out,
-                            uint64_t capacity, StaCounters *ctr, uint32_t lbuf)
+                            uint64_t capacity, StaCounters *ctr, uint32_t lbuf, bool status_zeroed)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
     const int64_t tcols = 4 * DF_SPAN;
     const int64_t n_tiles = (ncols + tcols - 1) / tcols;
-    hipMemsetAsync(status, 0, sta_depth_fused_status_bytes(ncols), s);
+    if (!status_zeroed) hipMemsetAsync(status, 0, sta_depth_fused_status_bytes(ncols), s);
     DepthFusedArgs a;
     a.status = (unsigned long long *)status;
     a.ticket = (unsigned int *)((char *)status + (size_t)n_tiles * 16);

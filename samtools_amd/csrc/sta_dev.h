@@ -76,8 +76,9 @@ struct StaCounters {          // device-side reduction targets, zeroed per plan
 // ---- launchers (defined in the .hip files) ----
 void sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
                            const sta_mplp_params &p, StaCounters *ctr);
-void sta_launch_prep_reads_depth(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
-                                 const sta_depth_params &p, StaCounters *ctr);
+// returns true when it also cleared `zero` (the depth kernel's look-back status): sta_launch_depth_fused then skips its memset
+bool sta_launch_prep_reads_depth(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
+                                 const sta_depth_params &p, StaCounters *ctr, void *zero = nullptr, size_t zero_bytes = 0);
 void sta_launch_cap_mapq(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int thres, int min_mq, StaCounters *ctr);
 void sta_launch_qual_prep(hipStream_t s, const StaReadsDev &r, int illumina13);
 void sta_launch_maxend_scan(hipStream_t s, const StaReadsDev &r, void *tmp, size_t tmp_bytes);
@@ -128,7 +129,7 @@ void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
 // depth
 size_t sta_depth_fused_status_bytes(int64_t ncols);
 void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, void *status, int32_t *counts, char *out,
-                            uint64_t capacity, StaCounters *ctr, uint32_t lbuf);
+                            uint64_t capacity, StaCounters *ctr, uint32_t lbuf, bool status_zeroed = false);
 void sta_launch_depth_pair(hipStream_t s, const StaReadsDev &r, int64_t origin, int32_t tid, void *table, size_t slots,
                            int32_t *chain_next, StaCounters *ctr);
 

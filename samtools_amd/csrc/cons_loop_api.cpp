@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <vector>
 
 namespace {
@@ -69,7 +70,27 @@ int64_t ref_end(const bam1_t *b)
 
 }  // namespace
 
+static int pileup_loop_impl(samFile *fp, sam_hdr_t *h,
+                            int (*seq_fetch)(void *, samFile *, sam_hdr_t *, bam1_t *),
+                            int (*seq_init)(void *, samFile *, sam_hdr_t *, sta_pileup_t *),
+                            int (*seq_column)(void *, samFile *, sam_hdr_t *, sta_pileup_t *, int, hts_pos_t, int, int),
+                            void (*seq_free)(void *, samFile *, sam_hdr_t *, sta_pileup_t *),
+                            void *cd);
+
 extern "C" int sta_pileup_loop(samFile *fp, sam_hdr_t *h,
+                               int (*seq_fetch)(void *, samFile *, sam_hdr_t *, bam1_t *),
+                               int (*seq_init)(void *, samFile *, sam_hdr_t *, sta_pileup_t *),
+                               int (*seq_column)(void *, samFile *, sam_hdr_t *, sta_pileup_t *, int, hts_pos_t, int, int),
+                               void (*seq_free)(void *, samFile *, sam_hdr_t *, sta_pileup_t *),
+                               void *cd)
+{
+    // no C++ exception may cross the C boundary
+    try { return pileup_loop_impl(fp, h, seq_fetch, seq_init, seq_column, seq_free, cd); }
+    catch (const std::exception &e) { fprintf(stderr, "pileup_loop: %s\n", e.what()); return -1; }
+    catch (...) { fprintf(stderr, "pileup_loop: unexpected failure\n"); return -1; }
+}
+
+static int pileup_loop_impl(samFile *fp, sam_hdr_t *h,
                                int (*seq_fetch)(void *, samFile *, sam_hdr_t *, bam1_t *),
                                int (*seq_init)(void *, samFile *, sam_hdr_t *, sta_pileup_t *),
                                int (*seq_column)(void *, samFile *, sam_hdr_t *, sta_pileup_t *, int, hts_pos_t, int, int),

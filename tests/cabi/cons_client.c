@@ -170,5 +170,11 @@ int main(int argc, char **argv)
     if (open_src(&c.src, argv[a]) < 0) { fprintf(stderr, "cons_client: cannot open %s\n", argv[a]); return 2; }
     ret = pileup_loop(NULL, NULL, fetch_cb, init_cb, column_cb, free_cb, &c);
     fprintf(stderr, "# init %ld free %ld\n", c.n_init, c.n_free);
+    {
+        int i;
+        for (i = 0; i < c.src.n_names; ++i) free(c.src.names[i]);
+        free(c.src.names); free(c.src.line);
+        if (c.src.fp) fclose(c.src.fp);
+    }
     return ret == 0 ? 0 : 1;
 }

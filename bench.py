@@ -214,7 +214,7 @@ def collect_pmc(a, kernels):
 
 
 # engine kernel label -> prefix of the rocprofv3 kernel name
-KNAME = {"baq_fwd": "void k_baq_fwd<7", "baq_bwd": "void k_baq_bwd<7", "mplp_emit": "k_mplp_emit_fast", "mplp_len": "k_mplp_len_fast",
+KNAME = {"baq_fwd": "void k_baq_fwd<7", "baq_bwd": "void k_baq_bwd<7", "mplp_emit": "k_mplp_emit_fast", "mplp_emit_deep": "k_mplp_emit_deep", "mplp_len": "k_mplp_len_fast",
          "depth_fused": "k_depth_fused", "glf_cols": "k_glf_cols", "cons_col": "k_cons_col", "cons_walk": "k_cons_walk", "cons_read_a": "k_cons_read_a"}
 # gfx950: FETCH_SIZE tallies a 16-byte-per-lane streaming read at half its bytes (MI355X_MICROARCH.md, HBM).  k_baq_bwd reads two
 # thirds of its forward-row stream that way (the (M, I) pairs of the odd rows) and one third as 8-byte loads: the raw counter is
@@ -456,7 +456,7 @@ def main():
             "roofline": roof(dom_name) if dom_name else None,
             "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
         }
-        emit_name = next((k for k in ({"mpileup": ["mplp_fused", "mplp_emit"], "depth": ["depth_fused", "depth_emit"], "glf": ["glf_cols"], "calmd": ["md_emit"], "consensus": ["cons_col"]}[kind]) if k in prof), None)
+        emit_name = next((k for k in ({"mpileup": ["mplp_fused", "mplp_emit_deep", "mplp_emit"], "depth": ["depth_fused", "depth_emit"], "glf": ["glf_cols"], "calmd": ["md_emit"], "consensus": ["cons_col"]}[kind]) if k in prof), None)
         if emit_name and emit_name != dom_name:
             res["roofline_pileup"] = roof(emit_name)
         # whole step against the same roof: every kernel of the step, SURVEY.md 8d bytes

@@ -620,8 +620,11 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     int rc = emit_common(e, dev_out, capacity, &out);
     if (rc) return rc;
     if (e->out_bytes == 0) return STA_OK;
-    ProfScope ps(e, "mplp_emit");
-    sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap);
+    // deep windows (mean depth of the data columns >= 100) take the read-major kernel; STA_EMIT_DEEP=0 / 1 forces either
+    bool deep = e->ctr_h.n_data_cols > 0 && e->ctr_h.piled_bases / e->ctr_h.n_data_cols >= 100;
+    if (const char *ev = getenv("STA_EMIT_DEEP")) deep = atoi(ev) != 0;
+    ProfScope ps(e, deep ? "mplp_emit_deep" : "mplp_emit");
+    sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap, deep);
     return STA_OK;
 }
 

@@ -765,6 +765,228 @@ __global__ void __launch_bounds__(256) k_mplp_emit_fast(StaWinDev W, MplpDevPar 
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Deep columns: the read-major emit kernel.  k_mplp_emit_fast gives every column a lane and needs the wave's 64 rows in LDS
+// (40 KB at 300x: one wave per SIMD, and 428 sequential read steps per wave).  Here a wave takes a strip of SIXTEEN consecutive
+// columns and its lanes are the READS: 64 reads at a time, each lane works out what its read shows in each of the columns, the
+// token offsets inside a base string are prefix counts over the lanes (ballots; a shuffle scan when a read with indels takes
+// part), and every lane stores its few bytes straight into the row in global memory -- neighbouring lanes write neighbouring
+// bytes, no LDS, full occupancy, ~5 read blocks per strip at 300x instead of 428 read steps per 64 columns.  The sixteen quality
+// bytes and the packed bases a plain read shows in the strip come from two vector loads.  The fixed parts of a row (name,
+// position, reference base, the per-file counts, separators, '*' placeholders) are written by lane k for column k.  The
+// (count, base-string bytes) of every column and file come from the measuring pass, as for k_mplp_emit_fast.
+#define DEEP_STRIP 16
+
+// the rare (read, strip) pairs that hold an indel / clip boundary / skip go through the general CIGAR resolution
+__device__ __forceinline__ Entry deep_entry(const StaReadsDev &R, int64_t r, int rpos, int rend, uint32_t info, int lq, uint64_t boff, int p)
+{
+    Entry e; e.r = r; e.rpos = rpos; e.rend = rend; e.info = info; e.lq = lq; e.boff = boff;
+    e.rs = resolve_general(R.cigar + R.cig_off[r], (int)(R.cig_off[r + 1] - R.cig_off[r]), rpos, p);
+    return e;
+}
+
+__global__ void __launch_bounds__(256) k_mplp_emit_deep(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo, char *out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t ncols = (int64_t)W.col_end - W.col_beg;
+    const int64_t c0 = wave * DEEP_STRIP;
+    __shared__ uint32_t s_off[4][64][DEEP_STRIP];
+    __shared__ uint8_t s_qc[4][64][DEEP_STRIP];
+    __shared__ uint8_t s_list[4][64];
+    if (c0 >= ncols) return;
+    const int wv = threadIdx.x >> 6;
+    uint32_t *const x_off = s_off[wv][lane]; uint8_t *const x_qc = s_qc[wv][lane];
+    const int nk = ncols - c0 < DEEP_STRIP ? (int)(ncols - c0) : DEEP_STRIP;
+    const int p0 = W.col_beg + (int)c0, plast = p0 + nk - 1;
+    const bool ends = !P.no_ends, has_ref = W.ref != nullptr;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint64_t base0 = offs[c0];                               // every offset of the strip below is relative to this row start
+    char *const out0 = out + base0;
+
+    // lane k < nk owns the fixed text of column k
+    bool my_ex = false; unsigned my_rb = 0;
+    Sink<false> fx; fx.cur = 0; fx.g = nullptr;
+    if (lane < nk) {
+        const uint64_t a = offs[c0 + lane], b = offs[c0 + lane + 1];
+        my_ex = b > a;
+        if (my_ex) {
+            const int64_t apos = W.origin + p0 + lane;
+            fx.g = out + a;
+            for (int t = 0; t < W.tname_len; ++t) fx.put(W.tname[t]);
+            fx.put('\t'); fx.put_dec(apos + 1); fx.put('\t');
+            const char rc = (has_ref && apos < W.ref_len) ? W.ref[apos] : 'N';
+            fx.put(rc);
+            if (has_ref) my_rb = apos < W.ref_len ? (unsigned)c_nt16_of_char[(unsigned char)rc] : 15u;
+        }
+    }
+    const unsigned exm = (unsigned)(__ballot(my_ex) & 0xffffull);
+    if (!exm) return;
+    unsigned long long rbpack = 0;                                 // 4-bit reference code of column k at bits 4k
+#pragma unroll
+    for (int k = 0; k < DEEP_STRIP; ++k) rbpack |= (unsigned long long)((unsigned)__builtin_amdgcn_readlane((int)my_rb, k) & 15u) << (4 * k);
+
+    for (int f = 0; f < W.nfiles; ++f) {
+        const StaReadsDev &R = W.files[f];
+        // "\tcount\t" and where the two strings of this file start; the separators and '*' placeholders right away
+        unsigned my_seq = 0, my_qual = 0;
+        if (lane < nk && my_ex) {
+            const uint2 ci = colinfo[(int64_t)f * ncols + c0 + lane];
+            const uint32_t cnt = ci.x, sl = ci.y ? ci.y : 1;
+            fx.put('\t'); fx.put_dec(cnt); fx.put('\t');
+            my_seq = (unsigned)(fx.g - out0);
+            if (!cnt) { fx.put('*'); fx.put('\t'); fx.put('*'); }
+            else { fx.g += sl; fx.put('\t'); my_qual = (unsigned)(fx.g - out0); fx.g += cnt; }
+        }
+        unsigned seqcur[DEEP_STRIP], qualcur[DEEP_STRIP];          // wave-uniform
+#pragma unroll
+        for (int k = 0; k < DEEP_STRIP; ++k) { seqcur[k] = (unsigned)__builtin_amdgcn_readlane((int)my_seq, k); qualcur[k] = (unsigned)__builtin_amdgcn_readlane((int)my_qual, k); }
+        if (R.n == 0) continue;
+        int64_t rlo, rhi;
+        wave_read_range(R, p0, plast, rlo, rhi);
+        const auto g_qual = GPTR(uint8_t, R.qual); const auto g_seq = GPTR(uint8_t, R.seq);
+        for (int64_t b0 = rlo; b0 < rhi; b0 += 64) {
+            const int64_t r = b0 + lane;
+            const bool ok = r < rhi;
+            const uint32_t info = ok ? R.info[r] : 0u;
+            const int rpos = ok ? R.pos[r] : 0, rend = ok ? R.end[r] : 0;
+            const bool keep = ok && (info & RI_KEEP) && rend > p0 && rpos <= plast;
+            if (!__ballot(keep)) continue;
+            const uint64_t boff = keep ? (uint64_t)R.base_off8[r] << 3 : 0;
+            const bool simple = (info & RI_SIMPLE) != 0, rev = (info & RI_REV) != 0;
+            // A read with indels / clips / skips is still PLAIN INSIDE THIS STRIP when the strip's columns all fall in one
+            // M/=/X op and none of them carries an indel: then qpos = p - qshift exactly as for a one-op read (qshift = rpos there).
+            bool fastl = keep && simple; int qshift = rpos, lq = 0;
+            const bool cplx = keep && !simple;
+            if (__ballot(cplx)) {
+                if (cplx) {
+                    lq = R.l_qseq[r];
+                    const uint32_t c_beg = R.cig_off[r];
+                    const uint32_t *cig = R.cigar + c_beg; const int n = (int)(R.cig_off[r + 1] - c_beg);
+                    const int ca = p0 > rpos ? p0 : rpos, cb = plast < rend - 1 ? plast : rend - 1;
+                    int x = rpos, y = 0, k = 0, op = 0, l = 0;
+                    for (k = 0; k < n; ++k) {                       // the op that holds the strip's first covered column (as resolve_general)
+                        const uint32_t c = cig[k];
+                        op = c & 0xf; l = (int)(c >> 4);
+                        if (cg_is_refop(op)) { if (ca < x + l) break; if (cg_is_mop(op)) y += l; x += l; }
+                        else if (cg_is_qop(op)) y += l;
+                    }
+                    if (k < n && cg_is_mop(op) && y + l <= lq) {
+                        bool quiet = cb < x + l - 1;
+                        if (!quiet && cb == x + l - 1) {
+                            if (k + 1 >= n) quiet = true;
+                            else { const int op2 = cig[k + 1] & 0xf; quiet = op2 != CG_D && op2 != CG_I && op2 != CG_P; }
+                        }
+                        if (quiet) { fastl = true; qshift = x - y; }
+                    }
+                }
+            }
+            const bool slow = keep && !fastl;
+            const unsigned long long sm = __ballot(slow);
+            // a plain read: the strip's 16 qualities and packed bases in two vector loads (byte 0 = query index qb)
+            uint32_t q4[4] = { 0, 0, 0, 0 }, s4[3] = { 0, 0, 0 }; int qb = 0;
+            if (fastl) {
+                qb = (p0 > rpos ? p0 : rpos) - qshift;
+                const uint64_t qa = boff + (uint64_t)qb, sa = (boff >> 1) + (uint64_t)(qb >> 1);
+                if (qa + 16 <= R.n_bases_total) __builtin_memcpy(q4, (const uint8_t *)g_qual + qa, 16);
+                else for (int t = 0; t < 16 && qa + t < R.n_bases_total; ++t) q4[t >> 2] |= (uint32_t)g_qual[qa + t] << (8 * (t & 3));
+                if (sa + 12 <= (R.n_bases_total >> 1)) __builtin_memcpy(s4, (const uint8_t *)g_seq + sa, 12);
+                else for (int t = 0; t < 12 && sa + t < (R.n_bases_total >> 1); ++t) s4[t >> 2] |= (uint32_t)g_seq[sa + t] << (8 * (t & 3));
+            }
+            const int mqc = (int)((info >> RI_MAPQ_SHIFT) & 0xff);
+            const char mq_char = (char)(mqc > 93 ? 126 : mqc + 33);
+            // the other reads: their (read, column) pairs are dealt out over the 64 lanes -- token length and quality now (LDS),
+            // the text after the column loop has placed them
+            const int n_pairs = sm ? __popcll(sm) * DEEP_STRIP : 0;
+            if (sm) {
+                if (slow) s_list[wv][__popcll(sm & lt)] = (uint8_t)lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+                for (int j0 = 0; j0 < n_pairs; j0 += 64) {
+                    const int j = j0 + lane; const bool valid = j < n_pairs;
+                    const int src = valid ? (int)s_list[wv][j >> 4] : lane, k = j & (DEEP_STRIP - 1);
+                    const int z_rpos = __shfl(rpos, src), z_rend = __shfl(rend, src), z_lq = __shfl(lq, src);
+                    const uint32_t z_info = (uint32_t)__shfl((int)info, src);
+                    const uint64_t z_boff = ((uint64_t)(uint32_t)__shfl((int)(boff >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)boff, src);
+                    if (!valid) continue;
+                    const int p = p0 + k;
+                    int tl = 0, qc = 0;
+                    if (((exm >> k) & 1u) && p >= z_rpos && p < z_rend) {
+                        const Entry e = deep_entry(R, b0 + src, z_rpos, z_rend, z_info, z_lq, z_boff, p);
+                        qc = e.rs.is_del ? placeholder_qual(R, e.r, e.rs.qpos, z_lq, z_boff, p) : (e.rs.qpos < z_lq ? (int)R.qual[z_boff + (uint64_t)e.rs.qpos] : 0);
+                        if (qc >= P.min_baseQ) tl = token_len(R, P, e, p);
+                    }
+                    s_off[wv][src][k] = (uint32_t)tl; s_qc[wv][src][k] = (uint8_t)qc;   // the length now, the destination (never 0) once it is known
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+#pragma unroll
+            for (int k = 0; k < DEEP_STRIP; ++k) {
+                if (!((exm >> k) & 1u)) continue;
+                const int p = p0 + k;
+                const bool cov = keep && p >= rpos && p < rend;
+                bool pass = false, head = false, tail = false; int tl = 0, qc = 0, bc = 0;
+                if (cov && fastl) {
+                    const int qpos = p - qshift, qi = qpos - qb, si = (qpos >> 1) - (qb >> 1);
+                    const uint32_t qw = (qi >> 2) == 0 ? q4[0] : (qi >> 2) == 1 ? q4[1] : (qi >> 2) == 2 ? q4[2] : q4[3];
+                    qc = (int)((qw >> (8 * (qi & 3))) & 255u);
+                    pass = qc >= P.min_baseQ;
+                    const uint32_t sw = (si >> 2) == 0 ? s4[0] : (si >> 2) == 1 ? s4[1] : s4[2];
+                    bc = (int)((sw >> (8 * (si & 3))) >> ((~qpos & 1) << 2)) & 0xf;
+                    head = pass && ends && p == rpos; tail = pass && ends && p == rend - 1;
+                    tl = pass ? 1 + (head ? 2 : 0) + (tail ? 1 : 0) : 0;
+                }
+                const bool cx = sm && cov && slow;
+                if (sm) {
+                    if (cx) { tl = (int)x_off[k]; qc = x_qc[k]; pass = tl > 0; }
+                }
+                const unsigned long long m = __ballot(pass);
+                if (!m) continue;
+                unsigned excl, total;
+                if (sm && __ballot(cx)) {
+                    int incl = tl;
+                    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+                    excl = (unsigned)(incl - tl); total = (unsigned)__builtin_amdgcn_readlane(incl, 63);
+                } else {
+                    const unsigned long long mh = __ballot(head), mt = __ballot(tail);
+                    excl = (unsigned)(__popcll(m & lt) + 2 * __popcll(mh & lt) + __popcll(mt & lt));
+                    total = (unsigned)(__popcll(m) + 2 * __popcll(mh) + __popcll(mt));
+                }
+                if (pass) {
+                    char *g = out0 + seqcur[k] + excl;
+                    if (!cx) {
+                        if (head) { *g++ = '^'; *g++ = mq_char; }
+                        if (has_ref && bc == (int)((rbpack >> (4 * k)) & 15u)) bc = 0;
+                        *g++ = base_char_fast(bc, rev);
+                        if (tail) *g = '$';
+                    } else x_off[k] = seqcur[k] + excl;
+                    out0[qualcur[k] + (unsigned)__popcll(m & lt)] = (char)(qc + 33 < 126 ? qc + 33 : 126);
+                }
+                seqcur[k] += total; qualcur[k] += (unsigned)__popcll(m);
+            }
+            if (sm) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+                for (int j0 = 0; j0 < n_pairs; j0 += 64) {
+                    const int j = j0 + lane; const bool valid = j < n_pairs;
+                    const int src = valid ? (int)s_list[wv][j >> 4] : lane, k = j & (DEEP_STRIP - 1);
+                    const int z_rpos = __shfl(rpos, src), z_rend = __shfl(rend, src), z_lq = __shfl(lq, src);
+                    const uint32_t z_info = (uint32_t)__shfl((int)info, src);
+                    const uint64_t z_boff = ((uint64_t)(uint32_t)__shfl((int)(boff >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)boff, src);
+                    if (!valid) continue;
+                    const uint32_t o = s_off[wv][src][k];
+                    if (!o) continue;
+                    const Entry e = deep_entry(R, b0 + src, z_rpos, z_rend, z_info, z_lq, z_boff, p0 + k);
+                    Sink<false> sk; sk.cur = 0; sk.g = out0 + o;
+                    token_write<false>(R, W, P, e, p0 + k, sk);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+    if (lane < nk && my_ex) fx.put('\n');
+}
+
 static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
 {
     MplpDevPar d;
@@ -788,10 +1010,15 @@ void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_param
 }
 
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
-                          char *out, uint32_t lds_cap)
+                          char *out, uint32_t lds_cap, bool deep)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
+    if (deep && sta_mplp_has_fast_path(p) && colinfo) {
+        const int64_t nwaves_d = (ncols + DEEP_STRIP - 1) / DEEP_STRIP;
+        hipLaunchKernelGGL(k_mplp_emit_deep, dim3((unsigned)((nwaves_d + 3) / 4)), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, out);
+        return;
+    }
     uint32_t slice = (lds_cap + 16 + 15) & ~15u;
     // waves per workgroup so that the workgroup's LDS (one slice per wave) stays within 64 KiB
     int wpb = 4 * slice <= 65536 ? 4 : (2 * slice <= 65536 ? 2 : 1);

@@ -89,7 +89,7 @@ void sta_launch_len_scan(hipStream_t s, const uint32_t *len, uint64_t *offs, int
 void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo /*[nfiles][ncols] (count, seq bytes)*/,
                          StaCounters *ctr);
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
-                          char *out, uint32_t lds_cap);
+                          char *out, uint32_t lds_cap, bool deep = false);
 bool sta_mplp_has_fast_path(const sta_mplp_params &p);
 void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, const uint32_t *line_len, int64_t ncols, StaCounters *ctr);
 

@@ -66,7 +66,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
     DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
@@ -185,7 +185,7 @@ void sta_engine_destroy(sta_engine *e)
     hipStreamSynchronize(e->stream);
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
-    DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->offs, &e->scan_tmp, &e->counters, &e->table,
+    DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
                       &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
                       &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
     for (DevBuf *b : all) b->release();
@@ -623,8 +623,13 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     // deep windows (mean depth of the data columns >= 100) take the read-major kernel; STA_EMIT_DEEP=0 / 1 forces either
     bool deep = e->ctr_h.n_data_cols > 0 && e->ctr_h.piled_bases / e->ctr_h.n_data_cols >= 100;
     if (const char *ev = getenv("STA_EMIT_DEEP")) deep = atoi(ev) != 0;
+    if (deep) {
+        const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
+        if (e->strip_rng.ensure((size_t)sta_mplp_deep_strips(ncols > 0 ? ncols : 1) * (size_t)(e->wd.nfiles > 0 ? e->wd.nfiles : 1) * 16 + 16))
+            return fail(e, STA_ERR_HIP, "hipMalloc(strip ranges) failed");
+    }
     ProfScope ps(e, deep ? "mplp_emit_deep" : "mplp_emit");
-    sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap, deep);
+    sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap, deep ? (int64_t *)e->strip_rng.p : nullptr);
     return STA_OK;
 }
 

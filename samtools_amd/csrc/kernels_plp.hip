@@ -785,7 +785,39 @@ __device__ __forceinline__ Entry deep_entry(const StaReadsDev &R, int64_t r, int
     return e;
 }
 
-__global__ void __launch_bounds__(256) k_mplp_emit_deep(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo, char *out)
+// c_nt16_of_char without the dependent table load
+__device__ __forceinline__ unsigned nt16_arith(unsigned char c)
+{
+    const unsigned li = (unsigned)(c | 32) - 'a';
+    if (li < 16u) return (unsigned)(0xfff3fcffb4ffd2e1ull >> (4 * li)) & 15u;          // a..p
+    if (li < 26u) return (unsigned)(0xfaf97f865full >> (4 * (li - 16u))) & 15u;        // q..z
+    if (c == '=') return 0u;
+    const unsigned di = (unsigned)c - '0';
+    return di < 4u ? 1u << di : 15u;
+}
+
+// [first, end) of the reads a strip has to look at, per (file, strip): found once by a thread here instead of by every wave of
+// k_mplp_emit_deep in eight dependent probe rounds
+__global__ void __launch_bounds__(256) k_mplp_strip_ranges(StaWinDev W, int64_t *__restrict__ rng, int64_t nstrips)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nstrips * W.nfiles) return;
+    const int f = (int)(i / nstrips); const int64_t sidx = i - (int64_t)f * nstrips;
+    const StaReadsDev &R = W.files[f];
+    const int64_t ncols = (int64_t)W.col_end - W.col_beg;
+    const int64_t c0 = sidx * DEEP_STRIP;
+    const int p0 = W.col_beg + (int)c0;
+    const int plast = p0 + (int)(ncols - c0 < DEEP_STRIP ? ncols - c0 : DEEP_STRIP) - 1;
+    int64_t lo = 0, hi = R.n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (R.maxend[mid] > p0) hi = mid; else lo = mid + 1; }
+    const int64_t rlo = lo;
+    hi = R.n;                                                      // pos is sorted and rhi >= rlo
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (R.pos[mid] > plast) hi = mid; else lo = mid + 1; }
+    rng[2 * i] = rlo; rng[2 * i + 1] = lo;
+}
+
+__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(4, 8))) k_mplp_emit_deep(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
+                                                        const int64_t *__restrict__ rng, char *out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -801,24 +833,28 @@ __global__ void __launch_bounds__(256) k_mplp_emit_deep(StaWinDev W, MplpDevPar 
     const int p0 = W.col_beg + (int)c0, plast = p0 + nk - 1;
     const bool ends = !P.no_ends, has_ref = W.ref != nullptr;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // everything the strip needs that does not depend on another load is asked for here, in one round trip
+    const int64_t nstrips = (ncols + DEEP_STRIP - 1) / DEEP_STRIP;
     const uint64_t base0 = offs[c0];                               // every offset of the strip below is relative to this row start
+    const int64_t apos = W.origin + p0 + lane;
+    uint64_t off_a = 0, off_b = 0; uint2 ci0 = make_uint2(0u, 0u); char rc = 'N';
+    if (lane < nk) {
+        off_a = offs[c0 + lane]; off_b = offs[c0 + lane + 1];
+        ci0 = colinfo[c0 + lane];
+        if (has_ref && apos < W.ref_len) rc = W.ref[apos];
+    }
+    int64_t rlo0 = rng[2 * wave], rhi0 = rng[2 * wave + 1];
     char *const out0 = out + base0;
 
     // lane k < nk owns the fixed text of column k
-    bool my_ex = false; unsigned my_rb = 0;
+    const bool my_ex = off_b > off_a; unsigned my_rb = 0;
     Sink<false> fx; fx.cur = 0; fx.g = nullptr;
-    if (lane < nk) {
-        const uint64_t a = offs[c0 + lane], b = offs[c0 + lane + 1];
-        my_ex = b > a;
-        if (my_ex) {
-            const int64_t apos = W.origin + p0 + lane;
-            fx.g = out + a;
-            for (int t = 0; t < W.tname_len; ++t) fx.put(W.tname[t]);
-            fx.put('\t'); fx.put_dec(apos + 1); fx.put('\t');
-            const char rc = (has_ref && apos < W.ref_len) ? W.ref[apos] : 'N';
-            fx.put(rc);
-            if (has_ref) my_rb = apos < W.ref_len ? (unsigned)c_nt16_of_char[(unsigned char)rc] : 15u;
-        }
+    if (my_ex) {
+        fx.g = out + off_a;
+        for (int t = 0; t < W.tname_len; ++t) fx.put(W.tname[t]);
+        fx.put('\t'); fx.put_dec(apos + 1); fx.put('\t');
+        fx.put(rc);
+        if (has_ref) my_rb = apos < W.ref_len ? nt16_arith((unsigned char)rc) : 15u;
     }
     const unsigned exm = (unsigned)(__ballot(my_ex) & 0xffffull);
     if (!exm) return;
@@ -830,8 +866,8 @@ __global__ void __launch_bounds__(256) k_mplp_emit_deep(StaWinDev W, MplpDevPar 
         const StaReadsDev &R = W.files[f];
         // "\tcount\t" and where the two strings of this file start; the separators and '*' placeholders right away
         unsigned my_seq = 0, my_qual = 0;
-        if (lane < nk && my_ex) {
-            const uint2 ci = colinfo[(int64_t)f * ncols + c0 + lane];
+        if (my_ex) {
+            const uint2 ci = f == 0 ? ci0 : colinfo[(int64_t)f * ncols + c0 + lane];
             const uint32_t cnt = ci.x, sl = ci.y ? ci.y : 1;
             fx.put('\t'); fx.put_dec(cnt); fx.put('\t');
             my_seq = (unsigned)(fx.g - out0);
@@ -842,8 +878,7 @@ __global__ void __launch_bounds__(256) k_mplp_emit_deep(StaWinDev W, MplpDevPar 
 #pragma unroll
         for (int k = 0; k < DEEP_STRIP; ++k) { seqcur[k] = (unsigned)__builtin_amdgcn_readlane((int)my_seq, k); qualcur[k] = (unsigned)__builtin_amdgcn_readlane((int)my_qual, k); }
         if (R.n == 0) continue;
-        int64_t rlo, rhi;
-        wave_read_range(R, p0, plast, rlo, rhi);
+        const int64_t rlo = f == 0 ? rlo0 : rng[2 * ((int64_t)f * nstrips + wave)], rhi = f == 0 ? rhi0 : rng[2 * ((int64_t)f * nstrips + wave) + 1];
         const auto g_qual = GPTR(uint8_t, R.qual); const auto g_seq = GPTR(uint8_t, R.seq);
         for (int64_t b0 = rlo; b0 < rhi; b0 += 64) {
             const int64_t r = b0 + lane;
@@ -984,7 +1019,7 @@ __global__ void __launch_bounds__(256) k_mplp_emit_deep(StaWinDev W, MplpDevPar 
             }
         }
     }
-    if (lane < nk && my_ex) fx.put('\n');
+    if (my_ex) fx.put('\n');
 }
 
 static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
@@ -1010,13 +1045,15 @@ void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_param
 }
 
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
-                          char *out, uint32_t lds_cap, bool deep)
+                          char *out, uint32_t lds_cap, int64_t *strip_rng)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
-    if (deep && sta_mplp_has_fast_path(p) && colinfo) {
-        const int64_t nwaves_d = (ncols + DEEP_STRIP - 1) / DEEP_STRIP;
-        hipLaunchKernelGGL(k_mplp_emit_deep, dim3((unsigned)((nwaves_d + 3) / 4)), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, out);
+    if (strip_rng && sta_mplp_has_fast_path(p) && colinfo) {
+        const int64_t nwaves_d = sta_mplp_deep_strips(ncols);
+        const int64_t nt = nwaves_d * w.nfiles;
+        hipLaunchKernelGGL(k_mplp_strip_ranges, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, w, strip_rng, nwaves_d);
+        hipLaunchKernelGGL(k_mplp_emit_deep, dim3((unsigned)((nwaves_d + 3) / 4)), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, (const int64_t *)strip_rng, out);
         return;
     }
     uint32_t slice = (lds_cap + 16 + 15) & ~15u;
@@ -1033,6 +1070,8 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
     }
     hipLaunchKernelGGL(k_mplp_emit, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, make_par(p, w.tlen), offs, out, lds_cap);
 }
+
+int64_t sta_mplp_deep_strips(int64_t ncols) { return (ncols + DEEP_STRIP - 1) / DEEP_STRIP; }
 
 // no --output-extra / -O / -s columns: the window takes the fast kernel pair
 bool sta_mplp_has_fast_path(const sta_mplp_params &p) { return !((uint32_t)p.flag & (EXTRA_MASK | STA_MPLP_OUTPUT_MODS)) && p.n_tags <= 0; }

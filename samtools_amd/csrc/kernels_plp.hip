@@ -785,6 +785,15 @@ __device__ __forceinline__ Entry deep_entry(const StaReadsDev &R, int64_t r, int
     return e;
 }
 
+// what a lane needs to know about its read before it can look at anything else of it
+struct DeepPre { uint32_t info, b8, c0, c1; int pos, end, lq; };
+__device__ __forceinline__ DeepPre deep_pre(const StaReadsDev &R, int64_t r, int64_t rhi)
+{
+    DeepPre d; d.info = 0; d.b8 = 0; d.c0 = 0; d.c1 = 0; d.pos = 0; d.end = 0; d.lq = 0;
+    if (r < rhi) { d.info = R.info[r]; d.pos = R.pos[r]; d.end = R.end[r]; d.b8 = R.base_off8[r]; d.c0 = R.cig_off[r]; d.c1 = R.cig_off[r + 1]; d.lq = R.l_qseq[r]; }
+    return d;
+}
+
 // c_nt16_of_char without the dependent table load
 __device__ __forceinline__ unsigned nt16_arith(unsigned char c)
 {
@@ -880,37 +889,56 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         if (R.n == 0) continue;
         const int64_t rlo = f == 0 ? rlo0 : rng[2 * ((int64_t)f * nstrips + wave)], rhi = f == 0 ? rhi0 : rng[2 * ((int64_t)f * nstrips + wave) + 1];
         const auto g_qual = GPTR(uint8_t, R.qual); const auto g_seq = GPTR(uint8_t, R.seq);
-        for (int64_t b0 = rlo; b0 < rhi; b0 += 64) {
+        // the per-read words of the NEXT block of 64 reads are asked for while this block is worked on
+        DeepPre cur = deep_pre(R, rlo + lane, rhi), nx;
+        for (int64_t b0 = rlo; b0 < rhi; b0 += 64, cur = nx) {
             const int64_t r = b0 + lane;
             const bool ok = r < rhi;
-            const uint32_t info = ok ? R.info[r] : 0u;
-            const int rpos = ok ? R.pos[r] : 0, rend = ok ? R.end[r] : 0;
+            nx = deep_pre(R, r + 64, rhi);
+            const uint32_t info = cur.info;
+            const int rpos = cur.pos, rend = cur.end;
             const bool keep = ok && (info & RI_KEEP) && rend > p0 && rpos <= plast;
             if (!__ballot(keep)) continue;
-            const uint64_t boff = keep ? (uint64_t)R.base_off8[r] << 3 : 0;
+            const uint64_t boff = (uint64_t)cur.b8 << 3;
             const bool simple = (info & RI_SIMPLE) != 0, rev = (info & RI_REV) != 0;
             // A read with indels / clips / skips is still PLAIN INSIDE THIS STRIP when the strip's columns all fall in one
             // M/=/X op and none of them carries an indel: then qpos = p - qshift exactly as for a one-op read (qshift = rpos there).
-            bool fastl = keep && simple; int qshift = rpos, lq = 0;
+            bool fastl = keep && simple; int qshift = rpos; const int lq = cur.lq;
             const bool cplx = keep && !simple;
             if (__ballot(cplx)) {
                 if (cplx) {
-                    lq = R.l_qseq[r];
-                    const uint32_t c_beg = R.cig_off[r];
-                    const uint32_t *cig = R.cigar + c_beg; const int n = (int)(R.cig_off[r + 1] - c_beg);
+                    const uint32_t *cig = R.cigar + cur.c0; const int n = (int)(cur.c1 - cur.c0);
+                    uint32_t cg[4];                                 // the first four ops in one round trip
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) cg[t] = t < n ? cig[t] : 0u;
                     const int ca = p0 > rpos ? p0 : rpos, cb = plast < rend - 1 ? plast : rend - 1;
-                    int x = rpos, y = 0, k = 0, op = 0, l = 0;
-                    for (k = 0; k < n; ++k) {                       // the op that holds the strip's first covered column (as resolve_general)
-                        const uint32_t c = cig[k];
-                        op = c & 0xf; l = (int)(c >> 4);
-                        if (cg_is_refop(op)) { if (ca < x + l) break; if (cg_is_mop(op)) y += l; x += l; }
-                        else if (cg_is_qop(op)) y += l;
+                    int x = rpos, y = 0, k = 0, op = 0, l = 0; bool found = false;
+                    // the op that holds the strip's first covered column (as resolve_general)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (!found && t < n) {
+                            op = (int)(cg[t] & 0xf); l = (int)(cg[t] >> 4); k = t;
+                            if (cg_is_refop(op)) { if (ca < x + l) found = true; else { if (cg_is_mop(op)) y += l; x += l; } }
+                            else if (cg_is_qop(op)) y += l;
+                        }
                     }
-                    if (k < n && cg_is_mop(op) && y + l <= lq) {
+                    if (!found) {
+                        for (k = 4; k < n; ++k) {
+                            const uint32_t c = cig[k];
+                            op = c & 0xf; l = (int)(c >> 4);
+                            if (cg_is_refop(op)) { if (ca < x + l) { found = true; break; } if (cg_is_mop(op)) y += l; x += l; }
+                            else if (cg_is_qop(op)) y += l;
+                        }
+                    }
+                    if (found && cg_is_mop(op) && y + l <= lq) {
                         bool quiet = cb < x + l - 1;
                         if (!quiet && cb == x + l - 1) {
                             if (k + 1 >= n) quiet = true;
-                            else { const int op2 = cig[k + 1] & 0xf; quiet = op2 != CG_D && op2 != CG_I && op2 != CG_P; }
+                            else {
+                                const uint32_t c2 = k + 1 == 1 ? cg[1] : k + 1 == 2 ? cg[2] : k + 1 == 3 ? cg[3] : cig[k + 1];
+                                const int op2 = (int)(c2 & 0xf);
+                                quiet = op2 != CG_D && op2 != CG_I && op2 != CG_P;
+                            }
                         }
                         if (quiet) { fastl = true; qshift = x - y; }
                     }

@@ -109,7 +109,7 @@ struct DRunner {
             if (ce_target <= cursor) { pump.skip_to(tid, cursor, INT64_MAX, window_cols); pump.drop_tid_carry(); break; }
             WinJob *j = pipe->acquire();
             int64_t ce;
-            { const double t0 = WinPipe::now(); ce = pump.fill_staged(tid, cursor, ce_target, j->staged); pipe->add_fill_time(WinPipe::now() - t0); }
+            { const double t0 = WinPipe::now(); ce = pump.fill_staged(tid, cursor, ce_target, j->staged); pipe->add_fill_time(WinPipe::now() - t0); double dw, sc; pump.producer_split(&dw, &sc); pipe->set_producer_split(dw, sc); }
             if (pump.error()) { pipe->release(j); return -1; }
             if (pump.next_pos(tid) == INT64_MAX) {
                 int64_t me = pump.carry_max_end();

@@ -56,9 +56,9 @@ public:
         if (dev_.joinable()) dev_.join();
         if (wr_.joinable()) wr_.join();
         if (timing_)
-            fprintf(stderr, "[driver timing] wall %.3f s | producer: fill+stage %.3f s, waiting for a slot %.3f s, waiting for results %.3f s | "
-                            "device thread busy %.3f s | writer busy %.3f s | %llu windows\n",
-                    now() - t0_, t_fill_, t_slot_, t_wait_, t_dev_, t_wr_, (unsigned long long)n_jobs_);
+            fprintf(stderr, "[driver timing] wall %.3f s | producer: fill+stage %.3f s (of it: waiting for the decode threads %.3f s, copying slices %.3f s), "
+                            "waiting for a slot %.3f s, waiting for results %.3f s | device thread busy %.3f s | writer busy %.3f s | %llu windows\n",
+                    now() - t0_, t_fill_, t_decode_wait_, t_stage_copy_, t_slot_, t_wait_, t_dev_, t_wr_, (unsigned long long)n_jobs_);
     }
     // a slot the producer may fill (blocks while all are in flight)
     WinJob *acquire()
@@ -96,6 +96,7 @@ public:
     }
     int error() { std::lock_guard<std::mutex> g(m_); return err_; }
     void add_fill_time(double s) { t_fill_ += s; }
+    void set_producer_split(double decode_wait, double stage_copy) { t_decode_wait_ = decode_wait; t_stage_copy_ = stage_copy; }
     static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 private:
@@ -149,7 +150,7 @@ private:
     std::mutex m_; std::condition_variable cv_;
     std::thread dev_, wr_;
     bool stop_ = false; int err_ = 0;
-    bool timing_ = false; double t0_ = 0, t_fill_ = 0, t_slot_ = 0, t_wait_ = 0, t_dev_ = 0, t_wr_ = 0; unsigned long long n_jobs_ = 0;
+    bool timing_ = false; double t0_ = 0, t_decode_wait_ = 0, t_stage_copy_ = 0, t_fill_ = 0, t_slot_ = 0, t_wait_ = 0, t_dev_ = 0, t_wr_ = 0; unsigned long long n_jobs_ = 0;
 };
 
 // Can the -d cap (bam_plp_push: a read is dropped when more than max_depth reads are live at its start) possibly trigger for these

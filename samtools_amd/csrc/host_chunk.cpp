@@ -1,5 +1,6 @@
 // host_chunk.cpp -- see host_chunk.h
 #include "host_chunk.h"
+#include <chrono>
 #include <algorithm>
 #include <climits>
 #include <cstring>
@@ -150,10 +151,14 @@ std::shared_ptr<Chunk> ChunkReader::next()
 }
 
 // ------------------------------------------------------------------------------------------------ ChunkPump
+static double mono_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 ChunkPump::ChunkPump(std::vector<std::unique_ptr<AlnReader>> &readers, const PumpConfig &cfg, int threads) : cfg_(cfg)
 {
     f_.resize(readers.size());
     for (size_t i = 0; i < readers.size(); ++i) f_[i].rd.reset(new ChunkReader(readers[i].get(), threads));
+    // threads that copy a window's chunk slices into the staging arrays (STA_STAGE_THREADS; 1 = the producer thread alone)
+    stage_threads_ = threads >= 8 ? 4 : threads >= 4 ? 2 : 1;
+    if (const char *ev = getenv("STA_STAGE_THREADS")) { const int v = atoi(ev); if (v >= 1 && v <= 64) { stage_threads_ = v; stage_min_bytes_ = 0; } }   // set explicitly: for every window, however small
 }
 
 bool ChunkPump::settle(File &f)
@@ -161,7 +166,8 @@ bool ChunkPump::settle(File &f)
     for (;;) {
         if (f.eof) return false;
         if (!f.cur || f.idx >= f.cur->n()) {
-            f.cur = f.rd->next(); f.idx = 0;
+            { const double t0 = mono_s(); f.cur = f.rd->next(); stats_.wait_s += mono_s() - t0; }
+            f.idx = 0;
             if (!f.cur) {
                 f.eof = true;
                 if (f.rd->status() < 0 && !err_) { err_ = -1; errtxt_ = "error reading from input file"; }
@@ -263,6 +269,8 @@ int64_t ChunkPump::fill_window(int tid, int64_t cb, int64_t ce_target, std::vect
     }
     if (!staged_out) { for (auto &f : f_) f.n_carry_staged = f.carry.size(); return ce; }
     std::vector<StagedFile> &staged = *staged_out;
+    const double t_stage0 = mono_s();
+    std::vector<StagedFile::Slice> slices;
     staged.resize(f_.size());
     for (size_t fi = 0; fi < f_.size(); ++fi) {
         File &f = f_[fi];
@@ -272,9 +280,12 @@ int64_t ChunkPump::fill_window(int tid, int64_t cb, int64_t ce_target, std::vect
         const XcolSpec *xp = xs.n_tags > 0 ? &xs : nullptr;
         for (auto &r : f.carry) s.add(r, cb, nullptr, xp);
         f.n_carry_staged = f.carry.size();
-        for (auto &g : f.fresh) s.add_range(*g.c, g.i0, g.i1, cb, xp);
+        slices.clear();
+        for (auto &g : f.fresh) slices.push_back(StagedFile::Slice{ g.c.get(), g.i0, g.i1 });
+        s.add_ranges(slices.data(), slices.size(), cb, xp, stage_threads_, stage_min_bytes_, &f.high_water);
         s.finish();
     }
+    stats_.stage_s += mono_s() - t_stage0;
     return ce;
 }
 

@@ -82,7 +82,13 @@ public:
     void drop_tid_carry() override;
     int error() const override { return err_; }
     const char *error_text() const override { return errtxt_.c_str(); }
+    // where the producer's time goes (seconds): waiting for the decode threads / assembling the staging arrays
+    struct Stats { double wait_s = 0, stage_s = 0; };
+    const Stats &stats() const { return stats_; }
+    void producer_split(double *decode_wait, double *stage_copy) const override { *decode_wait = stats_.wait_s; *stage_copy = stats_.stage_s; }
 private:
+    Stats stats_;
+    int stage_threads_ = 1; size_t stage_min_bytes_ = (size_t)4 << 20;
     struct Range { std::shared_ptr<Chunk> c; int64_t i0, i1; };
     struct File {
         std::unique_ptr<ChunkReader> rd;
@@ -93,6 +99,7 @@ private:
         std::vector<Range> fresh;                         // the current window's new reads, as chunk slices
         size_t n_carry_staged = 0;                        // carried reads at the front of the staged order
         std::vector<char> dropped;                        // per staged read: removed by the -d cap in this window
+        StagedFile::PoolSizes high_water;                 // largest staging pools a window of this input needed so far
     };
     PumpConfig cfg_;
     std::vector<File> f_;

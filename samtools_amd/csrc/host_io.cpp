@@ -68,7 +68,15 @@ struct AlnReader::Impl {
     {
         uint8_t *d = (uint8_t *)dst; size_t got = 0;
         while (got < n) {
-            if (bp >= bl && !fill()) break;
+            if (bp >= bl) {
+                if (n - got >= ((size_t)1 << 18) && !eof) {            // a bulk read: straight into the caller's buffer
+                    const size_t k = src->read(d + got, n - got);
+                    if (k == 0) { eof = true; bp = bl = 0; break; }
+                    got += k;
+                    continue;
+                }
+                if (!fill()) break;
+            }
             size_t k = std::min(bl - bp, n - got);
             memcpy(d + got, buf.data() + bp, k);
             bp += k; got += k;
@@ -376,16 +384,27 @@ int AlnReader::raw_group(std::vector<uint8_t> &out, size_t target, int64_t *n_re
     int64_t nrec = 0;
     out.clear();
     if (im.is_bam) {
-        while (out.size() < target) {
-            int32_t bs = 0;
-            size_t n = im.read(&bs, 4);
-            if (n == 0) break;
-            if (n != 4 || bs < 32) return -2;
-            size_t o = out.size();
-            out.resize(o + 4 + (size_t)bs);
-            memcpy(&out[o], &bs, 4);
-            if (im.read(&out[o + 4], (size_t)bs) != (size_t)bs) return -2;
-            ++nrec;
+        // `target` bytes in one go, then the block_size chain inside them; the record that straddles the end is completed
+        // (the group = the whole records up to the first boundary at or beyond `target`)
+        out.resize(target);
+        size_t got = im.read(out.data(), target), o = 0;
+        out.resize(got);
+        while (o < got) {
+            if (got - o < 4) {
+                const size_t need = 4 - (got - o);
+                out.resize(got + need);
+                if (im.read(&out[got], need) != need) return -2;
+                got += need;
+            }
+            int32_t bs; memcpy(&bs, &out[o], 4);
+            if (bs < 32) return -2;
+            const size_t end = o + 4 + (size_t)bs;
+            if (end > got) {
+                out.resize(end);
+                if (im.read(&out[got], end - got) != end - got) return -2;
+                got = end;
+            }
+            ++nrec; o = end;
         }
     } else {
         while (out.size() < target) {

@@ -6,6 +6,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <new>
 #include <vector>
 
 namespace sta {
@@ -19,6 +20,10 @@ template <class T> struct PinnedAlloc {
     template <class U> PinnedAlloc(const PinnedAlloc<U> &) noexcept {}
     T *allocate(size_t n) { return static_cast<T *>(pinned_alloc(n * sizeof(T))); }
     void deallocate(T *p, size_t) noexcept { pinned_free(p); }
+    // resize(n) leaves new elements of these plain-data vectors uninitialised (they are overwritten right away: bulk copies,
+    // device-to-host fetches) instead of zero-filling them first; resize(n, v) still fills
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&... a) { ::new (static_cast<void *>(p)) U(static_cast<A0 &&>(a0), static_cast<A &&>(a)...); }
     template <class U> bool operator==(const PinnedAlloc<U> &) const noexcept { return true; }
     template <class U> bool operator!=(const PinnedAlloc<U> &) const noexcept { return false; }
 };

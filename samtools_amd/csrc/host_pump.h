@@ -70,6 +70,8 @@ public:
     virtual void drop_tid_carry() = 0;
     virtual int error() const = 0;
     virtual const char *error_text() const = 0;
+    // seconds the producer spent waiting for decoded input / copying into the staging arrays (0, 0 when a lane does not keep them)
+    virtual void producer_split(double *decode_wait, double *stage_copy) const { *decode_wait = 0; *stage_copy = 0; }
 };
 
 class Pump : public WindowSource {

@@ -1,7 +1,10 @@
 // host_stage.cpp -- see host_stage.h
 #include "host_stage.h"
 #include "host_chunk.h"
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <climits>
 
 namespace sta {
@@ -57,8 +60,9 @@ void StagedFile::add(const Rec &r, int64_t origin, const std::set<std::string> *
     if (r.l_qseq) memcpy(&qual[b0], r.qual.data(), (size_t)r.l_qseq);
     seq.resize((b0 + padded) / 2, 0);
     if (r.l_qseq) memcpy(&seq[b0 / 2], r.seq.data(), ((size_t)r.l_qseq + 1) / 2);
-    bq.resize(b0 + padded, 64);               // '@' = "no adjustment"
-    if (bq_ok) { memcpy(&bq[b0], r.bq.data(), (size_t)r.l_qseq); any_bq = true; }
+    // BQ pool: materialised from the first record that carries BQ:Z on ('@' = "no adjustment" for everything before it)
+    if (bq_ok && !any_bq) { bq.assign(b0, 64); any_bq = true; }
+    if (any_bq) { bq.resize(b0 + padded, 64); if (bq_ok) memcpy(&bq[b0], r.bq.data(), (size_t)r.l_qseq); }
     mtid.push_back(r.mtid);
     mpos.push_back(r.mpos);
     int64_t is = r.isize;
@@ -102,10 +106,13 @@ void StagedFile::add_range(const Chunk &c, int64_t i0, int64_t i1, int64_t origi
     cigar.insert(cigar.end(), c.cigar.begin() + cg0, c.cigar.begin() + cg1);
     qual.insert(qual.end(), c.qual.begin() + ((size_t)b0 << 3), c.qual.begin() + ((size_t)b1 << 3));
     seq.insert(seq.end(), c.seq.begin() + ((size_t)b0 << 2), c.seq.begin() + ((size_t)b1 << 2));
-    if (c.has_bq_pool) {
-        bq.insert(bq.end(), c.bq.begin() + ((size_t)b0 << 3), c.bq.begin() + ((size_t)b1 << 3));
-        if (!any_bq) for (size_t k = a; k < b; ++k) if (c.aux[k] & STA_AUX_HAS_BQ) { any_bq = true; break; }
-    } else bq.resize(qual.size(), 64);
+    bool slice_bq = false;
+    if (c.has_bq_pool) for (size_t k = a; k < b; ++k) if (c.aux[k] & STA_AUX_HAS_BQ) { slice_bq = true; break; }
+    if (slice_bq && !any_bq) { bq.assign(qual.size() - (((size_t)b1 - b0) << 3), 64); any_bq = true; }
+    if (any_bq) {
+        if (c.has_bq_pool) bq.insert(bq.end(), c.bq.begin() + ((size_t)b0 << 3), c.bq.begin() + ((size_t)b1 << 3));
+        else bq.resize(qual.size(), 64);
+    }
     names.insert(names.end(), c.names.begin() + nm0, c.names.begin() + nm1);
     cig_off.resize(n0 + m); base_off8.resize(n0 + m); name_off.resize(n0 + m);
     for (size_t k = 0; k < m; ++k) {
@@ -113,6 +120,105 @@ void StagedFile::add_range(const Chunk &c, int64_t i0, int64_t i1, int64_t origi
         base_off8[n0 + k] = c.base_off8[a + k] - b0 + q_base8;
         name_off[n0 + k] = c.name_off[a + k] - nm0 + nm_base;
     }
+}
+
+void StagedFile::add_ranges(const Slice *g, size_t n_g, int64_t origin, const XcolSpec *xs, int threads, size_t min_bytes_for_threads, PoolSizes *hw)
+{
+    if (!n_g) return;
+    const int nt = xs ? xs->n_tags : 0;
+    // destination offsets of every slice
+    struct Dst { size_t rec, cig, b8, nm, xoff, xtext; };
+    std::vector<Dst> d(n_g + 1);
+    d[0] = Dst{ pos.size(), cigar.size(), qual.size() >> 3, names.size(), xcol_off.size(), xcol_text.size() };
+    bool slices_bq = false;
+    size_t bytes = 0;
+    for (size_t s = 0; s < n_g; ++s) {
+        const Chunk &c = *g[s].c; const size_t a = (size_t)g[s].i0, b = (size_t)g[s].i1;
+        Dst n = d[s];
+        n.rec += b - a; n.cig += c.cig_off[b] - c.cig_off[a]; n.b8 += c.base_off8[b] - c.base_off8[a]; n.nm += c.name_off[b] - c.name_off[a];
+        if (nt > 0) {
+            n.xoff += (b - a) * (size_t)nt;
+            for (size_t i = a; i < b; ++i)
+                for (int t = 0; t < nt; ++t) {
+                    const size_t e = i * (size_t)c.n_tags + (size_t)t;
+                    n.xtext += (t < c.n_tags && c.tag_has[e]) ? c.tag_off[e + 1] - c.tag_off[e] : 1;
+                }
+        }
+        if (c.has_bq_pool && !slices_bq) for (size_t k = a; k < b; ++k) if (c.aux[k] & STA_AUX_HAS_BQ) { slices_bq = true; break; }
+        d[s + 1] = n;
+        bytes += (b - a) * 48 + ((size_t)(c.base_off8[b] - c.base_off8[a]) << 3) * 3 / 2;
+    }
+    const Dst &z = d[n_g];
+    if (slices_bq && !any_bq) { bq.assign(qual.size(), 64); any_bq = true; }
+    {
+        PoolSizes local; PoolSizes &h = hw ? *hw : local;
+        h.rec = std::max(h.rec, z.rec); h.cig = std::max(h.cig, z.cig); h.b8 = std::max(h.b8, z.b8); h.nm = std::max(h.nm, z.nm);
+        h.xoff = std::max(h.xoff, z.xoff); h.xtext = std::max(h.xtext, z.xtext);
+        auto room = [](auto &v, size_t need, size_t mark) { if (v.capacity() < need) v.reserve(std::max(need, mark) + std::max(need, mark) / 4 + 64); };
+        room(pos, z.rec, h.rec); room(isize, z.rec, h.rec); room(flag, z.rec, h.rec); room(mapq, z.rec, h.rec); room(aux, z.rec, h.rec);
+        room(l_qseq, z.rec, h.rec); room(mtid, z.rec, h.rec); room(mpos, z.rec, h.rec);
+        room(cig_off, z.rec + 1, h.rec + 1); room(base_off8, z.rec, h.rec); room(name_off, z.rec + 1, h.rec + 1);
+        room(cigar, z.cig, h.cig); room(qual, z.b8 << 3, h.b8 << 3); room(seq, z.b8 << 2, h.b8 << 2); room(names, z.nm, h.nm);
+        if (any_bq) room(bq, z.b8 << 3, h.b8 << 3);
+        if (nt > 0) { room(xcol_off, z.xoff + 1, h.xoff + 1); room(xcol_text, z.xtext, h.xtext); }
+    }
+    pos.resize(z.rec); isize.resize(z.rec); flag.resize(z.rec); mapq.resize(z.rec); aux.resize(z.rec); l_qseq.resize(z.rec);
+    mtid.resize(z.rec); mpos.resize(z.rec); cig_off.resize(z.rec); base_off8.resize(z.rec); name_off.resize(z.rec);
+    cigar.resize(z.cig); qual.resize(z.b8 << 3); seq.resize(z.b8 << 2); names.resize(z.nm);
+    if (any_bq) bq.resize(z.b8 << 3);
+    if (nt > 0) { n_xcols = nt; xcol_off.resize(z.xoff); xcol_text.resize(z.xtext); }
+    const bool with_bq = any_bq; const char empty = xs ? xs->empty : '*';
+    auto copy_slice = [&](size_t s) {
+        const Chunk &c = *g[s].c; const size_t a = (size_t)g[s].i0, b = (size_t)g[s].i1, m = b - a;
+        const Dst &o = d[s];
+        for (size_t k = 0; k < m; ++k) pos[o.rec + k] = (int32_t)(c.pos[a + k] - origin);
+        for (size_t k = 0; k < m; ++k) {
+            const int64_t is = c.isize[a + k];
+            isize[o.rec + k] = (int32_t)(is > INT32_MAX ? INT32_MAX : is < -INT32_MAX ? -INT32_MAX : is);
+        }
+        memcpy(&flag[o.rec], &c.flag[a], m * sizeof(uint16_t));
+        memcpy(&mapq[o.rec], &c.mapq[a], m);
+        memcpy(&aux[o.rec], &c.aux[a], m);
+        memcpy(&l_qseq[o.rec], &c.l_qseq[a], m * sizeof(int32_t));
+        memcpy(&mtid[o.rec], &c.mtid[a], m * sizeof(int32_t));
+        memcpy(&mpos[o.rec], &c.mpos[a], m * sizeof(int64_t));
+        const uint32_t cg0 = c.cig_off[a], cg1 = c.cig_off[b], b0 = c.base_off8[a], b1 = c.base_off8[b], nm0 = c.name_off[a], nm1 = c.name_off[b];
+        if (cg1 > cg0) memcpy(&cigar[o.cig], &c.cigar[cg0], (size_t)(cg1 - cg0) * sizeof(uint32_t));
+        if (b1 > b0) {
+            memcpy(&qual[o.b8 << 3], &c.qual[(size_t)b0 << 3], (size_t)(b1 - b0) << 3);
+            memcpy(&seq[o.b8 << 2], &c.seq[(size_t)b0 << 2], (size_t)(b1 - b0) << 2);
+            if (with_bq) {
+                if (c.has_bq_pool) memcpy(&bq[o.b8 << 3], &c.bq[(size_t)b0 << 3], (size_t)(b1 - b0) << 3);
+                else memset(&bq[o.b8 << 3], 64, (size_t)(b1 - b0) << 3);
+            }
+        }
+        if (nm1 > nm0) memcpy(&names[o.nm], &c.names[nm0], nm1 - nm0);
+        for (size_t k = 0; k < m; ++k) {
+            cig_off[o.rec + k] = c.cig_off[a + k] - cg0 + (uint32_t)o.cig;
+            base_off8[o.rec + k] = c.base_off8[a + k] - b0 + (uint32_t)o.b8;
+            name_off[o.rec + k] = c.name_off[a + k] - nm0 + (uint32_t)o.nm;
+        }
+        if (nt > 0) {
+            size_t xo = o.xoff, xt = o.xtext;
+            for (size_t i = a; i < b; ++i)
+                for (int t = 0; t < nt; ++t) {
+                    xcol_off[xo++] = (uint32_t)xt;
+                    const size_t e = i * (size_t)c.n_tags + (size_t)t;
+                    if (t < c.n_tags && c.tag_has[e]) { const size_t l = c.tag_off[e + 1] - c.tag_off[e]; memcpy(&xcol_text[xt], c.tag_text.data() + c.tag_off[e], l); xt += l; }
+                    else xcol_text[xt++] = empty;
+                }
+        }
+    };
+    int nth = threads < 1 ? 1 : threads;
+    if ((size_t)nth > n_g) nth = (int)n_g;
+    if (bytes < min_bytes_for_threads) nth = 1;                  // small windows: not worth waking threads
+    if (nth <= 1) { for (size_t s = 0; s < n_g; ++s) copy_slice(s); return; }
+    std::atomic<size_t> next{ 0 };
+    auto work = [&] { for (size_t s; (s = next.fetch_add(1)) < n_g;) copy_slice(s); };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nth; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
 }
 
 void StagedFile::finish()

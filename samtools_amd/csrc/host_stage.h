@@ -42,6 +42,14 @@ struct StagedFile {
     // bulk form of add() for records [i0, i1) of a decoded chunk (no read-group list, no RNEXT / modification columns): pool
     // slices are copied whole and the offsets rebased; the chunk's aux-tag text becomes the tag columns
     void add_range(const Chunk &c, int64_t i0, int64_t i1, int64_t origin, const XcolSpec *xs = nullptr);     // xs: tag columns only
+    // the same for a window's whole list of slices: sizes first, every pool grown once, then the slices copied by `threads`
+    // threads (each slice knows its destination offsets after the prefix sums)
+    struct Slice { const Chunk *c; int64_t i0, i1; };
+    // largest pool sizes any window of this input has needed so far: a staging object that has to grow (every pool growth is a
+    // page-locking call) grows once, to a quarter beyond these, instead of creeping up window by window in each ring slot
+    struct PoolSizes { size_t rec = 0, cig = 0, b8 = 0, nm = 0, xoff = 0, xtext = 0; };
+    void add_ranges(const Slice *g, size_t n_g, int64_t origin, const XcolSpec *xs, int threads, size_t min_bytes_for_threads = (size_t)4 << 20,
+                    PoolSizes *high_water = nullptr);
     void finish();                 // closes the offset arrays
     sta_reads view() const;        // pointers into this object (valid until the next add/clear)
     int64_t n() const { return (int64_t)pos.size(); }

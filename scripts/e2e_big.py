@@ -104,14 +104,25 @@ def main():
     cmds = [("depth -a", ["depth", "-a", bam]), ("mpileup -B -f", ["mpileup", "-B", "-f", fa, bam]), ("mpileup -f", ["mpileup", "-f", fa, bam])]
     for name, args in cmds:
         best, best_err = 1e9, ""
+        # E2E_THREADS: decode threads per input, optionally "decode/stage" (STA_STAGE_THREADS: threads copying a window's slices)
         for thr in (os.environ.get("E2E_THREADS", "8,16,24").split(",")):
-            env = dict(os.environ, STA_IO_THREADS=thr, STA_DRIVER_TIMING="1")
+            env = dict(os.environ, STA_IO_THREADS=thr.split("/")[0], STA_DRIVER_TIMING="1")
+            if "/" in thr:
+                env["STA_STAGE_THREADS"] = thr.split("/")[1]
             dt, err = timed([ENG] + args, env=env)
             line = [l for l in err.split("\n") if l.startswith("[driver timing]")]
-            print("  %-14s io_threads=%-3s %.2f s  %.0f Mbases/s   %s" % (name, thr, dt, mb / dt, line[0] if line else ""))
+            print("  %-14s io_threads=%-5s %.2f s  %.0f Mbases/s   %s" % (name, thr, dt, mb / dt, line[0] if line else ""))
             if dt < best:
                 best, best_err = dt, thr
         print("%-14s best %.2f s = %.0f Mbases/s (io_threads=%s; %.0f net of start-up)" % (name, best, mb / best, best_err, mb / max(best - t_start, 1e-3)))
+    if os.environ.get("E2E_QUICK"):
+        # a short run (GPU minutes): the oracle only for depth -a; mpileup text compared between one and several staging threads
+        a, na = sha_of([ENG, "depth", "-a", bam]); b, nb = sha_of([ORA, "depth", "-a", bam])
+        print("parity depth -a engine %d bytes, oracle %d bytes: %s" % (na, nb, "IDENTICAL" if a == b else "DIFFERENT"))
+        a, na = sha_of([ENG, "mpileup", "-B", "-f", fa, bam], env=dict(os.environ, STA_STAGE_THREADS="1"))
+        b, nb = sha_of([ENG, "mpileup", "-B", "-f", fa, bam], env=dict(os.environ, STA_STAGE_THREADS="6"))
+        print("mpileup -B -f  1 vs 6 staging threads: %d / %d bytes: %s" % (na, nb, "IDENTICAL" if a == b else "DIFFERENT"))
+        return
     # the oracle on the same file (single thread); mpileup -f only on the first contig (x n_contigs = the whole file)
     for name, args, scale in (("depth -a", ["depth", "-a", bam], 1), ("mpileup -B -f", ["mpileup", "-B", "-f", fa, bam], 1),
                               ("mpileup -f (chr1 only)", ["mpileup", "-f", fa, "-r", "chr1", bam], n_contigs)):

@@ -117,6 +117,27 @@ def test_chunk_lane_stages_the_same_windows_as_the_record_lane(capi, files, whic
     assert _with_env(WINDOWS[1], lambda: capi.io_scan(src, 2, 1)) != _with_env(WINDOWS[0], lambda: capi.io_scan(src, 2, 1))
 
 
+def test_chunk_lane_with_bq_tags_and_staging_threads(capi, files):
+    """BQ:Z appears only from the middle of the file on (the staged BQ pool is materialised late, '@' before it), and the
+    slices of a window are copied by several threads (STA_STAGE_THREADS set: for every window, however small)."""
+    d, sam, _ = files
+    lines = open(sam).read().split("\n")
+    body = [i for i, l in enumerate(lines) if l and not l.startswith("@")]
+    for k, i in enumerate(body):
+        if k > len(body) // 2 and k % 3 == 0:
+            f = lines[i].split("\t")
+            lines[i] += "\tBQ:Z:" + "".join(chr(64 + (j * 7 + k) % 5) for j in range(len(f[9])))
+    src = os.path.join(d, "bq_mid.sam"); open(src, "w").write("\n".join(lines))
+    bam = sam_to_bam(src, os.path.join(d, "bq_mid.bam"), level=1, block=5000)
+    for env in ({}, {"STA_WINDOW_COLS": "900"}, {"STA_WINDOW_COLS": "5000", "STA_WINDOW_READS": "50"}):
+        ref = _with_env(env, lambda: capi.io_scan(src, 2, 1))
+        for st in ("1", "3"):
+            e2 = dict(env, STA_STAGE_THREADS=st)
+            assert _with_env(e2, lambda: capi.io_scan(src, 3, 2)) == ref, (env, st)
+            assert _with_env(e2, lambda: capi.io_scan(bam, 4, 2)) == ref, (env, st)
+    assert _with_env({}, lambda: capi.io_scan(src, 2, 1)) != _with_env({}, lambda: capi.io_scan(sam, 2, 1))
+
+
 def test_chunk_lane_on_the_reference_fixture_bams(capi):
     for sub in ("mpileup", "bedcov"):
         for fn in sorted(os.listdir(os.path.join(GOLD, sub))):

@@ -776,6 +776,7 @@ __global__ void __launch_bounds__(256) k_mplp_emit_fast(StaWinDev W, MplpDevPar 
 // position, reference base, the per-file counts, separators, '*' placeholders) are written by lane k for column k.  The
 // (count, base-string bytes) of every column and file come from the measuring pass, as for k_mplp_emit_fast.
 #define DEEP_STRIP 16
+#include "deep_strip.h"
 
 // the rare (read, strip) pairs that hold an indel / clip boundary / skip go through the general CIGAR resolution
 __device__ __forceinline__ Entry deep_entry(const StaReadsDev &R, int64_t r, int rpos, int rend, uint32_t info, int lq, uint64_t boff, int p)
@@ -829,14 +830,19 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                                                         const int64_t *__restrict__ rng, char *out)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // (readfirstlane: the compiler cannot see that the strip index is the same for the 64 lanes; with it the strip's bounds,
+    // row offsets and cursors live in scalar registers and the row stores take a scalar base + 32-bit offset)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
     const int64_t ncols = (int64_t)W.col_end - W.col_beg;
     const int64_t c0 = wave * DEEP_STRIP;
     __shared__ uint32_t s_off[4][64][DEEP_STRIP];
     __shared__ uint8_t s_qc[4][64][DEEP_STRIP];
     __shared__ uint8_t s_list[4][64];
+    __shared__ char s_chr[32];                                     // code -> character: forward strand, then reverse strand
+    if (threadIdx.x < 32) s_chr[threadIdx.x] = base_char_fast((int)(threadIdx.x & 15), threadIdx.x >= 16);
+    __syncthreads();
     if (c0 >= ncols) return;
-    const int wv = threadIdx.x >> 6;
     uint32_t *const x_off = s_off[wv][lane]; uint8_t *const x_qc = s_qc[wv][lane];
     const int nk = ncols - c0 < DEEP_STRIP ? (int)(ncols - c0) : DEEP_STRIP;
     const int p0 = W.col_beg + (int)c0, plast = p0 + nk - 1;
@@ -956,6 +962,15 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 if (sa + 12 <= (R.n_bases_total >> 1)) __builtin_memcpy(s4, (const uint8_t *)g_seq + sa, 12);
                 else for (int t = 0; t < 12 && sa + t < (R.n_bases_total >> 1); ++t) s4[t >> 2] |= (uint32_t)g_seq[sa + t] << (8 * (t & 3));
             }
+            // one shift per block: column k of the strip finds its quality in byte k of qs and its base code in nibble k of nib
+            // (0 where the base equals the reference) -- deep_strip.h
+            uint32_t qs[4] = { 0, 0, 0, 0 }; uint64_t nib = 0;
+            if (fastl) {
+                const int d0 = (p0 > rpos ? p0 : rpos) - p0;
+                deep_shift_quals(q4, d0, qs);
+                nib = deep_shift_bases(s4, qb, d0, rbpack, has_ref);
+            }
+            const int chr_row = rev ? 16 : 0;
             const int mqc = (int)((info >> RI_MAPQ_SHIFT) & 0xff);
             const char mq_char = (char)(mqc > 93 ? 126 : mqc + 33);
             // the other reads: their (read, column) pairs are dealt out over the 64 lanes -- token length and quality now (LDS),
@@ -988,42 +1003,41 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 if (!((exm >> k) & 1u)) continue;
                 const int p = p0 + k;
                 const bool cov = keep && p >= rpos && p < rend;
-                bool pass = false, head = false, tail = false; int tl = 0, qc = 0, bc = 0;
+                bool pass = false; int qc = 0; uint32_t bc = 0;
                 if (cov && fastl) {
-                    const int qpos = p - qshift, qi = qpos - qb, si = (qpos >> 1) - (qb >> 1);
-                    const uint32_t qw = (qi >> 2) == 0 ? q4[0] : (qi >> 2) == 1 ? q4[1] : (qi >> 2) == 2 ? q4[2] : q4[3];
-                    qc = (int)((qw >> (8 * (qi & 3))) & 255u);
+                    qc = (int)((qs[k >> 2] >> (8 * (k & 3))) & 255u);
                     pass = qc >= P.min_baseQ;
-                    const uint32_t sw = (si >> 2) == 0 ? s4[0] : (si >> 2) == 1 ? s4[1] : s4[2];
-                    bc = (int)((sw >> (8 * (si & 3))) >> ((~qpos & 1) << 2)) & 0xf;
-                    head = pass && ends && p == rpos; tail = pass && ends && p == rend - 1;
-                    tl = pass ? 1 + (head ? 2 : 0) + (tail ? 1 : 0) : 0;
+                    bc = (uint32_t)(nib >> (4 * k)) & 15u;
                 }
                 const bool cx = sm && cov && slow;
+                int tl = 0;
                 if (sm) {
                     if (cx) { tl = (int)x_off[k]; qc = x_qc[k]; pass = tl > 0; }
                 }
                 const unsigned long long m = __ballot(pass);
                 if (!m) continue;
+                const bool head = pass && !cx && ends && p == rpos, tail = pass && !cx && ends && p == rend - 1;
+                const unsigned pm = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));   // passing lanes below this one
                 unsigned excl, total;
                 if (sm && __ballot(cx)) {
+                    if (!cx) tl = pass ? 1 + (head ? 2 : 0) + (tail ? 1 : 0) : 0;
                     int incl = tl;
                     for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
                     excl = (unsigned)(incl - tl); total = (unsigned)__builtin_amdgcn_readlane(incl, 63);
                 } else {
                     const unsigned long long mh = __ballot(head), mt = __ballot(tail);
-                    excl = (unsigned)(__popcll(m & lt) + 2 * __popcll(mh & lt) + __popcll(mt & lt));
+                    excl = pm + 2u * __builtin_amdgcn_mbcnt_hi((unsigned)(mh >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mh, 0u))
+                              + __builtin_amdgcn_mbcnt_hi((unsigned)(mt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mt, 0u));
                     total = (unsigned)(__popcll(m) + 2 * __popcll(mh) + __popcll(mt));
                 }
                 if (pass) {
-                    char *g = out0 + seqcur[k] + excl;
+                    uint32_t o = seqcur[k] + excl;
                     if (!cx) {
-                        if (head) { *g++ = '^'; *g++ = mq_char; }
-                        if (has_ref && bc == (int)((rbpack >> (4 * k)) & 15u)) bc = 0;
-                        *g++ = base_char_fast(bc, rev);
-                        if (tail) *g = '$';
-                    } else x_off[k] = seqcur[k] + excl;
-                    out0[qualcur[k] + (unsigned)__popcll(m & lt)] = (char)(qc + 33 < 126 ? qc + 33 : 126);
+                        if (head) { out0[o] = '^'; out0[o + 1] = mq_char; o += 2; }
+                        out0[o] = s_chr[chr_row + (int)bc];
+                        if (tail) out0[o + 1] = '$';
+                    } else x_off[k] = o;
+                    out0[qualcur[k] + pm] = (char)(qc + 33 < 126 ? qc + 33 : 126);
                 }
                 seqcur[k] += total; qualcur[k] += (unsigned)__popcll(m);
             }

@@ -183,3 +183,13 @@ def test_external_consensus_client_builds_against_the_public_header_only(tmp_pat
         return
     p = subprocess.run([exe, os.path.join(REPO, "tests", "golden", "consensus", "consen1.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode != 0 and p.stdout == b"" and b"HIP device" in p.stderr
+
+
+def test_deep_strip_alignment_arithmetic_matches_plain_indexing(tmp_path):
+    """samtools_amd/csrc/deep_strip.h (the per-block shift of k_mplp_emit_deep) against the straightforward per-column indexing,
+    compiled for the host."""
+    import subprocess
+    exe = str(tmp_path / "deep_strip_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(REPO, "tests", "cpu", "deep_strip_test.cpp"), "-o", exe], check=True)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and b"deep_strip_test OK" in p.stdout, p.stdout.decode()[-400:]

@@ -196,3 +196,16 @@ def test_both_lanes_read_standard_input(files):
             with open(path, "rb") as fh:
                 got = subprocess.run([sys.executable, "-c", code, str(stage)], stdin=fh, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
             assert got.stdout.decode().strip() == want, (stage, os.path.basename(path))
+
+
+def test_producer_bench_harness_builds_and_runs(files, tmp_path):
+    """tests/cpu/stage_bench.cpp (decode threads -> chunk lane -> staged windows without a device; scripts/stage_bench.sh) stays
+    buildable against the host sources and walks a BAM to the end."""
+    import subprocess
+    d, sam, _ = files
+    bam = sam_to_bam(sam, os.path.join(d, "bench_in.bam"), level=1)
+    exe = str(tmp_path / "stage_bench")
+    subprocess.run(["bash", os.path.join(os.path.dirname(GOLD), "..", "scripts", "stage_bench.sh"), exe], check=True)
+    p = subprocess.run([exe, bam, "3", "20000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, STA_NO_PINNED="1", STA_STAGE_THREADS="2"))
+    assert p.returncode == 0, p.stderr.decode()[-400:]
+    assert b"windows" in p.stdout and b"reads" in p.stdout

@@ -35,6 +35,11 @@ def test_decoder_on_generated_and_damaged_streams(emul):
     assert p.returncode == 0 and b"synth OK" in p.stdout, (p.stdout + p.stderr).decode()[-800:]
 
 
+def test_damaged_bgzf_files_never_crash_the_header_walk_or_the_decoder(emul):
+    p = subprocess.run([emul, "--fuzz", os.path.join(GOLD, "mpileup", "mpileup.1.bam"), "400"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and b"fuzz OK" in p.stdout, (p.stdout + p.stderr).decode()[-800:]
+
+
 def test_decoder_on_a_bam_written_at_every_compression_level(emul, tmp_path):
     import sys
     sys.path.insert(0, os.path.join(REPO, "tests"))

@@ -373,6 +373,12 @@ int sta_profile_get(sta_engine *e, sta_kernel_time *out, int cap);
  * status as the reference sub-commands (bamtk.c:248,270 would dispatch here). */
 int sta_main_mpileup(int argc, char **argv);
 int sta_main_depth(int argc, char **argv);
+/* The same two drivers with the text they would print handed back in memory (argv[0] selects "mpileup" / "depth"; a -o option
+ * in argv still wins).  *text is malloc'ed: release it with sta_capture_free.  Returns the driver's exit status, or
+ * STA_ERR_ARG / STA_ERR_IO.  Used by the sharded launcher (samtools_amd/shard.py): a rank's block of columns goes from the
+ * driver straight into the gather, no temporary file.  No reference counterpart (bam_plcmd.c:663-868 prints as it goes). */
+int sta_main_capture(int argc, char **argv, char **text, uint64_t *n_bytes);
+void sta_capture_free(char *text);
 /* `glf [-Q min_baseQ] [-t theta] [-f ref.fa] in.bam`: one text line per column (what tests diff against the oracle) */
 int sta_main_glf(int argc, char **argv);
 /* `calmd [-erAEq] [-n max_nm] in.bam ref.fa`: dumps the record fields calmd changes (not a SAM writer) */

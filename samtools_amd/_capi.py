@@ -170,6 +170,8 @@ _PROTOS = {
     "sta_fetch_read_state": (C.c_int, [_P, C.c_int32, _P, _P]),
     "sta_main_mpileup": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_main_depth": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "sta_main_capture": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "sta_capture_free": (None, [_P]),
     "sta_glf_plan": (C.c_int, [_P, C.POINTER(GlfParams), C.POINTER(PlanInfo)]),
     "sta_glf_consensus": (C.c_int, [C.POINTER(GlfCol), C.c_char, C.c_char_p]),
     "sta_calmd_plan": (C.c_int, [_P, C.POINTER(CalmdParams), C.POINTER(PlanInfo)]),
@@ -223,6 +225,20 @@ def main_mpileup(args):
     """Run the `mpileup` driver in-process; args excludes the sub-command name."""
     a = ["mpileup"] + list(args)
     return lib.sta_main_mpileup(len(a), _argv(a))
+
+
+def main_capture(sub, args):
+    """(exit status, text bytes) of `sub args...` ("mpileup" / "depth") with the driver's output captured in memory."""
+    a = [sub] + list(args)
+    buf = _P()
+    n = C.c_uint64(0)
+    rc = lib.sta_main_capture(len(a), _argv(a), C.byref(buf), C.byref(n))
+    try:
+        data = C.string_at(buf, n.value) if buf and n.value else b""
+    finally:
+        if buf:
+            lib.sta_capture_free(buf)
+    return rc, data
 
 
 def main_depth(args):

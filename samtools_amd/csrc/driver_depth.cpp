@@ -28,7 +28,7 @@ struct DRunner {
     sta_engine *eng = nullptr;
     std::vector<std::unique_ptr<AlnReader>> readers;
     const Header *h = nullptr;
-    FILE *out = stdout;
+    FILE *out = driver_default_out();
     std::unique_ptr<Bed> bed;
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
     int64_t window_cols = 1 << 20, max_reads = 4 << 20;
@@ -280,7 +280,7 @@ extern "C" int sta_main_depth(int argc, char **argv)
         run.pipe.reset();
     }
     fflush(run.out);
-    if (run.out != stdout) fclose(run.out);
+    if (!driver_out_is_borrowed(run.out)) fclose(run.out);
     sta_engine_destroy(run.eng);
     return ret;
 }

@@ -68,7 +68,7 @@ struct Runner {
     sta_engine *eng = nullptr;
     std::vector<std::unique_ptr<AlnReader>> readers;
     const Header *h = nullptr;
-    FILE *out = stdout;
+    FILE *out = driver_default_out();
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
     std::unique_ptr<WinPipe> pipe;                    // producer (this thread) -> device thread -> writer thread
     std::vector<StagedFile> no_reads;                 // read-less windows (zero-depth rows); device thread only
@@ -117,6 +117,12 @@ struct Runner {
         if (sta_mpileup_plan(eng, &p, &j.info) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
         j.out_bytes = 0;
         j.read_info.clear();
+        if (j.info.n_maxcnt_dropped && j.have_reads && !j.lockstep) {
+            // safety net behind cap_may_trigger(): the producer has already moved on with reads the iterator never stored
+            fprintf(stderr, "samtools mpileup: internal error: the -d cap removed reads near %s:%lld in a window the producer did not wait for\n",
+                    h->names[(size_t)j.tid].c_str(), (long long)j.cb + 1);
+            return -1;
+        }
         if (j.info.n_maxcnt_dropped && j.have_reads) {
             // the cap removed reads from the iterator: the producer takes them out of the pump (info bit 0 = reached bam_plp_push,
             // bit 1 = in the pileup)
@@ -148,7 +154,7 @@ struct Runner {
         while (a < b) {
             int64_t e = std::min(b, a + conf.window_cols);
             WinJob *j = pipe->acquire();
-            j->tid = tid; j->cb = a; j->ce = e; j->have_reads = false; j->all_mode = 1; j->write = true; j->hold = false;
+            j->tid = tid; j->cb = a; j->ce = e; j->have_reads = false; j->all_mode = 1; j->write = true; j->hold = false; j->lockstep = false;
             pipe->submit(j);
             if (pipe->error()) return -1;
             a = e;
@@ -209,6 +215,7 @@ struct Runner {
                     return -1;
                 }
                 bool waited = false;
+                j->lockstep = lockstep || (mode == 1 && !started);
                 if (mode == 1 && !started) {
                     // -a: nothing of this contig is printed before its first data column is known
                     j->all_mode = 0; j->write = false; j->hold = true;
@@ -492,7 +499,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
         run.pipe.reset();                 // joins the device and writer threads (everything is written)
     }
     fflush(run.out);
-    if (run.out != stdout) fclose(run.out);
+    if (!driver_out_is_borrowed(run.out)) fclose(run.out);
     sta_engine_destroy(run.eng);
     return ret;
 }

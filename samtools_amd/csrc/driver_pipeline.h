@@ -12,6 +12,7 @@
 #pragma once
 #include "host_stage.h"
 #include "../../include/samtools_amd.h"
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <ctime>
@@ -28,6 +29,7 @@ struct WinJob {
     int tid = -1; int64_t cb = 0, ce = 0;
     bool have_reads = false;             // false: a read-less window (zero-depth rows): `staged` is ignored
     int all_mode = 0; bool write = true;
+    bool lockstep = false;               // the producer waits for this job's result before it stages the next window (-d cap, single -a)
     bool hold = false;                   // the producer will submit this job again (same staged reads): the slot is not recycled
     std::vector<StagedFile> staged;
     // set by the device stage
@@ -42,8 +44,9 @@ struct WinJob {
 class WinPipe {
 public:
     WinPipe(size_t n_slots, std::function<int(WinJob &)> device_fn, FILE *out, const char *write_error_text)
-        : fn_(std::move(device_fn)), out_(out), werr_(write_error_text), slots_(n_slots)
+        : fn_(std::move(device_fn)), out_(out), werr_(write_error_text), slots_(n_slots < 3 ? 3 : n_slots)
     {
+        // (at least three slots: the single `-a` path holds one job while it acquires the next; with one slot it would wait for itself)
         timing_ = getenv("STA_DRIVER_TIMING") != nullptr;
         t0_ = now();
         dev_ = std::thread([this] { device_loop(); });
@@ -111,9 +114,10 @@ private:
                 j = devq_.front(); devq_.pop_front();
             }
             const double a = now();
-            int rc = err_ ? err_ : fn_(*j);          // after an error the remaining jobs only drain
+            const int prior = err_.load();
+            int rc = prior ? prior : fn_(*j);        // after an error the remaining jobs only drain
             t_dev_ += now() - a;
-            { std::lock_guard<std::mutex> g(m_); j->rc = rc; if (rc < 0 && !err_) err_ = rc; j->state = 2; }
+            { std::lock_guard<std::mutex> g(m_); j->rc = rc; if (rc < 0 && !err_.load()) err_ = rc; j->state = 2; }
             cv_.notify_all();
         }
     }
@@ -129,13 +133,13 @@ private:
             }
             const double a = now();
             int rc = 0;
-            if (j->rc >= 0 && j->write && j->out_bytes && !err_) {
+            if (j->rc >= 0 && j->write && j->out_bytes && !err_.load()) {
                 if (fwrite(j->text.data(), 1, (size_t)j->out_bytes, out_) != (size_t)j->out_bytes) { fprintf(stderr, "%s", werr_); rc = -1; }
             }
             t_wr_ += now() - a;
             {
                 std::lock_guard<std::mutex> g(m_);
-                if (rc < 0 && !err_) err_ = rc;
+                if (rc < 0 && !err_.load()) err_ = rc;
                 order_.pop_front();
                 j->state = j->hold ? 3 : 0;       // a held job stays with the producer (it waits for state >= 2 and submits again)
             }
@@ -149,7 +153,7 @@ private:
     std::deque<WinJob *> devq_, order_;
     std::mutex m_; std::condition_variable cv_;
     std::thread dev_, wr_;
-    bool stop_ = false; int err_ = 0;
+    bool stop_ = false; std::atomic<int> err_{0};      // written under m_, read by the stage threads outside it
     bool timing_ = false; double t0_ = 0, t_decode_wait_ = 0, t_stage_copy_ = 0, t_fill_ = 0, t_slot_ = 0, t_wait_ = 0, t_dev_ = 0, t_wr_ = 0; unsigned long long n_jobs_ = 0;
 };
 
@@ -173,7 +177,9 @@ inline bool cap_may_trigger(const std::vector<StagedFile> &staged, int64_t max_d
         }
         int64_t lo = 0;
         for (int64_t i = 0; i < n; ++i) {
-            while (f.pos[(size_t)lo] <= f.pos[(size_t)i] - span_max) ++lo;
+            // the device counts read j as live at read i's start when pos[j] + span >= pos[i] (k_maxcnt_detect): keep every read
+            // with pos[j] >= pos[i] - span_max, boundary included, so that this stays an upper bound of the device's count
+            while (f.pos[(size_t)lo] < f.pos[(size_t)i] - span_max) ++lo;
             if (i - lo + 1 > max_depth) return true;
         }
     }

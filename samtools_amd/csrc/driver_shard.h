@@ -10,6 +10,7 @@
 // bam_consensus.c:2759-2810 and the region iterators of bam_plcmd.c:550.  State that crosses blocks is refused instead of
 // approximated: `-a` (one -a prints a contig only once it has shown data somewhere) and a -d cap that can actually trigger.
 #pragma once
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -56,5 +57,9 @@ struct Shard {
         if (*pe < *pb) *pe = *pb;
     }
 };
+
+// where a driver writes when the command names no -o file: stdout, or the memory stream of sta_main_capture (driver_capture.cpp)
+FILE *driver_default_out();
+bool driver_out_is_borrowed(FILE *f);     // stdout or the capture stream: the driver must not close it
 
 }  // namespace sta

@@ -333,7 +333,7 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
             int sz = aux_size(p[0]); uint32_t cnt; memcpy(&cnt, p + 1, 4);
             if (!sz || (uint64_t)sz * cnt > (uint64_t)(e - p - 5)) return -2;
             vlen = 5 + (size_t)sz * cnt;
-            if (tag[0] == 'C' && tag[1] == 'G' && p[0] == 'I') { cg = p + 5; cg_n = cnt; }
+            if (tag[0] == 'C' && tag[1] == 'G' && (p[0] == 'I' || p[0] == 'i') && !cg) { cg = p + 5; cg_n = cnt; }      // bam_aux_get: the first CG
             if (tag[0] == 'M' && (tag[1] == 'L' || tag[1] == 'l') && sz == 1) { r.has_ml = true; r.ml.assign(p + 5, p + 5 + cnt); }
         } else {
             int sz = aux_size(t);
@@ -368,7 +368,10 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
     }
     // SAM spec 4.2.2 / sam.c bam_tag2cigar: a CIGAR of more than 65535 operations is stored in CG:B,I and the record carries
     // the placeholder <l_seq>S<ref span>N
-    if (cg && n_cig == 2 && (r.cigar[0] & 0xf) == 4 && (int64_t)(r.cigar[0] >> 4) == (int64_t)l_seq && (r.cigar[1] & 0xf) == 3) {
+    // (bam_tag2cigar's conditions: a mapped record whose first op is <l_seq>S, CG of subtype I or i, at least as long as the
+    // placeholder and below 2^29 ops; the second placeholder op is not looked at)
+    if (cg && n_cig >= 1 && refID >= 0 && pos >= 0 && (r.cigar[0] & 0xf) == 4 && (int64_t)(r.cigar[0] >> 4) == (int64_t)l_seq
+        && cg_n >= (uint32_t)n_cig && cg_n < (1u << 29)) {
         r.cigar.resize(cg_n);
         if (cg_n) memcpy(r.cigar.data(), cg, 4 * (size_t)cg_n);
     }

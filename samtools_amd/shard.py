@@ -16,6 +16,7 @@ Two layers use this module:
 Nothing here computes pileups: it only decides who owns which columns and moves finished text.
 """
 import os
+import time
 import sys
 import tempfile
 from typing import List, Sequence, Tuple
@@ -154,28 +155,43 @@ def run_sharded_cli(argv: Sequence[str], out=None) -> int:
     sub, args = argv[0], list(argv[1:])
     if sub not in ("mpileup", "depth"):
         raise SystemExit("samtools_amd.shard: only mpileup and depth shard over reference columns")
-    # the command's own -o/--output is where rank 0 finally writes; every rank's block goes to a private file first
-    final = None
-    for k in range(len(args) - 1):
-        if args[k] in ("-o", "--output"):
-            final = args[k + 1]
-            del args[k:k + 2]
-            break
+    # the command's own -o/--output is where rank 0 finally writes (all four getopt spellings); every rank's block is
+    # captured in memory (sta_main_capture) and goes from there straight into the gather
+    final, rest, k = None, [], 0
+    while k < len(args):
+        a = args[k]
+        if a in ("-o", "--output") and k + 1 < len(args):
+            final = args[k + 1]; k += 2; continue
+        if a.startswith("--output="):
+            final = a[len("--output="):]; k += 1; continue
+        if a.startswith("-o") and len(a) > 2 and not a.startswith("--"):
+            final = a[2:]; k += 1; continue
+        rest.append(a); k += 1
+    args = rest
     use_cuda = dist.get_backend() == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
-    with tempfile.TemporaryDirectory() as tmp:
-        part = os.path.join(tmp, "part.%d" % rank)
-        os.environ["STA_SHARD"] = "%d/%d" % (rank, world)
-        try:
-            rc = (_capi.main_mpileup if sub == "mpileup" else _capi.main_depth)(args + ["-o", part])
-        finally:
-            os.environ.pop("STA_SHARD", None)
-        data = open(part, "rb").read() if os.path.exists(part) else b""
+    os.environ["STA_SHARD"] = "%d/%d" % (rank, world)
+    t0 = time.perf_counter()
+    try:
+        rc, data = _capi.main_capture(sub, args)
+    finally:
+        os.environ.pop("STA_SHARD", None)
+    t_drv = time.perf_counter() - t0
     local = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev) if data else torch.zeros(0, dtype=torch.uint8, device=dev)
     rcs = torch.tensor([rc], dtype=torch.int64, device=dev)
     dist.all_reduce(rcs, op=dist.ReduceOp.MAX)
+    worst = int(rcs.item())
+    t1 = time.perf_counter()
     whole = gather_text(local, dst=0)
+    t_gather = time.perf_counter() - t1
+    if os.environ.get("STA_SHARD_TIMING"):
+        sys.stderr.write("[shard %d/%d] driver %.3f s, %d bytes; gather %.3f s\n" % (rank, world, t_drv, len(data), t_gather))
     if rank == 0:
+        if worst != 0:
+            # a failed block would leave a silent hole in the concatenation: nothing is written (the ranks' own messages
+            # are on stderr already)
+            sys.stderr.write("samtools_amd.shard: a rank failed (worst exit status %d): no output written\n" % worst)
+            return worst
         buf = whole.cpu().numpy().tobytes()
         if out is not None:
             out.write(buf)
@@ -185,7 +201,7 @@ def run_sharded_cli(argv: Sequence[str], out=None) -> int:
         else:
             sys.stdout.buffer.write(buf)
             sys.stdout.buffer.flush()
-    return int(rcs.item())
+    return worst
 
 
 def main() -> int:

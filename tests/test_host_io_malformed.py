@@ -106,6 +106,18 @@ def test_cg_tag_cigar_is_expanded(tmp_path):
     b = sam_to_bam(str(parked), str(tmp_path / "parked.bam"))
     for stage in (0, 2):
         assert _scan(a, stage) == _scan(b, stage)
+    # bam_tag2cigar looks only at the first placeholder op and accepts subtype 'i' as well: `10S` alone + CG:B:i
+    short = tmp_path / "short.sam"
+    short.write_text("@SQ\tSN:c1\tLN:1000\nr2\t16\tc1\t21\t60\t10S\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII\tCG:B:i,%d,%d,%d\n"
+                     % (4 << 4 | 0, 2 << 4 | 2, 6 << 4 | 0))
+    d = sam_to_bam(str(short), str(tmp_path / "short.bam"))
+    for stage in (0, 2):
+        assert _scan(d, stage) == _scan(a, stage)
+    # a CG shorter than the placeholder is left alone (CG_len < n_cigar)
+    tiny = tmp_path / "tiny.sam"
+    tiny.write_text("@SQ\tSN:c1\tLN:1000\nr2\t16\tc1\t21\t60\t10S12N\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII\tCG:B:I,%d\n" % (10 << 4 | 0))
+    t = sam_to_bam(str(tiny), str(tmp_path / "tiny.bam"))
+    assert _scan(t) != _scan(a)
     # without the tag the placeholder is an ordinary CIGAR and decodes differently
     plain = tmp_path / "plain.sam"
     plain.write_text("@SQ\tSN:c1\tLN:1000\nr2\t16\tc1\t21\t60\t10S12N\t*\t0\t0\tACGTACGTAC\tIIIIIIIIII\n")

@@ -33,20 +33,52 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
+def _pile_bpb(depth):
+    """algorithmic HBM bytes per piled base of the pileup text path: seq 0.5 + qual 1 + record header / CIGAR /
+    offsets 0.19 + 2 output characters + (reference base 1 + fixed row text 17) / depth  ->  4.29 @30x, 3.87 @100x, 3.75 @300x"""
+    return 3.69 + 18.0 / depth
+
+
+def _wl(kind, depth, cols, argv, baq=False, bpb=None, gen=None, flags_on=0, flags_off=0, max_depth=None):
+    """one workload: kind, depth, default window columns per GPU, CLI form (what the oracle runs), generator options,
+    sta_mplp_params deltas.  bpb = algorithmic bytes per piled base of the WHOLE step (pileup text path + ~1 B/base of reference
+    window when BAQ runs); bpb_pileup = the text path alone (what the emit kernel is priced with)."""
+    pile = _pile_bpb(depth)
+    return {"kind": kind, "depth": depth, "cols": cols, "argv": argv, "baq": baq, "bpb": bpb if bpb is not None else pile + (1.0 if baq else 0.0),
+            "bpb_pileup": pile if kind == "mpileup" else (bpb if bpb is not None else pile), "gen": gen or {}, "flags_on": flags_on, "flags_off": flags_off,
+            "max_depth": max_depth}
+
+
+_REALN, _REDO_BAQ, _NO_ORPHAN = 1 << 4, 1 << 6, 1 << 3      # STA_MPLP_* (include/samtools_amd.h)
 WORKLOADS = {
-    # name: (kind, depth, default window columns per GPU, algorithmic HBM bytes per piled base, cli args)
-    "mpileup30": ("mpileup", 30, 4 << 20, 4.3 + 1.0, ["mpileup", "-f", "{fa}", "{sam}"]),       # + ~1 B/base of reference window for BAQ
-    "mpileup30_B": ("mpileup", 30, 4 << 20, 4.3, ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
-    "mpileup300": ("mpileup", 300, 1 << 19, 3.75 + 1.0, ["mpileup", "-f", "{fa}", "{sam}"]),
-    "mpileup300_B": ("mpileup", 300, 1 << 19, 3.75, ["mpileup", "-B", "-f", "{fa}", "{sam}"]),
-    "depth30": ("depth", 30, 8 << 20, 0.21, ["depth", "-a", "{sam}"]),
+    # BASELINE.json configs[2] (the metric's configuration): mpileup -f, BAQ on, 30x 150 bp
+    "mpileup30": _wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True),
+    "mpileup30_B": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN),
+    # configs[3] shape (deep columns); --gpus N shards it like mpileup30
+    "mpileup300": _wl("mpileup", 300, 1 << 19, ["mpileup", "-f", "{fa}", "{sam}"], baq=True),
+    "mpileup300_B": _wl("mpileup", 300, 1 << 19, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN),
+    # between the two emit kernels' home grounds
+    "mpileup100": _wl("mpileup", 100, 1 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True),
+    "mpileup100_B": _wl("mpileup", 100, 1 << 20, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN),
+    # configs[4]: -E -A, BAQ recomputed + mate-overlap resolution on 30x PAIRED reads (99/147 + 83/163, insert ~N(300,30): about a
+    # third of the pairs overlap); + 2 B per overlapping base of quality read-modify-write
+    "mpileup30_EA_pairs": _wl("mpileup", 30, 4 << 20, ["mpileup", "-E", "-A", "-f", "{fa}", "{sam}"], baq=True, gen={"paired": True},
+                              flags_on=_REDO_BAQ, flags_off=_NO_ORPHAN),
+    "mpileup30_B_pairs": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-A", "-f", "{fa}", "{sam}"], gen={"paired": True}, flags_off=_REALN | _NO_ORPHAN),
+    # the deep-amplicon shape inside an ordinary window: 30x + one 10 000x amplicon of 300 bp (-d raised so that the cap stays out of it)
+    "mpileup30_hotspot": _wl("mpileup", 30, 4 << 20, ["mpileup", "-d", "20000", "-f", "{fa}", "{sam}"], baq=True, gen={"hotspot": (300, 10000)}, max_depth=20000),
+    "mpileup30_B_hotspot": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-d", "20000", "-f", "{fa}", "{sam}"], gen={"hotspot": (300, 10000)}, flags_off=_REALN, max_depth=20000),
+    # BAQ with a real indel spectrum: 5 % of the reads carry a 1-3 bp insertion or deletion (band-8 / general-band kernels under load)
+    "mpileup30_indel": _wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True, gen={"indel_rate": 0.05}),
+    # configs[1]
+    "depth30": _wl("depth", 30, 8 << 20, ["depth", "-a", "{sam}"], bpb=0.21),
     # rows widened into after the pileup path (SURVEY.md 8a row a14, 8f row 3); single GPU, results stay on the device
-    "glf30": ("glf", 30, 4 << 20, 1.5 + 128.0 / 30.0, ["glf", "-f", "{fa}", "{sam}"]),
-    "calmd30": ("calmd", 30, 4 << 20, 4.0, ["calmd", "-r", "{sam}", "{fa}"]),
+    "glf30": _wl("glf", 30, 4 << 20, ["glf", "-f", "{fa}", "{sam}"], bpb=1.5 + 128.0 / 30.0),
+    "calmd30": _wl("calmd", 30, 4 << 20, ["calmd", "-r", "{sam}", "{fa}"], bpb=4.0),
     # SURVEY.md 8f row 4: `samtools consensus` columns (call + quality per column stay on the device).  Algorithmic bytes per piled
     # base: seq 0.5 + qual 1 + per-read header ~0.2 + per-column result 12 B / depth 30 = 0.4
-    "consensus30": ("consensus", 30, 4 << 20, 2.1, ["consensus", "-f", "fastq", "{sam}"]),
-    "consensus30_simple": ("consensus", 30, 4 << 20, 2.1, ["consensus", "-m", "simple", "-f", "fastq", "{sam}"]),
+    "consensus30": _wl("consensus", 30, 4 << 20, ["consensus", "-f", "fastq", "{sam}"], bpb=2.1),
+    "consensus30_simple": _wl("consensus", 30, 4 << 20, ["consensus", "-m", "simple", "-f", "fastq", "{sam}"], bpb=2.1),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec); ~6.3 TB/s is what a streaming copy reaches
 # fp64 vector ALU without fused multiply-add (BAQ must round like the CPU: -ffp-contract=off): 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz
@@ -132,13 +164,13 @@ def slice_reads(np, rd, lo, hi, origin):
 def oracle_text_hash(wl, n_cols, seed_ref=1, seed_reads=42, save_to=None, inputs=None, chunk_cols=None):
     """The checker: the oracle's text for the synthetic window (same generator, same seeds) -> sha256, bytes, wall time.
     inputs: optional dict from synth_inputs() so that several workloads of one shape share the generated reads and SAM text."""
-    kind, depth, _, _, argv = WORKLOADS[wl]
+    argv = WORKLOADS[wl]["argv"]
     oracle = os.path.join(REPO, "oracle", "_build", "oracle_samtools")
     if not os.path.exists(oracle):
         return None
     own = inputs is None
     if own:
-        inputs = synth_inputs(depth, n_cols, seed_ref, seed_reads, chunk_cols)
+        inputs = synth_inputs(wl, n_cols, seed_ref, seed_reads, chunk_cols)
     try:
         rd = inputs["rd"]
         args = [a.format(sam=inputs["sam"], fa=inputs["fa"]) for a in argv]
@@ -165,12 +197,30 @@ def oracle_text_hash(wl, n_cols, seed_ref=1, seed_reads=42, save_to=None, inputs
             shutil.rmtree(inputs["dir"], ignore_errors=True)
 
 
-def synth_inputs(depth, n_cols, seed_ref=1, seed_reads=42, chunk_cols=None):
-    """bench.py's synthetic window as numpy arrays AND as the SAM / FASTA files the oracle reads (caller removes ['dir']).
+def make_reads(wl, ref, chunk_cols, seed_reads=42, chunks=None):
+    """the workload's synthetic reads over `ref` (SURVEY.md 8d generator, tests/synth.py): ONE definition for the engine's
+    arrays, the oracle's SAM text and the parity tests"""
+    from synth import synth_chunked, synth_reads, synth_hotspot
+    spec = WORKLOADS[wl]
+    g = spec["gen"]
+    if g.get("paired"):
+        rd = synth_reads(ref, depth=spec["depth"], read_len=150, seed=seed_reads, paired=True)
+        rd["_abs_pos"] = rd["_abs_pos"].copy()
+        return rd
+    kw = {"indel_rate": g["indel_rate"]} if "indel_rate" in g else {}
+    rd = synth_chunked(ref, chunk_cols, depth=spec["depth"], read_len=150, seed=seed_reads, chunks=chunks, **kw)
+    if g.get("hotspot"):
+        hl, hd = g["hotspot"]
+        rd = synth_hotspot(ref, rd, hot_start=len(ref) // 4, hot_len=hl, hot_depth=hd, seed=seed_reads + 1000)
+    return rd
+
+
+def synth_inputs(wl, n_cols, seed_ref=1, seed_reads=42, chunk_cols=None):
+    """a workload's synthetic window as numpy arrays AND as the SAM / FASTA files the oracle reads (caller removes ['dir']).
     chunk_cols: the per-GPU window of a sharded run (the input is then assembled from pieces, tests/synth.py synth_chunked)."""
-    from synth import synth_ref, synth_chunked, write_sam, write_fasta
+    from synth import synth_ref, write_sam, write_fasta
     ref = synth_ref(n_cols, seed=seed_ref)
-    rd = synth_chunked(ref, chunk_cols or n_cols, depth=depth, read_len=150, seed=seed_reads)
+    rd = make_reads(wl, ref, chunk_cols or n_cols, seed_reads)
     d = tempfile.mkdtemp(prefix="sta_bench_")
     sam, fa = os.path.join(d, "s.sam"), os.path.join(d, "s.fa")
     write_sam(sam, rd, "chrS", n_cols)
@@ -227,7 +277,7 @@ def main():
     import numpy as np
     import torch
     import samtools_amd as sa
-    from synth import synth_ref, synth_chunked
+    from synth import synth_ref
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -248,14 +298,17 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    kind, depth, def_cols, alg_bpb, _ = WORKLOADS[a.workload]
+    spec = WORKLOADS[a.workload]
+    kind, depth, def_cols, alg_bpb = spec["kind"], spec["depth"], spec["cols"], spec["bpb"]
+    if world > 1 and (spec["gen"].get("paired") or spec["gen"].get("hotspot")):
+        raise SystemExit("workload %s is a single-GPU measurement (its generator is not built piecewise)" % a.workload)
     cols_per_gpu = a.cols or def_cols
     n_cols = cols_per_gpu * world
     from samtools_amd import shard
     # ONE input for the whole job, the same on every rank: piece k = the reads starting in the k-th window of cols_per_gpu columns
     # (seed 42 + k; they reach into the next window).  Rank r owns columns [blk_beg, blk_end) and only builds the pieces around them.
     ref = synth_ref(n_cols, seed=1)
-    rd_all = synth_chunked(ref, cols_per_gpu, depth=depth, read_len=150, seed=42, chunks=(rank - 1, rank, rank + 1))
+    rd_all = make_reads(a.workload, ref, cols_per_gpu, 42, chunks=(rank - 1, rank, rank + 1) if world > 1 else None)
     blk_beg, blk_end = shard.block_of(rank, world, n_cols)
     if world > 1:
         # reads that can touch the block plus the mate halo (reads starting up to 2 x the longest span before it)
@@ -272,8 +325,9 @@ def main():
     if kind == "mpileup":
         par = sa.MplpParams.defaults()
         par.has_fai = 1
-        if a.workload.endswith("_B"):
-            par.flag &= ~sa.MPLP.REALN
+        par.flag = (par.flag | spec["flags_on"]) & ~spec["flags_off"]
+        if spec["max_depth"]:
+            par.max_depth = spec["max_depth"]
     elif kind == "depth":
         par = sa.DepthParams.defaults()
         par.all_pos = 1
@@ -325,12 +379,15 @@ def main():
     if dist is not None and rank == 0:
         recv = [torch.empty(sum(sizes), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
     step_no = [0]
+    t_wait = [0.0]                         # host time spent waiting for gathers (this rank)
 
     def step():
         i = step_no[0] % n_buf
         step_no[0] += 1
         if pending[i] is not None:
+            tw = time.perf_counter()
             shard.wait_all(pending[i])     # the buffer's previous gather must have left it
+            t_wait[0] += time.perf_counter() - tw
             pending[i] = None
         if kind == "mpileup":
             eng.stage_window(w)
@@ -347,7 +404,9 @@ def main():
     def drain():
         for i in range(n_buf):
             if pending[i] is not None:
+                tw = time.perf_counter()
                 shard.wait_all(pending[i])
+                t_wait[0] += time.perf_counter() - tw
                 pending[i] = None
 
     if a.pmc_child:
@@ -362,17 +421,29 @@ def main():
     eng.profile(True)
     eng.profile_reset()
     torch.cuda.synchronize()
+    t_wait[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    t_issue = time.perf_counter() - t0     # this rank's own steps issued (kernels may still run, gathers may be in flight)
     drain()                                # every gather of the timed steps has completed inside the timed region
     torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0       # this rank done (text gathered / sent)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = eng.profile_get()
     eng.profile(False)
+    per_rank = None
+    if dist is not None:
+        # where every rank's time went (ms per step): its kernels by HIP events, host time waiting for gathers, time until its
+        # own work was done, and the barrier slack up to the slowest rank
+        mine = {"rank": rank, "kernels_ms": sum(v[1] for v in prof.values()) / a.steps, "gather_wait_ms": t_wait[0] / a.steps * 1e3,
+                "issue_ms": t_issue / a.steps * 1e3, "own_ms": t_own / a.steps * 1e3, "barrier_slack_ms": (dt - t_own) / a.steps * 1e3,
+                "out_bytes": out_bytes, "piled_bases": piled}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     tt = torch.tensor([dt, float(piled)], dtype=torch.float64, device=dev if backend == "nccl" else torch.device("cpu"))
     if dist is not None:
@@ -412,9 +483,11 @@ def main():
                 return None
             return (ent["FETCH_SIZE"] * (2.0 if name in FETCH_X2 else 1.0) + ent["WRITE_SIZE"]) * 1024.0
 
-        def roof(name):
+        def roof(name, bpb=None):
             """SURVEY.md 8(d) roofline of one kernel: the path's algorithmic bytes per piled base (each staged byte read once, each
-            output byte written once) x the bases one launch processes / the kernel's average launch time, against 8 TB/s."""
+            output byte written once) x the bases one launch processes / the kernel's average launch time, against 8 TB/s.
+            bpb: the text kernels are priced with the pileup path's own bytes (no BAQ reference window)."""
+            alg_bpb = bpb if bpb is not None else spec["bpb"]
             launches, ms = prof[name]
             per_step = max(1, launches // max(1, a.steps))
             avg_ms = ms / max(1, launches)
@@ -446,24 +519,26 @@ def main():
             "metric": "Mbases piled/s (mpileup, 30x 150bp)" if a.workload.startswith("mpileup30") else "Mbases piled/s (%s)" % a.workload,
             "value": value, "unit": "Mbases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt_all / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8/f64" if ((kind == "mpileup" and not a.workload.endswith("_B")) or kind in ("glf", "calmd") or a.workload == "consensus30") else "u8",
+            "vs_baseline": None, "dtype": "u8/f64" if (spec["baq"] or kind in ("glf", "calmd") or a.workload == "consensus30") else "u8",
             "data": "synthetic",
-            "config": {"workload": a.workload, "command": " ".join(x for x in WORKLOADS[a.workload][4] if x != "{sam}").replace("{fa}", "ref.fa"),
+            "config": {"workload": a.workload, "command": " ".join(x for x in spec["argv"] if x != "{sam}").replace("{fa}", "ref.fa"),
                        "read_len": 150, "depth": depth, "window_cols_per_gpu": cols_per_gpu, "input_cols": n_cols, "reads_per_gpu": int(rd["n"]),
                        "piled_bases_per_gpu_step": piled, "out_bytes_per_gpu_step": out_bytes,
                        "staged_in_bytes_per_gpu": in_bytes,
                        "parallelism": "one sorted input, reference columns sharded x%d (+ mate halo), 1 variable-size RCCL gather" % world},
-            "roofline": roof(dom_name) if dom_name else None,
+            "roofline": roof(dom_name, spec["bpb_pileup"] if dom_name and dom_name.startswith("mplp_") else None) if dom_name else None,
             "kernels_ms_per_step": {k: v[1] / a.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
         }
         emit_name = next((k for k in ({"mpileup": ["mplp_fused", "mplp_emit_deep", "mplp_emit"], "depth": ["depth_fused", "depth_emit"], "glf": ["glf_cols"], "calmd": ["md_emit"], "consensus": ["cons_col"]}[kind]) if k in prof), None)
         if emit_name and emit_name != dom_name:
-            res["roofline_pileup"] = roof(emit_name)
+            res["roofline_pileup"] = roof(emit_name, spec["bpb_pileup"])
         # whole step against the same roof: every kernel of the step, SURVEY.md 8d bytes
         res["roofline_step"] = {"bound": "hbm", "achieved": alg_bpb * piled_all / (dt_all / a.steps) / 1e9 / max(1, world), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s per GPU", "alg_bytes_per_unit": alg_bpb}
         res["roofline_step"]["frac"] = res["roofline_step"]["achieved"] / HBM_PEAK_GBS
         res["output_sha256"] = timed_sha
+        if per_rank:
+            res["per_rank"] = per_rank
         if kind in ("mpileup", "depth") and a.verify:
             # the timed window itself, byte for byte (hash of the whole text) against the oracle on the same seeds
             o = oracle_text_hash(a.workload, n_cols, chunk_cols=cols_per_gpu)
@@ -479,6 +554,8 @@ def main():
             sample = a.cpu_sample_cols or 2000000
             if depth >= 300:
                 sample //= 10
+            elif depth >= 100:
+                sample //= 4
             o = oracle_text_hash(a.workload, sample)
             if o:
                 res["cpu_baseline"] = {
@@ -515,8 +592,8 @@ def main():
                     nth = np.arange(int(ci.n_cols), dtype=np.int64) - np.repeat(first, ins + 1)
                     keepc = (cv[:, 0] > 0) & (cv[:, 1] != ord("*"))
                     got_rows = np.stack([pos[keepc], nth[keepc], cv[keepc, 0], cv[keepc, 1], cv[keepc, 2]], axis=1)
-                    pargs = [x for x in WORKLOADS[a.workload][4] if x not in ("-f", "fastq")]
-                    inp = synth_inputs(depth, sample)
+                    pargs = [x for x in spec["argv"] if x not in ("-f", "fastq")]
+                    inp = synth_inputs(a.workload, sample)
                     try:
                         pr = subprocess.run([os.path.join(REPO, "oracle", "_build", "oracle_samtools")] + [x.format(sam=inp["sam"], fa=inp["fa"]) for x in pargs[:-1]] + ["-f", "pileup", inp["sam"]],
                                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)

@@ -160,7 +160,7 @@ def write_synth_sam(outdir, n_ref=20000, depth=20, read_len=100, seed=7, paired=
 _CONCAT = ("flag", "mapq", "aux", "l_qseq", "mtid", "mpos", "isize", "cigar", "seq", "qual", "names", "_bases", "_quals")
 
 
-def synth_chunked(ref, chunk_cols, depth=30, read_len=150, seed=42, chunks=None):
+def synth_chunked(ref, chunk_cols, depth=30, read_len=150, seed=42, chunks=None, **kw):
     """ONE long sorted input assembled from pieces: piece k holds the reads STARTING in columns [k * chunk_cols, (k + 1) * chunk_cols)
     (seed + k; they extend into the next piece's columns, so block cuts do split reads), generated independently so that a rank of
     a sharded run only has to build the pieces around its block.  chunks = iterable of piece indices (None: all).  With one piece
@@ -176,7 +176,7 @@ def synth_chunked(ref, chunk_cols, depth=30, read_len=150, seed=42, chunks=None)
             continue
         sub = ref[c0:min(n, c0 + span + L + 16)]
         rd = synth_reads(sub, depth=depth, read_len=L, seed=seed + k, start_span=span,
-                         n_reads=max(1, int(depth * (n if n_chunks == 1 else min(chunk_cols, n - c0)) / L)))
+                         n_reads=max(1, int(depth * (n if n_chunks == 1 else min(chunk_cols, n - c0)) / L)), **kw)
         rd["_abs_pos"] = rd["_abs_pos"] + c0
         parts.append(rd)
     if len(parts) == 1:
@@ -200,3 +200,47 @@ def synth_chunked(ref, chunk_cols, depth=30, read_len=150, seed=42, chunks=None)
         base += len(p["qual"]) // 8
     out["base_off8"] = np.concatenate(offs).astype(np.uint32)
     return out
+
+
+def _gather_pool(pool, off, perm):
+    """variable-length per-read slices pool[off[r]:off[r+1]] re-ordered by perm -> (new pool, new offsets)"""
+    ln = (off[1:].astype(np.int64) - off[:-1].astype(np.int64))[perm]
+    new_off = np.zeros(len(perm) + 1, dtype=np.int64)
+    np.cumsum(ln, out=new_off[1:])
+    src = np.repeat(off[:-1].astype(np.int64)[perm], ln) + (np.arange(int(new_off[-1]), dtype=np.int64) - np.repeat(new_off[:-1], ln))
+    return pool[src], new_off.astype(np.uint32)
+
+
+def merge_reads(a, b):
+    """two generated read sets over the same contig -> one position-sorted set (ties: a's reads first, each set's own order kept)"""
+    n = a["n"] + b["n"]
+    L = a["L"]
+    Lp = (L + 7) & ~7
+    pos = np.concatenate([a["_abs_pos"], b["_abs_pos"]])
+    perm = np.argsort(pos, kind="stable")
+    out = {"n": n, "L": L}
+    for f in ("flag", "mapq", "aux", "l_qseq", "mtid", "mpos", "isize", "_bases", "_quals"):
+        out[f] = np.concatenate([a[f], b[f]])[perm]
+    out["_abs_pos"] = pos[perm]
+    out["pos"] = out["_abs_pos"].astype(np.int32)
+    out["qual"] = np.concatenate([a["qual"].reshape(-1, Lp), b["qual"].reshape(-1, Lp)])[perm].reshape(-1)
+    out["seq"] = np.concatenate([a["seq"].reshape(-1, Lp // 2), b["seq"].reshape(-1, Lp // 2)])[perm].reshape(-1)
+    out["base_off8"] = (np.arange(n, dtype=np.uint64) * (Lp >> 3)).astype(np.uint32)
+    for off_f, pool_f in (("cig_off", "cigar"), ("name_off", "names")):
+        pool = np.concatenate([a[pool_f], b[pool_f]])
+        off = np.concatenate([a[off_f][:-1].astype(np.int64), b[off_f].astype(np.int64) + len(a[pool_f])])
+        out[pool_f], out[off_f] = _gather_pool(pool, off, perm)
+    return out
+
+
+def synth_hotspot(ref, rd, hot_start, hot_len=300, hot_depth=10000, read_len=150, seed=1042):
+    """`rd` plus a deep amplicon: hot_depth x coverage by reads lying inside [hot_start, hot_start + hot_len) (the
+    "deep-amplicon shape" of BASELINE.json configs[3] inside an ordinary window).  Read names of the amplicon start with 'h'."""
+    hot_start = max(0, min(int(hot_start), len(ref) - hot_len))
+    sub = ref[hot_start:hot_start + hot_len]
+    h = synth_reads(sub, depth=hot_depth, read_len=read_len, seed=seed)
+    h["_abs_pos"] = h["_abs_pos"] + hot_start
+    names = h["names"].copy()
+    names[h["name_off"][:-1]] = ord("h")
+    h["names"] = names
+    return merge_reads(rd, h)

@@ -5,6 +5,9 @@ C-ABI) and the sha256 of its text must equal the oracle's for the same reads:
   * mpileup30     4 194 304 columns, 838 860 reads, BAQ on  (~20-40 s of oracle)
   * mpileup300    524 288 columns, 1 048 576 reads, BAQ on  (the deep-column emit path + BAQ together)
   * depth30       8 388 608 columns, -a
+  * (round 3) mpileup100[_B] 1 048 576 columns x 100; mpileup30_EA_pairs = BASELINE.json configs[4] (`-E -A`, proper pairs, mate
+    overlaps under load) and its -B form; mpileup30[_B]_hotspot (30x + one 10 000x amplicon of 300 bp: the per-wave deep / fast
+    emit choice); mpileup30_indel (5 % of the reads with an indel: band-8 and general-band BAQ under load)
   * engine paths that only an environment variable reaches: chunked BAQ slab (STA_BAQ_SLAB_GIB=1), no side stream
     for the band-8 groups (STA_BAQ_NO_SIDE_STREAM=1), at 786 432 columns
   * BASELINE.json configs[0]: examples/ex1.sam.gz (headerless, @SQ from the FASTA) + ex1.fa, SAM and BAM input.
@@ -30,11 +33,12 @@ def _shape(wl, n_cols):
     import atexit
     import shutil
     import bench
-    key = (bench.WORKLOADS[wl][1], n_cols)
+    spec = bench.WORKLOADS[wl]
+    key = (spec["depth"], repr(sorted(spec["gen"].items())), n_cols)       # workloads of one shape share the generated input
     if key not in _inputs:
         for k in list(_inputs):                       # one shape at a time: these are hundreds of MB each
             shutil.rmtree(_inputs.pop(k)["dir"], ignore_errors=True)
-        _inputs[key] = bench.synth_inputs(key[0], n_cols)
+        _inputs[key] = bench.synth_inputs(wl, n_cols)
         atexit.register(shutil.rmtree, _inputs[key]["dir"], True)
     return _inputs[key]
 
@@ -45,7 +49,8 @@ def _engine_sha(wl, n_cols, env=None):
     import torch
     import samtools_amd as sa
     import bench
-    kind = bench.WORKLOADS[wl][0]
+    spec = bench.WORKLOADS[wl]
+    kind = spec["kind"]
     dev = torch.device("cuda", 0)
     inp = _shape(wl, n_cols)
     ref, rd = inp["ref"], inp["rd"]
@@ -61,8 +66,9 @@ def _engine_sha(wl, n_cols, env=None):
         eng.stage_window(w)
         if kind == "mpileup":
             par = sa.MplpParams.defaults(); par.has_fai = 1
-            if wl.endswith("_B"):
-                par.flag &= ~sa.MPLP.REALN
+            par.flag = (par.flag | spec["flags_on"]) & ~spec["flags_off"]
+            if spec["max_depth"]:
+                par.max_depth = spec["max_depth"]
             info = eng.mpileup_plan(par)
             out = torch.empty(int(info.out_bytes) + 64, dtype=torch.uint8, device=dev)
             eng.mpileup_emit(out.data_ptr(), out.numel())
@@ -96,10 +102,17 @@ def _oracle(wl, n_cols):
     return _oracle_cache[key]
 
 
-@pytest.mark.parametrize("wl", ["mpileup30", "mpileup30_B", "mpileup300", "mpileup300_B", "depth30"])
+# Workloads of one input shape share a worker (pytest.ini: --dist loadgroup), so the generated input is built once per shape and at
+# most four of these windows (25 GiB of BAQ scratch each at 30x) are on the GPU at a time.
+_BENCH_WL = [("mpileup30", "a"), ("mpileup30_B", "a"), ("mpileup300", "b"), ("mpileup300_B", "b"), ("mpileup100", "b"), ("mpileup100_B", "b"),
+             ("mpileup30_EA_pairs", "c"), ("mpileup30_B_pairs", "c"), ("mpileup30_hotspot", "d"), ("mpileup30_B_hotspot", "d"),
+             ("mpileup30_indel", "a"), ("depth30", "c")]
+
+
+@pytest.mark.parametrize("wl", [pytest.param(w, marks=pytest.mark.xdist_group("benchsize_" + g)) for w, g in _BENCH_WL])
 def test_bench_window_text_is_byte_identical_to_the_oracle(wl):
     import bench
-    n_cols = bench.WORKLOADS[wl][2]
+    n_cols = bench.WORKLOADS[wl]["cols"]
     want_sha, want_n, _ = _oracle(wl, n_cols)
     got_sha, got_n, piled = _engine_sha(wl, n_cols)
     assert got_n == want_n
@@ -107,6 +120,7 @@ def test_bench_window_text_is_byte_identical_to_the_oracle(wl):
     assert piled > 0
 
 
+@pytest.mark.xdist_group("benchsize_d")
 @pytest.mark.parametrize("env", [{"STA_BAQ_SLAB_GIB": "1"}, {"STA_BAQ_NO_SIDE_STREAM": "1"}, {"STA_BAQ_SLAB_GIB": "1", "STA_BAQ_NO_SIDE_STREAM": "1"}],
                          ids=["slab1g", "noside", "slab1g_noside"])
 def test_env_only_engine_paths(env):

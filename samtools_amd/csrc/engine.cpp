@@ -83,6 +83,7 @@ struct sta_engine {
     StaCounters ctr_h{};
     uint64_t out_bytes = 0;
     uint32_t lds_cap = 0;
+    bool plp_legacy = false;           // STA_PLP_TILE=0: the lane-per-column kernel pair instead of the tile kernels (A/B measurements)
     void *last_out = nullptr;
     void *inf_last = nullptr; uint64_t inf_bytes = 0;      // output of the last sta_bgzf_inflate
     // profiling
@@ -175,6 +176,7 @@ int sta_engine_create(sta_engine **out, int device, void *hip_stream)
     sta_engine *e = new sta_engine();
     e->device = device;
     e->stream = (hipStream_t)hip_stream;   // nullptr = default stream
+    if (const char *ev = getenv("STA_PLP_TILE")) e->plp_legacy = atoi(ev) == 0;
     *out = e;
     return STA_OK;
 }
@@ -505,7 +507,7 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
         int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
         if (e->colinfo.ensure((size_t)(ncols > 0 ? ncols : 1) * (size_t)(nf > 0 ? nf : 1) * 8 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(column info) failed");
         ProfScope ps(e, "mplp_len");
-        sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr);
+        sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr, e->plp_legacy);
     }
     return STA_OK;
 }
@@ -621,16 +623,31 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     int rc = emit_common(e, dev_out, capacity, &out);
     if (rc) return rc;
     if (e->out_bytes == 0) return STA_OK;
-    // deep windows (mean depth of the data columns >= 100) take the read-major kernel; STA_EMIT_DEEP=0 / 1 forces either
+    // Which kernel writes which columns (windows without extra columns):
+    //  * deep windows (mean depth of the data columns >= 100): every strip through the read-major kernel k_mplp_emit_deep;
+    //  * otherwise k_mplp_emit_tile with an LDS slice of 1.5 x the mean bytes of a wave's 64 rows (at most 12 KiB: occupancy),
+    //    and the 64-column groups whose rows exceed it -- a deep amplicon inside an ordinary window -- through k_mplp_emit_deep.
+    // STA_EMIT_DEEP=0 / 1 forces the whole-window choice (tests).
+    const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
     bool deep = e->ctr_h.n_data_cols > 0 && e->ctr_h.piled_bases / e->ctr_h.n_data_cols >= 100;
     if (const char *ev = getenv("STA_EMIT_DEEP")) deep = atoi(ev) != 0;
-    if (deep) {
-        const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
+    const uint64_t mw = e->ctr_h.max_wave_bytes;
+    uint64_t tc = e->ctr_h.n_data_cols ? (e->out_bytes * 96) / e->ctr_h.n_data_cols : 1024;       // 1.5 x 64 x mean row
+    tc = (tc + 255) & ~255ull;
+    if (tc > 12288) tc = 12288;
+    if (tc > ((mw + 255) & ~255ull)) tc = (mw + 255) & ~255ull;
+    if (tc < 1024) tc = 1024;
+    const uint32_t tile_cap = (uint32_t)tc;
+    int deep_mode = deep ? 1 : 0;
+    if (!deep && !e->plp_legacy && mw > tile_cap) deep_mode = 2;
+    if (e->plp_legacy && !deep) deep_mode = 0;
+    if (deep_mode) {
         if (e->strip_rng.ensure((size_t)sta_mplp_deep_strips(ncols > 0 ? ncols : 1) * (size_t)(e->wd.nfiles > 0 ? e->wd.nfiles : 1) * 16 + 16))
             return fail(e, STA_ERR_HIP, "hipMalloc(strip ranges) failed");
     }
-    ProfScope ps(e, deep ? "mplp_emit_deep" : "mplp_emit");
-    sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap, deep ? (int64_t *)e->strip_rng.p : nullptr);
+    ProfScope ps(e, deep_mode == 1 ? "mplp_emit_deep" : "mplp_emit");
+    sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap, deep_mode ? (int64_t *)e->strip_rng.p : nullptr,
+                         tile_cap, deep_mode, e->plp_legacy);
     return STA_OK;
 }
 

@@ -19,19 +19,9 @@
 //                assembled in LDS and flushed with coalesced 16-byte stores; a wave whose
 //                lines exceed the LDS slice falls back to direct global byte stores.
 #include "dev_util.h"
+#include "plp_tile.h"
 #include <cstdlib>
 
-struct MplpDevPar {
-    int32_t min_baseQ, all, rev_del, flag, no_ins, no_del, no_ends;
-    int32_t n_tags, tag_sep;
-    int32_t mods, no_ins_mods;       // --output-mods: append StaReadsDev.mod_* text to modified bases (and to inserted ones unless no_ins_mods)
-    int64_t tlen;
-};
-#define TAGKIND (1 << 28)       // file_pass "kind" of tag column t is TAGKIND + t
-
-__constant__ char c_nt_lc[17] = ",acmgrsvtwyhkdbn";
-__constant__ char c_nt_uc[17] = ".ACMGRSVTWYHKDBN";
-__constant__ char c_nt16_str[17] = "=ACMGRSVTWYHKDBN";
 // seq_nt16_table (hts.c): character -> 4-bit code, 15 for anything else (a table: the switch in nt16_from_char costs ~300
 // scalar instructions of exec-mask juggling per wave when every lane holds a different character)
 __constant__ unsigned char c_nt16_of_char[256] = {
@@ -47,214 +37,6 @@ __constant__ unsigned char c_nt16_of_char[256] = {
 #define EXTRA_MASK (STA_MPLP_PRINT_MAPQ_CHAR | STA_MPLP_PRINT_QPOS | STA_MPLP_PRINT_QNAME | STA_MPLP_PRINT_FLAG | \
                     STA_MPLP_PRINT_RNAME | STA_MPLP_PRINT_POS | STA_MPLP_PRINT_MAPQ | STA_MPLP_PRINT_RNEXT | STA_MPLP_PRINT_PNEXT | \
                     STA_MPLP_PRINT_RLEN | STA_MPLP_PRINT_QPOS5)
-
-extern __shared__ __attribute__((aligned(16))) char lds_text[];
-
-// ---- byte sink: LDS slice of this wave, or global memory ----
-template <bool LDS> struct Sink {
-    uint32_t cur;        // LDS: offset into lds_text; global: unused
-    char *g;             // global cursor
-    __device__ __forceinline__ void put(char c)
-    {
-        if (LDS) lds_text[cur++] = c;
-        else *g++ = c;
-    }
-    __device__ __forceinline__ void put_dec(long long v)
-    {
-        if (v < 0) { put('-'); v = -v; }
-        unsigned long long u = (unsigned long long)v;
-        int n = dec_digits(u);
-        if (LDS) {
-            uint32_t e = cur + n;
-            for (uint32_t q = e; q > cur;) { lds_text[--q] = (char)('0' + u % 10); u /= 10; }
-            cur = e;
-        } else {
-            char *e = g + n;
-            for (char *q = e; q > g;) { *--q = (char)('0' + u % 10); u /= 10; }
-            g = e;
-        }
-    }
-};
-
-struct Resolved {
-    int qpos, indel, k;
-    bool is_del, is_refskip;
-};
-
-// stateless equivalent of HTSlib resolve_cigar2 for (read, column p) -- SURVEY.md A.2
-__device__ __forceinline__ Resolved resolve_general(const uint32_t *cig, int n, int rpos, int p)
-{
-    Resolved r;
-    int x = rpos, y = 0, k = 0, op = 0, l = 0;
-    for (k = 0; k < n; ++k) {
-        uint32_t c = cig[k];
-        op = c & 0xf; l = (int)(c >> 4);
-        if (cg_is_refop(op)) {
-            if (p < x + l) break;
-            if (cg_is_mop(op)) y += l;
-            x += l;
-        } else if (cg_is_qop(op)) y += l;
-    }
-    r.k = k; r.indel = 0; r.is_del = false; r.is_refskip = false;
-    if (x + l - 1 == p && k + 1 < n) {
-        int op2 = cig[k + 1] & 0xf, l2 = (int)(cig[k + 1] >> 4);
-        if (op2 == CG_D && op != CG_D) {
-            r.indel = -l2;
-            for (int j = k + 2; j < n; ++j) {
-                if ((cig[j] & 0xf) == CG_D) r.indel -= (int)(cig[j] >> 4); else break;
-            }
-        } else if (op2 == CG_I) {
-            r.indel = l2;
-            for (int j = k + 2; j < n; ++j) {
-                int o = cig[j] & 0xf;
-                if (o == CG_I) r.indel += (int)(cig[j] >> 4);
-                else if (o != CG_P) break;
-            }
-        } else if (op2 == CG_P && k + 2 < n) {
-            int l3 = 0;
-            for (int j = k + 2; j < n; ++j) {
-                int o = cig[j] & 0xf;
-                if (o == CG_I) l3 += (int)(cig[j] >> 4);
-                else if (cg_is_refop(o)) break;
-            }
-            if (l3 > 0) r.indel = l3;
-        }
-    }
-    if (cg_is_mop(op)) r.qpos = y + (p - x);
-    else { r.is_del = true; r.qpos = y; r.is_refskip = (op == CG_N); }
-    return r;
-}
-
-// --output-mods: the text HTSlib's bam_mods_at_qpos yields for query position qpos of read r ("[+m128]"), staged by the host
-// (host_mods.cpp); returns its length (0: the base is not modified) and where it starts
-__device__ __forceinline__ int mod_text_at(const StaReadsDev &R, int64_t r, int qpos, uint32_t &t0)
-{
-    if (!R.mod_off) return 0;
-    uint32_t lo = R.mod_off[r], hi = R.mod_off[r + 1];
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint32_t q = R.mod_qpos[mid];
-        if (q == (uint32_t)qpos) { t0 = R.mod_toff[mid]; return (int)(R.mod_toff[mid + 1] - t0); }
-        if (q < (uint32_t)qpos) lo = mid + 1; else hi = mid;
-    }
-    return 0;
-}
-
-// bam_plp_insertion: total length (I+P run after op k) and the D that may follow it
-__device__ __forceinline__ void insertion_shape(const uint32_t *cig, int n, int k, int &ins_total, int &del_after)
-{
-    ins_total = 0; del_after = 0;
-    int j = k + 1;
-    for (; j < n; ++j) {
-        int o = cig[j] & 0xf;
-        if (o == CG_I || o == CG_P) ins_total += (int)(cig[j] >> 4); else break;
-    }
-    if (j < n && (cig[j] & 0xf) == CG_D) del_after = (int)(cig[j] >> 4);
-}
-
-// One (read, column) entry after filtering: everything pileup_seq / the extra columns need.
-struct Entry {
-    int64_t r;           // read index
-    int rpos, rend, lq;
-    uint32_t info;
-    uint64_t boff;       // base offset (bytes into qual; /2 into seq)
-    Resolved rs;
-};
-
-__device__ __forceinline__ int token_len(const StaReadsDev &R, const MplpDevPar &P, const Entry &e, int p)
-{
-    int len = 1;
-    if (!P.no_ends) len += (p == e.rpos ? 2 : 0) + (p == e.rend - 1 ? 1 : 0);
-    uint32_t mt0;
-    if (P.mods && !e.rs.is_del) len += mod_text_at(R, e.r, e.rs.qpos, mt0);
-    if (e.rs.indel != 0) {
-        int del_len = -e.rs.indel;
-        if (e.rs.indel > 0) {
-            const uint32_t *cig = R.cigar + R.cig_off[e.r];
-            int n = (int)(R.cig_off[e.r + 1] - R.cig_off[e.r]);
-            int ins_total;
-            insertion_shape(cig, n, e.rs.k, ins_total, del_len);
-            if (P.no_ins < 2) len += 1 + dec_digits_u32((uint32_t)ins_total);
-            if (!P.no_ins) {
-                len += ins_total;
-                if (P.mods && !P.no_ins_mods) {
-                    // modification text of the inserted bases (bam_plp_insertion_mod)
-                    int j = 1;
-                    for (int kk = e.rs.k + 1; kk < n; ++kk) {
-                        int o = cig[kk] & 0xf, l = (int)(cig[kk] >> 4);
-                        if (o == CG_I) { for (int t = 0; t < l; ++t, ++j) len += mod_text_at(R, e.r, e.rs.qpos + j - (e.rs.is_del ? 1 : 0), mt0); }
-                        else if (o != CG_P) break;
-                    }
-                }
-            }
-        }
-        if (del_len > 0) {
-            if (P.no_del < 2) len += 1 + dec_digits_u32((uint32_t)del_len);
-            if (!P.no_del) len += del_len;
-        }
-    }
-    return len;
-}
-
-template <bool LDS>
-__device__ __forceinline__ void token_write(const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, const Entry &e, int p, Sink<LDS> &s)
-{
-    bool rev = (e.info & RI_REV) != 0;
-    int64_t apos = W.origin + p;
-    if (!P.no_ends && p == e.rpos) {
-        int mq = (int)((e.info >> RI_MAPQ_SHIFT) & 0xff);
-        s.put('^');
-        s.put((char)(mq > 93 ? 126 : mq + 33));
-    }
-    if (!e.rs.is_del) {
-        int c = e.rs.qpos < e.lq ? seq_nib(R.seq, e.boff >> 1, e.rs.qpos) : 15;
-        if (W.ref) {
-            int rb = apos < W.ref_len ? nt16_from_char((unsigned char)W.ref[apos]) : 15;
-            if (c == rb) c = 0;
-        }
-        s.put(rev ? c_nt_lc[c] : c_nt_uc[c]);
-        if (P.mods) { uint32_t t0; const int ml = mod_text_at(R, e.r, e.rs.qpos, t0); for (int t = 0; t < ml; ++t) s.put(R.mod_text[t0 + t]); }
-    } else {
-        s.put(e.rs.is_refskip ? (rev ? '<' : '>') : ((rev && P.rev_del) ? '#' : '*'));
-    }
-    if (e.rs.indel != 0) {
-        int del_len = -e.rs.indel;
-        if (e.rs.indel > 0) {
-            const uint32_t *cig = R.cigar + R.cig_off[e.r];
-            int n = (int)(R.cig_off[e.r + 1] - R.cig_off[e.r]);
-            int ins_total;
-            insertion_shape(cig, n, e.rs.k, ins_total, del_len);
-            if (P.no_ins < 2) { s.put('+'); s.put_dec(ins_total); }
-            if (!P.no_ins) {
-                char pad = (rev && P.rev_del) ? '#' : '*';
-                int j = 1;
-                for (int kk = e.rs.k + 1; kk < n; ++kk) {
-                    int o = cig[kk] & 0xf, l = (int)(cig[kk] >> 4);
-                    if (o == CG_P) { for (int t = 0; t < l; ++t) s.put(pad); }
-                    else if (o == CG_I) {
-                        for (int t = 0; t < l; ++t, ++j) {
-                            int qi = e.rs.qpos + j - (e.rs.is_del ? 1 : 0);
-                            char ch = qi < e.lq ? c_nt16_str[seq_nib(R.seq, e.boff >> 1, qi)] : 'N';
-                            s.put(rev ? lower_c(ch) : upper_c(ch));
-                            if (P.mods && !P.no_ins_mods) { uint32_t t0; const int ml = mod_text_at(R, e.r, qi, t0); for (int t2 = 0; t2 < ml; ++t2) s.put(R.mod_text[t0 + t2]); }
-                        }
-                    } else break;
-                }
-            }
-        }
-        if (del_len > 0) {
-            if (P.no_del < 2) { s.put('-'); s.put_dec(del_len); }
-            if (!P.no_del) {
-                for (int j = 1; j <= del_len; ++j) {
-                    // reference: (ref && (int)pos+j < ref_len) ? ref[pos+j] : 'N'   (bam_plcmd.c:158)
-                    char c = (W.ref && (int64_t)((int)apos + j) < W.ref_len) ? W.ref[apos + j] : 'N';
-                    s.put(rev ? lower_c(c) : upper_c(c));
-                }
-            }
-        }
-    }
-    if (!P.no_ends && p == e.rend - 1) s.put('$');
-}
 
 // extra per-read columns (bam_plcmd.c:727-796)
 __device__ __forceinline__ long long extra_value(const StaReadsDev &R, const StaWinDev &W, int kind, const Entry &e)
@@ -795,17 +577,6 @@ __device__ __forceinline__ DeepPre deep_pre(const StaReadsDev &R, int64_t r, int
     return d;
 }
 
-// c_nt16_of_char without the dependent table load
-__device__ __forceinline__ unsigned nt16_arith(unsigned char c)
-{
-    const unsigned li = (unsigned)(c | 32) - 'a';
-    if (li < 16u) return (unsigned)(0xfff3fcffb4ffd2e1ull >> (4 * li)) & 15u;          // a..p
-    if (li < 26u) return (unsigned)(0xfaf97f865full >> (4 * (li - 16u))) & 15u;        // q..z
-    if (c == '=') return 0u;
-    const unsigned di = (unsigned)c - '0';
-    return di < 4u ? 1u << di : 15u;
-}
-
 // [first, end) of the reads a strip has to look at, per (file, strip): found once by a thread here instead of by every wave of
 // k_mplp_emit_deep in eight dependent probe rounds
 __global__ void __launch_bounds__(256) k_mplp_strip_ranges(StaWinDev W, int64_t *__restrict__ rng, int64_t nstrips)
@@ -827,7 +598,7 @@ __global__ void __launch_bounds__(256) k_mplp_strip_ranges(StaWinDev W, int64_t 
 }
 
 __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(4, 8))) k_mplp_emit_deep(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
-                                                        const int64_t *__restrict__ rng, char *out)
+                                                        const int64_t *__restrict__ rng, char *out, uint32_t only_above)
 {
     const int lane = threadIdx.x & 63;
     // (readfirstlane: the compiler cannot see that the strip index is the same for the 64 lanes; with it the strip's bounds,
@@ -843,6 +614,12 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     if (threadIdx.x < 32) s_chr[threadIdx.x] = base_char_fast((int)(threadIdx.x & 15), threadIdx.x >= 16);
     __syncthreads();
     if (c0 >= ncols) return;
+    if (only_above) {
+        // beside k_mplp_emit_tile: only the 64-column groups whose rows did not fit that kernel's LDS slice (a deep amplicon inside
+        // an ordinary window) are written here
+        const int64_t g0 = c0 & ~(int64_t)63, g1 = g0 + 64 < ncols ? g0 + 64 : ncols;
+        if (offs[g1] - offs[g0] <= (uint64_t)only_above) return;
+    }
     uint32_t *const x_off = s_off[wv][lane]; uint8_t *const x_qc = s_qc[wv][lane];
     const int nk = ncols - c0 < DEEP_STRIP ? (int)(ncols - c0) : DEEP_STRIP;
     const int p0 = W.col_beg + (int)c0, plast = p0 + nk - 1;
@@ -1064,6 +841,160 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     if (my_ex) fx.put('\n');
 }
 
+
+// ================================================================================================
+// Tile kernels (step functions and the layout: plp_tile.h).  They replace k_mplp_len_fast / k_mplp_emit_fast for windows without
+// --output-extra / -O / -s columns; waves whose rows exceed the LDS slice are left to k_mplp_emit_deep.
+
+__global__ void __launch_bounds__(LEN_THREADS) k_mplp_len_rm(StaWinDev W, MplpDevPar P, uint32_t *line_len, uint2 *colinfo)
+{
+    __shared__ LenLds L;
+    const int t = threadIdx.x;
+    const int64_t ncols = (int64_t)W.col_end - W.col_beg;
+    const int64_t c0 = (int64_t)blockIdx.x * LEN_TC;
+    if (c0 >= ncols) return;
+    const int t0 = W.col_beg + (int)c0;
+    const int ntile = (int)(ncols - c0 < LEN_TC ? ncols - c0 : LEN_TC);
+    const int t1 = t0 + ntile;
+    uint32_t total[4] = { 0, 0, 0, 0 };
+    bool any[4] = { false, false, false, false };
+    for (int f = 0; f < W.nfiles; ++f) {
+        const StaReadsDev &R = W.files[f];
+        len_clear(L, t);
+        if (t < 64) {                                       // the first wave finds the tile's reads (two 64-ary searches)
+            int64_t rlo, rhi;
+            wave_read_range(R, t0, t1 - 1, rlo, rhi);
+            if (t == 0) { L.rlo = rlo; L.rhi = rhi; }
+        }
+        __syncthreads();
+        const long long rlo = L.rlo, rhi = L.rhi;
+        for (long long b0 = rlo; b0 < rhi; b0 += LEN_THREADS) {
+            len_step_a(L, t, R, P, t0, t1, b0);
+            __syncthreads();
+            len_step_b(L, t, R, P, t0, t1);
+            const int ng = L.gcount;
+            for (int gi = t >> 6; gi < ng; gi += LEN_THREADS / 64) len_step_c(L, gi, t & 63, 64, b0, R, P, t0, t1);
+            if (b0 + LEN_THREADS < rhi) {                   // the batch arrays are reused
+                __syncthreads();
+                if (t == 0) L.gcount = 0;
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        len_scan_1(L, t); __syncthreads();
+        len_scan_2(L, t); __syncthreads();
+        len_scan_3(L, t); __syncthreads();
+        const int before = len_scan_4(L, t);
+        len_file_result(L, t, before, ntile, colinfo + (int64_t)f * ncols + c0, total, any);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = 4 * t + i;
+        if (c >= ntile) continue;
+        const int64_t apos = W.origin + t0 + c;
+        const bool in_reg = column_selected(W, apos);
+        const bool data = in_reg && any[i];
+        bool exists = in_reg && (any[i] || (P.all && apos < P.tlen));
+        if (exists && W.has_bed) exists = bed_overlap_dev(W.bed_beg, W.bed_end, W.n_bed, apos, apos + 1);
+        uint32_t len = 0;
+        if (exists) len = (uint32_t)W.tname_len + 1 + (uint32_t)dec_digits((unsigned long long)(apos + 1)) + 1 + 1 + total[i] + 1;
+        line_len[c0 + c] = len | (data ? 0x80000000u : 0u);
+    }
+}
+
+#define TILE_WAVES 2            // waves per workgroup of k_mplp_emit_tile (they share nothing)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
+                                                                    char *out, uint32_t lds_cap)
+{
+    const int wid = threadIdx.x >> 6;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const int64_t ncols = (int64_t)W.col_end - W.col_beg;
+    const int64_t c0 = wave * 64;
+    if (c0 >= ncols) return;
+    const int64_t c1 = c0 + 64 < ncols ? c0 + 64 : ncols;
+    const int p0 = W.col_beg + (int)c0;
+    const int p = p0 + lane;
+    const bool active = p < W.col_end;
+    const int plast = W.col_beg + (int)c1 - 1;
+    const uint64_t o0 = offs[c0], o1 = offs[c1];
+    const uint64_t my0 = active ? offs[c0 + lane] : o1;
+    const uint64_t my1 = active ? offs[c0 + lane + 1] : o1;
+    const bool exists = my1 > my0;
+    const uint64_t wbytes = o1 - o0;
+    if (wbytes == 0 || wbytes > lds_cap) return;            // rows beyond the slice: k_mplp_emit_deep takes those columns
+    const uint32_t slice = (lds_cap + 48 + 15) & ~15u;      // text (+ up to 15 alignment bytes) + dump bytes for predicated writes
+    const uint32_t base = (uint32_t)wid * (slice + (uint32_t)TILE_LDS_BYTES);
+    TileLds &T = *reinterpret_cast<TileLds *>(lds_text + base + slice);
+    const uint32_t mis = (uint32_t)((uintptr_t)(out + o0) & 15);
+    const uint32_t dump = base + slice - 8;
+    const bool has_ref = W.ref != nullptr;
+    const int64_t apos = W.origin + p;
+
+    TileLane st;
+    tile_row_head(T, st, lane, W, base + mis + (uint32_t)(my0 - o0), exists, apos);
+    if (lane < 2 * TILE_SLOTS) tile_zero_column(T, lane);
+    wave_lds_sync();
+    if (lane < 4) tile_refpack(T, lane);
+    wave_lds_sync();
+
+    for (int f = 0; f < W.nfiles; ++f) {
+        const StaReadsDev &R = W.files[f];
+        int64_t rlo, rhi;
+        wave_read_range(R, p0, plast, rlo, rhi);
+        tile_file_head(st, lane, exists ? colinfo[(int64_t)f * ncols + c0 + lane] : make_uint2(0u, 0u), dump);
+        const auto g_info = GPTR(uint32_t, R.info); const auto g_pos = GPTR(int32_t, R.pos); const auto g_end = GPTR(int32_t, R.end);
+        const auto g_b8 = GPTR(uint32_t, R.base_off8);
+        for (int64_t b0 = rlo; b0 < rhi; b0 += 64) {
+            const int64_t ri = b0 + lane;
+            const bool ok = ri < rhi;
+            const uint32_t v_info = ok ? g_info[ri] : 0u;
+            const int v_pos = ok ? g_pos[ri] : 0;
+            const int v_end = ok ? g_end[ri] : 0;
+            const uint32_t v_b8 = ok ? g_b8[ri] : 0u;
+            const bool live = ok && tile_read_is_live(v_info, v_pos, v_end, p0, plast);
+            const unsigned long long livem = __ballot(live);
+            const int nlive = __popcll(livem);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(livem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)livem, 0u));
+            for (int first = 0; first < nlive; first += TILE_SLOTS) {
+                const int ns = nlive - first < TILE_SLOTS ? nlive - first : TILE_SLOTS;
+                if (live && rank >= first && rank < first + TILE_SLOTS) tile_set_slot(T, rank - first, lane, v_info, v_pos, v_end, v_b8);
+                wave_lds_sync();
+                tile_phase1(T, lane, ns, R, P, p0, has_ref);
+                wave_lds_sync();
+                for (int s = 0; s < ns; ++s) {
+                    const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.s_info[s]);
+                    if (info & RI_SIMPLE) tile_phase2_row(T, s, st.col, st.cur_s, st.cur_q);
+                    else tile_phase2_general(T, s, st, R, W, P, b0, p);       // (the read is the same for every lane)
+                }
+                wave_lds_sync();                              // the tile rows are rewritten by the next round
+            }
+        }
+        tile_file_tail(st);
+    }
+    if (exists) lds_text[st.cur] = '\n';
+    wave_lds_sync();
+    // flush: LDS offset == global address (mod 16)
+    char *dst = out + o0;
+    const uint32_t n = (uint32_t)wbytes;
+    uint32_t head = mis ? 16 - mis : 0; if (head > n) head = n;
+    if ((uint32_t)lane < head) dst[lane] = lds_text[base + mis + lane];
+    const uint32_t body = (n - head) >> 4;
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(lds_text + base + mis + head);
+    uint4 *dst4 = reinterpret_cast<uint4 *>(dst + head);
+    for (uint32_t i = lane; i < body; i += 64) dst4[i] = src4[i];
+    const uint32_t done = head + (body << 4);
+    if (done + lane < n) dst[done + lane] = lds_text[base + mis + done + lane];
+}
+
 static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
 {
     MplpDevPar d;
@@ -1074,36 +1005,54 @@ static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
     return d;
 }
 
-void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr)
+void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr, bool legacy)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
     int64_t nb = (ncols + 255) / 256;
     if (sta_mplp_has_fast_path(p) && colinfo) {
+        if (!legacy && sta_mplp_tile_ok(p)) {
+            hipLaunchKernelGGL(k_mplp_len_rm, dim3((unsigned)((ncols + LEN_TC - 1) / LEN_TC)), dim3(LEN_THREADS), 0, s, w, make_par(p, w.tlen), line_len, colinfo);
+            return;
+        }
         hipLaunchKernelGGL(k_mplp_len_fast, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, colinfo, ctr);
         return;
     }
     hipLaunchKernelGGL(k_mplp_len, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, ctr);
 }
 
+static void launch_deep(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo, char *out,
+                        int64_t *strip_rng, uint32_t only_above)
+{
+    const int64_t ncols = (int64_t)w.col_end - w.col_beg;
+    const int64_t nwaves_d = sta_mplp_deep_strips(ncols);
+    const int64_t nt = nwaves_d * w.nfiles;
+    hipLaunchKernelGGL(k_mplp_strip_ranges, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, w, strip_rng, nwaves_d);
+    hipLaunchKernelGGL(k_mplp_emit_deep, dim3((unsigned)((nwaves_d + 3) / 4)), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, (const int64_t *)strip_rng, out, only_above);
+}
+
+// deep_mode 0: lane-per-column kernel only; 1: every strip through k_mplp_emit_deep; 2 (tile kernel only): the 64-column groups whose
+// rows exceed tile_cap go through k_mplp_emit_deep, the rest through k_mplp_emit_tile
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
-                          char *out, uint32_t lds_cap, int64_t *strip_rng)
+                          char *out, uint32_t lds_cap, int64_t *strip_rng, uint32_t tile_cap, int deep_mode, bool legacy)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
-    if (strip_rng && sta_mplp_has_fast_path(p) && colinfo) {
-        const int64_t nwaves_d = sta_mplp_deep_strips(ncols);
-        const int64_t nt = nwaves_d * w.nfiles;
-        hipLaunchKernelGGL(k_mplp_strip_ranges, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, w, strip_rng, nwaves_d);
-        hipLaunchKernelGGL(k_mplp_emit_deep, dim3((unsigned)((nwaves_d + 3) / 4)), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, (const int64_t *)strip_rng, out);
+    const bool fast = sta_mplp_has_fast_path(p) && colinfo;
+    if (fast && strip_rng && deep_mode == 1) { launch_deep(s, w, p, offs, colinfo, out, strip_rng, 0u); return; }
+    int64_t nwaves = (ncols + 63) / 64;
+    if (fast && !legacy && sta_mplp_tile_ok(p)) {
+        const uint32_t slice = (tile_cap + 48 + 15) & ~15u;       // must match k_mplp_emit_tile
+        const size_t lds = (size_t)TILE_WAVES * (slice + TILE_LDS_BYTES);
+        hipLaunchKernelGGL(k_mplp_emit_tile, dim3((unsigned)((nwaves + TILE_WAVES - 1) / TILE_WAVES)), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, out, tile_cap);
+        if (deep_mode == 2 && strip_rng) launch_deep(s, w, p, offs, colinfo, out, strip_rng, tile_cap);
         return;
     }
     uint32_t slice = (lds_cap + 16 + 15) & ~15u;
     // waves per workgroup so that the workgroup's LDS (one slice per wave) stays within 64 KiB
     int wpb = 4 * slice <= 65536 ? 4 : (2 * slice <= 65536 ? 2 : 1);
-    int64_t nwaves = (ncols + 63) / 64;
     int64_t nb = (nwaves + wpb - 1) / wpb;
-    if (sta_mplp_has_fast_path(p) && colinfo) {
+    if (fast) {
         uint32_t fslice = (lds_cap + 48 + 15) & ~15u;      // must match k_mplp_emit_fast
         int fw = 4 * fslice <= 65536 ? 4 : (2 * fslice <= 65536 ? 2 : 1);
         int64_t fnb = (nwaves + fw - 1) / fw;
@@ -1116,4 +1065,6 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
 int64_t sta_mplp_deep_strips(int64_t ncols) { return (ncols + DEEP_STRIP - 1) / DEEP_STRIP; }
 
 // no --output-extra / -O / -s columns: the window takes the fast kernel pair
+// the tile kernels compare four quality bytes per word against -Q: it has to fit seven bits
+bool sta_mplp_tile_ok(const sta_mplp_params &p) { return p.min_baseQ <= 127; }
 bool sta_mplp_has_fast_path(const sta_mplp_params &p) { return !((uint32_t)p.flag & (EXTRA_MASK | STA_MPLP_OUTPUT_MODS)) && p.n_tags <= 0; }

@@ -63,7 +63,7 @@ def test_bulk_entry_through_the_c_abi(oracle_bin, mode):
     import samtools_amd as sa
     import bench
     n_cols = 1 << 18
-    inp = bench.synth_inputs(30, n_cols)
+    inp = bench.synth_inputs("consensus30", n_cols)
     try:
         dev = torch.device("cuda", 0)
         eng = sa.Engine(0, torch.cuda.current_stream().cuda_stream)

@@ -3,7 +3,9 @@
 // A sharded run (samtools_amd/shard.py) gathers every rank's block of text on rank 0; the drivers' writer thread
 // appends to a FILE*, so the capture form gives it a memory stream and returns the buffer: no temporary file between the
 // driver and the gather.  The reference has no counterpart (its column loop prints as it goes, bam_plcmd.c:663-868).
+#include "driver_pipeline.h"
 #include "driver_shard.h"
+#include <hip/hip_runtime.h>
 #include "../../include/samtools_amd.h"
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +15,41 @@ namespace sta {
 static thread_local FILE *t_capture = nullptr;
 FILE *driver_default_out() { return t_capture ? t_capture : stdout; }
 bool driver_out_is_borrowed(FILE *f) { return f == stdout || (t_capture && f == t_capture); }
+
+int dev_threads_from_env()
+{
+    const char *e = getenv("STA_DEV_THREADS");
+    const int n = e ? atoi(e) : 2;
+    return n < 1 ? 1 : (n > 4 ? 4 : n);
+}
+size_t pipe_slots_from_env(int n_dev)
+{
+    const char *ns = getenv("STA_PIPE_SLOTS");
+    return ns && atoi(ns) > 0 ? (size_t)atoi(ns) : (size_t)n_dev + 2;
+}
+int DevEngines::create(int device)
+{
+    const int n = dev_threads_from_env();
+    for (int d = 0; d < n; ++d) {
+        hipStream_t st = nullptr;
+        if (n > 1) {
+            if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; if (d > 0) break; }
+        }
+        sta_engine *e = nullptr;
+        const int rc = sta_engine_create(&e, device, st);
+        if (rc != STA_OK) { if (st) hipStreamDestroy(st); if (d == 0) return rc; break; }
+        eng.push_back(e); streams.push_back(st);
+    }
+    return STA_OK;
+}
+void DevEngines::destroy()
+{
+    for (size_t d = 0; d < eng.size(); ++d) {
+        sta_engine_destroy(eng[d]);
+        if (streams[d]) hipStreamDestroy((hipStream_t)streams[d]);
+    }
+    eng.clear(); streams.clear();
+}
 }  // namespace sta
 
 extern "C" int sta_main_capture(int argc, char **argv, char **text, uint64_t *n_bytes)

@@ -25,7 +25,7 @@ namespace {
 
 struct DRunner {
     sta_depth_params p{};
-    sta_engine *eng = nullptr;
+    DevEngines devs;                    // one engine per device thread
     std::vector<std::unique_ptr<AlnReader>> readers;
     const Header *h = nullptr;
     FILE *out = driver_default_out();
@@ -33,7 +33,7 @@ struct DRunner {
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
     int64_t window_cols = 1 << 20, max_reads = 4 << 20;
     std::unique_ptr<WinPipe> pipe;      // producer (this thread) -> device thread -> writer thread (driver_pipeline.h)
-    std::vector<StagedFile> no_reads;   // read-less windows; device thread only
+    std::vector<std::vector<StagedFile>> no_reads_d;   // per engine: read-less windows; its device thread only
     Shard shard;                        // STA_SHARD=rank/world: this rank's block of the columns (driver_shard.h)
     std::vector<int64_t> lin0;          // linear coordinate of every contig's first column (no region)
 
@@ -43,8 +43,10 @@ struct DRunner {
     }
 
     // device stage of one window (device thread): H2D, the depth kernels, D2H of the rows
-    int device_stage(WinJob &j)
+    int device_stage(WinJob &j, int d)
     {
+        sta_engine *eng = devs.eng[(size_t)d];
+        std::vector<StagedFile> &no_reads = no_reads_d[(size_t)d];
         size_t nf = readers.size();
         std::vector<sta_reads> views(nf);
         if (!j.have_reads && no_reads.size() != nf) { no_reads.assign(nf, StagedFile()); for (auto &e : no_reads) e.finish(); }
@@ -267,20 +269,21 @@ extern "C" int sta_main_depth(int argc, char **argv)
         for (auto &fn : fns) fprintf(run.out, "\t%s", fn.c_str());
         fputc('\n', run.out);
     }
-    if (sta_engine_create(&run.eng, getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0, nullptr) != STA_OK) {
+    const int erc = run.devs.create(getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0);
+    run.no_reads_d.resize((size_t)run.devs.n());
+    if (erc != STA_OK) {
         fprintf(stderr, "samtools depth: no usable HIP device (the MI355X engine has no CPU fallback)\n");
         return 1;
     }
     fflush(run.out);                  // the header line: the writer thread owns the stream from here on
     int ret;
     {
-        const char *ns = getenv("STA_PIPE_SLOTS");
-        run.pipe.reset(new WinPipe(ns && atoi(ns) > 0 ? (size_t)atoi(ns) : 3, [&run](WinJob &j) { return run.device_stage(j); }, run.out, "samtools depth: failed to write the output\n"));
+        run.pipe.reset(new WinPipe(pipe_slots_from_env(run.devs.n()), [&run](WinJob &j, int d) { return run.device_stage(j, d); }, run.out, "samtools depth: failed to write the output\n", run.devs.n()));
         ret = run.run();
         run.pipe.reset();
     }
     fflush(run.out);
     if (!driver_out_is_borrowed(run.out)) fclose(run.out);
-    sta_engine_destroy(run.eng);
+    run.devs.destroy();
     return ret;
 }

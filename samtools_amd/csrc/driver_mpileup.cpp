@@ -65,18 +65,18 @@ struct Samples {
 
 struct Runner {
     Conf &conf;
-    sta_engine *eng = nullptr;
+    DevEngines devs;                                  // one engine per device thread
     std::vector<std::unique_ptr<AlnReader>> readers;
     const Header *h = nullptr;
     FILE *out = driver_default_out();
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
     std::unique_ptr<WinPipe> pipe;                    // producer (this thread) -> device thread -> writer thread
-    std::vector<StagedFile> no_reads;                 // read-less windows (zero-depth rows); device thread only
+    std::vector<std::vector<StagedFile>> no_reads_d;  // per engine: read-less windows (zero-depth rows); its device thread only
     std::vector<std::vector<char>> cap_dropped;      // per file: reads of the last window that the -d cap dropped
     // host side of mplp_get_ref (the pump's lookahead asks which contig's FASTA is "loaded" and how long it is); producer thread
     int loaded_ref_tid = -2;
     int64_t loaded_ref_len = INT64_MAX;               // length of the FASTA contig (INT64_MAX: none, no length filter)
-    int dev_ref_tid = -2;                             // contig whose sequence is in HBM; device thread only
+    std::vector<int> dev_ref_tid;                     // per engine: contig whose sequence is in its HBM; its device thread only
     Shard shard;                                      // STA_SHARD=rank/world: this rank's block of the columns (driver_shard.h)
     std::vector<int64_t> lin0;                        // linear coordinate of every contig's first column (no region)
 
@@ -91,12 +91,14 @@ struct Runner {
     }
 
     // device stage of one window (device thread): reference, H2D, plan, emit, D2H of the text
-    int device_stage(WinJob &j)
+    int device_stage(WinJob &j, int d)
     {
+        sta_engine *eng = devs.eng[(size_t)d];
+        std::vector<StagedFile> &no_reads = no_reads_d[(size_t)d];
         const size_t nf = readers.size();
-        if (conf.fai && j.tid != dev_ref_tid) {
+        if (conf.fai && j.tid != dev_ref_tid[(size_t)d]) {
             sta_clear_references(eng);
-            dev_ref_tid = j.tid;
+            dev_ref_tid[(size_t)d] = j.tid;
             const std::string *s = conf.fai->fetch(h->names[(size_t)j.tid]);
             if (s && sta_set_reference(eng, j.tid, s->data(), (int64_t)s->size(), STA_MEM_HOST) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
         }
@@ -486,20 +488,20 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     if (!mp.max_depth) { mp.max_depth = INT_MAX; fprintf(stderr, "[mpileup] Max depth set to maximum value (%d)\n", INT_MAX); }
     else if ((long long)mp.max_depth * (long long)fns.size() > 1 << 20) fprintf(stderr, "[mpileup] Combined max depth is above 1M. Potential memory hog!\n");
 
-    int rc = sta_engine_create(&run.eng, getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0, nullptr);
+    int rc = run.devs.create(getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0);
+    run.dev_ref_tid.assign((size_t)run.devs.n(), -2); run.no_reads_d.resize((size_t)run.devs.n());
     if (rc != STA_OK) {
         fprintf(stderr, "samtools mpileup: no usable HIP device (the MI355X engine has no CPU fallback)\n");
         return 1;
     }
     int ret;
     {
-        const char *ns = getenv("STA_PIPE_SLOTS");
-        run.pipe.reset(new WinPipe(ns && atoi(ns) > 0 ? (size_t)atoi(ns) : 3, [&run](WinJob &j) { return run.device_stage(j); }, run.out, "Failed to write pileup data.\n"));
+        run.pipe.reset(new WinPipe(pipe_slots_from_env(run.devs.n()), [&run](WinJob &j, int d) { return run.device_stage(j, d); }, run.out, "Failed to write pileup data.\n", run.devs.n()));
         ret = run.run();
         run.pipe.reset();                 // joins the device and writer threads (everything is written)
     }
     fflush(run.out);
     if (!driver_out_is_borrowed(run.out)) fclose(run.out);
-    sta_engine_destroy(run.eng);
+    run.devs.destroy();
     return ret;
 }

@@ -43,25 +43,30 @@ struct WinJob {
 
 class WinPipe {
 public:
-    WinPipe(size_t n_slots, std::function<int(WinJob &)> device_fn, FILE *out, const char *write_error_text)
-        : fn_(std::move(device_fn)), out_(out), werr_(write_error_text), slots_(n_slots < 3 ? 3 : n_slots)
+    // n_dev device threads (each drives its own engine on its own stream: device_fn's second argument says which), so that the
+    // H2D / D2H copies of one window overlap the kernels of another; the writer keeps submission order
+    WinPipe(size_t n_slots, std::function<int(WinJob &, int)> device_fn, FILE *out, const char *write_error_text, int n_dev = 1)
+        : fn_(std::move(device_fn)), out_(out), werr_(write_error_text), slots_(n_slots < (size_t)(n_dev < 1 ? 1 : n_dev) + 2 ? (size_t)(n_dev < 1 ? 1 : n_dev) + 2 : n_slots)
     {
         // (at least three slots: the single `-a` path holds one job while it acquires the next; with one slot it would wait for itself)
         timing_ = getenv("STA_DRIVER_TIMING") != nullptr;
         t0_ = now();
-        dev_ = std::thread([this] { device_loop(); });
+        if (n_dev < 1) n_dev = 1;
+        t_devn_.assign((size_t)n_dev, 0.0);
+        for (int d = 0; d < n_dev; ++d) dev_.emplace_back([this, d] { device_loop(d); });
         wr_ = std::thread([this] { writer_loop(); });
     }
     ~WinPipe()
     {
         { std::lock_guard<std::mutex> g(m_); stop_ = true; }
         cv_.notify_all();
-        if (dev_.joinable()) dev_.join();
+        for (auto &t : dev_) if (t.joinable()) t.join();
         if (wr_.joinable()) wr_.join();
+        for (double x : t_devn_) t_dev_ = x > t_dev_ ? x : t_dev_;
         if (timing_)
             fprintf(stderr, "[driver timing] wall %.3f s | producer: fill+stage %.3f s (of it: waiting for the decode threads %.3f s, copying slices %.3f s), "
-                            "waiting for a slot %.3f s, waiting for results %.3f s | device thread busy %.3f s | writer busy %.3f s | %llu windows\n",
-                    now() - t0_, t_fill_, t_decode_wait_, t_stage_copy_, t_slot_, t_wait_, t_dev_, t_wr_, (unsigned long long)n_jobs_);
+                            "waiting for a slot %.3f s, waiting for results %.3f s | device thread busy %.3f s (the busiest of %d) | writer busy %.3f s | %llu windows\n",
+                    now() - t0_, t_fill_, t_decode_wait_, t_stage_copy_, t_slot_, t_wait_, t_dev_, (int)t_devn_.size(), t_wr_, (unsigned long long)n_jobs_);
     }
     // a slot the producer may fill (blocks while all are in flight)
     WinJob *acquire()
@@ -103,7 +108,7 @@ public:
     static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 private:
-    void device_loop()
+    void device_loop(int d)
     {
         for (;;) {
             WinJob *j = nullptr;
@@ -115,8 +120,8 @@ private:
             }
             const double a = now();
             const int prior = err_.load();
-            int rc = prior ? prior : fn_(*j);        // after an error the remaining jobs only drain
-            t_dev_ += now() - a;
+            int rc = prior ? prior : fn_(*j, d);     // after an error the remaining jobs only drain
+            t_devn_[(size_t)d] += now() - a;
             { std::lock_guard<std::mutex> g(m_); j->rc = rc; if (rc < 0 && !err_.load()) err_ = rc; j->state = 2; }
             cv_.notify_all();
         }
@@ -147,15 +152,28 @@ private:
         }
     }
 
-    std::function<int(WinJob &)> fn_;
+    std::function<int(WinJob &, int)> fn_;
     FILE *out_; const char *werr_;
     std::deque<WinJob> slots_;
     std::deque<WinJob *> devq_, order_;
     std::mutex m_; std::condition_variable cv_;
-    std::thread dev_, wr_;
+    std::vector<std::thread> dev_; std::thread wr_;
+    std::vector<double> t_devn_;
     bool stop_ = false; std::atomic<int> err_{0};      // written under m_, read by the stage threads outside it
     bool timing_ = false; double t0_ = 0, t_decode_wait_ = 0, t_stage_copy_ = 0, t_fill_ = 0, t_slot_ = 0, t_wait_ = 0, t_dev_ = 0, t_wr_ = 0; unsigned long long n_jobs_ = 0;
 };
+
+// The device side of a driver: n engines (default 2, STA_DEV_THREADS), each on its own non-blocking stream, one per device thread
+// of the WinPipe.  While one engine runs the kernels of a window the other copies its window in or its text out.
+struct DevEngines {
+    std::vector<sta_engine *> eng;
+    std::vector<void *> streams;
+    int create(int device);              // 0, or the sta_engine_create error
+    void destroy();
+    int n() const { return (int)eng.size(); }
+};
+int dev_threads_from_env();
+size_t pipe_slots_from_env(int n_dev);
 
 // Can the -d cap (bam_plp_push: a read is dropped when more than max_depth reads are live at its start) possibly trigger for these
 // staged reads?  Conservative host-side bound: at a read's start at most the reads starting within the longest reference span

@@ -66,7 +66,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, strip_rng, inf_comp, inf_blocks, inf_out, inf_status, inf_bad, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, inf_comp, inf_blocks, inf_out, inf_status, inf_bad, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
     DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
@@ -83,7 +83,9 @@ struct sta_engine {
     StaCounters ctr_h{};
     uint64_t out_bytes = 0;
     uint32_t lds_cap = 0;
+    bool have_wfirst = false;          // the plan built the per-group read index of the tile kernels
     bool plp_legacy = false;           // STA_PLP_TILE=0: the lane-per-column kernel pair instead of the tile kernels (A/B measurements)
+    bool plp_legacy_len = false;       // STA_PLP_TILE=3: only the measuring pass of the old pair (2: only its emit pass)
     void *last_out = nullptr;
     void *inf_last = nullptr; uint64_t inf_bytes = 0;      // output of the last sta_bgzf_inflate
     // profiling
@@ -176,7 +178,7 @@ int sta_engine_create(sta_engine **out, int device, void *hip_stream)
     sta_engine *e = new sta_engine();
     e->device = device;
     e->stream = (hipStream_t)hip_stream;   // nullptr = default stream
-    if (const char *ev = getenv("STA_PLP_TILE")) e->plp_legacy = atoi(ev) == 0;
+    if (const char *ev = getenv("STA_PLP_TILE")) { e->plp_legacy = atoi(ev) == 0 || atoi(ev) == 2; e->plp_legacy_len = atoi(ev) == 0 || atoi(ev) == 3; }
     *out = e;
     return STA_OK;
 }
@@ -188,7 +190,7 @@ void sta_engine_destroy(sta_engine *e)
     hipStreamSynchronize(e->stream);
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
-    DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->strip_rng, &e->inf_comp, &e->inf_blocks, &e->inf_out, &e->inf_status, &e->inf_bad, &e->offs, &e->scan_tmp, &e->counters, &e->table,
+    DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->wfirst, &e->strip_rng, &e->inf_comp, &e->inf_blocks, &e->inf_out, &e->inf_status, &e->inf_bad, &e->offs, &e->scan_tmp, &e->counters, &e->table,
                       &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
                       &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
     for (DevBuf *b : all) b->release();
@@ -506,8 +508,17 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
     } else {
         int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
         if (e->colinfo.ensure((size_t)(ncols > 0 ? ncols : 1) * (size_t)(nf > 0 ? nf : 1) * 8 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(column info) failed");
+        const bool tile = sta_mplp_has_fast_path(*p) && sta_mplp_tile_ok(*p) && !(e->plp_legacy && e->plp_legacy_len);
+        bool small = true;
+        for (int f = 0; f < nf; ++f) small = small && e->files_h[(size_t)f].n < 0xffffffffll;
+        e->have_wfirst = tile && small;
+        if (e->have_wfirst) {
+            if (e->wfirst.ensure((size_t)((ncols > 0 ? ncols : 1) / 64 + 2) * (size_t)(nf > 0 ? nf : 1) * 4 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(read index) failed");
+            ProfScope ps(e, "wave_first");
+            sta_launch_wave_first(s, e->wd, (uint32_t *)e->wfirst.p);
+        }
         ProfScope ps(e, "mplp_len");
-        sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr, e->plp_legacy);
+        sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr, e->plp_legacy_len);
     }
     return STA_OK;
 }
@@ -625,21 +636,26 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     if (e->out_bytes == 0) return STA_OK;
     // Which kernel writes which columns (windows without extra columns):
     //  * deep windows (mean depth of the data columns >= 100): every strip through the read-major kernel k_mplp_emit_deep;
-    //  * otherwise k_mplp_emit_tile with an LDS slice of 1.5 x the mean bytes of a wave's 64 rows (at most 12 KiB: occupancy),
-    //    and the 64-column groups whose rows exceed it -- a deep amplicon inside an ordinary window -- through k_mplp_emit_deep.
+    //  * otherwise k_mplp_emit_tile with an LDS text slice that holds the largest wave's 64 rows -- up to 12 KiB; beyond that (a
+    //    deep amplicon inside an ordinary window) the slice is 1.5 x the mean bytes of a wave's rows and the 64-column groups whose
+    //    rows exceed it go through k_mplp_emit_deep (a second launch over the strips, most of which return at once: ~0.06 ms).
     // STA_EMIT_DEEP=0 / 1 forces the whole-window choice (tests).
     const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
     bool deep = e->ctr_h.n_data_cols > 0 && e->ctr_h.piled_bases / e->ctr_h.n_data_cols >= 100;
     if (const char *ev = getenv("STA_EMIT_DEEP")) deep = atoi(ev) != 0;
     const uint64_t mw = e->ctr_h.max_wave_bytes;
-    uint64_t tc = e->ctr_h.n_data_cols ? (e->out_bytes * 96) / e->ctr_h.n_data_cols : 1024;       // 1.5 x 64 x mean row
-    tc = (tc + 255) & ~255ull;
-    if (tc > 12288) tc = 12288;
-    if (tc > ((mw + 255) & ~255ull)) tc = (mw + 255) & ~255ull;
+    static const uint64_t cap_pct = [] { const char *ev = getenv("STA_TILE_CAP_PCT"); const int v = ev ? atoi(ev) : 150; return (uint64_t)(v < 100 ? 100 : v > 400 ? 400 : v); }();      // experiment knob
+    uint64_t tc = (mw + 255) & ~255ull;
+    if (tc > 12288 || getenv("STA_TILE_CAP_PCT")) {
+        tc = e->ctr_h.n_data_cols ? (e->out_bytes * 64 * cap_pct / 100) / e->ctr_h.n_data_cols : 1024;
+        tc = (tc + 255) & ~255ull;
+        if (tc > 12288) tc = 12288;
+        if (tc > ((mw + 255) & ~255ull)) tc = (mw + 255) & ~255ull;
+    }
     if (tc < 1024) tc = 1024;
     const uint32_t tile_cap = (uint32_t)tc;
     int deep_mode = deep ? 1 : 0;
-    if (!deep && !e->plp_legacy && mw > tile_cap) deep_mode = 2;
+    if (!deep && !e->plp_legacy && e->have_wfirst && mw > tile_cap) deep_mode = 2;
     if (e->plp_legacy && !deep) deep_mode = 0;
     if (deep_mode) {
         if (e->strip_rng.ensure((size_t)sta_mplp_deep_strips(ncols > 0 ? ncols : 1) * (size_t)(e->wd.nfiles > 0 ? e->wd.nfiles : 1) * 16 + 16))
@@ -647,7 +663,7 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     }
     ProfScope ps(e, deep_mode == 1 ? "mplp_emit_deep" : "mplp_emit");
     sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap, deep_mode ? (int64_t *)e->strip_rng.p : nullptr,
-                         tile_cap, deep_mode, e->plp_legacy);
+                         tile_cap, deep_mode, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr, e->plp_legacy);
     return STA_OK;
 }
 

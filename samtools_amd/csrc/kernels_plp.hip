@@ -846,7 +846,38 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 // Tile kernels (step functions and the layout: plp_tile.h).  They replace k_mplp_len_fast / k_mplp_emit_fast for windows without
 // --output-extra / -O / -s columns; waves whose rows exceed the LDS slice are left to k_mplp_emit_deep.
 
-__global__ void __launch_bounds__(LEN_THREADS) k_mplp_len_rm(StaWinDev W, MplpDevPar P, uint32_t *line_len, uint2 *colinfo)
+// wfirst[f][w] = first read of file f that starts at or beyond column col_beg + 64 w (w = 0 .. nwaves): one thread per entry, a
+// binary search each.  The tile kernels find their reads from it with one more coalesced load instead of two 64-ary searches
+// (eight dependent loads at the head of every wave).
+__global__ void __launch_bounds__(256) k_wave_first(StaWinDev W, uint32_t *__restrict__ wfirst, int64_t nwaves)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (nwaves + 1) * W.nfiles) return;
+    const int f = (int)(i / (nwaves + 1)); const int64_t w = i - (int64_t)f * (nwaves + 1);
+    const StaReadsDev &R = W.files[f];
+    const int64_t key = (int64_t)W.col_beg + 64 * w;
+    int64_t lo = 0, hi = R.n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)R.pos[mid] >= key) hi = mid; else lo = mid + 1; }
+    wfirst[i] = (uint32_t)lo;
+}
+
+// reads that can touch columns [p0, ...) of the 64-column groups [w_lo, w_hi): a superset in file order.  rhi = first read starting
+// beyond them; rlo: maxend (prefix maximum of the read ends) is monotone, so the reads before `start` that still reach p0 are a
+// suffix of them -- counted on the 64 reads before `start` (one coalesced load), a search only when all 64 do.
+__device__ __forceinline__ void wave_range_indexed(const StaReadsDev &R, const uint32_t *__restrict__ wf, int64_t w_lo, int64_t w_hi, int p0, int64_t &rlo, int64_t &rhi)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t start = wf[w_lo];
+    rhi = wf[w_hi];
+    const int64_t i = start - 64 + lane;
+    const bool gt = i >= 0 && R.maxend[i] > p0;
+    const int cnt = __popcll(__ballot(gt));
+    if (cnt == 64 && start > 64) rlo = wave_upper_bound(R.maxend, start - 64, p0);
+    else rlo = start - cnt;
+    if (rlo > rhi) rlo = rhi;
+}
+
+__global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THREADS), amdgpu_waves_per_eu(6, 8))) k_mplp_len_rm(StaWinDev W, MplpDevPar P, uint32_t *line_len, uint2 *colinfo, const uint32_t *__restrict__ wfirst)
 {
     __shared__ LenLds L;
     const int t = threadIdx.x;
@@ -861,9 +892,10 @@ __global__ void __launch_bounds__(LEN_THREADS) k_mplp_len_rm(StaWinDev W, MplpDe
     for (int f = 0; f < W.nfiles; ++f) {
         const StaReadsDev &R = W.files[f];
         len_clear(L, t);
-        if (t < 64) {                                       // the first wave finds the tile's reads (two 64-ary searches)
+        if (t < 64) {                                       // the first wave finds the tile's reads
             int64_t rlo, rhi;
-            wave_read_range(R, t0, t1 - 1, rlo, rhi);
+            const int64_t nwaves = (ncols + 63) >> 6, w_lo = c0 >> 6, w_hi = w_lo + (LEN_TC >> 6) < nwaves ? w_lo + (LEN_TC >> 6) : nwaves;
+            wave_range_indexed(R, wfirst + (int64_t)f * (nwaves + 1), w_lo, w_hi, t0, rlo, rhi);
             if (t == 0) { L.rlo = rlo; L.rhi = rhi; }
         }
         __syncthreads();
@@ -912,7 +944,7 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
-                                                                    char *out, uint32_t lds_cap)
+                                                                    const uint32_t *__restrict__ wfirst, char *out, uint32_t lds_cap)
 {
     const int wid = threadIdx.x >> 6;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -949,7 +981,8 @@ __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W,
     for (int f = 0; f < W.nfiles; ++f) {
         const StaReadsDev &R = W.files[f];
         int64_t rlo, rhi;
-        wave_read_range(R, p0, plast, rlo, rhi);
+        const int64_t nwaves = (ncols + 63) >> 6;
+        wave_range_indexed(R, wfirst + (int64_t)f * (nwaves + 1), wave, wave + 1, p0, rlo, rhi);
         tile_file_head(st, lane, exists ? colinfo[(int64_t)f * ncols + c0 + lane] : make_uint2(0u, 0u), dump);
         const auto g_info = GPTR(uint32_t, R.info); const auto g_pos = GPTR(int32_t, R.pos); const auto g_end = GPTR(int32_t, R.end);
         const auto g_b8 = GPTR(uint32_t, R.base_off8);
@@ -968,12 +1001,14 @@ __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W,
                 const int ns = nlive - first < TILE_SLOTS ? nlive - first : TILE_SLOTS;
                 if (live && rank >= first && rank < first + TILE_SLOTS) tile_set_slot(T, rank - first, lane, v_info, v_pos, v_end, v_b8);
                 wave_lds_sync();
-                tile_phase1(T, lane, ns, R, P, p0, has_ref);
+                const bool slot_simple = tile_phase1(T, lane, ns, R, P, p0, has_ref);
+                const unsigned long long sm = __ballot(slot_simple && (lane & 3) == 0);      // bit 4 s: slot s is a one-op read
                 wave_lds_sync();
-                for (int s = 0; s < ns; ++s) {
-                    const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.s_info[s]);
-                    if (info & RI_SIMPLE) tile_phase2_row(T, s, st.col, st.cur_s, st.cur_q);
+                for (int s = 0; s < ns;) {
+                    if (s + 4 <= ns && ((sm >> (4 * s)) & 0x1111ull) == 0x1111ull) { tile_phase2_rows4(T, s, st.col, st.cur_s, st.cur_q); s += 4; continue; }
+                    if ((sm >> (4 * s)) & 1ull) tile_phase2_row(T, s, st.col, st.cur_s, st.cur_q);
                     else tile_phase2_general(T, s, st, R, W, P, b0, p);       // (the read is the same for every lane)
+                    ++s;
                 }
                 wave_lds_sync();                              // the tile rows are rewritten by the next round
             }
@@ -1005,14 +1040,22 @@ static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
     return d;
 }
 
-void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr, bool legacy)
+void sta_launch_wave_first(hipStream_t s, const StaWinDev &w, uint32_t *wfirst)
+{
+    const int64_t ncols = (int64_t)w.col_end - w.col_beg;
+    if (ncols <= 0 || w.nfiles <= 0) return;
+    const int64_t nwaves = (ncols + 63) / 64, nt = (nwaves + 1) * w.nfiles;
+    hipLaunchKernelGGL(k_wave_first, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, w, wfirst, nwaves);
+}
+
+void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr, const uint32_t *wfirst, bool legacy)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
     int64_t nb = (ncols + 255) / 256;
     if (sta_mplp_has_fast_path(p) && colinfo) {
-        if (!legacy && sta_mplp_tile_ok(p)) {
-            hipLaunchKernelGGL(k_mplp_len_rm, dim3((unsigned)((ncols + LEN_TC - 1) / LEN_TC)), dim3(LEN_THREADS), 0, s, w, make_par(p, w.tlen), line_len, colinfo);
+        if (!legacy && wfirst && sta_mplp_tile_ok(p)) {
+            hipLaunchKernelGGL(k_mplp_len_rm, dim3((unsigned)((ncols + LEN_TC - 1) / LEN_TC)), dim3(LEN_THREADS), 0, s, w, make_par(p, w.tlen), line_len, colinfo, wfirst);
             return;
         }
         hipLaunchKernelGGL(k_mplp_len_fast, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, colinfo, ctr);
@@ -1034,17 +1077,17 @@ static void launch_deep(hipStream_t s, const StaWinDev &w, const sta_mplp_params
 // deep_mode 0: lane-per-column kernel only; 1: every strip through k_mplp_emit_deep; 2 (tile kernel only): the 64-column groups whose
 // rows exceed tile_cap go through k_mplp_emit_deep, the rest through k_mplp_emit_tile
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
-                          char *out, uint32_t lds_cap, int64_t *strip_rng, uint32_t tile_cap, int deep_mode, bool legacy)
+                          char *out, uint32_t lds_cap, int64_t *strip_rng, uint32_t tile_cap, int deep_mode, const uint32_t *wfirst, bool legacy)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
     const bool fast = sta_mplp_has_fast_path(p) && colinfo;
     if (fast && strip_rng && deep_mode == 1) { launch_deep(s, w, p, offs, colinfo, out, strip_rng, 0u); return; }
     int64_t nwaves = (ncols + 63) / 64;
-    if (fast && !legacy && sta_mplp_tile_ok(p)) {
+    if (fast && !legacy && wfirst && sta_mplp_tile_ok(p)) {
         const uint32_t slice = (tile_cap + 48 + 15) & ~15u;       // must match k_mplp_emit_tile
         const size_t lds = (size_t)TILE_WAVES * (slice + TILE_LDS_BYTES);
-        hipLaunchKernelGGL(k_mplp_emit_tile, dim3((unsigned)((nwaves + TILE_WAVES - 1) / TILE_WAVES)), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, out, tile_cap);
+        hipLaunchKernelGGL(k_mplp_emit_tile, dim3((unsigned)((nwaves + TILE_WAVES - 1) / TILE_WAVES)), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, wfirst, out, tile_cap);
         if (deep_mode == 2 && strip_rng) launch_deep(s, w, p, offs, colinfo, out, strip_rng, tile_cap);
         return;
     }

@@ -95,15 +95,22 @@ PLP_HD void tile_convert16(const uint32_t q4[4], const uint32_t s4[3], int qb, i
     uint32_t qs[4];
     deep_shift_quals(q4, d0, qs);
     const uint64_t nib = deep_shift_bases(s4, qb, d0, rbpack, has_ref);
-    const int e0 = d0 + ncov;
+    const uint32_t vm16 = ((1u << (d0 + ncov)) - 1u) & ~((1u << d0) - 1u);          // bit k: chunk column k is covered (d0 + ncov <= 16)
+    // quality characters: qualities below 64 (everything a sequencer writes) take one packed add; anything else the general form
+    const bool plain_q = ((qs[0] | qs[1] | qs[2] | qs[3]) & 0xc0c0c0c0u) == 0u;
+    const bool all_plain = !PLP_WAVE_ANY(!plain_q);
+    const int hsel = head_col >> 2, tsel = tail_col >> 2;                          // (-1 >> 2 = -1: no word)
+    const uint32_t hbit = 0x80u << (8 * (head_col & 3)), tbit = 0x80u << (8 * (tail_col & 3));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const uint32_t valid = swar_byte_range(d0 - 4 * j, e0 - 4 * j);
-        const uint32_t pass = swar_expand80(swar_ge_u8(qs[j], minq4)) & valid;
-        uint32_t qc = swar_qual_chars(qs[j]);
+        // bit i of the nibble -> bit 7 of byte i: the products of the three low bits with 2^7, 2^14, 2^21 fall on distinct positions
+        const uint32_t x = (vm16 >> (4 * j)) & 15u;
+        const uint32_t valid = ((x * 0x204080u) | (x << 28)) & 0x80808080u;
+        const uint32_t pass = swar_expand80(swar_ge_u8(qs[j], minq4) & valid);
+        uint32_t qc = all_plain ? qs[j] + 0x21212121u : swar_qual_chars(qs[j]);
         uint32_t bc = swar_base_chars(swar_spread_nibbles(nib, j), rev);
-        if ((head_col >> 2) == j) qc |= 0x80u << (8 * (head_col & 3));     // (head_col = -1: -1 >> 2 = -1, never equal)
-        if ((tail_col >> 2) == j) bc |= 0x80u << (8 * (tail_col & 3));
+        qc |= hsel == j ? hbit : 0u;
+        bc |= tsel == j ? tbit : 0u;
         tq[j] = qc & pass;
         tb[j] = bc & pass;
     }
@@ -357,15 +364,18 @@ PLP_HD void tile_refpack(TileLds &T, int k)
 }
 
 // phase 1: lane = (slot, chunk): the round's read `slot` (of nslots) in tile columns [16 chunk, 16 chunk + 16)
-PLP_HD void tile_phase1(TileLds &T, int lane, int nslots, const StaReadsDev &R, const MplpDevPar &P, int p0, bool has_ref)
+// Returns whether the lane's slot holds a one-op read (phase 2 walks its tile row) -- the kernel ballots it into a slot mask.
+PLP_HD bool tile_phase1(TileLds &T, int lane, int nslots, const StaReadsDev &R, const MplpDevPar &P, int p0, bool has_ref)
 {
     const int slot = lane >> 2, k = lane & 3;
     uint32_t tb[4] = { 0, 0, 0, 0 }, tq[4] = { 0, 0, 0, 0 };
     const int idx = slot;
+    bool simple = false;
     if (idx < nslots) {
         const uint32_t info = T.s_info[idx];
         const int pos = T.s_pos[idx], end = T.s_end[idx];
         if (info & RI_SIMPLE) {
+            simple = true;
             const int c_lo = 16 * k;
             const int a = pos - p0 > c_lo ? pos - p0 : c_lo, b = end - p0 < c_lo + 16 ? end - p0 : c_lo + 16;
             if (b > a) {
@@ -390,18 +400,19 @@ PLP_HD void tile_phase1(TileLds &T, int lane, int nslots, const StaReadsDev &R, 
     }
     __builtin_memcpy(&T.tb[slot * TILE_STRIDE + 16 * k], tb, 16);
     __builtin_memcpy(&T.tq[slot * TILE_STRIDE + 16 * k], tq, 16);
+    return simple;
 }
 
-// phase 2, one tile row: the lane of column `col` (TILE_ZERO_COL for a lane without entries) appends what the row shows there.
+// phase 2: the lane of column `col` (TILE_ZERO_COL for a lane without entries) appends what a tile row shows there.
 // cur_s / cur_q: the lane's cursors into the wave's text (base string, quality string); a lane that appends nothing still
 // writes at its cursors without advancing them -- the bytes are overwritten by its next real write or by the separators.
-PLP_HD void tile_phase2_row(const TileLds &T, int slot, int col, uint32_t &cur_s, uint32_t &cur_q)
+// b, q: the row's tile bytes of the column; mq: the row's '^' character.
+PLP_HD void tile_phase2_apply(uint32_t b, uint32_t q, uint32_t mq, uint32_t &cur_s, uint32_t &cur_q)
 {
-    const uint32_t b = T.tb[slot * TILE_STRIDE + col], q = T.tq[slot * TILE_STRIDE + col];
     const uint32_t pass = q != 0 ? 1u : 0u, hd = q >> 7, tl = b >> 7;
     if (PLP_WAVE_ANY(hd)) {
         PLP_LDS[cur_s] = '^';
-        PLP_LDS[cur_s + hd] = (char)T.s_mq[slot];
+        PLP_LDS[cur_s + hd] = (char)mq;
         cur_s += 2 * hd;
     }
     PLP_LDS[cur_s] = (char)(b & 0x7f);
@@ -412,6 +423,20 @@ PLP_HD void tile_phase2_row(const TileLds &T, int slot, int col, uint32_t &cur_s
     }
     PLP_LDS[cur_q] = (char)(q & 0x7f);
     cur_q += pass;
+}
+PLP_HD void tile_phase2_row(const TileLds &T, int slot, int col, uint32_t &cur_s, uint32_t &cur_q)
+{
+    tile_phase2_apply(T.tb[slot * TILE_STRIDE + col], T.tq[slot * TILE_STRIDE + col], T.s_mq[slot], cur_s, cur_q);
+}
+// four consecutive rows (slot a multiple of four): every tile byte is asked for before the first is used
+PLP_HD void tile_phase2_rows4(const TileLds &T, int slot, int col, uint32_t &cur_s, uint32_t &cur_q)
+{
+    uint32_t b[4], q[4], mq4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { b[i] = T.tb[(slot + i) * TILE_STRIDE + col]; q[i] = T.tq[(slot + i) * TILE_STRIDE + col]; }
+    __builtin_memcpy(&mq4, &T.s_mq[slot], 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile_phase2_apply(b[i], q[i], (mq4 >> (8 * i)) & 0xffu, cur_s, cur_q);
 }
 
 // phase 2 for a read with a general CIGAR (indels, clips, pads, skips): per-entry resolution, as k_mplp_emit does it

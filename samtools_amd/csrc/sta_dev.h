@@ -87,10 +87,13 @@ void sta_launch_scan_max_i32(hipStream_t s, const int32_t *in, int32_t *out, int
 // exclusive scan of u32 lengths into u64 offsets (offs has n+1 entries)
 void sta_launch_len_scan(hipStream_t s, const uint32_t *len, uint64_t *offs, int64_t n, void *tmp, size_t tmp_bytes);
 void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo /*[nfiles][ncols] (count, seq bytes)*/,
-                         StaCounters *ctr, bool legacy = false /* the lane-per-column pair instead of the tile kernels (A/B measurements) */);
+                         StaCounters *ctr, const uint32_t *wfirst /* sta_launch_wave_first's table; null: lane-per-column kernels */,
+                         bool legacy = false /* the lane-per-column pair instead of the tile kernels (A/B measurements) */);
+// wfirst[nfiles][ncols / 64 + 2]: first read starting at or beyond every 64-column group (where the tile kernels start looking)
+void sta_launch_wave_first(hipStream_t s, const StaWinDev &w, uint32_t *wfirst);
 int64_t sta_mplp_deep_strips(int64_t ncols);      // strips of the read-major emit kernel; strip_rng holds 2 x int64 per (file, strip)
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
-                          char *out, uint32_t lds_cap, int64_t *strip_rng /* workspace of the read-major kernel */, uint32_t tile_cap, int deep_mode, bool legacy = false);
+                          char *out, uint32_t lds_cap, int64_t *strip_rng /* workspace of the read-major kernel */, uint32_t tile_cap, int deep_mode, const uint32_t *wfirst, bool legacy = false);
 bool sta_mplp_has_fast_path(const sta_mplp_params &p);
 bool sta_mplp_tile_ok(const sta_mplp_params &p);
 void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, const uint32_t *line_len, int64_t ncols, StaCounters *ctr);

@@ -8,8 +8,9 @@ cd $GRAFT_REPO_ROOT
 TAG=${TAG:-r03}; O=gpurun_out/$TAG; mkdir -p $O
 STEPS=${STEPS:-10}; WARM=${WARM:-3}
 if [ -n "$TESTS" ]; then
-  if [ "$TESTS" = 1 ]; then ( time timeout 1500 python -m pytest tests -m gpu -q -x ) > $O/pytest_gpu.log 2>&1
-  else ( time timeout 1500 python -m pytest tests -m gpu -q -k "$TESTS" ) > $O/pytest_gpu.log 2>&1; fi
+  # (a hung kernel must not eat the GPU budget: 240 s per test, 900 s for the suite -- it needs ~160 s)
+  if [ "$TESTS" = 1 ]; then ( time timeout 900 python -m pytest tests -m gpu -q -x -o timeout=240 ) > $O/pytest_gpu.log 2>&1
+  else ( time timeout 900 python -m pytest tests -m gpu -q -o timeout=240 -k "$TESTS" ) > $O/pytest_gpu.log 2>&1; fi
   tail -4 $O/pytest_gpu.log
 fi
 summ() { tail -1 $1 | python -c 'import sys,json
@@ -18,15 +19,15 @@ try:
     print(d["config"]["workload"], round(d["value"]), "Mb/s", round(d["ms_per_step"],3), "ms", json.dumps({k: round(v,3) for k,v in list(d["kernels_ms_per_step"].items())[:9]}), "parity", (d.get("parity_check") or {}).get("identical"))
 except Exception as e: print("no json:", e)'; }
 for wl in $FULL; do
-  timeout 900 python bench.py --steps $STEPS --warmup $WARM --workload $wl $BENCH_EXTRA > $O/bench_${wl}_full.json 2> $O/bench_${wl}_full.err; summ $O/bench_${wl}_full.json
+  timeout 400 python bench.py --steps $STEPS --warmup $WARM --workload $wl $BENCH_EXTRA > $O/bench_${wl}_full.json 2> $O/bench_${wl}_full.err; summ $O/bench_${wl}_full.json
 done
 for wl in $WL; do
-  timeout 600 python bench.py --steps $STEPS --warmup $WARM --workload $wl --no-cpu-baseline --no-pmc $BENCH_EXTRA > $O/bench_$wl.json 2> $O/bench_$wl.err; summ $O/bench_$wl.json
+  timeout 200 python bench.py --steps $STEPS --warmup $WARM --workload $wl --no-cpu-baseline --no-pmc $BENCH_EXTRA > $O/bench_$wl.json 2> $O/bench_$wl.err; summ $O/bench_$wl.json
 done
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for wl in $STATS; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$wl -o $TAG -- python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-pmc --workload $wl $BENCH_EXTRA > $R/$O/prof_$wl.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$wl -o $TAG -- python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-pmc --workload $wl $BENCH_EXTRA > $R/$O/prof_$wl.log 2>&1
   f=$(ls $R/$O/prof_$wl/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $R/$O/${wl}_kernel_stats.csv && head -8 $f | cut -c1-150
 done
 cd $R

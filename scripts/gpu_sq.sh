@@ -5,7 +5,7 @@ mkdir -p $R/gpurun_out/$TAG
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/p$i -o x -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --workload $WL > $R/gpurun_out/$TAG/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/p$i -o x -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --workload $WL > $R/gpurun_out/$TAG/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections

@@ -14,13 +14,13 @@ int main()
     FILE *out = fdopen(fd, "w+");
     std::string want;
     {
-        WinPipe pipe(3, [](WinJob &j) {
+        WinPipe pipe(3, [](WinJob &j, int) {
             if (j.tid == 777) return -1;
             usleep((useconds_t)((j.cb * 37) % 700));                  // uneven device times
             char buf[64]; int n = snprintf(buf, sizeof buf, "win %lld all=%d\n", (long long)j.cb, j.all_mode);
             j.text.assign(buf, buf + n); j.out_bytes = (uint64_t)n; j.info.n_data_cols = (uint64_t)(j.cb % 3);
             return 0;
-        }, out, "write error\n");
+        }, out, "write error\n", 2);
         for (int k = 0; k < 200; ++k) {
             WinJob *j = pipe.acquire();
             j->tid = 0; j->cb = k; j->ce = k + 1; j->have_reads = false; j->write = true; j->hold = false; j->all_mode = 0;

@@ -92,9 +92,16 @@ int main(int argc, char **argv)
     MplpDevPar P; memset(&P, 0, sizeof P);
     P.min_baseQ = min_baseQ; P.no_ends = no_ends; P.all = all; P.tlen = n_cols; P.tag_sep = ',';
 
+    // wave_range_indexed (kernels_plp.hip): from the first read starting at or beyond p0, back over the (up to 64, else searched)
+    // earlier reads whose prefix-maximum end still reaches p0; up to the first read starting at or beyond the next 64-column group
     auto read_range = [&](int p0, int plast, long long &rlo, long long &rhi) {
-        rlo = std::upper_bound(maxend.begin(), maxend.end(), p0) - maxend.begin();          // first read with an end beyond p0
-        rhi = std::upper_bound(pos.begin(), pos.end(), plast) - pos.begin();                // first read starting beyond plast
+        const long long start = std::lower_bound(pos.begin(), pos.end(), p0) - pos.begin();
+        const int next_group = (plast | 63) + 1;
+        rhi = std::lower_bound(pos.begin(), pos.end(), next_group) - pos.begin();
+        int cnt = 0;
+        for (long long i = start - 64; i < start; ++i) if (i >= 0 && maxend[(size_t)i] > p0) ++cnt;
+        if (cnt == 64 && start > 64) rlo = std::upper_bound(maxend.begin(), maxend.begin() + (start - 64), p0) - maxend.begin();
+        else rlo = start - cnt;
         if (rlo > rhi) rlo = rhi;
     };
 
@@ -170,12 +177,19 @@ int main(int argc, char **argv)
             for (int first = 0; first < nlive; first += TILE_SLOTS) {
                 const int ns = std::min(TILE_SLOTS, nlive - first);
                 for (int i = 0; i < ns; ++i) { const long long ri = b0 + live[(size_t)(first + i)]; tile_set_slot(T, i, live[(size_t)(first + i)], info[(size_t)ri], pos[(size_t)ri], end[(size_t)ri], b8[(size_t)ri]); }
-                for (int lane = 0; lane < 64; ++lane) tile_phase1(T, lane, ns, R, P, p0, W.ref != nullptr);
-                for (int s = 0; s < ns; ++s)
+                unsigned long long sm = 0;
+                for (int lane = 0; lane < 64; ++lane) if (tile_phase1(T, lane, ns, R, P, p0, W.ref != nullptr) && (lane & 3) == 0) sm |= 1ull << lane;
+                for (int s = 0; s < ns;) {
+                    if (s + 4 <= ns && ((sm >> (4 * s)) & 0x1111ull) == 0x1111ull) {
+                        for (int lane = 0; lane < 64; ++lane) tile_phase2_rows4(T, s, st[lane].col, st[lane].cur_s, st[lane].cur_q);
+                        s += 4; continue;
+                    }
                     for (int lane = 0; lane < 64; ++lane) {
-                        if (T.s_info[s] & RI_SIMPLE) tile_phase2_row(T, s, st[lane].col, st[lane].cur_s, st[lane].cur_q);
+                        if ((sm >> (4 * s)) & 1ull) tile_phase2_row(T, s, st[lane].col, st[lane].cur_s, st[lane].cur_q);
                         else tile_phase2_general(T, s, st[lane], R, W, P, b0, p0 + lane);
                     }
+                    ++s;
+                }
             }
         }
         for (int lane = 0; lane < 64; ++lane) { tile_file_tail(st[lane]); if (st[lane].exists) lds[st[lane].cur] = '\n'; }

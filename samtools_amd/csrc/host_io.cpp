@@ -522,29 +522,40 @@ std::unique_ptr<Fasta> Fasta::load(const std::string &path)
 {
     gzFile fp = gzopen(path.c_str(), "rb");
     if (!fp) return nullptr;
-    gzbuffer(fp, 1 << 18);
+    gzbuffer(fp, 1 << 20);
     std::unique_ptr<Fasta> fa(new Fasta());
-    std::vector<char> buf(1 << 18);
+    // Line at a time inside 4 MiB reads: a sequence line is appended whole (faidx keeps the isgraph() characters; the scan for
+    // anything else runs over the line once and almost never finds one).  A genome-sized FASTA (gigabytes) used to take longer
+    // to parse byte by byte than the whole device pipeline took to pile it.
+    std::vector<char> buf(4 << 20);
     std::string name; bool in_name = false, bol = true;
     int n;
     while ((n = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) {
-        for (int i = 0; i < n; ++i) {
-            char c = buf[(size_t)i];
-            if (in_name) {
-                if (c == '\n') {
-                    in_name = false; bol = true;
+        const char *p = buf.data(), *e = p + n;
+        while (p < e) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+            const char *le = nl ? nl : e;                 // this piece of the line (a line may straddle reads)
+            if (in_name) name.append(p, le);
+            else if (bol && p < le && *p == '>') { in_name = true; name.assign(p + 1, le); }
+            else if (p < le && !fa->seqs_.empty()) {
+                std::string &sq = fa->seqs_.back();
+                const char *q = p;
+                while (q < le && isgraph((unsigned char)*q)) ++q;
+                if (q == le) sq.append(p, le);
+                else for (q = p; q < le; ++q) if (isgraph((unsigned char)*q)) sq += *q;
+            }
+            if (p < le) bol = false;
+            if (nl) {
+                if (in_name) {
+                    in_name = false;
                     size_t k = 0; while (k < name.size() && !isspace((unsigned char)name[k])) ++k;
                     name.resize(k);
                     fa->idx_[name] = fa->seqs_.size();
                     fa->seqs_.emplace_back();
-                } else name += c;
-                continue;
-            }
-            if (bol && c == '>') { in_name = true; name.clear(); continue; }
-            if (c == '\n') { bol = true; continue; }
-            bol = false;
-            if (!isgraph((unsigned char)c) || fa->seqs_.empty()) continue;
-            fa->seqs_.back() += c;
+                }
+                bol = true;
+                p = nl + 1;
+            } else p = e;
         }
     }
     gzclose(fp);

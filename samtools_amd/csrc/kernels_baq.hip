@@ -381,12 +381,17 @@ __device__ __forceinline__ int64_t baq_pick(const StaReadsDev &R, int64_t g, int
 // which the backward kernel re-evaluates with the forward kernel's operations in the forward kernel's order, so the stream is
 // 3 * NB doubles per row PAIR instead of 4 * NB (-25 %).  Pair t = (i - 1) / 2 starts at lane row t * 3NB: the odd row's cells are
 // (M, I) pairs of 16 bytes per lane (two lane rows per cell), the even row's are 8-byte M values after them.
+// DEC == 2 (band width 7, the default): only the ODD rows are stored, and -- except row 1 -- RAW, before the division by the row
+// sum s[i].  The backward kernel redoes `x * (1 / s[i])` (the forward kernel's own operation on the same operands), re-runs the
+// odd row's D chain from the raw M values, and re-evaluates the whole even row above it from the normalised (M, I, D) with the
+// forward kernel's expressions: bit-identical, 2 * NB doubles per row PAIR (-33 % against DEC == 1, -50 % against every row).
+// Pair t = (i - 1) / 2 (i odd) at lane row t * 2NB.
 // Without DEC every row stores (M, I) pairs: row i at lane row (i - 1) * 2NB.
 // After the rows: s[0 .. lq_cap + 1] (one lane row each), then -- only when the per-row states do not fit LDS -- one int32 per row.
-template <int NB, bool DEC> __host__ __device__ constexpr size_t baq_rows_lr(int lq_cap) { return DEC ? (size_t)((lq_cap + 1) / 2) * (3 * NB) : (size_t)lq_cap * (2 * NB); }
+template <int NB, int DEC> __host__ __device__ constexpr size_t baq_rows_lr(int lq_cap) { return DEC == 2 ? (size_t)((lq_cap + 1) / 2) * (2 * NB) : DEC ? (size_t)((lq_cap + 1) / 2) * (3 * NB) : (size_t)lq_cap * (2 * NB); }
 #define BAQ_LDS_ROWS_MAX 256          // per-row state bytes live in LDS up to this read length (16 KB per wave)
 
-template <int BW, bool DEC>
+template <int BW, int DEC>
 __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
                                                  double *scratch, size_t slot_dbl, int lq_cap)
 {
@@ -469,10 +474,16 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
             pm = fm; pd = fd;
         }
         S[(size_t)i * 64] = sum;
+        if (DEC == 2 && (i & 1)) {           // raw (M, I) of an odd row; even rows are not stored at all
+            const size_t t2 = (size_t)((i - 1) >> 1) * (2 * NB);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { baq_d2 v = { M[j], I[j] }; __builtin_nontemporal_store(v, &F2[(t2 + 2 * j) * 32]); }
+        }
         double inv = 1. / sum;
 #pragma unroll
         for (int j = 0; j < NB; ++j) { M[j] *= inv; I[j] *= inv; D[j] *= inv; }
-        if (DEC) {
+        if (DEC == 2) {
+        } else if (DEC) {
             const size_t t = (size_t)((i - 1) >> 1) * (3 * NB);
             if (i & 1) {
 #pragma unroll
@@ -513,7 +524,7 @@ __device__ __forceinline__ void baq_cur_seek(BaqCur &cu, const uint32_t *cigar, 
     }
 }
 
-template <int BW, bool DEC, bool PLDS>
+template <int BW, int DEC, bool PLDS>
 __global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
                                                     double *scratch, size_t slot_dbl, int lq_cap, int lds_rows)
 {
@@ -578,30 +589,35 @@ __global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, 
     // One row: backward update (b[i] from b[i+1]) unless i == lq, then the MAP step against the forward row.  Forward row of
     // row i: (fM, fI) loaded, or -- EVEN row under DEC -- fM loaded and fI re-evaluated from the row below (Mp, Ip) and 1 / s[i].
     double inv_i = 1. / s_top;
-#define BAQ_BWD_UPDATE(i)                                                                                                   \
-    if ((i) < lq) {                                                                                                         \
-        const float qf = c_qf; const int sb = c_sb; const int nrc = c_rc; const double si = c_s;                            \
+    // row inputs of the backward step i (the emission of row i + 1): advances the prefetch pipeline and the reference word
+    int u_qyc = 9; double u_ematch = 0., u_elo = 1., u_yv = 0., u_si = 1.;
+#define BAQ_BWD_INPUTS(i)                                                                                                   \
+    {                                                                                                                       \
+        const float qf = c_qf; const int sb = c_sb; const int nrc = c_rc; u_si = c_s;                                       \
         c_qf = q2p[r_q]; c_sb = r_sb; c_rc = RCONV(r_rr); c_s = r_s;                                                        \
         if ((i) - 2 >= 1) { int i2 = (i) - 2; r_q = qual[i2]; r_sb = SEQB(i2); r_s = S[(size_t)i2 * 64]; r_rr = RRAW(i2 - BW); } \
         if ((i) < lq - 1) rw = (rw << 3) | (uint64_t)nrc;                                                                   \
         const int qy = QCONV(sb, (i));                                                                                      \
         const double qli1 = qf;                                                                                             \
-        const double ematch = 1. - qli1, e_lo = qy > 3 ? 1. : qli1 * EM;                                                    \
-        const int qyc = qy > 3 ? 9 : qy;                                                                                    \
-        const double yv = (i) > 1 ? 1. : 0.;                                                                                \
+        u_ematch = 1. - qli1; u_elo = qy > 3 ? 1. : qli1 * EM;                                                              \
+        u_qyc = qy > 3 ? 9 : qy;                                                                                            \
+        u_yv = (i) > 1 ? 1. : 0.;                                                                                           \
+    }
+#define BAQ_BWD_APPLY(i)                                                                                                    \
+    {                                                                                                                       \
         double dnext = 0.;                                                                                                  \
         _Pragma("unroll")                                                                                                   \
         for (int j = NB - 1; j >= 0; --j) {                                                                                 \
             int rc = FLD(rw, j);                                                                                            \
-            double e = emis_sel(rc, qyc, ematch, e_lo) * bMr[j];     /* rc == 7 <=> k >= l_ref: e = 0 * b */                 \
+            double e = emis_sel(rc, u_qyc, u_ematch, u_elo) * bMr[j];     /* rc == 7 <=> k >= l_ref: e = 0 * b */            \
             double bi1 = j > 0 ? bIr[j - 1] : 0.;                                                                           \
             double bm = e * p.m0 + p.eim1 * bi1 + p.m2 * dnext;                                                             \
             double bi_ = e * p.m3 + p.eim4 * bi1;                                                                           \
-            double bd = (e * p.m6 + p.m8 * dnext) * yv;                                                                     \
+            double bd = (e * p.m6 + p.m8 * dnext) * u_yv;                                                                   \
             bMr[j] = bm; bIr[j] = bi_;                                                                                      \
             dnext = bd;                                                                                                     \
         }                                                                                                                   \
-        inv_i = 1. / si;                                                                                                    \
+        inv_i = 1. / u_si;                                                                                                  \
         _Pragma("unroll")                                                                                                   \
         for (int j = 0; j < NB; ++j) { bMr[j] *= inv_i; bIr[j] *= inv_i; }                                                  \
         if ((i) <= BW) {            /* cells with k < 1 do not exist in the reference: keep them at zero */                  \
@@ -609,6 +625,7 @@ __global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, 
             for (int j = 0; j < BW; ++j) if (j < BW + 1 - (i)) { bMr[j] = 0.; bIr[j] = 0.; }                                \
         }                                                                                                                   \
     }
+#define BAQ_BWD_UPDATE(i) if ((i) < lq) { BAQ_BWD_INPUTS(i) BAQ_BWD_APPLY(i) }
     // MAP of row i given z-terms; then the per-row result: quality from the right-hand running maximum straight away (the
     // left-hand one follows in the forward pass at the end), state byte kept for that pass
 #define BAQ_MAP_FINISH(i, sum, max, max_k)                                                                                  \
@@ -642,10 +659,15 @@ __global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, 
             double fM[NB], fI[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                baq_d2 v = __builtin_nontemporal_load(DEC ? &F2[((size_t)((i - 1) >> 1) * (3 * NB) + 2 * j) * 32] : &F2[((size_t)(i - 1) * NB + j) * 64]);
+                baq_d2 v = __builtin_nontemporal_load(DEC == 2 ? &F2[((size_t)((i - 1) >> 1) * (2 * NB) + 2 * j) * 32]
+                                                      : DEC ? &F2[((size_t)((i - 1) >> 1) * (3 * NB) + 2 * j) * 32] : &F2[((size_t)(i - 1) * NB + j) * 64]);
                 fM[j] = v.x; fI[j] = v.y;
             }
             BAQ_BWD_UPDATE(i)
+            if (DEC == 2 && i > 1) {         // a raw row (the top row of a read of odd length): the forward kernel's M *= inv, I *= inv
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { fM[j] *= inv_i; fI[j] *= inv_i; }
+            }
             double sum = 0., max = 0.; int max_k = -1;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
@@ -657,7 +679,58 @@ __global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, 
             if (DEC) { --i; break; }
         }
     }
-    if (DEC) {
+    if (DEC == 2) {
+        // pairs (i even, i - 1 odd): only the odd row was stored -- raw, unless it is row 1
+#pragma unroll 1
+        for (; i >= 2; i -= 2) {
+            const size_t t2 = (size_t)((i - 1) >> 1) * (2 * NB);
+            double Mp[NB], Ip[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { baq_d2 v = __builtin_nontemporal_load(&F2[(t2 + 2 * j) * 32]); Mp[j] = v.x; Ip[j] = v.y; }
+            BAQ_BWD_UPDATE(i)
+            // inputs of the backward step i - 1 = the emission of row i, which the re-evaluation of that row needs first
+            BAQ_BWD_INPUTS(i - 1)
+            {
+                // One sweep over the cells: cell j of the odd row is normalised (and its D state re-run from the raw chain), which
+                // completes I of cell j - 1 and M of cell j of the even row; their MAP terms are taken at once, in the order
+                // M0, I0, M1, I1, ... of the other variants, so the even row is never held as a whole.
+                const bool row1 = i == 2;                   // row 1 is stored normalised and has no D state
+                const double inv_o = row1 ? 1. : 1. / u_si, m2o = row1 ? 0. : p.m2, m8o = row1 ? 0. : p.m8;
+                double pm = 0., pd = 0.;                    // the odd row's raw M and D at j - 1
+                double sum = 0., max = 0.; int max_k = -1;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int idx = i - 1 - BW - 1 + j;     // reference index of cell j of row i - 1
+                    double fd = m2o * pm + m8o * pd;
+                    fd = (idx < 0 || idx >= l_ref) ? 0. : fd;
+                    pm = Mp[j]; pd = fd;
+                    const double Mn = Mp[j] * inv_o, In = Ip[j] * inv_o, Dn = fd * inv_o;
+                    Mp[j] = Mn; Ip[j] = In;
+                    double z;
+                    if (j > 0) {
+                        const double fi = (EI * (p.m1 * Mn + p.m4 * In)) * inv_i;           // the forward kernel's I[i][j - 1]
+                        z = fi * bIr[j - 1]; if (z > max) { max = z; max_k = (i - BW - 1 + j - 1) << 2 | 1; } sum += z;
+                    }
+                    const double e = emis_sel(FLD(rw, j), u_qyc, u_ematch, u_elo);
+                    const double fm = (e * (p.m0 * Mn + p.m3 * In + p.m6 * Dn)) * inv_i;     // the forward kernel's M[i][j]
+                    z = fm * bMr[j]; if (z > max) { max = z; max_k = (i - BW - 1 + j) << 2 | 0; } sum += z;
+                }
+                sum += 0. * bIr[NB - 1];                    // I[i][NB - 1] = 0: the last term of the other variants' sum
+                BAQ_MAP_FINISH(i, sum, max, max_k)
+            }
+            BAQ_BWD_APPLY(i - 1)
+            {
+                double sum = 0., max = 0.; int max_k = -1;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    double z;
+                    z = Mp[j] * bMr[j]; if (z > max) { max = z; max_k = (i - 1 - BW - 1 + j) << 2 | 0; } sum += z;
+                    z = Ip[j] * bIr[j]; if (z > max) { max = z; max_k = (i - 1 - BW - 1 + j) << 2 | 1; } sum += z;
+                }
+                BAQ_MAP_FINISH(i - 1, sum, max, max_k)
+            }
+        }
+    } else if (DEC) {
         // pairs (i even, i - 1 odd): M of the even row + the full odd row are fetched before the even row's update
 #pragma unroll 1
         for (; i >= 2; i -= 2) {
@@ -693,6 +766,8 @@ __global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, 
         }
     }
 #undef BAQ_BWD_UPDATE
+#undef BAQ_BWD_INPUTS
+#undef BAQ_BWD_APPLY
 #undef BAQ_MAP_FINISH
 
     /*** realn.c, extended BAQ: bq = min(running max from the left, from the right) inside each M block; qual = min(qual, bq) ***/
@@ -753,7 +828,7 @@ __global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, 
     }
 }
 
-template <int NB, bool DEC>
+template <int NB, int DEC>
 static size_t baq_slot_dbl_t(int lq_cap)
 {
     // forward rows + s[] + the per-row state ints of the fallback path (reads longer than BAQ_LDS_ROWS_MAX)
@@ -761,10 +836,12 @@ static size_t baq_slot_dbl_t(int lq_cap)
 }
 // band width 7 stores I rows every second row (DEC), band width 8 (a few reads with a 2-3 bp deletion: it would not fit the register
 // file at two waves per SIMD) stores every row
-static size_t baq_slot_dbl(int lq_cap, int bw) { return bw == 7 ? baq_slot_dbl_t<15, true>(lq_cap) : baq_slot_dbl_t<17, false>(lq_cap); }
+// STA_BAQ_DEC=1 selects the previous layout (M every row + I every second row) for A/B measurements
+static int baq_dec_mode() { static const int m = [] { const char *e = getenv("STA_BAQ_DEC"); return e && atoi(e) == 1 ? 1 : 2; }(); return m; }
+static size_t baq_slot_dbl(int lq_cap, int bw) { return bw == 7 ? (baq_dec_mode() == 2 ? baq_slot_dbl_t<15, 2>(lq_cap) : baq_slot_dbl_t<15, 1>(lq_cap)) : baq_slot_dbl_t<17, 0>(lq_cap); }
 
 // bytes of forward-row stream per query base of the band-7 kernel pair (written once, read once): what bench.py reports as DRAM traffic
-extern "C" double sta_baq_stream_bytes_per_base(void) { return 3 * 15 * 8 / 2.0; }
+extern "C" double sta_baq_stream_bytes_per_base(void) { return (baq_dec_mode() == 2 ? 2 : 3) * 15 * 8 / 2.0; }
 
 size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_launch, int slab_gib_cap)
 {
@@ -793,7 +870,7 @@ size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_l
     return (size_t)gpl * slot;
 }
 
-template <int BW, bool DEC>
+template <int BW, int DEC>
 static void run_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int64_t g0, int64_t ng, int use_list, int pass)
 {
     unsigned nb = (unsigned)((ng + 3) / 4);
@@ -817,6 +894,6 @@ void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
         g_tables_init = true;
     }
     if (r.n == 0 || lq_cap <= 0 || ng <= 0) return;
-    if (bw == 7) run_band<7, true>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass);
-    else if (bw == 8) run_band<8, false>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass);
+    if (bw == 7) { if (baq_dec_mode() == 2) run_band<7, 2>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass); else run_band<7, 1>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass); }
+    else if (bw == 8) run_band<8, 0>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass);
 }

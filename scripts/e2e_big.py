@@ -3,6 +3,10 @@ several contigs), samtools-amd vs the CPU oracle.  Host decode, staging, PCIe an
 this is NOT bench.py's HBM-resident number.
 
     python scripts/e2e_big.py [contigs=8] [columns_per_contig=4375000] [outdir=/dev/shm/sta_e2e]
+    E2E_DEPTH=1.5 E2E_GENOME=1 python scripts/e2e_big.py 24 100000000      # genome-sized: 24 contigs, 2.4 Gbp (> 2^31 linear columns)
+E2E_GENOME=1: one thread setting, the oracle only for `depth -a` of the whole file and `mpileup -f` of the last 2 Mbp of the last
+contig (xxhash of the streams), plus -- E2E_SHARDS=N -- the N blocks of a sharded `depth -a` (STA_SHARD=r/N, run one after the
+other) whose concatenation must hash like the unsharded text.
 
 The input is generated in parallel (one process per contig), BGZF level 1.  Output goes to /dev/null for the timings; one
 extra run per command writes to a file and is compared (sha256) with the oracle's text (`mpileup -f` on one contig only:
@@ -31,7 +35,7 @@ def make_contig(i):
     from bamio import bam_record_bytes, bgzf_compress
     name = "chr%d" % (i + 1)
     ref = synth_ref(cols, seed=1 + i)
-    rd = synth_reads(ref, depth=30, read_len=150, seed=42 + i)
+    rd = synth_reads(ref, depth=float(os.environ.get("E2E_DEPTH", "30")), read_len=150, seed=42 + i)
     tid = {"chr%d" % (k + 1): k for k in range(n_contigs)}
     names = rd["names"].tobytes().split(b"\0")
     recs = []
@@ -61,9 +65,12 @@ def timed(cmd, env=None, stdout=None):
     return dt, p.stderr.decode()
 
 
-def sha_of(cmd, env=None):
+def sha_of(cmd, env=None, h=None):
+    """(hex digest, bytes) of the command's stdout; h: a running hash object to continue (sharded blocks)"""
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
-    h = hashlib.sha256(); n = 0
+    if h is None:
+        h = hashlib.sha256()
+    n = 0
     while True:
         b = p.stdout.read(1 << 22)
         if not b:
@@ -79,7 +86,7 @@ def main():
     bam, fa = os.path.join(out, "big.bam"), os.path.join(out, "big.fa")
     t0 = time.perf_counter()
     if not os.path.exists(bam):
-        with mp.Pool(min(n_contigs, 16)) as pool:
+        with mp.Pool(min(n_contigs, 24)) as pool:
             counts = pool.map(make_contig, range(n_contigs))
         names = ["chr%d" % (k + 1) for k in range(n_contigs)]
         hdr = ["@HD\tVN:1.6\tSO:coordinate"] + ["@SQ\tSN:%s\tLN:%d" % (n, cols) for n in names]
@@ -102,10 +109,10 @@ def main():
     t_start, _ = timed([ENG, "depth", os.path.join(REPO, "tests", "golden", "mpileup", "mp_D.sam")])
     print("engine start-up (tiny input): %.2f s" % t_start)
     cmds = [("depth -a", ["depth", "-a", bam]), ("mpileup -B -f", ["mpileup", "-B", "-f", fa, bam]), ("mpileup -f", ["mpileup", "-f", fa, bam])]
-    for name, args in cmds:
+    for name, args in ([] if os.environ.get("E2E_ONLY_SHARDS") else cmds):
         best, best_err = 1e9, ""
         # E2E_THREADS: decode threads per input, optionally "decode/stage" (STA_STAGE_THREADS: threads copying a window's slices)
-        for thr in (os.environ.get("E2E_THREADS", "8,16,24").split(",")):
+        for thr in (os.environ.get("E2E_THREADS", "16/4" if os.environ.get("E2E_GENOME") else "8,16,24").split(",")):
             env = dict(os.environ, STA_IO_THREADS=thr.split("/")[0], STA_DRIVER_TIMING="1")
             if "/" in thr:
                 env["STA_STAGE_THREADS"] = thr.split("/")[1]
@@ -115,6 +122,29 @@ def main():
             if dt < best:
                 best, best_err = dt, thr
         print("%-14s best %.2f s = %.0f Mbases/s (io_threads=%s; %.0f net of start-up)" % (name, best, mb / best, best_err, mb / max(best - t_start, 1e-3)))
+    if os.environ.get("E2E_GENOME"):
+        import xxhash
+    if os.environ.get("E2E_GENOME") and not os.environ.get("E2E_ONLY_SHARDS"):
+        t1 = time.perf_counter()
+        a, na = sha_of([ENG, "depth", "-a", bam], h=xxhash.xxh3_128()); t2 = time.perf_counter()
+        b, nb = sha_of([ORA, "depth", "-a", bam], h=xxhash.xxh3_128()); t3 = time.perf_counter()
+        print("parity depth -a (whole file) engine %d bytes in %.1f s, oracle %d bytes in %.1f s: %s" % (na, t2 - t1, nb, t3 - t2, "IDENTICAL" if a == b else "DIFFERENT"))
+        reg = "chr%d:%d-%d" % (n_contigs, cols - 2000000 + 1, cols)
+        for args in (["mpileup", "-f", fa, "-r", reg, bam], ["mpileup", "-B", "-a", "-f", fa, "-r", "chr%d:1-3000000" % (n_contigs // 2), bam]):
+            a, na = sha_of([ENG] + args, h=xxhash.xxh3_128()); b, nb = sha_of([ORA] + args, h=xxhash.xxh3_128())
+            print("parity %s engine %d bytes, oracle %d bytes: %s" % (" ".join(args[:-1]).replace(fa, "ref.fa"), na, nb, "IDENTICAL" if a == b else "DIFFERENT"))
+    if os.environ.get("E2E_GENOME"):
+        ns = int(os.environ.get("E2E_SHARDS", "0"))
+        if ns:
+            whole, nw = sha_of([ENG, "depth", "-aa", bam], h=xxhash.xxh3_128())          # (a sharded run refuses single -a: whether a contig prints depends on every block)
+            h = xxhash.xxh3_128(); tot = 0; times = []
+            for r in range(ns):
+                t1 = time.perf_counter()
+                _, nb_ = sha_of([ENG, "depth", "-aa", bam], env=dict(os.environ, STA_SHARD="%d/%d" % (r, ns)), h=h)
+                times.append(time.perf_counter() - t1); tot += nb_
+            print("sharded depth -aa, %d blocks one after the other (%d linear columns): %d bytes vs %d unsharded: %s; seconds per block: %s"
+                  % (ns, n_contigs * cols, tot, nw, "IDENTICAL" if h.hexdigest() == whole else "DIFFERENT", " ".join("%.1f" % x for x in times)))
+        return
     if os.environ.get("E2E_QUICK"):
         # a short run (GPU minutes): the oracle only for depth -a; mpileup text compared between one and several staging threads
         a, na = sha_of([ENG, "depth", "-a", bam]); b, nb = sha_of([ORA, "depth", "-a", bam])

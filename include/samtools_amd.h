@@ -397,6 +397,10 @@ int sta_main_consensus(int argc, char **argv);
  * window: 1 = one decoded record at a time (host_pump.h), 2 = chunk slices decoded on `threads` parser threads
  * (host_chunk.h); both lanes must give the same checksum.  Returns 0, or <0 on error. */
 int sta_io_scan(const char *path, int threads, int stage, uint64_t *n_records, uint64_t *checksum);
+/* Text of an 'f' / 'd' aux value as `mpileup --output-extra TAG` prints it: HTSlib's kputd (bam_plcmd.c:838-840), which is not
+ * printf("%g") -- six significant digits, half rounded UP on the truncated decimal expansion inside [0.0001, 999999], "%g"
+ * outside.  Host only.  Returns the length written (NUL-terminated), or -1 when cap is too small. */
+int sta_format_aux_float(double v, char *buf, int cap);
 
 /* ---- BGZF inflate on the device ----
  * Stands where HTSlib's bgzf.c stands per block: check_header / bgzf_read_block (the BC subfield, BSIZE, ISIZE, CRC32) and

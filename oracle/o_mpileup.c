@@ -289,8 +289,54 @@ static void smpl_add(smpl_t *sm, const char *fn, const char *txt)
     free(first_sm); free(buf.s); free(copy);
 }
 
-/* kputd-compatible enough for tag output of floats (%g) */
-static void put_double(ostr_t *s, double d) { char b[64]; snprintf(b, sizeof b, "%g", d); os_puts(s, b); }
+/* HTSlib kputd (kstring.c), which bam_plcmd.c:840 calls for 'f' / 'd' aux values.  Restated from the published source (HTSlib is
+ * not in the reference tree): zero -> "0" / "-0"; outside [0.0001, 999999] -> "%g"; inside, the value times 10^10 is truncated
+ * to an integer, half a unit of the sixth significant digit added, the decimal digits written right to left into a small
+ * buffer, cut to six significant digits, the point inserted and trailing zeros culled.  Unlike "%g" this rounds half UP on the
+ * truncated decimal expansion: 123456.5 -> "123457", 12345.25 -> "12345.3". */
+static void put_double(ostr_t *s, double d)
+{
+    char buf[21], *cp = buf + 20, *ep;
+    if (d == 0) { os_puts(s, signbit(d) ? "-0" : "0"); return; }
+    if (d < 0) { os_putc(s, '-'); d = -d; }
+    if (!(d >= 0.0001 && d <= 999999)) { char b[64]; snprintf(b, sizeof b, "%g", d); os_puts(s, b); return; }
+    uint64_t i = (uint64_t)(d * 10000000000LL);
+    if (d < .0001) i += 0;
+    else if (d < 0.001) i += 5;
+    else if (d < 0.01) i += 50;
+    else if (d < 0.1) i += 500;
+    else if (d < 1) i += 5000;
+    else if (d < 10) i += 50000;
+    else if (d < 100) i += 500000;
+    else if (d < 1000) i += 5000000;
+    else if (d < 10000) i += 50000000;
+    else if (d < 100000) i += 500000000;
+    else i += 5000000000LL;
+    do { *--cp = (char)('0' + i % 10); i /= 10; } while (i >= 1);
+    buf[20] = 0;
+    int p = (int)(buf + 20 - cp);
+    if (p <= 10) {                      /* d < 1 */
+        cp[6] = 0; ep = cp + 5;         /* six digits */
+        while (p < 10) { *--cp = '0'; p++; }
+        *--cp = '.';
+        *--cp = '0';
+    } else {
+        char *xp = --cp;
+        while (p > 10) { xp[0] = xp[1]; p--; xp++; }
+        xp[0] = '.';
+        cp[7] = 0; ep = cp + 6;
+        if (cp[6] == '.') cp[6] = 0;
+    }
+    while (*ep == '0' && ep > cp) ep--;            /* cull trailing zeros */
+    {
+        char *z = ep + 1;
+        while (ep > cp) {
+            if (*ep == '.') { if (z[-1] == '.') z[-1] = 0; else z[0] = 0; break; }
+            ep--;
+        }
+    }
+    os_puts(s, cp);
+}
 
 static long long aux2i(const uint8_t *t)
 {

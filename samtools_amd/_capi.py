@@ -184,6 +184,7 @@ _PROTOS = {
     "sta_cons_entries_run": (C.c_int, [_P, C.POINTER(ConsInfo)]),
     "sta_fetch_cons_entries": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "sta_io_scan": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "sta_format_aux_float": (C.c_int, [C.c_double, C.c_char_p, C.c_int]),
     "sta_bgzf_scan": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sta_bgzf_inflate": (C.c_int, [_P, _P, C.c_uint64, C.c_int, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sta_fetch_inflated": (C.c_int, [_P, _P, C.c_uint64]),

@@ -34,6 +34,7 @@ struct DRunner {
     int64_t window_cols = 1 << 20, max_reads = 4 << 20;
     std::unique_ptr<WinPipe> pipe;      // producer (this thread) -> device thread -> writer thread (driver_pipeline.h)
     std::vector<std::vector<StagedFile>> no_reads_d;   // per engine: read-less windows; its device thread only
+    int64_t win_cols = 0; bool adaptive_windows = true;   // columns of the next data window (widened for sparse input unless STA_WINDOW_COLS fixes it)
     Shard shard;                        // STA_SHARD=rank/world: this rank's block of the columns (driver_shard.h)
     std::vector<int64_t> lin0;          // linear coordinate of every contig's first column (no region)
 
@@ -107,12 +108,22 @@ struct DRunner {
             bool more = pump.next_pos(tid) != INT64_MAX;
             if (!more && !pump.has_carry()) break;
             if (!started && !pump.has_carry()) cursor = std::max(cursor, pump.next_pos(tid));
-            int64_t ce_target = std::min(cursor + window_cols, stop);
+            if (!win_cols) win_cols = window_cols;
+            int64_t ce_target = std::min(cursor + win_cols, stop);
             if (ce_target <= cursor) { pump.skip_to(tid, cursor, INT64_MAX, window_cols); pump.drop_tid_carry(); break; }
             WinJob *j = pipe->acquire();
             int64_t ce;
             { const double t0 = WinPipe::now(); ce = pump.fill_staged(tid, cursor, ce_target, j->staged); pipe->add_fill_time(WinPipe::now() - t0); double dw, sc; pump.producer_split(&dw, &sc); pipe->set_producer_split(dw, sc); }
             if (pump.error()) { pipe->release(j); return -1; }
+            if (adaptive_windows) {
+                // sparse input (a genome at 1x: ~7 000 reads per 2^20 columns): the per-window fixed cost (uploads, launches, host
+                // round trips, ~1.3 ms) would dominate, so windows widen until they hold about 10^5 reads; dense input narrows
+                // them again.  Where windows are cut never changes the text (the sharded and 37-column-window tests rely on it).
+                int64_t nr = 0;
+                for (const StagedFile &sf : j->staged) nr += sf.n();
+                if (nr < 100000 && win_cols < ((int64_t)8 << 20)) win_cols *= 2;
+                else if (nr > 1500000 && win_cols > ((int64_t)1 << 18)) win_cols /= 2;
+            }
             if (pump.next_pos(tid) == INT64_MAX) {
                 int64_t me = pump.carry_max_end();
                 if (me != INT64_MIN) ce = std::min(ce, std::max(me, cursor));
@@ -204,7 +215,7 @@ extern "C" int sta_main_depth(int argc, char **argv)
     opt.skip_del = 1;
     std::string file_list, out_file, reg;
     bool header = false;
-    if (const char *e = getenv("STA_WINDOW_COLS")) run.window_cols = std::max<long long>(1, atoll(e));
+    if (const char *e = getenv("STA_WINDOW_COLS")) { run.window_cols = std::max<long long>(1, atoll(e)); run.adaptive_windows = false; }
     if (const char *e = getenv("STA_WINDOW_READS")) run.max_reads = std::max<long long>(1, atoll(e));
 
     static const struct option lopts[] = {

@@ -77,6 +77,7 @@ struct Runner {
     int loaded_ref_tid = -2;
     int64_t loaded_ref_len = INT64_MAX;               // length of the FASTA contig (INT64_MAX: none, no length filter)
     std::vector<int> dev_ref_tid;                     // per engine: contig whose sequence is in its HBM; its device thread only
+    int64_t win_cols = 0; bool adaptive_windows = true;  // columns of the next data window (widened for sparse input unless STA_WINDOW_COLS fixes it)
     Shard shard;                                      // STA_SHARD=rank/world: this rank's block of the columns (driver_shard.h)
     std::vector<int64_t> lin0;                        // linear coordinate of every contig's first column (no region)
 
@@ -185,13 +186,14 @@ struct Runner {
             lo = pb; hi_all = pe; stop = std::min(stop, pe);
         }
         bool started = mode == 2;
+        if (!win_cols) win_cols = conf.window_cols;
         // (a block that starts inside the contig starts at its first column: carried reads may cover it)
         int64_t cursor = (started || shard.on) ? lo : std::max(lo, pump.next_pos(tid));
         for (;;) {
             bool more = pump.next_pos(tid) != INT64_MAX;
             if (!more && !pump.has_carry()) break;
             if (!started) cursor = std::max(cursor, std::min(pump.carry_next_covered(cursor), pump.next_pos(tid)));   // skip uncovered gap
-            int64_t ce_target = std::min(cursor + conf.window_cols, stop);
+            int64_t ce_target = std::min(cursor + win_cols, stop);
             if (ce_target <= cursor) {              // past the region / block end: pass over the rest of this contig
                 pump.skip_to(tid, cursor, INT64_MAX, conf.window_cols);
                 pump.drop_tid_carry();
@@ -201,6 +203,15 @@ struct Runner {
             int64_t ce;
             { const double t0 = WinPipe::now(); ce = pump.fill_staged(tid, cursor, ce_target, j->staged); pipe->add_fill_time(WinPipe::now() - t0); double dw, sc; pump.producer_split(&dw, &sc); pipe->set_producer_split(dw, sc); }
             if (pump.error()) { pipe->release(j); return -1; }
+            if (adaptive_windows) {
+                // sparse input (a genome at 1x: ~7 000 reads per 2^20 columns): the per-window fixed cost (uploads, launches, host
+                // round trips, ~1.3 ms) would dominate, so windows widen until they hold about 10^5 reads; dense input narrows
+                // them again.  Where windows are cut never changes the text (the sharded and 37-column-window tests rely on it).
+                int64_t nr = 0;
+                for (const StagedFile &sf : j->staged) nr += sf.n();
+                if (nr < 100000 && win_cols < ((int64_t)8 << 20)) win_cols *= 2;
+                else if (nr > 1500000 && win_cols > ((int64_t)1 << 18)) win_cols /= 2;
+            }
             if (pump.next_pos(tid) == INT64_MAX) {  // last reads of the contig: stop where they stop
                 int64_t me = pump.carry_max_end();
                 if (me != INT64_MIN) ce = std::min(ce, std::max(me, cursor));
@@ -459,6 +470,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
 
     mp.n_tags = (int32_t)conf.tags.size(); mp.tag_sep = conf.sep;
     Runner run(conf);
+    run.adaptive_windows = getenv("STA_WINDOW_COLS") == nullptr;
     Samples sm;
     for (auto &fn : fns) {
         std::string err;

@@ -7,6 +7,7 @@
 #include <mutex>
 #include <thread>
 #include <zlib.h>
+#include <cmath>
 #include <cstring>
 #include <cstdlib>
 #include <cstdio>
@@ -261,13 +262,65 @@ static int parse_sam(const Header &h, std::string &line, Rec &r, const std::vect
     return 1;
 }
 
-// text of one aux value the way mpileup prints it (bam_plcmd.c:811-850): Z/H as is, integers in decimal, floats with %g
-// (HTSlib's kputd is approximated by %g, as in the oracle), A as the character, anything else (B arrays) as '*'
+// HTSlib kputd (kstring.c; called for 'f' / 'd' aux values at bam_plcmd.c:838-840).  It is NOT printf("%g"): inside
+// [0.0001, 999999] the value is scaled to a 10^-10 fixed-point integer (truncating), half a unit of the sixth significant digit is
+// added (round half UP on the truncated expansion, where printf rounds the exact binary value half to even), six significant
+// digits are kept and trailing zeros / a trailing point dropped; zero prints "0" / "-0"; everything else is left to "%g".
+// E.g. 123456.5 -> "123457" (%g: "123456"), 12345.25 -> "12345.3" (%g: "12345.2").  Restated from the published algorithm.
+static void format_kputd(double d, std::string &out)
+{
+    out.clear();
+    if (d == 0) { out = std::signbit(d) ? "-0" : "0"; return; }
+    if (d < 0) { out = "-"; d = -d; }
+    if (!(d >= 0.0001 && d <= 999999)) { char b[64]; snprintf(b, sizeof b, "%g", d); out += b; return; }
+    uint64_t v = (uint64_t)(d * 10000000000LL);
+    // position of the sixth significant digit by the magnitude of d, as the source's ladder of comparisons does
+    static const double lim[] = { 0.001, 0.01, 0.1, 1, 10, 100, 1000, 10000, 100000 };
+    uint64_t half = 5;
+    for (double l : lim) { if (d < l) break; half *= 10; }
+    v += half;
+    char dig[24]; int nd = 0;
+    do { dig[nd++] = (char)('0' + v % 10); v /= 10; } while (v >= 1);        // least significant first
+    std::string t;
+    if (nd <= 10) {                                  // below 1: "0." + leading zeros + the first six digits
+        t = "0.";
+        t.append((size_t)(10 - nd), '0');
+        for (int k = 0; k < 6 && k < nd; ++k) t += dig[nd - 1 - k];
+    } else {                                         // nd - 10 integer digits, then the fraction, seven characters in all
+        const int ni = nd - 10;
+        for (int k = 0; k < ni; ++k) t += dig[nd - 1 - k];
+        t += '.';
+        for (int k = ni; (int)t.size() < 7; ++k) t += dig[nd - 1 - k];
+        if (t.size() > 7) t.resize(7);
+        if (t[6] == '.') t.resize(6);
+    }
+    // trailing zeros behind a decimal point go, and the point with them
+    if (t.find('.') != std::string::npos) {
+        size_t e = t.size();
+        while (e > 1 && t[e - 1] == '0') --e;
+        if (t[e - 1] == '.') --e;
+        t.resize(e);
+    }
+    out += t;
+}
+
+// the formatter on its own (include/samtools_amd.h): what the drivers print for an 'f' / 'd' aux value
+extern "C" int sta_format_aux_float(double v, char *buf, int cap)
+{
+    std::string t;
+    format_kputd(v, t);
+    if (!buf || cap <= (int)t.size()) return -1;
+    memcpy(buf, t.c_str(), t.size() + 1);
+    return (int)t.size();
+}
+
+// text of one aux value the way mpileup prints it (bam_plcmd.c:811-850): Z/H as is, integers in decimal, floats through kputd,
+// A as the character, anything else (B arrays) as '*'
 static void tag_from_sam(const char *val, size_t n, char type, std::string &out)
 {
     if (type == 'Z' || type == 'H' || type == 'A') out.assign(val, n);
     else if (type == 'i') { char b[32]; snprintf(b, sizeof b, "%lld", strtoll(std::string(val, n).c_str(), nullptr, 10)); out = b; }
-    else if (type == 'f') { char b[64]; snprintf(b, sizeof b, "%g", (double)strtof(std::string(val, n).c_str(), nullptr)); out = b; }
+    else if (type == 'f') format_kputd((double)strtof(std::string(val, n).c_str(), nullptr), out);
     else out = "*";
 }
 
@@ -354,8 +407,8 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
                     else if (t == 'S') { uint16_t v; memcpy(&v, p, 2); snprintf(nb, sizeof nb, "%d", (int)v); out = nb; }
                     else if (t == 'i') { int32_t v; memcpy(&v, p, 4); snprintf(nb, sizeof nb, "%d", v); out = nb; }
                     else if (t == 'I') { uint32_t v; memcpy(&v, p, 4); snprintf(nb, sizeof nb, "%u", v); out = nb; }
-                    else if (t == 'f') { float v; memcpy(&v, p, 4); snprintf(nb, sizeof nb, "%g", (double)v); out = nb; }
-                    else if (t == 'd') { double v; memcpy(&v, p, 8); snprintf(nb, sizeof nb, "%g", v); out = nb; }
+                    else if (t == 'f') { float v; memcpy(&v, p, 4); format_kputd((double)v, out); }
+                    else if (t == 'd') { double v; memcpy(&v, p, 8); format_kputd(v, out); }
                     else out = "*";
                 }
         if (t == 'Z') {

@@ -402,31 +402,6 @@ int sta_io_scan(const char *path, int threads, int stage, uint64_t *n_records, u
  * outside.  Host only.  Returns the length written (NUL-terminated), or -1 when cap is too small. */
 int sta_format_aux_float(double v, char *buf, int cap);
 
-/* ---- BGZF inflate on the device ----
- * Stands where HTSlib's bgzf.c stands per block: check_header / bgzf_read_block (the BC subfield, BSIZE, ISIZE, CRC32) and
- * inflate_block (raw DEFLATE) + the CRC-32 comparison.  HTSlib is not in the reference tree; the formats are SAM
- * specification 4.1, RFC 1951 and RFC 1952.  A BGZF block is self-contained, so a file is thousands of independent streams:
- * sta_bgzf_scan lists them (host, header walk only), sta_bgzf_inflate decodes them all in one launch, one block per lane,
- * into one contiguous device buffer in file order (block i at out_off).  The BAM records in that buffer are not parsed on the
- * device yet: the drivers still read through the host lane above. */
-typedef struct sta_bgzf_block {
-    uint64_t in_off;      /* raw DEFLATE data of the block, from the start of the BGZF bytes */
-    uint64_t out_off;     /* where its inflated bytes go (running sum of out_len) */
-    uint32_t in_len;      /* BSIZE + 1 - XLEN - 20 */
-    uint32_t out_len;     /* ISIZE (<= 65536) */
-    uint32_t crc32;       /* CRC-32 of the inflated bytes, from the block trailer */
-    uint32_t reserved;
-} sta_bgzf_block;
-/* blocks == NULL: count only.  STA_ERR_IO: not BGZF / truncated; STA_ERR_ARG: more than `cap` blocks */
-int sta_bgzf_scan(const void *bytes, uint64_t n, sta_bgzf_block *blocks, uint64_t cap, uint64_t *n_blocks, uint64_t *out_bytes);
-/* comp: the BGZF bytes (mem = STA_MEM_HOST: copied to the device first; STA_MEM_DEVICE: used in place); dev_out: device buffer
- * of >= the scan's out_bytes (NULL: engine-owned, read it with sta_fetch_inflated).  Every block's size and CRC-32 are checked
- * on the device; *n_bad (may be NULL) = blocks that failed (malformed DEFLATE, size or CRC mismatch), first_bad (may be NULL) =
- * index of the first one or UINT64_MAX.  Returns STA_OK when every block checked out, STA_ERR_IO when some did not. */
-int sta_bgzf_inflate(sta_engine *e, const void *comp, uint64_t comp_bytes, int mem, const sta_bgzf_block *blocks, uint64_t n_blocks,
-                     void *dev_out, uint64_t out_cap, uint64_t *n_bad, uint64_t *first_bad);
-int sta_fetch_inflated(sta_engine *e, void *host_dst, uint64_t bytes);      /* engine-owned output of the last sta_bgzf_inflate */
-
 #ifdef __cplusplus
 }
 #endif

@@ -185,9 +185,6 @@ _PROTOS = {
     "sta_fetch_cons_entries": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "sta_io_scan": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sta_format_aux_float": (C.c_int, [C.c_double, C.c_char_p, C.c_int]),
-    "sta_bgzf_scan": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "sta_bgzf_inflate": (C.c_int, [_P, _P, C.c_uint64, C.c_int, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "sta_fetch_inflated": (C.c_int, [_P, _P, C.c_uint64]),
 }
 EXPORTED_SYMBOLS = sorted(_PROTOS)
 for _name, (_res, _args) in _PROTOS.items():
@@ -259,26 +256,6 @@ def io_scan(path, threads=0, stage=False):
     return n.value, h.value
 
 
-class BgzfBlock(C.Structure):
-    """mirror of sta_bgzf_block (include/samtools_amd.h)"""
-    _fields_ = [("in_off", C.c_uint64), ("out_off", C.c_uint64), ("in_len", C.c_uint32), ("out_len", C.c_uint32),
-                ("crc32", C.c_uint32), ("reserved", C.c_uint32)]
-
-
-def bgzf_scan(data):
-    """(array of BgzfBlock, inflated bytes) of BGZF bytes; header walk on the host, needs no device"""
-    buf = (C.c_char * len(data)).from_buffer_copy(data) if not isinstance(data, C.Array) else data
-    n, total = C.c_uint64(0), C.c_uint64(0)
-    rc = lib.sta_bgzf_scan(C.cast(buf, _P), len(data), None, 0, C.byref(n), C.byref(total))
-    if rc != STA_OK:
-        raise RuntimeError("sta_bgzf_scan failed: %d" % rc)
-    blocks = (BgzfBlock * max(n.value, 1))()
-    rc = lib.sta_bgzf_scan(C.cast(buf, _P), len(data), C.cast(blocks, _P), n.value, C.byref(n), C.byref(total))
-    if rc != STA_OK:
-        raise RuntimeError("sta_bgzf_scan failed: %d" % rc)
-    return blocks, int(n.value), int(total.value)
-
-
 class Engine:
     """Owns one sta_engine.  `stream` is a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
 
@@ -305,19 +282,6 @@ class Engine:
     def _chk(self, rc, what):
         if rc != STA_OK:
             raise EngineError("%s failed (%d): %s" % (what, rc, lib.sta_last_error(self._h).decode()))
-
-    def bgzf_inflate(self, data):
-        """inflate every BGZF block of `data` (bytes) on the device; returns (inflated bytes, failed blocks, first failed index).
-        A damaged block does not raise: it is counted (the bytes of the other blocks are still returned)."""
-        blocks, n, total = bgzf_scan(data)
-        buf = (C.c_char * max(len(data), 1)).from_buffer_copy(data or b"\0")
-        nbad, first = C.c_uint64(0), C.c_uint64(0)
-        rc = lib.sta_bgzf_inflate(self._h, C.cast(buf, _P), len(data), STA_MEM_HOST, C.cast(blocks, _P), n, None, 0, C.byref(nbad), C.byref(first))
-        if rc != STA_OK and rc != STA_ERR_IO:
-            self._chk(rc, "sta_bgzf_inflate")
-        out = (C.c_char * max(total, 1))()
-        self._chk(lib.sta_fetch_inflated(self._h, C.cast(out, _P), total), "sta_fetch_inflated")
-        return bytes(out[:total]), int(nbad.value), (None if nbad.value == 0 else int(first.value))
 
     def set_reference(self, tid, ptr, length, mem=STA_MEM_HOST):
         self._chk(lib.sta_set_reference(self._h, tid, _P(ptr), length, mem), "sta_set_reference")

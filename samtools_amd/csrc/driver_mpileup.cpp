@@ -207,10 +207,15 @@ struct Runner {
                 // sparse input (a genome at 1x: ~7 000 reads per 2^20 columns): the per-window fixed cost (uploads, launches, host
                 // round trips, ~1.3 ms) would dominate, so windows widen until they hold about 10^5 reads; dense input narrows
                 // them again.  Where windows are cut never changes the text (the sharded and 37-column-window tests rely on it).
+                // (by the reads a FULL window of this density would hold: the short last window of a contig says nothing)
                 int64_t nr = 0;
                 for (const StagedFile &sf : j->staged) nr += sf.n();
-                if (nr < 100000 && win_cols < ((int64_t)8 << 20)) win_cols *= 2;
-                else if (nr > 1500000 && win_cols > ((int64_t)1 << 18)) win_cols /= 2;
+                const int64_t got_cols = std::max<int64_t>(1, std::min(ce, ce_target) - cursor);
+                const double full = (double)nr / (double)got_cols * (double)win_cols;
+                if (got_cols >= win_cols / 2) {
+                    if (full < 100000 && win_cols < ((int64_t)8 << 20)) win_cols *= 2;
+                    else if (full > 1500000 && win_cols > ((int64_t)1 << 18)) win_cols /= 2;
+                }
             }
             if (pump.next_pos(tid) == INT64_MAX) {  // last reads of the contig: stop where they stop
                 int64_t me = pump.carry_max_end();

@@ -66,7 +66,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, inf_comp, inf_blocks, inf_out, inf_status, inf_bad, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
     DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
@@ -87,7 +87,6 @@ struct sta_engine {
     bool plp_legacy = false;           // STA_PLP_TILE=0: the lane-per-column kernel pair instead of the tile kernels (A/B measurements)
     bool plp_legacy_len = false;       // STA_PLP_TILE=3: only the measuring pass of the old pair (2: only its emit pass)
     void *last_out = nullptr;
-    void *inf_last = nullptr; uint64_t inf_bytes = 0;      // output of the last sta_bgzf_inflate
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;
@@ -190,7 +189,7 @@ void sta_engine_destroy(sta_engine *e)
     hipStreamSynchronize(e->stream);
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
-    DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->wfirst, &e->strip_rng, &e->inf_comp, &e->inf_blocks, &e->inf_out, &e->inf_status, &e->inf_bad, &e->offs, &e->scan_tmp, &e->counters, &e->table,
+    DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->wfirst, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
                       &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
                       &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
     for (DevBuf *b : all) b->release();
@@ -1199,66 +1198,6 @@ int sta_fetch_output(sta_engine *e, char *host_out, uint64_t n)
     HIPCHK(hipStreamSynchronize(e->stream));
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "emit kernel");
-    return STA_OK;
-}
-
-/* ---- BGZF inflate on the device (kernels_inflate.hip) ---- */
-int sta_bgzf_inflate(sta_engine *e, const void *comp, uint64_t comp_bytes, int mem, const sta_bgzf_block *blocks, uint64_t n_blocks,
-                     void *dev_out, uint64_t out_cap, uint64_t *n_bad, uint64_t *first_bad)
-{
-    if (!e) return STA_ERR_ARG;
-    if ((!comp && comp_bytes) || (!blocks && n_blocks)) return fail(e, STA_ERR_ARG, "sta_bgzf_inflate: null input");
-    if (mem != STA_MEM_HOST && mem != STA_MEM_DEVICE) return fail(e, STA_ERR_ARG, "sta_bgzf_inflate: bad memory kind");
-    hipSetDevice(e->device);
-    uint64_t total = 0;
-    for (uint64_t i = 0; i < n_blocks; ++i) {
-        if (blocks[i].out_len > 65536 || blocks[i].out_off != total) return fail(e, STA_ERR_ARG, "sta_bgzf_inflate: block table is not a running sum of sizes <= 64 KiB");
-        total += blocks[i].out_len;
-    }
-    e->inf_bytes = 0;
-    uint8_t *out = (uint8_t *)dev_out;
-    if (dev_out) { if (out_cap < total) return fail(e, STA_ERR_ARG, "output buffer too small"); }
-    else {
-        if (e->inf_out.ensure((size_t)total + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(inflated bytes) failed");
-        out = (uint8_t *)e->inf_out.p; out_cap = total;
-    }
-    if (n_bad) *n_bad = 0;
-    if (first_bad) *first_bad = UINT64_MAX;
-    if (!n_blocks) return STA_OK;
-    const uint8_t *dcomp = (const uint8_t *)comp;
-    if (mem == STA_MEM_HOST) {
-        if (e->inf_comp.ensure((size_t)comp_bytes + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BGZF bytes) failed");
-        HIPCHK(hipMemcpyAsync(e->inf_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, e->stream));
-        dcomp = (const uint8_t *)e->inf_comp.p;
-    }
-    if (e->inf_blocks.ensure((size_t)n_blocks * sizeof(sta_bgzf_block)) || e->inf_status.ensure((size_t)n_blocks * 4 + 16) || e->inf_bad.ensure(16))
-        return fail(e, STA_ERR_HIP, "hipMalloc(block table) failed");
-    HIPCHK(hipMemcpyAsync(e->inf_blocks.p, blocks, (size_t)n_blocks * sizeof(sta_bgzf_block), hipMemcpyHostToDevice, e->stream));
-    const unsigned long long init[2] = { 0ull, ~0ull };
-    HIPCHK(hipMemcpyAsync(e->inf_bad.p, init, sizeof init, hipMemcpyHostToDevice, e->stream));
-    {
-        ProfScope ps(e, "bgzf_inflate");
-        sta_launch_bgzf_inflate(e->stream, dcomp, comp_bytes, (const sta_bgzf_block *)e->inf_blocks.p, n_blocks, out, out_cap, (uint32_t *)e->inf_status.p, (unsigned long long *)e->inf_bad.p);
-    }
-    unsigned long long res[2] = { 0, 0 };
-    HIPCHK(hipMemcpyAsync(res, e->inf_bad.p, sizeof res, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    hipError_t le = hipGetLastError();
-    if (le != hipSuccess) return hipfail(e, le, "k_bgzf_inflate");
-    e->inf_last = out; e->inf_bytes = total;
-    if (n_bad) *n_bad = res[0];
-    if (first_bad) *first_bad = res[0] ? res[1] : UINT64_MAX;
-    if (res[0]) return fail(e, STA_ERR_IO, "a BGZF block failed to inflate (malformed DEFLATE data, or its size / CRC-32 does not match the trailer)");
-    return STA_OK;
-}
-
-int sta_fetch_inflated(sta_engine *e, void *host_dst, uint64_t bytes)
-{
-    if (!e || (!host_dst && bytes)) return STA_ERR_ARG;
-    hipSetDevice(e->device);
-    if (bytes > e->inf_bytes || !e->inf_last) return fail(e, STA_ERR_ARG, "fetch larger than the inflated output");
-    if (bytes) HIPCHK(hipMemcpyAsync(host_dst, e->inf_last, (size_t)bytes, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
     return STA_OK;
 }
 

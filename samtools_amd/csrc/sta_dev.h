@@ -148,8 +148,3 @@ void sta_launch_cons_colpos(hipStream_t s, const cons::Win &w);
 void sta_launch_cons_walk(hipStream_t s, const cons::Win &w, const cons::Par &o, int64_t n_list, bool so_words);
 void sta_launch_cons_col(hipStream_t s, const cons::Win &w, const cons::Par &o, const cons::Tables *t, int64_t n_cols);
 void sta_launch_cons_text(hipStream_t s, const cons::Win &w, const cons::Par &o, int64_t n_cols);
-
-// kernels_inflate.hip: BGZF blocks inflated on the device, one block per lane
-struct sta_bgzf_block;
-void sta_launch_bgzf_inflate(hipStream_t s, const uint8_t *comp, uint64_t comp_bytes, const sta_bgzf_block *blocks, uint64_t n_blocks,
-                             uint8_t *out, uint64_t out_cap, uint32_t *status, unsigned long long *bad /* [0] = failed blocks, [1] = first failed index */);

@@ -1,11 +1,4 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/dbg
-for ov in 0 4 8 16; do
-  STA_BAQ_OVERLAP=$ov timeout 300 python bench.py --workload mpileup30 --steps 5 --warmup 2 --no-pmc > gpurun_out/dbg/bench_ov$ov.json 2> gpurun_out/dbg/bench_ov$ov.err
-  echo "overlap $ov rc=$?"; tail -1 gpurun_out/dbg/bench_ov$ov.json | python -c 'import sys,json
-try:
-    d=json.loads(sys.stdin.read()); print(round(d["value"]), round(d["ms_per_step"],3), {k: round(v,3) for k,v in list(d["kernels_ms_per_step"].items())[:5]}, (d.get("parity_check") or {}).get("identical"))
-except Exception as e: print("nojson", e)'
-done
-STA_BAQ_OVERLAP=8 STA_BAQ_DEC=1 timeout 300 python bench.py --workload mpileup30 --steps 5 --warmup 2 --no-pmc --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json
-d=json.loads(sys.stdin.read()); print("dec1 ov8", round(d["value"]), round(d["ms_per_step"],3))'
+mkdir -p gpurun_out/r03g
+E2E_QUICK=1 E2E_THREADS=16/4,24/4 timeout 400 python scripts/e2e_big.py 8 4375000 /dev/shm/sta_e2e30 > gpurun_out/r03g/e2e_30x.log 2>&1; tail -12 gpurun_out/r03g/e2e_30x.log | cut -c1-420
+for n in 1 2; do echo "STA_DEV_THREADS=$n"; STA_DEV_THREADS=$n STA_IO_THREADS=16 STA_STAGE_THREADS=4 STA_DRIVER_TIMING=1 samtools_amd/bin/samtools-amd mpileup -f /dev/shm/sta_e2e30/big.fa /dev/shm/sta_e2e30/big.bam 2>&1 >/dev/null | tail -1 | cut -c1-400; STA_DEV_THREADS=$n STA_IO_THREADS=16 STA_STAGE_THREADS=4 STA_DRIVER_TIMING=1 samtools_amd/bin/samtools-amd mpileup -B -f /dev/shm/sta_e2e30/big.fa /dev/shm/sta_e2e30/big.bam 2>&1 >/dev/null | tail -1 | cut -c1-400; done

@@ -95,8 +95,7 @@ def test_ctypes_mirror_matches_the_header(tmp_path):
     names = [("sta_reads", _capi.Reads), ("sta_window", _capi.Window), ("sta_mplp_params", _capi.MplpParams),
              ("sta_depth_params", _capi.DepthParams), ("sta_plan_info", _capi.PlanInfo), ("sta_kernel_time", _capi.KernelTime),
              ("sta_glf_params", _capi.GlfParams), ("sta_glf_col", _capi.GlfCol), ("sta_calmd_params", _capi.CalmdParams),
-             ("sta_cons_params", _capi.ConsParams), ("sta_cons_col", _capi.ConsCol), ("sta_cons_info", _capi.ConsInfo),
-             ("sta_bgzf_block", _capi.BgzfBlock)]
+             ("sta_cons_params", _capi.ConsParams), ("sta_cons_col", _capi.ConsCol), ("sta_cons_info", _capi.ConsInfo)]
     src = tmp_path / "sz.c"
     body = "".join('printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n, _ in names)
     body += 'printf("off_window_files %zu\\n", offsetof(sta_window, files));\nprintf("off_mplp_flag %zu\\n", offsetof(sta_mplp_params, flag));\n'

@@ -19,7 +19,7 @@ bool driver_out_is_borrowed(FILE *f) { return f == stdout || (t_capture && f == 
 int dev_threads_from_env()
 {
     const char *e = getenv("STA_DEV_THREADS");
-    const int n = e ? atoi(e) : 2;
+    const int n = e ? atoi(e) : 1;      // measured (profiles/r03_e2e_*.log): the drivers are producer-bound, a second engine buys nothing and doubles the BAQ slab start-up
     return n < 1 ? 1 : (n > 4 ? 4 : n);
 }
 size_t pipe_slots_from_env(int n_dev)

@@ -212,8 +212,10 @@ struct Runner {
                 for (const StagedFile &sf : j->staged) nr += sf.n();
                 const int64_t got_cols = std::max<int64_t>(1, std::min(ce, ce_target) - cursor);
                 const double full = (double)nr / (double)got_cols * (double)win_cols;
+                static const bool trace = getenv("STA_WINDOW_TRACE") != nullptr;
+                if (trace) fprintf(stderr, "[window] tid %d [%lld, %lld) target %lld reads %lld win_cols %lld full %.0f\n", tid, (long long)cursor, (long long)ce, (long long)ce_target, (long long)nr, (long long)win_cols, full);
                 if (got_cols >= win_cols / 2) {
-                    if (full < 100000 && win_cols < ((int64_t)8 << 20)) win_cols *= 2;
+                    if (full < 20000 && win_cols < ((int64_t)8 << 20)) win_cols *= 2;          // below ~3x depth
                     else if (full > 1500000 && win_cols > ((int64_t)1 << 18)) win_cols /= 2;
                 }
             }

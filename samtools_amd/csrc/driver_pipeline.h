@@ -163,7 +163,7 @@ private:
     bool timing_ = false; double t0_ = 0, t_decode_wait_ = 0, t_stage_copy_ = 0, t_fill_ = 0, t_slot_ = 0, t_wait_ = 0, t_dev_ = 0, t_wr_ = 0; unsigned long long n_jobs_ = 0;
 };
 
-// The device side of a driver: n engines (default 2, STA_DEV_THREADS), each on its own non-blocking stream, one per device thread
+// The device side of a driver: n engines (default 1; STA_DEV_THREADS=2..4), each on its own non-blocking stream, one per device thread
 // of the WinPipe.  While one engine runs the kernels of a window the other copies its window in or its text out.
 struct DevEngines {
     std::vector<sta_engine *> eng;

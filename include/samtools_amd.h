@@ -397,6 +397,11 @@ int sta_main_consensus(int argc, char **argv);
  * window: 1 = one decoded record at a time (host_pump.h), 2 = chunk slices decoded on `threads` parser threads
  * (host_chunk.h); both lanes must give the same checksum.  Returns 0, or <0 on error. */
 int sta_io_scan(const char *path, int threads, int stage, uint64_t *n_records, uint64_t *checksum);
+/* The records of one region ("chr", "chr:beg-end") of one file as a `-r` run reads them (stands where sam_itr_querys stands at
+ * bam_plcmd.c:550 / bam2depth.c:961-975): with use_index != 0 and a .bai beside the BAM the reader starts at the linear
+ * index's virtual offset for the region start and stops at the first record beyond the region; otherwise it filters the whole
+ * file.  Same record count and checksum either way; *used_index = 1 when the index was used.  Host only. */
+int sta_io_scan_region(const char *path, const char *region, int threads, int use_index, uint64_t *n_records, uint64_t *checksum, int *used_index);
 /* Text of an 'f' / 'd' aux value as `mpileup --output-extra TAG` prints it: HTSlib's kputd (bam_plcmd.c:838-840), which is not
  * printf("%g") -- six significant digits, half rounded UP on the truncated decimal expansion inside [0.0001, 999999], "%g"
  * outside.  Host only.  Returns the length written (NUL-terminated), or -1 when cap is too small. */

@@ -184,6 +184,7 @@ _PROTOS = {
     "sta_cons_entries_run": (C.c_int, [_P, C.POINTER(ConsInfo)]),
     "sta_fetch_cons_entries": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "sta_io_scan": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "sta_io_scan_region": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "sta_format_aux_float": (C.c_int, [C.c_double, C.c_char_p, C.c_int]),
 }
 EXPORTED_SYMBOLS = sorted(_PROTOS)
@@ -237,6 +238,15 @@ def main_capture(sub, args):
         if buf:
             lib.sta_capture_free(buf)
     return rc, data
+
+
+def io_scan_region(path, region, threads=0, use_index=True):
+    """(records, checksum, used_index) of one region of a BAM, read the way a `-r` run reads it; needs no device."""
+    n = C.c_uint64(0); h = C.c_uint64(0); u = C.c_int(0)
+    rc = lib.sta_io_scan_region(path.encode(), region.encode(), threads, 1 if use_index else 0, C.byref(n), C.byref(h), C.byref(u))
+    if rc != 0:
+        raise RuntimeError("sta_io_scan_region(%s, %s) failed: %d" % (path, region, rc))
+    return n.value, h.value, bool(u.value)
 
 
 def main_depth(args):

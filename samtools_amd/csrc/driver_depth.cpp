@@ -34,6 +34,7 @@ struct DRunner {
     int64_t window_cols = 1 << 20, max_reads = 4 << 20;
     std::unique_ptr<WinPipe> pipe;      // producer (this thread) -> device thread -> writer thread (driver_pipeline.h)
     std::vector<std::vector<StagedFile>> no_reads_d;   // per engine: read-less windows; its device thread only
+    bool shard_done = false;            // the block's last column has been passed: the rest of the input is not read
     int64_t win_cols = 0; bool adaptive_windows = true;   // columns of the next data window (widened for sparse input unless STA_WINDOW_COLS fixes it)
     Shard shard;                        // STA_SHARD=rank/world: this rank's block of the columns (driver_shard.h)
     std::vector<int64_t> lin0;          // linear coordinate of every contig's first column (no region)
@@ -110,7 +111,10 @@ struct DRunner {
             if (!started && !pump.has_carry()) cursor = std::max(cursor, pump.next_pos(tid));
             if (!win_cols) win_cols = window_cols;
             int64_t ce_target = std::min(cursor + win_cols, stop);
-            if (ce_target <= cursor) { pump.skip_to(tid, cursor, INT64_MAX, window_cols); pump.drop_tid_carry(); break; }
+            if (ce_target <= cursor) {
+                if (shard.on && !has_reg) { shard_done = true; pump.drop_tid_carry(); break; }      // nothing behind a block is this rank's: stop reading
+                pump.skip_to(tid, cursor, INT64_MAX, window_cols); pump.drop_tid_carry(); break;
+            }
             WinJob *j = pipe->acquire();
             int64_t ce;
             { const double t0 = WinPipe::now(); ce = pump.fill_staged(tid, cursor, ce_target, j->staged); pipe->add_fill_time(WinPipe::now() - t0); double dw, sc; pump.producer_split(&dw, &sc); pipe->set_producer_split(dw, sc); }
@@ -190,8 +194,10 @@ struct DRunner {
                 next_full = tid < 0 ? h->nref() : tid + 1;
             }
             if (tid < 0) break;
+            if (shard.on && !has_reg && lin0[(size_t)tid] >= shard.E) break;       // every later contig lies behind this rank's block
             if (has_reg && tid == tid0) did_tid0 = true;
             if (process_tid(pump, tid, mode) < 0) { if (pump.error()) break; pipe->drain(); return 1; }
+            if (shard_done) break;
         }
         if (pump.error()) {
             pipe->drain();
@@ -278,6 +284,7 @@ extern "C" int sta_main_depth(int argc, char **argv)
             if (i == 0) { run.has_reg = true; run.tid0 = t; run.beg0 = b; run.end0 = e; }
         }
     }
+    seek_readers_by_index(run.readers, fns, *run.h, run.has_reg, run.tid0, run.beg0, run.end0);      // region / sharded runs start at their first column
     if (!out_file.empty()) {
         run.out = fopen(out_file.c_str(), "w");
         if (!run.out) { fprintf(stderr, "samtools depth: Cannot open \"%s\" for writing.\n", out_file.c_str()); return 1; }

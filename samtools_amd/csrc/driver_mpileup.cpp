@@ -77,6 +77,7 @@ struct Runner {
     int loaded_ref_tid = -2;
     int64_t loaded_ref_len = INT64_MAX;               // length of the FASTA contig (INT64_MAX: none, no length filter)
     std::vector<int> dev_ref_tid;                     // per engine: contig whose sequence is in its HBM; its device thread only
+    bool shard_done = false;            // the block's last column has been passed: the rest of the input is not read
     int64_t win_cols = 0; bool adaptive_windows = true;  // columns of the next data window (widened for sparse input unless STA_WINDOW_COLS fixes it)
     Shard shard;                                      // STA_SHARD=rank/world: this rank's block of the columns (driver_shard.h)
     std::vector<int64_t> lin0;                        // linear coordinate of every contig's first column (no region)
@@ -195,6 +196,7 @@ struct Runner {
             if (!started) cursor = std::max(cursor, std::min(pump.carry_next_covered(cursor), pump.next_pos(tid)));   // skip uncovered gap
             int64_t ce_target = std::min(cursor + win_cols, stop);
             if (ce_target <= cursor) {              // past the region / block end: pass over the rest of this contig
+                if (shard.on && !has_reg) { shard_done = true; pump.drop_tid_carry(); break; }      // ... or stop reading altogether: nothing behind a block is this rank's
                 pump.skip_to(tid, cursor, INT64_MAX, conf.window_cols);
                 pump.drop_tid_carry();
                 break;
@@ -326,8 +328,10 @@ struct Runner {
                 next_full = tid < 0 ? h->nref() : tid + 1;
             }
             if (tid < 0) break;
+            if (shard.on && !has_reg && lin0[(size_t)tid] >= shard.E) break;       // every later contig lies behind this rank's block
             if (has_reg && tid == tid0) did_tid0 = true;
             if (process_tid(pump, tid, mode) < 0) { if (pump.error()) break; pipe->drain(); return 1; }
+            if (shard_done) break;
         }
         if (pump.error()) {
             pipe->drain();
@@ -499,6 +503,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
             if (i == 0) { run.has_reg = true; run.tid0 = t; run.beg0 = b; run.end0 = e; }
         }
     }
+    seek_readers_by_index(run.readers, fns, *run.h, run.has_reg, run.tid0, run.beg0, run.end0);      // region / sharded runs start at their first column
     fprintf(stderr, "[mpileup] %d samples in %d input files\n", (int)sm.sm.size(), (int)fns.size());
     if (!conf.output_fname.empty()) {
         run.out = fopen(conf.output_fname.c_str(), "w");

@@ -15,6 +15,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <memory>
+#include <string>
+#include <algorithm>
+#include "host_io.h"
 
 namespace sta {
 
@@ -57,6 +61,43 @@ struct Shard {
         if (*pe < *pb) *pe = *pb;
     }
 };
+
+// Index-driven start of a region or sharded run (the reference: sam_itr_querys at bam_plcmd.c:550, bam2depth.c:961-975).
+// Every input with a .bai beside it starts reading at the linear index's offset for the first column this run needs instead of
+// inflating and parsing the file's prefix; a region start needs no margin (records that do not overlap the region are filtered
+// anyway), a block start inside a contig steps back `margin` columns so that the reads, mates and lookahead records the
+// unsharded run carries into the block are all read.  STA_NO_INDEX=1 switches it off.  Returns the number of inputs that seeked.
+inline int seek_readers_by_index(std::vector<std::unique_ptr<AlnReader>> &readers, const std::vector<std::string> &paths, const Header &h,
+                                 bool has_reg, int tid0, int64_t beg0, int64_t end0, int64_t margin = (int64_t)1 << 20)
+{
+    if (getenv("STA_NO_INDEX")) return 0;
+    Shard sh = Shard::from_env();
+    int tid = -1; int64_t pos = 0;
+    if (has_reg) { tid = tid0; pos = beg0; }
+    if (sh.on) {
+        int64_t total = 0;
+        if (has_reg) total = std::max<int64_t>(0, std::min(end0, h.lens[(size_t)tid0]) - beg0);
+        else for (int t = 0; t < h.nref(); ++t) total += h.lens[(size_t)t];
+        sh.set_total(total);
+        if (has_reg) pos = std::max(beg0, beg0 + sh.B - margin);
+        else {
+            int64_t lin = 0; tid = -1;
+            for (int t = 0; t < h.nref(); ++t) { if (sh.B < lin + h.lens[(size_t)t]) { tid = t; pos = std::max<int64_t>(0, sh.B - lin - margin); break; } lin += h.lens[(size_t)t]; }
+            if (tid < 0) return 0;                         // an empty block behind the last contig: nothing to find
+            if (tid == 0 && pos == 0) return 0;            // the first block starts where the file starts
+        }
+    }
+    if (tid < 0) return 0;
+    int n = 0;
+    for (size_t i = 0; i < readers.size() && i < paths.size(); ++i) {
+        if (!readers[i]->is_bam()) continue;
+        std::unique_ptr<BaiIndex> ix = BaiIndex::load_for(paths[i]);
+        if (!ix) continue;
+        const uint64_t v = ix->start_offset(tid, pos);
+        if (readers[i]->seek_voffset(v)) ++n;
+    }
+    return n;
+}
 
 // where a driver writes when the command names no -o file: stdout, or the memory stream of sta_main_capture (driver_capture.cpp)
 FILE *driver_default_out();

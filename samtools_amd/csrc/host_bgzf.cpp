@@ -241,4 +241,16 @@ std::unique_ptr<ByteSource> ByteSource::open(const std::string &path, int thread
     return std::unique_ptr<ByteSource>(new GzSource(g));
 }
 
+std::unique_ptr<ByteSource> ByteSource::open_bgzf_at(const std::string &path, int threads, uint64_t coffset, std::string *err)
+{
+    if (threads <= 0) threads = io_default_threads();
+    FILE *fp = path == "-" ? nullptr : fopen(path.c_str(), "rb");
+    if (!fp) { if (err) *err = "failed to open " + path; return nullptr; }
+    setvbuf(fp, nullptr, _IOFBF, 1 << 20);
+    uint8_t h[64];
+    const size_t n = fread(h, 1, sizeof h, fp);
+    if (!looks_like_bgzf(h, n) || fseeko(fp, (off_t)coffset, SEEK_SET) != 0) { fclose(fp); if (err) *err = "cannot seek in " + path; return nullptr; }
+    return std::unique_ptr<ByteSource>(new BgzfSource(fp, threads));
+}
+
 }  // namespace sta

@@ -20,6 +20,9 @@ public:
     virtual bool failed() const = 0;
     // threads <= 0: $STA_IO_THREADS, else 4..8 depending on the machine
     static std::unique_ptr<ByteSource> open(const std::string &path, int threads, std::string *err);
+    // a BGZF file from the block that starts at compressed offset `coffset` on (the upper 48 bits of a BAI virtual offset);
+    // nullptr when the file is not BGZF or the offset cannot be reached
+    static std::unique_ptr<ByteSource> open_bgzf_at(const std::string &path, int threads, uint64_t coffset, std::string *err);
 };
 
 int io_default_threads();

@@ -120,6 +120,9 @@ void ChunkReader::work()
             o += used;
             r.rlen = 0;
             for (uint32_t cg : r.cigar) { int op = (int)(cg & 0xf); if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) r.rlen += (cg >> 4); }
+            // (a record beyond the region of a sorted file: the groups behind this one are not cut any more; the ones already
+            // in flight filter their records as before)
+            if (rd_->past_region(r) && !io_end_.load()) { std::lock_guard<std::mutex> g2(out_m_); io_status_.store(0); io_end_.store(true); cv_out_.notify_all(); }
             if (!rd_->in_region(r)) continue;
             c->append(r);
         }

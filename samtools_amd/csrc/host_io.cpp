@@ -39,6 +39,7 @@ struct AlnReader::Impl {
     std::vector<std::string> want;   // aux tags to format (--output-extra)
 
     std::unique_ptr<ByteSource> src;
+    std::string path; int threads = 0;       // for seek_voffset(): the source is reopened at a block offset
     bool is_bam = false;
     std::vector<uint8_t> buf; size_t bp = 0, bl = 0; bool eof = false;
     std::string line; bool have_line = false;
@@ -153,6 +154,7 @@ std::unique_ptr<AlnReader> AlnReader::open(const std::string &path, std::string 
     Impl &im = *r->p_;
     im.src = ByteSource::open(path, threads, err);
     if (!im.src) return nullptr;
+    im.path = path; im.threads = threads;
     im.fill();
     if (im.bl >= 4 && memcmp(im.buf.data(), "BAM\1", 4) == 0) {
         im.is_bam = true; im.bp = 4;
@@ -185,6 +187,66 @@ std::unique_ptr<AlnReader> AlnReader::open(const std::string &path, std::string 
         header_from_text(r->hdr_, true);
     }
     return r;
+}
+
+bool AlnReader::seek_voffset(uint64_t voffset)
+{
+    Impl &im = *p_;
+    if (!im.is_bam || im.started || voffset == 0 || voffset == UINT64_MAX) return false;
+    std::string err;
+    std::unique_ptr<ByteSource> at = ByteSource::open_bgzf_at(im.path, im.threads, voffset >> 16, &err);
+    if (!at) return false;
+    im.src = std::move(at);
+    im.bp = im.bl = 0; im.eof = false;
+    size_t skip = (size_t)(voffset & 0xffff);
+    uint8_t tmp[4096];
+    while (skip) { const size_t k = im.read(tmp, skip < sizeof tmp ? skip : sizeof tmp); if (!k) return false; skip -= k; }
+    return true;
+}
+
+std::unique_ptr<BaiIndex> BaiIndex::load_for(const std::string &bam_path)
+{
+    std::vector<std::string> cand = { bam_path + ".bai" };
+    if (bam_path.size() > 4 && bam_path.compare(bam_path.size() - 4, 4, ".bam") == 0) cand.push_back(bam_path.substr(0, bam_path.size() - 4) + ".bai");
+    for (const std::string &p : cand) {
+        FILE *fp = fopen(p.c_str(), "rb");
+        if (!fp) continue;
+        std::unique_ptr<BaiIndex> ix(new BaiIndex());
+        bool ok = false;
+        auto rd = [&](void *d, size_t n) { return fread(d, 1, n, fp) == n; };
+        char magic[4]; int32_t n_ref = 0;
+        if (rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0 && n_ref < (1 << 26)) {
+            ok = true;
+            ix->lin_.resize((size_t)n_ref);
+            for (int32_t t = 0; t < n_ref && ok; ++t) {
+                int32_t n_bin = 0;
+                if (!rd(&n_bin, 4) || n_bin < 0) { ok = false; break; }
+                for (int32_t b = 0; b < n_bin && ok; ++b) {
+                    uint32_t bin; int32_t n_chunk = 0;
+                    if (!rd(&bin, 4) || !rd(&n_chunk, 4) || n_chunk < 0 || fseeko(fp, (off_t)n_chunk * 16, SEEK_CUR) != 0) ok = false;
+                }
+                int32_t n_intv = 0;
+                if (!ok || !rd(&n_intv, 4) || n_intv < 0) { ok = false; break; }
+                ix->lin_[(size_t)t].resize((size_t)n_intv);
+                if (n_intv && !rd(ix->lin_[(size_t)t].data(), (size_t)n_intv * 8)) ok = false;
+            }
+        }
+        fclose(fp);
+        if (ok) return ix;
+    }
+    return nullptr;
+}
+
+uint64_t BaiIndex::start_offset(int tid, int64_t pos) const
+{
+    if (tid < 0 || (size_t)tid >= lin_.size()) return 0;
+    if (pos < 0) pos = 0;
+    // the first non-empty window at or after pos of this reference, else the first of a later one
+    for (size_t t = (size_t)tid; t < lin_.size(); ++t) {
+        const std::vector<uint64_t> &io = lin_[t];
+        for (size_t k = t == (size_t)tid ? (size_t)(pos >> 14) : 0; k < io.size(); ++k) if (io[k]) return io[k];
+    }
+    return UINT64_MAX;
 }
 
 static void finish_rec(Rec &r)
@@ -519,6 +581,7 @@ void AlnReader::parse_ahead()
             Rec &r = b.r[b.n];
             status = next_raw(r);
             if (status <= 0) break;
+            if (past_region(r)) { status = 0; break; }    // sorted input: nothing further can overlap the region
             if (has_reg_ && (r.tid != rtid_ || r.pos >= rend_ || r.endpos() <= rbeg_)) continue;
             r.accepted = false;
             ++b.n;

@@ -63,6 +63,12 @@ public:
     int raw_group(std::vector<uint8_t> &out, size_t target, int64_t *n_records);
     int parse_raw(const uint8_t *p, size_t avail, size_t *used, Rec &r, std::string &scratch) const;
     bool is_bam() const;
+    // Start reading at a BAI virtual offset (coffset << 16 | offset inside the inflated block) instead of behind the header:
+    // what sam_itr_querys does with the index for a region (bam_plcmd.c:550, bam2depth.c:961-975).  Only before the first
+    // record has been asked for, BGZF BAM only; false (and nothing changes) otherwise.
+    bool seek_voffset(uint64_t voffset);
+    // a record beyond the region in a position-sorted file: nothing further can match (next() / the chunk lane stop there)
+    bool past_region(const Rec &r) const { return has_reg_ && r.tid >= 0 && (r.tid > rtid_ || (r.tid == rtid_ && r.pos >= rend_)); }
     bool has_region() const { return has_reg_; }
     bool in_region(const Rec &r) const { return !has_reg_ || !(r.tid != rtid_ || r.pos >= rend_ || r.endpos() <= rbeg_); }
     struct Impl;
@@ -77,6 +83,20 @@ private:
 
 // hts_parse_reg-like ("chr", "chr:beg", "chr:beg-end", thousands commas); 0-based half open
 bool parse_region(const Header &h, const std::string &reg, int *tid, int64_t *beg, int64_t *end);
+
+// The linear index of a BAI file (SAM spec 5.2): per reference, the smallest virtual offset of any alignment overlapping each
+// 16 kbp window.  Stands where hts_idx_load + the iterator's start offset stand for region runs; bins are skipped (a sorted
+// scan from the linear offset reads at most one window of extra records).
+class BaiIndex {
+public:
+    // <bam>.bai, else the .bam suffix replaced by .bai; nullptr when there is none or it is malformed
+    static std::unique_ptr<BaiIndex> load_for(const std::string &bam_path);
+    // virtual offset to start reading from so that every alignment overlapping [pos, ...) of tid -- and everything after -- is
+    // seen; 0 = unknown (read from the start); UINT64_MAX = nothing at or beyond (tid, pos)
+    uint64_t start_offset(int tid, int64_t pos) const;
+private:
+    std::vector<std::vector<uint64_t>> lin_;
+};
 
 // whole-file FASTA (faidx stand-in)
 class Fasta {

@@ -115,3 +115,34 @@ extern "C" int sta_io_scan(const char *path, int threads, int stage, uint64_t *n
     if (checksum) *checksum = f.h;
     return 0;
 }
+
+// sta_io_scan for one region of one file, the way a `-r` run reads it: with a BAI beside the BAM the reader starts at the linear
+// index's offset for the region start and stops at the first record beyond the region; without one it filters the whole file.
+// Both must deliver the same records (count + checksum).  *used_index says which happened.
+extern "C" int sta_io_scan_region(const char *path, const char *region, int threads, int use_index, uint64_t *n_records, uint64_t *checksum, int *used_index)
+{
+    if (!path || !region) return -1;
+    std::string err;
+    std::unique_ptr<AlnReader> rd = AlnReader::open(path, &err, threads);
+    if (!rd) return -1;
+    int tid; int64_t beg, end;
+    if (!parse_region(rd->header(), region, &tid, &beg, &end)) return -3;
+    rd->set_region(tid, beg, end);
+    bool used = false;
+    if (use_index) {
+        std::unique_ptr<BaiIndex> ix = BaiIndex::load_for(path);
+        if (ix) {
+            const uint64_t v = ix->start_offset(tid, beg);
+            if (v == UINT64_MAX) { if (n_records) *n_records = 0; if (checksum) *checksum = Fnv().h; if (used_index) *used_index = 1; return 0; }
+            used = rd->seek_voffset(v);
+        }
+    }
+    Fnv f; uint64_t n = 0;
+    Rec r; int st;
+    while ((st = rd->next(r)) > 0) { fold(f, r); ++n; }
+    if (st < 0) return -2;
+    if (n_records) *n_records = n;
+    if (checksum) *checksum = f.h;
+    if (used_index) *used_index = used ? 1 : 0;
+    return 0;
+}

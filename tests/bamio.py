@@ -132,3 +132,74 @@ def bam_filter(src, dst, require=0, exclude=0, level=1):
             fo.write(_bgzf_block(data[k:k + 0xff00], level))
         fo.write(_EOF)
     return dst
+
+
+def write_bai(bam_path, bai_path=None):
+    """A BAI index (SAM spec 5.2: bins, chunks, 16 kbp linear index) for any coordinate-sorted BGZF BAM -- the test stand-in for
+    `samtools index`.  Walks the BGZF blocks for the virtual offsets and the records for positions."""
+    raw_file = open(bam_path, "rb").read()
+    # blocks: compressed start, inflated start, inflated size
+    blocks, o, u, parts = [], 0, 0, []
+    while o < len(raw_file):
+        xlen = struct.unpack("<H", raw_file[o + 10:o + 12])[0]
+        bsize = None
+        x = raw_file[o + 12:o + 12 + xlen]; k = 0
+        while k + 4 <= xlen:
+            sl = struct.unpack("<H", x[k + 2:k + 4])[0]
+            if x[k:k + 2] == b"BC": bsize = struct.unpack("<H", x[k + 4:k + 6])[0] + 1
+            k += 4 + sl
+        data = zlib.decompress(raw_file[o + 12 + xlen:o + bsize - 8], -15)
+        blocks.append((o, u, len(data))); parts.append(data)
+        o += bsize; u += len(data)
+    raw = b"".join(parts)
+    starts = [b[1] for b in blocks]
+    import bisect
+
+    def voff(upos):
+        i = bisect.bisect_right(starts, upos) - 1
+        while i + 1 < len(blocks) and blocks[i][2] == 0: i += 1
+        if upos >= blocks[i][1] + blocks[i][2] and i + 1 < len(blocks): i += 1
+        return blocks[i][0] << 16 | (upos - blocks[i][1])
+
+    l_text = struct.unpack("<i", raw[4:8])[0]
+    p = 8 + l_text
+    n_ref = struct.unpack("<i", raw[p:p + 4])[0]; p += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack("<i", raw[p:p + 4])[0]; p += 4 + l_name + 4
+    bins = [dict() for _ in range(n_ref)]
+    lin = [dict() for _ in range(n_ref)]
+    n_no_coor = 0
+    while p < len(raw):
+        bs = struct.unpack("<i", raw[p:p + 4])[0]
+        ref, pos, l_rn, mapq, bn, n_cig, flag, l_seq = struct.unpack("<iiBBHHHi", raw[p + 4:p + 24])
+        if ref < 0:
+            n_no_coor += 1
+        else:
+            cig = struct.unpack("<%dI" % n_cig, raw[p + 36 + l_rn:p + 36 + l_rn + 4 * n_cig]) if n_cig else ()
+            rlen = sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3, 7, 8))
+            end = pos + (rlen if rlen > 0 and not (flag & 4) else 1)
+            v0, v1 = voff(p), voff(p + 4 + bs)
+            b = _reg2bin(max(pos, 0), max(end, 1))
+            ch = bins[ref].setdefault(b, [])
+            if ch and ch[-1][1] >> 16 == v0 >> 16: ch[-1][1] = v1          # same block: extend the chunk
+            else: ch.append([v0, v1])
+            for w in range(max(pos, 0) >> 14, ((max(end, 1) - 1) >> 14) + 1):
+                if w not in lin[ref] or v0 < lin[ref][w]: lin[ref][w] = v0
+        p += 4 + bs
+    out = [b"BAI\1", struct.pack("<i", n_ref)]
+    for t in range(n_ref):
+        out.append(struct.pack("<i", len(bins[t])))
+        for b in sorted(bins[t]):
+            out.append(struct.pack("<Ii", b, len(bins[t][b])))
+            for v0, v1 in bins[t][b]: out.append(struct.pack("<QQ", v0, v1))
+        n_intv = max(lin[t]) + 1 if lin[t] else 0
+        out.append(struct.pack("<i", n_intv))
+        prev = 0
+        for w in range(n_intv):                         # empty windows take the offset of the next filled one's predecessor (as samtools fills them)
+            prev = lin[t].get(w, prev)
+            out.append(struct.pack("<Q", prev))
+    out.append(struct.pack("<Q", n_no_coor))
+    bai_path = bai_path or bam_path + ".bai"
+    with open(bai_path, "wb") as fo:
+        fo.write(b"".join(out))
+    return bai_path

@@ -1,0 +1,60 @@
+"""Index-driven region reads (the host side of `-r` / sharded runs; sam_itr_querys at bam_plcmd.c:550): with a .bai beside the BAM
+the reader starts at the linear index's virtual offset and stops behind the region; it must deliver exactly the records a scan
+of the whole file with the region filter delivers.  No device needed.  The BAI writer is test infrastructure (tests/bamio.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from bamio import sam_to_bam, write_bai
+from synth import synth_ref, synth_reads, write_sam
+
+
+@pytest.fixture(scope="module")
+def bam(tmp_path_factory):
+    d = tmp_path_factory.mktemp("bai")
+    # three contigs, the second one empty; small BGZF blocks so that records straddle blocks and offsets inside blocks matter
+    sam = str(d / "x.sam")
+    parts = []
+    for name, n, seed in (("c1", 300000, 1), ("c2", 50000, 2), ("c3", 200000, 3)):
+        ref = synth_ref(n, seed=seed)
+        rd = synth_reads(ref, depth=0 if name == "c2" else 4, read_len=150, seed=seed + 10, indel_rate=0.02) if name != "c2" else None
+        parts.append((name, n, rd))
+    with open(sam, "w") as fh:
+        fh.write("@HD\tVN:1.6\tSO:coordinate\n")
+        for name, n, _ in parts:
+            fh.write("@SQ\tSN:%s\tLN:%d\n" % (name, n))
+        for name, n, rd in parts:
+            if rd is None:
+                continue
+            tmp = str(d / "t.sam")
+            write_sam(tmp, rd, name, n)
+            for line in open(tmp):
+                if not line.startswith("@"):
+                    fh.write(line)
+    b = sam_to_bam(sam, str(d / "x.bam"), block=7000)
+    write_bai(b)
+    return b
+
+
+REGIONS = ["c1", "c1:1-1000", "c1:150000-150100", "c1:299000-300000", "c2", "c3", "c3:1-50", "c3:100000-199999", "c1:16384-16385", "c3:199990"]
+
+
+@pytest.mark.parametrize("reg", REGIONS)
+def test_indexed_region_read_equals_filtered_full_scan(bam, reg):
+    from samtools_amd import _capi
+    n_ix, h_ix, used = _capi.io_scan_region(bam, reg, threads=2, use_index=True)
+    n_fs, h_fs, used_fs = _capi.io_scan_region(bam, reg, threads=2, use_index=False)
+    assert not used_fs
+    assert (n_ix, h_ix) == (n_fs, h_fs)
+    if reg != "c1" and not reg.startswith("c1:1-") and reg != "c2":
+        assert used            # (a region at the very start of the file has offset = the first record: seeking is still "used")
+    if reg == "c2":
+        assert n_ix == 0
+
+
+def test_region_counts_match_the_generator(bam):
+    from samtools_amd import _capi
+    n_all, _, _ = _capi.io_scan_region(bam, "c3", threads=1)
+    n_part, _, _ = _capi.io_scan_region(bam, "c3:100001-100150", threads=1)
+    assert n_all > 4000 and 0 < n_part < 40

@@ -105,3 +105,42 @@ def test_two_processes_one_gather(tmp_path, product_bin, pairs, cmd):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=REPO)
     assert p.returncode == 0, p.stderr.decode()[-800:]
     assert open(outp, "rb").read() == want
+
+
+def test_four_processes_unequal_blocks_against_the_oracle(tmp_path, oracle_bin, pairs):
+    """world size 4 under torch.distributed.run (gloo, all on the box's one GPU), unequal blocks (STA_SHARD_CUTS: one cut inside a
+    mate overlap, one a column behind it, one near the end), BAM input with a .bai beside it -- every rank starts from the
+    index -- and the gathered text is compared with the ORACLE's, not with the unsharded engine."""
+    from bamio import sam_to_bam, write_bai
+    sam, fa = pairs
+    bam = sam_to_bam(sam, str(tmp_path / "p.bam"), block=20000)
+    write_bai(bam)
+    for cmd, port in ((["mpileup", "-f", fa], "29541"), (["depth", "-aa"], "29542")):
+        want = subprocess.run([oracle_bin] + cmd + [sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        outp = str(tmp_path / ("sharded_%s.txt" % cmd[0]))
+        env = dict(os.environ, STA_SHARD_BACKEND="gloo", STA_SHARD_ONE_DEVICE="1", PYTHONPATH=REPO, STA_SHARD_CUTS="30100,30101,58000")
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                            "--master-port", port, "-m", "samtools_amd.shard"] + cmd + [bam, "-o", outp],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=REPO)
+        assert p.returncode == 0, p.stderr.decode()[-800:]
+        assert open(outp, "rb").read() == want, cmd
+
+
+def test_indexed_and_unindexed_sharded_and_region_runs_agree(tmp_path, product_bin, oracle_bin, rich):
+    """a .bai beside the BAM changes where the readers start (linear index offset instead of the file's first record) and where
+    they stop, never the text: blocks, regions and both together, against the same runs with STA_NO_INDEX=1 and the oracle."""
+    from bamio import sam_to_bam, write_bai
+    sam, fa = rich
+    bam = sam_to_bam(sam, str(tmp_path / "r.bam"), block=9000)
+    write_bai(bam)
+    for cmd in (["mpileup", "-f", fa], ["depth", "-aa"]):
+        want = _run(product_bin, cmd + [sam])
+        assert subprocess.run([oracle_bin] + cmd + [sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout == want
+        for world in (3, 7):
+            assert _sharded(product_bin, cmd + [bam], world) == want
+            assert _sharded(product_bin, cmd + [bam], world, env={"STA_NO_INDEX": "1"}) == want
+        for reg in ("c1:100-20000", "c2", "c3:20000-44999", "c3:44000"):
+            rwant = subprocess.run([oracle_bin] + cmd + ["-r", reg, sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+            assert _run(product_bin, cmd + ["-r", reg, bam]) == rwant, (cmd, reg)
+            assert _run(product_bin, cmd + ["-r", reg, bam], {"STA_NO_INDEX": "1"}) == rwant, (cmd, reg)
+            assert _sharded(product_bin, cmd + ["-r", reg, bam], 2) == rwant, (cmd, reg)

@@ -46,3 +46,23 @@ def test_oracle_prints_the_same_vectors(tmp_path, oracle_bin):
         got[(int(f[1]) - 1) // 10] = f[6]
     for k, (text, want) in enumerate(VECTORS):
         assert got[k] == want, (text, got[k], want)
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_engine_cli_prints_float_tags_like_the_oracle(tmp_path, oracle_bin, product_bin):
+    """the same vectors end to end: `mpileup --output-extra XF,XD` on SAM and BAM input (f values; BAM also carries them as 'f')"""
+    from bamio import sam_to_bam
+    sam = tmp_path / "f.sam"
+    with open(sam, "w") as fh:
+        fh.write("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c\tLN:100000\n")
+        for k, (text, _) in enumerate(VECTORS):
+            fh.write("r%d\t0\tc\t%d\t60\t4M\t*\t0\t0\tACGT\tIIII\tXF:f:%s\n" % (k, 1 + 10 * k, text))
+    bam = sam_to_bam(str(sam), str(tmp_path / "f.bam"))
+    want = subprocess.run([oracle_bin, "mpileup", "--output-extra", "XF", str(sam)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    for inp in (str(sam), bam):
+        got = subprocess.run([product_bin, "mpileup", "--output-extra", "XF", inp], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert got.returncode == 0, got.stderr.decode()[-300:]
+        assert got.stdout == want

@@ -83,6 +83,7 @@ struct sta_engine {
     StaCounters ctr_h{};
     uint64_t out_bytes = 0;
     uint32_t lds_cap = 0;
+    bool len_fused = false;            // the measuring kernel also produced offsets / totals (no scan, no column statistics)
     bool have_wfirst = false;          // the plan built the per-group read index of the tile kernels
     bool plp_legacy = false;           // STA_PLP_TILE=0: the lane-per-column kernel pair instead of the tile kernels (A/B measurements)
     bool plp_legacy_len = false;       // STA_PLP_TILE=3: only the measuring pass of the old pair (2: only its emit pass)
@@ -321,17 +322,19 @@ static int push_files(sta_engine *e)
 
 static int finish_plan(sta_engine *e, int64_t ncols, sta_plan_info *info)
 {
-    {
-        ProfScope ps(e, "len_scan");
-        sta_launch_len_scan(e->stream, (const uint32_t *)e->line_len.p, (uint64_t *)e->offs.p, ncols, e->scan_tmp.p, e->scan_tmp.cap);
-    }
-    {
+    if (!e->len_fused) {
+        {
+            ProfScope ps(e, "len_scan");
+            sta_launch_len_scan(e->stream, (const uint32_t *)e->line_len.p, (uint64_t *)e->offs.p, ncols, e->scan_tmp.p, e->scan_tmp.cap);
+        }
         ProfScope ps(e, "col_stats");
         sta_launch_wave_bytes_max(e->stream, (const uint64_t *)e->offs.p, (const uint32_t *)e->line_len.p, ncols, (StaCounters *)e->counters.p);
     }
     uint64_t total = 0;
     HIPCHK(hipMemcpyAsync(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(&total, (const uint64_t *)e->offs.p + (ncols > 0 ? ncols : 0), 8, hipMemcpyDeviceToHost, e->stream));
+    // (after the tile measuring kernel the offsets are tile-relative and the window's text bytes close the tile bases)
+    const uint64_t *total_at = e->len_fused ? sta_mplp_tile_base(e->fused_status.p, ncols) + (ncols + 1023) / 1024 : (const uint64_t *)e->offs.p + (ncols > 0 ? ncols : 0);
+    HIPCHK(hipMemcpyAsync(&total, total_at, 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "kernel launch");
@@ -353,6 +356,7 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
     hipStream_t s = e->stream;
     StaCounters *ctr = (StaCounters *)e->counters.p;
     HIPCHK(hipMemsetAsync(ctr, 0, sizeof(StaCounters), s));
+    e->len_fused = false;
     const int nf = (int)e->files_h.size();
     bool has_ref = e->wd.ref != nullptr;
     bool realn = (p->flag & STA_MPLP_REALN) && has_ref;
@@ -513,11 +517,13 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
         e->have_wfirst = tile && small;
         if (e->have_wfirst) {
             if (e->wfirst.ensure((size_t)((ncols > 0 ? ncols : 1) / 64 + 2) * (size_t)(nf > 0 ? nf : 1) * 4 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(read index) failed");
+            if (e->fused_status.ensure(sta_mplp_len_status_bytes(ncols) + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(look-back words) failed");
             ProfScope ps(e, "wave_first");
-            sta_launch_wave_first(s, e->wd, (uint32_t *)e->wfirst.p);
+            sta_launch_wave_first(s, e->wd, (uint32_t *)e->wfirst.p, e->fused_status.p);
         }
         ProfScope ps(e, "mplp_len");
-        sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr, e->plp_legacy_len);
+        e->len_fused = sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr, e->plp_legacy_len,
+                                           e->have_wfirst && !e->plp_legacy ? e->fused_status.p : nullptr, (uint64_t *)e->offs.p);
     }
     return STA_OK;
 }
@@ -662,7 +668,8 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     }
     ProfScope ps(e, deep_mode == 1 ? "mplp_emit_deep" : "mplp_emit");
     sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap, deep_mode ? (int64_t *)e->strip_rng.p : nullptr,
-                         tile_cap, deep_mode, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr, e->plp_legacy);
+                         tile_cap, deep_mode, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr,
+                         e->len_fused ? sta_mplp_tile_base(e->fused_status.p, ncols) : nullptr, e->plp_legacy);
     return STA_OK;
 }
 

@@ -20,6 +20,7 @@
 //                lines exceed the LDS slice falls back to direct global byte stores.
 #include "dev_util.h"
 #include "plp_tile.h"
+#include "dev_lookback.h"
 #include <cstdlib>
 
 // seq_nt16_table (hts.c): character -> 4-bit code, 15 for anything else (a table: the switch in nt16_from_char costs ~300
@@ -298,6 +299,14 @@ __global__ void __launch_bounds__(256) k_mplp_emit(StaWinDev W, MplpDevPar P, co
 // Pointers that reach a kernel through W.files[] (a struct read from memory) are "generic" to the compiler, which then
 // emits flat_load (slower, and it couples vmcnt with lgkmcnt).  They always point to HBM: say so.
 #define GPTR(T, p) ((const __attribute__((address_space(1))) T *)(p))
+
+// Row offset of column c.  After k_mplp_len_rm the per-column offsets are relative to their measuring tile (LEN_TC columns) and
+// tbase[tile] holds the tile's place in the text (k_tile_scan); tbase == nullptr: absolute offsets (the scan launches).
+__device__ __forceinline__ uint64_t row_off(const uint64_t *__restrict__ offs, const uint64_t *__restrict__ tbase, int64_t c)
+{
+    return tbase ? offs[c] + tbase[c >> 10] : offs[c];
+}
+static_assert(LEN_TC == 1024, "row_off() shifts by the measuring tile's width");
 
 __device__ __forceinline__ int rl_i(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
 __device__ __forceinline__ uint32_t rl_u(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
@@ -598,7 +607,7 @@ __global__ void __launch_bounds__(256) k_mplp_strip_ranges(StaWinDev W, int64_t 
 }
 
 __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(4, 8))) k_mplp_emit_deep(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
-                                                        const int64_t *__restrict__ rng, char *out, uint32_t only_above)
+                                                        const int64_t *__restrict__ rng, char *out, uint32_t only_above, const uint64_t *__restrict__ tbase)
 {
     const int lane = threadIdx.x & 63;
     // (readfirstlane: the compiler cannot see that the strip index is the same for the 64 lanes; with it the strip's bounds,
@@ -618,7 +627,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
         // beside k_mplp_emit_tile: only the 64-column groups whose rows did not fit that kernel's LDS slice (a deep amplicon inside
         // an ordinary window) are written here
         const int64_t g0 = c0 & ~(int64_t)63, g1 = g0 + 64 < ncols ? g0 + 64 : ncols;
-        if (offs[g1] - offs[g0] <= (uint64_t)only_above) return;
+        if (row_off(offs, tbase, g1) - row_off(offs, tbase, g0) <= (uint64_t)only_above) return;
     }
     uint32_t *const x_off = s_off[wv][lane]; uint8_t *const x_qc = s_qc[wv][lane];
     const int nk = ncols - c0 < DEEP_STRIP ? (int)(ncols - c0) : DEEP_STRIP;
@@ -627,11 +636,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     const unsigned long long lt = (1ull << lane) - 1ull;
     // everything the strip needs that does not depend on another load is asked for here, in one round trip
     const int64_t nstrips = (ncols + DEEP_STRIP - 1) / DEEP_STRIP;
-    const uint64_t base0 = offs[c0];                               // every offset of the strip below is relative to this row start
+    const uint64_t base0 = row_off(offs, tbase, c0);               // every offset of the strip below is relative to this row start
     const int64_t apos = W.origin + p0 + lane;
     uint64_t off_a = 0, off_b = 0; uint2 ci0 = make_uint2(0u, 0u); char rc = 'N';
     if (lane < nk) {
-        off_a = offs[c0 + lane]; off_b = offs[c0 + lane + 1];
+        off_a = row_off(offs, tbase, c0 + lane); off_b = row_off(offs, tbase, c0 + lane + 1);
         ci0 = colinfo[c0 + lane];
         if (has_ref && apos < W.ref_len) rc = W.ref[apos];
     }
@@ -849,9 +858,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 // wfirst[f][w] = first read of file f that starts at or beyond column col_beg + 64 w (w = 0 .. nwaves): one thread per entry, a
 // binary search each.  The tile kernels find their reads from it with one more coalesced load instead of two 64-ary searches
 // (eight dependent loads at the head of every wave).
-__global__ void __launch_bounds__(256) k_wave_first(StaWinDev W, uint32_t *__restrict__ wfirst, int64_t nwaves)
+__global__ void __launch_bounds__(256) k_wave_first(StaWinDev W, uint32_t *__restrict__ wfirst, int64_t nwaves, unsigned long long *__restrict__ status, int64_t n_status)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (the measuring kernel's look-back words and ticket, cleared here: this launch runs right before it)
+    for (int64_t k = i; k < n_status; k += (int64_t)gridDim.x * blockDim.x) status[k] = 0ull;
     if (i >= (nwaves + 1) * W.nfiles) return;
     const int f = (int)(i / (nwaves + 1)); const int64_t w = i - (int64_t)f * (nwaves + 1);
     const StaReadsDev &R = W.files[f];
@@ -877,12 +888,15 @@ __device__ __forceinline__ void wave_range_indexed(const StaReadsDev &R, const u
     if (rlo > rhi) rlo = rhi;
 }
 
-__global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THREADS), amdgpu_waves_per_eu(6, 8))) k_mplp_len_rm(StaWinDev W, MplpDevPar P, uint32_t *line_len, uint2 *colinfo, const uint32_t *__restrict__ wfirst)
+__global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THREADS), amdgpu_waves_per_eu(6, 8))) k_mplp_len_rm(StaWinDev W, MplpDevPar P, uint32_t *line_len, uint2 *colinfo, const uint32_t *__restrict__ wfirst,
+                                                                              unsigned long long *__restrict__ status, uint64_t *__restrict__ offs, StaCounters *ctr)
 {
     __shared__ LenLds L;
     const int t = threadIdx.x;
     const int64_t ncols = (int64_t)W.col_end - W.col_beg;
-    const int64_t c0 = (int64_t)blockIdx.x * LEN_TC;
+    if (t == 0) { L.n_lines = 0; L.n_data = 0; L.wave_max = 0; }
+    const unsigned tile = blockIdx.x;
+    const int64_t c0 = (int64_t)tile * LEN_TC;
     if (c0 >= ncols) return;
     const int t0 = W.col_beg + (int)c0;
     const int ntile = (int)(ncols - c0 < LEN_TC ? ncols - c0 : LEN_TC);
@@ -920,6 +934,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THRE
         len_file_result(L, t, before, ntile, colinfo + (int64_t)f * ncols + c0, total, any);
         __syncthreads();
     }
+    // row lengths of the thread's four columns and their exclusive scan inside the tile; the tile's bytes / rows / largest wave go to
+    // k_tile_scan (one small workgroup), which replaces the whole-window scan and column-statistics launches of the lane-per-column
+    // pair.  (A decoupled look-back inside this kernel was measured first: the ticket + wait cost what the two launches had cost.)
+    uint32_t len4[4] = { 0, 0, 0, 0 };
+    unsigned my_lines = 0, my_data = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = 4 * t + i;
@@ -932,19 +951,70 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THRE
         uint32_t len = 0;
         if (exists) len = (uint32_t)W.tname_len + 1 + (uint32_t)dec_digits((unsigned long long)(apos + 1)) + 1 + 1 + total[i] + 1;
         line_len[c0 + c] = len | (data ? 0x80000000u : 0u);
+        len4[i] = len; my_lines += len != 0; my_data += data ? 1u : 0u;
+    }
+    L.part[t] = (int)(len4[0] + len4[1] + len4[2] + len4[3]);
+    if (my_lines) atomicAdd(&L.n_lines, my_lines);
+    if (my_data) atomicAdd(&L.n_data, my_data);
+    __syncthreads();
+    len_scan_2(L, t);
+    if ((t & 15) == 0) {                                   // bytes of one wave's 64 rows (what the emit kernel stages in LDS)
+        unsigned long long wb = 0;
+        for (int k = 0; k < 16; ++k) wb += (unsigned)L.part[t + k];
+        atomicMax(&L.wave_max, wb);
+    }
+    __syncthreads();
+    len_scan_3(L, t); __syncthreads();
+    const uint64_t before = (uint64_t)(unsigned)len_scan_4(L, t);
+    if (t == LEN_THREADS - 1) L.tile_bytes = before + (unsigned)L.part[t];
+    __syncthreads();
+    // the tile's aggregates for k_tile_scan: text bytes, rows << 31 | data columns, largest wave; offsets stay tile-relative
+    if (t == 0) {
+        unsigned long long *agg = status + 3 * (size_t)tile;
+        agg[0] = L.tile_bytes; agg[1] = ((unsigned long long)L.n_lines << 31) | L.n_data; agg[2] = L.wave_max;
+    }
+    uint64_t o = before;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = 4 * t + i;
+        if (c < ntile) offs[c0 + c] = o;
+        o += len4[i];
+    }
+    // (the entry behind the last column: the end of the last tile, or -- a window of whole tiles -- the start of the tile behind it)
+    if (t == LEN_THREADS - 1 && c0 + ntile == ncols) offs[ncols] = ntile == LEN_TC ? 0 : L.tile_bytes;
+    (void)ctr;
+}
+
+// exclusive scan of the measuring tiles' text bytes -> tbase[0 .. ntiles] (tbase[ntiles] = the window's text bytes), and the window's
+// totals.  One workgroup: a window has a few thousand tiles.
+__global__ void __launch_bounds__(1024) k_tile_scan(const unsigned long long *__restrict__ agg, uint64_t *__restrict__ tbase, int64_t ntiles, StaCounters *ctr)
+{
+    __shared__ unsigned long long s_sum[1024], s_rows[1024], s_max[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (ntiles + 1023) / 1024, a = (int64_t)t * per, b = a + per < ntiles ? a + per : ntiles;
+    unsigned long long sum = 0, rows = 0, mx = 0;
+    for (int64_t i = a; i < b; ++i) { sum += agg[3 * i]; rows += agg[3 * i + 1]; const unsigned long long m = agg[3 * i + 2]; mx = m > mx ? m : mx; }
+    s_sum[t] = sum; s_rows[t] = rows; s_max[t] = mx;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                    // inclusive scan of the per-thread sums (and totals of the other two)
+        unsigned long long v = 0, r = 0, m = s_max[t];
+        if (t >= o) { v = s_sum[t - o]; r = s_rows[t - o]; const unsigned long long m2 = s_max[t - o]; m = m2 > m ? m2 : m; }
+        __syncthreads();
+        s_sum[t] += v; s_rows[t] += r; s_max[t] = m;
+        __syncthreads();
+    }
+    unsigned long long run = s_sum[t] - sum;                // exclusive prefix of this thread's first tile
+    for (int64_t i = a; i < b; ++i) { tbase[i] = run; run += agg[3 * i]; }
+    if (t == 1023) {
+        tbase[ntiles] = s_sum[1023];
+        ctr->n_lines = s_rows[1023] >> 31; ctr->n_data_cols = s_rows[1023] & 0x7fffffffull; ctr->max_wave_bytes = s_max[1023];
     }
 }
 
 #define TILE_WAVES 2            // waves per workgroup of k_mplp_emit_tile (they share nothing)
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
-                                                                    const uint32_t *__restrict__ wfirst, char *out, uint32_t lds_cap)
+                                                                    const uint32_t *__restrict__ wfirst, const uint64_t *__restrict__ tbase, char *out, uint32_t lds_cap)
 {
     const int wid = threadIdx.x >> 6;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -957,9 +1027,9 @@ __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W,
     const int p = p0 + lane;
     const bool active = p < W.col_end;
     const int plast = W.col_beg + (int)c1 - 1;
-    const uint64_t o0 = offs[c0], o1 = offs[c1];
-    const uint64_t my0 = active ? offs[c0 + lane] : o1;
-    const uint64_t my1 = active ? offs[c0 + lane + 1] : o1;
+    const uint64_t o0 = row_off(offs, tbase, c0), o1 = row_off(offs, tbase, c1);
+    const uint64_t my0 = active ? row_off(offs, tbase, c0 + lane) : o1;
+    const uint64_t my1 = active ? row_off(offs, tbase, c0 + lane + 1) : o1;
     const bool exists = my1 > my0;
     const uint64_t wbytes = o1 - o0;
     if (wbytes == 0 || wbytes > lds_cap) return;            // rows beyond the slice: k_mplp_emit_deep takes those columns
@@ -1040,55 +1110,64 @@ static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
     return d;
 }
 
-void sta_launch_wave_first(hipStream_t s, const StaWinDev &w, uint32_t *wfirst)
+size_t sta_mplp_len_status_bytes(int64_t ncols) { return (size_t)(4 * ((ncols + LEN_TC - 1) / LEN_TC) + 2) * 8; }      // 3 aggregates per tile + tbase[ntiles + 1]
+const uint64_t *sta_mplp_tile_base(const void *status, int64_t ncols) { return (const uint64_t *)status + 3 * ((ncols + LEN_TC - 1) / LEN_TC); }
+
+void sta_launch_wave_first(hipStream_t s, const StaWinDev &w, uint32_t *wfirst, void *status)
 {
     const int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0 || w.nfiles <= 0) return;
     const int64_t nwaves = (ncols + 63) / 64, nt = (nwaves + 1) * w.nfiles;
-    hipLaunchKernelGGL(k_wave_first, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, w, wfirst, nwaves);
+    (void)status;
+    hipLaunchKernelGGL(k_wave_first, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, w, wfirst, nwaves, (unsigned long long *)nullptr, (int64_t)0);
 }
 
-void sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr, const uint32_t *wfirst, bool legacy)
+bool sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr, const uint32_t *wfirst, bool legacy,
+                         void *status, uint64_t *offs)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
-    if (ncols <= 0) return;
+    if (ncols <= 0) return false;
     int64_t nb = (ncols + 255) / 256;
     if (sta_mplp_has_fast_path(p) && colinfo) {
-        if (!legacy && wfirst && sta_mplp_tile_ok(p)) {
-            hipLaunchKernelGGL(k_mplp_len_rm, dim3((unsigned)((ncols + LEN_TC - 1) / LEN_TC)), dim3(LEN_THREADS), 0, s, w, make_par(p, w.tlen), line_len, colinfo, wfirst);
-            return;
+        if (!legacy && wfirst && status && offs && sta_mplp_tile_ok(p)) {
+            const int64_t ntiles = (ncols + LEN_TC - 1) / LEN_TC;
+            hipLaunchKernelGGL(k_mplp_len_rm, dim3((unsigned)ntiles), dim3(LEN_THREADS), 0, s, w, make_par(p, w.tlen), line_len, colinfo, wfirst,
+                               (unsigned long long *)status, offs, ctr);
+            hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, (const unsigned long long *)status, (uint64_t *)status + 3 * ntiles, ntiles, ctr);
+            return true;          // offsets, totals and the largest wave are done as well: no scan / column statistics launches
         }
         hipLaunchKernelGGL(k_mplp_len_fast, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, colinfo, ctr);
-        return;
+        return false;
     }
     hipLaunchKernelGGL(k_mplp_len, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, ctr);
+    return false;
 }
 
 static void launch_deep(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo, char *out,
-                        int64_t *strip_rng, uint32_t only_above)
+                        int64_t *strip_rng, uint32_t only_above, const uint64_t *tbase)
 {
     const int64_t ncols = (int64_t)w.col_end - w.col_beg;
     const int64_t nwaves_d = sta_mplp_deep_strips(ncols);
     const int64_t nt = nwaves_d * w.nfiles;
     hipLaunchKernelGGL(k_mplp_strip_ranges, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, w, strip_rng, nwaves_d);
-    hipLaunchKernelGGL(k_mplp_emit_deep, dim3((unsigned)((nwaves_d + 3) / 4)), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, (const int64_t *)strip_rng, out, only_above);
+    hipLaunchKernelGGL(k_mplp_emit_deep, dim3((unsigned)((nwaves_d + 3) / 4)), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, (const int64_t *)strip_rng, out, only_above, tbase);
 }
 
 // deep_mode 0: lane-per-column kernel only; 1: every strip through k_mplp_emit_deep; 2 (tile kernel only): the 64-column groups whose
 // rows exceed tile_cap go through k_mplp_emit_deep, the rest through k_mplp_emit_tile
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
-                          char *out, uint32_t lds_cap, int64_t *strip_rng, uint32_t tile_cap, int deep_mode, const uint32_t *wfirst, bool legacy)
+                          char *out, uint32_t lds_cap, int64_t *strip_rng, uint32_t tile_cap, int deep_mode, const uint32_t *wfirst, const uint64_t *tbase, bool legacy)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
     const bool fast = sta_mplp_has_fast_path(p) && colinfo;
-    if (fast && strip_rng && deep_mode == 1) { launch_deep(s, w, p, offs, colinfo, out, strip_rng, 0u); return; }
+    if (fast && strip_rng && deep_mode == 1) { launch_deep(s, w, p, offs, colinfo, out, strip_rng, 0u, tbase); return; }
     int64_t nwaves = (ncols + 63) / 64;
     if (fast && !legacy && wfirst && sta_mplp_tile_ok(p)) {
         const uint32_t slice = (tile_cap + 48 + 15) & ~15u;       // must match k_mplp_emit_tile
         const size_t lds = (size_t)TILE_WAVES * (slice + TILE_LDS_BYTES);
-        hipLaunchKernelGGL(k_mplp_emit_tile, dim3((unsigned)((nwaves + TILE_WAVES - 1) / TILE_WAVES)), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, wfirst, out, tile_cap);
-        if (deep_mode == 2 && strip_rng) launch_deep(s, w, p, offs, colinfo, out, strip_rng, tile_cap);
+        hipLaunchKernelGGL(k_mplp_emit_tile, dim3((unsigned)((nwaves + TILE_WAVES - 1) / TILE_WAVES)), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, wfirst, tbase, out, tile_cap);
+        if (deep_mode == 2 && strip_rng) launch_deep(s, w, p, offs, colinfo, out, strip_rng, tile_cap, tbase);
         return;
     }
     uint32_t slice = (lds_cap + 16 + 15) & ~15u;

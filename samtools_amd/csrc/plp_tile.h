@@ -133,6 +133,8 @@ struct LenLds {
     int gcount;
     int part[LEN_THREADS], part2[LEN_THREADS / 16 + 1];
     long long rlo, rhi;
+    // the tile's place in the window's text (the kernel's own look-back over the tiles, kernels_plp.hip)
+    unsigned tile; unsigned n_lines, n_data; unsigned long long tile_bytes, wave_max, ex_bytes;
 };
 
 PLP_HD void len_clear(LenLds &L, int t)

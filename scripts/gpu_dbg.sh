@@ -1,2 +1,10 @@
 cd $GRAFT_REPO_ROOT
-( timeout 400 python -m pytest tests/test_gpu_shard_driver.py tests/test_kputd.py tests/test_gpu_goldens.py -m gpu -q -o timeout=200 2>&1 | tail -15 | cut -c1-400 )
+mkdir -p gpurun_out/dbg
+( timeout 300 python -m pytest tests/test_gpu_goldens.py tests/test_gpu_synth.py tests/test_gpu_deep_emit.py tests/test_gpu_plp_api.py -m gpu -q -x -o timeout=100 2>&1 | tail -4 | cut -c1-300 )
+for wl in mpileup30_B mpileup30_B_hotspot mpileup100_B; do
+  timeout 200 python bench.py --workload $wl --steps 10 --warmup 3 --no-pmc > gpurun_out/dbg/bench_$wl.json 2> gpurun_out/dbg/bench_$wl.err
+  echo "$wl rc=$?"; tail -1 gpurun_out/dbg/bench_$wl.json | python -c 'import sys,json
+try:
+    d=json.loads(sys.stdin.read()); print(round(d["value"]), round(d["ms_per_step"],3), {k: round(v,3) for k,v in list(d["kernels_ms_per_step"].items())[:8]}, (d.get("parity_check") or {}).get("identical"))
+except Exception as e: print("nojson", e)'
+done

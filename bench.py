@@ -12,7 +12,8 @@ its own columns, and the per-block text is collected on rank 0 with one size all
 gather over RCCL (samtools_amd/shard.py) inside the timed step.  Per-GPU work is fixed as N grows (the input
 has N x the single-GPU window): weak scaling.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mpileup30|mpileup30_B|mpileup300|depth30|glf30|calmd30]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mpileup30|mpileup30_B|mpileup300|mpileup100|mpileup30_EA_pairs|
+                    mpileup30_hotspot|mpileup30_indel|depth30|glf30|calmd30|consensus30 ...]
                     [--verify] [--no-pmc] [--no-cpu-baseline]
 
 Prints ONE JSON line on rank 0.  The CPU oracle appears only as the checker / cpu_baseline leg (rank 0).
@@ -264,7 +265,7 @@ def collect_pmc(a, kernels):
 
 
 # engine kernel label -> prefix of the rocprofv3 kernel name
-KNAME = {"baq_fwd": "void k_baq_fwd<7", "baq_bwd": "void k_baq_bwd<7", "mplp_emit": "k_mplp_emit_fast", "mplp_emit_deep": "k_mplp_emit_deep", "mplp_len": "k_mplp_len_fast",
+KNAME = {"baq_fwd": "void k_baq_fwd<7", "baq_bwd": "void k_baq_bwd<7", "mplp_emit": "k_mplp_emit_tile", "mplp_emit_deep": "k_mplp_emit_deep", "mplp_len": "k_mplp_len_rm",
          "depth_fused": "k_depth_fused", "glf_cols": "k_glf_cols", "cons_col": "k_cons_col", "cons_walk": "k_cons_walk", "cons_read_a": "k_cons_read_a"}
 # gfx950: FETCH_SIZE tallies a 16-byte-per-lane streaming read at half its bytes (MI355X_MICROARCH.md, HBM).  k_baq_bwd reads two
 # thirds of its forward-row stream that way (the (M, I) pairs of the odd rows) and one third as 8-byte loads: the raw counter is

@@ -85,8 +85,6 @@ struct sta_engine {
     uint32_t lds_cap = 0;
     bool len_fused = false;            // the measuring kernel also produced offsets / totals (no scan, no column statistics)
     bool have_wfirst = false;          // the plan built the per-group read index of the tile kernels
-    bool plp_legacy = false;           // STA_PLP_TILE=0: the lane-per-column kernel pair instead of the tile kernels (A/B measurements)
-    bool plp_legacy_len = false;       // STA_PLP_TILE=3: only the measuring pass of the old pair (2: only its emit pass)
     void *last_out = nullptr;
     // profiling
     bool prof_on = false;
@@ -178,7 +176,6 @@ int sta_engine_create(sta_engine **out, int device, void *hip_stream)
     sta_engine *e = new sta_engine();
     e->device = device;
     e->stream = (hipStream_t)hip_stream;   // nullptr = default stream
-    if (const char *ev = getenv("STA_PLP_TILE")) { e->plp_legacy = atoi(ev) == 0 || atoi(ev) == 2; e->plp_legacy_len = atoi(ev) == 0 || atoi(ev) == 3; }
     *out = e;
     return STA_OK;
 }
@@ -511,7 +508,7 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
     } else {
         int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
         if (e->colinfo.ensure((size_t)(ncols > 0 ? ncols : 1) * (size_t)(nf > 0 ? nf : 1) * 8 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(column info) failed");
-        const bool tile = sta_mplp_has_fast_path(*p) && sta_mplp_tile_ok(*p) && !(e->plp_legacy && e->plp_legacy_len);
+        const bool tile = sta_mplp_has_fast_path(*p) && sta_mplp_tile_ok(*p);
         bool small = true;
         for (int f = 0; f < nf; ++f) small = small && e->files_h[(size_t)f].n < 0xffffffffll;
         e->have_wfirst = tile && small;
@@ -522,8 +519,8 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             sta_launch_wave_first(s, e->wd, (uint32_t *)e->wfirst.p, e->fused_status.p);
         }
         ProfScope ps(e, "mplp_len");
-        e->len_fused = sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr, e->plp_legacy_len,
-                                           e->have_wfirst && !e->plp_legacy ? e->fused_status.p : nullptr, (uint64_t *)e->offs.p);
+        e->len_fused = sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr,
+                                           e->have_wfirst ? e->fused_status.p : nullptr, (uint64_t *)e->offs.p);
     }
     return STA_OK;
 }
@@ -660,8 +657,8 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     if (tc < 1024) tc = 1024;
     const uint32_t tile_cap = (uint32_t)tc;
     int deep_mode = deep ? 1 : 0;
-    if (!deep && !e->plp_legacy && e->have_wfirst && mw > tile_cap) deep_mode = 2;
-    if (e->plp_legacy && !deep) deep_mode = 0;
+    if (!e->len_fused) deep_mode = 0;                     // the generic walker writes every row itself
+    else if (!deep && mw > tile_cap) deep_mode = 2;
     if (deep_mode) {
         if (e->strip_rng.ensure((size_t)sta_mplp_deep_strips(ncols > 0 ? ncols : 1) * (size_t)(e->wd.nfiles > 0 ? e->wd.nfiles : 1) * 16 + 16))
             return fail(e, STA_ERR_HIP, "hipMalloc(strip ranges) failed");
@@ -669,7 +666,7 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     ProfScope ps(e, deep_mode == 1 ? "mplp_emit_deep" : "mplp_emit");
     sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap, deep_mode ? (int64_t *)e->strip_rng.p : nullptr,
                          tile_cap, deep_mode, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr,
-                         e->len_fused ? sta_mplp_tile_base(e->fused_status.p, ncols) : nullptr, e->plp_legacy);
+                         e->len_fused ? sta_mplp_tile_base(e->fused_status.p, ncols) : nullptr, e->len_fused);
     return STA_OK;
 }
 

@@ -287,14 +287,8 @@ __global__ void __launch_bounds__(256) k_mplp_emit(StaWinDev W, MplpDevPar P, co
 
 
 // ================================================================================================
-// Fast column kernels (no --output-extra / -O / -s columns): same column-per-lane layout, but
-//  * read metadata is fetched 64 reads at a time with coalesced vector loads and broadcast with
-//    v_readlane, so the walk issues no dependent scalar loads;
-//  * only reads that can touch the wave's 64 columns are visited (ballot of a per-lane test);
-//  * four reads are in flight at once (their quality / base bytes are loaded before any is used);
-//  * the measuring pass stores (count, seq bytes) per column and file, so the emit pass walks the
-//    reads ONCE and writes the base string and the quality string at two cursors.
-// Non-simple reads (indels, clips, pads, ref skips) take the generic per-entry path inline.
+// Helpers of the fast kernels (windows without --output-extra / -O / -s columns): the tile kernels further down and the read-major
+// deep kernel.  (Round 2's lane-per-column pair k_mplp_len_fast / k_mplp_emit_fast was retired in round 3: profiles/r03_tile_kernel_counters.md.)
 
 // Pointers that reach a kernel through W.files[] (a struct read from memory) are "generic" to the compiler, which then
 // emits flat_load (slower, and it couples vmcnt with lgkmcnt).  They always point to HBM: say so.
@@ -321,243 +315,8 @@ __device__ __forceinline__ char base_char_fast(int c, bool rev)
     return (char)ch;
 }
 
-template <bool EMIT, bool LDS>
-__device__ __forceinline__ void fast_walk(const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int p0, int plast,
-                                          int p, bool active, int rbcode, int64_t rlo, int64_t rhi,
-                                          uint32_t &n_plp, uint32_t &cnt, uint32_t &seq_len, Sink<LDS> &ss, Sink<LDS> &sq)
-{
-    const int lane = threadIdx.x & 63;
-    const bool ends = !P.no_ends;
-    const auto g_info = GPTR(uint32_t, R.info); const auto g_pos = GPTR(int32_t, R.pos); const auto g_end = GPTR(int32_t, R.end);
-    const auto g_b8 = GPTR(uint32_t, R.base_off8); const auto g_qual = GPTR(uint8_t, R.qual); const auto g_seq = GPTR(uint8_t, R.seq);
-    for (int64_t b0 = rlo; b0 < rhi; b0 += 64) {
-        const int64_t ri = b0 + lane;
-        const bool ok = ri < rhi;
-        const uint32_t v_info = ok ? g_info[ri] : 0u;
-        const int v_pos = ok ? g_pos[ri] : 0;
-        const int v_end = ok ? g_end[ri] : 0;
-        const uint32_t v_b8 = ok ? g_b8[ri] : 0u;
-        unsigned long long live = __ballot(ok && (v_info & RI_KEEP) && v_end > p0 && v_pos <= plast);
-        while (live) {
-            bool valid[4], cov[4];
-            uint32_t info[4], b8[4];
-            int rpos[4], rend[4], jx[4], qv[4], sv[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                valid[k] = live != 0;
-                int j = valid[k] ? __ffsll((long long)live) - 1 : 0;
-                if (valid[k]) live &= live - 1;
-                jx[k] = j;
-                info[k] = rl_u(v_info, j); rpos[k] = rl_i(v_pos, j); rend[k] = rl_i(v_end, j); b8[k] = rl_u(v_b8, j);
-                cov[k] = valid[k] && active && p >= rpos[k] && p < rend[k];
-                qv[k] = 0; sv[k] = 0;
-                if (cov[k] && (info[k] & RI_SIMPLE)) {
-                    uint64_t boff = (uint64_t)b8[k] << 3;
-                    int qpos = p - rpos[k];
-                    qv[k] = g_qual[boff + (uint64_t)qpos];
-                    if (EMIT) sv[k] = g_seq[(boff >> 1) + (uint64_t)(qpos >> 1)];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!valid[k]) continue;
-                if (info[k] & RI_SIMPLE) {
-                    // branch-free: every lane runs the same code; a lane that has nothing to add writes at its cursor
-                    // without advancing it (the byte is overwritten by its next real write, or by the separator that
-                    // emit_column_fast puts there after the walk)
-                    const bool pass = cov[k] && qv[k] >= P.min_baseQ;
-                    const bool head = pass && ends && p == rpos[k], tail = pass && ends && p == rend[k] - 1;
-                    if (!EMIT) {
-                        n_plp += cov[k] ? 1u : 0u;
-                        cnt += pass ? 1u : 0u;
-                        seq_len += (pass ? 1u : 0u) + (head ? 2u : 0u) + (tail ? 1u : 0u);
-                    } else if (LDS) {
-                        const bool rev = (info[k] & RI_REV) != 0;
-                        const int mq = (int)((info[k] >> RI_MAPQ_SHIFT) & 0xff);
-                        const int qpos = p - rpos[k];
-                        int c = (sv[k] >> ((~qpos & 1) << 2)) & 0xf;
-                        if (c == rbcode) c = 0;
-                        uint32_t cur = ss.cur;
-                        // a read starts (ends) inside the wave's 64 columns in only ~30 % of the steps: the marker stores are
-                        // skipped by a wave-uniform branch otherwise (every LDS byte store of this kernel is bank-conflicted)
-                        if (__ballot(head)) {
-                            lds_text[cur] = '^';
-                            lds_text[cur + (head ? 1u : 0u)] = (char)(mq > 93 ? 126 : mq + 33);
-                            cur += head ? 2u : 0u;
-                        }
-                        lds_text[cur] = base_char_fast(c, rev);
-                        cur += pass ? 1u : 0u;
-                        if (__ballot(tail)) {
-                            lds_text[cur] = '$';
-                            cur += tail ? 1u : 0u;
-                        }
-                        ss.cur = cur;
-                        lds_text[sq.cur] = (char)(qv[k] + 33 < 126 ? qv[k] + 33 : 126);
-                        sq.cur += pass ? 1u : 0u;
-                    } else if (pass) {
-                        bool rev = (info[k] & RI_REV) != 0;
-                        if (head) {
-                            int mq = (int)((info[k] >> RI_MAPQ_SHIFT) & 0xff);
-                            ss.put('^'); ss.put((char)(mq > 93 ? 126 : mq + 33));
-                        }
-                        int qpos = p - rpos[k];
-                        int c = (sv[k] >> ((~qpos & 1) << 2)) & 0xf;
-                        if (c == rbcode) c = 0;
-                        ss.put(base_char_fast(c, rev));
-                        if (tail) ss.put('$');
-                        sq.put((char)(qv[k] + 33 < 126 ? qv[k] + 33 : 126));
-                    }
-                } else {
-                    // generic entry (uniform branch: the read is the same for every lane)
-                    if (__ballot(cov[k]) == 0) continue;
-                    if (cov[k]) {
-                        Entry e;
-                        e.r = b0 + jx[k]; e.rpos = rpos[k]; e.rend = rend[k]; e.info = info[k];
-                        e.lq = R.l_qseq[e.r];
-                        e.boff = (uint64_t)b8[k] << 3;
-                        e.rs = resolve_general(R.cigar + R.cig_off[e.r], (int)(R.cig_off[e.r + 1] - R.cig_off[e.r]), e.rpos, p);
-                        if (!EMIT) n_plp++;
-                        int c = e.rs.is_del ? placeholder_qual(R, e.r, e.rs.qpos, e.lq, e.boff, p) : (e.rs.qpos < e.lq ? R.qual[e.boff + (uint64_t)e.rs.qpos] : 0);
-                        if (c >= P.min_baseQ) {
-                            if (!EMIT) { cnt++; seq_len += (uint32_t)token_len(R, P, e, p); }
-                            else {
-                                token_write<LDS>(R, W, P, e, p, ss);
-                                sq.put((char)(c + 33 < 126 ? c + 33 : 126));
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256) k_mplp_len_fast(StaWinDev W, MplpDevPar P, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr)
-{
-    int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    int lane = threadIdx.x & 63;
-    int64_t ncols = (int64_t)W.col_end - W.col_beg;
-    int64_t c0 = (int64_t)wave * 64;
-    if (c0 >= ncols) return;
-    int p0 = W.col_beg + (int)c0;
-    int p = p0 + lane;
-    bool active = p < W.col_end;
-    int plast = p0 + 63 < W.col_end ? p0 + 63 : W.col_end - 1;
-    int64_t apos = W.origin + p;
-
-    uint32_t total = 0; bool any = false;
-    Sink<false> d1, d2; d1.g = d2.g = nullptr; d1.cur = d2.cur = 0;
-    for (int f = 0; f < W.nfiles; ++f) {
-        const StaReadsDev &R = W.files[f];
-        int64_t rlo, rhi;
-        wave_read_range(R, p0, plast, rlo, rhi);
-        uint32_t n_plp = 0, cnt = 0, seq_len = 0;
-        fast_walk<false, false>(R, W, P, p0, plast, p, active, -1, rlo, rhi, n_plp, cnt, seq_len, d1, d2);
-        any |= n_plp > 0;
-        total += 1 + (uint32_t)dec_digits_u32(cnt) + 1 + (seq_len ? seq_len : 1) + 1 + (cnt ? cnt : 1);
-        if (active) colinfo[(int64_t)f * ncols + c0 + lane] = make_uint2(cnt, seq_len);
-    }
-    bool in_reg = active && column_selected(W, apos);
-    bool data = in_reg && any;
-    bool exists = in_reg && (any || (P.all && apos < P.tlen));
-    if (exists && W.has_bed) exists = bed_overlap_dev(W.bed_beg, W.bed_end, W.n_bed, apos, apos + 1);
-    uint32_t len = 0;
-    if (exists) len = (uint32_t)W.tname_len + 1 + (uint32_t)dec_digits((unsigned long long)(apos + 1)) + 1 + 1 + total + 1;
-    if (active) line_len[c0 + lane] = len | (data ? 0x80000000u : 0u);     // rows / data columns are counted by k_col_stats
-    (void)ctr;
-}
-
-template <bool LDS>
-__device__ __forceinline__ void emit_column_fast(const StaWinDev &W, const MplpDevPar &P, const uint2 *colinfo, int64_t ncols, int64_t col,
-                                                 int p0, int plast, int p, bool exists, Sink<LDS> &s, uint32_t dump)
-{
-    int64_t apos = W.origin + p;
-    int rbcode = -1;
-    if (exists) {
-        for (int t = 0; t < W.tname_len; ++t) s.put(W.tname[t]);
-        s.put('\t');
-        s.put_dec(apos + 1);
-        s.put('\t');
-        char rc = (W.ref && apos < W.ref_len) ? W.ref[apos] : 'N';
-        s.put(rc);
-        if (W.ref) rbcode = apos < W.ref_len ? (int)c_nt16_of_char[(unsigned char)rc] : 15;
-    }
-    for (int f = 0; f < W.nfiles; ++f) {
-        const StaReadsDev &R = W.files[f];
-        int64_t rlo, rhi;
-        wave_read_range(R, p0, plast, rlo, rhi);
-        uint2 ci = exists ? colinfo[(int64_t)f * ncols + col] : make_uint2(0, 0);
-        uint32_t cnt = ci.x, seq_len = ci.y;
-        Sink<LDS> ss = s, sq = s;
-        uint32_t sl = seq_len ? seq_len : 1;
-        if (exists) {
-            s.put('\t'); s.put_dec(cnt); s.put('\t');
-            ss = s;
-            sq = s; sq.cur += sl + 1; sq.g += sl + 1;
-        }
-        const bool walk = exists && cnt;
-        if (LDS && !walk) ss.cur = sq.cur = dump;       // lanes without entries: predicated writes land in the wave's dump bytes
-        uint32_t d0 = 0, d1 = 0, d2 = 0;
-        fast_walk<true, LDS>(R, W, P, p0, plast, p, walk, rbcode, rlo, rhi, d0, d1, d2, ss, sq);
-        if (exists) {
-            // separators and the '*' placeholders go in AFTER the walk (its last predicated write may sit on them)
-            Sink<LDS> st = s;
-            if (!cnt) { st.put('*'); st.put('\t'); st.put('*'); }
-            else { st.cur += sl; st.g += sl; st.put('\t'); }
-            s.cur += sl + 1 + (cnt ? cnt : 1); s.g += sl + 1 + (cnt ? cnt : 1);
-        }
-    }
-    if (exists) s.put('\n');
-}
-
-__global__ void __launch_bounds__(256) k_mplp_emit_fast(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
-                                                        char *out, uint32_t lds_cap)
-{
-    int wid = threadIdx.x >> 6;
-    int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    int lane = threadIdx.x & 63;
-    int64_t ncols = (int64_t)W.col_end - W.col_beg;
-    int64_t c0 = (int64_t)wave * 64;
-    if (c0 >= ncols) return;
-    int64_t c1 = c0 + 64 < ncols ? c0 + 64 : ncols;
-    int p0 = W.col_beg + (int)c0;
-    int p = p0 + lane;
-    bool active = p < W.col_end;
-    int plast = W.col_beg + (int)c1 - 1;
-    uint64_t o0 = offs[c0], o1 = offs[c1];
-    uint64_t my0 = active ? offs[c0 + lane] : o1;
-    uint64_t my1 = active ? offs[c0 + lane + 1] : o1;
-    bool exists = my1 > my0;
-    uint64_t wbytes = o1 - o0;
-    if (wbytes == 0) return;
-    if (wbytes <= lds_cap) {
-        uint32_t slice = (lds_cap + 48 + 15) & ~15u;       // text (+ up to 15 alignment bytes) + 16 dump bytes for predicated writes
-        uint32_t base = (uint32_t)wid * slice;
-        uint32_t mis = (uint32_t)((uintptr_t)(out + o0) & 15);
-        Sink<true> s; s.g = nullptr; s.cur = base + mis + (uint32_t)(my0 - o0);
-        emit_column_fast<true>(W, P, colinfo, ncols, c0 + lane, p0, plast, p, exists, s, base + slice - 8);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        char *dst = out + o0;
-        uint32_t n = (uint32_t)wbytes;
-        uint32_t head = mis ? 16 - mis : 0; if (head > n) head = n;
-        if ((uint32_t)lane < head) dst[lane] = lds_text[base + mis + lane];
-        uint32_t body = (n - head) >> 4;
-        const uint4 *src4 = reinterpret_cast<const uint4 *>(lds_text + base + mis + head);
-        uint4 *dst4 = reinterpret_cast<uint4 *>(dst + head);
-        for (uint32_t i = lane; i < body; i += 64) dst4[i] = src4[i];
-        uint32_t done = head + (body << 4);
-        if (done + lane < n) dst[done + lane] = lds_text[base + mis + done + lane];
-    } else {
-        Sink<false> s; s.cur = 0; s.g = out + my0;
-        emit_column_fast<false>(W, P, colinfo, ncols, c0 + lane, p0, plast, p, exists, s, 0);
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------
-// Deep columns: the read-major emit kernel.  k_mplp_emit_fast gives every column a lane and needs the wave's 64 rows in LDS
+// Deep columns: the read-major emit kernel.  The tile kernel gives every column a lane and needs the wave's 64 rows in LDS
 // (40 KB at 300x: one wave per SIMD, and 428 sequential read steps per wave).  Here a wave takes a strip of SIXTEEN consecutive
 // columns and its lanes are the READS: 64 reads at a time, each lane works out what its read shows in each of the columns, the
 // token offsets inside a base string are prefix counts over the lanes (ballots; a shuffle scan when a read with indels takes
@@ -565,7 +324,7 @@ __global__ void __launch_bounds__(256) k_mplp_emit_fast(StaWinDev W, MplpDevPar 
 // bytes, no LDS, full occupancy, ~5 read blocks per strip at 300x instead of 428 read steps per 64 columns.  The sixteen quality
 // bytes and the packed bases a plain read shows in the strip come from two vector loads.  The fixed parts of a row (name,
 // position, reference base, the per-file counts, separators, '*' placeholders) are written by lane k for column k.  The
-// (count, base-string bytes) of every column and file come from the measuring pass, as for k_mplp_emit_fast.
+// (count, base-string bytes) of every column and file come from the measuring pass, as for k_mplp_emit_tile.
 #define DEEP_STRIP 16
 #include "deep_strip.h"
 
@@ -852,8 +611,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
 
 
 // ================================================================================================
-// Tile kernels (step functions and the layout: plp_tile.h).  They replace k_mplp_len_fast / k_mplp_emit_fast for windows without
-// --output-extra / -O / -s columns; waves whose rows exceed the LDS slice are left to k_mplp_emit_deep.
+// Tile kernels (step functions and the layout: plp_tile.h) for windows without --output-extra / -O / -s columns; waves whose rows exceed
+// the LDS slice are left to k_mplp_emit_deep.
 
 // wfirst[f][w] = first read of file f that starts at or beyond column col_beg + 64 w (w = 0 .. nwaves): one thread per entry, a
 // binary search each.  The tile kernels find their reads from it with one more coalesced load instead of two 64-ary searches
@@ -1122,23 +881,19 @@ void sta_launch_wave_first(hipStream_t s, const StaWinDev &w, uint32_t *wfirst, 
     hipLaunchKernelGGL(k_wave_first, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, w, wfirst, nwaves, (unsigned long long *)nullptr, (int64_t)0);
 }
 
-bool sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr, const uint32_t *wfirst, bool legacy,
+bool sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr, const uint32_t *wfirst,
                          void *status, uint64_t *offs)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return false;
-    int64_t nb = (ncols + 255) / 256;
-    if (sta_mplp_has_fast_path(p) && colinfo) {
-        if (!legacy && wfirst && status && offs && sta_mplp_tile_ok(p)) {
-            const int64_t ntiles = (ncols + LEN_TC - 1) / LEN_TC;
-            hipLaunchKernelGGL(k_mplp_len_rm, dim3((unsigned)ntiles), dim3(LEN_THREADS), 0, s, w, make_par(p, w.tlen), line_len, colinfo, wfirst,
-                               (unsigned long long *)status, offs, ctr);
-            hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, (const unsigned long long *)status, (uint64_t *)status + 3 * ntiles, ntiles, ctr);
-            return true;          // offsets, totals and the largest wave are done as well: no scan / column statistics launches
-        }
-        hipLaunchKernelGGL(k_mplp_len_fast, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, colinfo, ctr);
-        return false;
+    if (sta_mplp_has_fast_path(p) && colinfo && wfirst && status && offs && sta_mplp_tile_ok(p)) {
+        const int64_t ntiles = (ncols + LEN_TC - 1) / LEN_TC;
+        hipLaunchKernelGGL(k_mplp_len_rm, dim3((unsigned)ntiles), dim3(LEN_THREADS), 0, s, w, make_par(p, w.tlen), line_len, colinfo, wfirst,
+                           (unsigned long long *)status, offs, ctr);
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, (const unsigned long long *)status, (uint64_t *)status + 3 * ntiles, ntiles, ctr);
+        return true;          // offsets (tile-relative + tile bases), totals and the largest wave are done: no scan / column statistics launches
     }
+    int64_t nb = (ncols + 255) / 256;
     hipLaunchKernelGGL(k_mplp_len, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, ctr);
     return false;
 }
@@ -1153,17 +908,17 @@ static void launch_deep(hipStream_t s, const StaWinDev &w, const sta_mplp_params
     hipLaunchKernelGGL(k_mplp_emit_deep, dim3((unsigned)((nwaves_d + 3) / 4)), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, (const int64_t *)strip_rng, out, only_above, tbase);
 }
 
-// deep_mode 0: lane-per-column kernel only; 1: every strip through k_mplp_emit_deep; 2 (tile kernel only): the 64-column groups whose
-// rows exceed tile_cap go through k_mplp_emit_deep, the rest through k_mplp_emit_tile
+// tile = true (the measuring pass was k_mplp_len_rm: colinfo, wfirst and tbase are valid): deep_mode 1 = every strip through
+// k_mplp_emit_deep; otherwise k_mplp_emit_tile, and with deep_mode 2 the 64-column groups whose rows exceed tile_cap through
+// k_mplp_emit_deep beside it.  tile = false: the generic walker (absolute offsets, any option set).
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
-                          char *out, uint32_t lds_cap, int64_t *strip_rng, uint32_t tile_cap, int deep_mode, const uint32_t *wfirst, const uint64_t *tbase, bool legacy)
+                          char *out, uint32_t lds_cap, int64_t *strip_rng, uint32_t tile_cap, int deep_mode, const uint32_t *wfirst, const uint64_t *tbase, bool tile)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
-    const bool fast = sta_mplp_has_fast_path(p) && colinfo;
-    if (fast && strip_rng && deep_mode == 1) { launch_deep(s, w, p, offs, colinfo, out, strip_rng, 0u, tbase); return; }
     int64_t nwaves = (ncols + 63) / 64;
-    if (fast && !legacy && wfirst && sta_mplp_tile_ok(p)) {
+    if (tile) {
+        if (strip_rng && deep_mode == 1) { launch_deep(s, w, p, offs, colinfo, out, strip_rng, 0u, tbase); return; }
         const uint32_t slice = (tile_cap + 48 + 15) & ~15u;       // must match k_mplp_emit_tile
         const size_t lds = (size_t)TILE_WAVES * (slice + TILE_LDS_BYTES);
         hipLaunchKernelGGL(k_mplp_emit_tile, dim3((unsigned)((nwaves + TILE_WAVES - 1) / TILE_WAVES)), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, wfirst, tbase, out, tile_cap);
@@ -1174,13 +929,6 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
     // waves per workgroup so that the workgroup's LDS (one slice per wave) stays within 64 KiB
     int wpb = 4 * slice <= 65536 ? 4 : (2 * slice <= 65536 ? 2 : 1);
     int64_t nb = (nwaves + wpb - 1) / wpb;
-    if (fast) {
-        uint32_t fslice = (lds_cap + 48 + 15) & ~15u;      // must match k_mplp_emit_fast
-        int fw = 4 * fslice <= 65536 ? 4 : (2 * fslice <= 65536 ? 2 : 1);
-        int64_t fnb = (nwaves + fw - 1) / fw;
-        hipLaunchKernelGGL(k_mplp_emit_fast, dim3((unsigned)fnb), dim3(64 * fw), (size_t)fw * fslice, s, w, make_par(p, w.tlen), offs, colinfo, out, lds_cap);
-        return;
-    }
     hipLaunchKernelGGL(k_mplp_emit, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, make_par(p, w.tlen), offs, out, lds_cap);
 }
 

@@ -86,20 +86,19 @@ size_t sta_scan_tmp_bytes(int64_t n);
 void sta_launch_scan_max_i32(hipStream_t s, const int32_t *in, int32_t *out, int64_t n, void *tmp);
 // exclusive scan of u32 lengths into u64 offsets (offs has n+1 entries)
 void sta_launch_len_scan(hipStream_t s, const uint32_t *len, uint64_t *offs, int64_t n, void *tmp, size_t tmp_bytes);
-// returns true when the launch also produced the row offsets, the totals (n_lines, n_data_cols) and max_wave_bytes (the tile kernel
-// with its own look-back): the caller then skips the scan and column-statistics launches
+// The measuring pass.  With wfirst / status / offs (and an option set the tile kernels cover) it is k_mplp_len_rm + k_tile_scan and returns
+// true: colinfo, TILE-RELATIVE row offsets + tile bases (sta_mplp_tile_base), n_lines, n_data_cols and max_wave_bytes are all produced, the
+// caller skips the scan and column-statistics launches.  Otherwise the generic walker k_mplp_len (line lengths only), false.
 bool sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo /*[nfiles][ncols] (count, seq bytes)*/,
-                         StaCounters *ctr, const uint32_t *wfirst /* sta_launch_wave_first's table; null: lane-per-column kernels */,
-                         bool legacy = false /* the lane-per-column pair instead of the tile kernels (A/B measurements) */,
-                         void *status = nullptr /* sta_mplp_len_status_bytes(), cleared by sta_launch_wave_first */, uint64_t *offs = nullptr);
+                         StaCounters *ctr, const uint32_t *wfirst /* sta_launch_wave_first's table */, void *status /* sta_mplp_len_status_bytes() */, uint64_t *offs);
 // wfirst[nfiles][ncols / 64 + 2]: first read starting at or beyond every 64-column group (where the tile kernels start looking)
 void sta_launch_wave_first(hipStream_t s, const StaWinDev &w, uint32_t *wfirst, void *status);
 size_t sta_mplp_len_status_bytes(int64_t ncols);
 const uint64_t *sta_mplp_tile_base(const void *status, int64_t ncols);
 int64_t sta_mplp_deep_strips(int64_t ncols);      // strips of the read-major emit kernel; strip_rng holds 2 x int64 per (file, strip)
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
-                          char *out, uint32_t lds_cap, int64_t *strip_rng /* workspace of the read-major kernel */, uint32_t tile_cap, int deep_mode, const uint32_t *wfirst,
-                          const uint64_t *tbase /* sta_mplp_tile_base(): the offsets are tile-relative; null: absolute */, bool legacy = false);
+                          char *out, uint32_t lds_cap /* generic walker's slice */, int64_t *strip_rng /* workspace of the read-major kernel */, uint32_t tile_cap, int deep_mode,
+                          const uint32_t *wfirst, const uint64_t *tbase /* sta_mplp_tile_base() */, bool tile /* the measuring pass returned true */);
 bool sta_mplp_has_fast_path(const sta_mplp_params &p);
 bool sta_mplp_tile_ok(const sta_mplp_params &p);
 void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, const uint32_t *line_len, int64_t ncols, StaCounters *ctr);

@@ -473,8 +473,10 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             // span of read ends relative to the smallest start: computed on the host from the staged window bounds
             int32_t lo = e->min_pos[(size_t)f], hi = e->max_pos_hint[(size_t)f];
             int64_t span = (int64_t)hi - lo + 2;
-            if (e->maxcnt_scratch.ensure((size_t)(span + 4) * 4)) return fail(e, STA_ERR_HIP, "hipMalloc(maxcnt) failed");
+            if (e->maxcnt_scratch.ensure((size_t)(span + 4) * 4 + 32)) return fail(e, STA_ERR_HIP, "hipMalloc(maxcnt) failed");
+            if (e->scan_tmp.ensure(sta_scan_tmp_bytes(d.n) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
             ProfScope ps(e, "maxcnt_serial");
+            sta_launch_maxend_scan(s, d, e->scan_tmp.p, e->scan_tmp.cap);           // prefix maxima BEFORE the cap: the replay's candidate bounds
             sta_launch_maxcnt(s, d, p->max_depth, lo, (int32_t)span, (int32_t *)e->maxcnt_scratch.p, ctr);
         }
     }

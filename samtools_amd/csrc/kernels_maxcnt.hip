@@ -25,14 +25,64 @@ __global__ void __launch_bounds__(256) k_maxcnt_detect(StaReadsDev R, int maxcnt
     if (__ballot(hit) && (threadIdx.x & 63) == 0) atomicAdd(&ctr->maxcnt_flag, 1ull);
 }
 
-// exact replay; hist[] counts kept reads by (end - col_lo), zero-initialised, length span+2
-__global__ void k_maxcnt_serial(StaReadsDev R, int maxcnt, int32_t col_lo, int32_t span, int32_t *hist, StaCounters *ctr)
+// first / last read the cap can possibly drop (the detector's bound, per read): range[0] = n - first (so that zero means "none" and a
+// maximum finds the smallest index), range[1] = last + 1
+__global__ void __launch_bounds__(256) k_maxcnt_range(StaReadsDev R, int maxcnt, unsigned long long *range)
 {
-    if (threadIdx.x || blockIdx.x) return;
-    long long live = 0;
-    int32_t cur_p = INT32_MIN, retired = col_lo - 1;   // ends <= retired have left the buffer
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    if (i < R.n && (R.info[i] & RI_PUSHED) && i + 1 >= maxcnt) {      // (zero-span reads too: the replay un-marks those the cap would have dropped)
+        int32_t key = R.pos[i] - 1;
+        int64_t lo = 0, hi = i;
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (R.maxend[mid] > key) hi = mid; else lo = mid + 1; }
+        hit = (i - lo + 1) >= (int64_t)maxcnt;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (m && (threadIdx.x & 63) == 0) {
+        const int64_t base = i;                                   // lane 0's read
+        atomicMax(&range[0], (unsigned long long)(R.n - (base + (__ffsll((long long)m) - 1))));
+        atomicMax(&range[1], (unsigned long long)(base + (63 - __clzll((long long)m)) + 1));
+    }
+}
+
+// Exact replay of bam_plp_push's cap; hist[] counts kept reads by (end - col_lo), zero-initialised, length span+2.
+// Only the reads between the first and the last one the cap can possibly drop are replayed one at a time (a read whose stack bound
+// is below maxcnt is never dropped, and nothing behind the last candidate depends on the drops): the state in front of the first
+// candidate's start position -- every kept read still alive there -- is built by the whole workgroup, then lane 0 walks.  A window with
+// one 10 000x amplicon replays 20 000 reads instead of all 860 000 (0.71 s -> ~20 ms).
+__global__ void __launch_bounds__(256) k_maxcnt_serial(StaReadsDev R, int maxcnt, int32_t col_lo, int32_t span, int32_t *hist, StaCounters *ctr,
+                                                       const unsigned long long *range)
+{
+    __shared__ long long s_i[3];
+    __shared__ unsigned long long s_live;
+    if (range[1] == 0) return;
+    const int64_t i0 = R.n - (int64_t)range[0], i1 = (int64_t)range[1] - 1;
+    const int32_t p0 = R.pos[i0];
+    if (threadIdx.x == 0) {
+        int64_t lo = 0, hi = i0;                                   // first read starting at p0
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (R.pos[mid] >= p0) hi = mid; else lo = mid + 1; }
+        s_i[0] = lo;
+        int64_t a = 0, b = lo;                                     // first read whose prefix-maximum end reaches p0
+        while (a < b) { int64_t mid = (a + b) >> 1; if (R.maxend[mid] > p0 - 1) b = mid; else a = mid + 1; }
+        s_i[1] = a;
+        s_live = 0;
+    }
+    __syncthreads();
+    const int64_t s0 = s_i[0], lo0 = s_i[1];
+    unsigned long long mine = 0;
+    for (int64_t j = lo0 + threadIdx.x; j < s0; j += blockDim.x) {
+        const uint32_t info = R.info[j];
+        const int32_t e = R.end[j];
+        if ((info & RI_PUSHED) && (info & RI_KEEP) && e >= p0) { atomicAdd(&hist[e - col_lo], 1); ++mine; }
+    }
+    if (mine) atomicAdd(&s_live, mine);
+    __syncthreads();
+    if (threadIdx.x) return;
+    __threadfence();
+    long long live = (long long)s_live;
+    int32_t cur_p = INT32_MIN, retired = p0 - 1;       // ends <= retired have left the buffer
     unsigned long long dropped = 0;
-    for (int64_t i = 0; i < R.n; ++i) {
+    for (int64_t i = s0; i <= i1; ++i) {
         uint32_t info = R.info[i];
         if (!(info & RI_PUSHED)) continue;
         int32_t p = R.pos[i], e = R.end[i];
@@ -58,10 +108,15 @@ void sta_launch_maxcnt_detect(hipStream_t s, const StaReadsDev &r, int maxcnt, S
     hipLaunchKernelGGL(k_maxcnt_detect, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, s, r, maxcnt, ctr);
 }
 
+// scratch: span + 2 histogram ints, then two 8-byte range words (8-byte aligned).  R.maxend must hold the prefix maxima of the reads
+// as they are BEFORE the cap (the caller runs the scan first and again afterwards).
 void sta_launch_maxcnt(hipStream_t s, const StaReadsDev &r, int maxcnt, int32_t col_lo, int32_t span,
                        int32_t *scratch, StaCounters *ctr)
 {
     if (r.n == 0) return;
-    hipMemsetAsync(scratch, 0, ((size_t)span + 2) * sizeof(int32_t), s);
-    hipLaunchKernelGGL(k_maxcnt_serial, dim3(1), dim3(64), 0, s, r, maxcnt, col_lo, span, scratch, ctr);
+    const size_t hist_ints = ((size_t)span + 2 + 1) & ~(size_t)1;
+    hipMemsetAsync(scratch, 0, hist_ints * sizeof(int32_t) + 16, s);
+    unsigned long long *range = reinterpret_cast<unsigned long long *>(scratch + hist_ints);
+    hipLaunchKernelGGL(k_maxcnt_range, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, s, r, maxcnt, range);
+    hipLaunchKernelGGL(k_maxcnt_serial, dim3(1), dim3(256), 0, s, r, maxcnt, col_lo, span, scratch, ctr, (const unsigned long long *)range);
 }

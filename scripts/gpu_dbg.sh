@@ -1,10 +1,14 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/dbg
-( timeout 300 python -m pytest tests/test_gpu_goldens.py tests/test_gpu_synth.py tests/test_gpu_deep_emit.py tests/test_gpu_plp_api.py -m gpu -q -x -o timeout=100 2>&1 | tail -4 | cut -c1-300 )
-for wl in mpileup30_B mpileup30_B_hotspot mpileup100_B; do
-  timeout 200 python bench.py --workload $wl --steps 10 --warmup 3 --no-pmc > gpurun_out/dbg/bench_$wl.json 2> gpurun_out/dbg/bench_$wl.err
-  echo "$wl rc=$?"; tail -1 gpurun_out/dbg/bench_$wl.json | python -c 'import sys,json
-try:
-    d=json.loads(sys.stdin.read()); print(round(d["value"]), round(d["ms_per_step"],3), {k: round(v,3) for k,v in list(d["kernels_ms_per_step"].items())[:8]}, (d.get("parity_check") or {}).get("identical"))
-except Exception as e: print("nojson", e)'
-done
+( timeout 300 python -m pytest tests/test_gpu_synth.py tests/test_gpu_goldens.py tests/test_gpu_plp_api.py -m gpu -q -x -o timeout=150 2>&1 | tail -4 | cut -c1-300 )
+python - <<'PY'
+import sys, os, subprocess, time
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import bench
+inp = bench.synth_inputs("mpileup30_B_hotspot", 4 << 20)
+from bamio import sam_to_bam
+bam = sam_to_bam(inp["sam"], inp["dir"] + "/s.bam")
+for args in (["mpileup", "-B", "-f", inp["fa"], bam],):
+    t = time.perf_counter(); p = subprocess.run(["samtools_amd/bin/samtools-amd"] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, STA_DRIVER_TIMING="1", STA_WINDOW_COLS=str(4 << 20))); dt = time.perf_counter() - t
+    print("default -d 8000 on the hotspot input (one 4 M-column window):", round(dt, 2), "s", p.stderr.decode().strip().split("\n")[-1][:200])
+PY

@@ -225,3 +225,23 @@ def test_overlap_rewrites_beyond_first_mates_end_survive_window_changes(tmp_path
     res = subprocess.run([oracle_bin, "mpileup", "-Q", "0", str(path)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
     pick = lambda t: [l for l in t.split(b"\n") if l.startswith(b"c\t191\t")]
     assert pick(raw) != pick(res)
+
+
+def test_depth_cap_inside_a_deep_amplicon(tmp_path, oracle_bin, product_bin):
+    """the default -d 8000 meeting a 12 000x amplicon inside an ordinary 20x contig (and -d 500 meeting it everywhere): the exact
+    replay of bam_plp_push's cap now walks only the reads between the first and the last one the cap can possibly drop -- the text
+    must stay the oracle's, in one window and with the amplicon cut by window boundaries"""
+    import numpy as np
+    from synth import synth_ref, synth_reads, synth_hotspot, write_sam, write_fasta
+    n = 40000
+    ref = synth_ref(n, seed=5)
+    rd = synth_hotspot(ref, synth_reads(ref, depth=20, read_len=150, seed=6, indel_rate=0.02), hot_start=17000, hot_len=300, hot_depth=12000, seed=7)
+    sam, fa = str(tmp_path / "h.sam"), str(tmp_path / "h.fa")
+    write_sam(sam, rd, "chrS", n)
+    write_fasta(fa, "chrS", ref)
+    for args in (["mpileup", "-B", "-f", fa, sam], ["mpileup", "-B", "-d", "500", "-f", fa, sam], ["mpileup", "-d", "9000", "-f", fa, "-r", "chrS:16900-17500", sam]):
+        want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        for env in ({}, {"STA_WINDOW_COLS": "17100"}, {"STA_WINDOW_COLS": "333"}):
+            got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+            assert got.returncode == 0, got.stderr.decode()[-400:]
+            assert got.stdout == want, (args, env)

@@ -828,7 +828,7 @@ __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W,
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(livem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)livem, 0u));
             for (int first = 0; first < nlive; first += TILE_SLOTS) {
                 const int ns = nlive - first < TILE_SLOTS ? nlive - first : TILE_SLOTS;
-                if (live && rank >= first && rank < first + TILE_SLOTS) tile_set_slot(T, rank - first, lane, v_info, v_pos, v_end, v_b8);
+                if (live && rank >= first && rank < first + TILE_SLOTS) tile_set_slot(T, rank - first, lane, ri, v_info, v_pos, v_end, v_b8);
                 wave_lds_sync();
                 const bool slot_simple = tile_phase1(T, lane, ns, R, P, p0, has_ref);
                 const unsigned long long sm = __ballot(slot_simple && (lane & 3) == 0);      // bit 4 s: slot s is a one-op read
@@ -836,7 +836,7 @@ __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W,
                 for (int s = 0; s < ns;) {
                     if (s + 4 <= ns && ((sm >> (4 * s)) & 0x1111ull) == 0x1111ull) { tile_phase2_rows4(T, s, st.col, st.cur_s, st.cur_q); s += 4; continue; }
                     if ((sm >> (4 * s)) & 1ull) tile_phase2_row(T, s, st.col, st.cur_s, st.cur_q);
-                    else tile_phase2_general(T, s, st, R, W, P, b0, p);       // (the read is the same for every lane)
+                    else tile_phase2_mixed(T, s, st, R, W, P, b0, p, p0);     // (the read is the same for every lane)
                     ++s;
                 }
                 wave_lds_sync();                              // the tile rows are rewritten by the next round

@@ -279,7 +279,9 @@ struct TileLds {
     int s_pos[TILE_SLOTS], s_end[TILE_SLOTS];   // the round's reads: the next sixteen live reads of the block of 64, in file order
     uint32_t s_b8[TILE_SLOTS], s_info[TILE_SLOTS];
     uint8_t s_lane[TILE_SLOTS];                 // their lane (= index in the block)
+    long long s_ridx[TILE_SLOTS];               // their read index
     uint8_t s_mq[TILE_SLOTS];                   // their '^' character
+    uint16_t s_plain[TILE_SLOTS * 4];           // reads with a general CIGAR: bit c of word (slot, chunk) = column 16 chunk + c was converted as plain
     uint8_t s_ref[64];                          // 4-bit reference code per column (0xff: none)
     uint64_t s_refpack[4];                      // the same, sixteen nibbles per chunk
 };
@@ -352,9 +354,9 @@ PLP_HD void tile_file_tail(TileLane &st)
     st.cur += st.sl + 1 + (st.cnt ? st.cnt : 1u);
 }
 PLP_HD bool tile_read_is_live(uint32_t info, int pos, int end, int p0, int plast) { return (info & RI_KEEP) && end > p0 && pos <= plast; }
-PLP_HD void tile_set_slot(TileLds &T, int i, int lane, uint32_t info, int pos, int end, uint32_t b8)
+PLP_HD void tile_set_slot(TileLds &T, int i, int lane, long long ridx, uint32_t info, int pos, int end, uint32_t b8)
 {
-    T.s_pos[i] = pos; T.s_end[i] = end; T.s_b8[i] = b8; T.s_info[i] = info; T.s_lane[i] = (uint8_t)lane;
+    T.s_pos[i] = pos; T.s_end[i] = end; T.s_b8[i] = b8; T.s_info[i] = info; T.s_lane[i] = (uint8_t)lane; T.s_ridx[i] = ridx;
 }
 
 // 16 reference codes (bytes, 0xff = no reference) -> nibble k = code of column k; lanes 0..3 run this for their chunk
@@ -376,12 +378,42 @@ PLP_HD bool tile_phase1(TileLds &T, int lane, int nslots, const StaReadsDev &R, 
     if (idx < nslots) {
         const uint32_t info = T.s_info[idx];
         const int pos = T.s_pos[idx], end = T.s_end[idx];
-        if (info & RI_SIMPLE) {
-            simple = true;
-            const int c_lo = 16 * k;
-            const int a = pos - p0 > c_lo ? pos - p0 : c_lo, b = end - p0 < c_lo + 16 ? end - p0 : c_lo + 16;
-            if (b > a) {
-                const int d0 = a - c_lo, qb = p0 + a - pos;
+        const int c_lo = 16 * k;
+        const int a = pos - p0 > c_lo ? pos - p0 : c_lo, b = end - p0 < c_lo + 16 ? end - p0 : c_lo + 16;
+        // query index shown in the chunk's first covered column, or -1: the chunk is not plain for this read
+        int qb = -1;
+        if (info & RI_SIMPLE) { simple = true; if (b > a) qb = p0 + a - pos; }
+        else if (b > a) {
+            // A read with indels / clips / skips is still PLAIN INSIDE THIS CHUNK when its covered columns all fall in one M/=/X op and
+            // the last of them carries no indel token (resolve_general: only the op's last column can, and only before D / I / P):
+            // then qpos = column - (x - y) exactly as for a one-op read, '^' / '$' included.  Everything else stays with token_write.
+            const long long r = T.s_ridx[idx];
+            const uint32_t *cig = R.cigar + R.cig_off[r];
+            const int n = (int)(R.cig_off[r + 1] - R.cig_off[r]), lq = R.l_qseq[r];
+            const int ca = p0 + a, cb = p0 + b - 1;
+            int x = pos, y = 0;
+            for (int kk = 0; kk < n; ++kk) {
+                const uint32_t c = cig[kk];
+                const int op = (int)(c & 0xf), l = (int)(c >> 4);
+                if (cg_is_refop(op)) {
+                    if (ca < x + l) {
+                        if (cg_is_mop(op) && cb <= x + l - 1 && y + l <= lq) {
+                            bool quiet = cb < x + l - 1 || kk + 1 >= n;
+                            if (!quiet) { const int op2 = (int)(cig[kk + 1] & 0xf); quiet = op2 != CG_D && op2 != CG_I && op2 != CG_P; }
+                            if (quiet) qb = y + (ca - x);
+                        }
+                        break;
+                    }
+                    if (cg_is_mop(op)) y += l;
+                    x += l;
+                } else if (cg_is_qop(op)) y += l;
+            }
+        }
+        uint32_t plain16 = 0;
+        if (qb >= 0) {
+            {
+                const int d0 = a - c_lo;
+                if (!simple) plain16 = ((1u << (d0 + (b - a))) - 1u) & ~((1u << d0) - 1u);
                 const uint64_t boff = (uint64_t)T.s_b8[idx] << 3;
                 uint32_t q4[4] = { 0, 0, 0, 0 }, s4[3] = { 0, 0, 0 };
                 const uint64_t qa = boff + (uint64_t)qb, sa = (boff >> 1) + (uint64_t)(qb >> 1);
@@ -398,6 +430,7 @@ PLP_HD bool tile_phase1(TileLds &T, int lane, int nslots, const StaReadsDev &R, 
                 tile_convert16(q4, s4, qb, d0, b - a, T.s_refpack[k], has_ref, (uint32_t)P.min_baseQ * 0x01010101u, (info & RI_REV) != 0, hc, tc, tb, tq);
             }
         }
+        T.s_plain[slot * 4 + k] = (uint16_t)plain16;
         if (k == 0) { const int mq = (int)((info >> RI_MAPQ_SHIFT) & 0xff); T.s_mq[slot] = (uint8_t)(mq > 93 ? 126 : mq + 33); }
     }
     __builtin_memcpy(&T.tb[slot * TILE_STRIDE + 16 * k], tb, 16);
@@ -442,10 +475,11 @@ PLP_HD void tile_phase2_rows4(const TileLds &T, int slot, int col, uint32_t &cur
 }
 
 // phase 2 for a read with a general CIGAR (indels, clips, pads, skips): per-entry resolution, as k_mplp_emit does it
-PLP_HD void tile_phase2_general(const TileLds &T, int slot, TileLane &st, const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int64_t b0, int p)
+PLP_HD void tile_phase2_general(const TileLds &T, int slot, TileLane &st, const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int64_t b0, int p, int p0)
 {
     const int rpos = T.s_pos[slot], rend = T.s_end[slot];
-    const bool cov = st.walk && p >= rpos && p < rend;
+    const int c = p - p0;                                       // the lane's tile column: plain columns were converted by phase 1
+    const bool cov = st.walk && p >= rpos && p < rend && !((T.s_plain[slot * 4 + (c >> 4)] >> (c & 15)) & 1u);
     if (!PLP_WAVE_ANY(cov)) return;
     if (!cov) return;
     Entry e;
@@ -453,10 +487,16 @@ PLP_HD void tile_phase2_general(const TileLds &T, int slot, TileLane &st, const 
     e.lq = R.l_qseq[e.r];
     e.boff = (uint64_t)T.s_b8[slot] << 3;
     e.rs = resolve_general(R.cigar + R.cig_off[e.r], (int)(R.cig_off[e.r + 1] - R.cig_off[e.r]), rpos, p);
-    const int c = e.rs.is_del ? placeholder_qual(R, e.r, e.rs.qpos, e.lq, e.boff, p) : (e.rs.qpos < e.lq ? (int)R.qual[e.boff + (uint64_t)e.rs.qpos] : 0);
-    if (c < P.min_baseQ) return;
+    const int qc = e.rs.is_del ? placeholder_qual(R, e.r, e.rs.qpos, e.lq, e.boff, p) : (e.rs.qpos < e.lq ? (int)R.qual[e.boff + (uint64_t)e.rs.qpos] : 0);
+    if (qc < P.min_baseQ) return;
     Sink<true> ss; ss.g = nullptr; ss.cur = st.cur_s;
     token_write<true>(R, W, P, e, p, ss);
     st.cur_s = ss.cur;
-    PLP_LDS[st.cur_q++] = (char)(c + 33 < 126 ? c + 33 : 126);
+    PLP_LDS[st.cur_q++] = (char)(qc + 33 < 126 ? qc + 33 : 126);
+}
+// a read with a general CIGAR: its plain chunks through the tile row, the remaining columns through token_write (a column is one or the other)
+PLP_HD void tile_phase2_mixed(const TileLds &T, int slot, TileLane &st, const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int64_t b0, int p, int p0)
+{
+    tile_phase2_row(T, slot, st.col, st.cur_s, st.cur_q);
+    tile_phase2_general(T, slot, st, R, W, P, b0, p, p0);
 }

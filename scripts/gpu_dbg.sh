@@ -1,12 +1,11 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r03n2
-for wl in mpileup30 mpileup300; do
-  STA_BENCH_ONE_DEVICE=1 STA_BENCH_BACKEND=gloo timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 2 --steps 3 --warmup 1 --workload $wl $( [ $wl = mpileup30 ] && echo --verify ) > gpurun_out/r03n2/bench_n2_$wl.json 2> gpurun_out/r03n2/bench_n2_$wl.err
-  echo "$wl rc=$?"; tail -1 gpurun_out/r03n2/bench_n2_$wl.json | python -c 'import sys,json
+mkdir -p gpurun_out/dbg
+( timeout 400 python -m pytest tests/test_gpu_synth.py tests/test_gpu_goldens.py tests/test_gpu_deep_emit.py tests/test_gpu_fullsize.py -m gpu -q -x -o timeout=150 2>&1 | tail -4 | cut -c1-300 )
+( timeout 300 python -m pytest tests/test_gpu_benchsize_parity.py -m gpu -q -x -o timeout=250 -k "indel or mpileup30_B or mpileup100_B or hotspot" 2>&1 | tail -3 | cut -c1-300 )
+for wl in mpileup30_indel mpileup30_B; do
+  timeout 200 python bench.py --workload $wl --steps 10 --warmup 3 --no-pmc --no-cpu-baseline > gpurun_out/dbg/bench_$wl.json 2> gpurun_out/dbg/bench_$wl.err
+  echo "$wl rc=$?"; tail -1 gpurun_out/dbg/bench_$wl.json | python -c 'import sys,json
 try:
-    d=json.loads(sys.stdin.read()); print(round(d["value"]), d["n_gpus"], round(d["ms_per_step"],3), d.get("verify"), json.dumps(d.get("per_rank"))[:500])
+    d=json.loads(sys.stdin.read()); print(round(d["value"]), round(d["ms_per_step"],3), {k: round(v,3) for k,v in list(d["kernels_ms_per_step"].items())[:7]})
 except Exception as e: print("nojson", e)'
-  tail -3 gpurun_out/r03n2/bench_n2_$wl.err | cut -c1-300
 done
-# NCCL (RCCL) with both ranks on the one device: expected to be refused by RCCL (duplicate GPU); shown for the record
-STA_BENCH_ONE_DEVICE=1 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29578 bench.py --gpus 2 --steps 2 --warmup 1 --workload mpileup30_B > gpurun_out/r03n2/bench_n2_rccl.json 2> gpurun_out/r03n2/bench_n2_rccl.err; echo "rccl one-device rc=$?"; tail -2 gpurun_out/r03n2/bench_n2_rccl.err | cut -c1-300

@@ -176,7 +176,7 @@ int main(int argc, char **argv)
             const int nlive = (int)live.size();
             for (int first = 0; first < nlive; first += TILE_SLOTS) {
                 const int ns = std::min(TILE_SLOTS, nlive - first);
-                for (int i = 0; i < ns; ++i) { const long long ri = b0 + live[(size_t)(first + i)]; tile_set_slot(T, i, live[(size_t)(first + i)], info[(size_t)ri], pos[(size_t)ri], end[(size_t)ri], b8[(size_t)ri]); }
+                for (int i = 0; i < ns; ++i) { const long long ri = b0 + live[(size_t)(first + i)]; tile_set_slot(T, i, live[(size_t)(first + i)], ri, info[(size_t)ri], pos[(size_t)ri], end[(size_t)ri], b8[(size_t)ri]); }
                 unsigned long long sm = 0;
                 for (int lane = 0; lane < 64; ++lane) if (tile_phase1(T, lane, ns, R, P, p0, W.ref != nullptr) && (lane & 3) == 0) sm |= 1ull << lane;
                 for (int s = 0; s < ns;) {
@@ -186,7 +186,7 @@ int main(int argc, char **argv)
                     }
                     for (int lane = 0; lane < 64; ++lane) {
                         if ((sm >> (4 * s)) & 1ull) tile_phase2_row(T, s, st[lane].col, st[lane].cur_s, st[lane].cur_q);
-                        else tile_phase2_general(T, s, st[lane], R, W, P, b0, p0 + lane);
+                        else tile_phase2_mixed(T, s, st[lane], R, W, P, b0, p0 + lane, p0);
                     }
                     ++s;
                 }

@@ -254,6 +254,11 @@ typedef struct sta_cov_params {
     int32_t skip_dn;             /* bedcov -j */
     int32_t max_depth;           /* iterator depth cap (bam_mplp_set_maxcnt) */
     int32_t min_mq, rflag_require, rflag_filter, min_qlen;     /* read filters of the commands' read_bam callbacks */
+    /* coverage -m / -D (coverage.c:632-668): hist_bins > 0 adds every column at or after hist_beg to bin
+     * (pos - hist_beg) / hist_bin_width of the histogram opened with sta_cov_hist_begin -- one per column that counts
+     * (breadth), or with hist_depth the column's filtered depth summed over the files */
+    int32_t hist_bins, hist_depth;
+    int64_t hist_beg, hist_bin_width;
 } sta_cov_params;
 typedef struct sta_cov_totals {  /* coverage: sums over the window's columns (and all files) */
     uint64_t n_covered_bases, summed_coverage, summed_baseQ, quality_bases, missing_qual;
@@ -261,6 +266,10 @@ typedef struct sta_cov_totals {  /* coverage: sums over the window's columns (an
 /* per_file: [n_files][2] = {sum of per-column depth, columns at or above min_depth} (bedcov); may be NULL for coverage.
  * info->n_kept_reads = reads that entered the pileup (bedcov -c).  Synchronises the stream. */
 int sta_cov_plan(sta_engine *e, const sta_cov_params *p, sta_cov_totals *totals, uint64_t *per_file, sta_plan_info *info);
+/* The histogram lives on the device across the windows of one contig: begin zeroes n_bins 32-bit counters (they wrap like the
+ * reference's uint32_t array), fetch copies them out.  Synchronise the stream. */
+int sta_cov_hist_begin(sta_engine *e, int32_t n_bins);
+int sta_cov_hist_fetch(sta_engine *e, uint32_t *hist, int32_t n_bins);
 
 /* ---- per-column genotype-likelihood packer (bcf_call_init / bcf_call_glfgen, bam2bcf.c:38-48,65-123; errmod_cal in
  * HTSlib; the consensus call of bam_tview.c:194-212).  Columns come from the plain iterator (no filters, no overlaps), as

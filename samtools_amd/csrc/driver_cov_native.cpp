@@ -1,5 +1,5 @@
-// driver_cov_native.cpp -- `coverage` (tabular) and `bedcov` with the column work done on the device
-// (sta_cov_plan / k_cov_cols) instead of a host loop over the pileup iterator.  Same options, text and exit status
+// driver_cov_native.cpp -- `coverage` (tabular, histogram -m and depth plot -D) and `bedcov` with the column work done on the
+// device (sta_cov_plan / k_cov_cols) instead of a host loop over the pileup iterator.  Same options, text and exit status
 // as driver_coverage.cpp / driver_bedcov.cpp (which keep the reference's loops on the bam_mplp_* surface and are
 // selected with STA_COV_ITERATOR=1); reference: coverage.c:176-221,:572-700 and bedcov.c:54-70,:297-360.
 #include "../../include/samtools_amd.h"
@@ -9,10 +9,12 @@
 #include <algorithm>
 #include <cctype>
 #include <climits>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <getopt.h>
+#include <sys/ioctl.h>
 #include <string>
 #include <vector>
 
@@ -106,7 +108,7 @@ struct CStats {
     unsigned long long n_covered_bases = 0, summed_coverage = 0, summed_baseQ = 0, summed_mapQ = 0, quality_bases = 0;
     unsigned int n_reads = 0, n_selected_reads = 0;
     bool covered = false;
-    int64_t beg = 0, end = 0;
+    int64_t beg = 0, end = 0, bin_width = 0;
 };
 
 int cigar2qlen(const Rec &r)
@@ -128,6 +130,78 @@ void print_tabular_line(FILE *out, const Header &h, const std::vector<CStats> &s
             s.n_selected_reads > 0 ? s.summed_mapQ / (double)s.n_selected_reads : 0);
 }
 
+// coverage.c:163-173: 1234567 -> "1.2M" (as many decimals as thousands were divided out)
+const char *readable_bps(double base_pairs, char *buf)
+{
+    static const char *const units[] = { "", "K", "M", "G", "T" };
+    int i = 0;
+    while (base_pairs >= 1000 && i < 4) { base_pairs /= 1000; i++; }
+    sprintf(buf, "%.*f%s", i, base_pairs, units[i]);
+    return buf;
+}
+
+// coverage.c:150-161: a label centred in a ten-character field of the x axis
+const char *center_text(const char *text, char *buf, int width)
+{
+    const int len = (int)strlen(text), padding = (width - len) / 2, padding_ex = (width - len) % 2;
+    if (padding >= 1) sprintf(buf, " %*s%*s", len + padding, text, padding - 1 + padding_ex, " ");
+    else sprintf(buf, "%s", text);
+    return buf;
+}
+
+// coverage.c:223-304: ten text rows over hist_size columns; a column's height is its bin value relative to the largest bin, drawn
+// in eighths of a row with the UTF-8 block elements (or halves with '.' ':' for -A), the contig's statistics to the right
+void print_hist(FILE *out, const Header &h, const std::vector<CStats> &stats, int tid, const uint32_t *hist, int hist_size, bool full_utf, bool plot_coverage)
+{
+    static const char *const blocks8[8] = { "\xE2\x96\x81", "\xE2\x96\x82", "\xE2\x96\x83", "\xE2\x96\x84", "\xE2\x96\x85", "\xE2\x96\x86", "\xE2\x96\x87", "\xE2\x96\x88" };
+    static const char *const blocks2[2] = { ".", ":" };
+    static const char *const vline = "\xE2\x94\x82";
+    const CStats &s = stats[(size_t)tid];
+    const int n_rows = 10, blockchar_len = full_utf ? 8 : 2;
+    const char *const *block = full_utf ? blocks8 : blocks2;
+    const double region_len = (double)(s.end - s.beg);
+    std::vector<double> hist_data((size_t)(hist_size > 0 ? hist_size : 0));
+    double max_val = 0.0;
+    for (int i = 0; i < hist_size; ++i) {
+        hist_data[(size_t)i] = (plot_coverage ? 1 : 100) * hist[i] / (double)s.bin_width;
+        if (hist_data[(size_t)i] > max_val) max_val = hist_data[(size_t)i];
+    }
+    char buf[64], buf2[64];
+    fprintf(out, "%s (%sbp)\n", h.names[(size_t)tid].c_str(), readable_bps((double)h.lens[(size_t)tid], buf));
+    const double row_bin_size = max_val / (double)n_rows;
+    for (int i = n_rows - 1; i >= 0; --i) {
+        const double current_bin = row_bin_size * i;
+        if (plot_coverage) fprintf(out, ">%8.1f ", i * row_bin_size);
+        else fprintf(out, ">%7.2f%% ", current_bin);
+        fputs(full_utf ? vline : "|", out);
+        for (int col = 0; col < hist_size; ++col) {
+            int cur_val_diff = (int)(round(blockchar_len * (hist_data[(size_t)col] - current_bin) / row_bin_size) - 1);
+            if (cur_val_diff < 0) fputc(' ', out);
+            else fputs(block[cur_val_diff >= blockchar_len ? blockchar_len - 1 : cur_val_diff], out);
+        }
+        fputs(full_utf ? vline : "|", out);
+        fputc(' ', out);
+        switch (i) {
+        case 9: fprintf(out, "Number of reads: %u", s.n_selected_reads); break;
+        case 8: if (s.n_reads - s.n_selected_reads > 0) fprintf(out, "    (%i filtered)", (int)(s.n_reads - s.n_selected_reads)); break;
+        case 7: fprintf(out, "Covered bases:   %sbp", readable_bps((double)s.n_covered_bases, buf)); break;
+        case 6: fprintf(out, "Percent covered: %.4g%%", 100.0 * s.n_covered_bases / region_len); break;
+        case 5: fprintf(out, "Mean coverage:   %.3gx", s.summed_coverage / region_len); break;
+        case 4: fprintf(out, "Mean baseQ:      %.3g", s.quality_bases > 0 ? s.summed_baseQ / (double)s.quality_bases : 0); break;
+        case 3: fprintf(out, "Mean mapQ:       %.3g", s.summed_mapQ / (double)s.n_selected_reads); break;
+        case 1: fprintf(out, "Histo bin width: %sbp", readable_bps((double)s.bin_width, buf)); break;
+        case 0: if (plot_coverage) fprintf(out, "Histo max cov:   %.5g", max_val); else fprintf(out, "Histo max bin:   %.5g%%", max_val); break;
+        }
+        fputc('\n', out);
+    }
+    // the x axis: a label every ten columns, the region's end after the remainder
+    fprintf(out, "     %s", center_text(readable_bps((double)(s.beg + 1), buf), buf2, 10));
+    for (int rest = 10; rest < 10 * (hist_size / 10); rest += 10)
+        fprintf(out, "%s", center_text(readable_bps((double)(s.beg + s.bin_width * rest), buf), buf2, 10));
+    fprintf(out, "%*s%s", hist_size % 10, " ", center_text(readable_bps((double)s.end, buf), buf2, 10));
+    fprintf(out, "\n");
+}
+
 }  // namespace
 
 extern "C" int sta_main_coverage(int argc, char **argv)
@@ -135,8 +209,9 @@ extern "C" int sta_main_coverage(int argc, char **argv)
     if (getenv("STA_COV_ITERATOR")) return sta_main_coverage_iter(argc, argv);
     int c, i, max_depth = 1000000, opt_min_baseQ = 0, opt_min_mapQ = 0, opt_min_len = 0, mindepth = 1;
     int fail_flags = 4 | 256 | 512 | 1024, required_flags = 0;
-    bool opt_print_header = true;
-    const char *opt_reg = nullptr, *opt_output_file = nullptr;
+    bool opt_print_header = true, opt_print_tabular = true, opt_print_histogram = false, opt_plot_coverage = false, opt_full_utf = true, opt_full_width = true;
+    int opt_n_bins = 50;
+    const char *opt_reg = nullptr, *opt_output_file = nullptr, *opt_file_list = nullptr;
     static const struct option lopts[] = {
         { "rf", required_argument, NULL, 1 }, { "ff", required_argument, NULL, 2 }, { "incl-flags", required_argument, NULL, 1 },
         { "excl-flags", required_argument, NULL, 2 }, { "min-read-len", required_argument, NULL, 'l' }, { "min-MQ", required_argument, NULL, 'q' },
@@ -144,43 +219,57 @@ extern "C" int sta_main_coverage(int argc, char **argv)
         { "histogram", no_argument, NULL, 'm' }, { "ascii", no_argument, NULL, 'A' }, { "plot-depth", no_argument, NULL, 'D' },
         { "output", required_argument, NULL, 'o' }, { "no-header", no_argument, NULL, 'H' }, { "n-bins", required_argument, NULL, 'w' },
         { "region", required_argument, NULL, 'r' }, { "depth", required_argument, NULL, 'd' }, { "min-depth", required_argument, NULL, 3 },
-        { NULL, 0, NULL, 0 } };
+        { "bam-list", required_argument, NULL, 'b' }, { NULL, 0, NULL, 0 } };
     optind = 1;
     while ((c = getopt_long(argc, argv, "Ao:l:q:Q:hHw:r:b:md:D", lopts, NULL)) >= 0) {
         switch (c) {
         case 1: if ((required_flags = str2flag(optarg)) < 0) { fprintf(stderr, "Could not parse --rf %s\n", optarg); return 1; } break;
         case 2: if ((fail_flags = str2flag(optarg)) < 0) { fprintf(stderr, "Could not parse --ff %s\n", optarg); return 1; } break;
         case 3: if ((i = atoi(optarg)) > 0) mindepth = i; break;
-        case 'o': opt_output_file = optarg; break;
+        case 'o': opt_output_file = optarg; opt_full_width = false; break;
         case 'l': opt_min_len = atoi(optarg); break;
         case 'q': opt_min_mapQ = atoi(optarg); break;
         case 'Q': opt_min_baseQ = atoi(optarg); break;
         case 'd': max_depth = atoi(optarg); break;
         case 'r': opt_reg = optarg; break;
         case 'H': opt_print_header = false; break;
-        case 'm': case 'A': case 'D': case 'w': case 'b':
-            fprintf(stderr, "samtools coverage: option -%c (histogram / plot / file list) is not provided by the MI355X engine build\n", c); return 1;
+        case 'w': opt_n_bins = atoi(optarg); opt_full_width = false; opt_print_histogram = true; opt_print_tabular = false; break;
+        case 'b': opt_file_list = optarg; break;
+        case 'm': opt_print_histogram = true; opt_print_tabular = false; break;
+        case 'A': opt_full_utf = false; opt_print_histogram = true; opt_print_tabular = false; break;
+        case 'D': opt_print_histogram = true; opt_print_tabular = false; opt_plot_coverage = true; break;
         default: fprintf(stderr, "Usage: samtools coverage [options] in1.bam [in2.bam [...]]\n"); return 1;
         }
     }
-    if (optind == argc) { fprintf(stderr, "Usage: samtools coverage [options] in1.bam [in2.bam [...]]\n"); return 1; }
+    if (optind == argc && !opt_file_list) { fprintf(stderr, "Usage: samtools coverage [options] in1.bam [in2.bam [...]]\n"); return 1; }
     FILE *file_out = stdout;
     if (opt_output_file && strcmp(opt_output_file, "-") != 0) {
         file_out = fopen(opt_output_file, "w");
         if (!file_out) { fprintf(stderr, "samtools coverage: Cannot open \"%s\" for writing.\n", opt_output_file); return 1; }
     }
-    const int nfiles = argc - optind;
+    if (opt_n_bins <= 0 || opt_full_width) {
+        // coverage.c:427-451: the terminal's width ($COLUMNS, else the tty behind stderr) less the 40 characters beside the plot
+        int columns = 0;
+        if (const char *env_columns = getenv("COLUMNS")) columns = atoi(env_columns);
+        else { struct winsize w; if (ioctl(2, TIOCGWINSZ, &w) == 0) columns = w.ws_col; }
+        opt_n_bins = columns > 60 ? columns - 40 : 40;
+    }
+    std::vector<std::string> fns;
+    if (opt_file_list) {
+        if (!read_file_list(opt_file_list, &fns)) { fprintf(stderr, "samtools coverage: Cannot open file list \"%s\".\n", opt_file_list); return 1; }
+    } else for (i = optind; i < argc; ++i) fns.push_back(argv[i]);
+    const int nfiles = (int)fns.size();
     std::vector<std::unique_ptr<AlnReader>> readers;
     std::vector<CStats> stats;
     int reg_tid = -1; int64_t reg_beg = 0, reg_end = INT64_MAX;
     for (i = 0; i < nfiles; ++i) {
         std::string err;
-        auto r = AlnReader::open(argv[optind + i], &err);
-        if (!r) { fprintf(stderr, "samtools coverage: Could not open \"%s\"\n", argv[optind + i]); return 1; }
+        auto r = AlnReader::open(fns[(size_t)i], &err);
+        if (!r) { fprintf(stderr, "samtools coverage: Could not open \"%s\"\n", fns[(size_t)i].c_str()); return 1; }
         if (opt_reg) {
             int t; int64_t b, e;
             if (!parse_region(r->header(), opt_reg, &t, &b, &e)) {
-                fprintf(stderr, "samtools coverage: Failed to parse region \"%s\". Check the region format or region name presence in the file \"%s\"\n", opt_reg, argv[optind + i]);
+                fprintf(stderr, "samtools coverage: Failed to parse region \"%s\". Check the region format or region name presence in the file \"%s\"\n", opt_reg, fns[(size_t)i].c_str());
                 return 1;
             }
             r->set_region(t, b, e);
@@ -191,10 +280,14 @@ extern "C" int sta_main_coverage(int argc, char **argv)
     const Header &h = readers[0]->header();
     const int n_targets = h.nref();
     stats.assign((size_t)(n_targets > 0 ? n_targets : 1), CStats());
+    int64_t n_bins = opt_n_bins;
+    std::vector<uint32_t> hist((size_t)opt_n_bins, 0u);
     if (opt_reg) {
         CStats &s = stats[(size_t)reg_tid];
         s.beg = reg_beg; s.end = reg_end;
         if (s.end == INT64_MAX || s.end > h.lens[(size_t)reg_tid]) s.end = h.lens[(size_t)reg_tid];
+        n_bins = opt_n_bins > s.end - s.beg ? s.end - s.beg : opt_n_bins;
+        s.bin_width = (s.end - s.beg) / (n_bins > 0 ? n_bins : 1);
     }
     // read-level statistics: what coverage.c's read_bam callback counts (coverage.c:182-196)
     for (auto &r : readers) {
@@ -227,6 +320,14 @@ extern "C" int sta_main_coverage(int argc, char **argv)
         if (tid >= n_targets) { std::vector<std::vector<const Rec *>> dump; pump.fill(tid, 0, INT64_MAX, dump); pump.drop_tid_carry(); continue; }
         CStats &s = stats[(size_t)tid];
         if (!opt_reg) s.end = h.lens[(size_t)tid];
+        int64_t tid_bins = 0;
+        if (opt_print_histogram && s.end > s.beg) {
+            // coverage.c:606-609: at most one bin per base of the contig; the histogram is kept on the device while its windows run
+            tid_bins = opt_n_bins > s.end - s.beg ? s.end - s.beg : opt_n_bins;
+            s.bin_width = (s.end - s.beg) / tid_bins;
+            cp.hist_bins = (int32_t)tid_bins; cp.hist_depth = opt_plot_coverage ? 1 : 0; cp.hist_beg = s.beg; cp.hist_bin_width = s.bin_width;
+            if (sta_cov_hist_begin(eng, (int32_t)tid_bins) != STA_OK) { fprintf(stderr, "samtools coverage: %s\n", sta_last_error(eng)); status = 1; break; }
+        }
         CovAccum acc((size_t)nfiles);
         if (cov_run_tid(eng, pump, readers, tid, s.beg, s.end, cp, window_cols, false, acc, "coverage") < 0) { status = 1; break; }
         s.n_covered_bases = acc.tot.n_covered_bases; s.summed_coverage = acc.tot.summed_coverage;
@@ -234,14 +335,23 @@ extern "C" int sta_main_coverage(int argc, char **argv)
         warn |= acc.tot.missing_qual != 0;
         if (acc.n_kept) {                      // the iterator returned at least one column of this contig
             s.covered = true;
-            print_tabular_line(file_out, h, stats, tid, &opt_print_header);
+            if (opt_print_histogram) {
+                // the previous contig's plot was followed by an empty line when this one turned up (coverage.c:592-596)
+                if (last_tid >= 0) fputc('\n', file_out);
+                n_bins = tid_bins;
+                if (tid_bins > 0 && sta_cov_hist_fetch(eng, hist.data(), (int32_t)tid_bins) != STA_OK) { fprintf(stderr, "samtools coverage: %s\n", sta_last_error(eng)); status = 1; break; }
+                print_hist(file_out, h, stats, tid, hist.data(), (int)n_bins, opt_full_utf, opt_plot_coverage);
+            } else print_tabular_line(file_out, h, stats, tid, &opt_print_header);
             last_tid = tid;
         }
     }
     if (pump.error()) { fprintf(stderr, "samtools coverage: %s\n", pump.error_text()); status = 1; }
     if (!status) {
-        if (last_tid == -1 && opt_reg && *opt_reg != '*') print_tabular_line(file_out, h, stats, reg_tid, &opt_print_header);
-        if (!opt_reg)
+        if (last_tid == -1 && opt_reg && *opt_reg != '*') {
+            if (opt_print_histogram) { std::fill(hist.begin(), hist.end(), 0u); print_hist(file_out, h, stats, reg_tid, hist.data(), (int)n_bins, opt_full_utf, opt_plot_coverage); }
+            else print_tabular_line(file_out, h, stats, reg_tid, &opt_print_header);
+        }
+        if (!opt_reg && opt_print_tabular)
             for (i = 0; i < n_targets; ++i)
                 if (!stats[(size_t)i].covered) { stats[(size_t)i].end = h.lens[(size_t)i]; print_tabular_line(file_out, h, stats, i, &opt_print_header); }
         if (warn) fprintf(stderr, "samtools coverage: Warning:  Missing quality values in alignments.  Mean base quality calculated only on available values.\n");

@@ -66,7 +66,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, cov_hist, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
     DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
@@ -78,6 +78,7 @@ struct sta_engine {
     int planned = 0;   // 1 mpileup, 2 depth, 3 plp entries
     bool plp_mode = false;
     bool cov_mode = false;          // coverage / bedcov: the pipeline stops before the per-column text measuring pass
+    int32_t cov_hist_bins = 0;      // coverage -m / -D: bins of the open histogram (sta_cov_hist_begin)
     sta_mplp_params mp{};
     sta_depth_params dp{};
     StaCounters ctr_h{};
@@ -188,7 +189,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->wfirst, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
+                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->cov_hist, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
                       &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
@@ -771,7 +772,9 @@ int sta_cov_plan(sta_engine *e, const sta_cov_params *cp, sta_cov_totals *totals
     {
         ProfScope ps(e, "cov_cols");
         sta_launch_cov_cols(e->stream, e->wd, cp->mode, cp->min_baseQ, cp->min_depth, cp->skip_dn, (unsigned long long *)e->cov_out.p,
-                            (unsigned long long *)e->cov_out.p + 5);
+                            (unsigned long long *)e->cov_out.p + 5,
+                            cp->hist_bins > 0 && e->cov_hist_bins >= cp->hist_bins ? (uint32_t *)e->cov_hist.p : nullptr, cp->hist_bins, cp->hist_depth,
+                            cp->hist_beg, cp->hist_bin_width);
     }
     std::vector<uint64_t> host(5 + nf * 2);
     HIPCHK(hipMemcpyAsync(host.data(), e->cov_out.p, host.size() * 8, hipMemcpyDeviceToHost, e->stream));
@@ -783,6 +786,28 @@ int sta_cov_plan(sta_engine *e, const sta_cov_params *cp, sta_cov_totals *totals
     if (per_file) for (size_t i = 0; i < nf * 2; ++i) per_file[i] = host[5 + i];
     if (info) { memset(info, 0, sizeof *info); info->n_kept_reads = e->ctr_h.n_kept; info->piled_bases = e->ctr_h.piled_bases; info->n_maxcnt_dropped = e->ctr_h.n_dropped; }
     e->planned = 4;      // read state can be fetched; there is nothing to emit
+    return STA_OK;
+}
+
+// coverage -m / -D: the per-contig histogram sta_cov_plan adds to (coverage.c:588, :599 memset between contigs)
+int sta_cov_hist_begin(sta_engine *e, int32_t n_bins)
+{
+    if (!e || n_bins <= 0) return STA_ERR_ARG;
+    hipSetDevice(e->device);
+    if (e->cov_hist.ensure((size_t)n_bins * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+    HIPCHK(hipMemsetAsync(e->cov_hist.p, 0, (size_t)n_bins * 4, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->cov_hist_bins = n_bins;
+    return STA_OK;
+}
+
+int sta_cov_hist_fetch(sta_engine *e, uint32_t *hist, int32_t n_bins)
+{
+    if (!e || !hist || n_bins <= 0) return STA_ERR_ARG;
+    if (n_bins > e->cov_hist_bins) return fail(e, STA_ERR_ARG, "histogram was opened with fewer bins");
+    hipSetDevice(e->device);
+    HIPCHK(hipMemcpyAsync(hist, e->cov_hist.p, (size_t)n_bins * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return STA_OK;
 }
 

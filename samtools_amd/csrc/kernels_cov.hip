@@ -7,11 +7,34 @@
 // and the per-window totals are block-reduced into a handful of 64-bit counters.  No text, no per-column output.
 #include "dev_util.h"
 
-struct CovPar { int32_t mode, min_baseQ, min_depth, skip_dn; };
+struct CovPar { int32_t mode, min_baseQ, min_depth, skip_dn, hist_bins, hist_depth; int64_t hist_beg, hist_bin_width; };
+
+// coverage -m / -D (coverage.c:632-668): `add` goes to bin (pos - hist_beg) / hist_bin_width.  Columns of a wave are consecutive, so
+// the bins are non-decreasing over the lanes: one lane per run of equal bins adds the run's sum (a 64-lane wave usually lies in one bin)
+__device__ __forceinline__ void cov_hist_add(const CovPar &P, uint32_t *hist, int64_t pos, bool on, uint32_t add)
+{
+    const int lane = threadIdx.x & 63;
+    int64_t bin = -1;
+    if (on && pos >= P.hist_beg) { bin = (pos - P.hist_beg) / P.hist_bin_width; if (bin >= P.hist_bins) bin = -1; }
+    if (bin < 0) add = 0;
+    const int b32 = (int)bin;
+    // inclusive prefix sum of `add` over the wave, then the sum of a run = prefix at its last lane - prefix before its first
+    uint32_t pre = add;
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl_up((int)pre, d); if (lane >= d) pre += o; }
+    const int prev_bin = __shfl_up(b32, 1), next_bin = __shfl_down(b32, 1);
+    const bool head = lane == 0 || prev_bin != b32, tail = lane == 63 || next_bin != b32;
+    const unsigned long long heads = __ballot(head);
+    const int first = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));          // first lane of this lane's run
+    const uint32_t before_all = (uint32_t)__shfl((int)pre, first > 0 ? first - 1 : 0);   // (every lane takes part in the shuffle)
+    if (tail && b32 >= 0) {
+        const uint32_t sum = pre - (first > 0 ? before_all : 0u);
+        if (sum) atomicAdd(&hist[b32], sum);
+    }
+}
 
 // totals[0..4] = n_covered_bases, summed_coverage, summed_baseQ, quality_bases, missing_qual (coverage)
 // per_file[f*2 + 0] = cnt, [f*2 + 1] = pcov (bedcov)
-__global__ void __launch_bounds__(256) k_cov_cols(StaWinDev W, CovPar P, unsigned long long *totals, unsigned long long *per_file)
+__global__ void __launch_bounds__(256) k_cov_cols(StaWinDev W, CovPar P, unsigned long long *totals, unsigned long long *per_file, uint32_t *hist)
 {
     const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
@@ -24,6 +47,7 @@ __global__ void __launch_bounds__(256) k_cov_cols(StaWinDev W, CovPar P, unsigne
     const int plast = p0 + 63 < W.col_end ? p0 + 63 : W.col_end - 1;
 
     unsigned long long depth = 0, sumq_all = 0, nq_all = 0, noq = 0;
+    uint32_t hsum = 0;                     // coverage -D: the per-file depths of this column, summed
     unsigned long long okmask = 0;         // bedcov -d: bit f = this column reaches the depth threshold in file f
     bool count_base = false, visited = false;
     for (int f = 0; f < W.nfiles; ++f) {
@@ -60,6 +84,7 @@ __global__ void __launch_bounds__(256) k_cov_cols(StaWinDev W, CovPar P, unsigne
             // coverage.c:639-662
             int dap = (int)n_plp - (int)n_dn - (int)n_low;
             if (dap > 0) { count_base = true; depth += (unsigned long long)dap; }
+            hsum += (uint32_t)dap;
             sumq_all += sumq; nq_all += nq;
         } else {
             // bedcov.c:318-330 (deletions / ref skips are subtracted with -j, and also whenever -d is given)
@@ -77,6 +102,7 @@ __global__ void __launch_bounds__(256) k_cov_cols(StaWinDev W, CovPar P, unsigne
         unsigned long long v[5] = { take ? 1ull : 0ull, take ? depth : 0ull, take ? sumq_all : 0ull, take ? nq_all : 0ull, active ? noq : 0ull };
         unsigned long long *const dst[5] = { &totals[0], &totals[1], &totals[2], &totals[3], &totals[4] };
         block_reduce_atomic<5, 5>(v, dst);
+        if (P.hist_bins > 0) cov_hist_add(P, hist, W.origin + p, active, P.hist_depth ? hsum : (take ? 1u : 0u));
     } else if (P.min_depth >= 0) {
         // the iterator only visits columns where some file has an entry: only those can count towards the -d column
         for (int f = 0; f < W.nfiles && f < 64; ++f) {
@@ -88,10 +114,11 @@ __global__ void __launch_bounds__(256) k_cov_cols(StaWinDev W, CovPar P, unsigne
 }
 
 void sta_launch_cov_cols(hipStream_t s, const StaWinDev &w, int mode, int min_baseQ, int min_depth, int skip_dn,
-                         unsigned long long *totals, unsigned long long *per_file)
+                         unsigned long long *totals, unsigned long long *per_file,
+                         uint32_t *hist, int hist_bins, int hist_depth, int64_t hist_beg, int64_t hist_bin_width)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
-    CovPar p{ mode, min_baseQ, min_depth, skip_dn };
-    hipLaunchKernelGGL(k_cov_cols, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, w, p, totals, per_file);
+    CovPar p{ mode, min_baseQ, min_depth, skip_dn, hist && hist_bin_width > 0 ? hist_bins : 0, hist_depth, hist_beg, hist_bin_width };
+    hipLaunchKernelGGL(k_cov_cols, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, w, p, totals, per_file, hist);
 }

@@ -115,7 +115,8 @@ void sta_launch_md_len(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, 
 void sta_launch_md_emit(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int use_equal, int bin_qual, int max_nm,
                         const int32_t *nm, const uint64_t *md_off, char *md_text, uint8_t *seq_work);
 void sta_launch_cov_cols(hipStream_t s, const StaWinDev &w, int mode, int min_baseQ, int min_depth, int skip_dn,
-                         unsigned long long *totals /*[5]*/, unsigned long long *per_file /*[nfiles][2]*/);
+                         unsigned long long *totals, unsigned long long *per_file,
+                         uint32_t *hist, int hist_bins, int hist_depth, int64_t hist_beg, int64_t hist_bin_width);
 
 // overlap (mate) resolution
 size_t sta_overlap_table_slots(int64_t n_reads);

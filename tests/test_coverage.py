@@ -42,3 +42,50 @@ def test_engine_coverage_matches_reference_goldens(product_bin, oracle_bin, tmp_
     for args in (["-r", "17:200-900", big], ["-H", "--ff", "UNMAP,DUP", "-l", "50", "-Q", "20", big], ["-q", "30", "-d", "10", big],
                  ["--min-depth", "40", "-Q", "30"] + three, ["-r", "17:4100-4200", big]):
         assert run(product_bin, args, iterator) == run(oracle_bin, args), args
+
+
+# ---- histogram (-m / -A / -w) and depth plot (-D): coverage.c:223-304.  The reference holds no expected output for these modes
+# (the oracle's plot is unpinned); what can be checked independently is that the numbers the plot prints agree with `depth`.
+def hist_args(big, three):
+    return (["-m", big], ["-A", "-w", "32", big], ["-D", "-w", "37", big], ["-m", "-r", "17:100-2000", big], ["-D", "-A", "-Q", "20", "--min-depth", "3"] + three,
+            ["-w", "50", "-r", "17:4100-4200", big], ["-w", "2000", "-r", "17:150-200", big], ["-m", "-o", "-", big])
+
+
+def test_oracle_plot_numbers_agree_with_depth(oracle_bin):
+    big = os.path.join(os.path.dirname(G), "dat", "mpileup.1.sam")
+    out = run(oracle_bin, ["-D", "-w", "37", big]).decode()
+    # `depth -a -J`-free recount: coverage drops deletions and default-filtered reads; depth's default filter is the same flag set
+    p = subprocess.run([oracle_bin, "depth", "-a", big], stdout=subprocess.PIPE, check=True)
+    dep = [int(l.split(b"\t")[2]) for l in p.stdout.splitlines()]
+    n = len(dep)
+    width = n // 37
+    bins = [0] * 37
+    for i, d in enumerate(dep):
+        if i // width < 37:
+            bins[i // width] += d
+    assert ("Histo max cov:   %.5g" % (max(bins) / width)) in out
+    assert ("Histo bin width: %dbp" % width) in out
+    rows = [l for l in out.splitlines() if l.startswith(">")]
+    assert len(rows) == 10 and all(l.count("│") == 2 for l in rows)
+
+
+@pytest.mark.gpu
+def test_engine_histogram_and_depth_plot_match_oracle(product_bin, oracle_bin, tmp_path):
+    big = os.path.join(os.path.dirname(G), "dat", "mpileup.1.sam")
+    three = [os.path.join(os.path.dirname(G), "dat", "mpileup.%d.sam" % k) for k in (1, 2, 3)]
+    env = dict(os.environ, COLUMNS="100")
+    for args in hist_args(big, three):
+        a = subprocess.run([product_bin, "coverage"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        b = subprocess.run([oracle_bin, "coverage"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert a.returncode == 0 and b.returncode == 0, (args, a.stderr[-300:], b.stderr[-300:])
+        assert a.stdout == b.stdout, args
+    # several contigs (an empty line between the plots), windows much narrower than a bin and much wider
+    from synth_rich import write_rich_sam
+    sam, _fa = write_rich_sam(str(tmp_path), seed=5, n_templates=3000)
+    for wcols in ("700", "4194304"):
+        e2 = dict(env, STA_WINDOW_COLS=wcols)
+        for args in (["-m", sam], ["-D", "-w", "64", sam], ["-A", "-w", "17", "-q", "20", sam]):
+            a = subprocess.run([product_bin, "coverage"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e2)
+            b = subprocess.run([oracle_bin, "coverage"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert a.returncode == 0 and b.returncode == 0, (args, a.stderr[-300:], b.stderr[-300:])
+            assert a.stdout == b.stdout, (wcols, args)

@@ -83,6 +83,8 @@ extern "C" {
 #define STA_AUX_SKIP     4   /* excluded by -G read-group list    */
 #define STA_AUX_ACCEPTED 8   /* carried over from an earlier window of the same iterator, where the -d cap (bam_plp_push)
                               * already accepted it: the cap is not re-tested, the read still counts as live */
+#define STA_AUX_ZQ_RESTORE 16 /* calmd -r without -A: the read's slice of the bq pool holds its ZQ:Z string; the qualities get the
+                              * stored difference back and the tag becomes BQ:Z (realn.c's ZQ -> BQ branch)          */
 
 /* where the arrays of a sta_reads / sta_window live */
 #define STA_MEM_HOST   0     /* engine copies them to HBM (pinned staging) */
@@ -307,6 +309,7 @@ typedef struct sta_calmd_params { int32_t flag; int32_t max_nm; /* -n, 0 = off *
 #define STA_CALMD_HAS_MD    1    /* state[]: NM / MD are valid (mapped record with a sequence on a contig that has a reference) */
 #define STA_CALMD_NEW_TAG   2    /*          BAQ was computed: tag[] holds the BQ:Z (or, with -A, ZQ:Z) string               */
 #define STA_CALMD_BQ_TO_ZQ  4    /*          an existing BQ:Z was applied to the qualities (realn.c renames it ZQ:Z)          */
+#define STA_CALMD_ZQ_TO_BQ  8    /*          an existing ZQ:Z was taken back out of the qualities (renamed BQ:Z; STA_AUX_ZQ_RESTORE) */
 /* info->out_bytes = bytes of MD text */
 int sta_calmd_plan(sta_engine *e, const sta_calmd_params *p, sta_plan_info *info);
 /* Results of the planned window (any pointer may be NULL): nm[n]; md_off[n+1] into md_text; state[n]; the quality, 4-bit
@@ -415,6 +418,10 @@ int sta_io_scan_region(const char *path, const char *region, int threads, int us
  * printf("%g") -- six significant digits, half rounded UP on the truncated decimal expansion inside [0.0001, 999999], "%g"
  * outside.  Host only.  Returns the length written (NUL-terminated), or -1 when cap is too small. */
 int sta_format_aux_float(double v, char *buf, int cap);
+/* Every record of `path` read with the drivers' reader and written back to out_path as SAM text behind the header, the way
+ * sam_write1 writes a record calmd did not change (bam_md.c:486-489): integer aux fields of every width as `i`, floats through
+ * kputd, B arrays comma separated.  Host only; returns 0 or <0. */
+int sta_io_write_sam(const char *path, const char *out_path);
 
 #ifdef __cplusplus
 }

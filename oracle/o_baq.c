@@ -173,7 +173,10 @@ int o_prob_realn(orec_t *b, const char *ref, hpos_t ref_len, int flag)
     zqt = rec_aux_get(b, "ZQ");
     if (zqt && *zqt != 'Z') return -1;
     if (bqt && redo_baq) bqt = NULL;          /* tag deleted and recomputed */
-    if (bqt && zqt) zqt = NULL;
+    if (bqt && zqt) {                         /* both: the ZQ tag is removed from the record */
+        rec_aux_del(b, zqt); zqt = NULL;
+        bqt = rec_aux_get(b, "BQ");
+    }
     if (bqt || zqt) {
         if ((apply_baq && zqt) || (!apply_baq && bqt)) return -3;
         if (bqt && apply_baq) {
@@ -182,6 +185,10 @@ int o_prob_realn(orec_t *b, const char *ref, hpos_t ref_len, int flag)
                 qual[i] = (uint8_t)(qual[i] + 64 < bq[i] ? 0 : qual[i] - ((int)bq[i] - 64));
             /* tag renamed BQ->ZQ in the record: mark so a second call is a no-op */
             ((uint8_t *)bqt)[-2] = 'Z';
+        } else if (zqt && !apply_baq) {       /* ZQ back to BQ: the qualities get the stored difference back */
+            const uint8_t *zq = zqt + 1;
+            for (i = 0; i < b->l_qseq; ++i) qual[i] = (uint8_t)(qual[i] + ((int)zq[i] - 64));
+            ((uint8_t *)zqt)[-2] = 'B';
         }
         return 0;
     }

@@ -74,6 +74,9 @@ int rec_copy(orec_t *dst, const orec_t *src);   /* bam_copy1 */
 hpos_t rec_rlen(const orec_t *r);               /* bam_cigar2rlen */
 hpos_t rec_endpos(const orec_t *r);             /* bam_endpos: pos + max(rlen,1) */
 const uint8_t *rec_aux_get(const orec_t *r, const char tag[2]); /* -> type byte */
+const uint8_t *rec_aux_next(const uint8_t *p, const uint8_t *end);   /* tag start -> next tag start */
+int rec_aux_del(orec_t *r, const uint8_t *v);                    /* bam_aux_del */
+void o_put_double(ostr_t *s, double d);                          /* HTSlib kputd (o_mpileup.c) */
 
 /* ---- header ---- */
 typedef struct {

@@ -151,6 +151,38 @@ const uint8_t *rec_aux_get(const orec_t *r, const char tag[2])
     return NULL;
 }
 
+/* one field further: p at a tag's first byte -> the next tag's first byte (NULL on damage) */
+const uint8_t *rec_aux_next(const uint8_t *p, const uint8_t *end)
+{
+    if (p + 3 > end) return NULL;
+    int t = p[2];
+    p += 3;
+    if (t == 'Z' || t == 'H') { while (p < end && *p) ++p; ++p; }
+    else if (t == 'B') {
+        if (p + 5 > end) return NULL;
+        int sz = aux_type_size(p[0]);
+        uint32_t n; memcpy(&n, p + 1, 4);
+        if (!sz) return NULL;
+        p += 5 + (size_t)sz * n;
+    } else {
+        int sz = aux_type_size(t);
+        if (!sz) return NULL;
+        p += sz;
+    }
+    return p <= end ? p : NULL;
+}
+
+/* bam_aux_del: v = what rec_aux_get returned (the type byte); the field is cut out of the block */
+int rec_aux_del(orec_t *r, const uint8_t *v)
+{
+    uint8_t *beg = (uint8_t *)v - 2, *end = r->aux + r->l_aux;
+    const uint8_t *nx = rec_aux_next(beg, end);
+    if (!nx) return -1;
+    memmove(beg, nx, (size_t)(end - nx));
+    r->l_aux -= (int)(nx - beg);
+    return 0;
+}
+
 /* ---------------- header ---------------- */
 int hdr_name2tid(const ohdr_t *h, const char *name)
 {

@@ -294,6 +294,8 @@ static void smpl_add(smpl_t *sm, const char *fn, const char *txt)
  * to an integer, half a unit of the sixth significant digit added, the decimal digits written right to left into a small
  * buffer, cut to six significant digits, the point inserted and trailing zeros culled.  Unlike "%g" this rounds half UP on the
  * truncated decimal expansion: 123456.5 -> "123457", 12345.25 -> "12345.3". */
+static void put_double(ostr_t *s, double d);
+void o_put_double(ostr_t *s, double d) { put_double(s, d); }
 static void put_double(ostr_t *s, double d)
 {
     char buf[21], *cp = buf + 20, *ep;

@@ -186,6 +186,9 @@ _PROTOS = {
     "sta_io_scan": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sta_io_scan_region": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "sta_format_aux_float": (C.c_int, [C.c_double, C.c_char_p, C.c_int]),
+    "sta_io_write_sam": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "sta_cov_hist_begin": (C.c_int, [_P, C.c_int32]),
+    "sta_cov_hist_fetch": (C.c_int, [_P, _P, C.c_int32]),
 }
 EXPORTED_SYMBOLS = sorted(_PROTOS)
 for _name, (_res, _args) in _PROTOS.items():
@@ -247,6 +250,13 @@ def io_scan_region(path, region, threads=0, use_index=True):
     if rc != 0:
         raise RuntimeError("sta_io_scan_region(%s, %s) failed: %d" % (path, region, rc))
     return n.value, h.value, bool(u.value)
+
+
+def io_write_sam(path, out_path):
+    """every record of a SAM/BAM file written back as SAM text by the drivers' reader + record formatter; needs no device."""
+    rc = lib.sta_io_write_sam(os.fsencode(path), os.fsencode(out_path))
+    if rc != 0:
+        raise RuntimeError("sta_io_write_sam(%s) failed: %d" % (path, rc))
 
 
 def main_depth(args):

@@ -1,17 +1,22 @@
-// driver_calmd.cpp -- `samtools-amd calmd`: calmd's per-record arithmetic on the engine.
+// driver_calmd.cpp -- `samtools-amd calmd`: calmd on the engine, records out as SAM text.
 // The loop of bam_fillmd (bam_md.c:457-497) restated over batches: records of one contig are staged as a window (the window is
-// only a coordinate frame here), sta_calmd_plan runs BAQ (-r) and the MD / NM kernels, and the fields calmd changes are dumped:
-//   calmd [-e] [-r] [-A] [-E] [-q] [-n max_nm] in.bam ref.fa
-//   qname  flag  rname  pos  mapq  NM|*  MD|*  SEQ  QUAL  BQ:Z:..|ZQ:Z:..|ZQ<-BQ|*
-// It is not a SAM/BAM writer: sam_write1 and the aux re-encoding are HTSlib I/O, outside the hot path.
+// only a coordinate frame here), sta_calmd_plan runs BAQ (-r) and the MD / NM kernels, and every record is written the way
+// sam_write1 would write it after sam_prob_realn + bam_fillmd1_core touched it:
+//   calmd [-e] [-r] [-A] [-E] [-q] [-d] [-N] [-Q] [-n max_nm] [--no-PG] in.bam ref.fa  > out.sam
+// The device computes what changes (NM, the MD string, '=' bases, qualities, the BQ / ZQ string and which of realn.c's tag branches a
+// record took: kernels_md.hip); the host keeps the aux fields as text (host_io.h Rec::auxv) and does the bookkeeping of
+// bam_md.c:156-199 on them -- a tag whose stored value is right stays where it is, a wrong one is removed and the new value appended.
+// Output is SAM with the header (mode "wh"); BAM output (-b / -u) is HTSlib's writer and is not provided, nor is -C.
 #include "../../include/samtools_amd.h"
 #include "host_io.h"
 #include "host_stage.h"
+#include <cctype>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <getopt.h>
+#include <set>
 
 using namespace sta;
 
@@ -21,38 +26,45 @@ struct Ctx {
     sta_engine *eng = nullptr;
     sta_calmd_params cp{};
     const Header *h = nullptr;
+    bool quiet = false, drop_tag = false, update = true;
     std::vector<Rec> batch;
     StagedFile staged;
     std::vector<int32_t> nm; std::vector<uint64_t> off; std::vector<char> md; std::vector<uint8_t> state, qual, seq, tag;
     std::string line;
+    FILE *out = stdout;
 };
 
-void print_plain(const Header &h, const Rec &r)
+int find_tag(const std::vector<std::string> &aux, const char *tag)
 {
-    static const char nt[] = "=ACMGRSVTWYHKDBN";
-    printf("%s\t%d\t%s\t%lld\t%d\t*\t*\t", r.qname.c_str(), (int)r.flag, r.tid >= 0 ? h.names[(size_t)r.tid].c_str() : "*", (long long)r.pos + 1, (int)r.mapq);
-    if (r.l_qseq == 0) fputs("*\t*\t", stdout);
-    else {
-        for (int i = 0; i < r.l_qseq; ++i) putchar(nt[(r.seq[(size_t)i >> 1] >> ((~i & 1) << 2)) & 0xf]);
-        putchar('\t');
-        if (r.qual[0] == 0xff) putchar('*'); else for (int i = 0; i < r.l_qseq; ++i) putchar(r.qual[(size_t)i] + 33);
-        putchar('\t');
-    }
-    fputs("*\n", stdout);
+    for (size_t i = 0; i < aux.size(); ++i) if (aux[i].size() >= 5 && aux[i][0] == tag[0] && aux[i][1] == tag[1]) return (int)i;
+    return -1;
 }
+
+void put_record(Ctx &c, const Rec &r, const uint8_t *seq4, const uint8_t *qual, const std::vector<std::string> &aux)
+{
+    format_sam_record(*c.h, r, seq4, qual, aux, c.line);
+    fwrite(c.line.data(), 1, c.line.size(), c.out);
+}
+
+void put_unchanged(Ctx &c, const Rec &r) { put_record(c, r, r.seq.data(), r.qual.data(), r.auxv); }
 
 // one batch = records of one contig in non-decreasing position order
 int flush(Ctx &c, int tid, const std::string *ref)
 {
     if (c.batch.empty()) return 0;
-    if (!ref) { for (const Rec &r : c.batch) print_plain(*c.h, r); c.batch.clear(); return 0; }
+    if (!ref) { for (const Rec &r : c.batch) put_unchanged(c, r); c.batch.clear(); return 0; }
+    const bool realn = (c.cp.flag & STA_CALMD_REALN) != 0, apply = (c.cp.flag & STA_CALMD_APPLY) != 0;
     const int64_t origin = c.batch.front().pos;
     int64_t hi = origin + 1;
     c.staged.clear();
-    for (const Rec &r : c.batch) { c.staged.add(r, origin, nullptr); hi = std::max(hi, r.end() + 1); }
+    for (Rec &r : c.batch) {
+        // realn.c without -A: a ZQ:Z tag (and no BQ:Z) goes back into the qualities; its bytes ride in the BQ pool
+        if (realn && !apply && r.has_zq && !r.has_bq && (int32_t)r.zq.size() >= r.l_qseq) { r.bq = r.zq; r.zq_restore = true; }
+        c.staged.add(r, origin, nullptr);
+        hi = std::max(hi, r.end() + 1);
+    }
     c.staged.finish();
     sta_reads view = c.staged.view();
-    if (!(c.cp.flag & STA_CALMD_APPLY)) view.bq = nullptr;
     sta_window w; memset(&w, 0, sizeof w);
     w.tid = tid; w.origin = origin; w.col_beg = 0; w.col_end = (int32_t)std::min<int64_t>(hi - origin, INT32_MAX - 1);
     w.tname = c.h->names[(size_t)tid].c_str(); w.tlen = c.h->lens[(size_t)tid];
@@ -65,35 +77,100 @@ int flush(Ctx &c, int tid, const std::string *ref)
     if (sta_fetch_calmd(c.eng, c.nm.data(), c.off.data(), c.md.data(), c.state.data(), c.qual.data(), c.seq.data(), c.tag.data()) != STA_OK) {
         fprintf(stderr, "samtools calmd: %s\n", sta_last_error(c.eng)); return -1;
     }
-    static const char nt[] = "=ACMGRSVTWYHKDBN";
+    std::string t;
     for (size_t i = 0; i < n; ++i) {
-        const Rec &r = c.batch[i];
+        Rec &r = c.batch[i];
         const size_t boff = (size_t)c.staged.base_off8[i] << 3;
-        std::string &s = c.line; s.clear();
-        char num[64];
-        s += r.qname; snprintf(num, sizeof num, "\t%d\t", (int)r.flag); s += num;
-        s += c.h->names[(size_t)tid]; snprintf(num, sizeof num, "\t%lld\t%d\t", (long long)r.pos + 1, (int)r.mapq); s += num;
-        if (c.state[i] & STA_CALMD_HAS_MD) {
-            snprintf(num, sizeof num, "%d\t", c.nm[i]); s += num;
-            s.append(c.md.data() + c.off[i], (size_t)(c.off[i + 1] - c.off[i])); s += '\t';
-        } else s += "*\t*\t";
-        if (r.l_qseq == 0) s += "*\t*\t";
-        else {
-            for (int k = 0; k < r.l_qseq; ++k) s += nt[(c.seq[(boff >> 1) + ((size_t)k >> 1)] >> ((~k & 1) << 2)) & 0xf];
-            s += '\t';
-            if (c.qual[boff] == 0xff) s += '*'; else for (int k = 0; k < r.l_qseq; ++k) s += (char)(c.qual[boff + (size_t)k] + 33);
-            s += '\t';
+        std::vector<std::string> &aux = r.auxv;
+        const uint8_t st = c.state[i];
+        if (realn && !(r.flag & 4) && r.l_qseq > 0 && r.qual[0] != 0xff) {
+            // sam_prob_realn's tag branches (HTSlib realn.c; call site bam_md.c:474-479)
+            const int bq = find_tag(aux, "BQ"), zq = find_tag(aux, "ZQ");
+            if (bq >= 0 && zq >= 0) aux.erase(aux.begin() + zq);                             // both: the ZQ tag is removed
+            if (st & STA_CALMD_BQ_TO_ZQ) { const int k = find_tag(aux, "BQ"); if (k >= 0) aux[(size_t)k][0] = 'Z'; }
+            if (st & STA_CALMD_ZQ_TO_BQ) { const int k = find_tag(aux, "ZQ"); if (k >= 0) aux[(size_t)k][0] = 'B'; }
+            if (st & STA_CALMD_NEW_TAG) {
+                t = apply ? "ZQ:Z:" : "BQ:Z:";
+                t.append((const char *)c.tag.data() + boff, (size_t)r.l_qseq);
+                aux.push_back(t);
+            }
         }
-        if (c.state[i] & STA_CALMD_NEW_TAG) {
-            s += (c.cp.flag & STA_CALMD_APPLY) ? "ZQ:Z:" : "BQ:Z:";
-            s.append((const char *)c.tag.data() + boff, (size_t)r.l_qseq);
-        } else if (c.state[i] & STA_CALMD_BQ_TO_ZQ) s += "ZQ<-BQ";
-        else s += '*';
-        s += '\n';
-        fwrite(s.data(), 1, s.size(), stdout);
+        if (r.l_qseq == 0) {
+            if (!c.quiet)
+                fprintf(stderr, "[bam_fillmd1] no sequence in alignment record for '%s' at %s:%lld, skipped\n", r.qname.c_str(), c.h->names[(size_t)tid].c_str(), (long long)r.pos + 1);
+        } else if ((st & STA_CALMD_HAS_MD) && c.update) {
+            // bam_md.c:156-193
+            const int nm = c.nm[i];
+            const int old_nm = find_tag(aux, "NM");
+            char num[48];
+            snprintf(num, sizeof num, "NM:i:%d", nm);
+            if (old_nm < 0) aux.push_back(num);
+            else {
+                const std::string &o = aux[(size_t)old_nm];
+                const int old_i = o[3] == 'i' ? (int)strtoll(o.c_str() + 5, nullptr, 10) : 0;           // bam_aux2i: 0 for a non-integer tag
+                if (old_i != nm) {
+                    if (!c.quiet) fprintf(stderr, "[bam_fillmd1] different NM for read '%s': %d -> %d\n", r.qname.c_str(), old_i, nm);
+                    aux.erase(aux.begin() + old_nm);
+                    aux.push_back(num);
+                }
+            }
+            const char *ms = c.md.data() + c.off[i];
+            const size_t ml = (size_t)(c.off[i + 1] - c.off[i]);
+            const int old_md = find_tag(aux, "MD");
+            t = "MD:Z:"; t.append(ms, ml);
+            if (old_md < 0) aux.push_back(t);
+            else {
+                const std::string &o = aux[(size_t)old_md];
+                bool is_diff = o.size() - 5 != ml;
+                for (size_t k = 0; !is_diff && k < ml; ++k) is_diff = toupper((unsigned char)o[5 + k]) != toupper((unsigned char)ms[k]);
+                if (is_diff) {
+                    if (!c.quiet) fprintf(stderr, "[bam_fillmd1] different MD for read '%s': '%s' -> '%.*s'\n", r.qname.c_str(), o.c_str() + 5, (int)ml, ms);
+                    aux.erase(aux.begin() + old_md);
+                    aux.push_back(t);
+                }
+            }
+        }
+        if (c.drop_tag && r.l_qseq > 0) {
+            // bam_md.c:195-199 (bam_aux_drop_other): nothing but the RG tag stays
+            const int rg = find_tag(aux, "RG");
+            if (rg >= 0) { std::string keep = aux[(size_t)rg]; aux.assign(1, keep); } else aux.clear();
+        }
+        put_record(c, r, c.seq.data() + (boff >> 1), c.qual.data() + boff, aux);
     }
     c.batch.clear();
     return 0;
+}
+
+// sam_hdr_add_pg(h, "samtools", VN, CL): one @PG line per end of a PP chain (or one line when there is none), ID made unique
+void put_header(Ctx &c, bool no_pg, int argc, char **argv)
+{
+    const std::string &text = c.h->text;
+    fwrite(text.data(), 1, text.size(), c.out);
+    if (!text.empty() && text.back() != '\n') fputc('\n', c.out);
+    if (no_pg) return;
+    std::vector<std::string> ids; std::set<std::string> is_pp;
+    size_t p = 0;
+    while (p < text.size()) {
+        size_t e = text.find('\n', p); if (e == std::string::npos) e = text.size();
+        if (e - p > 4 && text.compare(p, 4, "@PG\t") == 0) {
+            size_t f = p + 4;
+            while (f < e) {
+                size_t g = text.find('\t', f); if (g == std::string::npos || g > e) g = e;
+                if (g - f > 3 && text.compare(f, 3, "ID:") == 0) ids.push_back(text.substr(f + 3, g - f - 3));
+                if (g - f > 3 && text.compare(f, 3, "PP:") == 0) is_pp.insert(text.substr(f + 3, g - f - 3));
+                f = g + 1;
+            }
+        }
+        p = e + 1;
+    }
+    std::string cl = "samtools-amd";
+    for (int i = 0; i < argc; ++i) { cl += ' '; cl += argv[i]; }
+    std::set<std::string> used(ids.begin(), ids.end());
+    auto fresh = [&]() { std::string id = "samtools"; for (int k = 1; used.count(id); ++k) id = "samtools." + std::to_string(k); used.insert(id); return id; };
+    std::vector<std::string> ends;
+    for (const std::string &id : ids) if (!is_pp.count(id)) ends.push_back(id);
+    if (ends.empty()) fprintf(c.out, "@PG\tID:%s\tPN:samtools\tVN:%s\tCL:%s\n", fresh().c_str(), sta_version(), cl.c_str());
+    else for (const std::string &pp : ends) fprintf(c.out, "@PG\tID:%s\tPN:samtools\tPP:%s\tVN:%s\tCL:%s\n", fresh().c_str(), pp.c_str(), sta_version(), cl.c_str());
 }
 
 }  // namespace
@@ -102,8 +179,10 @@ extern "C" int sta_main_calmd(int argc, char **argv)
 {
     Ctx c;
     int o;
+    bool no_pg = false;
+    static const struct option lopts[] = { { "no-PG", no_argument, NULL, 1 }, { NULL, 0, NULL, 0 } };
     optind = 1;
-    while ((o = getopt(argc, argv, "erAEqn:C:dhQ")) >= 0) {
+    while ((o = getopt_long(argc, argv, "EqQreuNhbSC:n:Ad", lopts, NULL)) >= 0) {
         switch (o) {
         case 'e': c.cp.flag |= STA_CALMD_USE_EQUAL; break;
         case 'r': c.cp.flag |= STA_CALMD_REALN; break;
@@ -111,19 +190,26 @@ extern "C" int sta_main_calmd(int argc, char **argv)
         case 'E': c.cp.flag |= STA_CALMD_EXTENDED; break;
         case 'q': c.cp.flag |= STA_CALMD_BIN_QUAL; break;
         case 'n': c.cp.max_nm = atoi(optarg); break;
-        case 'Q': break;
+        case 'd': c.drop_tag = true; break;
+        case 'N': c.update = false; break;
+        case 'Q': c.quiet = true; break;
+        case 'h': case 'S': break;
+        case 1: no_pg = true; break;
+        case 'b': case 'u': fprintf(stderr, "[calmd] BAM output (-%c) is not provided: the records are written as SAM text\n", o); return 1;
         default: fprintf(stderr, "[calmd] option -%c is not part of the engine's rows\n", o); return 1;
         }
     }
-    if (argc - optind != 2) { fprintf(stderr, "usage: samtools-amd calmd [-erAEq] [-n max_nm] in.bam ref.fa\n"); return 1; }
+    if (argc - optind != 2) { fprintf(stderr, "usage: samtools-amd calmd [-erAEqdNQ] [-n max_nm] [--no-PG] in.bam ref.fa\n"); return 1; }
     if (sta_device_count() < 1) { fprintf(stderr, "samtools calmd: no usable HIP device (the MI355X engine has no CPU fallback)\n"); return 2; }
     std::string err;
     auto rd = AlnReader::open(argv[optind], &err);
     if (!rd) { fprintf(stderr, "samtools calmd: %s\n", err.c_str()); return 1; }
+    rd->set_keep_aux(true);
     c.h = &rd->header();
     auto fa = Fasta::load(argv[optind + 1]);
     if (!fa) { fprintf(stderr, "samtools calmd: Failed to open reference file '%s'\n", argv[optind + 1]); return 1; }
     if (sta_engine_create(&c.eng, 0, nullptr) != STA_OK) { fprintf(stderr, "samtools calmd: no usable HIP device\n"); return 2; }
+    put_header(c, no_pg, argc, argv);
     const bool realn = (c.cp.flag & STA_CALMD_REALN) != 0;
     size_t max_batch = 1 << 18;
     if (const char *e = getenv("STA_CALMD_BATCH")) max_batch = (size_t)std::max<long long>(1, atoll(e));
@@ -148,7 +234,7 @@ extern "C" int sta_main_calmd(int argc, char **argv)
                 } else if (sta_set_reference(c.eng, r.tid, ref->data(), (int64_t)ref->size(), STA_MEM_HOST) != STA_OK) { status = 1; break; }
             }
         }
-        if (r.tid < 0) { print_plain(*c.h, r); continue; }
+        if (r.tid < 0) { put_unchanged(c, r); continue; }
         if (ref && r.l_qseq == 0) ++skipped;
         c.batch.push_back(r);
     }
@@ -156,5 +242,6 @@ extern "C" int sta_main_calmd(int argc, char **argv)
     if (st < 0) { fprintf(stderr, "[bam_fillmd] Error reading input.\n"); status = 1; }
     if (skipped) fprintf(stderr, "[calmd] Warning: %u records skipped due to no query sequence\n", skipped);
     sta_engine_destroy(c.eng);
+    if (fflush(c.out) != 0) { fprintf(stderr, "[bam_fillmd] error when closing output file\n"); status = 1; }
     return status;
 }

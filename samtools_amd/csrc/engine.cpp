@@ -1040,7 +1040,7 @@ int sta_calmd_plan(sta_engine *e, const sta_calmd_params *cp, sta_plan_info *inf
         d.qual = (uint8_t *)b.qual_work.p;
     }
     if (n) {
-        if (realn) { ProfScope ps(e, "calmd_tag"); sta_launch_calmd_tag(s, d, apply ? 1 : 0, (uint8_t *)e->md_tag.p, (uint8_t *)e->md_state.p); }
+        if (realn) { ProfScope ps(e, "calmd_tag"); sta_launch_calmd_tag(s, d, apply ? 1 : 0, (uint8_t *)e->md_tag.p, (uint8_t *)e->md_state.p, saved_bq); }
         { ProfScope ps(e, "md_len"); sta_launch_md_len(s, d, e->wd, (int32_t *)e->md_nm.p, (uint32_t *)e->md_len.p, (uint8_t *)e->md_state.p); }
         { ProfScope ps(e, "len_scan"); sta_launch_len_scan(s, (const uint32_t *)e->md_len.p, (uint64_t *)e->offs.p, (int64_t)n, e->scan_tmp.p, e->scan_tmp.cap); }
     }

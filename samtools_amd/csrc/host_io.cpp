@@ -37,6 +37,7 @@ inline bool is_refop(int op) { return op == 0 || op == 2 || op == 3 || op == 7 |
 
 struct AlnReader::Impl {
     std::vector<std::string> want;   // aux tags to format (--output-extra)
+    bool keep_aux = false;           // every aux field as SAM text in Rec::auxv (record writers)
 
     std::unique_ptr<ByteSource> src;
     std::string path; int threads = 0;       // for seek_voffset(): the source is reopened at a block offset
@@ -257,7 +258,9 @@ static void finish_rec(Rec &r)
 
 static void tag_from_sam(const char *val, size_t n, char type, std::string &out);
 
-static int parse_sam(const Header &h, std::string &line, Rec &r, const std::vector<std::string> *want)
+static void aux_text_from_sam(const char *f, size_t n, std::string &out);
+
+static int parse_sam(const Header &h, std::string &line, Rec &r, const std::vector<std::string> *want, bool keep_aux)
 {
     char *f[11]; size_t fl[11]; int nf = 0;
     char *p = &line[0], *e = p + line.size();
@@ -300,16 +303,18 @@ static int parse_sam(const Header &h, std::string &line, Rec &r, const std::vect
     else { if (fl[10] != l) return -2; for (size_t i = 0; i < l; ++i) r.qual[i] = (uint8_t)(f[10][i] - 33); }
     r.has_bq = r.has_zq = false; r.bq.clear(); r.rg.clear(); r.mm.clear(); r.ml.clear(); r.has_ml = false;
     if (want) { r.tagtext.assign(want->size(), std::string()); r.tag_has.assign(want->size(), 0); }
+    r.auxv.clear(); r.zq.clear();
     while (aux < e) {
         char *t = (char *)memchr(aux, '\t', (size_t)(e - aux));
         size_t n = t ? (size_t)(t - aux) : (size_t)(e - aux);
+        if (keep_aux && n >= 5 && aux[2] == ':' && aux[4] == ':') { r.auxv.emplace_back(); aux_text_from_sam(aux, n, r.auxv.back()); if (r.auxv.back().empty()) r.auxv.pop_back(); }
         if (want && n >= 5 && aux[2] == ':' && aux[4] == ':')
             for (size_t w = 0; w < want->size(); ++w)
                 if (!r.tag_has[w] && (*want)[w][0] == aux[0] && (*want)[w][1] == aux[1]) { r.tag_has[w] = 1; tag_from_sam(aux + 5, n - 5, aux[3], r.tagtext[w]); }
         if (n >= 5 && aux[2] == ':' && aux[4] == ':' && aux[3] == 'Z') {
             if (aux[0] == 'R' && aux[1] == 'G') r.rg.assign(aux + 5, n - 5);
             else if (aux[0] == 'B' && aux[1] == 'Q') { r.has_bq = true; r.bq.assign(aux + 5, aux + n); }
-            else if (aux[0] == 'Z' && aux[1] == 'Q') r.has_zq = true;
+            else if (aux[0] == 'Z' && aux[1] == 'Q') { if (keep_aux && !r.has_zq) r.zq.assign(aux + 5, aux + n); r.has_zq = true; }
             else if (aux[0] == 'M' && (aux[1] == 'M' || aux[1] == 'm')) r.mm.assign(aux + 5, n - 5);
         }
         if (n >= 7 && aux[2] == ':' && aux[3] == 'B' && aux[4] == ':' && aux[0] == 'M' && (aux[1] == 'L' || aux[1] == 'l') && (aux[5] == 'C' || aux[5] == 'c')) {
@@ -387,6 +392,107 @@ static void tag_from_sam(const char *val, size_t n, char type, std::string &out)
     else out = "*";
 }
 
+// ---- an aux field as sam_format1 writes it ("TG:T:value", HTSlib sam.c; SAM spec 1.5): integers of every width as `i`, floats
+// through kputd, B arrays comma separated behind their subtype.  Kept per record only for the commands that write records (calmd).
+static void aux_put_ll(std::string &o, long long v) { char b[32]; snprintf(b, sizeof b, "%lld", v); o += b; }
+static void aux_put_fl(std::string &o, double v) { std::string t; format_kputd(v, t); o += t; }
+
+// from SAM text: what the field reads after a round trip through the binary record (sam_parse1 + sam_format1)
+static void aux_text_from_sam(const char *f, size_t n, std::string &out)
+{
+    const char type = f[3];
+    const std::string v(f + 5, n - 5);
+    out.assign(f, 5);
+    if (type == 'i') aux_put_ll(out, strtoll(v.c_str(), nullptr, 10));
+    else if (type == 'f') aux_put_fl(out, (double)strtof(v.c_str(), nullptr));
+    else if (type == 'd') aux_put_fl(out, strtod(v.c_str(), nullptr));
+    else if (type == 'A') out += v.empty() ? ' ' : v[0];
+    else if (type == 'Z' || type == 'H') out += v;
+    else if (type == 'B' && !v.empty() && strchr("cCsSiIf", v[0])) {
+        const char sub = v[0];
+        out += sub;
+        const char *p = v.c_str() + 1;
+        while (*p) {
+            if (*p == ',') { ++p; continue; }
+            char *q;
+            out += ',';
+            if (sub == 'f') { float x = strtof(p, &q); aux_put_fl(out, (double)x); }
+            else {
+                long long x = strtoll(p, &q, 10);
+                switch (sub) {     // stored at the subtype's width
+                case 'c': x = (int8_t)x; break; case 'C': x = (uint8_t)x; break; case 's': x = (int16_t)x; break;
+                case 'S': x = (uint16_t)x; break; case 'i': x = (int32_t)x; break; default: x = (uint32_t)x; break;
+                }
+                aux_put_ll(out, x);
+            }
+            if (q == p) { out.pop_back(); break; }
+            p = q;
+        }
+    } else out.clear();
+}
+
+// from the BAM encoding: tag = the two name bytes, p = the value (behind the type byte t)
+static void aux_text_from_bam(const uint8_t *tag, const uint8_t *p, int t, std::string &out)
+{
+    out.assign((const char *)tag, 2); out += ':';
+    auto num = [&](long long v) { out += "i:"; aux_put_ll(out, v); };
+    switch (t) {
+    case 'A': out += "A:"; out += (char)p[0]; break;
+    case 'c': num((int8_t)p[0]); break;
+    case 'C': num(p[0]); break;
+    case 's': { int16_t v; memcpy(&v, p, 2); num(v); break; }
+    case 'S': { uint16_t v; memcpy(&v, p, 2); num(v); break; }
+    case 'i': { int32_t v; memcpy(&v, p, 4); num(v); break; }
+    case 'I': { uint32_t v; memcpy(&v, p, 4); num(v); break; }
+    case 'f': { float v; memcpy(&v, p, 4); out += "f:"; aux_put_fl(out, (double)v); break; }
+    case 'd': { double v; memcpy(&v, p, 8); out += "d:"; aux_put_fl(out, v); break; }
+    case 'Z': case 'H': out += (char)t; out += ':'; out += (const char *)p; break;
+    case 'B': {
+        const int sub = p[0]; uint32_t cnt; memcpy(&cnt, p + 1, 4);
+        const uint8_t *q = p + 5;
+        out += "B:"; out += (char)sub;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            out += ',';
+            switch (sub) {
+            case 'c': aux_put_ll(out, (int8_t)q[0]); q += 1; break;
+            case 'C': aux_put_ll(out, q[0]); q += 1; break;
+            case 's': { int16_t v; memcpy(&v, q, 2); aux_put_ll(out, v); q += 2; break; }
+            case 'S': { uint16_t v; memcpy(&v, q, 2); aux_put_ll(out, v); q += 2; break; }
+            case 'i': { int32_t v; memcpy(&v, q, 4); aux_put_ll(out, v); q += 4; break; }
+            case 'I': { uint32_t v; memcpy(&v, q, 4); aux_put_ll(out, v); q += 4; break; }
+            default: { float v; memcpy(&v, q, 4); aux_put_fl(out, (double)v); q += 4; break; }
+            }
+        }
+        break; }
+    }
+}
+
+void format_sam_record(const Header &h, const Rec &r, const uint8_t *seq4, const uint8_t *qual, const std::vector<std::string> &aux, std::string &s)
+{
+    static const char nt[] = "=ACMGRSVTWYHKDBN";
+    char num[96];
+    s.clear();
+    s += r.qname;
+    snprintf(num, sizeof num, "\t%d\t", (int)r.flag); s += num;
+    s += (r.tid >= 0 && r.tid < h.nref()) ? h.names[(size_t)r.tid].c_str() : "*";
+    snprintf(num, sizeof num, "\t%lld\t%d\t", (long long)r.pos + 1, (int)r.mapq); s += num;
+    if (r.cigar.empty()) s += '*';
+    else for (uint32_t cg : r.cigar) { snprintf(num, sizeof num, "%u%c", cg >> 4, "MIDNSHP=XB"[cg & 0xf]); s += num; }
+    s += '\t';
+    if (r.mtid < 0) s += '*';
+    else if (r.mtid == r.tid) s += '=';
+    else s += r.mtid < h.nref() ? h.names[(size_t)r.mtid].c_str() : "*";
+    snprintf(num, sizeof num, "\t%lld\t%lld\t", (long long)r.mpos + 1, (long long)r.isize); s += num;
+    if (r.l_qseq == 0) s += "*\t*";
+    else {
+        for (int k = 0; k < r.l_qseq; ++k) s += nt[(seq4[(size_t)k >> 1] >> ((~k & 1) << 2)) & 0xf];
+        s += '\t';
+        if (qual[0] == 0xff) s += '*'; else for (int k = 0; k < r.l_qseq; ++k) s += (char)(qual[(size_t)k] + 33);
+    }
+    for (const std::string &a : aux) { s += '\t'; s += a; }
+    s += '\n';
+}
+
 static int aux_size(int t) { switch (t) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; case 'd': return 8; } return 0; }
 
 static int parse_bam(AlnReader::Impl &im, Rec &r);
@@ -397,10 +503,10 @@ int AlnReader::next_raw(Rec &r)
     if (im.is_bam) return parse_bam(im, r);
     if (im.have_line) im.have_line = false;
     else { do { if (!im.getline(im.line)) return 0; } while (im.line.empty()); }
-    return parse_sam(hdr_, im.line, r, im.want.empty() ? nullptr : &im.want);
+    return parse_sam(hdr_, im.line, r, im.want.empty() ? nullptr : &im.want, im.keep_aux);
 }
 
-static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::string> &wanted, Rec &r, int32_t n_ref);
+static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::string> &wanted, Rec &r, int32_t n_ref, bool keep_aux);
 
 static int parse_bam(AlnReader::Impl &im, Rec &r)
 {
@@ -410,11 +516,11 @@ static int parse_bam(AlnReader::Impl &im, Rec &r)
     if (n != 4 || bs < 32) return -2;
     if (im.blk.size() < (size_t)bs) im.blk.resize((size_t)bs * 2);
     if (im.read(im.blk.data(), (size_t)bs) != (size_t)bs) return -2;
-    return parse_bam_mem(im.blk.data(), bs, im.want, r, im.n_ref);
+    return parse_bam_mem(im.blk.data(), bs, im.want, r, im.n_ref, im.keep_aux);
 }
 
 // one BAM alignment record (SAM spec 4.2) of bs bytes, block_size prefix already consumed
-static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::string> &wanted, Rec &r, int32_t n_ref)
+static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::string> &wanted, Rec &r, int32_t n_ref, bool keep_aux)
 {
     int32_t refID, pos, l_seq, nref, npos, tlen; uint16_t n_cig, flag;
     memcpy(&refID, b, 4); memcpy(&pos, b + 4, 4);
@@ -436,6 +542,8 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
     const bool want = !wanted.empty();
     if (want) { r.tagtext.assign(wanted.size(), std::string()); r.tag_has.assign(wanted.size(), 0); }
     const uint8_t *cg = nullptr; uint32_t cg_n = 0;          // CG:B,I: the real CIGAR of a read with more than 65535 operations
+    r.auxv.clear(); r.zq.clear();
+    int cg_field = -1;
     while (p + 3 <= e) {
         int t = p[2]; const uint8_t *tag = p; p += 3;
         // size of the value, checked against the record end before anything is read (a truncated field is a malformed record)
@@ -449,7 +557,7 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
             int sz = aux_size(p[0]); uint32_t cnt; memcpy(&cnt, p + 1, 4);
             if (!sz || (uint64_t)sz * cnt > (uint64_t)(e - p - 5)) return -2;
             vlen = 5 + (size_t)sz * cnt;
-            if (tag[0] == 'C' && tag[1] == 'G' && (p[0] == 'I' || p[0] == 'i') && !cg) { cg = p + 5; cg_n = cnt; }      // bam_aux_get: the first CG
+            if (tag[0] == 'C' && tag[1] == 'G' && (p[0] == 'I' || p[0] == 'i') && !cg) { cg = p + 5; cg_n = cnt; cg_field = (int)r.auxv.size(); }      // bam_aux_get: the first CG
             if (tag[0] == 'M' && (tag[1] == 'L' || tag[1] == 'l') && sz == 1) { r.has_ml = true; r.ml.assign(p + 5, p + 5 + cnt); }
         } else {
             int sz = aux_size(t);
@@ -474,10 +582,11 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
                     else if (t == 'd') { double v; memcpy(&v, p, 8); format_kputd(v, out); }
                     else out = "*";
                 }
+        if (keep_aux) { r.auxv.emplace_back(); aux_text_from_bam(tag, p, t, r.auxv.back()); }
         if (t == 'Z') {
             if (tag[0] == 'R' && tag[1] == 'G') r.rg.assign((const char *)p, vlen - 1);
             else if (tag[0] == 'B' && tag[1] == 'Q') { r.has_bq = true; r.bq.assign(p, p + vlen - 1); }
-            else if (tag[0] == 'Z' && tag[1] == 'Q') r.has_zq = true;
+            else if (tag[0] == 'Z' && tag[1] == 'Q') { if (keep_aux && !r.has_zq) r.zq.assign(p, p + vlen - 1); r.has_zq = true; }
             else if (tag[0] == 'M' && (tag[1] == 'M' || tag[1] == 'm')) r.mm.assign((const char *)p, vlen - 1);
         }
         p += vlen;
@@ -490,6 +599,7 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
         && cg_n >= (uint32_t)n_cig && cg_n < (1u << 29)) {
         r.cigar.resize(cg_n);
         if (cg_n) memcpy(r.cigar.data(), cg, 4 * (size_t)cg_n);
+        if (keep_aux && cg_field >= 0 && (size_t)cg_field < r.auxv.size()) r.auxv.erase(r.auxv.begin() + cg_field);     // bam_tag2cigar removes the tag
     }
     finish_rec(r);
     return 1;
@@ -551,16 +661,17 @@ int AlnReader::parse_raw(const uint8_t *p, size_t avail, size_t *used, Rec &r, s
         int32_t bs; memcpy(&bs, p, 4);
         if (bs < 32 || (size_t)bs + 4 > avail) return -2;
         *used = (size_t)bs + 4;
-        return parse_bam_mem(p + 4, bs, im.want, r, im.n_ref);
+        return parse_bam_mem(p + 4, bs, im.want, r, im.n_ref, im.keep_aux);
     }
     const uint8_t *nl = (const uint8_t *)memchr(p, '\n', avail);
     if (!nl) return -2;
     scratch.assign((const char *)p, (size_t)(nl - p));
     *used = (size_t)(nl - p) + 1;
-    return parse_sam(hdr_, scratch, r, im.want.empty() ? nullptr : &im.want);
+    return parse_sam(hdr_, scratch, r, im.want.empty() ? nullptr : &im.want, im.keep_aux);
 }
 
 void AlnReader::set_wanted_tags(const std::vector<std::string> &tags) { p_->want = tags; }
+void AlnReader::set_keep_aux(bool on) { p_->keep_aux = on; }
 
 // parser thread: decode + region filter, one batch at a time
 void AlnReader::parse_ahead()

@@ -32,6 +32,9 @@ struct Rec {
     std::vector<uint8_t> seq;    // 4-bit packed
     std::vector<uint8_t> qual;
     std::vector<uint8_t> bq;     // BQ:Z bytes (empty if absent)
+    std::vector<uint8_t> zq;     // ZQ:Z bytes, kept only with set_keep_aux (calmd -r without -A turns them back into BQ:Z)
+    bool zq_restore = false;     // staging: `bq` holds the ZQ:Z string to be added back to the qualities (STA_AUX_ZQ_RESTORE)
+    std::vector<std::string> auxv;   // with set_keep_aux: every aux field as sam_format1 prints it ("NM:i:3"), in record order
     bool has_bq = false, has_zq = false;
     std::string rg;              // RG:Z value ("" if absent)
     std::string mm;              // MM:Z / Mm:Z base-modification list ("" if absent) and its ML / Ml probabilities (--output-mods)
@@ -54,6 +57,8 @@ public:
     void set_region(int tid, int64_t beg, int64_t end) { has_reg_ = true; rtid_ = tid; rbeg_ = beg; rend_ = end; }
     // two-character aux tags whose values next() should format into Rec::tagtext (in this order)
     void set_wanted_tags(const std::vector<std::string> &tags);
+    // keep every aux field of a record as SAM text in Rec::auxv (for the commands that write records: calmd)
+    void set_keep_aux(bool on);
     // called for every record next() returns (read-level statistics of `coverage`: coverage.c:182-196 counts in its callback)
     std::function<void(const Rec &)> on_record;
     // 1 = record, 0 = EOF, <0 = error
@@ -119,6 +124,10 @@ public:
 private:
     std::unordered_map<std::string, Ivals> m_;
 };
+
+// One record as a SAM text line the way sam_format1 writes it (HTSlib sam.c; SAM spec 1.4): seq4 / qual are the record's bases
+// (4-bit packed from an even offset, one quality byte each -- the record's own or a changed copy), aux its fields as text
+void format_sam_record(const Header &h, const Rec &r, const uint8_t *seq4, const uint8_t *qual, const std::vector<std::string> &aux, std::string &out);
 
 int str2flag(const char *s);   // bam_str2flag
 bool read_file_list(const std::string &path, std::vector<std::string> *out);   // bam_plcmd.c:944-999

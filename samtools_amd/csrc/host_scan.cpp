@@ -146,3 +146,27 @@ extern "C" int sta_io_scan_region(const char *path, const char *region, int thre
     if (used_index) *used_index = used ? 1 : 0;
     return 0;
 }
+
+// Every record of `path` read with the drivers' reader and written back as SAM text behind the header: what calmd's writer does to
+// a record it does not change (the aux fields go through their sam_format1 text form, host_io.h Rec::auxv).  Host only.
+extern "C" int sta_io_write_sam(const char *path, const char *out_path)
+{
+    if (!path || !out_path) return STA_ERR_ARG;
+    std::string err;
+    auto rd = AlnReader::open(path, &err);
+    if (!rd) return STA_ERR_IO;
+    rd->set_keep_aux(true);
+    FILE *fo = fopen(out_path, "w");
+    if (!fo) return STA_ERR_IO;
+    const Header &h = rd->header();
+    fwrite(h.text.data(), 1, h.text.size(), fo);
+    if (!h.text.empty() && h.text.back() != '\n') fputc('\n', fo);
+    Rec r; std::string line;
+    int st;
+    while ((st = rd->next(r)) > 0) {
+        format_sam_record(h, r, r.seq.data(), r.qual.data(), r.auxv, line);
+        fwrite(line.data(), 1, line.size(), fo);
+    }
+    const bool bad = fclose(fo) != 0;
+    return st < 0 || bad ? STA_ERR_IO : STA_OK;
+}

@@ -43,8 +43,8 @@ void StagedFile::add(const Rec &r, int64_t origin, const std::set<std::string> *
     flag.push_back(r.flag);
     mapq.push_back(r.mapq);
     uint8_t a = 0;
-    bool bq_ok = r.has_bq && (int32_t)r.bq.size() >= r.l_qseq;
-    if (bq_ok) a |= STA_AUX_HAS_BQ;
+    bool bq_ok = (r.has_bq || r.zq_restore) && (int32_t)r.bq.size() >= r.l_qseq;
+    if (bq_ok) a |= r.zq_restore ? STA_AUX_ZQ_RESTORE : STA_AUX_HAS_BQ;
     if (r.has_zq) a |= STA_AUX_HAS_ZQ;
     if (rg_excl && !r.rg.empty() && rg_excl->count(r.rg)) a |= STA_AUX_SKIP;
     if (r.accepted) a |= STA_AUX_ACCEPTED;

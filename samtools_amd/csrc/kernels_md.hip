@@ -14,7 +14,7 @@
 struct MdPar { int32_t use_equal, bin_qual, max_nm, apply; };
 
 // one wave per 64 consecutive records, the lanes stride over the bases of one record at a time (coalesced byte streams)
-__global__ void __launch_bounds__(256) k_calmd_tag(StaReadsDev R, MdPar P, uint8_t *tag_pool, uint8_t *state)
+__global__ void __launch_bounds__(256) k_calmd_tag(StaReadsDev R, MdPar P, uint8_t *tag_pool, uint8_t *state, const uint8_t *bq_pool)
 {
     const int lane = threadIdx.x & 63;
     const int64_t r0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(int64_t)63;
@@ -34,6 +34,9 @@ __global__ void __launch_bounds__(256) k_calmd_tag(StaReadsDev R, MdPar P, uint8
             }
         } else if (P.apply && (aux & STA_AUX_HAS_BQ) && R.bq && !(R.flag[r] & BAM_FUNMAP) && lq > 0 && R.qual_in[boff] != 0xff) {
             st |= 4;                   // an existing BQ:Z was applied by k_qual_prep (realn.c renames it ZQ:Z)
+        } else if (!P.apply && (aux & STA_AUX_ZQ_RESTORE) && bq_pool && !(R.flag[r] & BAM_FUNMAP) && lq > 0 && R.qual_in[boff] != 0xff) {
+            st |= 8;                   // ZQ:Z back to BQ:Z: the qualities get the stored difference back (realn.c: qual[i] += zq[i] - 64)
+            for (int i = lane; i < lq; i += 64) R.qual[boff + i] = (uint8_t)(R.qual_in[boff + i] + ((int)bq_pool[boff + i] - 64));
         }
         if (lane == 0) state[r] = st;
     }
@@ -150,11 +153,11 @@ __global__ void __launch_bounds__(256) k_md_emit(StaReadsDev R, StaWinDev W, MdP
         for (int i = 0; i < lq; ++i) { uint8_t q = R.qual[boff + i]; if (q >= 3) R.qual[boff + i] = (uint8_t)(q / 10 * 10 + 7); }
 }
 
-void sta_launch_calmd_tag(hipStream_t s, const StaReadsDev &r, int apply, uint8_t *tag_pool, uint8_t *state)
+void sta_launch_calmd_tag(hipStream_t s, const StaReadsDev &r, int apply, uint8_t *tag_pool, uint8_t *state, const uint8_t *bq_pool)
 {
     if (!r.n) return;
     MdPar p{ 0, 0, 0, apply };
-    hipLaunchKernelGGL(k_calmd_tag, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, s, r, p, tag_pool, state);
+    hipLaunchKernelGGL(k_calmd_tag, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, s, r, p, tag_pool, state, bq_pool);
 }
 
 void sta_launch_md_len(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int32_t *nm, uint32_t *md_len, uint8_t *state)

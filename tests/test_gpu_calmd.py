@@ -1,5 +1,6 @@
 """8(f) row 3 on the GPU: `samtools-amd calmd` (k_md_len / k_md_emit / k_calmd_tag + the BAQ kernels in plain and extended
-mode) against the oracle's restatement of bam_fillmd1_core and the BAQ tag writer, field for field."""
+mode, the aux bookkeeping of bam_md.c:156-199 and the SAM record writer) against the oracle's restatement, byte for byte: the
+whole output file and the warnings on stderr."""
 import os
 import subprocess
 
@@ -11,13 +12,15 @@ from bamio import sam_to_bam
 
 pytestmark = pytest.mark.gpu
 DAT = os.path.join(os.path.dirname(__file__), "golden", "dat")
-OPTS = [[], ["-e"], ["-r"], ["-r", "-E"], ["-r", "-A"], ["-r", "-A", "-E", "-e"], ["-q"], ["-n", "2"], ["-e", "-n", "3", "-q", "-r"]]
+OPTS = [[], ["-e"], ["-r"], ["-r", "-E"], ["-r", "-A"], ["-r", "-A", "-E", "-e"], ["-q"], ["-n", "2"], ["-e", "-n", "3", "-q", "-r"],
+        ["-d"], ["-N", "-e"], ["-Q", "-r", "-d"]]
 
 
 def run_both(oracle_bin, product_bin, args, env=None, product_args=None):
     want = subprocess.run([oracle_bin, "calmd"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    got = subprocess.run([product_bin, "calmd"] + (product_args or args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    got = subprocess.run([product_bin, "calmd", "--no-PG"] + (product_args or args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert got.returncode == want.returncode, got.stderr.decode()[-300:]
+    assert got.stderr == want.stderr, (args, got.stderr.decode()[-300:], want.stderr.decode()[-300:])
     return got.stdout, want.stdout
 
 
@@ -27,14 +30,9 @@ def test_calmd_on_the_reference_inputs(oracle_bin, product_bin, n):
     for opts in OPTS:
         got, want = run_both(oracle_bin, product_bin, opts + [sam, fa])
         assert got == want, opts
-    # the stored aligner tags are reproduced by the device path too
+    # the stored aligner tags are reproduced by the device path: the input comes back byte for byte
     got, _ = run_both(oracle_bin, product_bin, [sam, fa])
-    recs = [l.rstrip("\n").split("\t") for l in open(sam) if not l.startswith("@")]
-    for line, rec in zip(got.decode().split("\n"), recs):
-        f = line.split("\t")
-        tags = {t[:2]: t[5:] for t in rec[11:]}
-        if "MD" in tags and f[6] != "*":
-            assert f[6].upper() == tags["MD"].upper() and int(f[5]) == int(tags["NM"])
+    assert got == open(sam, "rb").read()
 
 
 @pytest.mark.parametrize("batch", [None, "97"])
@@ -49,3 +47,62 @@ def test_calmd_equals_oracle_on_synthetic_and_messy_input(tmp_path, oracle_bin, 
         for opts in OPTS:
             got, want = run_both(oracle_bin, product_bin, opts + [src, ref], env, opts + [bam, ref])
             assert got == want, (os.path.basename(src), opts)
+
+
+def test_records_that_already_carry_baq_tags(tmp_path, oracle_bin, product_bin):
+    """sam_prob_realn's tag branches (HTSlib realn.c): BQ:Z with -A is applied and renamed ZQ:Z, ZQ:Z without -A is taken back
+    out of the qualities and renamed BQ:Z, the matching cases are left alone, a record with both loses its ZQ:Z; wrong stored
+    MD / NM values are replaced on the way."""
+    sam, fa = os.path.join(DAT, "mpileup.1.sam"), os.path.join(DAT, "mpileup.ref.fa")
+    made = {}
+    for name, opts in (("bq", ["-r"]), ("zq", ["-r", "-A"]), ("bq_ext", ["-r", "-E"])):
+        out = subprocess.run([oracle_bin, "calmd"] + opts + [sam, fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+        made[name] = str(tmp_path / (name + ".sam"))
+        open(made[name], "wb").write(out)
+        assert (b"\tBQ:Z:" if name != "zq" else b"\tZQ:Z:") in out
+    # both tags on every third tagged record, a wrong NM on every fifth, MD stripped on every seventh
+    lines = open(made["bq"]).read().splitlines()
+    k = 0
+    both = []
+    for l in lines:
+        if not l.startswith("@") and "\tBQ:Z:" in l:
+            k += 1
+            f = l.split("\t")
+            if k % 3 == 0:
+                f.insert(11, "ZQ:Z:" + "@" * len(f[9]))
+            if k % 5 == 0:
+                f = [("NM:i:41" if t.startswith("NM:i:") else t) for t in f]
+            if k % 7 == 0:
+                f = [t for t in f if not t.startswith("MD:Z:")]
+            l = "\t".join(f)
+        both.append(l)
+    made["both"] = str(tmp_path / "both.sam")
+    open(made["both"], "w").write("\n".join(both) + "\n")
+    for name, path in made.items():
+        bam = sam_to_bam(path, path[:-4] + ".bam", level=1)
+        for opts in (["-r"], ["-r", "-A"], ["-r", "-E"], ["-r", "-A", "-e", "-q"], []):
+            got, want = run_both(oracle_bin, product_bin, opts + [path, fa], None, opts + [bam, fa])
+            assert got == want, (name, opts)
+    # and the round trip the two conversions promise: BQ -> (-A) ZQ -> (no -A) BQ gives the BQ file back
+    z = subprocess.run([product_bin, "calmd", "--no-PG", "-r", "-A", made["bq"], fa], stdout=subprocess.PIPE, check=True).stdout
+    zp = str(tmp_path / "z.sam"); open(zp, "wb").write(z)
+    back = subprocess.run([product_bin, "calmd", "--no-PG", "-r", zp, fa], stdout=subprocess.PIPE, check=True).stdout
+    assert back == open(made["bq"], "rb").read()
+
+
+def test_pg_line(tmp_path, product_bin):
+    """without --no-PG a @PG line is chained to the end of the header's program chain (sam_hdr_add_pg, bam_md.c:425-431)"""
+    sam, fa = os.path.join(DAT, "mpileup.1.sam"), os.path.join(DAT, "mpileup.ref.fa")
+    out = subprocess.run([product_bin, "calmd", "-e", sam, fa], stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()
+    src = open(sam).read().splitlines()
+    hdr = [l for l in out if l.startswith("@")]
+    src_hdr = [l for l in src if l.startswith("@")]
+    assert hdr[:len(src_hdr)] == src_hdr and len(hdr) == len(src_hdr) + 1
+    pg = hdr[-1].split("\t")
+    assert pg[0] == "@PG" and pg[1].startswith("ID:samtools") and pg[2] == "PN:samtools" and pg[-1].startswith("CL:samtools-amd calmd -e ")
+    prev = [l for l in src_hdr if l.startswith("@PG")]
+    if prev:
+        last_id = [t for t in prev[-1].split("\t") if t.startswith("ID:")][0][3:]
+        assert ("PP:" + last_id) in pg
+    plain = subprocess.run([product_bin, "calmd", "--no-PG", "-e", sam, fa], stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()
+    assert plain == out[:len(src_hdr)] + out[len(src_hdr) + 1:]

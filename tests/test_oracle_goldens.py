@@ -66,25 +66,52 @@ def test_oracle_glfgen_reproduces_tview_consensus_line(oracle_bin):
 
 @pytest.mark.parametrize("n", ["1", "2", "3"])
 def test_oracle_calmd_recomputes_the_md_and_nm_tags_the_reference_inputs_carry(oracle_bin, n):
-    """8(f) row 3 (bam_fillmd1_core): test/dat/mpileup.{1,2,3}.sam carry MD:Z / NM:i written by the aligner against
-    test/dat/mpileup.ref.fa, the very pair the reference's calmd test runs on (test/test.pl:3652-3661, which only checks the
-    container magic).  Recomputed values must equal the stored ones (MD compared case-insensitively, as bam_md.c:182-190 does)."""
+    """8(f) row 3 (bam_fillmd1_core + the record writer): test/dat/mpileup.{1,2,3}.sam carry MD:Z / NM:i written by the aligner
+    against test/dat/mpileup.ref.fa, the very pair the reference's calmd test runs on (test/test.pl:3652-3661, which only checks
+    the container magic).  bam_md.c:156-193 leaves a tag alone when the recomputed value equals the stored one (MD compared case-
+    insensitively), so `calmd in.sam ref.fa` must hand the input back byte for byte and stay silent; a wrong stored tag is
+    replaced at the END of the record and reported."""
     import subprocess
     dat = os.path.join(os.path.dirname(__file__), "golden", "dat")
     sam = os.path.join(dat, "mpileup.%s.sam" % n)
-    out = subprocess.run([oracle_bin, "calmd", sam, os.path.join(dat, "mpileup.ref.fa")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
-    recs = [l.rstrip("\n").split("\t") for l in open(sam) if not l.startswith("@")]
-    lines = [l.split("\t") for l in out.stdout.decode().split("\n") if l]
-    assert len(lines) == len(recs)
-    checked = 0
-    for got, rec in zip(lines, recs):
-        tags = {t[:2]: t[5:] for t in rec[11:]}
-        assert got[0] == rec[0] and got[1] == rec[1]
-        if "MD" in tags and got[6] != "*":
-            assert got[6].upper() == tags["MD"].upper(), rec[0]
-            assert int(got[5]) == int(tags["NM"]), rec[0]
-            checked += 1
-    assert checked >= 230
+    ref = os.path.join(dat, "mpileup.ref.fa")
+    out = subprocess.run([oracle_bin, "calmd", sam, ref], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    src = open(sam, "rb").read()
+    assert out.stdout == src and out.stderr == b""
+    recs = [l for l in src.decode().splitlines() if not l.startswith("@")]
+    assert sum("\tMD:Z:" in l and "\tNM:i:" in l for l in recs) >= 230
+
+
+def test_oracle_calmd_replaces_wrong_tags_and_appends_missing_ones(oracle_bin, tmp_path):
+    """hand-made damage on the reference input: a wrong NM, a wrong MD, both tags stripped"""
+    import subprocess
+    dat = os.path.join(os.path.dirname(__file__), "golden", "dat")
+    ref = os.path.join(dat, "mpileup.ref.fa")
+    lines = open(os.path.join(dat, "mpileup.1.sam")).read().splitlines()
+    hdr = [l for l in lines if l.startswith("@")]
+    recs = [l.split("\t") for l in lines if not l.startswith("@")]
+    pick = [r for r in recs if any(t.startswith("MD:Z:") for t in r[11:]) and any(t.startswith("NM:i:") for t in r[11:])][:3]
+    good = ["\t".join(r) for r in pick]
+    a, b, c = [list(r) for r in pick]
+    nm_a = [t for t in a if t.startswith("NM:i:")][0]; md_b = [t for t in b if t.startswith("MD:Z:")][0]
+    a[a.index(nm_a)] = "NM:i:77"
+    b[b.index(md_b)] = "MD:Z:1A1"
+    nm_c = [t for t in c if t.startswith("NM:i:")][0]; md_c = [t for t in c if t.startswith("MD:Z:")][0]
+    c = [t for t in c if t not in (nm_c, md_c)]
+    sam = tmp_path / "bad.sam"
+    sam.write_text("\n".join(hdr + ["\t".join(a), "\t".join(b), "\t".join(c)]) + "\n")
+    out = subprocess.run([oracle_bin, "calmd", str(sam), ref], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    got = [l for l in out.stdout.decode().splitlines() if not l.startswith("@")]
+    # the replaced tag moves to the end; everything else stays where it was
+    wa = [t for t in good[0].split("\t") if t != nm_a] + [nm_a]
+    wb = [t for t in good[1].split("\t") if t != md_b] + [md_b]
+    wc = c + [nm_c, md_c]
+    assert got == ["\t".join(wa), "\t".join(wb), "\t".join(wc)]
+    err = out.stderr.decode()
+    assert "[bam_fillmd1] different NM for read '%s': 77 -> %s" % (a[0], nm_a[5:]) in err
+    assert "[bam_fillmd1] different MD for read '%s': '1A1' -> '%s'" % (b[0], md_b[5:]) in err
+    quiet = subprocess.run([oracle_bin, "calmd", "-Q", str(sam), ref], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    assert quiet.stdout == out.stdout and quiet.stderr == b""
 
 
 @pytest.mark.parametrize("exp,require,exclude", [("44.out", 16, 0), ("46.out", 0, 16)])

@@ -26,6 +26,7 @@
  *   coverage / bedcov column loops coverage.c:621-672, bedcov.c:316-333   sta_cov_plan
  *   bcf_call_init / bcf_call_glfgen bam2bcf.c:38-48,65-123 sta_glf_plan (+ sta_glf_consensus, bam_tview.c:194-212)
  *   bam_fillmd1_core + BAQ tag     bam_md.c:64-224,474-479 sta_calmd_plan / sta_fetch_calmd
+ *   stats coverage round buffer    stats.c:311-391,1452-1508 sta_statcov_begin / _add / _fetch
  *   sam_open / sam_read1 (host)    bam_plcmd.c:500-569    sta_io_scan exercises the drivers' reader (BGZF worker pool)
  *   bam_mpileup / main_depth (CLI) bam_plcmd.c:1075, bam2depth.c:732   sta_main_mpileup / sta_main_depth
  *   pileup_loop + get_next_base    consensus_pileup.c:69-608            sta_consensus_run (columns incl. insertion columns)
@@ -273,6 +274,19 @@ int sta_cov_plan(sta_engine *e, const sta_cov_params *p, sta_cov_totals *totals,
 int sta_cov_hist_begin(sta_engine *e, int32_t n_bins);
 int sta_cov_hist_fetch(sta_engine *e, uint32_t *hist, int32_t n_bins);
 
+/* ---- `samtools stats`, the coverage distribution (COV section): stats.c:311-391 (coverage_idx, the pileup round buffer),
+ * :1452-1508 (the aligned blocks of a read go in), :1884-1892 (the lines).  The device does not keep a ring: an aligned block is a
+ * pair of marks (+1 at its first position, -1 behind its last) and a batch of marks SORTED BY POSITION becomes the histogram
+ * directly -- depth after mark i = carry_in + the sum of delta[0..i], it holds for pos[i+1] - pos[i] positions, and every
+ * non-zero depth adds that many positions to bin coverage_idx(depth).  The last mark of a batch only closes the last run (its
+ * delta is not applied: it opens the next batch).  The ring's aliasing (positions folding back modulo 5 x the longest read, the
+ * slot that misses a whole-buffer flush, the short copy when the buffer grows) is applied by the caller to the marks; the
+ * stats driver does so (driver_stats.cpp), DESIGN.md section 7 states the rules. ---- */
+typedef struct sta_statcov_params { int32_t cov_min, cov_max, cov_step; } sta_statcov_params;   /* after stats.c:2398-2405 */
+int sta_statcov_begin(sta_engine *e, const sta_statcov_params *p, int32_t *ncov);            /* zeroes 3 + (max-min)/step bins */
+int sta_statcov_add(sta_engine *e, const int64_t *pos, const int32_t *delta, int64_t n, int64_t carry_in, int mem);
+int sta_statcov_fetch(sta_engine *e, uint64_t *cov, int32_t ncov);
+
 /* ---- per-column genotype-likelihood packer (bcf_call_init / bcf_call_glfgen, bam2bcf.c:38-48,65-123; errmod_cal in
  * HTSlib; the consensus call of bam_tview.c:194-212).  Columns come from the plain iterator (no filters, no overlaps), as
  * tview drives it through bam_lplbuf.  The reference FASTA set with sta_set_reference supplies the column's base ('N' if
@@ -393,8 +407,13 @@ int sta_main_capture(int argc, char **argv, char **text, uint64_t *n_bytes);
 void sta_capture_free(char *text);
 /* `glf [-Q min_baseQ] [-t theta] [-f ref.fa] in.bam`: one text line per column (what tests diff against the oracle) */
 int sta_main_glf(int argc, char **argv);
-/* `calmd [-erAEq] [-n max_nm] in.bam ref.fa`: dumps the record fields calmd changes (not a SAM writer) */
+/* `calmd [-erAEqdNQ] [-n max_nm] [--no-PG] in.bam ref.fa`: bam_fillmd (bam_md.c:346-520); the records are written as SAM text
+ * with the header (BAM output -b / -u and -C are refused) */
 int sta_main_calmd(int argc, char **argv);
+/* `stats [-c min,max,step] [-f INT] [-F INT] [-d] [-l INT] [-I ID] in.bam`: the coverage distribution of `samtools stats`
+ * (the comment line and the COV lines of stats.c:1884-1892; nothing else of that report).  --marks-out FILE writes the sorted
+ * marks the device would be given ("epoch<TAB>position<TAB>delta" lines) instead, without touching a device. */
+int sta_main_stats(int argc, char **argv);
 /* `consensus [options] in.bam`: options, text and exit status of `samtools consensus` (bam_consensus.c:3082-3593; -X presets
  * and the named calibration tables other than :flat are not built) */
 int sta_main_consensus(int argc, char **argv);

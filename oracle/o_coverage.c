@@ -148,7 +148,7 @@ int o_main_coverage(int argc, char *argv[])
         { "min-depth", required_argument, NULL, 3 }, { "histogram", no_argument, NULL, 'm' }, { "ascii", no_argument, NULL, 'A' },
         { "plot-depth", no_argument, NULL, 'D' }, { "n-bins", required_argument, NULL, 'w' }, { NULL, 0, NULL, 0 } };
     optind = 1;
-    while ((c = getopt_long(argc, argv, "l:q:Q:Hr:d:mADw:", lopts, NULL)) >= 0) {
+    while ((c = getopt_long(argc, argv, "l:q:Q:Hr:d:mADw:o:", lopts, NULL)) >= 0) {
         switch (c) {
         case 1: if ((required_flags = str2flag(optarg)) < 0) return 1; break;
         case 2: if ((fail_flags = str2flag(optarg)) < 0) return 1; break;
@@ -159,6 +159,7 @@ int o_main_coverage(int argc, char *argv[])
         case 'd': max_depth = atoi(optarg); break;
         case 'r': reg = optarg; break;
         case 'H': print_header = 0; break;
+        case 'o': full_width = 0; if (strcmp(optarg, "-") != 0 && !freopen(optarg, "w", stdout)) { fprintf(stderr, "samtools coverage: Cannot open \"%s\" for writing.\n", optarg); return 1; } break;
         case 'w': n_bins_opt = atoi(optarg); full_width = 0; histogram = 1; tabular = 0; break;
         case 'm': histogram = 1; tabular = 0; break;
         case 'A': full_utf = 0; histogram = 1; tabular = 0; break;

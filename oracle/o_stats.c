@@ -1,0 +1,221 @@
+/*
+ * oracle/o_stats.c -- TEST INFRASTRUCTURE ONLY (CPU oracle).
+ *
+ * SURVEY.md 8(f) row 3, second half: the coverage distribution of `samtools stats` (the COV section), i.e. the pileup round
+ * buffer of stats.c restated as it is -- quirks included, because the numbers depend on them:
+ *   coverage_idx / round_buffer_lidx2ridx / round_buffer_flush / round_buffer_insert_read   stats.c:311-391
+ *   the read filters in front of it and the CIGAR walk that feeds it                           stats.c:1212-1273, :1330-1340, :1380-1393, :1452-1508
+ *   realloc_buffers' copy of the ring into a bigger one (byte counts where element counts were meant)   stats.c:690-692, :766-778
+ *   bin setup and the printed lines                                                            stats.c:2396-2411, :1884-1892
+ * The ring's aliasing rules that follow from that code (DESIGN.md section 7 spells them out for the device version):
+ *   1. an aligned block [from, to) of a read at pos P lands in slots (from - P) mod size .. (to - P) mod size: reference
+ *      positions further than `size` = 5 x (longest read so far, at least 300) behind the read's start fold back onto it;
+ *   2. when the next read starts `size` or more positions later (or at a contig change / the end), all but the LAST slot is
+ *      counted; what the last slot holds is added to the depth of the next read's first position (or, across a contig
+ *      change, of the position its slot index maps to there; at the end of the input it is lost);
+ *   3. when a read at least as long as the per-cycle arrays arrives, the ring is copied into a bigger one with memcpy(n) where
+ *      n counts elements: only the first quarter of the pending positions (and of the wrapped part) survives.
+ * PINNING: the COV lines of test/stat/{1..9,15}.stats.expected and the `.large` variants (test/test.pl:3394-3429; whole-file
+ * runs without -t / -p / regions): tests/test_stats_cov.py.
+ *
+ * Options restated: -c min,max,step  -f / -F flags  -d  -l readlen  -I read group or sample; -r -q -i -m -x -s are accepted and
+ * have no effect on this section.  -t, -p, -S and region arguments are refused.
+ */
+#include "o_plp.h"
+#include <getopt.h>
+#include <limits.h>
+
+typedef struct { int32_t *buffer; int start, size; hpos_t pos; } rbuf_t;
+
+typedef struct {
+    int cov_min, cov_max, cov_step, ncov;
+    uint64_t *cov;
+    rbuf_t rb;
+    int nbases, is_sorted, tid;
+    hpos_t pos;
+} cstat_t;
+
+static int coverage_idx(int min, int max, int n, int step, int depth)
+{
+    if (depth < min) return 0;
+    if (depth > max) return n - 1;
+    return 1 + (depth - min) / step;
+}
+
+static int lidx2ridx(int offset, int size, hpos_t refpos, hpos_t pos) { return (int)((offset + (pos - refpos) % size) % size); }
+
+static int rb_flush(cstat_t *s, hpos_t pos)
+{
+    int ibuf, idp;
+    if (pos == s->rb.pos) return 0;
+    hpos_t new_pos = pos;
+    if (pos == -1 || pos - s->rb.pos >= s->rb.size) pos = s->rb.pos + s->rb.size - 1;      /* the whole buffer -- but for its last slot */
+    if (pos < s->rb.pos) { fprintf(stderr, "Expected coordinates in ascending order, got %lld after %lld\n", (long long)pos, (long long)s->rb.pos); return -1; }
+    int ifrom = s->rb.start;
+    int ito = lidx2ridx(s->rb.start, s->rb.size, s->rb.pos, pos - 1);
+    if (ifrom > ito) {
+        for (ibuf = ifrom; ibuf < s->rb.size; ibuf++) {
+            if (!s->rb.buffer[ibuf]) continue;
+            idp = coverage_idx(s->cov_min, s->cov_max, s->ncov, s->cov_step, s->rb.buffer[ibuf]);
+            s->cov[idp]++;
+            s->rb.buffer[ibuf] = 0;
+        }
+        ifrom = 0;
+    }
+    for (ibuf = ifrom; ibuf <= ito; ibuf++) {
+        if (!s->rb.buffer[ibuf]) continue;
+        idp = coverage_idx(s->cov_min, s->cov_max, s->ncov, s->cov_step, s->rb.buffer[ibuf]);
+        s->cov[idp]++;
+        s->rb.buffer[ibuf] = 0;
+    }
+    s->rb.start = (new_pos == -1) ? 0 : lidx2ridx(s->rb.start, s->rb.size, s->rb.pos, pos);
+    s->rb.pos = new_pos;
+    return 0;
+}
+
+static int rb_insert(rbuf_t *rb, hpos_t from, hpos_t to)
+{
+    if (to - from > rb->size) { fprintf(stderr, "The read length too big (%lld), please increase the buffer length (currently %d)\n", (long long)(to - from), rb->size); return -1; }
+    if (from < rb->pos) { fprintf(stderr, "The reads are not sorted (%lld comes after %lld).\n", (long long)from, (long long)rb->pos); return -1; }
+    int ifrom = lidx2ridx(rb->start, rb->size, rb->pos, from), ito = lidx2ridx(rb->start, rb->size, rb->pos, to), ibuf;
+    if (ifrom > ito) {
+        for (ibuf = ifrom; ibuf < rb->size; ibuf++) rb->buffer[ibuf]++;
+        ifrom = 0;
+    }
+    for (ibuf = ifrom; ibuf < ito; ibuf++) rb->buffer[ibuf]++;
+    return 0;
+}
+
+/* stats.c:690-692 + :766-778 (the other per-cycle arrays the function grows do not touch this section) */
+static void grow(cstat_t *s, int seq_len)
+{
+    int n = 2 * (1 + seq_len - s->nbases) + s->nbases;
+    s->nbases = n;
+    int32_t *rbuffer = (int32_t *)calloc(sizeof(int32_t), (size_t)seq_len * 5);
+    n = s->rb.size - s->rb.start;
+    memcpy(rbuffer, s->rb.buffer + s->rb.start, (size_t)n);                      /* n BYTES, as the reference has it */
+    if (s->rb.start > 1) memcpy(rbuffer + n, s->rb.buffer, (size_t)s->rb.start);
+    s->rb.start = 0;
+    free(s->rb.buffer);
+    s->rb.buffer = rbuffer;
+    s->rb.size = seq_len * 5;
+}
+
+static int unclipped_length(const orec_t *b)
+{
+    int len = b->l_qseq;
+    for (uint32_t k = 0; k < b->n_cigar; ++k) if (cig_op(b->cigar[k]) == C_H) len += (int)cig_len(b->cigar[k]);
+    return len;
+}
+
+int o_main_stats(int argc, char *argv[])
+{
+    int c, flag_require = 0, flag_filter = 0, filter_readlen = -1, tmp;
+    const char *group_id = NULL;
+    cstat_t st; memset(&st, 0, sizeof st);
+    st.cov_min = 1; st.cov_max = 1000; st.cov_step = 1;
+    static const struct option lopts[] = {
+        { "coverage", required_argument, NULL, 'c' }, { "required-flag", required_argument, NULL, 'f' }, { "filtering-flag", required_argument, NULL, 'F' },
+        { "remove-dups", no_argument, NULL, 'd' }, { "read-length", required_argument, NULL, 'l' }, { "id", required_argument, NULL, 'I' },
+        { "ref-seq", required_argument, NULL, 'r' }, { "insert-size", required_argument, NULL, 'i' }, { "most-inserts", required_argument, NULL, 'm' },
+        { "trim-quality", required_argument, NULL, 'q' }, { "sparse", no_argument, NULL, 'x' }, { "sam", no_argument, NULL, 's' }, { NULL, 0, NULL, 0 } };
+    optind = 1;
+    while ((c = getopt_long(argc, argv, "dsxr:c:l:i:m:q:f:F:I:t:pS:", lopts, NULL)) >= 0) {
+        switch (c) {
+        case 'f': if ((tmp = str2flag(optarg)) < 0) { fprintf(stderr, "samtools stats: Unknown flag '%s'\n", optarg); return 1; } flag_require = tmp; break;
+        case 'F': if ((tmp = str2flag(optarg)) < 0) { fprintf(stderr, "samtools stats: Unknown flag '%s'\n", optarg); return 1; } flag_filter |= tmp; break;
+        case 'd': flag_filter |= F_DUP; break;
+        case 'c': if (sscanf(optarg, "%d,%d,%d", &st.cov_min, &st.cov_max, &st.cov_step) != 3) { fprintf(stderr, "Unable to parse -c %s\n", optarg); return 1; } break;
+        case 'l': filter_readlen = atoi(optarg); break;
+        case 'I': group_id = optarg; break;
+        case 'r': case 'i': case 'm': case 'q': case 'x': case 's': break;
+        default: fprintf(stderr, "[stats] option -%c is not part of the restated section (COV)\n", c); return 1;
+        }
+    }
+    if (argc - optind != 1) { fprintf(stderr, "usage: oracle_samtools stats [-c min,max,step] [-f INT] [-F INT] [-d] [-l INT] [-I ID] in.bam\n"); return 1; }
+    oreader_t *rd = rd_open(argv[optind]);
+    if (!rd) { fprintf(stderr, "samtools stats: failed to open \"%s\"\n", argv[optind]); return 1; }
+    ohdr_t *h = rd_header(rd);
+    /* stats.c:2396-2411 */
+    if (st.cov_step > st.cov_max - st.cov_min + 1) { st.cov_step = st.cov_max - st.cov_min; if (st.cov_step <= 0) st.cov_step = 1; }
+    st.ncov = 3 + (st.cov_max - st.cov_min) / st.cov_step;
+    st.cov_max = st.cov_min + ((st.cov_max - st.cov_min) / st.cov_step + 1) * st.cov_step - 1;
+    st.cov = (uint64_t *)calloc(sizeof(uint64_t), (size_t)st.ncov);
+    st.nbases = 300;
+    st.rb.size = st.nbases * 5;
+    st.rb.buffer = (int32_t *)calloc(sizeof(int32_t), (size_t)st.rb.size);
+    st.is_sorted = 1; st.tid = -1; st.pos = -1;
+    /* stats.c:2151-2177: the read groups whose ID or SM is `group_id` */
+    char **rg_ok = NULL; int n_rg_ok = 0;
+    if (group_id) {
+        for (const char *l = h->text; l && *l; ) {
+            const char *e = strchr(l, '\n'); size_t n = e ? (size_t)(e - l) : strlen(l);
+            if (n > 4 && strncmp(l, "@RG\t", 4) == 0) {
+                char *line = strndup(l, n), *id = NULL, *sm = NULL, *save = NULL;
+                for (char *f = strtok_r(line + 4, "\t", &save); f; f = strtok_r(NULL, "\t", &save)) {
+                    if (strncmp(f, "ID:", 3) == 0 && !id) id = f + 3;
+                    if (strncmp(f, "SM:", 3) == 0 && !sm) sm = f + 3;
+                }
+                if (id && (strcmp(id, group_id) == 0 || (sm && strcmp(sm, group_id) == 0))) {
+                    rg_ok = (char **)realloc(rg_ok, sizeof(char *) * (size_t)(n_rg_ok + 1)); rg_ok[n_rg_ok++] = strdup(id);
+                }
+                free(line);
+            }
+            l = e ? e + 1 : NULL;
+        }
+    }
+    orec_t b; memset(&b, 0, sizeof b);
+    int r, ret = 0;
+    while ((r = rd_next(rd, &b)) >= 0) {
+        /* stats.c:1212-1273 */
+        if (group_id) {
+            const uint8_t *rg = rec_aux_get(&b, "RG");
+            if (!rg) continue;
+            int ok = 0;
+            for (int k = 0; k < n_rg_ok; ++k) if (strcmp(rg_ok[k], (const char *)rg + 1) == 0) { ok = 1; break; }
+            if (!ok) continue;
+        }
+        if (flag_require && (b.flag & flag_require) != flag_require) continue;
+        if (flag_filter && (b.flag & flag_filter)) continue;
+        if (filter_readlen != -1 && b.l_qseq != filter_readlen) continue;
+        if (b.flag & F_SECONDARY) continue;
+        if (!b.l_qseq) continue;
+        int read_len = unclipped_length(&b);
+        if (read_len >= st.nbases) grow(&st, read_len);
+        if (b.flag & F_UNMAP) continue;
+        if (b.n_cigar == 0) { fprintf(stderr, "FIXME: mapped read with no cigar?\n"); ret = 1; break; }
+        /* stats.c:1380-1393 */
+        if (st.tid == b.tid && b.pos < st.pos) st.is_sorted = 0;
+        st.pos = b.pos;
+        if (!st.is_sorted) continue;
+        if (st.tid == -1 || st.tid != b.tid) { if (rb_flush(&st, -1) < 0) { ret = 1; break; } }
+        st.tid = b.tid;
+        /* stats.c:1452-1508 */
+        if (rb_flush(&st, b.pos) < 0) { ret = 1; break; }
+        hpos_t p = b.pos;
+        int bad = 0;
+        for (uint32_t j = 0; j < b.n_cigar; ++j) {
+            int op = cig_op(b.cigar[j]), oplen = (int)cig_len(b.cigar[j]);
+            if (op == C_M || op == C_EQ || op == C_X) { if (rb_insert(&st.rb, p, p + oplen) < 0) { bad = 1; break; } }
+            if (op == C_M || op == C_D || op == C_N || op == C_EQ || op == C_X) p += oplen;
+        }
+        if (bad) { ret = 1; break; }
+    }
+    if (r < -1) { fprintf(stderr, "Failure while decoding file\n"); ret = 1; }
+    if (!ret) {
+        rb_flush(&st, -1);
+        if (st.is_sorted) {
+            /* stats.c:1884-1892 */
+            printf("# Coverage distribution. Use `grep ^COV | cut -f 2-` to extract this part.\n");
+            if (st.cov[0]) printf("COV\t[<%d]\t%d\t%ld\n", st.cov_min, st.cov_min - 1, (long)st.cov[0]);
+            for (int i = 1; i < st.ncov - 1; i++)
+                if (st.cov[i]) printf("COV\t[%d-%d]\t%d\t%ld\n", st.cov_min + (i - 1) * st.cov_step, st.cov_min + i * st.cov_step - 1, st.cov_min + i * st.cov_step - 1, (long)st.cov[i]);
+            if (st.cov[st.ncov - 1]) printf("COV\t[%d<]\t%d\t%ld\n", st.cov_min + (st.ncov - 2) * st.cov_step - 1, st.cov_min + (st.ncov - 2) * st.cov_step - 1, (long)st.cov[st.ncov - 1]);
+        }
+    }
+    rec_free(&b); free(st.cov); free(st.rb.buffer);
+    for (int k = 0; k < n_rg_ok; ++k) free(rg_ok[k]);
+    free(rg_ok);
+    rd_close(rd);
+    return ret;
+}

@@ -66,7 +66,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, cov_hist, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
     DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
@@ -79,6 +79,7 @@ struct sta_engine {
     bool plp_mode = false;
     bool cov_mode = false;          // coverage / bedcov: the pipeline stops before the per-column text measuring pass
     int32_t cov_hist_bins = 0;      // coverage -m / -D: bins of the open histogram (sta_cov_hist_begin)
+    sta_statcov_params sc{}; int32_t sc_ncov = 0;     // stats COV: the open distribution (sta_statcov_begin)
     sta_mplp_params mp{};
     sta_depth_params dp{};
     StaCounters ctr_h{};
@@ -189,7 +190,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->wfirst, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->cov_hist, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
+                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->cov_hist, &e->sc_pos, &e->sc_delta, &e->sc_tmp, &e->sc_cov, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
                       &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
@@ -807,6 +808,55 @@ int sta_cov_hist_fetch(sta_engine *e, uint32_t *hist, int32_t n_bins)
     if (n_bins > e->cov_hist_bins) return fail(e, STA_ERR_ARG, "histogram was opened with fewer bins");
     hipSetDevice(e->device);
     HIPCHK(hipMemcpyAsync(hist, e->cov_hist.p, (size_t)n_bins * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return STA_OK;
+}
+
+// `stats` coverage distribution (kernels_statcov.hip): the bins live on the device from begin to fetch
+int sta_statcov_begin(sta_engine *e, const sta_statcov_params *p, int32_t *ncov_out)
+{
+    if (!e || !p || p->cov_step <= 0 || p->cov_max < p->cov_min) return STA_ERR_ARG;
+    hipSetDevice(e->device);
+    const int32_t ncov = 3 + (p->cov_max - p->cov_min) / p->cov_step;      // stats.c:2404 (the caller has applied :2398-2405 to the triple)
+    if (e->sc_cov.ensure((size_t)ncov * 8 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+    HIPCHK(hipMemsetAsync(e->sc_cov.p, 0, (size_t)ncov * 8, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->sc = *p; e->sc_ncov = ncov;
+    if (ncov_out) *ncov_out = ncov;
+    return STA_OK;
+}
+
+int sta_statcov_add(sta_engine *e, const int64_t *pos, const int32_t *delta, int64_t n, int64_t carry_in, int mem)
+{
+    if (!e || !pos || !delta || n < 0) return STA_ERR_ARG;
+    if (!e->sc_ncov) return fail(e, STA_ERR_ARG, "sta_statcov_begin has not been called");
+    if (n < 2) return STA_OK;
+    hipSetDevice(e->device);
+    hipStream_t s = e->stream;
+    const int64_t *dpos = pos; const int32_t *ddelta = delta;
+    if (mem == STA_MEM_HOST) {
+        if (e->sc_pos.ensure((size_t)n * 8 + 64) || e->sc_delta.ensure((size_t)n * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+        HIPCHK(hipMemcpyAsync(e->sc_pos.p, pos, (size_t)n * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(e->sc_delta.p, delta, (size_t)n * 4, hipMemcpyHostToDevice, s));
+        dpos = (const int64_t *)e->sc_pos.p; ddelta = (const int32_t *)e->sc_delta.p;
+    }
+    if (e->sc_tmp.ensure(sta_statcov_tmp_bytes(n) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+    {
+        ProfScope ps(e, "statcov");
+        sta_launch_statcov(s, dpos, ddelta, n, (long long)carry_in, e->sc.cov_min, e->sc.cov_max, e->sc.cov_step, e->sc_ncov, (unsigned long long *)e->sc_cov.p, e->sc_tmp.p);
+    }
+    HIPCHK(hipStreamSynchronize(s));         // the host buffers may be reused by the caller
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return hipfail(e, le, "stats coverage kernels");
+    return STA_OK;
+}
+
+int sta_statcov_fetch(sta_engine *e, uint64_t *cov, int32_t ncov)
+{
+    if (!e || !cov || ncov <= 0) return STA_ERR_ARG;
+    if (ncov != e->sc_ncov) return fail(e, STA_ERR_ARG, "bin count differs from the open distribution");
+    hipSetDevice(e->device);
+    HIPCHK(hipMemcpyAsync(cov, e->sc_cov.p, (size_t)ncov * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return STA_OK;
 }

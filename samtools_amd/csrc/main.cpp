@@ -10,7 +10,7 @@ extern "C" int sta_main_coverage(int argc, char **argv);  // coverage.c tabular 
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        fprintf(stderr, "Usage: samtools-amd <mpileup|depth|consensus|bedcov|coverage|plpdump|glf|calmd> [options]\n%s\n", sta_version());
+        fprintf(stderr, "Usage: samtools-amd <mpileup|depth|consensus|bedcov|coverage|stats|plpdump|glf|calmd> [options]\n%s\n", sta_version());
         return 1;
     }
     if (strcmp(argv[1], "mpileup") == 0) return sta_main_mpileup(argc - 1, argv + 1);
@@ -21,6 +21,7 @@ int main(int argc, char **argv)
     if (strcmp(argv[1], "plpdump") == 0) return sta_main_plpdump(argc - 1, argv + 1);
     if (strcmp(argv[1], "bedcov") == 0) return sta_main_bedcov(argc - 1, argv + 1);
     if (strcmp(argv[1], "coverage") == 0) return sta_main_coverage(argc - 1, argv + 1);
+    if (strcmp(argv[1], "stats") == 0) return sta_main_stats(argc - 1, argv + 1);
     fprintf(stderr, "[main] unrecognized command '%s'\n", argv[1]);
     return 1;
 }

@@ -118,6 +118,11 @@ void sta_launch_cov_cols(hipStream_t s, const StaWinDev &w, int mode, int min_ba
                          unsigned long long *totals, unsigned long long *per_file,
                          uint32_t *hist, int hist_bins, int hist_depth, int64_t hist_beg, int64_t hist_bin_width);
 
+// `stats` coverage distribution from sorted marks (kernels_statcov.hip)
+size_t sta_statcov_tmp_bytes(int64_t n);
+void sta_launch_statcov(hipStream_t s, const int64_t *pos, const int32_t *delta, int64_t n, long long carry_in,
+                        int cov_min, int cov_max, int cov_step, int ncov, unsigned long long *cov, void *tmp);
+
 // overlap (mate) resolution
 size_t sta_overlap_table_slots(int64_t n_reads);
 size_t sta_overlap_table_bytes(size_t slots);

@@ -10,7 +10,8 @@ than 16 KiB are stored gzip-compressed.  Run from the repo root in the build con
 
 Sources: /root/reference/test/bedcov/* and test/coverage/* (+ test/dat/sample.sam) copied whole, /root/reference/test/mpileup/{*.sam,*.bam,*.fa,regions,xx.bed*,expected/*.out},
 /root/reference/test/dat/{mpileup.*,view.001.sam}, /root/reference/test/large_pos/*, /root/reference/examples/{ex1.sam.gz,ex1.fa},
-/root/reference/test/consensus/{*.sam,*.fa,*.fai,*.bed,expected/*.out}.
+/root/reference/test/consensus/{*.sam,*.fa,*.fai,*.bed,expected/*.out},
+/root/reference/test/stat/{inputs of regcases.STATS_COV; of the expected files only the COV section}.
 """
 import gzip
 import os
@@ -88,6 +89,12 @@ def main():
         for r in rgs:
             if r != "ERR013140":
                 fh.write(r + "\n")
+    # `stats`, coverage distribution: inputs + the COV section of each expected file (comment line and COV lines)
+    for exp, _opts, inp in regcases.STATS_COV:
+        copy(os.path.join(REF, "stat", inp), os.path.join(OUT, "stat", inp))
+        sec = [l for l in open(os.path.join(REF, "stat", exp)) if l.startswith("COV\t") or l.startswith("# Coverage distribution")]
+        with open(os.path.join(OUT, "stat", exp + ".cov"), "w") as fh:
+            fh.writelines(sec)
     total = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(OUT) for f in fs)
     print("golden fixtures: %.1f MiB under %s" % (total / 2 ** 20, OUT))
 

@@ -91,18 +91,27 @@ def test_records_that_already_carry_baq_tags(tmp_path, oracle_bin, product_bin):
 
 
 def test_pg_line(tmp_path, product_bin):
-    """without --no-PG a @PG line is chained to the end of the header's program chain (sam_hdr_add_pg, bam_md.c:425-431)"""
+    """without --no-PG every end of a @PG chain in the header gets a samtools line chained to it (sam_hdr_add_pg, bam_md.c:425-431),
+    with IDs made unique (samtools, samtools.1, ...)"""
     sam, fa = os.path.join(DAT, "mpileup.1.sam"), os.path.join(DAT, "mpileup.ref.fa")
     out = subprocess.run([product_bin, "calmd", "-e", sam, fa], stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()
-    src = open(sam).read().splitlines()
-    hdr = [l for l in out if l.startswith("@")]
-    src_hdr = [l for l in src if l.startswith("@")]
-    assert hdr[:len(src_hdr)] == src_hdr and len(hdr) == len(src_hdr) + 1
-    pg = hdr[-1].split("\t")
-    assert pg[0] == "@PG" and pg[1].startswith("ID:samtools") and pg[2] == "PN:samtools" and pg[-1].startswith("CL:samtools-amd calmd -e ")
-    prev = [l for l in src_hdr if l.startswith("@PG")]
-    if prev:
-        last_id = [t for t in prev[-1].split("\t") if t.startswith("ID:")][0][3:]
-        assert ("PP:" + last_id) in pg
+    src_hdr = [l for l in open(sam).read().splitlines() if l.startswith("@")]
+    prev = [dict(t.split(":", 1) for t in l.split("\t")[1:]) for l in src_hdr if l.startswith("@PG")]
+    ends = [p["ID"] for p in prev if p["ID"] not in {q.get("PP") for q in prev}]
+    assert out[:len(src_hdr)] == src_hdr
+    new = out[len(src_hdr):len(src_hdr) + max(1, len(ends))]
+    ids = set()
+    for l, pp in zip(new, ends):
+        f = l.split("\t")
+        assert f[0] == "@PG" and f[1].startswith("ID:samtools") and f[2] == "PN:samtools" and f[3] == "PP:" + pp
+        assert f[-1].startswith("CL:samtools-amd calmd -e ") and f[-2].startswith("VN:")
+        ids.add(f[1])
+    assert len(ids) == len(new) == len(ends)
     plain = subprocess.run([product_bin, "calmd", "--no-PG", "-e", sam, fa], stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()
-    assert plain == out[:len(src_hdr)] + out[len(src_hdr) + 1:]
+    assert plain == out[:len(src_hdr)] + out[len(src_hdr) + len(new):]
+    # a header without any @PG line: one line without PP
+    bare = tmp_path / "bare.sam"
+    bare.write_text("\n".join(l for l in open(sam).read().splitlines() if not l.startswith("@PG")) + "\n")
+    out = subprocess.run([product_bin, "calmd", str(bare), fa], stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()
+    pg = [l for l in out if l.startswith("@PG")]
+    assert len(pg) == 1 and pg[0].startswith("@PG\tID:samtools\tPN:samtools\tVN:")

@@ -245,3 +245,49 @@ def test_depth_cap_inside_a_deep_amplicon(tmp_path, oracle_bin, product_bin):
             got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
             assert got.returncode == 0, got.stderr.decode()[-400:]
             assert got.stdout == want, (args, env)
+
+
+def test_depth_cap_meeting_the_lookahead_record_of_a_window(tmp_path, oracle_bin, product_bin):
+    """The corner DESIGN.md section 2 used to list as a residual: the record that releases a window's last columns (the first one
+    beyond the window that reaches bam_plp_push) being dropped by the -d cap, while a deletion placeholder of an overlapping pair
+    looks at a base inside the overlap.  It cannot be observed: bam_plp_push's cap only ever drops a read that is NOT the first
+    pushed read of its start position (iter->pos reaches a position only after a read starting there was pushed), and the record the
+    host stops its lookahead at is the first pushed record of a position beyond the window; where the host cannot tell which records
+    are pushed (-G, -l) it stages the whole run and the device picks the releasing read among them, skipping cap-dropped ones
+    (read_advances_iterator).  Constructed here: a pile of reads on the mate's start position, the mate in front of, inside and behind
+    the pile, caps below / at / above the pile height, every window end across the run, both lookahead modes."""
+    def sam(pile, mate_at, skip_cigar):
+        qlen = 70
+        a_q = ("5" * 50 + "&" + "5" * 40)[:qlen]
+        lines = ["@HD\tVN:1.6\tSO:coordinate", "@SQ\tSN:c\tLN:2000", "@RG\tID:a\tSM:s", "@RG\tID:b\tSM:s",
+                 "p1\t99\tc\t101\t60\t%s\t=\t153\t122\t%s\t%s\tRG:Z:a" % (skip_cigar, "A" * qlen, a_q)]
+        for k in range(8):       # depth in front of the pile, so that small caps bite at 153
+            lines.append("d%d\t0\tc\t%d\t60\t90M\t*\t0\t0\t%s\t%s\tRG:Z:a" % (k, 110 + k, "G" * 90, "H" * 90))
+        mate = "p1\t147\tc\t153\t60\t70M\t=\t101\t-122\t%s\t%s\tRG:Z:a" % ("A" * 70, "?" * 70)
+        for k in range(pile + 1):
+            if k == mate_at:
+                lines.append(mate)
+            if k < pile:
+                lines.append("x%d\t0\tc\t153\t60\t30M\t*\t0\t0\t%s\t%s\tRG:Z:a" % (k, "C" * 30, "I" * 30))
+        lines.append("z\t0\tc\t400\t60\t30M\t*\t0\t0\t%s\t%s\tRG:Z:a" % ("T" * 30, "I" * 30))
+        return "\n".join(lines) + "\n"
+
+    rg = tmp_path / "rg.txt"; rg.write_text("b\n")                 # -G b: excludes nothing here, but the host can no longer tell who is pushed
+    bed = tmp_path / "all.bed"; bed.write_text("c\t0\t2000\n")
+    n = 0
+    outcomes = set()
+    for cig in ("50M2D20M", "50M2N20M"):
+        for pile, mate_at in ((6, 0), (6, 3), (12, 12)):
+            path = tmp_path / ("c%d.sam" % n); n += 1
+            path.write_text(sam(pile, mate_at, cig))
+            for cap in ("4", "12", "40"):
+                for mode in ([], ["-G", str(rg)], ["-l", str(bed)]):
+                    args = ["mpileup", "-Q", "0", "-d", cap] + mode + [str(path)]
+                    want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+                    outcomes.add(tuple(l for l in want.split(b"\n") if l.startswith(b"c\t151\t") or l.startswith(b"c\t153\t")))
+                    for w in (None, "51", "52", "53"):       # window ends at 152, 153, 154 (origin 101)
+                        env = dict(os.environ) if w is None else dict(os.environ, STA_WINDOW_COLS=w, STA_PLP_BATCH="1")
+                        got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+                        assert got.returncode == 0, got.stderr.decode()[-300:]
+                        assert got.stdout == want, (cig, pile, mate_at, cap, mode, w)
+    assert len(outcomes) >= 4      # the caps, the pile and the mate's place in it do change what columns 151 and 153 show

@@ -408,7 +408,7 @@ void sta_capture_free(char *text);
 /* `glf [-Q min_baseQ] [-t theta] [-f ref.fa] in.bam`: one text line per column (what tests diff against the oracle) */
 int sta_main_glf(int argc, char **argv);
 /* `calmd [-erAEqdNQ] [-n max_nm] [--no-PG] in.bam ref.fa`: bam_fillmd (bam_md.c:346-520); the records are written as SAM text
- * with the header (BAM output -b / -u and -C are refused) */
+ * with the header, or as BAM with -b / -u (-C is refused) */
 int sta_main_calmd(int argc, char **argv);
 /* `stats [-c min,max,step] [-f INT] [-F INT] [-d] [-l INT] [-I ID] in.bam`: the coverage distribution of `samtools stats`
  * (the comment line and the COV lines of stats.c:1884-1892; nothing else of that report).  --marks-out FILE writes the sorted
@@ -441,6 +441,8 @@ int sta_format_aux_float(double v, char *buf, int cap);
  * sam_write1 writes a record calmd did not change (bam_md.c:486-489): integer aux fields of every width as `i`, floats through
  * kputd, B arrays comma separated.  Host only; returns 0 or <0. */
 int sta_io_write_sam(const char *path, const char *out_path);
+/* The same as BAM (SAM spec 4.1 / 4.2; what calmd -b / -u write): level 0 = stored BGZF blocks, otherwise compressed. */
+int sta_io_write_bam(const char *path, const char *out_path, int level);
 
 #ifdef __cplusplus
 }

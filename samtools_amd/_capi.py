@@ -187,6 +187,7 @@ _PROTOS = {
     "sta_io_scan_region": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "sta_format_aux_float": (C.c_int, [C.c_double, C.c_char_p, C.c_int]),
     "sta_io_write_sam": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "sta_io_write_bam": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
     "sta_cov_hist_begin": (C.c_int, [_P, C.c_int32]),
     "sta_cov_hist_fetch": (C.c_int, [_P, _P, C.c_int32]),
 }
@@ -257,6 +258,13 @@ def io_write_sam(path, out_path):
     rc = lib.sta_io_write_sam(os.fsencode(path), os.fsencode(out_path))
     if rc != 0:
         raise RuntimeError("sta_io_write_sam(%s) failed: %d" % (path, rc))
+
+
+def io_write_bam(path, out_path, level=6):
+    """the same as BAM: level 0 = stored BGZF blocks (calmd -u), otherwise compressed (-b); needs no device."""
+    rc = lib.sta_io_write_bam(os.fsencode(path), os.fsencode(out_path), int(level))
+    if rc != 0:
+        raise RuntimeError("sta_io_write_bam(%s) failed: %d" % (path, rc))
 
 
 def main_depth(args):

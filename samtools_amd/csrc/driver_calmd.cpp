@@ -6,9 +6,10 @@
 // The device computes what changes (NM, the MD string, '=' bases, qualities, the BQ / ZQ string and which of realn.c's tag branches a
 // record took: kernels_md.hip); the host keeps the aux fields as text (host_io.h Rec::auxv) and does the bookkeeping of
 // bam_md.c:156-199 on them -- a tag whose stored value is right stays where it is, a wrong one is removed and the new value appended.
-// Output is SAM with the header (mode "wh"); BAM output (-b / -u) is HTSlib's writer and is not provided, nor is -C.
+// Output is SAM with the header (mode "wh"), or BAM with -b (compressed) / -u (stored BGZF blocks) through host_bamout.h; -C is refused.
 #include "../../include/samtools_amd.h"
 #include "host_io.h"
+#include "host_bamout.h"
 #include "host_stage.h"
 #include <cctype>
 #include <climits>
@@ -32,6 +33,8 @@ struct Ctx {
     std::vector<int32_t> nm; std::vector<uint64_t> off; std::vector<char> md; std::vector<uint8_t> state, qual, seq, tag;
     std::string line;
     FILE *out = stdout;
+    std::unique_ptr<BamWriter> bam;            // -b / -u
+    bool io_error = false;
 };
 
 int find_tag(const std::vector<std::string> &aux, const char *tag)
@@ -42,6 +45,7 @@ int find_tag(const std::vector<std::string> &aux, const char *tag)
 
 void put_record(Ctx &c, const Rec &r, const uint8_t *seq4, const uint8_t *qual, const std::vector<std::string> &aux)
 {
+    if (c.bam) { if (!c.bam->record(*c.h, r, seq4, qual, aux)) c.io_error = true; return; }
     format_sam_record(*c.h, r, seq4, qual, aux, c.line);
     fwrite(c.line.data(), 1, c.line.size(), c.out);
 }
@@ -141,13 +145,13 @@ int flush(Ctx &c, int tid, const std::string *ref)
     return 0;
 }
 
-// sam_hdr_add_pg(h, "samtools", VN, CL): one @PG line per end of a PP chain (or one line when there is none), ID made unique
-void put_header(Ctx &c, bool no_pg, int argc, char **argv)
+// the output header: the input's text, plus -- unless --no-PG -- what sam_hdr_add_pg(h, "samtools", VN, CL) adds: one @PG line per end
+// of a PP chain (or one line when there is none), ID made unique
+std::string output_header(const Header &h, bool no_pg, int argc, char **argv)
 {
-    const std::string &text = c.h->text;
-    fwrite(text.data(), 1, text.size(), c.out);
-    if (!text.empty() && text.back() != '\n') fputc('\n', c.out);
-    if (no_pg) return;
+    std::string text = h.text;
+    if (!text.empty() && text.back() != '\n') text += '\n';
+    if (no_pg) return text;
     std::vector<std::string> ids; std::set<std::string> is_pp;
     size_t p = 0;
     while (p < text.size()) {
@@ -169,8 +173,9 @@ void put_header(Ctx &c, bool no_pg, int argc, char **argv)
     auto fresh = [&]() { std::string id = "samtools"; for (int k = 1; used.count(id); ++k) id = "samtools." + std::to_string(k); used.insert(id); return id; };
     std::vector<std::string> ends;
     for (const std::string &id : ids) if (!is_pp.count(id)) ends.push_back(id);
-    if (ends.empty()) fprintf(c.out, "@PG\tID:%s\tPN:samtools\tVN:%s\tCL:%s\n", fresh().c_str(), sta_version(), cl.c_str());
-    else for (const std::string &pp : ends) fprintf(c.out, "@PG\tID:%s\tPN:samtools\tPP:%s\tVN:%s\tCL:%s\n", fresh().c_str(), pp.c_str(), sta_version(), cl.c_str());
+    if (ends.empty()) text += "@PG\tID:" + fresh() + "\tPN:samtools\tVN:" + sta_version() + "\tCL:" + cl + "\n";
+    else for (const std::string &pp : ends) text += "@PG\tID:" + fresh() + "\tPN:samtools\tPP:" + pp + "\tVN:" + sta_version() + "\tCL:" + cl + "\n";
+    return text;
 }
 
 }  // namespace
@@ -180,6 +185,7 @@ extern "C" int sta_main_calmd(int argc, char **argv)
     Ctx c;
     int o;
     bool no_pg = false;
+    int bam_level = -1;                        // -1: SAM text
     static const struct option lopts[] = { { "no-PG", no_argument, NULL, 1 }, { NULL, 0, NULL, 0 } };
     optind = 1;
     while ((o = getopt_long(argc, argv, "EqQreuNhbSC:n:Ad", lopts, NULL)) >= 0) {
@@ -195,11 +201,12 @@ extern "C" int sta_main_calmd(int argc, char **argv)
         case 'Q': c.quiet = true; break;
         case 'h': case 'S': break;
         case 1: no_pg = true; break;
-        case 'b': case 'u': fprintf(stderr, "[calmd] BAM output (-%c) is not provided: the records are written as SAM text\n", o); return 1;
+        case 'b': if (bam_level < 0) bam_level = 6; break;
+        case 'u': bam_level = 0; break;
         default: fprintf(stderr, "[calmd] option -%c is not part of the engine's rows\n", o); return 1;
         }
     }
-    if (argc - optind != 2) { fprintf(stderr, "usage: samtools-amd calmd [-erAEqdNQ] [-n max_nm] [--no-PG] in.bam ref.fa\n"); return 1; }
+    if (argc - optind != 2) { fprintf(stderr, "usage: samtools-amd calmd [-erAEqdNQbu] [-n max_nm] [--no-PG] in.bam ref.fa\n"); return 1; }
     if (sta_device_count() < 1) { fprintf(stderr, "samtools calmd: no usable HIP device (the MI355X engine has no CPU fallback)\n"); return 2; }
     std::string err;
     auto rd = AlnReader::open(argv[optind], &err);
@@ -209,7 +216,11 @@ extern "C" int sta_main_calmd(int argc, char **argv)
     auto fa = Fasta::load(argv[optind + 1]);
     if (!fa) { fprintf(stderr, "samtools calmd: Failed to open reference file '%s'\n", argv[optind + 1]); return 1; }
     if (sta_engine_create(&c.eng, 0, nullptr) != STA_OK) { fprintf(stderr, "samtools calmd: no usable HIP device\n"); return 2; }
-    put_header(c, no_pg, argc, argv);
+    {
+        const std::string text = output_header(*c.h, no_pg, argc, argv);
+        if (bam_level >= 0) { c.bam.reset(new BamWriter(c.out, bam_level)); if (!c.bam->header(*c.h, text)) c.io_error = true; }
+        else fwrite(text.data(), 1, text.size(), c.out);
+    }
     const bool realn = (c.cp.flag & STA_CALMD_REALN) != 0;
     size_t max_batch = 1 << 18;
     if (const char *e = getenv("STA_CALMD_BATCH")) max_batch = (size_t)std::max<long long>(1, atoll(e));
@@ -242,6 +253,7 @@ extern "C" int sta_main_calmd(int argc, char **argv)
     if (st < 0) { fprintf(stderr, "[bam_fillmd] Error reading input.\n"); status = 1; }
     if (skipped) fprintf(stderr, "[calmd] Warning: %u records skipped due to no query sequence\n", skipped);
     sta_engine_destroy(c.eng);
-    if (fflush(c.out) != 0) { fprintf(stderr, "[bam_fillmd] error when closing output file\n"); status = 1; }
+    if (c.bam && !c.bam->close()) c.io_error = true;
+    if (fflush(c.out) != 0 || c.io_error) { fprintf(stderr, "[bam_fillmd] error when closing output file\n"); status = 1; }
     return status;
 }

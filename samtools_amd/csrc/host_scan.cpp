@@ -2,6 +2,7 @@
 // Test / benchmark hook for the host plumbing either side of the engine.
 #include "../../include/samtools_amd.h"
 #include "host_io.h"
+#include "host_bamout.h"
 #include "host_pump.h"
 #include "host_stage.h"
 #include "host_chunk.h"
@@ -145,6 +146,27 @@ extern "C" int sta_io_scan_region(const char *path, const char *region, int thre
     if (checksum) *checksum = f.h;
     if (used_index) *used_index = used ? 1 : 0;
     return 0;
+}
+
+// The same through the BAM writer (host_bamout.h): level 0 = stored blocks (calmd -u), otherwise compressed (-b).  Host only.
+extern "C" int sta_io_write_bam(const char *path, const char *out_path, int level)
+{
+    if (!path || !out_path) return STA_ERR_ARG;
+    std::string err;
+    auto rd = AlnReader::open(path, &err);
+    if (!rd) return STA_ERR_IO;
+    rd->set_keep_aux(true);
+    FILE *fo = fopen(out_path, "wb");
+    if (!fo) return STA_ERR_IO;
+    const Header &h = rd->header();
+    BamWriter bw(fo, level);
+    bool ok = bw.header(h, h.text);
+    Rec r;
+    int st = 1;
+    while (ok && (st = rd->next(r)) > 0) ok = bw.record(h, r, r.seq.data(), r.qual.data(), r.auxv);
+    ok = ok && bw.close();
+    const bool bad = fclose(fo) != 0;
+    return st < 0 || bad || !ok ? STA_ERR_IO : STA_OK;
 }
 
 // Every record of `path` read with the drivers' reader and written back as SAM text behind the header: what calmd's writer does to

@@ -115,3 +115,19 @@ def test_pg_line(tmp_path, product_bin):
     out = subprocess.run([product_bin, "calmd", str(bare), fa], stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()
     pg = [l for l in out if l.startswith("@PG")]
     assert len(pg) == 1 and pg[0].startswith("@PG\tID:samtools\tPN:samtools\tVN:")
+
+
+def test_bam_output(tmp_path, oracle_bin, product_bin):
+    """calmd -b / -u (bam_md.c:386-395): the reference's own test runs `calmd -uAr` and checks the BGZF magic (test/test.pl:3652-3661);
+    here the BAM is also decoded again and must hold the records of the SAM output, header included"""
+    from samtools_amd import _capi
+    sam, fa = os.path.join(DAT, "mpileup.1.sam"), os.path.join(DAT, "mpileup.ref.fa")
+    for flag in ("-u", "-b"):
+        out = subprocess.run([product_bin, "calmd", "--no-PG", flag + "Ar", sam, fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert out.returncode == 0, out.stderr.decode()[-300:]
+        assert out.stdout[:2] == b"\x1f\x8b"
+        bam = str(tmp_path / "o.bam"); open(bam, "wb").write(out.stdout)
+        back = str(tmp_path / "o.sam")
+        _capi.io_write_sam(bam, back)
+        want = subprocess.run([oracle_bin, "calmd", "-Ar", sam, fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+        assert open(back, "rb").read() == want, flag

@@ -84,3 +84,74 @@ def test_reference_inputs_come_back_unchanged(oracle_bin, tmp_path, n):
     bam = sam_to_bam(sam, str(tmp_path / "t.bam"), level=1, block=20000)
     _capi.io_write_sam(bam, out)
     assert open(out, "rb").read() == open(sam, "rb").read()
+
+
+# ---- BAM output (calmd -b / -u): host_bamout.h behind sta_io_write_bam ----
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bgzf_blocks(path):
+    """(compressed size, inflated size) of every BGZF block + whether the file ends with the 28-byte EOF marker"""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    out, p = [], 0
+    while p < len(raw):
+        assert raw[p:p + 4] == b"\x1f\x8b\x08\x04" and raw[p + 12:p + 16] == b"BC\x02\x00"
+        bsize = struct.unpack("<H", raw[p + 16:p + 18])[0] + 1
+        data = zlib.decompress(raw[p + 18:p + bsize - 8], -15)
+        crc, isz = struct.unpack("<II", raw[p + bsize - 8:p + bsize])
+        assert isz == len(data) and crc == (zlib.crc32(data) & 0xffffffff)
+        out.append((bsize, isz))
+        p += bsize
+    return out, raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+
+
+@pytest.mark.parametrize("level", [0, 6])
+def test_bam_writer_reproduces_the_payload_of_a_bam_the_reference_ships(tmp_path, level):
+    """test/mpileup/ce#5b.{sam,bam} are the same records as text and as a samtools-written BAM: encoding the text must give the
+    BAM's inflated byte stream (header, bins, the smallest integer types, 4-bit bases), in well-formed BGZF blocks + EOF marker"""
+    import gzip
+    from samtools_amd import _capi
+    out = str(tmp_path / "x.bam")
+    _capi.io_write_bam(os.path.join(GOLD, "mpileup", "ce#5b.sam"), out, level)
+    assert gzip.open(out).read() == gzip.open(os.path.join(GOLD, "mpileup", "ce#5b.bam")).read()
+    blocks, has_eof = bgzf_blocks(out)
+    assert has_eof and all(i <= 0xff00 for _, i in blocks)
+    if level == 0:
+        assert all(c > i for c, i in blocks[:-1])          # stored, not compressed (calmd -u)
+
+
+def test_bam_writer_round_trips_every_aux_type_and_long_inputs(oracle_bin, tmp_path):
+    from samtools_amd import _capi
+    sam = str(tmp_path / "t.sam")
+    write_case(sam)
+    src = open(sam, "rb").read()
+    bam = str(tmp_path / "t.bam"); back = str(tmp_path / "b.sam")
+    _capi.io_write_bam(sam, bam, 6)
+    _capi.io_write_sam(bam, back)
+    assert open(back, "rb").read() == src
+    assert oracle_rewrite(oracle_bin, bam, os.path.join(DAT, "mpileup.ref.fa")) == src       # the oracle's BAM reader agrees
+    # many blocks: records never straddle a block boundary unless they are bigger than one
+    big = os.path.join(DAT, "mpileup.1.sam")
+    _capi.io_write_bam(big, bam, 0)
+    _capi.io_write_sam(bam, back)
+    assert open(back, "rb").read() == open(big, "rb").read()
+    blocks, has_eof = bgzf_blocks(bam)
+    assert has_eof and len(blocks) > 4
+    import gzip
+    import struct
+    raw = gzip.open(bam).read()
+    # walk the records and check each one lies inside one block of the inflated stream
+    edges, acc = set(), 0
+    for _, isz in blocks:
+        acc += isz; edges.add(acc)
+    l_text = struct.unpack("<i", raw[4:8])[0]; p = 8 + l_text
+    n_ref = struct.unpack("<i", raw[p:p + 4])[0]; p += 4
+    for _ in range(n_ref):
+        l = struct.unpack("<i", raw[p:p + 4])[0]; p += 4 + l + 4
+    assert p in edges                                       # the header ends its block
+    while p < len(raw):
+        bs = struct.unpack("<i", raw[p:p + 4])[0]
+        assert not any(p < e < p + 4 + bs for e in edges)
+        p += 4 + bs

@@ -27,23 +27,38 @@ size_t pipe_slots_from_env(int n_dev)
     const char *ns = getenv("STA_PIPE_SLOTS");
     return ns && atoi(ns) > 0 ? (size_t)atoi(ns) : (size_t)n_dev + 2;
 }
+int DevEngines::dev_threads() { return dev_threads_from_env(); }
 int DevEngines::create(int device)
 {
-    const int n = dev_threads_from_env();
-    for (int d = 0; d < n; ++d) {
+    for (int d = 0; d < n_; ++d) {
         hipStream_t st = nullptr;
-        if (n > 1) {
-            if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; if (d > 0) break; }
+        if (n_ > 1) {
+            if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return STA_ERR_HIP; }
         }
         sta_engine *e = nullptr;
         const int rc = sta_engine_create(&e, device, st);
-        if (rc != STA_OK) { if (st) hipStreamDestroy(st); if (d == 0) return rc; break; }
+        if (rc != STA_OK) { if (st) hipStreamDestroy(st); return rc; }
         eng.push_back(e); streams.push_back(st);
     }
     return STA_OK;
 }
+void DevEngines::start(int device)
+{
+    std::lock_guard<std::mutex> lk(m_);
+    if (started_) return;
+    started_ = true;
+    th_ = std::thread([this, device] { rc_ = create(device); });
+}
+int DevEngines::ready()
+{
+    std::lock_guard<std::mutex> lk(m_);
+    if (!started_) return STA_ERR_ARG;
+    if (!joined_) { th_.join(); joined_ = true; }
+    return rc_;
+}
 void DevEngines::destroy()
 {
+    if (started_) (void)ready();
     for (size_t d = 0; d < eng.size(); ++d) {
         sta_engine_destroy(eng[d]);
         if (streams[d]) hipStreamDestroy((hipStream_t)streams[d]);

@@ -13,6 +13,7 @@
 #include "driver_pipeline.h"
 #include "driver_shard.h"
 #include <cstdlib>
+#include <atomic>
 #include <getopt.h>
 #include <cstdio>
 #include <cstring>
@@ -26,6 +27,7 @@ namespace {
 struct DRunner {
     sta_depth_params p{};
     DevEngines devs;                    // one engine per device thread
+    std::atomic<bool> no_device{false};
     std::vector<std::unique_ptr<AlnReader>> readers;
     const Header *h = nullptr;
     FILE *out = driver_default_out();
@@ -47,6 +49,7 @@ struct DRunner {
     // device stage of one window (device thread): H2D, the depth kernels, D2H of the rows
     int device_stage(WinJob &j, int d)
     {
+        if (devs.ready() != STA_OK) { if (!no_device.exchange(true)) fprintf(stderr, "samtools depth: no usable HIP device (the MI355X engine has no CPU fallback)\n"); return -1; }
         sta_engine *eng = devs.eng[(size_t)d];
         std::vector<StagedFile> &no_reads = no_reads_d[(size_t)d];
         size_t nf = readers.size();
@@ -223,6 +226,7 @@ void usage_exit(FILE *fp)
 extern "C" int sta_main_depth(int argc, char **argv)
 {
     DRunner run;
+    run.devs.start(getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0);      // the runtime comes up while the inputs are opened and decoded
     sta_depth_params &opt = run.p;
     opt.flag = 4 | 256 | 1024 | 512;
     opt.skip_del = 1;
@@ -294,12 +298,7 @@ extern "C" int sta_main_depth(int argc, char **argv)
         for (auto &fn : fns) fprintf(run.out, "\t%s", fn.c_str());
         fputc('\n', run.out);
     }
-    const int erc = run.devs.create(getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0);
     run.no_reads_d.resize((size_t)run.devs.n());
-    if (erc != STA_OK) {
-        fprintf(stderr, "samtools depth: no usable HIP device (the MI355X engine has no CPU fallback)\n");
-        return 1;
-    }
     fflush(run.out);                  // the header line: the writer thread owns the stream from here on
     int ret;
     {
@@ -309,6 +308,8 @@ extern "C" int sta_main_depth(int argc, char **argv)
     }
     fflush(run.out);
     if (!driver_out_is_borrowed(run.out)) fclose(run.out);
+    // (an input without a single window never asked for the engine: a machine without a device is an error all the same)
+    if (run.devs.ready() != STA_OK) { if (!run.no_device.exchange(true)) fprintf(stderr, "samtools depth: no usable HIP device (the MI355X engine has no CPU fallback)\n"); ret = 1; }
     run.devs.destroy();
     return ret;
 }

@@ -13,6 +13,7 @@
 #include "host_bgzf.h"
 #include "driver_pipeline.h"
 #include "driver_shard.h"
+#include <atomic>
 #include <getopt.h>
 #include <ctime>
 #include <cstdio>
@@ -65,7 +66,8 @@ struct Samples {
 
 struct Runner {
     Conf &conf;
-    DevEngines devs;                                  // one engine per device thread
+    DevEngines &devs;                                 // one engine per device thread (started by sta_main_mpileup before the options are read)
+    std::atomic<bool> no_device{false};
     std::vector<std::unique_ptr<AlnReader>> readers;
     const Header *h = nullptr;
     FILE *out = driver_default_out();
@@ -82,7 +84,7 @@ struct Runner {
     Shard shard;                                      // STA_SHARD=rank/world: this rank's block of the columns (driver_shard.h)
     std::vector<int64_t> lin0;                        // linear coordinate of every contig's first column (no region)
 
-    explicit Runner(Conf &c) : conf(c) {}
+    Runner(Conf &c, DevEngines &d) : conf(c), devs(d) {}
 
     void host_ref(int tid)
     {
@@ -95,6 +97,7 @@ struct Runner {
     // device stage of one window (device thread): reference, H2D, plan, emit, D2H of the text
     int device_stage(WinJob &j, int d)
     {
+        if (devs.ready() != STA_OK) { if (!no_device.exchange(true)) fprintf(stderr, "samtools mpileup: no usable HIP device (the MI355X engine has no CPU fallback)\n"); return -1; }
         sta_engine *eng = devs.eng[(size_t)d];
         std::vector<StagedFile> &no_reads = no_reads_d[(size_t)d];
         const size_t nf = readers.size();
@@ -356,6 +359,10 @@ void usage(FILE *fp)
 
 extern "C" int sta_main_mpileup(int argc, char **argv)
 {
+    // the HIP runtime and the engine come up on their own thread while the options are read, the FASTA is loaded, the inputs are opened
+    // and their decode threads fill the first windows (DevEngines, driver_pipeline.h); declared first = destroyed last
+    DevEngines devs;
+    devs.start(getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0);
     Conf conf;
     sta_mplp_params &mp = conf.p;
     mp.min_baseQ = 13; mp.capQ_thres = 0; mp.max_depth = 8000;
@@ -480,7 +487,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     if (fns.empty()) { fprintf(stderr, "[mpileup] no input file/data given\n"); return 1; }
 
     mp.n_tags = (int32_t)conf.tags.size(); mp.tag_sep = conf.sep;
-    Runner run(conf);
+    Runner run(conf, devs);
     run.adaptive_windows = getenv("STA_WINDOW_COLS") == nullptr;
     Samples sm;
     for (auto &fn : fns) {
@@ -512,12 +519,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     if (!mp.max_depth) { mp.max_depth = INT_MAX; fprintf(stderr, "[mpileup] Max depth set to maximum value (%d)\n", INT_MAX); }
     else if ((long long)mp.max_depth * (long long)fns.size() > 1 << 20) fprintf(stderr, "[mpileup] Combined max depth is above 1M. Potential memory hog!\n");
 
-    int rc = run.devs.create(getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0);
     run.dev_ref_tid.assign((size_t)run.devs.n(), -2); run.no_reads_d.resize((size_t)run.devs.n());
-    if (rc != STA_OK) {
-        fprintf(stderr, "samtools mpileup: no usable HIP device (the MI355X engine has no CPU fallback)\n");
-        return 1;
-    }
     int ret;
     {
         run.pipe.reset(new WinPipe(pipe_slots_from_env(run.devs.n()), [&run](WinJob &j, int d) { return run.device_stage(j, d); }, run.out, "Failed to write pileup data.\n", run.devs.n()));
@@ -526,6 +528,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     }
     fflush(run.out);
     if (!driver_out_is_borrowed(run.out)) fclose(run.out);
+    if (run.devs.ready() != STA_OK) { if (!run.no_device.exchange(true)) fprintf(stderr, "samtools mpileup: no usable HIP device (the MI355X engine has no CPU fallback)\n"); ret = 1; }
     run.devs.destroy();
     return ret;
 }

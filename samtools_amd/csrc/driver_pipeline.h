@@ -165,12 +165,24 @@ private:
 
 // The device side of a driver: n engines (default 1; STA_DEV_THREADS=2..4), each on its own non-blocking stream, one per device thread
 // of the WinPipe.  While one engine runs the kernels of a window the other copies its window in or its text out.
+// Bringing up the HIP runtime and an engine takes ~0.25 s -- a third of a whole 1 Gbase run -- and needs nothing from the input: start()
+// does it on a thread of its own while the driver parses options, loads the FASTA, opens the inputs and its decode threads fill the first
+// windows; ready() is what the first user of an engine (a device thread of the WinPipe) waits on.
 struct DevEngines {
     std::vector<sta_engine *> eng;
     std::vector<void *> streams;
-    int create(int device);              // 0, or the sta_engine_create error
-    void destroy();
-    int n() const { return (int)eng.size(); }
+    DevEngines() : n_(dev_threads()) {}
+    ~DevEngines() { destroy(); }
+    void start(int device);              // begins creating n() engines in the background
+    int ready();                         // waits for start(); 0, or the sta_engine_create error (STA_ERR_HIP if fewer than n() engines came up)
+    void destroy();                      // waits, then destroys what was created
+    int n() const { return n_; }         // engines asked for (STA_DEV_THREADS, default 1): known before they exist
+private:
+    static int dev_threads();
+    int create(int device);
+    int n_, rc_ = STA_ERR_NO_DEVICE;
+    bool started_ = false, joined_ = false;
+    std::thread th_; std::mutex m_;
 };
 int dev_threads_from_env();
 size_t pipe_slots_from_env(int n_dev);

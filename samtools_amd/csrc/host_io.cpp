@@ -611,10 +611,11 @@ int AlnReader::raw_group(std::vector<uint8_t> &out, size_t target, int64_t *n_re
 {
     Impl &im = *p_;
     int64_t nrec = 0;
-    out.clear();
     if (im.is_bam) {
         // `target` bytes in one go, then the block_size chain inside them; the record that straddles the end is completed
-        // (the group = the whole records up to the first boundary at or beyond `target`)
+        // (the group = the whole records up to the first boundary at or beyond `target`).  The buffer is NOT cleared first: a caller's
+        // vector keeps its size from the last group (about `target`), so resize() does not zero a megabyte per call -- this runs on
+        // the one thread at a time that may cut the stream, and that memset was as expensive as the copy itself
         out.resize(target);
         size_t got = im.read(out.data(), target), o = 0;
         out.resize(got);
@@ -636,6 +637,7 @@ int AlnReader::raw_group(std::vector<uint8_t> &out, size_t target, int64_t *n_re
             ++nrec; o = end;
         }
     } else {
+        out.clear();
         while (out.size() < target) {
             if (im.have_line) im.have_line = false;
             else if (!im.getline(im.line)) break;

@@ -410,7 +410,7 @@ int sta_main_glf(int argc, char **argv);
 /* `calmd [-erAEqdNQ] [-n max_nm] [--no-PG] in.bam ref.fa`: bam_fillmd (bam_md.c:346-520); the records are written as SAM text
  * with the header, or as BAM with -b / -u (-C is refused) */
 int sta_main_calmd(int argc, char **argv);
-/* `stats [-c min,max,step] [-f INT] [-F INT] [-d] [-l INT] [-I ID] in.bam`: the coverage distribution of `samtools stats`
+/* `stats [-c min,max,step] [-f INT] [-F INT] [-d] [-l INT] [-I ID] [-t targets] in.bam [region ...]`: the coverage distribution of `samtools stats`
  * (the comment line and the COV lines of stats.c:1884-1892; nothing else of that report).  --marks-out FILE writes the sorted
  * marks the device would be given ("epoch<TAB>position<TAB>delta" lines) instead, without touching a device. */
 int sta_main_stats(int argc, char **argv);

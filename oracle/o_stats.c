@@ -15,19 +15,28 @@
  *      change, of the position its slot index maps to there; at the end of the input it is lost);
  *   3. when a read at least as long as the per-cycle arrays arrives, the ring is copied into a bigger one with memcpy(n) where
  *      n counts elements: only the first quarter of the pending positions (and of the wrapped part) survives.
- * PINNING: the COV lines of test/stat/{1..9,15}.stats.expected and the `.large` variants (test/test.pl:3394-3429; whole-file
- * runs without -t / -p / regions): tests/test_stats_cov.py.
+ *   target regions: -t file (init_regions :1954-2043), region arguments (replicate_regions :2104-2149), is_in_regions :2067-2102,
+ *   and the chunk-clipped CIGAR walk :1454-1487
+ * PINNING: the COV lines of test/stat/{1..8,11,12,14,15}*.expected and the `.large` variants (test/test.pl:3394-3429; every run
+ * there that does not use -p or -S): tests/test_stats_cov.py.
  *
- * Options restated: -c min,max,step  -f / -F flags  -d  -l readlen  -I read group or sample; -r -q -i -m -x -s are accepted and
- * have no effect on this section.  -t, -p, -S and region arguments are refused.
+ * Options restated: -c min,max,step  -f / -F flags  -d  -l readlen  -I read group or sample  -t targets  region arguments (the
+ * reference reads those through the index: here the whole file is read and is_in_regions does the filtering, which gives the
+ * same section); -r -q -i -m -x -s -g are accepted and have no effect on this section.  -p and -S are refused.
  */
 #include "o_plp.h"
+#include <ctype.h>
 #include <getopt.h>
 #include <limits.h>
 
 typedef struct { int32_t *buffer; int start, size; hpos_t pos; } rbuf_t;
 
+typedef struct { hpos_t beg, end; } ival_t;                 /* 1-based, both ends included (stats.c regions_t.pos) */
+typedef struct { int npos, mpos, cpos; ival_t *pos; } regs_t;
+
 typedef struct {
+    regs_t *regions; int nregions;            /* per tid; NULL = no target regions */
+    ival_t *chunks; int nchunks, mchunks;     /* the regions the current read overlaps, clipped to it */
     int cov_min, cov_max, cov_step, ncov;
     uint64_t *cov;
     rbuf_t rb;
@@ -101,6 +110,111 @@ static void grow(cstat_t *s, int seq_len)
     s->rb.size = seq_len * 5;
 }
 
+static int ival_lt(const void *a, const void *b)
+{
+    const ival_t *x = (const ival_t *)a, *y = (const ival_t *)b;
+    return x->beg > y->beg ? 1 : x->beg < y->beg ? -1 : x->end > y->end ? 1 : x->end < y->end ? -1 : 0;
+}
+
+static void regs_add(cstat_t *s, int tid, hpos_t beg, hpos_t end)
+{
+    if (tid >= s->nregions) {
+        s->regions = (regs_t *)realloc(s->regions, sizeof(regs_t) * (size_t)(tid + 10));
+        memset(s->regions + s->nregions, 0, sizeof(regs_t) * (size_t)(tid + 10 - s->nregions));
+        s->nregions = tid + 10;
+    }
+    regs_t *r = &s->regions[tid];
+    if (r->npos >= r->mpos) { r->mpos = r->npos + 1000; r->pos = (ival_t *)realloc(r->pos, sizeof(ival_t) * (size_t)r->mpos); }
+    r->pos[r->npos].beg = beg; r->pos[r->npos].end = end; r->npos++;
+}
+
+/* stats.c:2018-2031: per contig, sorted, overlapping intervals merged */
+static void regs_finish(cstat_t *s)
+{
+    s->mchunks = 1;
+    for (int t = 0; t < s->nregions; ++t) {
+        regs_t *r = &s->regions[t];
+        if (r->npos > 1) {
+            qsort(r->pos, (size_t)r->npos, sizeof(ival_t), ival_lt);
+            int n = 0;
+            for (int p = 1; p < r->npos; ++p) {
+                if (r->pos[n].end < r->pos[p].beg) r->pos[++n] = r->pos[p];
+                else if (r->pos[n].end < r->pos[p].end) r->pos[n].end = r->pos[p].end;
+            }
+            r->npos = n + 1;
+        }
+        if (r->npos > s->mchunks) s->mchunks = r->npos;
+    }
+    s->chunks = (ival_t *)calloc((size_t)s->mchunks, sizeof(ival_t));
+}
+
+/* stats.c:1954-2016 */
+static int regs_from_file(cstat_t *s, const ohdr_t *h, const char *file)
+{
+    FILE *fp = fopen(file, "r");
+    if (!fp) { fprintf(stderr, "%s: cannot open\n", file); return -1; }
+    char line[4096];
+    int warned = 0, prev_tid = -1; hpos_t prev_pos = -1;
+    while (fgets(line, sizeof line, fp)) {
+        if (line[0] == '#') continue;
+        size_t l = strlen(line);
+        while (l && (line[l - 1] == '\n' || line[l - 1] == '\r')) line[--l] = 0;
+        size_t i = 0;
+        while (i < l && !isspace((unsigned char)line[i])) i++;
+        if (i >= l) { fprintf(stderr, "Could not parse the file: %s [%s]\n", file, line); fclose(fp); return -1; }
+        line[i] = 0;
+        const int tid = hdr_name2tid(h, line);
+        if (tid < 0) {
+            if (!warned) fprintf(stderr, "Warning: Some sequences not present in the BAM, e.g. \"%s\". This message is printed only once.\n", line);
+            warned = 1;
+            continue;
+        }
+        long long b, e;
+        if (sscanf(line + i + 1, "%lld %lld", &b, &e) != 2) { fprintf(stderr, "Could not parse the region [%s]\n", line + i + 1); fclose(fp); return -1; }
+        if (prev_tid == -1 || prev_tid != tid) { prev_tid = tid; prev_pos = b; }
+        if (prev_pos > b) { fprintf(stderr, "The positions are not in chromosomal order (%s:%lld comes after %lld)\n", line, b, (long long)prev_pos); fclose(fp); return -1; }
+        regs_add(s, tid, b, e);
+    }
+    fclose(fp);
+    if (!s->regions) { fprintf(stderr, "Unable to map the -t sequences to the BAM sequences.\n"); return -1; }
+    regs_finish(s);
+    return 0;
+}
+
+static hpos_t endpos_of(const orec_t *b)
+{
+    hpos_t rlen = 0;
+    if (!(b->flag & F_UNMAP))
+        for (uint32_t k = 0; k < b->n_cigar; ++k) { int op = cig_op(b->cigar[k]); if (op == C_M || op == C_D || op == C_N || op == C_EQ || op == C_X) rlen += cig_len(b->cigar[k]); }
+    return b->pos + (rlen > 0 ? rlen : 1);
+}
+
+/* stats.c:2067-2102; 1 = counted (and s->chunks / nchunks set), 0 = not in a region, -1 = error */
+static int is_in_regions(cstat_t *s, const orec_t *b)
+{
+    if (!s->regions) return 1;
+    if (b->tid >= s->nregions || b->tid < 0) return 0;
+    if (!s->is_sorted) { fprintf(stderr, "The BAM must be sorted in order for -t to work.\n"); return -1; }
+    regs_t *reg = &s->regions[b->tid];
+    if (reg->cpos == reg->npos) return 0;
+    int i = reg->cpos;
+    while (i < reg->npos && reg->pos[i].end <= b->pos) i++;
+    if (i >= reg->npos) { reg->cpos = reg->npos; return 0; }
+    const hpos_t endpos = endpos_of(b);
+    if (endpos < reg->pos[i].beg) return 0;
+    reg->cpos = i;
+    s->nchunks = 0;
+    while (i < reg->npos) {
+        if (b->pos < reg->pos[i].end && endpos >= reg->pos[i].beg) {
+            s->chunks[s->nchunks].beg = b->pos + 1 > reg->pos[i].beg ? b->pos + 1 : reg->pos[i].beg;
+            s->chunks[s->nchunks].end = endpos < reg->pos[i].end ? endpos : reg->pos[i].end;
+            s->nchunks++;
+        }
+        i++;
+    }
+    return 1;
+}
+
 static int unclipped_length(const orec_t *b)
 {
     int len = b->l_qseq;
@@ -111,16 +225,17 @@ static int unclipped_length(const orec_t *b)
 int o_main_stats(int argc, char *argv[])
 {
     int c, flag_require = 0, flag_filter = 0, filter_readlen = -1, tmp;
-    const char *group_id = NULL;
+    const char *group_id = NULL, *targets = NULL;
     cstat_t st; memset(&st, 0, sizeof st);
     st.cov_min = 1; st.cov_max = 1000; st.cov_step = 1;
     static const struct option lopts[] = {
         { "coverage", required_argument, NULL, 'c' }, { "required-flag", required_argument, NULL, 'f' }, { "filtering-flag", required_argument, NULL, 'F' },
         { "remove-dups", no_argument, NULL, 'd' }, { "read-length", required_argument, NULL, 'l' }, { "id", required_argument, NULL, 'I' },
         { "ref-seq", required_argument, NULL, 'r' }, { "insert-size", required_argument, NULL, 'i' }, { "most-inserts", required_argument, NULL, 'm' },
-        { "trim-quality", required_argument, NULL, 'q' }, { "sparse", no_argument, NULL, 'x' }, { "sam", no_argument, NULL, 's' }, { NULL, 0, NULL, 0 } };
+        { "trim-quality", required_argument, NULL, 'q' }, { "sparse", no_argument, NULL, 'x' }, { "sam", no_argument, NULL, 's' },
+        { "target-regions", required_argument, NULL, 't' }, { "cov-threshold", required_argument, NULL, 'g' }, { NULL, 0, NULL, 0 } };
     optind = 1;
-    while ((c = getopt_long(argc, argv, "dsxr:c:l:i:m:q:f:F:I:t:pS:", lopts, NULL)) >= 0) {
+    while ((c = getopt_long(argc, argv, "dsxr:c:l:i:m:q:f:F:I:t:g:pS:", lopts, NULL)) >= 0) {
         switch (c) {
         case 'f': if ((tmp = str2flag(optarg)) < 0) { fprintf(stderr, "samtools stats: Unknown flag '%s'\n", optarg); return 1; } flag_require = tmp; break;
         case 'F': if ((tmp = str2flag(optarg)) < 0) { fprintf(stderr, "samtools stats: Unknown flag '%s'\n", optarg); return 1; } flag_filter |= tmp; break;
@@ -128,11 +243,12 @@ int o_main_stats(int argc, char *argv[])
         case 'c': if (sscanf(optarg, "%d,%d,%d", &st.cov_min, &st.cov_max, &st.cov_step) != 3) { fprintf(stderr, "Unable to parse -c %s\n", optarg); return 1; } break;
         case 'l': filter_readlen = atoi(optarg); break;
         case 'I': group_id = optarg; break;
-        case 'r': case 'i': case 'm': case 'q': case 'x': case 's': break;
+        case 't': targets = optarg; break;
+        case 'r': case 'i': case 'm': case 'q': case 'x': case 's': case 'g': break;
         default: fprintf(stderr, "[stats] option -%c is not part of the restated section (COV)\n", c); return 1;
         }
     }
-    if (argc - optind != 1) { fprintf(stderr, "usage: oracle_samtools stats [-c min,max,step] [-f INT] [-F INT] [-d] [-l INT] [-I ID] in.bam\n"); return 1; }
+    if (argc - optind < 1) { fprintf(stderr, "usage: oracle_samtools stats [-c min,max,step] [-f INT] [-F INT] [-d] [-l INT] [-I ID] [-t targets] in.bam [region ...]\n"); return 1; }
     oreader_t *rd = rd_open(argv[optind]);
     if (!rd) { fprintf(stderr, "samtools stats: failed to open \"%s\"\n", argv[optind]); return 1; }
     ohdr_t *h = rd_header(rd);
@@ -145,6 +261,16 @@ int o_main_stats(int argc, char *argv[])
     st.rb.size = st.nbases * 5;
     st.rb.buffer = (int32_t *)calloc(sizeof(int32_t), (size_t)st.rb.size);
     st.is_sorted = 1; st.tid = -1; st.pos = -1;
+    if (targets) { if (regs_from_file(&st, h, targets) < 0) return 1; }
+    else if (argc - optind > 1) {
+        /* stats.c:2104-2149: the regions of the command line (the reference gets them, merged, from the multi-region iterator) */
+        for (int a = optind + 1; a < argc; ++a) {
+            int t; hpos_t rb, re;
+            if (parse_region(h, argv[a], &t, &rb, &re) < 0) { fprintf(stderr, "Multi-region iterator could not be created\n"); return 1; }
+            regs_add(&st, t, rb + 1, re);
+        }
+        regs_finish(&st);
+    }
     /* stats.c:2151-2177: the read groups whose ID or SM is `group_id` */
     char **rg_ok = NULL; int n_rg_ok = 0;
     if (group_id) {
@@ -168,6 +294,7 @@ int o_main_stats(int argc, char *argv[])
     int r, ret = 0;
     while ((r = rd_next(rd, &b)) >= 0) {
         /* stats.c:1212-1273 */
+        { const int in = is_in_regions(&st, &b); if (in < 0) { ret = 1; break; } if (!in) continue; }
         if (group_id) {
             const uint8_t *rg = rec_aux_get(&b, "RG");
             if (!rg) continue;
@@ -194,6 +321,20 @@ int o_main_stats(int argc, char *argv[])
         if (rb_flush(&st, b.pos) < 0) { ret = 1; break; }
         hpos_t p = b.pos;
         int bad = 0;
+        if (st.regions) {
+            /* stats.c:1454-1487: every aligned block clipped to the chunks; a block that reaches beyond a chunk is looked at again with the next */
+            uint32_t j = 0; int i = 0;
+            while (j < b.n_cigar && i < st.nchunks) {
+                int op = cig_op(b.cigar[j]), oplen = (int)cig_len(b.cigar[j]);
+                if (op == C_M || op == C_EQ || op == C_X) {
+                    hpos_t pmin = p > st.chunks[i].beg - 1 ? p : st.chunks[i].beg - 1, pmax = p + oplen < st.chunks[i].end ? p + oplen : st.chunks[i].end;
+                    if (pmax > pmin && rb_insert(&st.rb, pmin, pmax) < 0) { bad = 1; break; }
+                }
+                hpos_t pnew = p + ((op == C_M || op == C_D || op == C_N || op == C_EQ || op == C_X) ? oplen : 0);
+                if (pnew >= st.chunks[i].end) i++;
+                else { j++; p = pnew; }
+            }
+        } else
         for (uint32_t j = 0; j < b.n_cigar; ++j) {
             int op = cig_op(b.cigar[j]), oplen = (int)cig_len(b.cigar[j]);
             if (op == C_M || op == C_EQ || op == C_X) { if (rb_insert(&st.rb, p, p + oplen) < 0) { bad = 1; break; } }

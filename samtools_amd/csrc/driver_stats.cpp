@@ -15,11 +15,15 @@
 //             the element on the boundary keeps its low bytes.
 // Pending marks (those at or beyond the last read's start) sit in an ordered map; a flush moves the marks in front of the new start
 // to the output stream, which is therefore sorted; rules 2 and 3 read the pending depths back from the map (rare events).
-// Options: -c min,max,step  -f / -F  -d  -l  -I; -r -q -i -m -x -s are accepted (no effect on this section); -t -p -S and region
-// arguments are refused.  Only this section is printed (the comment line and the COV lines of stats.c:1884-1892).
+// Target regions (-t file, stats.c:1954-2043; region arguments, :2104-2149): a read counts if it overlaps a region (is_in_regions,
+// :2067-2102) and its aligned blocks are clipped to the regions it overlaps (:1454-1487).  With region arguments the reference reads
+// through the index; here the whole file is read and the same filter decides, which gives the same section.
+// Options: -c min,max,step  -f / -F  -d  -l  -I  -t  regions; -r -q -i -m -x -s -g are accepted (no effect on this section); -p and -S
+// are refused.  Only this section is printed (the comment line and the COV lines of stats.c:1884-1892).
 #include "../../include/samtools_amd.h"
 #include "host_io.h"
 #include <algorithm>
+#include <cctype>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -111,6 +115,49 @@ struct CovRing {
     }
 };
 
+// target regions per contig: 1-based, both ends included, sorted, overlapping ones merged (stats.c:2018-2031)
+struct Regions {
+    struct Ival { int64_t beg, end; };
+    std::vector<std::vector<Ival>> pos;          // [tid]
+    std::vector<size_t> cpos;                    // [tid]: first region that can still overlap a read (reads arrive sorted)
+    std::vector<Ival> chunks;                    // the regions the current read overlaps, clipped to it
+    bool on = false;
+    void add(int tid, int64_t beg, int64_t end) { if ((size_t)tid >= pos.size()) pos.resize((size_t)tid + 1); pos[(size_t)tid].push_back({ beg, end }); on = true; }
+    void finish()
+    {
+        for (auto &v : pos) {
+            if (v.size() > 1) {
+                std::sort(v.begin(), v.end(), [](const Ival &a, const Ival &b) { return a.beg != b.beg ? a.beg < b.beg : a.end < b.end; });
+                size_t n = 0;
+                for (size_t p = 1; p < v.size(); ++p) {
+                    if (v[n].end < v[p].beg) v[++n] = v[p];
+                    else if (v[n].end < v[p].end) v[n].end = v[p].end;
+                }
+                v.resize(n + 1);
+            }
+        }
+        cpos.assign(pos.size(), 0);
+    }
+    // stats.c:2067-2102 (the caller has checked that the input is still sorted)
+    bool contains(const Rec &r)
+    {
+        if (r.tid < 0 || (size_t)r.tid >= pos.size()) return false;
+        const std::vector<Ival> &v = pos[(size_t)r.tid];
+        size_t &c = cpos[(size_t)r.tid];
+        if (c == v.size()) return false;
+        size_t i = c;
+        while (i < v.size() && v[i].end <= r.pos) ++i;
+        if (i >= v.size()) { c = v.size(); return false; }
+        const int64_t endpos = r.endpos();
+        if (endpos < v[i].beg) return false;
+        c = i;
+        chunks.clear();
+        for (; i < v.size(); ++i)
+            if (r.pos < v[i].end && endpos >= v[i].beg) chunks.push_back({ std::max(r.pos + 1, v[i].beg), std::min(endpos, v[i].end) });
+        return true;
+    }
+};
+
 int unclipped_length(const Rec &r)
 {
     int len = r.l_qseq;
@@ -160,15 +207,16 @@ extern "C" int sta_main_stats(int argc, char **argv)
 {
     int c, flag_require = 0, flag_filter = 0, filter_readlen = -1, tmp;
     int cov_min = 1, cov_max = 1000, cov_step = 1;
-    const char *group_id = nullptr, *marks_out = nullptr;
+    const char *group_id = nullptr, *marks_out = nullptr, *targets = nullptr;
     static const struct option lopts[] = {
         { "coverage", required_argument, NULL, 'c' }, { "required-flag", required_argument, NULL, 'f' }, { "filtering-flag", required_argument, NULL, 'F' },
         { "remove-dups", no_argument, NULL, 'd' }, { "read-length", required_argument, NULL, 'l' }, { "id", required_argument, NULL, 'I' },
         { "ref-seq", required_argument, NULL, 'r' }, { "insert-size", required_argument, NULL, 'i' }, { "most-inserts", required_argument, NULL, 'm' },
         { "trim-quality", required_argument, NULL, 'q' }, { "sparse", no_argument, NULL, 'x' }, { "sam", no_argument, NULL, 's' },
+        { "target-regions", required_argument, NULL, 't' }, { "cov-threshold", required_argument, NULL, 'g' },
         { "marks-out", required_argument, NULL, 1 }, { NULL, 0, NULL, 0 } };
     optind = 1;
-    while ((c = getopt_long(argc, argv, "dsxr:c:l:i:m:q:f:F:I:t:pS:", lopts, NULL)) >= 0) {
+    while ((c = getopt_long(argc, argv, "dsxr:c:l:i:m:q:f:F:I:t:g:pS:", lopts, NULL)) >= 0) {
         switch (c) {
         case 'f': if ((tmp = str2flag(optarg)) < 0) { fprintf(stderr, "samtools stats: Unknown flag '%s'\n", optarg); return 1; } flag_require = tmp; break;
         case 'F': if ((tmp = str2flag(optarg)) < 0) { fprintf(stderr, "samtools stats: Unknown flag '%s'\n", optarg); return 1; } flag_filter |= tmp; break;
@@ -177,11 +225,12 @@ extern "C" int sta_main_stats(int argc, char **argv)
         case 'l': filter_readlen = atoi(optarg); break;
         case 'I': group_id = optarg; break;
         case 1: marks_out = optarg; break;
-        case 'r': case 'i': case 'm': case 'q': case 'x': case 's': break;
+        case 't': targets = optarg; break;
+        case 'r': case 'i': case 'm': case 'q': case 'x': case 's': case 'g': break;
         default: fprintf(stderr, "[stats] option -%c is not part of the engine's section (COV)\n", c); return 1;
         }
     }
-    if (argc - optind != 1) { fprintf(stderr, "usage: samtools-amd stats [-c min,max,step] [-f INT] [-F INT] [-d] [-l INT] [-I ID] in.bam   (prints the COV section)\n"); return 1; }
+    if (argc - optind < 1) { fprintf(stderr, "usage: samtools-amd stats [-c min,max,step] [-f INT] [-F INT] [-d] [-l INT] [-I ID] [-t targets] in.bam [region ...]   (prints the COV section)\n"); return 1; }
     if (!marks_out && sta_device_count() < 1) { fprintf(stderr, "samtools stats: no usable HIP device (the MI355X engine has no CPU fallback)\n"); return 2; }
     std::string err;
     auto rd = AlnReader::open(argv[optind], &err);
@@ -211,6 +260,44 @@ extern "C" int sta_main_stats(int argc, char **argv)
             p = e + 1;
         }
     }
+    Regions regs;
+    if (targets) {
+        // stats.c:1954-2016: "name beg end" lines, '#' comments; names the header does not know are skipped with one warning
+        FILE *fp = fopen(targets, "r");
+        if (!fp) { fprintf(stderr, "%s: cannot open\n", targets); return 1; }
+        char line[4096];
+        bool warned = false; int prev_tid = -1; long long prev_pos = -1;
+        while (fgets(line, sizeof line, fp)) {
+            if (line[0] == '#') continue;
+            size_t l = strlen(line);
+            while (l && (line[l - 1] == '\n' || line[l - 1] == '\r')) line[--l] = 0;
+            size_t i = 0;
+            while (i < l && !isspace((unsigned char)line[i])) i++;
+            if (i >= l) { fprintf(stderr, "Could not parse the file: %s [%s]\n", targets, line); fclose(fp); return 1; }
+            line[i] = 0;
+            const int tid = h.tid(line);
+            if (tid < 0) {
+                if (!warned) fprintf(stderr, "Warning: Some sequences not present in the BAM, e.g. \"%s\". This message is printed only once.\n", line);
+                warned = true;
+                continue;
+            }
+            long long b, e;
+            if (sscanf(line + i + 1, "%lld %lld", &b, &e) != 2) { fprintf(stderr, "Could not parse the region [%s]\n", line + i + 1); fclose(fp); return 1; }
+            if (prev_tid == -1 || prev_tid != tid) { prev_tid = tid; prev_pos = b; }
+            if (prev_pos > b) { fprintf(stderr, "The positions are not in chromosomal order (%s:%lld comes after %lld)\n", line, b, prev_pos); fclose(fp); return 1; }
+            regs.add(tid, b, e);
+        }
+        fclose(fp);
+        if (!regs.on) { fprintf(stderr, "Unable to map the -t sequences to the BAM sequences.\n"); return 1; }
+        regs.finish();
+    } else if (argc - optind > 1) {
+        for (int a = optind + 1; a < argc; ++a) {
+            int t; int64_t rb, re;
+            if (!parse_region(h, argv[a], &t, &rb, &re)) { fprintf(stderr, "Multi-region iterator could not be created\n"); return 1; }
+            regs.add(t, rb + 1, re);
+        }
+        regs.finish();
+    }
     Sink sink;
     if (marks_out) { sink.dump = fopen(marks_out, "w"); if (!sink.dump) { fprintf(stderr, "samtools stats: cannot write %s\n", marks_out); return 1; } }
     else {
@@ -237,6 +324,11 @@ extern "C" int sta_main_stats(int argc, char **argv)
     int st;
     while ((st = rd->next(r)) > 0) {
         // stats.c:1212-1273
+        if (regs.on) {
+            if (r.tid < 0 || (size_t)r.tid >= regs.pos.size()) continue;
+            if (!is_sorted) { fprintf(stderr, "The BAM must be sorted in order for -t to work.\n"); status = 1; break; }
+            if (!regs.contains(r)) continue;
+        }
         if (group_id) { if (r.rg.empty() || !rg_ok.count(r.rg)) continue; }
         if (flag_require && (r.flag & flag_require) != flag_require) continue;
         if (flag_filter && (r.flag & flag_filter)) continue;
@@ -258,6 +350,20 @@ extern "C" int sta_main_stats(int argc, char **argv)
         if (!ring.flush(r.pos, false, &sslot, &sdepth)) { status = 1; break; }
         int64_t p = r.pos;
         bool bad = false;
+        if (regs.on) {
+            // stats.c:1454-1487: every aligned block clipped to the chunks; a block that reaches beyond a chunk is looked at again with the next
+            size_t j = 0, i = 0;
+            while (j < r.cigar.size() && i < regs.chunks.size()) {
+                const int op = (int)(r.cigar[j] & 0xf); const int64_t len = (int64_t)(r.cigar[j] >> 4);
+                if (op == 0 || op == 7 || op == 8) {
+                    const int64_t pmin = std::max(p, regs.chunks[i].beg - 1), pmax = std::min(p + len, regs.chunks[i].end);
+                    if (pmax > pmin && !ring.insert(pmin, pmax)) { bad = true; break; }
+                }
+                const int64_t pnew = p + ((op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ? len : 0);
+                if (pnew >= regs.chunks[i].end) ++i;
+                else { ++j; p = pnew; }
+            }
+        } else
         for (uint32_t cg : r.cigar) {
             const int op = (int)(cg & 0xf); const int64_t len = (int64_t)(cg >> 4);
             if (op == 0 || op == 7 || op == 8) { if (!ring.insert(p, p + len)) { bad = true; break; } }

@@ -90,8 +90,12 @@ def main():
             if r != "ERR013140":
                 fh.write(r + "\n")
     # `stats`, coverage distribution: inputs + the COV section of each expected file (comment line and COV lines)
-    for exp, _opts, inp in regcases.STATS_COV:
+    for case in regcases.STATS_COV:
+        exp, opts, inp = case[:3]
         copy(os.path.join(REF, "stat", inp), os.path.join(OUT, "stat", inp))
+        for tok in opts.split():
+            if tok.startswith("{G}/"):
+                copy(os.path.join(REF, "stat", tok[4:]), os.path.join(OUT, "stat", tok[4:]))
         sec = [l for l in open(os.path.join(REF, "stat", exp)) if l.startswith("COV\t") or l.startswith("# Coverage distribution")]
         with open(os.path.join(OUT, "stat", exp + ".cov"), "w") as fh:
             fh.writelines(sec)

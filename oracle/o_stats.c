@@ -17,12 +17,14 @@
  *      n counts elements: only the first quarter of the pending positions (and of the wrapped part) survives.
  *   target regions: -t file (init_regions :1954-2043), region arguments (replicate_regions :2104-2149), is_in_regions :2067-2102,
  *   and the chunk-clipped CIGAR walk :1454-1487
+ *   -p: remove_overlaps :1088-1210 (the part of a second mate that the first mate's blocks already cover is not counted) with the
+ *   pair table's clean-up schedule :1392-1402 (it decides which line of a template counts as the first)
  * PINNING: the COV lines of test/stat/{1..8,11,12,14,15}*.expected and the `.large` variants (test/test.pl:3394-3429; every run
- * there that does not use -p or -S): tests/test_stats_cov.py.
+ * there that does not use -S): tests/test_stats_cov.py.
  *
  * Options restated: -c min,max,step  -f / -F flags  -d  -l readlen  -I read group or sample  -t targets  region arguments (the
  * reference reads those through the index: here the whole file is read and is_in_regions does the filtering, which gives the
- * same section); -r -q -i -m -x -s -g are accepted and have no effect on this section.  -p and -S are refused.
+ * same section)  -p; -r -q -i -m -x -s -g are accepted and have no effect on this section.  -S is refused.
  */
 #include "o_plp.h"
 #include <ctype.h>
@@ -215,6 +217,63 @@ static int is_in_regions(cstat_t *s, const orec_t *b)
     return 1;
 }
 
+/* ---- -p: the pair table (khash qn2pair in the reference; a chained table here) ---- */
+typedef struct pair_s { char *name; ival_t *chunks; int n, m; unsigned first; struct pair_s *next; } pair_t;
+#define PAIR_BUCKETS 65536
+typedef struct { pair_t *b[PAIR_BUCKETS]; } pairtab_t;
+static unsigned pair_hash(const char *s) { unsigned h = 2166136261u; while (*s) { h ^= (unsigned char)*s++; h *= 16777619u; } return h & (PAIR_BUCKETS - 1); }
+static pair_t **pair_find(pairtab_t *t, const char *name) { pair_t **pp = &t->b[pair_hash(name)]; while (*pp && strcmp((*pp)->name, name)) pp = &(*pp)->next; return pp; }
+static void pair_del(pair_t **pp) { pair_t *p = *pp; *pp = p->next; free(p->name); free(p->chunks); free(p); }
+
+/* stats.c:1056-1085: entries whose last block ends before `max` */
+static int cleanup_overlaps(pairtab_t *t, hpos_t max)
+{
+    int count = 0;
+    for (int k = 0; k < PAIR_BUCKETS; ++k)
+        for (pair_t **pp = &t->b[k]; *pp;) {
+            if ((*pp)->chunks[(*pp)->n - 1].end < max) { pair_del(pp); count++; }
+            else pp = &(*pp)->next;
+        }
+    return count;
+}
+
+/* stats.c:1088-1210; [pmin, pmax) 0-based half open; pmin == -1: the line is finished */
+static int remove_overlaps(cstat_t *s, pairtab_t *t, unsigned *pair_count, const orec_t *b, hpos_t pmin, hpos_t pmax)
+{
+    const unsigned order = ((b->flag & 64) ? 1u : 0u) + ((b->flag & 128) ? 2u : 0u);
+    long long isz = b->isize < 0 ? -(long long)b->isize : (long long)b->isize;
+    if (!(b->flag & 1) || (b->flag & 8) || isz >= 2ll * b->l_qseq || (order != 1 && order != 2)) {
+        if (pmin >= 0) return rb_insert(&s->rb, pmin, pmax);
+        return 0;
+    }
+    pair_t **pp = pair_find(t, b->qname);
+    if (!*pp) {
+        if (pmin == -1) return 0;
+        pair_t *pc = (pair_t *)calloc(1, sizeof(pair_t));
+        pc->name = strdup(b->qname); pc->m = 8; pc->chunks = (ival_t *)calloc((size_t)pc->m, sizeof(ival_t));
+        pc->chunks[0].beg = pmin; pc->chunks[0].end = pmax; pc->n = 1; pc->first = order;
+        *pp = pc;
+        (*pair_count)++;
+    } else {
+        pair_t *pc = *pp;
+        if (order == pc->first) {
+            if (pmin == -1) return 0;
+            if (pc->n == pc->m) { pc->m <<= 1; pc->chunks = (ival_t *)realloc(pc->chunks, sizeof(ival_t) * (size_t)pc->m); }
+            pc->chunks[pc->n].beg = pmin; pc->chunks[pc->n].end = pmax; pc->n++;
+        } else {
+            if (pmin == -1) { pair_del(pp); (*pair_count)--; return 0; }
+            for (int i = 0; i < pc->n; i++) {
+                if (pmin >= pc->chunks[i].end) continue;
+                if (pmax <= pc->chunks[i].beg) break;
+                if (pmin < pc->chunks[i].beg) { if (rb_insert(&s->rb, pmin, pc->chunks[i].beg) < 0) return -1; pmin = pc->chunks[i].beg; }
+                if (pmax <= pc->chunks[i].end) return 0;
+                pmin = pc->chunks[i].end;
+            }
+        }
+    }
+    return rb_insert(&s->rb, pmin, pmax);
+}
+
 static int unclipped_length(const orec_t *b)
 {
     int len = b->l_qseq;
@@ -224,7 +283,8 @@ static int unclipped_length(const orec_t *b)
 
 int o_main_stats(int argc, char *argv[])
 {
-    int c, flag_require = 0, flag_filter = 0, filter_readlen = -1, tmp;
+    int c, flag_require = 0, flag_filter = 0, filter_readlen = -1, tmp, remove_olap = 0;
+    static pairtab_t pairs; unsigned pair_count = 0, last_read_flush = 0; int last_pair_tid = -2;
     const char *group_id = NULL, *targets = NULL;
     cstat_t st; memset(&st, 0, sizeof st);
     st.cov_min = 1; st.cov_max = 1000; st.cov_step = 1;
@@ -244,6 +304,7 @@ int o_main_stats(int argc, char *argv[])
         case 'l': filter_readlen = atoi(optarg); break;
         case 'I': group_id = optarg; break;
         case 't': targets = optarg; break;
+        case 'p': remove_olap = 1; break;
         case 'r': case 'i': case 'm': case 'q': case 'x': case 's': case 'g': break;
         default: fprintf(stderr, "[stats] option -%c is not part of the restated section (COV)\n", c); return 1;
         }
@@ -316,6 +377,10 @@ int o_main_stats(int argc, char *argv[])
         st.pos = b.pos;
         if (!st.is_sorted) continue;
         if (st.tid == -1 || st.tid != b.tid) { if (rb_flush(&st, -1) < 0) { ret = 1; break; } }
+        /* stats.c:1392-1402: the pair table is thinned out every 10 000 reads once it holds 10 000 pairs, and emptied at a contig change */
+        last_read_flush++;
+        if (pair_count > 10000 && last_read_flush > 10000) { pair_count -= (unsigned)cleanup_overlaps(&pairs, b.pos); last_read_flush = 0; }
+        if (last_pair_tid != b.tid) { pair_count -= (unsigned)cleanup_overlaps(&pairs, HPOS_MAX - 1); last_pair_tid = b.tid; last_read_flush = 0; }
         st.tid = b.tid;
         /* stats.c:1452-1508 */
         if (rb_flush(&st, b.pos) < 0) { ret = 1; break; }
@@ -328,7 +393,7 @@ int o_main_stats(int argc, char *argv[])
                 int op = cig_op(b.cigar[j]), oplen = (int)cig_len(b.cigar[j]);
                 if (op == C_M || op == C_EQ || op == C_X) {
                     hpos_t pmin = p > st.chunks[i].beg - 1 ? p : st.chunks[i].beg - 1, pmax = p + oplen < st.chunks[i].end ? p + oplen : st.chunks[i].end;
-                    if (pmax > pmin && rb_insert(&st.rb, pmin, pmax) < 0) { bad = 1; break; }
+                    if (pmax > pmin && (remove_olap ? remove_overlaps(&st, &pairs, &pair_count, &b, pmin, pmax) : rb_insert(&st.rb, pmin, pmax)) < 0) { bad = 1; break; }
                 }
                 hpos_t pnew = p + ((op == C_M || op == C_D || op == C_N || op == C_EQ || op == C_X) ? oplen : 0);
                 if (pnew >= st.chunks[i].end) i++;
@@ -337,10 +402,11 @@ int o_main_stats(int argc, char *argv[])
         } else
         for (uint32_t j = 0; j < b.n_cigar; ++j) {
             int op = cig_op(b.cigar[j]), oplen = (int)cig_len(b.cigar[j]);
-            if (op == C_M || op == C_EQ || op == C_X) { if (rb_insert(&st.rb, p, p + oplen) < 0) { bad = 1; break; } }
+            if (op == C_M || op == C_EQ || op == C_X) { if ((remove_olap ? remove_overlaps(&st, &pairs, &pair_count, &b, p, p + oplen) : rb_insert(&st.rb, p, p + oplen)) < 0) { bad = 1; break; } }
             if (op == C_M || op == C_D || op == C_N || op == C_EQ || op == C_X) p += oplen;
         }
         if (bad) { ret = 1; break; }
+        if (remove_olap) remove_overlaps(&st, &pairs, &pair_count, &b, -1, -1);        /* the line is finished (stats.c:1509-1510) */
     }
     if (r < -1) { fprintf(stderr, "Failure while decoding file\n"); ret = 1; }
     if (!ret) {

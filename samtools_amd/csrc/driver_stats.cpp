@@ -18,8 +18,10 @@
 // Target regions (-t file, stats.c:1954-2043; region arguments, :2104-2149): a read counts if it overlaps a region (is_in_regions,
 // :2067-2102) and its aligned blocks are clipped to the regions it overlaps (:1454-1487).  With region arguments the reference reads
 // through the index; here the whole file is read and the same filter decides, which gives the same section.
-// Options: -c min,max,step  -f / -F  -d  -l  -I  -t  regions; -r -q -i -m -x -s -g are accepted (no effect on this section); -p and -S
-// are refused.  Only this section is printed (the comment line and the COV lines of stats.c:1884-1892).
+// -p (remove_overlaps, stats.c:1088-1210): the part of a second mate that the first mate's blocks already cover is not counted; the
+// pair table's clean-up schedule (:1392-1402) is kept, because it decides which line of a template counts as the first.
+// Options: -c min,max,step  -f / -F  -d  -l  -I  -t  -p  regions; -r -q -i -m -x -s -g are accepted (no effect on this section); -S is
+// refused.  Only this section is printed (the comment line and the COV lines of stats.c:1884-1892).
 #include "../../include/samtools_amd.h"
 #include "host_io.h"
 #include <algorithm>
@@ -31,6 +33,7 @@
 #include <getopt.h>
 #include <map>
 #include <set>
+#include <unordered_map>
 
 using namespace sta;
 
@@ -158,6 +161,57 @@ struct Regions {
     }
 };
 
+// -p: the pair table of stats.c (khash qn2pair)
+struct PairTab {
+    struct Pair { std::vector<std::pair<int64_t, int64_t>> chunks; unsigned first = 0; };
+    std::unordered_map<std::string, Pair> tab;
+    unsigned pair_count = 0, last_read_flush = 0; int last_pair_tid = -2;
+    // stats.c:1056-1085
+    unsigned cleanup(int64_t max)
+    {
+        unsigned count = 0;
+        for (auto it = tab.begin(); it != tab.end();) { if (it->second.chunks.back().second < max) { it = tab.erase(it); ++count; } else ++it; }
+        return count;
+    }
+    // stats.c:1392-1402, once per read that reaches the coverage code
+    void schedule(int tid, int64_t pos)
+    {
+        last_read_flush++;
+        if (pair_count > 10000 && last_read_flush > 10000) { pair_count -= cleanup(pos); last_read_flush = 0; }
+        if (last_pair_tid != tid) { pair_count -= cleanup(INT64_MAX - 1); last_pair_tid = tid; last_read_flush = 0; }
+    }
+    // stats.c:1088-1210; [pmin, pmax) 0-based half open, pmin == -1: the line is finished.  What is to be counted goes to `ring`.
+    bool block(CovRing &ring, const Rec &r, int64_t pmin, int64_t pmax)
+    {
+        const unsigned order = ((r.flag & 64) ? 1u : 0u) + ((r.flag & 128) ? 2u : 0u);
+        const long long isz = r.isize < 0 ? -(long long)r.isize : (long long)r.isize;
+        if (!(r.flag & 1) || (r.flag & 8) || isz >= 2ll * r.l_qseq || (order != 1 && order != 2)) return pmin >= 0 ? ring.insert(pmin, pmax) : true;
+        auto it = tab.find(r.qname);
+        if (it == tab.end()) {
+            if (pmin == -1) return true;
+            Pair &pc = tab[r.qname];
+            pc.chunks.push_back({ pmin, pmax }); pc.first = order;
+            pair_count++;
+        } else {
+            Pair &pc = it->second;
+            if (order == pc.first) {
+                if (pmin == -1) return true;
+                pc.chunks.push_back({ pmin, pmax });
+            } else {
+                if (pmin == -1) { tab.erase(it); pair_count--; return true; }
+                for (const auto &ch : pc.chunks) {
+                    if (pmin >= ch.second) continue;
+                    if (pmax <= ch.first) break;
+                    if (pmin < ch.first) { if (!ring.insert(pmin, ch.first)) return false; pmin = ch.first; }
+                    if (pmax <= ch.second) return true;
+                    pmin = ch.second;
+                }
+            }
+        }
+        return ring.insert(pmin, pmax);
+    }
+};
+
 int unclipped_length(const Rec &r)
 {
     int len = r.l_qseq;
@@ -206,6 +260,7 @@ struct Sink {
 extern "C" int sta_main_stats(int argc, char **argv)
 {
     int c, flag_require = 0, flag_filter = 0, filter_readlen = -1, tmp;
+    bool remove_olap = false;
     int cov_min = 1, cov_max = 1000, cov_step = 1;
     const char *group_id = nullptr, *marks_out = nullptr, *targets = nullptr;
     static const struct option lopts[] = {
@@ -226,6 +281,7 @@ extern "C" int sta_main_stats(int argc, char **argv)
         case 'I': group_id = optarg; break;
         case 1: marks_out = optarg; break;
         case 't': targets = optarg; break;
+        case 'p': remove_olap = true; break;
         case 'r': case 'i': case 'm': case 'q': case 'x': case 's': case 'g': break;
         default: fprintf(stderr, "[stats] option -%c is not part of the engine's section (COV)\n", c); return 1;
         }
@@ -307,6 +363,8 @@ extern "C" int sta_main_stats(int argc, char **argv)
         if (sta_statcov_begin(sink.eng, &sp, &nc) != STA_OK || nc != ncov) { fprintf(stderr, "samtools stats: %s\n", sta_last_error(sink.eng)); return 1; }
     }
     CovRing ring;
+    PairTab pairs;
+    auto count = [&](const Rec &rec, int64_t a, int64_t b) { return remove_olap ? pairs.block(ring, rec, a, b) : ring.insert(a, b); };
     size_t batch = 1 << 21;                     // marks per device call
     if (const char *e = getenv("STA_STATS_BATCH")) batch = (size_t)std::max<long long>(2, atoll(e));
     bool is_sorted = true;
@@ -344,6 +402,7 @@ extern "C" int sta_main_stats(int argc, char **argv)
         last_pos = r.pos;
         if (!is_sorted) continue;
         if (cur_tid == -1 || cur_tid != r.tid) { if (!end_epoch(false)) { status = 1; break; } }
+        pairs.schedule(r.tid, r.pos);
         cur_tid = r.tid;
         // stats.c:1452-1508
         int64_t sslot, sdepth;
@@ -357,7 +416,7 @@ extern "C" int sta_main_stats(int argc, char **argv)
                 const int op = (int)(r.cigar[j] & 0xf); const int64_t len = (int64_t)(r.cigar[j] >> 4);
                 if (op == 0 || op == 7 || op == 8) {
                     const int64_t pmin = std::max(p, regs.chunks[i].beg - 1), pmax = std::min(p + len, regs.chunks[i].end);
-                    if (pmax > pmin && !ring.insert(pmin, pmax)) { bad = true; break; }
+                    if (pmax > pmin && !count(r, pmin, pmax)) { bad = true; break; }
                 }
                 const int64_t pnew = p + ((op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ? len : 0);
                 if (pnew >= regs.chunks[i].end) ++i;
@@ -366,10 +425,11 @@ extern "C" int sta_main_stats(int argc, char **argv)
         } else
         for (uint32_t cg : r.cigar) {
             const int op = (int)(cg & 0xf); const int64_t len = (int64_t)(cg >> 4);
-            if (op == 0 || op == 7 || op == 8) { if (!ring.insert(p, p + len)) { bad = true; break; } }
+            if (op == 0 || op == 7 || op == 8) { if (!count(r, p, p + len)) { bad = true; break; } }
             if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) p += len;
         }
         if (bad) { status = 1; break; }
+        if (remove_olap) pairs.block(ring, r, -1, -1);               // the line is finished (stats.c:1509-1510)
         if (ring.out.pos.size() >= batch && !sink.send(ring.out, false)) { status = 1; break; }
     }
     if (!ring.err.empty()) fprintf(stderr, "%s\n", ring.err.c_str());

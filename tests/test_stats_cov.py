@@ -214,6 +214,48 @@ def test_target_regions_against_the_restated_ring(oracle_bin, product_bin, tmp_p
     assert differs >= 10
 
 
+def paired_sam(seed, path, n_templates, far_mates=0):
+    """templates whose mates overlap in every way (contained, staggered, touching, apart), spliced mates, a third line of a template
+    (supplementary, same read number as the first), tlen both sides of the 2 x length rule; far_mates: that many templates whose
+    second mate lies far downstream, so that the pair table fills up and its clean-up schedule runs"""
+    rnd = random.Random(seed)
+    recs = []
+    pos = 100
+    for t in range(n_templates):
+        L = rnd.choice([50, 100, 150])
+        far = t < far_mates
+        off = rnd.choice([0, 1, L // 3, L - 1, L, L + 5, 3 * L]) if not far else 40000 + rnd.randint(0, 500)
+        cig1 = rnd.choice(["%dM" % L, "%dM5D%dM" % (L // 2, L - L // 2), "%dM300N%dM" % (L // 3, L - L // 3), "5S%dM" % (L - 5)])
+        cig2 = rnd.choice(["%dM" % L, "%dM2I%dM" % (L // 2, L - L // 2 - 2), "%dM40N%dM" % (L // 4, L - L // 4)])
+        tlen = rnd.choice([off + L, 2 * L - 1, 2 * L, 2 * L + 1, 0])
+        f1, f2 = rnd.choice([(99, 147), (97, 145), (65, 129), (73, 133), (0, 16)])
+        recs.append((pos, "t%d\t%d\tc0\t%d\t30\t%s\t=\t%d\t%d\t%s\t*" % (t, f1, pos, cig1, pos + off, tlen, "A" * L)))
+        recs.append((pos + off, "t%d\t%d\tc0\t%d\t30\t%s\t=\t%d\t%d\t%s\t*" % (t, f2, pos + off, cig2, pos, -tlen, "A" * L)))
+        if rnd.random() < 0.1:
+            recs.append((pos + off + 3, "t%d\t%d\tc0\t%d\t30\t%dM\t=\t%d\t%d\t%s\t*" % (t, (f1 | 2048) & ~0, pos + off + 3, L, pos + off, tlen, "A" * L)))
+        pos += rnd.choice([0, 1, 3, 20]) if far_mates else rnd.choice([0, 3, 40, 400])
+    recs.sort(key=lambda r: r[0])
+    with open(path, "w") as fh:
+        fh.write("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c0\tLN:9000000\n" + "\n".join(r[1] for r in recs) + "\n")
+
+
+def test_mate_overlap_removal_against_the_restated_ring(oracle_bin, product_bin, tmp_path):
+    sam = str(tmp_path / "p.sam")
+    changed = 0
+    for seed in range(12):
+        paired_sam(seed, sam, 400)
+        rc, want, err = oracle_section(oracle_bin, ["-p", sam])
+        rc2, got, err2 = engine_marks_section(product_bin, ["-p", sam], tmp_path)
+        assert rc == rc2 == 0 and got == want, (seed, err, err2)
+        changed += want != oracle_section(oracle_bin, [sam])[1]
+    assert changed >= 8
+    # more than 10 000 templates waiting for their mates: the table is thinned out on the reference's schedule
+    paired_sam(99, sam, 14000, far_mates=12000)
+    rc, want, err = oracle_section(oracle_bin, ["-p", sam])
+    rc2, got, err2 = engine_marks_section(product_bin, ["-p", sam], tmp_path)
+    assert rc == rc2 == 0 and got == want, (err, err2)
+
+
 def test_options_and_unsorted_input(oracle_bin, product_bin, tmp_path):
     sam = str(tmp_path / "f.sam")
     fuzz_sam(1007, sam)
@@ -240,7 +282,7 @@ def test_options_and_unsorted_input(oracle_bin, product_bin, tmp_path):
         rc2, got, _ = engine_marks_section(product_bin, [bad], tmp_path)
         assert rc == rc2 == 0 and want == "" and got == ""
     # refused: what the section would need regions for
-    for opts in (["-p"], ["-S", "RG"]):
+    for opts in (["-S", "RG"],):
         assert subprocess.run([product_bin, "stats"] + opts + [sam], stderr=subprocess.PIPE).returncode == 1
 
 

@@ -443,6 +443,12 @@ int sta_format_aux_float(double v, char *buf, int cap);
 int sta_io_write_sam(const char *path, const char *out_path);
 /* The same as BAM (SAM spec 4.1 / 4.2; what calmd -b / -u write): level 0 = stored BGZF blocks, otherwise compressed. */
 int sta_io_write_bam(const char *path, const char *out_path, int level);
+/* Every contig of a reference FASTA through the drivers' loader (stands where fai_load / faidx_fetch_seq64 stand at
+ * bam_plcmd.c:289-352): with a .fai beside a plain file only the index is read up front and a contig's bases are read when first
+ * asked for (the next contig of the file on a thread of its own meanwhile); otherwise, or with STA_FASTA_WHOLE=1, or when the file does
+ * not fit its index, the whole file is parsed.  Count, total bases, a checksum over names and bases in file order (order != 0: fetched
+ * from the last contig to the first), *lazy = 1 when the index was used.  Host only. */
+int sta_io_fasta_scan(const char *path, int order, uint64_t *n_contigs, uint64_t *n_bases, uint64_t *checksum, int *lazy);
 
 #ifdef __cplusplus
 }

@@ -188,6 +188,7 @@ _PROTOS = {
     "sta_format_aux_float": (C.c_int, [C.c_double, C.c_char_p, C.c_int]),
     "sta_io_write_sam": (C.c_int, [C.c_char_p, C.c_char_p]),
     "sta_io_write_bam": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
+    "sta_io_fasta_scan": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "sta_cov_hist_begin": (C.c_int, [_P, C.c_int32]),
     "sta_cov_hist_fetch": (C.c_int, [_P, _P, C.c_int32]),
 }
@@ -265,6 +266,15 @@ def io_write_bam(path, out_path, level=6):
     rc = lib.sta_io_write_bam(os.fsencode(path), os.fsencode(out_path), int(level))
     if rc != 0:
         raise RuntimeError("sta_io_write_bam(%s) failed: %d" % (path, rc))
+
+
+def io_fasta_scan(path, order=0):
+    """(contigs, bases, checksum, used_index) of a reference FASTA read through the drivers' loader; needs no device."""
+    n, b, h, z = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+    rc = lib.sta_io_fasta_scan(os.fsencode(path), int(order), C.byref(n), C.byref(b), C.byref(h), C.byref(z))
+    if rc != 0:
+        raise RuntimeError("sta_io_fasta_scan(%s) failed: %d" % (path, rc))
+    return n.value, b.value, h.value, bool(z.value)
 
 
 def main_depth(args):

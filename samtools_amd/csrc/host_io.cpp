@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstring>
 #include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstdio>
 #include <cctype>
@@ -748,7 +750,160 @@ bool parse_region(const Header &h, const std::string &reg, int *tid, int64_t *be
     return *beg < *end;
 }
 
+// ---- index-driven loading: the .fai line of a contig is NAME, LENGTH, OFFSET of its first base, LINEBASES, LINEWIDTH (faidx format) ----
+struct Fasta::Lazy {
+    struct Ent { int64_t len = 0, offset = 0; int32_t linebases = 0, linewidth = 0; int state = 0; };   // state: 0 not read, 1 being read, 2 there
+    std::string path;
+    int fd = -1;
+    int64_t file_size = 0;
+    std::vector<Ent> ent;
+    std::mutex m; std::condition_variable cv;
+    std::thread pre;                       // the one read-ahead in flight
+    bool broken = false;                   // the file did not fit its index: everything was parsed instead (seqs_ replaced under m)
+    bool spawning = false;                 // a thread is replacing `pre`
+    ~Lazy() { if (pre.joinable()) pre.join(); if (fd >= 0) close(fd); }
+    // the bases of entry e into out; false if the file does not look the way the index says
+    bool read_contig(const Ent &e, std::string &out) const
+    {
+        out.clear();
+        if (e.len == 0) return true;
+        if (e.linebases <= 0 || e.linewidth < e.linebases || e.offset <= 0) return false;
+        const int64_t full = e.len / e.linebases, rest = e.len % e.linebases;
+        const int64_t bytes = full * e.linewidth + rest;
+        if (e.offset + bytes - (rest == 0 ? e.linewidth - e.linebases : 0) > file_size) return false;
+        char before = 0;
+        if (pread(fd, &before, 1, (off_t)(e.offset - 1)) != 1 || before != '\n') return false;      // the bases start behind the name line
+        out.resize((size_t)e.len);
+        std::vector<char> buf((size_t)std::min<int64_t>(bytes, (int64_t)e.linewidth * 65536));
+        int64_t done = 0, got_bases = 0;
+        while (done < bytes) {
+            // whole lines per read, so that a line never straddles two reads
+            const int64_t want = std::min<int64_t>((int64_t)buf.size(), bytes - done);
+            int64_t have = 0;
+            while (have < want) { const ssize_t k = pread(fd, buf.data() + have, (size_t)(want - have), (off_t)(e.offset + done + have)); if (k <= 0) break; have += k; }
+            if (have <= 0) break;
+            for (int64_t o = 0; o < have; o += e.linewidth) {
+                const int64_t n = std::min<int64_t>(std::min<int64_t>(e.linebases, have - o), e.len - got_bases);
+                memcpy(&out[(size_t)got_bases], buf.data() + o, (size_t)n);
+                got_bases += n;
+            }
+            done += have;
+        }
+        if (got_bases != e.len) return false;
+        // what faidx would have kept: printable characters only; a line break or a name line inside means the index is stale
+        unsigned bad = 0;
+        for (size_t i = 0; i < out.size(); ++i) bad |= (unsigned)((unsigned char)(out[i] - 33) >= 94u) | (unsigned)(out[i] == '>');
+        return bad == 0;
+    }
+};
+
+Fasta::~Fasta() { delete lz_; }
+
+const std::string *Fasta::fetch(const std::string &name) const
+{
+    auto it = idx_.find(name);
+    if (it == idx_.end()) return nullptr;
+    const size_t i = it->second;
+    if (!lazy_) return &seqs_[i];
+    Lazy &z = *lz_;
+    std::unique_lock<std::mutex> lk(z.m);
+    auto load_now = [&](size_t k) {          // called with the lock held and ent[k].state == 1; returns with the lock held
+        std::string tmp;
+        lk.unlock();
+        const bool ok = z.read_contig(z.ent[k], tmp);
+        lk.lock();
+        if (ok && !z.broken) seqs_[k].swap(tmp);
+        else if (!z.broken) {
+            // the file is not what the index describes: parse all of it once, the way a run without an index does
+            z.broken = true;
+            lk.unlock();
+            std::unique_ptr<Fasta> whole = load_whole(z.path);
+            lk.lock();
+            for (size_t j = 0; j < names_.size(); ++j) {
+                const std::string *s2 = whole ? whole->fetch(names_[j]) : nullptr;
+                if (s2) seqs_[j] = *s2; else seqs_[j].clear();
+            }
+            for (auto &e : z.ent) e.state = 2;
+        }
+        z.ent[k].state = 2;
+        z.cv.notify_all();
+    };
+    while (z.ent[i].state == 1) z.cv.wait(lk);
+    if (z.ent[i].state == 0) { z.ent[i].state = 1; load_now(i); }
+    // the next contig of the file on a thread of its own (one at a time)
+    if (i + 1 < z.ent.size() && z.ent[i + 1].state == 0 && !z.broken && !z.spawning) {
+        z.spawning = true;                                   // one thread at a time retires the old read-ahead and starts the next
+        std::thread old = std::move(z.pre);
+        if (old.joinable()) { lk.unlock(); old.join(); lk.lock(); }
+        if (z.ent[i + 1].state == 0 && !z.broken) {
+            z.ent[i + 1].state = 1;
+            const size_t k = i + 1;
+            z.pre = std::thread([this, k] {
+                Lazy &zz = *lz_;
+                std::string tmp;
+                const bool ok = zz.read_contig(zz.ent[k], tmp);
+                std::lock_guard<std::mutex> g(zz.m);
+                if (ok && !zz.broken) { seqs_[k].swap(tmp); zz.ent[k].state = 2; }
+                else if (zz.ent[k].state == 1) zz.ent[k].state = 0;        // let the thread that needs it deal with the mismatch
+                zz.cv.notify_all();
+            });
+        }
+        z.spawning = false;
+    }
+    return &seqs_[i];
+}
+
 std::unique_ptr<Fasta> Fasta::load(const std::string &path)
+{
+    // index first: plain file with a readable <path>.fai
+    if (!getenv("STA_FASTA_WHOLE")) {
+        FILE *fi = fopen((path + ".fai").c_str(), "r");
+        int fd = fi ? open(path.c_str(), O_RDONLY) : -1;
+        unsigned char magic[2] = { 0, 0 };
+        if (fi && fd >= 0 && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+            std::unique_ptr<Fasta> fa(new Fasta());
+            fa->lz_ = new Lazy();
+            Lazy &z = *fa->lz_;
+            z.path = path; z.fd = fd;
+            { struct stat st; if (fstat(fd, &st) == 0) z.file_size = (int64_t)st.st_size; }
+            char line[8192];
+            bool ok = true;
+            while (fgets(line, sizeof line, fi)) {
+                char *tab = strchr(line, '\t');
+                if (!tab) { if (line[0] == '\n' || line[0] == 0) continue; ok = false; break; }
+                Lazy::Ent e; long long a, b; int c, d;
+                if (sscanf(tab + 1, "%lld\t%lld\t%d\t%d", &a, &b, &c, &d) != 4 || a < 0 || b < 0) { ok = false; break; }
+                e.len = a; e.offset = b; e.linebases = c; e.linewidth = d;
+                std::string name(line, (size_t)(tab - line));
+                if (fa->idx_.count(name)) continue;                 // faidx keeps the first of equal names
+                fa->idx_[name] = fa->names_.size();
+                fa->names_.push_back(name);
+                z.ent.push_back(e);
+            }
+            fclose(fi); fi = nullptr;
+            // does the file look the way the index says?  It starts with the first name, and a line ends right in front of every contig's
+            // first base and no contig reaches beyond the file (one byte read per contig); anything else: parse the file instead
+            if (ok && !fa->names_.empty()) {
+                std::vector<char> head(fa->names_[0].size() + 1);
+                if (pread(fd, head.data(), head.size(), 0) != (ssize_t)head.size() || head[0] != '>' || memcmp(head.data() + 1, fa->names_[0].data(), fa->names_[0].size()) != 0) ok = false;
+                for (size_t k = 0; ok && k < z.ent.size(); ++k) {
+                    const Lazy::Ent &e = z.ent[k];
+                    char before = 0;
+                    if (e.offset <= 0 || e.offset > z.file_size || pread(fd, &before, 1, (off_t)(e.offset - 1)) != 1 || before != '\n') ok = false;
+                    else if (e.len > 0 && (e.linebases <= 0 || e.linewidth < e.linebases || e.offset + (e.len / e.linebases) * e.linewidth + e.len % e.linebases - (e.linewidth - e.linebases) > z.file_size)) ok = false;
+                }
+            }
+            if (ok && !fa->names_.empty()) { fa->seqs_.resize(fa->names_.size()); fa->lazy_ = true; return fa; }
+            // (the Lazy object owns fd and closes it)
+            fd = -1;
+        }
+        if (fi) fclose(fi);
+        if (fd >= 0) close(fd);
+    }
+    return load_whole(path);
+}
+
+std::unique_ptr<Fasta> Fasta::load_whole(const std::string &path)
 {
     gzFile fp = gzopen(path.c_str(), "rb");
     if (!fp) return nullptr;
@@ -784,6 +939,7 @@ std::unique_ptr<Fasta> Fasta::load(const std::string &path)
                     size_t k = 0; while (k < name.size() && !isspace((unsigned char)name[k])) ++k;
                     name.resize(k);
                     fa->idx_[name] = fa->seqs_.size();
+                    fa->names_.push_back(name);
                     fa->seqs_.emplace_back();
                     // a contig cannot be longer than what is left of the file: one reservation instead of repeated doubling and
                     // copying of a string that reaches hundreds of megabytes (untouched pages cost nothing; plain files only)

@@ -103,14 +103,28 @@ private:
     std::vector<std::vector<uint64_t>> lin_;
 };
 
-// whole-file FASTA (faidx stand-in)
+// Reference FASTA (faidx stand-in: fai_load + faidx_fetch_seq64).  With a `.fai` beside an uncompressed file the index is all
+// load() reads; a contig's bases are read (offset, line geometry of its index line) when they are first asked for, and the contig
+// behind it in the file is fetched on a thread of its own meanwhile -- a genome-sized reference used to cost seconds of parsing
+// before the first window.  Without an index, or for a compressed file, or when the file does not fit its index, the whole file is
+// parsed as before.  fetch() may be called from several threads; the pointers it returns stay valid for the object's lifetime.
 class Fasta {
 public:
     static std::unique_ptr<Fasta> load(const std::string &path);
-    const std::string *fetch(const std::string &name) const { auto it = idx_.find(name); return it == idx_.end() ? nullptr : &seqs_[it->second]; }
+    ~Fasta();
+    const std::string *fetch(const std::string &name) const;
+    // contig names in file (index) order
+    const std::vector<std::string> &names() const { return names_; }
+    bool lazy() const { return lazy_; }
 private:
-    std::vector<std::string> seqs_;
+    Fasta() = default;
+    struct Lazy;
+    static std::unique_ptr<Fasta> load_whole(const std::string &path);
+    std::vector<std::string> names_;
+    mutable std::vector<std::string> seqs_;
     std::unordered_map<std::string, size_t> idx_;
+    bool lazy_ = false;
+    Lazy *lz_ = nullptr;
 };
 
 // BED / position list (bedidx.c:258-364), kept as merged disjoint sorted intervals per contig:

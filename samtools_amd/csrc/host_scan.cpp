@@ -192,3 +192,30 @@ extern "C" int sta_io_write_sam(const char *path, const char *out_path)
     const bool bad = fclose(fo) != 0;
     return st < 0 || bad ? STA_ERR_IO : STA_OK;
 }
+
+// Every contig of a reference FASTA through the drivers' loader (host_io.h Fasta: index-driven when a .fai lies beside a plain file,
+// whole-file parsing otherwise; STA_FASTA_WHOLE=1 forces the latter): count, total bases and a checksum over names and bases in file
+// order; order != 0 fetches the contigs from the last to the first instead (the read-ahead then never helps).  *lazy = 1 when the
+// index was used.  Host only.
+extern "C" int sta_io_fasta_scan(const char *path, int order, uint64_t *n_contigs, uint64_t *n_bases, uint64_t *checksum, int *lazy)
+{
+    if (!path) return STA_ERR_ARG;
+    auto fa = Fasta::load(path);
+    if (!fa) return STA_ERR_IO;
+    const std::vector<std::string> &names = fa->names();
+    std::vector<uint64_t> h(names.size(), 0);
+    uint64_t nb = 0;
+    for (size_t k = 0; k < names.size(); ++k) {
+        const size_t i = order ? names.size() - 1 - k : k;
+        const std::string *s = fa->fetch(names[i]);
+        if (!s) return STA_ERR_IO;
+        Fnv f; f.bytes(names[i].data(), names[i].size()); f.u64(s->size()); f.bytes(s->data(), s->size());
+        h[i] = f.h; nb += s->size();
+    }
+    Fnv all; for (uint64_t x : h) all.u64(x);
+    if (n_contigs) *n_contigs = names.size();
+    if (n_bases) *n_bases = nb;
+    if (checksum) *checksum = all.h;
+    if (lazy) *lazy = fa->lazy() ? 1 : 0;
+    return STA_OK;
+}

@@ -12,8 +12,9 @@ namespace {
 //   op & OP_EOB        end of block
 //   op & OP_LINK       go to the second-level table at val, indexed by the next `bits` bits (the primary index bits are dropped first)
 //   op & OP_BAD        no code ends here (incomplete code): the stream is damaged
-struct Entry { uint16_t val; uint8_t bits; uint8_t op; };
+struct Entry { uint8_t bits; uint8_t op; uint16_t val; };       // as one little-endian word: bits | op << 8 | val << 16 (the fast loop shifts by the word itself)
 enum { OP_BASE = 16, OP_EOB = 32, OP_LINK = 64, OP_BAD = 128 };
+static_assert(sizeof(Entry) == 4, "the fast loop reads an entry as one 32-bit word");
 
 enum { LIT_PB = 10, DIST_PB = 8, LIT_CAP = (1 << LIT_PB) + 288 * 32, DIST_CAP = (1 << DIST_PB) + 32 * 128 };
 
@@ -208,45 +209,50 @@ int fast_inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
             // extra bits (15 + 15 + 15 + 5); a second refill covers the distance code and its extra bits (15 + 13). ----
             const Entry *const lt = t->lit, *const dt = t->dist;
             bool done = false;
-            while ((ptrdiff_t)(b.end - b.next) >= 16 && (ptrdiff_t)(oend - o) >= 258 + 16) {
+            {
+                // entries as 32-bit words: the code length sits in the low byte, so `buf >> (e & 63)` needs no field extraction on the
+                // path from one look-up to the next (a shift count is taken modulo 64 anyway); literal <=> bits 8..15 clear
                 uint64_t buf = b.buf; int cnt = b.cnt; const uint8_t *nx = b.next;
-                { uint64_t w; memcpy(&w, nx, 8); buf |= w << cnt; nx += (63 - cnt) >> 3; cnt |= 56; }
-                Entry e = lt[buf & ((1u << LIT_PB) - 1)];
-                if (e.op == 0) {
-                    buf >>= e.bits; cnt -= e.bits; *o++ = (uint8_t)e.val;
-                    e = lt[buf & ((1u << LIT_PB) - 1)];
-                    if (e.op == 0) {
-                        buf >>= e.bits; cnt -= e.bits; *o++ = (uint8_t)e.val;
-                        e = lt[buf & ((1u << LIT_PB) - 1)];
-                        if (e.op == 0) { buf >>= e.bits; cnt -= e.bits; *o++ = (uint8_t)e.val; b.buf = buf; b.cnt = cnt; b.next = nx; continue; }
+                const auto ld = [](const Entry *t2, uint64_t idx) { uint32_t w; memcpy(&w, t2 + idx, 4); return w; };
+                while ((ptrdiff_t)(b.end - nx) >= 16 && (ptrdiff_t)(oend - o) >= 258 + 16) {
+                    { uint64_t w; memcpy(&w, nx, 8); buf |= w << cnt; nx += (63 - cnt) >> 3; cnt |= 56; }
+                    uint32_t e = ld(lt, buf & ((1u << LIT_PB) - 1));
+                    if (!(e & 0xff00u)) {
+                        buf >>= (e & 63); cnt -= (int)(e & 63); *o++ = (uint8_t)(e >> 16);
+                        e = ld(lt, buf & ((1u << LIT_PB) - 1));
+                        if (!(e & 0xff00u)) {
+                            buf >>= (e & 63); cnt -= (int)(e & 63); *o++ = (uint8_t)(e >> 16);
+                            e = ld(lt, buf & ((1u << LIT_PB) - 1));
+                            if (!(e & 0xff00u)) { buf >>= (e & 63); cnt -= (int)(e & 63); *o++ = (uint8_t)(e >> 16); continue; }
+                        }
                     }
+                    if (e & ((uint32_t)OP_LINK << 8)) { buf >>= LIT_PB; cnt -= LIT_PB; e = ld(lt, (e >> 16) + (buf & ((1u << (e & 63)) - 1))); }
+                    buf >>= (e & 63); cnt -= (int)(e & 63);
+                    if (!(e & 0xff00u)) { *o++ = (uint8_t)(e >> 16); continue; }                       // a literal with a long code
+                    if (!(e & ((uint32_t)OP_BASE << 8))) { if (e & ((uint32_t)OP_EOB << 8)) { done = true; break; } return 1; }
+                    const int xl = (int)((e >> 8) & 15);
+                    const unsigned len = (e >> 16) + (unsigned)(buf & ((1u << xl) - 1));
+                    buf >>= xl; cnt -= xl;
+                    { uint64_t w; memcpy(&w, nx, 8); buf |= w << cnt; nx += (63 - cnt) >> 3; cnt |= 56; }
+                    uint32_t d = ld(dt, buf & ((1u << DIST_PB) - 1));
+                    if (d & ((uint32_t)OP_LINK << 8)) { buf >>= DIST_PB; cnt -= DIST_PB; d = ld(dt, (d >> 16) + (buf & ((1u << (d & 63)) - 1))); }
+                    buf >>= (d & 63); cnt -= (int)(d & 63);
+                    if (!(d & ((uint32_t)OP_BASE << 8))) return 1;
+                    const int xd = (int)((d >> 8) & 15);
+                    const unsigned dist = (d >> 16) + (unsigned)(buf & ((1u << xd) - 1));
+                    buf >>= xd; cnt -= xd;
+                    if (dist > (size_t)(o - out)) return 1;
+                    const uint8_t *src = o - dist;
+                    uint8_t *dst = o;
+                    o += len;
+                    if (dist >= 16) {
+                        memcpy(dst, src, 16);                                           // most matches are short: one 16-byte move
+                        if (len > 16) { dst += 16; src += 16; do { memcpy(dst, src, 16); dst += 16; src += 16; } while (dst < o); }
+                    } else if (dist >= 8) { do { memcpy(dst, src, 8); dst += 8; src += 8; } while (dst < o); }
+                    else if (dist == 1) { uint64_t v = 0x0101010101010101ull * *src; do { memcpy(dst, &v, 8); dst += 8; } while (dst < o); }
+                    else { while (dst < o) *dst++ = *src++; }
                 }
-                if (e.op & OP_LINK) { buf >>= LIT_PB; cnt -= LIT_PB; e = lt[e.val + (buf & ((1u << e.bits) - 1))]; }
-                buf >>= e.bits; cnt -= e.bits;
-                if (e.op == 0) { *o++ = (uint8_t)e.val; b.buf = buf; b.cnt = cnt; b.next = nx; continue; }      // a literal with a long code
-                if (!(e.op & OP_BASE)) { b.buf = buf; b.cnt = cnt; b.next = nx; if (e.op & OP_EOB) { done = true; break; } return 1; }
-                const int xl = e.op & 15;
-                const unsigned len = e.val + (unsigned)(buf & ((1u << xl) - 1));
-                buf >>= xl; cnt -= xl;
-                { uint64_t w; memcpy(&w, nx, 8); buf |= w << cnt; nx += (63 - cnt) >> 3; cnt |= 56; }
-                Entry d = dt[buf & ((1u << DIST_PB) - 1)];
-                if (d.op & OP_LINK) { buf >>= DIST_PB; cnt -= DIST_PB; d = dt[d.val + (buf & ((1u << d.bits) - 1))]; }
-                buf >>= d.bits; cnt -= d.bits;
-                if (!(d.op & OP_BASE)) return 1;
-                const int xd = d.op & 15;
-                const unsigned dist = d.val + (unsigned)(buf & ((1u << xd) - 1));
-                buf >>= xd; cnt -= xd;
                 b.buf = buf; b.cnt = cnt; b.next = nx;
-                if (dist > (size_t)(o - out)) return 1;
-                const uint8_t *src = o - dist;
-                uint8_t *dst = o;
-                o += len;
-                if (dist >= 16) {
-                    memcpy(dst, src, 16);                                           // most matches are short: one 16-byte move
-                    if (len > 16) { dst += 16; src += 16; do { memcpy(dst, src, 16); dst += 16; src += 16; } while (dst < o); }
-                } else if (dist >= 8) { do { memcpy(dst, src, 8); dst += 8; src += 8; } while (dst < o); }
-                else if (dist == 1) { uint64_t v = 0x0101010101010101ull * *src; do { memcpy(dst, &v, 8); dst += 8; } while (dst < o); }
-                else { while (dst < o) *dst++ = *src++; }
             }
             // ---- careful loop: the last bytes of the block, every access checked ----
             while (!done) {

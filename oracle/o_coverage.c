@@ -3,9 +3,11 @@
  *
  * Restatement of `samtools coverage` (coverage.c:176-221 read_bam + print_tabular_line, :572-700 the multi-pileup loop,
  * :150-173 + :223-304 the histogram / depth plot of -m -A -D -w).
- * Pinned by test/coverage/{1..5}.expected (test/test.pl:4143-4161) for the tabular mode.  The reference holds NO expected
- * output for the histogram modes: the plot is PARITY UNPINNED (restated from coverage.c alone); its inputs -- the per-bin
- * counts -- are sums of the very per-column values the pinned tabular mode adds up.
+ * Pinned by test/coverage/{1..5}.expected (test/test.pl:4143-4161) for the tabular mode.  For the histogram modes the reference
+ * holds no expected file; what it holds is the worked example of its manual (doc/samtools-coverage.1:147-178), which pins the title
+ * line, the x axis (label positions, centring, readable_bps rounding) and the bin-width text for two regions
+ * (tests/test_coverage.py); the bars themselves are PARITY UNPINNED (restated from coverage.c alone) -- their inputs, the per-bin
+ * counts, are sums of the very per-column values the pinned tabular mode adds up.
  */
 #include "o_plp.h"
 #include <getopt.h>

@@ -521,6 +521,25 @@ int rd_next(oreader_t *r, orec_t *rec)
 }
 
 /* ---------------- region ---------------- */
+/* HTSlib hts_parse_decimal: digits with thousands commas, optional fraction / exponent, suffixes k M G ("1M", "1.5k", "2,500,000") */
+static long long parse_decimal(const char *s, char **endp)
+{
+    long long n = 0; int decimals = 0, e = 0, digits = 0, neg = 0;
+    const char *p = s;
+    while (isspace((unsigned char)*p)) ++p;
+    if (*p == '-' && isdigit((unsigned char)p[1])) { neg = 1; ++p; } else if (*p == '+') ++p;
+    for (; isdigit((unsigned char)*p) || (*p == ',' && digits); ++p) if (*p != ',') { n = n * 10 + (*p - '0'); digits = 1; }
+    if (*p == '.') { ++p; for (; isdigit((unsigned char)*p); ++p) { n = n * 10 + (*p - '0'); ++decimals; digits = 1; } }
+    if (!digits) { *endp = (char *)s; return 0; }
+    if ((*p == 'e' || *p == 'E') && (isdigit((unsigned char)p[1]) || ((p[1] == '+' || p[1] == '-') && isdigit((unsigned char)p[2])))) { char *q; e = (int)strtol(p + 1, &q, 10); p = q; }
+    if (*p == 'k' || *p == 'K') { e += 3; ++p; } else if (*p == 'm' || *p == 'M') { e += 6; ++p; } else if (*p == 'g' || *p == 'G') { e += 9; ++p; }
+    e -= decimals;
+    while (e > 0) { n *= 10; --e; }
+    while (e < 0) { n /= 10; ++e; }
+    *endp = (char *)p;
+    return neg ? -n : n;
+}
+
 int parse_region(const ohdr_t *h, const char *reg, int *tid, hpos_t *beg, hpos_t *end)
 {
     int t = hdr_name2tid(h, reg);
@@ -533,17 +552,15 @@ int parse_region(const ohdr_t *h, const char *reg, int *tid, hpos_t *beg, hpos_t
     t = hdr_name2tid(h, name);
     free(name);
     if (t < 0) return -1;
-    /* strip commas */
-    char num[128]; size_t n = 0;
-    for (const char *p = colon + 1; *p && n + 1 < sizeof(num); ++p) if (*p != ',') num[n++] = *p;
-    num[n] = 0;
+    const char *num = colon + 1;
     char *q;
-    long long b = strtoll(num, &q, 10);
+    long long b = parse_decimal(num, &q);
     if (q == num) {
         if (*q == '-') { b = 1; } else return -1;
     }
+    if (b < 0 && !*q) { *tid = t; *beg = 0; *end = -b; return 0; }      /* hts_parse_region: chr:-100 is chr:1-100 */
     long long e = HPOS_MAX;
-    if (*q == '-') { if (q[1]) e = strtoll(q + 1, NULL, 10); }
+    if (*q == '-') { if (q[1]) { char *q2; e = parse_decimal(q + 1, &q2); if (q2 == q + 1 || *q2) return -1; } }
     else if (*q) return -1;
     *tid = t;
     *beg = b > 0 ? b - 1 : 0;

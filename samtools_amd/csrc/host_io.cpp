@@ -729,6 +729,27 @@ int AlnReader::next(Rec &r)
     }
 }
 
+// HTSlib hts_parse_decimal (what hts_parse_reg reads coordinates with): digits with thousands commas, an optional fraction and
+// exponent, and the suffixes k / M / G -- "1M", "1.5k", "2,500,000", "1e6".  *endp = first character not consumed.
+static long long parse_decimal(const char *s, const char **endp)
+{
+    long long n = 0; int decimals = 0, e = 0; bool digits = false;
+    const char *p = s;
+    while (isspace((unsigned char)*p)) ++p;
+    const bool neg = *p == '-' && isdigit((unsigned char)p[1]);
+    if (*p == '+' || neg) ++p;
+    for (; isdigit((unsigned char)*p) || (*p == ',' && digits); ++p) if (*p != ',') { n = n * 10 + (*p - '0'); digits = true; }
+    if (*p == '.') { ++p; for (; isdigit((unsigned char)*p); ++p) { n = n * 10 + (*p - '0'); ++decimals; digits = true; } }
+    if (!digits) { *endp = s; return 0; }
+    if ((*p == 'e' || *p == 'E') && (isdigit((unsigned char)p[1]) || ((p[1] == '+' || p[1] == '-') && isdigit((unsigned char)p[2])))) { char *q; e = (int)strtol(p + 1, &q, 10); p = q; }
+    switch (*p) { case 'k': case 'K': e += 3; ++p; break; case 'm': case 'M': e += 6; ++p; break; case 'g': case 'G': e += 9; ++p; break; }
+    e -= decimals;
+    while (e > 0) { n *= 10; --e; }
+    while (e < 0) { n /= 10; ++e; }
+    *endp = p;
+    return neg ? -n : n;
+}
+
 bool parse_region(const Header &h, const std::string &reg, int *tid, int64_t *beg, int64_t *end)
 {
     *beg = 0; *end = INT64_MAX;
@@ -738,13 +759,13 @@ bool parse_region(const Header &h, const std::string &reg, int *tid, int64_t *be
     if (colon == std::string::npos) return false;
     t = h.tid(reg.substr(0, colon));
     if (t < 0) return false;
-    std::string num;
-    for (size_t i = colon + 1; i < reg.size(); ++i) if (reg[i] != ',') num += reg[i];
-    char *q;
-    long long b = strtoll(num.c_str(), &q, 10);
+    const std::string num = reg.substr(colon + 1);
+    const char *q;
+    long long b = parse_decimal(num.c_str(), &q);
     if (q == num.c_str()) { if (*q == '-') b = 1; else return false; }
+    if (b < 0 && !*q) { *tid = t; *beg = 0; *end = -b; return true; }            // hts_parse_region: chr:-100 is chr:1-100
     long long e = INT64_MAX;
-    if (*q == '-') { if (q[1]) e = strtoll(q + 1, nullptr, 10); }
+    if (*q == '-') { if (q[1]) { const char *q2; e = parse_decimal(q + 1, &q2); if (q2 == q + 1 || *q2) return false; } }
     else if (*q) return false;
     *tid = t; *beg = b > 0 ? b - 1 : 0; *end = e;
     return *beg < *end;

@@ -209,3 +209,22 @@ def test_producer_bench_harness_builds_and_runs(files, tmp_path):
     p = subprocess.run([exe, bam, "3", "20000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, STA_NO_PINNED="1", STA_STAGE_THREADS="2"))
     assert p.returncode == 0, p.stderr.decode()[-400:]
     assert b"windows" in p.stdout and b"reads" in p.stdout
+
+
+def test_region_coordinates_the_way_hts_parse_decimal_reads_them(capi, tmp_path):
+    """HTSlib reads region coordinates with hts_parse_decimal: thousands commas, a fraction, an exponent and the suffixes k / M / G
+    (the reference's manual itself writes `-r chr1:1M-12M`, doc/samtools-coverage.1:148)"""
+    sam = tmp_path / "r.sam"
+    read = "%s\t0\tchr1\t%d\t60\t50M\t*\t0\t0\t" + "A" * 50 + "\t" + "I" * 50
+    sam.write_text("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:249250621\n"
+                   + "\n".join(read % ("r%d" % i, p) for i, p in enumerate([999900, 1000000, 5000000, 11999999, 12000000, 12000001, 25000000])) + "\n")
+    bam = sam_to_bam(str(sam), str(tmp_path / "r.bam"), level=1)
+    want = capi.io_scan_region(bam, "chr1:1000000-12000000", 1, False)[:2]
+    assert want[0] == 4
+    for spelling in ("chr1:1M-12M", "chr1:1,000,000-12,000,000", "chr1:1e6-1.2e7", "chr1:1000k-12000K", "chr1:0.001G-0.012g", "chr1:1.0M-12.0M"):
+        assert capi.io_scan_region(bam, spelling, 1, False)[:2] == want, spelling
+    assert capi.io_scan_region(bam, "chr1:12M", 1, False)[0] == 4            # from 12 000 000 to the end (the read that starts one base earlier reaches in)
+    assert capi.io_scan_region(bam, "chr1:-1M", 1, False)[0] == 2            # up to 1 000 000
+    for bad in ("chr1:1M-12Q", "chr1:x-5", "chr1:5M-1M"):
+        with pytest.raises(RuntimeError):
+            capi.io_scan_region(bam, bad, 1, False)

@@ -16,10 +16,11 @@ namespace sta {
 int io_default_threads()
 {
     if (const char *e = getenv("STA_IO_THREADS")) { int v = atoi(e); if (v > 0) return v > 64 ? 64 : v; }
-    // half the hardware threads, between 4 and 8, on an ordinary host; a quarter (up to 24) on a many-core GPU node, where the
-    // inflate workers and the chunk parsers keep scaling (profiles/r02_e2e_cli.log)
+    // half the hardware threads, between 4 and 8, on an ordinary host; a quarter, up to 16, on a many-core GPU node: on the two-socket
+    // 256-thread host of the measurements 16 decode threads are the best setting and 32 or more make the whole pipeline slower (the
+    // slice copies of the staging threads slow down by more than the decode wait shrinks: profiles/r03_e2e_30x_1gbase_threads.log)
     const unsigned hw = std::thread::hardware_concurrency();
-    if (hw >= 48) { const int q = (int)(hw / 4); return q > 24 ? 24 : q; }
+    if (hw >= 48) { const int q = (int)(hw / 4); return q > 16 ? 16 : q; }
     const int v = (int)(hw / 2);
     return v < 4 ? 4 : v > 8 ? 8 : v;
 }

@@ -53,7 +53,7 @@ def test_index_driven_loading_equals_parsing(tmp_path):
         contigs = [("c%d some description" % i if rnd.random() < 0.3 else "c%d" % i, rand_seq(rnd, rnd.choice([0, 1, 59, 60, 61, 600, 4096, 70001]))) for i in range(n)]
         widths = [rnd.choice([1, 7, 60, 70, 80, 100000]) for _ in contigs]
         path = str(tmp_path / ("r%d.fa" % case))
-        fai = write_fasta(path, contigs, widths, final_newline=case % 3 != 0 or not contigs[-1][1])
+        fai = write_fasta(path, contigs, widths, final_newline=case % 3 != 0 or not contigs[-1][1], crlf=case % 4 == 1)
         whole_only = _capi.io_fasta_scan(path)
         assert not whole_only[3] and whole_only[0] == n and whole_only[1] == sum(len(s) for _, s in contigs)
         open(path + ".fai", "w").write(fai)

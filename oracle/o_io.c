@@ -528,13 +528,13 @@ static long long parse_decimal(const char *s, char **endp)
     const char *p = s;
     while (isspace((unsigned char)*p)) ++p;
     if (*p == '-' && isdigit((unsigned char)p[1])) { neg = 1; ++p; } else if (*p == '+') ++p;
-    for (; isdigit((unsigned char)*p) || (*p == ',' && digits); ++p) if (*p != ',') { n = n * 10 + (*p - '0'); digits = 1; }
-    if (*p == '.') { ++p; for (; isdigit((unsigned char)*p); ++p) { n = n * 10 + (*p - '0'); ++decimals; digits = 1; } }
+    for (; isdigit((unsigned char)*p) || (*p == ',' && digits); ++p) if (*p != ',') { if (n < LLONG_MAX / 10 - 1) n = n * 10 + (*p - '0'); digits = 1; }
+    if (*p == '.') { ++p; for (; isdigit((unsigned char)*p); ++p) { if (n < LLONG_MAX / 10 - 1) { n = n * 10 + (*p - '0'); ++decimals; } digits = 1; } }
     if (!digits) { *endp = (char *)s; return 0; }
     if ((*p == 'e' || *p == 'E') && (isdigit((unsigned char)p[1]) || ((p[1] == '+' || p[1] == '-') && isdigit((unsigned char)p[2])))) { char *q; e = (int)strtol(p + 1, &q, 10); p = q; }
     if (*p == 'k' || *p == 'K') { e += 3; ++p; } else if (*p == 'm' || *p == 'M') { e += 6; ++p; } else if (*p == 'g' || *p == 'G') { e += 9; ++p; }
     e -= decimals;
-    while (e > 0) { n *= 10; --e; }
+    while (e > 0) { if (n < LLONG_MAX / 10 - 1) n *= 10; --e; }       /* (absurd coordinates saturate instead of overflowing) */
     while (e < 0) { n /= 10; ++e; }
     *endp = (char *)p;
     return neg ? -n : n;

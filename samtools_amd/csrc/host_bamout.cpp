@@ -130,6 +130,7 @@ bool BamWriter::header(const Header &h, const std::string &text)
 bool BamWriter::record(const Header &h, const Rec &r, const uint8_t *seq4, const uint8_t *qual, const std::vector<std::string> &aux)
 {
     (void)h;
+    if (r.qname.size() > 254 || r.l_qseq < 0) return false;         // l_read_name is one byte and counts the NUL (SAM spec 4.2)
     std::vector<uint8_t> &o = rec_;
     o.clear();
     const size_t n_cig = r.cigar.size();

@@ -738,13 +738,13 @@ static long long parse_decimal(const char *s, const char **endp)
     while (isspace((unsigned char)*p)) ++p;
     const bool neg = *p == '-' && isdigit((unsigned char)p[1]);
     if (*p == '+' || neg) ++p;
-    for (; isdigit((unsigned char)*p) || (*p == ',' && digits); ++p) if (*p != ',') { n = n * 10 + (*p - '0'); digits = true; }
-    if (*p == '.') { ++p; for (; isdigit((unsigned char)*p); ++p) { n = n * 10 + (*p - '0'); ++decimals; digits = true; } }
+    for (; isdigit((unsigned char)*p) || (*p == ',' && digits); ++p) if (*p != ',') { if (n < LLONG_MAX / 10 - 1) n = n * 10 + (*p - '0'); digits = true; }
+    if (*p == '.') { ++p; for (; isdigit((unsigned char)*p); ++p) { if (n < LLONG_MAX / 10 - 1) { n = n * 10 + (*p - '0'); ++decimals; } digits = true; } }
     if (!digits) { *endp = s; return 0; }
     if ((*p == 'e' || *p == 'E') && (isdigit((unsigned char)p[1]) || ((p[1] == '+' || p[1] == '-') && isdigit((unsigned char)p[2])))) { char *q; e = (int)strtol(p + 1, &q, 10); p = q; }
     switch (*p) { case 'k': case 'K': e += 3; ++p; break; case 'm': case 'M': e += 6; ++p; break; case 'g': case 'G': e += 9; ++p; break; }
     e -= decimals;
-    while (e > 0) { n *= 10; --e; }
+    while (e > 0) { if (n < LLONG_MAX / 10 - 1) n *= 10; --e; }       /* (absurd coordinates saturate instead of overflowing) */
     while (e < 0) { n /= 10; ++e; }
     *endp = p;
     return neg ? -n : n;

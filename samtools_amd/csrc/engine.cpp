@@ -397,35 +397,43 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
         HIPCHK(hipMemcpyAsync(&c, ctr, sizeof(c), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] n_baq=%llu (fast %llu, lq<=%llu) slow: max_lq=%llu max_bw=%llu kept=%llu\n", c.n_baq, c.n_baq_fast, c.max_lq_fast, c.max_lq, c.max_bw, c.n_kept);
-        if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] bw8=%llu general=%llu\n", c.n_baq_bw8, c.n_baq_general);
+        if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] bw8=%llu general=%llu class_s=%llu (lq<=%llu) bw7_list=%llu\n", c.n_baq_bw8, c.n_baq_general, c.n_baq_s, c.max_lq_s, c.n_baq_bw7l);
         for (int f = 0; f < nf && c.n_baq; ++f) {
             StaReadsDev &d = e->files_h[(size_t)f];
             if (!d.n) continue;
             int32_t n_list = 0;
-            if (c.n_baq > c.n_baq_fast) {
+            if (c.n_baq > c.n_baq_fast + c.n_baq_s) {
                 HIPCHK(hipMemcpyAsync(&n_list, d.chain, 4, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
             }
-            if (c.n_baq_fast || c.n_baq_bw8) {
+            const bool has_main = c.n_baq_fast || c.n_baq_s;
+            const bool has_list_band = c.n_baq_bw8 || c.n_baq_bw7l;
+            if (has_main || has_list_band) {
                 // band-in-registers kernels: groups of 64 reads, one scratch slot (forward rows) per group in flight
                 int gpl = 0;
                 size_t need = sta_baq_band_scratch_bytes(d.n, (int)c.max_lq_fast, &gpl, e->baq_slab_gib_cap);
-                if (e->baq_scratch.ensure(need + 64)) {
+                int s_waves = 0;
+                const size_t need_s = c.n_baq_s ? sta_baq7s_scratch_bytes((int)c.max_lq_s, (d.n + 63) / 64, &s_waves) : 0;
+                if (!c.n_baq_fast) {
+                    // nothing is taken in place (class S is on): the band slab only has to hold the list's groups when they run on this stream
+                    need = sta_baq_band_scratch_bytes(has_list_band ? (int64_t)n_list : 0, (int)c.max_lq_fast, &gpl, e->baq_slab_gib_cap);
+                }
+                if (e->baq_scratch.ensure(std::max(need, need_s) + 64)) {
                     // not enough free HBM for the one-launch slab: this engine falls back to a 4 GiB slab (more, smaller launches)
                     (void)hipGetLastError();
                     e->baq_slab_gib_cap = 4;
-                    need = sta_baq_band_scratch_bytes(d.n, (int)c.max_lq_fast, &gpl, e->baq_slab_gib_cap);
-                    if (e->baq_scratch.ensure(need + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ scratch) failed");
+                    need = sta_baq_band_scratch_bytes(c.n_baq_fast ? d.n : (int64_t)n_list, (int)c.max_lq_fast, &gpl, e->baq_slab_gib_cap);
+                    if (e->baq_scratch.ensure(std::max(need, need_s) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ scratch) failed");
                 }
-                // class 1 (band width 8, through the list: a few dozen groups, latency bound) runs on a side stream beside
-                // class 0 (band width 7, reads in place) when both exist; the stream was synchronised above, so the side
-                // stream may start at once, and the main stream waits for it before the qualities are used
+                // The list's band kernels (band width 8, and band width 7 reads that class S does not take: a few dozen groups,
+                // latency bound) run on a side stream beside the main kernel(s) when both exist; the stream was synchronised
+                // above, so the side stream may start at once, and the main stream waits for it before the qualities are used
                 const size_t slot_bytes = need / (size_t)(gpl > 0 ? gpl : 1);
-                const int64_t groups8 = c.n_baq_bw8 ? ((int64_t)n_list + 63) / 64 : 0;
-                bool side = c.n_baq_fast && groups8 > 0 && groups8 <= 4096 && !getenv("STA_BAQ_NO_SIDE_STREAM");
+                const int64_t groupsL = has_list_band ? ((int64_t)n_list + 63) / 64 : 0;
+                bool side = has_main && groupsL > 0 && groupsL <= 4096 && !getenv("STA_BAQ_NO_SIDE_STREAM");
                 char *side_scratch = nullptr;
                 if (side) {
-                    size_t extra = (size_t)groups8 * slot_bytes;
+                    size_t extra = (size_t)groupsL * slot_bytes;
                     if (e->baq_scratch2.ensure(extra + 64)) { (void)hipGetLastError(); side = false; }
                     else side_scratch = (char *)e->baq_scratch2.p;
                     if (side && !e->side) {
@@ -434,21 +442,27 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                         }
                     }
                 }
-                for (int cls = 1; cls >= 0; --cls) {
-                    // class 0: band width 7, reads taken in place; class 1: band width 8, through the list
-                    int64_t items = cls == 0 ? (c.n_baq_fast ? d.n : 0) : (c.n_baq_bw8 ? (int64_t)n_list : 0);
+                // classes: 2 = band width 8 through the list, 1 = band width 7 through the list, 0 = band width 7 in place (round-3
+                // kernels, only with STA_BAQ_CLASS_S=0), then class S
+                for (int cls = 2; cls >= 0; --cls) {
+                    int64_t items = cls == 0 ? (c.n_baq_fast ? d.n : 0) : cls == 1 ? (c.n_baq_bw7l ? (int64_t)n_list : 0) : (c.n_baq_bw8 ? (int64_t)n_list : 0);
                     int64_t ngroups = (items + 63) / 64;
-                    const bool on_side = side && cls == 1;
+                    const bool on_side = side && cls != 0;
                     hipStream_t st = on_side ? e->side : s;
                     int64_t step = on_side ? ngroups : gpl;
+                    static const char *const names[3][2] = { { "baq_fwd", "baq_bwd" }, { "baq7l_fwd", "baq7l_bwd" }, { "baq8_fwd", "baq8_bwd" } };
                     for (int64_t g0 = 0; g0 < ngroups; g0 += step) {
                         int64_t ng = ngroups - g0 < step ? ngroups - g0 : step;
                         for (int pass = 0; pass < 2; ++pass) {
-                            ProfScope ps(e, cls == 0 ? (pass ? "baq_bwd" : "baq_fwd") : (pass ? "baq8_bwd" : "baq8_fwd"), st, true);
-                            sta_launch_baq_band(st, d, e->wd, on_side ? (void *)side_scratch : e->baq_scratch.p, (int)c.max_lq_fast, cls == 0 ? 7 : 8, g0, ng, cls, pass);
+                            ProfScope ps(e, names[cls][pass], st, true);
+                            sta_launch_baq_band(st, d, e->wd, on_side ? (void *)side_scratch : e->baq_scratch.p, (int)c.max_lq_fast, cls == 2 ? 8 : 7, g0, ng, cls != 0, pass);
                         }
                     }
-                    if (on_side) HIPCHK(hipEventRecord(e->side_done, e->side));
+                    if (on_side && cls == 1) HIPCHK(hipEventRecord(e->side_done, e->side));
+                }
+                if (c.n_baq_s) {
+                    ProfScope ps(e, "baq_s");
+                    sta_launch_baq7s(s, d, e->wd, e->baq_scratch.p, (int)c.max_lq_s, s_waves);
                 }
                 if (side) HIPCHK(hipStreamWaitEvent(s, e->side_done, 0));
             }

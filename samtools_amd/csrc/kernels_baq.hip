@@ -897,3 +897,149 @@ void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
     if (bw == 7) { if (baq_dec_mode() == 2) run_band<7, 2>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass); else run_band<7, 1>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass); }
     else if (bw == 8) run_band<8, 0>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass);
 }
+
+// ================================================================================================
+// Class S (baq_band7s.h): one persistent, fused kernel.  A wave takes groups of 64 consecutive reads from a counter; for each it
+// packs the per-row inputs, runs the forward pass into its scratch slot and, one group later, the backward pass out of it.  Half
+// of the waves run one forward pass ahead of the other half (two slots per wave), so that at any time about half of a CU's waves
+// are in the store-heavy forward phase and half in the issue-heavy backward phase: the forward rows' write stream, their read
+// stream and the fp64 issue overlap inside one launch instead of alternating between two.
+#include "baq_band7s.h"
+
+__device__ __forceinline__ double baq_uni(double x)       // a wave-uniform double into scalar registers
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+struct Baq7sSlot { uint32_t *IN; baq7s::d2 *F2; double *S; };
+__host__ __device__ inline size_t baq7s_in_bytes(int lq_cap) { return (((size_t)(lq_cap + 2) * 64 * 4) + 1023) & ~(size_t)1023; }
+__host__ __device__ inline size_t baq7s_f2_bytes(int lq_cap) { return (size_t)((lq_cap + 1) / 2) * baq7s::NB * 64 * 16; }
+__host__ __device__ inline size_t baq7s_slot_bytes(int lq_cap) { return baq7s_in_bytes(lq_cap) + baq7s_f2_bytes(lq_cap) + (size_t)(lq_cap + 2) * 64 * 8; }
+__device__ __forceinline__ Baq7sSlot baq7s_slot(uint8_t *scratch, size_t slot_bytes, int64_t idx, int lq_cap, int lane)
+{
+    uint8_t *b = scratch + (size_t)idx * slot_bytes;
+    Baq7sSlot s;
+    s.IN = reinterpret_cast<uint32_t *>(b) + lane;
+    s.F2 = reinterpret_cast<baq7s::d2 *>(b + baq7s_in_bytes(lq_cap)) + lane;
+    s.S = reinterpret_cast<double *>(b + baq7s_in_bytes(lq_cap) + baq7s_f2_bytes(lq_cap)) + lane;
+    return s;
+}
+
+struct Baq7sRead { bool active; int lq; baq7s::Shape sh; uint8_t *qual; const uint8_t *seq; };
+__device__ __forceinline__ Baq7sRead baq7s_read(const StaReadsDev &R, const StaWinDev &W, int64_t g, int lane)
+{
+    Baq7sRead d; d.active = false; d.lq = 0; d.qual = nullptr; d.seq = nullptr; d.sh.ok = false; d.sh.ys = d.sh.mlen = 0; d.sh.xb = 0;
+    const int64_t r = g * 64 + lane;
+    if (r < R.n && (R.info[r] & RI_BAQ_S)) {
+        d.active = true;
+        d.lq = R.l_qseq[r];
+        const uint32_t c0 = R.cig_off[r];
+        d.sh = baq7s::classify(R.cigar + c0, (int)(R.cig_off[r + 1] - c0), W.origin + R.pos[r], d.lq, W.ref_len);
+        const uint64_t boff = (uint64_t)R.base_off8[r] << 3;
+        d.qual = R.qual + boff; d.seq = R.seq + (boff >> 1);
+    }
+    return d;
+}
+
+// two waves per SIMD: the backward pass holds 120 doubles of band state (256 VGPRs; 168 would spill 230 of them)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_baq7s(StaReadsDev R, StaWinDev W, BaqTables T, int64_t ngroups, unsigned *next,
+                                              uint8_t *scratch, size_t slot_bytes, int lq_cap, int lead_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t baq7s_state[];      // [row][lane]: b of every row of the group in its backward pass
+    __shared__ float q2p[256];
+    __shared__ uint8_t refc[256];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < 256; k += 64) { q2p[k] = T.q2p[k]; refc[k] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)k)); }
+    __syncthreads();
+    uint8_t *state = baq7s_state + lane;
+    int64_t pend0 = -1, pend1 = -1;                   // groups whose forward rows wait in a slot (slot index in bit 62), oldest first
+    int np = 0, cur = 0;
+    bool extra = (blockIdx.x & lead_mask) != 0;         // this wave runs one forward pass ahead
+    for (;;) {
+        unsigned gt = 0;
+        if (lane == 0) gt = atomicAdd(next, 1u);
+        const int64_t g = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)gt);
+        const bool have = g < ngroups;
+        if (have) {
+            const Baq7sRead d = baq7s_read(R, W, g, lane);
+            const unsigned long long act = __ballot(d.active);
+            if (act) {
+                const int lq = __builtin_amdgcn_readfirstlane(__shfl(d.lq, __ffsll((long long)act) - 1));
+                const Baq7sSlot sl = baq7s_slot(scratch, slot_bytes, (int64_t)blockIdx.x * 2 + cur, lq_cap, lane);
+                bool all_edge = false;
+                if (d.active) {
+                    baq7s::Par p = baq7s::make_par(lq, lq + 6);
+                    p.m0 = baq_uni(p.m0); p.m1 = baq_uni(p.m1); p.m2 = baq_uni(p.m2); p.m3 = baq_uni(p.m3); p.m4 = baq_uni(p.m4);
+                    p.m6 = baq_uni(p.m6); p.m8 = baq_uni(p.m8); p.sM = baq_uni(p.sM); p.sI = baq_uni(p.sI); p.bM = baq_uni(p.bM); p.bI = baq_uni(p.bI);
+                    const bool amb = baq7s::pack_lane<64>(lq, lq + 6, d.qual, d.seq, W.ref + d.sh.xb, refc, sl.IN);
+                    all_edge = baq7s::wave_any(amb);
+                    baq7s::fwd_lane<64>(p, lq, all_edge, sl.IN, sl.F2, sl.S, q2p);
+                }
+                all_edge = __ballot(all_edge) != 0;
+                const int64_t tag = g | ((int64_t)cur << 62) | ((int64_t)(all_edge ? 1 : 0) << 61);
+                if (np == 0) pend0 = tag; else pend1 = tag;
+                ++np;
+                cur ^= 1;
+            }
+        }
+        if (extra && have) { extra = false; continue; }
+        if (np > 0) {
+            const int64_t pg = pend0;
+            pend0 = pend1; --np;
+            const int64_t g2 = pg & (((int64_t)1 << 61) - 1);
+            const int sidx = (int)(pg >> 62) & 1;
+            const bool all_edge = ((pg >> 61) & 1) != 0;
+            const Baq7sRead d = baq7s_read(R, W, g2, lane);
+            const unsigned long long act = __ballot(d.active);
+            const int lq = __builtin_amdgcn_readfirstlane(__shfl(d.lq, __ffsll((long long)act) - 1));
+            const Baq7sSlot sl = baq7s_slot(scratch, slot_bytes, (int64_t)blockIdx.x * 2 + sidx, lq_cap, lane);
+            if (d.active) {
+                baq7s::Par p = baq7s::make_par(lq, lq + 6);
+                p.m0 = baq_uni(p.m0); p.m1 = baq_uni(p.m1); p.m2 = baq_uni(p.m2); p.m3 = baq_uni(p.m3); p.m4 = baq_uni(p.m4);
+                p.m6 = baq_uni(p.m6); p.m8 = baq_uni(p.m8); p.sM = baq_uni(p.sM); p.sI = baq_uni(p.sI);
+                p.eim1 = baq_uni(p.eim1); p.eim4 = baq_uni(p.eim4);
+                baq7s::BwdCtx c; c.ys = d.sh.ys; c.mlen = d.sh.mlen; c.run_r = 0; c.plain = W.baq_plain != 0;
+                baq7s::bwd_lane<64>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, q2p, state, c);
+                baq7s::final_lane<64>(lq, sl.IN, state, c, d.qual);
+            }
+        } else if (!have) break;
+    }
+}
+
+static int g_baq7s_waves = 0;
+// scratch for the class-S kernel: a 256-byte header (the group counter) + two slots per resident wave
+size_t sta_baq7s_scratch_bytes(int lq_cap, int64_t ngroups, int *waves_out)
+{
+    if (!g_baq7s_waves) {
+        int dev = 0, cus = 256, per = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        const int rows = (256 + 3) & ~3;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_baq7s, 64, (size_t)rows * 64) != hipSuccess || per < 1) { (void)hipGetLastError(); per = 8; }
+        const char *e = getenv("STA_BAQ7S_WAVES_PER_CU");
+        if (e && atoi(e) > 0 && atoi(e) < per) per = atoi(e);
+        g_baq7s_waves = cus * per;
+    }
+    int64_t waves = g_baq7s_waves;
+    if (waves > ngroups) waves = ngroups;
+    if (waves < 1) waves = 1;
+    if (waves_out) *waves_out = (int)waves;
+    return 256 + (size_t)waves * 2 * baq7s_slot_bytes(lq_cap);
+}
+
+void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int waves)
+{
+    if (!g_tables_init) {
+        for (int i = 0; i < 256; ++i) g_tables.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
+        g_tables_init = true;
+    }
+    const int64_t ngroups = (r.n + 63) / 64;
+    if (ngroups <= 0 || waves <= 0) return;
+    static const int lead = [] { const char *e = getenv("STA_BAQ7S_LEAD"); return e ? atoi(e) : 1; }();   // 0: every wave forward-then-backward; 1: odd waves one forward pass ahead
+    hipMemsetAsync(scratch, 0, 256, s);
+    const int rows = (lq_cap + 3) & ~3;
+    hipLaunchKernelGGL(k_baq7s, dim3((unsigned)waves), dim3(64), (size_t)rows * 64, s, r, w, g_tables, ngroups, (unsigned *)scratch,
+                       (uint8_t *)scratch + 256, baq7s_slot_bytes(lq_cap), lq_cap, lead);
+}

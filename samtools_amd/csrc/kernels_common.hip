@@ -8,11 +8,12 @@
 //                     elementwise pass over the quality pool, 16 B per lane.
 // scans             : three-phase block scans (reduce / scan of block sums / rescan), wave64 shuffles.
 #include "dev_util.h"
+#include "baq_band7s.h"
 #include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 struct PrepArgs {
-    int32_t min_mq, rflag_require, rflag_filter, flag, all, baq_force_slow, min_qlen;
+    int32_t min_mq, rflag_require, rflag_filter, flag, all, baq_force_slow, min_qlen, baq_class_s;
 };
 
 __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, PrepArgs P, StaCounters *ctr)
@@ -20,7 +21,7 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
     // grid-stride over the reads: the counters are reduced ONCE per block at the end (a counter word sustains only ~90
     // atomics/us, so one reduction per 256 reads cost more than the reads themselves)
     unsigned long long piled = 0, kept = 0;
-    unsigned long long c_baq = 0, c_fast = 0, c_bw8 = 0, c_gen = 0, m_lqf = 0, m_lq = 0, m_bw = 0;
+    unsigned long long c_baq = 0, c_fast = 0, c_bw8 = 0, c_gen = 0, m_lqf = 0, m_lq = 0, m_bw = 0, c_s = 0, m_lqs = 0, c_bw7l = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R.n; i += (int64_t)gridDim.x * blockDim.x) {
         int32_t pos = R.pos[i];
         uint32_t flag = R.flag[i];
@@ -70,7 +71,8 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
             bool no = (mtid >= 0 && mtid != W.tid) || (isz >= 2ll * lq && mpos >= W.origin + end);
             if (!no) info |= RI_OLAP_EL;
         }
-        // BAQ needed? (realn.c early returns, A.4)
+        // BAQ needed? (realn.c early returns, A.4)  baq_cls: 0 none, 1 band width 7 in place, 2 through the list, 3 class-S candidate
+        int baq_cls = 0, baq_bw = 0, baq_gbw = 0;
         if (pushed && (P.flag & STA_MPLP_REALN) && has_ref && lq > 0 && has_m && !has_n) {
             bool redo = (P.flag & STA_MPLP_REDO_BAQ) != 0;
             bool q_absent = R.qual_in[(uint64_t)R.base_off8[i] << 3] == 0xff;
@@ -80,23 +82,39 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
                     info |= RI_BAQ;
                     c_baq += 1;
                     bool band = (g.bw == 7 || g.bw == 8) && lq <= STA_BAQ7_LQ_MAX && !P.baq_force_slow;
-                    if (band) {
-                        info |= (uint32_t)g.bw << RI_BAQ_BW_SHIFT;
-                        if ((unsigned long long)lq > m_lqf) m_lqf = (unsigned long long)lq;
-                    } else {
-                        if ((unsigned long long)lq > m_lq) m_lq = (unsigned long long)lq;
-                        if ((unsigned long long)g.bw > m_bw) m_bw = (unsigned long long)g.bw;
-                    }
-                    if (band && g.bw == 7) c_fast += 1;
-                    else {
-                        if (band) c_bw8 += 1; else c_gen += 1;
-                        info |= RI_BAQ_SLOW;
-                        int slot = atomicAdd(&R.chain[0], 1);
-                        R.chain[1 + slot] = (int32_t)i;
-                    }
+                    baq_bw = band ? g.bw : 0; baq_gbw = g.bw;
+                    baq_cls = (band && g.bw == 7) ? 1 : 2;
+                    if (baq_cls == 1 && P.baq_class_s && baq7s::classify(R.cigar + c0, (int)(c1 - c0), apos, lq, W.ref_len).ok && g.l_ref == lq + 6) baq_cls = 3;
                 }
             }
             // both BQ and ZQ without redo: ZQ is dropped and BQ applied by k_qual_prep
+        }
+        if (P.baq_class_s) {
+            // class S wants ONE read length per group of 64 consecutive reads (its parameters live in scalar registers): the
+            // length of the group's first candidate; every other band-width-7 read goes through the list
+            const unsigned long long cand = __ballot(baq_cls == 3);
+            if (cand) {
+                const int lq0 = __shfl(lq, __ffsll((long long)cand) - 1);
+                if (baq_cls == 3 && lq != lq0) baq_cls = 1;
+            }
+            if (baq_cls == 1) baq_cls = 2;
+        }
+        if (baq_cls) {
+            if (baq_bw) {
+                info |= (uint32_t)baq_bw << RI_BAQ_BW_SHIFT;
+                if ((unsigned long long)lq > m_lqf) m_lqf = (unsigned long long)lq;
+            } else {
+                if ((unsigned long long)lq > m_lq) m_lq = (unsigned long long)lq;
+                if ((unsigned long long)baq_gbw > m_bw) m_bw = (unsigned long long)baq_gbw;
+            }
+            if (baq_cls == 3) { info |= RI_BAQ_S; c_s += 1; if ((unsigned long long)lq > m_lqs) m_lqs = (unsigned long long)lq; }
+            else if (baq_cls == 1) c_fast += 1;
+            else {
+                if (baq_bw == 7) c_bw7l += 1; else if (baq_bw == 8) c_bw8 += 1; else c_gen += 1;
+                info |= RI_BAQ_SLOW;
+                int slot = atomicAdd(&R.chain[0], 1);
+                R.chain[1 + slot] = (int32_t)i;
+            }
         }
         R.end[i] = end;
         R.info[i] = info;
@@ -107,16 +125,18 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
         }
     }
     // block reduce, then one atomic per counter and block
-    unsigned long long v[9] = { piled, kept, c_baq, c_fast, c_bw8, c_gen, m_lqf, m_lq, m_bw };
-    unsigned long long *const dst[9] = { &ctr->piled_bases, &ctr->n_kept, &ctr->n_baq, &ctr->n_baq_fast, &ctr->n_baq_bw8, &ctr->n_baq_general,
-                                         &ctr->max_lq_fast, &ctr->max_lq, &ctr->max_bw };
-    block_reduce_atomic<9, 6>(v, dst);
+    unsigned long long v[12] = { piled, kept, c_baq, c_fast, c_bw8, c_gen, c_s, c_bw7l, m_lqf, m_lq, m_bw, m_lqs };
+    unsigned long long *const dst[12] = { &ctr->piled_bases, &ctr->n_kept, &ctr->n_baq, &ctr->n_baq_fast, &ctr->n_baq_bw8, &ctr->n_baq_general,
+                                          &ctr->n_baq_s, &ctr->n_baq_bw7l, &ctr->max_lq_fast, &ctr->max_lq, &ctr->max_bw, &ctr->max_lq_s };
+    block_reduce_atomic<12, 8>(v, dst);
 }
 
 void sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
                            const sta_mplp_params &p, StaCounters *ctr)
 {
-    PrepArgs a{ p.min_mq, p.rflag_require, p.rflag_filter, p.flag, p.all, getenv("STA_BAQ_FORCE_SLOW") ? 1 : 0, p.min_qlen };
+    // STA_BAQ_CLASS_S=0: the round-3 kernels take every band-width-7 read in place (A/B measurements, tests of both paths)
+    static const int class_s = [] { const char *e = getenv("STA_BAQ_CLASS_S"); return e ? atoi(e) : 1; }();
+    PrepArgs a{ p.min_mq, p.rflag_require, p.rflag_filter, p.flag, p.all, getenv("STA_BAQ_FORCE_SLOW") ? 1 : 0, p.min_qlen, class_s && !getenv("STA_BAQ_FORCE_SLOW") };
     for (int f = 0; f < nfiles; ++f) {
         const StaReadsDev &R = files_host[f];
         if (R.n == 0) continue;

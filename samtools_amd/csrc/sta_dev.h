@@ -16,6 +16,7 @@
 #define RI_BAQ_SLOW 0x40u   // ... by the general-band kernel (band width != 7 or very long read); listed in `chain`
 #define RI_BAQ_BW_SHIFT 16  // bits 16..20: band width handled by a band-in-registers BAQ kernel (7 or 8), 0 = general kernel
 #define RI_MAPQ_SHIFT 8     // bits 8..15: mapping quality after -C
+#define RI_BAQ_S    0x200000u  // BAQ by the class-S kernel (baq_band7s.h: one M operation, unclipped window, band width 7, one read length per group of 64)
 
 // one input file's reads as the kernels see them (all device pointers)
 struct StaReadsDev {
@@ -69,7 +70,7 @@ struct StaWinDev {
 };
 
 struct StaCounters {          // device-side reduction targets, zeroed per plan
-    unsigned long long n_lines, n_data_cols, n_kept, piled_bases, n_dropped, max_wave_bytes, n_anom, maxcnt_flag, max_lq, max_bw, n_baq, max_lq_fast, n_baq_fast, n_baq_bw8, n_baq_general;
+    unsigned long long n_lines, n_data_cols, n_kept, piled_bases, n_dropped, max_wave_bytes, n_anom, maxcnt_flag, max_lq, max_bw, n_baq, max_lq_fast, n_baq_fast, n_baq_bw8, n_baq_general, n_baq_s, max_lq_s, n_baq_bw7l;
     unsigned long long out_bytes, overflow;      // single-pass kernels: total text bytes of the window; set when the output buffer was too small
 };
 
@@ -141,6 +142,10 @@ void sta_launch_baq(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int
 size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_launch, int slab_gib_cap /* 0 = $STA_BAQ_SLAB_GIB or 48 */);
 void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw,
                          int64_t g0, int64_t ng, int use_list, int pass /*0 forward, 1 backward*/);
+
+// class S (baq_band7s.h): one fused persistent kernel over all groups of 64 reads; scratch = 256-byte header + two slots per resident wave
+size_t sta_baq7s_scratch_bytes(int lq_cap, int64_t ngroups, int *waves_out);
+void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int waves);
 
 // depth
 size_t sta_depth_fused_status_bytes(int64_t ncols);

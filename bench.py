@@ -86,7 +86,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec); ~6.3 TB/s is
 FP64_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # BAQ arithmetic per band cell (kernels_baq.hip): forward M 6 + I 4 + D 3 + row sum 3 + scaling 3 = 19 fp64 operations,
 # backward M 6 + I 3 + D 4 + scaling 2 + MAP 6 = 21; 2*7+1 = 15 band cells per query base
-BAQ_FP64_OPS_PER_BASE = {"baq_fwd": 19 * 15, "baq_bwd": 21 * 15}
+BAQ_FP64_OPS_PER_BASE = {"baq_fwd": 19 * 15, "baq_bwd": 21 * 15, "baq_s": (19 + 21) * 15}     # baq_s: both passes in one launch (class S, baq_band7s.h)
 
 
 def parse():
@@ -270,12 +270,14 @@ def collect_pmc(a, wlname, kernels):
 
 
 # engine kernel label -> prefix of the rocprofv3 kernel name
-KNAME = {"baq_fwd": "void k_baq_fwd<7", "baq_bwd": "void k_baq_bwd<7", "mplp_emit": "k_mplp_emit_tile", "mplp_emit_deep": "k_mplp_emit_deep", "mplp_len": "k_mplp_len_rm",
+KNAME = {"baq_s": "k_baq7s", "baq_fwd": "void k_baq_fwd<7", "baq_bwd": "void k_baq_bwd<7", "mplp_emit": "k_mplp_emit_tile", "mplp_emit_deep": "k_mplp_emit_deep", "mplp_len": "k_mplp_len_rm",
          "depth_fused": "k_depth_fused", "glf_cols": "k_glf_cols", "cons_col": "k_cons_col", "cons_walk": "k_cons_walk", "cons_read_a": "k_cons_read_a"}
-# gfx950: FETCH_SIZE tallies a 16-byte-per-lane streaming read at half its bytes (MI355X_MICROARCH.md, HBM).  k_baq_bwd reads two
-# thirds of its forward-row stream that way (the (M, I) pairs of the odd rows) and one third as 8-byte loads: the raw counter is
-# reported, and roofline.dram_util gives the stream the kernel must move by construction
-FETCH_X2 = set()
+# gfx950 calibration (scripts/ubench/pmc_calib.hip, profiles/r04_pmc_calibration.md): kernels that read exactly 4 GiB from HBM
+# with 16 / 8 / 4 / 1 bytes per lane, temporal and non-temporal, all count FETCH_SIZE = 2 GiB (TCC_EA0_RDREQ = one request per 128 B
+# of it, none of them 32 B), and kernels that write 4 GiB count WRITE_SIZE = 4 GiB: on this chip FETCH_SIZE is half the bytes
+# fetched whatever the access width, WRITE_SIZE is exact.  The factor is applied to every kernel.
+FETCH_SCALE = 2.0
+WRITE_SCALE = 1.0
 
 
 def self_launch(a):
@@ -551,7 +553,7 @@ def run_workload(a, wlname, ctx, secondary=False):
             ent = next((v for k, v in (pmc or {}).items() if k.startswith(pre)), None)
             if not ent or "FETCH_SIZE" not in ent or "WRITE_SIZE" not in ent:
                 return None
-            return (ent["FETCH_SIZE"] * (2.0 if name in FETCH_X2 else 1.0) + ent["WRITE_SIZE"]) * 1024.0
+            return (ent["FETCH_SIZE"] * FETCH_SCALE + ent["WRITE_SIZE"] * WRITE_SCALE) * 1024.0
 
         def roof(name, bpb=None):
             """SURVEY.md 8(d) roofline of one kernel: the path's algorithmic bytes per piled base (each staged byte read once, each
@@ -565,7 +567,8 @@ def run_workload(a, wlname, ctx, secondary=False):
             ach = alg_bpb * units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             tr = traffic_of(name)
             r = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                 "traffic": tr, "traffic_source": pmc_src if tr is not None else None,
+                 "traffic": tr, "traffic_ratio": (tr / (alg_bpb * units)) if (tr is not None and units) else None,
+                 "traffic_source": (pmc_src + "; FETCH_SIZE x %.1f (gfx950 calibration)" % FETCH_SCALE) if tr is not None else None,
                  "alg_bytes_per_unit": alg_bpb, "units_per_launch": units, "avg_launch_ms": avg_ms, "launches_per_step": per_step}
             if name in BAQ_FP64_OPS_PER_BASE:
                 # BAQ is fp64 work ("flops, not bytes, then dominate BAQ (report separately)")
@@ -574,7 +577,8 @@ def run_workload(a, wlname, ctx, secondary=False):
                 r["fp64"] = {"ops_per_unit": BAQ_FP64_OPS_PER_BASE[name], "achieved": tops, "peak": FP64_PEAK_TOPS, "unit": "Tflop/s (no FMA)",
                              "frac": tops / FP64_PEAK_TOPS}
                 # the forward-row scratch stream the kernel pair moves through HBM: implementation traffic, reported as DRAM utilisation
-                sb = float(os.environ.get("STA_BAQ_STREAM_BPB", "0")) or eng_baq_stream_bpb
+                # (the fused class-S kernel writes AND reads it inside one launch: twice the bytes per unit)
+                sb = (float(os.environ.get("STA_BAQ_STREAM_BPB", "0")) or eng_baq_stream_bpb) * (2.0 if name == "baq_s" else 1.0)
                 r["dram_util"] = {"stream_bytes_per_unit": sb, "achieved": sb * units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s"}
                 r["dram_util"]["frac"] = r["dram_util"]["achieved"] / HBM_PEAK_GBS
@@ -583,7 +587,7 @@ def run_workload(a, wlname, ctx, secondary=False):
         # forward rows streamed per query base by the BAQ pair (2 doubles per band cell and stored row, see kernels_baq.hip)
         eng_baq_stream_bpb = float(sa.baq_stream_bytes_per_base()) if hasattr(sa, "baq_stream_bytes_per_base") else 240.0
         # kernels on the side stream (band-8 BAQ groups) overlap the main ones: they cannot be "the" dominant kernel
-        main_k = {k: v for k, v in prof.items() if not k.startswith("baq8")}
+        main_k = {k: v for k, v in prof.items() if not k.startswith(("baq8", "baq7l"))}
         dom_name = max(main_k.items(), key=lambda kv: kv[1][1])[0] if main_k else None
         res = {
             "metric": "Mbases piled/s (mpileup, 30x 150bp)" if wlname == "mpileup30" else "Mbases piled/s (%s: %s, %dx 150bp)" % (wlname, " ".join(spec["argv"][:-2] if kind == "mpileup" else spec["argv"][:-1]), depth),

@@ -395,6 +395,12 @@ class Engine:
         self._chk(lib.sta_fetch_output(self._h, C.cast(buf, _P), int(nbytes)), "sta_fetch_output")
         return buf.raw[:int(nbytes)]
 
+    def fetch_col_offsets(self, n):
+        """first n (<= columns + 1) exclusive column offsets of the planned window, in bytes of the window's text"""
+        arr = (C.c_uint64 * int(n))()
+        self._chk(lib.sta_fetch_col_offsets(self._h, C.cast(arr, _P), int(n)), "sta_fetch_col_offsets")
+        return list(arr)
+
     def sync(self):
         self._chk(lib.sta_sync(self._h), "sta_sync")
 

@@ -61,13 +61,17 @@ BQS_HD Par make_par(int lq, int l_ref)
 // ---- the things that differ between the device and the CPU harness ----
 #if defined(__HIP_DEVICE_COMPILE__)
 BQS_HD bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
-BQS_HD d2 ld_d2(const d2 *p) { return __builtin_nontemporal_load(p); }
-BQS_HD void st_d2(d2 *p, d2 v) { __builtin_nontemporal_store(v, p); }
+// MODE: 0 = non-temporal row stream, 1 = plain loads / stores; diagnostics with wrong results: 2 = no row stream at all (the
+// arithmetic and the small per-row inputs), 3 = 2 with the small inputs taken from a handful of cache-hot rows
+template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { if (MODE >= 2) { d2 v = { 1e-3, 1e-3 }; return v; } return MODE ? *p : __builtin_nontemporal_load(p); }
+template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { if (MODE >= 2) return; if (MODE) *p = v; else __builtin_nontemporal_store(v, p); }
+template <int MODE> BQS_HD int hot_row(int i) { return MODE == 3 ? 1 + (i & 7) : i; }
 BQS_HD double fmax_(double a, double b) { return __builtin_fmax(a, b); }
 #else
 BQS_HD bool wave_any(bool c) { return c; }
-BQS_HD d2 ld_d2(const d2 *p) { return *p; }
-BQS_HD void st_d2(d2 *p, d2 v) { *p = v; }
+template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { return *p; }
+template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { *p = v; }
+template <int MODE> BQS_HD int hot_row(int i) { return i; }
 BQS_HD double fmax_(double a, double b) { return fmax(a, b); }
 #endif
 
@@ -157,12 +161,12 @@ BQS_HD double fwd_row(const Par &p, const Emis &em, uint64_t rw, double (&M)[NB]
 struct FwdState { double M[NB], I[NB], D[NB]; uint64_t rw; uint32_t w_next, w_next2; };
 
 // one row i >= 2: inputs, the row, its sum, the raw store of an odd row, the normalisation
-template <int LS, bool EDGE>
+template <int LS, bool EDGE, int MODE>
 BQS_HD void fwd_step(const Par &p, int lq, int i, const uint32_t *IN, d2 *F2, double *S, const float *q2p, FwdState &f)
 {
     const uint32_t w = f.w_next;
     f.w_next = f.w_next2;
-    if (i + 2 <= lq) f.w_next2 = IN[(size_t)(i + 2) * LS];
+    if (i + 2 <= lq) f.w_next2 = IN[(size_t)hot_row<MODE>(i + 2) * LS];
     f.rw = (f.rw >> 3) | ((uint64_t)((w >> 11) & 7u) << (3 * (NB - 1)));
     const Emis em = make_emis(w, f.rw, q2p);
     const double sum = fwd_row<EDGE>(p, em, f.rw, f.M, f.I, f.D);
@@ -170,7 +174,7 @@ BQS_HD void fwd_step(const Par &p, int lq, int i, const uint32_t *IN, d2 *F2, do
     if (i & 1) {                          // raw (M, I) of an odd row; even rows are not stored
         const size_t t = (size_t)((i - 1) >> 1) * NB;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2(&F2[(t + j) * LS], v); }
+        for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(&F2[(t + j) * LS], v); }
     }
     const double inv = 1. / sum;
 #pragma unroll
@@ -180,7 +184,7 @@ BQS_HD void fwd_step(const Par &p, int lq, int i, const uint32_t *IN, d2 *F2, do
 // all_edge: the group's windows hold an ambiguous reference base somewhere: every row takes the all-tests code.  Otherwise rows
 // 8 .. lq - 1 (all 15 cells inside the window) take the interior code.  Three loops, not a branch per row: a row body that exists
 // in two variants inside one loop doubles the live state at the join (measured: +130 spilled registers).
-template <int LS>
+template <int LS, int MODE = 0>
 BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2 *F2, double *S, const float *q2p)
 {
     FwdState f;
@@ -207,17 +211,17 @@ BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2
 #pragma unroll
         for (int j = 0; j < NB; ++j) { f.M[j] /= sum; f.I[j] /= sum; }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2(&F2[(size_t)j * LS], v); }
+        for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(&F2[(size_t)j * LS], v); }
     }
     f.w_next = IN[(size_t)2 * LS]; f.w_next2 = lq >= 3 ? IN[(size_t)3 * LS] : 0;
     const int e1 = (all_edge || BQS_TEST_FORCE_EDGE) ? lq : BW;
     int i = 2;
 #pragma unroll 1
-    for (; i <= e1; ++i) fwd_step<LS, true>(p, lq, i, IN, F2, S, q2p, f);
+    for (; i <= e1; ++i) fwd_step<LS, true, MODE>(p, lq, i, IN, F2, S, q2p, f);
 #pragma unroll 1
-    for (; i <= lq - 1; ++i) fwd_step<LS, false>(p, lq, i, IN, F2, S, q2p, f);
+    for (; i <= lq - 1; ++i) fwd_step<LS, false, MODE>(p, lq, i, IN, F2, S, q2p, f);
 #pragma unroll 1
-    for (; i <= lq; ++i) fwd_step<LS, true>(p, lq, i, IN, F2, S, q2p, f);
+    for (; i <= lq; ++i) fwd_step<LS, true, MODE>(p, lq, i, IN, F2, S, q2p, f);
     {   // s[l_query + 1]
         double sum = 0.;
 #pragma unroll
@@ -346,15 +350,16 @@ struct BwdState { double bM[NB], bI[NB]; uint64_t rw; uint32_t w_up; };
 
 // one pair (i even, i - 1 odd).  b.rw is the band word of row min(i + 2, lq) when a pair starts, b.w_up the input word of row i + 1
 // (of row lq for the first pair).
-template <int LS, bool EDGE, class St>
+template <int LS, bool EDGE, int MODE, class St>
 BQS_HD void bwd_pair(const Par &p, int lq, int l_ref, int i, uint32_t *IN, const d2 *F2, const double *S, const float *q2p, St state, BwdCtx &c, BwdState &b)
 {
     const size_t t = (size_t)((i - 1) >> 1) * NB;
+    // the small inputs in FRONT of the thirty cell loads: the first thing the pair needs is 1 / s[i], and loads come back in order
+    const uint32_t w_i = IN[(size_t)hot_row<MODE>(i) * LS], w_o = IN[(size_t)hot_row<MODE>(i - 1) * LS];
+    const double s_i = S[(size_t)hot_row<MODE>(i) * LS], s_o = S[(size_t)hot_row<MODE>(i - 1) * LS];
     double Mp[NB], Ip[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) { const d2 v = ld_d2(&F2[(t + j) * LS]); Mp[j] = v.x; Ip[j] = v.y; }
-    const uint32_t w_i = IN[(size_t)i * LS], w_o = IN[(size_t)(i - 1) * LS];
-    const double s_i = S[(size_t)i * LS], s_o = S[(size_t)(i - 1) * LS];
+    for (int j = 0; j < NB; ++j) { const d2 v = ld_d2<MODE>(&F2[(t + j) * LS]); Mp[j] = v.x; Ip[j] = v.y; }
     // band words: row i + 1 (emissions of the step to row i) and row i (re-evaluation of row i, step to row i - 1)
     uint64_t rw1 = b.rw;
     if (!EDGE || i < lq - 1) rw1 = ((b.rw << 3) | (uint64_t)((b.w_up >> 14) & 7u)) & WORD_MASK;
@@ -379,7 +384,7 @@ BQS_HD void bwd_pair(const Par &p, int lq, int l_ref, int i, uint32_t *IN, const
 
 // all_edge as in fwd_lane.  Otherwise the pairs with 10 <= i <= lq - 2 (rows i - 1 .. i + 1 have all cells inside the window)
 // take the interior code: loops, not a branch per pair.
-template <int LS, class St>
+template <int LS, int MODE = 0, class St>
 BQS_HD void bwd_lane(const Par &p, int lq, int l_ref, bool all_edge, uint32_t *IN, const d2 *F2, const double *S, const float *q2p, St state, BwdCtx &c)
 {
     BwdState b;
@@ -403,7 +408,7 @@ BQS_HD void bwd_lane(const Par &p, int lq, int l_ref, bool all_edge, uint32_t *I
         const double inv = 1. / s_top;
         double fM[NB], fI[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { const d2 v = ld_d2(&F2[(t + j) * LS]); fM[j] = v.x * inv; fI[j] = v.y * inv; }
+        for (int j = 0; j < NB; ++j) { const d2 v = ld_d2<MODE>(&F2[(t + j) * LS]); fM[j] = v.x * inv; fI[j] = v.y * inv; }
         MapAcc a; map_row(a, fM, fI, b.bM, b.bI);
         finish_row<LS>(c, lq, a, b.w_up, IN, state);
         --i;
@@ -411,11 +416,11 @@ BQS_HD void bwd_lane(const Par &p, int lq, int l_ref, bool all_edge, uint32_t *I
     const bool ae = all_edge || BQS_TEST_FORCE_EDGE;
     const int hi = ae ? 0 : lq - 2, lo = ae ? 2 : BW + 3;          // interior pairs: lo <= i <= hi
 #pragma unroll 1
-    for (; i >= 2 && i > hi; i -= 2) bwd_pair<LS, true>(p, lq, l_ref, i, IN, F2, S, q2p, state, c, b);
+    for (; i >= 2 && i > hi; i -= 2) bwd_pair<LS, true, MODE>(p, lq, l_ref, i, IN, F2, S, q2p, state, c, b);
 #pragma unroll 1
-    for (; i >= lo && !ae; i -= 2) bwd_pair<LS, false>(p, lq, l_ref, i, IN, F2, S, q2p, state, c, b);
+    for (; i >= lo && !ae; i -= 2) bwd_pair<LS, false, MODE>(p, lq, l_ref, i, IN, F2, S, q2p, state, c, b);
 #pragma unroll 1
-    for (; i >= 2; i -= 2) bwd_pair<LS, true>(p, lq, l_ref, i, IN, F2, S, q2p, state, c, b);
+    for (; i >= 2; i -= 2) bwd_pair<LS, true, MODE>(p, lq, l_ref, i, IN, F2, S, q2p, state, c, b);
 }
 
 // the left-hand running maximum (realn.c's extended BAQ: bq = min(left, right) inside the M operation) and the qualities' way home

@@ -751,6 +751,19 @@ int sta_fetch_col_offsets(sta_engine *e, uint64_t *host_offs, uint64_t n)
     uint64_t ncols = (uint64_t)((int64_t)e->wd.col_end - e->wd.col_beg);
     if (n > ncols + 1) return fail(e, STA_ERR_ARG, "more offsets requested than columns + 1");
     HIPCHK(hipMemcpyAsync(host_offs, e->offs.p, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream));
+    if (e->len_fused) {
+        // the tile path keeps row offsets relative to each column's measuring tile of 1 024 columns, with the tiles' bases (and, behind
+        // them, the window total) in the look-back buffer: what the header promises are offsets inside the whole window
+        const uint64_t tiles = (ncols + 1023) / 1024;
+        std::vector<uint64_t> tb((size_t)tiles + 1);
+        HIPCHK(hipMemcpyAsync(tb.data(), sta_mplp_tile_base(e->fused_status.p, ncols), (size_t)(tiles + 1) * 8, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        for (uint64_t c = 0; c < n; ++c) {
+            if (c == ncols) host_offs[c] = tb[(size_t)tiles];          // the window's total bytes
+            else host_offs[c] += tb[(size_t)(c >> 10)];
+        }
+        return STA_OK;
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
     return STA_OK;
 }

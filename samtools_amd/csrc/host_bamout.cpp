@@ -140,7 +140,7 @@ bool BamWriter::record(const Header &h, const Rec &r, const uint8_t *seq4, const
     put_u32(o, 0);                                                  // block_size, patched below
     put_u32(o, (uint32_t)r.tid); put_u32(o, (uint32_t)(int32_t)r.pos);
     o.push_back((uint8_t)(r.qname.size() + 1)); o.push_back(r.mapq);
-    put_u16(o, (uint32_t)reg2bin(r.pos < 0 ? 0 : r.pos, end < 1 ? 1 : end));
+    put_u16(o, (uint32_t)(uint16_t)reg2bin(r.pos, end));           // (an unplaced record, pos -1: hts_reg2bin(-1, 0) = 4680, by the arithmetic shifts)
     put_u16(o, long_cigar ? 2u : (uint32_t)n_cig);
     put_u16(o, r.flag);
     put_u32(o, (uint32_t)r.l_qseq);
@@ -153,7 +153,13 @@ bool BamWriter::record(const Header &h, const Rec &r, const uint8_t *seq4, const
     put_bytes(o, seq4, sb);
     if (r.l_qseq & 1) o[s0 + sb - 1] &= 0xf0;                       // the unused low nibble of an odd-length sequence is zero
     put_bytes(o, qual, (size_t)r.l_qseq);
-    for (const std::string &a : aux) if (!aux_to_bam(a, o)) return false;
+    for (const std::string &a : aux) {
+        // a field that came from a BAM record and still reads the same goes out with the bytes it came in with
+        const std::string *raw = nullptr;
+        for (const auto &pr : r.aux_bam) if (pr.first == a) { raw = &pr.second; break; }
+        if (raw) o.insert(o.end(), raw->begin(), raw->end());
+        else if (!aux_to_bam(a, o)) return false;
+    }
     if (long_cigar) {
         o.push_back('C'); o.push_back('G'); o.push_back('B'); o.push_back('I');
         put_u32(o, (uint32_t)n_cig);

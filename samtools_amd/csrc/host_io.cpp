@@ -305,7 +305,7 @@ static int parse_sam(const Header &h, std::string &line, Rec &r, const std::vect
     else { if (fl[10] != l) return -2; for (size_t i = 0; i < l; ++i) r.qual[i] = (uint8_t)(f[10][i] - 33); }
     r.has_bq = r.has_zq = false; r.bq.clear(); r.rg.clear(); r.mm.clear(); r.ml.clear(); r.has_ml = false;
     if (want) { r.tagtext.assign(want->size(), std::string()); r.tag_has.assign(want->size(), 0); }
-    r.auxv.clear(); r.zq.clear();
+    r.auxv.clear(); r.zq.clear(); r.aux_bam.clear();
     while (aux < e) {
         char *t = (char *)memchr(aux, '\t', (size_t)(e - aux));
         size_t n = t ? (size_t)(t - aux) : (size_t)(e - aux);
@@ -544,7 +544,7 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
     const bool want = !wanted.empty();
     if (want) { r.tagtext.assign(wanted.size(), std::string()); r.tag_has.assign(wanted.size(), 0); }
     const uint8_t *cg = nullptr; uint32_t cg_n = 0;          // CG:B,I: the real CIGAR of a read with more than 65535 operations
-    r.auxv.clear(); r.zq.clear();
+    r.auxv.clear(); r.zq.clear(); r.aux_bam.clear();
     int cg_field = -1;
     while (p + 3 <= e) {
         int t = p[2]; const uint8_t *tag = p; p += 3;
@@ -584,7 +584,10 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
                     else if (t == 'd') { double v; memcpy(&v, p, 8); format_kputd(v, out); }
                     else out = "*";
                 }
-        if (keep_aux) { r.auxv.emplace_back(); aux_text_from_bam(tag, p, t, r.auxv.back()); }
+        if (keep_aux) {
+            r.auxv.emplace_back(); aux_text_from_bam(tag, p, t, r.auxv.back());
+            r.aux_bam.emplace_back(r.auxv.back(), std::string((const char *)tag, 3 + vlen));
+        }
         if (t == 'Z') {
             if (tag[0] == 'R' && tag[1] == 'G') r.rg.assign((const char *)p, vlen - 1);
             else if (tag[0] == 'B' && tag[1] == 'Q') { r.has_bq = true; r.bq.assign(p, p + vlen - 1); }

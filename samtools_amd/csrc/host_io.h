@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+#include <utility>
 #include <unordered_map>
 #include <memory>
 #include <functional>
@@ -35,6 +36,10 @@ struct Rec {
     std::vector<uint8_t> zq;     // ZQ:Z bytes, kept only with set_keep_aux (calmd -r without -A turns them back into BQ:Z)
     bool zq_restore = false;     // staging: `bq` holds the ZQ:Z string to be added back to the qualities (STA_AUX_ZQ_RESTORE)
     std::vector<std::string> auxv;   // with set_keep_aux: every aux field as sam_format1 prints it ("NM:i:3"), in record order
+    // with set_keep_aux, BAM input only: (text, raw BAM bytes) of every aux field as it was read.  The BAM writer copies the raw
+    // bytes of a field whose text it is handed unchanged (sam_write1 on the same bam1_t keeps untouched aux bytes: floats at full
+    // precision, integer widths as they were); only fields a command rewrote are encoded from text.  Empty for SAM input.
+    std::vector<std::pair<std::string, std::string>> aux_bam;
     bool has_bq = false, has_zq = false;
     std::string rg;              // RG:Z value ("" if absent)
     std::string mm;              // MM:Z / Mm:Z base-modification list ("" if absent) and its ML / Ml probabilities (--output-mods)

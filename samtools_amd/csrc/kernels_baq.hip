@@ -944,6 +944,7 @@ __device__ __forceinline__ Baq7sRead baq7s_read(const StaReadsDev &R, const StaW
 }
 
 // two waves per SIMD: the backward pass holds 120 doubles of band state (256 VGPRs; 168 would spill 230 of them)
+template <int MODE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_baq7s(StaReadsDev R, StaWinDev W, BaqTables T, int64_t ngroups, unsigned *next,
                                               uint8_t *scratch, size_t slot_bytes, int lq_cap, int lead_mask)
 {
@@ -975,7 +976,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     p.m6 = baq_uni(p.m6); p.m8 = baq_uni(p.m8); p.sM = baq_uni(p.sM); p.sI = baq_uni(p.sI); p.bM = baq_uni(p.bM); p.bI = baq_uni(p.bI);
                     const bool amb = baq7s::pack_lane<64>(lq, lq + 6, d.qual, d.seq, W.ref + d.sh.xb, refc, sl.IN);
                     all_edge = baq7s::wave_any(amb);
-                    baq7s::fwd_lane<64>(p, lq, all_edge, sl.IN, sl.F2, sl.S, q2p);
+                    baq7s::fwd_lane<64, MODE>(p, lq, all_edge, sl.IN, sl.F2, sl.S, q2p);
                 }
                 all_edge = __ballot(all_edge) != 0;
                 const int64_t tag = g | ((int64_t)cur << 62) | ((int64_t)(all_edge ? 1 : 0) << 61);
@@ -1001,7 +1002,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 p.m6 = baq_uni(p.m6); p.m8 = baq_uni(p.m8); p.sM = baq_uni(p.sM); p.sI = baq_uni(p.sI);
                 p.eim1 = baq_uni(p.eim1); p.eim4 = baq_uni(p.eim4);
                 baq7s::BwdCtx c; c.ys = d.sh.ys; c.mlen = d.sh.mlen; c.run_r = 0; c.plain = W.baq_plain != 0;
-                baq7s::bwd_lane<64>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, q2p, state, c);
+                baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, q2p, state, c);
                 baq7s::final_lane<64>(lq, sl.IN, state, c, d.qual);
             }
         } else if (!have) break;
@@ -1017,7 +1018,7 @@ size_t sta_baq7s_scratch_bytes(int lq_cap, int64_t ngroups, int *waves_out)
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         const int rows = (256 + 3) & ~3;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_baq7s, 64, (size_t)rows * 64) != hipSuccess || per < 1) { (void)hipGetLastError(); per = 8; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_baq7s<0>, 64, (size_t)rows * 64) != hipSuccess || per < 1) { (void)hipGetLastError(); per = 8; }
         const char *e = getenv("STA_BAQ7S_WAVES_PER_CU");
         if (e && atoi(e) > 0 && atoi(e) < per) per = atoi(e);
         g_baq7s_waves = cus * per;
@@ -1040,6 +1041,10 @@ void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, v
     static const int lead = [] { const char *e = getenv("STA_BAQ7S_LEAD"); return e ? atoi(e) : 1; }();   // 0: every wave forward-then-backward; 1: odd waves one forward pass ahead
     hipMemsetAsync(scratch, 0, 256, s);
     const int rows = (lq_cap + 3) & ~3;
-    hipLaunchKernelGGL(k_baq7s, dim3((unsigned)waves), dim3(64), (size_t)rows * 64, s, r, w, g_tables, ngroups, (unsigned *)scratch,
-                       (uint8_t *)scratch + 256, baq7s_slot_bytes(lq_cap), lq_cap, lead);
+    // STA_BAQ7S_MODE: 0 non-temporal row stream (default), 1 plain loads / stores; 2, 3: diagnostics with wrong results (baq_band7s.h)
+    static const int mode = [] { const char *e = getenv("STA_BAQ7S_MODE"); return e ? atoi(e) : 0; }();
+#define BAQ7S_LAUNCH(M) hipLaunchKernelGGL(k_baq7s<M>, dim3((unsigned)waves), dim3(64), (size_t)rows * 64, s, r, w, g_tables, ngroups, (unsigned *)scratch, \
+                                           (uint8_t *)scratch + 256, baq7s_slot_bytes(lq_cap), lq_cap, lead)
+    if (mode == 1) BAQ7S_LAUNCH(1); else if (mode == 2) BAQ7S_LAUNCH(2); else if (mode == 3) BAQ7S_LAUNCH(3); else BAQ7S_LAUNCH(0);
+#undef BAQ7S_LAUNCH
 }

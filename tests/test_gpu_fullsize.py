@@ -150,3 +150,19 @@ def test_mpileup_baq_idempotent_and_monotone_at_bench_size(big):
     assert len(c_b) == len(c_1)
     assert np.all(c_1 <= c_b)                                          # BAQ only lowers base qualities
     assert int(c_1.sum()) < int(c_b.sum())
+
+
+def test_col_offsets_are_window_offsets_of_the_emitted_rows(big):
+    """sta_fetch_col_offsets after a text plan: offsets inside the WHOLE window's text (include/samtools_amd.h), also on the tile
+    path, whose device-side offsets restart every 1 024 columns: the offsets must be the row starts of the text."""
+    info, text = _mpileup_text(big, realn=False)
+    eng = big["eng"]
+    offs = np.array(eng.fetch_col_offsets(N_COLS + 1), dtype=np.int64)
+    assert offs[0] == 0 and int(offs[-1]) == len(text) == int(info.out_bytes)
+    assert np.all(np.diff(offs) >= 0)
+    nl = np.flatnonzero(np.frombuffer(text, dtype=np.uint8) == 10)
+    starts = np.concatenate(([0], nl[:-1] + 1))
+    cov = _numpy_depth(big["rd"], N_COLS) > 0                          # without -a a row exists only for covered columns
+    assert len(starts) == int(cov.sum())
+    assert np.array_equal(offs[:-1][cov], starts)
+    assert np.array_equal(np.diff(offs)[~cov], np.zeros(int((~cov).sum()), dtype=np.int64))

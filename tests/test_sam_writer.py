@@ -155,3 +155,32 @@ def test_bam_writer_round_trips_every_aux_type_and_long_inputs(oracle_bin, tmp_p
         bs = struct.unpack("<i", raw[p:p + 4])[0]
         assert not any(p < e < p + 4 + bs for e in edges)
         p += 4 + bs
+
+
+def test_bam_to_bam_keeps_untouched_aux_bytes(tmp_path):
+    """a BAM -> BAM run must hand untouched aux fields on byte for byte (sam_write1 on the same bam1_t does,
+    bam_md.c:386-395): floats / doubles at full precision (not through kputd's six digits), B:f arrays, integers in the width
+    they came in (an `i`-typed 3 stays four bytes)."""
+    import gzip
+    import struct
+    from samtools_amd import _capi
+    import bamio
+    hdr = ["@HD\tVN:1.6\tSO:coordinate", "@SQ\tSN:c1\tLN:1000"]
+    head = bamio.bam_header_bytes(hdr, ["c1"], [1000])
+    aux = (b"XFf" + struct.pack("<f", 1.2345678806304932) + b"XDd" + struct.pack("<d", 3.141592653589793)
+           + b"XIi" + struct.pack("<i", 3) + b"XSs" + struct.pack("<h", 7) + b"XBBf" + struct.pack("<I", 3) + struct.pack("<3f", 0.1, 1e-7, 123456.789)
+           + b"XZZhello\0" + b"XCC" + struct.pack("<B", 200))
+    qname = b"r1\0"; seq = bytes([0x12, 0x48]); qual = bytes([30, 31, 32, 33])
+    core = struct.pack("<iiBBHHHIiii", 0, 99, len(qname), 60, 4681, 1, 0, 4, -1, -1, 0)
+    body = core + qname + struct.pack("<I", (4 << 4) | 0) + seq + qual + aux
+    rec = struct.pack("<I", len(body)) + body
+    src = str(tmp_path / "in.bam"); out = str(tmp_path / "out.bam")
+    open(src, "wb").write(bamio.bgzf_compress(head + rec, 1))
+    _capi.io_write_bam(src, out, 6)
+    raw = gzip.open(out).read()
+    assert raw[len(head):].endswith(aux), (raw[len(head):], aux)
+    # and the text route still prints them as sam_format1 does
+    sam = str(tmp_path / "out.sam")
+    _capi.io_write_sam(src, sam)
+    line = [l for l in open(sam).read().split("\n") if l.startswith("r1")][0]
+    assert "XF:f:1.23457" in line and "XI:i:3" in line and "XB:B:f,0.1,1e-07,123457" in line

@@ -40,17 +40,18 @@ def _pile_bpb(depth):
     return 3.69 + 18.0 / depth
 
 
-def _wl(kind, depth, cols, argv, baq=False, bpb=None, gen=None, flags_on=0, flags_off=0, max_depth=None):
+def _wl(kind, depth, cols, argv, baq=False, bpb=None, gen=None, flags_on=0, flags_off=0, max_depth=None, files=1, n_tags=0):
     """one workload: kind, depth, default window columns per GPU, CLI form (what the oracle runs), generator options,
     sta_mplp_params deltas.  bpb = algorithmic bytes per piled base of the WHOLE step (pileup text path + ~1 B/base of reference
     window when BAQ runs); bpb_pileup = the text path alone (what the emit kernel is priced with)."""
     pile = _pile_bpb(depth)
     return {"kind": kind, "depth": depth, "cols": cols, "argv": argv, "baq": baq, "bpb": bpb if bpb is not None else pile + (1.0 if baq else 0.0),
             "bpb_pileup": pile if kind == "mpileup" else (bpb if bpb is not None else pile), "gen": gen or {}, "flags_on": flags_on, "flags_off": flags_off,
-            "max_depth": max_depth}
+            "max_depth": max_depth, "files": files, "n_tags": n_tags}
 
 
 _REALN, _REDO_BAQ, _NO_ORPHAN = 1 << 4, 1 << 6, 1 << 3      # STA_MPLP_* (include/samtools_amd.h)
+_PRINT_MAPQ_CHAR, _PRINT_QPOS, _PRINT_QNAME = 1 << 11, 1 << 12, 1 << 13
 WORKLOADS = {
     # BASELINE.json configs[2] (the metric's configuration): mpileup -f, BAQ on, 30x 150 bp
     "mpileup30": _wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True),
@@ -71,6 +72,13 @@ WORKLOADS = {
     "mpileup30_B_hotspot": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-d", "100000", "-f", "{fa}", "{sam}"], gen={"hotspot": (300, 10000)}, flags_off=_REALN, max_depth=100000),
     # BAQ with a real indel spectrum: 5 % of the reads carry a 1-3 bp insertion or deletion (band-8 / general-band kernels under load)
     "mpileup30_indel": _wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True, gen={"indel_rate": 0.05}),
+    # three input files, 10x each (the shape of test/dat/mpileup.out.1): the per-file column groups of bam_plcmd.c:669-857 at bench size
+    "mpileup30_3files": _wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True, files=3),
+    "mpileup30_B_3files": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN, files=3),
+    # the generic column walkers (k_mplp_len / k_mplp_emit): -s -O and --output-extra columns (bam_plcmd.c:727-855); the generated
+    # reads carry no NM tag: that column is "*"
+    "mpileup30_B_sOx": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-s", "-O", "--output-extra", "QNAME,NM", "-f", "{fa}", "{sam}"],
+                           flags_on=_PRINT_MAPQ_CHAR | _PRINT_QPOS | _PRINT_QNAME, flags_off=_REALN, n_tags=1),
     # configs[1]
     "depth30": _wl("depth", 30, 8 << 20, ["depth", "-a", "{sam}"], bpb=0.21),
     # rows widened into after the pileup path; single GPU, results stay on the device
@@ -132,19 +140,31 @@ def upload_reads(torch, np, sa, rd, dev, keep):
     return reads
 
 
-def build_window(torch, np, sa, rd, n_cols, dev, origin=0, col_beg=0, col_end=None, tlen=None):
+def build_window(torch, np, sa, rd, n_cols, dev, origin=0, col_beg=0, col_end=None, tlen=None, star_tags=0):
+    """rd: one generated read set, or a list of them (one per input file).  star_tags: every read gets that many "*" text columns
+    (aux-tag columns of --output-extra for reads that carry no such tag)."""
+    rds = rd if isinstance(rd, (list, tuple)) else [rd]
     keep = []
-    reads = upload_reads(torch, np, sa, rd, dev, keep)
-    files = (sa.Reads * 1)(reads)
+    files = (sa.Reads * len(rds))(*[upload_reads(torch, np, sa, r, dev, keep) for r in rds])
+    if star_tags:
+        for f, r in enumerate(rds):
+            n = int(r["n"]) * star_tags
+            xo = torch.arange(n + 1, dtype=torch.int32, device=dev); xt = torch.full((n + 1,), ord("*"), dtype=torch.uint8, device=dev)
+            keep += [xo, xt]
+            files[f].n_xcols = star_tags; files[f].xcol_off = xo.data_ptr(); files[f].xcol_text = xt.data_ptr(); files[f].n_xcol_bytes = n
     w = sa.Window()
     w.tid = 0; w.origin = origin; w.col_beg = col_beg; w.col_end = n_cols if col_end is None else col_end
     w.tname = b"chrS"; w.tlen = n_cols if tlen is None else tlen
-    w.n_files = 1; w.files = files; w.mem = 1
+    w.n_files = len(rds); w.files = files; w.mem = 1
     w.has_bed = 0; w.has_reg = 0
     keep.append(files)
-    in_bytes = sum(int(rd[f].nbytes) for f in ("pos", "flag", "mapq", "aux", "l_qseq", "cig_off", "base_off8", "mtid",
-                                                 "mpos", "isize", "name_off", "cigar", "seq", "qual")) + (w.col_end - w.col_beg)
+    in_bytes = sum(int(r[f].nbytes) for r in rds for f in ("pos", "flag", "mapq", "aux", "l_qseq", "cig_off", "base_off8", "mtid",
+                                                          "mpos", "isize", "name_off", "cigar", "seq", "qual")) + (w.col_end - w.col_beg)
     return w, keep, in_bytes
+
+
+def n_reads_of(rd):
+    return sum(int(r["n"]) for r in rd) if isinstance(rd, (list, tuple)) else int(rd["n"])
 
 
 def slice_reads(np, rd, lo, hi, origin):
@@ -179,7 +199,10 @@ def oracle_text_hash(wl, n_cols, seed_ref=1, seed_reads=42, save_to=None, inputs
         inputs = synth_inputs(wl, n_cols, seed_ref, seed_reads, chunk_cols)
     try:
         rd = inputs["rd"]
-        args = [a.format(sam=inputs["sam"], fa=inputs["fa"]) for a in argv]
+        args = []
+        for a_ in argv:
+            if a_ == "{sam}": args += list(inputs["sams"])
+            else: args.append(a_.format(fa=inputs["fa"]))
         h = hashlib.sha256()
         n = 0
         t0 = time.perf_counter()
@@ -196,7 +219,7 @@ def oracle_text_hash(wl, n_cols, seed_ref=1, seed_reads=42, save_to=None, inputs
             if p.wait() != 0:
                 raise RuntimeError("oracle failed on the %s sample" % wl)
         dt = time.perf_counter() - t0
-        return {"sha256": h.hexdigest(), "bytes": n, "seconds": dt, "n_reads": int(rd["n"]), "bases": int(rd["n"]) * 150,
+        return {"sha256": h.hexdigest(), "bytes": n, "seconds": dt, "n_reads": n_reads_of(rd), "bases": n_reads_of(rd) * 150,
                 "argv": " ".join(x for x in argv if x != "{sam}").replace("{fa}", "ref.fa"), "ref": inputs["ref"], "rd": rd}
     finally:
         if own:
@@ -214,6 +237,10 @@ def make_reads(wl, ref, chunk_cols, seed_reads=42, chunks=None):
         rd["_abs_pos"] = rd["_abs_pos"].copy()
         return rd
     kw = {"indel_rate": g["indel_rate"]} if "indel_rate" in g else {}
+    if spec["files"] > 1:
+        # one read set per input file, depth / files each, its own seed (single-GPU workloads)
+        return [synth_chunked(ref, chunk_cols, depth=spec["depth"] // spec["files"], read_len=150, seed=seed_reads + 1000 * k, chunks=chunks, **kw)
+                for k in range(spec["files"])]
     rd = synth_chunked(ref, chunk_cols, depth=spec["depth"], read_len=150, seed=seed_reads, chunks=chunks, **kw)
     if g.get("hotspot"):
         hl, hd = g["hotspot"]
@@ -228,10 +255,13 @@ def synth_inputs(wl, n_cols, seed_ref=1, seed_reads=42, chunk_cols=None):
     ref = synth_ref(n_cols, seed=seed_ref)
     rd = make_reads(wl, ref, chunk_cols or n_cols, seed_reads)
     d = tempfile.mkdtemp(prefix="sta_bench_")
-    sam, fa = os.path.join(d, "s.sam"), os.path.join(d, "s.fa")
-    write_sam(sam, rd, "chrS", n_cols)
+    fa = os.path.join(d, "s.fa")
+    sams = []
+    for k, r in enumerate(rd if isinstance(rd, list) else [rd]):
+        sams.append(os.path.join(d, "s%d.sam" % k if k else "s.sam"))
+        write_sam(sams[-1], r, "chrS", n_cols)
     write_fasta(fa, "chrS", ref)
-    return {"ref": ref, "rd": rd, "sam": sam, "fa": fa, "dir": d}
+    return {"ref": ref, "rd": rd, "sam": sams[0], "sams": sams, "fa": fa, "dir": d}
 
 
 def collect_pmc(a, wlname, kernels):
@@ -356,7 +386,7 @@ def run_workload(a, wlname, ctx, secondary=False):
 
     spec = WORKLOADS[wlname]
     kind, depth, def_cols, alg_bpb = spec["kind"], spec["depth"], spec["cols"], spec["bpb"]
-    if world > 1 and (spec["gen"].get("paired") or spec["gen"].get("hotspot")):
+    if world > 1 and (spec["gen"].get("paired") or spec["gen"].get("hotspot") or spec["files"] > 1):
         raise SystemExit("workload %s is a single-GPU measurement (its generator is not built piecewise)" % wlname)
     cols_per_gpu = a.cols or def_cols
     n_cols = cols_per_gpu * world
@@ -379,13 +409,15 @@ def run_workload(a, wlname, ctx, secondary=False):
         eng = ctx["eng"] = sa.Engine(local, stream)
     ref_t = torch.from_numpy(ref.copy()).to(dev)
     eng.set_reference(0, ref_t.data_ptr(), n_cols, 1)
-    w, keep, in_bytes = build_window(torch, np, sa, rd, n_cols, dev, origin=origin, col_beg=blk_beg - origin, col_end=blk_end - origin, tlen=n_cols)
+    w, keep, in_bytes = build_window(torch, np, sa, rd, n_cols, dev, origin=origin, col_beg=blk_beg - origin, col_end=blk_end - origin, tlen=n_cols,
+                                     star_tags=spec["n_tags"])
     if kind == "mpileup":
         par = sa.MplpParams.defaults()
         par.has_fai = 1
         par.flag = (par.flag | spec["flags_on"]) & ~spec["flags_off"]
         if spec["max_depth"]:
             par.max_depth = spec["max_depth"]
+        par.n_tags = spec["n_tags"]
     elif kind == "depth":
         par = sa.DepthParams.defaults()
         par.all_pos = 1
@@ -420,7 +452,7 @@ def run_workload(a, wlname, ctx, secondary=False):
 
     info = plan()
     out_bytes = int(info.out_bytes)
-    piled = int(info.piled_bases) or int(rd["n"]) * 150      # (the calmd plan reports no pileup counters: every base is aligned)
+    piled = int(info.piled_bases) or n_reads_of(rd) * 150      # (the calmd plan reports no pileup counters: every base is aligned)
     # (piled_bases counts only the columns this rank owns: k_prep_reads clips every read to [col_beg, col_end))
     sizes = None
     cap = out_bytes + 4096
@@ -596,7 +628,7 @@ def run_workload(a, wlname, ctx, secondary=False):
             "vs_baseline": None, "dtype": "u8/f64" if (spec["baq"] or kind in ("glf", "calmd") or wlname == "consensus30") else "u8",
             "data": "synthetic",
             "config": {"workload": wlname, "command": " ".join(x for x in spec["argv"] if x != "{sam}").replace("{fa}", "ref.fa"),
-                       "read_len": 150, "depth": depth, "window_cols_per_gpu": cols_per_gpu, "input_cols": n_cols, "reads_per_gpu": int(rd["n"]),
+                       "read_len": 150, "depth": depth, "window_cols_per_gpu": cols_per_gpu, "input_cols": n_cols, "reads_per_gpu": n_reads_of(rd), "input_files": spec["files"],
                        "piled_bases_per_gpu_step": piled, "out_bytes_per_gpu_step": out_bytes,
                        "staged_in_bytes_per_gpu": in_bytes,
                        "parallelism": "one sorted input, reference columns sharded x%d (+ mate halo), 1 variable-size RCCL gather" % world},
@@ -643,7 +675,7 @@ def run_workload(a, wlname, ctx, secondary=False):
                     # the same sample through the engine: byte parity of every default bench run (the oracle is only the checker)
                     ref_s = torch.from_numpy(o["ref"].copy()).to(dev)
                     eng.set_reference(0, ref_s.data_ptr(), sample, 1)
-                    ws, keep_s, _ = build_window(torch, np, sa, o["rd"], sample, dev)
+                    ws, keep_s, _ = build_window(torch, np, sa, o["rd"], sample, dev, star_tags=spec["n_tags"])
                     eng.stage_window(ws)
                     inf = eng.mpileup_plan(par) if kind == "mpileup" else eng.depth_plan(par)
                     (eng.mpileup_emit if kind == "mpileup" else eng.depth_emit)()

@@ -170,13 +170,13 @@ BQS_HD void fwd_step(const Par &p, int lq, int i, const uint32_t *IN, d2 *F2, do
     f.rw = (f.rw >> 3) | ((uint64_t)((w >> 11) & 7u) << (3 * (NB - 1)));
     const Emis em = make_emis(w, f.rw, q2p);
     const double sum = fwd_row<EDGE>(p, em, f.rw, f.M, f.I, f.D);
-    S[(size_t)i * LS] = sum;
     if (i & 1) {                          // raw (M, I) of an odd row; even rows are not stored
         const size_t t = (size_t)((i - 1) >> 1) * NB;
 #pragma unroll
         for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(&F2[(t + j) * LS], v); }
     }
     const double inv = 1. / sum;
+    S[(size_t)i * LS] = i < lq ? inv : sum;      // rows below the top: 1 / s[i], the value the backward pass multiplies by (no division there)
 #pragma unroll
     for (int j = 0; j < NB; ++j) { f.M[j] *= inv; f.I[j] *= inv; f.D[j] *= inv; }
 }
@@ -207,7 +207,7 @@ BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2
             f.M[j] = a; f.I[j] = b2; f.D[j] = 0.;
             sum += a + b2;
         }
-        S[(size_t)1 * LS] = sum;
+        S[(size_t)1 * LS] = 1. / sum;             // (row 1 itself is normalised by divisions; the backward step to row 1 multiplies by 1 / s[1])
 #pragma unroll
         for (int j = 0; j < NB; ++j) { f.M[j] /= sum; f.I[j] /= sum; }
 #pragma unroll
@@ -365,9 +365,9 @@ BQS_HD void bwd_pair(const Par &p, int lq, int l_ref, int i, uint32_t *IN, const
     if (!EDGE || i < lq - 1) rw1 = ((b.rw << 3) | (uint64_t)((b.w_up >> 14) & 7u)) & WORD_MASK;
     uint64_t rw0 = rw1;
     if (!EDGE || i < lq) rw0 = ((rw1 << 3) | (uint64_t)((w_i >> 14) & 7u)) & WORD_MASK;
-    const double inv_i = 1. / s_i;
+    const double inv_i = (EDGE && i >= lq) ? 1. / s_i : s_i;       // S[] holds 1 / s[row] below the top row, s[lq] itself for the top row
     const bool row1 = EDGE && i == 2;           // row 1 is stored normalised and has no D state
-    const double inv_s = 1. / s_o;              // the backward step to row i - 1 divides by s[i - 1] whatever the row
+    const double inv_s = s_o;                   // the backward step to row i - 1 multiplies by 1 / s[i - 1] whatever the row
     const double inv_o = row1 ? 1. : inv_s;
     const Emis em0 = make_emis(w_i, rw0, q2p);
     if (!EDGE || i < lq) { const Emis em1 = make_emis(b.w_up, rw1, q2p); bwd_apply<EDGE>(p, em1, rw1, i, inv_i, b.bM, b.bI); }

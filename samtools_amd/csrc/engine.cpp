@@ -55,8 +55,8 @@ struct ProfPending { std::string name; hipEvent_t a, b; };
 struct sta_engine {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;        // second stream: the few band-8 BAQ groups run beside the band-7 kernels
-    hipEvent_t side_done = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr;   // side streams: the list's BAQ groups (band width 8 / band width 7) run beside the main BAQ kernel
+    hipEvent_t side_done = nullptr, side2_done = nullptr;
     std::string err;
     std::map<int32_t, RefSeq> refs;
     // current window
@@ -195,6 +195,8 @@ void sta_engine_destroy(sta_engine *e)
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
     if (e->side_done) hipEventDestroy(e->side_done);
+    if (e->side2) hipStreamDestroy(e->side2);
+    if (e->side2_done) hipEventDestroy(e->side2_done);
     for (auto &p : e->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     delete e;
@@ -433,38 +435,48 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                 bool side = has_main && groupsL > 0 && groupsL <= 4096 && !getenv("STA_BAQ_NO_SIDE_STREAM");
                 char *side_scratch = nullptr;
                 if (side) {
-                    size_t extra = (size_t)groupsL * slot_bytes;
+                    // (one region per list class: the two run at the same time, and their slot layouts differ)
+                    size_t extra = (size_t)groupsL * slot_bytes * 2;
                     if (e->baq_scratch2.ensure(extra + 64)) { (void)hipGetLastError(); side = false; }
                     else side_scratch = (char *)e->baq_scratch2.p;
                     if (side && !e->side) {
-                        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->side_done, hipEventDisableTiming) != hipSuccess) {
+                        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->side_done, hipEventDisableTiming) != hipSuccess
+                            || hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->side2_done, hipEventDisableTiming) != hipSuccess) {
                             (void)hipGetLastError(); side = false;
                         }
                     }
                 }
                 // classes: 2 = band width 8 through the list, 1 = band width 7 through the list, 0 = band width 7 in place (round-3
-                // kernels, only with STA_BAQ_CLASS_S=0), then class S
+                // kernels, only with STA_BAQ_CLASS_S=0), then class S.  On the side streams a list class is ONE launch (both passes):
+                // its waves are placed before the persistent class-S kernel fills the chip and run to the end beside it.
                 for (int cls = 2; cls >= 0; --cls) {
                     int64_t items = cls == 0 ? (c.n_baq_fast ? d.n : 0) : cls == 1 ? (c.n_baq_bw7l ? (int64_t)n_list : 0) : (c.n_baq_bw8 ? (int64_t)n_list : 0);
                     int64_t ngroups = (items + 63) / 64;
                     const bool on_side = side && cls != 0;
-                    hipStream_t st = on_side ? e->side : s;
-                    int64_t step = on_side ? ngroups : gpl;
                     static const char *const names[3][2] = { { "baq_fwd", "baq_bwd" }, { "baq7l_fwd", "baq7l_bwd" }, { "baq8_fwd", "baq8_bwd" } };
+                    if (on_side) {
+                        hipStream_t st = cls == 2 ? e->side : e->side2;
+                        if (ngroups) {
+                            ProfScope ps(e, cls == 2 ? "baq8_list" : "baq7_list", st, true);
+                            sta_launch_baq_list(st, d, e->wd, side_scratch + (cls == 2 ? 0 : (size_t)groupsL * slot_bytes), (int)c.max_lq_fast, cls == 2 ? 8 : 7, ngroups);
+                        }
+                        HIPCHK(hipEventRecord(cls == 2 ? e->side_done : e->side2_done, st));
+                        continue;
+                    }
+                    int64_t step = gpl;
                     for (int64_t g0 = 0; g0 < ngroups; g0 += step) {
                         int64_t ng = ngroups - g0 < step ? ngroups - g0 : step;
                         for (int pass = 0; pass < 2; ++pass) {
-                            ProfScope ps(e, names[cls][pass], st, true);
-                            sta_launch_baq_band(st, d, e->wd, on_side ? (void *)side_scratch : e->baq_scratch.p, (int)c.max_lq_fast, cls == 2 ? 8 : 7, g0, ng, cls != 0, pass);
+                            ProfScope ps(e, names[cls][pass], s, true);
+                            sta_launch_baq_band(s, d, e->wd, e->baq_scratch.p, (int)c.max_lq_fast, cls == 2 ? 8 : 7, g0, ng, cls != 0, pass);
                         }
                     }
-                    if (on_side && cls == 1) HIPCHK(hipEventRecord(e->side_done, e->side));
                 }
                 if (c.n_baq_s) {
                     ProfScope ps(e, "baq_s");
                     sta_launch_baq7s(s, d, e->wd, e->baq_scratch.p, (int)c.max_lq_s, s_waves);
                 }
-                if (side) HIPCHK(hipStreamWaitEvent(s, e->side_done, 0));
+                if (side) { HIPCHK(hipStreamWaitEvent(s, e->side_done, 0)); HIPCHK(hipStreamWaitEvent(s, e->side2_done, 0)); }
             }
             if (c.n_baq_general && n_list) {
                 size_t need = sta_baq_scratch_bytes(d.n, (int)c.max_lq, (int)c.max_bw);

@@ -392,15 +392,10 @@ template <int NB, int DEC> __host__ __device__ constexpr size_t baq_rows_lr(int 
 #define BAQ_LDS_ROWS_MAX 256          // per-row state bytes live in LDS up to this read length (16 KB per wave)
 
 template <int BW, int DEC>
-__global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
-                                                 double *scratch, size_t slot_dbl, int lq_cap)
+__device__ __forceinline__ void baq_fwd_body(const StaReadsDev &R, const StaWinDev &W, const float *q2p, const uint8_t *refc, int64_t g0, int64_t ngroups, int use_list,
+                                             double *scratch, size_t slot_dbl, int lq_cap)
 {
     constexpr int NB = 2 * BW + 1;
-    __shared__ float q2p[256];
-    __shared__ uint8_t refc[256];
-    q2p[threadIdx.x] = T.q2p[threadIdx.x];
-    refc[threadIdx.x] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)threadIdx.x));
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int64_t gl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // group within this launch == scratch slot
     if (gl >= ngroups) return;
@@ -505,6 +500,21 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
     }
 }
 
+// the tables both passes look things up in: q2p = g_qual2prob, refc = reference character -> code 0..3 / 4
+#define BAQ_TABLES_INIT()                                                                                                   \
+    __shared__ float q2p[256];                                                                                              \
+    __shared__ uint8_t refc[256];                                                                                           \
+    for (int k_ = threadIdx.x; k_ < 256; k_ += blockDim.x) { q2p[k_] = T.q2p[k_]; refc[k_] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)k_)); } \
+    __syncthreads();
+
+template <int BW, int DEC>
+__global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
+                                                 double *scratch, size_t slot_dbl, int lq_cap)
+{
+    BAQ_TABLES_INIT()
+    baq_fwd_body<BW, DEC>(R, W, q2p, refc, g0, ngroups, use_list, scratch, slot_dbl, lq_cap);
+}
+
 // ---- backward + MAP + apply ----
 // Per-lane CIGAR cursor walking the query backwards: which operation covers query index q, and where it starts (realn.c's block
 // walk, evaluated on the fly so that the per-row MAP state never leaves the wave).
@@ -525,16 +535,10 @@ __device__ __forceinline__ void baq_cur_seek(BaqCur &cu, const uint32_t *cigar, 
 }
 
 template <int BW, int DEC, bool PLDS>
-__global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
-                                                    double *scratch, size_t slot_dbl, int lq_cap, int lds_rows)
+__device__ __forceinline__ void baq_bwd_body(const StaReadsDev &R, const StaWinDev &W, const float *q2p, const uint8_t *refc, uint8_t *baq_state, int64_t g0, int64_t ngroups,
+                                             int use_list, double *scratch, size_t slot_dbl, int lq_cap, int lds_rows)
 {
     constexpr int NB = 2 * BW + 1;
-    extern __shared__ __attribute__((aligned(16))) uint8_t baq_state[];        // PLDS: [wave][row][lane], one byte per row and read
-    __shared__ float q2p[256];
-    __shared__ uint8_t refc[256];
-    q2p[threadIdx.x] = T.q2p[threadIdx.x];
-    refc[threadIdx.x] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)threadIdx.x));
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int64_t gl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gl >= ngroups) return;
@@ -828,6 +832,27 @@ __global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, 
     }
 }
 
+template <int BW, int DEC, bool PLDS>
+__global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, BaqTables T, int64_t g0, int64_t ngroups, int use_list,
+                                                    double *scratch, size_t slot_dbl, int lq_cap, int lds_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t baq_state[];        // PLDS: [wave][row][lane], one byte per row and read
+    BAQ_TABLES_INIT()
+    baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, baq_state, g0, ngroups, use_list, scratch, slot_dbl, lq_cap, lds_rows);
+}
+
+// Both passes of one group in one launch, for the reads that go through the list (a few dozen waves, latency bound): once its waves
+// are placed they run to the end beside the persistent class-S kernel, instead of the second pass queueing behind it for a free slot.
+// A wave's own forward rows are visible to its backward pass in program order; nothing is shared between waves.
+template <int BW, int DEC, bool PLDS>
+__global__ void __launch_bounds__(256, 2) k_baq_list(StaReadsDev R, StaWinDev W, BaqTables T, int64_t ngroups, double *scratch, size_t slot_dbl, int lq_cap, int lds_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t baq_state[];
+    BAQ_TABLES_INIT()
+    baq_fwd_body<BW, DEC>(R, W, q2p, refc, 0, ngroups, 1, scratch, slot_dbl, lq_cap);
+    baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, baq_state, 0, ngroups, 1, scratch, slot_dbl, lq_cap, lds_rows);
+}
+
 template <int NB, int DEC>
 static size_t baq_slot_dbl_t(int lq_cap)
 {
@@ -882,6 +907,27 @@ static void run_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, vo
         hipLaunchKernelGGL((k_baq_bwd<BW, DEC, true>), dim3(nb), dim3(256), (size_t)4 * rows * 64, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap, rows);
     } else
         hipLaunchKernelGGL((k_baq_bwd<BW, DEC, false>), dim3(nb), dim3(256), 0, s, r, w, g_tables, g0, ng, use_list, (double *)scratch, slot, lq_cap, 0);
+}
+
+// both passes of the list's band-width-bw reads (ng groups of 64 list entries) in one launch, blocks of one wave
+void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw, int64_t ng)
+{
+    if (!g_tables_init) {
+        for (int i = 0; i < 256; ++i) g_tables.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
+        g_tables_init = true;
+    }
+    if (r.n == 0 || lq_cap <= 0 || ng <= 0) return;
+    const size_t slot = std::max(baq_slot_dbl(lq_cap, 8), baq_slot_dbl(lq_cap, 7));
+    const unsigned nb = (unsigned)((ng + 3) / 4);
+    const bool plds = lq_cap <= BAQ_LDS_ROWS_MAX;
+    const int rows = plds ? (lq_cap + 3) & ~3 : 0;
+    const size_t lds = plds ? (size_t)4 * rows * 64 : 0;
+#define BAQ_LIST_LAUNCH(BW_, DEC_, P_) hipLaunchKernelGGL((k_baq_list<BW_, DEC_, P_>), dim3(nb), dim3(256), lds, s, r, w, g_tables, ng, (double *)scratch, slot, lq_cap, rows)
+    if (bw == 7) {
+        if (baq_dec_mode() == 2) { if (plds) BAQ_LIST_LAUNCH(7, 2, true); else BAQ_LIST_LAUNCH(7, 2, false); }
+        else { if (plds) BAQ_LIST_LAUNCH(7, 1, true); else BAQ_LIST_LAUNCH(7, 1, false); }
+    } else if (bw == 8) { if (plds) BAQ_LIST_LAUNCH(8, 0, true); else BAQ_LIST_LAUNCH(8, 0, false); }
+#undef BAQ_LIST_LAUNCH
 }
 
 // One pass (0 = forward, 1 = backward + MAP + apply) over groups [g0, g0 + ng) of 64 reads; the engine calls the two passes

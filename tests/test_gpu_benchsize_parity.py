@@ -8,6 +8,8 @@ C-ABI) and the sha256 of its text must equal the oracle's for the same reads:
   * (round 3) mpileup100[_B] 1 048 576 columns x 100; mpileup30_EA_pairs = BASELINE.json configs[4] (`-E -A`, proper pairs, mate
     overlaps under load) and its -B form; mpileup30[_B]_hotspot (30x + one 10 000x amplicon of 300 bp: the per-wave deep / fast
     emit choice); mpileup30_indel (5 % of the reads with an indel: band-8 and general-band BAQ under load)
+  * (round 4) mpileup30[_B]_3files: three inputs of 10x each (the dat/mpileup.out.1 shape: per-file column groups, bam_plcmd.c:669-857);
+    mpileup30_B_sOx: `-s -O --output-extra QNAME,NM` through the generic walkers k_mplp_len / k_mplp_emit (bam_plcmd.c:727-855)
   * engine paths that only an environment variable reaches: chunked BAQ slab (STA_BAQ_SLAB_GIB=1), no side stream
     for the band-8 groups (STA_BAQ_NO_SIDE_STREAM=1), at 786 432 columns
   * BASELINE.json configs[0]: examples/ex1.sam.gz (headerless, @SQ from the FASTA) + ex1.fa, SAM and BAM input.
@@ -34,7 +36,7 @@ def _shape(wl, n_cols):
     import shutil
     import bench
     spec = bench.WORKLOADS[wl]
-    key = (spec["depth"], repr(sorted(spec["gen"].items())), n_cols)       # workloads of one shape share the generated input
+    key = (spec["depth"], spec["files"], repr(sorted(spec["gen"].items())), n_cols)       # workloads of one shape share the generated input
     if key not in _inputs:
         for k in list(_inputs):                       # one shape at a time: these are hundreds of MB each
             shutil.rmtree(_inputs.pop(k)["dir"], ignore_errors=True)
@@ -62,13 +64,14 @@ def _engine_sha(wl, n_cols, env=None):
         eng = sa.Engine(0, torch.cuda.current_stream().cuda_stream)
         ref_t = torch.from_numpy(ref.copy()).to(dev)
         eng.set_reference(0, ref_t.data_ptr(), n_cols, 1)
-        w, keep, _ = bench.build_window(torch, np, sa, rd, n_cols, dev)
+        w, keep, _ = bench.build_window(torch, np, sa, rd, n_cols, dev, star_tags=spec["n_tags"])
         eng.stage_window(w)
         if kind == "mpileup":
             par = sa.MplpParams.defaults(); par.has_fai = 1
             par.flag = (par.flag | spec["flags_on"]) & ~spec["flags_off"]
             if spec["max_depth"]:
                 par.max_depth = spec["max_depth"]
+            par.n_tags = spec["n_tags"]
             info = eng.mpileup_plan(par)
             out = torch.empty(int(info.out_bytes) + 64, dtype=torch.uint8, device=dev)
             eng.mpileup_emit(out.data_ptr(), out.numel())
@@ -106,7 +109,9 @@ def _oracle(wl, n_cols):
 # most four of these windows (25 GiB of BAQ scratch each at 30x) are on the GPU at a time.
 _BENCH_WL = [("mpileup30", "a"), ("mpileup30_B", "a"), ("mpileup300", "b"), ("mpileup300_B", "b"), ("mpileup100", "b"), ("mpileup100_B", "b"),
              ("mpileup30_EA_pairs", "c"), ("mpileup30_B_pairs", "c"), ("mpileup30_hotspot", "d"), ("mpileup30_B_hotspot", "d"),
-             ("mpileup30_indel", "a"), ("depth30", "c")]
+             ("mpileup30_indel", "a"), ("depth30", "c"),
+             # round 4: three input files (per-file column groups of the tile kernels), the generic walkers (-s -O --output-extra)
+             ("mpileup30_3files", "e"), ("mpileup30_B_3files", "e"), ("mpileup30_B_sOx", "a")]
 
 
 @pytest.mark.parametrize("wl", [pytest.param(w, marks=pytest.mark.xdist_group("benchsize_" + g)) for w, g in _BENCH_WL])

@@ -138,7 +138,24 @@ typedef struct sta_reads {
     const uint32_t *mod_toff;    /* n_mod_entries + 1 */
     const char *mod_text;
     uint64_t n_mod_entries, n_mod_bytes;
+    /* optional (STA_MEM_HOST only): reads [raw_first, n_reads) are staged on the DEVICE out of raw BAM records.  Their scalars and
+     * offsets (pos .. name_off) are filled in as for any read, but their slices of the pools cigar / seq / qual / names are left
+     * unwritten by the host: the engine uploads the inflated BAM bytes they lie in (`raw_pieces`, concatenated in this order)
+     * and a HIP kernel copies every record's CIGAR, 4-bit bases, qualities and name from its alignment record (SAM spec 4.2:
+     * block_size | refID pos l_read_name mapq bin n_cigar_op flag l_seq next_refID next_pos tlen | read_name | cigar | seq | qual | aux)
+     * to the pool offsets cig_off / base_off8 / name_off name, zero-padding the bases to 8 (the feed this replaces on the host:
+     * sam_read1 in bam_plcmd.c:409, bam2depth.c:541-543).  raw_rec_off[i - raw_first] = byte offset, inside the concatenated pieces,
+     * of read i's refID field.  The pools' host-written prefixes are cigar[0 .. cig_off[raw_first]), bases [0 .. 8 * base_off8[raw_first]),
+     * names[0 .. name_off[raw_first]).  raw_first == n_reads or n_raw_pieces == 0: everything was staged by the host (the default).
+     * A read whose CIGAR lives in a CG:B,I tag, or a window with BQ:Z values, must not be staged this way. */
+    int64_t raw_first;
+    int32_t n_raw_pieces;
+    const struct sta_raw_piece *raw_pieces;
+    const uint32_t *raw_rec_off;
+    int32_t raw_verify;          /* != 0: the host pools ARE fully written as well; the engine compares its device-built pools with them and fails on a difference (tests) */
 } sta_reads;
+
+typedef struct sta_raw_piece { const uint8_t *bytes; uint64_t n_bytes; } sta_raw_piece;
 
 /* One window of reference columns on one contig, with every read (of every
  * input file) whose reference span can touch it. */
@@ -238,6 +255,9 @@ typedef struct sta_plp_entry {
 /* info->out_bytes = 16 * entries, n_lines = columns with >= 1 entry */
 int sta_plp_plan(sta_engine *e, int32_t max_depth, int32_t overlaps, sta_plan_info *info);
 int sta_plp_emit(sta_engine *e, void *dev_entries, uint64_t capacity);     /* NULL: engine buffer, read with sta_fetch_output */
+/* reads whose pools the engine has cut out of raw BAM records on the device since it was created (sta_reads.raw_*): lets a caller
+ * (and the tests) see that the device staging path, not the host copy, fed the windows */
+uint64_t sta_stage_raw_reads(sta_engine *e);
 /* first n (<= columns + 1) exclusive column offsets of the planned window (bytes for text plans, entries for sta_plp_plan) */
 int sta_fetch_col_offsets(sta_engine *e, uint64_t *host_offs, uint64_t n);
 /* per-read state after a plan: info words (bit 1 = read is in the pileup) and the working quality

@@ -50,6 +50,8 @@ class Reads(C.Structure):
         ("n_xcols", C.c_int32), ("xcol_off", C.c_void_p), ("xcol_text", C.c_void_p), ("n_xcol_bytes", C.c_uint64),
         ("mod_off", C.c_void_p), ("mod_qpos", C.c_void_p), ("mod_toff", C.c_void_p), ("mod_text", C.c_void_p),
         ("n_mod_entries", C.c_uint64), ("n_mod_bytes", C.c_uint64),
+        # device staging out of raw BAM records (host drivers only; zero here: everything staged by the caller)
+        ("raw_first", C.c_int64), ("n_raw_pieces", C.c_int32), ("raw_pieces", C.c_void_p), ("raw_rec_off", C.c_void_p), ("raw_verify", C.c_int32),
     ]
 
 
@@ -167,6 +169,7 @@ _PROTOS = {
     "sta_plp_plan": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(PlanInfo)]),
     "sta_plp_emit": (C.c_int, [_P, _P, C.c_uint64]),
     "sta_fetch_col_offsets": (C.c_int, [_P, _P, C.c_uint64]),
+    "sta_stage_raw_reads": (C.c_uint64, [_P]),
     "sta_fetch_read_state": (C.c_int, [_P, C.c_int32, _P, _P]),
     "sta_main_mpileup": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_main_depth": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),

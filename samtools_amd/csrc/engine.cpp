@@ -35,12 +35,14 @@ struct DevBuf {
 struct FileBufs {
     // staged input copies (only used with STA_MEM_HOST)
     DevBuf pos, flag, mapq, aux, lq, cig_off, base_off8, mtid, mpos, isize, name_off, cigar, seq, qual, bq, names, xoff, xtext, moff, mqpos, mtoff, mtext;
+    // device staging (sta_reads.raw_*): the uploaded BAM bytes, the records' offsets in them, the pools built for a verify run
+    DevBuf raw, raw_off, raw_vfy;
     // workspace
     DevBuf qual_work, end, maxend, info, clip, chain, fix_y, fix_mate, fix_q;
     void release()
     {
         DevBuf *all[] = { &pos, &flag, &mapq, &aux, &lq, &cig_off, &base_off8, &mtid, &mpos, &isize, &name_off, &cigar,
-                          &seq, &qual, &bq, &names, &xoff, &xtext, &moff, &mqpos, &mtoff, &mtext, &qual_work, &end, &maxend, &info, &clip, &chain, &fix_y, &fix_mate, &fix_q };
+                          &seq, &qual, &bq, &names, &xoff, &xtext, &moff, &mqpos, &mtoff, &mtext, &raw, &raw_off, &raw_vfy, &qual_work, &end, &maxend, &info, &clip, &chain, &fix_y, &fix_mate, &fix_q };
         for (DevBuf *b : all) b->release();
     }
 };
@@ -66,7 +68,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, stage_bad, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
     DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
@@ -85,6 +87,7 @@ struct sta_engine {
     StaCounters ctr_h{};
     uint64_t out_bytes = 0;
     uint32_t lds_cap = 0;
+    uint64_t n_raw_staged = 0;         // reads whose pools were cut out of raw BAM records on the device (sta_stage_stats)
     bool len_fused = false;            // the measuring kernel also produced offsets / totals (no scan, no column statistics)
     bool have_wfirst = false;          // the plan built the per-group read index of the tile kernels
     void *last_out = nullptr;
@@ -184,13 +187,14 @@ int sta_engine_create(sta_engine **out, int device, void *hip_stream)
 
 void sta_engine_destroy(sta_engine *e)
 {
+    if (e && getenv("STA_STAGE_REPORT")) fprintf(stderr, "[sta] reads staged on the device out of raw BAM records: %llu\n", (unsigned long long)e->n_raw_staged);
     if (!e) return;
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->wfirst, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->cov_out, &e->cov_hist, &e->sc_pos, &e->sc_delta, &e->sc_tmp, &e->sc_cov, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
+                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->stage_bad, &e->cov_out, &e->cov_hist, &e->sc_pos, &e->sc_delta, &e->sc_tmp, &e->sc_cov, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
                       &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
@@ -255,11 +259,62 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
         rc |= upload(e, b.mpos, r.mpos, n, &d.mpos, mem);
         rc |= upload(e, b.isize, r.isize, n, &d.isize, mem);
         rc |= upload(e, b.name_off, r.name_off, n + 1, &d.name_off, mem);
-        rc |= upload(e, b.cigar, r.cigar, (size_t)r.n_cigar_total, &d.cigar, mem);
-        rc |= upload(e, b.seq, r.seq, (size_t)(r.n_bases_total / 2), &d.seq, mem);
-        rc |= upload(e, b.qual, r.qual, (size_t)r.n_bases_total, &d.qual_in, mem);
-        if (r.bq) rc |= upload(e, b.bq, r.bq, (size_t)r.n_bases_total, &d.bq, mem); else d.bq = nullptr;
-        rc |= upload(e, b.names, r.names, (size_t)r.n_name_bytes, &d.names, mem);
+        // device staging: the pools of reads [raw_first, n) come out of raw BAM records (kernels_stage.hip)
+        const bool raw_mode = mem == STA_MEM_HOST && r.n_raw_pieces > 0 && r.raw_pieces && r.raw_rec_off && r.raw_first >= 0 && r.raw_first < r.n_reads && !r.bq;
+        size_t cig0 = 0, bases0 = 0, names0 = 0;
+        if (raw_mode && !r.raw_verify) {
+            // only the host-written prefixes of the pools travel as pools
+            cig0 = r.cig_off[r.raw_first]; bases0 = (size_t)r.base_off8[r.raw_first] << 3; names0 = r.name_off[r.raw_first];
+            if (b.cigar.ensure((size_t)r.n_cigar_total * 4 + 16) || b.seq.ensure((size_t)(r.n_bases_total / 2) + 16) || b.qual.ensure((size_t)r.n_bases_total + 16)
+                || b.names.ensure((size_t)r.n_name_bytes + 16)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+            if (cig0) HIPCHK(hipMemcpyAsync(b.cigar.p, r.cigar, cig0 * 4, hipMemcpyHostToDevice, e->stream));
+            if (bases0) { HIPCHK(hipMemcpyAsync(b.seq.p, r.seq, bases0 / 2, hipMemcpyHostToDevice, e->stream)); HIPCHK(hipMemcpyAsync(b.qual.p, r.qual, bases0, hipMemcpyHostToDevice, e->stream)); }
+            if (names0) HIPCHK(hipMemcpyAsync(b.names.p, r.names, names0, hipMemcpyHostToDevice, e->stream));
+            d.cigar = (const uint32_t *)b.cigar.p; d.seq = (const uint8_t *)b.seq.p; d.qual_in = (const uint8_t *)b.qual.p; d.names = (const char *)b.names.p;
+            d.bq = nullptr;
+        } else {
+            rc |= upload(e, b.cigar, r.cigar, (size_t)r.n_cigar_total, &d.cigar, mem);
+            rc |= upload(e, b.seq, r.seq, (size_t)(r.n_bases_total / 2), &d.seq, mem);
+            rc |= upload(e, b.qual, r.qual, (size_t)r.n_bases_total, &d.qual_in, mem);
+            if (r.bq) rc |= upload(e, b.bq, r.bq, (size_t)r.n_bases_total, &d.bq, mem); else d.bq = nullptr;
+            rc |= upload(e, b.names, r.names, (size_t)r.n_name_bytes, &d.names, mem);
+        }
+        if (raw_mode && !rc) {
+            const int64_t n_raw = r.n_reads - r.raw_first;
+            uint64_t raw_bytes = 0;
+            for (int32_t k = 0; k < r.n_raw_pieces; ++k) raw_bytes += r.raw_pieces[k].n_bytes;
+            if (raw_bytes > 0xfffffff0ull) return fail(e, STA_ERR_ARG, "raw staging pieces beyond 4 GiB");
+            if (b.raw.ensure((size_t)raw_bytes + 64) || b.raw_off.ensure((size_t)n_raw * 4 + 16) || e->stage_bad.ensure(64)) return fail(e, STA_ERR_HIP, "hipMalloc(raw staging) failed");
+            uint64_t o = 0;
+            for (int32_t k = 0; k < r.n_raw_pieces; ++k) {
+                if (r.raw_pieces[k].n_bytes) HIPCHK(hipMemcpyAsync((char *)b.raw.p + o, r.raw_pieces[k].bytes, (size_t)r.raw_pieces[k].n_bytes, hipMemcpyHostToDevice, e->stream));
+                o += r.raw_pieces[k].n_bytes;
+            }
+            HIPCHK(hipMemcpyAsync(b.raw_off.p, r.raw_rec_off, (size_t)n_raw * 4, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemsetAsync(e->stage_bad.p, 0, 16, e->stream));
+            unsigned long long *bad = (unsigned long long *)e->stage_bad.p;
+            uint32_t *o_cig; uint8_t *o_seq, *o_qual; char *o_names;
+            if (r.raw_verify) {
+                // build beside the (complete, host-written) pools and compare
+                const size_t cb = ((size_t)r.n_cigar_total * 4 + 63) & ~(size_t)63, sb = ((size_t)(r.n_bases_total / 2) + 63) & ~(size_t)63, qb = ((size_t)r.n_bases_total + 63) & ~(size_t)63;
+                if (b.raw_vfy.ensure(cb + sb + qb + (size_t)r.n_name_bytes + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(raw staging) failed");
+                o_cig = (uint32_t *)b.raw_vfy.p; o_seq = (uint8_t *)b.raw_vfy.p + cb; o_qual = o_seq + sb; o_names = (char *)(o_qual + qb);
+                cig0 = r.cig_off[r.raw_first]; bases0 = (size_t)r.base_off8[r.raw_first] << 3; names0 = r.name_off[r.raw_first];
+            } else { o_cig = (uint32_t *)b.cigar.p; o_seq = (uint8_t *)b.seq.p; o_qual = (uint8_t *)b.qual.p; o_names = (char *)b.names.p; }
+            sta_launch_bam_pools(e->stream, (const uint8_t *)b.raw.p, (const uint32_t *)b.raw_off.p, r.raw_first, n_raw, d, o_cig, o_seq, o_qual, o_names, bad);
+            if (r.raw_verify) {
+                sta_launch_stage_compare(e->stream, (const char *)o_cig + cig0 * 4, (const char *)d.cigar + cig0 * 4, ((size_t)r.n_cigar_total - cig0) * 4, bad + 1);
+                sta_launch_stage_compare(e->stream, o_seq + bases0 / 2, d.seq + bases0 / 2, (size_t)(r.n_bases_total - bases0) / 2, bad + 1);
+                sta_launch_stage_compare(e->stream, o_qual + bases0, d.qual_in + bases0, (size_t)(r.n_bases_total - bases0), bad + 1);
+                sta_launch_stage_compare(e->stream, o_names + names0, d.names + names0, (size_t)r.n_name_bytes - names0, bad + 1);
+            }
+            unsigned long long bad_h[2] = { 0, 0 };
+            HIPCHK(hipMemcpyAsync(bad_h, bad, 16, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            if (bad_h[0]) return fail(e, STA_ERR_ARG, "raw staging: an alignment record does not match the offsets staged for it");
+            if (bad_h[1]) return fail(e, STA_ERR_HIP, "raw staging (verify): the device-built pools differ from the host-built ones");
+            e->n_raw_staged += (uint64_t)n_raw;
+        }
         d.n_xcols = r.n_xcols > 0 && r.xcol_off && r.xcol_text ? r.n_xcols : 0;
         d.xcol_off = nullptr; d.xcol_text = nullptr;
         if (d.n_xcols) {
@@ -754,6 +809,8 @@ int sta_plp_emit(sta_engine *e, void *dev_entries, uint64_t capacity)
     sta_launch_plp_fill(e->stream, e->wd, (const uint64_t *)e->offs.p, out);
     return STA_OK;
 }
+
+uint64_t sta_stage_raw_reads(sta_engine *e) { return e ? e->n_raw_staged : 0; }
 
 int sta_fetch_col_offsets(sta_engine *e, uint64_t *host_offs, uint64_t n)
 {

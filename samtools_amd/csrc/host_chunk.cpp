@@ -71,7 +71,7 @@ void Chunk::to_rec(int64_t i, Rec &r) const
 // ------------------------------------------------------------------------------------------------ ChunkReader
 static constexpr size_t GROUP_BYTES = 1 << 20;
 
-ChunkReader::ChunkReader(AlnReader *rd, int threads) : rd_(rd)
+ChunkReader::ChunkReader(AlnReader *rd, int threads, bool keep_raw) : rd_(rd), keep_raw_(keep_raw)
 {
     if (threads < 1) threads = 1;
     max_ahead_ = (size_t)threads * 2 + 2;
@@ -85,9 +85,24 @@ ChunkReader::~ChunkReader()
     for (auto &t : th_) if (t.joinable()) t.join();
 }
 
+std::shared_ptr<pvector<uint8_t>> ChunkReader::get_buf()
+{
+    std::unique_ptr<pvector<uint8_t>> b;
+    {
+        std::lock_guard<std::mutex> g(pool_->m);
+        if (!pool_->free.empty()) { b = std::move(pool_->free.back()); pool_->free.pop_back(); }
+    }
+    if (!b) { b.reset(new pvector<uint8_t>()); b->reserve(GROUP_BYTES + (GROUP_BYTES >> 3)); }
+    std::shared_ptr<RawPool> pool = pool_;
+    return std::shared_ptr<pvector<uint8_t>>(b.release(), [pool](pvector<uint8_t> *p) {
+        std::lock_guard<std::mutex> g(pool->m);
+        if (pool->free.size() < 256) pool->free.emplace_back(p); else delete p;
+    });
+}
+
 void ChunkReader::work()
 {
-    std::vector<uint8_t> raw;
+    pvector<uint8_t> own_raw;
     Rec r; std::string scratch;
     for (;;) {
         uint64_t seq;
@@ -98,6 +113,8 @@ void ChunkReader::work()
             if (stop_) return;
         }
         int64_t nrec = 0;
+        std::shared_ptr<pvector<uint8_t>> keep = keep_raw_ ? get_buf() : nullptr;
+        pvector<uint8_t> &raw = keep ? *keep : own_raw;
         {
             std::lock_guard<std::mutex> g(io_m_);
             if (io_end_.load()) return;
@@ -125,8 +142,10 @@ void ChunkReader::work()
             if (rd_->past_region(r) && !io_end_.load()) { std::lock_guard<std::mutex> g2(out_m_); io_status_.store(0); io_end_.store(true); cv_out_.notify_all(); }
             if (!rd_->in_region(r)) continue;
             c->append(r);
+            if (keep) { c->rec_off.push_back((uint32_t)(o - used + 4)); if (r.cigar_from_tag) c->raw_ok = false; }
         }
         c->close();
+        if (keep) c->raw = std::move(keep);
         std::lock_guard<std::mutex> g(out_m_);
         if (bad && seq < bad_seq_) bad_seq_ = seq;
         done_[seq] = std::move(c);
@@ -158,7 +177,12 @@ static double mono_s() { return std::chrono::duration<double>(std::chrono::stead
 ChunkPump::ChunkPump(std::vector<std::unique_ptr<AlnReader>> &readers, const PumpConfig &cfg, int threads) : cfg_(cfg)
 {
     f_.resize(readers.size());
-    for (size_t i = 0; i < readers.size(); ++i) f_[i].rd.reset(new ChunkReader(readers[i].get(), threads));
+    // STA_STAGE_DEVICE: 1 (default for BAM input) = a window's new reads reach the device as raw alignment records and their pools are
+    // built there (kernels_stage.hip); 0 = pools copied on the host (round-3 path); 2 = both, compared on the device (tests)
+    raw_mode_ = cfg.device_pools ? 1 : 0;
+    if (const char *ev = getenv("STA_STAGE_DEVICE")) if (cfg.device_pools) raw_mode_ = atoi(ev);
+    if (cfg.xs_n_tags > 0) raw_mode_ = 0;                           // tag text columns are formatted per record on the host
+    for (size_t i = 0; i < readers.size(); ++i) f_[i].rd.reset(new ChunkReader(readers[i].get(), threads, raw_mode_ != 0 && readers[i]->is_bam()));
     // threads that copy a window's chunk slices into the staging arrays (STA_STAGE_THREADS; 1 = the producer thread alone)
     stage_threads_ = threads >= 8 ? 4 : threads >= 4 ? 2 : 1;
     if (const char *ev = getenv("STA_STAGE_THREADS")) { const int v = atoi(ev); if (v >= 1 && v <= 64) { stage_threads_ = v; stage_min_bytes_ = 0; } }   // set explicitly: for every window, however small
@@ -285,7 +309,7 @@ int64_t ChunkPump::fill_window(int tid, int64_t cb, int64_t ce_target, std::vect
         f.n_carry_staged = f.carry.size();
         slices.clear();
         for (auto &g : f.fresh) slices.push_back(StagedFile::Slice{ g.c.get(), g.i0, g.i1 });
-        s.add_ranges(slices.data(), slices.size(), cb, xp, stage_threads_, stage_min_bytes_, &f.high_water);
+        s.add_ranges(slices.data(), slices.size(), cb, xp, stage_threads_, stage_min_bytes_, &f.high_water, raw_mode_);
         s.finish();
     }
     stats_.stage_s += mono_s() - t_stage0;

@@ -34,6 +34,12 @@ struct Chunk {
     // columns (--output-extra tags of mpileup; MD:Z for the consensus path)
     int n_tags = 0;
     std::vector<uint32_t> tag_off; std::vector<char> tag_text, tag_has;
+    // BAM input with device staging on (host_stage.h add_ranges): the group's inflated bytes as they came off the stream, page-locked,
+    // and for every record kept here the offset of its refID field in them.  The window producer then uploads these bytes instead of
+    // copying the pools above; raw_ok = false when a record's CIGAR came out of a CG tag (its own CIGAR field is a placeholder).
+    std::shared_ptr<pvector<uint8_t>> raw;
+    std::vector<uint32_t> rec_off;
+    bool raw_ok = true;
     int64_t n() const { return (int64_t)pos.size(); }
     int64_t end(int64_t i) const { return pos[(size_t)i] + rlen[(size_t)i]; }
     int64_t endpos(int64_t i) const { int64_t l = (flag[(size_t)i] & 4) ? 0 : rlen[(size_t)i]; return pos[(size_t)i] + (l > 0 ? l : 1); }
@@ -45,7 +51,7 @@ struct Chunk {
 // decodes one input on `threads` parser threads; chunks come out in file order
 class ChunkReader {
 public:
-    ChunkReader(AlnReader *rd, int threads);
+    ChunkReader(AlnReader *rd, int threads, bool keep_raw = false);
     ~ChunkReader();
     // next chunk in file order; nullptr at end of data or after an error (status() tells which)
     std::shared_ptr<Chunk> next();
@@ -62,6 +68,12 @@ private:
     int status_ = 0;
     uint64_t bad_seq_ = UINT64_MAX;               // first group that failed to parse
     size_t max_ahead_;
+    bool keep_raw_ = false;
+    // page-locked group buffers go round: a chunk hands its buffer back when the last window that uploads from it is done
+    // (the pool is shared with the buffers' deleters: staged windows may still hold buffers when the reader has gone)
+    struct RawPool { std::mutex m; std::vector<std::unique_ptr<pvector<uint8_t>>> free; };
+    std::shared_ptr<RawPool> pool_ = std::make_shared<RawPool>();
+    std::shared_ptr<pvector<uint8_t>> get_buf();
     void work();
 };
 
@@ -89,6 +101,7 @@ public:
 private:
     Stats stats_;
     int stage_threads_ = 1; size_t stage_min_bytes_ = (size_t)4 << 20;
+    int raw_mode_ = 0;       // 0: pools copied on the host; 1: pools of a window's new reads built on the device out of the raw records; 2: both, compared (tests)
     struct Range { std::shared_ptr<Chunk> c; int64_t i0, i1; };
     struct File {
         std::unique_ptr<ChunkReader> rd;

@@ -544,7 +544,7 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
     const bool want = !wanted.empty();
     if (want) { r.tagtext.assign(wanted.size(), std::string()); r.tag_has.assign(wanted.size(), 0); }
     const uint8_t *cg = nullptr; uint32_t cg_n = 0;          // CG:B,I: the real CIGAR of a read with more than 65535 operations
-    r.auxv.clear(); r.zq.clear(); r.aux_bam.clear();
+    r.auxv.clear(); r.zq.clear(); r.aux_bam.clear(); r.cigar_from_tag = false;
     int cg_field = -1;
     while (p + 3 <= e) {
         int t = p[2]; const uint8_t *tag = p; p += 3;
@@ -603,6 +603,7 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
     if (cg && n_cig >= 1 && refID >= 0 && pos >= 0 && (r.cigar[0] & 0xf) == 4 && (int64_t)(r.cigar[0] >> 4) == (int64_t)l_seq
         && cg_n >= (uint32_t)n_cig && cg_n < (1u << 29)) {
         r.cigar.resize(cg_n);
+        r.cigar_from_tag = true;
         if (cg_n) memcpy(r.cigar.data(), cg, 4 * (size_t)cg_n);
         if (keep_aux && cg_field >= 0 && (size_t)cg_field < r.auxv.size()) r.auxv.erase(r.auxv.begin() + cg_field);     // bam_tag2cigar removes the tag
     }
@@ -612,7 +613,7 @@ static int parse_bam_mem(const uint8_t *b, int32_t bs, const std::vector<std::st
 
 // ---- raw record groups for the chunked reader (host_chunk.cpp): whole BAM records (with their block_size prefix) or whole
 // SAM lines ('\n' terminated), about `target` bytes per call; appended to `out`.  Not to be mixed with next().
-int AlnReader::raw_group(std::vector<uint8_t> &out, size_t target, int64_t *n_records)
+int AlnReader::raw_group(pvector<uint8_t> &out, size_t target, int64_t *n_records)
 {
     Impl &im = *p_;
     int64_t nrec = 0;

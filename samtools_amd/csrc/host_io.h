@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+#include "host_pinned.h"
 #include <utility>
 #include <unordered_map>
 #include <memory>
@@ -48,6 +49,7 @@ struct Rec {
     std::vector<std::string> tagtext;
     std::vector<char> tag_has;
     int64_t rlen = 0;            // reference span (bam_cigar2rlen)
+    bool cigar_from_tag = false; // BAM: the CIGAR came out of a CG:B,I tag (the record's own CIGAR field is the <l_seq>S<span>N placeholder)
     bool accepted = false;       // carried from an earlier window whose -d replay kept it (STA_AUX_ACCEPTED when re-staged)
     int64_t end() const { return pos + rlen; }
     int64_t endpos() const { int64_t l = (flag & 4) ? 0 : rlen; return pos + (l > 0 ? l : 1); }   // bam_endpos
@@ -70,7 +72,7 @@ public:
     int next(Rec &r);
     // chunked access (host_chunk.h): raw_group() cuts the byte stream into groups of whole records on one thread (1 = group,
     // 0 = end of data, <0 = error), parse_raw() decodes one record of a group and may run on any number of threads at once.
-    int raw_group(std::vector<uint8_t> &out, size_t target, int64_t *n_records);
+    int raw_group(pvector<uint8_t> &out, size_t target, int64_t *n_records);      // (a page-locked vector: a BAM group may be uploaded as it is, host_chunk.h)
     int parse_raw(const uint8_t *p, size_t avail, size_t *used, Rec &r, std::string &scratch) const;
     bool is_bam() const;
     // Start reading at a BAI virtual offset (coffset << 16 | offset inside the inflated block) instead of behind the header:

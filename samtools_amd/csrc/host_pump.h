@@ -34,6 +34,10 @@ struct PumpConfig {
     // contigs of the header the driver prints from (the first input's): a record of any input naming a later one is an error
     // instead of an out-of-range name / length lookup
     int nref_limit = INT32_MAX;
+    // chunk lane, BAM input: hand the engine the raw alignment records of a window's new reads and let it cut their CIGAR / bases /
+    // qualities / names out on the device (host_stage.h add_ranges raw_mode, kernels_stage.hip) instead of copying them into the
+    // staging pools here.  Set by drivers whose windows go to an engine through sta_stage_window(); STA_STAGE_DEVICE=0 turns it off.
+    bool device_pools = false;
 };
 
 // What the window loops of the drivers need from an input lane (Pump below: one decoded record at a time; ChunkPump in

@@ -17,6 +17,7 @@ void StagedFile::clear()
     xcol_off.clear(); xcol_text.clear(); n_xcols = 0;
     mod_off.clear(); mod_qpos.clear(); mod_toff.clear(); mod_text.clear(); with_mods = false;
     any_bq = false;
+    raw_first = -1; raw_verify = 0; raw_pieces.clear(); raw_rec_off.clear(); raw_keep.clear();
 }
 
 void StagedFile::add(const Rec &r, int64_t origin, const std::set<std::string> *rg_excl, const XcolSpec *xs)
@@ -122,10 +123,12 @@ void StagedFile::add_range(const Chunk &c, int64_t i0, int64_t i1, int64_t origi
     }
 }
 
-void StagedFile::add_ranges(const Slice *g, size_t n_g, int64_t origin, const XcolSpec *xs, int threads, size_t min_bytes_for_threads, PoolSizes *hw)
+void StagedFile::add_ranges(const Slice *g, size_t n_g, int64_t origin, const XcolSpec *xs, int threads, size_t min_bytes_for_threads, PoolSizes *hw, int raw_mode)
 {
     if (!n_g) return;
     const int nt = xs ? xs->n_tags : 0;
+    if (nt > 0 || any_bq) raw_mode = 0;
+    for (size_t s = 0; s < n_g && raw_mode; ++s) if (!g[s].c->raw || !g[s].c->raw_ok || g[s].c->rec_off.size() != (size_t)g[s].c->n()) raw_mode = 0;
     // destination offsets of every slice
     struct Dst { size_t rec, cig, b8, nm, xoff, xtext; };
     std::vector<Dst> d(n_g + 1);
@@ -149,7 +152,29 @@ void StagedFile::add_ranges(const Slice *g, size_t n_g, int64_t origin, const Xc
         bytes += (b - a) * 48 + ((size_t)(c.base_off8[b] - c.base_off8[a]) << 3) * 3 / 2;
     }
     const Dst &z = d[n_g];
+    if (slices_bq) raw_mode = 0;
     if (slices_bq && !any_bq) { bq.assign(qual.size(), 64); any_bq = true; }
+    if (raw_mode) {
+        // the engine gets the raw records of the slices: one piece per slice, every new read's record offset inside the concatenation
+        uint64_t base = 0, total = 0;
+        for (size_t s = 0; s < n_g; ++s) total += g[s].c->raw->size();
+        if (total > 0xfffffff0ull) raw_mode = 0;
+        else {
+            raw_first = (int64_t)d[0].rec; raw_verify = raw_mode == 2;
+            raw_rec_off.resize(z.rec - d[0].rec);
+            for (size_t s = 0; s < n_g; ++s) {
+                const Chunk &c = *g[s].c; const size_t a = (size_t)g[s].i0, b = (size_t)g[s].i1;
+                if (b <= a) continue;
+                const uint32_t p0 = c.rec_off[a], p1 = b < (size_t)c.n() ? c.rec_off[b] : (uint32_t)c.raw->size();
+                raw_pieces.push_back(sta_raw_piece{ c.raw->data() + p0, (uint64_t)(p1 - p0) });
+                raw_keep.push_back(c.raw);
+                uint32_t *dst = &raw_rec_off[d[s].rec - d[0].rec];
+                for (size_t k = 0; k < b - a; ++k) dst[k] = (uint32_t)(base + (c.rec_off[a + k] - p0));
+                base += p1 - p0;
+            }
+        }
+    }
+    const bool copy_pools = raw_mode != 1;
     {
         PoolSizes local; PoolSizes &h = hw ? *hw : local;
         h.rec = std::max(h.rec, z.rec); h.cig = std::max(h.cig, z.cig); h.b8 = std::max(h.b8, z.b8); h.nm = std::max(h.nm, z.nm);
@@ -183,8 +208,8 @@ void StagedFile::add_ranges(const Slice *g, size_t n_g, int64_t origin, const Xc
         memcpy(&mtid[o.rec], &c.mtid[a], m * sizeof(int32_t));
         memcpy(&mpos[o.rec], &c.mpos[a], m * sizeof(int64_t));
         const uint32_t cg0 = c.cig_off[a], cg1 = c.cig_off[b], b0 = c.base_off8[a], b1 = c.base_off8[b], nm0 = c.name_off[a], nm1 = c.name_off[b];
-        if (cg1 > cg0) memcpy(&cigar[o.cig], &c.cigar[cg0], (size_t)(cg1 - cg0) * sizeof(uint32_t));
-        if (b1 > b0) {
+        if (copy_pools && cg1 > cg0) memcpy(&cigar[o.cig], &c.cigar[cg0], (size_t)(cg1 - cg0) * sizeof(uint32_t));
+        if (copy_pools && b1 > b0) {
             memcpy(&qual[o.b8 << 3], &c.qual[(size_t)b0 << 3], (size_t)(b1 - b0) << 3);
             memcpy(&seq[o.b8 << 2], &c.seq[(size_t)b0 << 2], (size_t)(b1 - b0) << 2);
             if (with_bq) {
@@ -192,7 +217,7 @@ void StagedFile::add_ranges(const Slice *g, size_t n_g, int64_t origin, const Xc
                 else memset(&bq[o.b8 << 3], 64, (size_t)(b1 - b0) << 3);
             }
         }
-        if (nm1 > nm0) memcpy(&names[o.nm], &c.names[nm0], nm1 - nm0);
+        if (copy_pools && nm1 > nm0) memcpy(&names[o.nm], &c.names[nm0], nm1 - nm0);
         for (size_t k = 0; k < m; ++k) {
             cig_off[o.rec + k] = c.cig_off[a + k] - cg0 + (uint32_t)o.cig;
             base_off8[o.rec + k] = c.base_off8[a + k] - b0 + (uint32_t)o.b8;
@@ -243,6 +268,11 @@ sta_reads StagedFile::view() const
     if (with_mods && mod_off.size() == pos.size() + 1) {
         v.mod_off = mod_off.data(); v.mod_qpos = mod_qpos.data(); v.mod_toff = mod_toff.data(); v.mod_text = mod_text.data();
         v.n_mod_entries = mod_qpos.size(); v.n_mod_bytes = mod_text.size();
+    }
+    v.raw_first = v.n_reads;
+    if (raw_first >= 0 && !raw_pieces.empty() && !any_bq) {
+        v.raw_first = raw_first; v.n_raw_pieces = (int32_t)raw_pieces.size(); v.raw_pieces = raw_pieces.data(); v.raw_rec_off = raw_rec_off.data();
+        v.raw_verify = raw_verify;
     }
     return v;
 }

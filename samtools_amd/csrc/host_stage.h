@@ -6,6 +6,7 @@
 #include "host_pinned.h"
 #include "../../include/samtools_amd.h"
 #include <set>
+#include <memory>
 
 namespace sta {
 
@@ -48,8 +49,16 @@ struct StagedFile {
     // largest pool sizes any window of this input has needed so far: a staging object that has to grow (every pool growth is a
     // page-locking call) grows once, to a quarter beyond these, instead of creeping up window by window in each ring slot
     struct PoolSizes { size_t rec = 0, cig = 0, b8 = 0, nm = 0, xoff = 0, xtext = 0; };
+    // raw_mode (host_chunk.h): 1 = the slices' pool bytes are NOT copied: the chunks' raw alignment records are handed to the engine
+    // instead (sta_reads.raw_*), which cuts the pools out of them on the device; 2 = both, and the engine compares.  Falls back to
+    // copying when a slice has no usable raw bytes (SAM input, a CIGAR from a CG tag) or BQ:Z values are around.
     void add_ranges(const Slice *g, size_t n_g, int64_t origin, const XcolSpec *xs, int threads, size_t min_bytes_for_threads = (size_t)4 << 20,
-                    PoolSizes *high_water = nullptr);
+                    PoolSizes *high_water = nullptr, int raw_mode = 0);
+    // device staging of this window's new reads (set by add_ranges)
+    int64_t raw_first = -1; int raw_verify = 0;
+    std::vector<sta_raw_piece> raw_pieces;
+    pvector<uint32_t> raw_rec_off;
+    std::vector<std::shared_ptr<pvector<uint8_t>>> raw_keep;      // the chunks' buffers stay alive while the window may still be uploaded
     void finish();                 // closes the offset arrays
     sta_reads view() const;        // pointers into this object (valid until the next add/clear)
     int64_t n() const { return (int64_t)pos.size(); }

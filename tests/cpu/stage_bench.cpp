@@ -21,7 +21,7 @@ int main(int argc, char **argv)
     if (!r) { fprintf(stderr, "open: %s\n", err.c_str()); return 1; }
     if (argc > 5 && atoi(argv[5])) {
         // the serial section of the chunk lane alone: raw record groups off the BGZF stream
-        std::vector<uint8_t> raw; int64_t nrec = 0, tot = 0, groups = 0; size_t bytes = 0;
+        sta::pvector<uint8_t> raw; int64_t nrec = 0, tot = 0, groups = 0; size_t bytes = 0;
         const double a = now();
         while (r->raw_group(raw, 1 << 20, &nrec) > 0) { tot += nrec; bytes += raw.size(); ++groups; }
         printf("raw_group: %lld groups, %lld records, %zu bytes in %.3f s\n", (long long)groups, (long long)tot, bytes, now() - a);

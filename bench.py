@@ -370,7 +370,7 @@ def collect_pmc(a, wlname, kernels):
 
 
 # engine kernel label -> prefix of the rocprofv3 kernel name
-KNAME = {"baq_s": "k_baq7s", "baq_fwd": "void k_baq_fwd<7", "baq_bwd": "void k_baq_bwd<7", "mplp_emit": "k_mplp_emit_tile", "mplp_emit_deep": "k_mplp_emit_deep", "mplp_len": "k_mplp_len_rm",
+KNAME = {"baq_s": "void k_baq7s", "baq_fwd": "void k_baq_fwd<7", "baq_bwd": "void k_baq_bwd<7", "mplp_emit": "k_mplp_emit_tile", "mplp_emit_deep": "k_mplp_emit_deep", "mplp_len": "k_mplp_len_rm",
          "depth_fused": "k_depth_fused", "glf_cols": "k_glf_cols", "cons_col": "k_cons_col", "cons_walk": "k_cons_walk", "cons_read_a": "k_cons_read_a"}
 # gfx950 calibration (scripts/ubench/pmc_calib.hip, profiles/r04_pmc_calibration.md): kernels that read exactly 4 GiB from HBM
 # with 16 / 8 / 4 / 1 bytes per lane, temporal and non-temporal, all count FETCH_SIZE = 2 GiB (TCC_EA0_RDREQ = one request per 128 B

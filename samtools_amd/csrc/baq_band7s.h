@@ -67,16 +67,22 @@ template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { if (MODE >= 2) { d2 v = { 1e-
 template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { if (MODE >= 2) return; if (MODE) *p = v; else __builtin_nontemporal_store(v, p); }
 template <int MODE> BQS_HD int hot_row(int i) { return MODE == 3 ? 1 + (i & 7) : i; }
 BQS_HD double fmax_(double a, double b) { return __builtin_fmax(a, b); }
+BQS_HD void sched_fence() { __builtin_amdgcn_sched_barrier(0); }       // nothing is scheduled across this point
 #else
 BQS_HD bool wave_any(bool c) { return c; }
 template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { return *p; }
 template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { *p = v; }
 template <int MODE> BQS_HD int hot_row(int i) { return i; }
 BQS_HD double fmax_(double a, double b) { return fmax(a, b); }
+BQS_HD void sched_fence() {}
 #endif
 
 BQS_HD uint64_t d_bits(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
 BQS_HD double bits_d(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
+
+// element (row, lane) of a [row][lane] array of a slot: the slot pointers are wave-uniform, the index is 32 bits (one VGPR instead of a
+// 64-bit address per array)
+template <int LS> BQS_HD uint32_t at(int row, int ln) { return (uint32_t)row * (uint32_t)LS + (uint32_t)ln; }
 
 #define BQS_FLD(w, j) ((int)((uint32_t)((w) >> (3 * (j))) & 7u))
 
@@ -93,7 +99,7 @@ BQS_HD int qcode(int nib) { return nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : 
 
 // returns true when the window holds an ambiguous reference base (such a group takes the all-tests code in every row)
 template <int LS>
-BQS_HD bool pack_lane(int lq, int l_ref, const uint8_t *qual, const uint8_t *seq, const char *ref, const uint8_t *refc, uint32_t *IN)
+BQS_HD bool pack_lane(int lq, int l_ref, const uint8_t *qual, const uint8_t *seq, const char *ref, const uint8_t *refc, uint32_t *IN, int ln)
 {
     bool amb = false;
     for (int r = 1; r <= lq; ++r) {
@@ -103,7 +109,7 @@ BQS_HD bool pack_lane(int lq, int l_ref, const uint8_t *qual, const uint8_t *seq
         const int fc = rcode(ref, l_ref, r + BW - 1, refc), bc = rcode(ref, l_ref, r - BW - 1, refc);
         amb |= fc == 4 || bc == 4;
         const uint32_t w = q | (uint32_t)qcode(nib) << 8 | (uint32_t)fc << 11 | (uint32_t)bc << 14 | q << 24;
-        IN[(size_t)r * LS] = w;
+        IN[at<LS>(r, ln)] = w;
     }
     return amb;
 }
@@ -162,21 +168,21 @@ struct FwdState { double M[NB], I[NB], D[NB]; uint64_t rw; uint32_t w_next, w_ne
 
 // one row i >= 2: inputs, the row, its sum, the raw store of an odd row, the normalisation
 template <int LS, bool EDGE, int MODE>
-BQS_HD void fwd_step(const Par &p, int lq, int i, const uint32_t *IN, d2 *F2, double *S, const float *q2p, FwdState &f)
+BQS_HD void fwd_step(const Par &p, int lq, int i, const uint32_t *IN, d2 *F2, double *S, int ln, const float *q2p, FwdState &f)
 {
     const uint32_t w = f.w_next;
     f.w_next = f.w_next2;
-    if (i + 2 <= lq) f.w_next2 = IN[(size_t)hot_row<MODE>(i + 2) * LS];
+    if (i + 2 <= lq) f.w_next2 = IN[at<LS>(hot_row<MODE>(i + 2), ln)];
     f.rw = (f.rw >> 3) | ((uint64_t)((w >> 11) & 7u) << (3 * (NB - 1)));
     const Emis em = make_emis(w, f.rw, q2p);
     const double sum = fwd_row<EDGE>(p, em, f.rw, f.M, f.I, f.D);
     if (i & 1) {                          // raw (M, I) of an odd row; even rows are not stored
-        const size_t t = (size_t)((i - 1) >> 1) * NB;
+        const int t = ((i - 1) >> 1) * NB;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(&F2[(t + j) * LS], v); }
+        for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(&F2[at<LS>(t + j, ln)], v); }
     }
     const double inv = 1. / sum;
-    S[(size_t)i * LS] = i < lq ? inv : sum;      // rows below the top: 1 / s[i], the value the backward pass multiplies by (no division there)
+    S[at<LS>(i, ln)] = i < lq ? inv : sum;      // rows below the top: 1 / s[i], the value the backward pass multiplies by (no division there)
 #pragma unroll
     for (int j = 0; j < NB; ++j) { f.M[j] *= inv; f.I[j] *= inv; f.D[j] *= inv; }
 }
@@ -185,16 +191,16 @@ BQS_HD void fwd_step(const Par &p, int lq, int i, const uint32_t *IN, d2 *F2, do
 // 8 .. lq - 1 (all 15 cells inside the window) take the interior code.  Three loops, not a branch per row: a row body that exists
 // in two variants inside one loop doubles the live state at the join (measured: +130 spilled registers).
 template <int LS, int MODE = 0>
-BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2 *F2, double *S, const float *q2p)
+BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2 *F2, double *S, int ln, const float *q2p)
 {
     FwdState f;
     // band word of row 1: field j = code(j - BW): outside the window below cell BW, code(0..7) above = the lower-end codes of rows 8..15
     f.rw = 0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) f.rw |= (uint64_t)(j < BW ? 7u : ((IN[(size_t)(j + 1) * LS] >> 14) & 7u)) << (3 * j);
-    S[0] = 1.;
+    for (int j = 0; j < NB; ++j) f.rw |= (uint64_t)(j < BW ? 7u : ((IN[at<LS>(j + 1, ln)] >> 14) & 7u)) << (3 * j);
+    S[at<LS>(0, ln)] = 1.;
     {   // row 1 (no D state; the only row normalised by a division)
-        const uint32_t w = IN[(size_t)1 * LS];
+        const uint32_t w = IN[at<LS>(1, ln)];
         const Emis em = make_emis(w, f.rw, q2p);
         const double eibi = kEI * p.bI;
         double sum = 0.;
@@ -207,26 +213,26 @@ BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2
             f.M[j] = a; f.I[j] = b2; f.D[j] = 0.;
             sum += a + b2;
         }
-        S[(size_t)1 * LS] = 1. / sum;             // (row 1 itself is normalised by divisions; the backward step to row 1 multiplies by 1 / s[1])
+        S[at<LS>(1, ln)] = 1. / sum;             // (row 1 itself is normalised by divisions; the backward step to row 1 multiplies by 1 / s[1])
 #pragma unroll
         for (int j = 0; j < NB; ++j) { f.M[j] /= sum; f.I[j] /= sum; }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(&F2[(size_t)j * LS], v); }
+        for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(&F2[at<LS>(j, ln)], v); }
     }
-    f.w_next = IN[(size_t)2 * LS]; f.w_next2 = lq >= 3 ? IN[(size_t)3 * LS] : 0;
+    f.w_next = IN[at<LS>(2, ln)]; f.w_next2 = lq >= 3 ? IN[at<LS>(3, ln)] : 0;
     const int e1 = (all_edge || BQS_TEST_FORCE_EDGE) ? lq : BW;
     int i = 2;
 #pragma unroll 1
-    for (; i <= e1; ++i) fwd_step<LS, true, MODE>(p, lq, i, IN, F2, S, q2p, f);
+    for (; i <= e1; ++i) fwd_step<LS, true, MODE>(p, lq, i, IN, F2, S, ln, q2p, f);
 #pragma unroll 1
-    for (; i <= lq - 1; ++i) fwd_step<LS, false, MODE>(p, lq, i, IN, F2, S, q2p, f);
+    for (; i <= lq - 1; ++i) fwd_step<LS, false, MODE>(p, lq, i, IN, F2, S, ln, q2p, f);
 #pragma unroll 1
-    for (; i <= lq; ++i) fwd_step<LS, true, MODE>(p, lq, i, IN, F2, S, q2p, f);
+    for (; i <= lq; ++i) fwd_step<LS, true, MODE>(p, lq, i, IN, F2, S, ln, q2p, f);
     {   // s[l_query + 1]
         double sum = 0.;
 #pragma unroll
         for (int j = 0; j < NB; ++j) sum += f.M[j] * p.sM + f.I[j] * p.sI;
-        S[(size_t)(lq + 1) * LS] = sum;
+        S[at<LS>(lq + 1, ln)] = sum;
     }
 }
 
@@ -267,7 +273,7 @@ struct BwdCtx {
 // the result of row i: b (0 unless the MAP state is M on the read's diagonal), kept as a byte for the final pass, and the
 // working quality lowered to the right-hand limit
 template <int LS, class St>
-BQS_HD void finish_row(BwdCtx &c, int i, const MapAcc &a, uint32_t w, uint32_t *IN, St state)
+BQS_HD void finish_row(BwdCtx &c, int i, const MapAcc &a, uint32_t w, uint32_t *IN, int ln, St state)
 {
     const int q = i - 1;
     const int kq = map_quality(a.zs, a.sum);
@@ -278,7 +284,7 @@ BQS_HD void finish_row(BwdCtx &c, int i, const MapAcc &a, uint32_t w, uint32_t *
     const int lim = c.plain ? b : c.run_r;
     const int q0 = (int)(w >> 24);
     const int q1 = (in_m && q0 > lim) ? lim : q0;
-    IN[(size_t)i * LS] = (w & 0x00ffffffu) | ((uint32_t)q1 << 24);
+    IN[at<LS>(i, ln)] = (w & 0x00ffffffu) | ((uint32_t)q1 << 24);
 }
 
 // b[i] from b[i + 1] (in place), with the emissions of row i + 1 (band word rw1), then the division by s[i]
@@ -351,87 +357,90 @@ struct BwdState { double bM[NB], bI[NB]; uint64_t rw; uint32_t w_up; };
 // one pair (i even, i - 1 odd).  b.rw is the band word of row min(i + 2, lq) when a pair starts, b.w_up the input word of row i + 1
 // (of row lq for the first pair).
 template <int LS, bool EDGE, int MODE, class St>
-BQS_HD void bwd_pair(const Par &p, int lq, int l_ref, int i, uint32_t *IN, const d2 *F2, const double *S, const float *q2p, St state, BwdCtx &c, BwdState &b)
+BQS_HD void bwd_pair(const Par &p, int lq, int l_ref, int i, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, St state, BwdCtx &c, BwdState &b)
 {
-    const size_t t = (size_t)((i - 1) >> 1) * NB;
+    const int t = ((i - 1) >> 1) * NB;
     // the small inputs in FRONT of the thirty cell loads: the first thing the pair needs is 1 / s[i], and loads come back in order
-    const uint32_t w_i = IN[(size_t)hot_row<MODE>(i) * LS], w_o = IN[(size_t)hot_row<MODE>(i - 1) * LS];
-    const double s_i = S[(size_t)hot_row<MODE>(i) * LS], s_o = S[(size_t)hot_row<MODE>(i - 1) * LS];
+    const double s_i = S[at<LS>(hot_row<MODE>(i), ln)], s_o = S[at<LS>(hot_row<MODE>(i - 1), ln)];
+    const uint32_t w_i = IN[at<LS>(hot_row<MODE>(i), ln)], w_o = IN[at<LS>(hot_row<MODE>(i - 1), ln)];
     double Mp[NB], Ip[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) { const d2 v = ld_d2<MODE>(&F2[(t + j) * LS]); Mp[j] = v.x; Ip[j] = v.y; }
+    for (int j = 0; j < NB; ++j) { const d2 v = ld_d2<MODE>(&F2[at<LS>(t + j, ln)]); Mp[j] = v.x; Ip[j] = v.y; }
     // band words: row i + 1 (emissions of the step to row i) and row i (re-evaluation of row i, step to row i - 1)
     uint64_t rw1 = b.rw;
     if (!EDGE || i < lq - 1) rw1 = ((b.rw << 3) | (uint64_t)((b.w_up >> 14) & 7u)) & WORD_MASK;
-    uint64_t rw0 = rw1;
-    if (!EDGE || i < lq) rw0 = ((rw1 << 3) | (uint64_t)((w_i >> 14) & 7u)) & WORD_MASK;
     const double inv_i = (EDGE && i >= lq) ? 1. / s_i : s_i;       // S[] holds 1 / s[row] below the top row, s[lq] itself for the top row
     const bool row1 = EDGE && i == 2;           // row 1 is stored normalised and has no D state
     const double inv_s = s_o;                   // the backward step to row i - 1 multiplies by 1 / s[i - 1] whatever the row
     const double inv_o = row1 ? 1. : inv_s;
-    const Emis em0 = make_emis(w_i, rw0, q2p);
     if (!EDGE || i < lq) { const Emis em1 = make_emis(b.w_up, rw1, q2p); bwd_apply<EDGE>(p, em1, rw1, i, inv_i, b.bM, b.bI); }
+    // the emissions of row i only now: they hang on w_i, which was asked for at the top of this pair -- computed up there (where the
+    // compiler would put them) the wave waits a whole memory round trip before its first fp64 instruction
+    sched_fence();
+    uint64_t rw0 = rw1;
+    if (!EDGE || i < lq) rw0 = ((rw1 << 3) | (uint64_t)((w_i >> 14) & 7u)) & WORD_MASK;
+    const Emis em0 = make_emis(w_i, rw0, q2p);
     MapAcc a;
     double pm = 0., pd = 0.;
     a.init();
     EvenCell<EDGE, 0>::run(p, em0, rw0, i, l_ref, inv_o, inv_i, row1 ? 0. : p.m2, row1 ? 0. : p.m8, Mp, Ip, b.bM, b.bI, pm, pd, a);
-    finish_row<LS>(c, i, a, w_i, IN, state);
+    finish_row<LS>(c, i, a, w_i, IN, ln, state);
     bwd_apply<EDGE>(p, em0, rw0, i - 1, inv_s, b.bM, b.bI);
     map_row(a, Mp, Ip, b.bM, b.bI);
-    finish_row<LS>(c, i - 1, a, w_o, IN, state);
+    finish_row<LS>(c, i - 1, a, w_o, IN, ln, state);
     b.rw = rw0; b.w_up = w_o;
 }
 
 // all_edge as in fwd_lane.  Otherwise the pairs with 10 <= i <= lq - 2 (rows i - 1 .. i + 1 have all cells inside the window)
 // take the interior code: loops, not a branch per pair.
 template <int LS, int MODE = 0, class St>
-BQS_HD void bwd_lane(const Par &p, int lq, int l_ref, bool all_edge, uint32_t *IN, const d2 *F2, const double *S, const float *q2p, St state, BwdCtx &c)
+BQS_HD void bwd_lane(const Par &p, int lq, int l_ref, bool all_edge, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, St state, BwdCtx &c)
 {
     BwdState b;
     // band word of row lq: field j = code(lq - BW - 1 + j) = the upper-end code of row lq - 2 BW + j
     b.rw = 0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) b.rw |= (uint64_t)((IN[(size_t)(lq - 2 * BW + j) * LS] >> 11) & 7u) << (3 * j);
-    const double s_top = S[(size_t)lq * LS];
+    for (int j = 0; j < NB; ++j) b.rw |= (uint64_t)((IN[at<LS>(lq - 2 * BW + j, ln)] >> 11) & 7u) << (3 * j);
+    const double s_top = S[at<LS>(lq, ln)];
     {
-        const double sl1 = S[(size_t)(lq + 1) * LS];
+        const double sl1 = S[at<LS>(lq + 1, ln)];
         const double vM = p.sM / s_top / sl1, vI = p.sI / s_top / sl1;
 #pragma unroll
         for (int j = 0; j < NB; ++j) { const bool valid = BQS_FLD(b.rw, j) != 7; b.bM[j] = valid ? vM : 0.; b.bI[j] = valid ? vI : 0.; }
     }
     c.run_r = 0;
     int i = lq;
-    b.w_up = IN[(size_t)lq * LS];
+    b.w_up = IN[at<LS>(lq, ln)];
     if (lq & 1) {
         // the top row is odd: stored raw, on its own
-        const size_t t = (size_t)((lq - 1) >> 1) * NB;
+        const int t = ((lq - 1) >> 1) * NB;
         const double inv = 1. / s_top;
         double fM[NB], fI[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { const d2 v = ld_d2<MODE>(&F2[(t + j) * LS]); fM[j] = v.x * inv; fI[j] = v.y * inv; }
+        for (int j = 0; j < NB; ++j) { const d2 v = ld_d2<MODE>(&F2[at<LS>(t + j, ln)]); fM[j] = v.x * inv; fI[j] = v.y * inv; }
         MapAcc a; map_row(a, fM, fI, b.bM, b.bI);
-        finish_row<LS>(c, lq, a, b.w_up, IN, state);
+        finish_row<LS>(c, lq, a, b.w_up, IN, ln, state);
         --i;
     }
     const bool ae = all_edge || BQS_TEST_FORCE_EDGE;
     const int hi = ae ? 0 : lq - 2, lo = ae ? 2 : BW + 3;          // interior pairs: lo <= i <= hi
 #pragma unroll 1
-    for (; i >= 2 && i > hi; i -= 2) bwd_pair<LS, true, MODE>(p, lq, l_ref, i, IN, F2, S, q2p, state, c, b);
+    for (; i >= 2 && i > hi; i -= 2) bwd_pair<LS, true, MODE>(p, lq, l_ref, i, IN, F2, S, ln, q2p, state, c, b);
 #pragma unroll 1
-    for (; i >= lo && !ae; i -= 2) bwd_pair<LS, false, MODE>(p, lq, l_ref, i, IN, F2, S, q2p, state, c, b);
+    for (; i >= lo && !ae; i -= 2) bwd_pair<LS, false, MODE>(p, lq, l_ref, i, IN, F2, S, ln, q2p, state, c, b);
 #pragma unroll 1
-    for (; i >= 2; i -= 2) bwd_pair<LS, true, MODE>(p, lq, l_ref, i, IN, F2, S, q2p, state, c, b);
+    for (; i >= 2; i -= 2) bwd_pair<LS, true, MODE>(p, lq, l_ref, i, IN, F2, S, ln, q2p, state, c, b);
 }
 
 // the left-hand running maximum (realn.c's extended BAQ: bq = min(left, right) inside the M operation) and the qualities' way home
 template <int LS, class St>
-BQS_HD void final_lane(int lq, const uint32_t *IN, St state, const BwdCtx &c, uint8_t *qual)
+BQS_HD void final_lane(int lq, const uint32_t *IN, int ln, St state, const BwdCtx &c, uint8_t *qual)
 {
     int run = 0;
     for (int q = c.ys; q < c.ys + c.mlen; ++q) {
         const int b = state[(size_t)q * LS];
         run = b > run ? b : run;
-        const int q1 = (int)(IN[(size_t)(q + 1) * LS] >> 24);
+        const int q1 = (int)(IN[at<LS>(q + 1, ln)] >> 24);
         qual[q] = (uint8_t)((!c.plain && q1 > run) ? run : q1);
     }
 }

@@ -967,9 +967,10 @@ __device__ __forceinline__ Baq7sSlot baq7s_slot(uint8_t *scratch, size_t slot_by
 {
     uint8_t *b = scratch + (size_t)idx * slot_bytes;
     Baq7sSlot s;
-    s.IN = reinterpret_cast<uint32_t *>(b) + lane;
-    s.F2 = reinterpret_cast<baq7s::d2 *>(b + baq7s_in_bytes(lq_cap)) + lane;
-    s.S = reinterpret_cast<double *>(b + baq7s_in_bytes(lq_cap) + baq7s_f2_bytes(lq_cap)) + lane;
+    (void)lane;             // the slot pointers stay wave-uniform: the lane goes into the 32-bit element index (baq7s::at)
+    s.IN = reinterpret_cast<uint32_t *>(b);
+    s.F2 = reinterpret_cast<baq7s::d2 *>(b + baq7s_in_bytes(lq_cap));
+    s.S = reinterpret_cast<double *>(b + baq7s_in_bytes(lq_cap) + baq7s_f2_bytes(lq_cap));
     return s;
 }
 
@@ -1020,9 +1021,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     baq7s::Par p = baq7s::make_par(lq, lq + 6);
                     p.m0 = baq_uni(p.m0); p.m1 = baq_uni(p.m1); p.m2 = baq_uni(p.m2); p.m3 = baq_uni(p.m3); p.m4 = baq_uni(p.m4);
                     p.m6 = baq_uni(p.m6); p.m8 = baq_uni(p.m8); p.sM = baq_uni(p.sM); p.sI = baq_uni(p.sI); p.bM = baq_uni(p.bM); p.bI = baq_uni(p.bI);
-                    const bool amb = baq7s::pack_lane<64>(lq, lq + 6, d.qual, d.seq, W.ref + d.sh.xb, refc, sl.IN);
+                    const bool amb = baq7s::pack_lane<64>(lq, lq + 6, d.qual, d.seq, W.ref + d.sh.xb, refc, sl.IN, lane);
                     all_edge = baq7s::wave_any(amb);
-                    baq7s::fwd_lane<64, MODE>(p, lq, all_edge, sl.IN, sl.F2, sl.S, q2p);
+                    baq7s::fwd_lane<64, MODE>(p, lq, all_edge, sl.IN, sl.F2, sl.S, lane, q2p);
                 }
                 all_edge = __ballot(all_edge) != 0;
                 const int64_t tag = g | ((int64_t)cur << 62) | ((int64_t)(all_edge ? 1 : 0) << 61);
@@ -1048,8 +1049,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 p.m6 = baq_uni(p.m6); p.m8 = baq_uni(p.m8); p.sM = baq_uni(p.sM); p.sI = baq_uni(p.sI);
                 p.eim1 = baq_uni(p.eim1); p.eim4 = baq_uni(p.eim4);
                 baq7s::BwdCtx c; c.ys = d.sh.ys; c.mlen = d.sh.mlen; c.run_r = 0; c.plain = W.baq_plain != 0;
-                baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, q2p, state, c);
-                baq7s::final_lane<64>(lq, sl.IN, state, c, d.qual);
+                baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, lane, q2p, state, c);
+                baq7s::final_lane<64>(lq, sl.IN, lane, state, c, d.qual);
             }
         } else if (!have) break;
     }

@@ -119,7 +119,7 @@ def test_concurrent_fetches_under_thread_sanitizer(tmp_path):
     csrc = os.path.join(os.path.dirname(here), "samtools_amd", "csrc")
     exe = str(tmp_path / "fasta_threads")
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe,
-                    os.path.join(here, "cpu", "fasta_threads.cpp"), os.path.join(csrc, "host_io.cpp"), os.path.join(csrc, "host_bgzf.cpp"),
+                    os.path.join(here, "cpu", "fasta_threads.cpp"), os.path.join(here, "cpu", "pinned_stub.cpp"), os.path.join(csrc, "host_io.cpp"), os.path.join(csrc, "host_bgzf.cpp"),
                     os.path.join(csrc, "host_inflate.cpp"), "-lz", "-pthread"], check=True)
     rnd = random.Random(3)
     contigs = [("s%d" % i, rand_seq(rnd, rnd.randint(100, 120000))) for i in range(12)]

@@ -62,9 +62,11 @@ BQS_HD Par make_par(int lq, int l_ref)
 #if defined(__HIP_DEVICE_COMPILE__)
 BQS_HD bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
 // MODE: 0 = non-temporal row stream, 1 = plain loads / stores; diagnostics with wrong results: 2 = no row stream at all (the
-// arithmetic and the small per-row inputs), 3 = 2 with the small inputs taken from a handful of cache-hot rows
-template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { if (MODE >= 2) { d2 v = { 1e-3, 1e-3 }; return v; } return MODE ? *p : __builtin_nontemporal_load(p); }
-template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { if (MODE >= 2) return; if (MODE) *p = v; else __builtin_nontemporal_store(v, p); }
+// arithmetic and the small per-row inputs), 3 = 2 with the small inputs taken from a handful of cache-hot rows; 4, 5, 6: scheduling
+// experiments with right results (4: the backward step's scaling fenced behind its chain; 5: 4 + the pair's phases fenced apart; 6: the
+// forward pass fetches its row words four rows ahead; 7: plain stores + non-temporal loads; 8: non-temporal stores + plain loads)
+template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { if (MODE == 2 || MODE == 3) { d2 v = { 1e-3, 1e-3 }; return v; } return (MODE == 1 || MODE == 8) ? *p : __builtin_nontemporal_load(p); }
+template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { if (MODE == 2 || MODE == 3) return; if (MODE == 1 || MODE == 7) *p = v; else __builtin_nontemporal_store(v, p); }
 template <int MODE> BQS_HD int hot_row(int i) { return MODE == 3 ? 1 + (i & 7) : i; }
 BQS_HD double fmax_(double a, double b) { return __builtin_fmax(a, b); }
 BQS_HD void sched_fence() { __builtin_amdgcn_sched_barrier(0); }       // nothing is scheduled across this point
@@ -164,7 +166,7 @@ BQS_HD double fwd_row(const Par &p, const Emis &em, uint64_t rw, double (&M)[NB]
     return sum;
 }
 
-struct FwdState { double M[NB], I[NB], D[NB]; uint64_t rw; uint32_t w_next, w_next2; };
+struct FwdState { double M[NB], I[NB], D[NB]; uint64_t rw; uint32_t w_next, w_next2, w_next3, w_next4; };
 
 // one row i >= 2: inputs, the row, its sum, the raw store of an odd row, the normalisation
 template <int LS, bool EDGE, int MODE>
@@ -172,7 +174,10 @@ BQS_HD void fwd_step(const Par &p, int lq, int i, const uint32_t *IN, d2 *F2, do
 {
     const uint32_t w = f.w_next;
     f.w_next = f.w_next2;
-    if (i + 2 <= lq) f.w_next2 = IN[at<LS>(hot_row<MODE>(i + 2), ln)];
+    if (MODE == 6) {                          // experiment: four rows ahead
+        f.w_next2 = f.w_next3; f.w_next3 = f.w_next4;
+        if (i + 4 <= lq) f.w_next4 = IN[at<LS>(i + 4, ln)];
+    } else if (i + 2 <= lq) f.w_next2 = IN[at<LS>(hot_row<MODE>(i + 2), ln)];
     f.rw = (f.rw >> 3) | ((uint64_t)((w >> 11) & 7u) << (3 * (NB - 1)));
     const Emis em = make_emis(w, f.rw, q2p);
     const double sum = fwd_row<EDGE>(p, em, f.rw, f.M, f.I, f.D);
@@ -220,6 +225,7 @@ BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2
         for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(&F2[at<LS>(j, ln)], v); }
     }
     f.w_next = IN[at<LS>(2, ln)]; f.w_next2 = lq >= 3 ? IN[at<LS>(3, ln)] : 0;
+    f.w_next3 = (MODE == 6 && lq >= 4) ? IN[at<LS>(4, ln)] : 0; f.w_next4 = (MODE == 6 && lq >= 5) ? IN[at<LS>(5, ln)] : 0;
     const int e1 = (all_edge || BQS_TEST_FORCE_EDGE) ? lq : BW;
     int i = 2;
 #pragma unroll 1
@@ -288,7 +294,7 @@ BQS_HD void finish_row(BwdCtx &c, int i, const MapAcc &a, uint32_t w, uint32_t *
 }
 
 // b[i] from b[i + 1] (in place), with the emissions of row i + 1 (band word rw1), then the division by s[i]
-template <bool EDGE>
+template <bool EDGE, int MODE = 0>
 BQS_HD void bwd_apply(const Par &p, const Emis &em, uint64_t rw1, int i, double inv_i, double (&bM)[NB], double (&bI)[NB])
 {
     double dnext = 0.;
@@ -304,6 +310,7 @@ BQS_HD void bwd_apply(const Par &p, const Emis &em, uint64_t rw1, int i, double 
         bM[j] = bm; bI[j] = bi_;
         dnext = bd;
     }
+    if (MODE == 4 || MODE == 5) sched_fence();      // experiment: 1 / s[i] (a load of this pair) is first needed here, not a hundred instructions in
 #pragma unroll
     for (int j = 0; j < NB; ++j) { bM[j] *= inv_i; bI[j] *= inv_i; }
     if (EDGE && i <= BW) {                  // cells with k < 1 do not exist in the reference: keep them at zero
@@ -373,7 +380,7 @@ BQS_HD void bwd_pair(const Par &p, int lq, int l_ref, int i, uint32_t *IN, const
     const bool row1 = EDGE && i == 2;           // row 1 is stored normalised and has no D state
     const double inv_s = s_o;                   // the backward step to row i - 1 multiplies by 1 / s[i - 1] whatever the row
     const double inv_o = row1 ? 1. : inv_s;
-    if (!EDGE || i < lq) { const Emis em1 = make_emis(b.w_up, rw1, q2p); bwd_apply<EDGE>(p, em1, rw1, i, inv_i, b.bM, b.bI); }
+    if (!EDGE || i < lq) { const Emis em1 = make_emis(b.w_up, rw1, q2p); bwd_apply<EDGE, MODE>(p, em1, rw1, i, inv_i, b.bM, b.bI); }
     // the emissions of row i only now: they hang on w_i, which was asked for at the top of this pair -- computed up there (where the
     // compiler would put them) the wave waits a whole memory round trip before its first fp64 instruction
     sched_fence();
@@ -384,8 +391,11 @@ BQS_HD void bwd_pair(const Par &p, int lq, int l_ref, int i, uint32_t *IN, const
     double pm = 0., pd = 0.;
     a.init();
     EvenCell<EDGE, 0>::run(p, em0, rw0, i, l_ref, inv_o, inv_i, row1 ? 0. : p.m2, row1 ? 0. : p.m8, Mp, Ip, b.bM, b.bI, pm, pd, a);
+    if (MODE == 5) sched_fence();
     finish_row<LS>(c, i, a, w_i, IN, ln, state);
-    bwd_apply<EDGE>(p, em0, rw0, i - 1, inv_s, b.bM, b.bI);
+    if (MODE == 5) sched_fence();
+    bwd_apply<EDGE, MODE>(p, em0, rw0, i - 1, inv_s, b.bM, b.bI);
+    if (MODE == 5) sched_fence();
     map_row(a, Mp, Ip, b.bM, b.bI);
     finish_row<LS>(c, i - 1, a, w_o, IN, ln, state);
     b.rw = rw0; b.w_up = w_o;

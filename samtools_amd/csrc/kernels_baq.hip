@@ -1092,6 +1092,7 @@ void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, v
     static const int mode = [] { const char *e = getenv("STA_BAQ7S_MODE"); return e ? atoi(e) : 0; }();
 #define BAQ7S_LAUNCH(M) hipLaunchKernelGGL(k_baq7s<M>, dim3((unsigned)waves), dim3(64), (size_t)rows * 64, s, r, w, g_tables, ngroups, (unsigned *)scratch, \
                                            (uint8_t *)scratch + 256, baq7s_slot_bytes(lq_cap), lq_cap, lead)
-    if (mode == 1) BAQ7S_LAUNCH(1); else if (mode == 2) BAQ7S_LAUNCH(2); else if (mode == 3) BAQ7S_LAUNCH(3); else BAQ7S_LAUNCH(0);
+    if (mode == 1) BAQ7S_LAUNCH(1); else if (mode == 2) BAQ7S_LAUNCH(2); else if (mode == 3) BAQ7S_LAUNCH(3); else if (mode == 4) BAQ7S_LAUNCH(4);
+    else if (mode == 5) BAQ7S_LAUNCH(5); else if (mode == 6) BAQ7S_LAUNCH(6); else if (mode == 7) BAQ7S_LAUNCH(7); else if (mode == 8) BAQ7S_LAUNCH(8); else BAQ7S_LAUNCH(0);
 #undef BAQ7S_LAUNCH
 }

@@ -14,10 +14,12 @@
 //
 // One lane per read.  Per wave ("slot") scratch in HBM, [row][lane] so that a wave access is one contiguous run:
 //     IN  uint32 [lq_cap + 2][64]   packed per-row inputs (see pack_lane)
-//     F2  (M, I) pairs of doubles [pairs][15][64]: the RAW forward cells of the ODD rows only (row 1: normalised)
+//     F2  (M, I) pairs of doubles [stored rows][15][64]: the RAW forward cells of every THIRD row only (rows 1, 4, 7, ...; row 1: normalised)
 //     S   double [lq_cap + 2][64]   the forward row sums s[0 .. lq + 1]
-// The forward pass stores odd rows only; the backward pass re-normalises them, re-runs their D chain and re-evaluates the even
-// row above with the forward pass's own expressions (same scheme as k_baq_bwd<7, 2> in kernels_baq.hip).
+// The forward pass stores one row of three; the backward pass re-normalises it, re-runs its D chain and re-evaluates the two rows above
+// it with the forward pass's own expressions (the scheme of k_baq_bwd<7, 2> in kernels_baq.hip -- one row of two there -- taken one row
+// further: 80 + 8 + 8 instead of 120 + 8 + 8 bytes per query base and pass, for 8 % more vector instructions).  The middle row's
+// normalised (M, I) wait for their own MAP step in LDS, [cell][lane] (15 KB per wave); the rows' results ride in their input words.
 #pragma once
 #include <stdint.h>
 #include <math.h>
@@ -93,6 +95,7 @@ template <int LS> BQS_HD uint32_t at(int row, int ln) { return (uint32_t)row * (
 //   bits  8..10  query code 0..3, 4 = anything else
 //   bits 11..13  reference code entering the band at its upper end in row r  = code(r + BW - 1)   (forward pass)
 //   bits 14..16  reference code entering the band at its lower end in row r  = code(r - BW - 1)   (backward pass)
+//   bits 17..23  b of the row (backward pass): the MAP quality if the MAP state is M on the read's diagonal, else 0
 //   bits 24..31  the quality being worked on: the backward pass lowers it to the right-hand running maximum, the final
 //                pass to the left-hand one
 // code(idx): 0..3 = A C G T, 4 = ambiguous, 7 = idx outside [0, l_ref)
@@ -181,8 +184,8 @@ BQS_HD void fwd_step(const Par &p, int lq, int i, const uint32_t *IN, d2 *F2, do
     f.rw = (f.rw >> 3) | ((uint64_t)((w >> 11) & 7u) << (3 * (NB - 1)));
     const Emis em = make_emis(w, f.rw, q2p);
     const double sum = fwd_row<EDGE>(p, em, f.rw, f.M, f.I, f.D);
-    if (i & 1) {                          // raw (M, I) of an odd row; even rows are not stored
-        const int t = ((i - 1) >> 1) * NB;
+    if ((i - 1) % 3 == 0) {               // raw (M, I) of one row of three (rows 4, 7, ...); the others are not stored
+        const int t = ((i - 1) / 3) * NB;
 #pragma unroll
         for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(&F2[at<LS>(t + j, ln)], v); }
     }
@@ -276,21 +279,20 @@ struct BwdCtx {
     bool plain;             // per-base BAQ (calmd -r without -E): no running maxima
 };
 
-// the result of row i: b (0 unless the MAP state is M on the read's diagonal), kept as a byte for the final pass, and the
+// the result of row i: b (0 unless the MAP state is M on the read's diagonal), kept in the row's word for the final pass, and the
 // working quality lowered to the right-hand limit
-template <int LS, class St>
-BQS_HD void finish_row(BwdCtx &c, int i, const MapAcc &a, uint32_t w, uint32_t *IN, int ln, St state)
+template <int LS>
+BQS_HD void finish_row(BwdCtx &c, int i, const MapAcc &a, uint32_t w, uint32_t *IN, int ln)
 {
     const int q = i - 1;
     const int kq = map_quality(a.zs, a.sum);
     const bool in_m = q >= c.ys && q < c.ys + c.mlen;
-    const int b = (in_m && !a.kill && a.zs > 0.) ? kq : 0;
-    state[(size_t)q * LS] = (uint8_t)b;
+    const int b = (in_m && !a.kill && a.zs > 0.) ? kq : 0;      // 0 .. 99
     c.run_r = b > c.run_r ? b : c.run_r;                  // (b is 0 outside the M operation: no effect there)
     const int lim = c.plain ? b : c.run_r;
     const int q0 = (int)(w >> 24);
     const int q1 = (in_m && q0 > lim) ? lim : q0;
-    IN[at<LS>(i, ln)] = (w & 0x00ffffffu) | ((uint32_t)q1 << 24);
+    IN[at<LS>(i, ln)] = (w & 0x0001ffffu) | ((uint32_t)b << 17) | ((uint32_t)q1 << 24);
 }
 
 // b[i] from b[i + 1] (in place), with the emissions of row i + 1 (band word rw1), then the division by s[i]
@@ -329,128 +331,185 @@ BQS_HD void map_row(MapAcc &a, const double (&fM)[NB], const double (&fI)[NB], c
 #undef BQS_MAP_CELL
 }
 
-// The even row i from the odd row i - 1 below it, fused with the even row's MAP terms.  (Mp, Ip): the RAW cells of row i - 1
-// as stored (row 1: normalised); on return they are that row's normalised (M, I).  inv_o = 1 / s[i - 1], inv_i = 1 / s[i];
-// em / rw: emissions and band word of row i.
-template <bool EDGE, int J> struct EvenCell {
-    static BQS_HD void run(const Par &p, const Emis &em, uint64_t rw, int i, int l_ref, double inv_o, double inv_i, double m2o, double m8o,
-                           double (&Mp)[NB], double (&Ip)[NB], const double (&bM)[NB], const double (&bI)[NB], double &pm, double &pd, MapAcc &a)
+// MAP of a row whose normalised (M, I) come back from LDS (the middle row of a group)
+template <int LS, class Ld>
+BQS_HD void map_row_lds(MapAcc &a, Ld Ln, const double (&bM)[NB], const double (&bI)[NB])
+{
+    a.init();
+#define BQS_MAP_CELL(j) { const d2 v = Ln[(j) * LS]; a.template add<2 * (j)>(v.x * bM[j]); a.template add<2 * (j) + 1>(v.y * bI[j]); }
+    BQS_MAP_CELL(0) BQS_MAP_CELL(1) BQS_MAP_CELL(2) BQS_MAP_CELL(3) BQS_MAP_CELL(4) BQS_MAP_CELL(5) BQS_MAP_CELL(6) BQS_MAP_CELL(7)
+    BQS_MAP_CELL(8) BQS_MAP_CELL(9) BQS_MAP_CELL(10) BQS_MAP_CELL(11) BQS_MAP_CELL(12) BQS_MAP_CELL(13) BQS_MAP_CELL(14)
+#undef BQS_MAP_CELL
+}
+
+// A group of rows (a, a + 1 [, a + 2]); row a is the stored one.  One ascending sweep over the cells, skewed by one cell:
+//   step J   row a     : its D chain re-run from the raw cells, cell J normalised (kept in Mp / Ip for the row's own MAP step);
+//            row a + 1 : M and D of cell J, I of cell J - 1, with the forward pass's expressions on the normalised row a (raw, then x 1 / s[a + 1]);
+//                        cell J - 1 is complete with that I: with ROWS == 3 it goes to LDS (Ln) for the row's own MAP step, with ROWS == 2 its MAP
+//                        terms are taken at once;
+//            row a + 2 : (ROWS == 3) M of cell J - 1 and I of cell J - 2 from the complete cell J - 1 of row a + 1, and their MAP terms
+//                        at once, in the order M0, I0, M1, I1, ... of probaln_glocal -- the top row of the group is never held.
+// e1 / rw_1: emissions and band word of row a + 1; e2 / rw_2: of row a + 2; inv_a: 1 / s[a] (1 for row 1, which is stored normalised and has
+// no D state: m2o = m8o = 0); inv1 = 1 / s[a + 1], inv2 = 1 / s[a + 2]; bM / bI: b of the group's top row.
+template <bool EDGE, int ROWS, int J> struct GroupCell {
+    template <int LS, class Ld>
+    static BQS_HD void run(const Par &p, const Emis &e1, uint64_t rw_1, const Emis &e2, uint64_t rw_2, int a, int l_ref, double inv_a, double inv1, double inv2,
+                           double m2o, double m8o, double (&Mp)[NB], double (&Ip)[NB], Ld Ln, const double (&bM)[NB], const double (&bI)[NB],
+                           double &pm, double &pd, double &q1m, double &q1d, double &cM, double &cD, MapAcc &acc)
     {
-        double fd = m2o * pm + m8o * pd;
-        if (EDGE) { const int idx = i - 1 - BW - 1 + J; fd = (idx < 0 || idx >= l_ref) ? 0. : fd; }
-        pm = Mp[J]; pd = fd;
-        const double Mn = Mp[J] * inv_o, In = Ip[J] * inv_o, Dn = fd * inv_o;
-        Mp[J] = Mn; Ip[J] = In;
-        if (J > 0) {
-            const double fi = (kEI * (p.m1 * Mn + p.m4 * In)) * inv_i;             // the forward pass's I[i][J - 1]
-            a.template add<2 * (J > 0 ? J - 1 : 0) + 1>(fi * bI[J > 0 ? J - 1 : 0]);
+        double i1_prev = 0., M1n = 0., D1n = 0., M1r = 0., D1r = 0.;
+        if (J < NB) {
+            double fd = m2o * pm + m8o * pd;
+            if (EDGE) { const int idx = a - BW - 1 + J; fd = (idx < 0 || idx >= l_ref) ? 0. : fd; }
+            pm = Mp[J < NB ? J : 0]; pd = fd;
+            const double Mn = Mp[J < NB ? J : 0] * inv_a, In = Ip[J < NB ? J : 0] * inv_a, Dn = fd * inv_a;
+            Mp[J < NB ? J : 0] = Mn; Ip[J < NB ? J : 0] = In;
+            if (J > 0) i1_prev = (kEI * (p.m1 * Mn + p.m4 * In)) * inv1;                 // the forward pass's I[a + 1][J - 1]
+            const double e = emis_cell<EDGE>(e1, rw_1, J < NB ? J : 0);
+            M1r = e * (p.m0 * Mn + p.m3 * In + p.m6 * Dn);                                // the forward pass's raw M[a + 1][J] ...
+            D1r = p.m2 * q1m + p.m8 * q1d;                                                 // ... and raw D[a + 1][J]
+            if (EDGE) D1r = BQS_FLD(rw_1, J < NB ? J : 0) == 7 ? 0. : D1r;
+            M1n = M1r * inv1; D1n = D1r * inv1;
         }
-        const double e = emis_cell<EDGE>(em, rw, J);
-        const double fm = (e * (p.m0 * Mn + p.m3 * In + p.m6 * Dn)) * inv_i;        // the forward pass's M[i][J]
-        a.template add<2 * J>(fm * bM[J]);
-        EvenCell<EDGE, J + 1>::run(p, em, rw, i, l_ref, inv_o, inv_i, m2o, m8o, Mp, Ip, bM, bI, pm, pd, a);
+        if (J > 0) {
+            constexpr int C = J > 0 ? J - 1 : 0;                                           // the cell of row a + 1 that is complete now
+            const double I1n = J < NB ? i1_prev : 0. * inv1;                               // (I of the last cell: 0, scaled like every other)
+            if (ROWS == 3) {
+                { d2 v = { cM, I1n }; Ln[C * LS] = v; }
+                if (C > 0) {
+                    const double fi2 = (kEI * (p.m1 * cM + p.m4 * I1n)) * inv2;           // the forward pass's I[a + 2][C - 1]
+                    acc.template add<2 * (C > 0 ? C - 1 : 0) + 1>(fi2 * bI[C > 0 ? C - 1 : 0]);
+                }
+                const double e = emis_cell<EDGE>(e2, rw_2, C);
+                const double fm2 = (e * (p.m0 * cM + p.m3 * I1n + p.m6 * cD)) * inv2;     // the forward pass's M[a + 2][C]
+                acc.template add<2 * C>(fm2 * bM[C]);
+            } else {
+                acc.template add<2 * C>(cM * bM[C]);
+                acc.template add<2 * C + 1>(I1n * bI[C]);
+            }
+        }
+        if (J < NB) { q1m = M1r; q1d = D1r; cM = M1n; cD = D1n; }
+        GroupCell<EDGE, ROWS, J + 1>::template run<LS>(p, e1, rw_1, e2, rw_2, a, l_ref, inv_a, inv1, inv2, m2o, m8o, Mp, Ip, Ln, bM, bI, pm, pd, q1m, q1d, cM, cD, acc);
     }
 };
-template <bool EDGE> struct EvenCell<EDGE, NB> {
-    static BQS_HD void run(const Par &, const Emis &, uint64_t, int, int, double, double, double, double, double (&)[NB], double (&)[NB],
-                           const double (&)[NB], const double (&bI)[NB], double &, double &, MapAcc &a)
+template <bool EDGE, int ROWS> struct GroupCell<EDGE, ROWS, NB + 1> {
+    template <int LS, class Ld>
+    static BQS_HD void run(const Par &, const Emis &, uint64_t, const Emis &, uint64_t, int, int, double, double, double, double, double, double (&)[NB], double (&)[NB], Ld,
+                           const double (&)[NB], const double (&bI)[NB], double &, double &, double &, double &, double &, double &, MapAcc &acc)
     {
-        a.template add<2 * (NB - 1) + 1>(0. * bI[NB - 1]);      // I[i][NB - 1] = 0: the last term of the row
+        if (ROWS == 3) acc.template add<2 * (NB - 1) + 1>(0. * bI[NB - 1]);      // I[a + 2][NB - 1] = 0: the last term of the row
     }
 };
 
 struct BwdState { double bM[NB], bI[NB]; uint64_t rw; uint32_t w_up; };
 
-// one pair (i even, i - 1 odd).  b.rw is the band word of row min(i + 2, lq) when a pair starts, b.w_up the input word of row i + 1
-// (of row lq for the first pair).
-template <int LS, bool EDGE, int MODE, class St>
-BQS_HD void bwd_pair(const Par &p, int lq, int l_ref, int i, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, St state, BwdCtx &c, BwdState &b)
+BQS_HD uint64_t word_down(uint64_t rw, uint32_t w) { return ((rw << 3) | (uint64_t)((w >> 14) & 7u)) & WORD_MASK; }      // band word of the row below, given that row's input word
+
+// One group: the stored row a and the ROWS - 1 rows above it.  b.rw is the band word of row a + ROWS (of row lq when that is beyond the read: the
+// group is the topmost and its top row IS row lq), b.w_up the input word of that row.
+template <int LS, bool EDGE, int ROWS, int MODE, class Ld>
+BQS_HD void bwd_group(const Par &p, int lq, int l_ref, int a, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, Ld Ln, BwdCtx &c, BwdState &b)
 {
-    const int t = ((i - 1) >> 1) * NB;
-    // the small inputs in FRONT of the thirty cell loads: the first thing the pair needs is 1 / s[i], and loads come back in order
-    const double s_i = S[at<LS>(hot_row<MODE>(i), ln)], s_o = S[at<LS>(hot_row<MODE>(i - 1), ln)];
-    const uint32_t w_i = IN[at<LS>(hot_row<MODE>(i), ln)], w_o = IN[at<LS>(hot_row<MODE>(i - 1), ln)];
+    const int top = a + ROWS - 1;
+    // the small inputs in front of the cell loads: loads come back in order
+    const double s_top = S[at<LS>(hot_row<MODE>(top), ln)], s_a = S[at<LS>(hot_row<MODE>(a), ln)];
+    const double s_mid = ROWS == 3 ? S[at<LS>(hot_row<MODE>(a + 1), ln)] : 0.;
+    const uint32_t w_top = IN[at<LS>(hot_row<MODE>(top), ln)], w_a = IN[at<LS>(hot_row<MODE>(a), ln)];
+    const uint32_t w_mid = ROWS == 3 ? IN[at<LS>(hot_row<MODE>(a + 1), ln)] : 0u;
+    const int t = ((a - 1) / 3) * NB;
     double Mp[NB], Ip[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) { const d2 v = ld_d2<MODE>(&F2[at<LS>(t + j, ln)]); Mp[j] = v.x; Ip[j] = v.y; }
-    // band words: row i + 1 (emissions of the step to row i) and row i (re-evaluation of row i, step to row i - 1)
-    uint64_t rw1 = b.rw;
-    if (!EDGE || i < lq - 1) rw1 = ((b.rw << 3) | (uint64_t)((b.w_up >> 14) & 7u)) & WORD_MASK;
-    const double inv_i = (EDGE && i >= lq) ? 1. / s_i : s_i;       // S[] holds 1 / s[row] below the top row, s[lq] itself for the top row
-    const bool row1 = EDGE && i == 2;           // row 1 is stored normalised and has no D state
-    const double inv_s = s_o;                   // the backward step to row i - 1 multiplies by 1 / s[i - 1] whatever the row
-    const double inv_o = row1 ? 1. : inv_s;
-    if (!EDGE || i < lq) { const Emis em1 = make_emis(b.w_up, rw1, q2p); bwd_apply<EDGE, MODE>(p, em1, rw1, i, inv_i, b.bM, b.bI); }
-    // the emissions of row i only now: they hang on w_i, which was asked for at the top of this pair -- computed up there (where the
-    // compiler would put them) the wave waits a whole memory round trip before its first fp64 instruction
-    sched_fence();
-    uint64_t rw0 = rw1;
-    if (!EDGE || i < lq) rw0 = ((rw1 << 3) | (uint64_t)((w_i >> 14) & 7u)) & WORD_MASK;
-    const Emis em0 = make_emis(w_i, rw0, q2p);
-    MapAcc a;
-    double pm = 0., pd = 0.;
-    a.init();
-    EvenCell<EDGE, 0>::run(p, em0, rw0, i, l_ref, inv_o, inv_i, row1 ? 0. : p.m2, row1 ? 0. : p.m8, Mp, Ip, b.bM, b.bI, pm, pd, a);
-    if (MODE == 5) sched_fence();
-    finish_row<LS>(c, i, a, w_i, IN, ln, state);
-    if (MODE == 5) sched_fence();
-    bwd_apply<EDGE, MODE>(p, em0, rw0, i - 1, inv_s, b.bM, b.bI);
-    if (MODE == 5) sched_fence();
-    map_row(a, Mp, Ip, b.bM, b.bI);
-    finish_row<LS>(c, i - 1, a, w_o, IN, ln, state);
-    b.rw = rw0; b.w_up = w_o;
+    const bool is_top = EDGE && top >= lq;                       // the group's top row is row lq: b is the start vector, nothing to step from
+    // S[] holds 1 / s[row] below row lq, s[lq] itself for row lq
+    const double inv_top = is_top ? 1. / s_top : s_top;
+    const bool row1 = EDGE && a == 1;                            // row 1 is stored normalised and has no D state
+    const double inv_a_step = s_a;                               // the backward step to row a multiplies by 1 / s[a] whatever the row
+    const double inv_a = row1 ? 1. : s_a;
+    const double inv_mid = ROWS == 3 ? s_mid : inv_top;          // 1 / s[a + 1]
+    uint64_t rw_top = b.rw;
+    if (!is_top) {
+        // band word of the top row from the one above it; b[top] from b[top + 1] with the emissions of row top + 1
+        const Emis e_up = make_emis(b.w_up, b.rw, q2p);
+        bwd_apply<EDGE, MODE>(p, e_up, b.rw, top, inv_top, b.bM, b.bI);
+        sched_fence();
+        rw_top = word_down(b.rw, w_top);
+    }
+    MapAcc acc;
+    if (ROWS == 1) {
+        // the stored row on its own (the topmost group of a read whose length is 1 mod 3): normalise, MAP
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { Mp[j] *= inv_top; Ip[j] *= inv_top; }      // (a == top here)
+        map_row(acc, Mp, Ip, b.bM, b.bI);
+        finish_row<LS>(c, a, acc, w_a, IN, ln);
+        b.rw = rw_top; b.w_up = w_a;
+        return;
+    }
+    const uint64_t rw_1 = ROWS == 3 ? word_down(rw_top, w_mid) : rw_top;         // band word of row a + 1
+    const Emis e2 = make_emis(w_top, rw_top, q2p);                                // emissions of row a + 2 (ROWS == 3)
+    const Emis e1 = ROWS == 3 ? make_emis(w_mid, rw_1, q2p) : e2;                 // emissions of row a + 1
+    double pm = 0., pd = 0., q1m = 0., q1d = 0., cM = 0., cD = 0.;
+    acc.init();
+    GroupCell<EDGE, ROWS, 0>::template run<LS>(p, e1, rw_1, e2, rw_top, a, l_ref, inv_a, inv_mid, inv_top, row1 ? 0. : p.m2, row1 ? 0. : p.m8, Mp, Ip, Ln,
+                                               b.bM, b.bI, pm, pd, q1m, q1d, cM, cD, acc);
+    finish_row<LS>(c, top, acc, w_top, IN, ln);
+    if (ROWS == 3) {
+        bwd_apply<EDGE, MODE>(p, e2, rw_top, a + 1, inv_mid, b.bM, b.bI);
+        map_row_lds<LS>(acc, Ln, b.bM, b.bI);
+        finish_row<LS>(c, a + 1, acc, w_mid, IN, ln);
+    }
+    bwd_apply<EDGE, MODE>(p, e1, rw_1, a, inv_a_step, b.bM, b.bI);
+    map_row(acc, Mp, Ip, b.bM, b.bI);
+    finish_row<LS>(c, a, acc, w_a, IN, ln);
+    b.rw = word_down(rw_1, w_a); b.w_up = w_a;
 }
 
-// all_edge as in fwd_lane.  Otherwise the pairs with 10 <= i <= lq - 2 (rows i - 1 .. i + 1 have all cells inside the window)
-// take the interior code: loops, not a branch per pair.
-template <int LS, int MODE = 0, class St>
-BQS_HD void bwd_lane(const Par &p, int lq, int l_ref, bool all_edge, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, St state, BwdCtx &c)
+// all_edge as in fwd_lane.  Otherwise the groups whose rows a - 1 .. a + 3 have all cells inside the window take the interior code: loops, not a
+// branch per group.  Ln: this lane's 15 (M, I) pairs of LDS, stride LS.
+template <int LS, int MODE = 0, class Ld>
+BQS_HD void bwd_lane(const Par &p, int lq, int l_ref, bool all_edge, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, Ld Ln, BwdCtx &c)
 {
     BwdState b;
     // band word of row lq: field j = code(lq - BW - 1 + j) = the upper-end code of row lq - 2 BW + j
     b.rw = 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) b.rw |= (uint64_t)((IN[at<LS>(lq - 2 * BW + j, ln)] >> 11) & 7u) << (3 * j);
-    const double s_top = S[at<LS>(lq, ln)];
     {
-        const double sl1 = S[at<LS>(lq + 1, ln)];
+        const double s_top = S[at<LS>(lq, ln)], sl1 = S[at<LS>(lq + 1, ln)];
         const double vM = p.sM / s_top / sl1, vI = p.sI / s_top / sl1;
 #pragma unroll
         for (int j = 0; j < NB; ++j) { const bool valid = BQS_FLD(b.rw, j) != 7; b.bM[j] = valid ? vM : 0.; b.bI[j] = valid ? vI : 0.; }
     }
     c.run_r = 0;
-    int i = lq;
     b.w_up = IN[at<LS>(lq, ln)];
-    if (lq & 1) {
-        // the top row is odd: stored raw, on its own
-        const int t = ((lq - 1) >> 1) * NB;
-        const double inv = 1. / s_top;
-        double fM[NB], fI[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) { const d2 v = ld_d2<MODE>(&F2[at<LS>(t + j, ln)]); fM[j] = v.x * inv; fI[j] = v.y * inv; }
-        MapAcc a; map_row(a, fM, fI, b.bM, b.bI);
-        finish_row<LS>(c, lq, a, b.w_up, IN, ln, state);
-        --i;
-    }
+    // the topmost group: the last stored row and the 0, 1 or 2 rows above it
+    int a = 3 * ((lq - 1) / 3) + 1;
+    const int above = lq - a;
+    if (above == 0) bwd_group<LS, true, 1, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
+    else if (above == 1) bwd_group<LS, true, 2, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
+    else bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
+    a -= 3;
     const bool ae = all_edge || BQS_TEST_FORCE_EDGE;
-    const int hi = ae ? 0 : lq - 2, lo = ae ? 2 : BW + 3;          // interior pairs: lo <= i <= hi
+    // interior groups: rows a .. a + 3 are all between row BW + 1 and row lq - 1 (row a + 3 lends its emissions to the first backward step)
+    const int hi = ae ? 0 : lq - 4, lo = ae ? 1 : BW + 3;          // interior groups: lo <= a <= hi
 #pragma unroll 1
-    for (; i >= 2 && i > hi; i -= 2) bwd_pair<LS, true, MODE>(p, lq, l_ref, i, IN, F2, S, ln, q2p, state, c, b);
+    for (; a >= 1 && a > hi; a -= 3) bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
 #pragma unroll 1
-    for (; i >= lo && !ae; i -= 2) bwd_pair<LS, false, MODE>(p, lq, l_ref, i, IN, F2, S, ln, q2p, state, c, b);
+    for (; a >= lo && !ae; a -= 3) bwd_group<LS, false, 3, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
 #pragma unroll 1
-    for (; i >= 2; i -= 2) bwd_pair<LS, true, MODE>(p, lq, l_ref, i, IN, F2, S, ln, q2p, state, c, b);
+    for (; a >= 1; a -= 3) bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
 }
 
 // the left-hand running maximum (realn.c's extended BAQ: bq = min(left, right) inside the M operation) and the qualities' way home
-template <int LS, class St>
-BQS_HD void final_lane(int lq, const uint32_t *IN, int ln, St state, const BwdCtx &c, uint8_t *qual)
+template <int LS>
+BQS_HD void final_lane(int lq, const uint32_t *IN, int ln, const BwdCtx &c, uint8_t *qual)
 {
     int run = 0;
     for (int q = c.ys; q < c.ys + c.mlen; ++q) {
-        const int b = state[(size_t)q * LS];
+        const uint32_t w = IN[at<LS>(q + 1, ln)];
+        const int b = (int)((w >> 17) & 127u);
         run = b > run ? b : run;
-        const int q1 = (int)(IN[at<LS>(q + 1, ln)] >> 24);
+        const int q1 = (int)(w >> 24);
         qual[q] = (uint8_t)((!c.plain && q1 > run) ? run : q1);
     }
 }

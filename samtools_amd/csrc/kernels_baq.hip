@@ -961,7 +961,7 @@ __device__ __forceinline__ double baq_uni(double x)       // a wave-uniform doub
 
 struct Baq7sSlot { uint32_t *IN; baq7s::d2 *F2; double *S; };
 __host__ __device__ inline size_t baq7s_in_bytes(int lq_cap) { return (((size_t)(lq_cap + 2) * 64 * 4) + 1023) & ~(size_t)1023; }
-__host__ __device__ inline size_t baq7s_f2_bytes(int lq_cap) { return (size_t)((lq_cap + 1) / 2) * baq7s::NB * 64 * 16; }
+__host__ __device__ inline size_t baq7s_f2_bytes(int lq_cap) { return (size_t)((lq_cap + 2) / 3) * baq7s::NB * 64 * 16; }      // one row of three is stored
 __host__ __device__ inline size_t baq7s_slot_bytes(int lq_cap) { return baq7s_in_bytes(lq_cap) + baq7s_f2_bytes(lq_cap) + (size_t)(lq_cap + 2) * 64 * 8; }
 __device__ __forceinline__ Baq7sSlot baq7s_slot(uint8_t *scratch, size_t slot_bytes, int64_t idx, int lq_cap, int lane)
 {
@@ -995,13 +995,16 @@ template <int MODE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_baq7s(StaReadsDev R, StaWinDev W, BaqTables T, int64_t ngroups, unsigned *next,
                                               uint8_t *scratch, size_t slot_bytes, int lq_cap, int lead_mask)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t baq7s_state[];      // [row][lane]: b of every row of the group in its backward pass
+    __shared__ __attribute__((aligned(16))) baq7s::d2 mid_row[baq7s::NB * 64];   // [cell][lane]: the normalised middle row of the group in work (backward pass)
     __shared__ float q2p[256];
     __shared__ uint8_t refc[256];
     const int lane = threadIdx.x;
     for (int k = lane; k < 256; k += 64) { q2p[k] = T.q2p[k]; refc[k] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)k)); }
     __syncthreads();
-    uint8_t *state = baq7s_state + lane;
+    // volatile, and in the LDS address space: these stores and loads must BE ds_write_b128 / ds_read_b128 (forwarded through registers
+    // they would cost 60 VGPRs; through a generic pointer they become flat accesses)
+    typedef __attribute__((address_space(3))) volatile baq7s::d2 lds_d2;
+    lds_d2 *Ln = (lds_d2 *)mid_row + lane;
     int64_t pend0 = -1, pend1 = -1;                   // groups whose forward rows wait in a slot (slot index in bit 62), oldest first
     int np = 0, cur = 0;
     bool extra = (blockIdx.x & lead_mask) != 0;         // this wave runs one forward pass ahead
@@ -1049,8 +1052,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 p.m6 = baq_uni(p.m6); p.m8 = baq_uni(p.m8); p.sM = baq_uni(p.sM); p.sI = baq_uni(p.sI);
                 p.eim1 = baq_uni(p.eim1); p.eim4 = baq_uni(p.eim4);
                 baq7s::BwdCtx c; c.ys = d.sh.ys; c.mlen = d.sh.mlen; c.run_r = 0; c.plain = W.baq_plain != 0;
-                baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, lane, q2p, state, c);
-                baq7s::final_lane<64>(lq, sl.IN, lane, state, c, d.qual);
+                baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, lane, q2p, Ln, c);
+                baq7s::final_lane<64>(lq, sl.IN, lane, c, d.qual);
             }
         } else if (!have) break;
     }
@@ -1064,8 +1067,7 @@ size_t sta_baq7s_scratch_bytes(int lq_cap, int64_t ngroups, int *waves_out)
         int dev = 0, cus = 256, per = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        const int rows = (256 + 3) & ~3;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_baq7s<0>, 64, (size_t)rows * 64) != hipSuccess || per < 1) { (void)hipGetLastError(); per = 8; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_baq7s<0>, 64, 0) != hipSuccess || per < 1) { (void)hipGetLastError(); per = 8; }
         const char *e = getenv("STA_BAQ7S_WAVES_PER_CU");
         if (e && atoi(e) > 0 && atoi(e) < per) per = atoi(e);
         g_baq7s_waves = cus * per;
@@ -1087,10 +1089,9 @@ void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, v
     if (ngroups <= 0 || waves <= 0) return;
     static const int lead = [] { const char *e = getenv("STA_BAQ7S_LEAD"); return e ? atoi(e) : 1; }();   // 0: every wave forward-then-backward; 1: odd waves one forward pass ahead
     hipMemsetAsync(scratch, 0, 256, s);
-    const int rows = (lq_cap + 3) & ~3;
     // STA_BAQ7S_MODE: 0 non-temporal row stream (default), 1 plain loads / stores; 2, 3: diagnostics with wrong results (baq_band7s.h)
     static const int mode = [] { const char *e = getenv("STA_BAQ7S_MODE"); return e ? atoi(e) : 0; }();
-#define BAQ7S_LAUNCH(M) hipLaunchKernelGGL(k_baq7s<M>, dim3((unsigned)waves), dim3(64), (size_t)rows * 64, s, r, w, g_tables, ngroups, (unsigned *)scratch, \
+#define BAQ7S_LAUNCH(M) hipLaunchKernelGGL(k_baq7s<M>, dim3((unsigned)waves), dim3(64), 0, s, r, w, g_tables, ngroups, (unsigned *)scratch, \
                                            (uint8_t *)scratch + 256, baq7s_slot_bytes(lq_cap), lq_cap, lead)
     if (mode == 1) BAQ7S_LAUNCH(1); else if (mode == 2) BAQ7S_LAUNCH(2); else if (mode == 3) BAQ7S_LAUNCH(3); else if (mode == 4) BAQ7S_LAUNCH(4);
     else if (mode == 5) BAQ7S_LAUNCH(5); else if (mode == 6) BAQ7S_LAUNCH(6); else if (mode == 7) BAQ7S_LAUNCH(7); else if (mode == 8) BAQ7S_LAUNCH(8); else BAQ7S_LAUNCH(0);

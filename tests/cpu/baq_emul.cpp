@@ -86,16 +86,17 @@ int main(int argc, char **argv)
         // lane functions, one lane (LS = 1)
         const int l_ref = lq + 6;
         std::vector<uint32_t> IN(lq + 2, 0);
-        std::vector<baq7s::d2> F2((size_t)((lq + 1) / 2) * baq7s::NB);
+        std::vector<baq7s::d2> F2((size_t)((lq + 2) / 3) * baq7s::NB);
+        baq7s::d2 Ln[baq7s::NB];                      // what is LDS on the device: the normalised middle row of the group in work
         std::vector<double> S(lq + 2, 0.);
-        std::vector<uint8_t> state(lq + 1, 0), mq(qual);
+        std::vector<uint8_t> mq(qual);
         const baq7s::Par par = baq7s::make_par(lq, l_ref);
         const bool amb = baq7s::pack_lane<1>(lq, l_ref, mq.data(), seq.data(), ref.c_str() + sh.xb, refc, IN.data(), 0);
         if (amb) ++n_amb;
         baq7s::fwd_lane<1>(par, lq, amb, IN.data(), F2.data(), S.data(), 0, q2p);
         baq7s::BwdCtx ctx; ctx.ys = sh.ys; ctx.mlen = sh.mlen; ctx.run_r = 0; ctx.plain = plain;
-        baq7s::bwd_lane<1>(par, lq, l_ref, amb, IN.data(), F2.data(), S.data(), 0, q2p, state.data(), ctx);
-        baq7s::final_lane<1>(lq, IN.data(), 0, state.data(), ctx, mq.data());
+        baq7s::bwd_lane<1>(par, lq, l_ref, amb, IN.data(), F2.data(), S.data(), 0, q2p, &Ln[0], ctx);
+        baq7s::final_lane<1>(lq, IN.data(), 0, ctx, mq.data());
 
         if (memcmp(oq.data(), qual.data(), (size_t)lq) != 0) ++n_changed;
         if (memcmp(oq.data(), mq.data(), (size_t)lq) != 0) {

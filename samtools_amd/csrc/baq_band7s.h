@@ -72,6 +72,19 @@ template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { if (MODE == 2 || MODE == 3)
 template <int MODE> BQS_HD int hot_row(int i) { return MODE == 3 ? 1 + (i & 7) : i; }
 BQS_HD double fmax_(double a, double b) { return __builtin_fmax(a, b); }
 BQS_HD void sched_fence() { __builtin_amdgcn_sched_barrier(0); }       // nothing is scheduled across this point
+// bit `pos` of w set ? a : b, without a condition register: mask = the bit sign-extended (v_bfe_i32), then v_bfi_b32 on either half.
+// The empty asm hides where the mask comes from: the compiler would turn the blend back into v_cmp + v_cndmask.
+// `dep` (any value that becomes available just before the blend is needed) ties the mask to that point of the schedule: left free, the fifteen
+// masks of a row are all computed up front and cost fifteen registers (measured: 240 spilled registers).
+BQS_HD double blend_bit(uint64_t w, int pos, double a, double b, double dep)
+{
+    const uint32_t word = pos < 32 ? (uint32_t)w : (uint32_t)(w >> 32);
+    uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)word, (unsigned)(pos & 31), 1u);
+    asm("" : "+v"(m) : "v"((uint32_t)(uint64_t)__double_as_longlong(dep)));
+    const uint64_t ua = (uint64_t)__double_as_longlong(a), ub = (uint64_t)__double_as_longlong(b);
+    const uint32_t lo = ((uint32_t)ua & m) | ((uint32_t)ub & ~m), hi = ((uint32_t)(ua >> 32) & m) | ((uint32_t)(ub >> 32) & ~m);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
 #else
 BQS_HD bool wave_any(bool c) { return c; }
 template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { return *p; }
@@ -79,6 +92,7 @@ template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { *p = v; }
 template <int MODE> BQS_HD int hot_row(int i) { return i; }
 BQS_HD double fmax_(double a, double b) { return fmax(a, b); }
 BQS_HD void sched_fence() {}
+BQS_HD double blend_bit(uint64_t w, int pos, double a, double b, double) { return ((w >> pos) & 1) ? a : b; }
 #endif
 
 BQS_HD uint64_t d_bits(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
@@ -136,7 +150,7 @@ BQS_HD Emis make_emis(uint32_t w, uint64_t rw, const float *q2p)
     return e;
 }
 template <bool EDGE>
-BQS_HD double emis_cell(const Emis &e, uint64_t rw, int j)
+BQS_HD double emis_cell(const Emis &e, uint64_t rw, int j, double dep)
 {
     if (EDGE) {
         const int rc = BQS_FLD(rw, j);
@@ -144,9 +158,10 @@ BQS_HD double emis_cell(const Emis &e, uint64_t rw, int j)
         const double hi = (rc == 7) ? 0. : 1.;
         return rc > 3 ? hi : v;
     }
-    // a bit-wise blend, not `bit ? ematch : e_lo`: the compiler turned that select into a two-entry table in scratch memory
-    const uint64_t m = 0 - ((e.nm >> (3 * j)) & 1);
-    return bits_d((d_bits(e.ematch) & m) | (d_bits(e.e_lo) & ~m));
+    // A bit-wise blend by a register mask, not a select on a condition.  Measured on this chip (scripts/ubench/valu_cost.hip,
+    // profiles/r04_valu_cost.md): v_cmp + two v_cndmask_b32 on VCC cost ~20 clocks of a saturated SIMD and ~50 of a single wave, v_bfe_i32 +
+    // two v_bfi_b32 4.2 each.  (And written as `bit ? ematch : e_lo` the select became a two-entry table in scratch memory.)
+    return blend_bit(e.nm, 3 * j, e.ematch, e.e_lo, dep);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -157,8 +172,9 @@ BQS_HD double fwd_row(const Par &p, const Emis &em, uint64_t rw, double (&M)[NB]
     double sum = 0., pm = 0., pd = 0.;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const double e = emis_cell<EDGE>(em, rw, j);
-        const double fm = e * (p.m0 * M[j] + p.m3 * I[j] + p.m6 * D[j]);
+        const double t3 = p.m0 * M[j] + p.m3 * I[j] + p.m6 * D[j];
+        const double e = emis_cell<EDGE>(em, rw, j, t3);
+        const double fm = e * t3;
         const double fi = (j + 1 < NB) ? kEI * (p.m1 * M[j + 1] + p.m4 * I[j + 1]) : 0.;
         double fd = p.m2 * pm + p.m8 * pd;
         if (EDGE) fd = BQS_FLD(rw, j) == 7 ? 0. : fd;
@@ -215,7 +231,7 @@ BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int rc = BQS_FLD(f.rw, j);
-            const double e = emis_cell<true>(em, f.rw, j);
+            const double e = emis_cell<true>(em, f.rw, j, 0.);
             const double a = e * p.bM;
             const double b2 = rc == 7 ? 0. : eibi;
             f.M[j] = a; f.I[j] = b2; f.D[j] = 0.;
@@ -303,7 +319,7 @@ BQS_HD void bwd_apply(const Par &p, const Emis &em, uint64_t rw1, int i, double 
     const double yv = i > 1 ? 1. : 0.;
 #pragma unroll
     for (int j = NB - 1; j >= 0; --j) {
-        const double e = emis_cell<EDGE>(em, rw1, j) * bM[j];           // outside the window: 0 * b, as in the reference
+        const double e = emis_cell<EDGE>(em, rw1, j, dnext) * bM[j];    // outside the window: 0 * b, as in the reference
         const double bi1 = j > 0 ? bI[j - 1] : 0.;
         const double bm = e * p.m0 + p.eim1 * bi1 + p.m2 * dnext;
         const double bi_ = e * p.m3 + p.eim4 * bi1;
@@ -365,8 +381,9 @@ template <bool EDGE, int ROWS, int J> struct GroupCell {
             const double Mn = Mp[J < NB ? J : 0] * inv_a, In = Ip[J < NB ? J : 0] * inv_a, Dn = fd * inv_a;
             Mp[J < NB ? J : 0] = Mn; Ip[J < NB ? J : 0] = In;
             if (J > 0) i1_prev = (kEI * (p.m1 * Mn + p.m4 * In)) * inv1;                 // the forward pass's I[a + 1][J - 1]
-            const double e = emis_cell<EDGE>(e1, rw_1, J < NB ? J : 0);
-            M1r = e * (p.m0 * Mn + p.m3 * In + p.m6 * Dn);                                // the forward pass's raw M[a + 1][J] ...
+            const double t3 = p.m0 * Mn + p.m3 * In + p.m6 * Dn;
+            const double e = emis_cell<EDGE>(e1, rw_1, J < NB ? J : 0, t3);
+            M1r = e * t3;                                                                  // the forward pass's raw M[a + 1][J] ...
             D1r = p.m2 * q1m + p.m8 * q1d;                                                 // ... and raw D[a + 1][J]
             if (EDGE) D1r = BQS_FLD(rw_1, J < NB ? J : 0) == 7 ? 0. : D1r;
             M1n = M1r * inv1; D1n = D1r * inv1;
@@ -380,8 +397,9 @@ template <bool EDGE, int ROWS, int J> struct GroupCell {
                     const double fi2 = (kEI * (p.m1 * cM + p.m4 * I1n)) * inv2;           // the forward pass's I[a + 2][C - 1]
                     acc.template add<2 * (C > 0 ? C - 1 : 0) + 1>(fi2 * bI[C > 0 ? C - 1 : 0]);
                 }
-                const double e = emis_cell<EDGE>(e2, rw_2, C);
-                const double fm2 = (e * (p.m0 * cM + p.m3 * I1n + p.m6 * cD)) * inv2;     // the forward pass's M[a + 2][C]
+                const double t3 = p.m0 * cM + p.m3 * I1n + p.m6 * cD;
+                const double e = emis_cell<EDGE>(e2, rw_2, C, t3);
+                const double fm2 = (e * t3) * inv2;                                        // the forward pass's M[a + 2][C]
                 acc.template add<2 * C>(fm2 * bM[C]);
             } else {
                 acc.template add<2 * C>(cM * bM[C]);

@@ -71,6 +71,7 @@ template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { if (MODE == 2 || MODE == 3) {
 template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { if (MODE == 2 || MODE == 3) return; if (MODE == 1 || MODE == 7) *p = v; else __builtin_nontemporal_store(v, p); }
 template <int MODE> BQS_HD int hot_row(int i) { return MODE == 3 ? 1 + (i & 7) : i; }
 BQS_HD double fmax_(double a, double b) { return __builtin_fmax(a, b); }
+BQS_HD double fmin_(double a, double b) { return __builtin_fmin(a, b); }
 BQS_HD void sched_fence() { __builtin_amdgcn_sched_barrier(0); }       // nothing is scheduled across this point
 // bit `pos` of w set ? a : b, without a condition register: mask = the bit sign-extended (v_bfe_i32), then v_bfi_b32 on either half.
 // The empty asm hides where the mask comes from: the compiler would turn the blend back into v_cmp + v_cndmask.
@@ -91,6 +92,7 @@ template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { return *p; }
 template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { *p = v; }
 template <int MODE> BQS_HD int hot_row(int i) { return i; }
 BQS_HD double fmax_(double a, double b) { return fmax(a, b); }
+BQS_HD double fmin_(double a, double b) { return fmin(a, b); }
 BQS_HD void sched_fence() {}
 BQS_HD double blend_bit(uint64_t w, int pos, double a, double b, double) { return ((w >> pos) & 1) ? a : b; }
 #endif
@@ -141,12 +143,12 @@ BQS_HD Emis make_emis(uint32_t w, uint64_t rw, const float *q2p)
     Emis e;
     const double qli = q2p[w & 255];
     const int qy = (int)((w >> 8) & 7);
-    e.ematch = 1. - qli; e.e_lo = qy > 3 ? 1. : qli * kEM;
-    e.qyc = qy > 3 ? 9 : qy;
+    // (query code 4 = anything but A C G T: emission 1 whatever the reference says; bit 10 of the word is that code's bit 2)
+    e.ematch = blend_bit(w, 10, 1., 1. - qli, qli); e.e_lo = blend_bit(w, 10, 1., qli * kEM, qli);
+    e.qyc = qy + 5 * (qy >> 2);               // 9 for code 4: matches no reference code
     // bit 3j of nm: field j of the band word equals the query code (fields are <= 3 where this is used)
     const uint64_t x = rw ^ ((uint64_t)(qy & 3) * ONE_MASK);
     e.nm = ~(x | (x >> 1) | (x >> 2)) & ONE_MASK;
-    if (qy > 3) e.ematch = 1.;          // an ambiguous query base: emission 1 whatever the reference says
     return e;
 }
 template <bool EDGE>
@@ -280,19 +282,26 @@ struct MapAcc {
     }
 };
 
-// (int)v the way x86-64's cvttsd2si does it for out-of-range values and NaN (the CPU reference's behaviour), then probaln's cap
+// probaln_glocal: k = (int)(-4.343 * log(1. - max) + .499); q = k > 100 ? 99 : k, stored in a byte.  (int)v is x86-64's cvttsd2si in the CPU
+// reference: INT_MIN for v >= 2^31, +inf and NaN (a posterior of exactly 1 gives log(0) = -inf, v = +inf, k = INT_MIN, q = (uint8_t)k = 0).
+// v >= .499 otherwise.  In integer arithmetic, without a condition register (v_cmp + v_cndmask cost 20-50 clocks a piece on this chip):
+// the value is clamped to [0, 2^31] (a NaN goes to 2^31 through fmin), converted as unsigned, 2^31 is the one "bad" pattern.
 BQS_HD int map_quality(double zs, double sum)
 {
     const double mx = zs / sum;
     const double v = -4.343 * log(1. - mx) + .499;
-    int kq = (v >= 2147483648.0 || v < -2147483648.0 || v != v) ? INT32_MIN : (int)v;
-    return (int)(uint8_t)(kq > 100 ? 99 : kq);
+    const double vc = fmax_(fmin_(v, 2147483648.0), 0.);
+    const uint32_t ku = (uint32_t)vc;                            // <= 2^31: in range
+    const int32_t bad = (int32_t)ku >> 31;                       // -1 for the INT_MIN cases
+    const int32_t kk = (int32_t)(ku & ~(uint32_t)bad);           // those give the byte 0
+    const int32_t k100 = kk < 100 ? kk : 100;
+    return k100 - (int32_t)((uint32_t)(100 - kk) >> 31);         // k for k <= 100, 99 above
 }
 
 struct BwdCtx {
     int ys, mlen;           // the M operation covers query indices [ys, ys + mlen)
     int run_r;              // running maximum of b from the right inside it
-    bool plain;             // per-base BAQ (calmd -r without -E): no running maxima
+    int plain_mask;         // -1: per-base BAQ (calmd -r without -E): no running maxima; 0: extended BAQ
 };
 
 // the result of row i: b (0 unless the MAP state is M on the read's diagonal), kept in the row's word for the final pass, and the
@@ -302,12 +311,16 @@ BQS_HD void finish_row(BwdCtx &c, int i, const MapAcc &a, uint32_t w, uint32_t *
 {
     const int q = i - 1;
     const int kq = map_quality(a.zs, a.sum);
-    const bool in_m = q >= c.ys && q < c.ys + c.mlen;
-    const int b = (in_m && !a.kill && a.zs > 0.) ? kq : 0;      // 0 .. 99
-    c.run_r = b > c.run_r ? b : c.run_r;                  // (b is 0 outside the M operation: no effect there)
-    const int lim = c.plain ? b : c.run_r;
+    // masks instead of conditions: inside the M operation (0 <= q - ys < mlen); the MAP state is M on the diagonal
+    const int32_t t = q - c.ys;
+    const int32_t m_in = ((t - c.mlen) & ~t) >> 31;
+    const int32_t m_ok = (!a.kill && a.zs > 0.) ? -1 : 0;
+    const int b = kq & m_in & m_ok;                             // 0 .. 100
+    c.run_r = b > c.run_r ? b : c.run_r;                        // (b is 0 outside the M operation: no effect there)
+    const int lim = c.run_r ^ ((c.run_r ^ b) & c.plain_mask);   // per-base BAQ: the row's own b
     const int q0 = (int)(w >> 24);
-    const int q1 = (in_m && q0 > lim) ? lim : q0;
+    const int qmin = q0 < lim ? q0 : lim;
+    const int q1 = q0 ^ ((q0 ^ qmin) & m_in);
     IN[at<LS>(i, ln)] = (w & 0x0001ffffu) | ((uint32_t)b << 17) | ((uint32_t)q1 << 24);
 }
 
@@ -528,7 +541,7 @@ BQS_HD void final_lane(int lq, const uint32_t *IN, int ln, const BwdCtx &c, uint
         const int b = (int)((w >> 17) & 127u);
         run = b > run ? b : run;
         const int q1 = (int)(w >> 24);
-        qual[q] = (uint8_t)((!c.plain && q1 > run) ? run : q1);
+        qual[q] = (uint8_t)((!c.plain_mask && q1 > run) ? run : q1);
     }
 }
 

@@ -1051,7 +1051,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 p.m0 = baq_uni(p.m0); p.m1 = baq_uni(p.m1); p.m2 = baq_uni(p.m2); p.m3 = baq_uni(p.m3); p.m4 = baq_uni(p.m4);
                 p.m6 = baq_uni(p.m6); p.m8 = baq_uni(p.m8); p.sM = baq_uni(p.sM); p.sI = baq_uni(p.sI);
                 p.eim1 = baq_uni(p.eim1); p.eim4 = baq_uni(p.eim4);
-                baq7s::BwdCtx c; c.ys = d.sh.ys; c.mlen = d.sh.mlen; c.run_r = 0; c.plain = W.baq_plain != 0;
+                baq7s::BwdCtx c; c.ys = d.sh.ys; c.mlen = d.sh.mlen; c.run_r = 0; c.plain_mask = W.baq_plain != 0 ? -1 : 0;
                 baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, lane, q2p, Ln, c);
                 baq7s::final_lane<64>(lq, sl.IN, lane, c, d.qual);
             }

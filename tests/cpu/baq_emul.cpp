@@ -94,7 +94,7 @@ int main(int argc, char **argv)
         const bool amb = baq7s::pack_lane<1>(lq, l_ref, mq.data(), seq.data(), ref.c_str() + sh.xb, refc, IN.data(), 0);
         if (amb) ++n_amb;
         baq7s::fwd_lane<1>(par, lq, amb, IN.data(), F2.data(), S.data(), 0, q2p);
-        baq7s::BwdCtx ctx; ctx.ys = sh.ys; ctx.mlen = sh.mlen; ctx.run_r = 0; ctx.plain = plain;
+        baq7s::BwdCtx ctx; ctx.ys = sh.ys; ctx.mlen = sh.mlen; ctx.run_r = 0; ctx.plain_mask = plain ? -1 : 0;
         baq7s::bwd_lane<1>(par, lq, l_ref, amb, IN.data(), F2.data(), S.data(), 0, q2p, &Ln[0], ctx);
         baq7s::final_lane<1>(lq, IN.data(), 0, ctx, mq.data());
 

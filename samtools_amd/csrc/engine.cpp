@@ -54,6 +54,8 @@ struct ProfPending { std::string name; hipEvent_t a, b; };
 
 }  // namespace
 
+enum { PIN_FILES = 1024, PIN_BYTES = 16384 };
+
 struct sta_engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -68,6 +70,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
+    std::vector<char> late_copy;       // mpileup plan, per file: the working quality pool exists only if the window has overlap-eligible reads
     DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, stage_bad, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
     DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
@@ -90,6 +93,8 @@ struct sta_engine {
     uint64_t n_raw_staged = 0;         // reads whose pools were cut out of raw BAM records on the device (sta_stage_stats)
     bool len_fused = false;            // the measuring kernel also produced offsets / totals (no scan, no column statistics)
     bool have_wfirst = false;          // the plan built the per-group read index of the tile kernels
+    char *pin = nullptr;               // page-locked: [0, PIN_FILES) counters + text bytes read back, [PIN_FILES, PIN_BYTES) the file descriptors pushed
+    DevBuf chunk_words; StaChunkState chunk_st;   // the preparation kernels' in-kernel prefix maximum (kernels_common.hip ChunkScan)
     void *last_out = nullptr;
     // profiling
     bool prof_on = false;
@@ -181,6 +186,9 @@ int sta_engine_create(sta_engine **out, int device, void *hip_stream)
     sta_engine *e = new sta_engine();
     e->device = device;
     e->stream = (hipStream_t)hip_stream;   // nullptr = default stream
+    // a page-locked block for the plan's small transfers (file descriptors in, counters out): copies from and to pageable memory are
+    // staged by the runtime and block the caller; without it (allocation refused) the plan falls back to those
+    if (hipHostMalloc(&e->pin, PIN_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); e->pin = nullptr; }
     *out = e;
     return STA_OK;
 }
@@ -193,8 +201,9 @@ void sta_engine_destroy(sta_engine *e)
     hipStreamSynchronize(e->stream);
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
+    if (e->pin) hipHostFree(e->pin);
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->wfirst, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->stage_bad, &e->cov_out, &e->cov_hist, &e->sc_pos, &e->sc_delta, &e->sc_tmp, &e->sc_cov, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
+                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->stage_bad, &e->chunk_words, &e->cov_out, &e->cov_hist, &e->sc_pos, &e->sc_delta, &e->sc_tmp, &e->sc_cov, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
                       &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
@@ -371,7 +380,13 @@ static int push_files(sta_engine *e)
 {
     size_t bytes = e->files_h.size() * sizeof(StaReadsDev);
     if (e->files_d.ensure(bytes + 16)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
-    if (bytes) HIPCHK(hipMemcpyAsync(e->files_d.p, e->files_h.data(), bytes, hipMemcpyHostToDevice, e->stream));
+    const void *src = e->files_h.data();
+    if (e->pin && bytes <= PIN_BYTES - PIN_FILES) {
+        // (the previous plan's copy out of this block has completed: every plan ends with a synchronisation behind it)
+        memcpy(e->pin + PIN_FILES, e->files_h.data(), bytes);
+        src = e->pin + PIN_FILES;
+    }
+    if (bytes) HIPCHK(hipMemcpyAsync(e->files_d.p, src, bytes, hipMemcpyHostToDevice, e->stream));
     e->wd.files = (const StaReadsDev *)e->files_d.p;
     return STA_OK;
 }
@@ -387,11 +402,15 @@ static int finish_plan(sta_engine *e, int64_t ncols, sta_plan_info *info)
         sta_launch_wave_bytes_max(e->stream, (const uint64_t *)e->offs.p, (const uint32_t *)e->line_len.p, ncols, (StaCounters *)e->counters.p);
     }
     uint64_t total = 0;
-    HIPCHK(hipMemcpyAsync(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
-    // (after the tile measuring kernel the offsets are tile-relative and the window's text bytes close the tile bases)
-    const uint64_t *total_at = e->len_fused ? sta_mplp_tile_base(e->fused_status.p, ncols) + (ncols + 1023) / 1024 : (const uint64_t *)e->offs.p + (ncols > 0 ? ncols : 0);
-    HIPCHK(hipMemcpyAsync(&total, total_at, 8, hipMemcpyDeviceToHost, e->stream));
+    static_assert(sizeof(StaCounters) + 8 <= PIN_FILES, "counter block outgrew its page-locked slot");
+    StaCounters *ctr_dst = e->pin ? (StaCounters *)e->pin : &e->ctr_h;
+    uint64_t *total_dst = e->pin ? (uint64_t *)(e->pin + sizeof(StaCounters)) : &total;
+    HIPCHK(hipMemcpyAsync(ctr_dst, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
+    // (after the tile measuring kernel the offsets are tile-relative and k_tile_scan left the window's text bytes in the counter block)
+    if (!e->len_fused) HIPCHK(hipMemcpyAsync(total_dst, (const uint64_t *)e->offs.p + (ncols > 0 ? ncols : 0), 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->pin) { e->ctr_h = *ctr_dst; total = *total_dst; }
+    if (e->len_fused) total = e->ctr_h.out_bytes;
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "kernel launch");
     e->out_bytes = total;
@@ -407,6 +426,17 @@ static int finish_plan(sta_engine *e, int64_t ncols, sta_plan_info *info)
     return STA_OK;
 }
 
+// the zero-initialised words of the preparation kernels' prefix maximum (allocated once per engine)
+static int chunk_state(sta_engine *e)
+{
+    if (e->chunk_st.words) return STA_OK;
+    if (e->chunk_words.ensure(STA_CHUNK_WORDS * 8)) return fail(e, STA_ERR_HIP, "hipMalloc(scan words) failed");
+    HIPCHK(hipMemsetAsync(e->chunk_words.p, 0, STA_CHUNK_WORDS * 8, e->stream));
+    e->chunk_st = StaChunkState{};
+    e->chunk_st.words = (unsigned long long *)e->chunk_words.p;
+    return STA_OK;
+}
+
 static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_maxcnt)
 {
     hipStream_t s = e->stream;
@@ -419,19 +449,26 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
     bool redo = (p->flag & STA_MPLP_REDO_BAQ) != 0;
     bool olap = (p->flag & STA_MPLP_SMART_OVERLAPS) != 0;
     bool illum = (p->flag & STA_MPLP_ILLUMINA13) != 0;
-    // working quality pool needed?
+    // Working quality pool: built up front (k_qual_prep) when something rewrites qualities whatever the reads look like (-6, BAQ,
+    // BQ tags, -C); when only the mate-overlap pass could, the copy waits for k_prep_reads' count of eligible reads and is decided on
+    // the device (k_olap_setup) -- a window without proper pairs is then read straight from the input pool.
+    const bool capq = has_ref && p->capQ_thres > 10;
+    std::vector<char> &late_copy = e->late_copy;      // per file: the working pool is k_olap_setup's business
+    late_copy.assign((size_t)nf, 0);
     for (int f = 0; f < nf; ++f) {
         StaReadsDev &d = e->files_h[(size_t)f];
         bool tag_bq = realn && !redo && d.bq != nullptr;
-        bool need = illum || realn || olap;
-        if (need && d.n_bases_total) {
+        const bool up_front = illum || realn || capq;
+        if ((up_front || olap) && d.n_bases_total) {
             FileBufs &b = e->fb[(size_t)f];
             if (b.qual_work.ensure((size_t)d.n_bases_total + 32)) return fail(e, STA_ERR_HIP, "hipMalloc(qual) failed");
             d.qual = (uint8_t *)b.qual_work.p;
-            StaReadsDev tmp = d;
-            if (!tag_bq) tmp.bq = nullptr;
-            ProfScope ps(e, "qual_prep");
-            sta_launch_qual_prep(s, tmp, illum ? 1 : 0);
+            if (up_front) {
+                StaReadsDev tmp = d;
+                if (!tag_bq) tmp.bq = nullptr;
+                ProfScope ps(e, "qual_prep");
+                sta_launch_qual_prep(s, tmp, illum ? 1 : 0);
+            } else late_copy[(size_t)f] = 1;
         } else d.qual = const_cast<uint8_t *>(d.qual_in);
         d.fix_y = nullptr; d.fix_mate = nullptr; d.fix_q = nullptr;
         if (olap && d.n) {
@@ -439,20 +476,34 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             if (b.fix_y.ensure((size_t)d.n * 4 + 16) || b.fix_mate.ensure((size_t)d.n * 4 + 16) || b.fix_q.ensure((size_t)d.n + 16))
                 return fail(e, STA_ERR_HIP, "hipMalloc(overlap fix-up) failed");
             d.fix_y = (int32_t *)b.fix_y.p; d.fix_mate = (int32_t *)b.fix_mate.p; d.fix_q = (uint8_t *)b.fix_q.p;
-            HIPCHK(hipMemsetAsync(d.fix_y, 0xff, (size_t)d.n * 4, s));
         }
     }
     int rc = push_files(e);
     if (rc) return rc;
+    rc = chunk_state(e);
+    if (rc) return rc;
+    // the text plan's tile kernels find their reads through a column -> read index built from the input positions: the first
+    // preparation launch carries it
+    const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
+    e->have_wfirst = false;
+    if (!e->cov_mode && !e->plp_mode && sta_mplp_has_fast_path(*p) && sta_mplp_tile_ok(*p)) {
+        bool small = true;
+        for (int f = 0; f < nf; ++f) small = small && e->files_h[(size_t)f].n < 0xffffffffll;
+        e->have_wfirst = small;
+    }
+    bool wf_done = false;
+    if (e->have_wfirst && e->wfirst.ensure((size_t)((ncols > 0 ? ncols : 1) / 64 + 2) * (size_t)(nf > 0 ? nf : 1) * 4 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(read index) failed");
     {
         ProfScope ps(e, "prep_reads");
-        sta_launch_prep_reads(s, e->wd, e->files_h.data(), nf, *p, ctr);
+        wf_done = sta_launch_prep_reads(s, e->wd, e->files_h.data(), nf, *p, ctr, e->chunk_st, e->have_wfirst ? (uint32_t *)e->wfirst.p : nullptr);
     }
     if (realn) {
         // geometry bounds of the reads that need BAQ (written by k_prep_reads; maxima over all files)
         StaCounters c{};
-        HIPCHK(hipMemcpyAsync(&c, ctr, sizeof(c), hipMemcpyDeviceToHost, s));
+        StaCounters *c_dst = e->pin ? (StaCounters *)e->pin : &c;
+        HIPCHK(hipMemcpyAsync(c_dst, ctr, sizeof(c), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        if (e->pin) c = *c_dst;
         if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] n_baq=%llu (fast %llu, lq<=%llu) slow: max_lq=%llu max_bw=%llu kept=%llu\n", c.n_baq, c.n_baq_fast, c.max_lq_fast, c.max_lq, c.max_bw, c.n_kept);
         if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] bw8=%llu general=%llu class_s=%llu (lq<=%llu) bw7_list=%llu\n", c.n_baq_bw8, c.n_baq_general, c.n_baq_s, c.max_lq_s, c.n_baq_bw7l);
         for (int f = 0; f < nf && c.n_baq; ++f) {
@@ -559,18 +610,24 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             if (e->maxcnt_scratch.ensure((size_t)(span + 4) * 4 + 32)) return fail(e, STA_ERR_HIP, "hipMalloc(maxcnt) failed");
             if (e->scan_tmp.ensure(sta_scan_tmp_bytes(d.n) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
             ProfScope ps(e, "maxcnt_serial");
-            sta_launch_maxend_scan(s, d, e->scan_tmp.p, e->scan_tmp.cap);           // prefix maxima BEFORE the cap: the replay's candidate bounds
+            // (R.maxend = prefix maxima BEFORE the cap, from k_prep_reads: the replay's candidate bounds -- unless -C dropped reads since)
+            if (has_ref && p->capQ_thres > 10) sta_launch_maxend_scan(s, d, e->scan_tmp.p, e->scan_tmp.cap);
             sta_launch_maxcnt(s, d, p->max_depth, lo, (int32_t)span, (int32_t *)e->maxcnt_scratch.p, ctr);
         }
     }
-    for (int f = 0; f < nf; ++f) {
+    // R.maxend comes out of k_prep_reads; only -C and the -d replay change the set of kept reads afterwards
+    const bool rescan = do_maxcnt || (has_ref && p->capQ_thres > 10);
+    for (int f = 0; f < nf && rescan; ++f) {
         StaReadsDev &d = e->files_h[(size_t)f];
         if (!d.n) continue;
         if (e->scan_tmp.ensure(sta_scan_tmp_bytes(d.n) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
         ProfScope ps(e, "maxend_scan");
         sta_launch_maxend_scan(s, d, e->scan_tmp.p, e->scan_tmp.cap);
     }
-    if (!do_maxcnt && p->max_depth > 0 && p->max_depth < INT_MAX) {
+    // the -d detector rides in the tile measuring kernel when that one runs
+    const bool want_detect = !do_maxcnt && p->max_depth > 0 && p->max_depth < INT_MAX;
+    const bool detect_in_len = want_detect && e->have_wfirst && ncols > 0;
+    if (want_detect && !detect_in_len) {
         for (int f = 0; f < nf; ++f) {
             ProfScope ps(e, "maxcnt_detect");
             sta_launch_maxcnt_detect(s, e->files_h[(size_t)f], p->max_depth, ctr);
@@ -583,6 +640,7 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             size_t slots = sta_overlap_table_slots(d.n);
             if (e->table.ensure(sta_overlap_table_bytes(slots) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(name table) failed");
             ProfScope ps(e, "overlap");
+            sta_launch_overlap_setup(s, d, (StaReadsDev *)e->files_d.p + f, late_copy[(size_t)f] != 0, e->table.p, slots, ctr);
             sta_launch_overlap(s, d, e->wd.origin, e->wd.tid, e->table.p, slots, (int32_t *)e->fb[(size_t)f].chain.p, ctr);
         }
     }
@@ -591,21 +649,17 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
         ProfScope ps(e, "plp_count");
         sta_launch_plp_count(s, e->wd, (uint32_t *)e->line_len.p);
     } else {
-        int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
         if (e->colinfo.ensure((size_t)(ncols > 0 ? ncols : 1) * (size_t)(nf > 0 ? nf : 1) * 8 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(column info) failed");
-        const bool tile = sta_mplp_has_fast_path(*p) && sta_mplp_tile_ok(*p);
-        bool small = true;
-        for (int f = 0; f < nf; ++f) small = small && e->files_h[(size_t)f].n < 0xffffffffll;
-        e->have_wfirst = tile && small;
         if (e->have_wfirst) {
-            if (e->wfirst.ensure((size_t)((ncols > 0 ? ncols : 1) / 64 + 2) * (size_t)(nf > 0 ? nf : 1) * 4 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(read index) failed");
             if (e->fused_status.ensure(sta_mplp_len_status_bytes(ncols) + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(look-back words) failed");
-            ProfScope ps(e, "wave_first");
-            sta_launch_wave_first(s, e->wd, (uint32_t *)e->wfirst.p, e->fused_status.p);
+            if (!wf_done) {                      // (every file empty: no preparation launch carried the index)
+                ProfScope ps(e, "wave_first");
+                sta_launch_wave_first(s, e->wd, (uint32_t *)e->wfirst.p, e->fused_status.p);
+            }
         }
         ProfScope ps(e, "mplp_len");
         e->len_fused = sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr,
-                                           e->have_wfirst ? e->fused_status.p : nullptr, (uint64_t *)e->offs.p);
+                                           e->have_wfirst ? e->fused_status.p : nullptr, (uint64_t *)e->offs.p, detect_in_len ? p->max_depth : 0);
     }
     return STA_OK;
 }
@@ -655,8 +709,10 @@ static int counting_pipeline(sta_engine *e, const sta_mplp_params *p)
 // totals of a single-pass kernel (k_depth_fused): counters -> host, one synchronisation
 static int fused_finish(sta_engine *e, sta_plan_info *info)
 {
-    HIPCHK(hipMemcpyAsync(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
+    StaCounters *ctr_dst = e->pin ? (StaCounters *)e->pin : &e->ctr_h;
+    HIPCHK(hipMemcpyAsync(ctr_dst, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->pin) e->ctr_h = *ctr_dst;
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "kernel launch");
     e->out_bytes = e->ctr_h.out_bytes;
@@ -844,7 +900,9 @@ int sta_fetch_read_state(sta_engine *e, int32_t file, uint32_t *host_info, uint8
     hipSetDevice(e->device);
     StaReadsDev &d = e->files_h[(size_t)file];
     if (host_info && d.n) HIPCHK(hipMemcpyAsync(host_info, d.info, (size_t)d.n * 4, hipMemcpyDeviceToHost, e->stream));
-    if (host_qual && d.n_bases_total) HIPCHK(hipMemcpyAsync(host_qual, d.qual, (size_t)d.n_bases_total, hipMemcpyDeviceToHost, e->stream));
+    // (a working pool left to k_olap_setup was never written when the window had no eligible read: the qualities in use are the input's)
+    const bool unused_pool = (size_t)file < e->late_copy.size() && e->late_copy[(size_t)file] && e->ctr_h.n_olap_el == 0;
+    if (host_qual && d.n_bases_total) HIPCHK(hipMemcpyAsync(host_qual, unused_pool ? d.qual_in : d.qual, (size_t)d.n_bases_total, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return STA_OK;
 }
@@ -1257,7 +1315,7 @@ int sta_fetch_overlap_fixups(sta_engine *e, int32_t file, int32_t *fix_y, int32_
     hipSetDevice(e->device);
     StaReadsDev &d = e->files_h[(size_t)file];
     if (!d.n) return STA_OK;
-    if (!d.fix_y) { for (int64_t i = 0; i < d.n; ++i) fix_y[i] = -1; return STA_OK; }
+    if (!d.fix_y || e->ctr_h.n_olap_el == 0) { for (int64_t i = 0; i < d.n; ++i) fix_y[i] = -1; return STA_OK; }     // (no eligible read: the pass did not run)
     HIPCHK(hipMemcpyAsync(fix_y, d.fix_y, (size_t)d.n * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(fix_mate, d.fix_mate, (size_t)d.n * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(fix_q, d.fix_q, (size_t)d.n, hipMemcpyDeviceToHost, e->stream));
@@ -1275,13 +1333,16 @@ static int depth_text(sta_engine *e, const sta_depth_params *p, char *out, uint6
     const int nf = (int)e->files_h.size();
     const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
     for (auto &d : e->files_h) d.qual = const_cast<uint8_t *>(d.qual_in);
+    e->late_copy.clear();
     int rc = push_files(e);
     if (rc) return rc;
     if (e->fused_status.ensure(sta_depth_fused_status_bytes(ncols) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(look-back status) failed");
     bool status_zeroed;
+    rc = chunk_state(e);
+    if (rc) return rc;
     {
         ProfScope ps(e, "prep_reads_depth");
-        status_zeroed = sta_launch_prep_reads_depth(s, e->wd, e->files_h.data(), nf, *p, ctr, e->fused_status.p, sta_depth_fused_status_bytes(ncols));
+        status_zeroed = sta_launch_prep_reads_depth(s, e->wd, e->files_h.data(), nf, *p, ctr, e->chunk_st, e->fused_status.p, sta_depth_fused_status_bytes(ncols));
     }
     if (p->remove_overlaps) {
         for (int f = 0; f < nf; ++f) {
@@ -1293,13 +1354,7 @@ static int depth_text(sta_engine *e, const sta_depth_params *p, char *out, uint6
             sta_launch_depth_pair(s, d, e->wd.origin, e->wd.tid, e->table.p, slots, (int32_t *)e->fb[(size_t)f].chain.p, ctr);
         }
     }
-    for (int f = 0; f < nf; ++f) {
-        StaReadsDev &d = e->files_h[(size_t)f];
-        if (!d.n) continue;
-        if (e->scan_tmp.ensure(sta_scan_tmp_bytes(d.n) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
-        ProfScope ps(e, "maxend_scan");
-        sta_launch_maxend_scan(s, d, e->scan_tmp.p, e->scan_tmp.cap);
-    }
+    // (R.maxend comes out of k_prep_reads_depth: nothing changes the set of kept reads or their ends afterwards)
     const size_t drows = (size_t)(nf + 1) * (size_t)(ncols + 1);
     if (e->diff.ensure(drows * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(depth rows) failed");
     const bool own = out == nullptr;

@@ -11,18 +11,128 @@
 #include "baq_band7s.h"
 #include <cstdlib>
 
+
+// ------------------------------------------------------------------------------------------------
+// Block-level scan step shared by the three-phase scans below and by the preparation kernels' in-kernel prefix maximum.
+#define SCAN_BLOCK 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+
+struct OpSumU64 { typedef unsigned long long T; static __device__ T id() { return 0; } static __device__ T f(T a, T b) { return a + b; } };
+struct OpMaxI32 { typedef int T; static __device__ T id() { return INT32_MIN; } static __device__ T f(T a, T b) { return a > b ? a : b; } };
+struct OpSumI32 { typedef int T; static __device__ T id() { return 0; } static __device__ T f(T a, T b) { return a + b; } };
+
+template <class Op> __device__ typename Op::T block_scan_incl(typename Op::T v, typename Op::T *wave_tot /*LDS[5]*/, typename Op::T &block_total)
+{
+    typedef typename Op::T T;
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        T u = __shfl_up(v, o);
+        if (lane >= o) v = Op::f(u, v);
+    }
+    if (lane == 63) wave_tot[wid] = v;
+    __syncthreads();
+    T pre = Op::id();
+    for (int w = 0; w < wid; ++w) pre = Op::f(pre, wave_tot[w]);
+    T tot = Op::id();
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) tot = Op::f(tot, wave_tot[w]);
+    block_total = tot;
+    __syncthreads();
+    return Op::f(pre, v);
+}
+
+
+// R.maxend inside the preparation kernels (one launch instead of prep + three scan launches per file and window).  Every
+// workgroup owns `chunk` consecutive reads: it writes the running maximum of its own reads, publishes the chunk's maximum, takes
+// the maximum of every chunk in front of it (all of them read at once, 256 per round: a window has at most 2048 chunks) and raises
+// the entries that maximum exceeds.  Chunks are numbered by a ticket, so a workgroup only ever waits for workgroups that started
+// before it; neither the ticket nor the published words are cleared between launches -- the host passes the ticket's base and a
+// launch number (`epoch`) that the words carry in their upper half.
+struct ChunkScan {
+    unsigned long long *words;       // [0] ticket counter (monotone), [1 + b] = epoch << 32 | bits of chunk b's maximum
+    unsigned long long ticket_base;
+    uint32_t epoch;
+    int32_t nchunks;                 // tickets beyond the chunks do the launch's other work (k_prep_reads: the column -> read index)
+    int64_t chunk;                   // reads per chunk, a multiple of 256
+};
+
+__device__ __forceinline__ int chunk_ticket(const ChunkScan &cs)
+{
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = (int)(atomicAdd(&cs.words[0], 1ull) - cs.ticket_base);
+    __syncthreads();
+    return s_ticket;
+}
+
+// one tile of 256 reads: `ke` = the read's end if it is kept, INT32_MIN otherwise (also for threads beyond the chunk)
+__device__ __forceinline__ void chunk_tile(int ke, int &run, int32_t *maxend, int64_t i, bool in)
+{
+    __shared__ int s_wt[SCAN_BLOCK / 64];
+    int tot;
+    const int inc = block_scan_incl<OpMaxI32>(ke, s_wt, tot);
+    if (in) maxend[i] = inc > run ? inc : run;
+    run = tot > run ? tot : run;
+}
+
+__device__ __forceinline__ void chunk_finish(const ChunkScan &cs, int b, int run, int32_t *maxend, int64_t i0, int64_t i1)
+{
+    __shared__ int s_pre[SCAN_BLOCK / 64];
+    if (threadIdx.x == 0) __hip_atomic_store(&cs.words[1 + b], ((unsigned long long)cs.epoch << 32) | (uint32_t)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int pre = INT32_MIN;
+    for (int j = threadIdx.x; j < b; j += SCAN_BLOCK) {
+        unsigned long long v;
+        // (the word IS the value: one device-scope store, no fence pair -- as in dev_lookback.h)
+        while ((uint32_t)((v = __hip_atomic_load(&cs.words[1 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != cs.epoch) __builtin_amdgcn_s_sleep(2);
+        const int m = (int)(uint32_t)v;
+        pre = m > pre ? m : pre;
+    }
+    for (int o = 32; o; o >>= 1) { const int y = __shfl_down(pre, o); pre = y > pre ? y : pre; }
+    if ((threadIdx.x & 63) == 0) s_pre[threadIdx.x >> 6] = pre;
+    __syncthreads();
+    pre = s_pre[0];
+    for (int w = 1; w < SCAN_BLOCK / 64; ++w) pre = s_pre[w] > pre ? s_pre[w] : pre;
+    if (pre == INT32_MIN) return;
+    // (every thread re-reads what it wrote itself; maxend is non-decreasing, so only the chunk's first entries change)
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += SCAN_BLOCK) if (maxend[i] < pre) maxend[i] = pre;
+}
+
 // ------------------------------------------------------------------------------------------------
 struct PrepArgs {
     int32_t min_mq, rflag_require, rflag_filter, flag, all, baq_force_slow, min_qlen, baq_class_s;
 };
 
-__global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, PrepArgs P, StaCounters *ctr)
+// wfirst[f][w] = first read of file f that starts at or beyond column col_beg + 64 w (w = 0 .. nwaves): one thread per entry, a
+// binary search each over the INPUT positions.  The tile kernels find their reads from it with one more coalesced load instead of
+// two 64-ary searches (eight dependent loads at the head of every wave).
+__device__ __forceinline__ void wave_first_entry(const StaWinDev &W, uint32_t *__restrict__ wfirst, int64_t nwaves, int64_t i)
 {
-    // grid-stride over the reads: the counters are reduced ONCE per block at the end (a counter word sustains only ~90
-    // atomics/us, so one reduction per 256 reads cost more than the reads themselves)
+    if (i >= (nwaves + 1) * W.nfiles) return;
+    const int f = (int)(i / (nwaves + 1)); const int64_t w = i - (int64_t)f * (nwaves + 1);
+    const StaReadsDev &R = W.files[f];
+    const int64_t key = (int64_t)W.col_beg + 64 * w;
+    int64_t lo = 0, hi = R.n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)R.pos[mid] >= key) hi = mid; else lo = mid + 1; }
+    wfirst[i] = (uint32_t)lo;
+}
+
+__global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, PrepArgs P, StaCounters *ctr, ChunkScan cs, uint32_t *wfirst, int64_t nwaves)
+{
+    // a chunk of consecutive reads per workgroup (see ChunkScan); the counters are reduced ONCE per block at the end (a counter word
+    // sustains only ~90 atomics/us, so one reduction per 256 reads cost more than the reads themselves)
+    const int b = chunk_ticket(cs);
+    if (b >= cs.nchunks) {       // the launch's other work: the tile kernels' column -> read index of every file (first file's launch only)
+        wave_first_entry(W, wfirst, nwaves, (int64_t)(b - cs.nchunks) * 256 + threadIdx.x);
+        return;
+    }
     unsigned long long piled = 0, kept = 0;
-    unsigned long long c_baq = 0, c_fast = 0, c_bw8 = 0, c_gen = 0, m_lqf = 0, m_lq = 0, m_bw = 0, c_s = 0, m_lqs = 0, c_bw7l = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R.n; i += (int64_t)gridDim.x * blockDim.x) {
+    unsigned long long c_baq = 0, c_fast = 0, c_bw8 = 0, c_gen = 0, m_lqf = 0, m_lq = 0, m_bw = 0, c_s = 0, m_lqs = 0, c_bw7l = 0, c_olap = 0;
+    const int64_t i0 = (int64_t)b * cs.chunk, i1 = i0 + cs.chunk < R.n ? i0 + cs.chunk : R.n;
+    int run = INT32_MIN;
+    for (int64_t base = i0; base < i1; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        const bool in = i < i1;
+        int ke = INT32_MIN;
+        if (in) {
         int32_t pos = R.pos[i];
         uint32_t flag = R.flag[i];
         uint32_t c0 = R.cig_off[i], c1 = R.cig_off[i + 1];
@@ -69,7 +179,7 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
             int64_t mpos = R.mpos[i];
             long long isz = R.isize[i]; if (isz < 0) isz = -isz;
             bool no = (mtid >= 0 && mtid != W.tid) || (isz >= 2ll * lq && mpos >= W.origin + end);
-            if (!no) info |= RI_OLAP_EL;
+            if (!no) { info |= RI_OLAP_EL; c_olap += 1; }
         }
         // BAQ needed? (realn.c early returns, A.4)  baq_cls: 0 none, 1 band width 7 in place, 2 through the list, 3 class-S candidate
         int baq_cls = 0, baq_bw = 0, baq_gbw = 0;
@@ -120,31 +230,54 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
         R.info[i] = info;
         if (keep) {
             kept += 1;
-            int32_t a = pos > W.col_beg ? pos : W.col_beg, b = end < W.col_end ? end : W.col_end;
-            if (b > a) piled += (unsigned long long)(b - a);
+            ke = end;
+            int32_t ca = pos > W.col_beg ? pos : W.col_beg, cb = end < W.col_end ? end : W.col_end;
+            if (cb > ca) piled += (unsigned long long)(cb - ca);
         }
+        }
+        chunk_tile(ke, run, R.maxend, i, in);
     }
+    chunk_finish(cs, b, run, R.maxend, i0, i1);
     // block reduce, then one atomic per counter and block
-    unsigned long long v[12] = { piled, kept, c_baq, c_fast, c_bw8, c_gen, c_s, c_bw7l, m_lqf, m_lq, m_bw, m_lqs };
-    unsigned long long *const dst[12] = { &ctr->piled_bases, &ctr->n_kept, &ctr->n_baq, &ctr->n_baq_fast, &ctr->n_baq_bw8, &ctr->n_baq_general,
-                                          &ctr->n_baq_s, &ctr->n_baq_bw7l, &ctr->max_lq_fast, &ctr->max_lq, &ctr->max_bw, &ctr->max_lq_s };
-    block_reduce_atomic<12, 8>(v, dst);
+    unsigned long long v[13] = { piled, kept, c_baq, c_fast, c_bw8, c_gen, c_s, c_bw7l, c_olap, m_lqf, m_lq, m_bw, m_lqs };
+    unsigned long long *const dst[13] = { &ctr->piled_bases, &ctr->n_kept, &ctr->n_baq, &ctr->n_baq_fast, &ctr->n_baq_bw8, &ctr->n_baq_general,
+                                          &ctr->n_baq_s, &ctr->n_baq_bw7l, &ctr->n_olap_el, &ctr->max_lq_fast, &ctr->max_lq, &ctr->max_bw, &ctr->max_lq_s };
+    block_reduce_atomic<13, 9>(v, dst);
 }
 
-void sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
-                           const sta_mplp_params &p, StaCounters *ctr)
+// chunks of a launch over n reads: at most 2048, each a multiple of 256 reads
+static void chunk_geometry(int64_t n, ChunkScan &cs, StaChunkState &st)
+{
+    int64_t nc = (n + 255) / 256;
+    if (nc > 2048) nc = 2048;
+    cs.chunk = ((n + nc - 1) / nc + 255) / 256 * 256;
+    cs.nchunks = (int32_t)((n + cs.chunk - 1) / cs.chunk);
+    if (++st.epoch == 0) st.epoch = 1;
+    cs.words = st.words; cs.ticket_base = st.tickets; cs.epoch = st.epoch;
+}
+
+bool sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
+                           const sta_mplp_params &p, StaCounters *ctr, StaChunkState &st, uint32_t *wfirst)
 {
     // STA_BAQ_CLASS_S=0: the round-3 kernels take every band-width-7 read in place (A/B measurements, tests of both paths)
     static const int class_s = [] { const char *e = getenv("STA_BAQ_CLASS_S"); return e ? atoi(e) : 1; }();
     PrepArgs a{ p.min_mq, p.rflag_require, p.rflag_filter, p.flag, p.all, getenv("STA_BAQ_FORCE_SLOW") ? 1 : 0, p.min_qlen, class_s && !getenv("STA_BAQ_FORCE_SLOW") };
+    const int64_t ncols = (int64_t)w.col_end - w.col_beg, nwaves = (ncols + 63) / 64;
+    bool wf_done = !(wfirst && ncols > 0 && w.nfiles > 0);
     for (int f = 0; f < nfiles; ++f) {
         const StaReadsDev &R = files_host[f];
         if (R.n == 0) continue;
-        int64_t nb = (R.n + 255) / 256;
-        if (nb > 2048) nb = 2048;
+        ChunkScan cs;
+        chunk_geometry(R.n, cs, st);
+        int64_t nb = cs.nchunks;
+        const bool wf = !wf_done;            // the first launch also builds the column -> read index of EVERY file (input positions only)
+        if (wf) nb += ((nwaves + 1) * w.nfiles + 255) / 256;
         hipMemsetAsync(R.chain, 0, 4, s);
-        hipLaunchKernelGGL(k_prep_reads, dim3((unsigned)nb), dim3(256), 0, s, R, w, a, ctr);
+        hipLaunchKernelGGL(k_prep_reads, dim3((unsigned)nb), dim3(256), 0, s, R, w, a, ctr, cs, wf ? wfirst : nullptr, nwaves);
+        st.tickets += (unsigned long long)nb;
+        wf_done = wf_done || wf;
     }
+    return wf_done;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -230,12 +363,19 @@ void sta_launch_cap_mapq(hipStream_t s, const StaReadsDev &R, const StaWinDev &w
 // ------------------------------------------------------------------------------------------------
 struct PrepDepthArgs { int32_t flag, incl_flag, require_flag, min_mqual, min_len; };
 
-__global__ void __launch_bounds__(256) k_prep_reads_depth(StaReadsDev R, StaWinDev W, PrepDepthArgs P, StaCounters *ctr, uint4 *zero, int64_t zero_n16)
+__global__ void __launch_bounds__(256) k_prep_reads_depth(StaReadsDev R, StaWinDev W, PrepDepthArgs P, StaCounters *ctr, uint4 *zero, int64_t zero_n16, ChunkScan cs)
 {
     // (also clears the look-back status words of the depth kernel that follows: one small launch less per window)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n16; i += (int64_t)gridDim.x * blockDim.x) zero[i] = make_uint4(0, 0, 0, 0);
     unsigned long long piled = 0, kept = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = chunk_ticket(cs);
+    const int64_t i0 = (int64_t)b * cs.chunk, i1 = i0 + cs.chunk < R.n ? i0 + cs.chunk : R.n;
+    int run = INT32_MIN;
+    for (int64_t base = i0; base < i1; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        const bool in = i < i1;
+        int ke = INT32_MIN;
+        if (in) {
         int32_t pos = R.pos[i];
         uint32_t flag = R.flag[i];
         uint32_t c0 = R.cig_off[i], c1 = R.cig_off[i + 1];
@@ -277,27 +417,32 @@ __global__ void __launch_bounds__(256) k_prep_reads_depth(StaReadsDev R, StaWinD
         R.clip[i] = 0;
         if (ok) {
             kept += 1;
-            int32_t a = pos > W.col_beg ? pos : W.col_beg, b = end < W.col_end ? end : W.col_end;
-            if (b > a) piled += (unsigned long long)(b - a);
+            ke = cig_end;
+            int32_t ca = pos > W.col_beg ? pos : W.col_beg, cb = end < W.col_end ? end : W.col_end;
+            if (cb > ca) piled += (unsigned long long)(cb - ca);
         }
+        }
+        chunk_tile(ke, run, R.maxend, i, in);
     }
+    chunk_finish(cs, b, run, R.maxend, i0, i1);
     unsigned long long v[2] = { piled, kept };
     unsigned long long *const dst[2] = { &ctr->piled_bases, &ctr->n_kept };
     block_reduce_atomic<2, 2>(v, dst);
 }
 
 bool sta_launch_prep_reads_depth(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
-                                 const sta_depth_params &p, StaCounters *ctr, void *zero, size_t zero_bytes)
+                                 const sta_depth_params &p, StaCounters *ctr, StaChunkState &st, void *zero, size_t zero_bytes)
 {
     PrepDepthArgs a{ p.flag, p.incl_flag, p.require_flag, p.min_mqual, p.min_len };
     bool zeroed = false;                       // `zero` (16-byte aligned, a multiple of 16 bytes) is cleared by the first launch
     for (int f = 0; f < nfiles; ++f) {
         const StaReadsDev &R = files_host[f];
         if (R.n == 0) continue;
-        int64_t nb = (R.n + 255) / 256;
-        if (nb > 2048) nb = 2048;
+        ChunkScan cs;
+        chunk_geometry(R.n, cs, st);
         const bool z = !zeroed && zero && zero_bytes % 16 == 0;
-        hipLaunchKernelGGL(k_prep_reads_depth, dim3((unsigned)nb), dim3(256), 0, s, R, w, a, ctr, (uint4 *)(z ? zero : nullptr), (int64_t)(z ? zero_bytes / 16 : 0));
+        hipLaunchKernelGGL(k_prep_reads_depth, dim3((unsigned)cs.nchunks), dim3(256), 0, s, R, w, a, ctr, (uint4 *)(z ? zero : nullptr), (int64_t)(z ? zero_bytes / 16 : 0), cs);
+        st.tickets += (unsigned long long)cs.nchunks;
         zeroed = zeroed || z;
     }
     return zeroed;
@@ -353,32 +498,6 @@ void sta_launch_qual_prep(hipStream_t s, const StaReadsDev &r, int illumina13)
 
 // ------------------------------------------------------------------------------------------------
 // Generic three-phase scan.  TILE elements per 256-thread block.
-#define SCAN_BLOCK 256
-#define SCAN_ITEMS 8
-#define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
-
-struct OpSumU64 { typedef unsigned long long T; static __device__ T id() { return 0; } static __device__ T f(T a, T b) { return a + b; } };
-struct OpMaxI32 { typedef int T; static __device__ T id() { return INT32_MIN; } static __device__ T f(T a, T b) { return a > b ? a : b; } };
-struct OpSumI32 { typedef int T; static __device__ T id() { return 0; } static __device__ T f(T a, T b) { return a + b; } };
-
-template <class Op> __device__ typename Op::T block_scan_incl(typename Op::T v, typename Op::T *wave_tot /*LDS[5]*/, typename Op::T &block_total)
-{
-    typedef typename Op::T T;
-    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int o = 1; o < 64; o <<= 1) {
-        T u = __shfl_up(v, o);
-        if (lane >= o) v = Op::f(u, v);
-    }
-    if (lane == 63) wave_tot[wid] = v;
-    __syncthreads();
-    T pre = Op::id();
-    for (int w = 0; w < wid; ++w) pre = Op::f(pre, wave_tot[w]);
-    T tot = Op::id();
-    for (int w = 0; w < SCAN_BLOCK / 64; ++w) tot = Op::f(tot, wave_tot[w]);
-    block_total = tot;
-    __syncthreads();
-    return Op::f(pre, v);
-}
 
 // Loader functors turn input element i into Op::T
 struct LoadU32 { const uint32_t *p; __device__ unsigned long long operator()(int64_t i) const { return p[i] & 0x7fffffffu; } };   // bit 31 of a line length = "column has data"

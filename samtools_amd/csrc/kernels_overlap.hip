@@ -61,8 +61,9 @@ __device__ __forceinline__ bool in_set(const StaReadsDev &R, int64_t i, int sel)
     return (info & RI_KEEP) && (flag & BAM_FPAIRED) && !(flag & BAM_FMUNMAP);
 }
 
-__global__ void __launch_bounds__(256) k_name_insert(StaReadsDev R, NameSlot *tab, size_t mask, int32_t *chain_next, int sel)
+__global__ void __launch_bounds__(256) k_name_insert(StaReadsDev R, NameSlot *tab, size_t mask, int32_t *chain_next, int sel, const unsigned long long *gate)
 {
+    if (gate && *gate == 0) return;       // mpileup: no read of the window is eligible (counted by k_prep_reads)
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R.n || !in_set(R, i, sel)) return;
     uint32_t n0 = R.name_off[i];
@@ -206,8 +207,9 @@ __device__ __forceinline__ int prev_pushed_pos(const StaReadsDev &R, int64_t x)
 }
 
 __global__ void __launch_bounds__(256) k_name_groups(StaReadsDev R, int64_t origin, int32_t tid, const NameSlot *tab, size_t mask,
-                                                    const int32_t *chain_next, int sel, StaCounters *ctr)
+                                                    const int32_t *chain_next, int sel, StaCounters *ctr, const unsigned long long *gate)
 {
+    if (gate && *gate == 0) return;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R.n || !in_set(R, i, sel)) return;
     uint32_t n0 = R.name_off[i];
@@ -262,15 +264,50 @@ __global__ void __launch_bounds__(256) k_name_groups(StaReadsDev R, int64_t orig
     }
 }
 
+// mpileup, before the name matching: everything the mate-overlap pass needs is set up by ONE launch that looks at the window's
+// number of eligible reads first (StaCounters.n_olap_el, counted by k_prep_reads).  None -- single-end data, the usual case of a
+// long-read or amplicon run: the file's device descriptor is pointed back at the input quality pool and loses its fix-up arrays, and
+// neither the pool copy (one byte in, one out per staged base) nor the table clear nor the matching happens.  Otherwise: working
+// pool = input pool (unless k_qual_prep already built it: qout == NULL), name table cleared, fix_y = -1.
+__global__ void __launch_bounds__(256) k_olap_setup(const unsigned long long *gate, StaReadsDev *dev_file, const uint8_t *__restrict__ qin, uint8_t *__restrict__ qout,
+                                                    uint64_t nbytes, uint4 *__restrict__ table16, uint64_t table_n16, int32_t *__restrict__ fix_y, int64_t n)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    if (*gate == 0) {
+        if (tid == 0) { if (qout) dev_file->qual = const_cast<uint8_t *>(qin); dev_file->fix_y = nullptr; dev_file->fix_mate = nullptr; dev_file->fix_q = nullptr; }
+        return;
+    }
+    if (qout) {
+        const uint64_t n16 = nbytes >> 4;
+        for (uint64_t i = tid; i < n16; i += stride) reinterpret_cast<uint4 *>(qout)[i] = reinterpret_cast<const uint4 *>(qin)[i];
+        if (tid < (nbytes & 15)) qout[(n16 << 4) + tid] = qin[(n16 << 4) + tid];
+    }
+    for (uint64_t i = tid; i < table_n16; i += stride) table16[i] = make_uint4(0, 0, 0, 0);
+    for (uint64_t i = tid; i < (uint64_t)n; i += stride) fix_y[i] = -1;
+}
+
+void sta_launch_overlap_setup(hipStream_t s, const StaReadsDev &r, StaReadsDev *dev_file, bool copy_qual, void *table, size_t slots, const StaCounters *ctr)
+{
+    if (r.n == 0) return;
+    uint64_t work = (r.n_bases_total >> 4) > slots ? (r.n_bases_total >> 4) : slots;
+    uint64_t nb = (work + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(k_olap_setup, dim3((unsigned)nb), dim3(256), 0, s, &ctr->n_olap_el, dev_file, r.qual_in, copy_qual ? r.qual : (uint8_t *)nullptr,
+                       (uint64_t)r.n_bases_total, (uint4 *)table, (uint64_t)(slots * sizeof(NameSlot) / 16), r.fix_y, r.n);
+}
+
 static void run_names(hipStream_t s, const StaReadsDev &r, int64_t origin, int32_t tid, void *table, size_t slots,
                       int32_t *chain_next, int sel, StaCounters *ctr)
 {
     if (r.n == 0) return;
-    hipMemsetAsync(table, 0, slots * sizeof(NameSlot), s);
+    // (mpileup: sta_launch_overlap_setup cleared the table, and the two kernels return at once when no read is eligible)
+    const unsigned long long *gate = sel == SEL_MPLP ? &ctr->n_olap_el : nullptr;
+    if (sel != SEL_MPLP) hipMemsetAsync(table, 0, slots * sizeof(NameSlot), s);
     unsigned nb = (unsigned)((r.n + 255) / 256);
-    hipLaunchKernelGGL(k_name_insert, dim3(nb), dim3(256), 0, s, r, (NameSlot *)table, slots - 1, chain_next, sel);
+    hipLaunchKernelGGL(k_name_insert, dim3(nb), dim3(256), 0, s, r, (NameSlot *)table, slots - 1, chain_next, sel, gate);
     hipLaunchKernelGGL(k_name_groups, dim3(nb), dim3(256), 0, s, r, origin, tid, (const NameSlot *)table, slots - 1,
-                       (const int32_t *)chain_next, sel, ctr);
+                       (const int32_t *)chain_next, sel, ctr, gate);
 }
 
 size_t sta_overlap_table_bytes(size_t slots) { return slots * sizeof(NameSlot); }

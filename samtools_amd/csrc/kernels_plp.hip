@@ -648,7 +648,7 @@ __device__ __forceinline__ void wave_range_indexed(const StaReadsDev &R, const u
 }
 
 __global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THREADS), amdgpu_waves_per_eu(6, 8))) k_mplp_len_rm(StaWinDev W, MplpDevPar P, uint32_t *line_len, uint2 *colinfo, const uint32_t *__restrict__ wfirst,
-                                                                              unsigned long long *__restrict__ status, uint64_t *__restrict__ offs, StaCounters *ctr)
+                                                                              unsigned long long *__restrict__ status, uint64_t *__restrict__ offs, StaCounters *ctr, int maxcnt)
 {
     __shared__ LenLds L;
     const int t = threadIdx.x;
@@ -670,6 +670,17 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THRE
             const int64_t nwaves = (ncols + 63) >> 6, w_lo = c0 >> 6, w_hi = w_lo + (LEN_TC >> 6) < nwaves ? w_lo + (LEN_TC >> 6) : nwaves;
             wave_range_indexed(R, wfirst + (int64_t)f * (nwaves + 1), w_lo, w_hi, t0, rlo, rhi);
             if (t == 0) { L.rlo = rlo; L.rhi = rhi; }
+        } else if (t < 128 && maxcnt > 0) {
+            // the second wave, meanwhile: the -d detector (kernels_maxcnt.hip) for the reads that START in this tile (the first tile
+            // also takes the reads in front of the window, the last one those behind it).  A read can be dropped only if maxcnt - 1
+            // kept reads in front of it still reach its start: maxend is non-decreasing, so that is one look at maxend[i - maxcnt + 1].
+            const int64_t nwaves = (ncols + 63) >> 6, w_lo = c0 >> 6, w_hi = w_lo + (LEN_TC >> 6) < nwaves ? w_lo + (LEN_TC >> 6) : nwaves;
+            const uint32_t *wf = wfirst + (int64_t)f * (nwaves + 1);
+            const int64_t a = tile == 0 ? 0 : (int64_t)wf[w_lo], b = w_hi == nwaves ? R.n : (int64_t)wf[w_hi];
+            bool hit = false;
+            for (int64_t i = (a > maxcnt - 1 ? a : maxcnt - 1) + (t - 64); i < b; i += 64)
+                hit = hit || ((R.info[i] & RI_KEEP) && R.maxend[i - maxcnt + 1] > R.pos[i] - 1);
+            if (__ballot(hit) && t == 64) atomicAdd(&ctr->maxcnt_flag, 1ull);
         }
         __syncthreads();
         const long long rlo = L.rlo, rhi = L.rhi;
@@ -741,7 +752,6 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THRE
     }
     // (the entry behind the last column: the end of the last tile, or -- a window of whole tiles -- the start of the tile behind it)
     if (t == LEN_THREADS - 1 && c0 + ntile == ncols) offs[ncols] = ntile == LEN_TC ? 0 : L.tile_bytes;
-    (void)ctr;
 }
 
 // exclusive scan of the measuring tiles' text bytes -> tbase[0 .. ntiles] (tbase[ntiles] = the window's text bytes), and the window's
@@ -767,6 +777,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const unsigned long long *__
     if (t == 1023) {
         tbase[ntiles] = s_sum[1023];
         ctr->n_lines = s_rows[1023] >> 31; ctr->n_data_cols = s_rows[1023] & 0x7fffffffull; ctr->max_wave_bytes = s_max[1023];
+        ctr->out_bytes = s_sum[1023];                       // (the plan reads the window's text bytes with the counters: one transfer)
     }
 }
 
@@ -882,14 +893,14 @@ void sta_launch_wave_first(hipStream_t s, const StaWinDev &w, uint32_t *wfirst, 
 }
 
 bool sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr, const uint32_t *wfirst,
-                         void *status, uint64_t *offs)
+                         void *status, uint64_t *offs, int detect_maxcnt)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return false;
     if (sta_mplp_has_fast_path(p) && colinfo && wfirst && status && offs && sta_mplp_tile_ok(p)) {
         const int64_t ntiles = (ncols + LEN_TC - 1) / LEN_TC;
         hipLaunchKernelGGL(k_mplp_len_rm, dim3((unsigned)ntiles), dim3(LEN_THREADS), 0, s, w, make_par(p, w.tlen), line_len, colinfo, wfirst,
-                           (unsigned long long *)status, offs, ctr);
+                           (unsigned long long *)status, offs, ctr, detect_maxcnt);
         hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, (const unsigned long long *)status, (uint64_t *)status + 3 * ntiles, ntiles, ctr);
         return true;          // offsets (tile-relative + tile bases), totals and the largest wave are done: no scan / column statistics launches
     }

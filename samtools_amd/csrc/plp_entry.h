@@ -127,7 +127,6 @@ struct MplpDevPar {
 };
 #define TAGKIND (1 << 28)       // file_pass "kind" of tag column t is TAGKIND + t
 
-#define TAGKIND (1 << 28)       // file_pass "kind" of tag column t is TAGKIND + t
 
 // seq_nt16_table (hts.c) by arithmetic: character -> 4-bit code, 15 for anything that is not a nucleotide code letter, '=' or '0'..'3'
 PLP_HD unsigned nt16_arith(unsigned char c)

@@ -72,14 +72,21 @@ struct StaWinDev {
 struct StaCounters {          // device-side reduction targets, zeroed per plan
     unsigned long long n_lines, n_data_cols, n_kept, piled_bases, n_dropped, max_wave_bytes, n_anom, maxcnt_flag, max_lq, max_bw, n_baq, max_lq_fast, n_baq_fast, n_baq_bw8, n_baq_general, n_baq_s, max_lq_s, n_baq_bw7l;
     unsigned long long out_bytes, overflow;      // single-pass kernels: total text bytes of the window; set when the output buffer was too small
+    unsigned long long n_olap_el;                // mpileup: reads eligible for the mate-overlap pass (RI_OLAP_EL), the gate of that pass
 };
 
 // ---- launchers (defined in the .hip files) ----
-void sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
-                           const sta_mplp_params &p, StaCounters *ctr);
+// in-kernel prefix maximum of the preparation kernels (kernels_common.hip ChunkScan): STA_CHUNK_WORDS zero-initialised 8-byte words
+// on the device, and the host's view of the ticket counter / launch number kept in them
+#define STA_CHUNK_WORDS (1 + 2048 + 7)
+struct StaChunkState { unsigned long long *words = nullptr; unsigned long long tickets = 0; uint32_t epoch = 0; };
+// R.end / R.info / R.maxend of every file; with `wfirst` also the tile kernels' column -> read index (returns false when no launch
+// could carry it: every file empty)
+bool sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles, const sta_mplp_params &p, StaCounters *ctr,
+                           StaChunkState &st, uint32_t *wfirst);
 // returns true when it also cleared `zero` (the depth kernel's look-back status): sta_launch_depth_fused then skips its memset
 bool sta_launch_prep_reads_depth(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
-                                 const sta_depth_params &p, StaCounters *ctr, void *zero = nullptr, size_t zero_bytes = 0);
+                                 const sta_depth_params &p, StaCounters *ctr, StaChunkState &st, void *zero = nullptr, size_t zero_bytes = 0);
 void sta_launch_cap_mapq(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int thres, int min_mq, StaCounters *ctr);
 void sta_launch_qual_prep(hipStream_t s, const StaReadsDev &r, int illumina13);
 void sta_launch_maxend_scan(hipStream_t s, const StaReadsDev &r, void *tmp, size_t tmp_bytes);
@@ -91,7 +98,8 @@ void sta_launch_len_scan(hipStream_t s, const uint32_t *len, uint64_t *offs, int
 // true: colinfo, TILE-RELATIVE row offsets + tile bases (sta_mplp_tile_base), n_lines, n_data_cols and max_wave_bytes are all produced, the
 // caller skips the scan and column-statistics launches.  Otherwise the generic walker k_mplp_len (line lengths only), false.
 bool sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo /*[nfiles][ncols] (count, seq bytes)*/,
-                         StaCounters *ctr, const uint32_t *wfirst /* sta_launch_wave_first's table */, void *status /* sta_mplp_len_status_bytes() */, uint64_t *offs);
+                         StaCounters *ctr, const uint32_t *wfirst /* sta_launch_wave_first's table */, void *status /* sta_mplp_len_status_bytes() */, uint64_t *offs,
+                         int detect_maxcnt /* > 0: also run the -d detector (kernels_maxcnt.hip) for this cap */);
 // wfirst[nfiles][ncols / 64 + 2]: first read starting at or beyond every 64-column group (where the tile kernels start looking)
 void sta_launch_wave_first(hipStream_t s, const StaWinDev &w, uint32_t *wfirst, void *status);
 size_t sta_mplp_len_status_bytes(int64_t ncols);
@@ -127,6 +135,9 @@ void sta_launch_statcov(hipStream_t s, const int64_t *pos, const int32_t *delta,
 // overlap (mate) resolution
 size_t sta_overlap_table_slots(int64_t n_reads);
 size_t sta_overlap_table_bytes(size_t slots);
+// mpileup: the pass's setup, gated on StaCounters.n_olap_el on the device (kernels_overlap.hip k_olap_setup); `dev_file` = the file's
+// entry of StaWinDev.files, `table` must hold sta_overlap_table_bytes(slots)
+void sta_launch_overlap_setup(hipStream_t s, const StaReadsDev &r, StaReadsDev *dev_file, bool copy_qual, void *table, size_t slots, const StaCounters *ctr);
 void sta_launch_overlap(hipStream_t s, const StaReadsDev &r, int64_t origin, int32_t tid, void *table, size_t slots,
                         int32_t *chain_next, StaCounters *ctr);
 // -d cap

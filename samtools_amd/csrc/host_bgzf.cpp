@@ -2,6 +2,10 @@
 #include "host_bgzf.h"
 #include "host_inflate.h"
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -234,6 +238,69 @@ bool looks_like_bgzf(const uint8_t *h, size_t n)
 }
 
 }  // namespace
+
+// ---- the mapped file ----
+std::unique_ptr<BgzfMap> BgzfMap::open(const std::string &path, std::string *err)
+{
+    if (path == "-") return nullptr;
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) { if (err) *err = "failed to open " + path; return nullptr; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 18) { ::close(fd); return nullptr; }
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) return nullptr;
+    if (!looks_like_bgzf((const uint8_t *)m, (size_t)st.st_size < 64 ? (size_t)st.st_size : 64)) { munmap(m, (size_t)st.st_size); return nullptr; }
+    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    std::unique_ptr<BgzfMap> r(new BgzfMap());
+    r->base_ = (const uint8_t *)m; r->size_ = (size_t)st.st_size;
+    return r;
+}
+
+BgzfMap::~BgzfMap() { if (base_) munmap(const_cast<uint8_t *>(base_), size_); }
+
+int BgzfMap::block_at(uint64_t *coffset, Block *b) const
+{
+    const uint64_t o = *coffset;
+    if (o >= size_) return o == size_ ? 0 : -1;
+    // SAM spec 4.1 (as BgzfSource::io_loop): 12 fixed bytes, XLEN, extra subfields with BC = BSIZE - 1, deflate data, CRC32, ISIZE
+    if (size_ - o < 18) return -1;
+    const uint8_t *h = base_ + o;
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return -1;
+    const uint32_t xlen = h[10] | (uint32_t)h[11] << 8;
+    if (size_ - o < 12 + (uint64_t)xlen + 8) return -1;
+    uint32_t bsize = 0; bool found = false;
+    const uint8_t *x = h + 12;
+    for (uint32_t k = 0; k + 4 <= xlen;) {
+        const uint32_t sl = x[k + 2] | (uint32_t)x[k + 3] << 8;
+        if (x[k] == 'B' && x[k + 1] == 'C' && sl == 2 && k + 6 <= xlen) { bsize = (x[k + 4] | (uint32_t)x[k + 5] << 8) + 1u; found = true; }
+        k += 4 + sl;
+    }
+    if (!found || bsize < 12 + xlen + 8 || size_ - o < bsize) return -1;
+    const uint32_t rest = bsize - 12 - xlen;
+    if (rest < 8 || rest > (1u << 16) + 8) return -1;
+    b->comp = h + 12 + xlen; b->clen = rest - 8;
+    memcpy(&b->crc, b->comp + b->clen, 4); memcpy(&b->isize, b->comp + b->clen + 4, 4);
+    if (b->isize > (1u << 16)) return -1;
+    *coffset = o + bsize;
+    return 1;
+}
+
+bool bgzf_inflate_block(const BgzfMap::Block &b, uint8_t *dst)
+{
+    static const bool use_fast = !(getenv("STA_INFLATE") && !strcmp(getenv("STA_INFLATE"), "zlib"));
+    if (b.isize == 0) return true;            // (whatever the deflate data says: an empty block carries nothing)
+    size_t fl = 0;
+    if (use_fast && fast_inflate(b.comp, b.clen, dst, b.isize, &fl) == 0 && fl == b.isize && fast_crc32(dst, fl) == b.crc) return true;
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef *>(b.comp); zs.avail_in = b.clen;
+    zs.next_out = dst; zs.avail_out = b.isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && zs.avail_out == 0 && (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.isize) == b.crc;
+    inflateEnd(&zs);
+    return ok;
+}
 
 std::unique_ptr<ByteSource> ByteSource::open(const std::string &path, int threads, std::string *err)
 {

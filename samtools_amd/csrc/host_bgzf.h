@@ -25,6 +25,25 @@ public:
     static std::unique_ptr<ByteSource> open_bgzf_at(const std::string &path, int threads, uint64_t coffset, std::string *err);
 };
 
+// A BGZF file mapped read-only, for readers that cut it into blocks themselves and inflate them on their own threads straight into
+// their own buffers (host_chunk.h: the stream interface above hands every inflated byte over through one thread -- a copy of the
+// whole uncompressed file on the critical path; here no inflated byte is copied at all).
+class BgzfMap {
+public:
+    struct Block { const uint8_t *comp; uint32_t clen, crc, isize; };     // deflate data (readable 8 bytes beyond: CRC32 + ISIZE follow)
+    // nullptr when the path cannot be mapped (stdin, a pipe) or does not start with a BGZF block
+    static std::unique_ptr<BgzfMap> open(const std::string &path, std::string *err);
+    ~BgzfMap();
+    // the block at compressed offset *coffset (advanced behind it): 1 = a block (isize may be 0: the end-of-file marker), 0 = clean end
+    // of the file, -1 = not a BGZF block / truncated
+    int block_at(uint64_t *coffset, Block *b) const;
+private:
+    const uint8_t *base_ = nullptr; size_t size_ = 0;
+};
+// inflates one block into dst[0, isize) -- nothing beyond is written -- and checks size and CRC (host_inflate.h first, zlib for
+// whatever that does not deliver: zlib's verdict counts)
+bool bgzf_inflate_block(const BgzfMap::Block &b, uint8_t *dst);
+
 int io_default_threads();
 // per-input worker count when a command reads n_inputs files at once: the default is shared out (at least 1 each), so that
 // a hundred-file mpileup does not start a thousand threads

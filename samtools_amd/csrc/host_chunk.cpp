@@ -40,6 +40,14 @@ void Chunk::append(const Rec &r)
     name_off.push_back((uint32_t)names.size());
 }
 
+void Chunk::reset()
+{
+    tid.clear(); l_qseq.clear(); mtid.clear(); rlen.clear(); pos.clear(); mpos.clear(); isize.clear(); flag.clear(); mapq.clear(); aux.clear();
+    cig_off.clear(); base_off8.clear(); name_off.clear(); cigar.clear(); seq.clear(); qual.clear(); bq.clear(); has_bq_pool = false; names.clear();
+    n_tags = 0; tag_off.clear(); tag_text.clear(); tag_has.clear();
+    raw.reset(); rec_off.clear(); raw_ok = true;
+}
+
 void Chunk::close()
 {
     if (cig_off.empty()) { cig_off.push_back(0); base_off8.push_back(0); name_off.push_back(0); }
@@ -71,18 +79,180 @@ void Chunk::to_rec(int64_t i, Rec &r) const
 // ------------------------------------------------------------------------------------------------ ChunkReader
 static constexpr size_t GROUP_BYTES = 1 << 20;
 
+static constexpr size_t GROUP_HEAD = 1 << 16;      // free bytes in front of a mapped group's data: room for the record carried in
+
 ChunkReader::ChunkReader(AlnReader *rd, int threads, bool keep_raw) : rd_(rd), keep_raw_(keep_raw)
 {
     if (threads < 1) threads = 1;
     max_ahead_ = (size_t)threads * 2 + 2;
-    for (int i = 0; i < threads; ++i) th_.emplace_back([this] { work(); });
+    // a BAM file on disk is read through a mapping (work_mapped); anything else -- SAM text, stdin, STA_CHUNK_MAP=0 -- through the
+    // reader's byte stream (work)
+    std::string path, err; uint64_t coff = 0, consumed = 0;
+    const char *ev = getenv("STA_CHUNK_MAP");
+    if (!(ev && atoi(ev) == 0) && rd->record_stream_position(&path, &coff, &consumed)) {
+        map_ = BgzfMap::open(path, &err);
+        if (map_) {
+            cut_off_ = coff;
+            Link l0; l0.skip = consumed;
+            links_[0] = std::move(l0);
+            rd->release_source();
+        }
+    }
+    for (int i = 0; i < threads; ++i) th_.emplace_back([this] { if (map_) work_mapped(); else work(); });
 }
 
 ChunkReader::~ChunkReader()
 {
     { std::lock_guard<std::mutex> g(out_m_); stop_ = true; }
-    cv_room_.notify_all(); cv_out_.notify_all();
+    cv_room_.notify_all(); cv_out_.notify_all(); cv_link_.notify_all();
     for (auto &t : th_) if (t.joinable()) t.join();
+}
+
+void ChunkReader::publish_link(uint64_t seq, Link &&l)
+{
+    std::lock_guard<std::mutex> g(out_m_);
+    links_[seq] = std::move(l);
+    cv_link_.notify_all();
+}
+
+void ChunkReader::work_mapped()
+{
+    pvector<uint8_t> own_raw;
+    Rec r; std::string scratch;
+    std::vector<BgzfMap::Block> blocks;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(out_m_);
+            cv_room_.wait(lk, [this] { return stop_ || next_in_ - next_out_ < max_ahead_; });
+            if (stop_) return;
+        }
+        uint64_t seq = 0; size_t total = 0;
+        blocks.clear();
+        {
+            std::lock_guard<std::mutex> g(io_m_);
+            if (io_end_.load()) return;
+            int st = 1;
+            for (;;) {
+                BgzfMap::Block b; uint64_t o = cut_off_;
+                st = map_->block_at(&o, &b);
+                if (st <= 0) break;
+                if (total && total + b.isize > GROUP_BYTES) break;          // (stays for the next group)
+                cut_off_ = o;
+                if (b.isize) { blocks.push_back(b); total += b.isize; }
+            }
+            if (blocks.empty()) {
+                // the end of the file (st == 0) or a damaged block (-1).  A clean end must not leave a record unfinished: what the last
+                // group handed on has to be empty
+                std::unique_lock<std::mutex> lk(out_m_);
+                const uint64_t end_seq = next_in_;
+                cv_link_.wait(lk, [&] { return stop_ || links_.count(end_seq) != 0; });
+                if (stop_) return;
+                const Link &l = links_[end_seq];
+                io_status_.store(st < 0 ? -1 : (l.bad || !l.carry.empty()) ? -2 : 0);
+                io_end_.store(true);
+                cv_out_.notify_all();
+                return;
+            }
+            std::lock_guard<std::mutex> g2(out_m_);
+            seq = next_in_++;
+        }
+        std::shared_ptr<pvector<uint8_t>> keep = keep_raw_ ? get_buf() : nullptr;
+        pvector<uint8_t> &raw = keep ? *keep : own_raw;
+        raw.resize(GROUP_HEAD + total);
+        bool bad = false;
+        {
+            size_t off = GROUP_HEAD;
+            for (const BgzfMap::Block &b : blocks) { if (!bgzf_inflate_block(b, raw.data() + off)) { bad = true; break; } off += b.isize; }
+        }
+        Link in;
+        {
+            std::unique_lock<std::mutex> lk(out_m_);
+            cv_link_.wait(lk, [&] { return stop_ || links_.count(seq) != 0; });
+            if (stop_) return;
+            in = std::move(links_[seq]);
+            links_.erase(seq);
+        }
+        auto c = new_chunk();
+        Link out;
+        size_t beg = GROUP_HEAD, end = GROUP_HEAD + total, q = end;       // records: raw[beg, q); raw[q, end) goes on to the next group
+        bool records = false;
+        if (bad || in.bad) { bad = true; out.bad = true; }
+        else if (in.skip >= total) out.skip = in.skip - total;               // (still inside the header)
+        else {
+            beg += (size_t)in.skip;
+            bool whole = true;                                                // the record carried in ends inside this group
+            if (!in.carry.empty()) {
+                const size_t cl = in.carry.size();
+                uint8_t h[4];
+                for (size_t k = 0; k < 4; ++k) h[k] = k < cl ? in.carry[k] : (k - cl < total ? raw[GROUP_HEAD + (k - cl)] : 0);
+                int32_t bs = 0; memcpy(&bs, h, 4);
+                if (cl + total < 4) whole = false;
+                else if (bs < 32) bad = true;
+                else if (4 + (size_t)bs - cl > total) whole = false;
+                if (!bad) {
+                    if (!whole) { out.carry = std::move(in.carry); out.carry.insert(out.carry.end(), raw.begin() + (long)GROUP_HEAD, raw.begin() + (long)end); }
+                    else if (cl <= GROUP_HEAD) { memcpy(raw.data() + GROUP_HEAD - cl, in.carry.data(), cl); beg = GROUP_HEAD - cl; }
+                    else {
+                        // a carry larger than the free head (a record of more than 64 KiB): the data moves up behind it
+                        raw.resize(cl + total);
+                        memmove(raw.data() + cl, raw.data() + GROUP_HEAD, total);
+                        memcpy(raw.data(), in.carry.data(), cl);
+                        beg = 0; end = cl + total;
+                    }
+                }
+            }
+            if (!bad && whole) {
+                // the walk over the block_size fields: where the last whole record ends
+                q = beg;
+                while (end - q >= 4) {
+                    int32_t bs; memcpy(&bs, &raw[q], 4);
+                    if (bs < 32) { bad = true; break; }
+                    if ((size_t)bs + 4 > end - q) break;
+                    q += (size_t)bs + 4;
+                }
+                if (!bad) { out.carry.assign(raw.begin() + (long)q, raw.begin() + (long)end); records = true; }
+            }
+            if (bad) { out = Link(); out.bad = true; }
+        }
+        publish_link(seq + 1, std::move(out));
+        if (records) {
+            size_t o = beg;
+            while (o < q) {
+                size_t used = 0;
+                int st = rd_->parse_raw(raw.data() + o, q - o, &used, r, scratch);
+                if (st <= 0) { bad = true; break; }
+                o += used;
+                r.rlen = 0;
+                for (uint32_t cg : r.cigar) { int op = (int)(cg & 0xf); if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) r.rlen += (cg >> 4); }
+                if (rd_->past_region(r) && !io_end_.load()) { std::lock_guard<std::mutex> g2(out_m_); io_status_.store(0); io_end_.store(true); cv_out_.notify_all(); }
+                if (!rd_->in_region(r)) continue;
+                c->append(r);
+                if (keep) { c->rec_off.push_back((uint32_t)(o - used + 4)); if (r.cigar_from_tag) c->raw_ok = false; }
+            }
+        }
+        c->close();
+        if (keep) { raw.resize(q); c->raw = std::move(keep); }               // (a window uploads up to the end of the last whole record)
+        std::lock_guard<std::mutex> g(out_m_);
+        if (bad && seq < bad_seq_) bad_seq_ = seq;
+        done_[seq] = std::move(c);
+        cv_out_.notify_all();
+    }
+}
+
+std::shared_ptr<Chunk> ChunkReader::new_chunk()
+{
+    std::unique_ptr<Chunk> c;
+    {
+        std::lock_guard<std::mutex> g(cpool_->m);
+        if (!cpool_->free.empty()) { c = std::move(cpool_->free.back()); cpool_->free.pop_back(); }
+    }
+    if (!c) c.reset(new Chunk());
+    std::shared_ptr<ChunkPool> pool = cpool_;       // (held by the deleter: windows may keep chunks beyond the reader's life)
+    return std::shared_ptr<Chunk>(c.release(), [pool](Chunk *p) {
+        p->reset();
+        std::lock_guard<std::mutex> g(pool->m);
+        if (pool->free.size() < 256) pool->free.emplace_back(p); else delete p;
+    });
 }
 
 std::shared_ptr<pvector<uint8_t>> ChunkReader::get_buf()
@@ -128,7 +298,7 @@ void ChunkReader::work()
             std::lock_guard<std::mutex> g2(out_m_);
             seq = next_in_++;
         }
-        auto c = std::make_shared<Chunk>();
+        auto c = new_chunk();
         size_t o = 0; bool bad = false;
         while (o < raw.size()) {
             size_t used = 0;

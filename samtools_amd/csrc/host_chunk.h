@@ -9,6 +9,7 @@
 #include "host_io.h"
 #include "host_pump.h"
 #include "host_stage.h"
+#include "host_bgzf.h"
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -45,6 +46,7 @@ struct Chunk {
     int64_t endpos(int64_t i) const { int64_t l = (flag[(size_t)i] & 4) ? 0 : rlen[(size_t)i]; return pos[(size_t)i] + (l > 0 ? l : 1); }
     void append(const Rec &r);
     void close();                                 // final offset entries
+    void reset();                                 // empty again, capacities kept (chunks go round: ChunkReader::new_chunk)
     void to_rec(int64_t i, Rec &r) const;         // materialise one record (reads that stay carried across windows)
 };
 
@@ -74,7 +76,24 @@ private:
     struct RawPool { std::mutex m; std::vector<std::unique_ptr<pvector<uint8_t>>> free; };
     std::shared_ptr<RawPool> pool_ = std::make_shared<RawPool>();
     std::shared_ptr<pvector<uint8_t>> get_buf();
+    // chunks go round as well: a fresh Chunk per group meant ~20 growing vectors each, i.e. allocator calls, page faults and unmaps by
+    // the hundred thousand per second of input -- which do not scale beyond a few threads (address-space lock, TLB shootdowns)
+    struct ChunkPool { std::mutex m; std::vector<std::unique_ptr<Chunk>> free; };
+    std::shared_ptr<ChunkPool> cpool_ = std::make_shared<ChunkPool>();
+    std::shared_ptr<Chunk> new_chunk();
     void work();
+    // BAM files on disk: the file is mapped, every parser thread cuts the next group of BGZF blocks (under io_m_, headers only), inflates
+    // them itself straight into the group's buffer and parses it -- no inflated byte passes through a shared stream.  Groups are whole
+    // BGZF blocks, so a record may straddle two of them: a group hands the bytes of its unfinished last record (`carry`) to the next
+    // one, which puts them in front of its own data (the buffers keep HEAD bytes free for that).  That hand-over is the only serial
+    // step: a walk over the group's block_size fields.
+    struct Link { std::vector<uint8_t> carry; uint64_t skip = 0; bool bad = false; };      // skip: inflated bytes in front of the first record (the header)
+    std::unique_ptr<BgzfMap> map_;
+    uint64_t cut_off_ = 0;                         // compressed offset of the next block to cut (guarded by io_m_)
+    std::map<uint64_t, Link> links_;               // what group seq receives from group seq - 1 (guarded by out_m_)
+    std::condition_variable cv_link_;
+    void publish_link(uint64_t seq, Link &&l);
+    void work_mapped();
 };
 
 // window source over chunked readers

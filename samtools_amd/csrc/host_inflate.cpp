@@ -275,7 +275,10 @@ int fast_inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
                     const uint8_t *src = o - dist;
                     uint8_t *dst = o;
                     o += len;
-                    if (dist >= 8) { do { memcpy(dst, src, 8); dst += 8; src += 8; } while (dst < o); }      // may run up to 7 bytes past o
+                    if (dist >= 8) {                                                                        // (exact: a caller may have live data right behind out_cap)
+                        while (o - dst >= 8) { memcpy(dst, src, 8); dst += 8; src += 8; }
+                        while (dst < o) *dst++ = *src++;
+                    }
                     else if (dist == 1) memset(dst, *src, len);
                     else { while (dst < o) *dst++ = *src++; }
                 } else if (e.op & OP_EOB) break;

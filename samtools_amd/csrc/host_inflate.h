@@ -13,7 +13,8 @@
 namespace sta {
 
 // in[0, in_len): the deflate data; the buffer must be readable up to in + in_len + 8 (bytes beyond in_len are never used for output).
-// out[0, out_cap): the buffer must be writable up to out + out_cap + 16 (wide copies may scribble there).
+// out[0, out_cap): nothing beyond out + out_cap is written (the wide copies of the fast loop stop 274 bytes before it, the last bytes
+// are copied exactly), so a block may be inflated in front of live data when out_cap is its known size.
 // Returns 0 and *out_len on success (the final block was seen and everything fitted), non-zero on any malformed or truncated input.
 int fast_inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t *out_len);
 

@@ -43,6 +43,7 @@ struct AlnReader::Impl {
 
     std::unique_ptr<ByteSource> src;
     std::string path; int threads = 0;       // for seek_voffset(): the source is reopened at a block offset
+    uint64_t open_coffset = 0, pulled = 0;   // where the source was (re)opened in the file, and the inflated bytes taken from it since
     bool is_bam = false;
     std::vector<uint8_t> buf; size_t bp = 0, bl = 0; bool eof = false;
     std::string line; bool have_line = false;
@@ -67,7 +68,7 @@ struct AlnReader::Impl {
         if (buf.empty()) buf.resize(1 << 18);
         size_t n = src->read(buf.data(), buf.size());
         if (n == 0) { eof = true; bp = bl = 0; return false; }
-        bp = 0; bl = n;
+        bp = 0; bl = n; pulled += n;
         return true;
     }
     size_t read(void *dst, size_t n)
@@ -78,7 +79,7 @@ struct AlnReader::Impl {
                 if (n - got >= ((size_t)1 << 18) && !eof) {            // a bulk read: straight into the caller's buffer
                     const size_t k = src->read(d + got, n - got);
                     if (k == 0) { eof = true; bp = bl = 0; break; }
-                    got += k;
+                    got += k; pulled += k;
                     continue;
                 }
                 if (!fill()) break;
@@ -201,6 +202,7 @@ bool AlnReader::seek_voffset(uint64_t voffset)
     if (!at) return false;
     im.src = std::move(at);
     im.bp = im.bl = 0; im.eof = false;
+    im.open_coffset = voffset >> 16; im.pulled = 0;
     size_t skip = (size_t)(voffset & 0xffff);
     uint8_t tmp[4096];
     while (skip) { const size_t k = im.read(tmp, skip < sizeof tmp ? skip : sizeof tmp); if (!k) return false; skip -= k; }
@@ -653,12 +655,29 @@ int AlnReader::raw_group(pvector<uint8_t> &out, size_t target, int64_t *n_record
             ++nrec;
         }
     }
-    if (im.src->failed()) return -1;
+    if (im.src && im.src->failed()) return -1;
     if (n_records) *n_records = nrec;
     return nrec ? 1 : 0;
 }
 
 bool AlnReader::is_bam() const { return p_->is_bam; }
+
+// Where the next unread record starts, for a reader that maps the file itself (host_chunk.cpp): the compressed offset the byte source
+// was opened at and the inflated bytes consumed since.  false: not a BAM file on disk, or records have already been handed out.
+bool AlnReader::record_stream_position(std::string *path, uint64_t *coffset, uint64_t *consumed) const
+{
+    const Impl &im = *p_;
+    if (!im.is_bam || im.started || im.path.empty() || im.path == "-") return false;
+    *path = im.path; *coffset = im.open_coffset; *consumed = im.pulled - (im.bl - im.bp);
+    return true;
+}
+
+// the caller reads the file through its own mapping from here on: the stream source and its threads are let go
+void AlnReader::release_source()
+{
+    Impl &im = *p_;
+    im.src.reset(); im.eof = true; im.bp = im.bl = 0;
+}
 
 // parses one record of a group returned by raw_group(); *used = bytes consumed.  1 = record, <0 = malformed
 int AlnReader::parse_raw(const uint8_t *p, size_t avail, size_t *used, Rec &r, std::string &scratch) const
@@ -705,7 +724,7 @@ void AlnReader::parse_ahead()
             r.accepted = false;
             ++b.n;
         }
-        if (status < 0 || im.src->failed()) status = status < 0 ? status : -1;
+        if (status < 0 || (im.src && im.src->failed())) status = status < 0 ? status : -1;
         std::lock_guard<std::mutex> g(im.m);
         if (b.n) im.ready.push_back(std::move(b));
         if (status <= 0) { im.final_status = status; im.done = true; im.cv_ready.notify_all(); return; }

@@ -75,6 +75,8 @@ public:
     int raw_group(pvector<uint8_t> &out, size_t target, int64_t *n_records);      // (a page-locked vector: a BAM group may be uploaded as it is, host_chunk.h)
     int parse_raw(const uint8_t *p, size_t avail, size_t *used, Rec &r, std::string &scratch) const;
     bool is_bam() const;
+    bool record_stream_position(std::string *path, uint64_t *coffset, uint64_t *consumed) const;
+    void release_source();
     // Start reading at a BAI virtual offset (coffset << 16 | offset inside the inflated block) instead of behind the header:
     // what sam_itr_querys does with the index for a region (bam_plcmd.c:550, bam2depth.c:961-975).  Only before the first
     // record has been asked for, BGZF BAM only; false (and nothing changes) otherwise.

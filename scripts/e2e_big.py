@@ -145,6 +145,8 @@ def main():
             print("sharded depth -aa, %d blocks one after the other (%d linear columns): %d bytes vs %d unsharded: %s; seconds per block: %s"
                   % (ns, n_contigs * cols, tot, nw, "IDENTICAL" if h.hexdigest() == whole else "DIFFERENT", " ".join("%.1f" % x for x in times)))
         return
+    if os.environ.get("E2E_NO_ORACLE"):          # timings only (thread sweeps)
+        return
     if os.environ.get("E2E_QUICK"):
         # a short run (GPU minutes): the oracle only for depth -a; mpileup text compared between one and several staging threads
         a, na = sha_of([ENG, "depth", "-a", bam]); b, nb = sha_of([ORA, "depth", "-a", bam])

@@ -258,6 +258,15 @@ int sta_plp_emit(sta_engine *e, void *dev_entries, uint64_t capacity);     /* NU
 /* reads whose pools the engine has cut out of raw BAM records on the device since it was created (sta_reads.raw_*): lets a caller
  * (and the tests) see that the device staging path, not the host copy, fed the windows */
 uint64_t sta_stage_raw_reads(sta_engine *e);
+
+/* ---- BGZF blocks inflated on the device (csrc/kernels_inflate.hip, one wave per block; the decoder the drivers' BAM reader feeds
+ *      the compressed file to).  Replaces HTSlib bgzf.c inflate_block() under sam_read1 (bam_plcmd.c:409, bam2depth.c:541-543).
+ *      This entry takes host buffers: block b's raw deflate data comp[comp_off, comp_off + clen) -> out[out_off, out_off + isize);
+ *      status[b] = 0, or why the wave gave up on the block (damaged stream, table overflow, size mismatch: a caller then inflates
+ *      that block with zlib, whose verdict counts).  CRC-32s are the caller's to check.  kernel_ms (may be NULL): the launch alone. ---- */
+typedef struct sta_bgzf_block { uint64_t comp_off; uint32_t clen, isize; uint64_t out_off; } sta_bgzf_block;
+int sta_bgzf_inflate(int32_t device, const uint8_t *comp, uint64_t comp_bytes, const sta_bgzf_block *blocks, int32_t n_blocks,
+                     uint8_t *out, uint64_t out_bytes, uint32_t *status, double *kernel_ms);
 /* first n (<= columns + 1) exclusive column offsets of the planned window (bytes for text plans, entries for sta_plp_plan) */
 int sta_fetch_col_offsets(sta_engine *e, uint64_t *host_offs, uint64_t n);
 /* per-read state after a plan: info words (bit 1 = read is in the pileup) and the working quality

@@ -170,6 +170,7 @@ _PROTOS = {
     "sta_plp_emit": (C.c_int, [_P, _P, C.c_uint64]),
     "sta_fetch_col_offsets": (C.c_int, [_P, _P, C.c_uint64]),
     "sta_stage_raw_reads": (C.c_uint64, [_P]),
+    "sta_bgzf_inflate": (C.c_int, [C.c_int32, _P, C.c_uint64, _P, C.c_int32, _P, C.c_uint64, _P, _P]),
     "sta_fetch_read_state": (C.c_int, [_P, C.c_int32, _P, _P]),
     "sta_main_mpileup": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_main_depth": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
@@ -246,6 +247,34 @@ def main_capture(sub, args):
         if buf:
             lib.sta_capture_free(buf)
     return rc, data
+
+
+def bgzf_inflate(streams, sizes, device=0):
+    """Raw deflate streams (bytes objects) -> (list of inflated bytes or None where the device gave up, status list, kernel ms):
+    every stream is one block of sta_bgzf_inflate (csrc/kernels_inflate.hip, one wave per block)."""
+    import numpy as np
+
+    class Blk(C.Structure):
+        _fields_ = [("comp_off", C.c_uint64), ("clen", C.c_uint32), ("isize", C.c_uint32), ("out_off", C.c_uint64)]
+    n = len(streams)
+    comp = b"".join(streams)
+    blocks = (Blk * max(n, 1))()
+    co = oo = 0
+    for i, (st, sz) in enumerate(zip(streams, sizes)):
+        blocks[i].comp_off = co; blocks[i].clen = len(st); blocks[i].isize = sz; blocks[i].out_off = oo
+        co += len(st); oo += sz
+    cbuf = np.frombuffer(comp if comp else b"\0", dtype=np.uint8)
+    out = np.zeros(max(oo, 1), dtype=np.uint8)
+    status = np.zeros(max(n, 1), dtype=np.uint32)
+    ms = C.c_double(0.0)
+    rc = lib.sta_bgzf_inflate(device, cbuf.ctypes.data, len(comp), C.addressof(blocks), n, out.ctypes.data, oo, status.ctypes.data, C.byref(ms))
+    if rc != 0:
+        raise RuntimeError("sta_bgzf_inflate failed: %d" % rc)
+    res, o = [], 0
+    for i, sz in enumerate(sizes):
+        res.append(out[o:o + sz].tobytes() if status[i] == 0 else None)
+        o += sz
+    return res, [int(x) for x in status[:n]], ms.value
 
 
 def io_scan_region(path, region, threads=0, use_index=True):

@@ -1308,6 +1308,40 @@ int sta_glf_consensus(const sta_glf_col *c, char ref_base, char *call_char)
     return (int)(call & 0xffff);
 }
 
+int sta_bgzf_inflate(int32_t device, const uint8_t *comp, uint64_t comp_bytes, const sta_bgzf_block *blocks, int32_t n_blocks,
+                     uint8_t *out, uint64_t out_bytes, uint32_t *status, double *kernel_ms)
+{
+    static_assert(sizeof(sta_bgzf_block) == sizeof(StaBgzfBlock), "the public block record is the kernel's");
+    if (!comp || !blocks || !out || !status || n_blocks < 0) return STA_ERR_ARG;
+    for (int32_t b = 0; b < n_blocks; ++b)
+        if (blocks[b].comp_off + blocks[b].clen > comp_bytes || blocks[b].out_off + blocks[b].isize > out_bytes) return STA_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return STA_ERR_NO_DEVICE;
+    if (n_blocks == 0) return STA_OK;
+    uint8_t *d_comp = nullptr, *d_out = nullptr; StaBgzfBlock *d_blk = nullptr; uint32_t *d_st = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    int rc = STA_ERR_HIP;
+    // (1 KiB of zeros behind the compressed bytes: the decoder's input window runs ahead of the bit reader)
+    if (hipMalloc(&d_comp, comp_bytes + 1024) == hipSuccess && hipMalloc(&d_out, out_bytes + 64) == hipSuccess && hipMalloc(&d_blk, (size_t)n_blocks * sizeof(StaBgzfBlock)) == hipSuccess
+        && hipMalloc(&d_st, (size_t)n_blocks * 4) == hipSuccess && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess
+        && hipMemset(d_comp + comp_bytes, 0, 1024) == hipSuccess && hipMemcpy(d_comp, comp, comp_bytes, hipMemcpyHostToDevice) == hipSuccess
+        && hipMemcpy(d_blk, blocks, (size_t)n_blocks * sizeof(StaBgzfBlock), hipMemcpyHostToDevice) == hipSuccess && hipMemset(d_st, 0xff, (size_t)n_blocks * 4) == hipSuccess) {
+        hipEventRecord(a, nullptr);
+        sta_launch_bgzf_inflate(nullptr, d_comp, d_blk, n_blocks, d_out, d_st);
+        hipEventRecord(b, nullptr);
+        if (hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess && hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost) == hipSuccess
+            && hipMemcpy(status, d_st, (size_t)n_blocks * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            float ms = 0; hipEventElapsedTime(&ms, a, b);
+            if (kernel_ms) *kernel_ms = ms;
+            rc = STA_OK;
+        }
+    }
+    (void)hipGetLastError();
+    if (a) hipEventDestroy(a);
+    if (b) hipEventDestroy(b);
+    hipFree(d_comp); hipFree(d_out); hipFree(d_blk); hipFree(d_st);
+    return rc;
+}
+
 int sta_fetch_overlap_fixups(sta_engine *e, int32_t file, int32_t *fix_y, int32_t *fix_mate, uint8_t *fix_q)
 {
     if (!e || file < 0 || (size_t)file >= e->files_h.size() || !fix_y || !fix_mate || !fix_q) return STA_ERR_ARG;

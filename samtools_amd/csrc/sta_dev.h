@@ -75,6 +75,11 @@ struct StaCounters {          // device-side reduction targets, zeroed per plan
     unsigned long long n_olap_el;                // mpileup: reads eligible for the mate-overlap pass (RI_OLAP_EL), the gate of that pass
 };
 
+// one BGZF block for k_bgzf_inflate (kernels_inflate.hip): deflate bytes comp[comp_off, comp_off + clen) -> out[out_off, out_off + isize).
+// The compressed buffer must be readable 1 KiB beyond the last block's data (the decoder's input window runs ahead).
+struct StaBgzfBlock { uint64_t comp_off; uint32_t clen, isize; uint64_t out_off; };
+void sta_launch_bgzf_inflate(hipStream_t s, const uint8_t *comp, const StaBgzfBlock *blocks, int n_blocks, uint8_t *out, uint32_t *status);
+
 // ---- launchers (defined in the .hip files) ----
 // in-kernel prefix maximum of the preparation kernels (kernels_common.hip ChunkScan): STA_CHUNK_WORDS zero-initialised 8-byte words
 // on the device, and the host's view of the ticket counter / launch number kept in them

@@ -171,7 +171,7 @@ struct DRunner {
 
     int run()
     {
-        PumpConfig pc; pc.window_cols = window_cols; pc.max_reads = max_reads; pc.use_endpos = true; pc.nref_limit = h->nref(); pc.device_pools = true;
+        PumpConfig pc; pc.window_cols = window_cols; pc.max_reads = max_reads; pc.use_endpos = true; pc.nref_limit = h->nref(); pc.device_pools = true; pc.inflate_device = getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0;
         const char *lane = getenv("STA_IO_LANE");
         std::unique_ptr<WindowSource> src;
         if (lane && !strcmp(lane, "rec")) src.reset(new Pump(readers, pc));          // record-at-a-time lane

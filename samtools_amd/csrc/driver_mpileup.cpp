@@ -282,7 +282,7 @@ struct Runner {
 
     int run()
     {
-        PumpConfig pc; pc.window_cols = conf.window_cols; pc.max_reads = conf.max_reads; pc.use_endpos = false; pc.nref_limit = h->nref(); pc.device_pools = true;
+        PumpConfig pc; pc.window_cols = conf.window_cols; pc.max_reads = conf.max_reads; pc.use_endpos = false; pc.nref_limit = h->nref(); pc.device_pools = true; pc.inflate_device = getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0;
         if (conf.p.flag & STA_MPLP_SMART_OVERLAPS) {
             pc.keep_mates = true;
             // host-side "this record certainly reaches bam_plp_push" (subset of k_prep_reads' filters: whatever needs the

@@ -1,5 +1,6 @@
 // host_chunk.cpp -- see host_chunk.h
 #include "host_chunk.h"
+#include "host_inflate.h"
 #include <chrono>
 #include <algorithm>
 #include <climits>
@@ -81,7 +82,7 @@ static constexpr size_t GROUP_BYTES = 1 << 20;
 
 static constexpr size_t GROUP_HEAD = 1 << 16;      // free bytes in front of a mapped group's data: room for the record carried in
 
-ChunkReader::ChunkReader(AlnReader *rd, int threads, bool keep_raw) : rd_(rd), keep_raw_(keep_raw)
+ChunkReader::ChunkReader(AlnReader *rd, int threads, bool keep_raw, int gpu_device) : rd_(rd), keep_raw_(keep_raw)
 {
     if (threads < 1) threads = 1;
     max_ahead_ = (size_t)threads * 2 + 2;
@@ -98,13 +99,22 @@ ChunkReader::ChunkReader(AlnReader *rd, int threads, bool keep_raw) : rd_(rd), k
             rd->release_source();
         }
     }
+    if (map_ && gpu_device >= 0) gpu_ = make_gpu_inflater(gpu_device);
+    if (gpu_) {
+        // (two batches of groups in flight on the device besides what the parsers hold)
+        const char *e = getenv("STA_GPU_INFLATE_BATCH"); const int bg = e ? atoi(e) : 48;
+        max_ahead_ = (size_t)(bg < 1 ? 1 : bg > 512 ? 512 : bg) * 2 + (size_t)threads * 2 + 2;
+        th_.emplace_back([this] { work_gpu_feeder(); });
+        for (int i = 0; i < threads; ++i) th_.emplace_back([this] { work_gpu_parse(); });
+        return;
+    }
     for (int i = 0; i < threads; ++i) th_.emplace_back([this] { if (map_) work_mapped(); else work(); });
 }
 
 ChunkReader::~ChunkReader()
 {
     { std::lock_guard<std::mutex> g(out_m_); stop_ = true; }
-    cv_room_.notify_all(); cv_out_.notify_all(); cv_link_.notify_all();
+    cv_room_.notify_all(); cv_out_.notify_all(); cv_link_.notify_all(); cv_ready_.notify_all();
     for (auto &t : th_) if (t.joinable()) t.join();
 }
 
@@ -115,127 +125,232 @@ void ChunkReader::publish_link(uint64_t seq, Link &&l)
     cv_link_.notify_all();
 }
 
+// the next group's blocks (under io_m_): true = a group (seq, blocks, total filled in); false = nothing more to cut, *end_status =
+// 0 at the clean end of the file / of the region, -1 at a damaged block
+bool ChunkReader::cut_group(MGroup &g, int *end_status)
+{
+    std::lock_guard<std::mutex> lk(io_m_);
+    g.blocks.clear(); g.total = 0; g.bad = false; g.verify = false; g.keep.reset();
+    *end_status = 0;
+    if (io_end_.load()) return false;
+    int st = 1;
+    for (;;) {
+        BgzfMap::Block b; uint64_t o = cut_off_;
+        st = map_->block_at(&o, &b);
+        if (st <= 0) break;
+        if (g.total && g.total + b.isize > GROUP_BYTES) break;          // (stays for the next group)
+        cut_off_ = o;
+        if (b.isize) { g.blocks.push_back(b); g.total += b.isize; }
+    }
+    if (g.blocks.empty()) { *end_status = st < 0 ? -1 : 0; return false; }
+    std::lock_guard<std::mutex> g2(out_m_);
+    g.seq = next_in_++;
+    return true;
+}
+
+// the end of the file (st == 0) or a damaged block (-1).  A clean end must not leave a record unfinished: what the last group handed
+// on has to be empty
+void ChunkReader::finish_stream(int st)
+{
+    std::unique_lock<std::mutex> lk(out_m_);
+    if (io_end_.load()) return;                      // (the region's end was seen first: groups cut mid-record there are not an error)
+    const uint64_t end_seq = next_in_;
+    cv_link_.wait(lk, [&] { return stop_ || io_end_.load() || links_.count(end_seq) != 0; });
+    if (stop_ || io_end_.load()) return;
+    const Link &l = links_[end_seq];
+    io_status_.store(st < 0 ? -1 : (l.bad || !l.carry.empty()) ? -2 : 0);
+    io_end_.store(true);
+    cv_out_.notify_all(); cv_link_.notify_all();
+}
+
+// one inflated group -> its chunk: the record carried in from the group in front, the walk over the block_size fields, the hand-over to
+// the next group, the records
+void ChunkReader::process_group(MGroup &g, pvector<uint8_t> &raw, Rec &r, std::string &scratch)
+{
+    const uint64_t seq = g.seq; const size_t total = g.total;
+    bool bad = g.bad;
+    if (g.verify && !bad) {
+        // blocks that came back from the device: their CRC-32 is checked here; a mismatch (or a block the device gave up on, already
+        // redone by the feeder) goes through the host decoder, whose verdict counts
+        size_t off = GROUP_HEAD;
+        for (const BgzfMap::Block &b : g.blocks) {
+            if (fast_crc32(raw.data() + off, b.isize) != b.crc && !bgzf_inflate_block(b, raw.data() + off)) { bad = true; break; }
+            off += b.isize;
+        }
+    }
+    Link in;
+    {
+        std::unique_lock<std::mutex> lk(out_m_);
+        cv_link_.wait(lk, [&] { return stop_ || links_.count(seq) != 0; });
+        if (stop_) return;
+        in = std::move(links_[seq]);
+        links_.erase(seq);
+    }
+    auto c = new_chunk();
+    Link out;
+    size_t beg = GROUP_HEAD, end = GROUP_HEAD + total, q = end;       // records: raw[beg, q); raw[q, end) goes on to the next group
+    bool records = false;
+    if (bad || in.bad) { bad = true; out.bad = true; }
+    else if (in.skip >= total) out.skip = in.skip - total;               // (still inside the header)
+    else {
+        beg += (size_t)in.skip;
+        bool whole = true;                                                // the record carried in ends inside this group
+        if (!in.carry.empty()) {
+            const size_t cl = in.carry.size();
+            uint8_t h[4];
+            for (size_t k = 0; k < 4; ++k) h[k] = k < cl ? in.carry[k] : (k - cl < total ? raw[GROUP_HEAD + (k - cl)] : 0);
+            int32_t bs = 0; memcpy(&bs, h, 4);
+            if (cl + total < 4) whole = false;
+            else if (bs < 32) bad = true;
+            else if (4 + (size_t)bs - cl > total) whole = false;
+            if (!bad) {
+                if (!whole) { out.carry = std::move(in.carry); out.carry.insert(out.carry.end(), raw.begin() + (long)GROUP_HEAD, raw.begin() + (long)end); }
+                else if (cl <= GROUP_HEAD) { memcpy(raw.data() + GROUP_HEAD - cl, in.carry.data(), cl); beg = GROUP_HEAD - cl; }
+                else {
+                    // a carry larger than the free head (a record of more than 64 KiB): the data moves up behind it
+                    raw.resize(cl + total);
+                    memmove(raw.data() + cl, raw.data() + GROUP_HEAD, total);
+                    memcpy(raw.data(), in.carry.data(), cl);
+                    beg = 0; end = cl + total;
+                }
+            }
+        }
+        if (!bad && whole) {
+            // the walk over the block_size fields: where the last whole record ends
+            q = beg;
+            while (end - q >= 4) {
+                int32_t bs; memcpy(&bs, &raw[q], 4);
+                if (bs < 32) { bad = true; break; }
+                if ((size_t)bs + 4 > end - q) break;
+                q += (size_t)bs + 4;
+            }
+            if (!bad) { out.carry.assign(raw.begin() + (long)q, raw.begin() + (long)end); records = true; }
+        }
+        if (bad) { out = Link(); out.bad = true; }
+    }
+    publish_link(seq + 1, std::move(out));
+    if (records) {
+        size_t o = beg;
+        while (o < q) {
+            size_t used = 0;
+            int st = rd_->parse_raw(raw.data() + o, q - o, &used, r, scratch);
+            if (st <= 0) { bad = true; break; }
+            o += used;
+            r.rlen = 0;
+            for (uint32_t cg : r.cigar) { int op = (int)(cg & 0xf); if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) r.rlen += (cg >> 4); }
+            if (rd_->past_region(r) && !io_end_.load()) { std::lock_guard<std::mutex> g2(out_m_); io_status_.store(0); io_end_.store(true); cv_out_.notify_all(); cv_link_.notify_all(); }
+            if (!rd_->in_region(r)) continue;
+            c->append(r);
+            if (keep_raw_ && g.keep) { c->rec_off.push_back((uint32_t)(o - used + 4)); if (r.cigar_from_tag) c->raw_ok = false; }
+        }
+    }
+    c->close();
+    if (g.keep && keep_raw_) { raw.resize(q); c->raw = std::move(g.keep); }    // (a window uploads up to the end of the last whole record)
+    std::lock_guard<std::mutex> lk(out_m_);
+    if (bad && seq < bad_seq_) bad_seq_ = seq;
+    done_[seq] = std::move(c);
+    cv_out_.notify_all();
+}
+
 void ChunkReader::work_mapped()
 {
     pvector<uint8_t> own_raw;
     Rec r; std::string scratch;
-    std::vector<BgzfMap::Block> blocks;
+    MGroup g;
     for (;;) {
         {
             std::unique_lock<std::mutex> lk(out_m_);
             cv_room_.wait(lk, [this] { return stop_ || next_in_ - next_out_ < max_ahead_; });
             if (stop_) return;
         }
-        uint64_t seq = 0; size_t total = 0;
-        blocks.clear();
-        {
-            std::lock_guard<std::mutex> g(io_m_);
-            if (io_end_.load()) return;
-            int st = 1;
-            for (;;) {
-                BgzfMap::Block b; uint64_t o = cut_off_;
-                st = map_->block_at(&o, &b);
-                if (st <= 0) break;
-                if (total && total + b.isize > GROUP_BYTES) break;          // (stays for the next group)
-                cut_off_ = o;
-                if (b.isize) { blocks.push_back(b); total += b.isize; }
-            }
-            if (blocks.empty()) {
-                // the end of the file (st == 0) or a damaged block (-1).  A clean end must not leave a record unfinished: what the last
-                // group handed on has to be empty
-                std::unique_lock<std::mutex> lk(out_m_);
-                const uint64_t end_seq = next_in_;
-                cv_link_.wait(lk, [&] { return stop_ || links_.count(end_seq) != 0; });
-                if (stop_) return;
-                const Link &l = links_[end_seq];
-                io_status_.store(st < 0 ? -1 : (l.bad || !l.carry.empty()) ? -2 : 0);
-                io_end_.store(true);
-                cv_out_.notify_all();
-                return;
-            }
-            std::lock_guard<std::mutex> g2(out_m_);
-            seq = next_in_++;
-        }
-        std::shared_ptr<pvector<uint8_t>> keep = keep_raw_ ? get_buf() : nullptr;
-        pvector<uint8_t> &raw = keep ? *keep : own_raw;
-        raw.resize(GROUP_HEAD + total);
-        bool bad = false;
-        {
+        int end_status = 0;
+        if (!cut_group(g, &end_status)) { finish_stream(end_status); return; }
+        g.keep = keep_raw_ ? get_buf() : nullptr;
+        pvector<uint8_t> &raw = g.keep ? *g.keep : own_raw;
+        raw.resize(GROUP_HEAD + g.total);
+        size_t off = GROUP_HEAD;
+        for (const BgzfMap::Block &b : g.blocks) { if (!bgzf_inflate_block(b, raw.data() + off)) { g.bad = true; break; } off += b.isize; }
+        process_group(g, raw, r, scratch);
+    }
+}
+
+// ---- the same with the device's decoder (host_gpu_inflate.h): one feeder thread cuts groups by the batch, sends their blocks through
+// the device and queues the inflated groups; the parser threads check the CRCs and parse ----
+void ChunkReader::work_gpu_feeder()
+{
+    static const size_t batch_groups = [] { const char *e = getenv("STA_GPU_INFLATE_BATCH"); const int v = e ? atoi(e) : 48; return (size_t)(v < 1 ? 1 : v > 512 ? 512 : v); }();
+    struct Batch { std::vector<MGroup> groups; std::vector<GpuInflateJob> jobs; int ticket = -1; };
+    Batch bt[2];
+    std::vector<uint32_t> status;
+    int end_status = 0; bool ended = false;
+    auto finalize = [&](Batch &b) {
+        if (b.groups.empty()) return;
+        bool dev_ok = b.ticket >= 0 && gpu_->wait(b.ticket, status) && status.size() == b.jobs.size();
+        size_t j = 0;
+        for (MGroup &g : b.groups) {
             size_t off = GROUP_HEAD;
-            for (const BgzfMap::Block &b : blocks) { if (!bgzf_inflate_block(b, raw.data() + off)) { bad = true; break; } off += b.isize; }
+            for (const BgzfMap::Block &blk : g.blocks) {
+                // a block the device gave up on (or a whole batch it could not take) is inflated here; CRCs of the others: the parsers
+                if ((!dev_ok || status[j] != 0) && !bgzf_inflate_block(blk, g.keep->data() + off)) g.bad = true;
+                off += blk.isize; ++j;
+            }
+            g.verify = dev_ok;
         }
-        Link in;
+        {
+            std::lock_guard<std::mutex> lk(out_m_);
+            for (MGroup &g : b.groups) ready_q_.push_back(std::move(g));
+        }
+        cv_ready_.notify_all();
+        b.groups.clear(); b.jobs.clear(); b.ticket = -1;
+    };
+    for (int cur = 0; !ended; cur ^= 1) {
+        Batch &b = bt[cur];
+        finalize(b);                                        // (the batch that used this slot two rounds ago)
+        while (b.groups.size() < batch_groups) {
+            {
+                std::unique_lock<std::mutex> lk(out_m_);
+                // (a started batch goes out when the window of groups in flight is full: its groups are what the consumer waits for)
+                if (next_in_ - next_out_ >= max_ahead_ && !b.groups.empty()) break;
+                cv_room_.wait(lk, [this] { return stop_ || next_in_ - next_out_ < max_ahead_; });
+                if (stop_) return;
+            }
+            MGroup g;
+            if (!cut_group(g, &end_status)) { ended = true; break; }
+            g.keep = get_buf();
+            g.keep->resize(GROUP_HEAD + g.total);
+            size_t off = GROUP_HEAD;
+            for (const BgzfMap::Block &blk : g.blocks) { b.jobs.push_back(GpuInflateJob{ blk.comp, blk.clen, blk.isize, g.keep->data() + off }); off += blk.isize; }
+            b.groups.push_back(std::move(g));
+        }
+        if (!b.groups.empty()) b.ticket = gpu_->submit(b.jobs.data(), b.jobs.size());
+    }
+    // the two batches still in flight, the older one first: groups must reach the parsers in cut order (a parser holding group k waits
+    // for the hand-over from k - 1; were the later batch queued first, every parser could end up waiting for groups nobody is left to take)
+    {
+        const int older = bt[0].groups.empty() ? 1 : bt[1].groups.empty() ? 0 : (bt[0].groups.front().seq < bt[1].groups.front().seq ? 0 : 1);
+        finalize(bt[older]); finalize(bt[older ^ 1]);
+    }
+    {
+        std::lock_guard<std::mutex> lk(out_m_);
+        feed_end_ = true;
+    }
+    cv_ready_.notify_all();
+    finish_stream(end_status);
+}
+
+void ChunkReader::work_gpu_parse()
+{
+    Rec r; std::string scratch;
+    for (;;) {
+        MGroup g;
         {
             std::unique_lock<std::mutex> lk(out_m_);
-            cv_link_.wait(lk, [&] { return stop_ || links_.count(seq) != 0; });
+            cv_ready_.wait(lk, [this] { return stop_ || !ready_q_.empty() || feed_end_; });
             if (stop_) return;
-            in = std::move(links_[seq]);
-            links_.erase(seq);
+            if (ready_q_.empty()) return;                   // (the feeder is done)
+            g = std::move(ready_q_.front()); ready_q_.pop_front();
         }
-        auto c = new_chunk();
-        Link out;
-        size_t beg = GROUP_HEAD, end = GROUP_HEAD + total, q = end;       // records: raw[beg, q); raw[q, end) goes on to the next group
-        bool records = false;
-        if (bad || in.bad) { bad = true; out.bad = true; }
-        else if (in.skip >= total) out.skip = in.skip - total;               // (still inside the header)
-        else {
-            beg += (size_t)in.skip;
-            bool whole = true;                                                // the record carried in ends inside this group
-            if (!in.carry.empty()) {
-                const size_t cl = in.carry.size();
-                uint8_t h[4];
-                for (size_t k = 0; k < 4; ++k) h[k] = k < cl ? in.carry[k] : (k - cl < total ? raw[GROUP_HEAD + (k - cl)] : 0);
-                int32_t bs = 0; memcpy(&bs, h, 4);
-                if (cl + total < 4) whole = false;
-                else if (bs < 32) bad = true;
-                else if (4 + (size_t)bs - cl > total) whole = false;
-                if (!bad) {
-                    if (!whole) { out.carry = std::move(in.carry); out.carry.insert(out.carry.end(), raw.begin() + (long)GROUP_HEAD, raw.begin() + (long)end); }
-                    else if (cl <= GROUP_HEAD) { memcpy(raw.data() + GROUP_HEAD - cl, in.carry.data(), cl); beg = GROUP_HEAD - cl; }
-                    else {
-                        // a carry larger than the free head (a record of more than 64 KiB): the data moves up behind it
-                        raw.resize(cl + total);
-                        memmove(raw.data() + cl, raw.data() + GROUP_HEAD, total);
-                        memcpy(raw.data(), in.carry.data(), cl);
-                        beg = 0; end = cl + total;
-                    }
-                }
-            }
-            if (!bad && whole) {
-                // the walk over the block_size fields: where the last whole record ends
-                q = beg;
-                while (end - q >= 4) {
-                    int32_t bs; memcpy(&bs, &raw[q], 4);
-                    if (bs < 32) { bad = true; break; }
-                    if ((size_t)bs + 4 > end - q) break;
-                    q += (size_t)bs + 4;
-                }
-                if (!bad) { out.carry.assign(raw.begin() + (long)q, raw.begin() + (long)end); records = true; }
-            }
-            if (bad) { out = Link(); out.bad = true; }
-        }
-        publish_link(seq + 1, std::move(out));
-        if (records) {
-            size_t o = beg;
-            while (o < q) {
-                size_t used = 0;
-                int st = rd_->parse_raw(raw.data() + o, q - o, &used, r, scratch);
-                if (st <= 0) { bad = true; break; }
-                o += used;
-                r.rlen = 0;
-                for (uint32_t cg : r.cigar) { int op = (int)(cg & 0xf); if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) r.rlen += (cg >> 4); }
-                if (rd_->past_region(r) && !io_end_.load()) { std::lock_guard<std::mutex> g2(out_m_); io_status_.store(0); io_end_.store(true); cv_out_.notify_all(); }
-                if (!rd_->in_region(r)) continue;
-                c->append(r);
-                if (keep) { c->rec_off.push_back((uint32_t)(o - used + 4)); if (r.cigar_from_tag) c->raw_ok = false; }
-            }
-        }
-        c->close();
-        if (keep) { raw.resize(q); c->raw = std::move(keep); }               // (a window uploads up to the end of the last whole record)
-        std::lock_guard<std::mutex> g(out_m_);
-        if (bad && seq < bad_seq_) bad_seq_ = seq;
-        done_[seq] = std::move(c);
-        cv_out_.notify_all();
+        process_group(g, *g.keep, r, scratch);
     }
 }
 
@@ -352,7 +467,7 @@ ChunkPump::ChunkPump(std::vector<std::unique_ptr<AlnReader>> &readers, const Pum
     raw_mode_ = cfg.device_pools ? 1 : 0;
     if (const char *ev = getenv("STA_STAGE_DEVICE")) if (cfg.device_pools) raw_mode_ = atoi(ev);
     if (cfg.xs_n_tags > 0) raw_mode_ = 0;                           // tag text columns are formatted per record on the host
-    for (size_t i = 0; i < readers.size(); ++i) f_[i].rd.reset(new ChunkReader(readers[i].get(), threads, raw_mode_ != 0 && readers[i]->is_bam()));
+    for (size_t i = 0; i < readers.size(); ++i) f_[i].rd.reset(new ChunkReader(readers[i].get(), threads, raw_mode_ != 0 && readers[i]->is_bam(), cfg.inflate_device));
     // threads that copy a window's chunk slices into the staging arrays (STA_STAGE_THREADS; 1 = the producer thread alone)
     stage_threads_ = threads >= 8 ? 4 : threads >= 4 ? 2 : 1;
     if (const char *ev = getenv("STA_STAGE_THREADS")) { const int v = atoi(ev); if (v >= 1 && v <= 64) { stage_threads_ = v; stage_min_bytes_ = 0; } }   // set explicitly: for every window, however small

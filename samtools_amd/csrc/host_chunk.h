@@ -10,6 +10,7 @@
 #include "host_pump.h"
 #include "host_stage.h"
 #include "host_bgzf.h"
+#include "host_gpu_inflate.h"
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -53,7 +54,8 @@ struct Chunk {
 // decodes one input on `threads` parser threads; chunks come out in file order
 class ChunkReader {
 public:
-    ChunkReader(AlnReader *rd, int threads, bool keep_raw = false);
+    // gpu_device >= 0: BAM files on disk are inflated by that device's decoder (host_gpu_inflate.h) when it is usable
+    ChunkReader(AlnReader *rd, int threads, bool keep_raw = false, int gpu_device = -1);
     ~ChunkReader();
     // next chunk in file order; nullptr at end of data or after an error (status() tells which)
     std::shared_ptr<Chunk> next();
@@ -93,7 +95,21 @@ private:
     std::map<uint64_t, Link> links_;               // what group seq receives from group seq - 1 (guarded by out_m_)
     std::condition_variable cv_link_;
     void publish_link(uint64_t seq, Link &&l);
+    struct MGroup {                                // a group of whole BGZF blocks on its way to a chunk
+        uint64_t seq = 0; size_t total = 0;
+        std::vector<BgzfMap::Block> blocks;
+        std::shared_ptr<pvector<uint8_t>> keep;    // its buffer: GROUP_HEAD free bytes, then the inflated blocks
+        bool bad = false, verify = false;          // verify: the bytes came back from the device, their CRC-32s are still to be checked
+    };
+    bool cut_group(MGroup &g, int *end_status);
+    void finish_stream(int st);
+    void process_group(MGroup &g, pvector<uint8_t> &raw, Rec &r, std::string &scratch);
     void work_mapped();
+    // with the device's decoder: a feeder thread and a queue of inflated groups in front of the parsers
+    std::unique_ptr<GpuInflater> gpu_;
+    std::deque<MGroup> ready_q_; std::condition_variable cv_ready_; bool feed_end_ = false;     // (guarded by out_m_)
+    void work_gpu_feeder();
+    void work_gpu_parse();
 };
 
 // window source over chunked readers

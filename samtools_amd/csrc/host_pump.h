@@ -38,6 +38,9 @@ struct PumpConfig {
     // qualities / names out on the device (host_stage.h add_ranges raw_mode, kernels_stage.hip) instead of copying them into the
     // staging pools here.  Set by drivers whose windows go to an engine through sta_stage_window(); STA_STAGE_DEVICE=0 turns it off.
     bool device_pools = false;
+    // chunk lane, BAM files on disk: the device whose decoder inflates the BGZF blocks (kernels_inflate.hip through host_gpu_inflate.h),
+    // -1 = the reader's own threads do.  Set by the drivers next to device_pools; used only with STA_GPU_INFLATE=1 (see host_gpu_inflate.cpp).
+    int inflate_device = -1;
 };
 
 // What the window loops of the drivers need from an input lane (Pump below: one decoded record at a time; ChunkPump in

@@ -58,7 +58,7 @@ def make_contig(i):
 def timed(cmd, env=None, stdout=None):
     t0 = time.perf_counter()
     with open(os.devnull, "wb") as dn:
-        p = subprocess.run(cmd, stdout=stdout or dn, stderr=subprocess.PIPE, env=env)
+        p = subprocess.run(cmd, stdout=stdout or dn, stderr=subprocess.PIPE, env=env, timeout=float(os.environ.get("E2E_CMD_TIMEOUT", "600")))
     dt = time.perf_counter() - t0
     if p.returncode != 0:
         raise SystemExit("%s failed: %s" % (" ".join(cmd[:3]), p.stderr.decode()[-400:]))

@@ -434,6 +434,12 @@ int sta_main_depth(int argc, char **argv);
  * driver straight into the gather, no temporary file.  No reference counterpart (bam_plcmd.c:663-868 prints as it goes). */
 int sta_main_capture(int argc, char **argv, char **text, uint64_t *n_bytes);
 void sta_capture_free(char *text);
+/* The same with the windows' text left in device memory (a sharded run gathers it GPU to GPU: samtools_amd/shard.py).  What the driver
+ * itself writes (depth -H's header line) comes back as host text and goes first in the output; the windows' n_dev_bytes are kept until
+ * sta_capture_device_take() copies them (device to device) to dev_dst and releases them.  One capture at a time per process; needs
+ * STA_DEV_THREADS=1 (the default).  host_text: sta_capture_free(). */
+int sta_main_capture_device(int argc, char **argv, uint64_t *n_dev_bytes, char **host_text, uint64_t *n_host_bytes);
+int sta_capture_device_take(void *dev_dst, uint64_t capacity);
 /* `glf [-Q min_baseQ] [-t theta] [-f ref.fa] in.bam`: one text line per column (what tests diff against the oracle) */
 int sta_main_glf(int argc, char **argv);
 /* `calmd [-erAEqdNQ] [-n max_nm] [--no-PG] in.bam ref.fa`: bam_fillmd (bam_md.c:346-520); the records are written as SAM text

@@ -176,6 +176,8 @@ _PROTOS = {
     "sta_main_depth": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_main_capture": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "sta_capture_free": (None, [_P]),
+    "sta_main_capture_device": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "sta_capture_device_take": (C.c_int, [_P, C.c_uint64]),
     "sta_glf_plan": (C.c_int, [_P, C.POINTER(GlfParams), C.POINTER(PlanInfo)]),
     "sta_glf_consensus": (C.c_int, [C.POINTER(GlfCol), C.c_char, C.c_char_p]),
     "sta_calmd_plan": (C.c_int, [_P, C.POINTER(CalmdParams), C.POINTER(PlanInfo)]),
@@ -247,6 +249,28 @@ def main_capture(sub, args):
         if buf:
             lib.sta_capture_free(buf)
     return rc, data
+
+
+def main_capture_device(sub, args):
+    """(exit status, host text bytes, device byte count): the command's window text stays in device memory until
+    capture_device_take() copies it to a device pointer; what the driver wrote itself (depth -H's header) is the host text, which
+    precedes the windows in the output."""
+    a = [sub] + list(args)
+    buf = _P()
+    n_host, n_dev = C.c_uint64(0), C.c_uint64(0)
+    rc = lib.sta_main_capture_device(len(a), _argv(a), C.byref(n_dev), C.byref(buf), C.byref(n_host))
+    try:
+        head = C.string_at(buf, n_host.value) if buf and n_host.value else b""
+    finally:
+        if buf:
+            lib.sta_capture_free(buf)
+    return rc, head, n_dev.value
+
+
+def capture_device_take(dev_ptr, capacity):
+    rc = lib.sta_capture_device_take(dev_ptr, capacity)
+    if rc != 0:
+        raise RuntimeError("sta_capture_device_take failed: %d" % rc)
 
 
 def bgzf_inflate(streams, sizes, device=0):

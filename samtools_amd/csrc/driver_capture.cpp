@@ -13,6 +13,23 @@
 
 namespace sta {
 static thread_local FILE *t_capture = nullptr;
+static thread_local DevCapture *t_dev_capture = nullptr;
+DevCapture *driver_dev_capture() { return t_dev_capture; }
+char *DevCapture::reserve(size_t more)
+{
+    if (failed) return nullptr;
+    if (len + more > cap) {
+        size_t want = cap ? cap * 2 : (size_t)64 << 20;
+        while (want < len + more) want *= 2;
+        char *nb = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&nb, want) != hipSuccess) { (void)hipGetLastError(); failed = true; return nullptr; }
+        // (the emits so far ran on the engine's stream: everything is waited for before the text moves)
+        if (hipDeviceSynchronize() != hipSuccess || (len && hipMemcpy(nb, buf, len, hipMemcpyDeviceToDevice) != hipSuccess)) { (void)hipGetLastError(); hipFree(nb); failed = true; return nullptr; }
+        hipFree(buf);
+        buf = nb; cap = want;
+    }
+    return buf + len;
+}
 FILE *driver_default_out() { return t_capture ? t_capture : stdout; }
 bool driver_out_is_borrowed(FILE *f) { return f == stdout || (t_capture && f == t_capture); }
 
@@ -85,3 +102,46 @@ extern "C" int sta_main_capture(int argc, char **argv, char **text, uint64_t *n_
 }
 
 extern "C" void sta_capture_free(char *text) { free(text); }
+
+// ---- the same with the windows' text left on the device ----
+namespace { sta::DevCapture g_kept; bool g_have_kept = false; }
+
+extern "C" int sta_main_capture_device(int argc, char **argv, uint64_t *n_dev_bytes, char **host_text, uint64_t *n_host_bytes)
+{
+    if (!n_dev_bytes || !host_text || !n_host_bytes || argc < 1 || !argv || !argv[0]) return STA_ERR_ARG;
+    *n_dev_bytes = 0; *host_text = nullptr; *n_host_bytes = 0;
+    const bool mp = !strcmp(argv[0], "mpileup"), dp = !strcmp(argv[0], "depth");
+    if (!mp && !dp) return STA_ERR_ARG;
+    if (sta::dev_threads_from_env() != 1) return STA_ERR_ARG;        // windows must reach the device in output order
+    if (g_have_kept) { hipSetDevice(g_kept.device); hipFree(g_kept.buf); g_kept = sta::DevCapture(); g_have_kept = false; }
+    char *buf = nullptr; size_t len = 0;
+    FILE *ms = open_memstream(&buf, &len);
+    if (!ms) return STA_ERR_IO;
+    sta::DevCapture cap;
+    cap.device = getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0;
+    sta::t_capture = ms; sta::t_dev_capture = &cap;
+    int rc = mp ? sta_main_mpileup(argc, argv) : sta_main_depth(argc, argv);
+    sta::t_capture = nullptr; sta::t_dev_capture = nullptr;
+    if (fclose(ms) != 0) { free(buf); hipFree(cap.buf); return STA_ERR_IO; }
+    if (cap.failed && rc == 0) rc = STA_ERR_HIP;
+    hipSetDevice(cap.device);
+    (void)hipDeviceSynchronize();
+    // what the driver wrote itself (depth -H's header line) comes first in the output: the windows follow it
+    *host_text = buf; *n_host_bytes = (uint64_t)len; *n_dev_bytes = (uint64_t)cap.len;
+    g_kept = cap; g_have_kept = true;
+    return rc;
+}
+
+extern "C" int sta_capture_device_take(void *dev_dst, uint64_t capacity)
+{
+    if (!g_have_kept) return STA_ERR_ARG;
+    int rc = STA_OK;
+    hipSetDevice(g_kept.device);
+    if (g_kept.len) {
+        if (!dev_dst || capacity < g_kept.len) rc = STA_ERR_ARG;
+        else if (hipMemcpy(dev_dst, g_kept.buf, g_kept.len, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipGetLastError(); rc = STA_ERR_HIP; }
+    }
+    hipFree(g_kept.buf);
+    g_kept = sta::DevCapture(); g_have_kept = false;
+    return rc;
+}

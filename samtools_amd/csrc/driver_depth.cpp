@@ -31,6 +31,7 @@ struct DRunner {
     std::vector<std::unique_ptr<AlnReader>> readers;
     const Header *h = nullptr;
     FILE *out = driver_default_out();
+    DevCapture *dev_cap = driver_dev_capture();       // (sta_main_capture_device: window text stays on the device)
     std::unique_ptr<Bed> bed;
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
     int64_t window_cols = 1 << 20, max_reads = 4 << 20;
@@ -69,6 +70,13 @@ struct DRunner {
         j.out_bytes = 0;
         if (sta_depth_plan(eng, &pp, &j.info) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
         if (!j.write || j.info.out_bytes == 0) return 0;
+        if (dev_cap) {
+            // device capture: the window's rows are copied (device to device) behind the text captured so far
+            char *dst = dev_cap->reserve((size_t)j.info.out_bytes);
+            if (!dst || sta_depth_emit(eng, dst, j.info.out_bytes) != STA_OK || sta_sync(eng) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", dst ? sta_last_error(eng) : "no device memory for the captured text"); return -1; }
+            dev_cap->len += (size_t)j.info.out_bytes;
+            return 0;
+        }
         if (j.text.size() < (size_t)j.info.out_bytes) j.text.resize((size_t)j.info.out_bytes + (size_t)(j.info.out_bytes >> 3));
         if (sta_fetch_output(eng, j.text.data(), j.info.out_bytes) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
         j.out_bytes = j.info.out_bytes;

@@ -71,6 +71,7 @@ struct Runner {
     std::vector<std::unique_ptr<AlnReader>> readers;
     const Header *h = nullptr;
     FILE *out = driver_default_out();
+    DevCapture *dev_cap = driver_dev_capture();       // (sta_main_capture_device: window text stays on the device)
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
     std::unique_ptr<WinPipe> pipe;                    // producer (this thread) -> device thread -> writer thread
     std::vector<std::vector<StagedFile>> no_reads_d;  // per engine: read-less windows (zero-depth rows); its device thread only
@@ -141,6 +142,13 @@ struct Runner {
             }
         }
         if (!j.write || j.info.out_bytes == 0) return 0;
+        if (dev_cap) {
+            // device capture: the rows are written right behind the text captured so far and stay on the device
+            char *dst = dev_cap->reserve((size_t)j.info.out_bytes);
+            if (!dst || sta_mpileup_emit(eng, dst, j.info.out_bytes) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", dst ? sta_last_error(eng) : "no device memory for the captured text"); return -1; }
+            dev_cap->len += (size_t)j.info.out_bytes;
+            return 0;
+        }
         if (sta_mpileup_emit(eng, nullptr, 0) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
         if (j.text.size() < (size_t)j.info.out_bytes) j.text.resize((size_t)j.info.out_bytes + (size_t)(j.info.out_bytes >> 3));
         if (sta_fetch_output(eng, j.text.data(), j.info.out_bytes) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }

@@ -101,6 +101,16 @@ inline int seek_readers_by_index(std::vector<std::unique_ptr<AlnReader>> &reader
 
 // where a driver writes when the command names no -o file: stdout, or the memory stream of sta_main_capture (driver_capture.cpp)
 FILE *driver_default_out();
+// Device capture (sta_main_capture_device, driver_capture.cpp): the windows' text is not downloaded -- the device thread emits every
+// window right behind the text captured so far, in a device buffer the caller takes over (a sharded run gathers it GPU to GPU).  Only
+// with one device thread (windows then reach the device in output order).  Fetched once by the driver's main thread; nullptr = off.
+struct DevCapture {
+    int device = 0;
+    char *buf = nullptr; size_t cap = 0, len = 0;
+    bool failed = false;
+    char *reserve(size_t more);       // room for `more` bytes behind len (grows the buffer: synchronises the device); nullptr on failure
+};
+DevCapture *driver_dev_capture();
 bool driver_out_is_borrowed(FILE *f);     // stdout or the capture stream: the driver must not close it
 
 }  // namespace sta

@@ -172,12 +172,26 @@ def run_sharded_cli(argv: Sequence[str], out=None) -> int:
     dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
     os.environ["STA_SHARD"] = "%d/%d" % (rank, world)
     t0 = time.perf_counter()
+    # On GPUs (RCCL) the block's text never leaves device memory on its way into the gather: the driver emits every window behind the
+    # previous one in a device buffer (sta_main_capture_device), which is copied device to device into the tensor the collective
+    # sends -- rank 0's download of the gathered text is the only PCIe trip.  STA_SHARD_HOST_CAPTURE=1 (and the CPU / gloo form of the
+    # tests) takes the text through host memory as before.
+    dev_capture = use_cuda and not os.environ.get("STA_SHARD_HOST_CAPTURE") and int(os.environ.get("STA_DEV_THREADS", "1")) == 1
     try:
-        rc, data = _capi.main_capture(sub, args)
+        if dev_capture:
+            rc, head, n_dev = _capi.main_capture_device(sub, args)
+            local = torch.empty(len(head) + n_dev, dtype=torch.uint8, device=dev)
+            if head:
+                local[:len(head)].copy_(torch.frombuffer(bytearray(head), dtype=torch.uint8))
+            _capi.capture_device_take(local.data_ptr() + len(head) if n_dev else None, n_dev)
+            n_local = len(head) + n_dev
+        else:
+            rc, data = _capi.main_capture(sub, args)
+            local = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev) if data else torch.zeros(0, dtype=torch.uint8, device=dev)
+            n_local = len(data)
     finally:
         os.environ.pop("STA_SHARD", None)
     t_drv = time.perf_counter() - t0
-    local = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev) if data else torch.zeros(0, dtype=torch.uint8, device=dev)
     rcs = torch.tensor([rc], dtype=torch.int64, device=dev)
     dist.all_reduce(rcs, op=dist.ReduceOp.MAX)
     worst = int(rcs.item())
@@ -185,7 +199,7 @@ def run_sharded_cli(argv: Sequence[str], out=None) -> int:
     whole = gather_text(local, dst=0)
     t_gather = time.perf_counter() - t1
     if os.environ.get("STA_SHARD_TIMING"):
-        sys.stderr.write("[shard %d/%d] driver %.3f s, %d bytes; gather %.3f s\n" % (rank, world, t_drv, len(data), t_gather))
+        sys.stderr.write("[shard %d/%d] driver %.3f s, %d bytes (%s capture); gather %.3f s\n" % (rank, world, t_drv, n_local, "device" if dev_capture else "host", t_gather))
     if rank == 0:
         if worst != 0:
             # a failed block would leave a silent hole in the concatenation: nothing is written (the ranks' own messages

@@ -680,7 +680,7 @@ def run_workload(a, wlname, ctx, secondary=False):
                              "frac": tops / FP64_PEAK_TOPS}
                 # the forward-row scratch stream the kernel pair moves through HBM: implementation traffic, reported as DRAM utilisation
                 # (the fused class-S kernel writes AND reads it inside one launch: twice the bytes per unit)
-                sb = (float(os.environ.get("STA_BAQ_STREAM_BPB", "0")) or eng_baq_stream_bpb) * (2.0 if name == "baq_s" else 1.0)
+                sb = float(os.environ.get("STA_BAQ_STREAM_BPB", "0")) or (2.0 * eng_baq7s_stream_bpb if name == "baq_s" else eng_baq_stream_bpb)
                 r["dram_util"] = {"stream_bytes_per_unit": sb, "achieved": sb * units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s"}
                 r["dram_util"]["frac"] = r["dram_util"]["achieved"] / HBM_PEAK_GBS
@@ -688,6 +688,7 @@ def run_workload(a, wlname, ctx, secondary=False):
 
         # forward rows streamed per query base by the BAQ pair (2 doubles per band cell and stored row, see kernels_baq.hip)
         eng_baq_stream_bpb = float(sa.baq_stream_bytes_per_base()) if hasattr(sa, "baq_stream_bytes_per_base") else 240.0
+        eng_baq7s_stream_bpb = float(sa.baq7s_stream_bytes_per_base()) if hasattr(sa, "baq7s_stream_bytes_per_base") else 80.0
         # kernels on the side stream (band-8 BAQ groups) overlap the main ones: they cannot be "the" dominant kernel
         main_k = {k: v for k, v in prof.items() if not k.startswith(("baq8", "baq7l"))}
         dom_name = max(main_k.items(), key=lambda kv: kv[1][1])[0] if main_k else None

@@ -22,6 +22,7 @@ from ._capi import (  # noqa: F401
     Window,
     device_count,
     baq_stream_bytes_per_base,
+    baq7s_stream_bytes_per_base,
     lib,
     main_depth,
     main_mpileup,

@@ -212,6 +212,13 @@ def baq_stream_bytes_per_base():
     return float(f())
 
 
+def baq7s_stream_bytes_per_base():
+    """the same for the class-S kernel (one row of three stored): bytes written per query base; the launch reads them back once"""
+    f = lib.sta_baq7s_stream_bytes_per_base
+    f.restype = C.c_double
+    return float(f())
+
+
 def device_count():
     return int(lib.sta_device_count())
 

@@ -867,6 +867,8 @@ static size_t baq_slot_dbl(int lq_cap, int bw) { return bw == 7 ? (baq_dec_mode(
 
 // bytes of forward-row stream per query base of the band-7 kernel pair (written once, read once): what bench.py reports as DRAM traffic
 extern "C" double sta_baq_stream_bytes_per_base(void) { return (baq_dec_mode() == 2 ? 2 : 3) * 15 * 8 / 2.0; }
+// the same for the class-S kernel: one row of three stored, (M, I) of 15 cells, 16 bytes each -- written once and read once inside the launch
+extern "C" double sta_baq7s_stream_bytes_per_base(void) { return 15 * 16 / 3.0; }
 
 size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_launch, int slab_gib_cap)
 {

@@ -190,6 +190,13 @@ std::unique_ptr<AlnReader> AlnReader::open(const std::string &path, std::string 
         }
         header_from_text(r->hdr_, true);
     }
+    {
+        // @HD ... SO:coordinate (the first header line)
+        const std::string &t = r->hdr_.text;
+        const size_t e = t.find('\n');
+        const std::string first = t.substr(0, e == std::string::npos ? t.size() : e);
+        r->sorted_hint_ = first.compare(0, 3, "@HD") == 0 && first.find("\tSO:coordinate") != std::string::npos;
+    }
     return r;
 }
 
@@ -203,6 +210,7 @@ bool AlnReader::seek_voffset(uint64_t voffset)
     im.src = std::move(at);
     im.bp = im.bl = 0; im.eof = false;
     im.open_coffset = voffset >> 16; im.pulled = 0;
+    sorted_hint_ = true;                       // (an index exists for coordinate-sorted files only)
     size_t skip = (size_t)(voffset & 0xffff);
     uint8_t tmp[4096];
     while (skip) { const size_t k = im.read(tmp, skip < sizeof tmp ? skip : sizeof tmp); if (!k) return false; skip -= k; }
@@ -237,7 +245,12 @@ std::unique_ptr<BaiIndex> BaiIndex::load_for(const std::string &bam_path)
             }
         }
         fclose(fp);
-        if (ok) return ix;
+        if (ok) {
+            struct stat si, sd;
+            ix->stale_ = stat(p.c_str(), &si) == 0 && stat(bam_path.c_str(), &sd) == 0
+                         && (si.st_mtim.tv_sec < sd.st_mtim.tv_sec || (si.st_mtim.tv_sec == sd.st_mtim.tv_sec && si.st_mtim.tv_nsec < sd.st_mtim.tv_nsec));
+            return ix;
+        }
     }
     return nullptr;
 }
@@ -863,7 +876,9 @@ const std::string *Fasta::fetch(const std::string &name) const
             lk.unlock();
             std::unique_ptr<Fasta> whole = load_whole(z.path);
             lk.lock();
+            // (contigs already handed out keep their buffers: a device thread may still be reading one through the pointer it was given)
             for (size_t j = 0; j < names_.size(); ++j) {
+                if (j < z.ent.size() && z.ent[j].state == 2) continue;
                 const std::string *s2 = whole ? whole->fetch(names_[j]) : nullptr;
                 if (s2) seqs_[j] = *s2; else seqs_[j].clear();
             }

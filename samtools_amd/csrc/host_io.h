@@ -82,7 +82,10 @@ public:
     // record has been asked for, BGZF BAM only; false (and nothing changes) otherwise.
     bool seek_voffset(uint64_t voffset);
     // a record beyond the region in a position-sorted file: nothing further can match (next() / the chunk lane stop there)
-    bool past_region(const Rec &r) const { return has_reg_ && r.tid >= 0 && (r.tid > rtid_ || (r.tid == rtid_ && r.pos >= rend_)); }
+    // the first record beyond the region ends the reading -- only where the input is known to be in coordinate order: the header says so
+    // (@HD SO:coordinate) or the reader was positioned through an index (which exists for sorted files only); anything else is
+    // filtered to its last record, as HTSlib's unindexed region filter would
+    bool past_region(const Rec &r) const { return has_reg_ && sorted_hint_ && r.tid >= 0 && (r.tid > rtid_ || (r.tid == rtid_ && r.pos >= rend_)); }
     bool has_region() const { return has_reg_; }
     bool in_region(const Rec &r) const { return !has_reg_ || !(r.tid != rtid_ || r.pos >= rend_ || r.endpos() <= rbeg_); }
     struct Impl;
@@ -91,6 +94,7 @@ private:
     Impl *p_ = nullptr;
     Header hdr_;
     bool has_reg_ = false; int rtid_ = 0; int64_t rbeg_ = 0, rend_ = 0;
+    bool sorted_hint_ = false;
     int next_raw(Rec &r);
     void parse_ahead();
 };
@@ -108,8 +112,11 @@ public:
     // virtual offset to start reading from so that every alignment overlapping [pos, ...) of tid -- and everything after -- is
     // seen; 0 = unknown (read from the start); UINT64_MAX = nothing at or beyond (tid, pos)
     uint64_t start_offset(int tid, int64_t pos) const;
+    // the index file was last written before the data file (HTSlib warns about such a pair)
+    bool older_than_data() const { return stale_; }
 private:
     std::vector<std::vector<uint64_t>> lin_;
+    bool stale_ = false;
 };
 
 // Reference FASTA (faidx stand-in: fai_load + faidx_fetch_seq64).  With a `.fai` beside an uncompressed file the index is all

@@ -58,3 +58,32 @@ def test_region_counts_match_the_generator(bam):
     n_all, _, _ = _capi.io_scan_region(bam, "c3", threads=1)
     n_part, _, _ = _capi.io_scan_region(bam, "c3:100001-100150", threads=1)
     assert n_all > 4000 and 0 < n_part < 40
+
+
+def test_unsorted_input_is_filtered_to_its_last_record(tmp_path):
+    """The early stop behind a region is for coordinate-sorted input only (@HD SO:coordinate, or an index seek): a file that does not
+    say so is filtered to its last record, so records of the region that come after a later one are kept."""
+    from samtools_amd import _capi
+    ref = synth_ref(60000, seed=5)
+    rd = synth_reads(ref, depth=3, read_len=100, seed=6)
+    tmp = str(tmp_path / "t.sam"); write_sam(tmp, rd, "c1", len(ref))
+    head = [l for l in open(tmp) if l.startswith("@") and not l.startswith("@HD")]
+    recs = [l for l in open(tmp) if not l.startswith("@")]
+    recs_rev = recs[::-1]                                         # descending positions: every record of the region follows a "later" one
+    srt, uns = str(tmp_path / "s.sam"), str(tmp_path / "u.sam")
+    open(srt, "w").write("@HD\tVN:1.6\tSO:coordinate\n" + "".join(head) + "".join(recs))
+    open(uns, "w").write("@HD\tVN:1.6\tSO:unsorted\n" + "".join(head) + "".join(recs_rev))
+    n_s, _, _ = _capi.io_scan_region(srt, "c1:1000-2000", threads=1, use_index=False)
+    n_u, _, _ = _capi.io_scan_region(uns, "c1:1000-2000", threads=1, use_index=False)
+    assert n_s > 10 and n_u == n_s
+
+
+def test_an_index_older_than_its_data_file_is_not_used(bam, tmp_path):
+    import shutil
+    from samtools_amd import _capi
+    b2 = str(tmp_path / "y.bam")
+    shutil.copy(bam, b2); shutil.copy(bam + ".bai", b2 + ".bai")
+    os.utime(b2 + ".bai", (1, 1))                                 # the index is "from 1970", the data file is new
+    n_ix, h_ix, used = _capi.io_scan_region(b2, "c3:100000-199999", threads=2, use_index=True)
+    n_fs, h_fs, _ = _capi.io_scan_region(bam, "c3:100000-199999", threads=2, use_index=False)
+    assert (n_ix, h_ix) == (n_fs, h_fs) and not used

@@ -10,8 +10,9 @@
 // compiler keeps in scalar registers) and uses its 64 lanes where a step has width:
 //   * the compressed bytes are held 8 per lane (512 bytes of input in one coalesced load); the bit reader takes its next 64 bits
 //     from two lanes with v_readlane -- no memory round trip on the symbol path;
-//   * the whole output window lives in LDS (65 536 bytes): a literal is one ds_write_b8, a match is copied by up to 64 lanes at
-//     once (periodic source for overlapping copies), and the block leaves LDS once, as 16-byte stores;
+//   * the last 16 KiB of output live in an LDS ring: a literal is one ds_write_b8, a match is copied by up to 64 lanes at once
+//     (periodic source for overlapping copies); every finished 4 KiB page of the ring leaves LDS as 16-byte stores, and the few
+//     matches that reach further back than the ring (3 % on BAM data) read the bytes already written to the destination;
 //   * Huffman tables (two-level, 10 / 8 root bits, the layout of host_inflate.cpp) are built in LDS with lane-parallel fills.
 // Anything unexpected -- a damaged stream, a table that does not fit -- ends the block with a non-zero status; the host inflates
 // such a block again with zlib, whose verdict counts (host_bgzf.cpp bgzf_inflate_block).  The CRC-32 of every block is checked on
@@ -26,6 +27,7 @@
 #define BZ_NL 64
 #define BZ_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #define BZ_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#define BZ_MEM_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
 #define BZ_BALLOT(c) ((uint64_t)__ballot(c))
 #define BZ_COUNT(c) ((unsigned)__popcll(__ballot(c)))
 #define BZ_POPC(m) ((unsigned)__popcll((unsigned long long)(m)))
@@ -38,6 +40,7 @@
 #define BZ_NL 1
 #define BZ_UNI(x) ((uint32_t)(x))
 #define BZ_LDS_FENCE() ((void)0)
+#define BZ_MEM_FENCE() ((void)0)
 #define BZ_BALLOT(c) ((uint64_t)((c) ? 1 : 0))
 #define BZ_COUNT(c) ((unsigned)((c) ? 1 : 0))
 #define BZ_POPC(m) ((unsigned)__builtin_popcountll((unsigned long long)(m)))
@@ -48,7 +51,8 @@
 
 namespace bgzi {
 
-enum { LIT_PB = 10, DIST_PB = 8, LIT_CAP = (1 << LIT_PB) + 512, DIST_CAP = (1 << DIST_PB) + 256, WIN_BYTES = 65536 + 32 };
+// (table capacities: zlib's ENOUGH bounds for these root sizes are 1332 / ~400 entries)
+enum { LIT_PB = 10, DIST_PB = 8, LIT_CAP = (1 << LIT_PB) + 320, DIST_CAP = (1 << DIST_PB) + 256, RING = 16384, RING_MASK = RING - 1, PAGE_SHIFT = 12 };
 enum { OP_BASE = 16, OP_EOB = 32, OP_LINK = 64, OP_BAD = 128 };
 // a table entry as one word: bits | op << 8 | val << 16 (host_inflate.cpp's Entry)
 BZ_HD uint32_t mk_entry(int bits, int op, int val) { return (uint32_t)bits | (uint32_t)op << 8 | (uint32_t)val << 16; }
@@ -62,8 +66,7 @@ struct Lds {
     uint32_t ct[128];               // the code-length code's table
     uint16_t rev[320];
     uint8_t lens[320];
-    uint8_t maxlen[1 << LIT_PB];
-    alignas(16) uint8_t win[WIN_BYTES];         // the output window; the block starts at win[align], align = its global address mod 16
+    alignas(16) uint8_t ring[RING];             // the last RING output bytes: output position x lives at ring[(align + x) & RING_MASK], align = the block's destination address mod 16
 };
 
 struct Consts {                     // RFC 1951 3.2.5 tables (+ 2^20 / d rounded up, for the periodic copies), in device memory
@@ -137,7 +140,7 @@ BZ_HD int build_table(Lds &L, const Consts &C, const uint8_t *lens, int n, int k
     for (int l = 1; l <= 15; ++l) { code = (code + count[l - 1]) << 1; next[l] = code; }
     const int psize = 1 << pb;
     const uint32_t bad = mk_entry(0, OP_BAD, 0);
-    for (int i = lane; i < psize; i += BZ_NL) { tab[i] = bad; L.maxlen[i] = 0; }
+    for (int i = lane; i < psize; i += BZ_NL) tab[i] = bad;
     BZ_LDS_FENCE();
     bool any_long = false;
     for (int base = 0; base < n; base += BZ_NL) {
@@ -161,7 +164,8 @@ BZ_HD int build_table(Lds &L, const Consts &C, const uint8_t *lens, int n, int k
             const int j = BZ_FFS(lm); lm &= lm - 1;
             const int lj = (int)BZ_READLANE(ls, j);
             const unsigned prefix = (unsigned)BZ_READLANE(r, j) & (unsigned)(psize - 1);
-            if (lane == 0 && lj > L.maxlen[prefix]) L.maxlen[prefix] = (uint8_t)lj;
+            // (the longest code under a primary prefix is kept in that prefix's own -- still empty -- entry until the sub-table is placed)
+            if (lane == 0 && lj > (int)(tab[prefix] & 0xff)) tab[prefix] = mk_entry(lj, OP_BAD, 0);
             any_long = true;
         }
     }
@@ -180,7 +184,7 @@ BZ_HD int build_table(Lds &L, const Consts &C, const uint8_t *lens, int n, int k
             const unsigned prefix = rv & (unsigned)(psize - 1);
             uint32_t pe = BZ_UNI(tab[prefix]);
             if (!((pe >> 8) & OP_LINK)) {
-                const int sb = (int)BZ_UNI(L.maxlen[prefix]) - pb;
+                const int sb = (int)(pe & 0xff) - pb;
                 if (next_free + (1 << sb) > cap) return ST_TABLE;
                 pe = mk_entry(sb, OP_LINK, next_free);
                 if (lane == 0) tab[prefix] = pe;
@@ -301,7 +305,7 @@ BZ_HD int read_dynamic(Lds &L, const Consts &C, Bits &b, InWin &W)
     }
     BZ_LDS_FENCE();
     if (BZ_UNI(L.lens[256]) == 0) return ST_BAD_STREAM;             // no end-of-block code
-    // (the distance lengths are read before the literal table's build reuses `rev` and `maxlen`; `lens` itself is not touched)
+    // (the literal table's build reuses `rev`; `lens` itself is not touched)
     int rc = build_table(L, C, L.lens, hlit, K_LITLEN, LIT_PB, L.lit, LIT_CAP);
     if (rc) return rc;
     return build_table(L, C, L.lens + hlit, hdist, K_DIST, DIST_PB, L.dist, DIST_CAP);
@@ -318,15 +322,38 @@ BZ_HD int fixed_tables(Lds &L, const Consts &C)
     return build_table(L, C, L.lens + 288, 32, K_DIST, DIST_PB, L.dist, DIST_CAP);
 }
 
-// One BGZF block: in[0, in_len) deflate data (readable to in + in_len + 8 + 520: the window loads run ahead) -> L.win[align ..
-// align + isize).  Returns ST_OK when the final block ended exactly at isize bytes.
-BZ_HD int inflate_block(Lds &L, const Consts &C, const uint8_t *in, int64_t in_len, uint32_t isize, uint32_t align)
+// output bytes [x0, x1) of the block: ring -> dst (ring offset == destination address mod 16: 16-byte body, byte stores for ragged ends)
+BZ_HD void ring_flush(const Lds &L, uint32_t align, uint8_t *dst, uint32_t x0, uint32_t x1)
+{
+    const int lane = BZ_LANE;
+    if (x1 <= x0) return;
+    BZ_LDS_FENCE();
+    const uint32_t n = x1 - x0;
+    const uint32_t mis = (align + x0) & 15u;
+    uint32_t head = mis ? 16u - mis : 0u; if (head > n) head = n;
+    for (uint32_t i = (uint32_t)lane; i < head; i += BZ_NL) dst[x0 + i] = L.ring[(align + x0 + i) & RING_MASK];
+    const uint32_t body = (n - head) >> 4;
+    for (uint32_t i = (uint32_t)lane; i < body; i += BZ_NL) {
+        const uint32_t x = x0 + head + 16u * i;
+        uint32_t v[4];
+        __builtin_memcpy(v, &L.ring[(align + x) & RING_MASK], 16);       // (a 16-byte piece never wraps: ring size and pieces are 16-aligned)
+        __builtin_memcpy(dst + x, v, 16);
+    }
+    const uint32_t done = head + (body << 4);
+    for (uint32_t i = done + (uint32_t)lane; i < n; i += BZ_NL) dst[x0 + i] = L.ring[(align + x0 + i) & RING_MASK];
+}
+
+// One BGZF block: in[0, in_len) deflate data (readable to in + in_len + 8 + 520: the input window runs ahead) -> dst[0, isize), where
+// align = dst's address mod 16.  Returns ST_OK when the final block ended exactly at isize bytes (everything is then in dst).
+BZ_HD int inflate_block(Lds &L, const Consts &C, const uint8_t *in, int64_t in_len, uint32_t isize, uint32_t align, uint8_t *dst)
 {
     const int lane = BZ_LANE;
     Bits b; b.buf = 0; b.cnt = 0; b.next = 0; b.in = in; b.in_len = in_len;
     InWin W; W.base = -1;
-    uint8_t *const out = L.win + align;
-    uint32_t o = 0;
+    uint32_t o = 0;                  // output bytes so far
+    uint32_t flushed = 0;            // of them, already in dst: everything below the last finished ring page
+    // pages of the ring are finished when the output passes their end: (align + x) >> PAGE_SHIFT changes
+#define BZ_FLUSH_PAGES() do { const uint32_t pg_ = ((align + o) >> PAGE_SHIFT) << PAGE_SHIFT; if (pg_ > align + flushed) { ring_flush(L, align, dst, flushed, pg_ - align); flushed = pg_ - align; } } while (0)
     for (;;) {
         if (b.next > in_len + 8) return ST_INPUT;
         refill(b, W);
@@ -341,9 +368,13 @@ BZ_HD int inflate_block(Lds &L, const Consts &C, const uint8_t *in, int64_t in_l
             int64_t p = b.next - (b.cnt >> 3);
             b.buf = 0; b.cnt = 0;
             if (p + (int64_t)len > in_len || o + len > isize) return ST_BAD_STREAM;
-            for (unsigned i = (unsigned)lane; i < len; i += BZ_NL) out[o + i] = in[p + i];
-            o += len; b.next = p + len;
-            BZ_LDS_FENCE();
+            for (unsigned done = 0; done < len;) {          // a page at a time: the ring is smaller than a stored block may be
+                unsigned n = len - done; if (n > (1u << PAGE_SHIFT)) n = 1u << PAGE_SHIFT;
+                for (unsigned i = (unsigned)lane; i < n; i += BZ_NL) L.ring[(align + o + i) & RING_MASK] = in[p + done + i];
+                o += n; done += n;
+                BZ_FLUSH_PAGES();
+            }
+            b.next = p + len;
         } else if (type == 1 || type == 2) {
             int rc = type == 1 ? fixed_tables(L, C) : read_dynamic(L, C, b, W);
             if (rc) return rc;
@@ -353,8 +384,9 @@ BZ_HD int inflate_block(Lds &L, const Consts &C, const uint8_t *in, int64_t in_l
                 const unsigned op = (e >> 8) & 0xff;
                 if (op == 0) {
                     if (o >= isize) return ST_SIZE;
-                    if (lane == 0) out[o] = (uint8_t)(e >> 16);
+                    if (lane == 0) L.ring[(align + o) & RING_MASK] = (uint8_t)(e >> 16);
                     ++o;
+                    if (((align + o) & ((1u << PAGE_SHIFT) - 1)) == 0) BZ_FLUSH_PAGES();
                     continue;
                 }
                 if (op & OP_EOB) break;
@@ -366,26 +398,37 @@ BZ_HD int inflate_block(Lds &L, const Consts &C, const uint8_t *in, int64_t in_l
                 const unsigned dist = (d >> 16) + take(b, (int)(dop & 15));
                 if (dist > o || len > isize - o) return ST_BAD_STREAM;
                 BZ_LDS_FENCE();
-                const uint8_t *src = out + o - dist;
-                if (dist >= (unsigned)BZ_NL || dist >= len) {
+                const uint32_t s0 = align + o - dist, d0 = align + o;       // ring positions before masking
+                if (dist + len > (unsigned)RING) {
+                    // further back than the ring holds: those bytes are in dst already (dist + len > RING puts the whole source below the
+                    // last finished page; it cannot overlap the copy).  Same wave, program order: the flush stores are visible to these loads
+                    BZ_MEM_FENCE();
+                    const uint8_t *g = dst + (o - dist);
+                    for (unsigned i = (unsigned)lane; i < len; i += BZ_NL) { const uint8_t v = g[i]; L.ring[(d0 + i) & RING_MASK] = v; }
+                } else if (dist >= (unsigned)BZ_NL || dist >= len) {
                     // lanes of one pass never read what the same pass writes; the passes run in order
-                    for (unsigned i = (unsigned)lane; i < len; i += BZ_NL) { const uint8_t v = src[i]; out[o + i] = v; }
+                    for (unsigned i = (unsigned)lane; i < len; i += BZ_NL) { const uint8_t v = L.ring[(s0 + i) & RING_MASK]; L.ring[(d0 + i) & RING_MASK] = v; }
                 } else if (dist == 1) {
-                    const uint8_t v = src[0];
-                    for (unsigned i = (unsigned)lane; i < len; i += BZ_NL) out[o + i] = v;
+                    const uint8_t v = L.ring[s0 & RING_MASK];
+                    for (unsigned i = (unsigned)lane; i < len; i += BZ_NL) L.ring[(d0 + i) & RING_MASK] = v;
                 } else {
                     // an overlapping copy repeats the dist bytes in front of it
                     const uint32_t inv = C.inv20[dist];
-                    for (unsigned i = (unsigned)lane; i < len; i += BZ_NL) { const unsigned q = (i * inv) >> 20; const uint8_t v = src[i - q * dist]; out[o + i] = v; }
+                    for (unsigned i = (unsigned)lane; i < len; i += BZ_NL) { const unsigned q = (i * inv) >> 20; const uint8_t v = L.ring[(s0 + i - q * dist) & RING_MASK]; L.ring[(d0 + i) & RING_MASK] = v; }
                 }
+                const uint32_t page_before = (align + o) >> PAGE_SHIFT;
                 o += len;
                 BZ_LDS_FENCE();
+                if (((align + o) >> PAGE_SHIFT) != page_before) BZ_FLUSH_PAGES();
             }
         } else return ST_BAD_STREAM;
         if (final_block) break;
     }
+#undef BZ_FLUSH_PAGES
     if (b.next - (b.cnt >> 3) > in_len) return ST_INPUT;         // the stream needed bytes beyond its end
-    return o == isize ? ST_OK : ST_SIZE;
+    if (o != isize) return ST_SIZE;
+    ring_flush(L, align, dst, flushed, o);
+    return ST_OK;
 }
 
 }  // namespace bgzi

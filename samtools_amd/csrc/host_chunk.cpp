@@ -99,8 +99,17 @@ ChunkReader::ChunkReader(AlnReader *rd, int threads, bool keep_raw, int gpu_devi
             rd->release_source();
         }
     }
-    if (map_ && gpu_device >= 0) gpu_ = make_gpu_inflater(gpu_device);
-    if (gpu_) {
+    // the device decoder comes up on a thread of its own: until it is there the feeder hands single groups to the parsers, which inflate
+    // them themselves -- the first windows do not wait for the HIP runtime
+    const char *gi = getenv("STA_GPU_INFLATE"), *fk = getenv("STA_FAKE_GPU_INFLATE");
+    if (map_ && gpu_device >= 0 && ((gi && atoi(gi) != 0) || (fk && atoi(fk) != 0))) {
+        gpu_device_ = gpu_device;
+        gpu_init_ = std::thread([this] {
+            std::unique_ptr<GpuInflater> p = make_gpu_inflater(gpu_device_);
+            const bool ok = p != nullptr;
+            gpu_ = std::move(p);
+            gpu_state_.store(ok ? 1 : -1, std::memory_order_release);
+        });
         // (two batches of groups in flight on the device besides what the parsers hold)
         const char *e = getenv("STA_GPU_INFLATE_BATCH"); const int bg = e ? atoi(e) : 48;
         max_ahead_ = (size_t)(bg < 1 ? 1 : bg > 512 ? 512 : bg) * 2 + (size_t)threads * 2 + 2;
@@ -116,6 +125,7 @@ ChunkReader::~ChunkReader()
     { std::lock_guard<std::mutex> g(out_m_); stop_ = true; }
     cv_room_.notify_all(); cv_out_.notify_all(); cv_link_.notify_all(); cv_ready_.notify_all();
     for (auto &t : th_) if (t.joinable()) t.join();
+    if (gpu_init_.joinable()) gpu_init_.join();
 }
 
 void ChunkReader::publish_link(uint64_t seq, Link &&l)
@@ -306,6 +316,24 @@ void ChunkReader::work_gpu_feeder()
     for (int cur = 0; !ended; cur ^= 1) {
         Batch &b = bt[cur];
         finalize(b);                                        // (the batch that used this slot two rounds ago)
+        if (gpu_state_.load(std::memory_order_acquire) != 1) {
+            // no device decoder (yet): one group at a time, inflated by the parser that takes it.  Groups must reach the parsers in cut
+            // order, so the other slot's batch -- submitted when the decoder was there -- goes first
+            finalize(bt[cur ^ 1]);
+            {
+                std::unique_lock<std::mutex> lk(out_m_);
+                cv_room_.wait(lk, [this] { return stop_ || next_in_ - next_out_ < max_ahead_; });
+                if (stop_) return;
+            }
+            MGroup g;
+            if (!cut_group(g, &end_status)) { ended = true; break; }
+            g.keep = get_buf();
+            g.keep->resize(GROUP_HEAD + g.total);
+            g.inflate_here = true;
+            { std::lock_guard<std::mutex> lk(out_m_); ready_q_.push_back(std::move(g)); }
+            cv_ready_.notify_one();
+            continue;
+        }
         while (b.groups.size() < batch_groups) {
             {
                 std::unique_lock<std::mutex> lk(out_m_);
@@ -349,6 +377,10 @@ void ChunkReader::work_gpu_parse()
             if (stop_) return;
             if (ready_q_.empty()) return;                   // (the feeder is done)
             g = std::move(ready_q_.front()); ready_q_.pop_front();
+        }
+        if (g.inflate_here) {
+            size_t off = GROUP_HEAD;
+            for (const BgzfMap::Block &b : g.blocks) { if (!bgzf_inflate_block(b, g.keep->data() + off)) { g.bad = true; break; } off += b.isize; }
         }
         process_group(g, *g.keep, r, scratch);
     }

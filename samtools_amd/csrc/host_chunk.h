@@ -100,6 +100,7 @@ private:
         std::vector<BgzfMap::Block> blocks;
         std::shared_ptr<pvector<uint8_t>> keep;    // its buffer: GROUP_HEAD free bytes, then the inflated blocks
         bool bad = false, verify = false;          // verify: the bytes came back from the device, their CRC-32s are still to be checked
+        bool inflate_here = false;                 // the parser inflates the blocks itself (the device decoder was not up yet)
     };
     bool cut_group(MGroup &g, int *end_status);
     void finish_stream(int st);
@@ -107,6 +108,9 @@ private:
     void work_mapped();
     // with the device's decoder: a feeder thread and a queue of inflated groups in front of the parsers
     std::unique_ptr<GpuInflater> gpu_;
+    int gpu_device_ = -1;
+    std::atomic<int> gpu_state_{ 0 };              // 0 = coming up (its own thread: the HIP runtime takes a quarter of a second), 1 = ready, -1 = none
+    std::thread gpu_init_;
     std::deque<MGroup> ready_q_; std::condition_variable cv_ready_; bool feed_end_ = false;     // (guarded by out_m_)
     void work_gpu_feeder();
     void work_gpu_parse();

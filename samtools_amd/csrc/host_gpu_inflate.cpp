@@ -119,9 +119,9 @@ public:
 
 std::unique_ptr<GpuInflater> make_gpu_inflater(int device)
 {
-    // Opt-in (STA_GPU_INFLATE=1).  Measured on the 1-Gbase file (profiles/r04_bgzf_inflate_device.md): the kernel inflates 8.6 GB/s and
-    // takes the decode wait of a run from 0.28-0.37 s to 0.21-0.31 s on the 16-CPU container, but its 76 KB of LDS per wave and its
-    // transfers crowd the pileup kernels off the same device (device thread 0.29 -> 0.50 s): the run as a whole is slower today.
+    // Opt-in (STA_GPU_INFLATE=1).  Measured on the 1-Gbase file (profiles/r04_bgzf_inflate_device.md): the kernel inflates 19 GB/s and
+    // takes a third off the decode wait of a run on the 16-CPU container, but the run as a whole is still slower (page-locked buffers of
+    // two batches to allocate, the inflated bytes crossing PCIe twice more, the pileup kernels sharing the device).
     const char *e = getenv("STA_GPU_INFLATE");
     if (!e || atoi(e) == 0) return nullptr;
     int n = 0;

@@ -3,7 +3,7 @@
 // What it replaces on the host: bgzf.c inflate_block() under sam_read1 (bam_plcmd.c:409, bam2depth.c:541-543) -- and, in this engine,
 // the decode threads' inflate (host_bgzf.cpp bgzf_inflate_block), which bounded every file -> text run on a host with few cores: the
 // compressed file is uploaded as it is, and its tens of thousands of independent 64 KiB deflate streams are decoded side by side.
-// The decoder itself (bit reader over a lane-held input window, Huffman tables and the whole output window in LDS) is
+// The decoder itself (bit reader over a lane-held input window, Huffman tables and a 16 KiB ring of the output in LDS) is
 // bgzf_inflate_dev.h; this file is the launch: block b of the table -> out[out_off, out_off + isize), status[b] = 0 or why not.
 #include <hip/hip_runtime.h>
 #include "sta_dev.h"
@@ -19,20 +19,8 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *__restrict__
     uint8_t *dst = out + blk.out_off;
     const uint32_t align = (uint32_t)((uintptr_t)dst & 15);
     int st = bgzi::ST_SIZE;
-    if (blk.isize <= 65536u) st = bgzi::inflate_block(L, C, comp + blk.comp_off, (int64_t)blk.clen, blk.isize, align);
+    if (blk.isize <= 65536u) st = bgzi::inflate_block(L, C, comp + blk.comp_off, (int64_t)blk.clen, blk.isize, align, dst);
     if (lane == 0) status[b] = (uint32_t)st;
-    if (st != bgzi::ST_OK) return;
-    // the block leaves LDS once: LDS offset == global address (mod 16), 16-byte body stores, byte stores for the ragged ends
-    const uint8_t *src = L.win + align;
-    const uint32_t n = blk.isize;
-    uint32_t head = align ? 16 - align : 0; if (head > n) head = n;
-    if ((uint32_t)lane < head) dst[lane] = src[lane];
-    const uint32_t body = (n - head) >> 4;
-    const uint4 *src4 = reinterpret_cast<const uint4 *>(src + head);
-    uint4 *dst4 = reinterpret_cast<uint4 *>(dst + head);
-    for (uint32_t i = lane; i < body; i += 64) dst4[i] = src4[i];
-    const uint32_t done = head + (body << 4);
-    if (done + lane < n) dst[done + lane] = src[done + lane];
 }
 
 void sta_launch_bgzf_inflate(hipStream_t s, const uint8_t *comp, const StaBgzfBlock *blocks, int n_blocks, uint8_t *out, uint32_t *status)

@@ -6,6 +6,8 @@
 #include "../../samtools_amd/csrc/host_bgzf.h"
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <thread>
 namespace sta {
 namespace {
 class Fake : public GpuInflater {
@@ -38,6 +40,9 @@ std::unique_ptr<GpuInflater> make_gpu_inflater(int)
 {
     const char *e = getenv("STA_FAKE_GPU_INFLATE");
     if (!e || atoi(e) == 0) return nullptr;
+    // (the real decoder takes a while to come up -- the HIP runtime -- and the reader starts without it: STA_FAKE_GPU_INFLATE_DELAY_MS)
+    if (const char *d = getenv("STA_FAKE_GPU_INFLATE_DELAY_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(d)));
+    if (atoi(e) == 3) return nullptr;            // "no usable device": the reader stays with its own inflate
     return std::unique_ptr<GpuInflater>(new Fake(atoi(e)));
 }
 }  // namespace sta

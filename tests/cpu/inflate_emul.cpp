@@ -33,7 +33,7 @@ int main(int argc, char **argv)
     bgzi::Consts C; bgzi::fill_consts(C);
     long n_ok = 0, n_bad = 0, n_damaged = 0, n_damaged_caught = 0;
     for (int it = 0; it < rounds; ++it) {
-        const int kind = it % 7;
+        const int kind = it % 8;
         int n = it % 11 == 0 ? rnd(40) : it % 5 == 0 ? 65280 - rnd(3) : 1 + rnd(65280);
         if (it == 0) n = 0;
         std::vector<uint8_t> data((size_t)n);
@@ -54,7 +54,14 @@ int main(int argc, char **argv)
                 for (int i = 0; i < 150; ++i) r[k++] = (uint8_t)(rnd(10) ? 37 : 2 + rnd(38));
                 for (int i = 0; i < k && o < data.size(); ++i) data[o++] = r[i];
             }
-        } else for (int i = 0; i < n; ++i) data[(size_t)i] = (uint8_t)((i * 2654435761u) >> (24 + rnd(2)));
+        } else if (kind == 6) for (int i = 0; i < n; ++i) data[(size_t)i] = (uint8_t)((i * 2654435761u) >> (24 + rnd(2)));
+        else {
+            // stretches copied from 17 000 .. 32 000 bytes back: matches that reach behind the decoder's 16 KiB ring
+            for (int i = 0; i < n;) {
+                const int back = 17000 + rnd(15000), run = 20 + rnd(400);
+                for (int k = 0; k < run && i < n; ++k, ++i) data[(size_t)i] = (uint8_t)(i >= back && rnd(40) ? data[(size_t)(i - back)] : rnd(256));
+            }
+        }
         const int level = it % 13 == 0 ? 0 : 1 + rnd(9);
         const int strat = it % 17 == 3 ? Z_FIXED : it % 19 == 4 ? Z_HUFFMAN_ONLY : it % 23 == 5 ? Z_RLE : Z_DEFAULT_STRATEGY;
         std::vector<uint8_t> comp = deflate_raw(data, level, strat);
@@ -62,15 +69,19 @@ int main(int argc, char **argv)
         const bool damage = it % 9 == 8 && clen > 4;
         if (damage) { ++n_damaged; const int k = 1 + rnd(3); for (int j = 0; j < k; ++j) comp[(size_t)rnd((int)clen)] ^= (uint8_t)(1 << rnd(8)); }
         comp.resize(clen + 2048, 0);
+        // the destination: `align` = its address mod 16 (a 16-aligned buffer entered at that offset), guard bytes either side
         const uint32_t align = (uint32_t)rnd(16);
-        memset(L.win, 0xee, sizeof L.win);
-        const int st = bgzi::inflate_block(L, C, comp.data(), (int64_t)clen, (uint32_t)n, align);
+        alignas(16) static uint8_t outbuf[65536 + 64];
+        memset(outbuf, 0xee, sizeof outbuf);
+        uint8_t *dst = outbuf + 16 + align;
+        const int st = bgzi::inflate_block(L, C, comp.data(), (int64_t)clen, (uint32_t)n, align, dst);
         if (damage) {
             if (st != 0) ++n_damaged_caught;
-            else if (memcmp(L.win + align, data.data(), (size_t)n) != 0) { /* a damaged stream may decode to other bytes of the right size: the CRC catches that */ }
+            else if (n && memcmp(dst, data.data(), (size_t)n) != 0) { /* a damaged stream may decode to other bytes of the right size: the CRC catches that */ }
+            if (dst[n] != 0xee || dst[-1] != 0xee) { fprintf(stderr, "OUT OF BOUNDS write on a damaged stream, it %d\n", it); ++n_bad; }
             continue;
         }
-        if (st != 0 || memcmp(L.win + align, data.data(), (size_t)n) != 0 || L.win[align + (size_t)n] != 0xee || (align && L.win[align - 1] != 0xee)) {
+        if (st != 0 || (n && memcmp(dst, data.data(), (size_t)n) != 0) || dst[n] != 0xee || dst[-1] != 0xee) {
             if (n_bad < 5) fprintf(stderr, "MISMATCH it %d kind %d n %d level %d strat %d clen %zu status %d\n", it, kind, n, level, strat, clen, st);
             ++n_bad;
         } else ++n_ok;

@@ -48,3 +48,7 @@ def test_feeder_lane_stages_what_the_readers_own_inflate_stages(bench, bam):
         for batch in ("1", "3", "48"):
             for thr in ("1", "4"):
                 assert _run(bench, bam, {"STA_FAKE_GPU_INFLATE": mode, "STA_GPU_INFLATE_BATCH": batch}, thr) == want, (mode, batch, thr)
+    # the decoder comes up late (the reader starts with its own inflate and switches over mid-file), or not at all
+    for delay in ("2", "15", "60"):
+        assert _run(bench, bam, {"STA_FAKE_GPU_INFLATE": "2", "STA_GPU_INFLATE_BATCH": "3", "STA_FAKE_GPU_INFLATE_DELAY_MS": delay}) == want, delay
+    assert _run(bench, bam, {"STA_FAKE_GPU_INFLATE": "3", "STA_FAKE_GPU_INFLATE_DELAY_MS": "5"}) == want

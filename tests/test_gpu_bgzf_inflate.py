@@ -30,6 +30,14 @@ def _kinds(rng, n):
     yield (pat * (n // per + 1))[:n]
     q = np.where(rng.random(n) < 0.9, 37, rng.integers(2, 40, n)).astype(np.uint8)
     yield q.tobytes()
+    # stretches repeated from 17 000 .. 30 000 bytes back: matches that reach behind the decoder's 16 KiB LDS ring
+    far = rng.integers(0, 256, n, dtype=np.uint8)
+    i = 30000
+    while i < n:
+        back, run = int(rng.integers(17000, 30000)), int(rng.integers(20, 400))
+        far[i:i + run] = far[i - back:i - back + run][:max(0, min(run, n - i))]
+        i += run + int(rng.integers(0, 50))
+    yield far.tobytes()
 
 
 @pytest.mark.gpu

@@ -165,6 +165,25 @@ def test_chunk_lane_reports_unsorted_and_damaged_input(capi, files):
     p = os.path.join(d, "dmg_lane2.bam"); open(p, "wb").write(raw)
     with pytest.raises(RuntimeError):
         capi.io_scan(p, 3, 2)
+    # the chunk lane reads a BAM file through a mapping and cuts the blocks itself: its own view of the file's end
+    raw = open(bam, "rb").read()
+    good = capi.io_scan(bam, 3, 2)
+    p = os.path.join(d, "cut_mid_block.bam"); open(p, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(RuntimeError):
+        capi.io_scan(p, 3, 2)
+    # whole blocks only, but the last record unfinished (8 KiB blocks: records straddle them)
+    import struct
+    offs, o = [], 0
+    while o + 18 <= len(raw):
+        offs.append(o)
+        o += struct.unpack_from("<H", raw, o + 16)[0] + 1
+    cut = offs[len(offs) // 2]
+    p = os.path.join(d, "cut_mid_record.bam"); open(p, "wb").write(raw[:cut])
+    with pytest.raises(RuntimeError):
+        capi.io_scan(p, 3, 2)
+    p = os.path.join(d, "noeof_lane.bam"); open(p, "wb").write(raw[:-28])
+    assert capi.io_scan(p, 3, 2) == good
+    assert _with_env({"STA_CHUNK_MAP": "0"}, lambda: capi.io_scan(bam, 3, 2)) == good
 
 
 def test_chunk_lane_with_several_input_files(capi, files, tmp_path):

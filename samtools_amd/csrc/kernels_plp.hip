@@ -936,6 +936,12 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
         if (deep_mode == 2 && strip_rng) launch_deep(s, w, p, offs, colinfo, out, strip_rng, tile_cap, tbase);
         return;
     }
+    // A wave's 64 rows go through an LDS slice only while that slice leaves the CU its waves: with --output-extra columns a wave's rows
+    // reach 48 KB (three waves per CU), and the walker -- ~80 instructions per entry and pass, latency-bound -- ran 2.2x slower than
+    // with byte stores straight to the text and full occupancy (mpileup30_B_sOx: 37.2 -> 17.1 ms, profiles/r04_generic_walker_lds_cap.md).
+    // Waves above 8 KiB of rows therefore take the byte-store branch of k_mplp_emit (STA_GENERIC_LDS_CAP: experiment knob).
+    static const uint32_t generic_cap = [] { const char *e = getenv("STA_GENERIC_LDS_CAP"); const int v = e ? atoi(e) : 8192; return (uint32_t)(v < 1024 ? 1024 : v); }();
+    if (lds_cap > generic_cap) lds_cap = generic_cap;
     uint32_t slice = (lds_cap + 16 + 15) & ~15u;
     // waves per workgroup so that the workgroup's LDS (one slice per wave) stays within 64 KiB
     int wpb = 4 * slice <= 65536 ? 4 : (2 * slice <= 65536 ? 2 : 1);

@@ -46,7 +46,7 @@
 #define BZ_POPC(m) ((unsigned)__builtin_popcountll((unsigned long long)(m)))
 #define BZ_LT_MASK 0ull
 #define BZ_FFS(m) (__builtin_ffsll((long long)(m)) - 1)
-#define BZ_READLANE(v, l) (v)
+#define BZ_READLANE(v, l) ((void)(l), (v))
 #endif
 
 namespace bgzi {

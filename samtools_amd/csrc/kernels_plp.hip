@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const unsigned long long *__
     }
 }
 
-#define TILE_WAVES 2            // waves per workgroup of k_mplp_emit_tile (they share nothing)
+#define TILE_WAVES 1            // waves per workgroup of k_mplp_emit_tile (they share nothing; measured 1 / 2 / 4 in one box: 0.420 / 0.428 / 0.486 ms)
 
 __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
                                                                     const uint32_t *__restrict__ wfirst, const uint64_t *__restrict__ tbase, char *out, uint32_t lds_cap)

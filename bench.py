@@ -79,6 +79,10 @@ WORKLOADS = {
     # reads carry no NM tag: that column is "*"
     "mpileup30_B_sOx": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-s", "-O", "--output-extra", "QNAME,NM", "-f", "{fa}", "{sam}"],
                            flags_on=_PRINT_MAPQ_CHAR | _PRINT_QPOS | _PRINT_QNAME, flags_off=_REALN, n_tags=1),
+    # -s alone: the mapping-quality column rides in the tile kernels (round 4); three files and the 300x shape (read-major kernel) as well
+    "mpileup30_B_s": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-s", "-f", "{fa}", "{sam}"], flags_on=_PRINT_MAPQ_CHAR, flags_off=_REALN),
+    "mpileup300_B_s": _wl("mpileup", 300, 1 << 19, ["mpileup", "-B", "-s", "-f", "{fa}", "{sam}"], flags_on=_PRINT_MAPQ_CHAR, flags_off=_REALN),
+    "mpileup30_B_s_3files": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-s", "-f", "{fa}", "{sam}"], flags_on=_PRINT_MAPQ_CHAR, flags_off=_REALN, files=3),
     # configs[1]
     "depth30": _wl("depth", 30, 8 << 20, ["depth", "-a", "{sam}"], bpb=0.21),
     # rows widened into after the pileup path; single GPU, results stay on the device

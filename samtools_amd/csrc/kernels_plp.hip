@@ -425,18 +425,25 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     for (int f = 0; f < W.nfiles; ++f) {
         const StaReadsDev &R = W.files[f];
         // "\tcount\t" and where the two strings of this file start; the separators and '*' placeholders right away
-        unsigned my_seq = 0, my_qual = 0;
+        unsigned my_seq = 0, my_qual = 0, my_mqd = 0;
         if (my_ex) {
             const uint2 ci = f == 0 ? ci0 : colinfo[(int64_t)f * ncols + c0 + lane];
             const uint32_t cnt = ci.x, sl = ci.y ? ci.y : 1;
             fx.put('\t'); fx.put_dec(cnt); fx.put('\t');
             my_seq = (unsigned)(fx.g - out0);
-            if (!cnt) { fx.put('*'); fx.put('\t'); fx.put('*'); }
-            else { fx.g += sl; fx.put('\t'); my_qual = (unsigned)(fx.g - out0); fx.g += cnt; }
+            if (!cnt) { fx.put('*'); fx.put('\t'); fx.put('*'); if (P.mq_col) { fx.put('\t'); fx.put('*'); } }
+            else {
+                fx.g += sl; fx.put('\t'); my_qual = (unsigned)(fx.g - out0); fx.g += cnt;
+                // -s: the mapping-quality string mirrors the quality string, one tab and `cnt` bytes further on
+                if (P.mq_col) { fx.put('\t'); fx.g += cnt; my_mqd = cnt + 1; }
+            }
         }
-        unsigned seqcur[DEEP_STRIP], qualcur[DEEP_STRIP];          // wave-uniform
+        unsigned seqcur[DEEP_STRIP], qualcur[DEEP_STRIP], mqd[DEEP_STRIP];          // wave-uniform
 #pragma unroll
-        for (int k = 0; k < DEEP_STRIP; ++k) { seqcur[k] = (unsigned)__builtin_amdgcn_readlane((int)my_seq, k); qualcur[k] = (unsigned)__builtin_amdgcn_readlane((int)my_qual, k); }
+        for (int k = 0; k < DEEP_STRIP; ++k) {
+            seqcur[k] = (unsigned)__builtin_amdgcn_readlane((int)my_seq, k); qualcur[k] = (unsigned)__builtin_amdgcn_readlane((int)my_qual, k);
+            mqd[k] = P.mq_col ? (unsigned)__builtin_amdgcn_readlane((int)my_mqd, k) : 0u;
+        }
         if (R.n == 0) continue;
         const int64_t rlo = f == 0 ? rlo0 : rng[2 * ((int64_t)f * nstrips + wave)], rhi = f == 0 ? rhi0 : rng[2 * ((int64_t)f * nstrips + wave) + 1];
         const auto g_qual = GPTR(uint8_t, R.qual); const auto g_seq = GPTR(uint8_t, R.seq);
@@ -583,6 +590,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                         if (tail) out0[o + 1] = '$';
                     } else x_off[k] = o;
                     out0[qualcur[k] + pm] = (char)(qc + 33 < 126 ? qc + 33 : 126);
+                    if (P.mq_col) out0[qualcur[k] + pm + mqd[k]] = mq_char;
                 }
                 seqcur[k] += total; qualcur[k] += (unsigned)__popcll(m);
             }
@@ -701,7 +709,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THRE
         len_scan_2(L, t); __syncthreads();
         len_scan_3(L, t); __syncthreads();
         const int before = len_scan_4(L, t);
-        len_file_result(L, t, before, ntile, colinfo + (int64_t)f * ncols + c0, total, any);
+        len_file_result(L, t, before, ntile, colinfo + (int64_t)f * ncols + c0, total, any, P.mq_col != 0);
         __syncthreads();
     }
     // row lengths of the thread's four columns and their exclusive scan inside the tile; the tile's bytes / rows / largest wave go to
@@ -823,7 +831,7 @@ __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W,
         int64_t rlo, rhi;
         const int64_t nwaves = (ncols + 63) >> 6;
         wave_range_indexed(R, wfirst + (int64_t)f * (nwaves + 1), wave, wave + 1, p0, rlo, rhi);
-        tile_file_head(st, lane, exists ? colinfo[(int64_t)f * ncols + c0 + lane] : make_uint2(0u, 0u), dump);
+        tile_file_head(st, lane, exists ? colinfo[(int64_t)f * ncols + c0 + lane] : make_uint2(0u, 0u), dump, P.mq_col != 0);
         const auto g_info = GPTR(uint32_t, R.info); const auto g_pos = GPTR(int32_t, R.pos); const auto g_end = GPTR(int32_t, R.end);
         const auto g_b8 = GPTR(uint32_t, R.base_off8);
         for (int64_t b0 = rlo; b0 < rhi; b0 += 64) {
@@ -845,8 +853,8 @@ __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W,
                 const unsigned long long sm = __ballot(slot_simple && (lane & 3) == 0);      // bit 4 s: slot s is a one-op read
                 wave_lds_sync();
                 for (int s = 0; s < ns;) {
-                    if (s + 4 <= ns && ((sm >> (4 * s)) & 0x1111ull) == 0x1111ull) { tile_phase2_rows4(T, s, st.col, st.cur_s, st.cur_q); s += 4; continue; }
-                    if ((sm >> (4 * s)) & 1ull) tile_phase2_row(T, s, st.col, st.cur_s, st.cur_q);
+                    if (s + 4 <= ns && ((sm >> (4 * s)) & 0x1111ull) == 0x1111ull) { tile_phase2_rows4(T, s, st.col, st.cur_s, st.cur_q, st.mq_d); s += 4; continue; }
+                    if ((sm >> (4 * s)) & 1ull) tile_phase2_row(T, s, st.col, st.cur_s, st.cur_q, st.mq_d);
                     else tile_phase2_mixed(T, s, st, R, W, P, b0, p, p0);     // (the read is the same for every lane)
                     ++s;
                 }
@@ -877,6 +885,7 @@ static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
     d.no_ins = p.no_ins; d.no_del = p.no_del; d.no_ends = p.no_ends; d.tlen = tlen;
     d.n_tags = p.n_tags > 0 ? p.n_tags : 0; d.tag_sep = p.tag_sep ? p.tag_sep : ',';
     d.mods = (p.flag & STA_MPLP_OUTPUT_MODS) ? 1 : 0; d.no_ins_mods = (p.no_ins_mods || p.no_ins) ? 1 : 0;
+    d.mq_col = (sta_mplp_has_fast_path(p) && (p.flag & STA_MPLP_PRINT_MAPQ_CHAR)) ? 1 : 0;
     return d;
 }
 
@@ -954,4 +963,11 @@ int64_t sta_mplp_deep_strips(int64_t ncols) { return (ncols + DEEP_STRIP - 1) / 
 // no --output-extra / -O / -s columns: the window takes the fast kernel pair
 // the tile kernels compare four quality bytes per word against -Q: it has to fit seven bits
 bool sta_mplp_tile_ok(const sta_mplp_params &p) { return p.min_baseQ <= 127; }
-bool sta_mplp_has_fast_path(const sta_mplp_params &p) { return !((uint32_t)p.flag & (EXTRA_MASK | STA_MPLP_OUTPUT_MODS)) && p.n_tags <= 0; }
+// ... or -s alone among them: the mapping-quality column is one byte per entry that passed -Q, the quality string's mirror image, and
+// rides along in the tile kernels (STA_TILE_NO_MQ=1: back to the generic walkers, for A/B runs)
+bool sta_mplp_has_fast_path(const sta_mplp_params &p)
+{
+    static const bool no_mq = getenv("STA_TILE_NO_MQ") != nullptr;
+    const uint32_t extra = (uint32_t)p.flag & (EXTRA_MASK | STA_MPLP_OUTPUT_MODS);
+    return (extra == 0 || (extra == STA_MPLP_PRINT_MAPQ_CHAR && !no_mq)) && p.n_tags <= 0;
+}

@@ -123,6 +123,7 @@ struct MplpDevPar {
     int32_t min_baseQ, all, rev_del, flag, no_ins, no_del, no_ends;
     int32_t n_tags, tag_sep;
     int32_t mods, no_ins_mods;       // --output-mods: append StaReadsDev.mod_* text to modified bases (and to inserted ones unless no_ins_mods)
+    int32_t mq_col;                  // -s on the tile path: a third string per file, the mapping-quality character of every entry that passed -Q (bam_plcmd.c:727-737)
     int64_t tlen;
 };
 #define TAGKIND (1 << 28)       // file_pass "kind" of tag column t is TAGKIND + t

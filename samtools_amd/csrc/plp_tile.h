@@ -250,7 +250,7 @@ PLP_HD int len_scan_4(const LenLds &L, int t)
 
 // per-file result of thread t's four columns: (count after -Q, base string bytes) -> colinfo; adds the file's text bytes to total[]
 // (bytes of "\t cnt \t seq \t qual" as bam_plcmd.c:699-725 prints them), any[] |= the column has entries before -Q
-PLP_HD void len_file_result(const LenLds &L, int t, int depth_before, int ncols_tile, uint2 *colinfo_tile, uint32_t total[4], bool any[4])
+PLP_HD void len_file_result(const LenLds &L, int t, int depth_before, int ncols_tile, uint2 *colinfo_tile, uint32_t total[4], bool any[4], bool mq_col = false)
 {
     int d = depth_before;
 #pragma unroll
@@ -262,6 +262,8 @@ PLP_HD void len_file_result(const LenLds &L, int t, int depth_before, int ncols_
         const uint32_t seq_len = cnt + (uint32_t)L.extra[c];
         any[i] |= d > 0;
         total[i] += 1 + (uint32_t)dec_digits_u32(cnt) + 1 + (seq_len ? seq_len : 1) + 1 + (cnt ? cnt : 1);
+        if (mq_col) total[i] += 1 + (cnt ? cnt : 1);          // -s: "\t" + one mapping-quality character per entry, or '*'
+
         colinfo_tile[c] = make_uint2(cnt, seq_len);
     }
 }
@@ -301,6 +303,7 @@ struct TileLane {
     uint32_t cur;               // where the row's next fixed field goes
     uint32_t cur_s, cur_q;      // cursors of the current file's base string / quality string
     uint32_t cnt, sl;           // the current file's count and base-string bytes (1 for the '*' placeholder)
+    uint32_t mq_d;              // -s: distance from the quality cursor to the mapping-quality string's cursor (count + 1); 0 = no such column
     int col;                    // tile column the lane reads in phase 2 (TILE_ZERO_COL: it has no entries to append)
     bool exists, walk;
 };
@@ -322,7 +325,7 @@ PLP_HD void tile_row_head(TileLds &T, TileLane &st, int lane, const StaWinDev &W
         if (has_ref) rbcode = apos < W.ref_len ? (int)nt16_arith((unsigned char)rc) : 15;
     }
     T.s_ref[lane] = (uint8_t)rbcode;
-    st.cur = cur; st.exists = exists; st.cur_s = st.cur_q = 0; st.cnt = 0; st.sl = 1; st.col = TILE_ZERO_COL; st.walk = false;
+    st.cur = cur; st.exists = exists; st.cur_s = st.cur_q = 0; st.cnt = 0; st.sl = 1; st.col = TILE_ZERO_COL; st.walk = false; st.mq_d = 0;
 }
 // the sixteen zero bytes behind every tile row (lanes 0 .. 2 TILE_SLOTS - 1, once)
 PLP_HD void tile_zero_column(TileLds &T, int lane)
@@ -332,7 +335,7 @@ PLP_HD void tile_zero_column(TileLds &T, int lane)
     __builtin_memcpy(row, z, 16);
 }
 // "\t count \t" of one file and where its two strings start (bam_plcmd.c:699-725)
-PLP_HD void tile_file_head(TileLane &st, int lane, uint2 ci, uint32_t dump)
+PLP_HD void tile_file_head(TileLane &st, int lane, uint2 ci, uint32_t dump, bool mq_col = false)
 {
     st.cnt = ci.x; st.sl = ci.y ? ci.y : 1u;
     if (st.exists) {
@@ -344,14 +347,23 @@ PLP_HD void tile_file_head(TileLane &st, int lane, uint2 ci, uint32_t dump)
     st.cur_s = st.walk ? st.cur : dump;
     st.cur_q = st.walk ? st.cur + st.sl + 1 : dump;
     st.col = st.walk ? lane : TILE_ZERO_COL;
+    // (the mapping-quality string lies behind the quality string and its tab; a lane without entries writes next to the dump byte)
+    st.mq_d = mq_col ? (st.walk ? st.cnt + 1u : 1u) : 0u;
 }
 // separators and the '*' placeholders go in AFTER the walk (its last predicated write may sit on them)
 PLP_HD void tile_file_tail(TileLane &st)
 {
     if (!st.exists) return;
-    if (!st.cnt) { PLP_LDS[st.cur] = '*'; PLP_LDS[st.cur + 1] = '\t'; PLP_LDS[st.cur + 2] = '*'; }
-    else PLP_LDS[st.cur + st.sl] = '\t';
+    const bool mq = st.mq_d != 0;
+    if (!st.cnt) {
+        PLP_LDS[st.cur] = '*'; PLP_LDS[st.cur + 1] = '\t'; PLP_LDS[st.cur + 2] = '*';
+        if (mq) { PLP_LDS[st.cur + 3] = '\t'; PLP_LDS[st.cur + 4] = '*'; }
+    } else {
+        PLP_LDS[st.cur + st.sl] = '\t';
+        if (mq) PLP_LDS[st.cur + st.sl + 1 + st.cnt] = '\t';
+    }
     st.cur += st.sl + 1 + (st.cnt ? st.cnt : 1u);
+    if (mq) st.cur += 1 + (st.cnt ? st.cnt : 1u);
 }
 PLP_HD bool tile_read_is_live(uint32_t info, int pos, int end, int p0, int plast) { return (info & RI_KEEP) && end > p0 && pos <= plast; }
 PLP_HD void tile_set_slot(TileLds &T, int i, int lane, long long ridx, uint32_t info, int pos, int end, uint32_t b8)
@@ -442,7 +454,7 @@ PLP_HD bool tile_phase1(TileLds &T, int lane, int nslots, const StaReadsDev &R, 
 // cur_s / cur_q: the lane's cursors into the wave's text (base string, quality string); a lane that appends nothing still
 // writes at its cursors without advancing them -- the bytes are overwritten by its next real write or by the separators.
 // b, q: the row's tile bytes of the column; mq: the row's '^' character.
-PLP_HD void tile_phase2_apply(uint32_t b, uint32_t q, uint32_t mq, uint32_t &cur_s, uint32_t &cur_q)
+PLP_HD void tile_phase2_apply(uint32_t b, uint32_t q, uint32_t mq, uint32_t &cur_s, uint32_t &cur_q, uint32_t mq_d = 0)
 {
     const uint32_t pass = q != 0 ? 1u : 0u, hd = q >> 7, tl = b >> 7;
     if (PLP_WAVE_ANY(hd)) {
@@ -457,21 +469,22 @@ PLP_HD void tile_phase2_apply(uint32_t b, uint32_t q, uint32_t mq, uint32_t &cur
         cur_s += tl;
     }
     PLP_LDS[cur_q] = (char)(q & 0x7f);
+    if (mq_d) PLP_LDS[cur_q + mq_d] = (char)mq;                // (-s is a window's option: every lane or none)
     cur_q += pass;
 }
-PLP_HD void tile_phase2_row(const TileLds &T, int slot, int col, uint32_t &cur_s, uint32_t &cur_q)
+PLP_HD void tile_phase2_row(const TileLds &T, int slot, int col, uint32_t &cur_s, uint32_t &cur_q, uint32_t mq_d = 0)
 {
-    tile_phase2_apply(T.tb[slot * TILE_STRIDE + col], T.tq[slot * TILE_STRIDE + col], T.s_mq[slot], cur_s, cur_q);
+    tile_phase2_apply(T.tb[slot * TILE_STRIDE + col], T.tq[slot * TILE_STRIDE + col], T.s_mq[slot], cur_s, cur_q, mq_d);
 }
 // four consecutive rows (slot a multiple of four): every tile byte is asked for before the first is used
-PLP_HD void tile_phase2_rows4(const TileLds &T, int slot, int col, uint32_t &cur_s, uint32_t &cur_q)
+PLP_HD void tile_phase2_rows4(const TileLds &T, int slot, int col, uint32_t &cur_s, uint32_t &cur_q, uint32_t mq_d = 0)
 {
     uint32_t b[4], q[4], mq4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { b[i] = T.tb[(slot + i) * TILE_STRIDE + col]; q[i] = T.tq[(slot + i) * TILE_STRIDE + col]; }
     __builtin_memcpy(&mq4, &T.s_mq[slot], 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tile_phase2_apply(b[i], q[i], (mq4 >> (8 * i)) & 0xffu, cur_s, cur_q);
+    for (int i = 0; i < 4; ++i) tile_phase2_apply(b[i], q[i], (mq4 >> (8 * i)) & 0xffu, cur_s, cur_q, mq_d);
 }
 
 // phase 2 for a read with a general CIGAR (indels, clips, pads, skips): per-entry resolution, as k_mplp_emit does it
@@ -492,11 +505,12 @@ PLP_HD void tile_phase2_general(const TileLds &T, int slot, TileLane &st, const 
     Sink<true> ss; ss.g = nullptr; ss.cur = st.cur_s;
     token_write<true>(R, W, P, e, p, ss);
     st.cur_s = ss.cur;
+    if (st.mq_d) PLP_LDS[st.cur_q + st.mq_d] = (char)T.s_mq[slot];
     PLP_LDS[st.cur_q++] = (char)(qc + 33 < 126 ? qc + 33 : 126);
 }
 // a read with a general CIGAR: its plain chunks through the tile row, the remaining columns through token_write (a column is one or the other)
 PLP_HD void tile_phase2_mixed(const TileLds &T, int slot, TileLane &st, const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int64_t b0, int p, int p0)
 {
-    tile_phase2_row(T, slot, st.col, st.cur_s, st.cur_q);
+    tile_phase2_row(T, slot, st.col, st.cur_s, st.cur_q, st.mq_d);
     tile_phase2_general(T, slot, st, R, W, P, b0, p, p0);
 }

@@ -44,7 +44,7 @@ static void reference_rows(const StaReadsDev &R, const StaWinDev &W, const MplpD
     for (int p = pa; p < pb; ++p) {
         const uint64_t a = offs[(size_t)(p - W.col_beg)], b = offs[(size_t)(p - W.col_beg) + 1];
         if (b == a) continue;
-        std::string seq, qual; unsigned cnt = 0;
+        std::string seq, qual, mqs; unsigned cnt = 0;
         std::vector<char> buf(1 << 16);
         for (int64_t r = 0; r < R.n; ++r) {
             if (!(R.info[r] & RI_KEEP) || R.pos[r] > p || R.end[r] <= p) continue;
@@ -56,11 +56,12 @@ static void reference_rows(const StaReadsDev &R, const StaWinDev &W, const MplpD
             token_write<false>(R, W, P, e, p, s);
             seq.append(buf.data(), (size_t)(s.g - buf.data()));
             qual.push_back((char)(c + 33 < 126 ? c + 33 : 126));
+            { const int m = (int)((R.info[r] >> RI_MAPQ_SHIFT) & 0xff) + 33; mqs.push_back((char)(m > 126 ? 126 : m)); }
             ++cnt;
         }
         const int64_t apos = W.origin + p;
         std::string row = std::string(W.tname, (size_t)W.tname_len) + "\t" + std::to_string(apos + 1) + "\t" + ((W.ref && apos < W.ref_len) ? W.ref[apos] : 'N')
-                        + "\t" + std::to_string(cnt) + "\t" + (cnt ? seq : "*") + "\t" + (cnt ? qual : "*") + "\n";
+                        + "\t" + std::to_string(cnt) + "\t" + (cnt ? seq : "*") + "\t" + (cnt ? qual : "*") + (P.mq_col ? std::string("\t") + (cnt ? mqs : "*") : std::string()) + "\n";
         if (row.size() != b - a) { fprintf(stderr, "plp_emul: reference row of column %d has %zu bytes, the measuring pass said %llu\n", p, row.size(), (unsigned long long)(b - a)); exit(3); }
         memcpy(&out[a], row.data(), row.size());
     }
@@ -68,12 +69,13 @@ static void reference_rows(const StaReadsDev &R, const StaWinDev &W, const MplpD
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: plp_emul <dir> [min_baseQ] [tile_cap] [no_ends] [all]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: plp_emul <dir> [min_baseQ] [tile_cap] [no_ends] [all] [mq_col]\n"); return 2; }
     const std::string d = argv[1];
     const int min_baseQ = argc > 2 ? atoi(argv[2]) : 13;
     const uint32_t tile_cap = argc > 3 ? (uint32_t)atoi(argv[3]) : 12288u;
     const int no_ends = argc > 4 ? atoi(argv[4]) : 0;
     const int all = argc > 5 ? atoi(argv[5]) : 0;
+    const int mq_col = argc > 6 ? atoi(argv[6]) : 0;          // -s: the mapping-quality column rides in the tile kernels
     long long n_reads = 0, n_cols = 0; char tname[256] = "";
     { FILE *f = fopen((d + "/meta.txt").c_str(), "r"); if (!f || fscanf(f, "%lld %lld %255s", &n_reads, &n_cols, tname) != 3) { fprintf(stderr, "plp_emul: bad meta.txt\n"); return 2; } fclose(f); }
     auto pos = load<int32_t>(d + "/pos.i32"), end = load<int32_t>(d + "/end.i32"), lq = load<int32_t>(d + "/lq.i32");
@@ -90,7 +92,7 @@ int main(int argc, char **argv)
     W.col_beg = 0; W.col_end = (int32_t)n_cols; W.origin = 0; W.tid = 0; W.tlen = n_cols; W.nfiles = 1; W.files = &R;
     W.ref = (const char *)ref.data(); W.ref_len = (int64_t)ref.size(); W.tname = tname; W.tname_len = (int32_t)strlen(tname);
     MplpDevPar P; memset(&P, 0, sizeof P);
-    P.min_baseQ = min_baseQ; P.no_ends = no_ends; P.all = all; P.tlen = n_cols; P.tag_sep = ',';
+    P.min_baseQ = min_baseQ; P.no_ends = no_ends; P.all = all; P.tlen = n_cols; P.tag_sep = ','; P.mq_col = mq_col;
 
     // wave_range_indexed (kernels_plp.hip): from the first read starting at or beyond p0, back over the (up to 64, else searched)
     // earlier reads whose prefix-maximum end still reaches p0; up to the first read starting at or beyond the next 64-column group
@@ -125,7 +127,7 @@ int main(int argc, char **argv)
         for (int t = 0; t < LEN_THREADS; ++t) len_scan_1(L, t);
         for (int t = 0; t < LEN_THREADS; ++t) len_scan_2(L, t);
         for (int t = 0; t < LEN_THREADS; ++t) len_scan_3(L, t);
-        for (int t = 0; t < LEN_THREADS; ++t) len_file_result(L, t, len_scan_4(L, t), ntile, colinfo.data() + c0, total[t], any[t]);
+        for (int t = 0; t < LEN_THREADS; ++t) len_file_result(L, t, len_scan_4(L, t), ntile, colinfo.data() + c0, total[t], any[t], P.mq_col != 0);
         for (int t = 0; t < LEN_THREADS; ++t)
             for (int i = 0; i < 4; ++i) {
                 const int c = 4 * t + i;
@@ -166,7 +168,7 @@ int main(int argc, char **argv)
         for (int lane = 0; lane < 4; ++lane) tile_refpack(T, lane);
         long long rlo, rhi;
         read_range(p0, plast, rlo, rhi);
-        for (int lane = 0; lane < 64; ++lane) tile_file_head(st[lane], lane, st[lane].exists ? colinfo[(size_t)(c0 + lane)] : make_uint2(0u, 0u), dump);
+        for (int lane = 0; lane < 64; ++lane) tile_file_head(st[lane], lane, st[lane].exists ? colinfo[(size_t)(c0 + lane)] : make_uint2(0u, 0u), dump, P.mq_col != 0);
         for (long long b0 = rlo; b0 < rhi; b0 += 64) {
             std::vector<int> live;
             for (int lane = 0; lane < 64; ++lane) {
@@ -181,11 +183,11 @@ int main(int argc, char **argv)
                 for (int lane = 0; lane < 64; ++lane) if (tile_phase1(T, lane, ns, R, P, p0, W.ref != nullptr) && (lane & 3) == 0) sm |= 1ull << lane;
                 for (int s = 0; s < ns;) {
                     if (s + 4 <= ns && ((sm >> (4 * s)) & 0x1111ull) == 0x1111ull) {
-                        for (int lane = 0; lane < 64; ++lane) tile_phase2_rows4(T, s, st[lane].col, st[lane].cur_s, st[lane].cur_q);
+                        for (int lane = 0; lane < 64; ++lane) tile_phase2_rows4(T, s, st[lane].col, st[lane].cur_s, st[lane].cur_q, st[lane].mq_d);
                         s += 4; continue;
                     }
                     for (int lane = 0; lane < 64; ++lane) {
-                        if ((sm >> (4 * s)) & 1ull) tile_phase2_row(T, s, st[lane].col, st[lane].cur_s, st[lane].cur_q);
+                        if ((sm >> (4 * s)) & 1ull) tile_phase2_row(T, s, st[lane].col, st[lane].cur_s, st[lane].cur_q, st[lane].mq_d);
                         else tile_phase2_mixed(T, s, st[lane], R, W, P, b0, p0 + lane, p0);
                     }
                     ++s;

@@ -111,7 +111,9 @@ _BENCH_WL = [("mpileup30", "a"), ("mpileup30_B", "a"), ("mpileup300", "b"), ("mp
              ("mpileup30_EA_pairs", "c"), ("mpileup30_B_pairs", "c"), ("mpileup30_hotspot", "d"), ("mpileup30_B_hotspot", "d"),
              ("mpileup30_indel", "a"), ("depth30", "c"),
              # round 4: three input files (per-file column groups of the tile kernels), the generic walkers (-s -O --output-extra)
-             ("mpileup30_3files", "e"), ("mpileup30_B_3files", "e"), ("mpileup30_B_sOx", "a")]
+             ("mpileup30_3files", "e"), ("mpileup30_B_3files", "e"), ("mpileup30_B_sOx", "a"),
+             # -s on the tile path: tile kernel, read-major kernel (300x), three files
+             ("mpileup30_B_s", "a"), ("mpileup300_B_s", "b"), ("mpileup30_B_s_3files", "e")]
 
 
 @pytest.mark.parametrize("wl", [pytest.param(w, marks=pytest.mark.xdist_group("benchsize_" + g)) for w, g in _BENCH_WL])

@@ -75,11 +75,17 @@ CASES = [
     (9000, 90, 15, 13, 6144, 0, 0),          # rows around the slice size: both routes in one window
     (30000, 1, 16, 13, 12288, 0, 1),         # -a: zero-depth rows between the reads
     (30000, 1, 17, 13, 1024, 0, 0),
+    # -s: the mapping-quality column as a third string of the tile kernels
+    (20000, 30, 18, 13, 12288, 0, 0, 1),
+    (9000, 90, 19, 20, 6144, 0, 0, 1),
+    (30000, 1, 20, 13, 12288, 0, 1, 1),
 ]
 
 
-@pytest.mark.parametrize("n_cols,depth,seed,minq,cap,no_ends,all_", CASES)
-def test_tile_step_functions_reproduce_the_oracle_text(tmp_path, emul, oracle_bin, n_cols, depth, seed, minq, cap, no_ends, all_):
+@pytest.mark.parametrize("case", CASES)
+def test_tile_step_functions_reproduce_the_oracle_text(tmp_path, emul, oracle_bin, case):
+    n_cols, depth, seed, minq, cap, no_ends, all_ = case[:7]
+    mq_col = case[7] if len(case) > 7 else 0
     ref, rd, span, simple = _messy_reads(n_cols, depth, seed)
     d, sam, fa = _dump(tmp_path, ref, rd, span, simple, n_cols)
     args = ["mpileup", "-B", "-Q", str(minq), "-d", "1000000", "-f", fa]
@@ -87,10 +93,12 @@ def test_tile_step_functions_reproduce_the_oracle_text(tmp_path, emul, oracle_bi
         args.append("--no-output-ends")
     if all_:
         args.append("-a")
+    if mq_col:
+        args.append("-s")
     want = subprocess.run([oracle_bin] + args + [sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
     assert want.count(b"\n") > 1000
     for exe in emul:
-        got = subprocess.run([exe, d, str(minq), str(cap), str(no_ends), str(all_)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        got = subprocess.run([exe, d, str(minq), str(cap), str(no_ends), str(all_), str(mq_col)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert got.returncode == 0, got.stderr.decode()[-600:]
         if got.stdout != want:
             g, w = got.stdout.split(b"\n"), want.split(b"\n")

@@ -435,12 +435,21 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    force_dist = world == 1 and bool(os.environ.get("STA_BENCH_FORCE_DIST")) and not a.pmc_child
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        kw = {}
+        if force_dist and "MASTER_ADDR" not in os.environ:
+            # test hook for the 1-GPU box: a process group of ONE rank, so that the RCCL branch of everything below (communicator set-up,
+            # the size all-gather, reductions and barriers on device tensors) executes on real hardware; only the send / receive pair of
+            # the text gather needs a second GPU
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            kw = {"init_method": "tcp://127.0.0.1:%d" % port, "world_size": 1, "rank": 0}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
     ctx = {"np": np, "torch": torch, "sa": sa, "dist": dist, "rank": rank, "world": world, "local": local, "dev": dev, "backend": backend}
     primary = a.workload or "mpileup30"
     res = run_workload(a, primary, ctx)
@@ -449,7 +458,7 @@ def main():
         second = run_workload(a, "mpileup300", ctx, secondary=True)
         if rank == 0 and res is not None and second is not None:
             res["mpileup300"] = {k: second[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype",
-                                                         "config", "gather", "per_rank", "kernels_ms_per_step", "output_sha256", "verify") if k in second}
+                                                         "config", "gather", "per_rank", "distributed", "kernels_ms_per_step", "output_sha256", "verify") if k in second}
     if rank == 0 and res is not None:
         print(json.dumps(res))
         bad = [r for r in (res, res.get("mpileup300") or {}) if (r.get("parity_check") and not r["parity_check"]["identical"]) or (r.get("verify") and not r["verify"]["identical"])]
@@ -624,7 +633,10 @@ def run_workload(a, wlname, ctx, secondary=False):
         gather_ms = float(gt[0].item()) * 1e3
         # where every rank's time went (ms per step): its kernels by HIP events, host time waiting for gathers, time until its
         # own work was done, and the barrier slack up to the slowest rank
-        mine = {"rank": rank, "kernels_ms": sum(v[1] for v in prof.values()) / a.steps, "gather_wait_ms": t_wait[0] / a.steps * 1e3,
+        dp = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": local, "device_name": dp.name,
+                "device_uuid": str(getattr(dp, "uuid", "")), "pci_bus_id": getattr(dp, "pci_bus_id", None), "pid": os.getpid(),
+                "kernels_ms": sum(v[1] for v in prof.values()) / a.steps, "gather_wait_ms": t_wait[0] / a.steps * 1e3,
                 "issue_ms": t_issue / a.steps * 1e3, "own_ms": t_own / a.steps * 1e3, "barrier_slack_ms": (dt - t_own) / a.steps * 1e3,
                 "out_bytes": out_bytes, "piled_bases": piled}
         per_rank = [None] * world
@@ -688,7 +700,9 @@ def run_workload(a, wlname, ctx, secondary=False):
                 ops = BAQ_FP64_OPS_PER_BASE[name] * units
                 tops = ops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
                 r["fp64"] = {"ops_per_unit": BAQ_FP64_OPS_PER_BASE[name], "achieved": tops, "peak": FP64_PEAK_TOPS, "unit": "Tflop/s (no FMA)",
-                             "frac": tops / FP64_PEAK_TOPS}
+                             "frac": tops / FP64_PEAK_TOPS,
+                             "counts": "the reference's fp64 operations only (probaln_glocal: 19 + 21 per band cell x 15 cells); the rows the kernel "
+                                       "re-evaluates instead of storing, selects, integer and address work are excluded -- useful work, not pipe utilisation"}
                 # the forward-row scratch stream the kernel pair moves through HBM: implementation traffic, reported as DRAM utilisation
                 # (the fused class-S kernel writes AND reads it inside one launch: twice the bytes per unit)
                 sb = float(os.environ.get("STA_BAQ_STREAM_BPB", "0")) or (2.0 * eng_baq7s_stream_bpb if name == "baq_s" else eng_baq_stream_bpb)
@@ -727,6 +741,15 @@ def run_workload(a, wlname, ctx, secondary=False):
         res["output_sha256"] = timed_sha
         if per_rank:
             res["per_rank"] = per_rank
+            # what the collective actually ran on: the process group's own answers, not this script's arguments
+            try:
+                nccl_v = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+            except Exception:
+                nccl_v = None
+            res["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": nccl_v,
+                                  "distinct_devices": len({(r.get("device_uuid") or r["device"], r.get("pci_bus_id")) for r in per_rank}),
+                                  "launcher": "bench.py self-launch" if os.environ.get("STA_BENCH_SELF_LAUNCHED") else "external (torch.distributed.run)",
+                                  "one_device_test_hook": bool(os.environ.get("STA_BENCH_ONE_DEVICE"))}
             moved = sum(sizes) - sizes[0]
             res["gather"] = {"what": "one 8-byte size all-gather (once) + ONE variable-size gather of the ranks' text per step "
                                      "(dist.batch_isend_irecv = ncclGroupStart / ncclSend / ncclRecv on RCCL), overlapped with the next step",

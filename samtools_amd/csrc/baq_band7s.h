@@ -63,13 +63,19 @@ BQS_HD Par make_par(int lq, int l_ref)
 // ---- the things that differ between the device and the CPU harness ----
 #if defined(__HIP_DEVICE_COMPILE__)
 BQS_HD bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
-// MODE: 0 = non-temporal row stream, 1 = plain loads / stores; diagnostics with wrong results: 2 = no row stream at all (the
-// arithmetic and the small per-row inputs), 3 = 2 with the small inputs taken from a handful of cache-hot rows; 4, 5, 6: scheduling
-// experiments with right results (4: the backward step's scaling fenced behind its chain; 5: 4 + the pair's phases fenced apart; 6: the
-// forward pass fetches its row words four rows ahead; 7: plain stores + non-temporal loads; 8: non-temporal stores + plain loads)
-template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { if (MODE == 2 || MODE == 3) { d2 v = { 1e-3, 1e-3 }; return v; } return (MODE == 1 || MODE == 8) ? *p : __builtin_nontemporal_load(p); }
-template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { if (MODE == 2 || MODE == 3) return; if (MODE == 1 || MODE == 7) *p = v; else __builtin_nontemporal_store(v, p); }
-template <int MODE> BQS_HD int hot_row(int i) { return MODE == 3 ? 1 + (i & 7) : i; }
+// MODE is a bit field.  Low four bits, the row stream: 0 = non-temporal (default), 1 = plain loads / stores; diagnostics with wrong
+// results: 2 = no row stream at all (the arithmetic and the small per-row inputs), 3 = 2 with the small inputs taken from a handful of
+// cache-hot rows.  (The scheduling experiments that were modes 4 - 8 in round 4 -- fences, deeper row-word prefetch, mixed load / store
+// policies -- measured nothing and are gone: profiles/r04_baq_class_s.md.)  Feature bits, each its own instantiation so that builds can be
+// compared inside one box:
+//   M_LOGTAB  the MAP quality from the threshold table instead of an fp64 log (map_quality below)
+//   M_DMA     the backward pass's stored row arrives by global -> LDS DMA (no destination registers) issued one group ahead, into the LDS
+//             image the group's middle row is parked in afterwards
+//   M_L2PF    instead: one dummy dword load per 128-byte line of the next group's stored row (warms L2 / the memory-side cache, one VGPR)
+constexpr int M_MEM = 15, M_LOGTAB = 16, M_DMA = 32, M_L2PF = 64;
+template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { if ((MODE & M_MEM) >= 2) { d2 v = { 1e-3, 1e-3 }; return v; } return (MODE & M_MEM) == 1 ? *p : __builtin_nontemporal_load(p); }
+template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { if ((MODE & M_MEM) >= 2) return; if ((MODE & M_MEM) == 1) *p = v; else __builtin_nontemporal_store(v, p); }
+template <int MODE> BQS_HD int hot_row(int i) { return (MODE & M_MEM) == 3 ? 1 + (i & 7) : i; }
 BQS_HD double fmax_(double a, double b) { return __builtin_fmax(a, b); }
 BQS_HD double fmin_(double a, double b) { return __builtin_fmin(a, b); }
 BQS_HD void sched_fence() { __builtin_amdgcn_sched_barrier(0); }       // nothing is scheduled across this point
@@ -88,6 +94,7 @@ BQS_HD double blend_bit(uint64_t w, int pos, double a, double b, double dep)
 }
 #else
 BQS_HD bool wave_any(bool c) { return c; }
+constexpr int M_MEM = 15, M_LOGTAB = 16, M_DMA = 32, M_L2PF = 64;
 template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { return *p; }
 template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { *p = v; }
 template <int MODE> BQS_HD int hot_row(int i) { return i; }
@@ -100,9 +107,10 @@ BQS_HD double blend_bit(uint64_t w, int pos, double a, double b, double) { retur
 BQS_HD uint64_t d_bits(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
 BQS_HD double bits_d(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
 
-// element (row, lane) of a [row][lane] array of a slot: the slot pointers are wave-uniform, the index is 32 bits (one VGPR instead of a
-// 64-bit address per array)
-template <int LS> BQS_HD uint32_t at(int row, int ln) { return (uint32_t)row * (uint32_t)LS + (uint32_t)ln; }
+// element (row, lane) of a [row][lane] array of a slot: wave-uniform slot pointer + a 32-bit BYTE offset (a slot is < 1 MiB), so that an access
+// is `global_load/store v_off, s[base:base+1]` with one VGPR -- written as an element index the compiler forms a 64-bit address per access
+// (v_add + v_mov + v_lshl_add_u64, and for a row of cells fifteen loop-invariant index registers: seen in the round-4 assembly).
+template <int LS, class T> BQS_HD T *at(T *base, int row, int ln) { return (T *)((char *)base + (uint32_t)(((uint32_t)row * (uint32_t)LS + (uint32_t)ln) * (uint32_t)sizeof(T))); }
 
 #define BQS_FLD(w, j) ((int)((uint32_t)((w) >> (3 * (j))) & 7u))
 
@@ -130,7 +138,7 @@ BQS_HD bool pack_lane(int lq, int l_ref, const uint8_t *qual, const uint8_t *seq
         const int fc = rcode(ref, l_ref, r + BW - 1, refc), bc = rcode(ref, l_ref, r - BW - 1, refc);
         amb |= fc == 4 || bc == 4;
         const uint32_t w = q | (uint32_t)qcode(nib) << 8 | (uint32_t)fc << 11 | (uint32_t)bc << 14 | q << 24;
-        IN[at<LS>(r, ln)] = w;
+        *at<LS>(IN, r, ln) = w;
     }
     return amb;
 }
@@ -187,7 +195,7 @@ BQS_HD double fwd_row(const Par &p, const Emis &em, uint64_t rw, double (&M)[NB]
     return sum;
 }
 
-struct FwdState { double M[NB], I[NB], D[NB]; uint64_t rw; uint32_t w_next, w_next2, w_next3, w_next4; };
+struct FwdState { double M[NB], I[NB], D[NB]; uint64_t rw; uint32_t w_next, w_next2; };
 
 // one row i >= 2: inputs, the row, its sum, the raw store of an odd row, the normalisation
 template <int LS, bool EDGE, int MODE>
@@ -195,20 +203,17 @@ BQS_HD void fwd_step(const Par &p, int lq, int i, const uint32_t *IN, d2 *F2, do
 {
     const uint32_t w = f.w_next;
     f.w_next = f.w_next2;
-    if (MODE == 6) {                          // experiment: four rows ahead
-        f.w_next2 = f.w_next3; f.w_next3 = f.w_next4;
-        if (i + 4 <= lq) f.w_next4 = IN[at<LS>(i + 4, ln)];
-    } else if (i + 2 <= lq) f.w_next2 = IN[at<LS>(hot_row<MODE>(i + 2), ln)];
+    if (i + 2 <= lq) f.w_next2 = *at<LS>(IN, hot_row<MODE>(i + 2), ln);
     f.rw = (f.rw >> 3) | ((uint64_t)((w >> 11) & 7u) << (3 * (NB - 1)));
     const Emis em = make_emis(w, f.rw, q2p);
     const double sum = fwd_row<EDGE>(p, em, f.rw, f.M, f.I, f.D);
     if ((i - 1) % 3 == 0) {               // raw (M, I) of one row of three (rows 4, 7, ...); the others are not stored
-        const int t = ((i - 1) / 3) * NB;
+        d2 *row = at<LS>(F2, ((i - 1) / 3) * NB, ln);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(&F2[at<LS>(t + j, ln)], v); }
+        for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(row + j * LS, v); }
     }
     const double inv = 1. / sum;
-    S[at<LS>(i, ln)] = i < lq ? inv : sum;      // rows below the top: 1 / s[i], the value the backward pass multiplies by (no division there)
+    *at<LS>(S, i, ln) = i < lq ? inv : sum;      // rows below the top: 1 / s[i], the value the backward pass multiplies by (no division there)
 #pragma unroll
     for (int j = 0; j < NB; ++j) { f.M[j] *= inv; f.I[j] *= inv; f.D[j] *= inv; }
 }
@@ -223,10 +228,10 @@ BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2
     // band word of row 1: field j = code(j - BW): outside the window below cell BW, code(0..7) above = the lower-end codes of rows 8..15
     f.rw = 0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) f.rw |= (uint64_t)(j < BW ? 7u : ((IN[at<LS>(j + 1, ln)] >> 14) & 7u)) << (3 * j);
-    S[at<LS>(0, ln)] = 1.;
+    for (int j = 0; j < NB; ++j) f.rw |= (uint64_t)(j < BW ? 7u : ((*at<LS>(IN, j + 1, ln) >> 14) & 7u)) << (3 * j);
+    *at<LS>(S, 0, ln) = 1.;
     {   // row 1 (no D state; the only row normalised by a division)
-        const uint32_t w = IN[at<LS>(1, ln)];
+        const uint32_t w = *at<LS>(IN, 1, ln);
         const Emis em = make_emis(w, f.rw, q2p);
         const double eibi = kEI * p.bI;
         double sum = 0.;
@@ -239,14 +244,13 @@ BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2
             f.M[j] = a; f.I[j] = b2; f.D[j] = 0.;
             sum += a + b2;
         }
-        S[at<LS>(1, ln)] = 1. / sum;             // (row 1 itself is normalised by divisions; the backward step to row 1 multiplies by 1 / s[1])
+        *at<LS>(S, 1, ln) = 1. / sum;             // (row 1 itself is normalised by divisions; the backward step to row 1 multiplies by 1 / s[1])
 #pragma unroll
         for (int j = 0; j < NB; ++j) { f.M[j] /= sum; f.I[j] /= sum; }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(&F2[at<LS>(j, ln)], v); }
+        for (int j = 0; j < NB; ++j) { d2 v = { f.M[j], f.I[j] }; st_d2<MODE>(at<LS>(F2, 0, ln) + j * LS, v); }
     }
-    f.w_next = IN[at<LS>(2, ln)]; f.w_next2 = lq >= 3 ? IN[at<LS>(3, ln)] : 0;
-    f.w_next3 = (MODE == 6 && lq >= 4) ? IN[at<LS>(4, ln)] : 0; f.w_next4 = (MODE == 6 && lq >= 5) ? IN[at<LS>(5, ln)] : 0;
+    f.w_next = *at<LS>(IN, 2, ln); f.w_next2 = lq >= 3 ? *at<LS>(IN, 3, ln) : 0;
     const int e1 = (all_edge || BQS_TEST_FORCE_EDGE) ? lq : BW;
     int i = 2;
 #pragma unroll 1
@@ -259,7 +263,7 @@ BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2
         double sum = 0.;
 #pragma unroll
         for (int j = 0; j < NB; ++j) sum += f.M[j] * p.sM + f.I[j] * p.sI;
-        S[at<LS>(lq + 1, ln)] = sum;
+        *at<LS>(S, lq + 1, ln) = sum;
     }
 }
 
@@ -286,7 +290,9 @@ struct MapAcc {
 // reference: INT_MIN for v >= 2^31, +inf and NaN (a posterior of exactly 1 gives log(0) = -inf, v = +inf, k = INT_MIN, q = (uint8_t)k = 0).
 // v >= .499 otherwise.  In integer arithmetic, without a condition register (v_cmp + v_cndmask cost 20-50 clocks a piece on this chip):
 // the value is clamped to [0, 2^31] (a NaN goes to 2^31 through fmin), converted as unsigned, 2^31 is the one "bad" pattern.
-BQS_HD int map_quality(double zs, double sum)
+// This is the formula as the reference writes it: the CPU harness checks the table form below against it, the general kernels still use
+// its equivalent.
+BQS_HD int map_quality_formula(double zs, double sum)
 {
     const double mx = zs / sum;
     const double v = -4.343 * log(1. - mx) + .499;
@@ -298,19 +304,72 @@ BQS_HD int map_quality(double zs, double sum)
     return k100 - (int32_t)((uint32_t)(100 - kk) >> 31);         // k for k <= 100, 99 above
 }
 
+// The same value without the logarithm.  With x = 1. - max (the reference's own subtraction), F(x) = (int)(-4.343 * log(x) + .499) is a
+// non-increasing step function of x on (0, 1] with steps at 0 .. 159; only "k >= 101" matters above 100.  LT[k], k = 1 .. 101, is the
+// LARGEST double x with F(x) >= k, found on the host by bisection over the bit patterns with the host's own log() -- the routine the CPU
+// reference calls -- so F(x) >= k  <=>  x <= LT[k]; LT[0] = +inf, LT[102] = -1 (never).  The table is exact, not an approximation: the
+// neighbourhood of every step is walked double by double when the table is built (make_log_thresholds returns false unless F is a clean
+// single step there; tests/test_baq_emul.py re-checks it over 2 x 10^5 doubles either side and against the formula on random posteriors),
+// and away from a step a one-ulp wobble of log() cannot move F.  The device needs ~12 instructions instead of the ~45 of an fp64 log:
+// k_a from a single-precision log2 (v_log_f32; off by at most one step), then k = k_a - 1 + [x <= LT[k_a]] + [x <= LT[k_a + 1]].
+// x == 0 (a posterior that rounds to 1) is the reference's INT_MIN case: 0.  A NaN x fails both tests and is 0 as well (zs = 0 there).
+constexpr int LT_N = 104;                                        // LT[0 .. 102] used; padded to an even count of 16-byte pairs
+struct LogTab { double t[LT_N]; };
+inline int log_step_host(double x) { const double v = -4.343 * log(x) + .499; return v >= 2147483648.0 ? 2147483647 : (int)v; }   // (host; x > 0)
+inline bool make_log_thresholds(LogTab &T, int walk = 4096)
+{
+    T.t[0] = __builtin_inf(); for (int k = 102; k < LT_N; ++k) T.t[k] = -1.;
+    bool clean = true;
+    for (int k = 1; k <= 101; ++k) {
+        // bit patterns of positive doubles order like the doubles: lo has F >= k (tiny x), hi has F < k (x = 1: F = 0)
+        uint64_t lo, hi; { double a = 0x1p-60, b = 1.; __builtin_memcpy(&lo, &a, 8); __builtin_memcpy(&hi, &b, 8); }
+        while (hi - lo > 1) { const uint64_t mid = lo + (hi - lo) / 2; double x; __builtin_memcpy(&x, &mid, 8); if (log_step_host(x) >= k) lo = mid; else hi = mid; }
+        __builtin_memcpy(&T.t[k], &lo, 8);
+        for (int d = 1; d <= walk; ++d) {                        // a clean single step: >= k at and below the threshold, < k above it
+            double a, b; const uint64_t ua = lo - (uint64_t)(d - 1), ub = lo + (uint64_t)d; __builtin_memcpy(&a, &ua, 8); __builtin_memcpy(&b, &ub, 8);
+            if (log_step_host(a) < k || log_step_host(b) >= k) clean = false;
+        }
+    }
+    return clean;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+BQS_HD float log2_fast(float x) { return __builtin_amdgcn_logf(x); }            // v_log_f32 (x is 0 or a normal number here)
+#else
+BQS_HD float log2_fast(float x) { return log2f(x); }
+#endif
+template <class Tab>
+BQS_HD int map_quality(double zs, double sum, Tab LT)
+{
+    const double mx = zs / sum;
+    const double x = 1. - mx;
+    const float va = log2_fast((float)x) * (float)(-4.343 * 0.693147180559945309) + .499f;      // ~ -4.343 ln x + .499, within 1e-4
+    int ka = (int)fmaxf(fminf(va, 200.f), 0.f);                  // (x = 0: +inf -> 200; NaN -> 0)
+    ka = ka < 1 ? 1 : (ka > 100 ? 100 : ka);
+    const double t0 = LT[ka], t1 = LT[ka + 1];
+    const int k = ka - 1 + (x <= t0 ? 1 : 0) + (x <= t1 ? 1 : 0);  // 0 .. 101
+    const int k99 = k - 2 * (int)((uint32_t)(100 - k) >> 31);      // 101 -> 99
+    return x > 0. ? k99 : 0;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(3))) double *LtPtr;    // the threshold table lives in LDS on the device
+#else
+typedef const double *LtPtr;
+#endif
 struct BwdCtx {
     int ys, mlen;           // the M operation covers query indices [ys, ys + mlen)
     int run_r;              // running maximum of b from the right inside it
     int plain_mask;         // -1: per-base BAQ (calmd -r without -E): no running maxima; 0: extended BAQ
+    LtPtr LT;               // LogTab::t (M_LOGTAB)
 };
 
 // the result of row i: b (0 unless the MAP state is M on the read's diagonal), kept in the row's word for the final pass, and the
 // working quality lowered to the right-hand limit
-template <int LS>
+template <int LS, int MODE>
 BQS_HD void finish_row(BwdCtx &c, int i, const MapAcc &a, uint32_t w, uint32_t *IN, int ln)
 {
     const int q = i - 1;
-    const int kq = map_quality(a.zs, a.sum);
+    const int kq = (MODE & M_LOGTAB) ? map_quality(a.zs, a.sum, c.LT) : map_quality_formula(a.zs, a.sum);
     // masks instead of conditions: inside the M operation (0 <= q - ys < mlen); the MAP state is M on the diagonal
     const int32_t t = q - c.ys;
     const int32_t m_in = ((t - c.mlen) & ~t) >> 31;
@@ -321,7 +380,7 @@ BQS_HD void finish_row(BwdCtx &c, int i, const MapAcc &a, uint32_t w, uint32_t *
     const int q0 = (int)(w >> 24);
     const int qmin = q0 < lim ? q0 : lim;
     const int q1 = q0 ^ ((q0 ^ qmin) & m_in);
-    IN[at<LS>(i, ln)] = (w & 0x0001ffffu) | ((uint32_t)b << 17) | ((uint32_t)q1 << 24);
+    *at<LS>(IN, i, ln) = (w & 0x0001ffffu) | ((uint32_t)b << 17) | ((uint32_t)q1 << 24);
 }
 
 // b[i] from b[i + 1] (in place), with the emissions of row i + 1 (band word rw1), then the division by s[i]
@@ -341,7 +400,6 @@ BQS_HD void bwd_apply(const Par &p, const Emis &em, uint64_t rw1, int i, double 
         bM[j] = bm; bI[j] = bi_;
         dnext = bd;
     }
-    if (MODE == 4 || MODE == 5) sched_fence();      // experiment: 1 / s[i] (a load of this pair) is first needed here, not a hundred instructions in
 #pragma unroll
     for (int j = 0; j < NB; ++j) { bM[j] *= inv_i; bI[j] *= inv_i; }
     if (EDGE && i <= BW) {                  // cells with k < 1 do not exist in the reference: keep them at zero
@@ -380,18 +438,25 @@ BQS_HD void map_row_lds(MapAcc &a, Ld Ln, const double (&bM)[NB], const double (
 //                        at once, in the order M0, I0, M1, I1, ... of probaln_glocal -- the top row of the group is never held.
 // e1 / rw_1: emissions and band word of row a + 1; e2 / rw_2: of row a + 2; inv_a: 1 / s[a] (1 for row 1, which is stored normalised and has
 // no D state: m2o = m8o = 0); inv1 = 1 / s[a + 1], inv2 = 1 / s[a + 2]; bM / bI: b of the group's top row.
-template <bool EDGE, int ROWS, int J> struct GroupCell {
+// nxt: the RAW (M, I) of cell J of row a, fetched one step ahead -- from the registers Mp / Ip the row was loaded into, or (M_DMA) from
+// the LDS image the DMA wrote, whose cell J - 1 is overwritten with the middle row's cell at this very step (read J + 1, then write J - 1).
+template <bool EDGE, int ROWS, int MODE, int J> struct GroupCell {
     template <int LS, class Ld>
     static BQS_HD void run(const Par &p, const Emis &e1, uint64_t rw_1, const Emis &e2, uint64_t rw_2, int a, int l_ref, double inv_a, double inv1, double inv2,
                            double m2o, double m8o, double (&Mp)[NB], double (&Ip)[NB], Ld Ln, const double (&bM)[NB], const double (&bI)[NB],
-                           double &pm, double &pd, double &q1m, double &q1d, double &cM, double &cD, MapAcc &acc)
+                           double &pm, double &pd, double &q1m, double &q1d, double &cM, double &cD, MapAcc &acc, d2 nxt)
     {
         double i1_prev = 0., M1n = 0., D1n = 0., M1r = 0., D1r = 0.;
         if (J < NB) {
+            const d2 raw = nxt;
+            if (J + 1 < NB) {
+                if (MODE & M_DMA) nxt = Ln[(J + 1 < NB ? J + 1 : 0) * LS];
+                else { nxt.x = Mp[J + 1 < NB ? J + 1 : 0]; nxt.y = Ip[J + 1 < NB ? J + 1 : 0]; }
+            }
             double fd = m2o * pm + m8o * pd;
             if (EDGE) { const int idx = a - BW - 1 + J; fd = (idx < 0 || idx >= l_ref) ? 0. : fd; }
-            pm = Mp[J < NB ? J : 0]; pd = fd;
-            const double Mn = Mp[J < NB ? J : 0] * inv_a, In = Ip[J < NB ? J : 0] * inv_a, Dn = fd * inv_a;
+            pm = raw.x; pd = fd;
+            const double Mn = raw.x * inv_a, In = raw.y * inv_a, Dn = fd * inv_a;
             Mp[J < NB ? J : 0] = Mn; Ip[J < NB ? J : 0] = In;
             if (J > 0) i1_prev = (kEI * (p.m1 * Mn + p.m4 * In)) * inv1;                 // the forward pass's I[a + 1][J - 1]
             const double t3 = p.m0 * Mn + p.m3 * In + p.m6 * Dn;
@@ -420,13 +485,13 @@ template <bool EDGE, int ROWS, int J> struct GroupCell {
             }
         }
         if (J < NB) { q1m = M1r; q1d = D1r; cM = M1n; cD = D1n; }
-        GroupCell<EDGE, ROWS, J + 1>::template run<LS>(p, e1, rw_1, e2, rw_2, a, l_ref, inv_a, inv1, inv2, m2o, m8o, Mp, Ip, Ln, bM, bI, pm, pd, q1m, q1d, cM, cD, acc);
+        GroupCell<EDGE, ROWS, MODE, J + 1>::template run<LS>(p, e1, rw_1, e2, rw_2, a, l_ref, inv_a, inv1, inv2, m2o, m8o, Mp, Ip, Ln, bM, bI, pm, pd, q1m, q1d, cM, cD, acc, nxt);
     }
 };
-template <bool EDGE, int ROWS> struct GroupCell<EDGE, ROWS, NB + 1> {
+template <bool EDGE, int ROWS, int MODE> struct GroupCell<EDGE, ROWS, MODE, NB + 1> {
     template <int LS, class Ld>
     static BQS_HD void run(const Par &, const Emis &, uint64_t, const Emis &, uint64_t, int, int, double, double, double, double, double, double (&)[NB], double (&)[NB], Ld,
-                           const double (&)[NB], const double (&bI)[NB], double &, double &, double &, double &, double &, double &, MapAcc &acc)
+                           const double (&)[NB], const double (&bI)[NB], double &, double &, double &, double &, double &, double &, MapAcc &acc, d2)
     {
         if (ROWS == 3) acc.template add<2 * (NB - 1) + 1>(0. * bI[NB - 1]);      // I[a + 2][NB - 1] = 0: the last term of the row
     }
@@ -438,19 +503,23 @@ BQS_HD uint64_t word_down(uint64_t rw, uint32_t w) { return ((rw << 3) | (uint64
 
 // One group: the stored row a and the ROWS - 1 rows above it.  b.rw is the band word of row a + ROWS (of row lq when that is beyond the read: the
 // group is the topmost and its top row IS row lq), b.w_up the input word of that row.
-template <int LS, bool EDGE, int ROWS, int MODE, class Ld>
-BQS_HD void bwd_group(const Par &p, int lq, int l_ref, int a, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, Ld Ln, BwdCtx &c, BwdState &b)
+// pf(row): asks for the stored row `row` of the NEXT group (M_DMA: global -> LDS DMA into the image Ln points into; M_L2PF: cache-warming
+// loads), called where the LDS image is free: behind the last read of this group's middle row.  a_pf = that row, or 0 for the last group.
+template <int LS, bool EDGE, int ROWS, int MODE, class Ld, class Pf>
+BQS_HD void bwd_group(const Par &p, int lq, int l_ref, int a, int a_pf, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, Ld Ln, Pf pf, BwdCtx &c, BwdState &b)
 {
     const int top = a + ROWS - 1;
     // the small inputs in front of the cell loads: loads come back in order
-    const double s_top = S[at<LS>(hot_row<MODE>(top), ln)], s_a = S[at<LS>(hot_row<MODE>(a), ln)];
-    const double s_mid = ROWS == 3 ? S[at<LS>(hot_row<MODE>(a + 1), ln)] : 0.;
-    const uint32_t w_top = IN[at<LS>(hot_row<MODE>(top), ln)], w_a = IN[at<LS>(hot_row<MODE>(a), ln)];
-    const uint32_t w_mid = ROWS == 3 ? IN[at<LS>(hot_row<MODE>(a + 1), ln)] : 0u;
-    const int t = ((a - 1) / 3) * NB;
+    const double s_top = *at<LS>(S, hot_row<MODE>(top), ln), s_a = *at<LS>(S, hot_row<MODE>(a), ln);
+    const double s_mid = ROWS == 3 ? *at<LS>(S, hot_row<MODE>(a + 1), ln) : 0.;
+    const uint32_t w_top = *at<LS>(IN, hot_row<MODE>(top), ln), w_a = *at<LS>(IN, hot_row<MODE>(a), ln);
+    const uint32_t w_mid = ROWS == 3 ? *at<LS>(IN, hot_row<MODE>(a + 1), ln) : 0u;
     double Mp[NB], Ip[NB];
+    if (!(MODE & M_DMA)) {
+        const d2 *row = at<LS>(F2, ((a - 1) / 3) * NB, ln);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) { const d2 v = ld_d2<MODE>(&F2[at<LS>(t + j, ln)]); Mp[j] = v.x; Ip[j] = v.y; }
+        for (int j = 0; j < NB; ++j) { const d2 v = ld_d2<MODE>(row + j * LS); Mp[j] = v.x; Ip[j] = v.y; }
+    }
     const bool is_top = EDGE && top >= lq;                       // the group's top row is row lq: b is the start vector, nothing to step from
     // S[] holds 1 / s[row] below row lq, s[lq] itself for row lq
     const double inv_top = is_top ? 1. / s_top : s_top;
@@ -469,10 +538,15 @@ BQS_HD void bwd_group(const Par &p, int lq, int l_ref, int a, uint32_t *IN, cons
     MapAcc acc;
     if (ROWS == 1) {
         // the stored row on its own (the topmost group of a read whose length is 1 mod 3): normalise, MAP
+        if (MODE & M_DMA) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { const d2 v = Ln[j * LS]; Mp[j] = v.x; Ip[j] = v.y; }
+        }
+        if ((MODE & (M_DMA | M_L2PF)) && a_pf > 0) pf(a_pf);
 #pragma unroll
         for (int j = 0; j < NB; ++j) { Mp[j] *= inv_top; Ip[j] *= inv_top; }      // (a == top here)
         map_row(acc, Mp, Ip, b.bM, b.bI);
-        finish_row<LS>(c, a, acc, w_a, IN, ln);
+        finish_row<LS, MODE>(c, a, acc, w_a, IN, ln);
         b.rw = rw_top; b.w_up = w_a;
         return;
     }
@@ -481,54 +555,60 @@ BQS_HD void bwd_group(const Par &p, int lq, int l_ref, int a, uint32_t *IN, cons
     const Emis e1 = ROWS == 3 ? make_emis(w_mid, rw_1, q2p) : e2;                 // emissions of row a + 1
     double pm = 0., pd = 0., q1m = 0., q1d = 0., cM = 0., cD = 0.;
     acc.init();
-    GroupCell<EDGE, ROWS, 0>::template run<LS>(p, e1, rw_1, e2, rw_top, a, l_ref, inv_a, inv_mid, inv_top, row1 ? 0. : p.m2, row1 ? 0. : p.m8, Mp, Ip, Ln,
-                                               b.bM, b.bI, pm, pd, q1m, q1d, cM, cD, acc);
-    finish_row<LS>(c, top, acc, w_top, IN, ln);
+    d2 nxt;
+    if (MODE & M_DMA) nxt = Ln[0]; else { nxt.x = Mp[0]; nxt.y = Ip[0]; }
+    GroupCell<EDGE, ROWS, MODE, 0>::template run<LS>(p, e1, rw_1, e2, rw_top, a, l_ref, inv_a, inv_mid, inv_top, row1 ? 0. : p.m2, row1 ? 0. : p.m8, Mp, Ip, Ln,
+                                                     b.bM, b.bI, pm, pd, q1m, q1d, cM, cD, acc, nxt);
+    if (ROWS == 2 && (MODE & (M_DMA | M_L2PF)) && a_pf > 0) pf(a_pf);            // (two rows: nothing is parked in the image)
+    finish_row<LS, MODE>(c, top, acc, w_top, IN, ln);
     if (ROWS == 3) {
         bwd_apply<EDGE, MODE>(p, e2, rw_top, a + 1, inv_mid, b.bM, b.bI);
         map_row_lds<LS>(acc, Ln, b.bM, b.bI);
-        finish_row<LS>(c, a + 1, acc, w_mid, IN, ln);
+        if ((MODE & (M_DMA | M_L2PF)) && a_pf > 0) pf(a_pf);                      // the image is free from here to the next group's sweep
+        finish_row<LS, MODE>(c, a + 1, acc, w_mid, IN, ln);
     }
     bwd_apply<EDGE, MODE>(p, e1, rw_1, a, inv_a_step, b.bM, b.bI);
     map_row(acc, Mp, Ip, b.bM, b.bI);
-    finish_row<LS>(c, a, acc, w_a, IN, ln);
+    finish_row<LS, MODE>(c, a, acc, w_a, IN, ln);
     b.rw = word_down(rw_1, w_a); b.w_up = w_a;
 }
 
 // all_edge as in fwd_lane.  Otherwise the groups whose rows a - 1 .. a + 3 have all cells inside the window take the interior code: loops, not a
 // branch per group.  Ln: this lane's 15 (M, I) pairs of LDS, stride LS.
-template <int LS, int MODE = 0, class Ld>
-BQS_HD void bwd_lane(const Par &p, int lq, int l_ref, bool all_edge, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, Ld Ln, BwdCtx &c)
+struct NoPf { BQS_HD void operator()(int) const {} };
+template <int LS, int MODE = 0, class Ld, class Pf = NoPf>
+BQS_HD void bwd_lane(const Par &p, int lq, int l_ref, bool all_edge, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, Ld Ln, BwdCtx &c, Pf pf = Pf())
 {
     BwdState b;
+    // the topmost group: the last stored row and the 0, 1 or 2 rows above it
+    int a = 3 * ((lq - 1) / 3) + 1;
+    if (MODE & M_DMA) pf(a);                                     // its stored row: asked for before anything else
     // band word of row lq: field j = code(lq - BW - 1 + j) = the upper-end code of row lq - 2 BW + j
     b.rw = 0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) b.rw |= (uint64_t)((IN[at<LS>(lq - 2 * BW + j, ln)] >> 11) & 7u) << (3 * j);
+    for (int j = 0; j < NB; ++j) b.rw |= (uint64_t)((*at<LS>(IN, lq - 2 * BW + j, ln) >> 11) & 7u) << (3 * j);
     {
-        const double s_top = S[at<LS>(lq, ln)], sl1 = S[at<LS>(lq + 1, ln)];
+        const double s_top = *at<LS>(S, lq, ln), sl1 = *at<LS>(S, lq + 1, ln);
         const double vM = p.sM / s_top / sl1, vI = p.sI / s_top / sl1;
 #pragma unroll
         for (int j = 0; j < NB; ++j) { const bool valid = BQS_FLD(b.rw, j) != 7; b.bM[j] = valid ? vM : 0.; b.bI[j] = valid ? vI : 0.; }
     }
     c.run_r = 0;
-    b.w_up = IN[at<LS>(lq, ln)];
-    // the topmost group: the last stored row and the 0, 1 or 2 rows above it
-    int a = 3 * ((lq - 1) / 3) + 1;
+    b.w_up = *at<LS>(IN, lq, ln);
     const int above = lq - a;
-    if (above == 0) bwd_group<LS, true, 1, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
-    else if (above == 1) bwd_group<LS, true, 2, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
-    else bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
+    if (above == 0) bwd_group<LS, true, 1, MODE>(p, lq, l_ref, a, a - 3, IN, F2, S, ln, q2p, Ln, pf, c, b);
+    else if (above == 1) bwd_group<LS, true, 2, MODE>(p, lq, l_ref, a, a - 3, IN, F2, S, ln, q2p, Ln, pf, c, b);
+    else bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, a - 3, IN, F2, S, ln, q2p, Ln, pf, c, b);
     a -= 3;
     const bool ae = all_edge || BQS_TEST_FORCE_EDGE;
     // interior groups: rows a .. a + 3 are all between row BW + 1 and row lq - 1 (row a + 3 lends its emissions to the first backward step)
     const int hi = ae ? 0 : lq - 4, lo = ae ? 1 : BW + 3;          // interior groups: lo <= a <= hi
 #pragma unroll 1
-    for (; a >= 1 && a > hi; a -= 3) bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
+    for (; a >= 1 && a > hi; a -= 3) bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, a - 3, IN, F2, S, ln, q2p, Ln, pf, c, b);
 #pragma unroll 1
-    for (; a >= lo && !ae; a -= 3) bwd_group<LS, false, 3, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
+    for (; a >= lo && !ae; a -= 3) bwd_group<LS, false, 3, MODE>(p, lq, l_ref, a, a - 3, IN, F2, S, ln, q2p, Ln, pf, c, b);
 #pragma unroll 1
-    for (; a >= 1; a -= 3) bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
+    for (; a >= 1; a -= 3) bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, a - 3, IN, F2, S, ln, q2p, Ln, pf, c, b);
 }
 
 // the left-hand running maximum (realn.c's extended BAQ: bq = min(left, right) inside the M operation) and the qualities' way home
@@ -537,7 +617,7 @@ BQS_HD void final_lane(int lq, const uint32_t *IN, int ln, const BwdCtx &c, uint
 {
     int run = 0;
     for (int q = c.ys; q < c.ys + c.mlen; ++q) {
-        const uint32_t w = IN[at<LS>(q + 1, ln)];
+        const uint32_t w = *at<LS>(IN, q + 1, ln);
         const int b = (int)((w >> 17) & 127u);
         run = b > run ? b : run;
         const int q1 = (int)(w >> 24);

@@ -6,6 +6,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <sched.h>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -17,16 +18,48 @@
 
 namespace sta {
 
+// CPUs this process may actually use: the smaller of the hardware threads, the scheduler affinity mask and the cgroup CPU quota (cgroup v2
+// cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  The GPU boxes of the measurements report 256 hardware threads and run the
+// container under `cpu.max = 1600000 100000`: 16 CPUs (profiles/r04_box_cpu_probe.log) -- hardware_concurrency() alone oversubscribes 16x.
+int host_cpus_available()
+{
+    long n = (long)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && c < n) n = c; }
+    auto quota = [&](long q, long period) { if (q > 0 && period > 0) { const long c = (q + period - 1) / period; if (c >= 1 && c < n) n = c; } };
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[32] = { 0 }; long period = 0;
+        if (fscanf(f, "%31s %ld", a, &period) == 2 && strcmp(a, "max") != 0) quota(atol(a), period);
+        fclose(f);
+    } else {
+        long q = -1, period = 0;
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &q) != 1) q = -1; fclose(g); }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = 0; fclose(g); }
+        quota(q, period);
+    }
+    return (int)n;
+}
+
+// processes of this job that share the node's CPUs: STA_NODE_RANKS if set, else the world of STA_SHARD=rank/world (one process per GPU of one
+// node: driver_shard.h, samtools_amd/shard.py), else torchrun's LOCAL_WORLD_SIZE
+int host_node_ranks()
+{
+    if (const char *e = getenv("STA_NODE_RANKS")) { const int v = atoi(e); if (v >= 1) return v; }
+    if (const char *e = getenv("STA_SHARD")) { int r = 0, w = 0; if (sscanf(e, "%d/%d", &r, &w) == 2 && w >= 1) return w; }
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) { const int v = atoi(e); if (v >= 1) return v; }
+    return 1;
+}
+
 int io_default_threads()
 {
     if (const char *e = getenv("STA_IO_THREADS")) { int v = atoi(e); if (v > 0) return v > 64 ? 64 : v; }
-    // half the hardware threads, between 4 and 8, on an ordinary host; a quarter, up to 16, on a many-core GPU node: on the two-socket
-    // 256-thread host of the measurements 16 decode threads are the best setting and 32 or more make the whole pipeline slower (the
-    // slice copies of the staging threads slow down by more than the decode wait shrinks: profiles/r03_e2e_30x_1gbase_threads.log)
-    const unsigned hw = std::thread::hardware_concurrency();
-    if (hw >= 48) { const int q = (int)(hw / 4); return q > 16 ? 16 : q; }
-    const int v = (int)(hw / 2);
-    return v < 4 ? 4 : v > 8 ? 8 : v;
+    // this rank's share of the CPUs it may use, at most 16 decode threads: on the 16-CPU box 16 are the best setting and 32 or more make the
+    // whole pipeline slower (profiles/r04_e2e_threads_16cpu_quota.log; r03_e2e_30x_1gbase_threads.log on the unrestricted 256-thread host);
+    // eight ranks on such a box get two each instead of 8 x 16
+    const int share = host_cpus_available() / host_node_ranks();
+    return share > 16 ? 16 : share < 2 ? 2 : share;
 }
 
 int io_threads_per_input(int n_inputs)

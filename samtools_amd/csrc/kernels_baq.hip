@@ -18,7 +18,7 @@
 #define EI .25
 #define EM .33333333333
 
-struct BaqTables { float q2p[256]; };
+struct BaqTables { float q2p[256]; double lt[104]; };      // g_qual2prob; baq7s::LogTab (the MAP quality's thresholds, baq_band7s.h)
 
 __device__ __forceinline__ int nt16_int_dev(int c)   // seq_nt16_int
 {
@@ -260,14 +260,14 @@ size_t sta_baq_scratch_bytes(int64_t n_reads, int max_lq, int max_bw)
 
 static BaqTables g_tables;
 static bool g_tables_init = false;
+static bool g_logtab_ok = false;
+static void baq_tables_fill();
+static void baq_tables_init() { if (!g_tables_init) { baq_tables_fill(); g_tables_init = true; } }
 
 void sta_launch_baq(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int redo, void *scratch, size_t scratch_bytes,
                          int lq_max, int bw_max, int64_t n_slow)
 {
-    if (!g_tables_init) {
-        for (int i = 0; i < 256; ++i) g_tables.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
-        g_tables_init = true;
-    }
+    baq_tables_init();
     if (r.n == 0 || lq_max <= 0 || n_slow <= 0) return;
     int idim_max = (bw_max * 2 + 1) * 3 + 6;
     size_t dbl_per_read = (size_t)(lq_max + 1) * idim_max + (size_t)2 * idim_max + (size_t)(lq_max + 2);
@@ -914,10 +914,7 @@ static void run_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, vo
 // both passes of the list's band-width-bw reads (ng groups of 64 list entries) in one launch, blocks of one wave
 void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw, int64_t ng)
 {
-    if (!g_tables_init) {
-        for (int i = 0; i < 256; ++i) g_tables.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
-        g_tables_init = true;
-    }
+    baq_tables_init();
     if (r.n == 0 || lq_cap <= 0 || ng <= 0) return;
     const size_t slot = std::max(baq_slot_dbl(lq_cap, 8), baq_slot_dbl(lq_cap, 7));
     const unsigned nb = (unsigned)((ng + 3) / 4);
@@ -937,10 +934,7 @@ void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
 void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw,
                          int64_t g0, int64_t ng, int use_list, int pass)
 {
-    if (!g_tables_init) {
-        for (int i = 0; i < 256; ++i) g_tables.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
-        g_tables_init = true;
-    }
+    baq_tables_init();
     if (r.n == 0 || lq_cap <= 0 || ng <= 0) return;
     if (bw == 7) { if (baq_dec_mode() == 2) run_band<7, 2>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass); else run_band<7, 1>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass); }
     else if (bw == 8) run_band<8, 0>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass);
@@ -953,6 +947,17 @@ void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
 // are in the store-heavy forward phase and half in the issue-heavy backward phase: the forward rows' write stream, their read
 // stream and the fp64 issue overlap inside one launch instead of alternating between two.
 #include "baq_band7s.h"
+
+#ifndef BAQ7S_DEFAULT_MODE
+#define BAQ7S_DEFAULT_MODE 0
+#endif
+static void baq_tables_fill()
+{
+    for (int i = 0; i < 256; ++i) g_tables.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
+    baq7s::LogTab lt;
+    g_logtab_ok = baq7s::make_log_thresholds(lt);     // false: this host's log() is not a clean step function around a threshold -> the formula kernels
+    for (int i = 0; i < baq7s::LT_N; ++i) g_tables.lt[i] = lt.t[i];
+}
 
 __device__ __forceinline__ double baq_uni(double x)       // a wave-uniform double into scalar registers
 {
@@ -992,6 +997,42 @@ __device__ __forceinline__ Baq7sRead baq7s_read(const StaReadsDev &R, const StaW
     return d;
 }
 
+// M_DMA: the next group's stored row, global -> LDS, 15 x 1 KiB (16 bytes per lane; the LDS side is wave-uniform base + 16 x lane, which
+// is the [cell][lane] image of mid_row).  Non-temporal like the register path's loads.  hipcc orders the image's ds_reads behind it (vmcnt).
+struct Baq7sDma {
+    const baq7s::d2 *F2;                                        // the slot's stored rows (wave-uniform)
+    __attribute__((address_space(3))) char *img;                // mid_row (wave-uniform)
+    int lane;
+    __device__ __forceinline__ void operator()(int row) const
+    {
+        const int t = ((row - 1) / 3) * baq7s::NB;
+        const char *src = reinterpret_cast<const char *>(F2 + (size_t)t * 64 + lane);
+        cells<0>(src);
+    }
+    template <int J> __device__ __forceinline__ void cells(const char *src) const
+    {
+        if constexpr (J < baq7s::NB) {
+            // the instruction's immediate offset moves both sides: 4 cells per base pair, then both bases move on
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (J / 4) * 4096),
+                                             (__attribute__((address_space(3))) void *)(img + (J / 4) * 4096), 16, (J % 4) * 1024, 2);
+            cells<J + 1>(src);
+        }
+    }
+};
+// M_L2PF: touch every 128-byte line of the next group's stored row (15 KiB = 120 lines: two loads of one dword per lane); the results are
+// never used, so nothing waits for them.
+struct Baq7sL2pf {
+    const baq7s::d2 *F2; int lane;
+    __device__ __forceinline__ void operator()(int row) const
+    {
+        const int t = ((row - 1) / 3) * baq7s::NB;
+        const char *src = reinterpret_cast<const char *>(F2 + (size_t)t * 64) + lane * 128;
+        uint32_t d0, d1;
+        asm volatile("global_load_dword %0, %1, off nt" : "=v"(d0) : "v"(src));
+        if (lane < 56) asm volatile("global_load_dword %0, %1, off nt" : "=v"(d1) : "v"(src + 8192));
+    }
+};
+
 // two waves per SIMD: the backward pass holds 120 doubles of band state (256 VGPRs; 168 would spill 230 of them)
 template <int MODE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_baq7s(StaReadsDev R, StaWinDev W, BaqTables T, int64_t ngroups, unsigned *next,
@@ -1000,8 +1041,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     __shared__ __attribute__((aligned(16))) baq7s::d2 mid_row[baq7s::NB * 64];   // [cell][lane]: the normalised middle row of the group in work (backward pass)
     __shared__ float q2p[256];
     __shared__ uint8_t refc[256];
+    __shared__ double lt[(MODE & baq7s::M_LOGTAB) ? baq7s::LT_N : 2];
     const int lane = threadIdx.x;
     for (int k = lane; k < 256; k += 64) { q2p[k] = T.q2p[k]; refc[k] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)k)); }
+    if (MODE & baq7s::M_LOGTAB) for (int k = lane; k < baq7s::LT_N; k += 64) lt[k] = T.lt[k];
     __syncthreads();
     // volatile, and in the LDS address space: these stores and loads must BE ds_write_b128 / ds_read_b128 (forwarded through registers
     // they would cost 60 VGPRs; through a generic pointer they become flat accesses)
@@ -1054,7 +1097,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 p.m6 = baq_uni(p.m6); p.m8 = baq_uni(p.m8); p.sM = baq_uni(p.sM); p.sI = baq_uni(p.sI);
                 p.eim1 = baq_uni(p.eim1); p.eim4 = baq_uni(p.eim4);
                 baq7s::BwdCtx c; c.ys = d.sh.ys; c.mlen = d.sh.mlen; c.run_r = 0; c.plain_mask = W.baq_plain != 0 ? -1 : 0;
-                baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, lane, q2p, Ln, c);
+                c.LT = (baq7s::LtPtr)lt;
+                if (MODE & baq7s::M_DMA) {
+                    // (every lane of the wave must take part in a DMA row: the image is [cell][lane] for all 64 lanes; inactive lanes' slots hold
+                    // whatever the slot held -- never read)
+                    const Baq7sDma pf = { sl.F2, (__attribute__((address_space(3))) char *)mid_row, lane };
+                    baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, lane, q2p, Ln, c, pf);
+                } else if (MODE & baq7s::M_L2PF) {
+                    const Baq7sL2pf pf = { sl.F2, lane };
+                    baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, lane, q2p, Ln, c, pf);
+                } else
+                    baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, lane, q2p, Ln, c);
                 baq7s::final_lane<64>(lq, sl.IN, lane, c, d.qual);
             }
         } else if (!have) break;
@@ -1083,19 +1136,29 @@ size_t sta_baq7s_scratch_bytes(int lq_cap, int64_t ngroups, int *waves_out)
 
 void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int waves)
 {
-    if (!g_tables_init) {
-        for (int i = 0; i < 256; ++i) g_tables.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
-        g_tables_init = true;
-    }
+    baq_tables_init();
     const int64_t ngroups = (r.n + 63) / 64;
     if (ngroups <= 0 || waves <= 0) return;
     static const int lead = [] { const char *e = getenv("STA_BAQ7S_LEAD"); return e ? atoi(e) : 1; }();   // 0: every wave forward-then-backward; 1: odd waves one forward pass ahead
     hipMemsetAsync(scratch, 0, 256, s);
     // STA_BAQ7S_MODE: 0 non-temporal row stream (default), 1 plain loads / stores; 2, 3: diagnostics with wrong results (baq_band7s.h)
-    static const int mode = [] { const char *e = getenv("STA_BAQ7S_MODE"); return e ? atoi(e) : 0; }();
+    // (read per launch, not once per process: the parity tests switch builds inside one process)
+    int mode = BAQ7S_DEFAULT_MODE;
+    if (const char *e = getenv("STA_BAQ7S_MODE")) mode = atoi(e);
+    if (!g_logtab_ok) mode &= ~baq7s::M_LOGTAB;
 #define BAQ7S_LAUNCH(M) hipLaunchKernelGGL(k_baq7s<M>, dim3((unsigned)waves), dim3(64), 0, s, r, w, g_tables, ngroups, (unsigned *)scratch, \
                                            (uint8_t *)scratch + 256, baq7s_slot_bytes(lq_cap), lq_cap, lead)
-    if (mode == 1) BAQ7S_LAUNCH(1); else if (mode == 2) BAQ7S_LAUNCH(2); else if (mode == 3) BAQ7S_LAUNCH(3); else if (mode == 4) BAQ7S_LAUNCH(4);
-    else if (mode == 5) BAQ7S_LAUNCH(5); else if (mode == 6) BAQ7S_LAUNCH(6); else if (mode == 7) BAQ7S_LAUNCH(7); else if (mode == 8) BAQ7S_LAUNCH(8); else BAQ7S_LAUNCH(0);
+    switch (mode) {
+    case 0: BAQ7S_LAUNCH(0); break;
+    case 1: BAQ7S_LAUNCH(1); break;
+    case 2: BAQ7S_LAUNCH(2); break;
+    case 3: BAQ7S_LAUNCH(3); break;
+    case 16: BAQ7S_LAUNCH(16); break;          // M_LOGTAB
+    case 32: BAQ7S_LAUNCH(32); break;          // M_DMA
+    case 48: BAQ7S_LAUNCH(48); break;          // M_LOGTAB | M_DMA
+    case 64: BAQ7S_LAUNCH(64); break;          // M_L2PF
+    case 80: BAQ7S_LAUNCH(80); break;          // M_LOGTAB | M_L2PF
+    default: fprintf(stderr, "samtools-amd: STA_BAQ7S_MODE=%d is not built\n", mode); abort();
+    }
 #undef BAQ7S_LAUNCH
 }

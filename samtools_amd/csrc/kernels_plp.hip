@@ -365,14 +365,23 @@ __global__ void __launch_bounds__(256) k_mplp_strip_ranges(StaWinDev W, int64_t 
     rng[2 * i] = rlo; rng[2 * i + 1] = lo;
 }
 
+// XCD-aware block -> tile mapping.  Workgroup b runs on XCD b % 8 (observed; MI355X_MICROARCH.md "Workgroup dispatch"), each XCD has its
+// own 4 MiB L2, and consecutive 64-column groups read the same reads (a 150-bp read spans 3.3 of them): with the identity mapping every
+// group's re-reads miss the L2 of the XCD it lands on.  With xcd_tile(b, n) XCD x owns the contiguous run of tiles [x * per, (x + 1) * per),
+// dispatched in order.  n8 = the launched grid (a multiple of 8) or 0 for the identity mapping (STA_XCD_MAP=0).  Placement is for speed
+// only: nothing relies on it.
+__device__ __forceinline__ int64_t xcd_tile(unsigned b, unsigned n8) { return n8 ? (int64_t)(b & 7u) * (n8 >> 3) + (b >> 3) : (int64_t)b; }
+static bool xcd_map_on() { const char *e = getenv("STA_XCD_MAP"); return !(e && atoi(e) == 0); }      // (per launch: the tests switch it inside one process)
+static unsigned xcd_grid(int64_t nblocks) { return xcd_map_on() ? (unsigned)((nblocks + 7) / 8 * 8) : (unsigned)nblocks; }
+
 __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(4, 8))) k_mplp_emit_deep(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
-                                                        const int64_t *__restrict__ rng, char *out, uint32_t only_above, const uint64_t *__restrict__ tbase)
+                                                        const int64_t *__restrict__ rng, char *out, uint32_t only_above, const uint64_t *__restrict__ tbase, unsigned n8)
 {
     const int lane = threadIdx.x & 63;
     // (readfirstlane: the compiler cannot see that the strip index is the same for the 64 lanes; with it the strip's bounds,
     // row offsets and cursors live in scalar registers and the row stores take a scalar base + 32-bit offset)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t wave = xcd_tile(blockIdx.x, n8) * 4 + wv;
     const int64_t ncols = (int64_t)W.col_end - W.col_beg;
     const int64_t c0 = wave * DEEP_STRIP;
     __shared__ uint32_t s_off[4][64][DEEP_STRIP];
@@ -792,10 +801,10 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const unsigned long long *__
 #define TILE_WAVES 1            // waves per workgroup of k_mplp_emit_tile (they share nothing; measured 1 / 2 / 4 in one box: 0.420 / 0.428 / 0.486 ms)
 
 __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
-                                                                    const uint32_t *__restrict__ wfirst, const uint64_t *__restrict__ tbase, char *out, uint32_t lds_cap)
+                                                                    const uint32_t *__restrict__ wfirst, const uint64_t *__restrict__ tbase, char *out, uint32_t lds_cap, unsigned n8)
 {
     const int wid = threadIdx.x >> 6;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t wave = xcd_tile(blockIdx.x, n8) * TILE_WAVES + wid;
     const int lane = threadIdx.x & 63;
     const int64_t ncols = (int64_t)W.col_end - W.col_beg;
     const int64_t c0 = wave * 64;
@@ -925,7 +934,8 @@ static void launch_deep(hipStream_t s, const StaWinDev &w, const sta_mplp_params
     const int64_t nwaves_d = sta_mplp_deep_strips(ncols);
     const int64_t nt = nwaves_d * w.nfiles;
     hipLaunchKernelGGL(k_mplp_strip_ranges, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, w, strip_rng, nwaves_d);
-    hipLaunchKernelGGL(k_mplp_emit_deep, dim3((unsigned)((nwaves_d + 3) / 4)), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, (const int64_t *)strip_rng, out, only_above, tbase);
+    const unsigned gd = xcd_grid((nwaves_d + 3) / 4);
+    hipLaunchKernelGGL(k_mplp_emit_deep, dim3(gd), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, (const int64_t *)strip_rng, out, only_above, tbase, xcd_map_on() ? gd : 0u);
 }
 
 // tile = true (the measuring pass was k_mplp_len_rm: colinfo, wfirst and tbase are valid): deep_mode 1 = every strip through
@@ -941,7 +951,8 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
         if (strip_rng && deep_mode == 1) { launch_deep(s, w, p, offs, colinfo, out, strip_rng, 0u, tbase); return; }
         const uint32_t slice = (tile_cap + 48 + 15) & ~15u;       // must match k_mplp_emit_tile
         const size_t lds = (size_t)TILE_WAVES * (slice + TILE_LDS_BYTES);
-        hipLaunchKernelGGL(k_mplp_emit_tile, dim3((unsigned)((nwaves + TILE_WAVES - 1) / TILE_WAVES)), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, wfirst, tbase, out, tile_cap);
+        const unsigned gt = xcd_grid((nwaves + TILE_WAVES - 1) / TILE_WAVES);
+        hipLaunchKernelGGL(k_mplp_emit_tile, dim3(gt), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, wfirst, tbase, out, tile_cap, xcd_map_on() ? gt : 0u);
         if (deep_mode == 2 && strip_rng) launch_deep(s, w, p, offs, colinfo, out, strip_rng, tile_cap, tbase);
         return;
     }

@@ -5,8 +5,12 @@
 // harness is linked only by tests/test_baq_emul.py.
 //
 //   clang++ -O1 -std=c++17 -ffp-contract=off -I samtools_amd/csrc tests/cpu/baq_emul.cpp o_baq.o o_io.o -lz -lm -o baq_emul
-//   baq_emul <n_reads> <seed> [force_edge]
-// prints "reads N changed C mismatching_reads X" and exits 1 when X > 0.
+//   baq_emul <n_reads> <seed> [force_edge] [mode]
+// prints "reads N changed C mismatching_reads X" and exits 1 when X > 0.  mode: the kernel's STA_BAQ7S_MODE feature bits (16: the MAP
+// quality from the threshold table; 32: the stored row through the LDS image, as the DMA path reads it; 48: both).
+//   baq_emul logtab <n_random> <seed>
+// checks the threshold table on its own: clean steps over 2 x 10^5 doubles either side of every threshold, table == formula on random
+// posteriors (uniform, near 1, near the thresholds) and on the special values.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,8 +27,64 @@ static bool g_force_edge = false;
 #define BQS_TEST_FORCE_EDGE g_force_edge
 #include "baq_band7s.h"
 
+static int check_logtab(long n_random, unsigned seed)
+{
+    baq7s::LogTab T;
+    if (!baq7s::make_log_thresholds(T, 200000)) { printf("logtab: NOT a clean step function around a threshold\n"); return 1; }
+    std::mt19937_64 rng(seed);
+    long bad = 0, n = 0;
+    auto one = [&](double zs, double sum) {
+        const int a = baq7s::map_quality_formula(zs, sum), b = baq7s::map_quality(zs, sum, (const double *)T.t);
+        ++n;
+        if (a != b) { if (bad < 10) fprintf(stderr, "logtab mismatch zs %.17g sum %.17g formula %d table %d\n", zs, sum, a, b); ++bad; }
+    };
+    // special values: posterior 1 (x = 0), 0, NaN (0 / 0), tiny, the largest posterior below 1
+    one(1., 1.); one(0., 1.); one(0., 0.); one(1e-300, 1.); one(1. - 0x1p-53, 1.); one(0.5, 1.); one(3., 3.); one(1e-310, 1e-310);
+    // every threshold and its neighbours, as x = 1 - mx cannot be set directly: mx = 1 - x is exact for x >= 2^-53 multiples; walk mx
+    for (int k = 1; k <= 101; ++k) {
+        const double x = T.t[k];
+        for (int d = -300; d <= 300; ++d) {
+            double mx = 1. - x;                 // rounds; then walk the neighbouring posteriors
+            uint64_t u; memcpy(&u, &mx, 8); u += (uint64_t)(int64_t)d; memcpy(&mx, &u, 8);
+            if (mx >= 0. && mx <= 1.) one(mx, 1.);
+        }
+    }
+    std::uniform_real_distribution<double> U(0., 1.);
+    for (long i = 0; i < n_random; ++i) {
+        const double sum = ldexp(U(rng) + .5, (int)(rng() % 40) - 20);
+        double mx;
+        switch (i % 4) {
+        case 0: mx = U(rng); break;
+        case 1: mx = 1. - ldexp(U(rng), -(int)(rng() % 54)); break;          // near 1: the whole range of x
+        case 2: { const int k = 1 + (int)(rng() % 101); mx = 1. - T.t[k] * (1. + (U(rng) - .5) * 1e-9); break; }
+        default: mx = ldexp(U(rng), -(int)(rng() % 30)); break;
+        }
+        if (mx < 0.) mx = 0.; if (mx > 1.) mx = 1.;
+        one(mx * sum, sum);
+    }
+    printf("logtab checked %ld mismatches %ld\n", n, bad);
+    return bad ? 1 : 0;
+}
+
+template <int MODE>
+static void run_lanes(const baq7s::Par &par, int lq, int l_ref, bool amb, std::vector<uint32_t> &IN, std::vector<baq7s::d2> &F2, std::vector<double> &S,
+                      const float *q2p, baq7s::BwdCtx &ctx)
+{
+    baq7s::d2 Ln[baq7s::NB];                      // what is LDS on the device: the stored row's image (DMA path), then the normalised middle row
+    baq7s::fwd_lane<1, MODE>(par, lq, amb, IN.data(), F2.data(), S.data(), 0, q2p);
+    struct Pf {                                   // the device's DMA: the stored row -> the image, at the point of the program where the kernel issues it
+        const baq7s::d2 *F2; baq7s::d2 *Ln;
+        void operator()(int row) const { if (MODE & baq7s::M_DMA) { const int t = ((row - 1) / 3) * baq7s::NB; for (int j = 0; j < baq7s::NB; ++j) Ln[j] = F2[t + j]; } }
+    } pf = { F2.data(), &Ln[0] };
+    baq7s::bwd_lane<1, MODE>(par, lq, l_ref, amb, IN.data(), F2.data(), S.data(), 0, q2p, &Ln[0], ctx, pf);
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "logtab")) return check_logtab(argc > 2 ? atol(argv[2]) : 1000000, argc > 3 ? (unsigned)atoi(argv[3]) : 1);
+    const int mode = argc > 4 ? atoi(argv[4]) : 0;
+    baq7s::LogTab logtab;
+    if (!baq7s::make_log_thresholds(logtab)) { fprintf(stderr, "log thresholds: not a clean step function\n"); return 2; }
     const int n_reads = argc > 1 ? atoi(argv[1]) : 2000;
     const unsigned seed = argc > 2 ? (unsigned)atoi(argv[2]) : 1;
     g_force_edge = argc > 3 && atoi(argv[3]) != 0;
@@ -87,15 +147,19 @@ int main(int argc, char **argv)
         const int l_ref = lq + 6;
         std::vector<uint32_t> IN(lq + 2, 0);
         std::vector<baq7s::d2> F2((size_t)((lq + 2) / 3) * baq7s::NB);
-        baq7s::d2 Ln[baq7s::NB];                      // what is LDS on the device: the normalised middle row of the group in work
         std::vector<double> S(lq + 2, 0.);
         std::vector<uint8_t> mq(qual);
         const baq7s::Par par = baq7s::make_par(lq, l_ref);
         const bool amb = baq7s::pack_lane<1>(lq, l_ref, mq.data(), seq.data(), ref.c_str() + sh.xb, refc, IN.data(), 0);
         if (amb) ++n_amb;
-        baq7s::fwd_lane<1>(par, lq, amb, IN.data(), F2.data(), S.data(), 0, q2p);
-        baq7s::BwdCtx ctx; ctx.ys = sh.ys; ctx.mlen = sh.mlen; ctx.run_r = 0; ctx.plain_mask = plain ? -1 : 0;
-        baq7s::bwd_lane<1>(par, lq, l_ref, amb, IN.data(), F2.data(), S.data(), 0, q2p, &Ln[0], ctx);
+        baq7s::BwdCtx ctx; ctx.ys = sh.ys; ctx.mlen = sh.mlen; ctx.run_r = 0; ctx.plain_mask = plain ? -1 : 0; ctx.LT = logtab.t;
+        switch (mode) {
+        case 0: run_lanes<0>(par, lq, l_ref, amb, IN, F2, S, q2p, ctx); break;
+        case 16: run_lanes<16>(par, lq, l_ref, amb, IN, F2, S, q2p, ctx); break;
+        case 32: run_lanes<32>(par, lq, l_ref, amb, IN, F2, S, q2p, ctx); break;
+        case 48: run_lanes<48>(par, lq, l_ref, amb, IN, F2, S, q2p, ctx); break;
+        default: fprintf(stderr, "mode %d is not built into the harness\n", mode); return 2;
+        }
         baq7s::final_lane<1>(lq, IN.data(), 0, ctx, mq.data());
 
         if (memcmp(oq.data(), qual.data(), (size_t)lq) != 0) ++n_changed;

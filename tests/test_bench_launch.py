@@ -98,3 +98,38 @@ def test_plain_gpus_2_over_rccl_when_two_devices_are_visible():
     d = _last_json(p.stdout)
     _check_pair(d, 2)
     assert d["gather"]["backend"] == "nccl"
+
+
+@pytest.mark.gpu
+def test_gpus_8_on_one_device_over_gloo_verifies_both_configs():
+    """The driver's largest form, `python bench.py --gpus 8 --verify`, on the box's one GPU (eight ranks, gloo): ONE sorted input of
+    8 x 65 536 columns cut into eight column blocks, every rank stages its block + halo, the text of mpileup30 AND of the 300x shape
+    of BASELINE.json configs[3] is gathered on rank 0 and hashes to the oracle's for the whole input; the JSON line says what the
+    process group itself reports (world size, backend) and lists eight ranks."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--verify", "--steps", "2", "--warmup", "1", "--cols", "65536"],
+                       env=_env(STA_BENCH_ONE_DEVICE="1", STA_BENCH_BACKEND="gloo"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = _last_json(p.stdout)
+    _check_pair(d, 8)
+    for r in (d, d["mpileup300"]):
+        assert r["distributed"]["world_size"] == 8 and r["distributed"]["backend"] == "gloo"
+        assert sorted(x["rank"] for x in r["per_rank"]) == list(range(8))
+        assert all(x["out_bytes"] > 0 and x["piled_bases"] > 0 for x in r["per_rank"])
+        assert r["distributed"]["one_device_test_hook"] is True and r["distributed"]["distinct_devices"] == 1
+
+
+@pytest.mark.gpu
+def test_the_rccl_branch_executes_with_one_rank():
+    """One GPU cannot hold two RCCL ranks, so the send / receive pair of the text gather needs the driver's multi-GPU node -- but
+    everything else of the `nccl` branch runs here: STA_BENCH_FORCE_DIST=1 makes bench.py build a process group of one rank on RCCL
+    (communicator set-up, the 8-byte size all-gather, max / sum reductions and barriers on device tensors, the object gather) and
+    take the sharded code path with it; the text still hashes to the oracle's."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--verify", "--steps", "2", "--warmup", "1", "--cols", "262144", "--workload", "mpileup30",
+                        "--no-cpu-baseline", "--no-pmc"],
+                       env=_env(STA_BENCH_FORCE_DIST="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = _last_json(p.stdout)
+    assert d["verify"]["identical"], d["verify"]
+    assert d["distributed"]["backend"] == "nccl" and d["distributed"]["world_size"] == 1 and d["distributed"]["rccl_version"]
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["device_name"]
+    assert d["gather"]["backend"] == "nccl"

@@ -107,6 +107,26 @@ def test_two_processes_one_gather(tmp_path, product_bin, pairs, cmd):
     assert open(outp, "rb").read() == want
 
 
+@pytest.mark.parametrize("cmd", [["mpileup", "-f", "{fa}"], ["depth", "-aa"]], ids=["mpileup", "depth"])
+def test_one_process_over_rccl_with_device_capture(tmp_path, product_bin, pairs, cmd):
+    """The RCCL form of the product launcher on the hardware there is: `torch.distributed.run --nproc-per-node 1 -m samtools_amd.shard`
+    with the default backend (nccl = RCCL).  One GPU cannot hold two RCCL ranks, so the gather's send / receive pair is not reached,
+    but the communicator, the exit-status reduction and the size all-gather on device tensors, and the device capture feeding the
+    gather's tensor (sta_main_capture_device -> sta_capture_device_take) all execute; the text is the unsharded text."""
+    sam, fa = pairs
+    args = [a.format(fa=fa) for a in cmd] + [sam]
+    want = _run(product_bin, args)
+    outp = str(tmp_path / "rccl1.txt")
+    env = dict(os.environ, PYTHONPATH=REPO, STA_SHARD_TIMING="1")
+    env.pop("STA_SHARD_BACKEND", None); env.pop("STA_SHARD_HOST_CAPTURE", None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29535" if cmd[0] == "mpileup" else "29536", "-m", "samtools_amd.shard"] + args + ["-o", outp],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=REPO)
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    assert b"(device capture)" in p.stderr, p.stderr.decode()[-400:]
+    assert open(outp, "rb").read() == want
+
+
 def test_four_processes_unequal_blocks_against_the_oracle(tmp_path, oracle_bin, pairs):
     """world size 4 under torch.distributed.run (gloo, all on the box's one GPU), unequal blocks (STA_SHARD_CUTS: one cut inside a
     mate overlap, one a column behind it, one near the end), BAM input with a .bai beside it -- every rank starts from the

@@ -68,11 +68,11 @@ BQS_HD bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
 // cache-hot rows.  (The scheduling experiments that were modes 4 - 8 in round 4 -- fences, deeper row-word prefetch, mixed load / store
 // policies -- measured nothing and are gone: profiles/r04_baq_class_s.md.)  Feature bits, each its own instantiation so that builds can be
 // compared inside one box:
-//   M_LOGTAB  the MAP quality from the threshold table instead of an fp64 log (map_quality below)
-//   M_DMA     the backward pass's stored row arrives by global -> LDS DMA (no destination registers) issued one group ahead, into the LDS
-//             image the group's middle row is parked in afterwards
-//   M_L2PF    instead: one dummy dword load per 128-byte line of the next group's stored row (warms L2 / the memory-side cache, one VGPR)
-constexpr int M_MEM = 15, M_LOGTAB = 16, M_DMA = 32, M_L2PF = 64;
+//   M_LOGTAB  the MAP quality from the threshold table instead of an fp64 log (map_quality below): the default since round 5
+// (Round 5 also built and measured M_DMA = 32 -- the backward pass's stored row by global -> LDS DMA one group ahead, into the LDS image the
+// middle row is parked in afterwards -- and M_L2PF = 64 -- cache-warming loads of the next group's row: +0.4 and +1.0 ms, removed again;
+// commit 43a95ec holds the code, profiles/r05_baq7s_counters.md the numbers and why: the kernel is issue-bound, not wait-bound.)
+constexpr int M_MEM = 15, M_LOGTAB = 16;
 template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { if ((MODE & M_MEM) >= 2) { d2 v = { 1e-3, 1e-3 }; return v; } return (MODE & M_MEM) == 1 ? *p : __builtin_nontemporal_load(p); }
 template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { if ((MODE & M_MEM) >= 2) return; if ((MODE & M_MEM) == 1) *p = v; else __builtin_nontemporal_store(v, p); }
 template <int MODE> BQS_HD int hot_row(int i) { return (MODE & M_MEM) == 3 ? 1 + (i & 7) : i; }
@@ -94,7 +94,7 @@ BQS_HD double blend_bit(uint64_t w, int pos, double a, double b, double dep)
 }
 #else
 BQS_HD bool wave_any(bool c) { return c; }
-constexpr int M_MEM = 15, M_LOGTAB = 16, M_DMA = 32, M_L2PF = 64;
+constexpr int M_MEM = 15, M_LOGTAB = 16;
 template <int MODE> BQS_HD d2 ld_d2(const d2 *p) { return *p; }
 template <int MODE> BQS_HD void st_d2(d2 *p, d2 v) { *p = v; }
 template <int MODE> BQS_HD int hot_row(int i) { return i; }
@@ -126,26 +126,57 @@ template <int LS, class T> BQS_HD T *at(T *base, int row, int ln) { return (T *)
 BQS_HD int rcode(const char *ref, int l_ref, int idx, const uint8_t *refc) { return (idx >= 0 && idx < l_ref) ? (int)refc[(unsigned char)ref[idx]] : 7; }
 BQS_HD int qcode(int nib) { return nib == 1 ? 0 : nib == 2 ? 1 : nib == 4 ? 2 : nib == 8 ? 3 : 4; }
 
-// returns true when the window holds an ambiguous reference base (such a group takes the all-tests code in every row)
+// returns true when the window holds an ambiguous reference base (such a group takes the all-tests code in every row).
+// Eight rows per step: one 8-byte load of qualities, one 4-byte load of bases (both pools are padded to 8 bases per read and the read
+// starts on an 8-byte boundary), the sixteen reference characters asked for together -- one row per step was a chain of dependent
+// byte loads, 150 load latencies per read with nothing else to issue (round 5: the kernel is issue-bound, its latency-bound corners are
+// where the SIMDs idle).
 template <int LS>
 BQS_HD bool pack_lane(int lq, int l_ref, const uint8_t *qual, const uint8_t *seq, const char *ref, const uint8_t *refc, uint32_t *IN, int ln)
 {
     bool amb = false;
-    for (int r = 1; r <= lq; ++r) {
-        const int i0 = r - 1;
-        const uint32_t q = qual[i0];
-        const int nib = (seq[i0 >> 1] >> ((~i0 & 1) << 2)) & 0xf;
-        const int fc = rcode(ref, l_ref, r + BW - 1, refc), bc = rcode(ref, l_ref, r - BW - 1, refc);
-        amb |= fc == 4 || bc == 4;
-        const uint32_t w = q | (uint32_t)qcode(nib) << 8 | (uint32_t)fc << 11 | (uint32_t)bc << 14 | q << 24;
-        *at<LS>(IN, r, ln) = w;
+    for (int r0 = 1; r0 <= lq; r0 += 8) {
+        const int i0 = r0 - 1;                                    // a multiple of 8
+        uint64_t q8; uint32_t s4;
+        __builtin_memcpy(&q8, (const uint8_t *)__builtin_assume_aligned(qual, 8) + i0, 8);
+        __builtin_memcpy(&s4, (const uint8_t *)__builtin_assume_aligned(seq, 4) + (i0 >> 1), 4);
+        unsigned char fch[8], bch[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int fi = r0 + k + BW - 1, bi = r0 + k - BW - 1;
+            fch[k] = (fi >= 0 && fi < l_ref) ? (unsigned char)ref[fi] : 0; bch[k] = (bi >= 0 && bi < l_ref) ? (unsigned char)ref[bi] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = r0 + k;
+            if (r > lq) break;
+            const int fi = r + BW - 1, bi = r - BW - 1;
+            const uint32_t q = (uint32_t)(q8 >> (8 * k)) & 255u;
+            const int nib = (int)(s4 >> (8 * (k >> 1) + ((~k & 1) << 2))) & 0xf;      // byte k / 2 of the word, high nibble first
+            const int fc = (fi >= 0 && fi < l_ref) ? (int)refc[fch[k]] : 7, bc = (bi >= 0 && bi < l_ref) ? (int)refc[bch[k]] : 7;
+            amb |= fc == 4 || bc == 4;
+            const uint32_t w = q | (uint32_t)qcode(nib) << 8 | (uint32_t)fc << 11 | (uint32_t)bc << 14 | q << 24;
+            *at<LS>(IN, r, ln) = w;
+        }
     }
     return amb;
 }
 
 // emission of one band cell.  EDGE rows test everything; interior rows (all 15 cells inside the window, no ambiguous
 // reference base) pick between the row's two values with the match bit of the cell.
+// Interior rows hold only base codes 0..3 in their band word, so their words are kept two bits per field: fifteen fields in ONE 32-bit
+// register (rw_pack2; the three-bit form needs 45 bits, and every shift, xor and mask on it is a 64-bit operation, the multiply that
+// spreads the query code over the fields a full-rate-quarter v_mul_lo_u32).  The loops convert where they change between the two codes.
+#ifndef BQS_TWOBIT
+#define BQS_TWOBIT 1
+#endif
+constexpr bool TWOBIT = BQS_TWOBIT != 0;
+BQS_HD uint64_t rw_pack2(uint64_t rw3) { if (!TWOBIT) return rw3; uint32_t r = 0; for (int j = 0; j < NB; ++j) r |= ((uint32_t)(rw3 >> (3 * j)) & 3u) << (2 * j); return r; }
+BQS_HD uint64_t rw_unpack3(uint64_t rw2) { if (!TWOBIT) return rw2; uint64_t r = 0; for (int j = 0; j < NB; ++j) r |= (uint64_t)(((uint32_t)rw2 >> (2 * j)) & 3u) << (3 * j); return r; }
+constexpr uint32_t ONE2 = 0x15555555u, WORD2_MASK = 0x3fffffffu;
+
 struct Emis { double ematch, e_lo; uint64_t nm; int qyc; };
+template <bool EDGE>
 BQS_HD Emis make_emis(uint32_t w, uint64_t rw, const float *q2p)
 {
     Emis e;
@@ -154,9 +185,17 @@ BQS_HD Emis make_emis(uint32_t w, uint64_t rw, const float *q2p)
     // (query code 4 = anything but A C G T: emission 1 whatever the reference says; bit 10 of the word is that code's bit 2)
     e.ematch = blend_bit(w, 10, 1., 1. - qli, qli); e.e_lo = blend_bit(w, 10, 1., qli * kEM, qli);
     e.qyc = qy + 5 * (qy >> 2);               // 9 for code 4: matches no reference code
-    // bit 3j of nm: field j of the band word equals the query code (fields are <= 3 where this is used)
-    const uint64_t x = rw ^ ((uint64_t)(qy & 3) * ONE_MASK);
-    e.nm = ~(x | (x >> 1) | (x >> 2)) & ONE_MASK;
+    if (EDGE) { e.nm = 0; return e; }         // (the all-tests code compares the fields themselves)
+    if (!TWOBIT) {                            // round 4's form: three-bit fields, bit 3j of nm
+        const uint64_t x3 = rw ^ ((uint64_t)(qy & 3) * ONE_MASK);
+        e.nm = ~(x3 | (x3 >> 1) | (x3 >> 2)) & ONE_MASK;
+        return e;
+    }
+    // bit 2j of nm: field j of the two-bit band word equals the query code.  The code is spread over the fields by two masks (its bits 8 and
+    // 9 of the word sign-extended), not by a multiplication.
+    const uint32_t b0 = (uint32_t)((int32_t)(w << 23) >> 31), b1 = (uint32_t)((int32_t)(w << 22) >> 31);
+    const uint32_t x = (uint32_t)rw ^ ((b0 & ONE2) | (b1 & (ONE2 << 1)));
+    e.nm = (uint64_t)(~(x | (x >> 1)) & ONE2);
     return e;
 }
 template <bool EDGE>
@@ -171,7 +210,13 @@ BQS_HD double emis_cell(const Emis &e, uint64_t rw, int j, double dep)
     // A bit-wise blend by a register mask, not a select on a condition.  Measured on this chip (scripts/ubench/valu_cost.hip,
     // profiles/r04_valu_cost.md): v_cmp + two v_cndmask_b32 on VCC cost ~20 clocks of a saturated SIMD and ~50 of a single wave, v_bfe_i32 +
     // two v_bfi_b32 4.2 each.  (And written as `bit ? ematch : e_lo` the select became a two-entry table in scratch memory.)
-    return blend_bit(e.nm, 3 * j, e.ematch, e.e_lo, dep);
+    return blend_bit(e.nm, (TWOBIT ? 2 : 3) * j, e.ematch, e.e_lo, dep);
+}
+// band word of the next row up (forward pass), given that row's input word: its upper-end code comes in at cell NB - 1
+template <bool EDGE> BQS_HD uint64_t word_up(uint64_t rw, uint32_t w)
+{
+    if (EDGE || !TWOBIT) return (rw >> 3) | ((uint64_t)((w >> 11) & 7u) << (3 * (NB - 1)));
+    return (uint64_t)(((uint32_t)rw >> 2) | (((w >> 11) & 3u) << (2 * (NB - 1))));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -204,8 +249,8 @@ BQS_HD void fwd_step(const Par &p, int lq, int i, const uint32_t *IN, d2 *F2, do
     const uint32_t w = f.w_next;
     f.w_next = f.w_next2;
     if (i + 2 <= lq) f.w_next2 = *at<LS>(IN, hot_row<MODE>(i + 2), ln);
-    f.rw = (f.rw >> 3) | ((uint64_t)((w >> 11) & 7u) << (3 * (NB - 1)));
-    const Emis em = make_emis(w, f.rw, q2p);
+    f.rw = word_up<EDGE>(f.rw, w);
+    const Emis em = make_emis<EDGE>(w, f.rw, q2p);
     const double sum = fwd_row<EDGE>(p, em, f.rw, f.M, f.I, f.D);
     if ((i - 1) % 3 == 0) {               // raw (M, I) of one row of three (rows 4, 7, ...); the others are not stored
         d2 *row = at<LS>(F2, ((i - 1) / 3) * NB, ln);
@@ -232,7 +277,7 @@ BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2
     *at<LS>(S, 0, ln) = 1.;
     {   // row 1 (no D state; the only row normalised by a division)
         const uint32_t w = *at<LS>(IN, 1, ln);
-        const Emis em = make_emis(w, f.rw, q2p);
+        const Emis em = make_emis<true>(w, f.rw, q2p);
         const double eibi = kEI * p.bI;
         double sum = 0.;
 #pragma unroll
@@ -255,8 +300,12 @@ BQS_HD void fwd_lane(const Par &p, int lq, bool all_edge, const uint32_t *IN, d2
     int i = 2;
 #pragma unroll 1
     for (; i <= e1; ++i) fwd_step<LS, true, MODE>(p, lq, i, IN, F2, S, ln, q2p, f);
+    if (i <= lq - 1) {
+        f.rw = rw_pack2(f.rw);            // (row 7's word: its one field outside the window leaves with the first step)
 #pragma unroll 1
-    for (; i <= lq - 1; ++i) fwd_step<LS, false, MODE>(p, lq, i, IN, F2, S, ln, q2p, f);
+        for (; i <= lq - 1; ++i) fwd_step<LS, false, MODE>(p, lq, i, IN, F2, S, ln, q2p, f);
+        f.rw = rw_unpack3(f.rw);
+    }
 #pragma unroll 1
     for (; i <= lq; ++i) fwd_step<LS, true, MODE>(p, lq, i, IN, F2, S, ln, q2p, f);
     {   // s[l_query + 1]
@@ -438,25 +487,18 @@ BQS_HD void map_row_lds(MapAcc &a, Ld Ln, const double (&bM)[NB], const double (
 //                        at once, in the order M0, I0, M1, I1, ... of probaln_glocal -- the top row of the group is never held.
 // e1 / rw_1: emissions and band word of row a + 1; e2 / rw_2: of row a + 2; inv_a: 1 / s[a] (1 for row 1, which is stored normalised and has
 // no D state: m2o = m8o = 0); inv1 = 1 / s[a + 1], inv2 = 1 / s[a + 2]; bM / bI: b of the group's top row.
-// nxt: the RAW (M, I) of cell J of row a, fetched one step ahead -- from the registers Mp / Ip the row was loaded into, or (M_DMA) from
-// the LDS image the DMA wrote, whose cell J - 1 is overwritten with the middle row's cell at this very step (read J + 1, then write J - 1).
-template <bool EDGE, int ROWS, int MODE, int J> struct GroupCell {
+template <bool EDGE, int ROWS, int J> struct GroupCell {
     template <int LS, class Ld>
     static BQS_HD void run(const Par &p, const Emis &e1, uint64_t rw_1, const Emis &e2, uint64_t rw_2, int a, int l_ref, double inv_a, double inv1, double inv2,
                            double m2o, double m8o, double (&Mp)[NB], double (&Ip)[NB], Ld Ln, const double (&bM)[NB], const double (&bI)[NB],
-                           double &pm, double &pd, double &q1m, double &q1d, double &cM, double &cD, MapAcc &acc, d2 nxt)
+                           double &pm, double &pd, double &q1m, double &q1d, double &cM, double &cD, MapAcc &acc)
     {
         double i1_prev = 0., M1n = 0., D1n = 0., M1r = 0., D1r = 0.;
         if (J < NB) {
-            const d2 raw = nxt;
-            if (J + 1 < NB) {
-                if (MODE & M_DMA) nxt = Ln[(J + 1 < NB ? J + 1 : 0) * LS];
-                else { nxt.x = Mp[J + 1 < NB ? J + 1 : 0]; nxt.y = Ip[J + 1 < NB ? J + 1 : 0]; }
-            }
             double fd = m2o * pm + m8o * pd;
             if (EDGE) { const int idx = a - BW - 1 + J; fd = (idx < 0 || idx >= l_ref) ? 0. : fd; }
-            pm = raw.x; pd = fd;
-            const double Mn = raw.x * inv_a, In = raw.y * inv_a, Dn = fd * inv_a;
+            pm = Mp[J < NB ? J : 0]; pd = fd;
+            const double Mn = Mp[J < NB ? J : 0] * inv_a, In = Ip[J < NB ? J : 0] * inv_a, Dn = fd * inv_a;
             Mp[J < NB ? J : 0] = Mn; Ip[J < NB ? J : 0] = In;
             if (J > 0) i1_prev = (kEI * (p.m1 * Mn + p.m4 * In)) * inv1;                 // the forward pass's I[a + 1][J - 1]
             const double t3 = p.m0 * Mn + p.m3 * In + p.m6 * Dn;
@@ -485,13 +527,13 @@ template <bool EDGE, int ROWS, int MODE, int J> struct GroupCell {
             }
         }
         if (J < NB) { q1m = M1r; q1d = D1r; cM = M1n; cD = D1n; }
-        GroupCell<EDGE, ROWS, MODE, J + 1>::template run<LS>(p, e1, rw_1, e2, rw_2, a, l_ref, inv_a, inv1, inv2, m2o, m8o, Mp, Ip, Ln, bM, bI, pm, pd, q1m, q1d, cM, cD, acc, nxt);
+        GroupCell<EDGE, ROWS, J + 1>::template run<LS>(p, e1, rw_1, e2, rw_2, a, l_ref, inv_a, inv1, inv2, m2o, m8o, Mp, Ip, Ln, bM, bI, pm, pd, q1m, q1d, cM, cD, acc);
     }
 };
-template <bool EDGE, int ROWS, int MODE> struct GroupCell<EDGE, ROWS, MODE, NB + 1> {
+template <bool EDGE, int ROWS> struct GroupCell<EDGE, ROWS, NB + 1> {
     template <int LS, class Ld>
     static BQS_HD void run(const Par &, const Emis &, uint64_t, const Emis &, uint64_t, int, int, double, double, double, double, double, double (&)[NB], double (&)[NB], Ld,
-                           const double (&)[NB], const double (&bI)[NB], double &, double &, double &, double &, double &, double &, MapAcc &acc, d2)
+                           const double (&)[NB], const double (&bI)[NB], double &, double &, double &, double &, double &, double &, MapAcc &acc)
     {
         if (ROWS == 3) acc.template add<2 * (NB - 1) + 1>(0. * bI[NB - 1]);      // I[a + 2][NB - 1] = 0: the last term of the row
     }
@@ -499,14 +541,18 @@ template <bool EDGE, int ROWS, int MODE> struct GroupCell<EDGE, ROWS, MODE, NB +
 
 struct BwdState { double bM[NB], bI[NB]; uint64_t rw; uint32_t w_up; };
 
-BQS_HD uint64_t word_down(uint64_t rw, uint32_t w) { return ((rw << 3) | (uint64_t)((w >> 14) & 7u)) & WORD_MASK; }      // band word of the row below, given that row's input word
+// band word of the row below, given that row's input word: its lower-end code comes in at cell 0
+template <bool EDGE> BQS_HD uint64_t word_down(uint64_t rw, uint32_t w)
+{
+    if (EDGE || !TWOBIT) return ((rw << 3) | (uint64_t)((w >> 14) & 7u)) & WORD_MASK;
+    return (uint64_t)((((uint32_t)rw << 2) | ((w >> 14) & 3u)) & WORD2_MASK);
+}
 
 // One group: the stored row a and the ROWS - 1 rows above it.  b.rw is the band word of row a + ROWS (of row lq when that is beyond the read: the
-// group is the topmost and its top row IS row lq), b.w_up the input word of that row.
-// pf(row): asks for the stored row `row` of the NEXT group (M_DMA: global -> LDS DMA into the image Ln points into; M_L2PF: cache-warming
-// loads), called where the LDS image is free: behind the last read of this group's middle row.  a_pf = that row, or 0 for the last group.
-template <int LS, bool EDGE, int ROWS, int MODE, class Ld, class Pf>
-BQS_HD void bwd_group(const Par &p, int lq, int l_ref, int a, int a_pf, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, Ld Ln, Pf pf, BwdCtx &c, BwdState &b)
+// group is the topmost and its top row IS row lq), b.w_up the input word of that row.  In the interior groups (EDGE false) the band words
+// are the two-bit form (rw_pack2).
+template <int LS, bool EDGE, int ROWS, int MODE, class Ld>
+BQS_HD void bwd_group(const Par &p, int lq, int l_ref, int a, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, Ld Ln, BwdCtx &c, BwdState &b)
 {
     const int top = a + ROWS - 1;
     // the small inputs in front of the cell loads: loads come back in order
@@ -515,7 +561,7 @@ BQS_HD void bwd_group(const Par &p, int lq, int l_ref, int a, int a_pf, uint32_t
     const uint32_t w_top = *at<LS>(IN, hot_row<MODE>(top), ln), w_a = *at<LS>(IN, hot_row<MODE>(a), ln);
     const uint32_t w_mid = ROWS == 3 ? *at<LS>(IN, hot_row<MODE>(a + 1), ln) : 0u;
     double Mp[NB], Ip[NB];
-    if (!(MODE & M_DMA)) {
+    {
         const d2 *row = at<LS>(F2, ((a - 1) / 3) * NB, ln);
 #pragma unroll
         for (int j = 0; j < NB; ++j) { const d2 v = ld_d2<MODE>(row + j * LS); Mp[j] = v.x; Ip[j] = v.y; }
@@ -530,19 +576,14 @@ BQS_HD void bwd_group(const Par &p, int lq, int l_ref, int a, int a_pf, uint32_t
     uint64_t rw_top = b.rw;
     if (!is_top) {
         // band word of the top row from the one above it; b[top] from b[top + 1] with the emissions of row top + 1
-        const Emis e_up = make_emis(b.w_up, b.rw, q2p);
+        const Emis e_up = make_emis<EDGE>(b.w_up, b.rw, q2p);
         bwd_apply<EDGE, MODE>(p, e_up, b.rw, top, inv_top, b.bM, b.bI);
         sched_fence();
-        rw_top = word_down(b.rw, w_top);
+        rw_top = word_down<EDGE>(b.rw, w_top);
     }
     MapAcc acc;
     if (ROWS == 1) {
         // the stored row on its own (the topmost group of a read whose length is 1 mod 3): normalise, MAP
-        if (MODE & M_DMA) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j) { const d2 v = Ln[j * LS]; Mp[j] = v.x; Ip[j] = v.y; }
-        }
-        if ((MODE & (M_DMA | M_L2PF)) && a_pf > 0) pf(a_pf);
 #pragma unroll
         for (int j = 0; j < NB; ++j) { Mp[j] *= inv_top; Ip[j] *= inv_top; }      // (a == top here)
         map_row(acc, Mp, Ip, b.bM, b.bI);
@@ -550,39 +591,31 @@ BQS_HD void bwd_group(const Par &p, int lq, int l_ref, int a, int a_pf, uint32_t
         b.rw = rw_top; b.w_up = w_a;
         return;
     }
-    const uint64_t rw_1 = ROWS == 3 ? word_down(rw_top, w_mid) : rw_top;         // band word of row a + 1
-    const Emis e2 = make_emis(w_top, rw_top, q2p);                                // emissions of row a + 2 (ROWS == 3)
-    const Emis e1 = ROWS == 3 ? make_emis(w_mid, rw_1, q2p) : e2;                 // emissions of row a + 1
+    const uint64_t rw_1 = ROWS == 3 ? word_down<EDGE>(rw_top, w_mid) : rw_top;  // band word of row a + 1
+    const Emis e2 = make_emis<EDGE>(w_top, rw_top, q2p);                          // emissions of row a + 2 (ROWS == 3)
+    const Emis e1 = ROWS == 3 ? make_emis<EDGE>(w_mid, rw_1, q2p) : e2;           // emissions of row a + 1
     double pm = 0., pd = 0., q1m = 0., q1d = 0., cM = 0., cD = 0.;
     acc.init();
-    d2 nxt;
-    if (MODE & M_DMA) nxt = Ln[0]; else { nxt.x = Mp[0]; nxt.y = Ip[0]; }
-    GroupCell<EDGE, ROWS, MODE, 0>::template run<LS>(p, e1, rw_1, e2, rw_top, a, l_ref, inv_a, inv_mid, inv_top, row1 ? 0. : p.m2, row1 ? 0. : p.m8, Mp, Ip, Ln,
-                                                     b.bM, b.bI, pm, pd, q1m, q1d, cM, cD, acc, nxt);
-    if (ROWS == 2 && (MODE & (M_DMA | M_L2PF)) && a_pf > 0) pf(a_pf);            // (two rows: nothing is parked in the image)
+    GroupCell<EDGE, ROWS, 0>::template run<LS>(p, e1, rw_1, e2, rw_top, a, l_ref, inv_a, inv_mid, inv_top, row1 ? 0. : p.m2, row1 ? 0. : p.m8, Mp, Ip, Ln,
+                                               b.bM, b.bI, pm, pd, q1m, q1d, cM, cD, acc);
     finish_row<LS, MODE>(c, top, acc, w_top, IN, ln);
     if (ROWS == 3) {
         bwd_apply<EDGE, MODE>(p, e2, rw_top, a + 1, inv_mid, b.bM, b.bI);
         map_row_lds<LS>(acc, Ln, b.bM, b.bI);
-        if ((MODE & (M_DMA | M_L2PF)) && a_pf > 0) pf(a_pf);                      // the image is free from here to the next group's sweep
         finish_row<LS, MODE>(c, a + 1, acc, w_mid, IN, ln);
     }
     bwd_apply<EDGE, MODE>(p, e1, rw_1, a, inv_a_step, b.bM, b.bI);
     map_row(acc, Mp, Ip, b.bM, b.bI);
     finish_row<LS, MODE>(c, a, acc, w_a, IN, ln);
-    b.rw = word_down(rw_1, w_a); b.w_up = w_a;
+    b.rw = word_down<EDGE>(rw_1, w_a); b.w_up = w_a;
 }
 
 // all_edge as in fwd_lane.  Otherwise the groups whose rows a - 1 .. a + 3 have all cells inside the window take the interior code: loops, not a
 // branch per group.  Ln: this lane's 15 (M, I) pairs of LDS, stride LS.
-struct NoPf { BQS_HD void operator()(int) const {} };
-template <int LS, int MODE = 0, class Ld, class Pf = NoPf>
-BQS_HD void bwd_lane(const Par &p, int lq, int l_ref, bool all_edge, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, Ld Ln, BwdCtx &c, Pf pf = Pf())
+template <int LS, int MODE = 0, class Ld>
+BQS_HD void bwd_lane(const Par &p, int lq, int l_ref, bool all_edge, uint32_t *IN, const d2 *F2, const double *S, int ln, const float *q2p, Ld Ln, BwdCtx &c)
 {
     BwdState b;
-    // the topmost group: the last stored row and the 0, 1 or 2 rows above it
-    int a = 3 * ((lq - 1) / 3) + 1;
-    if (MODE & M_DMA) pf(a);                                     // its stored row: asked for before anything else
     // band word of row lq: field j = code(lq - BW - 1 + j) = the upper-end code of row lq - 2 BW + j
     b.rw = 0;
 #pragma unroll
@@ -595,33 +628,54 @@ BQS_HD void bwd_lane(const Par &p, int lq, int l_ref, bool all_edge, uint32_t *I
     }
     c.run_r = 0;
     b.w_up = *at<LS>(IN, lq, ln);
+    // the topmost group: the last stored row and the 0, 1 or 2 rows above it
+    int a = 3 * ((lq - 1) / 3) + 1;
     const int above = lq - a;
-    if (above == 0) bwd_group<LS, true, 1, MODE>(p, lq, l_ref, a, a - 3, IN, F2, S, ln, q2p, Ln, pf, c, b);
-    else if (above == 1) bwd_group<LS, true, 2, MODE>(p, lq, l_ref, a, a - 3, IN, F2, S, ln, q2p, Ln, pf, c, b);
-    else bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, a - 3, IN, F2, S, ln, q2p, Ln, pf, c, b);
+    if (above == 0) bwd_group<LS, true, 1, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
+    else if (above == 1) bwd_group<LS, true, 2, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
+    else bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
     a -= 3;
     const bool ae = all_edge || BQS_TEST_FORCE_EDGE;
     // interior groups: rows a .. a + 3 are all between row BW + 1 and row lq - 1 (row a + 3 lends its emissions to the first backward step)
     const int hi = ae ? 0 : lq - 4, lo = ae ? 1 : BW + 3;          // interior groups: lo <= a <= hi
 #pragma unroll 1
-    for (; a >= 1 && a > hi; a -= 3) bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, a - 3, IN, F2, S, ln, q2p, Ln, pf, c, b);
+    for (; a >= 1 && a > hi; a -= 3) bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
+    if (a >= lo && !ae) {
+        b.rw = rw_pack2(b.rw);                                     // (row a + 3 is an interior row: nothing is lost)
 #pragma unroll 1
-    for (; a >= lo && !ae; a -= 3) bwd_group<LS, false, 3, MODE>(p, lq, l_ref, a, a - 3, IN, F2, S, ln, q2p, Ln, pf, c, b);
+        for (; a >= lo; a -= 3) bwd_group<LS, false, 3, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
+        b.rw = rw_unpack3(b.rw);
+    }
 #pragma unroll 1
-    for (; a >= 1; a -= 3) bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, a - 3, IN, F2, S, ln, q2p, Ln, pf, c, b);
+    for (; a >= 1; a -= 3) bwd_group<LS, true, 3, MODE>(p, lq, l_ref, a, IN, F2, S, ln, q2p, Ln, c, b);
 }
 
-// the left-hand running maximum (realn.c's extended BAQ: bq = min(left, right) inside the M operation) and the qualities' way home
+// the left-hand running maximum (realn.c's extended BAQ: bq = min(left, right) inside the M operation) and the qualities' way home.
+// Eight rows per step: the eight row words are asked for together and the eight bytes leave as one store (the read's qualities start on an
+// 8-byte boundary) -- one row per step was a chain of 150 dependent load latencies.  Outside the M operation a row's word holds the staged
+// byte in its working-quality field and b = 0, so every byte of the read can be written.
 template <int LS>
 BQS_HD void final_lane(int lq, const uint32_t *IN, int ln, const BwdCtx &c, uint8_t *qual)
 {
     int run = 0;
-    for (int q = c.ys; q < c.ys + c.mlen; ++q) {
-        const uint32_t w = *at<LS>(IN, q + 1, ln);
-        const int b = (int)((w >> 17) & 127u);
-        run = b > run ? b : run;
-        const int q1 = (int)(w >> 24);
-        qual[q] = (uint8_t)((!c.plain_mask && q1 > run) ? run : q1);
+    const int m0 = c.ys, m1 = c.ys + c.mlen;
+    for (int q0 = 0; q0 < lq; q0 += 8) {
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = q0 + k < lq ? *at<LS>(IN, q0 + k + 1, ln) : 0u;
+        uint64_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = q0 + k;
+            const bool in_m = q >= m0 && q < m1;
+            const int b = in_m ? (int)((w[k] >> 17) & 127u) : 0;
+            run = b > run ? b : run;
+            const int q1 = (int)(w[k] >> 24);
+            const int v = (in_m && !c.plain_mask && q1 > run) ? run : q1;
+            out |= (uint64_t)(uint32_t)v << (8 * k);
+        }
+        if (q0 + 8 <= lq) __builtin_memcpy((uint8_t *)__builtin_assume_aligned(qual, 8) + q0, &out, 8);
+        else for (int k = 0; q0 + k < lq; ++k) qual[q0 + k] = (uint8_t)(out >> (8 * k));
     }
 }
 

@@ -275,7 +275,10 @@ BZ_HD int read_dynamic(Lds &L, const Consts &C, Bits &b, InWin &W)
     if (hlit > 286 || hdist > 30) return ST_BAD_STREAM;
     for (int i = lane; i < 19; i += BZ_NL) L.lens[i] = 0;
     BZ_LDS_FENCE();
-    for (int i = 0; i < hclen; ++i) { if (b.cnt < 3) refill(b, W); const unsigned v = take(b, 3); if (lane == 0) L.lens[C.order[i]] = (uint8_t)v; }
+    for (int i = 0; i < hclen; ++i) {
+        if (b.cnt < 3) { if (b.next > b.in_len + 8) return ST_INPUT; refill(b, W); }      // (a truncated header must not walk the window beyond the loader's pad)
+        const unsigned v = take(b, 3); if (lane == 0) L.lens[C.order[i]] = (uint8_t)v;
+    }
     BZ_LDS_FENCE();
     {
         // the 19 lengths move out of the way of the 320 they describe
@@ -290,6 +293,9 @@ BZ_HD int read_dynamic(Lds &L, const Consts &C, Bits &b, InWin &W)
     const int total = hlit + hdist;
     int prev = 0;
     while (i < total) {
+        // up to 316 refills in this loop: without the test a crafted or truncated header in the last block of a batch reads ~100 bytes
+        // beyond the 1 KiB zero pad behind the compressed bytes
+        if (b.next > b.in_len + 8) return ST_INPUT;
         refill(b, W);
         const uint32_t e = lookup(b, L.ct, 7);
         if ((e >> 8) & OP_BAD) return ST_BAD_STREAM;

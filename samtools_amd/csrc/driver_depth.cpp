@@ -234,7 +234,8 @@ void usage_exit(FILE *fp)
 extern "C" int sta_main_depth(int argc, char **argv)
 {
     DRunner run;
-    run.devs.start(getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0);      // the runtime comes up while the inputs are opened and decoded
+    run.devs.start(getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0);
+    if (getenv("STA_DRIVER_TIMING")) sta::report_thread_budget();      // the runtime comes up while the inputs are opened and decoded
     sta_depth_params &opt = run.p;
     opt.flag = 4 | 256 | 1024 | 512;
     opt.skip_del = 1;

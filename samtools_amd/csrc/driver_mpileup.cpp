@@ -371,6 +371,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     // and their decode threads fill the first windows (DevEngines, driver_pipeline.h); declared first = destroyed last
     DevEngines devs;
     devs.start(getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0);
+    if (getenv("STA_DRIVER_TIMING")) sta::report_thread_budget();
     Conf conf;
     sta_mplp_params &mp = conf.p;
     mp.min_baseQ = 13; mp.capQ_thres = 0; mp.max_depth = 8000;

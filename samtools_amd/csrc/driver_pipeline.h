@@ -10,7 +10,6 @@
 // producer.  The producer can wait for a job's device stage when the NEXT window depends on its result (the -d cap dropped
 // reads; `-a` still waiting for the contig's first data column) -- everything else runs ahead.
 #pragma once
-#include "host_bgzf.h"
 #include "host_stage.h"
 #include "../../include/samtools_amd.h"
 #include <atomic>
@@ -68,11 +67,6 @@ public:
             fprintf(stderr, "[driver timing] wall %.3f s | producer: fill+stage %.3f s (of it: waiting for the decode threads %.3f s, copying slices %.3f s), "
                             "waiting for a slot %.3f s, waiting for results %.3f s | device thread busy %.3f s (the busiest of %d) | writer busy %.3f s | %llu windows\n",
                     now() - t0_, t_fill_, t_decode_wait_, t_stage_copy_, t_slot_, t_wait_, t_dev_, (int)t_devn_.size(), t_wr_, (unsigned long long)n_jobs_);
-        if (timing_) {
-            const char *sh = getenv("STA_SHARD");
-            fprintf(stderr, "[driver threads] shard %s: %d decode threads per input lane (CPUs this process may use: %d, ranks sharing the node: %d)\n",
-                    sh && *sh ? sh : "0/1", sta::io_default_threads(), sta::host_cpus_available(), sta::host_node_ranks());
-        }
     }
     // a slot the producer may fill (blocks while all are in flight)
     WinJob *acquire()

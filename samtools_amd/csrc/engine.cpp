@@ -91,6 +91,8 @@ struct sta_engine {
     uint64_t out_bytes = 0;
     uint32_t lds_cap = 0;
     uint64_t n_raw_staged = 0;         // reads whose pools were cut out of raw BAM records on the device (sta_stage_stats)
+    bool stage_bad_pending = false;    // the device's verdict on the window's raw records is on its way to stage_bad_h (read behind the next synchronisation)
+    unsigned long long stage_bad_h[2] = { 0, 0 };
     bool len_fused = false;            // the measuring kernel also produced offsets / totals (no scan, no column statistics)
     bool have_wfirst = false;          // the plan built the per-group read index of the tile kernels
     char *pin = nullptr;               // page-locked: [0, PIN_FILES) counters + text bytes read back, [PIN_FILES, PIN_BYTES) the file descriptors pushed
@@ -122,6 +124,22 @@ int hipfail(sta_engine *e, hipError_t r, const char *what)
     return fail(e, STA_ERR_HIP, std::string(what) + ": " + hipGetErrorString(r));
 }
 #define HIPCHK(call) do { hipError_t r_ = (call); if (r_ != hipSuccess) return hipfail(e, r_, #call); } while (0)
+
+// Raw staging (k_bam_pools): the device's verdict on the window's records (offsets the host staged vs what the records say; records
+// inside the uploaded bytes) used to be read back with its own synchronisation in sta_stage_window, which serialised the window
+// producer with the device on the default BAM path.  It now travels behind the staging kernels and is looked at behind the
+// first synchronisation any later call performs: nothing computed from a bad window leaves the engine.
+static int stage_verdict(sta_engine *e)
+{
+    if (!e->stage_bad_pending) return STA_OK;
+    e->stage_bad_pending = false;
+    const unsigned long long *v = e->pin ? (const unsigned long long *)(e->pin + PIN_FILES - 32) : e->stage_bad_h;
+    if (v[0]) return fail(e, STA_ERR_ARG, "raw staging: an alignment record does not match the offsets staged for it (or lies outside the staged bytes)");
+    if (v[1]) return fail(e, STA_ERR_HIP, "raw staging (verify): the device-built pools differ from the host-built ones");
+    return STA_OK;
+}
+#define SYNC_STREAM() do { HIPCHK(hipStreamSynchronize(e->stream)); if (int v_ = stage_verdict(e)) return v_; } while (0)
+#define SYNC_S(st) do { HIPCHK(hipStreamSynchronize(st)); if (int v_ = stage_verdict(e)) return v_; } while (0)
 
 hipEvent_t get_event(sta_engine *e)
 {
@@ -227,7 +245,7 @@ int sta_set_reference(sta_engine *e, int32_t tid, const char *seq, int64_t len, 
     r.external = false;
     if (r.buf.ensure((size_t)len + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(reference) failed");
     if (len) HIPCHK(hipMemcpyAsync(r.buf.p, seq, (size_t)len, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     return STA_OK;
 }
 
@@ -249,6 +267,8 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
     e->tname = w->tname ? w->tname : "";
     if (e->fb.size() < (size_t)w->n_files) e->fb.resize((size_t)w->n_files);
     e->files_h.assign((size_t)w->n_files, StaReadsDev{});
+    bool any_raw = false;
+    if (e->stage_bad_pending) { SYNC_STREAM(); }        // (a window staged and never used: its verdict is not lost)
     for (int f = 0; f < w->n_files; ++f) {
         const sta_reads &r = w->files[f];
         FileBufs &b = e->fb[(size_t)f];
@@ -300,7 +320,7 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
                 o += r.raw_pieces[k].n_bytes;
             }
             HIPCHK(hipMemcpyAsync(b.raw_off.p, r.raw_rec_off, (size_t)n_raw * 4, hipMemcpyHostToDevice, e->stream));
-            HIPCHK(hipMemsetAsync(e->stage_bad.p, 0, 16, e->stream));
+            if (!any_raw) { HIPCHK(hipMemsetAsync(e->stage_bad.p, 0, 16, e->stream)); any_raw = true; }
             unsigned long long *bad = (unsigned long long *)e->stage_bad.p;
             uint32_t *o_cig; uint8_t *o_seq, *o_qual; char *o_names;
             if (r.raw_verify) {
@@ -310,18 +330,13 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
                 o_cig = (uint32_t *)b.raw_vfy.p; o_seq = (uint8_t *)b.raw_vfy.p + cb; o_qual = o_seq + sb; o_names = (char *)(o_qual + qb);
                 cig0 = r.cig_off[r.raw_first]; bases0 = (size_t)r.base_off8[r.raw_first] << 3; names0 = r.name_off[r.raw_first];
             } else { o_cig = (uint32_t *)b.cigar.p; o_seq = (uint8_t *)b.seq.p; o_qual = (uint8_t *)b.qual.p; o_names = (char *)b.names.p; }
-            sta_launch_bam_pools(e->stream, (const uint8_t *)b.raw.p, (const uint32_t *)b.raw_off.p, r.raw_first, n_raw, d, o_cig, o_seq, o_qual, o_names, bad);
+            sta_launch_bam_pools(e->stream, (const uint8_t *)b.raw.p, (const uint32_t *)b.raw_off.p, raw_bytes, r.raw_first, n_raw, d, o_cig, o_seq, o_qual, o_names, bad);
             if (r.raw_verify) {
                 sta_launch_stage_compare(e->stream, (const char *)o_cig + cig0 * 4, (const char *)d.cigar + cig0 * 4, ((size_t)r.n_cigar_total - cig0) * 4, bad + 1);
                 sta_launch_stage_compare(e->stream, o_seq + bases0 / 2, d.seq + bases0 / 2, (size_t)(r.n_bases_total - bases0) / 2, bad + 1);
                 sta_launch_stage_compare(e->stream, o_qual + bases0, d.qual_in + bases0, (size_t)(r.n_bases_total - bases0), bad + 1);
                 sta_launch_stage_compare(e->stream, o_names + names0, d.names + names0, (size_t)r.n_name_bytes - names0, bad + 1);
             }
-            unsigned long long bad_h[2] = { 0, 0 };
-            HIPCHK(hipMemcpyAsync(bad_h, bad, 16, hipMemcpyDeviceToHost, e->stream));
-            HIPCHK(hipStreamSynchronize(e->stream));
-            if (bad_h[0]) return fail(e, STA_ERR_ARG, "raw staging: an alignment record does not match the offsets staged for it");
-            if (bad_h[1]) return fail(e, STA_ERR_HIP, "raw staging (verify): the device-built pools differ from the host-built ones");
             e->n_raw_staged += (uint64_t)n_raw;
         }
         d.n_xcols = r.n_xcols > 0 && r.xcol_off && r.xcol_text ? r.n_xcols : 0;
@@ -344,6 +359,11 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
             return fail(e, STA_ERR_HIP, "hipMalloc(workspace) failed");
         d.end = (int32_t *)b.end.p; d.maxend = (int32_t *)b.maxend.p; d.info = (uint32_t *)b.info.p; d.clip = (int32_t *)b.clip.p; d.chain = (int32_t *)b.chain.p;
         d.qual = const_cast<uint8_t *>(d.qual_in);
+    }
+    if (any_raw) {
+        static_assert(sizeof(StaCounters) + 8 <= PIN_FILES - 32, "the staging verdict's page-locked slot overlaps the counter block");
+        HIPCHK(hipMemcpyAsync(e->pin ? (void *)(e->pin + PIN_FILES - 32) : (void *)e->stage_bad_h, e->stage_bad.p, 16, hipMemcpyDeviceToHost, e->stream));
+        e->stage_bad_pending = true;
     }
     // window constants
     StaWinDev &wd = e->wd;
@@ -408,7 +428,7 @@ static int finish_plan(sta_engine *e, int64_t ncols, sta_plan_info *info)
     HIPCHK(hipMemcpyAsync(ctr_dst, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
     // (after the tile measuring kernel the offsets are tile-relative and k_tile_scan left the window's text bytes in the counter block)
     if (!e->len_fused) HIPCHK(hipMemcpyAsync(total_dst, (const uint64_t *)e->offs.p + (ncols > 0 ? ncols : 0), 8, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     if (e->pin) { e->ctr_h = *ctr_dst; total = *total_dst; }
     if (e->len_fused) total = e->ctr_h.out_bytes;
     hipError_t le = hipGetLastError();
@@ -502,7 +522,7 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
         StaCounters c{};
         StaCounters *c_dst = e->pin ? (StaCounters *)e->pin : &c;
         HIPCHK(hipMemcpyAsync(c_dst, ctr, sizeof(c), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        SYNC_S(s);
         if (e->pin) c = *c_dst;
         if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] n_baq=%llu (fast %llu, lq<=%llu) slow: max_lq=%llu max_bw=%llu kept=%llu\n", c.n_baq, c.n_baq_fast, c.max_lq_fast, c.max_lq, c.max_bw, c.n_kept);
         if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] bw8=%llu general=%llu class_s=%llu (lq<=%llu) bw7_list=%llu\n", c.n_baq_bw8, c.n_baq_general, c.n_baq_s, c.max_lq_s, c.n_baq_bw7l);
@@ -512,7 +532,7 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             int32_t n_list = 0;
             if (c.n_baq > c.n_baq_fast + c.n_baq_s) {
                 HIPCHK(hipMemcpyAsync(&n_list, d.chain, 4, hipMemcpyDeviceToHost, s));
-                HIPCHK(hipStreamSynchronize(s));
+                SYNC_S(s);
             }
             const bool has_main = c.n_baq_fast || c.n_baq_s;
             const bool has_list_band = c.n_baq_bw8 || c.n_baq_bw7l;
@@ -698,7 +718,7 @@ static int counting_pipeline(sta_engine *e, const sta_mplp_params *p)
 {
     int rc = mpileup_pipeline(e, p, false);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     HIPCHK(hipMemcpy(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost));
     if (!e->ctr_h.maxcnt_flag) return STA_OK;
     rc = maxcnt_bounds(e);
@@ -711,7 +731,7 @@ static int fused_finish(sta_engine *e, sta_plan_info *info)
 {
     StaCounters *ctr_dst = e->pin ? (StaCounters *)e->pin : &e->ctr_h;
     HIPCHK(hipMemcpyAsync(ctr_dst, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     if (e->pin) e->ctr_h = *ctr_dst;
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "kernel launch");
@@ -882,14 +902,14 @@ int sta_fetch_col_offsets(sta_engine *e, uint64_t *host_offs, uint64_t n)
         const uint64_t tiles = (ncols + 1023) / 1024;
         std::vector<uint64_t> tb((size_t)tiles + 1);
         HIPCHK(hipMemcpyAsync(tb.data(), sta_mplp_tile_base(e->fused_status.p, ncols), (size_t)(tiles + 1) * 8, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        SYNC_STREAM();
         for (uint64_t c = 0; c < n; ++c) {
             if (c == ncols) host_offs[c] = tb[(size_t)tiles];          // the window's total bytes
             else host_offs[c] += tb[(size_t)(c >> 10)];
         }
         return STA_OK;
     }
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     return STA_OK;
 }
 
@@ -903,7 +923,7 @@ int sta_fetch_read_state(sta_engine *e, int32_t file, uint32_t *host_info, uint8
     // (a working pool left to k_olap_setup was never written when the window had no eligible read: the qualities in use are the input's)
     const bool unused_pool = (size_t)file < e->late_copy.size() && e->late_copy[(size_t)file] && e->ctr_h.n_olap_el == 0;
     if (host_qual && d.n_bases_total) HIPCHK(hipMemcpyAsync(host_qual, unused_pool ? d.qual_in : d.qual, (size_t)d.n_bases_total, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     return STA_OK;
 }
 
@@ -934,7 +954,7 @@ int sta_cov_plan(sta_engine *e, const sta_cov_params *cp, sta_cov_totals *totals
     std::vector<uint64_t> host(5 + nf * 2);
     HIPCHK(hipMemcpyAsync(host.data(), e->cov_out.p, host.size() * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "coverage kernels");
     if (totals) { totals->n_covered_bases = host[0]; totals->summed_coverage = host[1]; totals->summed_baseQ = host[2]; totals->quality_bases = host[3]; totals->missing_qual = host[4]; }
@@ -951,7 +971,7 @@ int sta_cov_hist_begin(sta_engine *e, int32_t n_bins)
     hipSetDevice(e->device);
     if (e->cov_hist.ensure((size_t)n_bins * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
     HIPCHK(hipMemsetAsync(e->cov_hist.p, 0, (size_t)n_bins * 4, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     e->cov_hist_bins = n_bins;
     return STA_OK;
 }
@@ -962,7 +982,7 @@ int sta_cov_hist_fetch(sta_engine *e, uint32_t *hist, int32_t n_bins)
     if (n_bins > e->cov_hist_bins) return fail(e, STA_ERR_ARG, "histogram was opened with fewer bins");
     hipSetDevice(e->device);
     HIPCHK(hipMemcpyAsync(hist, e->cov_hist.p, (size_t)n_bins * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     return STA_OK;
 }
 
@@ -974,7 +994,7 @@ int sta_statcov_begin(sta_engine *e, const sta_statcov_params *p, int32_t *ncov_
     const int32_t ncov = 3 + (p->cov_max - p->cov_min) / p->cov_step;      // stats.c:2404 (the caller has applied :2398-2405 to the triple)
     if (e->sc_cov.ensure((size_t)ncov * 8 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
     HIPCHK(hipMemsetAsync(e->sc_cov.p, 0, (size_t)ncov * 8, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     e->sc = *p; e->sc_ncov = ncov;
     if (ncov_out) *ncov_out = ncov;
     return STA_OK;
@@ -999,7 +1019,7 @@ int sta_statcov_add(sta_engine *e, const int64_t *pos, const int32_t *delta, int
         ProfScope ps(e, "statcov");
         sta_launch_statcov(s, dpos, ddelta, n, (long long)carry_in, e->sc.cov_min, e->sc.cov_max, e->sc.cov_step, e->sc_ncov, (unsigned long long *)e->sc_cov.p, e->sc_tmp.p);
     }
-    HIPCHK(hipStreamSynchronize(s));         // the host buffers may be reused by the caller
+    SYNC_S(s);         // the host buffers may be reused by the caller
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "stats coverage kernels");
     return STA_OK;
@@ -1011,7 +1031,7 @@ int sta_statcov_fetch(sta_engine *e, uint64_t *cov, int32_t ncov)
     if (ncov != e->sc_ncov) return fail(e, STA_ERR_ARG, "bin count differs from the open distribution");
     hipSetDevice(e->device);
     HIPCHK(hipMemcpyAsync(cov, e->sc_cov.p, (size_t)ncov * 8, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     return STA_OK;
 }
 
@@ -1050,7 +1070,7 @@ int sta_glf_plan(sta_engine *e, const sta_glf_params *gp, sta_plan_info *info)
         sta_launch_glf_cols(e->stream, e->wd, gp->min_baseQ, 60, saved_ref, saved_len, t + sta::GLF_FK_OFF, t + sta::GLF_BETA_OFF, t + sta::GLF_LHET_OFF, e->out.p);
     }
     HIPCHK(hipMemcpyAsync(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "glf kernels");
     e->out_bytes = bytes; e->last_out = e->out.p;
@@ -1139,7 +1159,7 @@ static int cons_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *inf
     HIPCHK(hipMemcpyAsync(&n_entries, w.rowoff + n, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&n_cols, w.colbase + W, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(ctr, w.counters, 32, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_S(s);
     if (ctr[1]) return fail(e, STA_ERR_ARG, "a CIGAR holds an operation outside MIDNSHP=X");
     if (n_cols > (uint64_t)INT32_MAX - 64 || n_entries > ((uint64_t)1 << 40)) return fail(e, STA_ERR_ARG, "consensus window too large: column indices are 32-bit (split the window)");
     if (e->cons_E.ensure((size_t)n_entries * 4 + 64) || ((bayes_mq || walk_all) && e->cons_Enm.ensure((size_t)n_entries * 4 + 64)) || e->cons_cols.ensure((size_t)n_cols * sizeof(sta_cons_col) + 64)
@@ -1161,7 +1181,7 @@ static int cons_run(sta_engine *e, const sta_cons_params *cp, sta_cons_info *inf
         { ProfScope ps(e, "cons_scans"); sta_launch_len_scan(s, w.depth, w.col_off, (int64_t)n_cols, e->scan_tmp.p, e->scan_tmp.cap); }
         { ProfScope ps(e, "cons_text"); sta_launch_cons_text(s, w, o, (int64_t)n_cols); }
     }
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_S(s);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "consensus kernels");
     prof_drain(e);
@@ -1185,7 +1205,7 @@ int sta_fetch_cons_entries(sta_engine *e, int32_t *ins, int32_t *first_col, int3
     if (entry_off) HIPCHK(hipMemcpyAsync(entry_off, w.rowoff, (n + 1) * 8, hipMemcpyDeviceToHost, s));
     if (entries && e->cons_nstored) HIPCHK(hipMemcpyAsync(entries, w.E, (size_t)e->cons_nstored * 4, hipMemcpyDeviceToHost, s));
     if (seq_offs && e->cons_nstored) HIPCHK(hipMemcpyAsync(seq_offs, w.Enm, (size_t)e->cons_nstored * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_S(s);
     return STA_OK;
 }
 
@@ -1202,7 +1222,7 @@ int sta_fetch_consensus(sta_engine *e, int32_t *ins, sta_cons_col *cols, uint64_
     if (col_off) HIPCHK(hipMemcpyAsync(col_off, w.col_off, (size_t)(e->cons_ncols + 1) * 8, hipMemcpyDeviceToHost, s));
     if (seq_chars && e->cons_nentries) HIPCHK(hipMemcpyAsync(seq_chars, w.seq_chars, (size_t)e->cons_nentries, hipMemcpyDeviceToHost, s));
     if (qual_chars && e->cons_nentries) HIPCHK(hipMemcpyAsync(qual_chars, w.qual_chars, (size_t)e->cons_nentries, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_S(s);
     return STA_OK;
 }
 
@@ -1250,7 +1270,7 @@ int sta_calmd_plan(sta_engine *e, const sta_calmd_params *cp, sta_plan_info *inf
     }
     uint64_t total = 0;
     if (n) HIPCHK(hipMemcpyAsync(&total, (uint64_t *)e->offs.p + n, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_S(s);
     if (e->out.ensure((size_t)total + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(output) failed");
     if (n) {
         ProfScope ps(e, "md_emit");
@@ -1258,7 +1278,7 @@ int sta_calmd_plan(sta_engine *e, const sta_calmd_params *cp, sta_plan_info *inf
                            (const int32_t *)e->md_nm.p, (const uint64_t *)e->offs.p, (char *)e->out.p, (uint8_t *)e->md_seq.p);
     }
     d.bq = saved_bq;
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_S(s);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "calmd kernels");
     e->out_bytes = total; e->last_out = e->out.p;
@@ -1282,7 +1302,7 @@ int sta_fetch_calmd(sta_engine *e, int32_t *nm, uint64_t *md_off, char *md_text,
     if (qual_pool && nb) HIPCHK(hipMemcpyAsync(qual_pool, d.qual, nb, hipMemcpyDeviceToHost, s));
     if (seq_pool && nb) HIPCHK(hipMemcpyAsync(seq_pool, e->md_seq.p, nb / 2, hipMemcpyDeviceToHost, s));
     if (tag_pool && nb) HIPCHK(hipMemcpyAsync(tag_pool, e->md_tag.p, nb, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_S(s);
     return STA_OK;
 }
 
@@ -1353,7 +1373,7 @@ int sta_fetch_overlap_fixups(sta_engine *e, int32_t file, int32_t *fix_y, int32_
     HIPCHK(hipMemcpyAsync(fix_y, d.fix_y, (size_t)d.n * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(fix_mate, d.fix_mate, (size_t)d.n * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(fix_q, d.fix_q, (size_t)d.n, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     return STA_OK;
 }
 
@@ -1461,7 +1481,7 @@ int sta_fetch_output(sta_engine *e, char *host_out, uint64_t n)
     hipSetDevice(e->device);
     if (n > e->out_bytes) return fail(e, STA_ERR_ARG, "fetch larger than output");
     if (n) HIPCHK(hipMemcpyAsync(host_out, e->last_out, (size_t)n, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return hipfail(e, le, "emit kernel");
     return STA_OK;
@@ -1471,7 +1491,7 @@ int sta_sync(sta_engine *e)
 {
     if (!e) return STA_ERR_ARG;
     hipSetDevice(e->device);
-    HIPCHK(hipStreamSynchronize(e->stream));
+    SYNC_STREAM();
     return STA_OK;
 }
 

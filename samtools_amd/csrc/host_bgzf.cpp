@@ -62,6 +62,14 @@ int io_default_threads()
     return share > 16 ? 16 : share < 2 ? 2 : share;
 }
 
+// STA_DRIVER_TIMING=1: what this rank decided (one line per process, on stderr)
+void report_thread_budget()
+{
+    const char *sh = getenv("STA_SHARD");
+    fprintf(stderr, "[driver threads] shard %s: %d decode threads per input lane (CPUs this process may use: %d, ranks sharing the node: %d)\n",
+            sh && *sh ? sh : "0/1", io_default_threads(), host_cpus_available(), host_node_ranks());
+}
+
 int io_threads_per_input(int n_inputs)
 {
     const int t = io_default_threads();

@@ -46,6 +46,7 @@ bool bgzf_inflate_block(const BgzfMap::Block &b, uint8_t *dst);
 
 int io_default_threads();
 int host_cpus_available();      // min(hardware threads, affinity mask, cgroup CPU quota)
+void report_thread_budget();     // STA_DRIVER_TIMING: one line on stderr
 int host_node_ranks();          // processes of this job sharing the node (STA_NODE_RANKS, STA_SHARD world, LOCAL_WORLD_SIZE)
 // per-input worker count when a command reads n_inputs files at once: the default is shared out (at least 1 each), so that
 // a hundred-file mpileup does not start a thousand threads

@@ -949,7 +949,7 @@ void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
 #include "baq_band7s.h"
 
 #ifndef BAQ7S_DEFAULT_MODE
-#define BAQ7S_DEFAULT_MODE 0
+#define BAQ7S_DEFAULT_MODE 16          // baq7s::M_LOGTAB
 #endif
 static void baq_tables_fill()
 {
@@ -996,42 +996,6 @@ __device__ __forceinline__ Baq7sRead baq7s_read(const StaReadsDev &R, const StaW
     }
     return d;
 }
-
-// M_DMA: the next group's stored row, global -> LDS, 15 x 1 KiB (16 bytes per lane; the LDS side is wave-uniform base + 16 x lane, which
-// is the [cell][lane] image of mid_row).  Non-temporal like the register path's loads.  hipcc orders the image's ds_reads behind it (vmcnt).
-struct Baq7sDma {
-    const baq7s::d2 *F2;                                        // the slot's stored rows (wave-uniform)
-    __attribute__((address_space(3))) char *img;                // mid_row (wave-uniform)
-    int lane;
-    __device__ __forceinline__ void operator()(int row) const
-    {
-        const int t = ((row - 1) / 3) * baq7s::NB;
-        const char *src = reinterpret_cast<const char *>(F2 + (size_t)t * 64 + lane);
-        cells<0>(src);
-    }
-    template <int J> __device__ __forceinline__ void cells(const char *src) const
-    {
-        if constexpr (J < baq7s::NB) {
-            // the instruction's immediate offset moves both sides: 4 cells per base pair, then both bases move on
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (J / 4) * 4096),
-                                             (__attribute__((address_space(3))) void *)(img + (J / 4) * 4096), 16, (J % 4) * 1024, 2);
-            cells<J + 1>(src);
-        }
-    }
-};
-// M_L2PF: touch every 128-byte line of the next group's stored row (15 KiB = 120 lines: two loads of one dword per lane); the results are
-// never used, so nothing waits for them.
-struct Baq7sL2pf {
-    const baq7s::d2 *F2; int lane;
-    __device__ __forceinline__ void operator()(int row) const
-    {
-        const int t = ((row - 1) / 3) * baq7s::NB;
-        const char *src = reinterpret_cast<const char *>(F2 + (size_t)t * 64) + lane * 128;
-        uint32_t d0, d1;
-        asm volatile("global_load_dword %0, %1, off nt" : "=v"(d0) : "v"(src));
-        if (lane < 56) asm volatile("global_load_dword %0, %1, off nt" : "=v"(d1) : "v"(src + 8192));
-    }
-};
 
 // two waves per SIMD: the backward pass holds 120 doubles of band state (256 VGPRs; 168 would spill 230 of them)
 template <int MODE>
@@ -1098,16 +1062,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 p.eim1 = baq_uni(p.eim1); p.eim4 = baq_uni(p.eim4);
                 baq7s::BwdCtx c; c.ys = d.sh.ys; c.mlen = d.sh.mlen; c.run_r = 0; c.plain_mask = W.baq_plain != 0 ? -1 : 0;
                 c.LT = (baq7s::LtPtr)lt;
-                if (MODE & baq7s::M_DMA) {
-                    // (every lane of the wave must take part in a DMA row: the image is [cell][lane] for all 64 lanes; inactive lanes' slots hold
-                    // whatever the slot held -- never read)
-                    const Baq7sDma pf = { sl.F2, (__attribute__((address_space(3))) char *)mid_row, lane };
-                    baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, lane, q2p, Ln, c, pf);
-                } else if (MODE & baq7s::M_L2PF) {
-                    const Baq7sL2pf pf = { sl.F2, lane };
-                    baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, lane, q2p, Ln, c, pf);
-                } else
-                    baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, lane, q2p, Ln, c);
+                baq7s::bwd_lane<64, MODE>(p, lq, lq + 6, all_edge, sl.IN, sl.F2, sl.S, lane, q2p, Ln, c);
                 baq7s::final_lane<64>(lq, sl.IN, lane, c, d.qual);
             }
         } else if (!have) break;
@@ -1153,11 +1108,8 @@ void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, v
     case 1: BAQ7S_LAUNCH(1); break;
     case 2: BAQ7S_LAUNCH(2); break;
     case 3: BAQ7S_LAUNCH(3); break;
-    case 16: BAQ7S_LAUNCH(16); break;          // M_LOGTAB
-    case 32: BAQ7S_LAUNCH(32); break;          // M_DMA
-    case 48: BAQ7S_LAUNCH(48); break;          // M_LOGTAB | M_DMA
-    case 64: BAQ7S_LAUNCH(64); break;          // M_L2PF
-    case 80: BAQ7S_LAUNCH(80); break;          // M_LOGTAB | M_L2PF
+    case 16: BAQ7S_LAUNCH(16); break;          // M_LOGTAB (default)
+    case 17: BAQ7S_LAUNCH(17); break;
     default: fprintf(stderr, "samtools-amd: STA_BAQ7S_MODE=%d is not built\n", mode); abort();
     }
 #undef BAQ7S_LAUNCH

@@ -17,7 +17,7 @@
 // that in the tests).
 #include "dev_util.h"
 
-__global__ void __launch_bounds__(256) k_bam_pools(const uint8_t *raw, const uint32_t *rec_off, int64_t raw_first, int64_t n_raw,
+__global__ void __launch_bounds__(256) k_bam_pools(const uint8_t *raw, const uint32_t *rec_off, uint64_t raw_bytes, int64_t raw_first, int64_t n_raw,
                                                    const int32_t *l_qseq, const uint32_t *cig_off, const uint32_t *base_off8, const uint32_t *name_off,
                                                    uint32_t *cigar, uint8_t *seq, uint8_t *qual, char *names, unsigned long long *bad)
 {
@@ -25,13 +25,17 @@ __global__ void __launch_bounds__(256) k_bam_pools(const uint8_t *raw, const uin
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n_raw) return;
     const int64_t i = raw_first + t;
-    const uint8_t *rec = raw + rec_off[t];
+    // (rec_off comes through the public sta_reads fields: a record must lie inside the uploaded bytes, head and all four slices)
+    const uint64_t ro = rec_off[t];
+    if (ro + 32 > raw_bytes) { if (lane == 0) atomicAdd(bad, 1ull); return; }
+    const uint8_t *rec = raw + ro;
     const int l_name = rec[8];
     const int n_cig = rec[12] | (rec[13] << 8);
     const int l_seq = (int)((uint32_t)rec[16] | ((uint32_t)rec[17] << 8) | ((uint32_t)rec[18] << 16) | ((uint32_t)rec[19] << 24));
     const uint32_t c0 = cig_off[i], c1 = cig_off[i + 1], n0 = name_off[i], n1 = name_off[i + 1];
     // the host's offsets were computed from ITS parse of the same record: a disagreement means the two views of the input differ
-    if (l_seq != l_qseq[i] || (int)(c1 - c0) != n_cig || (int)(n1 - n0) != l_name) { if (lane == 0) atomicAdd(bad, 1ull); return; }
+    if (l_seq != l_qseq[i] || (int)(c1 - c0) != n_cig || (int)(n1 - n0) != l_name || l_seq < 0
+        || ro + 32 + (uint64_t)l_name + 4ull * (uint64_t)n_cig + (uint64_t)((l_seq + 1) >> 1) + (uint64_t)l_seq > raw_bytes) { if (lane == 0) atomicAdd(bad, 1ull); return; }
     const uint8_t *s_name = rec + 32, *s_cig = s_name + l_name, *s_seq = s_cig + 4 * n_cig, *s_qual = s_seq + ((l_seq + 1) >> 1);
     for (int k = lane; k < l_name; k += 64) names[n0 + k] = (char)s_name[k];
     for (int k = lane; k < n_cig; k += 64) {
@@ -53,11 +57,11 @@ __global__ void __launch_bounds__(256) k_stage_compare(const uint8_t *a, const u
     if (d) atomicAdd(bad, d);
 }
 
-void sta_launch_bam_pools(hipStream_t s, const uint8_t *raw, const uint32_t *rec_off, int64_t raw_first, int64_t n_raw, const StaReadsDev &d,
+void sta_launch_bam_pools(hipStream_t s, const uint8_t *raw, const uint32_t *rec_off, uint64_t raw_bytes, int64_t raw_first, int64_t n_raw, const StaReadsDev &d,
                           uint32_t *cigar, uint8_t *seq, uint8_t *qual, char *names, unsigned long long *bad)
 {
     if (n_raw <= 0) return;
-    hipLaunchKernelGGL(k_bam_pools, dim3((unsigned)((n_raw + 3) / 4)), dim3(256), 0, s, raw, rec_off, raw_first, n_raw, d.l_qseq, d.cig_off, d.base_off8, d.name_off,
+    hipLaunchKernelGGL(k_bam_pools, dim3((unsigned)((n_raw + 3) / 4)), dim3(256), 0, s, raw, rec_off, raw_bytes, raw_first, n_raw, d.l_qseq, d.cig_off, d.base_off8, d.name_off,
                        cigar, seq, qual, names, bad);
 }
 

@@ -165,7 +165,7 @@ size_t sta_baq7s_scratch_bytes(int lq_cap, int64_t ngroups, int *waves_out);
 void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int waves);
 
 // device staging (kernels_stage.hip): pools of reads [raw_first, raw_first + n_raw) out of raw BAM alignment records
-void sta_launch_bam_pools(hipStream_t s, const uint8_t *raw, const uint32_t *rec_off, int64_t raw_first, int64_t n_raw, const StaReadsDev &d,
+void sta_launch_bam_pools(hipStream_t s, const uint8_t *raw, const uint32_t *rec_off, uint64_t raw_bytes, int64_t raw_first, int64_t n_raw, const StaReadsDev &d,
                           uint32_t *cigar, uint8_t *seq, uint8_t *qual, char *names, unsigned long long *bad);
 void sta_launch_stage_compare(hipStream_t s, const void *a, const void *b, uint64_t n, unsigned long long *bad);
 

@@ -6,8 +6,8 @@
 //
 //   clang++ -O1 -std=c++17 -ffp-contract=off -I samtools_amd/csrc tests/cpu/baq_emul.cpp o_baq.o o_io.o -lz -lm -o baq_emul
 //   baq_emul <n_reads> <seed> [force_edge] [mode]
-// prints "reads N changed C mismatching_reads X" and exits 1 when X > 0.  mode: the kernel's STA_BAQ7S_MODE feature bits (16: the MAP
-// quality from the threshold table; 32: the stored row through the LDS image, as the DMA path reads it; 48: both).
+// prints "reads N changed C mismatching_reads X" and exits 1 when X > 0.  mode: the kernel's STA_BAQ7S_MODE (16: the MAP quality from the
+// threshold table, the default build; 0: from the formula).
 //   baq_emul logtab <n_random> <seed>
 // checks the threshold table on its own: clean steps over 2 x 10^5 doubles either side of every threshold, table == formula on random
 // posteriors (uniform, near 1, near the thresholds) and on the special values.
@@ -70,13 +70,9 @@ template <int MODE>
 static void run_lanes(const baq7s::Par &par, int lq, int l_ref, bool amb, std::vector<uint32_t> &IN, std::vector<baq7s::d2> &F2, std::vector<double> &S,
                       const float *q2p, baq7s::BwdCtx &ctx)
 {
-    baq7s::d2 Ln[baq7s::NB];                      // what is LDS on the device: the stored row's image (DMA path), then the normalised middle row
+    baq7s::d2 Ln[baq7s::NB];                      // what is LDS on the device: the normalised middle row of the group in work
     baq7s::fwd_lane<1, MODE>(par, lq, amb, IN.data(), F2.data(), S.data(), 0, q2p);
-    struct Pf {                                   // the device's DMA: the stored row -> the image, at the point of the program where the kernel issues it
-        const baq7s::d2 *F2; baq7s::d2 *Ln;
-        void operator()(int row) const { if (MODE & baq7s::M_DMA) { const int t = ((row - 1) / 3) * baq7s::NB; for (int j = 0; j < baq7s::NB; ++j) Ln[j] = F2[t + j]; } }
-    } pf = { F2.data(), &Ln[0] };
-    baq7s::bwd_lane<1, MODE>(par, lq, l_ref, amb, IN.data(), F2.data(), S.data(), 0, q2p, &Ln[0], ctx, pf);
+    baq7s::bwd_lane<1, MODE>(par, lq, l_ref, amb, IN.data(), F2.data(), S.data(), 0, q2p, &Ln[0], ctx);
 }
 
 int main(int argc, char **argv)
@@ -148,7 +144,7 @@ int main(int argc, char **argv)
         std::vector<uint32_t> IN(lq + 2, 0);
         std::vector<baq7s::d2> F2((size_t)((lq + 2) / 3) * baq7s::NB);
         std::vector<double> S(lq + 2, 0.);
-        std::vector<uint8_t> mq(qual);
+        std::vector<uint8_t> mq(qual); mq.resize((size_t)(lq + 7) & ~(size_t)7, 0xee);      // the device pools pad every read to 8 bases
         const baq7s::Par par = baq7s::make_par(lq, l_ref);
         const bool amb = baq7s::pack_lane<1>(lq, l_ref, mq.data(), seq.data(), ref.c_str() + sh.xb, refc, IN.data(), 0);
         if (amb) ++n_amb;
@@ -156,13 +152,12 @@ int main(int argc, char **argv)
         switch (mode) {
         case 0: run_lanes<0>(par, lq, l_ref, amb, IN, F2, S, q2p, ctx); break;
         case 16: run_lanes<16>(par, lq, l_ref, amb, IN, F2, S, q2p, ctx); break;
-        case 32: run_lanes<32>(par, lq, l_ref, amb, IN, F2, S, q2p, ctx); break;
-        case 48: run_lanes<48>(par, lq, l_ref, amb, IN, F2, S, q2p, ctx); break;
         default: fprintf(stderr, "mode %d is not built into the harness\n", mode); return 2;
         }
         baq7s::final_lane<1>(lq, IN.data(), 0, ctx, mq.data());
 
         if (memcmp(oq.data(), qual.data(), (size_t)lq) != 0) ++n_changed;
+        for (size_t i = (size_t)lq; i < mq.size(); ++i) if (mq[i] != 0xee) { fprintf(stderr, "read %d: padding byte %zu was written\n", it, i); ++n_bad; break; }
         if (memcmp(oq.data(), mq.data(), (size_t)lq) != 0) {
             if (n_bad < 5) {
                 fprintf(stderr, "MISMATCH read %d lq %d pos %lld s5 %d s3 %d plain %d\n", it, lq, pos, s5, s3, (int)plain);

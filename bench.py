@@ -327,13 +327,11 @@ def e2e_file_to_text(inputs, sample_cols, oracle_sha_of_sample, oracle_text_path
         t, err = timed(args)
         out["commands"][label] = {"wall_s": t, "mbases_per_s": mbases / t if t else None,
                                   "mbases_per_s_net_of_startup": mbases / max(t - t_start, 1e-3) if (t and t_start) else None, "error": err}
-    # parity of one of them: the whole text against the oracle's text of the sample, replicated the same way
-    if oracle_text_path and os.path.exists(oracle_text_path):
-        want = hashlib.sha256()
-        txt = open(oracle_text_path, "rb").read()
-        for nm in names:
-            want.update(txt.replace(b"chrS\t", nm.encode() + b"\t"))
-        p = subprocess.Popen([exe, "mpileup", "-f", big_fa, bam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    # parity of ALL THREE: the whole text against the oracle's text of the sample, replicated the same way (round 5: `mpileup -B -f` and
+    # `depth -a` used to be timed but not checked).  The oracle runs once per command on the one-contig sample; its wall time is the
+    # same-boundary CPU figure (text input, text output, one thread), scaled to the replicated input.
+    def engine_sha(args):
+        p = subprocess.Popen([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
         got = hashlib.sha256()
         while True:
             b = p.stdout.read(1 << 22)
@@ -341,7 +339,35 @@ def e2e_file_to_text(inputs, sample_cols, oracle_sha_of_sample, oracle_text_path
                 break
             got.update(b)
         p.wait()
-        out["identical_to_oracle"] = {"command": "mpileup -f", "identical": got.hexdigest() == want.hexdigest() and p.returncode == 0}
+        return got.hexdigest() if p.returncode == 0 else None
+
+    def replicated_sha(txt):
+        want = hashlib.sha256()
+        for nm in names:
+            want.update(txt.replace(b"chrS\t", nm.encode() + b"\t"))
+        return want.hexdigest()
+
+    oracle_exe = os.path.join(REPO, "oracle", "_build", "oracle_samtools")
+    checks = {}
+    if oracle_text_path and os.path.exists(oracle_text_path):
+        checks["mpileup -f"] = (replicated_sha(open(oracle_text_path, "rb").read()), ["mpileup", "-f", big_fa, bam], None)
+    if os.path.exists(oracle_exe):
+        for label, o_args, e_args in (("mpileup -B -f", ["mpileup", "-B", "-f", inputs["fa"], inputs["sam"]], ["mpileup", "-B", "-f", big_fa, bam]),
+                                      ("depth -a", ["depth", "-a", inputs["sam"]], ["depth", "-a", bam])):
+            t0 = time.perf_counter()
+            pr = subprocess.run([oracle_exe] + o_args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+            t_or = time.perf_counter() - t0
+            if pr.returncode == 0:
+                checks[label] = (replicated_sha(pr.stdout), e_args, t_or)
+    out["identical_to_oracle"] = {}
+    for label, (want, e_args, t_or) in checks.items():
+        got = engine_sha(e_args)
+        out["identical_to_oracle"][label] = bool(got is not None and got == want)
+        if t_or and out["commands"].get(label, {}).get("wall_s"):
+            # same boundary on both sides: file in, text out (the oracle reads the SAM text of ONE contig: x copies)
+            out["commands"][label]["oracle_1_thread_mbases_per_s"] = mbases / copies / t_or
+            out["commands"][label]["vs_oracle_same_boundary"] = out["commands"][label]["mbases_per_s"] / (mbases / copies / t_or)
+    out["identical_to_oracle"]["all"] = bool(checks) and all(v for k, v in out["identical_to_oracle"].items())
     return out
 
 
@@ -462,7 +488,8 @@ def main():
     if rank == 0 and res is not None:
         print(json.dumps(res))
         bad = [r for r in (res, res.get("mpileup300") or {}) if (r.get("parity_check") and not r["parity_check"]["identical"]) or (r.get("verify") and not r["verify"]["identical"])]
-        if bad:
+        e2e_id = (res.get("e2e") or {}).get("identical_to_oracle")
+        if bad or (isinstance(e2e_id, dict) and e2e_id.get("all") is False):
             raise SystemExit("bench.py: the engine's text differs from the oracle's")
     if dist is not None:
         dist.destroy_process_group()

@@ -79,7 +79,13 @@ typedef struct bam_pileup1_t {
 } bam_pileup1_t;
 
 typedef struct kstring_t { size_t l, m; char *s; } kstring_t;
-typedef struct hts_base_mod_state hts_base_mod_state;      /* HTSlib's MM/ML parser state: opaque here */
+typedef struct hts_base_mod_state hts_base_mod_state;      /* the MM / ML evaluation of one read: opaque, as in HTSlib */
+typedef struct hts_base_mod {                               /* htslib/sam.h: one modification of one base */
+    int modified_base;      /* the code letter ('m', 'h', ...), or the ChEBI number negated */
+    int canonical_base;     /* the MM entry's base letter ('C', 'N', ...) */
+    int strand;             /* 0 '+', 1 '-' */
+    int qual;               /* the ML probability 0..255, -1 without an ML value */
+} hts_base_mod;
 
 #define bam_get_qname(b) ((char *)(b)->data)
 #define bam_get_cigar(b) ((uint32_t *)((b)->data + (b)->core.l_qname))
@@ -109,9 +115,18 @@ void sta_bam_plp_constructor(sta_bam_plp_t iter, int (*func)(void *data, const b
 void sta_bam_plp_destructor(sta_bam_plp_t iter, int (*func)(void *data, const bam1_t *b, bam_pileup_cd *cd));
 /* inserted sequence after p (pads as '*'), returns its length incl. pads or <0; *del_len = deletion that follows it */
 int sta_bam_plp_insertion(const bam_pileup1_t *p, kstring_t *ins, int *del_len);
-/* the form bam_plcmd.c:119 calls: m == NULL (no --output-mods) is bam_plp_insertion; a non-NULL HTSlib state cannot be
- * interpreted by this library and yields the plain inserted bases */
+/* the form bam_plcmd.c:119 calls: m == NULL (no --output-mods) is bam_plp_insertion; with a state (below) every inserted base is followed
+ * by the "[...]" text of its modifications; a state that bam_parse_basemod never filled is refused (< 0, message on stderr) */
 int sta_bam_plp_insertion_mod(const bam_pileup1_t *p, hts_base_mod_state *m, kstring_t *ins, int *del_len);
+
+/* ---- base modifications: the four HTSlib calls of bam_plcmd.c:86-109 and :356-369 (sam_mods.c is not in the reference tree: this
+ * library's own MM / ML evaluation, SAM tags specification 1.7, the one `samtools-amd mpileup --output-mods` prints from) ---- */
+hts_base_mod_state *sta_hts_base_mod_state_alloc(void);
+void sta_hts_base_mod_state_free(hts_base_mod_state *state);
+/* evaluates the record's MM:Z / ML:B:C aux fields; 0 on success (also without an MM tag), -1 on a malformed tag */
+int sta_bam_parse_basemod(const bam1_t *b, hts_base_mod_state *state);
+/* the modifications of query position qpos in MM order: fills up to n_mods entries, returns their number (0: none, < 0: error) */
+int sta_bam_mods_at_qpos(const bam1_t *b, int qpos, hts_base_mod_state *state, hts_base_mod *mods, int n_mods);
 
 /* ---- multi-file iterator (HTSlib bam_mplp_*) ---- */
 sta_bam_mplp_t sta_bam_mplp_init(int n, sta_bam_plp_auto_f func, void **data);
@@ -155,6 +170,10 @@ void sta_bam_plp_set_batch(sta_bam_plp_t iter, int n_records);
 #define bam_plp_destructor sta_bam_plp_destructor
 #define bam_plp_insertion sta_bam_plp_insertion
 #define bam_plp_insertion_mod sta_bam_plp_insertion_mod
+#define hts_base_mod_state_alloc sta_hts_base_mod_state_alloc
+#define hts_base_mod_state_free sta_hts_base_mod_state_free
+#define bam_parse_basemod sta_bam_parse_basemod
+#define bam_mods_at_qpos sta_bam_mods_at_qpos
 #define bam_mplp_init sta_bam_mplp_init
 #define bam_mplp_destroy sta_bam_mplp_destroy
 #define bam_mplp_set_maxcnt sta_bam_mplp_set_maxcnt

@@ -360,7 +360,7 @@ struct Runner {
 void usage(FILE *fp)
 {
     fprintf(fp, "\nUsage: samtools mpileup [options] in1.bam [in2.bam [...]]\n"
-                "(MI355X engine; options as samtools 1.23.1 mpileup except -X and CRAM input)\n");
+                "(MI355X engine; options as samtools 1.23.1 mpileup except CRAM input; -X takes BAI indexes)\n");
 }
 
 }  // namespace
@@ -379,7 +379,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     mp.rflag_filter = 4 | 256 | 512 | 1024;
     int use_orphan = 0;
     std::string file_list;
-    bool ignore_rg = false;
+    bool ignore_rg = false, has_index_file = false;
     if (const char *e = getenv("STA_WINDOW_COLS")) conf.window_cols = std::max<long long>(1, atoll(e));
     if (const char *e = getenv("STA_WINDOW_READS")) conf.max_reads = std::max<long long>(1, atoll(e));
 
@@ -461,7 +461,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
             if (!conf.bed) { fprintf(stderr, "samtools mpileup: Could not read file \"%s\"\n", optarg); return 1; }
             break;
         case 'B': mp.flag &= ~STA_MPLP_REALN; break;
-        case 'X': fprintf(stderr, "samtools mpileup: -X is not supported by the MI355X engine\n"); return 1;
+        case 'X': has_index_file = true; break;          // --customized-index: the second half of the file arguments names the indexes (bam_plcmd.c:1243-1262)
         case 'E': mp.flag |= STA_MPLP_REDO_BAQ; break;
         case '6': mp.flag |= STA_MPLP_ILLUMINA13; break;
         case 'R': ignore_rg = true; break;
@@ -491,8 +491,15 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     if (use_orphan) mp.flag &= ~STA_MPLP_NO_ORPHAN;
     if (argc == 1) { usage(stderr); return 1; }
     std::vector<std::string> fns;
-    if (!file_list.empty()) { if (!read_file_list(file_list, &fns)) { fprintf(stderr, "No files read from %s\n", file_list.c_str()); return 1; } }
-    else for (int i = optind; i < argc; ++i) fns.push_back(argv[i]);
+    std::vector<std::string> idx_fns;
+    if (!file_list.empty()) {
+        if (has_index_file) { fprintf(stderr, "Error: The -b option cannot be combined with -X\n"); return 1; }
+        if (!read_file_list(file_list, &fns)) { fprintf(stderr, "No files read from %s\n", file_list.c_str()); return 1; }
+    } else if (has_index_file) {
+        if ((argc - optind) % 2 != 0) { fprintf(stderr, "Odd number of filenames detected! Each BAM file should have an index file\n"); return 1; }
+        const int nf = (argc - optind) / 2;
+        for (int i = 0; i < nf; ++i) { fns.push_back(argv[optind + i]); idx_fns.push_back(argv[optind + nf + i]); }
+    } else for (int i = optind; i < argc; ++i) fns.push_back(argv[i]);
     if (fns.empty()) { fprintf(stderr, "[mpileup] no input file/data given\n"); return 1; }
 
     mp.n_tags = (int32_t)conf.tags.size(); mp.tag_sep = conf.sep;
@@ -519,7 +526,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
             if (i == 0) { run.has_reg = true; run.tid0 = t; run.beg0 = b; run.end0 = e; }
         }
     }
-    seek_readers_by_index(run.readers, fns, *run.h, run.has_reg, run.tid0, run.beg0, run.end0);      // region / sharded runs start at their first column
+    seek_readers_by_index(run.readers, fns, *run.h, run.has_reg, run.tid0, run.beg0, run.end0, (int64_t)1 << 20, has_index_file ? &idx_fns : nullptr);      // region / sharded runs start at their first column
     fprintf(stderr, "[mpileup] %d samples in %d input files\n", (int)sm.sm.size(), (int)fns.size());
     if (!conf.output_fname.empty()) {
         run.out = fopen(conf.output_fname.c_str(), "w");

@@ -67,8 +67,10 @@ struct Shard {
 // inflating and parsing the file's prefix; a region start needs no margin (records that do not overlap the region are filtered
 // anyway), a block start inside a contig steps back `margin` columns so that the reads, mates and lookahead records the
 // unsharded run carries into the block are all read.  STA_NO_INDEX=1 switches it off.  Returns the number of inputs that seeked.
+// An index older than its data file is used with HTSlib's warning (round 5; round 4 skipped it).
 inline int seek_readers_by_index(std::vector<std::unique_ptr<AlnReader>> &readers, const std::vector<std::string> &paths, const Header &h,
-                                 bool has_reg, int tid0, int64_t beg0, int64_t end0, int64_t margin = (int64_t)1 << 20)
+                                 bool has_reg, int tid0, int64_t beg0, int64_t end0, int64_t margin = (int64_t)1 << 20,
+                                 const std::vector<std::string> *index_paths = nullptr)
 {
     if (getenv("STA_NO_INDEX")) return 0;
     Shard sh = Shard::from_env();
@@ -91,13 +93,15 @@ inline int seek_readers_by_index(std::vector<std::unique_ptr<AlnReader>> &reader
     int n = 0;
     for (size_t i = 0; i < readers.size() && i < paths.size(); ++i) {
         if (!readers[i]->is_bam()) continue;
-        std::unique_ptr<BaiIndex> ix = BaiIndex::load_for(paths[i]);
-        if (!ix) continue;
-        if (ix->older_than_data()) {
-            // HTSlib warns and goes on; a stale index would start this reader at an offset of another file: the whole file is read instead
-            fprintf(stderr, "[W::samtools_amd] The index file of \"%s\" is older than the data file: not used\n", paths[i].c_str());
+        // -X / --customized-index: the index file the command names for this input instead of the one beside it
+        std::unique_ptr<BaiIndex> ix = (index_paths && i < index_paths->size()) ? BaiIndex::load_file((*index_paths)[i], paths[i]) : BaiIndex::load_for(paths[i]);
+        if (!ix) {
+            if (index_paths && i < index_paths->size()) fprintf(stderr, "[W::samtools_amd] could not load the index \"%s\" (BAI expected): \"%s\" is read from its start\n", (*index_paths)[i].c_str(), paths[i].c_str());
             continue;
         }
+        // as HTSlib: a warning, and the index is used (a pair whose time stamps are merely inverted -- copied data -- would otherwise lose
+        // its region start; an index of ANOTHER file fails where HTSlib's would: at the block it points into)
+        if (ix->older_than_data()) fprintf(stderr, "[W::samtools_amd] The index file is older than the data file: %s\n", paths[i].c_str());
         const uint64_t v = ix->start_offset(tid, pos);
         if (readers[i]->seek_voffset(v)) ++n;
     }

@@ -217,41 +217,43 @@ bool AlnReader::seek_voffset(uint64_t voffset)
     return true;
 }
 
+std::unique_ptr<BaiIndex> BaiIndex::load_file(const std::string &p, const std::string &bam_path)
+{
+    FILE *fp = fopen(p.c_str(), "rb");
+    if (!fp) return nullptr;
+    std::unique_ptr<BaiIndex> ix(new BaiIndex());
+    bool ok = false;
+    auto rd = [&](void *d, size_t n) { return fread(d, 1, n, fp) == n; };
+    char magic[4]; int32_t n_ref = 0;
+    if (rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0 && n_ref < (1 << 26)) {
+        ok = true;
+        ix->lin_.resize((size_t)n_ref);
+        for (int32_t t = 0; t < n_ref && ok; ++t) {
+            int32_t n_bin = 0;
+            if (!rd(&n_bin, 4) || n_bin < 0) { ok = false; break; }
+            for (int32_t b = 0; b < n_bin && ok; ++b) {
+                uint32_t bin; int32_t n_chunk = 0;
+                if (!rd(&bin, 4) || !rd(&n_chunk, 4) || n_chunk < 0 || fseeko(fp, (off_t)n_chunk * 16, SEEK_CUR) != 0) ok = false;
+            }
+            int32_t n_intv = 0;
+            if (!ok || !rd(&n_intv, 4) || n_intv < 0) { ok = false; break; }
+            ix->lin_[(size_t)t].resize((size_t)n_intv);
+            if (n_intv && !rd(ix->lin_[(size_t)t].data(), (size_t)n_intv * 8)) ok = false;
+        }
+    }
+    fclose(fp);
+    if (!ok) return nullptr;
+    struct stat si, sd;
+    ix->stale_ = stat(p.c_str(), &si) == 0 && stat(bam_path.c_str(), &sd) == 0
+                 && (si.st_mtim.tv_sec < sd.st_mtim.tv_sec || (si.st_mtim.tv_sec == sd.st_mtim.tv_sec && si.st_mtim.tv_nsec < sd.st_mtim.tv_nsec));
+    return ix;
+}
+
 std::unique_ptr<BaiIndex> BaiIndex::load_for(const std::string &bam_path)
 {
     std::vector<std::string> cand = { bam_path + ".bai" };
     if (bam_path.size() > 4 && bam_path.compare(bam_path.size() - 4, 4, ".bam") == 0) cand.push_back(bam_path.substr(0, bam_path.size() - 4) + ".bai");
-    for (const std::string &p : cand) {
-        FILE *fp = fopen(p.c_str(), "rb");
-        if (!fp) continue;
-        std::unique_ptr<BaiIndex> ix(new BaiIndex());
-        bool ok = false;
-        auto rd = [&](void *d, size_t n) { return fread(d, 1, n, fp) == n; };
-        char magic[4]; int32_t n_ref = 0;
-        if (rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0 && n_ref < (1 << 26)) {
-            ok = true;
-            ix->lin_.resize((size_t)n_ref);
-            for (int32_t t = 0; t < n_ref && ok; ++t) {
-                int32_t n_bin = 0;
-                if (!rd(&n_bin, 4) || n_bin < 0) { ok = false; break; }
-                for (int32_t b = 0; b < n_bin && ok; ++b) {
-                    uint32_t bin; int32_t n_chunk = 0;
-                    if (!rd(&bin, 4) || !rd(&n_chunk, 4) || n_chunk < 0 || fseeko(fp, (off_t)n_chunk * 16, SEEK_CUR) != 0) ok = false;
-                }
-                int32_t n_intv = 0;
-                if (!ok || !rd(&n_intv, 4) || n_intv < 0) { ok = false; break; }
-                ix->lin_[(size_t)t].resize((size_t)n_intv);
-                if (n_intv && !rd(ix->lin_[(size_t)t].data(), (size_t)n_intv * 8)) ok = false;
-            }
-        }
-        fclose(fp);
-        if (ok) {
-            struct stat si, sd;
-            ix->stale_ = stat(p.c_str(), &si) == 0 && stat(bam_path.c_str(), &sd) == 0
-                         && (si.st_mtim.tv_sec < sd.st_mtim.tv_sec || (si.st_mtim.tv_sec == sd.st_mtim.tv_sec && si.st_mtim.tv_nsec < sd.st_mtim.tv_nsec));
-            return ix;
-        }
-    }
+    for (const std::string &p : cand) if (auto ix = load_file(p, bam_path)) return ix;
     return nullptr;
 }
 

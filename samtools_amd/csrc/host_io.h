@@ -109,10 +109,13 @@ class BaiIndex {
 public:
     // <bam>.bai, else the .bam suffix replaced by .bai; nullptr when there is none or it is malformed
     static std::unique_ptr<BaiIndex> load_for(const std::string &bam_path);
+    // an index file named by the user (-X / --customized-index: bam_plcmd.c:1243-1262, bam2depth.c:873-911); nullptr if unreadable or not a BAI
+    static std::unique_ptr<BaiIndex> load_file(const std::string &index_path, const std::string &bam_path);
     // virtual offset to start reading from so that every alignment overlapping [pos, ...) of tid -- and everything after -- is
     // seen; 0 = unknown (read from the start); UINT64_MAX = nothing at or beyond (tid, pos)
     uint64_t start_offset(int tid, int64_t pos) const;
-    // the index file was last written before the data file (HTSlib warns about such a pair)
+    // the index file was last written before the data file: HTSlib warns about such a pair and uses it all the same, and so do the drivers
+    // (copied or checked-out data often carries an index whose time stamp is not the later one)
     bool older_than_data() const { return stale_; }
 private:
     std::vector<std::vector<uint64_t>> lin_;

@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
+#include <vector>
 
 namespace sta {
 
@@ -21,27 +23,27 @@ int code16(int ch)      // seq_nt16_table for the canonical-base letters
     switch (ch) { case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': case 'U': return 8; default: return 15; }
 }
 int comp16(int c) { return ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3); }
-struct Hit { uint32_t qpos; uint32_t order; int code, strand, qual; };
 }  // namespace
 
-void format_base_mods(const Rec &r, pvector<uint32_t> &qpos, pvector<uint32_t> &toff, pvector<char> &text)
+// the MM / ML evaluation itself, on plain fields: seq = 4-bit packed bases, mm = the MM:Z string, ml = the ML:B:C values (n_ml of them,
+// has_ml = the tag is there).  Fills `hits` sorted by query position (MM order within a position).  false: malformed MM (HTSlib reports a
+// parse error; the callers show no modifications).
+bool parse_base_mods(const uint8_t *seq, int L, bool rev, const char *mm, const uint8_t *ml, size_t n_ml, bool has_ml, std::vector<ModHit> &hits)
 {
-    if (r.mm.empty() || r.l_qseq <= 0) return;
-    const int L = r.l_qseq;
-    const bool rev = (r.flag & 16) != 0;
-    std::vector<Hit> hits;
+    hits.clear();
+    if (!mm || !*mm || L <= 0) return true;
     size_t ml_i = 0;
-    const char *p = r.mm.c_str();
+    const char *p = mm;
     while (*p) {
         int base = *p++;
         if (base >= 'a' && base <= 'z') base -= 32;
-        if (*p != '+' && *p != '-') return;              // malformed: no modifications (HTSlib reports a parse error)
+        if (*p != '+' && *p != '-') { hits.clear(); return false; }
         const int strand = *p++ == '-';
         const int want = base == 'N' ? 15 : code16(base);
         int codes[64], n_codes = 0;
         if (*p >= '0' && *p <= '9') { char *q; codes[n_codes++] = -(int)strtol(p, &q, 10); p = q; }
         else while (*p >= 'a' && *p <= 'z' && n_codes < 64) codes[n_codes++] = *p++;
-        if (!n_codes) return;
+        if (!n_codes) { hits.clear(); return false; }
         if (*p == '?' || *p == '.') ++p;
         int cand = rev ? L : -1;
         while (*p == ',') {
@@ -50,34 +52,54 @@ void format_base_mods(const Rec &r, pvector<uint32_t> &qpos, pvector<uint32_t> &
             while (need > 0) {
                 cand += rev ? -1 : 1;
                 if (cand < 0 || cand >= L) { cand = rev ? -1 : L; break; }
-                int c = (r.seq[(size_t)cand >> 1] >> ((~cand & 1) << 2)) & 0xf;
+                int c = (seq[(size_t)cand >> 1] >> ((~cand & 1) << 2)) & 0xf;
                 if (rev) c = comp16(c);
                 if (want == 15 || c == want) --need;
             }
             if (need == 0) at = cand;
             for (int c = 0; c < n_codes; ++c) {
-                const int qual = r.has_ml && ml_i < r.ml.size() ? (int)r.ml[ml_i] : -1;
+                const int qual = has_ml && ml_i < n_ml ? (int)ml[ml_i] : -1;
                 ++ml_i;
-                if (at >= 0) hits.push_back(Hit{ (uint32_t)at, (uint32_t)hits.size(), codes[c], strand, qual });
+                if (at >= 0) hits.push_back(ModHit{ (uint32_t)at, (uint32_t)hits.size(), codes[c], strand, qual, base });
             }
         }
-        if (*p == ';') ++p; else if (*p) return;
+        if (*p == ';') ++p; else if (*p) { hits.clear(); return false; }
     }
-    std::stable_sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.qpos < b.qpos; });
+    std::stable_sort(hits.begin(), hits.end(), [](const ModHit &a, const ModHit &b) { return a.qpos < b.qpos; });
+    return true;
+}
+
+// "[" + one "<strand><code><probability>" per modification + "]": what pileup_seq (bam_plcmd.c:86-109) and bam_plp_insertion_mod append
+// behind a modified base; at most 256 modifications per base are shown (the size of the array bam_mods_at_qpos is handed there)
+size_t append_mod_text(const ModHit *h, size_t n, std::string &out)
+{
+    const size_t before = out.size();
+    out.push_back('[');
+    for (size_t j = 0; j < n && j < 256; ++j) {
+        char buf[48]; int k;
+        if (h[j].code < 0) k = snprintf(buf, sizeof buf, "%c(%d)", "+-"[h[j].strand], -h[j].code);
+        else k = snprintf(buf, sizeof buf, "%c%c", "+-"[h[j].strand], h[j].code);
+        if (h[j].qual >= 0) k += snprintf(buf + k, sizeof buf - (size_t)k, "%d", h[j].qual);
+        out.append(buf, (size_t)k);
+    }
+    out.push_back(']');
+    return out.size() - before;
+}
+
+void format_base_mods(const Rec &r, pvector<uint32_t> &qpos, pvector<uint32_t> &toff, pvector<char> &text)
+{
+    if (r.mm.empty() || r.l_qseq <= 0) return;
+    std::vector<ModHit> hits;
+    if (!parse_base_mods(r.seq.data(), r.l_qseq, (r.flag & 16) != 0, r.mm.c_str(), r.ml.data(), r.ml.size(), r.has_ml, hits)) return;
+    std::string t;
     for (size_t i = 0; i < hits.size();) {
         size_t j = i;
+        while (j < hits.size() && hits[j].qpos == hits[i].qpos) ++j;
         qpos.push_back(hits[i].qpos);
         toff.push_back((uint32_t)text.size());
-        text.push_back('[');
-        for (; j < hits.size() && hits[j].qpos == hits[i].qpos; ++j) {
-            if (j - i >= 256) continue;                  // bam_mods_at_qpos is asked for at most 256 modifications per base
-            char buf[48]; int n;
-            if (hits[j].code < 0) n = snprintf(buf, sizeof buf, "%c(%d)", "+-"[hits[j].strand], -hits[j].code);
-            else n = snprintf(buf, sizeof buf, "%c%c", "+-"[hits[j].strand], hits[j].code);
-            if (hits[j].qual >= 0) n += snprintf(buf + n, sizeof buf - (size_t)n, "%d", hits[j].qual);
-            text.insert(text.end(), buf, buf + n);
-        }
-        text.push_back(']');
+        t.clear();
+        append_mod_text(&hits[i], j - i, t);
+        text.insert(text.end(), t.begin(), t.end());
         i = j;
     }
 }

@@ -132,7 +132,8 @@ extern "C" int sta_io_scan_region(const char *path, const char *region, int thre
     bool used = false;
     if (use_index) {
         std::unique_ptr<BaiIndex> ix = BaiIndex::load_for(path);
-        if (ix && !ix->older_than_data()) {                 // (a stale index is not trusted: driver_shard.h seek_readers_by_index)
+        if (ix && ix->older_than_data()) fprintf(stderr, "[W::samtools_amd] The index file is older than the data file: %s\n", path);
+        if (ix) {                                           // (an older index is used with HTSlib's warning: driver_shard.h seek_readers_by_index)
             const uint64_t v = ix->start_offset(tid, beg);
             if (v == UINT64_MAX) { if (n_records) *n_records = 0; if (checksum) *checksum = Fnv().h; if (used_index) *used_index = 1; return 0; }
             used = rd->seek_voffset(v);

@@ -2,6 +2,8 @@
 // This is the "C host code stages pre-decoded BAM records" half of the boundary (BASELINE.json
 // north_star); the arrays are what sta_stage_window() copies to HBM.
 #pragma once
+#include <string>
+#include <vector>
 #include "host_io.h"
 #include "host_pinned.h"
 #include "../../include/samtools_amd.h"
@@ -23,6 +25,10 @@ struct XcolSpec {
 struct Chunk;       // host_chunk.h
 // appends the modified bases of one record (host_mods.cpp): query position, offset of its "[+m128]" text, the text
 void format_base_mods(const Rec &r, pvector<uint32_t> &qpos, pvector<uint32_t> &toff, pvector<char> &text);
+// the evaluation of a read's MM / ML tags on plain fields (host_mods.cpp), shared with the drop-in surface (plp_api.cpp: bam_parse_basemod)
+struct ModHit { uint32_t qpos; uint32_t order; int code, strand, qual, canonical; };      // code < 0: ChEBI number (negated); canonical: the MM entry's base letter
+bool parse_base_mods(const uint8_t *seq, int l_qseq, bool rev, const char *mm, const uint8_t *ml, size_t n_ml, bool has_ml, std::vector<ModHit> &hits);
+size_t append_mod_text(const ModHit *h, size_t n, std::string &out);
 
 struct StagedFile {
     // page-locked (host_pinned.h): sta_stage_window copies straight out of these

@@ -8,6 +8,7 @@
 // HIP device the iterators fail.
 #include "../../include/samtools_amd.h"
 #include "../../include/samtools_amd_plp.h"
+#include "host_stage.h"
 #include <algorithm>
 #include <climits>
 #include <cstdio>
@@ -16,6 +17,8 @@
 #include <deque>
 #include <vector>
 #include <mutex>
+#include <new>
+#include <string>
 
 namespace {
 
@@ -521,13 +524,117 @@ int sta_bam_plp_insertion(const bam_pileup1_t *p, kstring_t *ins, int *del_len)
     return indel;
 }
 
-// bam_plcmd.c:119 calls the _mod form; with no modification state (m == NULL, i.e. without --output-mods) HTSlib's
-// bam_plp_insertion_mod is bam_plp_insertion.  A non-NULL state belongs to HTSlib's MM/ML parser (hts_base_mod_state is its
-// opaque type): this library cannot interpret it, so the inserted bases are returned without modification annotations.
+// ---- base modifications through the drop-in names (bam_plcmd.c:86-109, :119, :356-369) ----
+// HTSlib's sam_mods.c is absent from the reference tree; these are this library's own equivalents of the four calls mpileup makes
+// (hts_base_mod_state_alloc / _free, bam_parse_basemod, bam_mods_at_qpos) plus bam_plp_insertion_mod with a live state, all on the MM / ML
+// evaluation of host_mods.cpp that `samtools-amd mpileup --output-mods` itself uses (SAM tags specification 1.7).  The state is created
+// per read by the iterator's constructor hook exactly as bam_plcmd.c:356-362 does it.
+}  // extern "C"
+
+struct hts_base_mod_state { std::vector<sta::ModHit> hits; bool parsed = false; };
+
+namespace {
+int ks_reserve1(kstring_t *ks, size_t n) { if (ks->m < n) { char *t = (char *)realloc(ks->s, n); if (!t) return -1; ks->s = t; ks->m = n; } return 0; }
+// aux field `tag` of a record: pointer to its type byte, or NULL (BAM aux encoding, SAM specification 4.2.4)
+const uint8_t *aux_find(const bam1_t *b, const char *t1, const char *t2)
+{
+    const uint8_t *p = bam_get_qual(b) + b->core.l_qseq, *end = b->data + b->l_data;
+    while (p + 3 <= end) {
+        const bool hit = (p[0] == (uint8_t)t1[0] && p[1] == (uint8_t)t1[1]) || (p[0] == (uint8_t)t2[0] && p[1] == (uint8_t)t2[1]);
+        const uint8_t *v = p + 2;
+        if (hit) return v;
+        const int ty = *v++;
+        size_t sz = 0;
+        switch (ty) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'd': sz = 8; break;
+        case 'Z': case 'H': { const uint8_t *q = v; while (q < end && *q) ++q; if (q >= end) return nullptr; sz = (size_t)(q - v) + 1; break; }
+        case 'B': {
+            if (v + 5 > end) return nullptr;
+            const int sub = v[0]; uint32_t n; memcpy(&n, v + 1, 4);
+            const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            sz = 5 + es * (size_t)n; break;
+        }
+        default: return nullptr;
+        }
+        if ((size_t)(end - v) < sz) return nullptr;
+        p = v + sz;
+    }
+    return nullptr;
+}
+}  // namespace
+
+extern "C" {
+
+hts_base_mod_state *sta_hts_base_mod_state_alloc(void) { return new (std::nothrow) hts_base_mod_state(); }
+void sta_hts_base_mod_state_free(hts_base_mod_state *state) { delete state; }
+
+// 0 on success (also when the record has no MM tag), -1 on a malformed MM / ML
+int sta_bam_parse_basemod(const bam1_t *b, hts_base_mod_state *state)
+{
+    if (!b || !state) return -1;
+    state->hits.clear(); state->parsed = true;
+    const uint8_t *mm = aux_find(b, "MM", "Mm");
+    if (!mm) return 0;
+    if (*mm != 'Z') return -1;
+    const uint8_t *ml = aux_find(b, "ML", "Ml");
+    const uint8_t *mlv = nullptr; size_t n_ml = 0;
+    if (ml) {
+        if (ml[0] != 'B' || (ml[1] != 'C' && ml[1] != 'c')) return -1;
+        uint32_t n; memcpy(&n, ml + 2, 4); n_ml = n; mlv = ml + 6;
+    }
+    return sta::parse_base_mods(bam_get_seq(b), b->core.l_qseq, (b->core.flag & 16) != 0, (const char *)mm + 1, mlv, n_ml, ml != nullptr, state->hits) ? 0 : -1;
+}
+
+// the modifications of query position qpos: fills up to n_mods entries, returns how many there are (possibly more than n_mods), 0 for none
+int sta_bam_mods_at_qpos(const bam1_t *b, int qpos, hts_base_mod_state *state, hts_base_mod *mods, int n_mods)
+{
+    (void)b;
+    if (!state || qpos < 0) return -1;
+    auto lo = std::lower_bound(state->hits.begin(), state->hits.end(), (uint32_t)qpos, [](const sta::ModHit &h, uint32_t q) { return h.qpos < q; });
+    int n = 0;
+    for (auto it = lo; it != state->hits.end() && it->qpos == (uint32_t)qpos; ++it, ++n)
+        if (mods && n < n_mods) { mods[n].modified_base = it->code; mods[n].canonical_base = it->canonical; mods[n].strand = it->strand; mods[n].qual = it->qual; }
+    return n;
+}
+
+// bam_plcmd.c:119 calls the _mod form.  m == NULL (no --output-mods, or --no-output-ins-mods) is bam_plp_insertion; with a state every
+// inserted base is followed by the "[...]" text of its modifications, as pileup_seq prints them behind an aligned base (:86-109).
+// A state that was never handed to bam_parse_basemod is refused (< 0) instead of being read as "no modifications".
 int sta_bam_plp_insertion_mod(const bam_pileup1_t *p, hts_base_mod_state *m, kstring_t *ins, int *del_len)
 {
-    (void)m;
-    return sta_bam_plp_insertion(p, ins, del_len);
+    if (!m) return sta_bam_plp_insertion(p, ins, del_len);
+    if (!m->parsed) { fprintf(stderr, "[sta_bam_plp_insertion_mod] the modification state was not filled by bam_parse_basemod\n"); return -1; }
+    if (!p || !ins) return -1;
+    if (del_len) *del_len = 0;
+    ins->l = 0;
+    if (p->indel <= 0) { if (ks_reserve1(ins, 1) < 0) return -1; ins->s[0] = '\0'; return 0; }
+    const uint32_t *cigar = bam_get_cigar(p->b);
+    const uint32_t nc = p->b->core.n_cigar;
+    static const char nt16[] = "=ACMGRSVTWYHKDBN";
+    std::string out;
+    int indel = 0, j = 1;
+    for (uint32_t k = (uint32_t)p->cigar_ind + 1; k < nc; ++k) {
+        const int op = (int)(cigar[k] & 0xf), len = (int)(cigar[k] >> 4);
+        if (op == 6) { out.append((size_t)len, '*'); indel += len; }                      // P
+        else if (op == 1) {                                                              // I
+            for (int l = 0; l < len; ++l, ++j, ++indel) {
+                const int qi = p->qpos + j - (int)p->is_del;
+                out.push_back(qi < p->b->core.l_qseq ? nt16[bam_seqi(bam_get_seq(p->b), qi)] : 'N');
+                auto lo = std::lower_bound(m->hits.begin(), m->hits.end(), (uint32_t)qi, [](const sta::ModHit &h, uint32_t q) { return h.qpos < q; });
+                size_t n = 0;
+                while (lo + (long)n != m->hits.end() && (lo + (long)n)->qpos == (uint32_t)qi) ++n;
+                if (n) sta::append_mod_text(&*lo, n, out);
+            }
+        } else { if (op == 2 && del_len) *del_len = len; break; }                         // D ends the run
+    }
+    if (ks_reserve1(ins, out.size() + 1) < 0) return -1;
+    memcpy(ins->s, out.data(), out.size());
+    ins->s[out.size()] = '\0';
+    ins->l = out.size();
+    return indel;
 }
 
 }  // extern "C"

@@ -12,11 +12,16 @@
  *
  *   plp_client [-x] [-d maxcnt] [-p] in1.sam [in2.sam ...]
  * prints one line per column with every bam_pileup1_t field, in the format of the oracle's `plpdump`.
+ *   plp_client -M | -N [-x] in.sam
+ * prints `mpileup -Q0 --output-mods` lines instead (-N: with --no-output-ins-mods), the way bam_plcmd.c does it: a modification state per
+ * read through the iterator's constructor hook (bam_plcmd.c:356-369: hts_base_mod_state_alloc + bam_parse_basemod), bam_mods_at_qpos behind
+ * every base (:86-109), bam_plp_insertion_mod with the live state (:119).  For that the record source also keeps the MM:Z / ML:B:C fields.
  */
 #define _POSIX_C_SOURCE 200809L
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <ctype.h>
 #include "samtools_amd_plp.h"
 
 typedef struct {
@@ -61,9 +66,9 @@ static const char NT16[] = "=ACMGRSVTWYHKDBN";
 static int read_cb(void *data, bam1_t *b)
 {
     src_t *s = (src_t *)data;
-    char *f[11], *p;
+    char *f[11], *p, *mm = NULL, *ml = NULL;
     int i, n_cig = 0;
-    size_t l_qn, pad, l_seq, need;
+    size_t l_qn, pad, l_seq, need, l_aux = 0, n_ml = 0;
     uint8_t *d;
     if (s->have_line) s->have_line = 0;
     else if (getline(&s->line, &s->cap, s->fp) <= 0) return -1;
@@ -74,10 +79,23 @@ static int read_cb(void *data, bam1_t *b)
         if (*p == 0 && i < 10) return -2;
         if (*p) *p++ = 0;
     }
+    /* optional fields: only the two base-modification tags are kept (BAM aux encoding: MM Z string NUL, ML B C count values) */
+    while (*p) {
+        char *t = p;
+        p += strcspn(p, "\t\n");
+        if (*p) *p++ = 0;
+        if ((strncmp(t, "MM:Z:", 5) == 0 || strncmp(t, "Mm:Z:", 5) == 0) && !mm) { mm = t + 5; l_aux += 3 + strlen(mm) + 1; }
+        else if ((strncmp(t, "ML:B:C", 6) == 0 || strncmp(t, "Ml:B:C", 6) == 0) && !ml) {
+            char *q;
+            ml = t + 6;
+            for (q = ml; *q; ++q) if (*q == ',') ++n_ml;
+            l_aux += 3 + 1 + 4 + n_ml;
+        }
+    }
     if (strcmp(f[5], "*") != 0) for (p = f[5]; *p; ++p) if (*p < '0' || *p > '9') ++n_cig;
     l_qn = strlen(f[0]) + 1; pad = (4 - (l_qn & 3)) & 3;
     l_seq = strcmp(f[9], "*") == 0 ? 0 : strlen(f[9]);
-    need = l_qn + pad + 4 * (size_t)n_cig + (l_seq + 1) / 2 + l_seq;
+    need = l_qn + pad + 4 * (size_t)n_cig + (l_seq + 1) / 2 + l_seq + l_aux;
     if (b->m_data < need) { b->data = (uint8_t *)realloc(b->data, need); b->m_data = (uint32_t)need; }
     b->l_data = (int)need;
     b->core.tid = strcmp(f[2], "*") == 0 ? -1 : tid_of(s, f[2]);
@@ -108,6 +126,13 @@ static int read_cb(void *data, bam1_t *b)
     d += (l_seq + 1) / 2;
     if (strcmp(f[10], "*") == 0) memset(d, 0xff, l_seq);
     else { if (strlen(f[10]) != l_seq) return -2; for (i = 0; i < (int)l_seq; ++i) d[i] = (uint8_t)(f[10][i] - 33); }
+    d += l_seq;
+    if (mm) { size_t l = strlen(mm); d[0] = 'M'; d[1] = 'M'; d[2] = 'Z'; memcpy(d + 3, mm, l + 1); d += 3 + l + 1; }
+    if (ml) {
+        uint32_t n32 = (uint32_t)n_ml;
+        d[0] = 'M'; d[1] = 'L'; d[2] = 'B'; d[3] = 'C'; memcpy(d + 4, &n32, 4); d += 8;
+        for (p = ml; *p == ','; ) { char *q; *d++ = (uint8_t)strtoul(p + 1, &q, 10); p = q; }
+    }
     return 0;
 }
 
@@ -136,6 +161,69 @@ static int plbuf_cb(uint32_t tid, hts_pos_t pos, int n, const bam_pileup1_t *pl,
     return 0;
 }
 
+/* ---- mpileup --output-mods through the drop-in names ---- */
+static int mod_enter(void *data, const bam1_t *b, bam_pileup_cd *cd)
+{
+    hts_base_mod_state *m = hts_base_mod_state_alloc();
+    (void)data;
+    cd->p = m;
+    return m ? bam_parse_basemod(b, m) : -1;
+}
+static int mod_leave(void *data, const bam1_t *b, bam_pileup_cd *cd) { (void)data; (void)b; hts_base_mod_state_free((hts_base_mod_state *)cd->p); return 0; }
+
+static void put_mods(FILE *out, const hts_base_mod *mod, int nm)
+{
+    int j;
+    fputc('[', out);
+    for (j = 0; j < nm && j < 256; ++j) {
+        if (mod[j].modified_base < 0) fprintf(out, "%c(%d)", "+-"[mod[j].strand], -mod[j].modified_base);
+        else fprintf(out, "%c%c", "+-"[mod[j].strand], mod[j].modified_base);
+        if (mod[j].qual >= 0) fprintf(out, "%d", mod[j].qual);
+    }
+    fputc(']', out);
+}
+
+/* one column as `mpileup -Q0 --output-mods [--no-output-ins-mods]` prints it without a reference: name, position, N, depth, bases, qualities */
+static int print_mods_line(FILE *out, const char *name, hts_pos_t pos, int n, const bam_pileup1_t *plp, int no_ins_mods)
+{
+    int i, j;
+    fprintf(out, "%s\t%lld\tN\t%d\t", name, (long long)pos + 1, n);
+    if (n == 0) { fputs("*\t*\n", out); return 0; }
+    for (i = 0; i < n; ++i) {
+        const bam_pileup1_t *p = &plp[i];
+        hts_base_mod_state *m = (hts_base_mod_state *)p->cd.p;
+        const int rev = (p->b->core.flag & 16) != 0;
+        int del_len = -p->indel;
+        if (p->is_head) { fputc('^', out); fputc(p->b->core.qual > 93 ? 126 : p->b->core.qual + 33, out); }
+        if (!p->is_del) {
+            hts_base_mod mod[256];
+            int nm, c = p->qpos < p->b->core.l_qseq ? bam_seqi(bam_get_seq(p->b), p->qpos) : 15;
+            fputc(rev ? ",acmgrsvtwyhkdbn"[c] : ".ACMGRSVTWYHKDBN"[c], out);
+            if (m && (nm = bam_mods_at_qpos(p->b, p->qpos, m, mod, 256)) > 0) put_mods(out, mod, nm);
+        } else fputc(p->is_refskip ? (rev ? '<' : '>') : '*', out);
+        if (p->indel > 0) {
+            int in_mod = 0, len = bam_plp_insertion_mod(p, m && !no_ins_mods ? m : NULL, &g_ins, &del_len);
+            if (len < 0) return -1;
+            fprintf(out, "+%d", len);
+            for (j = 0; j < (int)g_ins.l; ++j) {
+                const char ch = g_ins.s[j];
+                if (ch == '[') in_mod = 1; else if (ch == ']') in_mod = 0;
+                fputc(in_mod || ch == '[' || ch == ']' ? ch : (rev ? tolower((unsigned char)ch) : toupper((unsigned char)ch)), out);
+            }
+        }
+        if (del_len > 0) { fprintf(out, "-%d", del_len); for (j = 0; j < del_len; ++j) fputc(rev ? 'n' : 'N', out); }
+        if (p->is_tail) fputc('$', out);
+    }
+    fputc('\t', out);
+    for (i = 0; i < n; ++i) {
+        const bam_pileup1_t *p = &plp[i];
+        int q = p->qpos < p->b->core.l_qseq ? bam_get_qual(p->b)[p->qpos] : 0;
+        fputc(q + 33 > 126 ? 126 : q + 33, out);
+    }
+    fputc('\n', out);
+    return 0;
+}
+
 /* constructor / destructor hooks (bam_plcmd.c:356-369, bedcov.c:71-75): count the reads that enter and leave */
 static long g_ctor = 0, g_dtor = 0;
 static int on_enter(void *data, const bam1_t *b, bam_pileup_cd *cd) { (void)data; (void)b; cd->i = ++g_ctor; return 0; }
@@ -143,11 +231,13 @@ static int on_leave(void *data, const bam1_t *b, bam_pileup_cd *cd) { (void)data
 
 int main(int argc, char **argv)
 {
-    int overlaps = 1, push = 0, maxcnt = 8000, a = 1, n, i, ret = 0;
+    int overlaps = 1, push = 0, maxcnt = 8000, a = 1, n, i, ret = 0, mods = 0;
     src_t *src; void **data;
     for (; a < argc && argv[a][0] == '-' && argv[a][1]; ++a) {
         if (!strcmp(argv[a], "-x")) overlaps = 0;
         else if (!strcmp(argv[a], "-p")) push = 1;
+        else if (!strcmp(argv[a], "-M")) mods = 1;
+        else if (!strcmp(argv[a], "-N")) mods = 2;
         else if (!strcmp(argv[a], "-d") && a + 1 < argc) maxcnt = atoi(argv[++a]);
         else return 2;
     }
@@ -178,9 +268,13 @@ int main(int argc, char **argv)
         if (!it) { fprintf(stderr, "plp_client: bam_mplp_init failed (no HIP device?)\n"); return 3; }
         if (overlaps) bam_mplp_init_overlaps(it);
         bam_mplp_set_maxcnt(it, maxcnt);
-        bam_mplp_constructor(it, on_enter);
-        bam_mplp_destructor(it, on_leave);
+        bam_mplp_constructor(it, mods ? mod_enter : on_enter);
+        bam_mplp_destructor(it, mods ? mod_leave : on_leave);
         while ((r = bam_mplp64_auto(it, &tid, &pos, n_plp, plp)) > 0) {
+            if (mods) {
+                if (tid < 0 || tid >= src[0].n_names || print_mods_line(stdout, src[0].names[tid], pos, n_plp[0], plp[0], mods == 2) < 0) { ret = 1; break; }
+                continue;
+            }
             printf("%d\t%lld", tid, (long long)pos);
             for (i = 0; i < n; ++i) print_entries(stdout, n_plp[i], plp[i]);
             fputc('\n', stdout);

@@ -78,7 +78,9 @@ def test_unsorted_input_is_filtered_to_its_last_record(tmp_path):
     assert n_s > 10 and n_u == n_s
 
 
-def test_an_index_older_than_its_data_file_is_not_used(bam, tmp_path):
+def test_an_index_older_than_its_data_file_is_used_with_a_warning(bam, tmp_path, capfd):
+    """HTSlib warns about an index older than its data file and uses it all the same (copied or checked-out data often carries time
+    stamps the wrong way round): so do the drivers (round 5; round 4 fell back to a whole-file read)."""
     import shutil
     from samtools_amd import _capi
     b2 = str(tmp_path / "y.bam")
@@ -86,4 +88,5 @@ def test_an_index_older_than_its_data_file_is_not_used(bam, tmp_path):
     os.utime(b2 + ".bai", (1, 1))                                 # the index is "from 1970", the data file is new
     n_ix, h_ix, used = _capi.io_scan_region(b2, "c3:100000-199999", threads=2, use_index=True)
     n_fs, h_fs, _ = _capi.io_scan_region(bam, "c3:100000-199999", threads=2, use_index=False)
-    assert (n_ix, h_ix) == (n_fs, h_fs) and not used
+    assert (n_ix, h_ix) == (n_fs, h_fs) and used
+    assert "older than the data file" in capfd.readouterr().err

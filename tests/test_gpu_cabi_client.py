@@ -54,6 +54,56 @@ def test_external_client_depth_cap_and_window_sizes(tmp_path, oracle_bin, client
         _diff(oracle_bin, client, [sam], {"STA_PLP_BATCH": batch} if batch else None)
 
 
+@pytest.mark.parametrize("flag,golden", [("-M", "mp2.out"), ("-N", "mp2-noins.out")], ids=["output_mods", "no_output_ins_mods"])
+def test_external_client_prints_the_reference_mods_goldens(client, flag, golden):
+    """`mpileup -x -Q0 --output-mods [--no-output-ins-mods] mod1.sam` (mpileup.reg: mp2.out, mp2-noins.out) reproduced by the EXTERNAL
+    client through the drop-in names alone: a modification state per read from the constructor hook (hts_base_mod_state_alloc +
+    bam_parse_basemod, bam_plcmd.c:356-369), bam_mods_at_qpos behind every base (:86-109), bam_plp_insertion_mod with the live state
+    (:119).  The expected text is the reference's own file."""
+    want = open(os.path.join(G, "mpileup", "expected", golden), "rb").read()
+    got = subprocess.run([client, flag, "-x", os.path.join(G, "mpileup", "mod1.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 0, got.stderr.decode()[-500:]
+    if got.stdout != want:
+        for i, (a, b) in enumerate(zip(got.stdout.split(b"\n"), want.split(b"\n"))):
+            assert a == b, "line %d differs\n got: %r\nwant: %r" % (i + 1, a[:300], b[:300])
+    assert got.stdout == want
+    assert b"[+m" in want and b"+3" in want
+
+
+def test_insertion_mod_refuses_a_state_that_was_never_parsed(tmp_path):
+    """a state straight from hts_base_mod_state_alloc (never handed to bam_parse_basemod) must not read as "no modifications": < 0"""
+    src = tmp_path / "t.c"
+    src.write_text("""
+#include <stdio.h>
+#include <string.h>
+#include "samtools_amd_plp.h"
+int main(void) {
+    hts_base_mod_state *m = hts_base_mod_state_alloc();
+    bam1_t b; bam_pileup1_t p; kstring_t ks = {0, 0, NULL}; int dl = 0;
+    unsigned char data[32];
+    memset(&b, 0, sizeof b); memset(&p, 0, sizeof p); memset(data, 0, sizeof data);
+    b.data = data; b.l_data = 16; b.core.l_qname = 4; b.core.n_cigar = 2; b.core.l_qseq = 2;
+    ((uint32_t *)(data + 4))[0] = 1u << 4 | 0; ((uint32_t *)(data + 4))[1] = 1u << 4 | 1;      /* 1M1I */
+    p.b = &b; p.indel = 1; p.cigar_ind = 0;
+    if (!m) return 2;
+    printf("%d\\n", bam_plp_insertion_mod(&p, m, &ks, &dl) < 0 ? 1 : 0);
+    if (bam_parse_basemod(&b, m) != 0) return 3;
+    printf("%d\\n", bam_plp_insertion_mod(&p, m, &ks, &dl));
+    hts_base_mod_state_free(m);
+    return 0;
+}
+""")
+    exe = str(tmp_path / "t")
+    lib = os.path.join(os.path.dirname(G), "..", "samtools_amd", "lib")
+    lib = os.path.abspath(lib)
+    subprocess.run(["gcc", "-std=c99", "-DSTA_PLP_DROPIN", "-I", os.path.join(os.path.dirname(lib), "..", "include"), str(src), "-L", lib, "-lsamtools_amd",
+                    "-Wl,-rpath," + lib, "-o", exe], check=True)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    assert p.stdout.split() == [b"1", b"1"], p.stdout            # refused; after parsing: one inserted base
+    assert b"bam_parse_basemod" in p.stderr
+
+
 # ---- the consensus iterator: pileup_loop() (include/samtools_amd_cons.h) from an external C99 client ----
 
 @pytest.fixture(scope="module")

@@ -166,6 +166,39 @@ def test_indexed_and_unindexed_sharded_and_region_runs_agree(tmp_path, product_b
             assert _sharded(product_bin, cmd + ["-r", reg, bam], 2) == rwant, (cmd, reg)
 
 
+def test_customized_index_names_the_index_files(tmp_path, product_bin, oracle_bin, rich):
+    """-X / --customized-index (bam_plcmd.c:1190,1243-1262; bam2depth.c:873-911): the second half of the file arguments names the index of
+    each input.  The indexes live in another directory under other names; region runs of one and of two inputs give the oracle's text,
+    and a trace of the reader's start shows the named index was used (STA_NO_INDEX=1 gives the same text from a whole-file read)."""
+    import shutil
+    from bamio import sam_to_bam, write_bai
+    sam, fa = rich
+    bam = sam_to_bam(sam, str(tmp_path / "x.bam"), block=9000)
+    write_bai(bam)
+    os.mkdir(str(tmp_path / "idx"))
+    ix1 = str(tmp_path / "idx" / "first.index"); ix2 = str(tmp_path / "idx" / "second.index")
+    shutil.move(bam + ".bai", ix1); shutil.copy(ix1, ix2)
+    bam2 = str(tmp_path / "x2.bam"); shutil.copy(bam, bam2)
+    for cmd in (["mpileup", "-f", fa], ["depth", "-aa"]):
+        for reg in ("c2:3000-9000", "c3:44000"):
+            want1 = subprocess.run([oracle_bin] + cmd + ["-r", reg, sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+            want2 = subprocess.run([oracle_bin] + cmd + ["-r", reg, sam, sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+            assert _run(product_bin, cmd + ["-r", reg, "-X", bam, ix1]) == want1, (cmd, reg)
+            long_name = "--customized-index" if cmd[0] == "mpileup" else "-X"       # (depth has only the short form: bam2depth.c:873)
+            assert _run(product_bin, cmd + ["-r", reg, long_name, bam, bam2, ix1, ix2]) == want2, (cmd, reg)
+            assert _run(product_bin, cmd + ["-r", reg, "-X", bam, ix1], {"STA_NO_INDEX": "1"}) == want1
+    # an odd number of names is refused, as is -X with a file list
+    p = subprocess.run([product_bin, "mpileup", "-X", bam, bam2, ix1], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"Odd number of filenames" in p.stderr
+    lst = str(tmp_path / "list.txt"); open(lst, "w").write(bam + "\n")
+    p = subprocess.run([product_bin, "mpileup", "-X", "-b", lst], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"cannot be combined with -X" in p.stderr
+    # a file that is not a BAI: a warning, and the whole file is read (same text)
+    want = subprocess.run([oracle_bin, "depth", "-r", "c2:3000-9000", sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    p = subprocess.run([product_bin, "depth", "-r", "c2:3000-9000", "-X", bam, fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and p.stdout == want and b"could not load the index" in p.stderr
+
+
 @pytest.mark.parametrize("cmd", [["mpileup", "-f", "{fa}"], ["mpileup", "-B", "-aa", "-f", "{fa}"], ["depth", "-H", "-aa"], ["depth", "-s", "-J"]],
                          ids=lambda c: "_".join(x for x in c if not x.startswith("{")))
 def test_device_capture_is_the_host_capture(pairs, cmd):

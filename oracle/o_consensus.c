@@ -940,8 +940,19 @@ err:
 }
 
 /* bam_consensus.c:674-738 (named tables other than :flat are not restated) */
+#include "o_qcal_tables.inc"      /* the platform tables as data (scripts/gen_qcal_tables.py; bam_consensus.c:446-662) */
+
+/* bam_consensus.c:664-670 */
+static int set_qcal(qcal_t *q, int id)
+{
+    if (id < 0 || id >= 6) return -1;
+    memcpy(q->smap, QCAL_TABLES[id][0], sizeof q->smap); memcpy(q->umap, QCAL_TABLES[id][1], sizeof q->umap); memcpy(q->omap, QCAL_TABLES[id][2], sizeof q->omap);
+    return 0;
+}
+
 static int load_qcal(qcal_t *q, const char *fn)
 {
+    for (int id = 1; id < 6; id++) if (fn[0] == ':' && strcmp(fn + 1, QCAL_NAMES[id]) == 0) return set_qcal(q, id);      /* :672-686 */
     for (int i = 0; i < 101; i++) q->smap[i] = q->umap[i] = q->omap[i] = i;
     if (strcmp(fn, ":flat") == 0) return 0;
     if (fn[0] == ':') { fprintf(stderr, "oracle consensus: calibration table %s is not restated\n", fn); return -1; }
@@ -974,7 +985,7 @@ int o_main_consensus(int argc, char *argv[])
     o.low_mqual = 1; o.high_mqual = 60; o.min_depth = 1; o.call_fract = 0.75; o.het_fract = 0.5; o.fmt = FMT_FASTA; o.cons_cutoff = 10;
     o.line_len = 70; o.default_qual = 10; o.show_ins = 1; o.excl_flags = F_UNMAP | F_SECONDARY | F_QCFAIL | F_DUP;
     o.P_het = 1e-3; o.P_indel = 2e-4; o.het_scale = 1.0; o.homopoly_redux = 0.01; o.out = stdout;
-    load_qcal(&o.qcal, ":flat");
+    set_qcal(&o.qcal, 0);                   /* bam_consensus.c:3196 */
 
     static const struct option lopts[] = {
         { "use-qual", no_argument, NULL, 'q' }, { "no-use-qual", no_argument, NULL, 'q' + 1000 }, { "adj-qual", no_argument, NULL, 'q' + 100 },
@@ -1054,7 +1065,19 @@ int o_main_consensus(int argc, char *argv[])
             else { fprintf(stderr, "Unknown format %s\n", optarg); return 1; }
             break;
         case 'o': if (!(o.out = fopen(optarg, "w"))) { perror(optarg); return 1; } break;
-        case 'X': fprintf(stderr, "oracle consensus: -X %s needs the platform calibration tables, which are not restated\n", optarg); return 1;
+        case 'X':      /* bam_consensus.c:3366-3421 */
+            if (strcasecmp(optarg, "hifi") == 0) {
+                set_qcal(&o.qcal, 1); o.mode = MODE_RECALL; o.homopoly_fix = 0.3; o.homopoly_redux = 0.01; o.low_mqual = 5; o.scale_mqual = 1.5; o.het_scale = 0.37;
+            } else if (strcasecmp(optarg, "hiseq") == 0) {
+                o.mode = MODE_RECALL; set_qcal(&o.qcal, 2); o.homopoly_redux = 0.01;
+            } else if (strcasecmp(optarg, "r10.4_sup") == 0) {
+                set_qcal(&o.qcal, 3); o.mode = MODE_RECALL; o.homopoly_fix = 0.3; o.homopoly_redux = 0.01; o.low_mqual = 5; o.scale_mqual = 1.5; o.het_scale = 0.37;
+            } else if (strcasecmp(optarg, "r10.4_dup") == 0) {
+                set_qcal(&o.qcal, 4); o.mode = MODE_RECALL; o.homopoly_fix = 0.3; o.homopoly_redux = 0.01; o.low_mqual = 5; o.scale_mqual = 1.5; o.het_scale = 0.37;
+            } else if (strcasecmp(optarg, "ultima") == 0) {
+                o.mode = MODE_RECALL; set_qcal(&o.qcal, 5); o.homopoly_fix = 0.3; o.homopoly_redux = 0.01; o.het_scale = 0.37; o.scale_mqual = 2; o.low_mqual = 10;
+            } else { fprintf(stderr, "Unrecognised configuration name: \"%s\"\n", optarg); return 1; }
+            break;
         case 11: if ((o.incl_flags = str2flag(optarg)) < 0) { fprintf(stderr, "samtools consensus: could not parse --rf %s\n", optarg); return 1; } break;
         case 12: if ((o.excl_flags = str2flag(optarg)) < 0) { fprintf(stderr, "samtools consensus: could not parse --ff %s\n", optarg); return 1; } break;
         case 't': if (load_qcal(&o.qcal, optarg) < 0) { fprintf(stderr, "samtools consensus: failed to load quality calibration '%s'\n", optarg); return 1; } break;

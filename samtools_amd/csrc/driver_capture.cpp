@@ -18,9 +18,10 @@ DevCapture *driver_dev_capture() { return t_dev_capture; }
 char *DevCapture::reserve(size_t more)
 {
     if (failed) return nullptr;
-    if (len + more > cap) {
+    // (64 bytes of slack behind the text, like the engine's own output buffer: the emit kernels' 16-byte flush may touch the tail's line)
+    if (len + more + 64 > cap) {
         size_t want = cap ? cap * 2 : (size_t)64 << 20;
-        while (want < len + more) want *= 2;
+        while (want < len + more + 64) want *= 2;
         char *nb = nullptr;
         if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&nb, want) != hipSuccess) { (void)hipGetLastError(); failed = true; return nullptr; }
         // (the emits so far ran on the engine's stream: everything is waited for before the text moves)

@@ -327,11 +327,22 @@ struct Runner {
     }
 };
 
+#include "cons_qcal_tables.inc"
+
+// one of the built-in tables (bam_consensus.c:664-670 set_qcal): 0 flat, 1 hifi, 2 hiseq, 3 r10.4_sup, 4 r10.4_dup, 5 ultima
+int set_qcal(int32_t q[3][101], int id)
+{
+    if (id < 0 || id >= 6) return -1;
+    memcpy(q, QCAL_TABLES[id], sizeof(int32_t) * 3 * 101);
+    return 0;
+}
+
+// --qual-calibration (bam_consensus.c:672-738): ":name" = a built-in table, else a file of "QUAL v sub under over" lines
 int load_qcal(int32_t q[3][101], const char *fn)
 {
+    for (int id = 1; id < 6; ++id) if (fn[0] == ':' && !strcmp(fn + 1, QCAL_NAMES[id])) return set_qcal(q, id);
     for (int i = 0; i < 101; ++i) q[0][i] = q[1][i] = q[2][i] = i;
     if (!strcmp(fn, ":flat")) return 0;
-    if (fn[0] == ':') { fprintf(stderr, "samtools consensus: the built-in calibration table %s is not part of this build\n", fn); return -1; }
     FILE *fp = fopen(fn, "r");
     if (!fp) return -1;
     char line[1024];
@@ -359,7 +370,7 @@ int consensus_cli(int argc, char **argv, const ConsCompute &compute)
     p.mode = STA_CONS_RECALL; p.adj_qual = 1; p.use_mqual = 1; p.scale_mqual = 1.00; p.nm_adjust = 1; p.nm_halo = 50; p.sc_cost = 60;
     p.low_mqual = 1; p.high_mqual = 60; p.min_depth = 1; p.call_fract = 0.75; p.het_fract = 0.5; p.cons_cutoff = 10; p.default_qual = 10;
     p.excl_flags = 4 | 256 | 512 | 1024; p.P_het = 1e-3; p.P_indel = 2e-4; p.het_scale = 1.0; p.homopoly_redux = 0.01;
-    load_qcal(p.qcal, ":flat");
+    set_qcal(p.qcal, 0);                    // (bam_consensus.c:3196: the flat table)
 
     static const struct option lopts[] = {
         { "use-qual", no_argument, NULL, 'q' }, { "no-use-qual", no_argument, NULL, 'q' + 1000 }, { "adj-qual", no_argument, NULL, 'q' + 100 },
@@ -439,7 +450,17 @@ int consensus_cli(int argc, char **argv, const ConsCompute &compute)
             else { fprintf(stderr, "Unknown format %s\n", optarg); return 1; }
             break;
         case 'o': if (!(o.out = fopen(optarg, "w"))) { perror(optarg); return 1; } break;
-        case 'X': fprintf(stderr, "samtools consensus: the -X %s preset needs a platform calibration table that is not part of this build\n", optarg); return 1;
+        case 'X':
+            // --config: the machine profiles of bam_consensus.c:3366-3421 -- a calibration table plus the option values tuned with it
+            if (!strcasecmp(optarg, "hifi") || !strcasecmp(optarg, "r10.4_sup") || !strcasecmp(optarg, "r10.4_dup")) {
+                set_qcal(p.qcal, !strcasecmp(optarg, "hifi") ? 1 : !strcasecmp(optarg, "r10.4_sup") ? 3 : 4);
+                p.mode = STA_CONS_RECALL; p.homopoly_fix = 0.3; p.homopoly_redux = 0.01; p.low_mqual = 5; p.scale_mqual = 1.5; p.het_scale = 0.37;
+            } else if (!strcasecmp(optarg, "hiseq")) {
+                p.mode = STA_CONS_RECALL; set_qcal(p.qcal, 2); p.homopoly_redux = 0.01;
+            } else if (!strcasecmp(optarg, "ultima")) {
+                p.mode = STA_CONS_RECALL; set_qcal(p.qcal, 5); p.homopoly_fix = 0.3; p.homopoly_redux = 0.01; p.het_scale = 0.37; p.scale_mqual = 2; p.low_mqual = 10;
+            } else { fprintf(stderr, "Unrecognised configuration name: \"%s\"\n", optarg); return 1; }
+            break;
         case 11: if ((p.incl_flags = str2flag(optarg)) < 0) { fprintf(stderr, "samtools consensus: could not parse --rf %s\n", optarg); return 1; } break;
         case 12: if ((p.excl_flags = str2flag(optarg)) < 0) { fprintf(stderr, "samtools consensus: could not parse --ff %s\n", optarg); return 1; } break;
         case 't': if (load_qcal(p.qcal, optarg) < 0) { fprintf(stderr, "samtools consensus: failed to load quality calibration '%s'\n", optarg); return 1; } break;

@@ -307,6 +307,12 @@ extern "C" int sta_main_depth(int argc, char **argv)
         }
     }
     seek_readers_by_index(run.readers, fns, *run.h, run.has_reg, run.tid0, run.beg0, run.end0, (int64_t)1 << 20, has_index_file ? &idx_fns : nullptr);      // region / sharded runs start at their first column
+    if (!out_file.empty() && run.dev_cap) {
+        // device capture keeps the window text on the device for the caller: a command that names its own output file would be left with
+        // an empty file and exit status 0 -- refused; samtools_amd/shard.py strips -o before it captures
+        fprintf(stderr, "samtools depth: -o cannot be combined with device capture (sta_main_capture_device): the text is handed to the caller\n");
+        return 1;
+    }
     if (!out_file.empty()) {
         run.out = fopen(out_file.c_str(), "w");
         if (!run.out) { fprintf(stderr, "samtools depth: Cannot open \"%s\" for writing.\n", out_file.c_str()); return 1; }

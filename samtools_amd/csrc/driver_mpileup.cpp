@@ -528,6 +528,12 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     }
     seek_readers_by_index(run.readers, fns, *run.h, run.has_reg, run.tid0, run.beg0, run.end0, (int64_t)1 << 20, has_index_file ? &idx_fns : nullptr);      // region / sharded runs start at their first column
     fprintf(stderr, "[mpileup] %d samples in %d input files\n", (int)sm.sm.size(), (int)fns.size());
+    if (!conf.output_fname.empty() && run.dev_cap) {
+        // device capture keeps the window text on the device for the caller: a command that names its own output file would be left with
+        // an empty file and exit status 0 -- refused; samtools_amd/shard.py strips -o before it captures
+        fprintf(stderr, "[mpileup] -o cannot be combined with device capture (sta_main_capture_device): the text is handed to the caller\n");
+        return 1;
+    }
     if (!conf.output_fname.empty()) {
         run.out = fopen(conf.output_fname.c_str(), "w");
         if (!run.out) { fprintf(stderr, "[mpileup] failed to write to %s: %s\n", conf.output_fname.c_str(), strerror(errno)); return 1; }

@@ -313,6 +313,9 @@ void ChunkReader::work_gpu_feeder()
         cv_ready_.notify_all();
         b.groups.clear(); b.jobs.clear(); b.ticket = -1;
     };
+    // leaving early (the reader is being torn down): the device may still be copying into the page-locked buffers of the batches in flight;
+    // they must not go back to the pool (or be freed) before those copies have landed
+    auto drain = [&] { for (Batch &b : bt) if (b.ticket >= 0 && gpu_) { gpu_->wait(b.ticket, status); b.ticket = -1; } };
     for (int cur = 0; !ended; cur ^= 1) {
         Batch &b = bt[cur];
         finalize(b);                                        // (the batch that used this slot two rounds ago)
@@ -323,7 +326,7 @@ void ChunkReader::work_gpu_feeder()
             {
                 std::unique_lock<std::mutex> lk(out_m_);
                 cv_room_.wait(lk, [this] { return stop_ || next_in_ - next_out_ < max_ahead_; });
-                if (stop_) return;
+                if (stop_) { drain(); return; }
             }
             MGroup g;
             if (!cut_group(g, &end_status)) { ended = true; break; }
@@ -340,7 +343,7 @@ void ChunkReader::work_gpu_feeder()
                 // (a started batch goes out when the window of groups in flight is full: its groups are what the consumer waits for)
                 if (next_in_ - next_out_ >= max_ahead_ && !b.groups.empty()) break;
                 cv_room_.wait(lk, [this] { return stop_ || next_in_ - next_out_ < max_ahead_; });
-                if (stop_) return;
+                if (stop_) { drain(); return; }
             }
             MGroup g;
             if (!cut_group(g, &end_status)) { ended = true; break; }

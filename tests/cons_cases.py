@@ -26,6 +26,15 @@ OPTION_SETS = [
     ["-f", "fasta", "-l", "60", "-C", "25", "--P-het", "0.01", "--P-indel", "0.001"],
     ["-f", "pileup", "-t", QCAL],                       # --qual-calibration file (bam_consensus.c:674-738)
     ["-m", "bayesian_m", "-f", "fastq", "-t", QCAL],
+    # round 5: the machine profiles (-X / --config, bam_consensus.c:3366-3421) and the named calibration tables (:672-686).  The
+    # reference holds no expected file for them: engine == oracle on the same tables (scripts/gen_qcal_tables.py)
+    ["-f", "pileup", "-X", "hifi"],
+    ["-f", "fastq", "-X", "hiseq"],
+    ["-f", "pileup", "--config", "r10.4_sup"],
+    ["-f", "fastq", "-X", "r10.4_dup"],
+    ["-f", "pileup", "-X", "ultima"],
+    ["-f", "pileup", "-t", ":hiseq"],
+    ["-m", "bayesian_m", "-f", "fastq", "-t", ":ultima"],
 ]
 
 

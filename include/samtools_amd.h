@@ -348,7 +348,11 @@ int sta_glf_consensus(const sta_glf_col *c, char ref_base, char *call_char);
 #define STA_CALMD_EXTENDED  4    /* -E */
 #define STA_CALMD_USE_EQUAL 8    /* -e: matching bases become '=' */
 #define STA_CALMD_BIN_QUAL  16   /* -q */
-typedef struct sta_calmd_params { int32_t flag; int32_t max_nm; /* -n, 0 = off */ } sta_calmd_params;
+typedef struct sta_calmd_params {
+    int32_t flag; int32_t max_nm; /* -n, 0 = off */
+    int32_t capQ;                 /* -C: > 10 = sam_cap_mapq's coefficient (bam_md.c:480-483): the caps are computed on the qualities the record
+                                     carries after -r [-A], before -q / -n touch them; fetch with sta_fetch_calmd_mapq_cap */
+} sta_calmd_params;
 #define STA_CALMD_HAS_MD    1    /* state[]: NM / MD are valid (mapped record with a sequence on a contig that has a reference) */
 #define STA_CALMD_NEW_TAG   2    /*          BAQ was computed: tag[] holds the BQ:Z (or, with -A, ZQ:Z) string               */
 #define STA_CALMD_BQ_TO_ZQ  4    /*          an existing BQ:Z was applied to the qualities (realn.c renames it ZQ:Z)          */
@@ -359,6 +363,9 @@ int sta_calmd_plan(sta_engine *e, const sta_calmd_params *p, sta_plan_info *info
  * sequence and tag pools in the staged layout (sta_reads.base_off8; seq at half the byte offset). */
 int sta_fetch_calmd(sta_engine *e, int32_t *nm, uint64_t *md_off, char *md_text, uint8_t *state, uint8_t *qual_pool,
                     uint8_t *seq_pool, uint8_t *tag_pool);
+/* cap[n]: sam_cap_mapq of every read of the planned window (-1: the read's mismatch score is beyond the coefficient); only after a plan
+ * with capQ > 10.  calmd then does `if (b->core.qual > q) b->core.qual = q` (a -1 lands in the unsigned field as 255). */
+int sta_fetch_calmd_mapq_cap(sta_engine *e, int16_t *cap);
 
 /* ---- consensus: `samtools consensus`' own column iterator (consensus_pileup.c:69-608: one column per
  * reference position plus one per inserted base, pads for the reads without the insertion) and its two callers, the

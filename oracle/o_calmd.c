@@ -15,8 +15,8 @@
  * `calmd in.sam ref.fa` to reproduce test/dat/mpileup.{1,2,3}.sam themselves (1 034 mapped records).  The BQ/ZQ strings are
  * pinned only through o_baq.c's mpileup goldens (qualities after BAQ), not as tags.
  *
- * Output: SAM text with the input's header (no @PG line is added: as --no-PG).  -b / -u (BAM output) and -C (its use of
- * sam_cap_mapq's -1 return is a quirk outside the BAQ/MD rows) are refused.
+ * Output: SAM text with the input's header (no @PG line is added: as --no-PG).  -b / -u (BAM output) are refused.  -C (round 5) lowers
+ * MAPQ by sam_cap_mapq as bam_md.c:480-483 does, -1 return included (it lands in the unsigned field as 255).
  */
 #include "o_plp.h"
 #include <ctype.h>
@@ -178,7 +178,7 @@ static int put_sam_record(ostr_t *o, const ohdr_t *h, const orec_t *b, const ost
 
 int o_main_calmd(int argc, char *argv[])
 {
-    int c, flt_flag = UPDATE_NM | UPDATE_MD, is_realn = 0, baq_flag = 0, max_nm = 0, quiet = 0;
+    int c, flt_flag = UPDATE_NM | UPDATE_MD, is_realn = 0, baq_flag = 0, max_nm = 0, quiet = 0, capQ = 0;
     static const struct option lopts[] = { { "no-PG", no_argument, NULL, 1 }, { NULL, 0, NULL, 0 } };
     optind = 1;
     while ((c = getopt_long(argc, argv, "EqQreuNhbSC:n:Ad", lopts, NULL)) >= 0) {
@@ -191,6 +191,7 @@ int o_main_calmd(int argc, char *argv[])
         case 'E': baq_flag |= 2; break;
         case 'q': flt_flag |= BIN_QUAL; break;
         case 'n': max_nm = atoi(optarg); break;
+        case 'C': capQ = atoi(optarg); break;
         case 'Q': quiet = 1; break;
         case 'h': case 'S': case 1: break;
         default: fprintf(stderr, "[calmd] option -%c is not part of the restated rows\n", c); return 1;
@@ -220,7 +221,7 @@ int o_main_calmd(int argc, char *argv[])
                 last_tid = b.tid;
                 if (!ref) {
                     fprintf(stderr, "[bam_fillmd] fail to find sequence '%s' in the reference.\n", h->name[b.tid]);
-                    if (is_realn) { ret = 1; break; }
+                    if (is_realn || capQ > 10) { ret = 1; break; }     /* bam_md.c:471 */
                 }
             }
             if (is_realn) {
@@ -241,6 +242,10 @@ int o_main_calmd(int argc, char *argv[])
                         app_tag(&extra, (baq_flag & 1) ? "ZQ" : "BQ", 'Z', q0, (size_t)b.l_qseq + 1);
                     } else if (b.l_qseq) memcpy(b.qual, q0, (size_t)b.l_qseq);
                 }
+            }
+            if (capQ > 10) {            /* bam_md.c:480-483; a -1 lands in the unsigned field as 255 */
+                int q = o_cap_mapq(&b, ref, ref_len, capQ);
+                if ((int)b.mapq > q) b.mapq = (uint8_t)q;
             }
             if (ref) {
                 if (b.l_qseq == 0 && !quiet)

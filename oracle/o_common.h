@@ -126,4 +126,7 @@ extern const int nt16_int[16];
 
 int str2flag(const char *s);           /* bam_str2flag */
 
+/* o_mpileup.c: HTSlib realn.c sam_cap_mapq */
+int o_cap_mapq(orec_t *b, const char *ref, hpos_t ref_len, int thres);
+
 #endif

@@ -68,8 +68,9 @@ static int mplp_get_ref(mplp_aux_t *ma, int tid, const char **ref, hpos_t *ref_l
     return 1;
 }
 
-/* HTSlib realn.c sam_cap_mapq (-C); parity UNPINNED: no reference golden uses -C */
-static int o_cap_mapq(orec_t *b, const char *ref, hpos_t ref_len, int thres)
+/* HTSlib realn.c sam_cap_mapq (mpileup -C, calmd -C).  No reference golden uses -C; tests/test_cap_mapq_vectors.py pins the clip term, the
+ * square root, the drop rule and the sign of the M term on vectors derived by hand from doc/samtools-mpileup.1:228-242 */
+int o_cap_mapq(orec_t *b, const char *ref, hpos_t ref_len, int thres)
 {
     uint8_t *seq = b->seq, *qual = b->qual;
     int i, y, mm, q, len, clip_l, clip_q;

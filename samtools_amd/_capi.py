@@ -100,7 +100,7 @@ class PlanInfo(C.Structure):
 
 
 class CalmdParams(C.Structure):
-    _fields_ = [("flag", C.c_int32), ("max_nm", C.c_int32)]
+    _fields_ = [("flag", C.c_int32), ("max_nm", C.c_int32), ("capQ", C.c_int32)]
 
 
 class GlfParams(C.Structure):
@@ -182,6 +182,7 @@ _PROTOS = {
     "sta_glf_consensus": (C.c_int, [C.POINTER(GlfCol), C.c_char, C.c_char_p]),
     "sta_calmd_plan": (C.c_int, [_P, C.POINTER(CalmdParams), C.POINTER(PlanInfo)]),
     "sta_fetch_calmd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "sta_fetch_calmd_mapq_cap": (C.c_int, [_P, _P]),
     "sta_main_calmd": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_main_glf": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "sta_consensus_run": (C.c_int, [_P, C.POINTER(ConsParams), C.POINTER(ConsInfo)]),
@@ -444,9 +445,9 @@ class Engine:
                                           C.cast(sq, _P) if want_text else None, C.cast(ql, _P) if want_text else None), "sta_fetch_consensus")
         return ins, cols, off, sq, ql
 
-    def calmd_plan(self, flag=0, max_nm=0):
+    def calmd_plan(self, flag=0, max_nm=0, capQ=0):
         """calmd's MD / NM / BAQ-tag arithmetic on file 0 of the staged window; info.out_bytes = MD text bytes."""
-        info, p = PlanInfo(), CalmdParams(flag, max_nm)
+        info, p = PlanInfo(), CalmdParams(flag, max_nm, capQ)
         self._chk(lib.sta_calmd_plan(self._h, C.byref(p), C.byref(info)), "sta_calmd_plan")
         return info
 

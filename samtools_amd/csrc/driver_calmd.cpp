@@ -6,7 +6,7 @@
 // The device computes what changes (NM, the MD string, '=' bases, qualities, the BQ / ZQ string and which of realn.c's tag branches a
 // record took: kernels_md.hip); the host keeps the aux fields as text (host_io.h Rec::auxv) and does the bookkeeping of
 // bam_md.c:156-199 on them -- a tag whose stored value is right stays where it is, a wrong one is removed and the new value appended.
-// Output is SAM with the header (mode "wh"), or BAM with -b (compressed) / -u (stored BGZF blocks) through host_bamout.h; -C is refused.
+// Output is SAM with the header (mode "wh"), or BAM with -b (compressed) / -u (stored BGZF blocks) through host_bamout.h; -C (sam_cap_mapq on the device: k_cap_mapq_vals) lowers the MAPQ field as bam_md.c:480-483 does.
 #include "../../include/samtools_amd.h"
 #include "host_io.h"
 #include "host_bamout.h"
@@ -30,7 +30,7 @@ struct Ctx {
     bool quiet = false, drop_tag = false, update = true;
     std::vector<Rec> batch;
     StagedFile staged;
-    std::vector<int32_t> nm; std::vector<uint64_t> off; std::vector<char> md; std::vector<uint8_t> state, qual, seq, tag;
+    std::vector<int32_t> nm; std::vector<uint64_t> off; std::vector<char> md; std::vector<uint8_t> state, qual, seq, tag; std::vector<int16_t> cap;
     std::string line;
     FILE *out = stdout;
     std::unique_ptr<BamWriter> bam;            // -b / -u
@@ -56,7 +56,10 @@ void put_unchanged(Ctx &c, const Rec &r) { put_record(c, r, r.seq.data(), r.qual
 int flush(Ctx &c, int tid, const std::string *ref)
 {
     if (c.batch.empty()) return 0;
-    if (!ref) { for (const Rec &r : c.batch) put_unchanged(c, r); c.batch.clear(); return 0; }
+    if (!ref) {
+        if (c.cp.capQ > 10) return -1;            // (bam_md.c:471: "Would otherwise crash" -- fatal with -r or -C)
+        for (const Rec &r : c.batch) put_unchanged(c, r); c.batch.clear(); return 0;
+    }
     const bool realn = (c.cp.flag & STA_CALMD_REALN) != 0, apply = (c.cp.flag & STA_CALMD_APPLY) != 0;
     const int64_t origin = c.batch.front().pos;
     int64_t hi = origin + 1;
@@ -81,10 +84,17 @@ int flush(Ctx &c, int tid, const std::string *ref)
     if (sta_fetch_calmd(c.eng, c.nm.data(), c.off.data(), c.md.data(), c.state.data(), c.qual.data(), c.seq.data(), c.tag.data()) != STA_OK) {
         fprintf(stderr, "samtools calmd: %s\n", sta_last_error(c.eng)); return -1;
     }
+    if (c.cp.capQ > 10) {
+        c.cap.resize(n);
+        if (sta_fetch_calmd_mapq_cap(c.eng, c.cap.data()) != STA_OK) { fprintf(stderr, "samtools calmd: %s\n", sta_last_error(c.eng)); return -1; }
+    }
     std::string t;
     for (size_t i = 0; i < n; ++i) {
         Rec &r = c.batch[i];
         const size_t boff = (size_t)c.staged.base_off8[i] << 3;
+        // bam_md.c:480-483: `if (b->core.qual > q) b->core.qual = q;` -- q = -1 (too many mismatches) compares below every quality and is
+        // stored into the unsigned field: 255
+        if (c.cp.capQ > 10 && (int)r.mapq > (int)c.cap[i]) r.mapq = (uint8_t)c.cap[i];
         std::vector<std::string> &aux = r.auxv;
         const uint8_t st = c.state[i];
         if (realn && !(r.flag & 4) && r.l_qseq > 0 && r.qual[0] != 0xff) {
@@ -196,6 +206,7 @@ extern "C" int sta_main_calmd(int argc, char **argv)
         case 'E': c.cp.flag |= STA_CALMD_EXTENDED; break;
         case 'q': c.cp.flag |= STA_CALMD_BIN_QUAL; break;
         case 'n': c.cp.max_nm = atoi(optarg); break;
+        case 'C': c.cp.capQ = atoi(optarg); break;
         case 'd': c.drop_tag = true; break;
         case 'N': c.update = false; break;
         case 'Q': c.quiet = true; break;
@@ -206,7 +217,7 @@ extern "C" int sta_main_calmd(int argc, char **argv)
         default: fprintf(stderr, "[calmd] option -%c is not part of the engine's rows\n", o); return 1;
         }
     }
-    if (argc - optind != 2) { fprintf(stderr, "usage: samtools-amd calmd [-erAEqdNQbu] [-n max_nm] [--no-PG] in.bam ref.fa\n"); return 1; }
+    if (argc - optind != 2) { fprintf(stderr, "usage: samtools-amd calmd [-erAEqdNQbu] [-n max_nm] [-C capQ] [--no-PG] in.bam ref.fa\n"); return 1; }
     if (sta_device_count() < 1) { fprintf(stderr, "samtools calmd: no usable HIP device (the MI355X engine has no CPU fallback)\n"); return 2; }
     std::string err;
     auto rd = AlnReader::open(argv[optind], &err);

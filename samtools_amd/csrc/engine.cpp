@@ -71,7 +71,7 @@ struct sta_engine {
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
     std::vector<char> late_copy;       // mpileup plan, per file: the working quality pool exists only if the window has overlap-eligible reads
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, stage_bad, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, stage_bad, md_cap, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
     DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
@@ -91,6 +91,7 @@ struct sta_engine {
     uint64_t out_bytes = 0;
     uint32_t lds_cap = 0;
     uint64_t n_raw_staged = 0;         // reads whose pools were cut out of raw BAM records on the device (sta_stage_stats)
+    bool md_cap_valid = false;         // the last calmd plan computed sam_cap_mapq values (md_cap)
     bool stage_bad_pending = false;    // the device's verdict on the window's raw records is on its way to stage_bad_h (read behind the next synchronisation)
     unsigned long long stage_bad_h[2] = { 0, 0 };
     bool len_fused = false;            // the measuring kernel also produced offsets / totals (no scan, no column statistics)
@@ -221,7 +222,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &r : e->refs) r.second.buf.release();
     if (e->pin) hipHostFree(e->pin);
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->wfirst, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->stage_bad, &e->chunk_words, &e->cov_out, &e->cov_hist, &e->sc_pos, &e->sc_delta, &e->sc_tmp, &e->sc_cov, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
+                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->stage_bad, &e->md_cap, &e->chunk_words, &e->cov_out, &e->cov_hist, &e->sc_pos, &e->sc_delta, &e->sc_tmp, &e->sc_cov, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
                       &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
@@ -1265,6 +1266,14 @@ int sta_calmd_plan(sta_engine *e, const sta_calmd_params *cp, sta_plan_info *inf
     }
     if (n) {
         if (realn) { ProfScope ps(e, "calmd_tag"); sta_launch_calmd_tag(s, d, apply ? 1 : 0, (uint8_t *)e->md_tag.p, (uint8_t *)e->md_state.p, saved_bq); }
+        if (cp->capQ > 10) {
+            // -C (bam_md.c:480-483): behind the BAQ step and its tag writer -- the qualities are what the record carries now -- and in front
+            // of the MD step, whose -q / -n rewrite them
+            if (!e->wd.ref) return fail(e, STA_ERR_ARG, "calmd -C needs the reference of the contig");
+            if (e->md_cap.ensure(n * 2 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+            ProfScope ps(e, "cap_mapq");
+            sta_launch_cap_mapq_vals(s, d, e->wd, cp->capQ, (int16_t *)e->md_cap.p);
+        }
         { ProfScope ps(e, "md_len"); sta_launch_md_len(s, d, e->wd, (int32_t *)e->md_nm.p, (uint32_t *)e->md_len.p, (uint8_t *)e->md_state.p); }
         { ProfScope ps(e, "len_scan"); sta_launch_len_scan(s, (const uint32_t *)e->md_len.p, (uint64_t *)e->offs.p, (int64_t)n, e->scan_tmp.p, e->scan_tmp.cap); }
     }
@@ -1284,6 +1293,18 @@ int sta_calmd_plan(sta_engine *e, const sta_calmd_params *cp, sta_plan_info *inf
     e->out_bytes = total; e->last_out = e->out.p;
     if (info) { memset(info, 0, sizeof *info); info->out_bytes = total; }
     e->planned = 6;
+    e->md_cap_valid = cp->capQ > 10;
+    return STA_OK;
+}
+
+int sta_fetch_calmd_mapq_cap(sta_engine *e, int16_t *cap)
+{
+    if (!e || !cap) return STA_ERR_ARG;
+    if (e->planned != 6 || !e->md_cap_valid) return fail(e, STA_ERR_ARG, "no calmd plan with capQ > 10");
+    hipSetDevice(e->device);
+    const size_t n = (size_t)e->files_h[0].n;
+    if (n) HIPCHK(hipMemcpyAsync(cap, e->md_cap.p, n * 2, hipMemcpyDeviceToHost, e->stream));
+    SYNC_STREAM();
     return STA_OK;
 }
 

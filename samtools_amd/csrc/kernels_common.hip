@@ -284,6 +284,57 @@ bool sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev 
 // -C / --adjust-MQ: HTSlib realn.c sam_cap_mapq (absent from the reference tree; call site bam_plcmd.c:453-457, run AFTER
 // BAQ, so it sees the BAQ-adjusted qualities).  One thread per read that is still pushed: count mismatches with quality >= 13
 // over the aligned bases, turn them into a cap for the mapping quality, then re-apply the -q filter (bam_plcmd.c:458).
+// sam_cap_mapq for read r: the cap, or -1 when the read's mismatch score exceeds the threshold
+__device__ __forceinline__ int cap_mapq_of(const StaReadsDev &R, const StaWinDev &W, int64_t r, int thres)
+{
+    const uint8_t *qual = R.qual + ((uint64_t)R.base_off8[r] << 3);
+    const uint8_t *seq = R.seq + ((uint64_t)R.base_off8[r] << 2);
+    int mm = 0, q = 0, len = 0, clip_l = 0, clip_q = 0, y = 0;
+    long long x = W.origin + R.pos[r];
+    bool stop = false;
+    if (thres < 0) thres = 40;
+    for (uint32_t k = R.cig_off[r]; k < R.cig_off[r + 1] && !stop; ++k) {
+        int op = R.cigar[k] & 0xf, l = (int)(R.cigar[k] >> 4);
+        if (cg_is_mop(op)) {
+            int j;
+            for (j = 0; j < l; ++j) {
+                int z = y + j;
+                if (x + j >= W.ref_len) break;
+                int c1 = (seq[z >> 1] >> ((~z & 1) << 2)) & 0xf, c2 = nt16_from_char((unsigned char)W.ref[x + j]);
+                if (c2 != 15 && c1 != 15 && qual[z] >= 13) {
+                    ++len;
+                    if (c1 && c1 != c2 && qual[z] >= 13) { ++mm; q += qual[z] > 33 ? 33 : qual[z]; }
+                }
+            }
+            if (j < l) { stop = true; break; }
+            x += l; y += l; len += l;
+        } else if (op == CG_D) {
+            if (x + l > W.ref_len) { stop = true; break; }
+            x += l;
+        } else if (op == CG_S) {
+            for (int j = 0; j < l; ++j) clip_q += qual[y + j];
+            clip_l += l; y += l;
+        } else if (op == CG_H) { clip_q += 13 * l; clip_l += l; }
+        else if (op == CG_I) y += l;
+        else if (op == CG_N) x += l;
+    }
+    (void)clip_l;
+    double t = 1;
+    for (int i = 0; i < mm; ++i) t *= (double)len / (i + 1);
+    t = q - 4.343 * log(t) + clip_q / 5.;
+    if (t > thres) return -1;
+    if (t < 0) t = 0;
+    t = sqrt((thres - t) / thres) * thres;
+    return (int)(t + .499);
+}
+
+// calmd -C (bam_md.c:480-483): the cap of every staged read, for the host to apply to the record's MAPQ field
+__global__ void __launch_bounds__(256) k_cap_mapq_vals(StaReadsDev R, StaWinDev W, int thres, int16_t *cap)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R.n) cap[r] = (int16_t)cap_mapq_of(R, W, r, thres);
+}
+
 __global__ void __launch_bounds__(256) k_cap_mapq(StaReadsDev R, StaWinDev W, int thres, int min_mq, StaCounters *ctr)
 {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,47 +342,7 @@ __global__ void __launch_bounds__(256) k_cap_mapq(StaReadsDev R, StaWinDev W, in
     if (r < R.n) {
         uint32_t info = R.info[r];
         if (info & RI_PUSHED) {
-            const uint8_t *qual = R.qual + ((uint64_t)R.base_off8[r] << 3);
-            const uint8_t *seq = R.seq + ((uint64_t)R.base_off8[r] << 2);
-            int mm = 0, q = 0, len = 0, clip_l = 0, clip_q = 0, y = 0;
-            long long x = W.origin + R.pos[r];
-            bool stop = false;
-            for (uint32_t k = R.cig_off[r]; k < R.cig_off[r + 1] && !stop; ++k) {
-                int op = R.cigar[k] & 0xf, l = (int)(R.cigar[k] >> 4);
-                if (cg_is_mop(op)) {
-                    int j;
-                    for (j = 0; j < l; ++j) {
-                        int z = y + j;
-                        if (x + j >= W.ref_len) break;
-                        int c1 = (seq[z >> 1] >> ((~z & 1) << 2)) & 0xf, c2 = nt16_from_char((unsigned char)W.ref[x + j]);
-                        if (c2 != 15 && c1 != 15 && qual[z] >= 13) {
-                            ++len;
-                            if (c1 && c1 != c2 && qual[z] >= 13) { ++mm; q += qual[z] > 33 ? 33 : qual[z]; }
-                        }
-                    }
-                    if (j < l) { stop = true; break; }
-                    x += l; y += l; len += l;
-                } else if (op == CG_D) {
-                    if (x + l > W.ref_len) { stop = true; break; }
-                    x += l;
-                } else if (op == CG_S) {
-                    for (int j = 0; j < l; ++j) clip_q += qual[y + j];
-                    clip_l += l; y += l;
-                } else if (op == CG_H) { clip_q += 13 * l; clip_l += l; }
-                else if (op == CG_I) y += l;
-                else if (op == CG_N) x += l;
-            }
-            (void)clip_l;
-            double t = 1;
-            for (int i = 0; i < mm; ++i) t *= (double)len / (i + 1);
-            t = q - 4.343 * log(t) + clip_q / 5.;
-            int cap;
-            if (t > thres) cap = -1;
-            else {
-                if (t < 0) t = 0;
-                t = sqrt((thres - t) / thres) * thres;
-                cap = (int)(t + .499);
-            }
+            const int cap = cap_mapq_of(R, W, r, thres);
             int mapq = (int)((info >> RI_MAPQ_SHIFT) & 0xff);
             bool drop = cap < 0;
             if (!drop && mapq > cap) mapq = cap;
@@ -352,6 +363,12 @@ __global__ void __launch_bounds__(256) k_cap_mapq(StaReadsDev R, StaWinDev W, in
     unsigned long long v[2] = { 0ull - d_piled, 0ull - d_kept };
     unsigned long long *const dst[2] = { &ctr->piled_bases, &ctr->n_kept };
     block_reduce_atomic<2, 2>(v, dst);
+}
+
+void sta_launch_cap_mapq_vals(hipStream_t s, const StaReadsDev &R, const StaWinDev &w, int thres, int16_t *cap)
+{
+    if (R.n == 0) return;
+    hipLaunchKernelGGL(k_cap_mapq_vals, dim3((unsigned)((R.n + 255) / 256)), dim3(256), 0, s, R, w, thres, cap);
 }
 
 void sta_launch_cap_mapq(hipStream_t s, const StaReadsDev &R, const StaWinDev &w, int thres, int min_mq, StaCounters *ctr)

@@ -93,6 +93,7 @@ bool sta_launch_prep_reads(hipStream_t s, const StaWinDev &w, const StaReadsDev 
 bool sta_launch_prep_reads_depth(hipStream_t s, const StaWinDev &w, const StaReadsDev *files_host, int nfiles,
                                  const sta_depth_params &p, StaCounters *ctr, StaChunkState &st, void *zero = nullptr, size_t zero_bytes = 0);
 void sta_launch_cap_mapq(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int thres, int min_mq, StaCounters *ctr);
+void sta_launch_cap_mapq_vals(hipStream_t s, const StaReadsDev &R, const StaWinDev &w, int thres, int16_t *cap);
 void sta_launch_qual_prep(hipStream_t s, const StaReadsDev &r, int illumina13);
 void sta_launch_maxend_scan(hipStream_t s, const StaReadsDev &r, void *tmp, size_t tmp_bytes);
 size_t sta_scan_tmp_bytes(int64_t n);

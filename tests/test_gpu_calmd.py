@@ -49,6 +49,27 @@ def test_calmd_equals_oracle_on_synthetic_and_messy_input(tmp_path, oracle_bin, 
             assert got == want, (os.path.basename(src), opts)
 
 
+def test_calmd_cap_mapq(tmp_path, oracle_bin, product_bin):
+    """-C (bam_md.c:480-483: sam_cap_mapq lowers the MAPQ field; a read beyond the coefficient gets -1 = 255 in the unsigned field): alone,
+    behind -r with and without -A (the cap sees the qualities the record carries at that point), with -q / -n (which rewrite qualities
+    only afterwards).  Mismatch-rich reads and the hand-derived vectors of tests/test_cap_mapq_vectors.py (clip term, square root, drop)."""
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=12000, depth=20, read_len=100, seed=43, paired=True, sub_rate=0.04, indel_rate=0.05)
+    changed = 0
+    for opts in (["-C", "50"], ["-C", "40", "-r"], ["-C", "50", "-r", "-A", "-E"], ["-C", "50", "-e", "-q", "-n", "4"], ["-C", "10"]):
+        got, want = run_both(oracle_bin, product_bin, opts + [sam, fa])
+        assert got == want, opts
+        base, _ = run_both(oracle_bin, product_bin, [o for o in opts if o not in ("-C", "50", "40", "10")] + [sam, fa])
+        changed += got != base
+    assert changed >= 4                      # (-C 10 is "off": capQ > 10)
+    import test_cap_mapq_vectors as V
+    vfa, vec = V._write(str(tmp_path))
+    for name, vsam, want_mq in vec:
+        p = subprocess.run([product_bin, "calmd", "-C", "50", "--no-PG", vsam, vfa], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-300:]
+        rec = [l for l in p.stdout.decode().splitlines() if not l.startswith("@")][0].split("\t")
+        assert int(rec[4]) == (255 if want_mq is None else want_mq), name
+
+
 def test_records_that_already_carry_baq_tags(tmp_path, oracle_bin, product_bin):
     """sam_prob_realn's tag branches (HTSlib realn.c): BQ:Z with -A is applied and renamed ZQ:Z, ZQ:Z without -A is taken back
     out of the qualities and renamed BQ:Z, the matching cases are left alone, a record with both loses its ZQ:Z; wrong stored

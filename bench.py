@@ -13,7 +13,7 @@ gather over RCCL (samtools_amd/shard.py) inside the timed step.  Per-GPU work is
 has N x the single-GPU window): weak scaling.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mpileup30|mpileup30_B|mpileup300|mpileup100|mpileup30_EA_pairs|
-                    mpileup30_hotspot|mpileup30_indel|depth30|glf30|calmd30|consensus30 ...]
+                    mpileup30_hotspot|mpileup30_indel|mpileup30_trim|depth30|glf30|calmd30|consensus30 ...]
                     [--verify] [--no-pmc] [--no-cpu-baseline]
 
 Prints ONE JSON line on rank 0.  The CPU oracle appears only as the checker / cpu_baseline leg (rank 0).
@@ -72,6 +72,10 @@ WORKLOADS = {
     "mpileup30_B_hotspot": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-d", "100000", "-f", "{fa}", "{sam}"], gen={"hotspot": (300, 10000)}, flags_off=_REALN, max_depth=100000),
     # BAQ with a real indel spectrum: 5 % of the reads carry a 1-3 bp insertion or deletion (band-8 / general-band kernels under load)
     "mpileup30_indel": _wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True, gen={"indel_rate": 0.05}),
+    # trimmed reads: half of the reads lose 1..50 bases at one end, i.e. fifty-one read lengths side by side (adapter / quality trimming of
+    # real data).  Round 4's class-S grouping (64 consecutive reads of ONE length) sent nearly all of them through the list kernels; the
+    # per-length dense groups of round 5 keep them in k_baq7s
+    "mpileup30_trim": _wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True, gen={"trim_rate": 0.5}),
     # three input files, 10x each (the shape of test/dat/mpileup.out.1): the per-file column groups of bam_plcmd.c:669-857 at bench size
     "mpileup30_3files": _wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True, files=3),
     "mpileup30_B_3files": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN, files=3),
@@ -241,7 +245,7 @@ def make_reads(wl, ref, chunk_cols, seed_reads=42, chunks=None):
         rd = synth_reads(ref, depth=spec["depth"], read_len=150, seed=seed_reads, paired=True)
         rd["_abs_pos"] = rd["_abs_pos"].copy()
         return rd
-    kw = {"indel_rate": g["indel_rate"]} if "indel_rate" in g else {}
+    kw = {k: g[k] for k in ("indel_rate", "trim_rate", "trim_max") if k in g}
     if spec["files"] > 1:
         # one read set per input file, depth / files each, its own seed (single-GPU workloads)
         return [synth_chunked(ref, chunk_cols, depth=spec["depth"] // spec["files"], read_len=150, seed=seed_reads + 1000 * k, chunks=chunks, **kw)

@@ -170,10 +170,12 @@ void sta_bam_plp_set_batch(sta_bam_plp_t iter, int n_records);
 #define bam_plp_destructor sta_bam_plp_destructor
 #define bam_plp_insertion sta_bam_plp_insertion
 #define bam_plp_insertion_mod sta_bam_plp_insertion_mod
+#ifndef STA_PLP_KEEP_HTSLIB_MODS      /* (with HTSlib linked as well: define this to keep its own sam_mods.c calls and state type) */
 #define hts_base_mod_state_alloc sta_hts_base_mod_state_alloc
 #define hts_base_mod_state_free sta_hts_base_mod_state_free
 #define bam_parse_basemod sta_bam_parse_basemod
 #define bam_mods_at_qpos sta_bam_mods_at_qpos
+#endif
 #define bam_mplp_init sta_bam_mplp_init
 #define bam_mplp_destroy sta_bam_mplp_destroy
 #define bam_mplp_set_maxcnt sta_bam_mplp_set_maxcnt

@@ -386,11 +386,17 @@ BQS_HD float log2_fast(float x) { return __builtin_amdgcn_logf(x); }            
 #else
 BQS_HD float log2_fast(float x) { return log2f(x); }
 #endif
+template <class Tab> BQS_HD int map_quality_x(double x, Tab LT);
 template <class Tab>
 BQS_HD int map_quality(double zs, double sum, Tab LT)
 {
     const double mx = zs / sum;
-    const double x = 1. - mx;
+    return map_quality_x(1. - mx, LT);
+}
+// x = 1. - max (the reference's own subtraction, done by the caller)
+template <class Tab>
+BQS_HD int map_quality_x(double x, Tab LT)
+{
     const float va = log2_fast((float)x) * (float)(-4.343 * 0.693147180559945309) + .499f;      // ~ -4.343 ln x + .499, within 1e-4
     int ka = (int)fmaxf(fminf(va, 200.f), 0.f);                  // (x = 0: +inf -> 200; NaN -> 0)
     ka = ka < 1 ? 1 : (ka > 100 ? 100 : ka);

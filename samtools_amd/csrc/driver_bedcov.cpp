@@ -68,7 +68,7 @@ extern "C" int sta_main_bedcov_iter(int argc, char **argv)
     uint32_t flags = 4 | 256 | 512 | 1024;
     static const struct option lopts[] = { { "min-MQ", required_argument, NULL, 'Q' }, { "min-mq", required_argument, NULL, 'Q' },
                                            { "max-depth", required_argument, NULL, 'd' + 1000 }, { NULL, 0, NULL, 0 } };
-    optind = 1;
+    optind = 0;          // (glibc: 0 = full re-initialisation; with 1 a second in-process call resumes at a stale pointer into the PREVIOUS argv)
     while ((c = getopt_long(argc, argv, "Q:g:G:jd:Hc", lopts, NULL)) >= 0) {
         switch (c) {
         case 'Q': min_mapQ = atoi(optarg); break;

@@ -197,7 +197,7 @@ extern "C" int sta_main_calmd(int argc, char **argv)
     bool no_pg = false;
     int bam_level = -1;                        // -1: SAM text
     static const struct option lopts[] = { { "no-PG", no_argument, NULL, 1 }, { NULL, 0, NULL, 0 } };
-    optind = 1;
+    optind = 0;          // (glibc: 0 = full re-initialisation; with 1 a second in-process call resumes at a stale pointer into the PREVIOUS argv)
     while ((o = getopt_long(argc, argv, "EqQreuNhbSC:n:Ad", lopts, NULL)) >= 0) {
         switch (o) {
         case 'e': c.cp.flag |= STA_CALMD_USE_EQUAL; break;

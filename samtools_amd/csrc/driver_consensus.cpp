@@ -392,7 +392,7 @@ int consensus_cli(int argc, char **argv, const ConsCompute &compute)
         { NULL, 0, NULL, 0 } };
     const char *usage = "Usage: samtools consensus [options] <in.bam>\n";
     int c;
-    optind = 1;
+    optind = 0;          // (glibc: 0 = full re-initialisation; with 1 a second in-process call resumes at a stale pointer into the PREVIOUS argv)
     while ((c = getopt_long(argc, argv, "@:qd:c:H:r:5f:C:aAl:o:m:pt:X:T:Z:", lopts, NULL)) >= 0) {
         switch (c) {
         case 'a': o.all_bases++; break;

@@ -220,7 +220,7 @@ extern "C" int sta_main_coverage(int argc, char **argv)
         { "output", required_argument, NULL, 'o' }, { "no-header", no_argument, NULL, 'H' }, { "n-bins", required_argument, NULL, 'w' },
         { "region", required_argument, NULL, 'r' }, { "depth", required_argument, NULL, 'd' }, { "min-depth", required_argument, NULL, 3 },
         { "bam-list", required_argument, NULL, 'b' }, { NULL, 0, NULL, 0 } };
-    optind = 1;
+    optind = 0;          // (glibc: 0 = full re-initialisation; with 1 a second in-process call resumes at a stale pointer into the PREVIOUS argv)
     while ((c = getopt_long(argc, argv, "Ao:l:q:Q:hHw:r:b:md:D", lopts, NULL)) >= 0) {
         switch (c) {
         case 1: if ((required_flags = str2flag(optarg)) < 0) { fprintf(stderr, "Could not parse --rf %s\n", optarg); return 1; } break;
@@ -383,7 +383,7 @@ extern "C" int sta_main_bedcov(int argc, char **argv)
     uint32_t flags = 4 | 256 | 512 | 1024;
     static const struct option lopts[] = { { "min-MQ", required_argument, NULL, 'Q' }, { "min-mq", required_argument, NULL, 'Q' },
                                            { "max-depth", required_argument, NULL, 'd' + 1000 }, { NULL, 0, NULL, 0 } };
-    optind = 1;
+    optind = 0;          // (glibc: 0 = full re-initialisation; with 1 a second in-process call resumes at a stale pointer into the PREVIOUS argv)
     while ((c = getopt_long(argc, argv, "Q:g:G:jd:Hc", lopts, NULL)) >= 0) {
         switch (c) {
         case 'Q': min_mapQ = atoi(optarg); break;

@@ -250,7 +250,7 @@ extern "C" int sta_main_depth(int argc, char **argv)
         { "excl-flags", required_argument, NULL, 'G' }, { "incl-flags", required_argument, NULL, 1 },
         { "require-flags", required_argument, NULL, 2 }, { "threads", required_argument, NULL, '@' },
         { NULL, 0, NULL, 0 } };
-    optind = 1;
+    optind = 0;          // (glibc: 0 = full re-initialisation; with 1 a second in-process call resumes at a stale pointer into the PREVIOUS argv)
     int c, tmp;
     while ((c = getopt_long(argc, argv, "@:q:Q:JHd:m:l:g:G:o:ar:Xf:b:s", lopts, NULL)) >= 0) {
         switch (c) {
@@ -334,6 +334,7 @@ extern "C" int sta_main_depth(int argc, char **argv)
     if (!driver_out_is_borrowed(run.out)) fclose(run.out);
     // (an input without a single window never asked for the engine: a machine without a device is an error all the same)
     if (run.devs.ready() != STA_OK) { if (!run.no_device.exchange(true)) fprintf(stderr, "samtools depth: no usable HIP device (the MI355X engine has no CPU fallback)\n"); ret = 1; }
+    driver_finish_process(ret);       // (the command-line binary: no unwinding; in-process callers go on)
     run.devs.destroy();
     return ret;
 }

@@ -21,7 +21,7 @@ extern "C" int sta_main_glf(int argc, char **argv)
     gp.min_baseQ = 13; gp.max_depth = 8000; gp.theta = 0.83;
     const char *fa_fn = nullptr;
     int c;
-    optind = 1;
+    optind = 0;          // (glibc: 0 = full re-initialisation; with 1 a second in-process call resumes at a stale pointer into the PREVIOUS argv)
     while ((c = getopt(argc, argv, "Q:t:f:")) >= 0) {
         if (c == 'Q') gp.min_baseQ = atoi(optarg);
         else if (c == 't') gp.theta = atof(optarg);

@@ -412,7 +412,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
         { "no-output-del", no_argument, NULL, 12 }, { "no-output-ends", no_argument, NULL, 13 },
         { NULL, 0, NULL, 0 } };
 
-    optind = 1;
+    optind = 0;          // (glibc: 0 = full re-initialisation; with 1 a second in-process call resumes at a stale pointer into the PREVIOUS argv)
     int c;
     while ((c = getopt_long(argc, argv, "Af:r:l:q:Q:RC:Bd:b:o:EG:6OsxXaM", lopts, NULL)) >= 0) {
         switch (c) {
@@ -551,6 +551,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     fflush(run.out);
     if (!driver_out_is_borrowed(run.out)) fclose(run.out);
     if (run.devs.ready() != STA_OK) { if (!run.no_device.exchange(true)) fprintf(stderr, "samtools mpileup: no usable HIP device (the MI355X engine has no CPU fallback)\n"); ret = 1; }
+    driver_finish_process(ret);       // (the command-line binary: no unwinding; in-process callers go on)
     run.devs.destroy();
     return ret;
 }

@@ -60,7 +60,7 @@ extern "C" int sta_main_plpdump(int argc, char **argv)
 {
     bool overlaps = true, push = false;
     int maxcnt = 8000, c;
-    optind = 1;
+    optind = 0;          // (glibc: 0 = full re-initialisation; with 1 a second in-process call resumes at a stale pointer into the PREVIOUS argv)
     while ((c = getopt(argc, argv, "xd:p")) >= 0) {
         if (c == 'x') overlaps = false;
         else if (c == 'd') maxcnt = atoi(optarg);

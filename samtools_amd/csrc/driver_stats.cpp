@@ -270,7 +270,7 @@ extern "C" int sta_main_stats(int argc, char **argv)
         { "trim-quality", required_argument, NULL, 'q' }, { "sparse", no_argument, NULL, 'x' }, { "sam", no_argument, NULL, 's' },
         { "target-regions", required_argument, NULL, 't' }, { "cov-threshold", required_argument, NULL, 'g' },
         { "marks-out", required_argument, NULL, 1 }, { NULL, 0, NULL, 0 } };
-    optind = 1;
+    optind = 0;          // (glibc: 0 = full re-initialisation; with 1 a second in-process call resumes at a stale pointer into the PREVIOUS argv)
     while ((c = getopt_long(argc, argv, "dsxr:c:l:i:m:q:f:F:I:t:g:pS:", lopts, NULL)) >= 0) {
         switch (c) {
         case 'f': if ((tmp = str2flag(optarg)) < 0) { fprintf(stderr, "samtools stats: Unknown flag '%s'\n", optarg); return 1; } flag_require = tmp; break;

@@ -38,11 +38,11 @@ struct FileBufs {
     // device staging (sta_reads.raw_*): the uploaded BAM bytes, the records' offsets in them, the pools built for a verify run
     DevBuf raw, raw_off, raw_vfy;
     // workspace
-    DevBuf qual_work, end, maxend, info, clip, chain, fix_y, fix_mate, fix_q;
+    DevBuf qual_work, end, maxend, info, clip, chain, fix_y, fix_mate, fix_q, slist;
     void release()
     {
         DevBuf *all[] = { &pos, &flag, &mapq, &aux, &lq, &cig_off, &base_off8, &mtid, &mpos, &isize, &name_off, &cigar,
-                          &seq, &qual, &bq, &names, &xoff, &xtext, &moff, &mqpos, &mtoff, &mtext, &raw, &raw_off, &raw_vfy, &qual_work, &end, &maxend, &info, &clip, &chain, &fix_y, &fix_mate, &fix_q };
+                          &seq, &qual, &bq, &names, &xoff, &xtext, &moff, &mqpos, &mtoff, &mtext, &raw, &raw_off, &raw_vfy, &qual_work, &end, &maxend, &info, &clip, &chain, &fix_y, &fix_mate, &fix_q, &slist };
         for (DevBuf *b : all) b->release();
     }
 };
@@ -359,6 +359,7 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
             || b.chain.ensure(n * 4 + 16))
             return fail(e, STA_ERR_HIP, "hipMalloc(workspace) failed");
         d.end = (int32_t *)b.end.p; d.maxend = (int32_t *)b.maxend.p; d.info = (uint32_t *)b.info.p; d.clip = (int32_t *)b.clip.p; d.chain = (int32_t *)b.chain.p;
+        d.s_ws = nullptr;        // (set by the plan when BAQ runs)
         d.qual = const_cast<uint8_t *>(d.qual_in);
     }
     if (any_raw) {
@@ -514,6 +515,17 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
     }
     bool wf_done = false;
     if (e->have_wfirst && e->wfirst.ensure((size_t)((ncols > 0 ? ncols : 1) / 64 + 2) * (size_t)(nf > 0 ? nf : 1) * 4 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(read index) failed");
+    for (int f = 0; f < nf; ++f) {
+        // class-S BAQ: histogram / layout / cursors / list of the candidates (sta_dev.h StaReadsDev::s_ws); the padding of 241 lengths to
+        // whole groups is at most 241 x 63 entries
+        StaReadsDev &d = e->files_h[(size_t)f];
+        d.s_ws = nullptr;
+        if (!realn || !d.n) continue;
+        FileBufs &b = e->fb[(size_t)f];
+        if (b.slist.ensure(((size_t)d.n + 64 * (size_t)STA_SLIST_BINS + STA_SLIST_HEAD) * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(class-S list) failed");
+        d.s_ws = (int32_t *)b.slist.p;
+        HIPCHK(hipMemsetAsync(d.s_ws, 0, (size_t)STA_SLIST_HEAD * 4, s));
+    }
     {
         ProfScope ps(e, "prep_reads");
         wf_done = sta_launch_prep_reads(s, e->wd, e->files_h.data(), nf, *p, ctr, e->chunk_st, e->have_wfirst ? (uint32_t *)e->wfirst.p : nullptr);
@@ -541,8 +553,23 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                 // band-in-registers kernels: groups of 64 reads, one scratch slot (forward rows) per group in flight
                 int gpl = 0;
                 size_t need = sta_baq_band_scratch_bytes(d.n, (int)c.max_lq_fast, &gpl, e->baq_slab_gib_cap);
+                // class S: the histogram of candidate lengths comes back, every length gets its run of whole groups in the list
                 int s_waves = 0;
-                const size_t need_s = c.n_baq_s ? sta_baq7s_scratch_bytes((int)c.max_lq_s, (d.n + 63) / 64, &s_waves) : 0;
+                int64_t s_groups = 0;
+                if (c.n_baq_s && d.s_ws) {
+                    int32_t hist[STA_SLIST_BINS], base[STA_SLIST_BINS];
+                    HIPCHK(hipMemcpyAsync(hist, d.s_ws, sizeof hist, hipMemcpyDeviceToHost, s));
+                    SYNC_S(s);
+                    int64_t at = 0;
+                    for (int l = 0; l < STA_SLIST_BINS; ++l) { base[l] = (int32_t)at; at += ((int64_t)hist[l] + 63) / 64 * 64; }
+                    s_groups = at / 64;
+                    if (at > d.n + 64 * (int64_t)STA_SLIST_BINS) return fail(e, STA_ERR_HIP, "class-S histogram out of range");
+                    HIPCHK(hipMemcpyAsync(d.s_ws + STA_SLIST_BINS, base, sizeof base, hipMemcpyHostToDevice, s));
+                    if (at) HIPCHK(hipMemsetAsync(d.s_ws + STA_SLIST_HEAD, 0xff, (size_t)at * 4, s));
+                    ProfScope ps(e, "baq_s_gather");
+                    sta_launch_baq7s_gather(s, d);
+                }
+                const size_t need_s = s_groups ? sta_baq7s_scratch_bytes((int)c.max_lq_s, s_groups, &s_waves) : 0;
                 if (!c.n_baq_fast) {
                     // nothing is taken in place (class S is on): the band slab only has to hold the list's groups when they run on this stream
                     need = sta_baq_band_scratch_bytes(has_list_band ? (int64_t)n_list : 0, (int)c.max_lq_fast, &gpl, e->baq_slab_gib_cap);
@@ -599,9 +626,9 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                         }
                     }
                 }
-                if (c.n_baq_s) {
+                if (s_groups) {
                     ProfScope ps(e, "baq_s");
-                    sta_launch_baq7s(s, d, e->wd, e->baq_scratch.p, (int)c.max_lq_s, s_waves);
+                    sta_launch_baq7s(s, d, e->wd, e->baq_scratch.p, (int)c.max_lq_s, s_waves, s_groups);
                 }
                 if (side) { HIPCHK(hipStreamWaitEvent(s, e->side_done, 0)); HIPCHK(hipStreamWaitEvent(s, e->side2_done, 0)); }
             }

@@ -18,7 +18,11 @@
 #define EI .25
 #define EM .33333333333
 
-struct BaqTables { float q2p[256]; double lt[104]; };      // g_qual2prob; baq7s::LogTab (the MAP quality's thresholds, baq_band7s.h)
+#include "baq_band7s.h"
+
+// g_qual2prob; the MAP quality's thresholds (baq7s::LogTab, baq_band7s.h: 104 doubles in device memory, NULL = this host's log() did not
+// give a clean step function and the kernels evaluate the formula)
+struct BaqTables { float q2p[256]; const double *lt; };
 
 __device__ __forceinline__ int nt16_int_dev(int c)   // seq_nt16_int
 {
@@ -199,9 +203,13 @@ __global__ void __launch_bounds__(64) k_baq(StaReadsDev R, StaWinDev W, BaqTable
         }
         max /= sum;
         state[(size_t)(i - 1) * 64] = max_k;
-        double v = -4.343 * log(1. - max) + .499;
-        // (int)v with x86 cvttsd2si semantics for out-of-range / NaN (the CPU reference's behaviour)
-        int kq = (v >= 2147483648.0 || v < -2147483648.0 || v != v) ? INT32_MIN : (int)v;
+        int kq;
+        if (T.lt) kq = baq7s::map_quality_x(1. - max, T.lt);        // the exact threshold table (baq_band7s.h), straight from device memory: a rare path
+        else {
+            double v = -4.343 * log(1. - max) + .499;
+            // (int)v with x86 cvttsd2si semantics for out-of-range / NaN (the CPU reference's behaviour)
+            kq = (v >= 2147483648.0 || v < -2147483648.0 || v != v) ? INT32_MIN : (int)v;
+        }
         qq[(size_t)(i - 1) * 64] = (uint8_t)(kq > 100 ? 99 : kq);
     }
     // note: e == 0*b for k >= l_ref keeps the reference's NaN/Inf propagation (cells are finite here)
@@ -504,7 +512,10 @@ __device__ __forceinline__ void baq_fwd_body(const StaReadsDev &R, const StaWinD
 #define BAQ_TABLES_INIT()                                                                                                   \
     __shared__ float q2p[256];                                                                                              \
     __shared__ uint8_t refc[256];                                                                                           \
+    __shared__ double lt_s[baq7s::LT_N];                                                                                    \
+    const bool lt_ok = T.lt != nullptr;                                                                                     \
     for (int k_ = threadIdx.x; k_ < 256; k_ += blockDim.x) { q2p[k_] = T.q2p[k_]; refc[k_] = (uint8_t)nt16_int_dev(nt16_from_char((unsigned char)k_)); } \
+    if (lt_ok) for (int k_ = threadIdx.x; k_ < baq7s::LT_N; k_ += blockDim.x) lt_s[k_] = T.lt[k_];                          \
     __syncthreads();
 
 template <int BW, int DEC>
@@ -535,7 +546,7 @@ __device__ __forceinline__ void baq_cur_seek(BaqCur &cu, const uint32_t *cigar, 
 }
 
 template <int BW, int DEC, bool PLDS>
-__device__ __forceinline__ void baq_bwd_body(const StaReadsDev &R, const StaWinDev &W, const float *q2p, const uint8_t *refc, uint8_t *baq_state, int64_t g0, int64_t ngroups,
+__device__ __forceinline__ void baq_bwd_body(const StaReadsDev &R, const StaWinDev &W, const float *q2p, const uint8_t *refc, const double *lt_tab, uint8_t *baq_state, int64_t g0, int64_t ngroups,
                                              int use_list, double *scratch, size_t slot_dbl, int lq_cap, int lds_rows)
 {
     constexpr int NB = 2 * BW + 1;
@@ -635,8 +646,12 @@ __device__ __forceinline__ void baq_bwd_body(const StaReadsDev &R, const StaWinD
 #define BAQ_MAP_FINISH(i, sum, max, max_k)                                                                                  \
     {                                                                                                                       \
         double mx_ = (max) / (sum);                                                                                         \
-        double v = -4.343 * log(1. - mx_) + .499;                                                                           \
-        int kq = (v >= 2147483648.0 || v < -2147483648.0 || v != v) ? INT32_MIN : (int)v;                                   \
+        int kq;                                                                                                             \
+        if (lt_tab) kq = baq7s::map_quality_x(1. - mx_, (baq7s::LtPtr)lt_tab);   /* the exact threshold table (baq_band7s.h), in LDS */ \
+        else {                                                                                                              \
+            double v = -4.343 * log(1. - mx_) + .499;                                                                       \
+            kq = (v >= 2147483648.0 || v < -2147483648.0 || v != v) ? INT32_MIN : (int)v;                                   \
+        }                                                                                                                   \
         kq = (int)(uint8_t)(kq > 100 ? 99 : kq);                                                                            \
         if (PLDS) {                                                                                                         \
             const int q = (i) - 1;                                                                                          \
@@ -838,7 +853,7 @@ __global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, 
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t baq_state[];        // PLDS: [wave][row][lane], one byte per row and read
     BAQ_TABLES_INIT()
-    baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, baq_state, g0, ngroups, use_list, scratch, slot_dbl, lq_cap, lds_rows);
+    baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, lt_ok ? lt_s : nullptr, baq_state, g0, ngroups, use_list, scratch, slot_dbl, lq_cap, lds_rows);
 }
 
 // Both passes of one group in one launch, for the reads that go through the list (a few dozen waves, latency bound): once its waves
@@ -850,7 +865,7 @@ __global__ void __launch_bounds__(256, 2) k_baq_list(StaReadsDev R, StaWinDev W,
     extern __shared__ __attribute__((aligned(16))) uint8_t baq_state[];
     BAQ_TABLES_INIT()
     baq_fwd_body<BW, DEC>(R, W, q2p, refc, 0, ngroups, 1, scratch, slot_dbl, lq_cap);
-    baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, baq_state, 0, ngroups, 1, scratch, slot_dbl, lq_cap, lds_rows);
+    baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, lt_ok ? lt_s : nullptr, baq_state, 0, ngroups, 1, scratch, slot_dbl, lq_cap, lds_rows);
 }
 
 template <int NB, int DEC>
@@ -946,7 +961,6 @@ void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
 // of the waves run one forward pass ahead of the other half (two slots per wave), so that at any time about half of a CU's waves
 // are in the store-heavy forward phase and half in the issue-heavy backward phase: the forward rows' write stream, their read
 // stream and the fp64 issue overlap inside one launch instead of alternating between two.
-#include "baq_band7s.h"
 
 #ifndef BAQ7S_DEFAULT_MODE
 #define BAQ7S_DEFAULT_MODE 16          // baq7s::M_LOGTAB
@@ -955,8 +969,14 @@ static void baq_tables_fill()
 {
     for (int i = 0; i < 256; ++i) g_tables.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
     baq7s::LogTab lt;
-    g_logtab_ok = baq7s::make_log_thresholds(lt);     // false: this host's log() is not a clean step function around a threshold -> the formula kernels
-    for (int i = 0; i < baq7s::LT_N; ++i) g_tables.lt[i] = lt.t[i];
+    g_logtab_ok = baq7s::make_log_thresholds(lt);     // false: this host's log() is not a clean step function around a threshold -> the formula
+    g_tables.lt = nullptr;
+    if (g_logtab_ok && !getenv("STA_BAQ_NO_LOGTAB")) {
+        // (one engine device per process: the table lives on the device that is current when the first BAQ launch is made)
+        double *dp = nullptr;
+        if (hipMalloc((void **)&dp, sizeof lt.t) == hipSuccess && hipMemcpy(dp, lt.t, sizeof lt.t, hipMemcpyHostToDevice) == hipSuccess) g_tables.lt = dp;
+        else { (void)hipGetLastError(); g_logtab_ok = false; }
+    } else g_logtab_ok = false;
 }
 
 __device__ __forceinline__ double baq_uni(double x)       // a wave-uniform double into scalar registers
@@ -985,8 +1005,9 @@ struct Baq7sRead { bool active; int lq; baq7s::Shape sh; uint8_t *qual; const ui
 __device__ __forceinline__ Baq7sRead baq7s_read(const StaReadsDev &R, const StaWinDev &W, int64_t g, int lane)
 {
     Baq7sRead d; d.active = false; d.lq = 0; d.qual = nullptr; d.seq = nullptr; d.sh.ok = false; d.sh.ys = d.sh.mlen = 0; d.sh.xb = 0;
-    const int64_t r = g * 64 + lane;
-    if (r < R.n && (R.info[r] & RI_BAQ_S)) {
+    // group g = entries [64 g, 64 g + 64) of the per-length list (one read length per group; -1 = padding behind a length's last read)
+    const int64_t r = R.s_ws[STA_SLIST_HEAD + g * 64 + lane];
+    if (r >= 0) {
         d.active = true;
         d.lq = R.l_qseq[r];
         const uint32_t c0 = R.cig_off[r];
@@ -995,6 +1016,43 @@ __device__ __forceinline__ Baq7sRead baq7s_read(const StaReadsDev &R, const StaW
         d.qual = R.qual + boff; d.seq = R.seq + (boff >> 1);
     }
     return d;
+}
+
+// the class-S candidates into their list: position = the length's first position (host) + the block's share of the length's cursor + the
+// read's place inside the block.  One DEVICE atomic per block and distinct length (one per wave was 13 000 atomics on the one word of the
+// common length: 0.15 ms); a wave's reads keep their order.
+__global__ void __launch_bounds__(1024) k_baq7s_gather(StaReadsDev R)
+{
+    __shared__ int s_cnt[STA_SLIST_BINS], s_gb[STA_SLIST_BINS];
+    for (int k = threadIdx.x; k < STA_SLIST_BINS; k += blockDim.x) s_cnt[k] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool s = i < R.n && (R.info[i] & RI_BAQ_S);
+    const int lq = s ? R.l_qseq[i] : -1;
+    int my_off = 0;
+    unsigned long long todo = __ballot(s);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        const int l0 = __shfl(lq, src);
+        const unsigned long long same = __ballot(s && lq == l0);
+        int at = 0;
+        if (lane == src) at = atomicAdd(&s_cnt[l0], (int)__popcll(same));
+        at = __shfl(at, src);
+        if (s && lq == l0) my_off = at + (int)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    __syncthreads();
+    int32_t *cur = R.s_ws + 2 * STA_SLIST_BINS;
+    for (int k = threadIdx.x; k < STA_SLIST_BINS; k += blockDim.x) if (s_cnt[k]) s_gb[k] = atomicAdd(&cur[k], s_cnt[k]);
+    __syncthreads();
+    if (s) R.s_ws[STA_SLIST_HEAD + R.s_ws[STA_SLIST_BINS + lq] + s_gb[lq] + my_off] = (int32_t)i;
+}
+
+void sta_launch_baq7s_gather(hipStream_t s, const StaReadsDev &r)
+{
+    if (r.n <= 0 || !r.s_ws) return;
+    hipLaunchKernelGGL(k_baq7s_gather, dim3((unsigned)((r.n + 1023) / 1024)), dim3(1024), 0, s, r);
 }
 
 // two waves per SIMD: the backward pass holds 120 doubles of band state (256 VGPRs; 168 would spill 230 of them)
@@ -1089,11 +1147,10 @@ size_t sta_baq7s_scratch_bytes(int lq_cap, int64_t ngroups, int *waves_out)
     return 256 + (size_t)waves * 2 * baq7s_slot_bytes(lq_cap);
 }
 
-void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int waves)
+void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int waves, int64_t ngroups)
 {
     baq_tables_init();
-    const int64_t ngroups = (r.n + 63) / 64;
-    if (ngroups <= 0 || waves <= 0) return;
+    if (ngroups <= 0 || waves <= 0 || !r.s_ws) return;
     static const int lead = [] { const char *e = getenv("STA_BAQ7S_LEAD"); return e ? atoi(e) : 1; }();   // 0: every wave forward-then-backward; 1: odd waves one forward pass ahead
     hipMemsetAsync(scratch, 0, 256, s);
     // STA_BAQ7S_MODE: 0 non-temporal row stream (default), 1 plain loads / stores; 2, 3: diagnostics with wrong results (baq_band7s.h)

@@ -124,6 +124,11 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
         wave_first_entry(W, wfirst, nwaves, (int64_t)(b - cs.nchunks) * 256 + threadIdx.x);
         return;
     }
+    // class-S candidates per read length: counted in LDS over the block's whole chunk, one device atomic per block and distinct length at the
+    // end (one per WAVE cost 0.1 ms at bench size: 13 000 atomics on the one word of the common length)
+    __shared__ int s_hist[STA_SLIST_BINS];
+    const bool want_hist = P.baq_class_s && R.s_ws != nullptr;
+    if (want_hist) { for (int k = threadIdx.x; k < STA_SLIST_BINS; k += blockDim.x) s_hist[k] = 0; __syncthreads(); }
     unsigned long long piled = 0, kept = 0;
     unsigned long long c_baq = 0, c_fast = 0, c_bw8 = 0, c_gen = 0, m_lqf = 0, m_lq = 0, m_bw = 0, c_s = 0, m_lqs = 0, c_bw7l = 0, c_olap = 0;
     const int64_t i0 = (int64_t)b * cs.chunk, i1 = i0 + cs.chunk < R.n ? i0 + cs.chunk : R.n;
@@ -200,14 +205,22 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
             // both BQ and ZQ without redo: ZQ is dropped and BQ applied by k_qual_prep
         }
         if (P.baq_class_s) {
-            // class S wants ONE read length per group of 64 consecutive reads (its parameters live in scalar registers): the
-            // length of the group's first candidate; every other band-width-7 read goes through the list
-            const unsigned long long cand = __ballot(baq_cls == 3);
-            if (cand) {
-                const int lq0 = __shfl(lq, __ffsll((long long)cand) - 1);
-                if (baq_cls == 3 && lq != lq0) baq_cls = 1;
-            }
+            // class S wants ONE read length per group of 64 lanes (its parameters live in scalar registers).  Round 4 formed the groups from
+            // 64 CONSECUTIVE reads and sent every candidate of another length than the group's first -- and every lane next to an indel
+            // read stayed idle -- through the list kernels: trimmed reads (many lengths) lost the fast kernel altogether.  Now every
+            // candidate is taken: the lengths are counted here (one atomic per wave and distinct length), the host lays the list out
+            // per length and k_baq7s_gather fills it (kernels_baq.hip).
             if (baq_cls == 1) baq_cls = 2;
+            if (R.s_ws) {
+                unsigned long long todo = __ballot(baq_cls == 3);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    const int l0 = __shfl(lq, src);
+                    const unsigned long long same = __ballot(baq_cls == 3 && lq == l0);
+                    if ((int)(threadIdx.x & 63) == src) atomicAdd(&s_hist[l0], (int)__popcll(same));
+                    todo &= ~same;
+                }
+            } else if (baq_cls == 3) baq_cls = 2;
         }
         if (baq_cls) {
             if (baq_bw) {
@@ -238,6 +251,10 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
         chunk_tile(ke, run, R.maxend, i, in);
     }
     chunk_finish(cs, b, run, R.maxend, i0, i1);
+    if (want_hist) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < STA_SLIST_BINS; k += blockDim.x) if (s_hist[k]) atomicAdd(&R.s_ws[k], s_hist[k]);
+    }
     // block reduce, then one atomic per counter and block
     unsigned long long v[13] = { piled, kept, c_baq, c_fast, c_bw8, c_gen, c_s, c_bw7l, c_olap, m_lqf, m_lq, m_bw, m_lqs };
     unsigned long long *const dst[13] = { &ctr->piled_bases, &ctr->n_kept, &ctr->n_baq, &ctr->n_baq_fast, &ctr->n_baq_bw8, &ctr->n_baq_general,

@@ -51,7 +51,13 @@ struct StaReadsDev {
     // pair was resolved, and the mate's read index.  NULL when overlaps are off.
     int32_t *fix_y, *fix_mate; uint8_t *fix_q;
     int32_t *chain;       // n+4 ints: BAQ slow-read list ([0] = count, then read indices) until the overlap pass reuses it as hash chains
+    // class-S BAQ (round 5): the candidates are gathered per read length into dense groups of 64.  STA_SLIST_BINS words each of: the
+    // histogram of candidate lengths (k_prep_reads), the first list position of a length (host: every length starts a new group of 64),
+    // the gather kernel's cursors; then the list itself (read indices, -1 = padding).  NULL: no class-S kernel in this plan.
+    int32_t *s_ws;
 };
+#define STA_SLIST_BINS 260                 // read lengths 0..256 (class S: 16..256)
+#define STA_SLIST_HEAD (3 * STA_SLIST_BINS)
 
 // window constants shared by the column kernels
 struct StaWinDev {
@@ -163,7 +169,9 @@ void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
 void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw, int64_t ng);   // both passes, list reads of band width bw
 // class S (baq_band7s.h): one fused persistent kernel over all groups of 64 reads; scratch = 256-byte header + two slots per resident wave
 size_t sta_baq7s_scratch_bytes(int lq_cap, int64_t ngroups, int *waves_out);
-void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int waves);
+void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int waves, int64_t ngroups);
+// the class-S candidates of a file (RI_BAQ_S) into r.s_ws's list at the positions the host laid out per read length
+void sta_launch_baq7s_gather(hipStream_t s, const StaReadsDev &r);
 
 // device staging (kernels_stage.hip): pools of reads [raw_first, raw_first + n_raw) out of raw BAM alignment records
 void sta_launch_bam_pools(hipStream_t s, const uint8_t *raw, const uint32_t *rec_off, uint64_t raw_bytes, int64_t raw_first, int64_t n_raw, const StaReadsDev &d,

@@ -19,12 +19,14 @@ def synth_ref(n, seed=1):
 
 
 def synth_reads(ref, depth=30, read_len=150, seed=42, paired=False, sub_rate=0.001, indel_rate=0.005,
-                mapq=60, origin=0, max_indel=3, start_span=None, n_reads=None):
+                mapq=60, origin=0, max_indel=3, start_span=None, n_reads=None, trim_rate=0.0, trim_max=50):
     """Returns a dict with the sta_reads arrays for ONE file covering the whole of `ref`.
 
     ref: uint8 array of ASCII bases (contig of length len(ref)); reads lie fully inside it.
     start_span / n_reads (unpaired only): draw that many start positions from [0, start_span) instead of depth * len(ref) / L
-    of them from the whole of `ref` -- synth_chunked() builds long inputs out of such pieces."""
+    of them from the whole of `ref` -- synth_chunked() builds long inputs out of such pieces.
+    trim_rate / trim_max: that fraction of the reads without an indel lose 1..trim_max bases at their right-hand end (adapter / quality
+    trimming: many read lengths in one input; nothing is drawn when trim_rate is 0, so the other inputs keep their seeds)."""
     rng = np.random.default_rng(seed)
     n_ref = len(ref)
     L = read_len
@@ -92,6 +94,16 @@ def synth_reads(ref, depth=30, read_len=150, seed=42, paired=False, sub_rate=0.0
         for j, (ln, op) in enumerate(ops):
             cigar[o + j] = (ln << 4) | op
 
+    l_qseq = np.full(n_reads, L, dtype=np.int32)
+    if trim_rate > 0:
+        cut = (rng.random(n_reads) < trim_rate) & ~has_indel
+        l_qseq[cut] = L - rng.integers(1, trim_max + 1, int(cut.sum()))
+        for r in np.nonzero(cut)[0]:
+            cigar[int(cig_off[r])] = (int(l_qseq[r]) << 4) | 0
+        beyond = np.arange(L)[None, :] >= l_qseq[:, None]
+        quals = quals.copy(); quals[beyond] = 0
+        bases = bases.copy(); bases[beyond] = ord("N")
+
     Lp = (L + 7) & ~7
     qual_pool = np.zeros((n_reads, Lp), dtype=np.uint8)
     qual_pool[:, :L] = quals
@@ -100,6 +112,8 @@ def synth_reads(ref, depth=30, read_len=150, seed=42, paired=False, sub_rate=0.0
         code[ord(ch)] = v
     codes = np.zeros((n_reads, Lp), dtype=np.uint8)
     codes[:, :L] = code[bases]
+    if trim_rate > 0:
+        codes[:, :L][np.arange(L)[None, :] >= l_qseq[:, None]] = 0        # the pools are zero beyond a read's last base
     seq_pool = ((codes[:, 0::2] << 4) | codes[:, 1::2]).astype(np.uint8)
     base_off8 = (np.arange(n_reads, dtype=np.uint64) * (Lp >> 3)).astype(np.uint32)
 
@@ -112,7 +126,7 @@ def synth_reads(ref, depth=30, read_len=150, seed=42, paired=False, sub_rate=0.0
     return {
         "n": n_reads, "L": L,
         "pos": (pos - origin).astype(np.int32), "flag": flag, "mapq": np.full(n_reads, mapq, dtype=np.uint8),
-        "aux": np.zeros(n_reads, dtype=np.uint8), "l_qseq": np.full(n_reads, L, dtype=np.int32),
+        "aux": np.zeros(n_reads, dtype=np.uint8), "l_qseq": l_qseq,
         "cig_off": cig_off, "base_off8": base_off8,
         "mtid": np.where(mpos >= 0, 0, -1).astype(np.int32) if paired else np.full(n_reads, -1, dtype=np.int32),
         "mpos": mpos.astype(np.int64), "isize": tlen.astype(np.int32), "name_off": name_off,
@@ -136,7 +150,7 @@ def write_sam(path, rd, ref_name, ref_len):
             fh.write("%s\t%d\t%s\t%d\t%d\t%s\t%s\t%d\t%d\t%s\t%s\n" % (
                 names[r].decode(), int(rd["flag"][r]), ref_name, int(rd["_abs_pos"][r]) + 1, int(rd["mapq"][r]),
                 cigar_str(rd, r), "=" if mp >= 0 else "*", mp + 1, int(rd["isize"][r]),
-                rd["_bases"][r].tobytes().decode(), (rd["_quals"][r] + 33).astype(np.uint8).tobytes().decode()))
+                rd["_bases"][r][:int(rd["l_qseq"][r])].tobytes().decode(), (rd["_quals"][r][:int(rd["l_qseq"][r])] + 33).astype(np.uint8).tobytes().decode()))
 
 
 def write_fasta(path, name, ref):

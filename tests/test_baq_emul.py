@@ -29,9 +29,11 @@ def emul(tmp_path_factory):
     return exe
 
 
+@pytest.mark.parametrize("mode", [16, 0], ids=["table", "formula"])
 @pytest.mark.parametrize("seed,force_edge", [(1, 0), (2, 0), (3, 1), (4, 0)])
-def test_lane_functions_equal_the_oracle(emul, seed, force_edge):
-    p = subprocess.run([emul, "6000", str(seed), str(force_edge)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+def test_lane_functions_equal_the_oracle(emul, seed, force_edge, mode):
+    """mode = the kernel's STA_BAQ7S_MODE: 16 (default build) takes the MAP quality from the exact threshold table, 0 from the formula"""
+    p = subprocess.run([emul, "6000", str(seed), str(force_edge), str(mode)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0, out + p.stderr.decode()[-2000:]
     f = out.split()
@@ -39,3 +41,14 @@ def test_lane_functions_equal_the_oracle(emul, seed, force_edge):
     assert n > 5000 and bad == 0
     assert changed > n * 0.9          # BAQ lowers something in nearly every read: the comparison is not vacuous
     assert amb > 100                  # windows with ambiguous reference bases (the all-tests code path) were among them
+
+
+def test_log_threshold_table_is_exact(emul):
+    """k = (int)(-4.343 * log(1 - max) + .499) without the logarithm (baq_band7s.h map_quality): the 101 thresholds are found by bisection
+    with the host's own log(), F must be a clean single step over 2 x 10^5 doubles either side of each (else the engine keeps the formula),
+    and table == formula on 4 million posteriors: uniform, near 1 over the whole range of 1 - max, within 1e-9 of every threshold, on the
+    300 neighbouring doubles of every threshold, and on the special values (posterior 1, 0, 0 / 0)."""
+    p = subprocess.run([emul, "logtab", "4000000", "7"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stdout.decode() + p.stderr.decode()[-2000:]
+    f = p.stdout.decode().split()
+    assert int(f[2]) > 4000000 and int(f[4]) == 0

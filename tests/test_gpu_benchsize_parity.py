@@ -109,7 +109,7 @@ def _oracle(wl, n_cols):
 # most four of these windows (25 GiB of BAQ scratch each at 30x) are on the GPU at a time.
 _BENCH_WL = [("mpileup30", "a"), ("mpileup30_B", "a"), ("mpileup300", "b"), ("mpileup300_B", "b"), ("mpileup100", "b"), ("mpileup100_B", "b"),
              ("mpileup30_EA_pairs", "c"), ("mpileup30_B_pairs", "c"), ("mpileup30_hotspot", "d"), ("mpileup30_B_hotspot", "d"),
-             ("mpileup30_indel", "a"), ("depth30", "c"),
+             ("mpileup30_indel", "a"), ("depth30", "c"), ("mpileup30_trim", "f"),
              # round 4: three input files (per-file column groups of the tile kernels), the generic walkers (-s -O --output-extra)
              ("mpileup30_3files", "e"), ("mpileup30_B_3files", "e"), ("mpileup30_B_sOx", "a"),
              # -s on the tile path: tile kernel, read-major kernel (300x), three files

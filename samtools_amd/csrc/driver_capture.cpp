@@ -32,18 +32,6 @@ char *DevCapture::reserve(size_t more)
     }
     return buf + len;
 }
-// The command-line binary (main.cpp) asks for this: when a driver has written and closed everything, the process ends at once instead of
-// unwinding -- freeing and page-unlocking the staging pools, unmapping the inputs, joining the decode threads and shutting the HIP runtime down
-// cost 0.13-0.16 s of a 0.7 s run (profiles/r05_e2e_breakdown.log) and the operating system does all of it anyway.  In-process callers
-// (sta_main_capture, the sharded launcher) never set it.
-static bool g_cli_fast_exit = false;
-extern "C" void sta_main_set_fast_exit(int on) { g_cli_fast_exit = on != 0 && !getenv("STA_NO_FAST_EXIT"); }
-void driver_finish_process(int ret)
-{
-    if (!g_cli_fast_exit || ret != 0) return;
-    fflush(NULL);
-    _exit(0);
-}
 FILE *driver_default_out() { return t_capture ? t_capture : stdout; }
 bool driver_out_is_borrowed(FILE *f) { return f == stdout || (t_capture && f == t_capture); }
 

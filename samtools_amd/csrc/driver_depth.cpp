@@ -334,7 +334,6 @@ extern "C" int sta_main_depth(int argc, char **argv)
     if (!driver_out_is_borrowed(run.out)) fclose(run.out);
     // (an input without a single window never asked for the engine: a machine without a device is an error all the same)
     if (run.devs.ready() != STA_OK) { if (!run.no_device.exchange(true)) fprintf(stderr, "samtools depth: no usable HIP device (the MI355X engine has no CPU fallback)\n"); ret = 1; }
-    driver_finish_process(ret);       // (the command-line binary: no unwinding; in-process callers go on)
     run.devs.destroy();
     return ret;
 }

@@ -551,7 +551,6 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     fflush(run.out);
     if (!driver_out_is_borrowed(run.out)) fclose(run.out);
     if (run.devs.ready() != STA_OK) { if (!run.no_device.exchange(true)) fprintf(stderr, "samtools mpileup: no usable HIP device (the MI355X engine has no CPU fallback)\n"); ret = 1; }
-    driver_finish_process(ret);       // (the command-line binary: no unwinding; in-process callers go on)
     run.devs.destroy();
     return ret;
 }

@@ -110,8 +110,6 @@ inline int seek_readers_by_index(std::vector<std::unique_ptr<AlnReader>> &reader
 
 // where a driver writes when the command names no -o file: stdout, or the memory stream of sta_main_capture (driver_capture.cpp)
 FILE *driver_default_out();
-// after a driver has flushed and closed its output: ends the process at once when the command-line binary asked for it (driver_capture.cpp)
-void driver_finish_process(int ret);
 // Device capture (sta_main_capture_device, driver_capture.cpp): the windows' text is not downloaded -- the device thread emits every
 // window right behind the text captured so far, in a device buffer the caller takes over (a sharded run gathers it GPU to GPU).  Only
 // with one device thread (windows then reach the device in output order).  Fetched once by the driver's main thread; nullptr = off.

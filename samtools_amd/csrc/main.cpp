@@ -4,7 +4,6 @@
 extern "C" int sta_main_plpdump(int argc, char **argv);   // diagnostic client of the bam_plp_* surface (driver_plpdump.cpp)
 extern "C" int sta_main_bedcov(int argc, char **argv);    // bedcov.c column loop on the engine iterator (driver_bedcov.cpp)
 extern "C" int sta_main_coverage(int argc, char **argv);  // coverage.c tabular loop on the engine iterator (driver_coverage.cpp)
-extern "C" void sta_main_set_fast_exit(int on);          // a finished mpileup / depth run ends the process without unwinding (driver_capture.cpp)
 #include <cstdio>
 #include <cstring>
 
@@ -14,7 +13,6 @@ int main(int argc, char **argv)
         fprintf(stderr, "Usage: samtools-amd <mpileup|depth|consensus|bedcov|coverage|stats|plpdump|glf|calmd> [options]\n%s\n", sta_version());
         return 1;
     }
-    sta_main_set_fast_exit(1);
     if (strcmp(argv[1], "mpileup") == 0) return sta_main_mpileup(argc - 1, argv + 1);
     if (strcmp(argv[1], "depth") == 0) return sta_main_depth(argc - 1, argv + 1);
     if (strcmp(argv[1], "consensus") == 0) return sta_main_consensus(argc - 1, argv + 1);

@@ -71,21 +71,41 @@ __device__ __forceinline__ int extra_len(const StaReadsDev &R, const StaWinDev &
     long long v = extra_value(R, W, kind, e);
     return (v < 0 ? 1 : 0) + dec_digits((unsigned long long)(v < 0 ? -v : v));
 }
-template <bool LDS>
+// l bytes of device text into a sink.  KIND 2: eight bytes per load and append; the last 0..7 as a 4-, a 2- and a 1-byte load asked for
+// together (a byte loop is l dependent load latencies per entry: a read name cost the walker more than everything else of its entry).
+typedef uint32_t __attribute__((aligned(1))) text_u32u;
+typedef uint16_t __attribute__((aligned(1))) text_u16u;
+template <int LDS>
+__device__ __forceinline__ void put_text(Sink<LDS> &s, const char *src, int l)
+{
+    if (LDS != 2) { for (int t = 0; t < l; ++t) s.put(src[t]); return; }
+    int t = 0;
+    for (; t + 8 <= l; t += 8) s.put_n(*reinterpret_cast<const sink_u64u *>(src + t), 8);
+    const int rem = l - t;
+    if (rem) {
+        const int o2 = t + (rem & 4), o1 = o2 + (rem & 2);
+        uint64_t v4 = 0, v2 = 0, v1 = 0;
+        if (rem & 4) v4 = *reinterpret_cast<const text_u32u *>(src + t);
+        if (rem & 2) v2 = *reinterpret_cast<const text_u16u *>(src + o2);
+        if (rem & 1) v1 = (unsigned char)src[o1];
+        s.put_n(v4 | v2 << (8 * (rem & 4)) | v1 << (8 * (rem & 6)), (uint32_t)rem);
+    }
+}
+template <int LDS>
 __device__ __forceinline__ void extra_write(const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int kind, const Entry &e, Sink<LDS> &s)
 {
     if (kind == STA_MPLP_PRINT_RNEXT || kind >= TAGKIND) {
         const uint32_t *o = R.xcol_off + (uint64_t)e.r * (uint64_t)R.n_xcols + (uint64_t)xcol_index(P, kind);
-        for (uint32_t t = o[0]; t < o[1]; ++t) s.put(R.xcol_text[t]);
+        const uint32_t o0 = o[0], o1 = o[1];
+        put_text<LDS>(s, R.xcol_text + o0, (int)(o1 - o0));
     } else if (kind == STA_MPLP_PRINT_MAPQ_CHAR) {
         int c = (int)((e.info >> RI_MAPQ_SHIFT) & 0xff) + 33;
         s.put((char)(c > 126 ? 126 : c));
     } else if (kind == STA_MPLP_PRINT_QNAME) {
-        const char *nm = R.names + R.name_off[e.r];
-        int l = (int)(R.name_off[e.r + 1] - R.name_off[e.r]) - 1;
-        for (int t = 0; t < l; ++t) s.put(nm[t]);
+        const auto n0 = R.name_off[e.r], n1 = R.name_off[e.r + 1];
+        put_text<LDS>(s, R.names + n0, (int)(n1 - n0) - 1);
     } else if (kind == STA_MPLP_PRINT_RNAME) {
-        for (int t = 0; t < W.tname_len; ++t) s.put(W.tname[t]);
+        put_text<LDS>(s, W.tname, W.tname_len);
     } else s.put_dec(extra_value(R, W, kind, e));
 }
 
@@ -240,7 +260,141 @@ __device__ __forceinline__ void emit_column(const StaWinDev &W, const MplpDevPar
     if (exists) s.put('\n');
 }
 
-__global__ void __launch_bounds__(256) k_mplp_emit(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, char *out, uint32_t lds_cap)
+// ---- the single-walk form of emit_column (round 5) ----
+// emit_column above walks a file's candidate reads once per string of the row: count, bases, qualities and one walk per extra
+// column -- six walks for "-s -O --output-QNAME", each ~80 latency-bound instructions per entry.  Here the first walk measures every
+// string separately (the measuring kernel kept only their sum), which fixes where each string starts inside the row, and ONE more
+// walk writes an entry's token, quality and extra fields through a cursor per string.  Up to GEN_NX extra columns; rows with more
+// keep the per-column walks.
+#define GEN_NX 8
+#ifndef GEN_OCC
+#define GEN_OCC __attribute__((amdgpu_waves_per_eu(4, 8)))     // 128 registers: four waves per SIMD
+#endif
+struct AccX { uint32_t n_plp, cnt, seq_len, xlen[GEN_NX]; };
+template <int LDS> __device__ __forceinline__ void sink_adv(Sink<LDS> &s, int32_t n) { if (LDS == 1) s.cur += (uint32_t)n; else s.g += n; }
+// a byte at `off` from the cursor, the cursor stays (a KIND 2 sink must be empty: its g is then the cursor)
+template <int LDS> __device__ __forceinline__ void sink_poke(const Sink<LDS> &s, int32_t off, char c) { if (LDS == 1) PLP_LDS[s.cur + (uint32_t)off] = c; else s.g[off] = c; }
+
+// what the walk needs of a read before it knows whether any lane's column is covered: asked for one read ahead, so that the answer
+// is there when the walk gets to it (five dependent load latencies per read otherwise -- the walker's time is latency, not issue)
+struct WalkHdr { uint32_t info, b8; int pos, end, lq; };
+__device__ __forceinline__ WalkHdr walk_hdr(const StaReadsDev &R, int64_t r)
+{
+    WalkHdr h; h.info = R.info[r]; h.pos = R.pos[r]; h.end = R.end[r]; h.lq = R.l_qseq[r]; h.b8 = R.base_off8[r];
+    return h;
+}
+
+template <bool WRITE, int LDS>
+__device__ __forceinline__ void file_walk_all(const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int p, bool active,
+                                              int64_t rlo, int64_t rhi, const int (&kinds)[GEN_NX], int nx, AccX &acc,
+                                              Sink<LDS> &sq, Sink<LDS> &qs, Sink<LDS> (&xs)[GEN_NX])
+{
+    uint32_t nw = 0;
+    WalkHdr ahead; ahead.info = 0; ahead.b8 = 0; ahead.pos = 0; ahead.end = 0; ahead.lq = 0;
+    if (rlo < rhi) ahead = walk_hdr(R, rlo);
+    for (int64_t r = rlo; r < rhi; ++r) {
+        const WalkHdr h = ahead;
+        if (r + 1 < rhi) ahead = walk_hdr(R, r + 1);
+        uint32_t info = h.info;
+        if (!(info & RI_KEEP)) continue;
+        int rpos = h.pos, rend = h.end;
+        bool cov = active && rpos <= p && p < rend;
+        if (__ballot(cov) == 0) continue;
+        if (!cov) continue;
+        Entry e;
+        e.r = r; e.rpos = rpos; e.rend = rend; e.info = info;
+        e.lq = h.lq;
+        e.boff = (uint64_t)h.b8 << 3;
+        if (info & RI_SIMPLE) { e.rs.qpos = p - rpos; e.rs.indel = 0; e.rs.k = 0; e.rs.is_del = false; e.rs.is_refskip = false; }
+        else e.rs = resolve_general(R.cigar + R.cig_off[r], (int)(R.cig_off[r + 1] - R.cig_off[r]), rpos, p);
+        if (!WRITE) acc.n_plp++;
+        int c = e.rs.is_del ? placeholder_qual(R, r, e.rs.qpos, e.lq, e.boff, p) : (e.rs.qpos < e.lq ? R.qual[e.boff + (uint64_t)e.rs.qpos] : 0);
+        if (c < P.min_baseQ) continue;
+        if (!WRITE) {
+            acc.cnt++;
+            acc.seq_len += (uint32_t)token_len(R, P, e, p);
+#pragma unroll
+            for (int k = 0; k < GEN_NX; ++k) if (k < nx) acc.xlen[k] += (uint32_t)extra_len(R, W, P, kinds[k], e);
+        } else {
+            token_write<LDS>(R, W, P, e, p, sq);
+            qs.put((char)(c + 33 < 126 ? c + 33 : 126));
+#pragma unroll
+            for (int k = 0; k < GEN_NX; ++k) if (k < nx) {
+                const int kd = kinds[k];
+                if (nw > 0 && kd != STA_MPLP_PRINT_MAPQ_CHAR) xs[k].put(kd >= TAGKIND ? (char)P.tag_sep : ',');
+                extra_write<LDS>(R, W, P, kd, e, xs[k]);
+            }
+        }
+        nw++;
+    }
+}
+
+template <int LDS>
+__device__ __forceinline__ void emit_column_1walk(const StaWinDev &W, const MplpDevPar &P, int p0, int plast, int p, bool exists, Sink<LDS> &s)
+{
+    int64_t apos = W.origin + p;
+    if (exists) {
+        for (int t = 0; t < W.tname_len; ++t) s.put(W.tname[t]);
+        s.put('\t');
+        s.put_dec(apos + 1);
+        s.put('\t');
+        s.put((W.ref && apos < W.ref_len) ? W.ref[apos] : 'N');
+    }
+    // the extra columns in output order: the flag columns by ascending bit, then the aux-tag columns (bam_plcmd.c:727-852)
+    int kinds[GEN_NX];
+    uint32_t ex = (uint32_t)P.flag & EXTRA_MASK;
+    const int nfl = __popc(ex), nx = nfl + P.n_tags;
+#pragma unroll
+    for (int k = 0; k < GEN_NX; ++k) {
+        kinds[k] = k < nfl ? (int)(ex & (~ex + 1)) : TAGKIND + (k - nfl);
+        ex &= ex - 1;
+    }
+    for (int f = 0; f < W.nfiles; ++f) {
+        const StaReadsDev &R = W.files[f];
+        int64_t rlo, rhi;
+        wave_read_range(R, p0, plast, rlo, rhi);
+        AccX a; a.n_plp = a.cnt = a.seq_len = 0;
+#pragma unroll
+        for (int k = 0; k < GEN_NX; ++k) a.xlen[k] = 0;
+        Sink<LDS> xs[GEN_NX];
+        file_walk_all<false, LDS>(R, W, P, p, exists, rlo, rhi, kinds, nx, a, s, s, xs);
+        if (exists) { s.put('\t'); s.put_dec(a.cnt); s.put('\t'); }
+        s.flush();
+        // where the strings of this file's part of the row start: bases | qualities | extra columns
+        Sink<LDS> sq = s;
+        const uint32_t sl = a.cnt ? a.seq_len : 1u, ql = a.cnt ? a.cnt : 1u;
+        Sink<LDS> qs = s; sink_adv(qs, (int32_t)(sl + 1));
+        Sink<LDS> end = qs; sink_adv(end, (int32_t)ql);
+#pragma unroll
+        for (int k = 0; k < GEN_NX; ++k) {
+            xs[k] = end;
+            if (k < nx) {
+                sink_adv(xs[k], 1);
+                const uint32_t xl = a.cnt ? a.xlen[k] + (kinds[k] != STA_MPLP_PRINT_MAPQ_CHAR ? a.cnt - 1 : 0u) : 1u;
+                sink_adv(end, (int32_t)(1 + xl));
+            }
+        }
+        if (exists) {                       // the separators, and '*' for the strings of a row without entries
+            sink_poke(qs, -1, '\t');
+            if (!a.cnt) { sink_poke(sq, 0, '*'); sink_poke(qs, 0, '*'); }
+#pragma unroll
+            for (int k = 0; k < GEN_NX; ++k) if (k < nx) {
+                sink_poke(xs[k], -1, '\t');
+                if (!a.cnt) sink_poke(xs[k], 0, '*');
+            }
+        }
+        file_walk_all<true, LDS>(R, W, P, p, exists && a.cnt, rlo, rhi, kinds, nx, a, sq, qs, xs);
+        sq.flush(); qs.flush();
+#pragma unroll
+        for (int k = 0; k < GEN_NX; ++k) if (k < nx) xs[k].flush();
+        s = end;
+    }
+    if (exists) s.put('\n');
+    s.flush();
+}
+
+template <bool ONE_WALK>
+__global__ void __launch_bounds__(256) GEN_OCC k_mplp_emit(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, char *out, uint32_t lds_cap)
 {
     int wid = threadIdx.x >> 6;
     int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -264,7 +418,7 @@ __global__ void __launch_bounds__(256) k_mplp_emit(StaWinDev W, MplpDevPar P, co
         uint32_t base = (uint32_t)wid * slice;
         uint32_t mis = (uint32_t)((uintptr_t)(out + o0) & 15);
         Sink<true> s; s.g = nullptr; s.cur = base + mis + (uint32_t)(my0 - o0);
-        emit_column<true>(W, P, p0, plast, p, exists, s);
+        if (ONE_WALK) emit_column_1walk<true>(W, P, p0, plast, p, exists, s); else emit_column<true>(W, P, p0, plast, p, exists, s);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -280,8 +434,8 @@ __global__ void __launch_bounds__(256) k_mplp_emit(StaWinDev W, MplpDevPar P, co
         uint32_t done = head + (body << 4);
         if (done + lane < n) dst[done + lane] = lds_text[base + mis + done + lane];
     } else {
-        Sink<false> s; s.cur = 0; s.g = out + my0;
-        emit_column<false>(W, P, p0, plast, p, exists, s);
+        if (ONE_WALK) { Sink<2> s; s.open(out + my0); emit_column_1walk<2>(W, P, p0, plast, p, exists, s); }
+        else { Sink<false> s; s.cur = 0; s.g = out + my0; emit_column<false>(W, P, p0, plast, p, exists, s); }
     }
 }
 
@@ -966,7 +1120,14 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
     // waves per workgroup so that the workgroup's LDS (one slice per wave) stays within 64 KiB
     int wpb = 4 * slice <= 65536 ? 4 : (2 * slice <= 65536 ? 2 : 1);
     int64_t nb = (nwaves + wpb - 1) / wpb;
-    hipLaunchKernelGGL(k_mplp_emit, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, make_par(p, w.tlen), offs, out, lds_cap);
+    // one walk for all strings of a row (emit_column_1walk) unless the row has more extra columns than it holds cursors for
+    const char *pe = getenv("STA_GENERIC_PASSES");
+    const MplpDevPar par = make_par(p, w.tlen);
+    const int n_extra = __builtin_popcount((unsigned)par.flag & (unsigned)EXTRA_MASK) + par.n_tags;
+    if (n_extra <= GEN_NX && !(pe && atoi(pe) == 1))
+        hipLaunchKernelGGL(k_mplp_emit<true>, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, par, offs, out, lds_cap);
+    else
+        hipLaunchKernelGGL(k_mplp_emit<false>, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, par, offs, out, lds_cap);
 }
 
 int64_t sta_mplp_deep_strips(int64_t ncols) { return (ncols + DEEP_STRIP - 1) / DEEP_STRIP; }

@@ -146,28 +146,62 @@ PLP_HD char nt16_uc(int c) { return ".ACMGRSVTWYHKDBN"[c]; }
 PLP_HD char nt16_chr(int c) { return "=ACMGRSVTWYHKDBN"[c]; }
 
 
-// ---- byte sink: LDS slice of this wave, or global memory ----
-template <bool LDS> struct Sink {
+// ---- byte sink: KIND 1 the LDS slice of this wave, 0 global memory byte by byte, 2 global memory eight bytes per store ----
+// KIND 2 (round 5, the generic walker's rows that exceed the LDS slice): a lane collects the bytes of ONE string in a register pair and
+// stores them eight at a time at the string's own (unaligned) addresses; flush() writes the last 0..7 with byte stores, so nothing outside
+// the string is touched.  The lanes of a wave write different rows: a byte store is one L2 request per lane and byte, and at 1.8 GB of
+// --output-extra text per window the request rate, not the bytes, was what the emit kernel waited for (profiles/r05_generic_walker.md).
+typedef uint64_t __attribute__((aligned(1))) sink_u64u;
+template <int KIND> struct Sink {
     uint32_t cur;        // LDS: offset into lds_text; global: unused
-    char *g;             // global cursor
+    char *g;             // global cursor (KIND 2: where the next eight bytes go)
+    uint64_t acc;        // KIND 2: the bytes not stored yet, first byte lowest
+    uint32_t nb;         // KIND 2: how many
+    PLP_HD void open(char *at) { g = at; cur = 0; acc = 0; nb = 0; }
+    PLP_HD void put_n(uint64_t v, uint32_t n)         // KIND 2: n <= 8 bytes, first byte lowest, the bytes above n zero
+    {
+        acc |= v << (8 * nb);
+        nb += n;
+        if (nb >= 8) {
+            *reinterpret_cast<sink_u64u *>(g) = acc;
+            g += 8; nb -= 8;
+            acc = nb ? v >> (8 * (n - nb)) : 0;
+        }
+    }
+    PLP_HD void put_digits(uint32_t w, uint32_t n)      // KIND 2: the n <= 8 low decimal digits of w < 10^8 (32-bit divisions by a constant)
+    {
+        uint64_t t = 0;
+        for (uint32_t i = 0; i < n; ++i) { t = (t << 8) | (uint64_t)('0' + w % 10u); w /= 10u; }
+        put_n(t, n);
+    }
+    PLP_HD void flush()
+    {
+        if (KIND == 2) { for (uint32_t i = 0; i < nb; ++i) g[i] = (char)(acc >> (8 * i)); g += nb; nb = 0; acc = 0; }
+    }
     PLP_HD void put(char c)
     {
-        if (LDS) PLP_LDS[cur++] = c;
-        else *g++ = c;
+        if (KIND == 1) PLP_LDS[cur++] = c;
+        else if (KIND == 0) *g++ = c;
+        else put_n((uint64_t)(unsigned char)c, 1);
     }
     PLP_HD void put_dec(long long v)
     {
         if (v < 0) { put('-'); v = -v; }
         unsigned long long u = (unsigned long long)v;
         int n = dec_digits(u);
-        if (LDS) {
+        if (KIND == 1) {
             uint32_t e = cur + n;
             for (uint32_t q = e; q > cur;) { PLP_LDS[--q] = (char)('0' + u % 10); u /= 10; }
             cur = e;
-        } else {
+        } else if (KIND == 0) {
             char *e = g + n;
             for (char *q = e; q > g;) { *--q = (char)('0' + u % 10); u /= 10; }
             g = e;
+        } else {
+            // groups of at most eight digits from the top (a group below the first one is zero-padded: its loop runs its full width)
+            if (n > 16) { const unsigned long long h = u / 10000000000000000ull; u -= h * 10000000000000000ull; put_digits((uint32_t)h, (uint32_t)(n - 16)); n = 16; }
+            if (n > 8) { const unsigned long long h = u / 100000000ull; u -= h * 100000000ull; put_digits((uint32_t)h, (uint32_t)(n - 8)); n = 8; }
+            put_digits((uint32_t)u, (uint32_t)n);
         }
     }
 };
@@ -292,7 +326,7 @@ PLP_HD int token_len(const StaReadsDev &R, const MplpDevPar &P, const Entry &e, 
     return len;
 }
 
-template <bool LDS>
+template <int LDS>
 PLP_HD void token_write(const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, const Entry &e, int p, Sink<LDS> &s)
 {
     bool rev = (e.info & RI_REV) != 0;

@@ -47,6 +47,38 @@ def test_engine_equals_oracle_on_synthetic(tmp_path, oracle_bin, product_bin, ci
         pytest.fail("line count differs: got %d want %d" % (len(g), len(w)))
 
 
+_GENERIC_OPTS = {
+    "sOx3": ["-s", "-O", "--output-QNAME"],
+    # eight extra columns: as many as emit_column_1walk holds cursors for (kernels_plp.hip GEN_NX); flag columns come out in bit order, tags after
+    "x8": ["-s", "-O", "--output-BP-5", "--output-extra", "QNAME,FLAG,POS,NM,RG"],
+    # eleven: the per-column walks of emit_column stay in charge
+    "x11": ["-s", "-O", "--output-BP-5", "--output-extra", "QNAME,FLAG,POS,MAPQ,RNAME,PNEXT,RLEN,NM"],
+    "Q30_a": ["-a", "-Q", "30", "-s", "--output-extra", "RLEN,NM"],      # rows without entries ('*' in every string), rows without reads
+}
+
+
+@pytest.mark.parametrize("env", [{}, {"STA_GENERIC_PASSES": "1"}, {"STA_GENERIC_LDS_CAP": "1024"}], ids=["1walk", "passes", "bytestores"])
+@pytest.mark.parametrize("opts", list(_GENERIC_OPTS), ids=list(_GENERIC_OPTS))
+def test_generic_walker_forms(tmp_path, oracle_bin, product_bin, opts, env):
+    """The generic walker's emit in its two forms (kernels_plp.hip emit_column_1walk: one measuring walk + one writing walk with a cursor
+    per string of the row; emit_column: one walk per string, STA_GENERIC_PASSES=1 or more than GEN_NX extra columns), both through the
+    LDS slice and with byte stores to the text, on reads with indels (deletion placeholders, inserted sequences in the base string) and
+    two input files, against the oracle (bam_plcmd.c:480-855)."""
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=9000, depth=25, read_len=100, seed=91, paired=True, indel_rate=0.25, max_indel=6)
+    d2 = tmp_path / "b"; d2.mkdir()
+    sam2, _ = write_synth_sam(str(d2), n_ref=9000, depth=7, read_len=80, seed=92, paired=False, indel_rate=0.1)
+    args = ["mpileup", "-B"] + _GENERIC_OPTS[opts] + ["-f", fa, sam, sam2]
+    want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    assert want.count(b"\n") > 8000
+    for wc in (None, "1000"):
+        e = dict(os.environ, **env)
+        if wc:
+            e["STA_WINDOW_COLS"] = wc
+        got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+        assert got.returncode == 0, got.stderr.decode()[-500:]
+        assert got.stdout == want, (opts, env, wc)
+
+
 @pytest.mark.parametrize("mode", ["band_even", "band_odd", "long_reads", "general", "plain_E_off"])
 def test_baq_kernels_agree_with_oracle(tmp_path, oracle_bin, product_bin, mode):
     """The band-in-registers BAQ kernels (band width 7 with I rows stored every second row, band width 8 with every row; per-row

@@ -110,8 +110,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=None,
                     help="ranks = GPUs of this node; without WORLD_SIZE in the environment bench.py launches itself under "
                          "torch.distributed.run with that many processes (default 1)")
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default mpileup30 (the metric's configuration); at N > 1 the default run also measures mpileup300 "
                          "(BASELINE.json configs[3], the north star's 8-GPU shape) and reports it inside the same JSON line")

@@ -57,6 +57,19 @@ _GENERIC_OPTS = {
 }
 
 
+def _long_names(sam):
+    """rewrite QNAME r<k> -> a name whose length depends on k (mates keep one name)"""
+    out = []
+    for line in open(sam):
+        if not line.startswith("@"):
+            f = line.split("\t", 1)
+            k = int(f[0][1:])
+            if k % 5:
+                line = ("INS%d:%s" % (k, "lane7:tile1101:x" * 2))[: 6 + k % 35] + "\t" + f[1]
+        out.append(line)
+    open(sam, "w").write("".join(out))
+
+
 @pytest.mark.parametrize("env", [{}, {"STA_GENERIC_PASSES": "1"}, {"STA_GENERIC_LDS_CAP": "1024"}], ids=["1walk", "passes", "bytestores"])
 @pytest.mark.parametrize("opts", list(_GENERIC_OPTS), ids=list(_GENERIC_OPTS))
 def test_generic_walker_forms(tmp_path, oracle_bin, product_bin, opts, env):
@@ -67,6 +80,7 @@ def test_generic_walker_forms(tmp_path, oracle_bin, product_bin, opts, env):
     sam, fa = write_synth_sam(str(tmp_path), n_ref=9000, depth=25, read_len=100, seed=91, paired=True, indel_rate=0.25, max_indel=6)
     d2 = tmp_path / "b"; d2.mkdir()
     sam2, _ = write_synth_sam(str(d2), n_ref=9000, depth=7, read_len=80, seed=92, paired=False, indel_rate=0.1)
+    _long_names(sam)          # names of 6..40 characters: the 8-byte loads of put_text and their 4 / 2 / 1-byte tails
     args = ["mpileup", "-B"] + _GENERIC_OPTS[opts] + ["-f", fa, sam, sam2]
     want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
     assert want.count(b"\n") > 8000

@@ -66,6 +66,10 @@ __device__ __forceinline__ void tile_lookback(unsigned long long *status, unsign
     }
 }
 
+// (Round 5 measured two other forms on k_depth_fused and kept neither -- profiles/r05_depth_phases.md: a workgroup-wide version asking for
+// 256 .. 2 048 predecessors per round trip instead of 64, 0.244 .. 0.31 ms against 0.235; and ONE status word per tile with the window totals
+// added to the counters by two fire-and-forget atomics per tile, 0.262 against 0.219 -- 2 048 atomics on one address are 23 us at the L2.)
+
 // the wave's finished text: LDS [lds, lds + n) -> dst, where the LDS offset is congruent to the global address mod 16 (16-byte
 // body stores, byte stores for the ragged ends)
 __device__ __forceinline__ void wave_flush_text(const char *lds, char *dst, uint32_t n)

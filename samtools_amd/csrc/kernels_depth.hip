@@ -83,6 +83,7 @@ struct DepthFusedArgs {
     StaCounters *ctr;
     uint32_t lbuf, per_wave, n_tiles;
     int32_t has_clip;
+    int32_t diag;          // timing diagnostics only (STA_DEPTH_DIAG; wrong text): 1 = no EMIT phase, 2 = no look-back wait, 3 = no COUNT marks
 };
 
 __device__ __forceinline__ void lds_mark(int *row, int a, int b, int p0)
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
             for (int k = 0; k < DF_CPL; ++k) d_file[DF_CPL * lane + k] = 0;
             if (lane == 0) d_file[DF_SPAN] = 0;
             wave_lds_sync();
-            depth_marks(R, P, A.has_clip, p0, plast, rlo, rhi, d_file, d_cover);
+            if (A.diag != 3) depth_marks(R, P, A.has_clip, p0, plast, rlo, rhi, d_file, d_cover);
             wave_lds_sync();
             depth_counts_from_marks(d_file, A.counts + (int64_t)f * (ncols + 1), c0, ncols);
             wave_lds_sync();                                         // d_file is zeroed again for the next file
@@ -262,7 +263,8 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
         const unsigned long long agg0 = s_wtot[0][0] + s_wtot[1][0] + s_wtot[2][0] + s_wtot[3][0];
         const unsigned long long agg1 = s_wtot[0][1] + s_wtot[1][1] + s_wtot[2][1] + s_wtot[3][1];
         unsigned long long ex0, ex1;
-        tile_lookback(A.status, tile, agg0, agg1, ex0, ex1);
+        if (A.diag == 2) { ex0 = (unsigned long long)tile * 30000ull; ex1 = 0; }
+        else tile_lookback(A.status, tile, agg0, agg1, ex0, ex1);
         if (lane == 0) {
             s_base[0] = ex0; s_base[1] = agg0;
             if (tile + 1 == A.n_tiles) {
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
     __syncthreads();
     const unsigned long long wg_off = s_base[0], wg_bytes = s_base[1];
     if (wg_off + wg_bytes > A.capacity) { if (threadIdx.x == 0) A.ctr->overflow = 1; return; }     // counted, not written: the host retries with room
-    if (!wave_on || wave_total == 0) return;
+    if (!wave_on || wave_total == 0 || A.diag == 1) return;
     unsigned long long off = wg_off;
     for (int w = 0; w < wid; ++w) off += s_wtot[w][0];
 
@@ -328,6 +330,7 @@ void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_p
     a.out = out; a.capacity = capacity; a.counts = counts; a.ctr = ctr;
     a.lbuf = lbuf; a.per_wave = ((lbuf + 16 + 15) & ~15u) + 16; a.n_tiles = (uint32_t)n_tiles;
     a.has_clip = p.remove_overlaps ? 1 : 0;
+    { const char *dg = getenv("STA_DEPTH_DIAG"); a.diag = dg ? atoi(dg) : 0; }
     DepthDevPar d{ p.min_qual, p.skip_del, p.all_pos };
     // STA_DEPTH_TICKET=0: tile = blockIdx.x (workgroups are dispatched in index order and never preempted, so a tile's
     // predecessors are finished or running); the default ticket does not rely on that

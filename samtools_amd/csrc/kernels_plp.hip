@@ -330,7 +330,7 @@ __device__ __forceinline__ void file_walk_all(const StaReadsDev &R, const StaWin
 }
 
 template <int LDS>
-__device__ __forceinline__ void emit_column_1walk(const StaWinDev &W, const MplpDevPar &P, int p0, int plast, int p, bool exists, Sink<LDS> &s)
+__device__ __forceinline__ void emit_column_1walk(const StaWinDev &W, const MplpDevPar &P, int p0, int plast, int p, bool exists, Sink<LDS> &s, int diag)
 {
     int64_t apos = W.origin + p;
     if (exists) {
@@ -383,7 +383,8 @@ __device__ __forceinline__ void emit_column_1walk(const StaWinDev &W, const Mplp
                 if (!a.cnt) sink_poke(xs[k], 0, '*');
             }
         }
-        file_walk_all<true, LDS>(R, W, P, p, exists && a.cnt, rlo, rhi, kinds, nx, a, sq, qs, xs);
+        // (diag: STA_GENERIC_DIAG, timing only, wrong text: 1 = no writing walk, 3 = the writing walk without the extra columns)
+        if (diag != 1) file_walk_all<true, LDS>(R, W, P, p, exists && a.cnt, rlo, rhi, kinds, diag == 3 ? 0 : nx, a, sq, qs, xs);
         sq.flush(); qs.flush();
 #pragma unroll
         for (int k = 0; k < GEN_NX; ++k) if (k < nx) xs[k].flush();
@@ -394,7 +395,7 @@ __device__ __forceinline__ void emit_column_1walk(const StaWinDev &W, const Mplp
 }
 
 template <bool ONE_WALK>
-__global__ void __launch_bounds__(256) GEN_OCC k_mplp_emit(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, char *out, uint32_t lds_cap)
+__global__ void __launch_bounds__(256) GEN_OCC k_mplp_emit(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, char *out, uint32_t lds_cap, int diag)
 {
     int wid = threadIdx.x >> 6;
     int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -418,7 +419,7 @@ __global__ void __launch_bounds__(256) GEN_OCC k_mplp_emit(StaWinDev W, MplpDevP
         uint32_t base = (uint32_t)wid * slice;
         uint32_t mis = (uint32_t)((uintptr_t)(out + o0) & 15);
         Sink<true> s; s.g = nullptr; s.cur = base + mis + (uint32_t)(my0 - o0);
-        if (ONE_WALK) emit_column_1walk<true>(W, P, p0, plast, p, exists, s); else emit_column<true>(W, P, p0, plast, p, exists, s);
+        if (ONE_WALK) emit_column_1walk<true>(W, P, p0, plast, p, exists, s, diag); else emit_column<true>(W, P, p0, plast, p, exists, s);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -434,7 +435,7 @@ __global__ void __launch_bounds__(256) GEN_OCC k_mplp_emit(StaWinDev W, MplpDevP
         uint32_t done = head + (body << 4);
         if (done + lane < n) dst[done + lane] = lds_text[base + mis + done + lane];
     } else {
-        if (ONE_WALK) { Sink<2> s; s.open(out + my0); emit_column_1walk<2>(W, P, p0, plast, p, exists, s); }
+        if (ONE_WALK) { Sink<2> s; s.open(out + my0); emit_column_1walk<2>(W, P, p0, plast, p, exists, s, diag); }
         else { Sink<false> s; s.cur = 0; s.g = out + my0; emit_column<false>(W, P, p0, plast, p, exists, s); }
     }
 }
@@ -1122,12 +1123,13 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
     int64_t nb = (nwaves + wpb - 1) / wpb;
     // one walk for all strings of a row (emit_column_1walk) unless the row has more extra columns than it holds cursors for
     const char *pe = getenv("STA_GENERIC_PASSES");
+    const char *gd = getenv("STA_GENERIC_DIAG"); const int gdiag = gd ? atoi(gd) : 0;
     const MplpDevPar par = make_par(p, w.tlen);
     const int n_extra = __builtin_popcount((unsigned)par.flag & (unsigned)EXTRA_MASK) + par.n_tags;
     if (n_extra <= GEN_NX && !(pe && atoi(pe) == 1))
-        hipLaunchKernelGGL(k_mplp_emit<true>, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, par, offs, out, lds_cap);
+        hipLaunchKernelGGL(k_mplp_emit<true>, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, par, offs, out, lds_cap, gdiag);
     else
-        hipLaunchKernelGGL(k_mplp_emit<false>, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, par, offs, out, lds_cap);
+        hipLaunchKernelGGL(k_mplp_emit<false>, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, par, offs, out, lds_cap, 0);
 }
 
 int64_t sta_mplp_deep_strips(int64_t ncols) { return (ncols + DEEP_STRIP - 1) / DEEP_STRIP; }

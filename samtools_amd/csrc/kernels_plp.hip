@@ -17,7 +17,12 @@
 //  (scan)      : exclusive scan of line lengths -> line offsets
 //  k_mplp_emit : writes the text.  A wave's lines are contiguous in the output, so they are
 //                assembled in LDS and flushed with coalesced 16-byte stores; a wave whose
-//                lines exceed the LDS slice falls back to direct global byte stores.
+//                lines exceed the LDS slice writes straight to the text, eight bytes per store.
+//                Since round 5 one measuring walk + one writing walk with a cursor per string
+//                of the row (emit_column_1walk); one walk per string for rows with more than
+//                GEN_NX extra columns (emit_column).
+// These two are the any-option-set path (--output-extra / -O / tag columns / --output-mods); windows without such
+// columns take the tile / read-major kernels further down.
 #include "dev_util.h"
 #include "plp_tile.h"
 #include "dev_lookback.h"

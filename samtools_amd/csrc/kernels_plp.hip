@@ -388,7 +388,7 @@ __device__ __forceinline__ void emit_column_1walk(const StaWinDev &W, const Mplp
                 if (!a.cnt) sink_poke(xs[k], 0, '*');
             }
         }
-        // (diag: STA_GENERIC_DIAG, timing only, wrong text: 1 = no writing walk, 3 = the writing walk without the extra columns)
+        // (diag: STA_GENERIC_DIAG, timing only, wrong text: 1 = no writing walk, 3 = the writing walk without the extra columns, 4 = without its eight-byte stores)
         if (diag != 1) file_walk_all<true, LDS>(R, W, P, p, exists && a.cnt, rlo, rhi, kinds, diag == 3 ? 0 : nx, a, sq, qs, xs);
         sq.flush(); qs.flush();
 #pragma unroll
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(256) GEN_OCC k_mplp_emit(StaWinDev W, MplpDevP
         uint32_t done = head + (body << 4);
         if (done + lane < n) dst[done + lane] = lds_text[base + mis + done + lane];
     } else {
-        if (ONE_WALK) { Sink<2> s; s.open(out + my0); emit_column_1walk<2>(W, P, p0, plast, p, exists, s, diag); }
+        if (ONE_WALK) { Sink<2> s; s.open(out + my0); s.dry = diag == 4; emit_column_1walk<2>(W, P, p0, plast, p, exists, s, diag); }
         else { Sink<false> s; s.cur = 0; s.g = out + my0; emit_column<false>(W, P, p0, plast, p, exists, s); }
     }
 }

@@ -157,13 +157,14 @@ template <int KIND> struct Sink {
     char *g;             // global cursor (KIND 2: where the next eight bytes go)
     uint64_t acc;        // KIND 2: the bytes not stored yet, first byte lowest
     uint32_t nb;         // KIND 2: how many
-    PLP_HD void open(char *at) { g = at; cur = 0; acc = 0; nb = 0; }
+    uint32_t dry;        // KIND 2, timing diagnostics only (STA_GENERIC_DIAG=4): the eight-byte stores are not executed
+    PLP_HD void open(char *at) { g = at; cur = 0; acc = 0; nb = 0; dry = 0; }
     PLP_HD void put_n(uint64_t v, uint32_t n)         // KIND 2: n <= 8 bytes, first byte lowest, the bytes above n zero
     {
         acc |= v << (8 * nb);
         nb += n;
         if (nb >= 8) {
-            *reinterpret_cast<sink_u64u *>(g) = acc;
+            if (!dry) *reinterpret_cast<sink_u64u *>(g) = acc;
             g += 8; nb -= 8;
             acc = nb ? v >> (8 * (n - nb)) : 0;
         }

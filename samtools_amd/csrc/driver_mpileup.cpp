@@ -240,7 +240,7 @@ struct Runner {
             if (ce > cursor) {
                 j->tid = tid; j->cb = cursor; j->ce = ce; j->have_reads = true; j->hold = false;
                 // the next window depends on this one's result only if the -d cap can drop reads here (they leave the pump)
-                const bool lockstep = cap_may_trigger(j->staged, conf.p.max_depth);
+                const bool lockstep = cap_may_trigger(j->staged, conf.p.max_depth, pump);
                 if (lockstep && shard.on) {
                     pipe->release(j);
                     fprintf(stderr, "samtools mpileup: the -d depth cap can trigger near %s:%lld, which couples this block to its predecessors; run unsharded or raise -d\n",

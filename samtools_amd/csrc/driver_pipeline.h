@@ -11,6 +11,7 @@
 // reads; `-a` still waiting for the contig's first data column) -- everything else runs ahead.
 #pragma once
 #include "host_stage.h"
+#include "host_pump.h"
 #include "../../include/samtools_amd.h"
 #include <atomic>
 #include <condition_variable>
@@ -190,21 +191,17 @@ size_t pipe_slots_from_env(int n_dev);
 // Can the -d cap (bam_plp_push: a read is dropped when more than max_depth reads are live at its start) possibly trigger for these
 // staged reads?  Conservative host-side bound: at a read's start at most the reads starting within the longest reference span
 // before it are live.  False for ordinary depths, so that the producer need not wait for the device's verdict.
-inline bool cap_may_trigger(const std::vector<StagedFile> &staged, int64_t max_depth)
+inline bool cap_may_trigger(const std::vector<StagedFile> &staged, int64_t max_depth, const WindowSource &src)
 {
     if (max_depth <= 0 || max_depth >= INT32_MAX) return false;
-    for (const StagedFile &f : staged) {
+    for (size_t fi = 0; fi < staged.size(); ++fi) {
+        const StagedFile &f = staged[fi];
         const int64_t n = f.n();
         if (n <= max_depth) continue;
-        int64_t span_max = 1;
-        for (int64_t i = 0; i < n; ++i) {
-            int64_t span = 0;
-            for (uint32_t k = f.cig_off[(size_t)i]; k < f.cig_off[(size_t)i + 1]; ++k) {
-                const uint32_t c = f.cigar[k]; const int op = (int)(c & 0xf);
-                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += (int64_t)(c >> 4);
-            }
-            if (span > span_max) span_max = span;
-        }
+        // (the spans come from the source: the staging arrays of a BAM lane with device-side pools hold no CIGARs -- reading them
+        // here made this bound meaningless and the safety net of the device thread ended such runs, found by scripts/hunt4.py)
+        int64_t span_max = src.staged_max_span(fi);
+        if (span_max < 1) span_max = 1;
         int64_t lo = 0;
         for (int64_t i = 0; i < n; ++i) {
             // the device counts read j as live at read i's start when pos[j] + span >= pos[i] (k_maxcnt_detect): keep every read

@@ -71,7 +71,8 @@ struct sta_engine {
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
     std::vector<char> late_copy;       // mpileup plan, per file: the working quality pool exists only if the window has overlap-eligible reads
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, stage_bad, md_cap, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    bool gen_xlen_on = false;          // this plan's generic measuring pass filled colinfo / gen_xlen for the emit
+    DevBuf files_d, tname_d, bed_d, line_len, colinfo, gen_xlen, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, stage_bad, md_cap, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
     DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
@@ -221,7 +222,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     if (e->pin) hipHostFree(e->pin);
-    DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->wfirst, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
+    DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->gen_xlen, &e->wfirst, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
                       &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->stage_bad, &e->md_cap, &e->chunk_words, &e->cov_out, &e->cov_hist, &e->sc_pos, &e->sc_delta, &e->sc_tmp, &e->sc_cov, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
                       &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
     for (DevBuf *b : all) b->release();
@@ -705,9 +706,18 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                 sta_launch_wave_first(s, e->wd, (uint32_t *)e->wfirst.p, e->fused_status.p);
             }
         }
+        // the generic walker's measuring pass keeps what it learns about every string of every row for its emit (k_mplp_len_x)
+        const bool tile_path = sta_mplp_has_fast_path(*p) && e->have_wfirst && sta_mplp_tile_ok(*p);
+        const int gx = tile_path ? -1 : sta_mplp_generic_extras(*p);
+        e->gen_xlen_on = false;
+        if (gx >= 0) {
+            if (e->gen_xlen.ensure((size_t)(ncols > 0 ? ncols : 1) * (size_t)(nf > 0 ? nf : 1) * (size_t)(gx > 0 ? gx : 1) * 4 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(extra-column lengths) failed");
+            e->gen_xlen_on = true;
+        }
         ProfScope ps(e, "mplp_len");
         e->len_fused = sta_launch_mplp_len(s, e->wd, *p, (uint32_t *)e->line_len.p, (uint2 *)e->colinfo.p, ctr, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr,
-                                           e->have_wfirst ? e->fused_status.p : nullptr, (uint64_t *)e->offs.p, detect_in_len ? p->max_depth : 0);
+                                           e->have_wfirst ? e->fused_status.p : nullptr, (uint64_t *)e->offs.p, detect_in_len ? p->max_depth : 0,
+                                           e->gen_xlen_on ? (uint32_t *)e->gen_xlen.p : nullptr);
     }
     return STA_OK;
 }
@@ -855,7 +865,8 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     ProfScope ps(e, deep_mode == 1 ? "mplp_emit_deep" : "mplp_emit");
     sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap, deep_mode ? (int64_t *)e->strip_rng.p : nullptr,
                          tile_cap, deep_mode, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr,
-                         e->len_fused ? sta_mplp_tile_base(e->fused_status.p, ncols) : nullptr, e->len_fused);
+                         e->len_fused ? sta_mplp_tile_base(e->fused_status.p, ncols) : nullptr, e->len_fused,
+                         (!e->len_fused && e->gen_xlen_on) ? (const uint32_t *)e->gen_xlen.p : nullptr);
     return STA_OK;
 }
 

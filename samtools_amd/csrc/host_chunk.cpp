@@ -646,6 +646,17 @@ bool ChunkPump::staged_has_span(size_t fi, size_t i) const
     return false;
 }
 
+int64_t ChunkPump::staged_max_span(size_t fi) const
+{
+    if (fi >= f_.size()) return 0;
+    const File &f = f_[fi];
+    int64_t m = 0;
+    size_t i = 0;
+    for (auto &r : f.carry) { if (i++ >= f.n_carry_staged) break; if ((int64_t)r.rlen > m) m = (int64_t)r.rlen; }
+    for (auto &g : f.fresh) for (int64_t k = g.i0; k < g.i1; ++k) if ((int64_t)g.c->rlen[(size_t)k] > m) m = (int64_t)g.c->rlen[(size_t)k];
+    return m;
+}
+
 void ChunkPump::drop(size_t fi, const std::vector<char> &dropped)
 {
     File &f = f_[fi];

@@ -128,6 +128,7 @@ public:
     int64_t fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged) override { return fill_window(tid, cb, ce_target, &staged); }
     int64_t fill_unstaged(int tid, int64_t cb, int64_t ce_target) override { return fill_window(tid, cb, ce_target, nullptr); }
     bool staged_has_span(size_t f, size_t i) const override;
+    int64_t staged_max_span(size_t f) const override;
     void drop(size_t f, const std::vector<char> &dropped) override;
     void retire(int64_t ce) override;
     void drop_tid_carry() override;

@@ -72,6 +72,9 @@ public:
         return pos;
     }
     virtual bool staged_has_span(size_t f, size_t i) const = 0;      // reference span > 0 of the i-th staged read of file f
+    // longest reference span among the staged reads of file f (the staging arrays need not hold the CIGARs: with device-side pools
+    // of BAM records they do not -- host_stage.h raw_mode)
+    virtual int64_t staged_max_span(size_t f) const = 0;
     virtual void drop(size_t f, const std::vector<char> &dropped) = 0;
     virtual void retire(int64_t ce) = 0;
     virtual void drop_tid_carry() = 0;
@@ -99,6 +102,7 @@ public:
     int64_t fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged) override;
     int64_t fill_unstaged(int tid, int64_t cb, int64_t ce_target) override { return fill(tid, cb, ce_target, last_); }
     bool staged_has_span(size_t f, size_t i) const override { return f < last_.size() && i < last_[f].size() && last_[f][i]->rlen > 0; }
+    int64_t staged_max_span(size_t f) const override { int64_t m = 0; if (f < last_.size()) for (const Rec *r : last_[f]) if ((int64_t)r->rlen > m) m = (int64_t)r->rlen; return m; }
     void retire(int64_t ce) override;
     // before retire(): reads of file f (indexed as fill() returned them) that the -d cap dropped in this window leave the
     // iterator for good, exactly as bam_plp_push never stored them

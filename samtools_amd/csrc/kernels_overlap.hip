@@ -51,12 +51,13 @@ __device__ __forceinline__ bool name_eq(const StaReadsDev &R, int64_t a, int64_t
 }
 
 // which reads take part in name matching
-#define SEL_MPLP 0   // RI_OLAP_EL, or pushed-but-dropped by the -d cap (those call overlap_remove)
+#define SEL_MPLP 0   // every read that reaches bam_plp_push: the eligible ones (RI_OLAP_EL) put and find entries; the others still REMOVE the
+                     // entry of their name -- dropped by the -d cap at the push, or when they leave the buffer (overlap_remove is by name)
 #define SEL_DEPTH 1  // kept && PAIRED && !MUNMAP
 __device__ __forceinline__ bool in_set(const StaReadsDev &R, int64_t i, int sel)
 {
     uint32_t info = R.info[i];
-    if (sel == SEL_MPLP) return (info & RI_OLAP_EL) || ((info & RI_PUSHED) && !(info & RI_KEEP) && R.end[i] > R.pos[i]);
+    if (sel == SEL_MPLP) return (info & RI_PUSHED) && R.end[i] > R.pos[i];
     uint32_t flag = R.flag[i];
     return (info & RI_KEEP) && (flag & BAM_FPAIRED) && !(flag & BAM_FMUNMAP);
 }
@@ -240,8 +241,20 @@ __global__ void __launch_bounds__(256) k_name_groups(StaReadsDev R, int64_t orig
         last = x;
         if (sel == SEL_MPLP) {
             uint32_t info = R.info[x];
-            if (!(info & RI_KEEP)) { holder = -1; continue; }              // dropped by -d: overlap_remove
-            if (holder >= 0 && members > 2 && prev_pushed_pos(R, x) > R.end[holder]) holder = -1;   // holder left the buffer
+            // A member that leaves the buffer takes the entry of its NAME with it (bam_plp_next frees a node whose end the iterator has
+            // passed and calls overlap_remove): the holder itself, or any other record of the template -- a supplementary alignment, a
+            // primary that overlap_push turned away.  A member e is freed once a read beyond its end has been pushed; the entry it finds
+            // is the holder's if the holder was put before that: max_pos at the holder's push <= end[e] < max_pos at x's push.
+            if (holder >= 0 && members > 2) {
+                const int before_x = prev_pushed_pos(R, x), before_h = prev_pushed_pos(R, holder);
+                for (unsigned int j = tab[s].head; j && holder >= 0; j = (unsigned int)chain_next[j - 1]) {
+                    const int64_t m = (int64_t)j - 1;
+                    if (m >= x || !(R.info[m] & RI_KEEP) || !(m == i || name_eq(R, i, m))) continue;
+                    if (before_h <= R.end[m] && R.end[m] < before_x) holder = -1;
+                }
+            }
+            if (!(info & RI_KEEP)) { holder = -1; continue; }              // dropped by -d at its push: overlap_remove
+            if (!(info & RI_OLAP_EL)) continue;                            // in the buffer, but overlap_push returned before the hash
             if (holder < 0) {
                 long long mpos = R.mpos[x];
                 if (mpos >= origin + R.pos[x] || ((R.flag[x] & BAM_FPAIRED) && mpos == -1)) holder = x;

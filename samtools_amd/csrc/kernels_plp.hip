@@ -334,8 +334,72 @@ __device__ __forceinline__ void file_walk_all(const StaReadsDev &R, const StaWin
     }
 }
 
+// the extra columns in output order: the flag columns by ascending bit, then the aux-tag columns (bam_plcmd.c:727-852)
+__device__ __forceinline__ int gen_kinds(const MplpDevPar &P, int (&kinds)[GEN_NX])
+{
+    uint32_t ex = (uint32_t)P.flag & EXTRA_MASK;
+    const int nfl = __popc(ex);
+#pragma unroll
+    for (int k = 0; k < GEN_NX; ++k) {
+        kinds[k] = k < nfl ? (int)(ex & (~ex + 1)) : TAGKIND + (k - nfl);
+        ex &= ex - 1;
+    }
+    return nfl + P.n_tags;
+}
+
+// k_mplp_len for windows whose rows the single-walk emit writes (at most GEN_NX extra columns): the same line lengths, and what the
+// measuring walk learnt about every string of every row is KEPT -- colinfo[file][column] = (entries, base-string bytes),
+// xlen[file][extra column][column] = bytes of that column's fields -- so that k_mplp_emit goes straight to its writing walk
+// (it used to repeat this walk: 2.1 of its 8.9 ms on mpileup30_B_sOx, profiles/r05_generic_walker.md).
+__global__ void __launch_bounds__(256) k_mplp_len_x(StaWinDev W, MplpDevPar P, uint32_t *line_len, uint2 *__restrict__ colinfo, uint32_t *__restrict__ xlen)
+{
+    int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    int lane = threadIdx.x & 63;
+    int64_t ncols = (int64_t)W.col_end - W.col_beg;
+    int64_t c0 = (int64_t)wave * 64;
+    if (c0 >= ncols) return;
+    int p0 = W.col_beg + (int)c0;
+    int p = p0 + lane;
+    bool active = p < W.col_end;
+    int plast = p0 + 63 < W.col_end ? p0 + 63 : W.col_end - 1;
+    int64_t apos = W.origin + p;
+    int kinds[GEN_NX];
+    const int nx = gen_kinds(P, kinds);
+
+    uint32_t total = 0; bool any = false;
+    Sink<0> dummy; dummy.g = nullptr; dummy.cur = 0;
+    Sink<0> dummies[GEN_NX];
+    for (int f = 0; f < W.nfiles; ++f) {
+        const StaReadsDev &R = W.files[f];
+        int64_t rlo, rhi;
+        wave_read_range(R, p0, plast, rlo, rhi);
+        AccX a; a.n_plp = a.cnt = a.seq_len = 0;
+#pragma unroll
+        for (int k = 0; k < GEN_NX; ++k) a.xlen[k] = 0;
+        file_walk_all<false, 0>(R, W, P, p, active, rlo, rhi, kinds, nx, a, dummy, dummy, dummies);
+        any |= a.n_plp > 0;
+        Acc t{ a.n_plp, a.cnt, a.seq_len, 0 };
+#pragma unroll
+        for (int k = 0; k < GEN_NX; ++k) if (k < nx) t.extras_len += a.xlen[k];
+        total += file_text_len(P, t);
+        if (active) {
+            colinfo[(int64_t)f * ncols + c0 + lane] = make_uint2(a.cnt, a.seq_len);
+#pragma unroll
+            for (int k = 0; k < GEN_NX; ++k) if (k < nx) xlen[((int64_t)f * nx + k) * ncols + c0 + lane] = a.xlen[k];
+        }
+    }
+    bool in_reg = active && column_selected(W, apos);
+    bool data = in_reg && any;
+    bool exists = in_reg && (any || (P.all && apos < P.tlen));
+    if (exists && W.has_bed) exists = bed_overlap_dev(W.bed_beg, W.bed_end, W.n_bed, apos, apos + 1);
+    uint32_t len = 0;
+    if (exists) len = (uint32_t)W.tname_len + 1 + (uint32_t)dec_digits((unsigned long long)(apos + 1)) + 1 + 1 + total + 1;
+    if (active) line_len[c0 + lane] = len | (data ? 0x80000000u : 0u);     // rows / data columns are counted by k_col_stats
+}
+
 template <int LDS>
-__device__ __forceinline__ void emit_column_1walk(const StaWinDev &W, const MplpDevPar &P, int p0, int plast, int p, bool exists, Sink<LDS> &s, int diag)
+__device__ __forceinline__ void emit_column_1walk(const StaWinDev &W, const MplpDevPar &P, int p0, int plast, int p, bool exists, Sink<LDS> &s, int diag,
+                                                  const uint2 *__restrict__ colinfo, const uint32_t *__restrict__ xlen /* k_mplp_len_x's; NULL: measure here */)
 {
     int64_t apos = W.origin + p;
     if (exists) {
@@ -345,15 +409,9 @@ __device__ __forceinline__ void emit_column_1walk(const StaWinDev &W, const Mplp
         s.put('\t');
         s.put((W.ref && apos < W.ref_len) ? W.ref[apos] : 'N');
     }
-    // the extra columns in output order: the flag columns by ascending bit, then the aux-tag columns (bam_plcmd.c:727-852)
     int kinds[GEN_NX];
-    uint32_t ex = (uint32_t)P.flag & EXTRA_MASK;
-    const int nfl = __popc(ex), nx = nfl + P.n_tags;
-#pragma unroll
-    for (int k = 0; k < GEN_NX; ++k) {
-        kinds[k] = k < nfl ? (int)(ex & (~ex + 1)) : TAGKIND + (k - nfl);
-        ex &= ex - 1;
-    }
+    const int nx = gen_kinds(P, kinds);
+    const int64_t ncols = (int64_t)W.col_end - W.col_beg, col = (int64_t)p - W.col_beg;
     for (int f = 0; f < W.nfiles; ++f) {
         const StaReadsDev &R = W.files[f];
         int64_t rlo, rhi;
@@ -362,7 +420,14 @@ __device__ __forceinline__ void emit_column_1walk(const StaWinDev &W, const Mplp
 #pragma unroll
         for (int k = 0; k < GEN_NX; ++k) a.xlen[k] = 0;
         Sink<LDS> xs[GEN_NX];
-        file_walk_all<false, LDS>(R, W, P, p, exists, rlo, rhi, kinds, nx, a, s, s, xs);
+        if (xlen) {
+            if (exists) {
+                const uint2 ci = colinfo[(int64_t)f * ncols + col];
+                a.cnt = ci.x; a.seq_len = ci.y;
+#pragma unroll
+                for (int k = 0; k < GEN_NX; ++k) if (k < nx) a.xlen[k] = xlen[((int64_t)f * nx + k) * ncols + col];
+            }
+        } else file_walk_all<false, LDS>(R, W, P, p, exists, rlo, rhi, kinds, nx, a, s, s, xs);
         if (exists) { s.put('\t'); s.put_dec(a.cnt); s.put('\t'); }
         s.flush();
         // where the strings of this file's part of the row start: bases | qualities | extra columns
@@ -400,7 +465,8 @@ __device__ __forceinline__ void emit_column_1walk(const StaWinDev &W, const Mplp
 }
 
 template <bool ONE_WALK>
-__global__ void __launch_bounds__(256) GEN_OCC k_mplp_emit(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, char *out, uint32_t lds_cap, int diag)
+__global__ void __launch_bounds__(256) GEN_OCC k_mplp_emit(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, char *out, uint32_t lds_cap, int diag,
+                                                               const uint2 *__restrict__ colinfo, const uint32_t *__restrict__ xlen)
 {
     int wid = threadIdx.x >> 6;
     int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -424,7 +490,7 @@ __global__ void __launch_bounds__(256) GEN_OCC k_mplp_emit(StaWinDev W, MplpDevP
         uint32_t base = (uint32_t)wid * slice;
         uint32_t mis = (uint32_t)((uintptr_t)(out + o0) & 15);
         Sink<true> s; s.g = nullptr; s.cur = base + mis + (uint32_t)(my0 - o0);
-        if (ONE_WALK) emit_column_1walk<true>(W, P, p0, plast, p, exists, s, diag); else emit_column<true>(W, P, p0, plast, p, exists, s);
+        if (ONE_WALK) emit_column_1walk<true>(W, P, p0, plast, p, exists, s, diag, colinfo, xlen); else emit_column<true>(W, P, p0, plast, p, exists, s);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -440,7 +506,7 @@ __global__ void __launch_bounds__(256) GEN_OCC k_mplp_emit(StaWinDev W, MplpDevP
         uint32_t done = head + (body << 4);
         if (done + lane < n) dst[done + lane] = lds_text[base + mis + done + lane];
     } else {
-        if (ONE_WALK) { Sink<2> s; s.open(out + my0); s.dry = diag == 4; emit_column_1walk<2>(W, P, p0, plast, p, exists, s, diag); }
+        if (ONE_WALK) { Sink<2> s; s.open(out + my0); s.dry = diag == 4; emit_column_1walk<2>(W, P, p0, plast, p, exists, s, diag, colinfo, xlen); }
         else { Sink<false> s; s.cur = 0; s.g = out + my0; emit_column<false>(W, P, p0, plast, p, exists, s); }
     }
 }
@@ -1047,6 +1113,13 @@ __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W,
     if (done + lane < n) dst[done + lane] = lds_text[base + mis + done + lane];
 }
 
+// extra columns of a window the generic walkers write: their number if the single-walk emit holds cursors for them, else -1
+int sta_mplp_generic_extras(const sta_mplp_params &p)
+{
+    const int n = __builtin_popcount((unsigned)p.flag & (unsigned)EXTRA_MASK) + (p.n_tags > 0 ? p.n_tags : 0);
+    return n <= GEN_NX ? n : -1;
+}
+
 static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
 {
     MplpDevPar d;
@@ -1071,7 +1144,7 @@ void sta_launch_wave_first(hipStream_t s, const StaWinDev &w, uint32_t *wfirst, 
 }
 
 bool sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo, StaCounters *ctr, const uint32_t *wfirst,
-                         void *status, uint64_t *offs, int detect_maxcnt)
+                         void *status, uint64_t *offs, int detect_maxcnt, uint32_t *gen_xlen)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return false;
@@ -1083,7 +1156,10 @@ bool sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_param
         return true;          // offsets (tile-relative + tile bases), totals and the largest wave are done: no scan / column statistics launches
     }
     int64_t nb = (ncols + 255) / 256;
-    hipLaunchKernelGGL(k_mplp_len, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, ctr);
+    if (gen_xlen && colinfo && sta_mplp_generic_extras(p) >= 0)
+        hipLaunchKernelGGL(k_mplp_len_x, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, colinfo, gen_xlen);
+    else
+        hipLaunchKernelGGL(k_mplp_len, dim3((unsigned)nb), dim3(256), 0, s, w, make_par(p, w.tlen), line_len, ctr);
     return false;
 }
 
@@ -1102,7 +1178,8 @@ static void launch_deep(hipStream_t s, const StaWinDev &w, const sta_mplp_params
 // k_mplp_emit_deep; otherwise k_mplp_emit_tile, and with deep_mode 2 the 64-column groups whose rows exceed tile_cap through
 // k_mplp_emit_deep beside it.  tile = false: the generic walker (absolute offsets, any option set).
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
-                          char *out, uint32_t lds_cap, int64_t *strip_rng, uint32_t tile_cap, int deep_mode, const uint32_t *wfirst, const uint64_t *tbase, bool tile)
+                          char *out, uint32_t lds_cap, int64_t *strip_rng, uint32_t tile_cap, int deep_mode, const uint32_t *wfirst, const uint64_t *tbase, bool tile,
+                          const uint32_t *gen_xlen)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
@@ -1130,11 +1207,11 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
     const char *pe = getenv("STA_GENERIC_PASSES");
     const char *gd = getenv("STA_GENERIC_DIAG"); const int gdiag = gd ? atoi(gd) : 0;
     const MplpDevPar par = make_par(p, w.tlen);
-    const int n_extra = __builtin_popcount((unsigned)par.flag & (unsigned)EXTRA_MASK) + par.n_tags;
-    if (n_extra <= GEN_NX && !(pe && atoi(pe) == 1))
-        hipLaunchKernelGGL(k_mplp_emit<true>, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, par, offs, out, lds_cap, gdiag);
+    if (pe && atoi(pe) == 2) gen_xlen = nullptr;           // STA_GENERIC_PASSES=2: the single-walk emit measuring for itself (A/B of k_mplp_len_x)
+    if (sta_mplp_generic_extras(p) >= 0 && !(pe && atoi(pe) == 1))
+        hipLaunchKernelGGL(k_mplp_emit<true>, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, par, offs, out, lds_cap, gdiag, colinfo, gen_xlen);
     else
-        hipLaunchKernelGGL(k_mplp_emit<false>, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, par, offs, out, lds_cap, 0);
+        hipLaunchKernelGGL(k_mplp_emit<false>, dim3((unsigned)nb), dim3(64 * wpb), (size_t)wpb * slice, s, w, par, offs, out, lds_cap, 0, (const uint2 *)nullptr, (const uint32_t *)nullptr);
 }
 
 int64_t sta_mplp_deep_strips(int64_t ncols) { return (ncols + DEEP_STRIP - 1) / DEEP_STRIP; }

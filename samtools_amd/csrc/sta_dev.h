@@ -111,7 +111,9 @@ void sta_launch_len_scan(hipStream_t s, const uint32_t *len, uint64_t *offs, int
 // caller skips the scan and column-statistics launches.  Otherwise the generic walker k_mplp_len (line lengths only), false.
 bool sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, uint32_t *line_len, uint2 *colinfo /*[nfiles][ncols] (count, seq bytes)*/,
                          StaCounters *ctr, const uint32_t *wfirst /* sta_launch_wave_first's table */, void *status /* sta_mplp_len_status_bytes() */, uint64_t *offs,
-                         int detect_maxcnt /* > 0: also run the -d detector (kernels_maxcnt.hip) for this cap */);
+                         int detect_maxcnt /* > 0: also run the -d detector (kernels_maxcnt.hip) for this cap */,
+                         uint32_t *gen_xlen = nullptr /* generic walker: [nfiles][sta_mplp_generic_extras()][ncols] bytes per extra column, kept for the emit */);
+int sta_mplp_generic_extras(const sta_mplp_params &p);
 // wfirst[nfiles][ncols / 64 + 2]: first read starting at or beyond every 64-column group (where the tile kernels start looking)
 void sta_launch_wave_first(hipStream_t s, const StaWinDev &w, uint32_t *wfirst, void *status);
 size_t sta_mplp_len_status_bytes(int64_t ncols);
@@ -119,7 +121,8 @@ const uint64_t *sta_mplp_tile_base(const void *status, int64_t ncols);
 int64_t sta_mplp_deep_strips(int64_t ncols);      // strips of the read-major emit kernel; strip_rng holds 2 x int64 per (file, strip)
 void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo,
                           char *out, uint32_t lds_cap /* generic walker's slice */, int64_t *strip_rng /* workspace of the read-major kernel */, uint32_t tile_cap, int deep_mode,
-                          const uint32_t *wfirst, const uint64_t *tbase /* sta_mplp_tile_base() */, bool tile /* the measuring pass returned true */);
+                          const uint32_t *wfirst, const uint64_t *tbase /* sta_mplp_tile_base() */, bool tile /* the measuring pass returned true */,
+                          const uint32_t *gen_xlen = nullptr /* what sta_launch_mplp_len kept (NULL: the generic emit measures for itself) */);
 bool sta_mplp_has_fast_path(const sta_mplp_params &p);
 bool sta_mplp_tile_ok(const sta_mplp_params &p);
 void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, const uint32_t *line_len, int64_t ncols, StaCounters *ctr);

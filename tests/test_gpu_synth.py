@@ -47,6 +47,45 @@ def test_engine_equals_oracle_on_synthetic(tmp_path, oracle_bin, product_bin, ci
         pytest.fail("line count differs: got %d want %d" % (len(g), len(w)))
 
 
+def test_template_with_three_records_in_the_overlap_hash(tmp_path, oracle_bin, product_bin):
+    """overlap_remove is BY NAME (HTSlib sam.c overlap_remove): a record that leaves the pileup buffer deletes the hash entry
+    of its template even when the entry belongs to another record of it.  tests/synth_rich.py seed 104 holds such a template (found by
+    scripts/hunt4.py): a primary that overlap_push turns away (mate beyond its end), a supplementary alignment that puts the entry, the
+    primary leaving the buffer before the mate arrives -- the mate must then find nothing, and the supplementary's ref-skip placeholder
+    keeps its quality.  Tile path and generic walker, against the oracle."""
+    from synth_rich import write_rich_sam
+    sam, fa = write_rich_sam(str(tmp_path), seed=4, n_templates=5000)
+    sam2, _ = write_rich_sam(str(tmp_path), seed=104, n_templates=1500)
+    for args in (["mpileup", "-B", "-Q", "20", "-f", fa, sam, sam2], ["mpileup", "-f", fa, sam2],
+                 ["mpileup", "-B", "-s", "--output-extra", "MD,XS", "-Q", "20", "-f", fa, sam, sam2]):
+        want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        row = [l for l in want.split(b"\n") if l.startswith(b"c2\t6949\t")]
+        assert len(row) == 1
+        for env in ({}, {"STA_WINDOW_COLS": "900"}):
+            got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+            assert got.returncode == 0, got.stderr.decode()[-500:]
+            assert [l for l in got.stdout.split(b"\n") if l.startswith(b"c2\t6949\t")] == row
+            assert got.stdout == want, (args, env)
+
+
+@pytest.mark.parametrize("opts", [["-B"], ["-B", "--output-BP-5", "--output-QNAME"]], ids=["tile", "generic"])
+def test_depth_cap_on_bam_input_with_small_windows(tmp_path, oracle_bin, product_bin, opts):
+    """-d 12 on a BAM (the lane whose staging arrays hold no CIGARs: the records' pools are cut out on the device) with windows of 3 000
+    columns: the producer's bound on where the cap can trigger (driver_pipeline.h cap_may_trigger) has to take the reads' spans from the
+    input lane.  It read the empty CIGAR pool, waited for no window, and the device thread's safety net ended the run
+    ("the -d cap removed reads ... in a window the producer did not wait for"; found by scripts/hunt4.py seed 6)."""
+    from synth_rich import write_rich_sam
+    from bamio import sam_to_bam
+    sam, fa = write_rich_sam(str(tmp_path), seed=6, n_templates=5000)
+    bam = sam_to_bam(sam, str(tmp_path / "rich.bam"), level=1, block=20000)
+    args = ["mpileup"] + opts + ["-d", "12", "-f", fa]
+    want = subprocess.run([oracle_bin] + args + [sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    for env in ({"STA_WINDOW_COLS": "3000", "STA_PLP_BATCH": "700"}, {"STA_WINDOW_COLS": "900"}, {}):
+        got = subprocess.run([product_bin] + args + [bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert got.returncode == 0, got.stderr.decode()[-500:]
+        assert got.stdout == want, env
+
+
 _GENERIC_OPTS = {
     "sOx3": ["-s", "-O", "--output-QNAME"],
     # eight extra columns: as many as emit_column_1walk holds cursors for (kernels_plp.hip GEN_NX); flag columns come out in bit order, tags after

@@ -9,6 +9,16 @@ REPO = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 sys.path.insert(0, REPO)
 
+from product_paths import hipemu, product_exe, product_root  # noqa: E402
+
+if hipemu():
+    # STA_HIPEMU=1 / =asan, set by hand: the same tests against the CPU emulation build of the library's own sources
+    # (tests/cpu/hipemu, test infrastructure for containers without a GPU).  `import samtools_amd` then finds the links to the package's
+    # Python files that sit next to the emulated library.
+    if not os.path.exists(product_exe()):
+        raise SystemExit("STA_HIPEMU is set but %s is missing: make -C tests/cpu/hipemu%s" % (product_exe(), " SAN=1" if hipemu() == "asan" else ""))
+    sys.path.insert(0, product_root())
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -17,6 +27,8 @@ def pytest_configure(config):
 def pytest_sessionstart(session):
     """The C-ABI library is built in-tree by __graft_entry__.build(); a fresh checkout that runs the tests first gets it built
     here (hipcc cross-compiles gfx950 without a GPU).  Nothing is built when the artefacts are already there."""
+    if hipemu():
+        return
     lib = os.path.join(REPO, "samtools_amd", "lib", "libsamtools_amd.so")
     exe = os.path.join(REPO, "samtools_amd", "bin", "samtools-amd")
     if os.path.exists(lib) and os.path.exists(exe):
@@ -41,7 +53,7 @@ def oracle_bin():
 @pytest.fixture(scope="session")
 def product_bin():
     """samtools-amd CLI (HIP engine).  Must already be built in-tree (see __graft_entry__.build)."""
-    exe = os.path.join(REPO, "samtools_amd", "bin", "samtools-amd")
+    exe = product_exe()
     if not os.path.exists(exe):
         pytest.fail("samtools_amd/bin/samtools-amd is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
     return exe

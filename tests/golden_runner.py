@@ -10,6 +10,8 @@ import os
 import subprocess
 import tempfile
 
+from product_paths import product_exe
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 
@@ -74,7 +76,7 @@ def read_expected(path, post):
 
 GOLDEN = os.path.join(HERE, "golden")
 ORACLE = os.path.join(REPO, "oracle", "_build", "oracle_samtools")
-PRODUCT = os.path.join(REPO, "samtools_amd", "bin", "samtools-amd")
+PRODUCT = product_exe()
 
 
 def case_paths(group, exp):

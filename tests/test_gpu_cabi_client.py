@@ -8,6 +8,7 @@ import subprocess
 import pytest
 
 from cabi_client import build_client, build_cons_client
+from product_paths import REPO, lib_dir
 from synth import write_synth_sam
 
 pytestmark = pytest.mark.gpu
@@ -94,9 +95,8 @@ int main(void) {
 }
 """)
     exe = str(tmp_path / "t")
-    lib = os.path.join(os.path.dirname(G), "..", "samtools_amd", "lib")
-    lib = os.path.abspath(lib)
-    subprocess.run(["gcc", "-std=c99", "-DSTA_PLP_DROPIN", "-I", os.path.join(os.path.dirname(lib), "..", "include"), str(src), "-L", lib, "-lsamtools_amd",
+    lib = lib_dir()
+    subprocess.run(["gcc", "-std=c99", "-DSTA_PLP_DROPIN", "-I", os.path.join(REPO, "include"), str(src), "-L", lib, "-lsamtools_amd",
                     "-Wl,-rpath," + lib, "-o", exe], check=True)
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr.decode()

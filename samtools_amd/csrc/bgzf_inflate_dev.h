@@ -411,9 +411,18 @@ BZ_HD int inflate_block(Lds &L, const Consts &C, const uint8_t *in, int64_t in_l
                     BZ_MEM_FENCE();
                     const uint8_t *g = dst + (o - dist);
                     for (unsigned i = (unsigned)lane; i < len; i += BZ_NL) { const uint8_t v = g[i]; L.ring[(d0 + i) & RING_MASK] = v; }
-                } else if (dist >= (unsigned)BZ_NL || dist >= len) {
-                    // lanes of one pass never read what the same pass writes; the passes run in order
+                } else if (dist >= len) {
+                    // no overlap
                     for (unsigned i = (unsigned)lane; i < len; i += BZ_NL) { const uint8_t v = L.ring[(s0 + i) & RING_MASK]; L.ring[(d0 + i) & RING_MASK] = v; }
+                } else if (dist >= (unsigned)BZ_NL) {
+                    // lanes of one pass never read what the same pass writes; a later pass reads what an earlier one wrote, so the passes
+                    // are separated (the wave runs them in order anyway; the fence says so to the compiler and to the CPU emulation of
+                    // tests/cpu/hipemu, where the lanes of a wave only meet at wave-level operations)
+                    for (unsigned i0 = 0; i0 < len; i0 += BZ_NL) {
+                        const unsigned i = i0 + (unsigned)lane;
+                        if (i < len) { const uint8_t v = L.ring[(s0 + i) & RING_MASK]; L.ring[(d0 + i) & RING_MASK] = v; }
+                        BZ_LDS_FENCE();
+                    }
                 } else if (dist == 1) {
                     const uint8_t v = L.ring[s0 & RING_MASK];
                     for (unsigned i = (unsigned)lane; i < len; i += BZ_NL) L.ring[(d0 + i) & RING_MASK] = v;

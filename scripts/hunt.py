@@ -21,7 +21,7 @@ for name, gen, argv in CASES:
     want = subprocess.run(["oracle/_build/oracle_samtools"] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.split(b"\n")
     t1 = time.time()
     for envx in ({}, {"STA_WINDOW_COLS": "5000", "STA_PLP_BATCH": "3000"}):
-        p = subprocess.run(["samtools_amd/bin/samtools-amd"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **envx))
+        p = subprocess.run([os.environ.get("STA_EXE", "samtools_amd/bin/samtools-amd")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **envx))
         got = p.stdout.split(b"\n")
         nd = [i for i, (x, y) in enumerate(zip(got, want)) if x != y]
         print("%-18s %s rc=%d lines %d/%d differing %d first %s (oracle %.1fs)" % (name, "small-windows" if envx else "default", p.returncode, len(got), len(want), len(nd), nd[:3], t1 - t0))

@@ -39,7 +39,7 @@ for name, args in CASES:
     want = o.stdout.split(b"\n")
     t1 = time.time()
     for envx in ({}, {"STA_WINDOW_COLS": "7000", "STA_PLP_BATCH": "2500"}):
-        p = subprocess.run(["samtools_amd/bin/samtools-amd"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **envx))
+        p = subprocess.run([os.environ.get("STA_EXE", "samtools_amd/bin/samtools-amd")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **envx))
         got = p.stdout.split(b"\n")
         nd = [i for i, (x, y) in enumerate(zip(got, want)) if x != y]
         print("%-18s %s rc=%d/%d lines %d/%d differing %d first %s (oracle %.1fs) %s" % (name, "small" if envx else "default", p.returncode, o.returncode, len(got), len(want), len(nd), nd[:3], t1 - t0, p.stderr.decode()[-120:].replace("\n", "|") if p.returncode else ""))

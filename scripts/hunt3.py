@@ -34,7 +34,7 @@ for seed in seeds:
         want = o.stdout.split(b"\n")
         for envx in ({}, {"STA_WINDOW_COLS": "900", "STA_PLP_BATCH": "700"}):
             eargs = [bam if (a == sam and envx) else a for a in args]
-            p = subprocess.run(["samtools_amd/bin/samtools-amd"] + eargs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **envx))
+            p = subprocess.run([os.environ.get("STA_EXE", "samtools_amd/bin/samtools-amd")] + eargs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **envx))
             got = p.stdout.split(b"\n")
             nd = [i for i, (x, y) in enumerate(zip(got, want)) if x != y]
             ok = p.returncode == o.returncode and len(got) == len(want) and not nd

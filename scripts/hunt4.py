@@ -37,7 +37,7 @@ for seed in seeds:
         o = subprocess.run(["oracle/_build/oracle_samtools"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         for envx in ({}, {"STA_GENERIC_PASSES": "1"}, {"STA_GENERIC_LDS_CAP": "1024", "STA_WINDOW_COLS": "900"}, {"STA_WINDOW_COLS": "3000", "STA_PLP_BATCH": "700"}):
             eargs = [bam if (a == sam and "STA_PLP_BATCH" in envx) else a for a in args]
-            p = subprocess.run(["samtools_amd/bin/samtools-amd"] + eargs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **envx))
+            p = subprocess.run([os.environ.get("STA_EXE", "samtools_amd/bin/samtools-amd")] + eargs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **envx))
             ok = p.returncode == o.returncode and p.stdout == o.stdout
             print("%s seed %d case %d %s %s rc=%d/%d bytes %d/%d" % ("ok  " if ok else "FAIL", seed, case, envx, " ".join(opts), p.returncode, o.returncode, len(p.stdout), len(o.stdout)), flush=True)
             if not ok:

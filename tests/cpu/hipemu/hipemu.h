@@ -85,8 +85,11 @@ struct Block { dim3 bid, bdim, gdim; };
 extern thread_local Lane *tl_lane;
 extern thread_local Block tl_block;
 
-uint64_t wave_op(int kind, uint64_t val, int arg, int width);
-void block_barrier();
+// `convergent`: what the device compiler knows about these operations -- a call may not be duplicated into, or moved under, control
+// flow it was not written in (the host compiler would otherwise clone a ballot into both arms of a lane-varying branch: two sites for
+// what the kernel wrote as one)
+__attribute__((convergent)) uint64_t wave_op(int kind, uint64_t val, int arg, int width);
+__attribute__((convergent)) void block_barrier();
 void lane_yield();            // s_sleep in a spin loop: let the other lanes (and, one day, workgroups) run
 
 template <class T> inline uint64_t to_bits(T v) { static_assert(sizeof(T) <= 8 && std::is_trivially_copyable<T>::value, "wave operand"); uint64_t u = 0; memcpy(&u, &v, sizeof(T)); return u; }

@@ -20,6 +20,7 @@
 #define HIPEMU_ASAN 1
 extern "C" void __sanitizer_start_switch_fiber(void **fake_stack_save, const void *bottom, size_t size);
 extern "C" void __sanitizer_finish_switch_fiber(void *fake_stack_save, const void **bottom_old, size_t *size_old);
+extern "C" void __asan_unpoison_memory_region(void const volatile *addr, size_t size);
 #endif
 #endif
 
@@ -96,6 +97,7 @@ thread_local Sched tl_s;
 
 long env_long(const char *k, long d) { const char *v = getenv(k); return v && *v ? atol(v) : d; }
 const bool g_trace = env_long("HIPEMU_TRACE", 0) != 0;
+const bool g_poison_lds = env_long("HIPEMU_POISON", 1) != 0;
 const bool g_diverge_log = env_long("HIPEMU_LOG_DIVERGENCE", 0) != 0;
 
 // a code address as an offset into the library (what llvm-symbolizer -e <library> wants)
@@ -110,6 +112,7 @@ uintptr_t off(const void *p) { return (uintptr_t)p - g_base; }
 
 inline void to_sched(Lane *me)
 {
+    { const uintptr_t here = (uintptr_t)__builtin_frame_address(0); if (here < me->low_sp) me->low_sp = here; }
 #ifdef HIPEMU_ASAN
     void *fake = nullptr;
     __sanitizer_start_switch_fiber(me->state == S_DONE ? nullptr : &fake, tl_s.sched_bottom, tl_s.sched_size);
@@ -148,8 +151,15 @@ inline void run_lane(Lane *l)
 
 void prepare_lane(Lane *l, char *stack, size_t bytes)
 {
-    l->stack = stack;
     uintptr_t top = ((uintptr_t)stack + bytes) & ~(uintptr_t)15;
+#ifdef HIPEMU_ASAN
+    // the stack is used again: whatever red zones its last fiber's frames left behind are stale
+    if (l->stack == stack && l->low_sp >= (uintptr_t)stack && l->low_sp < top) {
+        uintptr_t lo = l->low_sp > (uintptr_t)stack + 8192 ? l->low_sp - 8192 : (uintptr_t)stack;
+        __asan_unpoison_memory_region((void *)lo, top - lo);
+    } else __asan_unpoison_memory_region(stack, bytes);
+#endif
+    l->stack = stack; l->low_sp = top;
     void **sp = (void **)top;
     *--sp = nullptr;                       // the "return address" of fiber_entry (never used)
     *--sp = (void *)&fiber_entry;          // popped by hipemu_switch's ret
@@ -279,6 +289,9 @@ void run_block(const Launch &L, unsigned bx, unsigned by, unsigned bz)
     Sched &S = tl_s;
     const int n = (int)(L.block.x * L.block.y * L.block.z);
     tl_block.bid = dim3(bx, by, bz); tl_block.bdim = L.block; tl_block.gdim = L.grid;
+    if (g_poison_lds && L.shmem) {          // LDS holds whatever the last workgroup left there: nothing may depend on it
+        memset(baq_state, 0x5A, L.shmem); memset(lds, 0x5A, L.shmem); memset(lds_dtext, 0x5A, L.shmem); memset(tile, 0x5A, L.shmem); memset(lds_text, 0x5A, L.shmem);
+    }
     if ((int)S.lanes.size() < n) S.lanes.resize((size_t)n);
     while ((int)S.stacks.size() < n) {
         char *p = (char *)mmap(nullptr, S.stack_bytes + 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);

@@ -79,6 +79,7 @@ struct Lane {
     // for every loop of that function around the position, how many times the lane has gone round it
     uintptr_t kpos; int n_loops; struct { int id; int count; uintptr_t last; } loops[12];
     char *stack;
+    uintptr_t low_sp;         // the lowest stack pointer the fiber was seen with (what an AddressSanitizer build unpoisons before the stack is used again)
 };
 struct Block { dim3 bid, bdim, gdim; };
 

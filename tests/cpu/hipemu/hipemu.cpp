@@ -68,15 +68,23 @@ namespace {
 
 // ---- the loop table (mkloops.py): functions and the address ranges of their loops, as offsets into the library ----
 struct LoopTab {
-    struct Fn { uintptr_t lo, hi; int first_loop, n_loops; };
+    struct Fn { uintptr_t lo, hi; int first_block, n_blocks; };
+    struct Blk { uintptr_t start; int rpo; int first_loop, n_loops; };
     std::vector<Fn> fns;
-    std::vector<std::pair<uintptr_t, uintptr_t>> loops;
+    std::vector<Blk> blks;
+    std::vector<int> loop_pool;          // the loops around a block, outermost first
     const Fn *fn_of(uintptr_t a) const
     {
         auto it = std::upper_bound(fns.begin(), fns.end(), a, [](uintptr_t v, const Fn &f) { return v < f.lo; });
         if (it == fns.begin()) return nullptr;
         --it;
         return a <= it->hi ? &*it : nullptr;
+    }
+    const Blk *blk_of(const Fn &f, uintptr_t a) const
+    {
+        const Blk *b0 = blks.data() + f.first_block, *b1 = b0 + f.n_blocks;
+        const Blk *it = std::upper_bound(b0, b1, a, [](uintptr_t v, const Blk &b) { return v < b.start; });
+        return it == b0 ? nullptr : it - 1;
     }
 };
 
@@ -88,7 +96,7 @@ struct Sched {
     size_t stack_bytes = 0;
     bool spun = false;
     const LoopTab::Fn *kfn = nullptr; uintptr_t kfn_lo = 1, kfn_hi = 0;          // the launched kernel's function in the loop table
-    std::unordered_map<uintptr_t, std::vector<int>> site_loops;                   // position -> the loops around it
+    std::unordered_map<uintptr_t, const LoopTab::Blk *> site_blk;                 // code address -> its basic block
 #ifdef HIPEMU_ASAN
     void *fake_sched = nullptr; const void *sched_bottom = nullptr; size_t sched_size = 0;
 #endif
@@ -166,7 +174,7 @@ void prepare_lane(Lane *l, char *stack, size_t bytes)
     for (int i = 0; i < 6; ++i) *--sp = nullptr;
     l->sp = sp;
     l->state = S_READY;
-    l->n_loops = 0; l->kpos = 0; l->n_stack = 0;
+    l->n_loops = 0; l->kpos = 0; l->rpo = 0; l->n_stack = 0;
 }
 
 // ---- the loop table, loaded ----
@@ -180,58 +188,65 @@ const LoopTab &loop_tab()
         const std::string path = std::string(di.dli_fname) + ".loops";
         FILE *f = fopen(path.c_str(), "r");
         if (!f) { fprintf(stderr, "hipemu: %s is missing (tests/cpu/hipemu/mkloops.py writes it): diverged waves are ordered by code address alone\n", path.c_str()); return; }
-        char line[4096];
+        char line[8192];
         while (fgets(line, sizeof(line), f)) {
             unsigned long lo = 0, hi = 0;
-            if (line[0] == 'F' && sscanf(line + 1, "%lx %lx", &lo, &hi) == 2) { LoopTab::Fn fn = { lo, hi, (int)T.loops.size(), 0 }; T.fns.push_back(fn); }
-            else if (line[0] == 'L' && sscanf(line + 1, "%lx %lx", &lo, &hi) == 2 && !T.fns.empty()) { T.loops.push_back(std::make_pair((uintptr_t)lo, (uintptr_t)hi)); T.fns.back().n_loops++; }
+            if (line[0] == 'F' && sscanf(line + 1, "%lx %lx", &lo, &hi) == 2) { LoopTab::Fn fn = { lo, hi, (int)T.blks.size(), 0 }; T.fns.push_back(fn); }
+            else if (line[0] == 'B' && !T.fns.empty()) {
+                char *q = line + 1;
+                LoopTab::Blk b; b.start = strtoul(q, &q, 16); b.rpo = (int)strtol(q, &q, 10); b.first_loop = (int)T.loop_pool.size(); b.n_loops = 0;
+                for (;;) { while (*q == ' ') ++q; if (*q < '0' || *q > '9') break; T.loop_pool.push_back((int)strtol(q, &q, 10)); b.n_loops++; }
+                T.blks.push_back(b); T.fns.back().n_blocks++;
+            }
         }
         fclose(f);
     });
     return T;
 }
 
-// the lane has stopped at a wave operation or a barrier: where is that in the kernel's loop nest?
+// The lane is at code address `o` of the kernel's function (a stop at a wave operation or a barrier, or -- kernels are built with
+// -fsanitize-coverage=bb,trace-pc -- the entry of any basic block).  Because every block entry is seen, a loop's back edge is seen when
+// it is taken: the lane arrives, inside a loop it was already in, at a block that is not later in reverse post-order than the one it
+// came from; it is the innermost such loop that went round (going round an outer one passes blocks outside the inner one first).
+inline void observe(Lane *me, uintptr_t o)
+{
+    Sched &S = tl_s;
+    const LoopTab::Blk *b;
+    auto it = S.site_blk.find(o);
+    if (it != S.site_blk.end()) b = it->second;
+    else { b = loop_tab().blk_of(*S.kfn, o); S.site_blk.emplace(o, b); }
+    if (!b) return;
+    const int *ids = loop_tab().loop_pool.data() + b->first_loop;
+    const int nb = b->n_loops < 12 ? b->n_loops : 12;
+    int common = 0;
+    while (common < me->n_loops && common < nb && me->loops[common].id == ids[common]) ++common;
+    if (common > 0 && (b->rpo < me->rpo || (b->rpo == me->rpo && o <= me->kpos))) me->loops[common - 1].count++;
+    for (int i = common; i < nb; ++i) { me->loops[i].id = ids[i]; me->loops[i].count = 0; }
+    me->n_loops = nb; me->rpo = b->rpo; me->kpos = o;
+}
+
+// the lane has stopped at a wave operation or a barrier
 void note_position(Lane *me, const void *const *ra_outer_first, int n)
 {
     Sched &S = tl_s;
     uintptr_t kpos = 0;
     for (int i = 0; i < n; ++i) { const uintptr_t o = off(ra_outer_first[i]); if (o >= S.kfn_lo && o <= S.kfn_hi) { kpos = o; break; } }
-    if (!kpos) kpos = n ? off(ra_outer_first[n - 1]) : 0;
-    if (!S.kfn) { me->kpos = kpos; me->n_loops = 0; return; }
-    auto it = S.site_loops.find(kpos);
-    if (it == S.site_loops.end()) {
-        std::vector<int> ids;
-        const LoopTab &T = loop_tab();
-        for (int k = 0; k < S.kfn->n_loops; ++k) { const auto &l = T.loops[(size_t)(S.kfn->first_loop + k)]; if (l.first <= kpos && kpos <= l.second) ids.push_back(S.kfn->first_loop + k); }
-        it = S.site_loops.emplace(kpos, std::move(ids)).first;
-    }
-    const std::vector<int> &ids = it->second;
-    decltype(me->loops) nl; int nn = 0;
-    for (int id : ids) {
-        if (nn == 12) break;
-        int count = 0;
-        for (int j = 0; j < me->n_loops; ++j) if (me->loops[j].id == id) { count = me->loops[j].count + (kpos <= me->loops[j].last ? 1 : 0); break; }
-        nl[nn].id = id; nl[nn].count = count; nl[nn].last = kpos; ++nn;
-    }
-    memcpy(me->loops, nl, sizeof(nl)); me->n_loops = nn; me->kpos = kpos;
+    if (!S.kfn || !kpos) { me->kpos = n ? off(ra_outer_first[n - 1]) : 0; me->rpo = 0; me->n_loops = 0; return; }
+    observe(me, kpos);
 }
 
 // one wave: serve the group of lanes that wait at the lowest site
 void resolve_wave(Lane *w, int cnt)
 {
     // Which group first, when lanes of the wave wait at different sites?  The hardware runs an inner divergent region to its end while
-    // the lanes that skipped it stay masked at the point where control flow joins again.  The emulator does not see the control-flow
-    // graph; it orders the waiting lanes the way a structured program laid out in source order orders them: first by how many times they
-    // have gone round the loops they are both inside (a lane that took a loop's back edge is LATER than one still in the body, although
-    // its address is lower), then by code address (a join point lies behind the regions that join there; the Makefile keeps blocks in
-    // source order and loops rotated).  mkloops.py supplies the loops' address ranges.
+    // the lanes that skipped it stay masked where control flow joins again.  The emulator gets the same order from the control-flow graph
+    // of the code it runs (mkloops.py: basic blocks, natural loops, reverse post-order without the back edges): a lane is earlier when it
+    // has gone round a loop both are in fewer times; in the same iteration, when its block comes first in reverse post-order (a block
+    // that can be reached from another one without a back edge has the higher number: the lanes at the other one are on their way to it).
     auto earlier = [](const Lane &a, const Lane &b) {
-        int i = 0, j = 0;
-        while (i < a.n_loops && j < b.n_loops) {
-            if (a.loops[i].id == b.loops[j].id) { if (a.loops[i].count != b.loops[j].count) return a.loops[i].count < b.loops[j].count; ++i; ++j; }
-            else if (a.loops[i].id < b.loops[j].id) ++i; else ++j;
-        }
+        for (int i = 0; i < a.n_loops && i < b.n_loops && a.loops[i].id == b.loops[i].id; ++i)
+            if (a.loops[i].count != b.loops[i].count) return a.loops[i].count < b.loops[i].count;
+        if (a.rpo != b.rpo) return a.rpo < b.rpo;
         if (a.kpos != b.kpos) return a.kpos < b.kpos;
         const int n = a.n_stack < b.n_stack ? a.n_stack : b.n_stack;
         for (int k = 0; k < n; ++k) if (a.stack_sites[k] != b.stack_sites[k]) return (uintptr_t)a.stack_sites[k] < (uintptr_t)b.stack_sites[k];
@@ -430,7 +445,7 @@ void run(const Launch &L)
     {
         const uintptr_t k = off(L.kernel);
         const LoopTab::Fn *fn = loop_tab().fn_of(k);
-        if (fn != S.kfn) S.site_loops.clear();
+        if (fn != S.kfn) S.site_blk.clear();
         S.kfn = fn; S.kfn_lo = fn ? fn->lo : 1; S.kfn_hi = fn ? fn->hi : 0;
     }
     Lane *outer_lane = tl_lane; Block outer_block = tl_block;
@@ -440,6 +455,17 @@ void run(const Launch &L)
 }
 
 }  // namespace hipemu
+
+// every basic block of the kernels' translation units reports here (-fsanitize-coverage=bb,trace-pc); host code of those units, and
+// device functions that were not inlined into their kernel, are not tracked
+extern "C" void __sanitizer_cov_trace_pc()
+{
+    hipemu::Lane *l = hipemu::tl_lane;
+    if (!l) return;
+    const uintptr_t o = hipemu::off(__builtin_return_address(0));
+    if (o < hipemu::tl_s.kfn_lo || o > hipemu::tl_s.kfn_hi) return;
+    hipemu::observe(l, o);
+}
 
 // ---- runtime API ----
 namespace {

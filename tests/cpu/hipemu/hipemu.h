@@ -11,7 +11,9 @@
 // What it models and what it does not:
 //   * wave64, lanes of a wave meet at every wave-level operation; the lanes that meet are those waiting at the SAME call site (so an
 //     operation inside a divergent branch sees the lanes that took the branch, like the EXEC mask).  When lanes of one wave wait at
-//     different sites, the site with the lowest code address is served first (branch bodies before the code behind them).
+//     different sites, the order is that of the control-flow graph (mkloops.py reads it out of the built library): fewer trips round a
+//     shared loop first, then the earlier block in reverse post-order -- the inner divergent region runs to its end before the lanes
+//     that wait at the join point go on.  README.md has the details; selftest.cpp checks them on hand-worked kernels.
 //   * workgroups run sequentially in blockIdx order: look-back / ticket schemes that wait for EARLIER workgroups work, a kernel that
 //     waits for a later one is reported as a deadlock.
 //   * streams and events are ordered by program order (everything is synchronous); LDS is thread-local storage of the OS thread.
@@ -32,8 +34,11 @@
 #include <utility>
 
 // ---- language ----
-#define __global__
-#define __device__
+// Device functions are `convergent`, as the device compiler makes every function of a HIP translation unit until it has proved
+// otherwise: a call of a function that contains a wave operation must not be duplicated into the arms of a lane-varying branch any more
+// than the operation itself (seen with the AddressSanitizer build: a not-yet-inlined file_pass() call cloned for `active == false`).
+#define __global__ __attribute__((convergent))
+#define __device__ __attribute__((convergent))
 #define __host__
 #define __constant__
 #define __forceinline__ inline __attribute__((always_inline))
@@ -75,9 +80,9 @@ struct Lane {
     int state;
     const void *site; int kind; uint64_t val; int arg, width; uint64_t res;
     const void *stack_sites[24]; int n_stack;      // the return addresses of the waiting lane, outermost first (site == the innermost)
-    // where the lane is in the kernel's loop nest (hipemu.cpp, "which group first"): its position in the kernel function's own frame and,
-    // for every loop of that function around the position, how many times the lane has gone round it
-    uintptr_t kpos; int n_loops; struct { int id; int count; uintptr_t last; } loops[12];
+    // where the lane is in the kernel's control-flow graph (hipemu.cpp, "which group first"): the loops around its block with the number
+    // of times it has gone round each (outermost first), the block's number in reverse post-order, the code address
+    int rpo; uintptr_t kpos; int n_loops; struct { int id; int count; } loops[12];
     char *stack;
     uintptr_t low_sp;         // the lowest stack pointer the fiber was seen with (what an AddressSanitizer build unpoisons before the stack is used again)
 };

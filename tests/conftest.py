@@ -16,7 +16,7 @@ if hipemu():
     # (tests/cpu/hipemu, test infrastructure for containers without a GPU).  `import samtools_amd` then finds the links to the package's
     # Python files that sit next to the emulated library.
     if not os.path.exists(product_exe()):
-        raise SystemExit("STA_HIPEMU is set but %s is missing: make -C tests/cpu/hipemu%s" % (product_exe(), {"asan": " SAN=1", "ubsan": " SAN=ub"}.get(hipemu(), "")))
+        raise SystemExit("STA_HIPEMU is set but %s is missing: make -C tests/cpu/hipemu%s" % (product_exe(), {"asan": " SAN=1", "ubsan": " SAN=ub", "trace": " TRACE=1"}.get(hipemu(), "")))
     sys.path.insert(0, product_root())
 
 

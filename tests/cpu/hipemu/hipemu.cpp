@@ -63,13 +63,16 @@ enum { S_READY = 0, S_WAVE, S_BLOCK, S_DONE };
 
 thread_local Lane *tl_lane = nullptr;
 thread_local Block tl_block;
+// what the block-entry tracing needs of the running launch and lane, in one thread-local object (one TLS look-up per traced block)
+struct TraceCtx { Lane *lane; uintptr_t kfn_lo, kfn_span; const int32_t *addr2blk; const void *blks; const int *loop_pool; };
+thread_local TraceCtx tl_trace = { nullptr, 1, 0, nullptr, nullptr, nullptr };
 
 namespace {
 
 // ---- the loop table (mkloops.py): functions and the address ranges of their loops, as offsets into the library ----
 struct LoopTab {
     struct Fn { uintptr_t lo, hi; int first_block, n_blocks; };
-    struct Blk { uintptr_t start; int rpo; int first_loop, n_loops; };
+    struct Blk { uintptr_t start; int rpo; int first_loop, n_loops; int header; };
     std::vector<Fn> fns;
     std::vector<Blk> blks;
     std::vector<int> loop_pool;          // the loops around a block, outermost first
@@ -96,7 +99,8 @@ struct Sched {
     size_t stack_bytes = 0;
     bool spun = false;
     const LoopTab::Fn *kfn = nullptr; uintptr_t kfn_lo = 1, kfn_hi = 0;          // the launched kernel's function in the loop table
-    std::unordered_map<uintptr_t, const LoopTab::Blk *> site_blk;                 // code address -> its basic block
+    const int32_t *addr2blk = nullptr;                                            // code address - kfn_lo -> index of its basic block
+    std::unordered_map<const LoopTab::Fn *, std::vector<int32_t>> addr2blk_of;    // (built when a kernel is first launched on this thread)
 #ifdef HIPEMU_ASAN
     void *fake_sched = nullptr; const void *sched_bottom = nullptr; size_t sched_size = 0;
 #endif
@@ -146,7 +150,7 @@ void fiber_entry()
 
 inline void run_lane(Lane *l)
 {
-    tl_lane = l;
+    tl_lane = l; tl_trace.lane = tl_trace.addr2blk ? l : nullptr;
 #ifdef HIPEMU_ASAN
     void *fake = nullptr;
     __sanitizer_start_switch_fiber(&fake, l->stack, tl_s.stack_bytes);
@@ -174,7 +178,7 @@ void prepare_lane(Lane *l, char *stack, size_t bytes)
     for (int i = 0; i < 6; ++i) *--sp = nullptr;
     l->sp = sp;
     l->state = S_READY;
-    l->n_loops = 0; l->kpos = 0; l->rpo = 0; l->n_stack = 0;
+    l->n_loops = 0; l->kpos = 0; l->rpo = 0; l->n_stack = 0; l->blk = nullptr;
 }
 
 // ---- the loop table, loaded ----
@@ -194,7 +198,7 @@ const LoopTab &loop_tab()
             if (line[0] == 'F' && sscanf(line + 1, "%lx %lx", &lo, &hi) == 2) { LoopTab::Fn fn = { lo, hi, (int)T.blks.size(), 0 }; T.fns.push_back(fn); }
             else if (line[0] == 'B' && !T.fns.empty()) {
                 char *q = line + 1;
-                LoopTab::Blk b; b.start = strtoul(q, &q, 16); b.rpo = (int)strtol(q, &q, 10); b.first_loop = (int)T.loop_pool.size(); b.n_loops = 0;
+                LoopTab::Blk b; b.start = strtoul(q, &q, 16); b.rpo = (int)strtol(q, &q, 10); b.header = (int)strtol(q, &q, 10); b.first_loop = (int)T.loop_pool.size(); b.n_loops = 0;
                 for (;;) { while (*q == ' ') ++q; if (*q < '0' || *q > '9') break; T.loop_pool.push_back((int)strtol(q, &q, 10)); b.n_loops++; }
                 T.blks.push_back(b); T.fns.back().n_blocks++;
             }
@@ -210,19 +214,20 @@ const LoopTab &loop_tab()
 // came from; it is the innermost such loop that went round (going round an outer one passes blocks outside the inner one first).
 inline void observe(Lane *me, uintptr_t o)
 {
-    Sched &S = tl_s;
-    const LoopTab::Blk *b;
-    auto it = S.site_blk.find(o);
-    if (it != S.site_blk.end()) b = it->second;
-    else { b = loop_tab().blk_of(*S.kfn, o); S.site_blk.emplace(o, b); }
-    if (!b) return;
-    const int *ids = loop_tab().loop_pool.data() + b->first_loop;
+    const TraceCtx &C = tl_trace;
+    const LoopTab::Blk *b = (const LoopTab::Blk *)C.blks + (C.addr2blk[o - C.kfn_lo] >> 1);
+    if (b == (const LoopTab::Blk *)me->blk) {          // the same block again: further down it, or once round a loop that is this block
+        if (o <= me->kpos && me->n_loops > 0) me->loops[me->n_loops - 1].count++;
+        me->kpos = o;
+        return;
+    }
+    const int *ids = C.loop_pool + b->first_loop;
     const int nb = b->n_loops < 12 ? b->n_loops : 12;
     int common = 0;
     while (common < me->n_loops && common < nb && me->loops[common].id == ids[common]) ++common;
-    if (common > 0 && (b->rpo < me->rpo || (b->rpo == me->rpo && o <= me->kpos))) me->loops[common - 1].count++;
+    if (common > 0 && b->rpo <= me->rpo) me->loops[common - 1].count++;
     for (int i = common; i < nb; ++i) { me->loops[i].id = ids[i]; me->loops[i].count = 0; }
-    me->n_loops = nb; me->rpo = b->rpo; me->kpos = o;
+    me->n_loops = nb; me->rpo = b->rpo; me->kpos = o; me->blk = b;
 }
 
 // the lane has stopped at a wave operation or a barrier
@@ -264,7 +269,11 @@ void resolve_wave(Lane *w, int cnt)
     const void *site = pick->site;
     if (mixed && g_diverge_log) {
         fprintf(stderr, "hipemu: divergent wave operations in %s:", tl_s.launch->name);
-        for (int i = 0; i < cnt; ++i) if (w[i].state == S_WAVE && (i == 0 || w[i].site != w[i - 1].site || w[i - 1].state != S_WAVE)) fprintf(stderr, " lane %d.. 0x%zx/%d", i, off(w[i].site), w[i].kind);
+        for (int i = 0; i < cnt; ++i) if (w[i].state == S_WAVE && (i == 0 || w[i].site != w[i - 1].site || w[i - 1].state != S_WAVE)) {
+            fprintf(stderr, " lane %d.. 0x%zx/%d rpo %d [", i, off(w[i].site), w[i].kind, w[i].rpo);
+            for (int k = 0; k < w[i].n_loops; ++k) fprintf(stderr, "%s%d:%d", k ? " " : "", w[i].loops[k].id, w[i].loops[k].count);
+            fprintf(stderr, "]");
+        }
         fprintf(stderr, " -> 0x%zx\n", off(site));
     }
     uint64_t members = 0; int kind = 0;
@@ -445,12 +454,25 @@ void run(const Launch &L)
     {
         const uintptr_t k = off(L.kernel);
         const LoopTab::Fn *fn = loop_tab().fn_of(k);
-        if (fn != S.kfn) S.site_blk.clear();
         S.kfn = fn; S.kfn_lo = fn ? fn->lo : 1; S.kfn_hi = fn ? fn->hi : 0;
+        if (fn) {
+            std::vector<int32_t> &v = S.addr2blk_of[fn];
+            if (v.empty()) {
+                v.resize(fn->hi - fn->lo + 1);
+                const LoopTab &T = loop_tab();
+                for (int k = 0; k < fn->n_blocks; ++k) {
+                    const uintptr_t a0 = T.blks[(size_t)(fn->first_block + k)].start, a1 = k + 1 < fn->n_blocks ? T.blks[(size_t)(fn->first_block + k + 1)].start : fn->hi + 1;
+                    for (uintptr_t a = a0; a < a1; ++a) v[a - fn->lo] = (fn->first_block + k) * 2 + (T.blks[(size_t)(fn->first_block + k)].header ? 1 : 0);
+                }
+            }
+            S.addr2blk = v.data();
+            const LoopTab &T = loop_tab();
+            tl_trace.kfn_lo = fn->lo; tl_trace.kfn_span = fn->hi - fn->lo; tl_trace.addr2blk = v.data(); tl_trace.blks = T.blks.data(); tl_trace.loop_pool = T.loop_pool.data();
+        } else { tl_trace.kfn_lo = 1; tl_trace.kfn_span = 0; tl_trace.addr2blk = nullptr; }
     }
     Lane *outer_lane = tl_lane; Block outer_block = tl_block;
     for (unsigned z = 0; z < L.grid.z; ++z) for (unsigned y = 0; y < L.grid.y; ++y) for (unsigned x = 0; x < L.grid.x; ++x) run_block(L, x, y, z);
-    tl_lane = outer_lane; tl_block = outer_block;
+    tl_lane = outer_lane; tl_block = outer_block; tl_trace.lane = nullptr;
     S.launch = nullptr; reg_leave();
 }
 
@@ -460,11 +482,14 @@ void run(const Launch &L)
 // device functions that were not inlined into their kernel, are not tracked
 extern "C" void __sanitizer_cov_trace_pc()
 {
-    hipemu::Lane *l = hipemu::tl_lane;
-    if (!l) return;
-    const uintptr_t o = hipemu::off(__builtin_return_address(0));
-    if (o < hipemu::tl_s.kfn_lo || o > hipemu::tl_s.kfn_hi) return;
-    hipemu::observe(l, o);
+    const hipemu::TraceCtx &C = hipemu::tl_trace;
+    if (!C.lane) return;
+    const uintptr_t d = (uintptr_t)__builtin_return_address(0) - hipemu::g_base - C.kfn_lo;
+    if (d > C.kfn_span) return;
+    // only the entries of loop headers matter: that is where a back edge lands (a block that is not a header changes nothing that the
+    // lane's next stop does not see for itself)
+    if (!(C.addr2blk[d] & 1)) return;
+    hipemu::observe(C.lane, d + C.kfn_lo);
 }
 
 // ---- runtime API ----

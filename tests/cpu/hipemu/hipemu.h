@@ -82,7 +82,7 @@ struct Lane {
     const void *stack_sites[24]; int n_stack;      // the return addresses of the waiting lane, outermost first (site == the innermost)
     // where the lane is in the kernel's control-flow graph (hipemu.cpp, "which group first"): the loops around its block with the number
     // of times it has gone round each (outermost first), the block's number in reverse post-order, the code address
-    int rpo; uintptr_t kpos; int n_loops; struct { int id; int count; } loops[12];
+    int rpo; uintptr_t kpos; int n_loops; struct { int id; int count; } loops[12]; const void *blk;
     char *stack;
     uintptr_t low_sp;         // the lowest stack pointer the fiber was seen with (what an AddressSanitizer build unpoisons before the stack is used again)
 };

@@ -11,7 +11,7 @@ at A are still on their way to B).  Independent of how the compiler laid the blo
 
 Output, one function after the other:
     F <lo> <hi> <name>
-    B <start> <rpo> <loop id> ...          # loops that contain the block, outermost first (ids are global)
+    B <start> <rpo> <1 if the block is a loop header> <loop id> ...     # loops that contain the block, outermost first (ids are global)
 usage: mkloops.py <llvm-objdump> <library or executable> <out>"""
 import re
 import subprocess
@@ -84,14 +84,7 @@ def analyse(insns):
             state[v] = 2
             post.append(v)
             stack.pop()
-    rpo = [0] * n
-    for r, v in enumerate(reversed(post)):
-        rpo[v] = r
-    nreach = len(post)
-    for v in range(n):             # code the entry does not reach (landing pads): behind everything, in address order
-        if state[v] == 0:
-            rpo[v] = nreach
-            nreach += 1
+    reached = [st == 2 for st in state]
     # natural loops: the blocks that reach the back edge's source without passing the header
     pred = [[] for _ in range(n)]
     for v in range(n):
@@ -111,10 +104,85 @@ def analyse(insns):
     for h, body in loops.items():
         for v in body:
             in_loops[v].append((len(body), h))
+    for v in range(n):
+        in_loops[v].sort(key=lambda t: (-t[0], t[1]))          # outermost first
+    back_set = set(back)
+    # The order: reverse post-order of the graph without back edges in which EVERY LOOP IS CONTIGUOUS (all of a loop's blocks before
+    # anything behind its exits): region by region -- the function, then every loop -- with the region's inner loops collapsed to
+    # single nodes, and each collapsed loop expanded in place.
+    FUNC = -1
+    def chain(v):
+        return [h for _, h in in_loops[v]]
+    children = {FUNC: []}
+    parent = {}
+    for h in loops:
+        c = chain(h)               # the loops around the header, itself last
+        par = c[-2] if len(c) >= 2 else FUNC
+        parent[h] = par
+        children.setdefault(par, []).append(h)
+        children.setdefault(h, [])
+    def node_in(region, v):
+        """the node of `region` (a loop header or FUNC) that block v belongs to: v itself, or the child loop around it; None = outside"""
+        c = chain(v)
+        if region == FUNC:
+            return ("L", c[0]) if c else ("B", v)
+        if region not in c:
+            return None
+        i = c.index(region)
+        return ("L", c[i + 1]) if i + 1 < len(c) else ("B", v)
+    def order_region(region, entry):
+        members = list(loops[region]) if region != FUNC else list(range(n))
+        nsucc = {}
+        for v in members:
+            nv = node_in(region, v)
+            for w in succ[v]:
+                if (v, w) in back_set:
+                    continue
+                nw = node_in(region, w)
+                if nw is None or nw == nv:
+                    continue
+                nsucc.setdefault(nv, [])
+                if nw not in nsucc[nv]:
+                    nsucc[nv].append(nw)
+        seen, post2 = set(), []
+        def dfs(root):
+            st = [(root, 0)]
+            seen.add(root)
+            while st:
+                x, i = st[-1]
+                ss = nsucc.get(x, [])
+                if i < len(ss):
+                    st[-1] = (x, i + 1)
+                    y = ss[i]
+                    if y not in seen:
+                        seen.add(y)
+                        st.append((y, 0))
+                else:
+                    post2.append(x)
+                    st.pop()
+        dfs(node_in(region, entry))
+        seq = list(reversed(post2))
+        rest = []
+        for v in sorted(members):  # nodes the entry does not reach (landing pads, irreducible entries): behind everything, by address
+            nv = node_in(region, v)
+            if nv not in seen:
+                seen.add(nv)
+                rest.append(nv)
+        out_blocks = []
+        for kind, x in seq + rest:
+            if kind == "B":
+                out_blocks.append(x)
+            else:
+                out_blocks.extend(order_region(x, x))
+        return out_blocks
+    sys.setrecursionlimit(10000)
+    seq = order_region(FUNC, 0)
+    rpo = [0] * n
+    for r, v in enumerate(seq):
+        rpo[v] = r
     out = []
     for k, a in enumerate(starts):
-        chain = [h for _, h in sorted(in_loops[k], key=lambda t: (-t[0], t[1]))]
-        out.append((a, rpo[k], [starts[h] for h in chain]))
+        out.append((a, rpo[k], 1 if k in loops else 0, [starts[h] for h in chain(k)]))
     return out, len(loops)
 
 
@@ -146,9 +214,9 @@ def main():
             n_loops += nl
             n_blocks += len(blocks)
             fh.write("F %x %x %s\n" % (insns[0][0], insns[-1][0], name))
-            for a, r, chain in blocks:
+            for a, r, hdr, chain in blocks:
                 ids = [str(loop_ids.setdefault(h, len(loop_ids))) for h in chain]
-                fh.write("B %x %d%s\n" % (a, r, "".join(" " + i for i in ids)))
+                fh.write("B %x %d %d%s\n" % (a, r, hdr, "".join(" " + i for i in ids)))
     print("mkloops: %d functions, %d blocks, %d loops -> %s" % (len(funcs), n_blocks, n_loops, out))
 
 

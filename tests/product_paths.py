@@ -1,7 +1,7 @@
 """Where the library and the CLI under test live.
 
 Normally that is the package itself: samtools_amd/lib/libsamtools_amd.so and samtools_amd/bin/samtools-amd, the HIP build.
-With STA_HIPEMU=1 (or =asan / =ubsan) set BY HAND the same tests run against the CPU emulation build of the same sources
+With STA_HIPEMU=1 (or =asan / =ubsan / =trace) set BY HAND the same tests run against the CPU emulation build of the same sources
 (tests/cpu/hipemu: test infrastructure for containers without a GPU, never a fallback -- nothing in the package, bench.py or
 __graft_entry__ knows about it, and the driver's `-m gpu` run never sets the variable)."""
 import os
@@ -12,14 +12,14 @@ REPO = os.path.dirname(HERE)
 
 def hipemu():
     v = os.environ.get("STA_HIPEMU", "")
-    return v if v in ("1", "asan", "ubsan") else ""
+    return v if v in ("1", "asan", "ubsan", "trace") else ""
 
 
 def product_root():
     """The directory that holds samtools_amd/{lib,bin} (and, for the emulation, links to the package's Python files)."""
     v = hipemu()
     if v:
-        return os.path.join(HERE, "cpu", "hipemu", "_build", {"asan": "asan", "ubsan": "ubsan"}.get(v, "plain"))
+        return os.path.join(HERE, "cpu", "hipemu", "_build", {"asan": "asan", "ubsan": "ubsan", "trace": "plain_trace"}.get(v, "plain"))
     return REPO
 
 

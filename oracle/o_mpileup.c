@@ -84,6 +84,7 @@ int o_cap_mapq(orec_t *b, const char *ref, hpos_t ref_len, int thres)
             for (j = 0; j < l; ++j) {
                 int c1, c2, z = y + j;
                 if (x + j >= ref_len || ref[x + j] == '\0') break;
+                if (z >= b->l_qseq) continue;      /* a record without SEQ: HTSlib reads behind the record here (undefined); a base that is not there is no mismatch */
                 c1 = rec_seqi(seq, z); c2 = nt16_table[(unsigned char)ref[x + j]];
                 if (c2 != 15 && c1 != 15 && qual[z] >= 13) {
                     ++len;
@@ -97,7 +98,7 @@ int o_cap_mapq(orec_t *b, const char *ref, hpos_t ref_len, int thres)
             if (j < l) break;
             x += l;
         } else if (op == C_S) {
-            for (j = 0; j < l; ++j) clip_q += qual[y + j];
+            for (j = 0; j < l; ++j) if (y + j < b->l_qseq) clip_q += qual[y + j];
             clip_l += l; y += l;
         } else if (op == C_H) { clip_q += 13 * l; clip_l += l; }
         else if (op == C_I) y += l;

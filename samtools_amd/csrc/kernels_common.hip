@@ -190,7 +190,10 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
         int baq_cls = 0, baq_bw = 0, baq_gbw = 0;
         if (pushed && (P.flag & STA_MPLP_REALN) && has_ref && lq > 0 && has_m && !has_n) {
             bool redo = (P.flag & STA_MPLP_REDO_BAQ) != 0;
-            bool q_absent = R.qual_in[(uint64_t)R.base_off8[i] << 3] == 0xff;
+            // realn.c gives up when qual[0] == 0xff -- tested on the record mplp_func has ALREADY shifted for -6 (bam_plcmd.c:431-435 runs
+            // before :451): a read without qualities is then 224 everywhere and does get realigned (found by scripts/hunt5.py on the
+            // CPU emulation, round 5)
+            bool q_absent = R.qual_in[(uint64_t)R.base_off8[i] << 3] == 0xff && !(P.flag & STA_MPLP_ILLUMINA13);
             if (!q_absent && !(aux & STA_AUX_HAS_ZQ) && (redo || !(aux & STA_AUX_HAS_BQ))) {
                 BaqGeo g = baq_geometry(R.cigar + c0, (int)(c1 - c0), apos, lq, W.ref, W.ref_len);
                 if (g.ok) {         // !ok: probaln_glocal returns 0 and the qualities stay as they are
@@ -307,6 +310,9 @@ __device__ __forceinline__ int cap_mapq_of(const StaReadsDev &R, const StaWinDev
     const uint8_t *qual = R.qual + ((uint64_t)R.base_off8[r] << 3);
     const uint8_t *seq = R.seq + ((uint64_t)R.base_off8[r] << 2);
     int mm = 0, q = 0, len = 0, clip_l = 0, clip_q = 0, y = 0;
+    // A record without SEQ (l_qseq 0 under a CIGAR with M operations) makes HTSlib's loop read the bytes behind the record: undefined
+    // there.  Here, and in the oracle, a base that is not there is neither a mismatch nor a clipped quality.
+    const int lq = R.l_qseq[r];
     long long x = W.origin + R.pos[r];
     bool stop = false;
     if (thres < 0) thres = 40;
@@ -317,6 +323,7 @@ __device__ __forceinline__ int cap_mapq_of(const StaReadsDev &R, const StaWinDev
             for (j = 0; j < l; ++j) {
                 int z = y + j;
                 if (x + j >= W.ref_len) break;
+                if (z >= lq) continue;
                 int c1 = (seq[z >> 1] >> ((~z & 1) << 2)) & 0xf, c2 = nt16_from_char((unsigned char)W.ref[x + j]);
                 if (c2 != 15 && c1 != 15 && qual[z] >= 13) {
                     ++len;
@@ -329,7 +336,7 @@ __device__ __forceinline__ int cap_mapq_of(const StaReadsDev &R, const StaWinDev
             if (x + l > W.ref_len) { stop = true; break; }
             x += l;
         } else if (op == CG_S) {
-            for (int j = 0; j < l; ++j) clip_q += qual[y + j];
+            for (int j = 0; j < l; ++j) if (y + j < lq) clip_q += qual[y + j];
             clip_l += l; y += l;
         } else if (op == CG_H) { clip_q += 13 * l; clip_l += l; }
         else if (op == CG_I) y += l;

@@ -133,7 +133,7 @@ for seed in seeds:
         if rnd.random() < 0.3: env["STA_WINDOW_READS"] = str(rnd.choice([5, 50, 700]))
         if rnd.random() < 0.3: env["STA_PLP_BATCH"] = str(rnd.choice([64, 700]))
         if args[0] == "mpileup" and rnd.random() < 0.2: env["STA_EMIT_DEEP"] = rnd.choice(["0", "1"])
-        use_bam = rnd.random() < 0.5
+        use_bam = rnd.random() < 0.5 and "-H" not in args          # (depth -H prints the file names)
         o = subprocess.run([ORACLE] + args + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         eargs = args + [bam if (use_bam and a == sam) else a for a in files]
         try:

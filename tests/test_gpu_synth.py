@@ -376,3 +376,52 @@ def test_depth_cap_meeting_the_lookahead_record_of_a_window(tmp_path, oracle_bin
                         assert got.returncode == 0, got.stderr.decode()[-300:]
                         assert got.stdout == want, (cig, pile, mate_at, cap, mode, w)
     assert len(outcomes) >= 4      # the caps, the pile and the mate's place in it do change what columns 151 and 153 show
+
+
+def _rewrite_some_records(sam, every, fn):
+    """fn(fields) -> fields for every `every`-th alignment line"""
+    out, k = [], 0
+    for line in open(sam):
+        if not line.startswith("@"):
+            k += 1
+            if k % every == 0:
+                line = "\t".join(fn(line.rstrip("\n").split("\t"))) + "\n"
+        out.append(line)
+    open(sam, "w").write("".join(out))
+
+
+@pytest.mark.parametrize("opts", [["-6"], ["-6", "-E"], ["-6", "-B"], ["-6", "-Q", "0", "-A"]], ids=["baq", "E", "B", "Q0_A"])
+def test_illumina13_shift_comes_before_the_missing_quality_test_of_baq(tmp_path, oracle_bin, product_bin, opts):
+    """mplp_func rewrites the qualities for -6 (bam_plcmd.c:431-435) BEFORE it calls sam_prob_realn (:451), whose `qual[0] == 0xff: do
+    nothing` therefore sees 224 on a record without QUAL: such a read IS realigned under -6 (its qualities come out as the BAQ values,
+    not as '~').  Found by scripts/hunt5.py on the CPU emulation of the kernels (round 5): the engine tested the unshifted byte."""
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=12000, depth=12, read_len=100, seed=611, paired=True, indel_rate=0.05)
+    _rewrite_some_records(sam, 4, lambda f: f[:10] + ["*"] + f[11:])
+    args = ["mpileup"] + opts + ["-f", fa, sam]
+    want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    assert want.count(b"\n") > 10000
+    for wc in (None, "700"):
+        e = dict(os.environ)
+        if wc:
+            e["STA_WINDOW_COLS"] = wc
+        got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+        assert got.returncode == 0, got.stderr.decode()[-500:]
+        assert got.stdout == want, (opts, wc)
+    if opts == ["-6"]:
+        # and the realignment is visible: without -6 the same reads print '~' for every base (0xff + 33 capped), with -6 and BAQ they do not
+        plain = subprocess.run([product_bin, "mpileup", "-6", "-B", "-f", fa, sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        assert plain.count(b"~") > want.count(b"~")
+
+
+@pytest.mark.parametrize("cmd", ["mpileup", "calmd"])
+def test_adjust_mq_on_records_without_seq(tmp_path, oracle_bin, product_bin, cmd):
+    """-C on a record whose SEQ is '*' under a CIGAR with M operations: HTSlib's sam_cap_mapq walks seq / qual behind the record
+    (undefined in the reference).  Engine and oracle take a base that is not there as neither a mismatch nor a clipped quality: the read
+    keeps min(MAPQ, threshold).  Found by scripts/hunt5.py (engine and oracle each read their own neighbouring bytes)."""
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=9000, depth=10, read_len=100, seed=612, paired=False, sub_rate=0.02)
+    _rewrite_some_records(sam, 5, lambda f: f[:9] + ["*", "*"] + f[11:])
+    args = (["mpileup", "-C", "20", "-s", "-f", fa, sam] if cmd == "mpileup" else ["calmd", "--no-PG", "-C", "20", sam, fa])
+    want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 0, got.stderr.decode()[-500:]
+    assert got.stdout == want and len(want) > 100000

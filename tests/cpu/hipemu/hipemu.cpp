@@ -63,13 +63,15 @@ enum { S_READY = 0, S_WAVE, S_BLOCK, S_DONE };
 
 thread_local Lane *tl_lane = nullptr;
 thread_local Block tl_block;
-// what the block-entry tracing needs of the running launch and lane, in one thread-local object (one TLS look-up per traced block)
+// where the running launch's kernel lies in the control-flow table, and the running lane: what observe() needs, in one thread-local
+// object (one TLS look-up per traced block in the TRACE=1 flavour)
 struct TraceCtx { Lane *lane; uintptr_t kfn_lo, kfn_span; const int32_t *addr2blk; const void *blks; const int *loop_pool; };
 thread_local TraceCtx tl_trace = { nullptr, 1, 0, nullptr, nullptr, nullptr };
 
 namespace {
 
-// ---- the loop table (mkloops.py): functions and the address ranges of their loops, as offsets into the library ----
+// ---- the control-flow table (mkloops.py): per function its basic blocks (offsets into the library) with their number in the
+// loop-contiguous reverse post-order and the loops around them ----
 struct LoopTab {
     struct Fn { uintptr_t lo, hi; int first_block, n_blocks; };
     struct Blk { uintptr_t start; int rpo; int first_loop, n_loops; int header; };
@@ -83,12 +85,6 @@ struct LoopTab {
         --it;
         return a <= it->hi ? &*it : nullptr;
     }
-    const Blk *blk_of(const Fn &f, uintptr_t a) const
-    {
-        const Blk *b0 = blks.data() + f.first_block, *b1 = b0 + f.n_blocks;
-        const Blk *it = std::upper_bound(b0, b1, a, [](uintptr_t v, const Blk &b) { return v < b.start; });
-        return it == b0 ? nullptr : it - 1;
-    }
 };
 
 struct Sched {
@@ -99,10 +95,10 @@ struct Sched {
     size_t stack_bytes = 0;
     bool spun = false;
     const LoopTab::Fn *kfn = nullptr; uintptr_t kfn_lo = 1, kfn_hi = 0;          // the launched kernel's function in the loop table
-    const int32_t *addr2blk = nullptr;                                            // code address - kfn_lo -> index of its basic block
-    std::unordered_map<const LoopTab::Fn *, std::vector<int32_t>> addr2blk_of;    // (built when a kernel is first launched on this thread)
+    // code address - kfn_lo -> 2 * index of its basic block + (the block is a loop header), per kernel, built at its first launch on this thread
+    std::unordered_map<const LoopTab::Fn *, std::vector<int32_t>> addr2blk_of;
 #ifdef HIPEMU_ASAN
-    void *fake_sched = nullptr; const void *sched_bottom = nullptr; size_t sched_size = 0;
+    const void *sched_bottom = nullptr; size_t sched_size = 0;
 #endif
 };
 thread_local Sched tl_s;
@@ -465,7 +461,6 @@ void run(const Launch &L)
                     for (uintptr_t a = a0; a < a1; ++a) v[a - fn->lo] = (fn->first_block + k) * 2 + (T.blks[(size_t)(fn->first_block + k)].header ? 1 : 0);
                 }
             }
-            S.addr2blk = v.data();
             const LoopTab &T = loop_tab();
             tl_trace.kfn_lo = fn->lo; tl_trace.kfn_span = fn->hi - fn->lo; tl_trace.addr2blk = v.data(); tl_trace.blks = T.blks.data(); tl_trace.loop_pool = T.loop_pool.data();
         } else { tl_trace.kfn_lo = 1; tl_trace.kfn_span = 0; tl_trace.addr2blk = nullptr; }

@@ -690,18 +690,57 @@ void ChunkPump::retire(int64_t ce)
             for (; lo != stay.end() && lo->pos == mpos; ++lo) if (lo->qname != qname && !strcmp(lo->qname, qname)) return true;
             return false;
         };
+        // A record that stays ONLY for its mate's sake holds nothing any more once a read beyond its end was pushed before that mate
+        // (bam_plp_next frees it and overlap_remove takes the entry of its name along): see Pump::retire
+        auto freed_before_mate = [&](int64_t end, int64_t mpos) {
+            if (!cfg_.surely_pushed) return false;
+            for (auto &q : f.carry) { if (q.pos >= mpos) break; if (q.pos > end && cfg_.surely_pushed(q)) return true; }
+            Rec probe;
+            size_t sj = f.n_carry_staged;
+            for (auto &g : f.fresh)
+                for (int64_t i = g.i0; i < g.i1; ++i, ++sj) {
+                    const size_t k = (size_t)i;
+                    if (g.c->pos[k] >= mpos) return false;
+                    if (g.c->pos[k] <= end || is_dropped(sj)) continue;
+                    probe.tid = g.c->tid[k]; probe.pos = g.c->pos[k]; probe.flag = g.c->flag[k]; probe.mapq = g.c->mapq[k];
+                    if (cfg_.surely_pushed(probe)) return true;
+                }
+            return false;
+        };
         // pass 2: decide for the carried reads before anything moves (`stay` points into them), then keep / materialise
         std::vector<char> keepc(f.carry.size(), 0);
-        { size_t i = 0; for (auto &r : f.carry) keepc[i++] = span_end(r) > ce || mate_stays(r.flag, r.tid, r.mtid, r.mpos, r.qname.c_str()); }
+        // (where the host cannot tell who is pushed -- -l, -G, -C, --min-read-len -- the record stays together with every record that
+        // starts between its end and its mate: the replay sees from their RI_PUSHED whether one of them freed it)
+        std::vector<std::pair<int64_t, int64_t>> ctx;
+        auto for_mate_only = [&](int64_t end, unsigned flag, int32_t tid, int32_t mtid, int64_t mpos, const char *qname) {
+            if (!mate_stays(flag, tid, mtid, mpos, qname) || freed_before_mate(end, mpos)) return false;
+            ctx.emplace_back(end, mpos);
+            return true;
+        };
+        auto in_ctx = [&](int64_t pos) { for (auto &iv : ctx) if (pos > iv.first && pos < iv.second) return true; return false; };
+        { size_t i = 0; for (auto &r : f.carry) keepc[i++] = span_end(r) > ce || for_mate_only(span_end(r), r.flag, r.tid, r.mtid, r.mpos, r.qname.c_str()); }
         std::vector<std::pair<const Chunk *, int64_t>> fresh_keep;
         size_t si = f.n_carry_staged;
         for (auto &g : f.fresh)
             for (int64_t i = g.i0; i < g.i1; ++i, ++si) {
                 if (is_dropped(si)) continue;
                 const size_t k = (size_t)i;
-                if (span_end(*g.c, i) > ce || mate_stays(g.c->flag[k], g.c->tid[k], g.c->mtid[k], g.c->mpos[k], g.c->names.data() + g.c->name_off[k]))
+                if (span_end(*g.c, i) > ce || for_mate_only(span_end(*g.c, i), g.c->flag[k], g.c->tid[k], g.c->mtid[k], g.c->mpos[k], g.c->names.data() + g.c->name_off[k]))
                     fresh_keep.emplace_back(g.c.get(), i);
             }
+        if (!ctx.empty()) {          // the context records: merged back in position order (carried first, then the window's new reads)
+            { size_t i = 0; for (auto &r : f.carry) { if (!keepc[i] && in_ctx(r.pos)) keepc[i] = 1; ++i; } }
+            std::vector<std::pair<const Chunk *, int64_t>> all;
+            size_t sj = f.n_carry_staged, kk = 0;
+            for (auto &g : f.fresh)
+                for (int64_t i = g.i0; i < g.i1; ++i, ++sj) {
+                    if (is_dropped(sj)) continue;
+                    const bool kept = kk < fresh_keep.size() && fresh_keep[kk].first == g.c.get() && fresh_keep[kk].second == i;
+                    if (kept) ++kk;
+                    if (kept || in_ctx(g.c->pos[(size_t)i])) all.emplace_back(g.c.get(), i);
+                }
+            fresh_keep.swap(all);
+        }
         std::deque<Rec> keep;
         { size_t i = 0; for (auto &r : f.carry) { if (keepc[i++]) keep.push_back(std::move(r)); } }
         for (auto &pr : fresh_keep) { keep.emplace_back(); pr.first->to_rec(pr.second, keep.back()); }

@@ -148,9 +148,31 @@ void Pump::retire(int64_t ce)
             for (; lo != stay.end() && (*lo)->pos == r.mpos; ++lo) if (*lo != &r && (*lo)->qname == r.qname) return true;
             return false;
         };
+        // A record that stays ONLY for its mate's sake holds nothing any more once a read beyond its end was pushed before that mate:
+        // bam_plp_next frees it (overlap_remove takes the entry of its name along) as soon as max_pos has passed its end.  Carried on, it
+        // would look to the next window's replay (k_name_groups) like the holder of the template's entry -- the record that freed it is
+        // not staged there.  Seen with three records of one template: a supplementary alignment upstream of the primary pair, a window
+        // cut between them (scripts/hunt5.py, round 5).
+        auto freed_before_mate = [&](const Rec &r) {
+            if (!cfg_.surely_pushed) return false;
+            const int64_t e = span_end(r);
+            for (auto &q : c) { if (q.pos >= r.mpos) break; if (q.pos > e && cfg_.surely_pushed(q)) return true; }
+            return false;
+        };
+        // Where the host cannot tell who is pushed (-l, -G, -C, --min-read-len: surely_pushed says no), the record stays and so does
+        // every record that starts between its end and its mate: the replay then sees, from their RI_PUSHED, whether one of them freed it.
+        std::vector<std::pair<int64_t, int64_t>> ctx;      // (end of a record kept for its mate only, its mate's position)
         std::vector<char> gone(c.size(), 0);       // decided before anything moves: `stay` points into c
         size_t i = 0;
-        for (auto &r : c) { gone[i++] = span_end(r) <= ce && !(!stay.empty() && mate_stays(r)); }
+        for (auto &r : c) {
+            bool keep_r = span_end(r) > ce;
+            if (!keep_r && !stay.empty() && mate_stays(r) && !freed_before_mate(r)) { keep_r = true; ctx.emplace_back(span_end(r), r.mpos); }
+            gone[i++] = !keep_r;
+        }
+        if (!ctx.empty()) {
+            i = 0;
+            for (auto &r : c) { if (gone[i]) for (auto &iv : ctx) if (r.pos > iv.first && r.pos < iv.second) { gone[i] = 0; break; } ++i; }
+        }
         std::deque<Rec> keep;
         i = 0;
         for (auto &r : c) { if (!gone[i++]) keep.push_back(std::move(r)); }

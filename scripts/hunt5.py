@@ -79,6 +79,20 @@ def draw_consensus(rnd):
     return ["consensus"] + o
 
 
+def draw_calmd(rnd):
+    o = ["--no-PG"]
+    if rnd.random() < 0.3: o += ["-e"]
+    if rnd.random() < 0.5: o += ["-r"]
+    if rnd.random() < 0.3: o += ["-E"]
+    if rnd.random() < 0.3: o += ["-A"]
+    if rnd.random() < 0.2: o += ["-q"]
+    if rnd.random() < 0.2: o += ["-n", str(rnd.choice([1, 3]))]
+    if rnd.random() < 0.2: o += ["-C", str(rnd.choice([20, 50]))]
+    if rnd.random() < 0.2: o += ["-d"]
+    if rnd.random() < 0.15: o += ["-N"]
+    return ["calmd", "-Q"] + o
+
+
 def draw_other(rnd, fa, bed):
     k = rnd.random()
     if k < 0.25:
@@ -87,6 +101,7 @@ def draw_other(rnd, fa, bed):
         if rnd.random() < 0.4: o += ["-q", "5"]
         if rnd.random() < 0.3: o += ["-r", "c3:5000-20000"]
         if rnd.random() < 0.3: o += ["-l", "60"]
+        if rnd.random() < 0.25: o += rnd.choice([["-m"], ["-m", "-A"], ["-D"], ["-m", "-w", "60"]])
         return o, 2
     if k < 0.5:
         o = ["bedcov"]
@@ -125,9 +140,11 @@ for seed in seeds:
         k = rnd.random()
         if k < 0.5: args, nf = draw_mpileup(rnd, fa, bed), 2
         elif k < 0.7: args, nf = draw_depth(rnd, bed), 2
-        elif k < 0.85: args, nf = draw_consensus(rnd), 1
+        elif k < 0.8: args, nf = draw_consensus(rnd), 1
+        elif k < 0.88: args, nf = draw_calmd(rnd), 1
         else: args, nf = draw_other(rnd, fa, bed)
         files = [sam, sam2] if (nf > 1 and rnd.random() < 0.35) else [sam]
+        if args[0] == "calmd": files = [sam, fa]
         env = {}
         if rnd.random() < 0.6: env["STA_WINDOW_COLS"] = str(rnd.choice([37, 300, 900, 3000, 10000]))
         if rnd.random() < 0.3: env["STA_WINDOW_READS"] = str(rnd.choice([5, 50, 700]))

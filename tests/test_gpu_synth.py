@@ -425,3 +425,59 @@ def test_adjust_mq_on_records_without_seq(tmp_path, oracle_bin, product_bin, cmd
     got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert got.returncode == 0, got.stderr.decode()[-500:]
     assert got.stdout == want and len(want) > 100000
+
+
+def _add_upstream_supplementaries(sam, every, gap_lo, gap_hi, seed):
+    """For every `every`-th proper pair add a supplementary alignment of the LATER mate (flag 2048 | its flags; RNEXT / PNEXT = the earlier
+    mate, as an aligner writes them) that lies wholly upstream of the pair, gap_lo..gap_hi columns in front of it: three records of one
+    template, the first of which has left the pileup buffer (and taken the template's overlap-hash entry with it) before the pair arrives."""
+    import random
+    rnd = random.Random(seed)
+    head, recs = [], []
+    for line in open(sam):
+        (head if line.startswith("@") else recs).append(line)
+    by_name = {}
+    for line in recs:
+        f = line.rstrip("\n").split("\t")
+        by_name.setdefault(f[0], []).append(f)
+    extra, k = [], 0
+    for name, fs in by_name.items():
+        if len(fs) != 2 or not (int(fs[0][1]) & 2):
+            continue
+        k += 1
+        if k % every:
+            continue
+        a, b = fs                       # in position order
+        L = rnd.randint(30, 60)
+        spos = int(a[3]) - rnd.randint(gap_lo, gap_hi) - L
+        if spos < 1:
+            continue
+        extra.append((spos, "\t".join([name, str(int(b[1]) | 2048), b[2], str(spos), b[4], "%dM" % L, "=", a[3], "0", b[9][:L], b[10][:L]]) + "\n"))
+    allr = [(int(l.split("\t")[3]), i, l) for i, l in enumerate(recs)] + [(p, -1, l) for p, l in extra]
+    allr.sort(key=lambda t: (t[0], t[1]))
+    open(sam, "w").write("".join(head) + "".join(t[2] for t in allr))
+    return len(extra)
+
+
+@pytest.mark.parametrize("opts", [[], ["-l", "{bed}"], ["-B", "-C", "50"]], ids=["plain", "bed", "B_C50"])
+def test_supplementary_upstream_of_a_pair_across_window_cuts(tmp_path, oracle_bin, product_bin, opts):
+    """A record kept staged only for its mate's sake (PumpConfig::keep_mates) must not look like the holder of the template's overlap-hash
+    entry in the next window when the reference freed it long ago: bam_plp_next frees a node once a read beyond its end was pushed, and
+    overlap_remove deletes the entry BY NAME.  Three records of one template -- a supplementary alignment upstream of an overlapping
+    primary pair -- with a window cut between them: the engine paired the supplementary with the first mate and left the real pair
+    unresolved (found by scripts/hunt5.py on the CPU emulation, round 5).  Where the host knows who is pushed it drops the freed record at
+    the cut; where it does not (-l, -C ...) it carries the records in between along and the device's replay decides."""
+    from bamio import sam_to_bam
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=6000, depth=12, read_len=200, seed=613, paired=True)      # insert ~ 300: every pair overlaps
+    assert _add_upstream_supplementaries(sam, 2, 10, 120, 5) > 40
+    bed = str(tmp_path / "r.bed")
+    open(bed, "w").write("chrS\t0\t2500\nchrS\t2600\t5000\n")
+    bam = sam_to_bam(sam, str(tmp_path / "s.bam"), level=1, block=3000)
+    args = ["mpileup"] + [o.format(bed=bed) for o in opts] + ["-f", fa]
+    want = subprocess.run([oracle_bin] + args + [sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    assert want.count(b"\n") > 4000
+    for wr in ("2", "3", "4", "5", "6", "8", "13"):
+        for inp in (sam, bam):
+            got = subprocess.run([product_bin] + args + [inp], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, STA_WINDOW_READS=wr))
+            assert got.returncode == 0, got.stderr.decode()[-500:]
+            assert got.stdout == want, (opts, wr, os.path.basename(inp))

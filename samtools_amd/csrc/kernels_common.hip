@@ -186,6 +186,15 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
             bool no = (mtid >= 0 && mtid != W.tid) || (isz >= 2ll * lq && mpos >= W.origin + end);
             if (!no) { info |= RI_OLAP_EL; c_olap += 1; }
         }
+        // realn.c's first early return (unmapped, no bases, qual[0] == 0xff) comes BEFORE it looks for BQ:Z: such a record keeps its
+        // qualities whatever its tag says.  k_qual_prep applied the tag pool to every byte; put this read's bytes back.  (Found by
+        // scripts/hunt6.py on the CPU emulation, round 5: calmd -r -A printed 255 - (BQ - 64) for reads without QUAL.)
+        if ((P.flag & STA_MPLP_REALN) && W.ref != nullptr && !(P.flag & STA_MPLP_REDO_BAQ) && R.bq != nullptr && (aux & STA_AUX_HAS_BQ)
+            && R.qual != R.qual_in && lq > 0) {
+            const uint64_t bo = (uint64_t)R.base_off8[i] << 3;
+            if ((flag & BAM_FUNMAP) || (R.qual_in[bo] == 0xff && !(P.flag & STA_MPLP_ILLUMINA13)))
+                for (int32_t k = 0; k < lq; ++k) R.qual[bo + k] = R.qual_in[bo + k];
+        }
         // BAQ needed? (realn.c early returns, A.4)  baq_cls: 0 none, 1 band width 7 in place, 2 through the list, 3 class-S candidate
         int baq_cls = 0, baq_bw = 0, baq_gbw = 0;
         if (pushed && (P.flag & STA_MPLP_REALN) && has_ref && lq > 0 && has_m && !has_n) {

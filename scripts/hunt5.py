@@ -124,48 +124,53 @@ def draw_other(rnd, fa, bed):
     return ["stats"], 1
 
 
-bad = total = 0
-for seed in seeds:
-    rnd = random.Random(seed * 7919 + 5)
-    out = "/tmp/hunt5_%d" % seed; os.makedirs(out, exist_ok=True)
-    nt = rnd.choice([800, 1500, 2500])
-    sam, fa = write_rich_sam(out, seed=1000 + seed, n_templates=nt)
-    d2 = os.path.join(out, "b"); os.makedirs(d2, exist_ok=True)
-    sam2, _ = write_rich_sam(d2, seed=2000 + seed, n_templates=nt // 3)
-    bam = sam_to_bam(sam, os.path.join(out, "rich.bam"), level=1, block=rnd.choice([3000, 20000, 0xff00]))
-    bed = os.path.join(out, "r.bed")
-    with open(bed, "w") as f:
-        f.write("c1\t100\t9000\nc1\t9500\t9600\nc2\t0\t4000\tname\nc3\t20000\t44000\n")
-    for case in range(N_CASES):
-        k = rnd.random()
-        if k < 0.5: args, nf = draw_mpileup(rnd, fa, bed), 2
-        elif k < 0.7: args, nf = draw_depth(rnd, bed), 2
-        elif k < 0.8: args, nf = draw_consensus(rnd), 1
-        elif k < 0.88: args, nf = draw_calmd(rnd), 1
-        else: args, nf = draw_other(rnd, fa, bed)
-        files = [sam, sam2] if (nf > 1 and rnd.random() < 0.35) else [sam]
-        if args[0] == "calmd": files = [sam, fa]
-        env = {}
-        if rnd.random() < 0.6: env["STA_WINDOW_COLS"] = str(rnd.choice([37, 300, 900, 3000, 10000]))
-        if rnd.random() < 0.3: env["STA_WINDOW_READS"] = str(rnd.choice([5, 50, 700]))
-        if rnd.random() < 0.3: env["STA_PLP_BATCH"] = str(rnd.choice([64, 700]))
-        if args[0] == "mpileup" and rnd.random() < 0.2: env["STA_EMIT_DEEP"] = rnd.choice(["0", "1"])
-        use_bam = rnd.random() < 0.5 and "-H" not in args          # (depth -H prints the file names)
-        o = subprocess.run([ORACLE] + args + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        eargs = args + [bam if (use_bam and a == sam) else a for a in files]
-        try:
-            p = subprocess.run([EXE] + eargs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env), timeout=1800)
-            rc, got, err = p.returncode, p.stdout, p.stderr
-        except subprocess.TimeoutExpired:
-            rc, got, err = -999, b"", b"timeout"
-        total += 1
-        ok = rc == o.returncode and got == o.stdout
-        print("%s seed %d case %d %s %s rc=%d/%d bytes %d/%d" % ("ok  " if ok else "FAIL", seed, case, env, " ".join(a if len(a) < 30 else "~" + os.path.basename(a) for a in eargs), rc, o.returncode, len(got), len(o.stdout)), flush=True)
-        if not ok:
-            bad += 1
-            g, w = got.split(b"\n"), o.stdout.split(b"\n")
-            for i, (x, y) in enumerate(zip(g, w)):
-                if x != y:
-                    print("   line", i + 1, "\n   got ", x[:300], "\n   want", y[:300]); break
-            if rc != o.returncode: print("   stderr engine:", err.decode(errors="replace")[-300:].replace("\n", " | "), "\n   stderr oracle:", o.stderr.decode(errors="replace")[-200:].replace("\n", " | "))
-print("hunt5: %d failures in %d runs" % (bad, total))
+def main():
+    bad = total = 0
+    for seed in seeds:
+        rnd = random.Random(seed * 7919 + 5)
+        out = "/tmp/hunt5_%d" % seed; os.makedirs(out, exist_ok=True)
+        nt = rnd.choice([800, 1500, 2500])
+        sam, fa = write_rich_sam(out, seed=1000 + seed, n_templates=nt)
+        d2 = os.path.join(out, "b"); os.makedirs(d2, exist_ok=True)
+        sam2, _ = write_rich_sam(d2, seed=2000 + seed, n_templates=nt // 3)
+        bam = sam_to_bam(sam, os.path.join(out, "rich.bam"), level=1, block=rnd.choice([3000, 20000, 0xff00]))
+        bed = os.path.join(out, "r.bed")
+        with open(bed, "w") as f:
+            f.write("c1\t100\t9000\nc1\t9500\t9600\nc2\t0\t4000\tname\nc3\t20000\t44000\n")
+        for case in range(N_CASES):
+            k = rnd.random()
+            if k < 0.5: args, nf = draw_mpileup(rnd, fa, bed), 2
+            elif k < 0.7: args, nf = draw_depth(rnd, bed), 2
+            elif k < 0.8: args, nf = draw_consensus(rnd), 1
+            elif k < 0.88: args, nf = draw_calmd(rnd), 1
+            else: args, nf = draw_other(rnd, fa, bed)
+            files = [sam, sam2] if (nf > 1 and rnd.random() < 0.35) else [sam]
+            if args[0] == "calmd": files = [sam, fa]
+            env = {}
+            if rnd.random() < 0.6: env["STA_WINDOW_COLS"] = str(rnd.choice([37, 300, 900, 3000, 10000]))
+            if rnd.random() < 0.3: env["STA_WINDOW_READS"] = str(rnd.choice([5, 50, 700]))
+            if rnd.random() < 0.3: env["STA_PLP_BATCH"] = str(rnd.choice([64, 700]))
+            if args[0] == "mpileup" and rnd.random() < 0.2: env["STA_EMIT_DEEP"] = rnd.choice(["0", "1"])
+            use_bam = rnd.random() < 0.5 and "-H" not in args          # (depth -H prints the file names)
+            o = subprocess.run([ORACLE] + args + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            eargs = args + [bam if (use_bam and a == sam) else a for a in files]
+            try:
+                p = subprocess.run([EXE] + eargs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env), timeout=1800)
+                rc, got, err = p.returncode, p.stdout, p.stderr
+            except subprocess.TimeoutExpired:
+                rc, got, err = -999, b"", b"timeout"
+            total += 1
+            ok = rc == o.returncode and got == o.stdout
+            print("%s seed %d case %d %s %s rc=%d/%d bytes %d/%d" % ("ok  " if ok else "FAIL", seed, case, env, " ".join(a if len(a) < 30 else "~" + os.path.basename(a) for a in eargs), rc, o.returncode, len(got), len(o.stdout)), flush=True)
+            if not ok:
+                bad += 1
+                g, w = got.split(b"\n"), o.stdout.split(b"\n")
+                for i, (x, y) in enumerate(zip(g, w)):
+                    if x != y:
+                        print("   line", i + 1, "\n   got ", x[:300], "\n   want", y[:300]); break
+                if rc != o.returncode: print("   stderr engine:", err.decode(errors="replace")[-300:].replace("\n", " | "), "\n   stderr oracle:", o.stderr.decode(errors="replace")[-200:].replace("\n", " | "))
+    print("hunt5: %d failures in %d runs" % (bad, total))
+
+
+if __name__ == "__main__":
+    main()

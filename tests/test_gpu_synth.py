@@ -413,6 +413,41 @@ def test_illumina13_shift_comes_before_the_missing_quality_test_of_baq(tmp_path,
         assert plain.count(b"~") > want.count(b"~")
 
 
+@pytest.mark.parametrize("args", [["calmd", "--no-PG", "-r", "-A"], ["calmd", "--no-PG", "-r", "-A", "-E", "-n", "3"], ["mpileup"], ["mpileup", "-6"],
+                                  ["mpileup", "-E", "-Q", "0"]], ids=["calmd_rA", "calmd_rAE_n3", "mpileup", "mpileup_6", "mpileup_E"])
+def test_bq_tag_is_not_applied_to_records_the_realigner_turns_away(tmp_path, oracle_bin, product_bin, args):
+    """sam_prob_realn returns on an unmapped record, a record without bases and a record whose first quality is 0xff BEFORE it looks for
+    BQ:Z (realn.c; SURVEY.md A.4): a read without QUAL keeps 0xff everywhere whatever its tag says (`calmd -r -A` prints '*', mpileup '~');
+    under -6 the shifted byte is 224 and the tag IS applied.  The engine applies the tag pool to every byte up front (k_qual_prep) and
+    puts such reads back in k_prep_reads.  Found by scripts/hunt6.py on the CPU emulation of the kernels (round 5)."""
+    import random
+    rnd = random.Random(77)
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=9000, depth=10, read_len=100, seed=613, paired=True, indel_rate=0.03)
+
+    def tag(f):
+        bq = "BQ:Z:" + "".join(chr(64 + (rnd.randint(1, 40) if rnd.random() < 0.3 else 0)) for _ in f[9])
+        k = rnd.random()
+        if k < 0.4:
+            f = f[:10] + ["*"] + f[11:]                                  # no QUAL: the tag must be ignored (not under -6)
+        elif k < 0.5:
+            f = [f[0], str(int(f[1]) | 4)] + f[2:]                       # unmapped but placed: calmd hands it back untouched
+        return f + [bq]
+    _rewrite_some_records(sam, 3, tag)
+    files = [sam, fa] if args[0] == "calmd" else ["-f", fa, sam]
+    want = subprocess.run([oracle_bin] + args + files, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    assert len(want) > 100000
+    for wc in (None, "900"):
+        e = dict(os.environ)
+        if wc:
+            e["STA_WINDOW_COLS"] = wc
+        got = subprocess.run([product_bin] + args + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+        assert got.returncode == 0, got.stderr.decode()[-500:]
+        assert got.stdout == want, (args, wc)
+    if args == ["calmd", "--no-PG", "-r", "-A"]:
+        # the rule is visible: records without QUAL come out with '*' in the quality column
+        assert sum(1 for l in want.split(b"\n") if l and not l.startswith(b"@") and l.split(b"\t")[10] == b"*" and b"BQ:Z:" in l) > 20
+
+
 @pytest.mark.parametrize("cmd", ["mpileup", "calmd"])
 def test_adjust_mq_on_records_without_seq(tmp_path, oracle_bin, product_bin, cmd):
     """-C on a record whose SEQ is '*' under a CIGAR with M operations: HTSlib's sam_cap_mapq walks seq / qual behind the record

@@ -226,6 +226,14 @@ int o_prob_realn(orec_t *b, const char *ref, hpos_t ref_len, int flag)
             if (i >= ref_len || ref[i] == '\0') { xe = (int)i; break; }
             tref[i - xb] = (uint8_t)nt16_int[nt16_table[(unsigned char)ref[i]]];
         }
+        if (xe - xb <= 0) {
+            /* calmd only (mpileup skips reads that start behind the FASTA contig's end, bam_plcmd.c:440-445): the whole window lies
+               behind the end of the sequence.  HTSlib's probaln_glocal returns 0 at once for l_ref <= 0 and sam_prob_realn goes on
+               to read state[] and q[] it malloc'ed and never wrote: undefined in the reference.  Defined here (and in the engine,
+               dev_util.h baq_geometry: !ok) as "the record is left alone". */
+            free(tseq); free(tref); free(q); free(bq); free(state);
+            return -1;
+        }
         memcpy(bq, qual, (size_t)L);
         if (probaln_glocal(tref, xe - xb, tseq, L, qual, &conf, state, q) == INT_MIN) {
             free(tseq); free(tref); free(q); free(bq); free(state);

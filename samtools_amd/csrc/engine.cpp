@@ -1275,7 +1275,7 @@ int sta_calmd_plan(sta_engine *e, const sta_calmd_params *cp, sta_plan_info *inf
     const bool realn = (cp->flag & STA_CALMD_REALN) != 0, apply = (cp->flag & STA_CALMD_APPLY) != 0;
     if (realn && !e->wd.ref) return fail(e, STA_ERR_ARG, "calmd -r needs the reference of the contig");
     sta_mplp_params p; memset(&p, 0, sizeof p);
-    p.flag = realn ? STA_MPLP_REALN : 0;
+    p.flag = (realn ? STA_MPLP_REALN : 0) | STA_MPLP_INT_CALMD;
     e->mp = p;
     e->min_pos.assign(1, 0); e->max_pos_hint.assign(1, 0);
     StaReadsDev &d = e->files_h[0];

@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) k_prep_reads(StaReadsDev R, StaWinDev W, 
         }
         if (aux & STA_AUX_SKIP) pushed = false;
         bool has_ref = W.ref != nullptr;
-        if (has_ref && W.ref_len <= apos) pushed = false;   // "Skipping because ... is outside of ..."
+        if (has_ref && W.ref_len <= apos && !(P.flag & STA_MPLP_INT_CALMD)) pushed = false;   // "Skipping because ... is outside of ..."
         if (P.min_qlen) {
             // coverage -l: bam_cigar2qlen (coverage.c:189)
             int32_t ql = 0;

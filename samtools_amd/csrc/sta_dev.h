@@ -6,6 +6,9 @@
 #include "../../include/samtools_amd.h"
 
 // per-read packed info word produced by k_prep_reads
+// internal bit of sta_mplp_params.flag (never part of the C ABI): the pipeline runs for calmd -- no "read starts beyond the FASTA
+// contig" skip (that is mplp_func's, bam_plcmd.c:440-445; bam_md.c:461-476 hands every placed record to sam_prob_realn)
+#define STA_MPLP_INT_CALMD (1 << 30)
 #define RI_PUSHED   0x1u    // passed mplp_func filters -> reaches bam_plp_push
 #define RI_KEEP     0x2u    // in the pileup: pushed, reference span > 0, not dropped by -d cap
 #define RI_SIMPLE   0x4u    // CIGAR is a single M/=/X op

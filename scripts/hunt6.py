@@ -119,7 +119,7 @@ def enrich(rnd, sam, fa, out_sam, out_fa, mods=True):
         for r in recs:
             fh.write("\t".join(r[3]) + "\n")
     # the FASTA the commands are given: case, IUPAC codes, N runs (the reads were drawn from the plain sequence: mismatches there)
-    with open(out_fa, "w") as fh:
+    with open(out_fa, "w") as fh, open(out_fa + ".full.fa", "w") as fh_full:
         for c in order:
             s = list(refs[c])
             for _ in range(rnd.randint(2, 8)):
@@ -130,6 +130,13 @@ def enrich(rnd, sam, fa, out_sam, out_fa, mods=True):
                     elif kind < 0.75: s[i] = rnd.choice("RYMKSWHBVDNn") if rnd.random() < 0.3 else s[i]
                     else: s[i] = "N" if b - a < 60 else s[i]
             s = "".join(s)
+            fh_full.write(">%s\n" % c)             # (consensus -T reads c->ref[pos] without looking at its length, bam_consensus.c:2368,2502: it gets this one)
+            for i in range(0, len(s), 60):
+                fh_full.write(s[i:i + 60] + "\n")
+            # a contig shorter in the FASTA than its @SQ LN says (reads beyond its end: bam_plcmd.c:440-445), or absent from it
+            k = rnd.random()
+            if k < 0.2: s = s[:rnd.randint(len(s) // 2, len(s) - 1)]
+            elif k < 0.3 and c != order[0]: continue
             fh.write(">%s\n" % c)
             for i in range(0, len(s), 60):
                 fh.write(s[i:i + 60] + "\n")
@@ -217,7 +224,7 @@ def main():
                 args, nf = hunt5.draw_depth(rnd, bed), 2
                 if rnd.random() < 0.2: args += ["-d", str(rnd.choice([0, 5, 100]))]
                 if rnd.random() < 0.15: args += ["-f", blist]; files = []
-            elif k < 0.75: args, nf = draw_consensus6(rnd, fa), 1
+            elif k < 0.75: args, nf = draw_consensus6(rnd, fa + ".full.fa"), 1
             elif k < 0.83: args, nf = hunt5.draw_calmd(rnd), 1
             elif k < 0.9: args, nf = draw_stats(rnd, tgt), 1
             else: args, nf = hunt5.draw_other(rnd, fa, bed)
@@ -232,11 +239,22 @@ def main():
             use_bam = rnd.random() < 0.5 and "-H" not in args
             o = subprocess.run([ORACLE] + args + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             eargs = args + [bam if (use_bam and a == sam) else a for a in files]
+            # SURVEY.md 8e through the CLI: the command cut into W blocks of reference columns (STA_SHARD=r/W, random cuts), the blocks'
+            # texts concatenated in rank order = the unsharded text.  (A single -a and a -d cap that can trigger are refused: skipped.)
+            world = rnd.choice([2, 3, 5, 8]) if (args[0] in ("mpileup", "depth") and rnd.random() < 0.3 and "-H" not in args) else 1
+            if world > 1 and "-r" not in args and rnd.random() < 0.7:
+                env["STA_SHARD_CUTS"] = ",".join(str(c) for c in sorted(rnd.randint(0, 84000) for _ in range(world - 1)))
             try:
-                p = subprocess.run([EXE] + eargs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env), timeout=1800)
-                rc, got, err = p.returncode, p.stdout, p.stderr
+                rc, got, err = 0, b"", b""
+                for r in range(world):
+                    if world > 1: env["STA_SHARD"] = "%d/%d" % (r, world)
+                    p = subprocess.run([EXE] + eargs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env), timeout=1800)
+                    rc, got, err = max(rc, p.returncode), got + p.stdout, err + p.stderr
             except subprocess.TimeoutExpired:
                 rc, got, err = -999, b"", b"timeout"
+            if world > 1 and rc == 1 and (b"supports no single -a" in err or b"-d depth cap can trigger" in err):
+                print("skip seed %d case %d (refused in a sharded run) %s" % (seed, case, " ".join(args[:8])), flush=True)
+                continue
             total += 1
             ok = rc == o.returncode and got == o.stdout
             print("%s seed %d case %d %s %s rc=%d/%d bytes %d/%d" % ("ok  " if ok else "FAIL", seed, case, env, " ".join(a if len(a) < 30 else "~" + os.path.basename(a) for a in eargs), rc, o.returncode, len(got), len(o.stdout)), flush=True)

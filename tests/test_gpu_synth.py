@@ -448,6 +448,41 @@ def test_bq_tag_is_not_applied_to_records_the_realigner_turns_away(tmp_path, ora
         assert sum(1 for l in want.split(b"\n") if l and not l.startswith(b"@") and l.split(b"\t")[10] == b"*" and b"BQ:Z:" in l) > 20
 
 
+@pytest.mark.parametrize("args", [["calmd", "--no-PG", "-r"], ["calmd", "--no-PG", "-r", "-A", "-E"], ["calmd", "--no-PG", "-e"], ["mpileup"], ["mpileup", "-B", "-a"]],
+                         ids=["calmd_r", "calmd_rAE", "calmd_e", "mpileup", "mpileup_Ba"])
+def test_fasta_contig_shorter_than_the_header_says(tmp_path, oracle_bin, product_bin, args):
+    """A FASTA whose contig ends before @SQ LN.  mpileup skips reads that START behind the sequence's end (bam_plcmd.c:440-445); calmd has
+    no such rule: bam_md.c:461-476 hands every placed record to sam_prob_realn, whose window is clipped at the end of the sequence
+    (realn.c: `i >= ref_len: xe = i`), so a read starting up to bw/2 columns behind the end still gets its BQ:Z from the last few
+    reference bases.  The engine ran calmd through mpileup's skip (found by scripts/hunt6.py on the CPU emulation, round 5).  A window
+    wholly behind the end (l_ref <= 0) is undefined in the reference (probaln_glocal returns before writing state[] / q[]): engine and
+    oracle leave such a record alone."""
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=9000, depth=12, read_len=100, seed=614, paired=True, indel_rate=0.03)
+    lines = open(fa).read().split("\n")
+    # cut so that a plain read starts one column behind the last base (its window still holds two reference bases)
+    cut = next(int(f[3]) - 2 for f in (l.split("\t") for l in open(sam) if not l.startswith("@")) if int(f[3]) > 7000 and f[5] == "100M")
+    seq = "".join(l for l in lines[1:] if l)[:cut]
+    with open(fa, "w") as fh:
+        fh.write(lines[0] + "\n")
+        for i in range(0, len(seq), 60):
+            fh.write(seq[i:i + 60] + "\n")
+    if os.path.exists(fa + ".fai"):
+        os.remove(fa + ".fai")
+    files = [sam, fa] if args[0] == "calmd" else ["-f", fa, sam]
+    want = subprocess.run([oracle_bin] + args + files, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    assert len(want) > 100000
+    for wc in (None, "900"):
+        e = dict(os.environ)
+        if wc:
+            e["STA_WINDOW_COLS"] = wc
+        got = subprocess.run([product_bin] + args + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+        assert got.returncode == 0, got.stderr.decode()[-500:]
+        assert got.stdout == want, (args, wc)
+    if args == ["calmd", "--no-PG", "-r"]:
+        # the read the rule is about exists: it starts behind the last base and carries a computed BQ:Z
+        assert any(int(l.split(b"\t")[3]) == cut + 2 and b"BQ:Z:" in l for l in want.split(b"\n") if l and not l.startswith(b"@"))
+
+
 @pytest.mark.parametrize("cmd", ["mpileup", "calmd"])
 def test_adjust_mq_on_records_without_seq(tmp_path, oracle_bin, product_bin, cmd):
     """-C on a record whose SEQ is '*' under a CIGAR with M operations: HTSlib's sam_cap_mapq walks seq / qual behind the record

@@ -51,7 +51,7 @@ int cov_run_tid(sta_engine *eng, Pump &pump, std::vector<std::unique_ptr<AlnRead
         int64_t ce_target = std::min(cursor + window_cols, hi);
         if (ce_target <= cursor) { pump.fill(tid, cursor, INT64_MAX, reads); pump.drop_tid_carry(); break; }
         int64_t ce = pump.fill(tid, cursor, ce_target, reads);
-        if (pump.error()) return -1;
+        if (pump.error()) { fprintf(stderr, "samtools %s: error reading from input file\n", cmd); return -1; }     // (bedcov.c:333; found silent by scripts/hunt7.py)
         if (pump.next_pos(tid) == INT64_MAX) {
             int64_t me = pump.carry_max_end();
             if (me != INT64_MIN) ce = std::min(ce, std::max(me, cursor));

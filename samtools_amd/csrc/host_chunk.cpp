@@ -692,18 +692,32 @@ void ChunkPump::retire(int64_t ce)
         };
         // A record that stays ONLY for its mate's sake holds nothing any more once a read beyond its end was pushed before that mate
         // (bam_plp_next frees it and overlap_remove takes the entry of its name along): see Pump::retire
-        auto freed_before_mate = [&](int64_t end, int64_t mpos) {
+        // ("that mate" = the NEXT pushed record of its template, which need not be the one at its mate position: see Pump::retire.  `self`
+        // names the record asked about: a carried Rec, or (chunk, index) of a new one.)
+        auto freed_before_mate = [&](int64_t end, int64_t mpos, const char *qname, const void *self, int64_t self_i) {
             if (!cfg_.surely_pushed) return false;
-            for (auto &q : f.carry) { if (q.pos >= mpos) break; if (q.pos > end && cfg_.surely_pushed(q)) return true; }
+            bool behind = false;
+            for (auto &q : f.carry) {
+                if ((const void *)&q == self) { behind = true; continue; }
+                if (!behind) continue;
+                if (q.pos >= mpos) return false;
+                if (!cfg_.surely_pushed(q)) continue;
+                if (!strcmp(q.qname.c_str(), qname)) return false;
+                if (q.pos > end) return true;
+            }
             Rec probe;
             size_t sj = f.n_carry_staged;
             for (auto &g : f.fresh)
                 for (int64_t i = g.i0; i < g.i1; ++i, ++sj) {
                     const size_t k = (size_t)i;
+                    if ((const void *)g.c.get() == self && i == self_i) { behind = true; continue; }
+                    if (!behind) continue;
                     if (g.c->pos[k] >= mpos) return false;
-                    if (g.c->pos[k] <= end || is_dropped(sj)) continue;
+                    if (is_dropped(sj)) continue;
                     probe.tid = g.c->tid[k]; probe.pos = g.c->pos[k]; probe.flag = g.c->flag[k]; probe.mapq = g.c->mapq[k];
-                    if (cfg_.surely_pushed(probe)) return true;
+                    if (!cfg_.surely_pushed(probe)) continue;
+                    if (!strcmp(g.c->names.data() + g.c->name_off[k], qname)) return false;
+                    if (g.c->pos[k] > end) return true;
                 }
             return false;
         };
@@ -711,36 +725,97 @@ void ChunkPump::retire(int64_t ce)
         std::vector<char> keepc(f.carry.size(), 0);
         // (where the host cannot tell who is pushed -- -l, -G, -C, --min-read-len -- the record stays together with every record that
         // starts between its end and its mate: the replay sees from their RI_PUSHED whether one of them freed it)
-        std::vector<std::pair<int64_t, int64_t>> ctx;
-        auto for_mate_only = [&](int64_t end, unsigned flag, int32_t tid, int32_t mtid, int64_t mpos, const char *qname) {
-            if (!mate_stays(flag, tid, mtid, mpos, qname) || freed_before_mate(end, mpos)) return false;
-            ctx.emplace_back(end, mpos);
+        struct Ctx { int64_t pos, end, mpos; std::string qname; };
+        std::vector<Ctx> ctx;
+        auto for_mate_only = [&](int64_t pos, int64_t end, unsigned flag, int32_t tid, int32_t mtid, int64_t mpos, const char *qname, const void *self, int64_t self_i) {
+            if (!mate_stays(flag, tid, mtid, mpos, qname) || freed_before_mate(end, mpos, qname, self, self_i)) return false;
+            ctx.push_back(Ctx{ pos, end, mpos, qname });
             return true;
         };
-        auto in_ctx = [&](int64_t pos) { for (auto &iv : ctx) if (pos > iv.first && pos < iv.second) return true; return false; };
-        { size_t i = 0; for (auto &r : f.carry) keepc[i++] = span_end(r) > ce || for_mate_only(span_end(r), r.flag, r.tid, r.mtid, r.mpos, r.qname.c_str()); }
-        std::vector<std::pair<const Chunk *, int64_t>> fresh_keep;
-        size_t si = f.n_carry_staged;
-        for (auto &g : f.fresh)
-            for (int64_t i = g.i0; i < g.i1; ++i, ++si) {
-                if (is_dropped(si)) continue;
-                const size_t k = (size_t)i;
-                if (span_end(*g.c, i) > ce || for_mate_only(span_end(*g.c, i), g.c->flag[k], g.c->tid[k], g.c->mtid[k], g.c->mpos[k], g.c->names.data() + g.c->name_off[k]))
-                    fresh_keep.emplace_back(g.c.get(), i);
-            }
-        if (!ctx.empty()) {          // the context records: merged back in position order (carried first, then the window's new reads)
-            { size_t i = 0; for (auto &r : f.carry) { if (!keepc[i] && in_ctx(r.pos)) keepc[i] = 1; ++i; } }
-            std::vector<std::pair<const Chunk *, int64_t>> all;
-            size_t sj = f.n_carry_staged, kk = 0;
-            for (auto &g : f.fresh)
-                for (int64_t i = g.i0; i < g.i1; ++i, ++sj) {
-                    if (is_dropped(sj)) continue;
-                    const bool kept = kk < fresh_keep.size() && fresh_keep[kk].first == g.c.get() && fresh_keep[kk].second == i;
-                    if (kept) ++kk;
-                    if (kept || in_ctx(g.c->pos[(size_t)i])) all.emplace_back(g.c.get(), i);
+        // (by position, or as another record of the template: one that starts inside the kept record's span is no context record by position)
+        auto in_ctx = [&](int64_t pos, const char *qname) {
+            for (auto &iv : ctx) if (pos < iv.mpos && (pos > iv.end || (pos >= iv.pos && !strcmp(iv.qname.c_str(), qname)))) return true;
+            return false;
+        };
+        // (1) A record whose span ends at the cut is still in the reference's buffer while no pushed read has started beyond its end
+        // (Pump::retire): max_start = the last pushed start in front of the cut (the lists are position sorted: looked for from the back).
+        // Only while the contig has reads to come: at its end the reference flushes its buffer, and a record kept here for ever would keep
+        // the window loop going for ever.
+        int64_t max_start = INT64_MIN;
+        int cur_tid = -1;
+        if (!f.carry.empty()) cur_tid = f.carry.front().tid;
+        else for (auto &g : f.fresh) if (g.i1 > g.i0) { cur_tid = g.c->tid[(size_t)g.i0]; break; }
+        if (cfg_.keep_mates && cur_tid >= 0 && next_pos(cur_tid) != INT64_MAX) {
+            Rec probe;
+            bool found = false;
+            size_t sj = f.n_carry_staged;
+            for (auto &g : f.fresh) sj += (size_t)(g.i1 - g.i0);
+            for (auto g = f.fresh.rbegin(); g != f.fresh.rend() && !found; ++g)
+                for (int64_t i = g->i1 - 1; i >= g->i0; --i) {
+                    --sj;
+                    const size_t k = (size_t)i;
+                    if (is_dropped(sj) || g->c->pos[k] >= ce) continue;
+                    if (cfg_.surely_pushed) { probe.tid = g->c->tid[k]; probe.pos = g->c->pos[k]; probe.flag = g->c->flag[k]; probe.mapq = g->c->mapq[k]; if (!cfg_.surely_pushed(probe)) continue; }
+                    max_start = g->c->pos[k]; found = true; break;
                 }
-            fresh_keep.swap(all);
+            if (!found)
+                for (auto r = f.carry.rbegin(); r != f.carry.rend(); ++r)
+                    if (r->pos < ce && (!cfg_.surely_pushed || cfg_.surely_pushed(*r))) { max_start = r->pos; break; }
         }
+        const bool alive_rule = cfg_.keep_mates && max_start != INT64_MIN;
+        std::vector<const char *> multi;          // names of secondary / supplementary records: templates with more than two records
+        { size_t i = 0; for (auto &r : f.carry) {
+            const int64_t e = span_end(r);
+            if (cfg_.keep_mates && (r.flag & 0x900)) multi.push_back(r.qname.c_str());
+            keepc[i++] = e > ce || (alive_rule && e >= max_start) || for_mate_only(r.pos, e, r.flag, r.tid, r.mtid, r.mpos, r.qname.c_str(), &r, 0); } }
+        // the window's new reads, in staged order (dropped ones never kept)
+        size_t n_fresh = 0;
+        for (auto &g : f.fresh) n_fresh += (size_t)(g.i1 - g.i0);
+        std::vector<char> keepf(n_fresh, 0);
+        auto each_fresh = [&](auto &&fn) {          // fn(chunk, index in chunk, index in keepf); dropped records skipped
+            size_t si = f.n_carry_staged, j = 0;
+            for (auto &g : f.fresh)
+                for (int64_t i = g.i0; i < g.i1; ++i, ++si, ++j) if (!is_dropped(si)) fn(*g.c, i, j);
+        };
+        auto name_of = [](const Chunk &c, int64_t i) { return c.names.data() + c.name_off[(size_t)i]; };
+        each_fresh([&](const Chunk &c, int64_t i, size_t j) {
+            const size_t k = (size_t)i;
+            const int64_t e = span_end(c, i);
+            if (cfg_.keep_mates && (c.flag[k] & 0x900)) multi.push_back(name_of(c, i));
+            keepf[j] = e > ce || (alive_rule && e >= max_start) || for_mate_only(c.pos[k], e, c.flag[k], c.tid[k], c.mtid[k], c.mpos[k], name_of(c, i), &c, i);
+        });
+        if (cfg_.keep_mates) {
+            // (2) the records of a template with more than two records all stay while one of them does: see Pump::retire
+            if (!multi.empty()) {
+                std::vector<Ctx> tpl;                  // (first position, -, last position, name) of such a template with a record that stays
+                auto note = [&](const char *qn) {
+                    bool is_multi = false;
+                    for (const char *m : multi) if (!strcmp(m, qn)) { is_multi = true; break; }
+                    if (!is_multi) return;
+                    for (auto &t : tpl) if (!strcmp(t.qname.c_str(), qn)) return;
+                    tpl.push_back(Ctx{ INT64_MAX, 0, INT64_MIN, qn });
+                };
+                { size_t i = 0; for (auto &r : f.carry) { if (keepc[i]) note(r.qname.c_str()); ++i; } }
+                each_fresh([&](const Chunk &c, int64_t i, size_t j) { if (keepf[j]) note(name_of(c, i)); });
+                if (!tpl.empty()) {
+                    auto span = [&](const char *qn, int64_t pos) { for (auto &t : tpl) if (!strcmp(t.qname.c_str(), qn)) { t.pos = std::min(t.pos, pos); t.mpos = std::max(t.mpos, pos); } };
+                    for (auto &r : f.carry) span(r.qname.c_str(), r.pos);
+                    each_fresh([&](const Chunk &c, int64_t i, size_t) { span(name_of(c, i), c.pos[(size_t)i]); });
+                    auto of_tpl = [&](const char *qn, int64_t pos, int64_t end) {
+                        for (auto &t : tpl) if (!strcmp(t.qname.c_str(), qn)) { ctx.push_back(Ctx{ pos, end, t.mpos, qn }); return true; }
+                        return false;
+                    };
+                    { size_t i = 0; for (auto &r : f.carry) { if (!keepc[i] && of_tpl(r.qname.c_str(), r.pos, span_end(r))) keepc[i] = 1; ++i; } }
+                    each_fresh([&](const Chunk &c, int64_t i, size_t j) { if (!keepf[j] && of_tpl(name_of(c, i), c.pos[(size_t)i], span_end(c, i))) keepf[j] = 1; });
+                }
+            }
+        }
+        if (!ctx.empty()) {          // the context records
+            { size_t i = 0; for (auto &r : f.carry) { if (!keepc[i] && in_ctx(r.pos, r.qname.c_str())) keepc[i] = 1; ++i; } }
+            each_fresh([&](const Chunk &c, int64_t i, size_t j) { if (!keepf[j] && in_ctx(c.pos[(size_t)i], name_of(c, i))) keepf[j] = 1; });
+        }
+        std::vector<std::pair<const Chunk *, int64_t>> fresh_keep;       // in position order (carried first, then the window's new reads)
+        each_fresh([&](const Chunk &c, int64_t i, size_t j) { if (keepf[j]) fresh_keep.emplace_back(&c, i); });
         std::deque<Rec> keep;
         { size_t i = 0; for (auto &r : f.carry) { if (keepc[i++]) keep.push_back(std::move(r)); } }
         for (auto &pr : fresh_keep) { keep.emplace_back(); pr.first->to_rec(pr.second, keep.back()); }

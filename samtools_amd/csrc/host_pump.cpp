@@ -153,25 +153,82 @@ void Pump::retire(int64_t ce)
         // would look to the next window's replay (k_name_groups) like the holder of the template's entry -- the record that freed it is
         // not staged there.  Seen with three records of one template: a supplementary alignment upstream of the primary pair, a window
         // cut between them (scripts/hunt5.py, round 5).
+        // "Before that mate" means before the NEXT record of its template that is pushed, which need not be the one at its mate position: a
+        // supplementary alignment (mate position = the second primary) is still in the buffer when the FIRST primary arrives right behind
+        // its end -- that one finds the entry and deletes it, and the second primary finds nothing.  Dropped, the primaries would pair up
+        // in the next window's replay (scripts/hunt6.py seed 29, round 5).
         auto freed_before_mate = [&](const Rec &r) {
             if (!cfg_.surely_pushed) return false;
             const int64_t e = span_end(r);
-            for (auto &q : c) { if (q.pos >= r.mpos) break; if (q.pos > e && cfg_.surely_pushed(q)) return true; }
+            bool behind = false;
+            for (auto &q : c) {
+                if (&q == &r) { behind = true; continue; }
+                if (!behind) continue;
+                if (q.pos >= r.mpos) break;
+                if (!cfg_.surely_pushed(q)) continue;
+                if (q.qname == r.qname) return false;
+                if (q.pos > e) return true;
+            }
             return false;
         };
         // Where the host cannot tell who is pushed (-l, -G, -C, --min-read-len: surely_pushed says no), the record stays and so does
         // every record that starts between its end and its mate: the replay then sees, from their RI_PUSHED, whether one of them freed it.
-        std::vector<std::pair<int64_t, int64_t>> ctx;      // (end of a record kept for its mate only, its mate's position)
+        struct Ctx { int64_t pos, end, mpos; const std::string *qname; };      // a record kept for its mate only
+        std::vector<Ctx> ctx;
         std::vector<char> gone(c.size(), 0);       // decided before anything moves: `stay` points into c
         size_t i = 0;
         for (auto &r : c) {
             bool keep_r = span_end(r) > ce;
-            if (!keep_r && !stay.empty() && mate_stays(r) && !freed_before_mate(r)) { keep_r = true; ctx.emplace_back(span_end(r), r.mpos); }
+            if (!keep_r && !stay.empty() && mate_stays(r) && !freed_before_mate(r)) { keep_r = true; ctx.push_back(Ctx{ r.pos, span_end(r), r.mpos, &r.qname }); }
             gone[i++] = !keep_r;
+        }
+        if (cfg_.keep_mates) {
+            // (1) A record whose span ends at the cut is still in the reference's buffer -- and its template's entry in the hash -- while no
+            // pushed read has started beyond its end: the next window's first read still meets it (a supplementary alignment right in
+            // front of its primaries: the first primary finds its entry, deletes it, and the pair is never resolved).
+            // (Only while the contig has reads to come: at its end the reference flushes its buffer, and a record kept here for ever
+            // would keep the window loop going for ever.)
+            int64_t max_start = INT64_MIN;
+            const bool more = !c.empty() && next_pos(c.front().tid) != INT64_MAX;
+            if (more) for (auto &r : c) if (r.pos < ce && (!cfg_.surely_pushed || cfg_.surely_pushed(r))) max_start = std::max(max_start, r.pos);
+            i = 0;
+            if (more && max_start != INT64_MIN) for (auto &r : c) { if (gone[i] && span_end(r) >= max_start) gone[i] = 0; ++i; }
+            // (2) Templates with more than two records (one of them secondary / supplementary): what a record that stays finds in the hash
+            // depends on every record of its template the window has seen -- a primary that consumed the supplementary's entry three
+            // windows ago must not insert its own when the windows are replayed.  They all stay while one of them does, each ended one
+            // with the records up to the template's last one as context (scripts/hunt6.py seed 29, round 5).
+            std::vector<const Rec *> multi;
+            for (auto &r : c) if (r.flag & 0x900) multi.push_back(&r);
+            if (!multi.empty()) {
+                std::vector<Ctx> tpl;                      // (first pos, -, last pos, name) of a template with a staying record
+                i = 0;
+                for (auto &r : c) {
+                    if (!gone[i++]) {
+                        bool is_multi = false;
+                        for (const Rec *m : multi) if (m->qname == r.qname) { is_multi = true; break; }
+                        if (is_multi) {
+                            bool known = false;
+                            for (auto &t : tpl) if (*t.qname == r.qname) { known = true; break; }
+                            if (!known) tpl.push_back(Ctx{ INT64_MAX, 0, INT64_MIN, &r.qname });
+                        }
+                    }
+                }
+                if (!tpl.empty()) {
+                    for (auto &r : c) for (auto &t : tpl) if (r.qname == *t.qname) { t.pos = std::min(t.pos, r.pos); t.mpos = std::max(t.mpos, r.pos); }
+                    i = 0;
+                    for (auto &r : c) {
+                        if (gone[i]) for (auto &t : tpl) if (r.qname == *t.qname) { gone[i] = 0; ctx.push_back(Ctx{ r.pos, span_end(r), t.mpos, &r.qname }); break; }
+                        ++i;
+                    }
+                }
+            }
         }
         if (!ctx.empty()) {
             i = 0;
-            for (auto &r : c) { if (gone[i]) for (auto &iv : ctx) if (r.pos > iv.first && r.pos < iv.second) { gone[i] = 0; break; } ++i; }
+            for (auto &r : c) { if (gone[i]) for (auto &iv : ctx) if (r.pos > iv.end && r.pos < iv.mpos) { gone[i] = 0; break; } ++i; }
+            // ... and the other records of its template (one that starts inside its span is no context record by position)
+            i = 0;
+            for (auto &r : c) { if (gone[i]) for (auto &iv : ctx) if (r.pos >= iv.pos && r.pos < iv.mpos && r.qname == *iv.qname) { gone[i] = 0; break; } ++i; }
         }
         std::deque<Rec> keep;
         i = 0;

@@ -529,17 +529,23 @@ def _add_upstream_supplementaries(sam, every, gap_lo, gap_hi, seed):
     return len(extra)
 
 
+@pytest.mark.parametrize("gap", [(10, 120), (0, 4)], ids=["gap10_120", "gap0_4"])
 @pytest.mark.parametrize("opts", [[], ["-l", "{bed}"], ["-B", "-C", "50"]], ids=["plain", "bed", "B_C50"])
-def test_supplementary_upstream_of_a_pair_across_window_cuts(tmp_path, oracle_bin, product_bin, opts):
+def test_supplementary_upstream_of_a_pair_across_window_cuts(tmp_path, oracle_bin, product_bin, opts, gap):
     """A record kept staged only for its mate's sake (PumpConfig::keep_mates) must not look like the holder of the template's overlap-hash
     entry in the next window when the reference freed it long ago: bam_plp_next frees a node once a read beyond its end was pushed, and
     overlap_remove deletes the entry BY NAME.  Three records of one template -- a supplementary alignment upstream of an overlapping
     primary pair -- with a window cut between them: the engine paired the supplementary with the first mate and left the real pair
     unresolved (found by scripts/hunt5.py on the CPU emulation, round 5).  Where the host knows who is pushed it drops the freed record at
-    the cut; where it does not (-l, -C ...) it carries the records in between along and the device's replay decides."""
+    the cut; where it does not (-l, -C ...) it carries the records in between along and the device's replay decides.
+    gap0_4: the supplementary ends right in front of the first primary and no read starts in between, so it is STILL in the buffer when
+    that primary is pushed: the primary finds its entry, deletes it, and the pair is never resolved.  "Freed before its mate" has to mean
+    before the NEXT record of its template; a record whose span ends at a cut stays while no pushed read has started beyond its end; and the
+    records of a template with more than two records all stay while one of them does -- the engine dropped the supplementary at a later
+    cut and let the primaries pair up in the replay (found by scripts/hunt6.py seed 29 on the CPU emulation, round 5)."""
     from bamio import sam_to_bam
     sam, fa = write_synth_sam(str(tmp_path), n_ref=6000, depth=12, read_len=200, seed=613, paired=True)      # insert ~ 300: every pair overlaps
-    assert _add_upstream_supplementaries(sam, 2, 10, 120, 5) > 40
+    assert _add_upstream_supplementaries(sam, 2, gap[0], gap[1], 5) > 40
     bed = str(tmp_path / "r.bed")
     open(bed, "w").write("chrS\t0\t2500\nchrS\t2600\t5000\n")
     bam = sam_to_bam(sam, str(tmp_path / "s.bam"), level=1, block=3000)
@@ -551,3 +557,5 @@ def test_supplementary_upstream_of_a_pair_across_window_cuts(tmp_path, oracle_bi
             got = subprocess.run([product_bin] + args + [inp], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, STA_WINDOW_READS=wr))
             assert got.returncode == 0, got.stderr.decode()[-500:]
             assert got.stdout == want, (opts, wr, os.path.basename(inp))
+    got = subprocess.run([product_bin] + args + [sam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, STA_WINDOW_READS="5", STA_IO_LANE="rec"))
+    assert got.returncode == 0 and got.stdout == want, (opts, "record-at-a-time lane")

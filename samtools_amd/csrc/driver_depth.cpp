@@ -180,6 +180,11 @@ struct DRunner {
     int run()
     {
         PumpConfig pc; pc.window_cols = window_cols; pc.max_reads = max_reads; pc.use_endpos = true; pc.nref_limit = h->nref(); pc.device_pools = true; pc.inflate_device = getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0;
+        // -s: the name hash of bam2depth.c:598-623 is replayed per window from the staged records, and whether a record inserts its name or
+        // finds it depends on every earlier record of its template (three records of one template: the third inserts because the second
+        // consumed the first's entry).  A record that has ended stays staged while its mate does, as for mpileup's overlap pass
+        // (found by scripts/hunt6.py seed 47 with 5-read windows, round 5).
+        pc.keep_mates = p.remove_overlaps != 0; pc.mates_proper_only = false;
         const char *lane = getenv("STA_IO_LANE");
         std::unique_ptr<WindowSource> src;
         if (lane && !strcmp(lane, "rec")) src.reset(new Pump(readers, pc));          // record-at-a-time lane

@@ -671,7 +671,8 @@ void ChunkPump::drop(size_t fi, const std::vector<char> &dropped)
 void ChunkPump::retire(int64_t ce)
 {
     struct Stay { int64_t pos; const char *qname; };
-    auto paired_ok = [](unsigned flag) { return (flag & 1) && (flag & 2) && !(flag & 8); };
+    const bool proper_only = cfg_.mates_proper_only;
+    auto paired_ok = [proper_only](unsigned flag) { return (flag & 1) && ((flag & 2) || !proper_only) && !(flag & 8); };
     for (auto &f : f_) {
         auto is_dropped = [&](size_t staged_index) { return staged_index < f.dropped.size() && f.dropped[staged_index]; };
         // pass 1: who stays because its span reaches beyond ce (position sorted: carried reads first, then the new ones)

@@ -141,9 +141,9 @@ void Pump::retire(int64_t ce)
     for (auto &c : carry_) {
         std::vector<const Rec *> stay;
         if (cfg_.keep_mates)
-            for (auto &r : c) if (span_end(r) > ce && (r.flag & 1) && (r.flag & 2) && !(r.flag & 8)) stay.push_back(&r);
+            for (auto &r : c) if (span_end(r) > ce && (r.flag & 1) && ((r.flag & 2) || !cfg_.mates_proper_only) && !(r.flag & 8)) stay.push_back(&r);
         auto mate_stays = [&](const Rec &r) {
-            if (!(r.flag & 1) || !(r.flag & 2) || (r.flag & 8) || r.mtid != r.tid) return false;
+            if (!(r.flag & 1) || (!(r.flag & 2) && cfg_.mates_proper_only) || (r.flag & 8) || r.mtid != r.tid) return false;
             auto lo = std::lower_bound(stay.begin(), stay.end(), r.mpos, [](const Rec *s, int64_t p) { return s->pos < p; });   // carry is position sorted
             for (; lo != stay.end() && (*lo)->pos == r.mpos; ++lo) if (*lo != &r && (*lo)->qname == r.qname) return true;
             return false;

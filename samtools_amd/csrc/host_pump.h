@@ -28,6 +28,8 @@ struct PumpConfig {
     // the later mate beyond the earlier mate's end (the deletion branch of tweak_overlap_quality), and those stay visible
     // after the earlier mate has left the pileup.
     bool keep_mates = false;
+    // ... of PROPER pairs only (overlap_push's condition, mpileup); depth -s pairs up any paired read with a mapped mate (bam2depth.c:598-623)
+    bool mates_proper_only = true;
     // staging options of fill_staged(): -G read groups to mark STA_AUX_SKIP, --output-extra columns formatted on the host
     const std::set<std::string> *rg_excl = nullptr;
     bool xs_rnext = false; int xs_n_tags = 0; char xs_empty = '*'; bool xs_mods = false;

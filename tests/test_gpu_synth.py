@@ -559,3 +559,27 @@ def test_supplementary_upstream_of_a_pair_across_window_cuts(tmp_path, oracle_bi
             assert got.stdout == want, (opts, wr, os.path.basename(inp))
     got = subprocess.run([product_bin] + args + [sam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, STA_WINDOW_READS="5", STA_IO_LANE="rec"))
     assert got.returncode == 0 and got.stdout == want, (opts, "record-at-a-time lane")
+
+
+@pytest.mark.parametrize("gap", [(10, 120), (0, 4)], ids=["gap10_120", "gap0_4"])
+def test_depth_s_with_three_records_of_a_template_across_window_cuts(tmp_path, oracle_bin, product_bin, gap):
+    """depth -s (bam2depth.c:598-623): the first-seen record of a template puts its name and end into a hash, the next one finds it, is
+    clipped below that end and takes the entry out -- so a THIRD record inserts again.  The engine replays the hash per window from the
+    staged records: with a supplementary alignment upstream of an overlapping pair and a cut behind it, the first primary looked like the
+    first-seen record and the second was clipped, where the reference had let the first primary consume the supplementary's entry and left
+    the second alone (found by scripts/hunt6.py seed 47 with 5-read windows, round 5).  A record that has ended now stays staged while its
+    mate does (PumpConfig::keep_mates for depth -s, any paired read with a mapped mate)."""
+    from bamio import sam_to_bam
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=6000, depth=12, read_len=200, seed=615, paired=True)      # insert ~ 300: every pair overlaps
+    assert _add_upstream_supplementaries(sam, 2, gap[0], gap[1], 6) > 40
+    bam = sam_to_bam(sam, str(tmp_path / "s.bam"), level=1, block=3000)
+    for args in (["depth", "-s"], ["depth", "-s", "-J", "-aa", "-Q", "3"]):
+        want = subprocess.run([oracle_bin] + args + [sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        plain = subprocess.run([oracle_bin] + [a for a in args if a != "-s"] + [sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        assert want.count(b"\n") > 4000 and want != plain
+        for wr in ("2", "3", "5", "8", "13"):
+            for inp, lane in ((sam, "chunk"), (bam, "chunk"), (sam, "rec")):
+                got = subprocess.run([product_bin] + args + [inp], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, STA_WINDOW_READS=wr, STA_IO_LANE=lane))
+                assert got.returncode == 0, got.stderr.decode()[-500:]
+                assert got.stdout == want, (args, wr, os.path.basename(inp), lane)
+

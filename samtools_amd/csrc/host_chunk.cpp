@@ -701,7 +701,7 @@ void ChunkPump::retire(int64_t ce)
             for (auto &q : f.carry) {
                 if ((const void *)&q == self) { behind = true; continue; }
                 if (!behind) continue;
-                if (q.pos >= mpos) return false;
+                if (q.pos > mpos) return false;       // (a record AT the mate position in front of the mate in the file frees it too)
                 if (!cfg_.surely_pushed(q)) continue;
                 if (!strcmp(q.qname.c_str(), qname)) return false;
                 if (q.pos > end) return true;
@@ -713,7 +713,7 @@ void ChunkPump::retire(int64_t ce)
                     const size_t k = (size_t)i;
                     if ((const void *)g.c.get() == self && i == self_i) { behind = true; continue; }
                     if (!behind) continue;
-                    if (g.c->pos[k] >= mpos) return false;
+                    if (g.c->pos[k] > mpos) return false;
                     if (is_dropped(sj)) continue;
                     probe.tid = g.c->tid[k]; probe.pos = g.c->pos[k]; probe.flag = g.c->flag[k]; probe.mapq = g.c->mapq[k];
                     if (!cfg_.surely_pushed(probe)) continue;
@@ -735,7 +735,7 @@ void ChunkPump::retire(int64_t ce)
         };
         // (by position, or as another record of the template: one that starts inside the kept record's span is no context record by position)
         auto in_ctx = [&](int64_t pos, const char *qname) {
-            for (auto &iv : ctx) if (pos < iv.mpos && (pos > iv.end || (pos >= iv.pos && !strcmp(iv.qname.c_str(), qname)))) return true;
+            for (auto &iv : ctx) if (pos <= iv.mpos && (pos > iv.end || (pos >= iv.pos && !strcmp(iv.qname.c_str(), qname)))) return true;
             return false;
         };
         // (1) A record whose span ends at the cut is still in the reference's buffer while no pushed read has started beyond its end

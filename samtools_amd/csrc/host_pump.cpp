@@ -164,7 +164,7 @@ void Pump::retire(int64_t ce)
             for (auto &q : c) {
                 if (&q == &r) { behind = true; continue; }
                 if (!behind) continue;
-                if (q.pos >= r.mpos) break;
+                if (q.pos > r.mpos) break;            // (a record AT the mate position in front of the mate in the file frees it too)
                 if (!cfg_.surely_pushed(q)) continue;
                 if (q.qname == r.qname) return false;
                 if (q.pos > e) return true;
@@ -225,10 +225,10 @@ void Pump::retire(int64_t ce)
         }
         if (!ctx.empty()) {
             i = 0;
-            for (auto &r : c) { if (gone[i]) for (auto &iv : ctx) if (r.pos > iv.end && r.pos < iv.mpos) { gone[i] = 0; break; } ++i; }
+            for (auto &r : c) { if (gone[i]) for (auto &iv : ctx) if (r.pos > iv.end && r.pos <= iv.mpos) { gone[i] = 0; break; } ++i; }
             // ... and the other records of its template (one that starts inside its span is no context record by position)
             i = 0;
-            for (auto &r : c) { if (gone[i]) for (auto &iv : ctx) if (r.pos >= iv.pos && r.pos < iv.mpos && r.qname == *iv.qname) { gone[i] = 0; break; } ++i; }
+            for (auto &r : c) { if (gone[i]) for (auto &iv : ctx) if (r.pos >= iv.pos && r.pos <= iv.mpos && r.qname == *iv.qname) { gone[i] = 0; break; } ++i; }
         }
         std::deque<Rec> keep;
         i = 0;

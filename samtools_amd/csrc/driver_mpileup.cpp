@@ -297,6 +297,7 @@ struct Runner {
             // device's view -- BED, -C, contig length -- answers "not sure" and the lookahead just runs on)
             const sta_mplp_params pp = conf.p;
             const bool unsure = conf.bed || conf.has_rg_excl || pp.capQ_thres > 0 || pp.min_qlen > 0;
+            pc.pushed_unknown = unsure;
             pc.surely_pushed = [this, pp, unsure](const Rec &r) {
                 if (unsure || (r.flag & 4)) return false;
                 if (r.tid != loaded_ref_tid && conf.fai) return false;

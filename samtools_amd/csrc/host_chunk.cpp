@@ -756,12 +756,12 @@ void ChunkPump::retire(int64_t ce)
                     --sj;
                     const size_t k = (size_t)i;
                     if (is_dropped(sj) || g->c->pos[k] >= ce) continue;
-                    if (cfg_.surely_pushed) { probe.tid = g->c->tid[k]; probe.pos = g->c->pos[k]; probe.flag = g->c->flag[k]; probe.mapq = g->c->mapq[k]; if (!cfg_.surely_pushed(probe)) continue; }
+                    if (cfg_.surely_pushed && !cfg_.pushed_unknown) { probe.tid = g->c->tid[k]; probe.pos = g->c->pos[k]; probe.flag = g->c->flag[k]; probe.mapq = g->c->mapq[k]; if (!cfg_.surely_pushed(probe)) continue; }
                     max_start = g->c->pos[k]; found = true; break;
                 }
             if (!found)
                 for (auto r = f.carry.rbegin(); r != f.carry.rend(); ++r)
-                    if (r->pos < ce && (!cfg_.surely_pushed || cfg_.surely_pushed(*r))) { max_start = r->pos; break; }
+                    if (r->pos < ce && (!cfg_.surely_pushed || cfg_.pushed_unknown || cfg_.surely_pushed(*r))) { max_start = r->pos; break; }
         }
         const bool alive_rule = cfg_.keep_mates && max_start != INT64_MIN;
         std::vector<const char *> multi;          // names of secondary / supplementary records: templates with more than two records

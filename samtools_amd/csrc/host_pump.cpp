@@ -190,7 +190,7 @@ void Pump::retire(int64_t ce)
             // would keep the window loop going for ever.)
             int64_t max_start = INT64_MIN;
             const bool more = !c.empty() && next_pos(c.front().tid) != INT64_MAX;
-            if (more) for (auto &r : c) if (r.pos < ce && (!cfg_.surely_pushed || cfg_.surely_pushed(r))) max_start = std::max(max_start, r.pos);
+            if (more) for (auto &r : c) if (r.pos < ce && (!cfg_.surely_pushed || cfg_.pushed_unknown || cfg_.surely_pushed(r))) max_start = std::max(max_start, r.pos);
             i = 0;
             if (more && max_start != INT64_MIN) for (auto &r : c) { if (gone[i] && span_end(r) >= max_start) gone[i] = 0; ++i; }
             // (2) Templates with more than two records (one of them secondary / supplementary): what a record that stays finds in the hash

@@ -23,6 +23,9 @@ struct PumpConfig {
     // they can still be the mate of a staged read (start < largest staged end).  They add no columns to this window
     // and simply stay carried for the next one.  Empty function = no lookahead (depth, coverage).
     std::function<bool(const Rec &)> surely_pushed;
+    // ... and it answers "not sure" for EVERY record (-l, -G, -C, --min-read-len): where a rule needs "no pushed read has started beyond
+    // X" the host then takes every read for pushed (the side that keeps more staged; the device's replay sees their RI_PUSHED)
+    bool pushed_unknown = false;
     // Mate overlaps again: every window re-derives the resolved qualities from the records as read, so a read that can no
     // longer touch a column must still be staged for as long as its mate can -- HTSlib's resolution may rewrite bases of
     // the later mate beyond the earlier mate's end (the deletion branch of tweak_overlap_quality), and those stay visible

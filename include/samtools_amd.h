@@ -153,6 +153,18 @@ typedef struct sta_reads {
     const struct sta_raw_piece *raw_pieces;
     const uint32_t *raw_rec_off;
     int32_t raw_verify;          /* != 0: the host pools ARE fully written as well; the engine compares its device-built pools with them and fails on a difference (tests) */
+    /* optional: what every read found in the reference's read-name hash, worked out by the caller in FILE ORDER over the whole input.
+     * Both hashes are sequential state (an entry put by a record a million columns upstream decides what a later record of the
+     * template finds), so a caller that cuts the input into windows keeps them itself and hands over the outcome:
+     *   olap_clip[i]  depth -s (bam2depth.c:598-623): absolute column below which read i is not counted -- the end position the
+     *                 first-seen record of its template left in the hash -- or 0.  Used by sta_depth_plan when remove_overlaps is set.
+     *   olap_mate[i]  mpileup with overlap detection (HTSlib overlap_push, enabled at bam_plcmd.c:586): index, in this file's reads,
+     *                 of the record whose hash entry read i found at its push -- the pair tweak_overlap_quality(olap_mate[i], i)
+     *                 resolves -- or -1.  Used by the plans that resolve overlaps (STA_MPLP_SMART_OVERLAPS, sta_plp_plan).
+     * NULL (the default): the engine replays the hash itself from the names of the staged reads, which is exact when the window
+     * holds every record of the templates it touches (a whole contig staged at once, as bench.py does), and not otherwise. */
+    const int64_t *olap_clip;
+    const int32_t *olap_mate;
 } sta_reads;
 
 typedef struct sta_raw_piece { const uint8_t *bytes; uint64_t n_bytes; } sta_raw_piece;
@@ -272,6 +284,15 @@ int sta_fetch_col_offsets(sta_engine *e, uint64_t *host_offs, uint64_t n);
 /* per-read state after a plan: info words (bit 1 = read is in the pileup) and the working quality
  * pool (mate-overlap / BAQ adjusted), laid out like sta_reads.qual.  Either pointer may be NULL. */
 int sta_fetch_read_state(sta_engine *e, int32_t file, uint32_t *host_info, uint8_t *host_qual);
+/* Overlap detection where only the device knows who reaches bam_plp_push (-C: sam_cap_mapq reads the BAQ-adjusted qualities) or
+ * who bam_plp_push turns away (a -d cap that triggers): a caller that keeps the overlap hash itself (sta_reads.olap_mate) cannot
+ * fill olap_mate in before the plan.  With a resolver installed, sta_mpileup_plan / sta_plp_plan stop in front of the overlap pass,
+ * hand the resolver every file's read states (bit 0 = reached bam_plp_push, bit 1 = in the pileup; a pushed read with a reference
+ * span that is not in the pileup was turned away by the cap) and take olap_mate from it (mate_out[i] as in sta_reads.olap_mate; the
+ * resolver returns 0, anything else fails the plan).  It is called on the thread that runs the plan; one host round trip per
+ * window, so callers install it only for such windows.  fn == NULL removes it. */
+typedef int (*sta_mate_resolver)(void *user, int32_t file, const uint32_t *read_state, int64_t n_reads, int32_t *mate_out);
+int sta_set_mate_resolver(sta_engine *e, sta_mate_resolver fn, void *user);
 /* mate-overlap visibility records of the last plan (one per read; fix_y[i] = -1: none): the query index whose quality a
  * deletion / ref-skip placeholder of read i shows, that quality before the pair was resolved, and the mate's read index.
  * HTSlib resolves a pair when the second mate is pushed, so columns handed out earlier still see the old value

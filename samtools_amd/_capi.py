@@ -52,6 +52,8 @@ class Reads(C.Structure):
         ("n_mod_entries", C.c_uint64), ("n_mod_bytes", C.c_uint64),
         # device staging out of raw BAM records (host drivers only; zero here: everything staged by the caller)
         ("raw_first", C.c_int64), ("n_raw_pieces", C.c_int32), ("raw_pieces", C.c_void_p), ("raw_rec_off", C.c_void_p), ("raw_verify", C.c_int32),
+        # what every read found in the reference's name hash, worked out by the caller in file order (NULL: the engine replays the hash from the staged names)
+        ("olap_clip", C.c_void_p), ("olap_mate", C.c_void_p),
     ]
 
 

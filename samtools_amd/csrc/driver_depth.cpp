@@ -12,6 +12,7 @@
 #include "host_bgzf.h"
 #include "driver_pipeline.h"
 #include "driver_shard.h"
+#include "driver_globalopts.h"
 #include <cstdlib>
 #include <atomic>
 #include <getopt.h>
@@ -180,11 +181,13 @@ struct DRunner {
     int run()
     {
         PumpConfig pc; pc.window_cols = window_cols; pc.max_reads = max_reads; pc.use_endpos = true; pc.nref_limit = h->nref(); pc.device_pools = true; pc.inflate_device = getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0;
-        // -s: the name hash of bam2depth.c:598-623 is replayed per window from the staged records, and whether a record inserts its name or
-        // finds it depends on every earlier record of its template (three records of one template: the third inserts because the second
-        // consumed the first's entry).  A record that has ended stays staged while its mate does, as for mpileup's overlap pass
-        // (found by scripts/hunt6.py seed 47 with 5-read windows, round 5).
-        pc.keep_mates = p.remove_overlaps != 0; pc.mates_proper_only = false;
+        // -s: the name hash of bam2depth.c:598-623 is sequential over the whole file; the input lane keeps it itself, in file order, and
+        // stages every record's clip column (host_names.h; sta_reads.olap_clip) -- no window depends on records it does not stage
+        if (p.remove_overlaps) {
+            pc.tpl = PumpConfig::TPL_DEPTH;
+            pc.depth_filter.flag = p.flag; pc.depth_filter.incl_flag = p.incl_flag; pc.depth_filter.require_flag = p.require_flag;
+            pc.depth_filter.min_mqual = p.min_mqual; pc.depth_filter.min_len = p.min_len;
+        }
         const char *lane = getenv("STA_IO_LANE");
         std::unique_ptr<WindowSource> src;
         if (lane && !strcmp(lane, "rec")) src.reset(new Pump(readers, pc));          // record-at-a-time lane
@@ -249,11 +252,13 @@ extern "C" int sta_main_depth(int argc, char **argv)
     if (const char *e = getenv("STA_WINDOW_COLS")) { run.window_cols = std::max<long long>(1, atoll(e)); run.adaptive_windows = false; }
     if (const char *e = getenv("STA_WINDOW_READS")) run.max_reads = std::max<long long>(1, atoll(e));
 
+    GlobalArgs ga;
     static const struct option lopts[] = {
+        STA_GLOBAL_OPTIONS('-', 0, '-', '-', 0, '@'),          // bam2depth.c:765: --input-fmt-option, --reference, --threads / -@, --write-index, --verbosity
         { "min-MQ", required_argument, NULL, 'Q' }, { "min-mq", required_argument, NULL, 'Q' },
         { "min-BQ", required_argument, NULL, 'q' }, { "min-bq", required_argument, NULL, 'q' },
         { "excl-flags", required_argument, NULL, 'G' }, { "incl-flags", required_argument, NULL, 1 },
-        { "require-flags", required_argument, NULL, 2 }, { "threads", required_argument, NULL, '@' },
+        { "require-flags", required_argument, NULL, 2 },
         { NULL, 0, NULL, 0 } };
     optind = 0;          // (glibc: 0 = full re-initialisation; with 1 a second in-process call resumes at a stale pointer into the PREVIOUS argv)
     int c, tmp;
@@ -265,7 +270,7 @@ extern "C" int sta_main_depth(int argc, char **argv)
             if (!run.bed) { fprintf(stderr, "samtools depth: Could not read file \"%s\"\n", optarg); return 1; }
             break;
         case 'f': file_list = optarg; break;
-        case 'd': case 'm': case '@': break;
+        case 'd': case 'm': break;
         case 'g': tmp = str2flag(optarg); if (tmp < 0) { fprintf(stderr, "samtools depth: Unknown flag '%s'\n", optarg); return 1; } opt.flag &= ~tmp; break;
         case 'G': tmp = str2flag(optarg); if (tmp < 0) { fprintf(stderr, "samtools depth: Unknown flag '%s'\n", optarg); return 1; } opt.flag |= tmp; break;
         case 1: tmp = str2flag(optarg); if (tmp < 0) { fprintf(stderr, "samtools depth: Unknown flag '%s'\n", optarg); return 1; } opt.incl_flag |= tmp; break;
@@ -279,7 +284,11 @@ extern "C" int sta_main_depth(int argc, char **argv)
         case 'r': reg = optarg; break;
         case 's': opt.remove_overlaps = 1; break;
         case 'X': has_index_file = true; break;          // the second half of the file arguments names the indexes (bam2depth.c:873-911)
-        default: usage_exit(stderr); return 1;
+        default:
+            // bam2depth.c:877: the global options (-@ / --threads: decompression threads of HTSlib's reader; this engine sizes its own
+            // decode threads, STA_IO_THREADS; --reference: CRAM only)
+            if (c != '?' && parse_global_opt(c, optarg, lopts, &ga) == 0) break;
+            usage_exit(stderr); return 1;
         }
     }
     if (argc < optind + 1 && file_list.empty()) { usage_exit(argc == optind ? stdout : stderr); return argc == optind ? 0 : 1; }
@@ -311,7 +320,8 @@ extern "C" int sta_main_depth(int argc, char **argv)
             if (i == 0) { run.has_reg = true; run.tid0 = t; run.beg0 = b; run.end0 = e; }
         }
     }
-    seek_readers_by_index(run.readers, fns, *run.h, run.has_reg, run.tid0, run.beg0, run.end0, (int64_t)1 << 20, has_index_file ? &idx_fns : nullptr);      // region / sharded runs start at their first column
+    seek_readers_by_index(run.readers, fns, *run.h, run.has_reg, run.tid0, run.beg0, run.end0, (int64_t)1 << 20, has_index_file ? &idx_fns : nullptr,
+                          !opt.remove_overlaps);      // region / sharded runs start at their first column (-s: a sharded run reads from where the unsharded one starts)
     if (!out_file.empty() && run.dev_cap) {
         // device capture keeps the window text on the device for the caller: a command that names its own output file would be left with
         // an empty file and exit status 0 -- refused; samtools_amd/shard.py strips -o before it captures

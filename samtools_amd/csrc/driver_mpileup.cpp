@@ -13,6 +13,7 @@
 #include "host_bgzf.h"
 #include "driver_pipeline.h"
 #include "driver_shard.h"
+#include "driver_globalopts.h"
 #include <atomic>
 #include <getopt.h>
 #include <ctime>
@@ -83,6 +84,7 @@ struct Runner {
     bool shard_done = false;            // the block's last column has been passed: the rest of the input is not read
     int64_t win_cols = 0; bool adaptive_windows = true;  // columns of the next data window (widened for sparse input unless STA_WINDOW_COLS fixes it)
     Shard shard;                                      // STA_SHARD=rank/world: this rank's block of the columns (driver_shard.h)
+    WindowSource *src = nullptr;                      // the input lane (device_stage's resolver asks it; set by run())
     std::vector<int64_t> lin0;                        // linear coordinate of every contig's first column (no region)
 
     Runner(Conf &c, DevEngines &d) : conf(c), devs(d) {}
@@ -122,7 +124,13 @@ struct Runner {
         if (sta_stage_window(eng, &w) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
         sta_mplp_params p = conf.p;
         p.all = j.all_mode;
-        if (sta_mpileup_plan(eng, &p, &j.info) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
+        // a window whose overlap pairs wait for the device's verdict on its reads (-C, a -d cap that can trigger): the plan calls back into
+        // the input lane -- whose thread is waiting for this window (lockstep) -- in front of its overlap pass
+        if (j.resolve_mates && j.have_reads && src)
+            sta_set_mate_resolver(eng, [](void *user, int32_t file, const uint32_t *state, int64_t n, int32_t *mate_out) { ((WindowSource *)user)->pair_from_info((size_t)file, state, n, mate_out); return 0; }, src);
+        const int plan_rc = sta_mpileup_plan(eng, &p, &j.info);
+        sta_set_mate_resolver(eng, nullptr, nullptr);
+        if (plan_rc != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
         j.out_bytes = 0;
         j.read_info.clear();
         if (j.info.n_maxcnt_dropped && j.have_reads && !j.lockstep) {
@@ -240,7 +248,15 @@ struct Runner {
             if (ce > cursor) {
                 j->tid = tid; j->cb = cursor; j->ce = ce; j->have_reads = true; j->hold = false;
                 // the next window depends on this one's result only if the -d cap can drop reads here (they leave the pump)
-                const bool lockstep = cap_may_trigger(j->staged, conf.p.max_depth, pump);
+                bool lockstep = cap_may_trigger(j->staged, conf.p.max_depth, pump);
+                // the overlap hash: who reaches bam_plp_push is the host's to say -- unless the -d cap can turn reads away here, or -C drops /
+                // re-scores reads on the device; then the device thread asks the lane with the window's read states (sta_set_mate_resolver),
+                // and the producer waits for the window
+                j->resolve_mates = false;
+                if (conf.p.flag & STA_MPLP_SMART_OVERLAPS) {
+                    if (lockstep || (conf.fai && conf.p.capQ_thres > 10)) { j->resolve_mates = true; lockstep = true; }
+                    else pump.pair_staged(j->staged);
+                }
                 if (lockstep && shard.on) {
                     pipe->release(j);
                     fprintf(stderr, "samtools mpileup: the -d depth cap can trigger near %s:%lld, which couples this block to its predecessors; run unsharded or raise -d\n",
@@ -292,18 +308,21 @@ struct Runner {
     {
         PumpConfig pc; pc.window_cols = conf.window_cols; pc.max_reads = conf.max_reads; pc.use_endpos = false; pc.nref_limit = h->nref(); pc.device_pools = true; pc.inflate_device = getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0;
         if (conf.p.flag & STA_MPLP_SMART_OVERLAPS) {
-            pc.keep_mates = true;
-            // host-side "this record certainly reaches bam_plp_push" (subset of k_prep_reads' filters: whatever needs the
-            // device's view -- BED, -C, contig length -- answers "not sure" and the lookahead just runs on)
+            // HTSlib's overlap hash is sequential over the file: the input lane keeps it itself (host_names.h) and stages, for every
+            // record, the staged index of the record whose entry it found (sta_reads.olap_mate).  `pushed` = mplp_func's verdict
+            // (bam_plcmd.c:400-461), bit for bit what k_prep_reads computes on the device; what only the device can know -- -C (sam_cap_mapq
+            // reads the BAQ-adjusted qualities), a -d cap that triggers -- goes through the engine's resolver instead (device_stage).
+            pc.tpl = PumpConfig::TPL_MPLP;
+            pc.pushed_on_device = conf.fai && conf.p.capQ_thres > 10;
             const sta_mplp_params pp = conf.p;
-            const bool unsure = conf.bed || conf.has_rg_excl || pp.capQ_thres > 0 || pp.min_qlen > 0;
-            pc.pushed_unknown = unsure;
-            pc.surely_pushed = [this, pp, unsure](const Rec &r) {
-                if (unsure || (r.flag & 4)) return false;
-                if (r.tid != loaded_ref_tid && conf.fai) return false;
-                if (r.pos >= loaded_ref_len) return false;
+            pc.pushed = [this, pp](const Rec &r) {
+                if (r.flag & 4) return false;
                 if (pp.rflag_require && !(pp.rflag_require & r.flag)) return false;
                 if (pp.rflag_filter && (pp.rflag_filter & r.flag)) return false;
+                if (conf.bed && pp.all == 0 && !conf.bed->overlap(h->names[(size_t)r.tid], r.pos, r.pos + (r.rlen > 0 ? r.rlen : 1))) return false;
+                if (conf.has_rg_excl && !r.rg.empty() && conf.rg_excl.count(r.rg)) return false;
+                host_ref(r.tid);
+                if (r.pos >= loaded_ref_len) return false;             // "Skipping because ... is outside of ..." (INT64_MAX: the contig is not in the FASTA)
                 if ((int)r.mapq < pp.min_mq) return false;
                 if ((pp.flag & STA_MPLP_NO_ORPHAN) && (r.flag & 1) && !(r.flag & 2)) return false;
                 return true;
@@ -320,9 +339,16 @@ struct Runner {
         if (chunked) src.reset(new ChunkPump(readers, pc, io_threads_per_input((int)readers.size())));
         else src.reset(new Pump(readers, pc));
         WindowSource &pump = *src;
+        this->src = src.get();
         const int all = conf.p.all;
         const int mode = all >= 2 ? 2 : all;
         shard = Shard::from_env();
+        if (shard.on && (conf.p.flag & STA_MPLP_SMART_OVERLAPS) && conf.fai && conf.p.capQ_thres > 10) {
+            // who reaches the overlap hash is then the device's to say (sam_cap_mapq on BAQ-adjusted qualities), window after window from
+            // the first record on: state that crosses blocks is refused, not approximated
+            fprintf(stderr, "samtools mpileup: a sharded run (STA_SHARD) supports no -C together with overlap detection: the overlap hash then depends on every earlier block; add -x or run unsharded\n");
+            return 1;
+        }
         if (shard.on) {
             if (mode == 1) { fprintf(stderr, "samtools mpileup: a sharded run (STA_SHARD) supports no single -a: whether a contig is printed depends on every block; use -aa or no -a\n"); return 1; }
             lin0.assign((size_t)h->nref() + 1, 0);
@@ -384,7 +410,9 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     if (const char *e = getenv("STA_WINDOW_COLS")) conf.window_cols = std::max<long long>(1, atoll(e));
     if (const char *e = getenv("STA_WINDOW_READS")) conf.max_reads = std::max<long long>(1, atoll(e));
 
+    GlobalArgs ga;
     static const struct option lopts[] = {
+        STA_GLOBAL_OPTIONS('-', 0, '-', '-', 0, '-'),          // bam_plcmd.c:1098: --input-fmt-option, --reference, --write-index, --verbosity
         { "rf", required_argument, NULL, 1 }, { "ff", required_argument, NULL, 2 },
         { "incl-flags", required_argument, NULL, 1 }, { "excl-flags", required_argument, NULL, 2 },
         { "output", required_argument, NULL, 3 },
@@ -395,7 +423,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
         { "adjust-MQ", required_argument, NULL, 'C' }, { "adjust-mq", required_argument, NULL, 'C' },
         { "max-depth", required_argument, NULL, 'd' },
         { "redo-BAQ", no_argument, NULL, 'E' }, { "redo-baq", no_argument, NULL, 'E' },
-        { "fasta-ref", required_argument, NULL, 'f' }, { "reference", required_argument, NULL, 'f' },
+        { "fasta-ref", required_argument, NULL, 'f' },
         { "exclude-RG", required_argument, NULL, 'G' }, { "exclude-rg", required_argument, NULL, 'G' },
         { "positions", required_argument, NULL, 'l' }, { "region", required_argument, NULL, 'r' },
         { "ignore-RG", no_argument, NULL, 'R' }, { "ignore-rg", no_argument, NULL, 'R' },
@@ -485,8 +513,17 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
             break;
         }
         case 'a': mp.all++; break;
-        default: usage(stderr); return 1;
+        default:
+            if (c != '?' && parse_global_opt(c, optarg, lopts, &ga) == 0) break;
+            usage(stderr);
+            return 1;
         }
+    }
+    if (!conf.fai && !ga.reference.empty()) {
+        // bam_plcmd.c:1223-1227: --reference names the FASTA when -f did not
+        conf.fai = Fasta::load(ga.reference);
+        if (!conf.fai) { fprintf(stderr, "[E::fai_load] failed to load %s\n", ga.reference.c_str()); return 1; }
+        conf.fai_fname = ga.reference; mp.has_fai = 1;
     }
     if (!(mp.flag & STA_MPLP_REALN) && (mp.flag & STA_MPLP_REDO_BAQ)) { fprintf(stderr, "Error: The -B option cannot be combined with -E\n"); return 1; }
     if (use_orphan) mp.flag &= ~STA_MPLP_NO_ORPHAN;

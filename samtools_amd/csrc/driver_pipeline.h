@@ -32,6 +32,7 @@ struct WinJob {
     int all_mode = 0; bool write = true;
     bool lockstep = false;               // the producer waits for this job's result before it stages the next window (-d cap, single -a)
     bool hold = false;                   // the producer will submit this job again (same staged reads): the slot is not recycled
+    bool resolve_mates = false;          // mpileup: the overlap pairs of this window wait for the device's read states (sta_set_mate_resolver; implies lockstep)
     std::vector<StagedFile> staged;
     // set by the device stage
     pvector<char> text; uint64_t out_bytes = 0;

@@ -70,10 +70,14 @@ struct Shard {
 // An index older than its data file is used with HTSlib's warning (round 5; round 4 skipped it).
 inline int seek_readers_by_index(std::vector<std::unique_ptr<AlnReader>> &readers, const std::vector<std::string> &paths, const Header &h,
                                  bool has_reg, int tid0, int64_t beg0, int64_t end0, int64_t margin = (int64_t)1 << 20,
-                                 const std::vector<std::string> *index_paths = nullptr)
+                                 const std::vector<std::string> *index_paths = nullptr, bool seek_to_block = true)
 {
     if (getenv("STA_NO_INDEX")) return 0;
     Shard sh = Shard::from_env();
+    // seek_to_block = false: state that is sequential over the whole input (depth -s: a name hash that never forgets, bam2depth.c:598-623)
+    // -- a rank then reads from where the unsharded run starts (the file's start, or the region's) and passes over what is not its own
+    if (!seek_to_block) sh.on = false;
+    const bool block_seek = sh.on;
     int tid = -1; int64_t pos = 0;
     if (has_reg) { tid = tid0; pos = beg0; }
     if (sh.on) {
@@ -101,7 +105,13 @@ inline int seek_readers_by_index(std::vector<std::unique_ptr<AlnReader>> &reader
         }
         // as HTSlib: a warning, and the index is used (a pair whose time stamps are merely inverted -- copied data -- would otherwise lose
         // its region start; an index of ANOTHER file fails where HTSlib's would: at the block it points into)
-        if (ix->older_than_data()) fprintf(stderr, "[W::samtools_amd] The index file is older than the data file: %s\n", paths[i].c_str());
+        if (ix->older_than_data()) {
+            fprintf(stderr, "[W::samtools_amd] The index file is older than the data file: %s\n", paths[i].c_str());
+            // ... for a region, where the reference consults the index too.  A block start of a sharded run is this engine's own use of
+            // the index: a stale one could start a rank at a wrong offset and silently lose or repeat columns, so such a rank reads the
+            // file from its start instead
+            if (block_seek && !has_reg) continue;
+        }
         const uint64_t v = ix->start_offset(tid, pos);
         if (readers[i]->seek_voffset(v)) ++n;
     }

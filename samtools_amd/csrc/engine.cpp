@@ -38,11 +38,11 @@ struct FileBufs {
     // device staging (sta_reads.raw_*): the uploaded BAM bytes, the records' offsets in them, the pools built for a verify run
     DevBuf raw, raw_off, raw_vfy;
     // workspace
-    DevBuf qual_work, end, maxend, info, clip, chain, fix_y, fix_mate, fix_q, slist;
+    DevBuf qual_work, end, maxend, info, clip, chain, fix_y, fix_mate, fix_q, slist, clip_in, mate;
     void release()
     {
         DevBuf *all[] = { &pos, &flag, &mapq, &aux, &lq, &cig_off, &base_off8, &mtid, &mpos, &isize, &name_off, &cigar,
-                          &seq, &qual, &bq, &names, &xoff, &xtext, &moff, &mqpos, &mtoff, &mtext, &raw, &raw_off, &raw_vfy, &qual_work, &end, &maxend, &info, &clip, &chain, &fix_y, &fix_mate, &fix_q, &slist };
+                          &seq, &qual, &bq, &names, &xoff, &xtext, &moff, &mqpos, &mtoff, &mtext, &raw, &raw_off, &raw_vfy, &qual_work, &end, &maxend, &info, &clip, &chain, &fix_y, &fix_mate, &fix_q, &slist, &clip_in, &mate };
         for (DevBuf *b : all) b->release();
     }
 };
@@ -70,6 +70,7 @@ struct sta_engine {
     std::vector<FileBufs> fb;
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
+    sta_mate_resolver mate_fn = nullptr; void *mate_user = nullptr;     // sta_set_mate_resolver
     std::vector<char> late_copy;       // mpileup plan, per file: the working quality pool exists only if the window has overlap-eligible reads
     bool gen_xlen_on = false;          // this plan's generic measuring pass filled colinfo / gen_xlen for the emit
     DevBuf files_d, tname_d, bed_d, line_len, colinfo, gen_xlen, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, stage_bad, md_cap, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
@@ -354,6 +355,9 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
             rc |= upload(e, b.mtoff, r.mod_toff, (size_t)r.n_mod_entries + 1, &d.mod_toff, mem);
             rc |= upload(e, b.mtext, r.mod_text, (size_t)r.n_mod_bytes, &d.mod_text, mem);
         }
+        d.clip_in = nullptr; d.mate = nullptr;
+        if (r.olap_clip && n) rc |= upload(e, b.clip_in, r.olap_clip, n, &d.clip_in, mem);
+        if (r.olap_mate && n) rc |= upload(e, b.mate, r.olap_mate, n, &d.mate, mem);
         if (rc) return rc;
         // workspace
         if (b.end.ensure(n * 4 + 16) || b.maxend.ensure(n * 4 + 16) || b.info.ensure(n * 4 + 16) || b.clip.ensure(n * 4 + 16)
@@ -682,11 +686,31 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             sta_launch_maxcnt_detect(s, e->files_h[(size_t)f], p->max_depth, ctr);
         }
     }
+    if (olap && e->mate_fn) {
+        // the caller keeps the overlap hash, and only this plan's kernels know who reached bam_plp_push: one round trip (sta_set_mate_resolver)
+        bool repush = false;
+        for (int f = 0; f < nf; ++f) {
+            StaReadsDev &d = e->files_h[(size_t)f];
+            if (!d.n) continue;
+            std::vector<uint32_t> st((size_t)d.n);
+            std::vector<int32_t> mate((size_t)d.n, -1);
+            HIPCHK(hipMemcpyAsync(st.data(), d.info, (size_t)d.n * 4, hipMemcpyDeviceToHost, s));
+            SYNC_S(s);
+            if (e->mate_fn(e->mate_user, f, st.data(), d.n, mate.data()) != 0) return fail(e, STA_ERR_ARG, "the mate resolver failed");
+            FileBufs &b = e->fb[(size_t)f];
+            if (b.mate.ensure((size_t)d.n * 4 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc failed");
+            HIPCHK(hipMemcpyAsync(b.mate.p, mate.data(), (size_t)d.n * 4, hipMemcpyHostToDevice, s));
+            SYNC_S(s);                                 // (`mate` goes out of scope)
+            d.mate = (const int32_t *)b.mate.p;
+            repush = true;
+        }
+        if (repush) { int rc2 = push_files(e); if (rc2) return rc2; }
+    }
     if (olap) {
         for (int f = 0; f < nf; ++f) {
             StaReadsDev &d = e->files_h[(size_t)f];
             if (!d.n) continue;
-            size_t slots = sta_overlap_table_slots(d.n);
+            size_t slots = d.mate ? 1 : sta_overlap_table_slots(d.n);
             if (e->table.ensure(sta_overlap_table_bytes(slots) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(name table) failed");
             ProfScope ps(e, "overlap");
             sta_launch_overlap_setup(s, d, (StaReadsDev *)e->files_d.p + f, late_copy[(size_t)f] != 0, e->table.p, slots, ctr);
@@ -949,6 +973,13 @@ int sta_fetch_col_offsets(sta_engine *e, uint64_t *host_offs, uint64_t n)
         return STA_OK;
     }
     SYNC_STREAM();
+    return STA_OK;
+}
+
+int sta_set_mate_resolver(sta_engine *e, sta_mate_resolver fn, void *user)
+{
+    if (!e) return STA_ERR_ARG;
+    e->mate_fn = fn; e->mate_user = fn ? user : nullptr;
     return STA_OK;
 }
 
@@ -1460,7 +1491,7 @@ static int depth_text(sta_engine *e, const sta_depth_params *p, char *out, uint6
     if (p->remove_overlaps) {
         for (int f = 0; f < nf; ++f) {
             StaReadsDev &d = e->files_h[(size_t)f];
-            if (!d.n) continue;
+            if (!d.n || d.clip_in) continue;          // (the caller kept the name hash itself: k_prep_reads_depth took its clip columns)
             size_t slots = sta_overlap_table_slots(d.n);
             if (e->table.ensure(sta_overlap_table_bytes(slots) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(name table) failed");
             ProfScope ps(e, "depth_pair");

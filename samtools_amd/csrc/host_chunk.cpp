@@ -27,6 +27,7 @@ void Chunk::append(const Rec &r)
     if (has_bq_pool) { bq.resize(b0 + padded, 64); if (bq_ok) memcpy(&bq[b0], r.bq.data(), (size_t)r.l_qseq); }
     names.insert(names.end(), r.qname.begin(), r.qname.end());
     names.push_back('\0');
+    name_h.push_back(qname_hash64(r.qname.data(), r.qname.size()));
     if (!r.tagtext.empty()) {
         if (tag_off.empty()) { n_tags = (int)r.tagtext.size(); tag_off.push_back(0); }
         for (size_t t = 0; t < r.tagtext.size(); ++t) {
@@ -47,6 +48,7 @@ void Chunk::reset()
     cig_off.clear(); base_off8.clear(); name_off.clear(); cigar.clear(); seq.clear(); qual.clear(); bq.clear(); has_bq_pool = false; names.clear();
     n_tags = 0; tag_off.clear(); tag_text.clear(); tag_has.clear();
     raw.reset(); rec_off.clear(); raw_ok = true;
+    name_h.clear(); t_id.clear(); t_a.clear(); t_b.clear(); t_mode = 0;
 }
 
 void Chunk::close()
@@ -61,6 +63,8 @@ void Chunk::to_rec(int64_t i, Rec &r) const
     r.tid = tid[k]; r.mtid = mtid[k]; r.pos = pos[k]; r.mpos = mpos[k]; r.isize = isize[k];
     r.flag = flag[k]; r.mapq = mapq[k]; r.l_qseq = l_qseq[k]; r.rlen = rlen[k];
     r.qname.assign(names.data() + name_off[k]);
+    r.name_h = name_h[k];
+    if (t_id.size() == pos.size()) { r.id = t_id[k]; if (t_mode == 1) r.clip = t_a[k]; else r.mate_id = t_a[k]; r.mate_end = t_b[k]; }
     r.cigar.assign(cigar.begin() + cig_off[k], cigar.begin() + cig_off[k + 1]);
     const size_t b0 = (size_t)base_off8[k] << 3, l = (size_t)l_qseq[k];
     r.seq.assign(seq.begin() + (long)(b0 / 2), seq.begin() + (long)(b0 / 2 + (l + 1) / 2));
@@ -577,15 +581,29 @@ int64_t ChunkPump::carry_max_end() const
 int64_t ChunkPump::fill_window(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> *staged_out)
 {
     int64_t ce = ce_target;
-    auto take = [](File &f) {
+    const int tpl = cfg_.tpl;
+    auto take = [&](File &f) {
         // append the settled record to the window's slices
         if (!f.fresh.empty() && f.fresh.back().c == f.cur && f.fresh.back().i1 == f.idx) f.fresh.back().i1++;
         else f.fresh.push_back(Range{ f.cur, f.idx, f.idx + 1 });
+        if (tpl) {
+            Chunk &c = *f.cur; const size_t k = (size_t)f.idx;
+            c.tpl_touch(tpl);
+            c.t_id[k] = f.next_id;
+            if (tpl == PumpConfig::TPL_DEPTH) {
+                // bam2depth.c:598-623, in file order: a record that passes the read filters visits the name hash
+                c.t_a[k] = 0;
+                if (cfg_.depth_filter.passes(c.flag[k], c.mapq[k], c.l_qseq[k], c.cigar.data() + c.cig_off[k], c.cig_off[k + 1] - c.cig_off[k]))
+                    c.t_a[k] = f.dclip.visit(c.names.data() + c.name_off[k], c.flag[k], c.tid[k], c.endpos((int64_t)k), c.mtid[k], c.mpos[k]);
+            }
+        }
+        ++f.next_id;
         ++f.idx;
     };
     for (size_t fi = 0; fi < f_.size(); ++fi) {
         File &f = f_[fi];
         f.fresh.clear(); f.dropped.clear();
+        f.first_fresh_id = f.next_id; f.n_fresh_paired = 0;
         int64_t count = 0;
         while (settle(f) && f.cur->tid[(size_t)f.idx] == tid && f.cur->pos[(size_t)f.idx] < ce) {
             const int64_t p = f.cur->pos[(size_t)f.idx];
@@ -598,23 +616,35 @@ int64_t ChunkPump::fill_window(int tid, int64_t cb, int64_t ce_target, std::vect
             }
         }
     }
-    if (cfg_.surely_pushed) {
+    if (tpl == PumpConfig::TPL_MPLP) {
+        // Lookahead.  HTSlib hands out column c once a read starting beyond c was pushed, and a pair is resolved when its second mate is
+        // pushed: the placeholders of a deletion / reference skip that straddles the mate's start show the RESOLVED quality of the next
+        // query base from the column of the last push in front of the mate on (kernels_overlap.hip fix_y; dev_util.h placeholder_qual).
+        // So a window also stages the reads that start at or after its end, up to the first one that reaches bam_plp_push -- the trigger
+        // of the window's last columns -- as far as they can still be the mate of a staged read (start < largest staged end).  They add no
+        // column here and stay carried.  Where the host does not decide who is pushed (pushed_on_device) the lookahead runs on to that end.
         Rec probe;
         for (auto &f : f_) {
             int64_t me = INT64_MIN;
             for (auto &r : f.carry) me = std::max(me, span_end(r));
             for (auto &g : f.fresh) for (int64_t i = g.i0; i < g.i1; ++i) me = std::max(me, span_end(*g.c, i));
             bool sure = false;
-            for (auto &r : f.carry) if (r.pos >= ce && cfg_.surely_pushed(r)) { sure = true; break; }
+            if (!cfg_.pushed_on_device) for (auto &r : f.carry) if (r.pos >= ce && (!cfg_.pushed || cfg_.pushed(r))) { sure = true; break; }
             while (!sure && settle(f) && f.cur->tid[(size_t)f.idx] == tid && f.cur->pos[(size_t)f.idx] < me) {
                 const size_t k = (size_t)f.idx;
-                probe.tid = f.cur->tid[k]; probe.pos = f.cur->pos[k]; probe.flag = f.cur->flag[k]; probe.mapq = f.cur->mapq[k];
-                sure = cfg_.surely_pushed(probe);
+                if (!cfg_.pushed_on_device) {
+                    probe.tid = f.cur->tid[k]; probe.pos = f.cur->pos[k]; probe.flag = f.cur->flag[k]; probe.mapq = f.cur->mapq[k]; probe.rlen = f.cur->rlen[k];
+                    sure = !cfg_.pushed || cfg_.pushed(probe);
+                }
                 take(f);
             }
         }
     }
-    if (!staged_out) { for (auto &f : f_) f.n_carry_staged = f.carry.size(); return ce; }
+    if (!staged_out) {
+        // a window the lane only passes over: its reads visit the overlap hash at once (the host's own verdict on who is pushed)
+        for (auto &f : f_) { f.n_carry_staged = f.carry.size(); if (tpl == PumpConfig::TPL_MPLP) pair_fresh(f, nullptr, 0); }
+        return ce;
+    }
     std::vector<StagedFile> &staged = *staged_out;
     const double t_stage0 = mono_s();
     std::vector<StagedFile::Slice> slices;
@@ -631,9 +661,104 @@ int64_t ChunkPump::fill_window(int tid, int64_t cb, int64_t ce_target, std::vect
         for (auto &g : f.fresh) slices.push_back(StagedFile::Slice{ g.c.get(), g.i0, g.i1 });
         s.add_ranges(slices.data(), slices.size(), cb, xp, stage_threads_, stage_min_bytes_, &f.high_water, raw_mode_);
         s.finish();
+        if (tpl == PumpConfig::TPL_DEPTH) {
+            s.tpl = 1;
+            s.clip.resize((size_t)s.n());
+            size_t i = 0;
+            for (auto &r : f.carry) s.clip[i++] = r.clip;
+            for (auto &g : f.fresh) for (int64_t k = g.i0; k < g.i1; ++k) s.clip[i++] = g.c->t_a[(size_t)k];
+        }
     }
     stats_.stage_s += mono_s() - t_stage0;
     return ce;
+}
+
+// ---- mpileup's overlap hash (host_names.h) ----
+ChunkPump::Loc ChunkPump::locate(File &f, int64_t id)
+{
+    Loc l;
+    if (id < 0) return l;
+    if (id >= f.first_fresh_id) {
+        int64_t o = id - f.first_fresh_id;                      // the window's new reads were taken one after the other
+        for (auto &g : f.fresh) { if (o < g.i1 - g.i0) { l.c = g.c.get(); l.k = g.i0 + o; return l; } o -= g.i1 - g.i0; }
+        return l;
+    }
+    auto it = std::lower_bound(f.carry.begin(), f.carry.end(), id, [](const Rec &r, int64_t v) { return r.id < v; });
+    if (it != f.carry.end() && it->id == id) l.r = &*it;
+    return l;
+}
+
+// the window's new reads that have not been there yet visit the overlap hash, in file order.  info == nullptr: PumpConfig::pushed decides
+// who reaches bam_plp_push; otherwise the device's RI_* words of the staged reads do (bit 0 pushed, bit 1 in the pileup)
+void ChunkPump::pair_fresh(File &f, const uint32_t *info, int64_t n_info)
+{
+    Rec probe;
+    int64_t o = 0;
+    for (auto &g : f.fresh)
+        for (int64_t k = g.i0; k < g.i1; ++k, ++o) {
+            if (o < f.n_fresh_paired) continue;
+            Chunk &c = *g.c; const size_t q = (size_t)k;
+            bool pushed, dropped = false;
+            if (info) {
+                const int64_t si = (int64_t)f.n_carry_staged + o;
+                const uint32_t w = si < n_info ? info[si] : 0;
+                pushed = (w & 1u) != 0;
+                dropped = pushed && !(w & 2u) && c.rlen[q] > 0;
+            } else {
+                probe.tid = c.tid[q]; probe.pos = c.pos[q]; probe.flag = c.flag[q]; probe.mapq = c.mapq[q]; probe.rlen = c.rlen[q];
+                pushed = cfg_.pushed ? cfg_.pushed(probe) : !(c.flag[q] & 4);
+            }
+            if (!pushed) continue;
+            OverlapNames::Read r;
+            r.h = c.name_h[q]; r.qname = c.names.data() + c.name_off[q]; r.l_qname = c.name_off[q + 1] - c.name_off[q] - 1;
+            r.flag = c.flag[q]; r.tid = c.tid[q]; r.mtid = c.mtid[q]; r.l_qseq = c.l_qseq[q];
+            r.pos = c.pos[q]; r.end = c.end(k); r.mpos = c.mpos[q]; r.isize = c.isize[q]; r.id = c.t_id[q];
+            const int64_t holder = f.onames.push(r, dropped);
+            if (holder < 0) continue;
+            c.t_a[q] = holder;
+            // the two stay staged together while either can touch a column
+            Loc h = locate(f, holder);
+            if (h.r) { c.t_b[q] = h.r->end(); h.r->mate_end = r.end; }
+            else if (h.c) { c.t_b[q] = h.c->end(h.k); h.c->t_b[(size_t)h.k] = r.end; }
+        }
+    f.n_fresh_paired = o;
+}
+
+// mate[i] = staged index of the record whose entry staged read i found (-1: none, or that record is no longer staged -- it ended
+// before this window and shares no column with read i)
+void ChunkPump::fill_mates(File &f, int32_t *mate, int64_t n) const
+{
+    auto index_of = [&](int64_t id) -> int32_t {
+        if (id < 0) return -1;
+        if (id >= f.first_fresh_id) return (int32_t)((int64_t)f.n_carry_staged + (id - f.first_fresh_id));
+        auto it = std::lower_bound(f.carry.begin(), f.carry.end(), id, [](const Rec &r, int64_t v) { return r.id < v; });
+        return it != f.carry.end() && it->id == id ? (int32_t)(it - f.carry.begin()) : -1;
+    };
+    int64_t i = 0;
+    for (auto &r : f.carry) { if (i >= n) return; mate[i++] = index_of(r.mate_id); }
+    for (auto &g : f.fresh) for (int64_t k = g.i0; k < g.i1; ++k) { if (i >= n) return; mate[i++] = index_of(g.c->t_a[(size_t)k]); }
+}
+
+void ChunkPump::pair_staged(std::vector<StagedFile> &staged)
+{
+    if (cfg_.tpl != PumpConfig::TPL_MPLP) return;
+    for (size_t fi = 0; fi < f_.size() && fi < staged.size(); ++fi) {
+        File &f = f_[fi];
+        pair_fresh(f, nullptr, 0);
+        StagedFile &s = staged[fi];
+        s.tpl = 2;
+        s.mate.resize((size_t)s.n());
+        fill_mates(f, s.mate.data(), s.n());
+    }
+}
+
+void ChunkPump::pair_from_info(size_t fi, const uint32_t *info, int64_t n, int32_t *mate_out)
+{
+    for (int64_t i = 0; i < n; ++i) mate_out[i] = -1;
+    if (cfg_.tpl != PumpConfig::TPL_MPLP || fi >= f_.size()) return;
+    File &f = f_[fi];
+    pair_fresh(f, info, n);
+    fill_mates(f, mate_out, n);
 }
 
 bool ChunkPump::staged_has_span(size_t fi, size_t i) const
@@ -670,159 +795,24 @@ void ChunkPump::drop(size_t fi, const std::vector<char> &dropped)
 
 void ChunkPump::retire(int64_t ce)
 {
-    struct Stay { int64_t pos; const char *qname; };
-    const bool proper_only = cfg_.mates_proper_only;
-    auto paired_ok = [proper_only](unsigned flag) { return (flag & 1) && ((flag & 2) || !proper_only) && !(flag & 8); };
+    // What stays staged for the next window: a record whose span reaches beyond the cut, and -- mpileup with overlap detection -- a record
+    // whose partner in the overlap hash does (tweak_overlap_quality rewrites both, from both, so the two are staged together for as long as
+    // either can touch a column).  Nothing else: which record found which is the lane's own state (host_names.h), not a replay.
+    const bool partners = cfg_.tpl == PumpConfig::TPL_MPLP;
     for (auto &f : f_) {
         auto is_dropped = [&](size_t staged_index) { return staged_index < f.dropped.size() && f.dropped[staged_index]; };
-        // pass 1: who stays because its span reaches beyond ce (position sorted: carried reads first, then the new ones)
-        std::vector<Stay> stay;
-        if (cfg_.keep_mates) {
-            for (auto &r : f.carry) if (span_end(r) > ce && paired_ok(r.flag)) stay.push_back(Stay{ r.pos, r.qname.c_str() });
-            size_t si = f.n_carry_staged;
-            for (auto &g : f.fresh)
-                for (int64_t i = g.i0; i < g.i1; ++i, ++si)
-                    if (!is_dropped(si) && span_end(*g.c, i) > ce && paired_ok(g.c->flag[(size_t)i]))
-                        stay.push_back(Stay{ g.c->pos[(size_t)i], g.c->names.data() + g.c->name_off[(size_t)i] });
-        }
-        auto mate_stays = [&](unsigned flag, int32_t tid, int32_t mtid, int64_t mpos, const char *qname) {
-            if (stay.empty() || !paired_ok(flag) || mtid != tid) return false;
-            auto lo = std::lower_bound(stay.begin(), stay.end(), mpos, [](const Stay &s, int64_t p) { return s.pos < p; });
-            for (; lo != stay.end() && lo->pos == mpos; ++lo) if (lo->qname != qname && !strcmp(lo->qname, qname)) return true;
-            return false;
-        };
-        // A record that stays ONLY for its mate's sake holds nothing any more once a read beyond its end was pushed before that mate
-        // (bam_plp_next frees it and overlap_remove takes the entry of its name along): see Pump::retire
-        // ("that mate" = the NEXT pushed record of its template, which need not be the one at its mate position: see Pump::retire.  `self`
-        // names the record asked about: a carried Rec, or (chunk, index) of a new one.)
-        auto freed_before_mate = [&](int64_t end, int64_t mpos, const char *qname, const void *self, int64_t self_i) {
-            if (!cfg_.surely_pushed) return false;
-            bool behind = false;
-            for (auto &q : f.carry) {
-                if ((const void *)&q == self) { behind = true; continue; }
-                if (!behind) continue;
-                if (q.pos > mpos) return false;       // (a record AT the mate position in front of the mate in the file frees it too)
-                if (!cfg_.surely_pushed(q)) continue;
-                if (!strcmp(q.qname.c_str(), qname)) return false;
-                if (q.pos > end) return true;
-            }
-            Rec probe;
-            size_t sj = f.n_carry_staged;
-            for (auto &g : f.fresh)
-                for (int64_t i = g.i0; i < g.i1; ++i, ++sj) {
-                    const size_t k = (size_t)i;
-                    if ((const void *)g.c.get() == self && i == self_i) { behind = true; continue; }
-                    if (!behind) continue;
-                    if (g.c->pos[k] > mpos) return false;
-                    if (is_dropped(sj)) continue;
-                    probe.tid = g.c->tid[k]; probe.pos = g.c->pos[k]; probe.flag = g.c->flag[k]; probe.mapq = g.c->mapq[k];
-                    if (!cfg_.surely_pushed(probe)) continue;
-                    if (!strcmp(g.c->names.data() + g.c->name_off[k], qname)) return false;
-                    if (g.c->pos[k] > end) return true;
-                }
-            return false;
-        };
-        // pass 2: decide for the carried reads before anything moves (`stay` points into them), then keep / materialise
-        std::vector<char> keepc(f.carry.size(), 0);
-        // (where the host cannot tell who is pushed -- -l, -G, -C, --min-read-len -- the record stays together with every record that
-        // starts between its end and its mate: the replay sees from their RI_PUSHED whether one of them freed it)
-        struct Ctx { int64_t pos, end, mpos; std::string qname; };
-        std::vector<Ctx> ctx;
-        auto for_mate_only = [&](int64_t pos, int64_t end, unsigned flag, int32_t tid, int32_t mtid, int64_t mpos, const char *qname, const void *self, int64_t self_i) {
-            if (!mate_stays(flag, tid, mtid, mpos, qname) || freed_before_mate(end, mpos, qname, self, self_i)) return false;
-            ctx.push_back(Ctx{ pos, end, mpos, qname });
-            return true;
-        };
-        // (by position, or as another record of the template: one that starts inside the kept record's span is no context record by position)
-        auto in_ctx = [&](int64_t pos, const char *qname) {
-            for (auto &iv : ctx) if (pos <= iv.mpos && (pos > iv.end || (pos >= iv.pos && !strcmp(iv.qname.c_str(), qname)))) return true;
-            return false;
-        };
-        // (1) A record whose span ends at the cut is still in the reference's buffer while no pushed read has started beyond its end
-        // (Pump::retire): max_start = the last pushed start in front of the cut (the lists are position sorted: looked for from the back).
-        // Only while the contig has reads to come: at its end the reference flushes its buffer, and a record kept here for ever would keep
-        // the window loop going for ever.
-        int64_t max_start = INT64_MIN;
-        int cur_tid = -1;
-        if (!f.carry.empty()) cur_tid = f.carry.front().tid;
-        else for (auto &g : f.fresh) if (g.i1 > g.i0) { cur_tid = g.c->tid[(size_t)g.i0]; break; }
-        if (cfg_.keep_mates && cur_tid >= 0 && next_pos(cur_tid) != INT64_MAX) {
-            Rec probe;
-            bool found = false;
-            size_t sj = f.n_carry_staged;
-            for (auto &g : f.fresh) sj += (size_t)(g.i1 - g.i0);
-            for (auto g = f.fresh.rbegin(); g != f.fresh.rend() && !found; ++g)
-                for (int64_t i = g->i1 - 1; i >= g->i0; --i) {
-                    --sj;
-                    const size_t k = (size_t)i;
-                    if (is_dropped(sj) || g->c->pos[k] >= ce) continue;
-                    if (cfg_.surely_pushed && !cfg_.pushed_unknown) { probe.tid = g->c->tid[k]; probe.pos = g->c->pos[k]; probe.flag = g->c->flag[k]; probe.mapq = g->c->mapq[k]; if (!cfg_.surely_pushed(probe)) continue; }
-                    max_start = g->c->pos[k]; found = true; break;
-                }
-            if (!found)
-                for (auto r = f.carry.rbegin(); r != f.carry.rend(); ++r)
-                    if (r->pos < ce && (!cfg_.surely_pushed || cfg_.pushed_unknown || cfg_.surely_pushed(*r))) { max_start = r->pos; break; }
-        }
-        const bool alive_rule = cfg_.keep_mates && max_start != INT64_MIN;
-        std::vector<const char *> multi;          // names of secondary / supplementary records: templates with more than two records
-        { size_t i = 0; for (auto &r : f.carry) {
-            const int64_t e = span_end(r);
-            if (cfg_.keep_mates && (r.flag & 0x900)) multi.push_back(r.qname.c_str());
-            keepc[i++] = e > ce || (alive_rule && e >= max_start) || for_mate_only(r.pos, e, r.flag, r.tid, r.mtid, r.mpos, r.qname.c_str(), &r, 0); } }
-        // the window's new reads, in staged order (dropped ones never kept)
-        size_t n_fresh = 0;
-        for (auto &g : f.fresh) n_fresh += (size_t)(g.i1 - g.i0);
-        std::vector<char> keepf(n_fresh, 0);
-        auto each_fresh = [&](auto &&fn) {          // fn(chunk, index in chunk, index in keepf); dropped records skipped
-            size_t si = f.n_carry_staged, j = 0;
-            for (auto &g : f.fresh)
-                for (int64_t i = g.i0; i < g.i1; ++i, ++si, ++j) if (!is_dropped(si)) fn(*g.c, i, j);
-        };
-        auto name_of = [](const Chunk &c, int64_t i) { return c.names.data() + c.name_off[(size_t)i]; };
-        each_fresh([&](const Chunk &c, int64_t i, size_t j) {
-            const size_t k = (size_t)i;
-            const int64_t e = span_end(c, i);
-            if (cfg_.keep_mates && (c.flag[k] & 0x900)) multi.push_back(name_of(c, i));
-            keepf[j] = e > ce || (alive_rule && e >= max_start) || for_mate_only(c.pos[k], e, c.flag[k], c.tid[k], c.mtid[k], c.mpos[k], name_of(c, i), &c, i);
-        });
-        if (cfg_.keep_mates) {
-            // (2) the records of a template with more than two records all stay while one of them does: see Pump::retire
-            if (!multi.empty()) {
-                std::vector<Ctx> tpl;                  // (first position, -, last position, name) of such a template with a record that stays
-                auto note = [&](const char *qn) {
-                    bool is_multi = false;
-                    for (const char *m : multi) if (!strcmp(m, qn)) { is_multi = true; break; }
-                    if (!is_multi) return;
-                    for (auto &t : tpl) if (!strcmp(t.qname.c_str(), qn)) return;
-                    tpl.push_back(Ctx{ INT64_MAX, 0, INT64_MIN, qn });
-                };
-                { size_t i = 0; for (auto &r : f.carry) { if (keepc[i]) note(r.qname.c_str()); ++i; } }
-                each_fresh([&](const Chunk &c, int64_t i, size_t j) { if (keepf[j]) note(name_of(c, i)); });
-                if (!tpl.empty()) {
-                    auto span = [&](const char *qn, int64_t pos) { for (auto &t : tpl) if (!strcmp(t.qname.c_str(), qn)) { t.pos = std::min(t.pos, pos); t.mpos = std::max(t.mpos, pos); } };
-                    for (auto &r : f.carry) span(r.qname.c_str(), r.pos);
-                    each_fresh([&](const Chunk &c, int64_t i, size_t) { span(name_of(c, i), c.pos[(size_t)i]); });
-                    auto of_tpl = [&](const char *qn, int64_t pos, int64_t end) {
-                        for (auto &t : tpl) if (!strcmp(t.qname.c_str(), qn)) { ctx.push_back(Ctx{ pos, end, t.mpos, qn }); return true; }
-                        return false;
-                    };
-                    { size_t i = 0; for (auto &r : f.carry) { if (!keepc[i] && of_tpl(r.qname.c_str(), r.pos, span_end(r))) keepc[i] = 1; ++i; } }
-                    each_fresh([&](const Chunk &c, int64_t i, size_t j) { if (!keepf[j] && of_tpl(name_of(c, i), c.pos[(size_t)i], span_end(c, i))) keepf[j] = 1; });
-                }
-            }
-        }
-        if (!ctx.empty()) {          // the context records
-            { size_t i = 0; for (auto &r : f.carry) { if (!keepc[i] && in_ctx(r.pos, r.qname.c_str())) keepc[i] = 1; ++i; } }
-            each_fresh([&](const Chunk &c, int64_t i, size_t j) { if (!keepf[j] && in_ctx(c.pos[(size_t)i], name_of(c, i))) keepf[j] = 1; });
-        }
-        std::vector<std::pair<const Chunk *, int64_t>> fresh_keep;       // in position order (carried first, then the window's new reads)
-        each_fresh([&](const Chunk &c, int64_t i, size_t j) { if (keepf[j]) fresh_keep.emplace_back(&c, i); });
         std::deque<Rec> keep;
-        { size_t i = 0; for (auto &r : f.carry) { if (keepc[i++]) keep.push_back(std::move(r)); } }
-        for (auto &pr : fresh_keep) { keep.emplace_back(); pr.first->to_rec(pr.second, keep.back()); }
+        for (auto &r : f.carry) if (span_end(r) > ce || (partners && r.mate_end > ce)) keep.push_back(std::move(r));
+        size_t si = f.n_carry_staged;
+        for (auto &g : f.fresh)
+            for (int64_t i = g.i0; i < g.i1; ++i, ++si) {
+                if (is_dropped(si)) continue;
+                if (span_end(*g.c, i) > ce || (partners && g.c->t_id.size() == g.c->pos.size() && g.c->t_b[(size_t)i] > ce)) { keep.emplace_back(); g.c->to_rec(i, keep.back()); }
+            }
         f.carry.swap(keep);
         for (auto &r : f.carry) r.accepted = true;      // what stays was accepted by this window's -d replay
         f.fresh.clear(); f.dropped.clear(); f.n_carry_staged = 0;
+        f.first_fresh_id = f.next_id; f.n_fresh_paired = 0;
     }
 }
 

@@ -32,6 +32,11 @@ struct Chunk {
     std::vector<uint8_t> seq, qual, bq;           // bq maintained only once some record carries BQ:Z
     bool has_bq_pool = false;
     std::vector<char> names;
+    std::vector<uint64_t> name_h;                 // qname_hash64 of every name (host_names.h): hashed here, on the decode threads
+    // written by the window producer when it takes a record (PumpConfig::tpl, host_names.h): the lane's running number of the record; depth
+    // -s: its clip column / mpileup: the record whose overlap-hash entry it found (-1); mpileup: its partner's end (INT64_MIN: no partner)
+    std::vector<int64_t> t_id, t_a, t_b; int t_mode = 0;      // t_mode: PumpConfig::TPL_*
+    void tpl_touch(int mode) { if (t_id.size() != pos.size()) { t_mode = mode; t_id.assign(pos.size(), -1); t_a.assign(pos.size(), mode == 1 ? 0 : -1); t_b.assign(pos.size(), INT64_MIN); } }
     // wanted aux tags (AlnReader::set_wanted_tags) as text, n_tags entries per record: the staging layer turns them into text
     // columns (--output-extra tags of mpileup; MD:Z for the consensus path)
     int n_tags = 0;
@@ -130,6 +135,8 @@ public:
     bool staged_has_span(size_t f, size_t i) const override;
     int64_t staged_max_span(size_t f) const override;
     void drop(size_t f, const std::vector<char> &dropped) override;
+    void pair_staged(std::vector<StagedFile> &staged) override;
+    void pair_from_info(size_t f, const uint32_t *info, int64_t n, int32_t *mate_out) override;
     void retire(int64_t ce) override;
     void drop_tid_carry() override;
     int error() const override { return err_; }
@@ -153,7 +160,15 @@ private:
         size_t n_carry_staged = 0;                        // carried reads at the front of the staged order
         std::vector<char> dropped;                        // per staged read: removed by the -d cap in this window
         StagedFile::PoolSizes high_water;                 // largest staging pools a window of this input needed so far
+        // template state in file order (host_names.h)
+        int64_t next_id = 0, first_fresh_id = 0;          // running number of the next record taken / of the window's first new read
+        int64_t n_fresh_paired = 0;                       // new reads of the window that have visited the overlap hash
+        DepthMateClip dclip; OverlapNames onames;
     };
+    struct Loc { Rec *r = nullptr; Chunk *c = nullptr; int64_t k = 0; };
+    Loc locate(File &f, int64_t id);                      // a staged record by its running number (carried or new), or nothing
+    void pair_fresh(File &f, const uint32_t *info, int64_t n_info);
+    void fill_mates(File &f, int32_t *mate, int64_t n) const;
     PumpConfig cfg_;
     std::vector<File> f_;
     int err_ = 0; std::string errtxt_;

@@ -51,6 +51,11 @@ struct Rec {
     int64_t rlen = 0;            // reference span (bam_cigar2rlen)
     bool cigar_from_tag = false; // BAM: the CIGAR came out of a CG:B,I tag (the record's own CIGAR field is the <l_seq>S<span>N placeholder)
     bool accepted = false;       // carried from an earlier window whose -d replay kept it (STA_AUX_ACCEPTED when re-staged)
+    // template state kept by the input lanes in file order (host_names.h): the lane's running number of the record; depth -s: the column
+    // below which it is not counted; mpileup: the record whose overlap-hash entry it found (-1: none) and, for both partners of such a
+    // pair, the other one's end (a record stays staged while its partner can still touch a column)
+    int64_t id = -1, clip = 0, mate_id = -1, mate_end = INT64_MIN;
+    uint64_t name_h = 0;         // qname_hash64 of qname (chunk lane: computed by the decode threads)
     int64_t end() const { return pos + rlen; }
     int64_t endpos() const { int64_t l = (flag & 4) ? 0 : rlen; return pos + (l > 0 ? l : 1); }   // bam_endpos
 };

@@ -10,6 +10,7 @@ Pump::Pump(std::vector<std::unique_ptr<AlnReader>> &readers, const PumpConfig &c
     size_t n = rd_.size();
     pend_.resize(n); has_pend_.assign(n, 0); eof_.assign(n, 0); carry_.resize(n);
     last_pos_.assign(n, -1); last_tid_.assign(n, -1);
+    next_id_.assign(n, 0); n_carry_staged_.assign(n, 0); n_fresh_paired_.assign(n, 0); dclip_.resize(n); onames_.resize(n);
     for (size_t f = 0; f < n; ++f) advance(f);
 }
 
@@ -75,35 +76,49 @@ int64_t Pump::carry_max_end() const
     return m;
 }
 
+// a record leaves its file for the window: its running number, and -- depth -s -- its visit to the name hash (bam2depth.c:598-623)
+void Pump::take(size_t f)
+{
+    Rec &r = pend_[f];
+    r.id = next_id_[f]++;
+    if (cfg_.tpl == PumpConfig::TPL_DEPTH) {
+        r.clip = 0;
+        if (cfg_.depth_filter.passes(r.flag, r.mapq, r.l_qseq, r.cigar.data(), r.cigar.size()))
+            r.clip = dclip_[f].visit(r.qname.c_str(), r.flag, r.tid, r.endpos(), r.mtid, r.mpos);
+    } else if (cfg_.tpl == PumpConfig::TPL_MPLP) r.name_h = qname_hash64(r.qname.data(), r.qname.size());
+    carry_[f].push_back(std::move(r));
+    advance(f);
+}
+
 int64_t Pump::fill(int tid, int64_t cb, int64_t ce_target, std::vector<std::vector<const Rec *>> &reads)
 {
     size_t n = rd_.size();
     int64_t ce = ce_target;
     for (size_t f = 0; f < n; ++f) {
+        n_carry_staged_[f] = carry_[f].size(); n_fresh_paired_[f] = 0;
         int64_t count = 0;
         while (has_pend_[f] && pend_[f].tid == tid && pend_[f].pos < ce) {
             int64_t p = pend_[f].pos;
-            carry_[f].push_back(std::move(pend_[f]));
-            advance(f);
+            take(f);
             if (++count >= cfg_.max_reads && f == 0 && p >= cb) {
                 // cut the window after this start position (all reads sharing it stay together)
-                while (has_pend_[f] && pend_[f].tid == tid && pend_[f].pos == p) { carry_[f].push_back(std::move(pend_[f])); advance(f); }
+                while (has_pend_[f] && pend_[f].tid == tid && pend_[f].pos == p) take(f);
                 if (p + 1 > cb) ce = std::min(ce, p + 1);
                 break;
             }
         }
     }
-    if (cfg_.surely_pushed) {
+    if (cfg_.tpl == PumpConfig::TPL_MPLP) {
+        // lookahead up to the first read that reaches bam_plp_push: see ChunkPump::fill_window (the iterators of different files advance
+        // independently, bam_mplp_*: per file)
         for (size_t f = 0; f < n; ++f) {
-            // the iterators of different files advance independently (bam_mplp_*): lookahead is per file
             int64_t me = INT64_MIN;
             for (auto &r : carry_[f]) me = std::max(me, span_end(r));
             bool sure = false;
-            for (auto &r : carry_[f]) if (r.pos >= ce && cfg_.surely_pushed(r)) { sure = true; break; }   // cut windows
+            if (!cfg_.pushed_on_device) for (auto &r : carry_[f]) if (r.pos >= ce && (!cfg_.pushed || cfg_.pushed(r))) { sure = true; break; }
             while (!sure && has_pend_[f] && pend_[f].tid == tid && pend_[f].pos < me) {
-                sure = cfg_.surely_pushed(pend_[f]);
-                carry_[f].push_back(std::move(pend_[f]));
-                advance(f);
+                if (!cfg_.pushed_on_device) sure = !cfg_.pushed || cfg_.pushed(pend_[f]);
+                take(f);
             }
         }
     }
@@ -115,6 +130,72 @@ int64_t Pump::fill(int tid, int64_t cb, int64_t ce_target, std::vector<std::vect
     return ce;
 }
 
+int64_t Pump::fill_unstaged(int tid, int64_t cb, int64_t ce_target)
+{
+    const int64_t ce = fill(tid, cb, ce_target, last_);
+    // a window the lane only passes over: its reads visit the overlap hash at once (the host's own verdict on who is pushed)
+    if (cfg_.tpl == PumpConfig::TPL_MPLP) for (size_t f = 0; f < rd_.size(); ++f) pair_fresh(f, nullptr, 0);
+    return ce;
+}
+
+// ---- mpileup's overlap hash (host_names.h); the twin of ChunkPump::pair_fresh ----
+void Pump::pair_fresh(size_t f, const uint32_t *info, int64_t n_info)
+{
+    std::deque<Rec> &c = carry_[f];
+    for (size_t i = n_carry_staged_[f] + (size_t)n_fresh_paired_[f]; i < c.size(); ++i) {
+        Rec &x = c[i];
+        bool pushed, dropped = false;
+        if (info) {
+            const uint32_t w = (int64_t)i < n_info ? info[i] : 0;
+            pushed = (w & 1u) != 0;
+            dropped = pushed && !(w & 2u) && x.rlen > 0;
+        } else pushed = cfg_.pushed ? cfg_.pushed(x) : !(x.flag & 4);
+        if (!pushed) continue;
+        OverlapNames::Read r;
+        r.h = x.name_h; r.qname = x.qname.data(); r.l_qname = (uint32_t)x.qname.size();
+        r.flag = x.flag; r.tid = x.tid; r.mtid = x.mtid; r.l_qseq = x.l_qseq;
+        r.pos = x.pos; r.end = x.end(); r.mpos = x.mpos; r.isize = x.isize; r.id = x.id;
+        const int64_t holder = onames_[f].push(r, dropped);
+        if (holder < 0) continue;
+        x.mate_id = holder;
+        auto it = std::lower_bound(c.begin(), c.end(), holder, [](const Rec &q, int64_t v) { return q.id < v; });
+        if (it != c.end() && it->id == holder) { x.mate_end = it->end(); it->mate_end = x.end(); }      // the two stay staged together
+    }
+    n_fresh_paired_[f] = (int64_t)(c.size() - n_carry_staged_[f]);
+}
+
+void Pump::fill_mates(size_t f, int32_t *mate, int64_t n) const
+{
+    const std::deque<Rec> &c = carry_[f];
+    for (int64_t i = 0; i < n && (size_t)i < c.size(); ++i) {
+        mate[i] = -1;
+        const int64_t id = c[(size_t)i].mate_id;
+        if (id < 0) continue;
+        auto it = std::lower_bound(c.begin(), c.end(), id, [](const Rec &q, int64_t v) { return q.id < v; });
+        if (it != c.end() && it->id == id) mate[i] = (int32_t)(it - c.begin());
+    }
+}
+
+void Pump::pair_staged(std::vector<StagedFile> &staged)
+{
+    if (cfg_.tpl != PumpConfig::TPL_MPLP) return;
+    for (size_t f = 0; f < rd_.size() && f < staged.size(); ++f) {
+        pair_fresh(f, nullptr, 0);
+        StagedFile &s = staged[f];
+        s.tpl = 2;
+        s.mate.resize((size_t)s.n());
+        fill_mates(f, s.mate.data(), s.n());
+    }
+}
+
+void Pump::pair_from_info(size_t f, const uint32_t *info, int64_t n, int32_t *mate_out)
+{
+    for (int64_t i = 0; i < n; ++i) mate_out[i] = -1;
+    if (cfg_.tpl != PumpConfig::TPL_MPLP || f >= rd_.size()) return;
+    pair_fresh(f, info, n);
+    fill_mates(f, mate_out, n);
+}
+
 int64_t Pump::fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged)
 {
     int64_t ce = fill(tid, cb, ce_target, last_);
@@ -124,6 +205,11 @@ int64_t Pump::fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<St
         staged[f].clear();
         for (const Rec *r : last_[f]) staged[f].add(*r, cb, cfg_.rg_excl, (xs.n_cols() || xs.mods) ? &xs : nullptr);
         staged[f].finish();
+        if (cfg_.tpl == PumpConfig::TPL_DEPTH) {
+            staged[f].tpl = 1;
+            staged[f].clip.resize(last_[f].size());
+            for (size_t i = 0; i < last_[f].size(); ++i) staged[f].clip[i] = last_[f][i]->clip;
+        }
     }
     return ce;
 }
@@ -138,103 +224,15 @@ void Pump::drop(size_t f, const std::vector<char> &dropped)
 
 void Pump::retire(int64_t ce)
 {
-    for (auto &c : carry_) {
-        std::vector<const Rec *> stay;
-        if (cfg_.keep_mates)
-            for (auto &r : c) if (span_end(r) > ce && (r.flag & 1) && ((r.flag & 2) || !cfg_.mates_proper_only) && !(r.flag & 8)) stay.push_back(&r);
-        auto mate_stays = [&](const Rec &r) {
-            if (!(r.flag & 1) || (!(r.flag & 2) && cfg_.mates_proper_only) || (r.flag & 8) || r.mtid != r.tid) return false;
-            auto lo = std::lower_bound(stay.begin(), stay.end(), r.mpos, [](const Rec *s, int64_t p) { return s->pos < p; });   // carry is position sorted
-            for (; lo != stay.end() && (*lo)->pos == r.mpos; ++lo) if (*lo != &r && (*lo)->qname == r.qname) return true;
-            return false;
-        };
-        // A record that stays ONLY for its mate's sake holds nothing any more once a read beyond its end was pushed before that mate:
-        // bam_plp_next frees it (overlap_remove takes the entry of its name along) as soon as max_pos has passed its end.  Carried on, it
-        // would look to the next window's replay (k_name_groups) like the holder of the template's entry -- the record that freed it is
-        // not staged there.  Seen with three records of one template: a supplementary alignment upstream of the primary pair, a window
-        // cut between them (scripts/hunt5.py, round 5).
-        // "Before that mate" means before the NEXT record of its template that is pushed, which need not be the one at its mate position: a
-        // supplementary alignment (mate position = the second primary) is still in the buffer when the FIRST primary arrives right behind
-        // its end -- that one finds the entry and deletes it, and the second primary finds nothing.  Dropped, the primaries would pair up
-        // in the next window's replay (scripts/hunt6.py seed 29, round 5).
-        auto freed_before_mate = [&](const Rec &r) {
-            if (!cfg_.surely_pushed) return false;
-            const int64_t e = span_end(r);
-            bool behind = false;
-            for (auto &q : c) {
-                if (&q == &r) { behind = true; continue; }
-                if (!behind) continue;
-                if (q.pos > r.mpos) break;            // (a record AT the mate position in front of the mate in the file frees it too)
-                if (!cfg_.surely_pushed(q)) continue;
-                if (q.qname == r.qname) return false;
-                if (q.pos > e) return true;
-            }
-            return false;
-        };
-        // Where the host cannot tell who is pushed (-l, -G, -C, --min-read-len: surely_pushed says no), the record stays and so does
-        // every record that starts between its end and its mate: the replay then sees, from their RI_PUSHED, whether one of them freed it.
-        struct Ctx { int64_t pos, end, mpos; const std::string *qname; };      // a record kept for its mate only
-        std::vector<Ctx> ctx;
-        std::vector<char> gone(c.size(), 0);       // decided before anything moves: `stay` points into c
-        size_t i = 0;
-        for (auto &r : c) {
-            bool keep_r = span_end(r) > ce;
-            if (!keep_r && !stay.empty() && mate_stays(r) && !freed_before_mate(r)) { keep_r = true; ctx.push_back(Ctx{ r.pos, span_end(r), r.mpos, &r.qname }); }
-            gone[i++] = !keep_r;
-        }
-        if (cfg_.keep_mates) {
-            // (1) A record whose span ends at the cut is still in the reference's buffer -- and its template's entry in the hash -- while no
-            // pushed read has started beyond its end: the next window's first read still meets it (a supplementary alignment right in
-            // front of its primaries: the first primary finds its entry, deletes it, and the pair is never resolved).
-            // (Only while the contig has reads to come: at its end the reference flushes its buffer, and a record kept here for ever
-            // would keep the window loop going for ever.)
-            int64_t max_start = INT64_MIN;
-            const bool more = !c.empty() && next_pos(c.front().tid) != INT64_MAX;
-            if (more) for (auto &r : c) if (r.pos < ce && (!cfg_.surely_pushed || cfg_.pushed_unknown || cfg_.surely_pushed(r))) max_start = std::max(max_start, r.pos);
-            i = 0;
-            if (more && max_start != INT64_MIN) for (auto &r : c) { if (gone[i] && span_end(r) >= max_start) gone[i] = 0; ++i; }
-            // (2) Templates with more than two records (one of them secondary / supplementary): what a record that stays finds in the hash
-            // depends on every record of its template the window has seen -- a primary that consumed the supplementary's entry three
-            // windows ago must not insert its own when the windows are replayed.  They all stay while one of them does, each ended one
-            // with the records up to the template's last one as context (scripts/hunt6.py seed 29, round 5).
-            std::vector<const Rec *> multi;
-            for (auto &r : c) if (r.flag & 0x900) multi.push_back(&r);
-            if (!multi.empty()) {
-                std::vector<Ctx> tpl;                      // (first pos, -, last pos, name) of a template with a staying record
-                i = 0;
-                for (auto &r : c) {
-                    if (!gone[i++]) {
-                        bool is_multi = false;
-                        for (const Rec *m : multi) if (m->qname == r.qname) { is_multi = true; break; }
-                        if (is_multi) {
-                            bool known = false;
-                            for (auto &t : tpl) if (*t.qname == r.qname) { known = true; break; }
-                            if (!known) tpl.push_back(Ctx{ INT64_MAX, 0, INT64_MIN, &r.qname });
-                        }
-                    }
-                }
-                if (!tpl.empty()) {
-                    for (auto &r : c) for (auto &t : tpl) if (r.qname == *t.qname) { t.pos = std::min(t.pos, r.pos); t.mpos = std::max(t.mpos, r.pos); }
-                    i = 0;
-                    for (auto &r : c) {
-                        if (gone[i]) for (auto &t : tpl) if (r.qname == *t.qname) { gone[i] = 0; ctx.push_back(Ctx{ r.pos, span_end(r), t.mpos, &r.qname }); break; }
-                        ++i;
-                    }
-                }
-            }
-        }
-        if (!ctx.empty()) {
-            i = 0;
-            for (auto &r : c) { if (gone[i]) for (auto &iv : ctx) if (r.pos > iv.end && r.pos <= iv.mpos) { gone[i] = 0; break; } ++i; }
-            // ... and the other records of its template (one that starts inside its span is no context record by position)
-            i = 0;
-            for (auto &r : c) { if (gone[i]) for (auto &iv : ctx) if (r.pos >= iv.pos && r.pos <= iv.mpos && r.qname == *iv.qname) { gone[i] = 0; break; } ++i; }
-        }
+    // see ChunkPump::retire: a record stays while its span reaches beyond the cut, or -- mpileup with overlap detection -- while its
+    // partner in the overlap hash does
+    const bool partners = cfg_.tpl == PumpConfig::TPL_MPLP;
+    for (size_t f = 0; f < carry_.size(); ++f) {
         std::deque<Rec> keep;
-        i = 0;
-        for (auto &r : c) { if (!gone[i++]) keep.push_back(std::move(r)); }
-        c.swap(keep);
-        for (auto &r : c) r.accepted = true;       // what stays was accepted by this window's -d replay
+        for (auto &r : carry_[f]) if (span_end(r) > ce || (partners && r.mate_end > ce)) keep.push_back(std::move(r));
+        carry_[f].swap(keep);
+        for (auto &r : carry_[f]) r.accepted = true;       // what stays was accepted by this window's -d replay
+        n_carry_staged_[f] = carry_[f].size(); n_fresh_paired_[f] = 0;
     }
 }
 

@@ -7,6 +7,7 @@
 #pragma once
 #include "host_io.h"
 #include "host_stage.h"
+#include "host_names.h"
 #include <deque>
 #include <functional>
 #include <set>
@@ -17,22 +18,21 @@ struct PumpConfig {
     int64_t window_cols = 1 << 20;     // target columns per window
     int64_t max_reads = 4 << 20;       // soft cap of new reads per file per window
     bool use_endpos = false;           // carry criterion: bam_endpos (depth) instead of pos + rlen (mpileup)
-    // Mate-overlap lookahead (mpileup): HTSlib hands out column c once a read starting beyond c was pushed, and a pair is
-    // resolved when its second mate is pushed -- so a window must also stage the reads that start at or after its end,
-    // up to the first one that certainly reaches bam_plp_push (the trigger of the window's last columns), as far as
-    // they can still be the mate of a staged read (start < largest staged end).  They add no columns to this window
-    // and simply stay carried for the next one.  Empty function = no lookahead (depth, coverage).
-    std::function<bool(const Rec &)> surely_pushed;
-    // ... and it answers "not sure" for EVERY record (-l, -G, -C, --min-read-len): where a rule needs "no pushed read has started beyond
-    // X" the host then takes every read for pushed (the side that keeps more staged; the device's replay sees their RI_PUSHED)
-    bool pushed_unknown = false;
-    // Mate overlaps again: every window re-derives the resolved qualities from the records as read, so a read that can no
-    // longer touch a column must still be staged for as long as its mate can -- HTSlib's resolution may rewrite bases of
-    // the later mate beyond the earlier mate's end (the deletion branch of tweak_overlap_quality), and those stay visible
-    // after the earlier mate has left the pileup.
-    bool keep_mates = false;
-    // ... of PROPER pairs only (overlap_push's condition, mpileup); depth -s pairs up any paired read with a mapped mate (bam2depth.c:598-623)
-    bool mates_proper_only = true;
+    // Template state (host_names.h): the reference's name hashes are sequential over the whole file, so the lane runs them itself while it
+    // takes records off the inputs and stages what every record found.
+    //   TPL_DEPTH  depth -s (bam2depth.c:598-623): every record that passes `depth_filter` visits the per-file name -> end hash; the
+    //              staged arrays carry its clip column (sta_reads.olap_clip).
+    //   TPL_MPLP   mpileup's overlap hash: every record that reaches bam_plp_push -- `pushed` decides, EXACTLY as
+    //              k_prep_reads does on the device -- visits the per-file hash; the staged arrays carry the staged index of the record
+    //              whose entry it found (sta_reads.olap_mate), and the two partners stay staged while either can touch a column.
+    //              A window the lane only passes over (fill_unstaged) is paired at once; a staged window is paired when the driver
+    //              calls pair_staged() -- or, where the device decides who is pushed (-C) or turned away (a -d cap that triggers),
+    //              pair_from_info() with the window's RI_* words (driver_mpileup.cpp: the engine's resolver callback).
+    enum { TPL_NONE = 0, TPL_DEPTH = 1, TPL_MPLP = 2 };
+    int tpl = TPL_NONE;
+    DepthReadFilter depth_filter;
+    std::function<bool(const Rec &)> pushed;          // TPL_MPLP: tid, pos, rlen, flag, mapq (and rg in the record lane) are filled in
+    bool pushed_on_device = false;                    // TPL_MPLP: every staged window goes through pair_from_info() (-C): `pushed` only serves windows passed over
     // staging options of fill_staged(): -G read groups to mark STA_AUX_SKIP, --output-extra columns formatted on the host
     const std::set<std::string> *rg_excl = nullptr;
     bool xs_rnext = false; int xs_n_tags = 0; char xs_empty = '*'; bool xs_mods = false;
@@ -81,6 +81,13 @@ public:
     // of BAM records they do not -- host_stage.h raw_mode)
     virtual int64_t staged_max_span(size_t f) const = 0;
     virtual void drop(size_t f, const std::vector<char> &dropped) = 0;
+    // TPL_MPLP, after fill_staged(): the window's new reads visit the overlap hash (PumpConfig::pushed decides who reaches it) and
+    // staged[f].mate is filled in
+    virtual void pair_staged(std::vector<StagedFile> &staged) = 0;
+    // ... the same with the device's verdict on every staged read of file f (info[i]: bit 0 = reached bam_plp_push, bit 1 = in the
+    // pileup; a pushed read with a reference span that is not in the pileup was turned away by the -d cap): mate_out[i] = staged index
+    // of the record whose entry read i found, or -1
+    virtual void pair_from_info(size_t f, const uint32_t *info, int64_t n, int32_t *mate_out) = 0;
     virtual void retire(int64_t ce) = 0;
     virtual void drop_tid_carry() = 0;
     virtual int error() const = 0;
@@ -105,9 +112,11 @@ public:
     int64_t fill(int tid, int64_t cb, int64_t ce_target, std::vector<std::vector<const Rec *>> &reads);
     // After the window [cb, ce) was processed: keep only reads that extend beyond ce.
     int64_t fill_staged(int tid, int64_t cb, int64_t ce_target, std::vector<StagedFile> &staged) override;
-    int64_t fill_unstaged(int tid, int64_t cb, int64_t ce_target) override { return fill(tid, cb, ce_target, last_); }
+    int64_t fill_unstaged(int tid, int64_t cb, int64_t ce_target) override;
     bool staged_has_span(size_t f, size_t i) const override { return f < last_.size() && i < last_[f].size() && last_[f][i]->rlen > 0; }
     int64_t staged_max_span(size_t f) const override { int64_t m = 0; if (f < last_.size()) for (const Rec *r : last_[f]) if ((int64_t)r->rlen > m) m = (int64_t)r->rlen; return m; }
+    void pair_staged(std::vector<StagedFile> &staged) override;
+    void pair_from_info(size_t f, const uint32_t *info, int64_t n, int32_t *mate_out) override;
     void retire(int64_t ce) override;
     // before retire(): reads of file f (indexed as fill() returned them) that the -d cap dropped in this window leave the
     // iterator for good, exactly as bam_plp_push never stored them
@@ -124,6 +133,13 @@ private:
     int err_ = 0; std::string errtxt_;
     std::vector<std::vector<const Rec *>> last_;      // reads of the window fill_staged() staged last
     void advance(size_t f);
+    // template state in file order (host_names.h): running record numbers, the carried reads at the front of the staged order, the new
+    // reads that have visited the overlap hash, the two hashes
+    std::vector<int64_t> next_id_; std::vector<size_t> n_carry_staged_; std::vector<int64_t> n_fresh_paired_;
+    std::vector<DepthMateClip> dclip_; std::vector<OverlapNames> onames_;
+    void take(size_t f);
+    void pair_fresh(size_t f, const uint32_t *info, int64_t n_info);
+    void fill_mates(size_t f, int32_t *mate, int64_t n) const;
     int64_t span_end(const Rec &r) const { return cfg_.use_endpos ? r.endpos() : r.end(); }
 };
 

@@ -54,13 +54,14 @@ extern "C" int sta_io_scan(const char *path, int threads, int stage, uint64_t *n
         }
     } else {
         // what driver_mpileup does between the reader and sta_stage_window, minus the device: stage 1 = one decoded record
-        // at a time (Pump), stage 2 = chunk slices (ChunkPump); both must stage byte-identical windows.  The overlap
-        // lookahead and mate keeping of the mpileup driver are switched on so that they are part of the comparison.
+        // at a time (Pump), stage 2 = chunk slices (ChunkPump); both must stage byte-identical windows.
         PumpConfig pc; pc.window_cols = 1 << 20; pc.nref_limit = readers[0]->header().nref();
         if (const char *e = getenv("STA_WINDOW_COLS")) pc.window_cols = std::max<long long>(1, atoll(e));
         if (const char *e = getenv("STA_WINDOW_READS")) pc.max_reads = std::max<long long>(1, atoll(e));
-        pc.keep_mates = true;
-        pc.surely_pushed = [](const Rec &r) { return !(r.flag & 0x704) && r.mapq >= 1; };
+        // the lanes' template state (host_names.h) is part of the comparison: mpileup's overlap hash by default, depth -s's name hash
+        // with STA_SCAN_DEPTH_S=1
+        if (getenv("STA_SCAN_DEPTH_S")) { pc.tpl = PumpConfig::TPL_DEPTH; pc.use_endpos = true; pc.depth_filter.flag = 4 | 256 | 512 | 1024; }
+        else { pc.tpl = PumpConfig::TPL_MPLP; pc.pushed = [](const Rec &r) { return !(r.flag & 0x704) && r.mapq >= 1; }; }
         std::unique_ptr<WindowSource> src;
         if (stage == 2) src.reset(new ChunkPump(readers, pc, threads > 0 ? threads : io_default_threads()));
         else src.reset(new Pump(readers, pc));
@@ -75,6 +76,7 @@ extern "C" int sta_io_scan(const char *path, int threads, int stage, uint64_t *n
                 cursor = std::max(cursor, std::min(pump.carry_next_covered(cursor), pump.next_pos(tid)));
                 int64_t ce = pump.fill_staged(tid, cursor, cursor + pc.window_cols, staged);
                 if (pump.error()) break;
+                pump.pair_staged(staged);
                 if (pump.next_pos(tid) == INT64_MAX) {
                     int64_t me = pump.carry_max_end();
                     if (me != INT64_MIN) ce = std::min(ce, std::max(me, cursor));
@@ -92,6 +94,7 @@ extern "C" int sta_io_scan(const char *path, int threads, int stage, uint64_t *n
                     f.bytes(sf.cig_off.data(), sf.cig_off.size() * 4); f.bytes(sf.base_off8.data(), sf.base_off8.size() * 4); f.bytes(sf.name_off.data(), sf.name_off.size() * 4);
                     f.bytes(sf.cigar.data(), sf.cigar.size() * 4); f.bytes(sf.qual.data(), sf.qual.size()); f.bytes(sf.seq.data(), sf.seq.size());
                     f.bytes(sf.names.data(), sf.names.size()); f.u64(sf.any_bq); if (sf.any_bq) f.bytes(sf.bq.data(), sf.bq.size());
+                    f.u64((uint64_t)sf.tpl); f.bytes(sf.clip.data(), sf.clip.size() * 8); f.bytes(sf.mate.data(), sf.mate.size() * 4);
                     uint64_t spans = 0;
                     for (size_t i = 0; i < sf.pos.size(); ++i) spans = spans * 3 + (pump.staged_has_span(fi, i) ? 1 : 0);
                     f.u64(spans);

@@ -18,6 +18,7 @@ void StagedFile::clear()
     mod_off.clear(); mod_qpos.clear(); mod_toff.clear(); mod_text.clear(); with_mods = false;
     any_bq = false;
     raw_first = -1; raw_verify = 0; raw_pieces.clear(); raw_rec_off.clear(); raw_keep.clear();
+    clip.clear(); mate.clear(); tpl = 0;
 }
 
 void StagedFile::add(const Rec &r, int64_t origin, const std::set<std::string> *rg_excl, const XcolSpec *xs)
@@ -269,6 +270,8 @@ sta_reads StagedFile::view() const
         v.mod_off = mod_off.data(); v.mod_qpos = mod_qpos.data(); v.mod_toff = mod_toff.data(); v.mod_text = mod_text.data();
         v.n_mod_entries = mod_qpos.size(); v.n_mod_bytes = mod_text.size();
     }
+    if (tpl == 1 && clip.size() == pos.size()) v.olap_clip = clip.data();
+    if (tpl == 2 && mate.size() == pos.size()) v.olap_mate = mate.data();
     v.raw_first = v.n_reads;
     if (raw_first >= 0 && !raw_pieces.empty() && !any_bq) {
         v.raw_first = raw_first; v.n_raw_pieces = (int32_t)raw_pieces.size(); v.raw_pieces = raw_pieces.data(); v.raw_rec_off = raw_rec_off.data();

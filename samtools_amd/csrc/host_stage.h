@@ -43,6 +43,9 @@ struct StagedFile {
     // --output-mods (host_mods.cpp): entries of read i = mod_off[i] .. mod_off[i+1], sorted by query position
     pvector<uint32_t> mod_off, mod_qpos, mod_toff; pvector<char> mod_text; bool with_mods = false;
     bool any_bq = false;
+    // template state kept by the input lane (host_names.h; sta_reads.olap_clip / olap_mate): tpl = 1: clip[] filled (depth -s), 2: mate[] filled
+    // (mpileup overlaps), 0: neither -- the engine then replays the name hash from the staged names
+    pvector<int64_t> clip; pvector<int32_t> mate; int tpl = 0;
     void clear();
     // origin: absolute coordinate of relative 0; rg_excl: -G read groups to drop (may be null)
     void add(const Rec &r, int64_t origin, const std::set<std::string> *rg_excl, const XcolSpec *xs = nullptr);

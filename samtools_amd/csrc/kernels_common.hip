@@ -464,7 +464,15 @@ __global__ void __launch_bounds__(256) k_prep_reads_depth(StaReadsDev R, StaWinD
         const bool simple = (c1 - c0 == 1) && cg_is_mop(R.cigar[c0] & 0xf) && lq == rlen && !(flag & BAM_FUNMAP);
         R.end[i] = cig_end;
         R.info[i] = (ok ? (RI_PUSHED | RI_KEEP) : 0) | ((flag & BAM_FREVERSE) ? RI_REV : 0) | (simple ? RI_SIMPLE : 0) | (cig_end != end ? RI_UNMAP_SPAN : 0);
-        R.clip[i] = 0;
+        {
+            // depth -s with the caller's name hash (sta_reads.olap_clip): the clip column, window relative
+            int32_t cl = 0;
+            if (R.clip_in) {
+                const long long c = (long long)R.clip_in[i];
+                if (c) { const long long rel = c - (long long)W.origin; cl = (int32_t)(rel > INT32_MAX ? INT32_MAX : (rel < INT32_MIN + 1 ? INT32_MIN + 1 : rel)); }
+            }
+            R.clip[i] = cl;
+        }
         if (ok) {
             kept += 1;
             ke = cig_end;

@@ -277,6 +277,20 @@ __global__ void __launch_bounds__(256) k_name_groups(StaReadsDev R, int64_t orig
     }
 }
 
+// mpileup with the caller's overlap hash (sta_reads.olap_mate, host_names.h): read i found the entry of read mate[i] at its push -- the
+// pair tweak_overlap_quality(mate[i], i) resolves.  Pairs are disjoint (a record puts an entry or finds one, once), so one thread per
+// finder is race free.
+__global__ void __launch_bounds__(256) k_olap_pairs(StaReadsDev R, const unsigned long long *gate)
+{
+    if (gate && *gate == 0) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R.n) return;
+    const int64_t m = R.mate[i];
+    if (m < 0 || m >= R.n || m == i) return;
+    if (!(R.info[i] & RI_KEEP) || !(R.info[m] & RI_KEEP)) return;
+    tweak_overlap(R, m, i);
+}
+
 // mpileup, before the name matching: everything the mate-overlap pass needs is set up by ONE launch that looks at the window's
 // number of eligible reads first (StaCounters.n_olap_el, counted by k_prep_reads).  None -- single-end data, the usual case of a
 // long-read or amplicon run: the file's device descriptor is pointed back at the input quality pool and loses its fix-up arrays, and
@@ -328,6 +342,10 @@ size_t sta_overlap_table_bytes(size_t slots) { return slots * sizeof(NameSlot); 
 void sta_launch_overlap(hipStream_t s, const StaReadsDev &r, int64_t origin, int32_t tid, void *table, size_t slots,
                         int32_t *chain_next, StaCounters *ctr)
 {
+    if (r.mate) {
+        if (r.n) hipLaunchKernelGGL(k_olap_pairs, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, s, r, &ctr->n_olap_el);
+        return;
+    }
     run_names(s, r, origin, tid, table, slots, chain_next, SEL_MPLP, ctr);
 }
 

@@ -19,6 +19,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <algorithm>
+#include "host_names.h"
 
 namespace {
 
@@ -30,7 +32,10 @@ struct LiveRead {
     bool constructed = false;
     bool accepted = false;           // carried from an earlier window whose -d replay kept it
     bool cap_dropped = false;        // removed by the -d cap in the window just processed
-    bool ghost = false;              // left the pileup (destructor done) but still staged: its mate is live (overlap resolution)
+    bool ghost = false;              // left the pileup (destructor done) but still staged: its partner in the overlap hash is live
+    // the overlap hash, kept in push order by the iterator itself (host_names.h): has this record been there; the record whose entry it
+    // found (-1: none); for both partners of such a pair the other one's end
+    bool hashed = false; int64_t mate_id = -1, mate_end = INT64_MIN;
     bam_pileup_cd cd;
     std::vector<uint8_t> orig_qual;  // qualities as pushed (mate-overlap resolution restarts from these in every window)
 };
@@ -156,6 +161,7 @@ struct sta_bam_plp {
     bool eof = false;
     int error = 0;
     uint64_t next_id = 0;
+    sta::OverlapNames onames;          // HTSlib's overlap hash (overlap_push / overlap_remove) over everything pushed so far
     int max_tid = -1; int64_t max_pos = -1;
     // current window
     bool have_win = false;
@@ -215,24 +221,15 @@ void retire(sta_bam_plp *it)
 {
     // reads that cannot reach a column >= ce leave the iterator (destructor hook, like bam_plp_next's mp_free)
     std::deque<LiveRead *> keep;
-    // Overlap resolution is re-derived from the pushed qualities in every window, and HTSlib may rewrite bases of one mate
-    // beyond the other mate's end (deletion branch of tweak_overlap_quality): a read whose mate stays is kept staged as a
-    // "ghost" -- destructor hook fired, no columns -- until the mate leaves too.
-    std::vector<const LiveRead *> stay;
-    if (it->overlaps)
-        for (const LiveRead *r : it->live)
-            if (r->end > it->ce && !r->cap_dropped && (r->b.core.flag & 1) && (r->b.core.flag & 2) && !(r->b.core.flag & 8)) stay.push_back(r);
-    auto mate_stays = [&](const LiveRead *r) {
-        const auto &c = r->b.core;
-        if (!(c.flag & 1) || !(c.flag & 2) || (c.flag & 8) || c.mtid != c.tid) return false;
-        for (const LiveRead *s : stay) if (s != r && s->b.core.pos == c.mpos && !strcmp(bam_get_qname(&s->b), bam_get_qname(&r->b))) return true;
-        return false;
-    };
+    // Overlap resolution is re-derived from the pushed qualities in every window, and tweak_overlap_quality rewrites both partners from
+    // both: a read whose partner in the overlap hash (found by the iterator's own hash, in push order) can still touch a column is kept
+    // staged as a "ghost" -- destructor hook fired, no columns -- until the partner leaves too.
+    auto mate_stays = [&](const LiveRead *r) { return it->overlaps && r->mate_end > it->ce; };
     for (LiveRead *r : it->live) {
         if (r->end <= it->ce || r->cap_dropped) {
             if (r->constructed && it->dtor) it->dtor(it->data, &r->b, &r->cd);
             r->constructed = false;
-            if (!r->cap_dropped && !stay.empty() && mate_stays(r)) { r->ghost = true; r->accepted = true; keep.push_back(r); }
+            if (!r->cap_dropped && mate_stays(r)) { r->ghost = true; r->accepted = true; keep.push_back(r); }
             else free_read(r);
         } else { r->accepted = true; keep.push_back(r); }
     }
@@ -303,8 +300,42 @@ int build_window(sta_bam_plp *it)
     w.tid = tid; w.origin = origin; w.col_beg = (int32_t)(cb - origin); w.col_end = (int32_t)(ce - origin);
     w.tname = ""; w.tlen = INT64_MAX; w.n_files = 1; w.files = &rv; w.mem = STA_MEM_HOST;
     sta_plan_info pi;
-    if (sta_stage_window(it->eng, &w) != STA_OK || sta_plp_plan(it->eng, it->maxcnt, it->overlaps ? 1 : 0, &pi) != STA_OK
-        || sta_plp_emit(it->eng, nullptr, 0) != STA_OK) {
+    // The overlap hash is the iterator's own (host_names.h), in push order; who the -d cap turns away at the push is the plan's to say, so
+    // the plan stops in front of its overlap pass and asks (sta_set_mate_resolver): the window's new reads visit the hash, every read gets
+    // the staged index of the record whose entry it found
+    if (it->overlaps)
+        sta_set_mate_resolver(it->eng, [](void *user, int32_t, const uint32_t *state, int64_t n, int32_t *mate_out) {
+            sta_bam_plp *p = (sta_bam_plp *)user;
+            const std::vector<LiveRead *> &wr = p->win_reads;
+            for (int64_t i = 0; i < n && (size_t)i < wr.size(); ++i) {
+                LiveRead *r = wr[(size_t)i];
+                mate_out[i] = -1;
+                if (!r->hashed) {
+                    r->hashed = true;
+                    const bam1_t *b = &r->b;
+                    const int64_t span = ref_span(b);
+                    const bool pushed = (state[i] & 1u) != 0, dropped = pushed && !(state[i] & 2u) && span > 0;
+                    if (pushed) {
+                        sta::OverlapNames::Read q;
+                        q.qname = bam_get_qname(b); q.l_qname = (uint32_t)strnlen(q.qname, b->core.l_qname); q.h = sta::qname_hash64(q.qname, q.l_qname);
+                        q.flag = b->core.flag; q.tid = b->core.tid; q.mtid = b->core.mtid; q.l_qseq = b->core.l_qseq;
+                        q.pos = b->core.pos; q.end = b->core.pos + span; q.mpos = b->core.mpos; q.isize = b->core.isize; q.id = (int64_t)b->id;
+                        r->mate_id = p->onames.push(q, dropped);
+                    }
+                }
+                if (r->mate_id < 0) continue;
+                // (win_reads is in push order: ids ascend)
+                auto h = std::lower_bound(wr.begin(), wr.begin() + i, r->mate_id, [](const LiveRead *x, int64_t v) { return (int64_t)x->b.id < v; });
+                if (h != wr.begin() + i && (int64_t)(*h)->b.id == r->mate_id) {
+                    mate_out[i] = (int32_t)(h - wr.begin());
+                    r->mate_end = (*h)->end; (*h)->mate_end = r->end;
+                }
+            }
+            return 0;
+        }, it);
+    const bool plan_ok = sta_stage_window(it->eng, &w) == STA_OK && sta_plp_plan(it->eng, it->maxcnt, it->overlaps ? 1 : 0, &pi) == STA_OK;
+    sta_set_mate_resolver(it->eng, nullptr, nullptr);
+    if (!plan_ok || sta_plp_emit(it->eng, nullptr, 0) != STA_OK) {
         fprintf(stderr, "[E::bam_plp] %s\n", sta_last_error(it->eng));
         it->error = 1; return ST_ERR;
     }
@@ -485,6 +516,7 @@ void sta_bam_plp_reset(sta_bam_plp_t it)
     if (!it) return;
     clear_reads(it);
     it->eof = false; it->error = 0; it->max_tid = -1; it->max_pos = -1;
+    it->onames = sta::OverlapNames();
     it->have_win = false; it->prev_tid = -1; it->prev_ce = -1; it->n_new = 0;
     it->offs.clear(); it->ent.clear();
 }

@@ -43,6 +43,10 @@ struct StaReadsDev {
     uint64_t n_bases_total;
     int32_t n_xcols; const uint32_t *xcol_off; const char *xcol_text;     // host-formatted text columns (RNEXT, aux tags)
     const uint32_t *mod_off, *mod_qpos, *mod_toff; const char *mod_text;  // --output-mods: per-read modification text (NULL: none)
+    // what every read found in the reference's name hash, kept by the caller in file order (sta_reads.olap_clip / olap_mate; NULL: the
+    // device replays the hash from the staged names, kernels_overlap.hip)
+    const int64_t *clip_in;     // depth -s: absolute column below which the read is not counted (0: none)
+    const int32_t *mate;        // mpileup: read whose overlap-hash entry this one found (-1: none)
     // engine workspace
     uint8_t *qual;        // working qualities (== qual_in when nothing rewrites them)
     int32_t *end;         // pos + reference span

@@ -19,7 +19,7 @@ EOT
 S=$R/samtools_amd/csrc
 for san in thread address,undefined; do
   g++ -std=c++17 -g -O1 -fsanitize=$san -fno-omit-frame-pointer -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Wno-deprecated-declarations \
-      $S/host_bgzf.cpp $S/host_inflate.cpp $S/host_bamout.cpp $S/host_io.cpp $S/host_chunk.cpp $S/host_pump.cpp $S/host_stage.cpp $S/host_scan.cpp $S/host_pinned.cpp $S/host_mods.cpp $R/tests/cpu/gpu_inflate_stub.cpp $T/scan_main.cpp \
+      $S/host_bgzf.cpp $S/host_inflate.cpp $S/host_bamout.cpp $S/host_io.cpp $S/host_chunk.cpp $S/host_pump.cpp $S/host_names.cpp $S/host_stage.cpp $S/host_scan.cpp $S/host_pinned.cpp $S/host_mods.cpp $R/tests/cpu/gpu_inflate_stub.cpp $T/scan_main.cpp \
       -o $T/scan_${san%%,*} -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lz -pthread
 done
 export STA_NO_PINNED=1 ASAN_OPTIONS=detect_leaks=0

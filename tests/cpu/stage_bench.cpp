@@ -30,7 +30,7 @@ int main(int argc, char **argv)
     readers.push_back(std::move(r));
     PumpConfig pc; pc.window_cols = wcols; pc.use_endpos = !mplp;
     if (getenv("STA_FAKE_GPU_INFLATE")) pc.inflate_device = 0;       // (tests/cpu/gpu_inflate_stub.cpp: the feeder / parser threading without a GPU)
-    if (mplp) { pc.keep_mates = true; pc.surely_pushed = [](const Rec &rec) { return !(rec.flag & 4); }; }
+    if (mplp) { pc.tpl = PumpConfig::TPL_MPLP; pc.pushed = [](const Rec &rec) { return !(rec.flag & 4); }; }
     const double t0 = now();
     ChunkPump pump(readers, pc, threads);
     std::vector<StagedFile> ring[3];

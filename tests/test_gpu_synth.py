@@ -532,7 +532,8 @@ def _add_upstream_supplementaries(sam, every, gap_lo, gap_hi, seed):
 @pytest.mark.parametrize("gap", [(10, 120), (0, 4)], ids=["gap10_120", "gap0_4"])
 @pytest.mark.parametrize("opts", [[], ["-l", "{bed}"], ["-B", "-C", "50"]], ids=["plain", "bed", "B_C50"])
 def test_supplementary_upstream_of_a_pair_across_window_cuts(tmp_path, oracle_bin, product_bin, opts, gap):
-    """A record kept staged only for its mate's sake (PumpConfig::keep_mates) must not look like the holder of the template's overlap-hash
+    """(Round 5's per-window replay; since round 6 the input lane keeps HTSlib's overlap hash itself in file order -- host_names.h -- and these
+    are regression tests of that state machine.)  A record kept staged only for its mate's sake must not look like the holder of the template's overlap-hash
     entry in the next window when the reference freed it long ago: bam_plp_next frees a node once a read beyond its end was pushed, and
     overlap_remove deletes the entry BY NAME.  Three records of one template -- a supplementary alignment upstream of an overlapping
     primary pair -- with a window cut between them: the engine paired the supplementary with the first mate and left the real pair
@@ -561,6 +562,66 @@ def test_supplementary_upstream_of_a_pair_across_window_cuts(tmp_path, oracle_bi
     assert got.returncode == 0 and got.stdout == want, (opts, "record-at-a-time lane")
 
 
+def _add_four_record_templates(sam, every, seed):
+    """For every `every`-th proper pair whose mates lie 120-500 columns apart add TWO supplementary alignments of the second mate without the
+    proper-pair bit: one a few columns behind the first primary, one a few columns in front of the second primary, each naming the primary
+    next to it as its mate -- the shape of template t495 of scripts/hunt8.py seed 104 (primary 115 @7070, supplementary 2225 @7076,
+    supplementary 2225 @7416, primary 179 @7419).  In bam2depth.c's hash the first primary does not insert (its mate starts beyond its end),
+    the first supplementary does, the second one finds that entry 340 columns later and takes it out, and the second primary inserts: it
+    is NOT clipped.  A replay that sees only the last two records clips it."""
+    import random
+    rnd = random.Random(seed)
+    head, recs = [], []
+    for line in open(sam):
+        (head if line.startswith("@") else recs).append(line)
+    by_name = {}
+    for line in recs:
+        f = line.rstrip("\n").split("\t")
+        by_name.setdefault(f[0], []).append(f)
+    extra, k = [], 0
+    for name, fs in by_name.items():
+        if len(fs) != 2 or not (int(fs[0][1]) & 2):
+            continue
+        a, b = fs
+        if not 120 <= int(b[3]) - int(a[3]) <= 500:
+            continue
+        k += 1
+        if k % every:
+            continue
+        flag = (int(b[1]) & ~2) | 2048
+        for base, mate, lo, hi in ((int(a[3]), a, 1, 9), (int(b[3]), b, -9, -1)):
+            L = rnd.randint(40, 90)
+            spos = base + rnd.randint(lo, hi)
+            if spos < 1:
+                continue
+            extra.append((spos, "\t".join([name, str(flag), b[2], str(spos), b[4], "%dM" % L, "=", mate[3], "0", b[9][:L], b[10][:L]]) + "\n"))
+    allr = [(int(l.split("\t")[3]), i, l) for i, l in enumerate(recs)] + [(p, len(recs) + j, l) for j, (p, l) in enumerate(extra)]
+    allr.sort(key=lambda t: (t[0], t[1]))
+    open(sam, "w").write("".join(head) + "".join(t[2] for t in allr))
+    return len(extra)
+
+
+def test_four_records_of_a_template_across_window_cuts(tmp_path, oracle_bin, product_bin):
+    """Both name hashes of the path are sequential state over the whole file: depth -s's "never forgets" (bam2depth.c:598-623: an entry leaves
+    only when a record of its name finds it), and HTSlib's overlap hash loses an entry BY NAME whenever any record of the template leaves
+    the pileup buffer.  Round 5 replayed them per window from the staged records and got templates with four records wrong
+    at window cuts (scripts/hunt8.py seed 104, `c3 7419` one count short under windows of 4 and 13 reads and of 37 columns,
+    SAM and BAM lanes).  The input lanes now keep both hashes themselves in file order (host_names.h) and stage what every record found;
+    this input has such a template every few hundred columns."""
+    from bamio import sam_to_bam
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=9000, depth=10, read_len=100, seed=917, paired=True)      # mates ~200 columns apart
+    assert _add_four_record_templates(sam, 3, 11) > 60
+    bam = sam_to_bam(sam, str(tmp_path / "s.bam"), level=1, block=3000)
+    for args in (["depth", "-s"], ["depth", "-s", "-J"], ["depth", "-s", "-g", "SECONDARY"], ["mpileup", "-f", fa], ["mpileup", "-B", "-Q", "0", "-f", fa]):
+        want = subprocess.run([oracle_bin] + args + [sam], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        assert want.count(b"\n") > 6000
+        for env in ({"STA_WINDOW_READS": "4"}, {"STA_WINDOW_READS": "13"}, {"STA_WINDOW_COLS": "37"}, {"STA_WINDOW_READS": "2"}, {}):
+            for inp, lane in ((sam, "chunk"), (bam, "chunk"), (bam, "rec")):
+                got = subprocess.run([product_bin] + args + [inp], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, STA_IO_LANE=lane, **env))
+                assert got.returncode == 0, got.stderr.decode()[-500:]
+                assert got.stdout == want, (args, env, os.path.basename(inp), lane)
+
+
 @pytest.mark.parametrize("gap", [(10, 120), (0, 4)], ids=["gap10_120", "gap0_4"])
 def test_depth_s_with_three_records_of_a_template_across_window_cuts(tmp_path, oracle_bin, product_bin, gap):
     """depth -s (bam2depth.c:598-623): the first-seen record of a template puts its name and end into a hash, the next one finds it, is
@@ -568,7 +629,8 @@ def test_depth_s_with_three_records_of_a_template_across_window_cuts(tmp_path, o
     staged records: with a supplementary alignment upstream of an overlapping pair and a cut behind it, the first primary looked like the
     first-seen record and the second was clipped, where the reference had let the first primary consume the supplementary's entry and left
     the second alone (found by scripts/hunt6.py seed 47 with 5-read windows, round 5).  A record that has ended now stays staged while its
-    mate does (PumpConfig::keep_mates for depth -s, any paired read with a mapped mate)."""
+    mate does (round 5); since round 6 the input lane keeps the name hash itself in file order and stages every record's clip column
+    (host_names.h, sta_reads.olap_clip), so no window depends on records it does not stage."""
     from bamio import sam_to_bam
     sam, fa = write_synth_sam(str(tmp_path), n_ref=6000, depth=12, read_len=200, seed=615, paired=True)      # insert ~ 300: every pair overlaps
     assert _add_upstream_supplementaries(sam, 2, gap[0], gap[1], 6) > 40

@@ -787,6 +787,16 @@ def run_workload(a, wlname, ctx, secondary=False):
                              "backend": backend, "bytes_total": sum(sizes), "bytes_over_links": moved,
                              "ms_isolated": gather_ms, "gbs_isolated": moved / (gather_ms * 1e-3) / 1e9 if gather_ms else None,
                              "wait_ms_per_step_rank0": per_rank[0]["gather_wait_ms"]}
+            # The ceiling of the design: every rank's text crosses ITS OWN xGMI link into rank 0 (point to point,
+            # 7 links, 76.8 GB/s per direction at the link's peak = the "~153 GB/s" per link of both directions), all links at once, so
+            # one step's gather takes the largest peer block / 76.8 GB/s at best.  A step that computes faster than that is gather-bound:
+            # the N-GPU factor over one GPU is then N x (one-GPU step) / (gather time), not N.
+            XGMI_GBS_PER_DIR = 76.8
+            peer_max = max(sizes[1:]) if len(sizes) > 1 else 0
+            pred_ms = peer_max / (XGMI_GBS_PER_DIR * 1e9) * 1e3
+            res["gather"]["predicted"] = {"xgmi_link_gbs_per_direction_peak": XGMI_GBS_PER_DIR, "largest_peer_block_bytes": peer_max,
+                                          "ms_at_link_peak": pred_ms, "measured_over_predicted": (gather_ms / pred_ms) if gather_ms and pred_ms else None,
+                                          "step_is_gather_bound_at_link_peak": bool(pred_ms > res["ms_per_step"])}
         if kind in ("mpileup", "depth") and a.verify:
             # the timed window itself, byte for byte (hash of the whole text) against the oracle on the same seeds
             o = oracle_text_hash(wlname, n_cols, chunk_cols=cols_per_gpu)

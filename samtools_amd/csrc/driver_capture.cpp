@@ -66,7 +66,7 @@ void DevEngines::start(int device)
     std::lock_guard<std::mutex> lk(m_);
     if (started_) return;
     started_ = true;
-    th_ = std::thread([this, device] { rc_ = create(device); });
+    th_ = std::thread([this, device] { rc_ = create(device); timeline_mark("HIP runtime and engine(s) up"); });
 }
 int DevEngines::ready()
 {

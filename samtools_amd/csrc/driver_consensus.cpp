@@ -3,8 +3,8 @@
 // the reference does once per column after consensus_base(): the FASTA / FASTQ assembly with its gap filling
 // (basic_fasta, bam_consensus.c:2323-2455; dump_fastq :2054-2075), the pileup rows (basic_pileup :2191-2317, empty_pileup2
 // :2107-2131) and the per-region loop of the serial driver (:2898-3075).  The threaded driver (:2626-2890) produces the same
-// text and is not mirrored; -X presets and named calibration tables other than :flat are refused (their tables are data of
-// the reference that this tree does not carry).
+// text and is not mirrored; -X presets and the named calibration tables are built (cons_qcal_tables.inc: the reference's arrays
+// extracted as data by scripts/gen_qcal_tables.py).
 #include "cons_host.h"
 #include "host_io.h"
 #include "host_bgzf.h"

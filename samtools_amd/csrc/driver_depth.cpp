@@ -241,6 +241,7 @@ void usage_exit(FILE *fp)
 
 extern "C" int sta_main_depth(int argc, char **argv)
 {
+    timeline_mark("main entered");
     DRunner run;
     run.devs.start(getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0);
     if (getenv("STA_DRIVER_TIMING")) sta::report_thread_budget();      // the runtime comes up while the inputs are opened and decoded
@@ -337,18 +338,22 @@ extern "C" int sta_main_depth(int argc, char **argv)
         for (auto &fn : fns) fprintf(run.out, "\t%s", fn.c_str());
         fputc('\n', run.out);
     }
+    timeline_mark("options read, inputs open");
     run.no_reads_d.resize((size_t)run.devs.n());
     fflush(run.out);                  // the header line: the writer thread owns the stream from here on
     int ret;
     {
         run.pipe.reset(new WinPipe(pipe_slots_from_env(run.devs.n()), [&run](WinJob &j, int d) { return run.device_stage(j, d); }, run.out, "samtools depth: failed to write the output\n", run.devs.n()));
         ret = run.run();
+        timeline_mark("last window submitted and drained");
         run.pipe.reset();
+        timeline_mark("pipeline threads joined");
     }
     fflush(run.out);
     if (!driver_out_is_borrowed(run.out)) fclose(run.out);
     // (an input without a single window never asked for the engine: a machine without a device is an error all the same)
     if (run.devs.ready() != STA_OK) { if (!run.no_device.exchange(true)) fprintf(stderr, "samtools depth: no usable HIP device (the MI355X engine has no CPU fallback)\n"); ret = 1; }
     run.devs.destroy();
+    timeline_mark("engines destroyed");
     return ret;
 }

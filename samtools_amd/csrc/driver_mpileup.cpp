@@ -396,6 +396,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
 {
     // the HIP runtime and the engine come up on their own thread while the options are read, the FASTA is loaded, the inputs are opened
     // and their decode threads fill the first windows (DevEngines, driver_pipeline.h); declared first = destroyed last
+    timeline_mark("main entered");
     DevEngines devs;
     devs.start(getenv("STA_DEVICE") ? atoi(getenv("STA_DEVICE")) : 0);
     if (getenv("STA_DRIVER_TIMING")) sta::report_thread_budget();
@@ -580,15 +581,19 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     else if ((long long)mp.max_depth * (long long)fns.size() > 1 << 20) fprintf(stderr, "[mpileup] Combined max depth is above 1M. Potential memory hog!\n");
 
     run.dev_ref_tid.assign((size_t)run.devs.n(), -2); run.no_reads_d.resize((size_t)run.devs.n());
+    timeline_mark("options read, FASTA loaded, inputs open");
     int ret;
     {
         run.pipe.reset(new WinPipe(pipe_slots_from_env(run.devs.n()), [&run](WinJob &j, int d) { return run.device_stage(j, d); }, run.out, "Failed to write pileup data.\n", run.devs.n()));
         ret = run.run();
+        timeline_mark("last window submitted and drained");
         run.pipe.reset();                 // joins the device and writer threads (everything is written)
+        timeline_mark("pipeline threads joined");
     }
     fflush(run.out);
     if (!driver_out_is_borrowed(run.out)) fclose(run.out);
     if (run.devs.ready() != STA_OK) { if (!run.no_device.exchange(true)) fprintf(stderr, "samtools mpileup: no usable HIP device (the MI355X engine has no CPU fallback)\n"); ret = 1; }
     run.devs.destroy();
+    timeline_mark("engines destroyed");
     return ret;
 }

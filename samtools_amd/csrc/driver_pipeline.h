@@ -10,6 +10,11 @@
 // producer.  The producer can wait for a job's device stage when the NEXT window depends on its result (the -d cap dropped
 // reads; `-a` still waiting for the contig's first data column) -- everything else runs ahead.
 #pragma once
+#include <unistd.h>
+#include <ctime>
+#include <cstring>
+#include <cstdlib>
+#include <cstdio>
 #include "host_stage.h"
 #include "host_pump.h"
 #include "../../include/samtools_amd.h"
@@ -24,6 +29,29 @@
 #include <vector>
 
 namespace sta {
+
+// STA_DRIVER_TIMING=2: where a whole process's wall time goes outside the window pipeline -- every mark prints the seconds since the
+// process was started (its start time from /proc/self/stat, so that loading the executable and the HIP libraries is inside)
+inline void timeline_mark(const char *what)
+{
+    static const int on = [] { const char *e = getenv("STA_DRIVER_TIMING"); return e && atoi(e) >= 2 ? 1 : 0; }();
+    if (!on) return;
+    static const double t_start = [] {
+        double st = -1;
+        if (FILE *f = fopen("/proc/self/stat", "r")) {
+            char buf[2048]; size_t n = fread(buf, 1, sizeof buf - 1, f); buf[n] = 0; fclose(f);
+            if (const char *p = strrchr(buf, ')')) {
+                unsigned long long ticks = 0; int field = 2;
+                for (const char *q = p + 1; *q && field < 22; ++q) if (*q == ' ') { ++field; if (field == 22) ticks = strtoull(q + 1, nullptr, 10); }
+                if (ticks) st = (double)ticks / (double)sysconf(_SC_CLK_TCK);
+            }
+        }
+        return st;
+    }();
+    timespec ts; clock_gettime(CLOCK_BOOTTIME, &ts);
+    const double nowb = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    fprintf(stderr, "[timeline] +%.3f s %s\n", t_start >= 0 ? nowb - t_start : 0.0, what);
+}
 
 struct WinJob {
     // set by the producer

@@ -271,7 +271,11 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
     if (e->fb.size() < (size_t)w->n_files) e->fb.resize((size_t)w->n_files);
     e->files_h.assign((size_t)w->n_files, StaReadsDev{});
     bool any_raw = false;
-    if (e->stage_bad_pending) { SYNC_STREAM(); }        // (a window staged and never used: its verdict is not lost)
+    if (e->stage_bad_pending) {
+        // a window staged and never used: its verdict is not lost -- and is reported as what it is, the PREVIOUS window's
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (int v_ = stage_verdict(e)) { e->err = "the previously staged window (never planned): " + e->err; return v_; }
+    }
     for (int f = 0; f < w->n_files; ++f) {
         const sta_reads &r = w->files[f];
         FileBufs &b = e->fb[(size_t)f];

@@ -14,6 +14,9 @@
 #include <math.h>
 #include <cstdlib>
 #include <algorithm>
+#include <cstring>
+#include <map>
+#include <mutex>
 
 #define EI .25
 #define EM .33333333333
@@ -266,17 +269,16 @@ size_t sta_baq_scratch_bytes(int64_t n_reads, int max_lq, int max_bw)
     return (size_t)3 << 30;     // fixed 3 GiB slab, reads are processed in chunks that fit it
 }
 
-static BaqTables g_tables;
-static bool g_tables_init = false;
-static bool g_logtab_ok = false;
-static void baq_tables_fill();
-static void baq_tables_init() { if (!g_tables_init) { baq_tables_fill(); g_tables_init = true; } }
-
+// The tables the BAQ kernels take by value: g_qual2prob, and a pointer to the MAP-quality threshold table in device memory.  The host
+// copies are built once (function-local static: thread safe); the device copy exists once PER DEVICE, made under a lock by the first
+// launch on that device -- an engine on a second device (sta_engine_create(device = N)) or a second device thread of a driver
+// (STA_DEV_THREADS) must never see another device's pointer or a half-built table.
+static BaqTables baq_tables(bool *logtab_ok = nullptr);
 void sta_launch_baq(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int redo, void *scratch, size_t scratch_bytes,
                          int lq_max, int bw_max, int64_t n_slow)
 {
-    baq_tables_init();
     if (r.n == 0 || lq_max <= 0 || n_slow <= 0) return;
+    const BaqTables g_tables = baq_tables();
     int idim_max = (bw_max * 2 + 1) * 3 + 6;
     size_t dbl_per_read = (size_t)(lq_max + 1) * idim_max + (size_t)2 * idim_max + (size_t)(lq_max + 2);
     size_t bytes_per_read = dbl_per_read * 8 + (size_t)lq_max * 5;
@@ -915,6 +917,7 @@ size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_l
 template <int BW, int DEC>
 static void run_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int64_t g0, int64_t ng, int use_list, int pass)
 {
+    const BaqTables g_tables = baq_tables();
     unsigned nb = (unsigned)((ng + 3) / 4);
     // the slot stride is the same for both band widths (the engine sizes one slab for either): the larger of the two layouts
     size_t slot = std::max(baq_slot_dbl(lq_cap, 8), baq_slot_dbl(lq_cap, 7));
@@ -929,8 +932,8 @@ static void run_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, vo
 // both passes of the list's band-width-bw reads (ng groups of 64 list entries) in one launch, blocks of one wave
 void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw, int64_t ng)
 {
-    baq_tables_init();
     if (r.n == 0 || lq_cap <= 0 || ng <= 0) return;
+    const BaqTables g_tables = baq_tables();
     const size_t slot = std::max(baq_slot_dbl(lq_cap, 8), baq_slot_dbl(lq_cap, 7));
     const unsigned nb = (unsigned)((ng + 3) / 4);
     const bool plds = lq_cap <= BAQ_LDS_ROWS_MAX;
@@ -949,7 +952,6 @@ void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
 void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw,
                          int64_t g0, int64_t ng, int use_list, int pass)
 {
-    baq_tables_init();
     if (r.n == 0 || lq_cap <= 0 || ng <= 0) return;
     if (bw == 7) { if (baq_dec_mode() == 2) run_band<7, 2>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass); else run_band<7, 1>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass); }
     else if (bw == 8) run_band<8, 0>(s, r, w, scratch, lq_cap, g0, ng, use_list, pass);
@@ -965,18 +967,44 @@ void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
 #ifndef BAQ7S_DEFAULT_MODE
 #define BAQ7S_DEFAULT_MODE 16          // baq7s::M_LOGTAB
 #endif
-static void baq_tables_fill()
+struct BaqHostTables { float q2p[256]; baq7s::LogTab lt; bool lt_ok; };
+static const BaqHostTables &baq_host_tables()
 {
-    for (int i = 0; i < 256; ++i) g_tables.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
-    baq7s::LogTab lt;
-    g_logtab_ok = baq7s::make_log_thresholds(lt);     // false: this host's log() is not a clean step function around a threshold -> the formula
-    g_tables.lt = nullptr;
-    if (g_logtab_ok && !getenv("STA_BAQ_NO_LOGTAB")) {
-        // (one engine device per process: the table lives on the device that is current when the first BAQ launch is made)
-        double *dp = nullptr;
-        if (hipMalloc((void **)&dp, sizeof lt.t) == hipSuccess && hipMemcpy(dp, lt.t, sizeof lt.t, hipMemcpyHostToDevice) == hipSuccess) g_tables.lt = dp;
-        else { (void)hipGetLastError(); g_logtab_ok = false; }
-    } else g_logtab_ok = false;
+    static const BaqHostTables t = [] {
+        BaqHostTables h;
+        for (int i = 0; i < 256; ++i) h.q2p[i] = (float)pow(10, -i / 10.);   // g_qual2prob (probaln.c), host libm
+        h.lt_ok = baq7s::make_log_thresholds(h.lt);       // false: this host's log() is not a clean step function around a threshold -> the formula
+        return h;
+    }();
+    return t;
+}
+
+static BaqTables baq_tables(bool *logtab_ok)
+{
+    const BaqHostTables &h = baq_host_tables();
+    BaqTables T;
+    memcpy(T.q2p, h.q2p, sizeof T.q2p);
+    T.lt = nullptr;
+    if (h.lt_ok && !getenv("STA_BAQ_NO_LOGTAB")) {
+        static std::mutex m;
+        static std::map<int, const double *> by_dev;       // device -> its copy of the threshold table (nullptr: no memory for it, the formula then)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+        std::lock_guard<std::mutex> g(m);
+        auto it = by_dev.find(dev);
+        if (it == by_dev.end()) {
+            double *dp = nullptr;
+            if (dev < 0 || hipMalloc((void **)&dp, sizeof h.lt.t) != hipSuccess || hipMemcpy(dp, h.lt.t, sizeof h.lt.t, hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipGetLastError();
+                if (dp) (void)hipFree(dp);
+                dp = nullptr;
+            }
+            it = by_dev.emplace(dev, dp).first;
+        }
+        T.lt = it->second;
+    }
+    if (logtab_ok) *logtab_ok = T.lt != nullptr;
+    return T;
 }
 
 __device__ __forceinline__ double baq_uni(double x)       // a wave-uniform double into scalar registers
@@ -1149,8 +1177,9 @@ size_t sta_baq7s_scratch_bytes(int lq_cap, int64_t ngroups, int *waves_out)
 
 void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int waves, int64_t ngroups)
 {
-    baq_tables_init();
     if (ngroups <= 0 || waves <= 0 || !r.s_ws) return;
+    bool g_logtab_ok = false;
+    const BaqTables g_tables = baq_tables(&g_logtab_ok);       // (an M_LOGTAB instantiation is never launched without this device's table)
     static const int lead = [] { const char *e = getenv("STA_BAQ7S_LEAD"); return e ? atoi(e) : 1; }();   // 0: every wave forward-then-backward; 1: odd waves one forward pass ahead
     hipMemsetAsync(scratch, 0, 256, s);
     // STA_BAQ7S_MODE: 0 non-temporal row stream (default), 1 plain loads / stores; 2, 3: diagnostics with wrong results (baq_band7s.h)

@@ -567,34 +567,45 @@ struct hts_base_mod_state { std::vector<sta::ModHit> hits; bool parsed = false; 
 
 namespace {
 int ks_reserve1(kstring_t *ks, size_t n) { if (ks->m < n) { char *t = (char *)realloc(ks->s, n); if (!t) return -1; ks->s = t; ks->m = n; } return 0; }
-// aux field `tag` of a record: pointer to its type byte, or NULL (BAM aux encoding, SAM specification 4.2.4)
-const uint8_t *aux_find(const bam1_t *b, const char *t1, const char *t2)
+// aux field `tag` of a record: pointer to its type byte, or NULL (BAM aux encoding, SAM specification 4.2.4).  Every field walked over --
+// and the one returned -- is checked to lie inside the record (a Z / H value ends in a NUL before the end, a B array's n elements fit), as
+// HTSlib's bam_aux_get does: a truncated or malformed aux block in a caller's bam1_t yields NULL, never a read behind b->data + l_data.
+// *vend (if asked for) = the first byte behind the returned field's value.
+const uint8_t *aux_find1(const bam1_t *b, const char *tag, const uint8_t **vend)
 {
+    if (b->core.l_qseq < 0 || b->l_data < 0) return nullptr;
     const uint8_t *p = bam_get_qual(b) + b->core.l_qseq, *end = b->data + b->l_data;
-    while (p + 3 <= end) {
-        const bool hit = (p[0] == (uint8_t)t1[0] && p[1] == (uint8_t)t1[1]) || (p[0] == (uint8_t)t2[0] && p[1] == (uint8_t)t2[1]);
-        const uint8_t *v = p + 2;
-        if (hit) return v;
-        const int ty = *v++;
+    if (p > end) return nullptr;
+    while (end - p >= 3) {
+        const bool hit = p[0] == (uint8_t)tag[0] && p[1] == (uint8_t)tag[1];
+        const uint8_t *t = p + 2, *v = t + 1;
         size_t sz = 0;
-        switch (ty) {
+        switch (*t) {
         case 'A': case 'c': case 'C': sz = 1; break;
         case 's': case 'S': sz = 2; break;
         case 'i': case 'I': case 'f': sz = 4; break;
         case 'd': sz = 8; break;
         case 'Z': case 'H': { const uint8_t *q = v; while (q < end && *q) ++q; if (q >= end) return nullptr; sz = (size_t)(q - v) + 1; break; }
         case 'B': {
-            if (v + 5 > end) return nullptr;
+            if (end - v < 5) return nullptr;
             const int sub = v[0]; uint32_t n; memcpy(&n, v + 1, 4);
-            const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0;
+            if (!es || (size_t)n > ((size_t)(end - v) - 5) / es) return nullptr;
             sz = 5 + es * (size_t)n; break;
         }
         default: return nullptr;
         }
         if ((size_t)(end - v) < sz) return nullptr;
+        if (hit) { if (vend) *vend = v + sz; return t; }
         p = v + sz;
     }
     return nullptr;
+}
+// MM before Mm, ML before Ml (HTSlib looks the upper-case tag up first)
+const uint8_t *aux_find(const bam1_t *b, const char *t1, const char *t2, const uint8_t **vend = nullptr)
+{
+    const uint8_t *r = aux_find1(b, t1, vend);
+    return r ? r : aux_find1(b, t2, vend);
 }
 }  // namespace
 
@@ -615,7 +626,7 @@ int sta_bam_parse_basemod(const bam1_t *b, hts_base_mod_state *state)
     const uint8_t *mlv = nullptr; size_t n_ml = 0;
     if (ml) {
         if (ml[0] != 'B' || (ml[1] != 'C' && ml[1] != 'c')) return -1;
-        uint32_t n; memcpy(&n, ml + 2, 4); n_ml = n; mlv = ml + 6;
+        uint32_t n; memcpy(&n, ml + 2, 4); n_ml = n; mlv = ml + 6;          // (aux_find checked that the n bytes lie inside the record)
     }
     return sta::parse_base_mods(bam_get_seq(b), b->core.l_qseq, (b->core.flag & 16) != 0, (const char *)mm + 1, mlv, n_ml, ml != nullptr, state->hits) ? 0 : -1;
 }

@@ -130,6 +130,46 @@ def gather_text_v(local, n_local: int, dst: int = 0, group=None, sizes: Sequence
     return works
 
 
+def stream_text(local, n_local: int, write, dst: int = 0, group=None, sizes: Sequence[int] = None, chunk_bytes: int = 64 << 20):
+    """The gather without the staging tensor: `dst` hands its own text to `write` (a callable taking a bytes-like object), then takes the
+    other ranks' blocks in rank order, `chunk_bytes` at a time through TWO receive buffers -- the next chunk is in flight while the
+    previous one is written -- so rank 0 holds 2 x chunk_bytes instead of the whole job's text (2.2 GB per step at the bench's 8-GPU
+    shape).  Every other rank sends its block in the same chunks.  Same bytes over the same links as gather_text_v; the output is
+    byte-identical (tests/test_shard_gloo.py).  Precedent for writing blocks as they complete: the region jobs of
+    bam_consensus.c:2759-2790."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if sizes is None:
+        sizes = exchange_sizes(n_local, local.device, group)
+    sizes = [int(x) for x in sizes]
+    via_host = local.is_cuda and dist.get_backend(group) == "gloo"      # (the 1-GPU test box: ranks share a device and talk over gloo)
+    src = local[:sizes[rank]].cpu() if via_host else local[:sizes[rank]]
+    if rank != dst:
+        works = []
+        for off in range(0, sizes[rank], chunk_bytes):
+            works.append(dist.isend(src[off:min(off + chunk_bytes, sizes[rank])], dst, group=group))
+        wait_all(works)
+        return
+    write(src.cpu().numpy().tobytes() if src.is_cuda else src.numpy().tobytes())
+    bufs = [torch.empty(chunk_bytes, dtype=torch.uint8, device=src.device) for _ in range(2)]
+    jobs = [(r, off, min(chunk_bytes, sizes[r] - off)) for r in range(world) if r != dst for off in range(0, sizes[r], chunk_bytes)]
+    inflight = None
+    for k, (r, off, n) in enumerate(jobs):
+        w = dist.irecv(bufs[k & 1][:n], r, group=group)
+        if inflight is not None:
+            pw, pk, pn = inflight
+            pw.wait()
+            write(bufs[pk & 1][:pn].cpu().numpy().tobytes())
+        inflight = (w, k, n)
+    if inflight is not None:
+        pw, pk, pn = inflight
+        pw.wait()
+        write(bufs[pk & 1][:pn].cpu().numpy().tobytes())
+
+
 def gather_text(local, dst: int = 0, group=None, sizes: Sequence[int] = None):
     """Blocking form: every rank's byte tensor on `dst`, in rank order, as one contiguous tensor (None elsewhere)."""
     import torch.distributed as dist
@@ -196,7 +236,22 @@ def run_sharded_cli(argv: Sequence[str], out=None) -> int:
     dist.all_reduce(rcs, op=dist.ReduceOp.MAX)
     worst = int(rcs.item())
     t1 = time.perf_counter()
-    whole = gather_text(local, dst=0)
+    # STA_SHARD_STREAM=1: rank 0 writes every block as it arrives (two 64 MiB receive buffers) instead of staging the whole job's text
+    stream = bool(os.environ.get("STA_SHARD_STREAM"))
+    if stream:
+        sizes = exchange_sizes(n_local, dev)
+        sink = None
+        if rank == 0 and worst == 0:
+            sink = out if out is not None else (open(final, "wb") if final else sys.stdout.buffer)
+        stream_text(local, n_local, (sink.write if sink is not None else (lambda b: None)), dst=0, sizes=sizes,
+                    chunk_bytes=int(os.environ.get("STA_SHARD_STREAM_CHUNK", str(64 << 20))))
+        if rank == 0 and sink is not None:
+            sink.flush()
+            if final and out is None:
+                sink.close()
+        whole = None
+    else:
+        whole = gather_text(local, dst=0)
     t_gather = time.perf_counter() - t1
     if os.environ.get("STA_SHARD_TIMING"):
         sys.stderr.write("[shard %d/%d] driver %.3f s, %d bytes (%s capture); gather %.3f s\n" % (rank, world, t_drv, n_local, "device" if dev_capture else "host", t_gather))
@@ -205,6 +260,8 @@ def run_sharded_cli(argv: Sequence[str], out=None) -> int:
             # a failed block would leave a silent hole in the concatenation: nothing is written (the ranks' own messages
             # are on stderr already)
             sys.stderr.write("samtools_amd.shard: a rank failed (worst exit status %d): no output written\n" % worst)
+            return worst
+        if stream:
             return worst
         buf = whole.cpu().numpy().tobytes()
         if out is not None:

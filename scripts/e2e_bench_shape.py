@@ -32,10 +32,13 @@ print("input: %d contigs x %d columns, %.0f Mbases, BAM %.0f MB" % (copies, cols
 for env_extra in ({}, {"STA_GPU_INFLATE": "1"}):
     for args in (["depth", "-a", bam], ["mpileup", "-B", "-f", big_fa, bam], ["mpileup", "-f", big_fa, bam]):
         for rep in range(2):
-            env = dict(os.environ, STA_DRIVER_TIMING="1", **env_extra)
+            env = dict(os.environ, STA_DRIVER_TIMING=os.environ.get("STA_E2E_TIMING", "1"), **env_extra)
             t0 = time.perf_counter()
             p = subprocess.run([exe] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
             dt = time.perf_counter() - t0
             tl = [l for l in p.stderr.decode().split("\n") if "driver timing" in l or "driver threads" in l]
             print(" ".join(args[:3])[:24], env_extra or "", "%.3f s wall = %.0f Mbases/s |" % (dt, mb / dt), " ".join(tl)[:420])
+            if rep == 1:
+                for l in p.stderr.decode().split("\n"):
+                    if l.startswith("[timeline]"): print("     ", l)
 shutil.rmtree(d, ignore_errors=True)

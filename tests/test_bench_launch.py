@@ -47,7 +47,11 @@ def test_gpus_flag_starts_that_many_ranks():
                        stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode()
     assert p.returncode != 0
-    assert out.count("bench.py needs a HIP device") == 2, out[-2000:]
+    # Both ranks stop at "no device"; torch's elastic agent tears the second one down as soon as the first has failed, which -- on a busy
+    # box (eight xdist workers) -- can be before it has printed its line.  What the launcher was asked for is in the agent's own report.
+    n = out.count("bench.py needs a HIP device")
+    assert 1 <= n <= 2, out[-2000:]
+    assert "(local_rank: 0)" in out and "(local_rank: 1)" in out and "(local_rank: 2)" not in out, out[-2000:]
 
 
 def test_world_size_must_agree_with_gpus():

@@ -39,6 +39,14 @@ def _worker(rank, world, port, contigs, wcols, q):
     pend = [shard.gather_text_v(padded, local.numel(), dst=0, sizes=sizes, recv=recv[k]) for k in range(2)]
     for p in pend:
         shard.wait_all(p)
+    # the streaming form (STA_SHARD_STREAM): rank 0 writes the blocks as they arrive, through two small receive buffers -- chunks far
+    # smaller than a block here, so that blocks span many chunks and the last chunk of each is short
+    parts = []
+    shard.stream_text(padded, local.numel(), parts.append, dst=0, sizes=sizes, chunk_bytes=97)
+    if rank == 0:
+        assert b"".join(parts) == bytes(whole.numpy().tobytes())
+    else:
+        assert not parts
     if rank == 0:
         assert sum(sizes) == whole.numel()
         for k in range(2):
@@ -56,8 +64,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("contigs,wcols", [([1000, 37, 512], 128), ([90], 100), ([300, 300], 64)])
-def test_two_ranks_reassemble_single_process_output(contigs, wcols):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_ranks_reassemble_single_process_output(contigs, wcols, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

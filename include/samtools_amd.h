@@ -456,6 +456,10 @@ int sta_profile_get(sta_engine *e, sta_kernel_time *out, int cap);
  * status as the reference sub-commands (bamtk.c:248,270 would dispatch here). */
 int sta_main_mpileup(int argc, char **argv);
 int sta_main_depth(int argc, char **argv);
+/* A program that ends with the driver's exit status (csrc/main.cpp) may ask the drivers to end the PROCESS as soon as their output is
+ * written and flushed -- _exit(status) -- instead of returning through the teardown of page-locked pools, engine and HIP runtime
+ * (~0.28 s of a 0.7 s run).  Never set by an in-process caller. */
+void sta_exit_after_main(int on);
 /* The same two drivers with the text they would print handed back in memory (argv[0] selects "mpileup" / "depth"; a -o option
  * in argv still wins).  *text is malloc'ed: release it with sta_capture_free.  Returns the driver's exit status, or
  * STA_ERR_ARG / STA_ERR_IO.  Used by the sharded launcher (samtools_amd/shard.py): a rank's block of columns goes from the

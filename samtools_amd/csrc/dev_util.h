@@ -110,6 +110,21 @@ __device__ __forceinline__ void plp_resolve(const uint32_t *cig, int n, int rpos
 }
 
 
+// Inclusive prefix sum over the 64 lanes of a wave, every lane taking part (full EXEC): six v_add_u32 with DPP operands (row_shr 1 / 2 / 4 / 8
+// inside the rows of sixteen, then row_bcast:15 and row_bcast:31 across them) -- no LDS crossbar round trips as with six __shfl_up.
+// Lanes without a source read `old` = 0 (bound_ctrl off).
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
+    return (uint32_t)x;
+}
+
 // Block-wide reduction of N per-thread values followed by ONE global atomic per value and block
 // (sum for k < NSUM, max for the rest).  Keeps contended device atomics off the per-wave path: a
 // counter word sustains only ~90 atomics/us, so one atomic per wave (65k+ waves) costs milliseconds.

@@ -346,6 +346,12 @@ extern "C" int sta_main_depth(int argc, char **argv)
         run.pipe.reset(new WinPipe(pipe_slots_from_env(run.devs.n()), [&run](WinJob &j, int d) { return run.device_stage(j, d); }, run.out, "samtools depth: failed to write the output\n", run.devs.n()));
         ret = run.run();
         timeline_mark("last window submitted and drained");
+        if (!run.dev_cap) {
+            // a command-line run ends here (main.cpp): drain() has seen every window written
+            if (run.devs.ready() != STA_OK) { if (!run.no_device.exchange(true)) fprintf(stderr, "samtools depth: no usable HIP device (the MI355X engine has no CPU fallback)\n"); ret = 1; }
+            fflush(run.out);
+            driver_exit_now_if_asked(ret, driver_out_is_borrowed(run.out) ? nullptr : run.out);
+        }
         run.pipe.reset();
         timeline_mark("pipeline threads joined");
     }

@@ -27,6 +27,8 @@ using namespace sta;
 
 namespace {
 
+inline bool dev_captured_run(const DevCapture *c) { return c != nullptr; }
+
 struct Conf {
     sta_mplp_params p{};
     std::string reg, fai_fname, output_fname;
@@ -587,6 +589,12 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
         run.pipe.reset(new WinPipe(pipe_slots_from_env(run.devs.n()), [&run](WinJob &j, int d) { return run.device_stage(j, d); }, run.out, "Failed to write pileup data.\n", run.devs.n()));
         ret = run.run();
         timeline_mark("last window submitted and drained");
+        if (!dev_captured_run(run.dev_cap)) {
+            // a command-line run ends here (main.cpp): drain() has seen every window written
+            if (run.devs.ready() != STA_OK) { if (!run.no_device.exchange(true)) fprintf(stderr, "samtools mpileup: no usable HIP device (the MI355X engine has no CPU fallback)\n"); ret = 1; }
+            fflush(run.out);
+            driver_exit_now_if_asked(ret, driver_out_is_borrowed(run.out) ? nullptr : run.out);
+        }
         run.pipe.reset();                 // joins the device and writer threads (everything is written)
         timeline_mark("pipeline threads joined");
     }

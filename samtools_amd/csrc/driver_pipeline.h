@@ -69,6 +69,7 @@ struct WinJob {
     int rc = 0;
     // pipeline state
     int state = 0;                       // 0 free / with the producer, 1 queued for the device, 2 device done, 3 written
+    size_t trace_ix = (size_t)-1;        // STA_DRIVER_TIMING=3
 };
 
 class WinPipe {
@@ -80,6 +81,7 @@ public:
     {
         // (at least three slots: the single `-a` path holds one job while it acquires the next; with one slot it would wait for itself)
         timing_ = getenv("STA_DRIVER_TIMING") != nullptr;
+        trace_ = timing_ && atoi(getenv("STA_DRIVER_TIMING")) >= 3;
         t0_ = now();
         if (n_dev < 1) n_dev = 1;
         t_devn_.assign((size_t)n_dev, 0.0);
@@ -93,6 +95,10 @@ public:
         for (auto &t : dev_) if (t.joinable()) t.join();
         if (wr_.joinable()) wr_.join();
         for (double x : t_devn_) t_dev_ = x > t_dev_ ? x : t_dev_;
+        if (trace_)
+            for (const Trace &t : trace_log_)
+                fprintf(stderr, "[window %llu] tid %d cols %lld reads %lld | submitted +%.3f | device +%.3f .. +%.3f (%.1f ms) | written +%.3f | text %.1f MB\n", t.seq, t.tid, (long long)t.cols, (long long)t.reads,
+                        t.t_submit - t0_, t.t_dev0 - t0_, t.t_dev1 - t0_, (t.t_dev1 - t.t_dev0) * 1e3, t.t_written - t0_, (double)t.bytes / 1e6);
         if (timing_)
             fprintf(stderr, "[driver timing] wall %.3f s | producer: fill+stage %.3f s (of it: waiting for the decode threads %.3f s, copying slices %.3f s), "
                             "waiting for a slot %.3f s, waiting for results %.3f s | device thread busy %.3f s (the busiest of %d) | writer busy %.3f s | %llu windows\n",
@@ -112,7 +118,15 @@ public:
     void release(WinJob *j) { std::lock_guard<std::mutex> g(m_); j->state = 0; j->hold = false; cv_.notify_all(); }   // not submitted after all
     void submit(WinJob *j)
     {
-        { std::lock_guard<std::mutex> g(m_); j->state = 1; j->rc = 0; order_.push_back(j); devq_.push_back(j); ++n_jobs_; }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            j->state = 1; j->rc = 0; order_.push_back(j); devq_.push_back(j); ++n_jobs_;
+            if (trace_) {
+                Trace t; t.seq = n_jobs_ - 1; t.tid = j->tid; t.cols = j->ce - j->cb; t.reads = 0; t.t_submit = now();
+                if (j->have_reads) for (const StagedFile &sf : j->staged) t.reads += sf.n();
+                j->trace_ix = trace_log_.size(); trace_log_.push_back(t);
+            }
+        }
         cv_.notify_all();
     }
     // device stage of j finished (plan info, text in j->text): returns its rc.  A held job is waited for until the writer has
@@ -151,8 +165,9 @@ private:
             const double a = now();
             const int prior = err_.load();
             int rc = prior ? prior : fn_(*j, d);     // after an error the remaining jobs only drain
-            t_devn_[(size_t)d] += now() - a;
-            { std::lock_guard<std::mutex> g(m_); j->rc = rc; if (rc < 0 && !err_.load()) err_ = rc; j->state = 2; }
+            const double b = now();
+            t_devn_[(size_t)d] += b - a;
+            { std::lock_guard<std::mutex> g(m_); j->rc = rc; if (rc < 0 && !err_.load()) err_ = rc; j->state = 2; if (trace_ && j->trace_ix < trace_log_.size()) { Trace &t = trace_log_[j->trace_ix]; t.t_dev0 = a; t.t_dev1 = b; t.bytes = j->out_bytes; } }
             cv_.notify_all();
         }
     }
@@ -174,6 +189,7 @@ private:
             t_wr_ += now() - a;
             {
                 std::lock_guard<std::mutex> g(m_);
+                if (trace_ && j->trace_ix < trace_log_.size()) trace_log_[j->trace_ix].t_written = now();
                 if (rc < 0 && !err_.load()) err_ = rc;
                 order_.pop_front();
                 j->state = j->hold ? 3 : 0;       // a held job stays with the producer (it waits for state >= 2 and submits again)
@@ -190,6 +206,8 @@ private:
     std::vector<std::thread> dev_; std::thread wr_;
     std::vector<double> t_devn_;
     bool stop_ = false; std::atomic<int> err_{0};      // written under m_, read by the stage threads outside it
+    struct Trace { unsigned long long seq = 0; int tid = 0; int64_t cols = 0, reads = 0; double t_submit = 0, t_dev0 = 0, t_dev1 = 0, t_written = 0; uint64_t bytes = 0; };
+    std::vector<Trace> trace_log_; bool trace_ = false;      // STA_DRIVER_TIMING=3: one line per window at the end
     bool timing_ = false; double t0_ = 0, t_decode_wait_ = 0, t_stage_copy_ = 0, t_fill_ = 0, t_slot_ = 0, t_wait_ = 0, t_dev_ = 0, t_wr_ = 0; unsigned long long n_jobs_ = 0;
 };
 

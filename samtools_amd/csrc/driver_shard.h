@@ -131,5 +131,7 @@ struct DevCapture {
 };
 DevCapture *driver_dev_capture();
 bool driver_out_is_borrowed(FILE *f);     // stdout or the capture stream: the driver must not close it
+// command-line runs (main.cpp: sta_exit_after_main): everything is written -- close `out` if it is the command's own file, flush, _exit(status)
+void driver_exit_now_if_asked(int status, FILE *out);
 
 }  // namespace sta

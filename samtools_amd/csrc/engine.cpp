@@ -71,6 +71,7 @@ struct sta_engine {
     std::vector<StaReadsDev> files_h;
     std::vector<int32_t> min_pos, max_pos_hint;
     sta_mate_resolver mate_fn = nullptr; void *mate_user = nullptr;     // sta_set_mate_resolver
+    int32_t *pin_baq = nullptr; size_t pin_baq_words = 0;               // page-locked: per file the BAQ plan's list length + class-S histogram
     std::vector<char> late_copy;       // mpileup plan, per file: the working quality pool exists only if the window has overlap-eligible reads
     bool gen_xlen_on = false;          // this plan's generic measuring pass filled colinfo / gen_xlen for the emit
     DevBuf files_d, tname_d, bed_d, line_len, colinfo, gen_xlen, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, stage_bad, md_cap, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
@@ -223,6 +224,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &f : e->fb) f.release();
     for (auto &r : e->refs) r.second.buf.release();
     if (e->pin) hipHostFree(e->pin);
+    if (e->pin_baq) hipHostFree(e->pin_baq);
     DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->gen_xlen, &e->wfirst, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
                       &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->stage_bad, &e->md_cap, &e->chunk_words, &e->cov_out, &e->cov_hist, &e->sc_pos, &e->sc_delta, &e->sc_tmp, &e->sc_cov, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
                       &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
@@ -517,7 +519,7 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
     // preparation launch carries it
     const int64_t ncols = (int64_t)e->wd.col_end - e->wd.col_beg;
     e->have_wfirst = false;
-    if (!e->cov_mode && !e->plp_mode && sta_mplp_has_fast_path(*p) && sta_mplp_tile_ok(*p)) {
+    if (!e->cov_mode && !e->plp_mode && (sta_mplp_has_fast_path(*p) || sta_mplp_has_xfast_path(*p)) && sta_mplp_tile_ok(*p)) {
         bool small = true;
         for (int f = 0; f < nf; ++f) small = small && e->files_h[(size_t)f].n < 0xffffffffll;
         e->have_wfirst = small;
@@ -544,6 +546,23 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
         StaCounters c{};
         StaCounters *c_dst = e->pin ? (StaCounters *)e->pin : &c;
         HIPCHK(hipMemcpyAsync(c_dst, ctr, sizeof(c), hipMemcpyDeviceToHost, s));
+        // ... and with them, in the SAME round trip, what the plan used to fetch in two more: every file's list length
+        // (chain[0]) and its class-S histogram of candidate lengths -- all three are k_prep_reads' output.  Page-locked, 1 + STA_SLIST_BINS
+        // words per file.
+        const size_t per_file = 1 + (size_t)STA_SLIST_BINS;
+        if (e->pin_baq_words < (size_t)nf * per_file) {
+            if (e->pin_baq) { hipHostFree(e->pin_baq); e->pin_baq = nullptr; e->pin_baq_words = 0; }
+            if (hipHostMalloc((void **)&e->pin_baq, (size_t)nf * per_file * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(e, STA_ERR_HIP, "hipHostMalloc(BAQ plan words) failed"); }
+            e->pin_baq_words = (size_t)nf * per_file;
+        }
+        for (int f = 0; f < nf; ++f) {
+            StaReadsDev &d = e->files_h[(size_t)f];
+            int32_t *w = e->pin_baq + (size_t)f * per_file;
+            w[0] = 0;
+            if (!d.n) continue;
+            HIPCHK(hipMemcpyAsync(w, d.chain, 4, hipMemcpyDeviceToHost, s));
+            if (d.s_ws) HIPCHK(hipMemcpyAsync(w + 1, d.s_ws, (size_t)STA_SLIST_BINS * 4, hipMemcpyDeviceToHost, s));
+        }
         SYNC_S(s);
         if (e->pin) c = *c_dst;
         if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] n_baq=%llu (fast %llu, lq<=%llu) slow: max_lq=%llu max_bw=%llu kept=%llu\n", c.n_baq, c.n_baq_fast, c.max_lq_fast, c.max_lq, c.max_bw, c.n_kept);
@@ -551,11 +570,8 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
         for (int f = 0; f < nf && c.n_baq; ++f) {
             StaReadsDev &d = e->files_h[(size_t)f];
             if (!d.n) continue;
-            int32_t n_list = 0;
-            if (c.n_baq > c.n_baq_fast + c.n_baq_s) {
-                HIPCHK(hipMemcpyAsync(&n_list, d.chain, 4, hipMemcpyDeviceToHost, s));
-                SYNC_S(s);
-            }
+            const int32_t *plan_words = e->pin_baq + (size_t)f * per_file;
+            const int32_t n_list = c.n_baq > c.n_baq_fast + c.n_baq_s ? plan_words[0] : 0;
             const bool has_main = c.n_baq_fast || c.n_baq_s;
             const bool has_list_band = c.n_baq_bw8 || c.n_baq_bw7l;
             if (has_main || has_list_band) {
@@ -566,9 +582,8 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                 int s_waves = 0;
                 int64_t s_groups = 0;
                 if (c.n_baq_s && d.s_ws) {
-                    int32_t hist[STA_SLIST_BINS], base[STA_SLIST_BINS];
-                    HIPCHK(hipMemcpyAsync(hist, d.s_ws, sizeof hist, hipMemcpyDeviceToHost, s));
-                    SYNC_S(s);
+                    const int32_t *hist = plan_words + 1;
+                    int32_t base[STA_SLIST_BINS];
                     int64_t at = 0;
                     for (int l = 0; l < STA_SLIST_BINS; ++l) { base[l] = (int32_t)at; at += ((int64_t)hist[l] + 63) / 64 * 64; }
                     s_groups = at / 64;
@@ -735,8 +750,10 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             }
         }
         // the generic walker's measuring pass keeps what it learns about every string of every row for its emit (k_mplp_len_x)
+        // ... and so does the read-major pair when the window prints extra columns (sta_mplp_has_xfast_path)
+        const bool xfast = sta_mplp_has_xfast_path(*p) && e->have_wfirst;
         const bool tile_path = sta_mplp_has_fast_path(*p) && e->have_wfirst && sta_mplp_tile_ok(*p);
-        const int gx = tile_path ? -1 : sta_mplp_generic_extras(*p);
+        const int gx = tile_path ? -1 : xfast ? sta_mplp_xfast_extras(*p) : sta_mplp_generic_extras(*p);
         e->gen_xlen_on = false;
         if (gx >= 0) {
             if (e->gen_xlen.ensure((size_t)(ncols > 0 ? ncols : 1) * (size_t)(nf > 0 ? nf : 1) * (size_t)(gx > 0 ? gx : 1) * 4 + 16)) return fail(e, STA_ERR_HIP, "hipMalloc(extra-column lengths) failed");
@@ -885,6 +902,7 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     const uint32_t tile_cap = (uint32_t)tc;
     int deep_mode = deep ? 1 : 0;
     if (!e->len_fused) deep_mode = 0;                     // the generic walker writes every row itself
+    else if (sta_mplp_has_xfast_path(e->mp)) deep_mode = 1;      // extra columns: the read-major kernel at every depth
     else if (!deep && mw > tile_cap) deep_mode = 2;
     if (deep_mode) {
         if (e->strip_rng.ensure((size_t)sta_mplp_deep_strips(ncols > 0 ? ncols : 1) * (size_t)(e->wd.nfiles > 0 ? e->wd.nfiles : 1) * 16 + 16))
@@ -894,7 +912,7 @@ int sta_mpileup_emit(sta_engine *e, void *dev_out, uint64_t capacity)
     sta_launch_mplp_emit(e->stream, e->wd, e->mp, (const uint64_t *)e->offs.p, (const uint2 *)e->colinfo.p, out, e->lds_cap, deep_mode ? (int64_t *)e->strip_rng.p : nullptr,
                          tile_cap, deep_mode, e->have_wfirst ? (const uint32_t *)e->wfirst.p : nullptr,
                          e->len_fused ? sta_mplp_tile_base(e->fused_status.p, ncols) : nullptr, e->len_fused,
-                         (!e->len_fused && e->gen_xlen_on) ? (const uint32_t *)e->gen_xlen.p : nullptr);
+                         e->gen_xlen_on ? (const uint32_t *)e->gen_xlen.p : nullptr);
     return STA_OK;
 }
 

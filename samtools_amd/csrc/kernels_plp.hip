@@ -551,6 +551,105 @@ __device__ __forceinline__ char base_char_fast(int c, bool rev)
 // bytes and the packed bases a plain read shows in the strip come from two vector loads.  The fixed parts of a row (name,
 // position, reference base, the per-file counts, separators, '*' placeholders) are written by lane k for column k.  The
 // (count, base-string bytes) of every column and file come from the measuring pass, as for k_mplp_emit_tile.
+// ------------------------------------------------------------------------------------------------
+// Extra columns on the read-major path (round 6).  -O / --output-BP-5 / --output-extra print, per file and row, one
+// more string per requested item with one field per entry that passed -Q (bam_plcmd.c:727-855).  Every field is either a constant of
+// its read (name, flag, contig, position, mapping quality, mate contig / position, read length, an aux tag's text) or the decimal of a
+// query position.  So the measuring pass counts a string's bytes the way it counts depth -- a difference mark of the field's length at
+// a read's first column, the opposite mark behind its last, +-1 where a query position gains or loses a digit, and a point correction
+// where an entry fails -Q -- and the read-major emit kernel (lanes = reads) places the fields with a prefix sum over the passing lanes.
+// The -s column stays MplpDevPar.mq_col; --output-mods and rows with more than XF_NX such columns keep the generic walkers.
+#define XF_NX 8
+struct XfArgs { uint32_t *xlen; int nx; int kinds[XF_NX]; };       // xlen[file][x][column]: bytes of the fields of extra column x (separators not counted)
+#define XF_FLAGS (EXTRA_MASK & ~STA_MPLP_PRINT_MAPQ_CHAR)
+static int xf_kinds(const sta_mplp_params &p, int (&kinds)[XF_NX])
+{
+    uint32_t ex = (uint32_t)p.flag & (uint32_t)XF_FLAGS;
+    const int nfl = __builtin_popcount(ex), nt = p.n_tags > 0 ? p.n_tags : 0;
+    for (int k = 0; k < XF_NX; ++k) { kinds[k] = k < nfl ? (int)(ex & (~ex + 1)) : TAGKIND + (k - nfl); ex &= ex - 1; }
+    return nfl + nt;
+}
+__device__ __forceinline__ bool xf_per_entry(int kind) { return kind == STA_MPLP_PRINT_QPOS || kind == STA_MPLP_PRINT_QPOS5; }
+__device__ __forceinline__ int xf_digits_ll(long long v) { return (v < 0 ? 1 : 0) + dec_digits((unsigned long long)(v < 0 ? -v : v)); }
+// what a one-op read stores about extra column `kind` for the measuring steps: the field's bytes (>= 0) if they are the same in every
+// column, -1: the field is query index + 1, <= -2: it is (-code - 2) - query index (--output-BP-5 on the reverse strand)
+__device__ __forceinline__ int xf_read_code(const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int kind, long long r, int pos, uint32_t info, int lq)
+{
+    if (kind == STA_MPLP_PRINT_QPOS) return -1;
+    if (kind == STA_MPLP_PRINT_QPOS5) return (info & RI_REV) ? -(lq + 2) : -1;
+    Entry e; e.r = r; e.rpos = pos; e.rend = pos; e.info = info; e.lq = lq; e.boff = 0;
+    e.rs.qpos = 0; e.rs.indel = 0; e.rs.k = 0; e.rs.is_del = false; e.rs.is_refskip = false;
+    return extra_len(R, W, P, kind, e);
+}
+__device__ __forceinline__ int xf_code_len(int code, int qpos) { return code >= 0 ? code : dec_digits_u32((uint32_t)(code == -1 ? qpos + 1 : (-code - 2) - qpos)); }
+
+
+// one field of an extra column as the emit kernel holds it: up to sixteen bytes in a register pair (first byte lowest); longer text stays
+// in memory (src), a longer number in `num`
+struct XfField { uint64_t lo, hi; long long num; const char *src; int L; bool is_num; };
+__device__ __forceinline__ void xf_num_field(long long v, XfField &f)
+{
+    f.is_num = true; f.num = v; f.src = nullptr;
+    if (v >= 0 && v < 100000000ll) {
+        uint32_t w = (uint32_t)v; const int n = dec_digits_u32(w);
+        uint64_t t = 0;
+        for (int i = 0; i < n; ++i) { const uint32_t d = w / 10u; t = (t << 8) | (uint64_t)('0' + (w - d * 10u)); w = d; }
+        f.lo = t; f.hi = 0; f.L = n;
+        return;
+    }
+    const bool neg = v < 0;
+    unsigned long long u = (unsigned long long)(neg ? -v : v);
+    const int nd = dec_digits(u);
+    f.L = nd + (neg ? 1 : 0); f.lo = 0; f.hi = 0;
+    if (f.L > 16) return;
+    for (int i = 0; i < nd; ++i) { const unsigned long long d = u / 10u; f.hi = (f.hi << 8) | (f.lo >> 56); f.lo = (f.lo << 8) | (uint64_t)('0' + (u - d * 10u)); u = d; }
+    if (neg) { f.hi = (f.hi << 8) | (f.lo >> 56); f.lo = (f.lo << 8) | (uint64_t)'-'; }
+}
+// the first sixteen bytes of l bytes of text at src (the pool ends at pool_end: nothing behind it is read)
+__device__ __forceinline__ void xf_text_field(const char *src, int l, const char *pool_end, XfField &f)
+{
+    f.is_num = false; f.num = 0; f.src = src; f.L = l; f.lo = 0; f.hi = 0;
+    if (src + 16 <= pool_end) { f.lo = *reinterpret_cast<const sink_u64u *>(src); f.hi = *reinterpret_cast<const sink_u64u *>(src + 8); }
+    else for (int i = 0; i < l && i < 16; ++i) { const uint64_t b = (uint64_t)(unsigned char)src[i]; if (i < 8) f.lo |= b << (8 * i); else f.hi |= b << (8 * (i - 8)); }
+}
+// a field whose text does not depend on the column (bam_plcmd.c:749-852)
+__device__ __forceinline__ void xf_read_field(const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int kind, long long r, int rpos, uint32_t info, int lq, XfField &f)
+{
+    if (kind == STA_MPLP_PRINT_RNEXT || kind >= TAGKIND) {
+        const uint32_t *o = R.xcol_off + (uint64_t)r * (uint64_t)R.n_xcols + (uint64_t)xcol_index(P, kind);
+        const uint32_t o0 = o[0], o1 = o[1];
+        xf_text_field(R.xcol_text + o0, (int)(o1 - o0), R.xcol_text + R.xcol_off[(uint64_t)R.n * (uint64_t)R.n_xcols], f);
+    } else if (kind == STA_MPLP_PRINT_QNAME) {
+        const uint32_t n0 = R.name_off[r], n1 = R.name_off[r + 1];
+        xf_text_field(R.names + n0, (int)(n1 - n0) - 1, R.names + R.name_off[R.n], f);
+    } else if (kind == STA_MPLP_PRINT_RNAME) {
+        xf_text_field(W.tname, W.tname_len, W.tname + W.tname_len, f);
+    } else {
+        Entry e; e.r = r; e.rpos = rpos; e.rend = rpos; e.info = info; e.lq = lq; e.boff = 0;
+        e.rs.qpos = 0; e.rs.indel = 0; e.rs.k = 0; e.rs.is_del = false; e.rs.is_refskip = false;
+        xf_num_field(extra_value(R, W, kind, e), f);
+    }
+}
+// the field's L bytes at dst and nothing else: two overlapping stores of the widest size that fits
+__device__ __forceinline__ void xf_store(char *dst, const XfField &f)
+{
+    const int L = f.L;
+    if (L > 16) {
+        if (f.is_num) { Sink<0> sk; sk.cur = 0; sk.g = dst; sk.put_dec(f.num); return; }
+        for (int t = 0; t + 8 <= L; t += 8) *reinterpret_cast<sink_u64u *>(dst + t) = *reinterpret_cast<const sink_u64u *>(f.src + t);
+        if (L & 7) *reinterpret_cast<sink_u64u *>(dst + L - 8) = *reinterpret_cast<const sink_u64u *>(f.src + L - 8);
+    } else if (L >= 8) {
+        *reinterpret_cast<sink_u64u *>(dst) = f.lo;
+        if (L > 8) { const int sh = L - 8; *reinterpret_cast<sink_u64u *>(dst + sh) = sh == 8 ? f.hi : (f.lo >> (8 * sh)) | (f.hi << (64 - 8 * sh)); }
+    } else if (L >= 4) {
+        *reinterpret_cast<text_u32u *>(dst) = (uint32_t)f.lo;
+        if (L > 4) *reinterpret_cast<text_u32u *>(dst + L - 4) = (uint32_t)(f.lo >> (8 * (L - 4)));
+    } else if (L >= 2) {
+        *reinterpret_cast<text_u16u *>(dst) = (uint16_t)f.lo;
+        if (L == 3) dst[2] = (char)(f.lo >> 16);
+    } else if (L == 1) dst[0] = (char)f.lo;
+}
+
 #define DEEP_STRIP 16
 #include "deep_strip.h"
 
@@ -600,8 +699,11 @@ __device__ __forceinline__ int64_t xcd_tile(unsigned b, unsigned n8) { return n8
 static bool xcd_map_on() { const char *e = getenv("STA_XCD_MAP"); return !(e && atoi(e) == 0); }      // (per launch: the tests switch it inside one process)
 static unsigned xcd_grid(int64_t nblocks) { return xcd_map_on() ? (unsigned)((nblocks + 7) / 8 * 8) : (unsigned)nblocks; }
 
-__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(4, 8))) k_mplp_emit_deep(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
-                                                        const int64_t *__restrict__ rng, char *out, uint32_t only_above, const uint64_t *__restrict__ tbase, unsigned n8)
+// XF: the window prints extra columns (XfArgs above): after a block's bases and qualities are placed, every extra column's fields of the
+// block are -- per column of the strip one prefix sum of (field bytes + separator) over the lanes whose entry passed -Q.
+template <bool XF>
+__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(XF ? 2 : 4, 8))) k_mplp_emit_deep(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
+                                                        const int64_t *__restrict__ rng, char *out, uint32_t only_above, const uint64_t *__restrict__ tbase, unsigned n8, XfArgs X)
 {
     const int lane = threadIdx.x & 63;
     // (readfirstlane: the compiler cannot see that the strip index is the same for the 64 lanes; with it the strip's bounds,
@@ -614,6 +716,8 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     __shared__ uint8_t s_qc[4][64][DEEP_STRIP];
     __shared__ uint8_t s_list[4][64];
     __shared__ char s_chr[32];                                     // code -> character: forward strand, then reverse strand
+    __shared__ uint32_t s_qp[XF ? 4 : 1][XF ? 64 : 1][DEEP_STRIP]; // XF: query index (bit 31: placeholder) of the entries that went through the general CIGAR resolution
+    __shared__ __attribute__((aligned(16))) uint32_t s_xcur[XF ? 4 : 1][XF ? XF_NX : 1][DEEP_STRIP];      // XF: where the next field of (extra column, strip column) goes
     if (threadIdx.x < 32) s_chr[threadIdx.x] = base_char_fast((int)(threadIdx.x & 15), threadIdx.x >= 16);
     __syncthreads();
     if (c0 >= ncols) return;
@@ -672,7 +776,17 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 // -s: the mapping-quality string mirrors the quality string, one tab and `cnt` bytes further on
                 if (P.mq_col) { fx.put('\t'); fx.g += cnt; my_mqd = cnt + 1; }
             }
+            if (XF) {
+                // "\t" + the extra column's fields and separators (or '*'), one after the other behind the strings above
+                for (int x = 0; x < X.nx; ++x) {
+                    fx.put('\t');
+                    s_xcur[wv][x][lane] = (uint32_t)(fx.g - out0);
+                    if (!cnt) fx.put('*'); else fx.g += X.xlen[((int64_t)f * X.nx + x) * ncols + c0 + lane] + (cnt - 1);
+                }
+            }
         }
+        if (XF) wave_lds_sync();
+        uint32_t seen = 0;                                         // XF: bit k = column k of the strip already holds an entry of this file
         unsigned seqcur[DEEP_STRIP], qualcur[DEEP_STRIP], mqd[DEEP_STRIP];          // wave-uniform
 #pragma unroll
         for (int k = 0; k < DEEP_STRIP; ++k) {
@@ -780,11 +894,15 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                         const Entry e = deep_entry(R, b0 + src, z_rpos, z_rend, z_info, z_lq, z_boff, p);
                         qc = e.rs.is_del ? placeholder_qual(R, e.r, e.rs.qpos, z_lq, z_boff, p) : (e.rs.qpos < z_lq ? (int)R.qual[z_boff + (uint64_t)e.rs.qpos] : 0);
                         if (qc >= P.min_baseQ) tl = token_len(R, P, e, p);
+                        if (XF) s_qp[wv][src][k] = ((uint32_t)e.rs.qpos & 0x7fffffffu) | (e.rs.is_del ? 0x80000000u : 0u);
                     }
                     s_off[wv][src][k] = (uint32_t)tl; s_qc[wv][src][k] = (uint8_t)qc;   // the length now, the destination (never 0) once it is known
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+            unsigned long long passm[DEEP_STRIP];                  // XF: the lanes whose entry in column k passed -Q
+#pragma unroll
+            for (int k = 0; k < DEEP_STRIP; ++k) passm[k] = 0ull;
 #pragma unroll
             for (int k = 0; k < DEEP_STRIP; ++k) {
                 if (!((exm >> k) & 1u)) continue;
@@ -803,6 +921,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 }
                 const unsigned long long m = __ballot(pass);
                 if (!m) continue;
+                if (XF) passm[k] = m;
                 const bool head = pass && !cx && ends && p == rpos, tail = pass && !cx && ends && p == rend - 1;
                 const unsigned pm = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));   // passing lanes below this one
                 unsigned excl, total;
@@ -828,6 +947,55 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                     if (P.mq_col) out0[qualcur[k] + pm + mqd[k]] = mq_char;
                 }
                 seqcur[k] += total; qualcur[k] += (unsigned)__popcll(m);
+            }
+            if (XF) {
+                uint32_t blockm = 0;                                // columns of the strip that got entries from this block
+#pragma unroll
+                for (int k = 0; k < DEEP_STRIP; ++k) blockm |= passm[k] ? 1u << k : 0u;
+                if (blockm) {
+                    const uint32_t *const x_qp = s_qp[wv][lane];
+                    for (int x = 0; x < X.nx; ++x) {
+                        const int kind = X.kinds[x];
+                        const bool per_entry = xf_per_entry(kind);
+                        XfField fld; fld.lo = 0; fld.hi = 0; fld.num = 0; fld.src = nullptr; fld.L = 0; fld.is_num = false;
+                        if (!per_entry && keep) xf_read_field(R, W, P, kind, r, rpos, info, lq, fld);
+                        const char sepc = kind >= TAGKIND ? (char)P.tag_sep : ',';
+                        uint32_t xc[DEEP_STRIP];
+#pragma unroll
+                        for (int j = 0; j < DEEP_STRIP / 4; ++j) {
+                            const uint4 v = reinterpret_cast<const uint4 *>(s_xcur[wv][x])[j];
+                            xc[4 * j] = v.x; xc[4 * j + 1] = v.y; xc[4 * j + 2] = v.z; xc[4 * j + 3] = v.w;
+                        }
+#pragma unroll
+                        for (int k = 0; k < DEEP_STRIP; ++k) {
+                            const unsigned long long m = passm[k];
+                            if (!m) continue;
+                            const bool pass = (m >> lane) & 1ull;
+                            XfField fk = fld;
+                            if (per_entry && pass) {
+                                int qpos = p0 + k - qshift; bool isdel = false;
+                                if (slow) { const uint32_t w = x_qp[k]; qpos = (int)(w & 0x7fffffffu); isdel = (w >> 31) != 0; }
+                                const long long v = (kind == STA_MPLP_PRINT_QPOS5 && rev) ? (long long)lq - qpos + (isdel ? 1 : 0) : (long long)qpos + 1;
+                                xf_num_field(v, fk);
+                            }
+                            const uint32_t w = pass ? (uint32_t)fk.L + 1u : 0u;
+                            const uint32_t incl = wave_incl_scan_u32(w);
+                            const uint32_t total = rl_u(incl, 63);
+                            if (pass) {
+                                const uint32_t fp = xc[k] + incl - w;
+                                if (incl != w || ((seen >> k) & 1u)) out0[fp - 1] = sepc;     // (the row's first field has no separator)
+                                xf_store(out0 + fp, fk);
+                            }
+                            xc[k] += total;
+                        }
+                        if (lane == 0) {
+#pragma unroll
+                            for (int j = 0; j < DEEP_STRIP / 4; ++j) reinterpret_cast<uint4 *>(s_xcur[wv][x])[j] = make_uint4(xc[4 * j], xc[4 * j + 1], xc[4 * j + 2], xc[4 * j + 3]);
+                        }
+                    }
+                    seen |= blockm;
+                    wave_lds_sync();
+                }
             }
             if (sm) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -890,10 +1058,83 @@ __device__ __forceinline__ void wave_range_indexed(const StaReadsDev &R, const u
     if (rlo > rhi) rlo = rhi;
 }
 
-__global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THREADS), amdgpu_waves_per_eu(6, 8))) k_mplp_len_rm(StaWinDev W, MplpDevPar P, uint32_t *line_len, uint2 *colinfo, const uint32_t *__restrict__ wfirst,
-                                                                              unsigned long long *__restrict__ status, uint64_t *__restrict__ offs, StaCounters *ctr, int maxcnt)
+// len_step_b (plp_tile.h) for a window with extra columns: an entry that fails -Q also takes its fields out of the extra columns' rows
+// of marks -- a point correction, i.e. the opposite mark at the next column
+__device__ __forceinline__ void xf_len_step_b(LenLds &L, int t, const StaReadsDev &R, const MplpDevPar &P, int t0, int t1, int *xd, const int *xcode, int nx)
+{
+    if (P.min_baseQ <= 0) return;
+    const uint32_t minq4 = (uint32_t)P.min_baseQ * 0x01010101u;
+    const int g = t & 3;
+#pragma unroll 1
+    for (int sub = 0; sub < LEN_THREADS / 64; ++sub) {
+        const int slot = sub * 64 + (t >> 2);
+        if (L.m_kind[slot] != 1) continue;
+        const int pos = L.m_pos[slot], end = L.m_end[slot];
+        const uint64_t boff = (uint64_t)L.m_b8[slot] << 3;
+        const int qa = (pos > t0 ? pos : t0) - pos, qe = (end < t1 ? end : t1) - pos;
+        for (int j = (qa >> 4) + g; (j << 4) < qe; j += 4) {
+            const int q0 = j << 4;
+            uint32_t v[4] = { 0, 0, 0, 0 };
+            const uint64_t a = boff + (uint64_t)q0;
+            if (a + 16 <= R.n_bases_total) __builtin_memcpy(v, R.qual + a, 16);
+            else for (int i = 0; i < 16 && a + i < R.n_bases_total; ++i) v[i >> 2] |= (uint32_t)R.qual[a + i] << (8 * (i & 3));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int w0 = q0 + 4 * k;
+                uint32_t f = ~swar_ge_u8(v[k], minq4) & swar_byte_range(qa - w0, qe - w0) & 0x80808080u;
+                while (f) {
+                    const int i = (__builtin_ctz(f)) >> 3;
+                    const int col = pos + w0 + i - t0;
+                    atomicAdd(&L.fail[col], 1);
+                    for (int x = 0; x < nx; ++x) {
+                        const int l = xf_code_len(xcode[x * LEN_THREADS + slot], w0 + i);
+                        atomicAdd(&xd[x * (LEN_TC + 4) + col], -l);
+                        atomicAdd(&xd[x * (LEN_TC + 4) + col + 1], l);
+                    }
+                    f &= f - 1;
+                }
+            }
+        }
+    }
+}
+// len_step_c for such a window: a read with a general CIGAR adds its fields entry by entry
+__device__ __forceinline__ void xf_len_step_c(LenLds &L, int gi, int lane, int nlanes, long long b0, const StaReadsDev &R, const StaWinDev &W, const MplpDevPar &P, int t0, int t1,
+                                              int *xd, const XfArgs &X)
+{
+    const int slot = L.glist[gi];
+    const long long r = b0 + slot;
+    const int pos = L.m_pos[slot], end = L.m_end[slot];
+    const int ca = pos > t0 ? pos : t0, cb = end < t1 ? end : t1;
+    Entry e;
+    e.r = r; e.rpos = pos; e.rend = end; e.info = R.info[r]; e.lq = R.l_qseq[r];
+    e.boff = (uint64_t)L.m_b8[slot] << 3;
+    const uint32_t *cig = R.cigar + R.cig_off[r];
+    const int n = (int)(R.cig_off[r + 1] - R.cig_off[r]);
+    for (int p = ca + lane; p < cb; p += nlanes) {
+        e.rs = resolve_general(cig, n, pos, p);
+        const int c = e.rs.is_del ? placeholder_qual(R, r, e.rs.qpos, e.lq, e.boff, p) : (e.rs.qpos < e.lq ? (int)R.qual[e.boff + (uint64_t)e.rs.qpos] : 0);
+        if (c < P.min_baseQ) atomicAdd(&L.fail[p - t0], 1);
+        else {
+            const int tl = token_len(R, P, e, p);
+            if (tl != 1) atomicAdd(&L.extra[p - t0], tl - 1);
+            for (int x = 0; x < X.nx; ++x) {
+                const int l = extra_len(R, W, P, X.kinds[x], e);
+                atomicAdd(&xd[x * (LEN_TC + 4) + p - t0], l);
+                atomicAdd(&xd[x * (LEN_TC + 4) + p - t0 + 1], -l);
+            }
+        }
+    }
+}
+
+template <bool XF>
+__global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THREADS), amdgpu_waves_per_eu(XF ? 4 : 6, 8))) k_mplp_len_rm(StaWinDev W, MplpDevPar P, uint32_t *line_len, uint2 *colinfo, const uint32_t *__restrict__ wfirst,
+                                                                              unsigned long long *__restrict__ status, uint64_t *__restrict__ offs, StaCounters *ctr, int maxcnt, XfArgs X)
 {
     __shared__ LenLds L;
+    // XF: per extra column a row of difference marks over the tile and, per batch, what every one-op read stores about it (dynamic LDS)
+    int *const xd = reinterpret_cast<int *>(lds_text);                  // [nx][LEN_TC + 4]
+    int *const xcode = xd + (XF ? X.nx : 0) * (LEN_TC + 4);             // [nx][LEN_THREADS]
+    const int nx = XF ? X.nx : 0;
     const int t = threadIdx.x;
     const int64_t ncols = (int64_t)W.col_end - W.col_beg;
     if (t == 0) { L.n_lines = 0; L.n_data = 0; L.wave_max = 0; }
@@ -908,6 +1149,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THRE
     for (int f = 0; f < W.nfiles; ++f) {
         const StaReadsDev &R = W.files[f];
         len_clear(L, t);
+        if (XF) for (int i = t; i < nx * (LEN_TC + 4); i += LEN_THREADS) xd[i] = 0;
         if (t < 64) {                                       // the first wave finds the tile's reads
             int64_t rlo, rhi;
             const int64_t nwaves = (ncols + 63) >> 6, w_lo = c0 >> 6, w_hi = w_lo + (LEN_TC >> 6) < nwaves ? w_lo + (LEN_TC >> 6) : nwaves;
@@ -929,9 +1171,50 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THRE
         const long long rlo = L.rlo, rhi = L.rhi;
         for (long long b0 = rlo; b0 < rhi; b0 += LEN_THREADS) {
             len_step_a(L, t, R, P, t0, t1, b0);
+            if (XF) {
+                // thread t's read, if it is a one-op read in the tile: the marks of every extra column.  (--output-BP-5 on a reverse read whose
+                // SEQ is not its CIGAR's length would go negative: such a read takes the per-entry route below.)
+                if (L.m_kind[t] == 1) {
+                    const long long r = b0 + t;
+                    const int pos = L.m_pos[t], end = L.m_end[t], lq = R.l_qseq[r];
+                    const uint32_t info = R.info[r];
+                    bool general = false;
+                    for (int x = 0; x < nx; ++x) general = general || (X.kinds[x] == STA_MPLP_PRINT_QPOS5 && (info & RI_REV) && lq != end - pos);
+                    if (general) {
+                        // (its '^x' / '$' bytes are counted per entry by step C: take back what step A added)
+                        if (!P.no_ends) {
+                            const uint64_t boff = (uint64_t)L.m_b8[t] << 3;
+                            if (pos >= t0 && (int)R.qual[boff] >= P.min_baseQ) atomicAdd(&L.extra[pos - t0], -2);
+                            if (end <= t1 && (int)R.qual[boff + (uint64_t)(end - 1 - pos)] >= P.min_baseQ) atomicAdd(&L.extra[end - 1 - t0], -1);
+                        }
+                        L.m_kind[t] = 2; L.glist[atomicAdd(&L.gcount, 1)] = t;
+                    } else {
+                        const int a = (pos > t0 ? pos : t0) - t0, b = (end < t1 ? end : t1) - t0;
+                        for (int x = 0; x < nx; ++x) {
+                            const int code = xf_read_code(R, W, P, X.kinds[x], r, pos, info, lq);
+                            xcode[x * LEN_THREADS + t] = code;
+                            int *const D = xd + x * (LEN_TC + 4);
+                            atomicAdd(&D[a], xf_code_len(code, a + t0 - pos));
+                            atomicAdd(&D[b], -xf_code_len(code, b - 1 + t0 - pos));
+                            if (code < 0) {
+                                // the columns at which the decimal gains (forward) / loses (reverse) a digit
+                                uint32_t th = 10;
+                                for (int d = 1; d < 10; ++d, th *= 10u) {
+                                    const long long q = code == -1 ? (long long)th - 1 : (long long)(-code - 2) - (long long)th + 1;      // first query index on the far side
+                                    const long long c = q + pos - t0;
+                                    if (c > a && c < b) atomicAdd(&D[c], code == -1 ? 1 : -1);
+                                    if (th >= 1000000000u) break;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
             __syncthreads();
+            if (XF) xf_len_step_b(L, t, R, P, t0, t1, xd, xcode, nx); else
             len_step_b(L, t, R, P, t0, t1);
             const int ng = L.gcount;
+            if (XF) { for (int gi = t >> 6; gi < ng; gi += LEN_THREADS / 64) xf_len_step_c(L, gi, t & 63, 64, b0, R, W, P, t0, t1, xd, X); } else
             for (int gi = t >> 6; gi < ng; gi += LEN_THREADS / 64) len_step_c(L, gi, t & 63, 64, b0, R, P, t0, t1);
             if (b0 + LEN_THREADS < rhi) {                   // the batch arrays are reused
                 __syncthreads();
@@ -944,8 +1227,29 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(LEN_THREADS, LEN_THRE
         len_scan_2(L, t); __syncthreads();
         len_scan_3(L, t); __syncthreads();
         const int before = len_scan_4(L, t);
-        len_file_result(L, t, before, ntile, colinfo + (int64_t)f * ncols + c0, total, any, P.mq_col != 0);
+        uint32_t cnt4[4] = { 0, 0, 0, 0 };
+        len_file_result(L, t, before, ntile, colinfo + (int64_t)f * ncols + c0, total, any, P.mq_col != 0, XF ? cnt4 : nullptr);
         __syncthreads();
+        if (XF) {
+            // every extra column: prefix sum of its marks = bytes of its fields per column; "\t" + fields + separators (or '*') joins the row
+            for (int x = 0; x < nx; ++x) {
+                const int *const D = xd + x * (LEN_TC + 4);
+                L.part[t] = D[4 * t] + D[4 * t + 1] + D[4 * t + 2] + D[4 * t + 3]; __syncthreads();
+                len_scan_2(L, t); __syncthreads();
+                len_scan_3(L, t); __syncthreads();
+                int v = len_scan_4(L, t);
+                uint32_t *const xl = X.xlen + ((int64_t)f * nx + x) * ncols + c0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 4 * t + i;
+                    v += D[c];
+                    if (c >= ntile) continue;
+                    xl[c] = (uint32_t)v;
+                    total[i] += 1 + (cnt4[i] ? (uint32_t)v + (cnt4[i] - 1) : 1u);
+                }
+                __syncthreads();
+            }
+        }
     }
     // row lengths of the thread's four columns and their exclusive scan inside the tile; the tile's bytes / rows / largest wave go to
     // k_tile_scan (one small workgroup), which replaces the whole-window scan and column-statistics launches of the lane-per-column
@@ -1127,7 +1431,7 @@ static MplpDevPar make_par(const sta_mplp_params &p, int64_t tlen)
     d.no_ins = p.no_ins; d.no_del = p.no_del; d.no_ends = p.no_ends; d.tlen = tlen;
     d.n_tags = p.n_tags > 0 ? p.n_tags : 0; d.tag_sep = p.tag_sep ? p.tag_sep : ',';
     d.mods = (p.flag & STA_MPLP_OUTPUT_MODS) ? 1 : 0; d.no_ins_mods = (p.no_ins_mods || p.no_ins) ? 1 : 0;
-    d.mq_col = (sta_mplp_has_fast_path(p) && (p.flag & STA_MPLP_PRINT_MAPQ_CHAR)) ? 1 : 0;
+    d.mq_col = ((sta_mplp_has_fast_path(p) || sta_mplp_has_xfast_path(p)) && (p.flag & STA_MPLP_PRINT_MAPQ_CHAR)) ? 1 : 0;
     return d;
 }
 
@@ -1148,10 +1452,18 @@ bool sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_param
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return false;
-    if (sta_mplp_has_fast_path(p) && colinfo && wfirst && status && offs && sta_mplp_tile_ok(p)) {
+    const bool xf = sta_mplp_has_xfast_path(p) && gen_xlen;
+    if ((sta_mplp_has_fast_path(p) || xf) && colinfo && wfirst && status && offs && sta_mplp_tile_ok(p)) {
         const int64_t ntiles = (ncols + LEN_TC - 1) / LEN_TC;
-        hipLaunchKernelGGL(k_mplp_len_rm, dim3((unsigned)ntiles), dim3(LEN_THREADS), 0, s, w, make_par(p, w.tlen), line_len, colinfo, wfirst,
-                           (unsigned long long *)status, offs, ctr, detect_maxcnt);
+        XfArgs X; X.xlen = gen_xlen; X.nx = 0;
+        for (int k = 0; k < XF_NX; ++k) X.kinds[k] = 0;
+        if (xf) {
+            X.nx = xf_kinds(p, X.kinds);
+            hipLaunchKernelGGL(k_mplp_len_rm<true>, dim3((unsigned)ntiles), dim3(LEN_THREADS), (size_t)X.nx * (LEN_TC + 4 + LEN_THREADS) * 4, s, w, make_par(p, w.tlen), line_len, colinfo, wfirst,
+                               (unsigned long long *)status, offs, ctr, detect_maxcnt, X);
+        } else
+        hipLaunchKernelGGL(k_mplp_len_rm<false>, dim3((unsigned)ntiles), dim3(LEN_THREADS), 0, s, w, make_par(p, w.tlen), line_len, colinfo, wfirst,
+                           (unsigned long long *)status, offs, ctr, detect_maxcnt, X);
         hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, (const unsigned long long *)status, (uint64_t *)status + 3 * ntiles, ntiles, ctr);
         return true;          // offsets (tile-relative + tile bases), totals and the largest wave are done: no scan / column statistics launches
     }
@@ -1164,14 +1476,21 @@ bool sta_launch_mplp_len(hipStream_t s, const StaWinDev &w, const sta_mplp_param
 }
 
 static void launch_deep(hipStream_t s, const StaWinDev &w, const sta_mplp_params &p, const uint64_t *offs, const uint2 *colinfo, char *out,
-                        int64_t *strip_rng, uint32_t only_above, const uint64_t *tbase)
+                        int64_t *strip_rng, uint32_t only_above, const uint64_t *tbase, const uint32_t *xlen = nullptr /* the measuring pass's extra-column bytes: the XF form */)
 {
     const int64_t ncols = (int64_t)w.col_end - w.col_beg;
     const int64_t nwaves_d = sta_mplp_deep_strips(ncols);
     const int64_t nt = nwaves_d * w.nfiles;
     hipLaunchKernelGGL(k_mplp_strip_ranges, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, w, strip_rng, nwaves_d);
     const unsigned gd = xcd_grid((nwaves_d + 3) / 4);
-    hipLaunchKernelGGL(k_mplp_emit_deep, dim3(gd), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, (const int64_t *)strip_rng, out, only_above, tbase, xcd_map_on() ? gd : 0u);
+    XfArgs X; X.xlen = const_cast<uint32_t *>(xlen); X.nx = 0;
+    for (int k = 0; k < XF_NX; ++k) X.kinds[k] = 0;
+    if (xlen) {
+        X.nx = xf_kinds(p, X.kinds);
+        if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] extra columns on the read-major kernels: %d\n", X.nx);
+        hipLaunchKernelGGL(k_mplp_emit_deep<true>, dim3(gd), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, (const int64_t *)strip_rng, out, only_above, tbase, xcd_map_on() ? gd : 0u, X);
+    } else
+        hipLaunchKernelGGL(k_mplp_emit_deep<false>, dim3(gd), dim3(256), 0, s, w, make_par(p, w.tlen), offs, colinfo, (const int64_t *)strip_rng, out, only_above, tbase, xcd_map_on() ? gd : 0u, X);
 }
 
 // tile = true (the measuring pass was k_mplp_len_rm: colinfo, wfirst and tbase are valid): deep_mode 1 = every strip through
@@ -1185,6 +1504,7 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
     if (ncols <= 0) return;
     int64_t nwaves = (ncols + 63) / 64;
     if (tile) {
+        if (strip_rng && sta_mplp_has_xfast_path(p)) { launch_deep(s, w, p, offs, colinfo, out, strip_rng, 0u, tbase, gen_xlen); return; }      // extra columns: every strip, read-major
         if (strip_rng && deep_mode == 1) { launch_deep(s, w, p, offs, colinfo, out, strip_rng, 0u, tbase); return; }
         const uint32_t slice = (tile_cap + 48 + 15) & ~15u;       // must match k_mplp_emit_tile
         const size_t lds = (size_t)TILE_WAVES * (slice + TILE_LDS_BYTES);
@@ -1216,6 +1536,19 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
 
 int64_t sta_mplp_deep_strips(int64_t ncols) { return (ncols + DEEP_STRIP - 1) / DEEP_STRIP; }
 
+// extra columns the read-major kernels cover (XfArgs): -O, --output-BP-5, --output-extra items and tags, up to XF_NX of them beside -s;
+// not --output-mods.  STA_XFAST=0: back to the generic walkers (A/B runs, tests of the walkers).
+bool sta_mplp_has_xfast_path(const sta_mplp_params &p)
+{
+    const char *e = getenv("STA_XFAST");
+    if (e && atoi(e) == 0) return false;
+    if ((uint32_t)p.flag & STA_MPLP_OUTPUT_MODS) return false;
+    int kinds[XF_NX];
+    const int nx = __builtin_popcount((uint32_t)p.flag & (uint32_t)XF_FLAGS) + (p.n_tags > 0 ? p.n_tags : 0);
+    (void)kinds;
+    return nx >= 1 && nx <= XF_NX && sta_mplp_tile_ok(p);
+}
+int sta_mplp_xfast_extras(const sta_mplp_params &p) { return sta_mplp_has_xfast_path(p) ? __builtin_popcount((uint32_t)p.flag & (uint32_t)XF_FLAGS) + (p.n_tags > 0 ? p.n_tags : 0) : 0; }
 // no --output-extra / -O / -s columns: the window takes the fast kernel pair
 // the tile kernels compare four quality bytes per word against -Q: it has to fit seven bits
 bool sta_mplp_tile_ok(const sta_mplp_params &p) { return p.min_baseQ <= 127; }

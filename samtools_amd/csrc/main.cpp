@@ -13,6 +13,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "Usage: samtools-amd <mpileup|depth|consensus|bedcov|coverage|stats|plpdump|glf|calmd> [options]\n%s\n", sta_version());
         return 1;
     }
+    sta_exit_after_main(1);      // (the drivers of the hot path end the process once their text is out: no teardown of page-locked pools / the runtime)
     if (strcmp(argv[1], "mpileup") == 0) return sta_main_mpileup(argc - 1, argv + 1);
     if (strcmp(argv[1], "depth") == 0) return sta_main_depth(argc - 1, argv + 1);
     if (strcmp(argv[1], "consensus") == 0) return sta_main_consensus(argc - 1, argv + 1);

@@ -250,7 +250,8 @@ PLP_HD int len_scan_4(const LenLds &L, int t)
 
 // per-file result of thread t's four columns: (count after -Q, base string bytes) -> colinfo; adds the file's text bytes to total[]
 // (bytes of "\t cnt \t seq \t qual" as bam_plcmd.c:699-725 prints them), any[] |= the column has entries before -Q
-PLP_HD void len_file_result(const LenLds &L, int t, int depth_before, int ncols_tile, uint2 *colinfo_tile, uint32_t total[4], bool any[4], bool mq_col = false)
+PLP_HD void len_file_result(const LenLds &L, int t, int depth_before, int ncols_tile, uint2 *colinfo_tile, uint32_t total[4], bool any[4], bool mq_col = false,
+                            uint32_t *cnt_out = nullptr /* [4]: the columns' counts after -Q, for the caller that adds extra columns */)
 {
     int d = depth_before;
 #pragma unroll
@@ -265,6 +266,7 @@ PLP_HD void len_file_result(const LenLds &L, int t, int depth_before, int ncols_
         if (mq_col) total[i] += 1 + (cnt ? cnt : 1);          // -s: "\t" + one mapping-quality character per entry, or '*'
 
         colinfo_tile[c] = make_uint2(cnt, seq_len);
+        if (cnt_out) cnt_out[i] = cnt;
     }
 }
 

@@ -131,6 +131,8 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
                           const uint32_t *wfirst, const uint64_t *tbase /* sta_mplp_tile_base() */, bool tile /* the measuring pass returned true */,
                           const uint32_t *gen_xlen = nullptr /* what sta_launch_mplp_len kept (NULL: the generic emit measures for itself) */);
 bool sta_mplp_has_fast_path(const sta_mplp_params &p);
+bool sta_mplp_has_xfast_path(const sta_mplp_params &p);      // extra columns on the read-major kernels (k_mplp_len_rm<true> + k_mplp_emit_deep<true>)
+int sta_mplp_xfast_extras(const sta_mplp_params &p);         // their number (0: not that path): gen_xlen holds [nfiles][this][ncols] words
 bool sta_mplp_tile_ok(const sta_mplp_params &p);
 void sta_launch_wave_bytes_max(hipStream_t s, const uint64_t *offs, const uint32_t *line_len, int64_t ncols, StaCounters *ctr);
 

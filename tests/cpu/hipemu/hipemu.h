@@ -152,6 +152,21 @@ template <class T> HIPEMU_WOP T __shfl_down(T v, unsigned d, int width = 64) { r
 template <class T> HIPEMU_WOP T __shfl_xor(T v, int m, int width = 64) { return hipemu::from_bits<T>(hipemu::wave_op(hipemu::K_SHFL_XOR, hipemu::to_bits(v), m, width)); }
 HIPEMU_WOP int __builtin_amdgcn_readlane(int v, int lane) { return hipemu::from_bits<int>(hipemu::wave_op(hipemu::K_READLANE, hipemu::to_bits(v), lane, 64)); }
 HIPEMU_WOP int __builtin_amdgcn_readfirstlane(int v) { return hipemu::from_bits<int>(hipemu::wave_op(hipemu::K_READFIRST, hipemu::to_bits(v), 0, 64)); }
+// v_mov_b32_dpp as the kernels use it (row_shr:n, row_bcast:15 / :31; bound_ctrl off): a lane whose row / bank is masked out, or whose
+// source lies outside its row, keeps `old`.  Every lane of the wave takes part (the callers run it under full EXEC).
+HIPEMU_WOP int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+    const int l = hipemu::tl_lane->lin & 63, row = l >> 4, in_row = l & 15;
+    int from = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; if (in_row >= n) from = l - n; }
+    else if (ctrl == 0x142) { if (row >= 1) from = 16 * (row - 1) + 15; }
+    else if (ctrl == 0x143) { if (row >= 2) from = 31; }
+    else __builtin_trap();
+    const int got = hipemu::from_bits<int>(hipemu::wave_op(hipemu::K_SHFL, hipemu::to_bits(src), from < 0 ? l : from, 64));
+    if (!((row_mask >> row) & 1) || !((bank_mask >> (in_row >> 2)) & 1)) return old;
+    if (from < 0) return bound_ctrl ? 0 : old;
+    return got;
+}
 HIPEMU_WOP void hipemu_wave_sync() { (void)hipemu::wave_op(hipemu::K_SYNC, 0, 0, 64); }
 #define __builtin_amdgcn_wave_barrier() hipemu_wave_sync()
 #define __builtin_amdgcn_fence(order, scope) hipemu_wave_sync()

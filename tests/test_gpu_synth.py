@@ -109,10 +109,13 @@ def _long_names(sam):
     open(sam, "w").write("".join(out))
 
 
-@pytest.mark.parametrize("env", [{}, {"STA_GENERIC_PASSES": "1"}, {"STA_GENERIC_LDS_CAP": "1024"}], ids=["1walk", "passes", "bytestores"])
+@pytest.mark.parametrize("env", [{"STA_XFAST": "0"}, {"STA_XFAST": "0", "STA_GENERIC_PASSES": "1"}, {"STA_XFAST": "0", "STA_GENERIC_LDS_CAP": "1024"}, {}],
+                         ids=["1walk", "passes", "bytestores", "readmajor"])
 @pytest.mark.parametrize("opts", list(_GENERIC_OPTS), ids=list(_GENERIC_OPTS))
 def test_generic_walker_forms(tmp_path, oracle_bin, product_bin, opts, env):
-    """The generic walker's emit in its two forms (kernels_plp.hip emit_column_1walk: one measuring walk + one writing walk with a cursor
+    """(`readmajor`: the same rows through k_mplp_len_rm<true> + k_mplp_emit_deep<true>, the default since round 6 for up to eight extra
+    columns beside -s; STA_XFAST=0 selects the walkers.)
+    The generic walker's emit in its two forms (kernels_plp.hip emit_column_1walk: one measuring walk + one writing walk with a cursor
     per string of the row; emit_column: one walk per string, STA_GENERIC_PASSES=1 or more than GEN_NX extra columns), both through the
     LDS slice and with byte stores to the text, on reads with indels (deletion placeholders, inserted sequences in the base string) and
     two input files, against the oracle (bam_plcmd.c:480-855)."""
@@ -130,6 +133,54 @@ def test_generic_walker_forms(tmp_path, oracle_bin, product_bin, opts, env):
         got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
         assert got.returncode == 0, got.stderr.decode()[-500:]
         assert got.stdout == want, (opts, env, wc)
+
+
+def _spoil_for_extras(sam, seed):
+    """every 7th read loses SEQ / QUAL (l_qseq 0: --output-BP-5 of a reverse read goes negative), every 3rd gets a long Z tag and a long name"""
+    import random
+    rng = random.Random(seed)
+    out = []
+    k = 0
+    for line in open(sam):
+        if not line.startswith("@"):
+            f = line.rstrip("\n").split("\t")
+            k += 1
+            if k % 7 == 0:
+                f[9] = "*"; f[10] = "*"
+            if k % 3 == 0:
+                f.append("XZ:Z:" + "tag%d_" % k * rng.choice((1, 2, 5, 9)))
+            if k % 4 == 0:
+                f.append("XI:i:%d" % rng.choice((0, -7, 255, 70000, -2000000000)))
+            line = "\t".join(f) + "\n"
+        out.append(line)
+    open(sam, "w").write("".join(out))
+
+
+@pytest.mark.parametrize("opts", [["-O", "--output-BP-5"], ["-s", "--output-BP-5", "--output-extra", "XZ,QNAME,XI"], ["-Q", "0", "-O", "--output-extra", "FLAG,RNEXT,PNEXT,XZ"],
+                                  ["-a", "-a", "-Q", "25", "--output-extra", "RNAME,MAPQ,RLEN,POS", "--output-sep", ";", "--output-empty", "."],
+                                  ["--no-output-ins", "--no-output-del", "--no-output-ends", "-O", "--output-QNAME"]],
+                         ids=["O_BP5", "s_BP5_tags", "Q0_mates", "aa_sep", "no_ins_del_ends"])
+def test_extra_columns_on_the_read_major_kernels(tmp_path, oracle_bin, product_bin, opts):
+    """Extra columns through k_mplp_len_rm<true> / k_mplp_emit_deep<true> (bam_plcmd.c:727-855): piles deeper than one block of 64 reads
+    (the row's first field has no separator only once), reads without SEQ (query positions from the 3' end go negative), fields longer
+    than the sixteen bytes the emit holds in registers (names, Z tags), negative and wide integers, indel-rich reads (per-entry route),
+    three files, windows of 700 columns -- against the oracle, with the walkers (STA_XFAST=0) as a second witness."""
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=6000, depth=150, read_len=100, seed=171, paired=True, indel_rate=0.15, max_indel=5)
+    _long_names(sam); _spoil_for_extras(sam, 5)
+    d2 = tmp_path / "b"; d2.mkdir()
+    sam2, _ = write_synth_sam(str(d2), n_ref=6000, depth=9, read_len=60, seed=172, paired=False)
+    d3 = tmp_path / "c"; d3.mkdir()
+    sam3, _ = write_synth_sam(str(d3), n_ref=6000, depth=70, read_len=151, seed=173, paired=True, indel_rate=0.02)
+    _spoil_for_extras(sam3, 6)
+    # (-x: a pair with a SEQ-less mate ends the reference's run -- tweak_overlap_quality "fell off the end" -- and the extras do not depend on it)
+    args = ["mpileup", "-B", "-x", "-d", "100000"] + opts + ["-f", fa, sam, sam2, sam3]
+    want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    assert want.count(b"\n") > 5000
+    for env in ({}, {"STA_WINDOW_COLS": "700"}, {"STA_XFAST": "0"}):
+        got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, STA_DEBUG="1", **env))
+        assert got.returncode == 0, got.stderr.decode()[-500:]
+        assert got.stdout == want, (opts, env)
+        assert (b"extra columns on the read-major kernels" in got.stderr) == ("STA_XFAST" not in env)
 
 
 @pytest.mark.parametrize("mode", ["band_even", "band_odd", "long_reads", "general", "plain_E_off"])

@@ -27,6 +27,7 @@
 #include "plp_tile.h"
 #include "dev_lookback.h"
 #include <cstdlib>
+#include <type_traits>
 
 // seq_nt16_table (hts.c): character -> 4-bit code, 15 for anything else (a table: the switch in nt16_from_char costs ~300
 // scalar instructions of exec-mask juggling per wave when every lane holds a different character)
@@ -650,6 +651,33 @@ __device__ __forceinline__ void xf_store(char *dst, const XfField &f)
     } else if (L == 1) dst[0] = (char)f.lo;
 }
 
+// the steps of the extra columns over the sixteen columns of a strip, the column index a compile-time constant of each
+template <class F> __device__ __forceinline__ void xf_for_columns(F &&f)
+{
+    f(std::integral_constant<int, 0>()); f(std::integral_constant<int, 1>()); f(std::integral_constant<int, 2>()); f(std::integral_constant<int, 3>());
+    f(std::integral_constant<int, 4>()); f(std::integral_constant<int, 5>()); f(std::integral_constant<int, 6>()); f(std::integral_constant<int, 7>());
+    f(std::integral_constant<int, 8>()); f(std::integral_constant<int, 9>()); f(std::integral_constant<int, 10>()); f(std::integral_constant<int, 11>());
+    f(std::integral_constant<int, 12>()); f(std::integral_constant<int, 13>()); f(std::integral_constant<int, 14>()); f(std::integral_constant<int, 15>());
+}
+// v_writelane_b32: lane K of `old` takes the wave-uniform `val` (the CPU harness: a per-lane select -- every lane holds the uniform value)
+template <int K> __device__ __forceinline__ int xf_writelane(int val, int old)
+{
+#if defined(HIPEMU)
+    return (int)(threadIdx.x & 63) == K ? val : old;
+#else
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(K));
+    return old;
+#endif
+}
+// OR of the low sixteen bits over the wave (which strip columns have entries from any lane)
+__device__ __forceinline__ uint32_t xf_wave_or16(uint32_t v)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r |= __ballot((v >> k) & 1u) ? 1u << k : 0u;
+    return r;
+}
+
 #define DEEP_STRIP 16
 #include "deep_strip.h"
 
@@ -701,8 +729,11 @@ static unsigned xcd_grid(int64_t nblocks) { return xcd_map_on() ? (unsigned)((nb
 
 // XF: the window prints extra columns (XfArgs above): after a block's bases and qualities are placed, every extra column's fields of the
 // block are -- per column of the strip one prefix sum of (field bytes + separator) over the lanes whose entry passed -Q.
+#ifndef XF_OCC
+#define XF_OCC 3            // waves per SIMD the extra-column form is compiled for (A/B: -DXF_OCC=3 / 4)
+#endif
 template <bool XF>
-__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(XF ? 2 : 4, 8))) k_mplp_emit_deep(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
+__global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(XF ? XF_OCC : 4, 8))) k_mplp_emit_deep(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
                                                         const int64_t *__restrict__ rng, char *out, uint32_t only_above, const uint64_t *__restrict__ tbase, unsigned n8, XfArgs X)
 {
     const int lane = threadIdx.x & 63;
@@ -718,6 +749,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
     __shared__ char s_chr[32];                                     // code -> character: forward strand, then reverse strand
     __shared__ uint32_t s_qp[XF ? 4 : 1][XF ? 64 : 1][DEEP_STRIP]; // XF: query index (bit 31: placeholder) of the entries that went through the general CIGAR resolution
     __shared__ __attribute__((aligned(16))) uint32_t s_xcur[XF ? 4 : 1][XF ? XF_NX : 1][DEEP_STRIP];      // XF: where the next field of (extra column, strip column) goes
+    __shared__ uint32_t s_dec[XF ? 1000 : 1];                      // XF: the decimal of 0 .. 999: its characters, first in the lowest byte, and their number in the top byte
+    if (XF) for (uint32_t i = threadIdx.x; i < 1000u; i += 256u) {
+        const uint32_t h = i / 100u, t = (i / 10u) % 10u, o = i % 10u;
+        s_dec[i] = i >= 100u ? (3u << 24) | ('0' + h) | (('0' + t) << 8) | (('0' + o) << 16) : i >= 10u ? (2u << 24) | ('0' + t) | (('0' + o) << 8) : (1u << 24) | ('0' + o);
+    }
     if (threadIdx.x < 32) s_chr[threadIdx.x] = base_char_fast((int)(threadIdx.x & 15), threadIdx.x >= 16);
     __syncthreads();
     if (c0 >= ncols) return;
@@ -780,12 +816,11 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 // "\t" + the extra column's fields and separators (or '*'), one after the other behind the strings above
                 for (int x = 0; x < X.nx; ++x) {
                     fx.put('\t');
-                    s_xcur[wv][x][lane] = (uint32_t)(fx.g - out0);
+                    s_xcur[wv][x][lane] = (uint32_t)(fx.g - out0) - 1u;      // (the first unit starts ON this tab and carries one)
                     if (!cnt) fx.put('*'); else fx.g += X.xlen[((int64_t)f * X.nx + x) * ncols + c0 + lane] + (cnt - 1);
                 }
             }
         }
-        if (XF) wave_lds_sync();
         uint32_t seen = 0;                                         // XF: bit k = column k of the strip already holds an entry of this file
         unsigned seqcur[DEEP_STRIP], qualcur[DEEP_STRIP], mqd[DEEP_STRIP];          // wave-uniform
 #pragma unroll
@@ -900,9 +935,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            unsigned long long passm[DEEP_STRIP];                  // XF: the lanes whose entry in column k passed -Q
-#pragma unroll
-            for (int k = 0; k < DEEP_STRIP; ++k) passm[k] = 0ull;
+            uint32_t passbits = 0;                                 // XF: bit k = this lane's entry in column k passed -Q
 #pragma unroll
             for (int k = 0; k < DEEP_STRIP; ++k) {
                 if (!((exm >> k) & 1u)) continue;
@@ -921,7 +954,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 }
                 const unsigned long long m = __ballot(pass);
                 if (!m) continue;
-                if (XF) passm[k] = m;
+                if (XF) passbits |= pass ? 1u << k : 0u;
                 const bool head = pass && !cx && ends && p == rpos, tail = pass && !cx && ends && p == rend - 1;
                 const unsigned pm = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));   // passing lanes below this one
                 unsigned excl, total;
@@ -949,52 +982,144 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_wav
                 seqcur[k] += total; qualcur[k] += (unsigned)__popcll(m);
             }
             if (XF) {
-                uint32_t blockm = 0;                                // columns of the strip that got entries from this block
-#pragma unroll
-                for (int k = 0; k < DEEP_STRIP; ++k) blockm |= passm[k] ? 1u << k : 0u;
+                // The extra columns of this block.  A field travels with its separator in front of it (a "unit" of w = field + 1 bytes; the row's
+                // first unit starts on the tab in front of the string and carries a tab instead), so that a lane writes its unit with two
+                // overlapping stores of the widest size that fits and nothing else.  Per strip column: one prefix sum of w over the passing lanes.
+                // (The column index is a compile-time constant of each step -- xf_for_columns -- so that lane k of the cursor register is read and
+                // written with v_readlane / v_writelane; the steps hold no wave-uniform state of their own in scalar registers.)
+                const uint32_t blockm = (uint32_t)__builtin_amdgcn_readfirstlane((int)xf_wave_or16(passbits));      // columns of the strip that got entries from this block
                 if (blockm) {
                     const uint32_t *const x_qp = s_qp[wv][lane];
                     for (int x = 0; x < X.nx; ++x) {
                         const int kind = X.kinds[x];
-                        const bool per_entry = xf_per_entry(kind);
-                        XfField fld; fld.lo = 0; fld.hi = 0; fld.num = 0; fld.src = nullptr; fld.L = 0; fld.is_num = false;
-                        if (!per_entry && keep) xf_read_field(R, W, P, kind, r, rpos, info, lq, fld);
-                        const char sepc = kind >= TAGKIND ? (char)P.tag_sep : ',';
-                        uint32_t xc[DEEP_STRIP];
-#pragma unroll
-                        for (int j = 0; j < DEEP_STRIP / 4; ++j) {
-                            const uint4 v = reinterpret_cast<const uint4 *>(s_xcur[wv][x])[j];
-                            xc[4 * j] = v.x; xc[4 * j + 1] = v.y; xc[4 * j + 2] = v.z; xc[4 * j + 3] = v.w;
-                        }
-#pragma unroll
-                        for (int k = 0; k < DEEP_STRIP; ++k) {
-                            const unsigned long long m = passm[k];
-                            if (!m) continue;
-                            const bool pass = (m >> lane) & 1ull;
-                            XfField fk = fld;
-                            if (per_entry && pass) {
-                                int qpos = p0 + k - qshift; bool isdel = false;
-                                if (slow) { const uint32_t w = x_qp[k]; qpos = (int)(w & 0x7fffffffu); isdel = (w >> 31) != 0; }
-                                const long long v = (kind == STA_MPLP_PRINT_QPOS5 && rev) ? (long long)lq - qpos + (isdel ? 1 : 0) : (long long)qpos + 1;
-                                xf_num_field(v, fk);
+                        const uint32_t sep = kind >= TAGKIND ? (uint32_t)(unsigned char)P.tag_sep : (uint32_t)',';
+                        int myxc = lane < DEEP_STRIP ? (int)s_xcur[wv][x][lane] : 0;         // lane k: where column k's next unit starts
+                        const int myxc0 = myxc;
+                        if (!xf_per_entry(kind)) {
+                            // ---- the field is a constant of the read: unit, length and store class once per block ----
+                            XfField fld; fld.lo = 0; fld.hi = 0; fld.num = 0; fld.src = nullptr; fld.L = 0; fld.is_num = false;
+                            if (keep) xf_read_field(R, W, P, kind, r, rpos, info, lq, fld);
+                            const uint32_t w = keep ? (uint32_t)fld.L + 1u : 0u;
+                            // unit = separator + field: sixteen bytes in u0 .. u3 (fields of up to fifteen bytes; longer ones take the slow class)
+                            const uint32_t u0n = (uint32_t)fld.lo << 8, u1 = (uint32_t)(fld.lo >> 24), u2 = (uint32_t)(fld.lo >> 56) | ((uint32_t)fld.hi << 8), u3 = (uint32_t)(fld.hi >> 24);
+                            // store classes: 1 = two or three bytes, 2 = four to eight (two dwords), 3 = nine to sixteen (two qwords), 4 = longer (slow)
+                            const int cls = !keep ? 0 : w <= 3 ? 1 : w <= 8 ? 2 : w <= 16 ? 3 : 4;
+                            const uint32_t pA = cls == 1 ? passbits : 0u, pB = cls == 2 ? passbits : 0u, pC = cls == 3 ? passbits : 0u, pD = cls == 4 ? passbits : 0u;
+                            const int hasA = __builtin_amdgcn_readfirstlane(__ballot(pA != 0) != 0 ? 1 : 0), hasB = __builtin_amdgcn_readfirstlane(__ballot(pB != 0) != 0 ? 1 : 0),
+                                      hasC = __builtin_amdgcn_readfirstlane(__ballot(pC != 0) != 0 ? 1 : 0), hasD = __builtin_amdgcn_readfirstlane(__ballot(pD != 0) != 0 ? 1 : 0);
+                            const uint32_t wm4 = w - 4u, sh4 = 8u * (w - 4u);
+                            // class 3: bytes [w - 8, w) of the unit (w >= 9: the separator is not among them)
+                            uint32_t t_lo = 0, t_hi = 0;
+                            if (cls == 3) {
+                                const uint32_t sh = w - 8u;         // 1 .. 8
+                                const uint32_t a0 = sh < 4 ? u0n : sh < 8 ? u1 : u2, a1 = sh < 4 ? u1 : sh < 8 ? u2 : u3, a2 = sh < 4 ? u2 : sh < 8 ? u3 : 0u;
+                                t_lo = __builtin_amdgcn_alignbyte(a1, a0, sh & 3u); t_hi = __builtin_amdgcn_alignbyte(a2, a1, sh & 3u);
                             }
-                            const uint32_t w = pass ? (uint32_t)fk.L + 1u : 0u;
-                            const uint32_t incl = wave_incl_scan_u32(w);
-                            const uint32_t total = rl_u(incl, 63);
-                            if (pass) {
-                                const uint32_t fp = xc[k] + incl - w;
-                                if (incl != w || ((seen >> k) & 1u)) out0[fp - 1] = sepc;     // (the row's first field has no separator)
-                                xf_store(out0 + fp, fk);
+                            const uint64_t tail64 = (uint64_t)t_lo | ((uint64_t)t_hi << 32);
+                            xf_for_columns([&](auto kc) {
+                                constexpr int k = decltype(kc)::value;
+                                const uint32_t pkb = passbits & (1u << k);
+                                const unsigned long long m = __ballot(pkb != 0);
+                                if (!m) return;
+                                const uint32_t wk = pkb ? w : 0u;
+                                const uint32_t incl = wave_incl_scan_u32(wk);
+                                const int xck = __builtin_amdgcn_readlane(myxc, k);
+                                myxc = xf_writelane<k>(xck + __builtin_amdgcn_readlane((int)incl, 63), myxc);
+                                const uint32_t p = incl - wk + (uint32_t)xck;
+                                const int firstl = ((seen >> k) & 1u) ? 64 : __builtin_ctzll(m);
+                                const uint32_t d0 = u0n | (lane == firstl ? (uint32_t)'\t' : sep);
+                                if (hasA) if (pA & (1u << k)) {
+                                    *reinterpret_cast<text_u16u *>(out0 + p) = (uint16_t)d0;
+                                    if (w == 3) out0[p + 2] = (char)(d0 >> 16);
+                                }
+                                if (hasB) if (pB & (1u << k)) {
+                                    *reinterpret_cast<text_u32u *>(out0 + p) = d0;
+                                    *reinterpret_cast<text_u32u *>(out0 + p + wm4) = (uint32_t)(((uint64_t)d0 | ((uint64_t)u1 << 32)) >> sh4);
+                                }
+                                if (hasC) if (pC & (1u << k)) {
+                                    *reinterpret_cast<sink_u64u *>(out0 + p) = (uint64_t)d0 | ((uint64_t)u1 << 32);
+                                    *reinterpret_cast<sink_u64u *>(out0 + p + w - 8u) = tail64;
+                                }
+                            });
+                            if (hasD) {
+                                // fields of more than fifteen bytes (long names, Z tags): the same walk over the columns once more, rolled up, for the
+                                // lanes that hold one -- the separator as a byte, the field from where it lies in memory
+                                int mx = myxc0;
+#pragma unroll 1
+                                for (int k = 0; k < DEEP_STRIP; ++k) {
+                                    const uint32_t pk = (passbits >> k) & 1u;
+                                    const unsigned long long m = __ballot(pk != 0);
+                                    if (!m) continue;
+                                    const uint32_t wk = pk * w;
+                                    const uint32_t incl = wave_incl_scan_u32(wk);
+                                    const int xck = __builtin_amdgcn_readlane(mx, k);
+                                    const int tot = (int)rl_u(incl, 63);
+                                    mx = lane == k ? xck + tot : mx;
+                                    const uint32_t p = (uint32_t)xck + incl - wk;
+                                    const int firstl = ((seen >> k) & 1u) ? 64 : __builtin_ctzll(m);
+                                    if ((pD >> k) & 1u) {
+                                        out0[p] = lane == firstl ? '\t' : (char)sep;
+                                        xf_store(out0 + p + 1u, fld);
+                                    }
+                                }
                             }
-                            xc[k] += total;
+                        } else {
+                            // ---- the field is the decimal of a query position: up to three digits from the table, anything else through the general conversion ----
+                            const bool bp5 = kind == STA_MPLP_PRINT_QPOS5 && rev;
+                            const int vbase = bp5 ? lq - (p0 - qshift) : p0 - qshift + 1, vstep = bp5 ? -1 : 1;     // plain lanes: the value in column k is vbase + k vstep
+                            int somebig = 0;
+                            xf_for_columns([&](auto kc) {
+                                constexpr int k = decltype(kc)::value;
+                                const uint32_t pkb = passbits & (1u << k);
+                                const unsigned long long m = __ballot(pkb != 0);
+                                if (!m) return;
+                                int v = vbase + k * vstep;
+                                if (sm) if (slow) { const uint32_t qw = x_qp[k]; const int q = (int)(qw & 0x7fffffffu); v = bp5 ? lq - q + (int)(qw >> 31) : q + 1; }
+                                const bool big = pkb && (uint32_t)v >= 1000u;
+                                const unsigned long long mbig = __ballot(big);
+                                const uint32_t ent = s_dec[big || !pkb ? 0 : v];
+                                uint32_t wk = pkb ? (ent >> 24) + 1u : 0u;
+                                if (mbig) { somebig = 1; if (big) wk = (uint32_t)xf_digits_ll(v) + 1u; }
+                                const uint32_t incl = wave_incl_scan_u32(wk);
+                                const int xck = __builtin_amdgcn_readlane(myxc, k);
+                                myxc = xf_writelane<k>(xck + __builtin_amdgcn_readlane((int)incl, 63), myxc);
+                                const uint32_t p = incl - wk + (uint32_t)xck;
+                                const int firstl = ((seen >> k) & 1u) ? 64 : __builtin_ctzll(m);
+                                const uint32_t d0 = (ent << 8) | (lane == firstl ? (uint32_t)'\t' : sep);
+                                if (pkb && !big) {
+                                    if (wk == 4u) *reinterpret_cast<text_u32u *>(out0 + p) = d0;
+                                    else { *reinterpret_cast<text_u16u *>(out0 + p) = (uint16_t)d0; if (wk == 3u) out0[p + 2] = (char)(d0 >> 16); }
+                                }
+                            });
+                            if (somebig) {
+                                // values beyond the table (a read of a thousand bases and more; negative ones: a reverse read without SEQ): once more, rolled up
+                                int mx = myxc0;
+#pragma unroll 1
+                                for (int k = 0; k < DEEP_STRIP; ++k) {
+                                    const uint32_t pk = (passbits >> k) & 1u;
+                                    const unsigned long long m = __ballot(pk != 0);
+                                    if (!m) continue;
+                                    int v = vbase + k * vstep;
+                                    if (slow) { const uint32_t qw = x_qp[k]; const int q = (int)(qw & 0x7fffffffu); v = bp5 ? lq - q + (int)(qw >> 31) : q + 1; }
+                                    const bool big = pk && (uint32_t)v >= 1000u;
+                                    const uint32_t wk = !pk ? 0u : big ? (uint32_t)xf_digits_ll(v) + 1u : (s_dec[v] >> 24) + 1u;
+                                    const uint32_t incl = wave_incl_scan_u32(wk);
+                                    const int xck = __builtin_amdgcn_readlane(mx, k);
+                                    const int tot = (int)rl_u(incl, 63);
+                                    mx = lane == k ? xck + tot : mx;
+                                    const uint32_t p = (uint32_t)xck + incl - wk;
+                                    const int firstl = ((seen >> k) & 1u) ? 64 : __builtin_ctzll(m);
+                                    if (big) {
+                                        XfField fk; xf_num_field(v, fk);
+                                        out0[p] = lane == firstl ? '\t' : (char)sep;
+                                        xf_store(out0 + p + 1u, fk);
+                                    }
+                                }
+                            }
                         }
-                        if (lane == 0) {
-#pragma unroll
-                            for (int j = 0; j < DEEP_STRIP / 4; ++j) reinterpret_cast<uint4 *>(s_xcur[wv][x])[j] = make_uint4(xc[4 * j], xc[4 * j + 1], xc[4 * j + 2], xc[4 * j + 3]);
-                        }
+                        if (lane < DEEP_STRIP) s_xcur[wv][x][lane] = (uint32_t)myxc;
                     }
                     seen |= blockm;
-                    wave_lds_sync();
                 }
             }
             if (sm) {

@@ -167,6 +167,8 @@ HIPEMU_WOP int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_m
     if (from < 0) return bound_ctrl ? 0 : old;
     return got;
 }
+// v_alignbyte_b32: ({hi, lo} >> 8 * (sh & 3)) & 0xffffffff
+static inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3u))); }
 HIPEMU_WOP void hipemu_wave_sync() { (void)hipemu::wave_op(hipemu::K_SYNC, 0, 0, 64); }
 #define __builtin_amdgcn_wave_barrier() hipemu_wave_sync()
 #define __builtin_amdgcn_fence(order, scope) hipemu_wave_sync()

@@ -440,6 +440,9 @@ const int32_t *sta_depth_counts_dev(sta_engine *e);
 
 /* ---- results ---- */
 int sta_fetch_output(sta_engine *e, char *host_out, uint64_t n);   /* D2H + sync */
+/* n bytes of the output from byte `offset` on: a caller that writes the text out piece by piece through a small page-locked buffer
+ * (the drivers' text ring, csrc/driver_pipeline.h) instead of holding a window's whole text on the host.  D2H + sync. */
+int sta_fetch_output_at(sta_engine *e, char *host_out, uint64_t offset, uint64_t n);
 int sta_sync(sta_engine *e);
 
 /* ---- measurement support (bench.py) ---- */

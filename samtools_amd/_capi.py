@@ -164,6 +164,7 @@ _PROTOS = {
     "sta_depth_run": (C.c_int, [_P, C.POINTER(DepthParams), _P, C.c_uint64, C.POINTER(PlanInfo)]),
     "sta_depth_counts_dev": (_P, [_P]),
     "sta_fetch_output": (C.c_int, [_P, _P, C.c_uint64]),
+    "sta_fetch_output_at": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
     "sta_sync": (C.c_int, [_P]),
     "sta_profile_enable": (None, [_P, C.c_int]),
     "sta_profile_reset": (None, [_P]),

@@ -4,6 +4,9 @@
 // appends to a FILE*, so the capture form gives it a memory stream and returns the buffer: no temporary file between the
 // driver and the gather.  The reference has no counterpart (its column loop prints as it goes, bam_plcmd.c:663-868).
 #include <unistd.h>
+#include <sys/stat.h>
+#include <string>
+#include <vector>
 #include "driver_pipeline.h"
 #include <atomic>
 #include <unistd.h>
@@ -59,10 +62,23 @@ int dev_threads_from_env()
     const int n = e ? atoi(e) : 1;      // measured (profiles/r03_e2e_*.log): the drivers are producer-bound, a second engine buys nothing and doubles the BAQ slab start-up
     return n < 1 ? 1 : (n > 4 ? 4 : n);
 }
+// Pipeline slots: a slot owns a window's staging arrays.  With page-locked pools (large inputs) few of them, each costs page-locking time;
+// with plain memory (small inputs, driver_pin_policy) eight, so that the producer runs ahead while the HIP runtime is still coming up.
 size_t pipe_slots_from_env(int n_dev)
 {
     const char *ns = getenv("STA_PIPE_SLOTS");
-    return ns && atoi(ns) > 0 ? (size_t)atoi(ns) : (size_t)n_dev + 2;
+    return ns && atoi(ns) > 0 ? (size_t)atoi(ns) : pinned_policy() ? (size_t)n_dev + 2 : (size_t)n_dev + 7;
+}
+// Page-locked staging pools only for inputs large enough to pay for them (host_pinned.h): >= 1 GiB of input files, or input that is
+// not a regular file (a pipe: size unknown).  STA_PIN=0 / 1 overrides.  Call before the inputs are opened (their decode threads allocate).
+void driver_pin_policy(const std::vector<std::string> &paths)
+{
+    uint64_t total = 0; bool unknown = false;
+    for (const std::string &fn : paths) {
+        struct stat st;
+        if (fn == "-" || stat(fn.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) unknown = true; else total += (uint64_t)st.st_size;
+    }
+    pinned_set_policy(unknown || total >= (1ull << 30));
 }
 int DevEngines::dev_threads() { return dev_threads_from_env(); }
 int DevEngines::create(int device)
@@ -76,6 +92,22 @@ int DevEngines::create(int device)
         const int rc = sta_engine_create(&e, device, st);
         if (rc != STA_OK) { if (st) hipStreamDestroy(st); return rc; }
         eng.push_back(e); streams.push_back(st);
+    }
+    // the runtime exists: page-locked allocations are possible from here on (host_pinned.h), and the text ring is made now, on this
+    // thread, while the producer stages its first windows
+    pinned_runtime_is_up();
+    if (n_ == 1) {
+        int pieces = 6, mib = 8;
+        if (const char *e = getenv("STA_TEXT_RING")) { if (sscanf(e, "%dx%d", &pieces, &mib) != 2) { pieces = atoi(e) > 0 ? 6 : 0; mib = 8; } }
+        if (pieces > 0 && mib > 0) {
+            ring.piece = (size_t)mib << 20;
+            for (int i = 0; i < pieces; ++i) {
+                void *b = nullptr;
+                if (hipHostMalloc(&b, ring.piece, hipHostMallocDefault) != hipSuccess || !b) { (void)hipGetLastError(); break; }
+                ring.buf.push_back((char *)b);
+            }
+            if (ring.buf.size() < 2) { for (char *b : ring.buf) (void)hipHostFree(b); ring.buf.clear(); }
+        }
     }
     return STA_OK;
 }
@@ -101,6 +133,8 @@ void DevEngines::destroy()
         if (streams[d]) hipStreamDestroy((hipStream_t)streams[d]);
     }
     eng.clear(); streams.clear();
+    for (char *b : ring.buf) (void)hipHostFree(b);
+    ring.buf.clear();
 }
 }  // namespace sta
 
@@ -108,6 +142,7 @@ void DevEngines::destroy()
 // profiler flushes its traces from exit handlers that _exit() skips)
 static bool teardown_has_something_to_say()
 {
+    if (const char *f = getenv("STA_FAST_EXIT")) if (atoi(f) != 0) return false;      // (measurements: the timeline's marks up to "fast exit" with the timing variables set)
     for (const char *v : { "STA_NO_FAST_EXIT", "STA_DRIVER_TIMING", "STA_STAGE_REPORT", "STA_DEBUG", "STA_PROFILE", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB" })
         if (getenv(v)) return true;
     const char *pre = getenv("LD_PRELOAD");

@@ -36,6 +36,7 @@ struct DRunner {
     std::unique_ptr<Bed> bed;
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
     int64_t window_cols = 1 << 20, max_reads = 4 << 20;
+    std::atomic<bool> ring_asked{false};
     std::unique_ptr<WinPipe> pipe;      // producer (this thread) -> device thread -> writer thread (driver_pipeline.h)
     std::vector<std::vector<StagedFile>> no_reads_d;   // per engine: read-less windows; its device thread only
     bool shard_done = false;            // the block's last column has been passed: the rest of the input is not read
@@ -53,6 +54,7 @@ struct DRunner {
     {
         if (devs.ready() != STA_OK) { if (!no_device.exchange(true)) fprintf(stderr, "samtools depth: no usable HIP device (the MI355X engine has no CPU fallback)\n"); return -1; }
         sta_engine *eng = devs.eng[(size_t)d];
+        if (!ring_asked.exchange(true)) { if (!dev_cap) pipe->use_ring(&devs.ring); }      // (made by the engines' thread: complete once ready() has returned)
         std::vector<StagedFile> &no_reads = no_reads_d[(size_t)d];
         size_t nf = readers.size();
         std::vector<sta_reads> views(nf);
@@ -78,9 +80,7 @@ struct DRunner {
             dev_cap->len += (size_t)j.info.out_bytes;
             return 0;
         }
-        if (j.text.size() < (size_t)j.info.out_bytes) j.text.resize((size_t)j.info.out_bytes + (size_t)(j.info.out_bytes >> 3));
-        if (sta_fetch_output(eng, j.text.data(), j.info.out_bytes) != STA_OK) { fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; }
-        j.out_bytes = j.info.out_bytes;
+        { const int frc = fetch_text(*pipe, j, eng, j.info.out_bytes); if (frc) { if (frc == -2) fprintf(stderr, "samtools depth: %s\n", sta_last_error(eng)); return -1; } }
         return 0;
     }
 
@@ -306,6 +306,7 @@ extern "C" int sta_main_depth(int argc, char **argv)
         for (int i = 0; i < nf; ++i) { fns.push_back(argv[optind + i]); idx_fns.push_back(argv[optind + nf + i]); }
     } else for (int i = optind; i < argc; ++i) fns.push_back(argv[i]);
 
+    driver_pin_policy(fns);
     for (auto &fn : fns) {
         std::string err;
         auto r = AlnReader::open(fn, &err, io_threads_per_input((int)fns.size()));

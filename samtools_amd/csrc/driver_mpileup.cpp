@@ -76,6 +76,7 @@ struct Runner {
     FILE *out = driver_default_out();
     DevCapture *dev_cap = driver_dev_capture();       // (sta_main_capture_device: window text stays on the device)
     bool has_reg = false; int tid0 = 0; int64_t beg0 = 0, end0 = INT64_MAX;
+    std::atomic<bool> ring_asked{false};
     std::unique_ptr<WinPipe> pipe;                    // producer (this thread) -> device thread -> writer thread
     std::vector<std::vector<StagedFile>> no_reads_d;  // per engine: read-less windows (zero-depth rows); its device thread only
     std::vector<std::vector<char>> cap_dropped;      // per file: reads of the last window that the -d cap dropped
@@ -104,6 +105,7 @@ struct Runner {
     {
         if (devs.ready() != STA_OK) { if (!no_device.exchange(true)) fprintf(stderr, "samtools mpileup: no usable HIP device (the MI355X engine has no CPU fallback)\n"); return -1; }
         sta_engine *eng = devs.eng[(size_t)d];
+        if (!ring_asked.exchange(true)) { if (!dev_cap) pipe->use_ring(&devs.ring); }      // (made by the engines' thread: complete once ready() has returned)
         std::vector<StagedFile> &no_reads = no_reads_d[(size_t)d];
         const size_t nf = readers.size();
         if (conf.fai && j.tid != dev_ref_tid[(size_t)d]) {
@@ -160,9 +162,7 @@ struct Runner {
             return 0;
         }
         if (sta_mpileup_emit(eng, nullptr, 0) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
-        if (j.text.size() < (size_t)j.info.out_bytes) j.text.resize((size_t)j.info.out_bytes + (size_t)(j.info.out_bytes >> 3));
-        if (sta_fetch_output(eng, j.text.data(), j.info.out_bytes) != STA_OK) { fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; }
-        j.out_bytes = j.info.out_bytes;
+        { const int frc = fetch_text(*pipe, j, eng, j.info.out_bytes); if (frc) { if (frc == -2) fprintf(stderr, "samtools mpileup: %s\n", sta_last_error(eng)); return -1; } }
         return 0;
     }
 
@@ -193,7 +193,7 @@ struct Runner {
     int process_tid(WindowSource &pump, int tid, int mode)
     {
         int64_t tlen = h->lens[(size_t)tid];
-        host_ref(tid);                               // tells the pump's lookahead the FASTA length of this contig
+        { const double th0 = WinPipe::now(); host_ref(tid); pipe->add_part_time(3, WinPipe::now() - th0); }      // tells the pump's lookahead the FASTA length of this contig
         int64_t lo = has_reg ? beg0 : 0;
         int64_t hi_all = has_reg ? std::min(end0, tlen) : tlen;
         int64_t stop = has_reg ? end0 : INT64_MAX;       // no window reaches beyond this column
@@ -250,14 +250,16 @@ struct Runner {
             if (ce > cursor) {
                 j->tid = tid; j->cb = cursor; j->ce = ce; j->have_reads = true; j->hold = false;
                 // the next window depends on this one's result only if the -d cap can drop reads here (they leave the pump)
+                const double tc0 = WinPipe::now();
                 bool lockstep = cap_may_trigger(j->staged, conf.p.max_depth, pump);
+                pipe->add_part_time(0, WinPipe::now() - tc0);
                 // the overlap hash: who reaches bam_plp_push is the host's to say -- unless the -d cap can turn reads away here, or -C drops /
                 // re-scores reads on the device; then the device thread asks the lane with the window's read states (sta_set_mate_resolver),
                 // and the producer waits for the window
                 j->resolve_mates = false;
                 if (conf.p.flag & STA_MPLP_SMART_OVERLAPS) {
                     if (lockstep || (conf.fai && conf.p.capQ_thres > 10)) { j->resolve_mates = true; lockstep = true; }
-                    else pump.pair_staged(j->staged);
+                    else { const double tp0 = WinPipe::now(); pump.pair_staged(j->staged); pipe->add_part_time(1, WinPipe::now() - tp0); }
                 }
                 if (lockstep && shard.on) {
                     pipe->release(j);
@@ -298,7 +300,7 @@ struct Runner {
             if (pipe->error()) return -1;
             for (size_t f = 0; f < cap_dropped.size(); ++f) if (!cap_dropped[f].empty()) pump.drop(f, cap_dropped[f]);
             cap_dropped.clear();
-            pump.retire(ce);
+            { const double tr0 = WinPipe::now(); pump.retire(ce); pipe->add_part_time(2, WinPipe::now() - tr0); }
             cursor = std::max(cursor, ce);
         }
         pump.drop_tid_carry();
@@ -547,6 +549,7 @@ extern "C" int sta_main_mpileup(int argc, char **argv)
     Runner run(conf, devs);
     run.adaptive_windows = getenv("STA_WINDOW_COLS") == nullptr;
     Samples sm;
+    driver_pin_policy(fns);
     for (auto &fn : fns) {
         std::string err;
         auto r = AlnReader::open(fn, &err, io_threads_per_input((int)fns.size()));

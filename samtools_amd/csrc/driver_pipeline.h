@@ -25,6 +25,7 @@
 #include <deque>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -64,13 +65,21 @@ struct WinJob {
     std::vector<StagedFile> staged;
     // set by the device stage
     pvector<char> text; uint64_t out_bytes = 0;
+    std::deque<std::pair<int, size_t>> pieces;      // the text ring's pieces that hold this job's text, in order (WinPipe::ring_push; guarded by the pipe's mutex)
     sta_plan_info info{};
     std::vector<std::vector<uint32_t>> read_info;      // per file: engine info words, fetched only when the -d cap dropped reads
     int rc = 0;
+    bool ringed = false;                 // this run of the device stage sent the text through the ring (nothing in `text`)
     // pipeline state
     int state = 0;                       // 0 free / with the producer, 1 queued for the device, 2 device done, 3 written
     size_t trace_ix = (size_t)-1;        // STA_DRIVER_TIMING=3
 };
+
+// The text ring: a few page-locked pieces through which the device thread fetches a window's text and from which the writer writes it,
+// instead of one page-locked buffer of a whole window's text per pipeline slot (80 MB each for `mpileup` at 30x: 20-25 ms of page-locking
+// per slot on the device thread, inside the first windows' time -- profiles/r06_sessionG_e2e_window_trace.log).  Allocated once by
+// DevEngines when the runtime is up; used when one device thread feeds the writer (pieces then arrive in submission order).
+struct TextRing { std::vector<char *> buf; size_t piece = 0; };
 
 class WinPipe {
 public:
@@ -101,8 +110,8 @@ public:
                         t.t_submit - t0_, t.t_dev0 - t0_, t.t_dev1 - t0_, (t.t_dev1 - t.t_dev0) * 1e3, t.t_written - t0_, (double)t.bytes / 1e6);
         if (timing_)
             fprintf(stderr, "[driver timing] wall %.3f s | producer: fill+stage %.3f s (of it: waiting for the decode threads %.3f s, copying slices %.3f s), "
-                            "waiting for a slot %.3f s, waiting for results %.3f s | device thread busy %.3f s (the busiest of %d) | writer busy %.3f s | %llu windows\n",
-                    now() - t0_, t_fill_, t_decode_wait_, t_stage_copy_, t_slot_, t_wait_, t_dev_, (int)t_devn_.size(), t_wr_, (unsigned long long)n_jobs_);
+                            "waiting for a slot %.3f s, waiting for results %.3f s, depth-cap bound %.3f s, overlap pairs %.3f s, retiring reads %.3f s, reference %.3f s | device thread busy %.3f s (the busiest of %d) | writer busy %.3f s | %llu windows\n",
+                    now() - t0_, t_fill_, t_decode_wait_, t_stage_copy_, t_slot_, t_wait_, t_part_[0], t_part_[1], t_part_[2], t_part_[3], t_dev_, (int)t_devn_.size(), t_wr_, (unsigned long long)n_jobs_);
     }
     // a slot the producer may fill (blocks while all are in flight)
     WinJob *acquire()
@@ -120,7 +129,7 @@ public:
     {
         {
             std::lock_guard<std::mutex> g(m_);
-            j->state = 1; j->rc = 0; order_.push_back(j); devq_.push_back(j); ++n_jobs_;
+            j->state = 1; j->rc = 0; j->ringed = false; order_.push_back(j); devq_.push_back(j); ++n_jobs_;
             if (trace_) {
                 Trace t; t.seq = n_jobs_ - 1; t.tid = j->tid; t.cols = j->ce - j->cb; t.reads = 0; t.t_submit = now();
                 if (j->have_reads) for (const StagedFile &sf : j->staged) t.reads += sf.n();
@@ -147,7 +156,29 @@ public:
         return err_;
     }
     int error() { std::lock_guard<std::mutex> g(m_); return err_; }
+    // ---- the text ring (one device thread only) ----
+    void use_ring(TextRing *r)
+    {
+        std::lock_guard<std::mutex> g(m_);
+        if (!r || r->buf.empty() || !r->piece || t_devn_.size() != 1) return;
+        ring_ = r; ring_free_.clear();
+        for (size_t i = 0; i < r->buf.size(); ++i) ring_free_.push_back((int)i);
+    }
+    bool ring_on() { std::lock_guard<std::mutex> g(m_); return ring_ != nullptr; }
+    size_t ring_piece() const { return ring_ ? ring_->piece : 0; }
+    // a free piece (blocks while the writer holds them all); nullptr after an error
+    char *ring_acquire(int *idx)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return !ring_free_.empty() || err_.load() || stop_; });
+        if (ring_free_.empty()) return nullptr;
+        *idx = ring_free_.back(); ring_free_.pop_back();
+        return ring_->buf[(size_t)*idx];
+    }
+    void ring_release(int idx) { { std::lock_guard<std::mutex> g(m_); ring_free_.push_back(idx); } cv_.notify_all(); }
+    void ring_push(WinJob *j, int idx, size_t len) { { std::lock_guard<std::mutex> g(m_); j->pieces.emplace_back(idx, len); } cv_.notify_all(); }
     void add_fill_time(double s) { t_fill_ += s; }
+    void add_part_time(int what, double s) { if (what >= 0 && what < 4) t_part_[what] += s; }      // producer: 0 depth-cap bound, 1 overlap pairs, 2 retire, 3 reference
     void set_producer_split(double decode_wait, double stage_copy) { t_decode_wait_ = decode_wait; t_stage_copy_ = stage_copy; }
     static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
@@ -177,13 +208,29 @@ private:
             WinJob *j = nullptr;
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return (stop_ && order_.empty()) || (!order_.empty() && order_.front()->state == 2); });
+                cv_.wait(lk, [&] { return (stop_ && order_.empty()) || (!order_.empty() && (order_.front()->state == 2 || !order_.front()->pieces.empty())); });
                 if (order_.empty()) return;
                 j = order_.front();
+                if (!j->pieces.empty()) {
+                    // a piece of the front job's text (the job may still be on the device: its text leaves as it arrives)
+                    const std::pair<int, size_t> pc = j->pieces.front(); j->pieces.pop_front();
+                    const bool ok = !err_.load();
+                    lk.unlock();
+                    const double a = now();
+                    int rc = 0;
+                    if (ok && fwrite(ring_->buf[(size_t)pc.first], 1, pc.second, out_) != pc.second) { fprintf(stderr, "%s", werr_); rc = -1; }
+                    t_wr_ += now() - a;
+                    lk.lock();
+                    if (rc < 0 && !err_.load()) err_ = rc;
+                    ring_free_.push_back(pc.first);
+                    lk.unlock();
+                    cv_.notify_all();
+                    continue;
+                }
             }
             const double a = now();
             int rc = 0;
-            if (j->rc >= 0 && j->write && j->out_bytes && !err_.load()) {
+            if (j->rc >= 0 && j->write && j->out_bytes && !j->ringed && !err_.load()) {
                 if (fwrite(j->text.data(), 1, (size_t)j->out_bytes, out_) != (size_t)j->out_bytes) { fprintf(stderr, "%s", werr_); rc = -1; }
             }
             t_wr_ += now() - a;
@@ -208,6 +255,8 @@ private:
     bool stop_ = false; std::atomic<int> err_{0};      // written under m_, read by the stage threads outside it
     struct Trace { unsigned long long seq = 0; int tid = 0; int64_t cols = 0, reads = 0; double t_submit = 0, t_dev0 = 0, t_dev1 = 0, t_written = 0; uint64_t bytes = 0; };
     std::vector<Trace> trace_log_; bool trace_ = false;      // STA_DRIVER_TIMING=3: one line per window at the end
+    TextRing *ring_ = nullptr; std::vector<int> ring_free_;
+    double t_part_[4] = { 0, 0, 0, 0 };
     bool timing_ = false; double t0_ = 0, t_decode_wait_ = 0, t_stage_copy_ = 0, t_fill_ = 0, t_slot_ = 0, t_wait_ = 0, t_dev_ = 0, t_wr_ = 0; unsigned long long n_jobs_ = 0;
 };
 
@@ -219,6 +268,7 @@ private:
 struct DevEngines {
     std::vector<sta_engine *> eng;
     std::vector<void *> streams;
+    TextRing ring;                       // allocated behind the engines by start()'s thread (STA_TEXT_RING=pieces x MiB, default 6x8; 0: none)
     DevEngines() : n_(dev_threads()) {}
     ~DevEngines() { destroy(); }
     void start(int device);              // begins creating n() engines in the background
@@ -234,6 +284,30 @@ private:
 };
 int dev_threads_from_env();
 size_t pipe_slots_from_env(int n_dev);
+void driver_pin_policy(const std::vector<std::string> &paths);
+
+// the device stage's last step in both drivers: the window's text from the engine to the writer -- piece by piece through the ring, or
+// (several device threads, no ring) into the job's own buffer
+inline int fetch_text(WinPipe &pipe, WinJob &j, sta_engine *eng, uint64_t total)
+{
+    if (pipe.ring_on()) {
+        const size_t piece = pipe.ring_piece();
+        for (uint64_t off = 0; off < total; off += piece) {
+            const size_t n = (size_t)(total - off < piece ? total - off : piece);
+            int idx = -1;
+            char *b = pipe.ring_acquire(&idx);
+            if (!b) return -1;
+            if (sta_fetch_output_at(eng, b, off, n) != STA_OK) { pipe.ring_release(idx); return -2; }
+            pipe.ring_push(&j, idx, n);
+        }
+        j.ringed = true;
+    } else {
+        if (j.text.size() < (size_t)total) j.text.resize((size_t)total + (size_t)(total >> 3));
+        if (sta_fetch_output(eng, j.text.data(), total) != STA_OK) return -2;
+    }
+    j.out_bytes = total;
+    return 0;
+}
 
 // Can the -d cap (bam_plp_push: a read is dropped when more than max_depth reads are live at its start) possibly trigger for these
 // staged reads?  Conservative host-side bound: at a read's start at most the reads starting within the longest reference span

@@ -1599,6 +1599,18 @@ int sta_fetch_output(sta_engine *e, char *host_out, uint64_t n)
     return STA_OK;
 }
 
+int sta_fetch_output_at(sta_engine *e, char *host_out, uint64_t offset, uint64_t n)
+{
+    if (!e || (!host_out && n)) return STA_ERR_ARG;
+    hipSetDevice(e->device);
+    if (offset > e->out_bytes || n > e->out_bytes - offset) return fail(e, STA_ERR_ARG, "fetch beyond the output");
+    if (n) HIPCHK(hipMemcpyAsync(host_out, (const char *)e->last_out + offset, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    SYNC_STREAM();
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return hipfail(e, le, "emit kernel");
+    return STA_OK;
+}
+
 int sta_sync(sta_engine *e)
 {
     if (!e) return STA_ERR_ARG;

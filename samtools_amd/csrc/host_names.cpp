@@ -59,6 +59,12 @@ void OverlapNames::erase(Entry *e)
     if (!n_entries_) { for (Entry &x : tab_) x = Entry{}; n_tomb_ = 0; arena_.clear(); }     // (an empty table starts over: no tombstones, no names)
 }
 
+void OverlapNames::flush_pending()
+{
+    for (const Slot &b : pend_) if (!before(b.end, last_)) buf_add(b.h, b.end);
+    pend_.clear();
+}
+
 void OverlapNames::buf_add(uint64_t h, const Pt &end)
 {
     if ((buf_used_ + 1) * 2 > buf_.size()) {
@@ -107,6 +113,7 @@ int64_t OverlapNames::push(const Read &r, bool dropped)
             else if (r.mpos >= r.pos || ((r.flag & 1) && r.mpos == -1)) {
                 // the entry leaves with the first record of this name that leaves the buffer: this one, or one that is in there already
                 Pt kill = my_end;
+                flush_pending();
                 const size_t mask = buf_.size() - 1;
                 for (size_t s = (size_t)r.h & mask; buf_[s].h; s = (s + 1) & mask) {
                     const Slot &b = buf_[s];
@@ -119,7 +126,15 @@ int64_t OverlapNames::push(const Read &r, bool dropped)
             // in the buffer under this name without touching the hash: it takes the entry along when it leaves
             if (my_end.tid < e->kill.tid || (my_end.tid == e->kill.tid && my_end.pos < e->kill.pos)) e->kill = my_end;
         }
-        buf_add(r.h, my_end);
+        // (into the buffer's table only when somebody looks: single-end input never does, and the table insert -- with its rebuilds -- was a
+        // third of this function's time on the producer thread, profiles/r06_sessionI_e2e_big.log)
+        pend_.push_back(Slot{ r.h, my_end });
+        if (pend_.size() >= 8192) {
+            size_t k = 0;
+            for (const Slot &b : pend_) if (!before(b.end, last_)) pend_[k++] = b;
+            pend_.resize(k);
+            if (pend_.size() >= 4096) flush_pending();          // (really that many records in the pileup buffer: a deep pile)
+        }
     }
     last_ = Pt{ r.tid, r.pos };
     return found;

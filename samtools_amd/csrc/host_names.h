@@ -109,6 +109,8 @@ private:
     std::vector<Slot> buf_ = std::vector<Slot>(256);
     size_t buf_used_ = 0;
     void buf_add(uint64_t h, const Pt &end);
+    std::vector<Slot> pend_;                                      // buffered records not in the table yet (flush_pending)
+    void flush_pending();
 };
 
 }  // namespace sta

@@ -12,6 +12,13 @@
 namespace sta {
 
 void *pinned_alloc(size_t bytes);      // never returns nullptr (throws std::bad_alloc)
+// Page-locking costs ~0.3 ms per MB (a window's staging pools: ~15 ms per pipeline slot) and needs the HIP runtime, which takes the
+// first ~0.2 s of a process to come up.  The drivers therefore say when the runtime exists (until then an allocation is plain malloc
+// and nobody waits for the runtime: the producer stages its first windows while the engine is still being created), and whether the
+// input is large enough for page-locked staging pools to pay at all (round 6; profiles/r06_sessionG_e2e_window_trace.log).
+void pinned_runtime_is_up();
+void pinned_set_policy(bool page_lock);     // false: every pinned_alloc is plain malloc (small inputs); default true
+bool pinned_policy();
 void pinned_free(void *p) noexcept;
 
 template <class T> struct PinnedAlloc {

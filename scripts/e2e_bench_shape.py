@@ -30,15 +30,16 @@ exe = os.path.join(REPO, "samtools_amd", "bin", "samtools-amd")
 mb = reads.count("\n") * copies * 150 / 1e6
 print("input: %d contigs x %d columns, %.0f Mbases, BAM %.0f MB" % (copies, cols, mb, os.path.getsize(bam) / 1e6))
 # as a user runs it (no timing lines: the process ends as soon as its text is out, driver_capture.cpp driver_exit_now_if_asked), best of three
+big = os.environ.get("STA_E2E_BIG") is not None      # a multi-Gbase input: page-locked staging (the default there) against plain memory, nothing else
 for args in (["depth", "-a", bam], ["mpileup", "-B", "-f", big_fa, bam], ["mpileup", "-f", big_fa, bam]):
-    for env_extra in ({}, {"STA_NO_FAST_EXIT": "1"}):
+    for env_extra in (({}, {"STA_PIN": "0"}, {"STA_PIN": "0", "STA_PIPE_SLOTS": "3"}) if big else ({}, {"STA_NO_FAST_EXIT": "1"})):
         ts = []
         for rep in range(3):
             t0 = time.perf_counter()
             p = subprocess.run([exe] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, **env_extra))
             ts.append(time.perf_counter() - t0)
         print("plain run:", " ".join(args[:3])[:24], env_extra or "", " ".join("%.3f" % t for t in ts), "s wall; best = %.0f Mbases/s" % (mb / min(ts)), "rc", p.returncode)
-for env_extra in ({}, {"STA_GPU_INFLATE": "1"}):
+for env_extra in (({},) if big else ({}, {"STA_FAST_EXIT": "1"}, {"STA_GPU_INFLATE": "1"})):
     for args in (["depth", "-a", bam], ["mpileup", "-B", "-f", big_fa, bam], ["mpileup", "-f", big_fa, bam]):
         for rep in range(2):
             env = dict(os.environ, STA_DRIVER_TIMING=os.environ.get("STA_E2E_TIMING", "1"), **env_extra)
@@ -49,5 +50,5 @@ for env_extra in ({}, {"STA_GPU_INFLATE": "1"}):
             print(" ".join(args[:3])[:24], env_extra or "", "%.3f s wall = %.0f Mbases/s |" % (dt, mb / dt), " ".join(tl)[:420])
             if rep == 1:
                 for l in p.stderr.decode().split("\n"):
-                    if l.startswith("[timeline]"): print("     ", l)
+                    if l.startswith("[timeline]") or l.startswith("[window"): print("     ", l)
 shutil.rmtree(d, ignore_errors=True)

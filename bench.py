@@ -309,7 +309,7 @@ def e2e_file_to_text(inputs, sample_cols, oracle_sha_of_sample, oracle_text_path
            "includes": "process start, HIP context creation, BGZF inflate, staging, PCIe both ways, text written to /dev/null",
            "commands": {}}
 
-    def timed(args, reps=2):
+    def timed(args, reps=3):
         best = None
         for _ in range(reps):
             t0 = time.perf_counter()

@@ -1533,7 +1533,7 @@ static int depth_text(sta_engine *e, const sta_depth_params *p, char *out, uint6
         if (ncols > 0) {
             if (attempt) HIPCHK(hipMemsetAsync(&ctr->out_bytes, 0, 16, s));       // (the whole counter block was cleared before the first one)
             ProfScope ps(e, "depth_fused");
-            sta_launch_depth_fused(s, e->wd, *p, e->fused_status.p, (int32_t *)e->diff.p, out, cap, ctr, depth_lbuf(), status_zeroed && !attempt);
+            sta_launch_depth_fused(s, e->wd, *p, e->fused_status.p, (int32_t *)e->diff.p, out, cap, ctr, depth_lbuf(), status_zeroed && !attempt, (uint32_t *)e->line_len.p);
         }
         rc = fused_finish(e, info);
         if (rc) return rc;

@@ -84,6 +84,7 @@ struct DepthFusedArgs {
     uint32_t lbuf, per_wave, n_tiles;
     int32_t has_clip;
     int32_t diag;          // timing diagnostics only (STA_DEPTH_DIAG; wrong text): 1 = no EMIT phase, 2 = no look-back wait, 3 = no COUNT marks
+    uint32_t *lens;        // split form: the row length of every column (k_depth_fused<1> -> <2>)
 };
 
 __device__ __forceinline__ void lds_mark(int *row, int a, int b, int p0)
@@ -197,6 +198,12 @@ __device__ __forceinline__ uint32_t depth_row_len(const StaWinDev &W, const Dept
     return len;
 }
 
+// PHASE 0: the single launch described above.  The SPLIT form (round 6; STA_DEPTH_FORM=split) is the same code in two launches with a
+// one-workgroup scan between them: PHASE 1 = COUNT, the wave's text bytes and rows into status[2 (4 tile + wave)], every column's row
+// length into `lens`; k_depth_wave_scan turns the bytes into offsets and adds up the window's totals; PHASE 2 = EMIT from the stored
+// lengths.  No ticket (2 048 atomics on one address: 23 us) and no look-back chain (51 us with every tile resident and reaching it
+// together: profiles/r05_depth_phases.md); two more launches and 8 bytes per column through memory instead.
+template <int PHASE>
 __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P, DepthFusedArgs A)
 {
     __shared__ unsigned int s_tile;
@@ -208,7 +215,8 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
     int *s_diff = reinterpret_cast<int *>(lds_dtext);                 // [4 waves][2][DF_SPAN + 4]
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned int tile;
-    if (A.ticket) {
+    if (PHASE != 0) tile = blockIdx.x;
+    else if (A.ticket) {
         if (threadIdx.x == 0) s_tile = atomicAdd(A.ticket, 1u);      // tiles are handed out in start order (dev_lookback.h)
         __syncthreads();
         tile = s_tile;
@@ -224,6 +232,12 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
     unsigned long long n_rows = 0, n_cov = 0;
 #pragma unroll
     for (int k = 0; k < DF_CPL; ++k) len[k] = 0;
+    if (PHASE == 2) {
+        if (wave_on) {
+#pragma unroll
+            for (int k = 0; k < DF_CPL; ++k) { const int64_t col = c0 + DF_CPL * lane + k; len[k] = col < ncols ? A.lens[col] : 0u; lane_len += len[k]; }
+        }
+    } else
     if (wave_on) {
         const int p0 = W.col_beg + (int)c0;
         const int plast = c0 + DF_SPAN < ncols ? p0 + DF_SPAN - 1 : W.col_end - 1;
@@ -256,6 +270,21 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
     int wave_total_i;
     (void)wave_excl_scan_i32((int)lane_len, wave_total_i);
     const uint32_t wave_total = (uint32_t)wave_total_i;
+    if (PHASE == 1) {
+        n_rows = wave_sum_u64(n_rows); n_cov = wave_sum_u64(n_cov);
+        if (lane == 0) { unsigned long long *st = A.status + 2 * ((size_t)tile * 4 + wid); st[0] = wave_total; st[1] = (n_rows << 31) | n_cov; }
+        if (wave_on) {
+#pragma unroll
+            for (int k = 0; k < DF_CPL; ++k) { const int64_t col = c0 + DF_CPL * lane + k; if (col < ncols) A.lens[col] = len[k]; }
+        }
+        return;
+    }
+    unsigned long long off;
+    if (PHASE == 2) {
+        off = A.status[2 * ((size_t)tile * 4 + wid)];              // (k_depth_wave_scan: the exclusive prefix of the waves' bytes)
+        if (off + wave_total > A.capacity) return;                  // counted, not written: the host retries with room (the scan set the flag)
+        if (!wave_on || wave_total == 0) return;
+    } else {
     n_rows = wave_sum_u64(n_rows); n_cov = wave_sum_u64(n_cov);
     if (lane == 0) { s_wtot[wid][0] = wave_total; s_wtot[wid][1] = (n_rows << 31) | n_cov; }
     __syncthreads();
@@ -278,8 +307,9 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
     const unsigned long long wg_off = s_base[0], wg_bytes = s_base[1];
     if (wg_off + wg_bytes > A.capacity) { if (threadIdx.x == 0) A.ctr->overflow = 1; return; }     // counted, not written: the host retries with room
     if (!wave_on || wave_total == 0 || A.diag == 1) return;
-    unsigned long long off = wg_off;
+    off = wg_off;
     for (int w = 0; w < wid; ++w) off += s_wtot[w][0];
+    }
 
     // ---- EMIT: 64 consecutive rows at a time, lane j formats row j of the group.  (A lane formatting its own 8 consecutive rows
     // puts the lanes 8 x 16 = 128 bytes apart in the line buffer: with the usual 16-byte rows every byte store of the wave hit
@@ -314,17 +344,61 @@ __global__ void __launch_bounds__(256) k_depth_fused(StaWinDev W, DepthDevPar P,
     }
 }
 
-size_t sta_depth_fused_status_bytes(int64_t ncols) { const int64_t t = 4 * DF_SPAN; return (size_t)((ncols + t - 1) / t) * 16 + 16; }
+struct alignas(16) DU64x2 { unsigned long long x, y; };
+// the split form's scan: status[2 i] = bytes of wave i (four waves per tile) -> their exclusive prefix; the window's totals (and the
+// overflow flag) into the counters.  One workgroup; a thread takes whole tiles (64 contiguous bytes each, asked for together), the
+// per-thread sums are scanned wave by wave (shuffles) and across the sixteen waves by one of them: two barriers in all.
+__global__ void __launch_bounds__(1024) k_depth_wave_scan(unsigned long long *__restrict__ status, int64_t n_tiles, unsigned long long capacity, StaCounters *ctr)
+{
+    __shared__ unsigned long long s_w[16][2];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int64_t per = (n_tiles + 1023) / 1024, a = (int64_t)t * per, b = a + per < n_tiles ? a + per : n_tiles;
+    unsigned long long sum = 0, rows = 0;
+    for (int64_t i = a; i < b; ++i) {
+        const DU64x2 *q = reinterpret_cast<const DU64x2 *>(status + 8 * i);
+        const DU64x2 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+        sum += w0.x + w1.x + w2.x + w3.x; rows += w0.y + w1.y + w2.y + w3.y;
+    }
+    unsigned long long isum = sum, irows = rows;                   // inclusive scans over the wave
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long v = __shfl_up(isum, o), r = __shfl_up(irows, o);
+        if (lane >= o) { isum += v; irows += r; }
+    }
+    if (lane == 63) { s_w[wid][0] = isum; s_w[wid][1] = irows; }
+    __syncthreads();
+    unsigned long long base = 0, tot = 0, tot_rows = 0;
+    for (int w = 0; w < 16; ++w) { const unsigned long long v = s_w[w][0]; if (w < wid) base += v; tot += v; tot_rows += s_w[w][1]; }
+    unsigned long long run = base + isum - sum;                    // bytes in front of this thread's first tile
+    for (int64_t i = a; i < b; ++i) {
+        DU64x2 *q = reinterpret_cast<DU64x2 *>(status + 8 * i);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { DU64x2 v = q[w]; const unsigned long long bytes = v.x; v.x = run; q[w] = v; run += bytes; }
+    }
+    if (t == 0) {
+        ctr->out_bytes = tot;
+        ctr->n_lines = tot_rows >> 31; ctr->n_data_cols = tot_rows & 0x7fffffffull;
+        if (tot > capacity) ctr->overflow = 1;
+    }
+}
+
+// (two words per WAVE for the split form -- four waves per tile -- and the ticket behind them)
+size_t sta_depth_fused_status_bytes(int64_t ncols) { const int64_t t = 4 * DF_SPAN; return (size_t)((ncols + t - 1) / t) * 64 + 16; }
 
 void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, void *status, int32_t *counts, char *out,
-                            uint64_t capacity, StaCounters *ctr, uint32_t lbuf, bool status_zeroed)
+                            uint64_t capacity, StaCounters *ctr, uint32_t lbuf, bool status_zeroed, uint32_t *lens)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
     const int64_t tcols = 4 * DF_SPAN;
     const int64_t n_tiles = (ncols + tcols - 1) / tcols;
-    if (!status_zeroed) hipMemsetAsync(status, 0, sta_depth_fused_status_bytes(ncols), s);
+    // which form: the single launch.  The split one (STA_DEPTH_FORM=split) was measured at bench size in round 6 (profiles/r06_sessionK_depth_forms.log):
+    // count 0.107 + wave scan 0.026 + emit 0.076 = 0.210 ms against 0.219 ms -- the ticket and the look-back chain do go away, but a
+    // one-workgroup launch between the two halves costs most of what they cost; kept for A/B runs and as the tests' second witness.
+    bool split = false;
+    if (const char *f = getenv("STA_DEPTH_FORM")) split = lens != nullptr && f[0] == 's';
+    if (!split && !status_zeroed) hipMemsetAsync(status, 0, sta_depth_fused_status_bytes(ncols), s);
     DepthFusedArgs a;
+    a.lens = lens;
     a.status = (unsigned long long *)status;
     a.ticket = (unsigned int *)((char *)status + (size_t)n_tiles * 16);
     a.out = out; a.capacity = capacity; a.counts = counts; a.ctr = ctr;
@@ -337,5 +411,12 @@ void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_p
     static const bool use_ticket = !(getenv("STA_DEPTH_TICKET") && atoi(getenv("STA_DEPTH_TICKET")) == 0);
     if (!use_ticket) a.ticket = nullptr;
     const size_t marks = (size_t)4 * 2 * (DF_SPAN + 4) * sizeof(int), text = (size_t)4 * a.per_wave;
-    hipLaunchKernelGGL(k_depth_fused, dim3((unsigned)n_tiles), dim3(256), marks > text ? marks : text, s, w, d, a);
+    if (split) {
+        a.ticket = nullptr;
+        hipLaunchKernelGGL(k_depth_fused<1>, dim3((unsigned)n_tiles), dim3(256), marks, s, w, d, a);
+        hipLaunchKernelGGL(k_depth_wave_scan, dim3(1), dim3(1024), 0, s, a.status, n_tiles, (unsigned long long)capacity, ctr);
+        if (a.diag != 1) hipLaunchKernelGGL(k_depth_fused<2>, dim3((unsigned)n_tiles), dim3(256), text, s, w, d, a);
+        return;
+    }
+    hipLaunchKernelGGL(k_depth_fused<0>, dim3((unsigned)n_tiles), dim3(256), marks > text ? marks : text, s, w, d, a);
 }

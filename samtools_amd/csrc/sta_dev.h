@@ -193,7 +193,8 @@ void sta_launch_stage_compare(hipStream_t s, const void *a, const void *b, uint6
 // depth
 size_t sta_depth_fused_status_bytes(int64_t ncols);
 void sta_launch_depth_fused(hipStream_t s, const StaWinDev &w, const sta_depth_params &p, void *status, int32_t *counts, char *out,
-                            uint64_t capacity, StaCounters *ctr, uint32_t lbuf, bool status_zeroed = false);
+                            uint64_t capacity, StaCounters *ctr, uint32_t lbuf, bool status_zeroed = false,
+                            uint32_t *lens = nullptr /* ncols words: with it, windows of many tiles take the split form (count | scan | emit) */);
 void sta_launch_depth_pair(hipStream_t s, const StaReadsDev &r, int64_t origin, int32_t tid, void *table, size_t slots,
                            int32_t *chain_next, StaCounters *ctr);
 

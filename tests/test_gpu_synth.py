@@ -183,6 +183,27 @@ def test_extra_columns_on_the_read_major_kernels(tmp_path, oracle_bin, product_b
         assert (b"extra columns on the read-major kernels" in got.stderr) == ("STA_XFAST" not in env)
 
 
+@pytest.mark.parametrize("form", ["split", "fused"])
+def test_depth_in_its_two_forms(tmp_path, oracle_bin, product_bin, form):
+    """k_depth_fused as one launch (ticket + decoupled look-back) and split into count | wave scan | emit (kernels_depth.hip; the default from
+    256 tiles on, forced here on windows of every size): option sets of bam2depth.c:741-930 on three inputs, windows of 700 and 100 000
+    columns and one window per contig, against the oracle."""
+    sam, fa = write_synth_sam(str(tmp_path), n_ref=150000, depth=12, read_len=100, seed=181, paired=True, indel_rate=0.1, max_indel=8)
+    d2 = tmp_path / "b"; d2.mkdir()
+    sam2, _ = write_synth_sam(str(d2), n_ref=150000, depth=3, read_len=60, seed=182, paired=False)
+    d3 = tmp_path / "c"; d3.mkdir()
+    sam3, _ = write_synth_sam(str(d3), n_ref=150000, depth=40, read_len=151, seed=183, paired=True, indel_rate=0.02)
+    bed = tmp_path / "r.bed"
+    bed.write_text("chrS\t100\t5000\nchrS\t70000\t70001\nchrS\t90000\t149000\n")
+    for opts in ([], ["-a"], ["-aa", "-Q", "20", "-q", "15"], ["-J", "-s"], ["-H", "-a", "-b", str(bed)], ["-r", "chrS:60000-120000", "-g", "DUP"], ["-l", "70", "-a"]):
+        args = ["depth"] + opts + [sam, sam2, sam3]
+        want = subprocess.run([oracle_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        for env in ({}, {"STA_WINDOW_COLS": "700"}, {"STA_WINDOW_COLS": "100000"}):
+            got = subprocess.run([product_bin] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, STA_DEPTH_FORM=form, **env))
+            assert got.returncode == 0, got.stderr.decode()[-500:]
+            assert got.stdout == want, (opts, env, form)
+
+
 @pytest.mark.parametrize("mode", ["band_even", "band_odd", "long_reads", "general", "plain_E_off"])
 def test_baq_kernels_agree_with_oracle(tmp_path, oracle_bin, product_bin, mode):
     """The band-in-registers BAQ kernels (band width 7 with I rows stored every second row, band width 8 with every row; per-row

@@ -1455,6 +1455,9 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const unsigned long long *__
 
 #define TILE_WAVES 1            // waves per workgroup of k_mplp_emit_tile (they share nothing; measured 1 / 2 / 4 in one box: 0.420 / 0.428 / 0.486 ms)
 
+// DIAG (timing diagnostics only, STA_TILE_DIAG, wrong text; 0 = the product): 1 = no column walk (phase 2), 2 = neither conversion nor walk,
+// 3 = no flush of the text slice -- the phase budget of profiles/r06_tile_phase_budget.md
+template <int DIAG>
 __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W, MplpDevPar P, const uint64_t *__restrict__ offs, const uint2 *__restrict__ colinfo,
                                                                     const uint32_t *__restrict__ wfirst, const uint64_t *__restrict__ tbase, char *out, uint32_t lds_cap, unsigned n8)
 {
@@ -1513,9 +1516,10 @@ __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W,
                 const int ns = nlive - first < TILE_SLOTS ? nlive - first : TILE_SLOTS;
                 if (live && rank >= first && rank < first + TILE_SLOTS) tile_set_slot(T, rank - first, lane, ri, v_info, v_pos, v_end, v_b8);
                 wave_lds_sync();
-                const bool slot_simple = tile_phase1(T, lane, ns, R, P, p0, has_ref);
+                const bool slot_simple = DIAG == 2 ? true : tile_phase1(T, lane, ns, R, P, p0, has_ref);
                 const unsigned long long sm = __ballot(slot_simple && (lane & 3) == 0);      // bit 4 s: slot s is a one-op read
                 wave_lds_sync();
+                if (DIAG != 1 && DIAG != 2)
                 for (int s = 0; s < ns;) {
                     if (s + 4 <= ns && ((sm >> (4 * s)) & 0x1111ull) == 0x1111ull) { tile_phase2_rows4(T, s, st.col, st.cur_s, st.cur_q, st.mq_d); s += 4; continue; }
                     if ((sm >> (4 * s)) & 1ull) tile_phase2_row(T, s, st.col, st.cur_s, st.cur_q, st.mq_d);
@@ -1529,6 +1533,7 @@ __global__ void __launch_bounds__(64 * TILE_WAVES) k_mplp_emit_tile(StaWinDev W,
     }
     if (exists) lds_text[st.cur] = '\n';
     wave_lds_sync();
+    if (DIAG == 3) return;
     // flush: LDS offset == global address (mod 16)
     char *dst = out + o0;
     const uint32_t n = (uint32_t)wbytes;
@@ -1634,7 +1639,13 @@ void sta_launch_mplp_emit(hipStream_t s, const StaWinDev &w, const sta_mplp_para
         const uint32_t slice = (tile_cap + 48 + 15) & ~15u;       // must match k_mplp_emit_tile
         const size_t lds = (size_t)TILE_WAVES * (slice + TILE_LDS_BYTES);
         const unsigned gt = xcd_grid((nwaves + TILE_WAVES - 1) / TILE_WAVES);
-        hipLaunchKernelGGL(k_mplp_emit_tile, dim3(gt), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, wfirst, tbase, out, tile_cap, xcd_map_on() ? gt : 0u);
+        const char *td = getenv("STA_TILE_DIAG");
+        switch (td ? atoi(td) : 0) {
+        case 1: hipLaunchKernelGGL(k_mplp_emit_tile<1>, dim3(gt), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, wfirst, tbase, out, tile_cap, xcd_map_on() ? gt : 0u); break;
+        case 2: hipLaunchKernelGGL(k_mplp_emit_tile<2>, dim3(gt), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, wfirst, tbase, out, tile_cap, xcd_map_on() ? gt : 0u); break;
+        case 3: hipLaunchKernelGGL(k_mplp_emit_tile<3>, dim3(gt), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, wfirst, tbase, out, tile_cap, xcd_map_on() ? gt : 0u); break;
+        default: hipLaunchKernelGGL(k_mplp_emit_tile<0>, dim3(gt), dim3(64 * TILE_WAVES), lds, s, w, make_par(p, w.tlen), offs, colinfo, wfirst, tbase, out, tile_cap, xcd_map_on() ? gt : 0u);
+        }
         if (deep_mode == 2 && strip_rng) launch_deep(s, w, p, offs, colinfo, out, strip_rng, tile_cap, tbase);
         return;
     }

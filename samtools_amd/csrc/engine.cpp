@@ -74,7 +74,7 @@ struct sta_engine {
     int32_t *pin_baq = nullptr; size_t pin_baq_words = 0;               // page-locked: per file the BAQ plan's list length + class-S histogram
     std::vector<char> late_copy;       // mpileup plan, per file: the working quality pool exists only if the window has overlap-eligible reads
     bool gen_xlen_on = false;          // this plan's generic measuring pass filled colinfo / gen_xlen for the emit
-    DevBuf files_d, tname_d, bed_d, line_len, colinfo, gen_xlen, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, stage_bad, md_cap, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    DevBuf baq_list_tmp, files_d, tname_d, bed_d, line_len, colinfo, gen_xlen, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, stage_bad, md_cap, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
     DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
@@ -225,7 +225,7 @@ void sta_engine_destroy(sta_engine *e)
     for (auto &r : e->refs) r.second.buf.release();
     if (e->pin) hipHostFree(e->pin);
     if (e->pin_baq) hipHostFree(e->pin_baq);
-    DevBuf *all[] = { &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->gen_xlen, &e->wfirst, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
+    DevBuf *all[] = { &e->baq_list_tmp, &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->gen_xlen, &e->wfirst, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
                       &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->stage_bad, &e->md_cap, &e->chunk_words, &e->cov_out, &e->cov_hist, &e->sc_pos, &e->sc_delta, &e->sc_tmp, &e->sc_cov, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
                       &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
     for (DevBuf *b : all) b->release();
@@ -541,6 +541,18 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
         ProfScope ps(e, "prep_reads");
         wf_done = sta_launch_prep_reads(s, e->wd, e->files_h.data(), nf, *p, ctr, e->chunk_st, e->have_wfirst ? (uint32_t *)e->wfirst.p : nullptr);
     }
+    // the BAQ list of every file into class order (band width 7 | 8 | general: kernels_baq.hip k_baq_list_partition), while the host waits
+    // for the counters: one small workgroup per file.  STA_BAQ_LIST_SORT=0: not at all (every list kernel over the whole list, as in round 5)
+    bool list_sorted = false;
+    std::vector<size_t> list_tmp_off((size_t)nf, 0);
+    if (realn && !(getenv("STA_BAQ_LIST_SORT") && atoi(getenv("STA_BAQ_LIST_SORT")) == 0)) {
+        size_t words = 0;
+        for (int f = 0; f < nf; ++f) { list_tmp_off[(size_t)f] = words; words += (size_t)e->files_h[(size_t)f].n + 4; }
+        if (e->baq_list_tmp.ensure(words * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ list order) failed");
+        ProfScope ps(e, "baq_list_order");
+        for (int f = 0; f < nf; ++f) if (e->files_h[(size_t)f].n) sta_launch_baq_list_partition(s, e->files_h[(size_t)f], (int32_t *)e->baq_list_tmp.p + list_tmp_off[(size_t)f]);
+        list_sorted = true;
+    }
     if (realn) {
         // geometry bounds of the reads that need BAQ (written by k_prep_reads; maxima over all files)
         StaCounters c{};
@@ -627,6 +639,10 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                 // classes: 2 = band width 8 through the list, 1 = band width 7 through the list, 0 = band width 7 in place (round-3
                 // kernels, only with STA_BAQ_CLASS_S=0), then class S.  On the side streams a list class is ONE launch (both passes):
                 // its waves are placed before the persistent class-S kernel fills the chip and run to the end beside it.
+                // both band classes in the list: it was put in class order behind k_prep_reads (above); each list kernel's workgroups outside its
+                // own groups leave at once
+                const int32_t *list_rng = nullptr;
+                if (list_sorted && side && c.n_baq_bw8 && c.n_baq_bw7l && n_list > 0) list_rng = (const int32_t *)e->baq_list_tmp.p + list_tmp_off[(size_t)f] + n_list;
                 for (int cls = 2; cls >= 0; --cls) {
                     int64_t items = cls == 0 ? (c.n_baq_fast ? d.n : 0) : cls == 1 ? (c.n_baq_bw7l ? (int64_t)n_list : 0) : (c.n_baq_bw8 ? (int64_t)n_list : 0);
                     int64_t ngroups = (items + 63) / 64;
@@ -636,7 +652,8 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                         hipStream_t st = cls == 2 ? e->side : e->side2;
                         if (ngroups) {
                             ProfScope ps(e, cls == 2 ? "baq8_list" : "baq7_list", st, true);
-                            sta_launch_baq_list(st, d, e->wd, side_scratch + (cls == 2 ? 0 : (size_t)groupsL * slot_bytes), (int)c.max_lq_fast, cls == 2 ? 8 : 7, ngroups);
+                            sta_launch_baq_list(st, d, e->wd, side_scratch + (cls == 2 ? 0 : (size_t)groupsL * slot_bytes), (int)c.max_lq_fast, cls == 2 ? 8 : 7, ngroups,
+                                                list_rng ? list_rng + (cls == 2 ? 2 : 0) : nullptr);
                         }
                         HIPCHK(hipEventRecord(cls == 2 ? e->side_done : e->side2_done, st));
                         continue;

@@ -862,12 +862,51 @@ __global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, 
 // are placed they run to the end beside the persistent class-S kernel, instead of the second pass queueing behind it for a free slot.
 // A wave's own forward rows are visible to its backward pass in program order; nothing is shared between waves.
 template <int BW, int DEC, bool PLDS>
-__global__ void __launch_bounds__(256, 2) k_baq_list(StaReadsDev R, StaWinDev W, BaqTables T, int64_t ngroups, double *scratch, size_t slot_dbl, int lq_cap, int lds_rows)
+__global__ void __launch_bounds__(256, 2) k_baq_list(StaReadsDev R, StaWinDev W, BaqTables T, int64_t ngroups, double *scratch, size_t slot_dbl, int lq_cap, int lds_rows,
+                                                     const int32_t *__restrict__ range /* [lo, hi): the list groups that hold this kernel's reads (k_baq_list_partition); NULL: all */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t baq_state[];
+    if (range) {
+        // (a workgroup is four consecutive groups: it leaves when none of them is in the range -- before the tables are loaded)
+        const int64_t gb = (int64_t)blockIdx.x * 4;
+        if (gb + 4 <= range[0] || gb >= range[1]) return;
+    }
     BAQ_TABLES_INIT()
     baq_fwd_body<BW, DEC>(R, W, q2p, refc, 0, ngroups, 1, scratch, slot_dbl, lq_cap);
     baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, lt_ok ? lt_s : nullptr, baq_state, 0, ngroups, 1, scratch, slot_dbl, lq_cap, lds_rows);
+}
+
+// The list (R.chain[1 .. 1 + chain[0])) holds the reads of three kernels in the order k_prep_reads' blocks appended them: band width 7
+// outside class S, band width 8, general band.  Every list kernel walks groups of 64 list entries and a lane sits idle where the entry
+// is another kernel's -- on indel-rich input (mpileup30_indel: 42 000 list reads, half of them band width 8) both band kernels ran over
+// the whole list at half their lanes: twice the waves beside the persistent class-S kernel.  This puts the list in class order (7 | 8 |
+// general; the order inside a class does not matter: reads are independent) and says which groups hold which class, so that a list
+// kernel's workgroups outside its range leave at once.  One workgroup: LDS counters and cursors, the permutation through `tmp`, then back.
+__global__ void __launch_bounds__(1024) k_baq_list_partition(StaReadsDev R, int32_t *__restrict__ tmp)
+{
+    __shared__ int cnt[3], cur[3];
+    const int t = threadIdx.x;
+    if (t < 3) { cnt[t] = 0; cur[t] = 0; }
+    __syncthreads();
+    const int n = R.chain[0];
+    auto cls = [&](int32_t r) { const uint32_t info = R.info[r]; const int bw = (info & RI_BAQ) ? (int)((info >> RI_BAQ_BW_SHIFT) & 31) : 0; return bw == 7 ? 0 : bw == 8 ? 1 : 2; };
+    for (int i = t; i < n; i += 1024) atomicAdd(&cnt[cls(R.chain[1 + i])], 1);
+    __syncthreads();
+    const int n7 = cnt[0], n8 = cnt[1];
+    for (int i = t; i < n; i += 1024) {
+        const int32_t r = R.chain[1 + i];
+        const int k = cls(r);
+        tmp[(k == 0 ? 0 : k == 1 ? n7 : n7 + n8) + atomicAdd(&cur[k], 1)] = r;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) R.chain[1 + i] = tmp[i];
+    // the list groups (of 64 entries) that hold entries of band width 7 / 8: what k_baq_list<7 / 8> has to look at
+    if (t == 0) { tmp[n] = 0; tmp[n + 1] = (n7 + 63) / 64; tmp[n + 2] = n7 / 64; tmp[n + 3] = (n7 + n8 + 63) / 64; }
+}
+// tmp: chain[0] + 4 words; the group ranges [lo7, hi7, lo8, hi8] are left in its last four
+void sta_launch_baq_list_partition(hipStream_t s, const StaReadsDev &r, int32_t *tmp)
+{
+    hipLaunchKernelGGL(k_baq_list_partition, dim3(1), dim3(1024), 0, s, r, tmp);
 }
 
 template <int NB, int DEC>
@@ -930,7 +969,7 @@ static void run_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, vo
 }
 
 // both passes of the list's band-width-bw reads (ng groups of 64 list entries) in one launch, blocks of one wave
-void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw, int64_t ng)
+void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw, int64_t ng, const int32_t *range)
 {
     if (r.n == 0 || lq_cap <= 0 || ng <= 0) return;
     const BaqTables g_tables = baq_tables();
@@ -939,7 +978,7 @@ void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
     const bool plds = lq_cap <= BAQ_LDS_ROWS_MAX;
     const int rows = plds ? (lq_cap + 3) & ~3 : 0;
     const size_t lds = plds ? (size_t)4 * rows * 64 : 0;
-#define BAQ_LIST_LAUNCH(BW_, DEC_, P_) hipLaunchKernelGGL((k_baq_list<BW_, DEC_, P_>), dim3(nb), dim3(256), lds, s, r, w, g_tables, ng, (double *)scratch, slot, lq_cap, rows)
+#define BAQ_LIST_LAUNCH(BW_, DEC_, P_) hipLaunchKernelGGL((k_baq_list<BW_, DEC_, P_>), dim3(nb), dim3(256), lds, s, r, w, g_tables, ng, (double *)scratch, slot, lq_cap, rows, range)
     if (bw == 7) {
         if (baq_dec_mode() == 2) { if (plds) BAQ_LIST_LAUNCH(7, 2, true); else BAQ_LIST_LAUNCH(7, 2, false); }
         else { if (plds) BAQ_LIST_LAUNCH(7, 1, true); else BAQ_LIST_LAUNCH(7, 1, false); }

@@ -178,7 +178,11 @@ size_t sta_baq_band_scratch_bytes(int64_t n_reads, int lq_cap, int *groups_per_l
 void sta_launch_baq_band(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw,
                          int64_t g0, int64_t ng, int use_list, int pass /*0 forward, 1 backward*/);
 
-void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw, int64_t ng);   // both passes, list reads of band width bw
+void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int bw, int64_t ng,
+                         const int32_t *range = nullptr /* device: [lo, hi) of the list groups to look at */);   // both passes, list reads of band width bw
+// the list into class order (band width 7 | 8 | general); tmp = chain[0] + 4 words, the last four receive the group ranges
+// [lo7, hi7, lo8, hi8] for sta_launch_baq_list
+void sta_launch_baq_list_partition(hipStream_t s, const StaReadsDev &r, int32_t *tmp);
 // class S (baq_band7s.h): one fused persistent kernel over all groups of 64 reads; scratch = 256-byte header + two slots per resident wave
 size_t sta_baq7s_scratch_bytes(int lq_cap, int64_t ngroups, int *waves_out);
 void sta_launch_baq7s(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, void *scratch, int lq_cap, int waves, int64_t ngroups);

@@ -45,6 +45,47 @@ int main()
         assert(pipe.drain() < 0);
         assert(pipe.error() < 0);
     }
+    {
+        // the text ring (one device thread): three pieces of 16 bytes, so that a window's text is several pieces, the device stage waits for
+        // the writer, and the writer writes pieces of a job that is still on the device; held and unwritten jobs mixed in
+        TextRing ring; ring.piece = 16;
+        std::vector<std::vector<char>> store(3, std::vector<char>(16));
+        for (auto &b : store) ring.buf.push_back(b.data());
+        WinPipe *pp = nullptr;
+        WinPipe pipe(4, [&pp](WinJob &j, int) {
+            usleep((useconds_t)((j.cb * 53) % 400));
+            std::string t;
+            for (int r = 0; r < 1 + (int)(j.cb % 5); ++r) t += "ring " + std::to_string(j.cb) + " row " + std::to_string(r) + " all=" + std::to_string(j.all_mode) + "\n";
+            j.info.n_data_cols = (uint64_t)(j.cb % 3); j.out_bytes = 0;
+            if (!j.write) return 0;
+            // (fetch_text with a fake engine: the same acquire / push protocol)
+            for (size_t off = 0; off < t.size(); off += 16) {
+                const size_t n = t.size() - off < 16 ? t.size() - off : 16;
+                int idx = -1; char *b = pp->ring_acquire(&idx);
+                if (!b) return -1;
+                memcpy(b, t.data() + off, n);
+                pp->ring_push(&j, idx, n);
+            }
+            j.ringed = true; j.out_bytes = t.size();
+            return 0;
+        }, out, "write error\n", 1);
+        pp = &pipe;
+        pipe.use_ring(&ring);
+        assert(pipe.ring_on());
+        for (int k = 0; k < 150; ++k) {
+            WinJob *j = pipe.acquire();
+            j->tid = 0; j->cb = k; j->ce = k + 1; j->have_reads = false; j->write = true; j->hold = false; j->all_mode = 0;
+            auto text_of = [&](int all) { std::string t; for (int r = 0; r < 1 + k % 5; ++r) t += "ring " + std::to_string(k) + " row " + std::to_string(r) + " all=" + std::to_string(all) + "\n"; return t; };
+            if (k % 13 == 4) {
+                j->write = false; j->hold = true;
+                pipe.submit(j);
+                assert(pipe.wait(j) == 0);
+                if (j->info.n_data_cols) { j->all_mode = 1; j->write = true; j->hold = false; pipe.submit(j); want += text_of(1); }
+                else pipe.release(j);
+            } else { pipe.submit(j); want += text_of(0); }
+        }
+        assert(pipe.drain() == 0);
+    }
     fflush(out);
     rewind(out);
     std::string got; char buf[4096]; size_t n;

@@ -1,5 +1,6 @@
 """The drivers' three-stage window pipeline (samtools_amd/csrc/driver_pipeline.h) with a fake device stage, under ThreadSanitizer:
-output order == submission order, held jobs are submitted twice, wait() sees device results, device errors stop the output."""
+output order == submission order, held jobs are submitted twice, wait() sees device results, device errors stop the output; and the same
+through the text ring (round 6: pieces of a job's text leave while the job is still on the device, the device stage waits for free pieces)."""
 import os
 import subprocess
 

@@ -166,6 +166,9 @@ struct Runner {
         return 0;
     }
 
+    // -C with overlap detection: sam_cap_mapq reads BAQ-adjusted qualities, so only the device knows who reaches bam_plp_push
+    bool mates_on_device() const { return (conf.p.flag & STA_MPLP_SMART_OVERLAPS) && conf.fai && conf.p.capQ_thres > 10; }
+
     // the part of [lo, hi) of contig tid this rank prints (everything without STA_SHARD)
     void owned(int tid, int64_t lo, int64_t hi, int64_t *pb, int64_t *pe) const
     {
@@ -197,15 +200,19 @@ struct Runner {
         int64_t lo = has_reg ? beg0 : 0;
         int64_t hi_all = has_reg ? std::min(end0, tlen) : tlen;
         int64_t stop = has_reg ? end0 : INT64_MAX;       // no window reaches beyond this column
+        int64_t discard_until = INT64_MIN;               // sharded run: windows below this column are planned for their read states only
         if (shard.on) {
             // this rank's part of the contig: walk up to it with the pump's own bookkeeping (no staging, no device), so that the
             // first window inherits exactly the reads the unsharded run carries there
             int64_t pb, pe;
             owned(tid, lo, hi_all, &pb, &pe);
             if (pe <= pb) { pump.skip_to(tid, lo, INT64_MAX, conf.window_cols); pump.drop_tid_carry(); return pump.error() ? -1 : 0; }
-            if (pb > lo) pump.skip_to(tid, lo, pb, conf.window_cols);
+            // (-C with overlap detection: who reaches the overlap hash is the device's to say, so the windows in front of the block go
+            // through the plan like any other -- in lock-step, their text never made -- instead of being passed over on the host)
+            if (pb > lo && mates_on_device()) discard_until = pb;
+            else { if (pb > lo) pump.skip_to(tid, lo, pb, conf.window_cols); lo = pb; }
             if (pump.error()) return -1;
-            lo = pb; hi_all = pe; stop = std::min(stop, pe);
+            hi_all = pe; stop = std::min(stop, pe);
         }
         bool started = mode == 2;
         if (!win_cols) win_cols = conf.window_cols;
@@ -215,7 +222,10 @@ struct Runner {
             bool more = pump.next_pos(tid) != INT64_MAX;
             if (!more && !pump.has_carry()) break;
             if (!started) cursor = std::max(cursor, std::min(pump.carry_next_covered(cursor), pump.next_pos(tid)));   // skip uncovered gap
+            else if (cursor < discard_until) cursor = std::max(cursor, std::min(discard_until, std::min(pump.carry_next_covered(cursor), pump.next_pos(tid))));    // (nothing is printed there)
             int64_t ce_target = std::min(cursor + win_cols, stop);
+            const bool discard = cursor < discard_until;
+            if (discard) ce_target = std::min(ce_target, discard_until);
             if (ce_target <= cursor) {              // past the region / block end: pass over the rest of this contig
                 if (shard.on && !has_reg) { shard_done = true; pump.drop_tid_carry(); break; }      // ... or stop reading altogether: nothing behind a block is this rank's
                 pump.skip_to(tid, cursor, INT64_MAX, conf.window_cols);
@@ -252,16 +262,17 @@ struct Runner {
                 // the next window depends on this one's result only if the -d cap can drop reads here (they leave the pump)
                 const double tc0 = WinPipe::now();
                 bool lockstep = cap_may_trigger(j->staged, conf.p.max_depth, pump);
+                const bool cap_lockstep = lockstep;
                 pipe->add_part_time(0, WinPipe::now() - tc0);
                 // the overlap hash: who reaches bam_plp_push is the host's to say -- unless the -d cap can turn reads away here, or -C drops /
                 // re-scores reads on the device; then the device thread asks the lane with the window's read states (sta_set_mate_resolver),
                 // and the producer waits for the window
                 j->resolve_mates = false;
                 if (conf.p.flag & STA_MPLP_SMART_OVERLAPS) {
-                    if (lockstep || (conf.fai && conf.p.capQ_thres > 10)) { j->resolve_mates = true; lockstep = true; }
+                    if (lockstep || mates_on_device()) { j->resolve_mates = true; lockstep = true; }
                     else { const double tp0 = WinPipe::now(); pump.pair_staged(j->staged); pipe->add_part_time(1, WinPipe::now() - tp0); }
                 }
-                if (lockstep && shard.on) {
+                if (cap_lockstep && shard.on) {
                     pipe->release(j);
                     fprintf(stderr, "samtools mpileup: the -d depth cap can trigger near %s:%lld, which couples this block to its predecessors; run unsharded or raise -d\n",
                             h->names[(size_t)tid].c_str(), (long long)cursor + 1);
@@ -283,7 +294,7 @@ struct Runner {
                         if (pipe->wait(j) < 0) return -1;
                     } else pipe->release(j);                        // no column to print (the slot's read_info stays readable below)
                 } else {
-                    j->all_mode = started ? 1 : 0; j->write = true;
+                    j->all_mode = started ? 1 : 0; j->write = !discard;
                     pipe->submit(j);
                     if (lockstep) { if (pipe->wait(j) < 0) return -1; waited = true; }
                 }
@@ -347,12 +358,6 @@ struct Runner {
         const int all = conf.p.all;
         const int mode = all >= 2 ? 2 : all;
         shard = Shard::from_env();
-        if (shard.on && (conf.p.flag & STA_MPLP_SMART_OVERLAPS) && conf.fai && conf.p.capQ_thres > 10) {
-            // who reaches the overlap hash is then the device's to say (sam_cap_mapq on BAQ-adjusted qualities), window after window from
-            // the first record on: state that crosses blocks is refused, not approximated
-            fprintf(stderr, "samtools mpileup: a sharded run (STA_SHARD) supports no -C together with overlap detection: the overlap hash then depends on every earlier block; add -x or run unsharded\n");
-            return 1;
-        }
         if (shard.on) {
             if (mode == 1) { fprintf(stderr, "samtools mpileup: a sharded run (STA_SHARD) supports no single -a: whether a contig is printed depends on every block; use -aa or no -a\n"); return 1; }
             lin0.assign((size_t)h->nref() + 1, 0);

@@ -710,9 +710,11 @@ void ChunkPump::pair_fresh(File &f, const uint32_t *info, int64_t n_info)
             }
             if (!pushed) continue;
             OverlapNames::Read r;
-            r.h = c.name_h[q]; r.qname = c.names.data() + c.name_off[q]; r.l_qname = c.name_off[q + 1] - c.name_off[q] - 1;
-            r.flag = c.flag[q]; r.tid = c.tid[q]; r.mtid = c.mtid[q]; r.l_qseq = c.l_qseq[q];
-            r.pos = c.pos[q]; r.end = c.end(k); r.mpos = c.mpos[q]; r.isize = c.isize[q]; r.id = c.t_id[q];
+            r.flag = c.flag[q]; r.tid = c.tid[q]; r.pos = c.pos[q]; r.end = c.end(k);
+            if (!(r.flag & 2u) && f.onames.plain_case(dropped, false)) { f.onames.push_plain(c.name_h[q], r.tid, r.pos, r.end); continue; }
+            r.mtid = c.mtid[q]; r.l_qseq = c.l_qseq[q]; r.mpos = c.mpos[q]; r.isize = c.isize[q];
+            if (f.onames.plain_case(dropped, OverlapNames::eligible(r.flag, r.tid, r.mtid, r.l_qseq, r.end, r.mpos, r.isize))) { f.onames.push_plain(c.name_h[q], r.tid, r.pos, r.end); continue; }
+            r.h = c.name_h[q]; r.qname = c.names.data() + c.name_off[q]; r.l_qname = c.name_off[q + 1] - c.name_off[q] - 1; r.id = c.t_id[q];
             const int64_t holder = f.onames.push(r, dropped);
             if (holder < 0) continue;
             c.t_a[q] = holder;

@@ -105,10 +105,8 @@ int64_t OverlapNames::push(const Read &r, bool dropped)
         Entry *e = find(r);
         if (e && before(e->kill, last_)) { erase(e); e = nullptr; }
         // overlap_push's conditions (the device's RI_OLAP_EL)
-        int64_t isz = r.isize < 0 ? -r.isize : r.isize;
-        const bool eligible = !(r.flag & 8) && (r.flag & 2) && !((r.mtid >= 0 && r.mtid != r.tid) || (isz >= 2 * (int64_t)r.l_qseq && r.mpos >= r.end));
         const Pt my_end{ r.tid, r.end };
-        if (eligible) {
+        if (eligible(r.flag, r.tid, r.mtid, r.l_qseq, r.end, r.mpos, r.isize)) {
             if (e) { found = e->holder; erase(e); }
             else if (r.mpos >= r.pos || ((r.flag & 1) && r.mpos == -1)) {
                 // the entry leaves with the first record of this name that leaves the buffer: this one, or one that is in there already
@@ -129,15 +127,18 @@ int64_t OverlapNames::push(const Read &r, bool dropped)
         // (into the buffer's table only when somebody looks: single-end input never does, and the table insert -- with its rebuilds -- was a
         // third of this function's time on the producer thread, profiles/r06_sessionI_e2e_big.log)
         pend_.push_back(Slot{ r.h, my_end });
-        if (pend_.size() >= 8192) {
-            size_t k = 0;
-            for (const Slot &b : pend_) if (!before(b.end, last_)) pend_[k++] = b;
-            pend_.resize(k);
-            if (pend_.size() >= 4096) flush_pending();          // (really that many records in the pileup buffer: a deep pile)
-        }
+        if (pend_.size() >= 8192) thin_pending();
     }
     last_ = Pt{ r.tid, r.pos };
     return found;
+}
+
+void OverlapNames::thin_pending()
+{
+    size_t k = 0;
+    for (const Slot &b : pend_) if (!before(b.end, last_)) pend_[k++] = b;
+    pend_.resize(k);
+    if (pend_.size() >= 4096) flush_pending();          // (really that many records in the pileup buffer: a deep pile)
 }
 
 }  // namespace sta

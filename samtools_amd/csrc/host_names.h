@@ -91,6 +91,21 @@ public:
     // whose entry it found -- tweak_overlap_quality(that record, this one) -- or -1.
     int64_t push(const Read &r, bool dropped);
     size_t live_entries() const { return n_entries_; }
+    // overlap_push's conditions (the device's RI_OLAP_EL)
+    static bool eligible(unsigned flag, int32_t tid, int32_t mtid, int32_t l_qseq, int64_t end, int64_t mpos, int64_t isize)
+    {
+        if ((flag & (8u | 2u)) != 2u) return false;               // mate unmapped, or not a proper pair
+        const int64_t isz = isize < 0 ? -isize : isize;
+        return !((mtid >= 0 && mtid != tid) || (isz >= 2 * (int64_t)l_qseq && mpos >= end));
+    }
+    // push() of a record that was not turned away, is not eligible and meets an empty table (single-end input: every record): it only
+    // enters the buffer and moves the iterator -- the lanes call this without building a Read (the name is not looked at)
+    bool plain_case(bool dropped, bool is_eligible) const { return !dropped && !is_eligible && !n_entries_; }
+    void push_plain(uint64_t h, int32_t tid, int64_t pos, int64_t end)
+    {
+        if (end > pos) { pend_.push_back(Slot{ h, Pt{ tid, end } }); if (pend_.size() >= 8192) thin_pending(); }
+        last_ = Pt{ tid, pos };
+    }
 private:
     struct Pt { int32_t tid; int64_t pos; };
     static bool before(const Pt &kill, const Pt &max) { return max.tid > kill.tid || (max.tid == kill.tid && max.pos > kill.pos); }    // the iterator has passed `kill`
@@ -111,6 +126,7 @@ private:
     void buf_add(uint64_t h, const Pt &end);
     std::vector<Slot> pend_;                                      // buffered records not in the table yet (flush_pending)
     void flush_pending();
+    void thin_pending();
 };
 
 }  // namespace sta

@@ -189,6 +189,15 @@ template <int KIND> struct Sink {
     {
         if (v < 0) { put('-'); v = -v; }
         unsigned long long u = (unsigned long long)v;
+        if (KIND != 2 && u < 0x100000000ull) {
+            // (a position or a count: 32-bit arithmetic -- a 64-bit division by ten is a dozen vector instructions per digit, twice
+            // per digit with the counting loop, and the read-major kernel's row heads paid ~200 of them per strip)
+            uint32_t w = (uint32_t)u;
+            const int n = dec_digits_u32(w);
+            if (KIND == 1) { uint32_t e = cur + n; for (uint32_t q = e; q > cur;) { const uint32_t d = w / 10u; PLP_LDS[--q] = (char)('0' + (w - d * 10u)); w = d; } cur = e; }
+            else { char *e = g + n; for (char *q = e; q > g;) { const uint32_t d = w / 10u; *--q = (char)('0' + (w - d * 10u)); w = d; } g = e; }
+            return;
+        }
         int n = dec_digits(u);
         if (KIND == 1) {
             uint32_t e = cur + n;

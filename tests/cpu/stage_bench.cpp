@@ -34,7 +34,7 @@ int main(int argc, char **argv)
     const double t0 = now();
     ChunkPump pump(readers, pc, threads);
     std::vector<StagedFile> ring[3];
-    int64_t windows = 0, reads = 0, bases = 0; uint64_t sum = 0; double t_fill = 0;
+    int64_t windows = 0, reads = 0, bases = 0, mates = 0; uint64_t sum = 0; double t_fill = 0, t_pair = 0;
     for (;;) {
         const int tid = pump.next_tid();
         if (tid < 0 || pump.error()) break;
@@ -46,6 +46,13 @@ int main(int argc, char **argv)
             const int64_t ce = pump.fill_staged(tid, cursor, cursor + wcols, st);
             t_fill += now() - a;
             if (pump.error()) break;
+            if (mplp) {
+                // what driver_mpileup.cpp does on the producer thread behind fill_staged(): the window's new reads visit the overlap hash
+                const double b = now();
+                pump.pair_staged(st);
+                t_pair += now() - b;
+                for (int32_t m : st[0].mate) mates += m >= 0;
+            }
             const sta_reads v = st[0].view();
             reads += v.n_reads; bases += (int64_t)v.n_bases_total;
             if (v.n_bases_total) sum += v.qual[0] + v.qual[v.n_bases_total - 1] + v.seq[0];
@@ -60,5 +67,6 @@ int main(int argc, char **argv)
     printf("decode wait %.3f s, staging %.3f s | ", pump.stats().wait_s, pump.stats().stage_s);
     printf("windows %lld reads %lld padded bases %lld  wall %.3f s  fill_staged %.3f s  = %.0f Mbases/s (checksum %llu)\n",
            (long long)windows, (long long)reads, (long long)bases, dt, t_fill, bases / 1e6 / dt, (unsigned long long)sum);
+    if (mplp) printf("pair_staged %.3f s = %.1f ns per read, %lld reads found a partner\n", t_pair, t_pair * 1e9 / (double)(reads ? reads : 1), (long long)mates);
     return 0;
 }

@@ -84,6 +84,20 @@ def test_messy_multi_contig_input(product_bin, rich, cmd):
         assert _sharded(product_bin, rargs, world) == rwant
 
 
+@pytest.mark.parametrize("cmd", [["mpileup", "-C", "50", "-f", "{fa}"], ["mpileup", "-C", "20", "-aa", "-E", "-f", "{fa}"]], ids=["C50", "C20_aa_E"])
+def test_capq_with_overlap_detection_runs_the_windows_in_front_of_a_block_on_the_device(product_bin, pairs, rich, cmd):
+    """-C: sam_cap_mapq reads BAQ-adjusted qualities, so only the device knows who reaches the overlap hash; a rank plans the windows
+    in front of its block (text discarded) instead of passing them over on the host -- refused until round 6 (found by scripts/hunt6.py 612)"""
+    for sam, fa in (pairs, rich):
+        args = [a.format(fa=fa) for a in cmd] + [sam]
+        want = _run(product_bin, args)
+        assert len(want) > 100000
+        for world, env in ((2, None), (5, {"STA_WINDOW_COLS": "300", "STA_WINDOW_READS": "5"})):
+            assert _sharded(product_bin, args, world, env=env) == want, (world, env)
+        for cuts in ([30173], [13199], [100, 39001, 83990]):
+            assert _sharded(product_bin, args, len(cuts) + 1, cuts=cuts, env={"STA_WINDOW_COLS": "10000"}) == want, cuts
+
+
 def test_state_that_crosses_blocks_is_refused(product_bin, pairs):
     sam, fa = pairs
     for args, msg in ((["mpileup", "-a", "-f", fa, sam], b"single -a"), (["depth", "-a", sam], b"single -a"), (["mpileup", "-d", "10", "-B", sam], b"depth cap")):

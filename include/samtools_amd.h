@@ -449,6 +449,10 @@ int sta_sync(sta_engine *e);
 /* When enabled, every kernel launch is bracketed by HIP events on the engine
  * stream and accumulated per kernel name. */
 void sta_profile_enable(sta_engine *e, int on);
+/* Only the launches accumulated under `name` are bracketed (NULL or "": all of them again).  An event pair costs the stream
+ * 3-6 us, two dozen pairs a step were 0.07 ms of bench.py's timed region: the timed steps time the roofline's kernel only,
+ * the per-kernel table comes from a pass of its own. */
+void sta_profile_only(sta_engine *e, const char *name);
 void sta_profile_reset(sta_engine *e);
 /* Copies up to cap entries; returns the number of distinct kernels. */
 typedef struct sta_kernel_time { char name[48]; uint64_t launches; double total_ms; } sta_kernel_time;

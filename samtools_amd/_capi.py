@@ -167,6 +167,7 @@ _PROTOS = {
     "sta_fetch_output_at": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64]),
     "sta_sync": (C.c_int, [_P]),
     "sta_profile_enable": (None, [_P, C.c_int]),
+    "sta_profile_only": (None, [_P, C.c_char_p]),
     "sta_profile_reset": (None, [_P]),
     "sta_profile_get": (C.c_int, [_P, C.POINTER(KernelTime), C.c_int]),
     "sta_plp_plan": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(PlanInfo)]),
@@ -473,6 +474,9 @@ class Engine:
 
     def profile(self, on=True):
         lib.sta_profile_enable(self._h, 1 if on else 0)
+
+    def profile_only(self, name=None):
+        lib.sta_profile_only(self._h, name.encode() if name else None)
 
     def profile_reset(self):
         lib.sta_profile_reset(self._h)

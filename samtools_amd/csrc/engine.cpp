@@ -61,6 +61,7 @@ struct sta_engine {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr, side2 = nullptr;   // side streams: the list's BAQ groups (band width 8 / band width 7) run beside the main BAQ kernel
     hipEvent_t side_done = nullptr, side2_done = nullptr;
+    hipEvent_t plan_words_ev = nullptr, plan_ready_ev = nullptr;      // mpileup_pipeline: the BAQ plan's words are on the host / what the list kernels read is ready
     std::string err;
     std::map<int32_t, RefSeq> refs;
     // current window
@@ -104,6 +105,7 @@ struct sta_engine {
     void *last_out = nullptr;
     // profiling
     bool prof_on = false;
+    std::string prof_only;             // sta_profile_only: the one name that is timed (empty: every launch)
     std::map<std::string, ProfEntry> prof;
     std::vector<ProfPending> pending;
     std::vector<hipEvent_t> ev_pool;
@@ -151,14 +153,15 @@ hipEvent_t get_event(sta_engine *e)
     hipEvent_t ev; hipEventCreate(&ev); return ev;
 }
 struct ProfScope {
-    sta_engine *e; const char *name; hipEvent_t a{}, b{}; hipStream_t st;
+    sta_engine *e; const char *name; hipEvent_t a{}, b{}; hipStream_t st; bool active;
     ProfScope(sta_engine *e_, const char *n, hipStream_t on = nullptr, bool use_on = false) : e(e_), name(n), st(use_on ? on : e_->stream)
     {
-        if (e->prof_on) { a = get_event(e); b = get_event(e); hipEventRecord(a, st); }
+        active = e->prof_on && (e->prof_only.empty() || e->prof_only == n);
+        if (active) { a = get_event(e); b = get_event(e); hipEventRecord(a, st); }
     }
     ~ProfScope()
     {
-        if (e->prof_on) { hipEventRecord(b, st); e->pending.push_back(ProfPending{ name, a, b }); }
+        if (active) { hipEventRecord(b, st); e->pending.push_back(ProfPending{ name, a, b }); }
     }
 };
 void prof_drain(sta_engine *e)
@@ -233,6 +236,8 @@ void sta_engine_destroy(sta_engine *e)
     if (e->side_done) hipEventDestroy(e->side_done);
     if (e->side2) hipStreamDestroy(e->side2);
     if (e->side2_done) hipEventDestroy(e->side2_done);
+    if (e->plan_words_ev) hipEventDestroy(e->plan_words_ev);
+    if (e->plan_ready_ev) hipEventDestroy(e->plan_ready_ev);
     for (auto &p : e->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     delete e;
@@ -488,6 +493,7 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
     const bool capq = has_ref && p->capQ_thres > 10;
     std::vector<char> &late_copy = e->late_copy;      // per file: the working pool is k_olap_setup's business
     late_copy.assign((size_t)nf, 0);
+    std::vector<int> deferred_qp;                     // files whose working pool is copied while the host waits for the BAQ plan's words
     for (int f = 0; f < nf; ++f) {
         StaReadsDev &d = e->files_h[(size_t)f];
         bool tag_bq = realn && !redo && d.bq != nullptr;
@@ -496,7 +502,9 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             FileBufs &b = e->fb[(size_t)f];
             if (b.qual_work.ensure((size_t)d.n_bases_total + 32)) return fail(e, STA_ERR_HIP, "hipMalloc(qual) failed");
             d.qual = (uint8_t *)b.qual_work.p;
-            if (up_front) {
+            if (up_front && realn && !tag_bq) deferred_qp.push_back(f);      // behind k_prep_reads, inside the plan's host round trip (below)
+            else if (up_front) {
+                // (with a BQ:Z pool k_prep_reads puts the bytes of turned-away records back: the pool copy has to be there first)
                 StaReadsDev tmp = d;
                 if (!tag_bq) tmp.bq = nullptr;
                 ProfScope ps(e, "qual_prep");
@@ -541,16 +549,14 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
         ProfScope ps(e, "prep_reads");
         wf_done = sta_launch_prep_reads(s, e->wd, e->files_h.data(), nf, *p, ctr, e->chunk_st, e->have_wfirst ? (uint32_t *)e->wfirst.p : nullptr);
     }
-    // the BAQ list of every file into class order (band width 7 | 8 | general: kernels_baq.hip k_baq_list_partition), while the host waits
-    // for the counters: one small workgroup per file.  STA_BAQ_LIST_SORT=0: not at all (every list kernel over the whole list, as in round 5)
+    // the BAQ list of every file into class order (band width 7 | 8 | general: kernels_baq.hip k_baq_list_partition): one small workgroup per
+    // file, launched below while the host waits for the counters.  STA_BAQ_LIST_SORT=0: not at all (every list kernel over the whole list, as in round 5)
     bool list_sorted = false;
     std::vector<size_t> list_tmp_off((size_t)nf, 0);
     if (realn && !(getenv("STA_BAQ_LIST_SORT") && atoi(getenv("STA_BAQ_LIST_SORT")) == 0)) {
         size_t words = 0;
         for (int f = 0; f < nf; ++f) { list_tmp_off[(size_t)f] = words; words += (size_t)e->files_h[(size_t)f].n + 4; }
         if (e->baq_list_tmp.ensure(words * 4 + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ list order) failed");
-        ProfScope ps(e, "baq_list_order");
-        for (int f = 0; f < nf; ++f) if (e->files_h[(size_t)f].n) sta_launch_baq_list_partition(s, e->files_h[(size_t)f], (int32_t *)e->baq_list_tmp.p + list_tmp_off[(size_t)f]);
         list_sorted = true;
     }
     if (realn) {
@@ -575,7 +581,25 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
             HIPCHK(hipMemcpyAsync(w, d.chain, 4, hipMemcpyDeviceToHost, s));
             if (d.s_ws) HIPCHK(hipMemcpyAsync(w + 1, d.s_ws, (size_t)STA_SLIST_BINS * 4, hipMemcpyDeviceToHost, s));
         }
-        SYNC_S(s);
+        // The host waits for these words only (an event, not the stream): what does not depend on them -- the working copy of the quality
+        // pool, the list's class order -- is launched behind the event and runs during the round trip (they were 0.06 ms in front of it).
+        if (!e->plan_words_ev && hipEventCreateWithFlags(&e->plan_words_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return fail(e, STA_ERR_HIP, "hipEventCreate failed"); }
+        if (!e->plan_ready_ev && hipEventCreateWithFlags(&e->plan_ready_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return fail(e, STA_ERR_HIP, "hipEventCreate failed"); }
+        HIPCHK(hipEventRecord(e->plan_words_ev, s));
+        for (int f : deferred_qp) {
+            StaReadsDev tmp = e->files_h[(size_t)f];
+            tmp.bq = nullptr;
+            ProfScope ps(e, "qual_prep");
+            sta_launch_qual_prep(s, tmp, illum ? 1 : 0);
+        }
+        deferred_qp.clear();
+        if (list_sorted) {
+            ProfScope ps(e, "baq_list_order");
+            for (int f = 0; f < nf; ++f) if (e->files_h[(size_t)f].n) sta_launch_baq_list_partition(s, e->files_h[(size_t)f], (int32_t *)e->baq_list_tmp.p + list_tmp_off[(size_t)f]);
+        }
+        HIPCHK(hipEventRecord(e->plan_ready_ev, s));         // (the list kernels' side streams start behind this)
+        HIPCHK(hipEventSynchronize(e->plan_words_ev));
+        if (int v_ = stage_verdict(e)) return v_;
         if (e->pin) c = *c_dst;
         if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] n_baq=%llu (fast %llu, lq<=%llu) slow: max_lq=%llu max_bw=%llu kept=%llu\n", c.n_baq, c.n_baq_fast, c.max_lq_fast, c.max_lq, c.max_bw, c.n_kept);
         if (getenv("STA_DEBUG")) fprintf(stderr, "[sta] bw8=%llu general=%llu class_s=%llu (lq<=%llu) bw7_list=%llu\n", c.n_baq_bw8, c.n_baq_general, c.n_baq_s, c.max_lq_s, c.n_baq_bw7l);
@@ -618,8 +642,8 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                     if (e->baq_scratch.ensure(std::max(need, need_s) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(BAQ scratch) failed");
                 }
                 // The list's band kernels (band width 8, and band width 7 reads that class S does not take: a few dozen groups,
-                // latency bound) run on a side stream beside the main kernel(s) when both exist; the stream was synchronised
-                // above, so the side stream may start at once, and the main stream waits for it before the qualities are used
+                // latency bound) run on a side stream beside the main kernel(s) when both exist; the side streams wait for plan_ready_ev
+                // (the host only waited for the plan's words), and the main stream waits for them before the qualities are used
                 const size_t slot_bytes = need / (size_t)(gpl > 0 ? gpl : 1);
                 const int64_t groupsL = has_list_band ? ((int64_t)n_list + 63) / 64 : 0;
                 bool side = has_main && groupsL > 0 && groupsL <= 4096 && !getenv("STA_BAQ_NO_SIDE_STREAM");
@@ -650,6 +674,7 @@ static int mpileup_pipeline(sta_engine *e, const sta_mplp_params *p, bool do_max
                     static const char *const names[3][2] = { { "baq_fwd", "baq_bwd" }, { "baq7l_fwd", "baq7l_bwd" }, { "baq8_fwd", "baq8_bwd" } };
                     if (on_side) {
                         hipStream_t st = cls == 2 ? e->side : e->side2;
+                        HIPCHK(hipStreamWaitEvent(st, e->plan_ready_ev, 0));      // the working qualities and the list's order
                         if (ngroups) {
                             ProfScope ps(e, cls == 2 ? "baq8_list" : "baq7_list", st, true);
                             sta_launch_baq_list(st, d, e->wd, side_scratch + (cls == 2 ? 0 : (size_t)groupsL * slot_bytes), (int)c.max_lq_fast, cls == 2 ? 8 : 7, ngroups,
@@ -1637,6 +1662,7 @@ int sta_sync(sta_engine *e)
 }
 
 void sta_profile_enable(sta_engine *e, int on) { if (e) e->prof_on = on != 0; }
+void sta_profile_only(sta_engine *e, const char *name) { if (e) e->prof_only = name ? name : ""; }
 void sta_profile_reset(sta_engine *e) { if (e) { prof_drain(e); e->prof.clear(); } }
 int sta_profile_get(sta_engine *e, sta_kernel_time *out, int cap)
 {

@@ -1,0 +1,5 @@
+#!/bin/bash
+# Round 6, GPU session T: kernel + copy trace of mpileup30 steps with the re-ordered plan: where are the gaps now?
+cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=gpurun_out/r06t; mkdir -p $R/$O
+timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $R/$O/prof -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-e2e --workload mpileup30 > $R/$O/prof.log 2>&1
+cd $R; D=$(dirname $(ls $O/prof/*/*kernel_trace.csv $O/prof/*kernel_trace.csv 2>/dev/null | head -1)); python scripts/step_timeline.py $D | tee $O/timeline.txt

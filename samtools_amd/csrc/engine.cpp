@@ -368,7 +368,10 @@ int sta_stage_window(sta_engine *e, const sta_window *w)
         }
         d.clip_in = nullptr; d.mate = nullptr;
         if (r.olap_clip && n) rc |= upload(e, b.clip_in, r.olap_clip, n, &d.clip_in, mem);
-        if (r.olap_mate && n) rc |= upload(e, b.mate, r.olap_mate, n, &d.mate, mem);
+        // (STA_OLAP_DEVICE_TABLE=1, tests: the caller's partners are ignored and the window's own name table decides -- the path of callers that
+        //  stage no partners; right whenever the window holds every record of its templates)
+        static const bool own_table = getenv("STA_OLAP_DEVICE_TABLE") && atoi(getenv("STA_OLAP_DEVICE_TABLE")) != 0;
+        if (r.olap_mate && n && !own_table) rc |= upload(e, b.mate, r.olap_mate, n, &d.mate, mem);
         if (rc) return rc;
         // workspace
         if (b.end.ensure(n * 4 + 16) || b.maxend.ensure(n * 4 + 16) || b.info.ensure(n * 4 + 16) || b.clip.ensure(n * 4 + 16)

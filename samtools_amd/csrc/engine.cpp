@@ -75,7 +75,7 @@ struct sta_engine {
     int32_t *pin_baq = nullptr; size_t pin_baq_words = 0;               // page-locked: per file the BAQ plan's list length + class-S histogram
     std::vector<char> late_copy;       // mpileup plan, per file: the working quality pool exists only if the window has overlap-eligible reads
     bool gen_xlen_on = false;          // this plan's generic measuring pass filled colinfo / gen_xlen for the emit
-    DevBuf baq_list_tmp, files_d, tname_d, bed_d, line_len, colinfo, gen_xlen, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, stage_bad, md_cap, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, md_nm, md_len, md_state, md_tag, md_seq;
+    DevBuf baq_list_tmp, files_d, tname_d, bed_d, line_len, colinfo, gen_xlen, wfirst, strip_rng, offs, scan_tmp, counters, table, out, diff, fused_status, maxcnt_scratch, baq_scratch, baq_scratch2, stage_bad, md_cap, cov_out, cov_hist, sc_pos, sc_delta, sc_tmp, sc_cov, glf_tab, glf_redo, md_nm, md_len, md_state, md_tag, md_seq;
     // consensus
     DevBuf cons_tab, cons_ws, cons_E, cons_Enm, cons_cols, cons_depth, cons_coloff, cons_seq, cons_qual, cons_qwork, cons_nm, cons_colpos, cons_gran;
     sta_cons_params cons_p{}; bool cons_tab_ok = false;
@@ -229,7 +229,7 @@ void sta_engine_destroy(sta_engine *e)
     if (e->pin) hipHostFree(e->pin);
     if (e->pin_baq) hipHostFree(e->pin_baq);
     DevBuf *all[] = { &e->baq_list_tmp, &e->files_d, &e->tname_d, &e->bed_d, &e->line_len, &e->colinfo, &e->gen_xlen, &e->wfirst, &e->strip_rng, &e->offs, &e->scan_tmp, &e->counters, &e->table,
-                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->stage_bad, &e->md_cap, &e->chunk_words, &e->cov_out, &e->cov_hist, &e->sc_pos, &e->sc_delta, &e->sc_tmp, &e->sc_cov, &e->glf_tab, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
+                      &e->out, &e->diff, &e->fused_status, &e->maxcnt_scratch, &e->baq_scratch, &e->baq_scratch2, &e->stage_bad, &e->md_cap, &e->chunk_words, &e->cov_out, &e->cov_hist, &e->sc_pos, &e->sc_delta, &e->sc_tmp, &e->sc_cov, &e->glf_tab, &e->glf_redo, &e->md_nm, &e->md_len, &e->md_state, &e->md_tag, &e->md_seq,
                       &e->cons_tab, &e->cons_ws, &e->cons_E, &e->cons_Enm, &e->cons_cols, &e->cons_depth, &e->cons_coloff, &e->cons_seq, &e->cons_qual, &e->cons_qwork, &e->cons_nm, &e->cons_colpos, &e->cons_gran };
     for (DevBuf *b : all) b->release();
     if (e->side) hipStreamDestroy(e->side);
@@ -1204,7 +1204,11 @@ int sta_glf_plan(sta_engine *e, const sta_glf_params *gp, sta_plan_info *info)
     {
         ProfScope ps(e, "glf_cols");
         const double *t = (const double *)e->glf_tab.p;
-        sta_launch_glf_cols(e->stream, e->wd, gp->min_baseQ, 60, saved_ref, saved_len, t + sta::GLF_FK_OFF, t + sta::GLF_BETA_OFF, t + sta::GLF_LHET_OFF, e->out.p);
+        double mean_depth = 0;
+        for (int f = 0; f < nf; ++f) mean_depth += (double)e->files_h[(size_t)f].n_bases_total;
+        mean_depth = ncols > 0 ? mean_depth / (double)ncols / (double)(nf > 0 ? nf : 1) : 0;
+        if (e->glf_redo.ensure(sta_glf_redo_bytes(e->wd) + 64)) return fail(e, STA_ERR_HIP, "hipMalloc(glf groups) failed");
+        sta_launch_glf_cols(e->stream, e->wd, gp->min_baseQ, 60, saved_ref, saved_len, t + sta::GLF_FK_OFF, t + sta::GLF_BETA_OFF, t + sta::GLF_LHET_OFF, e->out.p, (uint8_t *)e->glf_redo.p, mean_depth);
     }
     HIPCHK(hipMemcpyAsync(&e->ctr_h, e->counters.p, sizeof(StaCounters), hipMemcpyDeviceToHost, e->stream));
     SYNC_STREAM();

@@ -24,17 +24,59 @@ __device__ __forceinline__ int nt16_to_2bit(int c) { return c == 1 ? 0 : c == 2 
 
 #define GLF_KEYS 600            // (q - 4) in 0..59, strand, base 0..4: key = ((q - 4) * 2 + strand) * 5 + base
 
-__global__ void __launch_bounds__(64) k_glf_cols(StaWinDev W, GlfPar P, GlfCol *out)
+// The per-column counters.  S == 0: one byte per key, tile[key * 64 + lane] -- 37.5 KB of LDS per wave, i.e. FOUR waves per CU, one per SIMD: the
+// kernel ran at 1.4 % of the HBM roof with nothing to hide its latencies behind (6.6 ms for 4 M columns at 30x).  A column holds few DISTINCT
+// keys (a handful of quality values x two strands x the reference base and an error or two): S > 0 keeps S slots (key << 8 | count) per column,
+// open addressing with linear probing, slots[slot * 64 + lane] -- 16 KB per wave at S = 64, ten waves per CU.  A column that needs more than
+// S slots marks its group of 64 columns in `redo` and a second launch of the S == 0 form computes those groups (and leaves at once elsewhere).
+template <int S> struct GlfCnt {
+    uint32_t *t; int lane; bool over;
+    __device__ __forceinline__ void clear() { for (int i = lane; i < (S ? S * 64 : GLF_KEYS * 64 / 4); i += 64) t[i] = S ? 0xffffffffu : 0u; over = false; }
+    __device__ __forceinline__ void add(int key)
+    {
+        if (S == 0) { reinterpret_cast<uint8_t *>(t)[key * 64 + lane]++; return; }
+        int h = key & (S - 1);
+        for (int probe = 0; probe < S; ++probe, h = (h + 1) & (S - 1)) {
+            const uint32_t w = t[h * 64 + lane];
+            if (w == 0xffffffffu) { t[h * 64 + lane] = (uint32_t)key << 8 | 1u; return; }
+            if ((int)(w >> 8) == key) { t[h * 64 + lane] = w + 1u; return; }
+        }
+        over = true;
+    }
+    // the count of a key that was added (S == 0: and the counter left clean for the next file)
+    __device__ __forceinline__ int take(int key)
+    {
+        if (S == 0) { uint8_t *b = reinterpret_cast<uint8_t *>(t) + key * 64 + lane; const int r = *b; *b = 0; return r; }
+        int h = key & (S - 1);
+        for (int probe = 0; probe < S; ++probe, h = (h + 1) & (S - 1)) {
+            const uint32_t w = t[h * 64 + lane];
+            if ((int)(w >> 8) == key) return (int)(w & 255u);
+            if (w == 0xffffffffu) break;
+        }
+        return 0;
+    }
+};
+
+// Which form a window starts with is decided on the device from a sample of its qualities (k_glf_tier: the number of distinct values that
+// can reach the counters, and the depth the host knows): tier[0] = the level, 16 | 32 | 64 slots | the byte tile.  The four forms are launched one behind the other; a form
+// below the chosen one leaves at once, the chosen one takes every group, a form above it the groups the one before it marked.
+template <int S>
+__global__ void __launch_bounds__(64) k_glf_cols(StaWinDev W, GlfPar P, GlfCol *out, uint8_t *redo, const uint32_t *tier)
 {
-    extern __shared__ uint8_t tile[];             // [GLF_KEYS][64] byte counters: lane's counter of a key at tile[key * 64 + lane]
+    extern __shared__ uint8_t tile[];             // S == 0: [GLF_KEYS][64] byte counters; S > 0: [S][64] slot words
+    if (tier) {
+        const int start = (int)*tier;             // level of the first form: 0 = 16 slots, 1 = 32, 2 = 64, 3 = the byte tile for every column
+        const int mine = S == 0 ? 3 : S == 64 ? 2 : S == 32 ? 1 : 0;
+        if (mine < start) return;
+        if (mine > start && !redo[blockIdx.x]) return;
+    }
     const int lane = threadIdx.x & 63;
     const int64_t ncols = (int64_t)W.col_end - W.col_beg;
     const int64_t c0 = (int64_t)blockIdx.x * 64;
     if (c0 >= ncols) return;
-    {
-        uint32_t *tw = reinterpret_cast<uint32_t *>(tile);
-        for (int i = lane; i < GLF_KEYS * 64 / 4; i += 64) tw[i] = 0u;     // one wave per block: no barrier needed
-    }
+    GlfCnt<S> cn; cn.t = reinterpret_cast<uint32_t *>(tile); cn.lane = lane;
+    cn.clear();                                    // one wave per block: no barrier needed
+    bool over_any = false;
     const int p0 = W.col_beg + (int)c0;
     const int p = p0 + lane;
     const bool active = p < W.col_end;
@@ -87,7 +129,7 @@ __global__ void __launch_bounds__(64) k_glf_cols(StaWinDev W, GlfPar P, GlfCol *
                     }
                     const int rev = (info & RI_REV) ? 1 : 0;
                     if (cnt < GLF_MAXB) {
-                        tile[(((q - 4) * 2 + rev) * 5 + b) * 64 + lane]++;
+                        cn.add(((q - 4) * 2 + rev) * 5 + b);
                         const uint64_t bit = 1ull << (q - 4);
                         const uint64_t fb = rev ? 0ull : bit, rb = rev ? bit : 0ull;
                         mf0 |= b == 0 ? fb : 0ull; mf1 |= b == 1 ? fb : 0ull; mf2 |= b == 2 ? fb : 0ull; mf3 |= b == 3 ? fb : 0ull; mf4 |= b == 4 ? fb : 0ull;
@@ -119,9 +161,7 @@ __global__ void __launch_bounds__(64) k_glf_cols(StaWinDev W, GlfPar P, GlfCol *
 #pragma unroll
                 for (int s = 1; s >= 0; --s) {
                     if (!(((s ? mr[b] : mf[b]) >> qi) & 1ull)) continue;
-                    const int key = ((qi * 2 + s) * 5 + b) * 64 + lane;
-                    const int reps = tile[key];
-                    tile[key] = 0;                                   // leave the tile clean for the next file
+                    const int reps = cn.take((qi * 2 + s) * 5 + b);
                     for (int t = 0; t < reps; ++t) {
                         const int wv = s ? wr : wf;
                         const double fk = P.fk[wv];
@@ -157,14 +197,60 @@ __global__ void __launch_bounds__(64) k_glf_cols(StaWinDev W, GlfPar P, GlfCol *
             }
         }
         if (active) out[(size_t)(c0 + lane) * (size_t)W.nfiles + (size_t)f] = o;
+        if (S) { over_any |= cn.over; if (f + 1 < W.nfiles) cn.clear(); }
+    }
+    if (S && redo) { const bool any = __ballot(over_any) != 0; if (lane == 0) redo[blockIdx.x] = any ? 1 : 0; }      // (S == 0 holds every key)
+}
+
+// distinct quality values (as they reach the counters: below min_baseQ dropped, clamped to [4, 63]) among the first 64 KiB of the first file's
+// qualities; with the window's mean depth: how many distinct (quality, strand, base) keys a column can be expected to hold at most
+__global__ void __launch_bounds__(1024) k_glf_tier(StaWinDev W, int min_baseQ, float depth, uint32_t *tier)
+{
+    __shared__ unsigned long long mask;
+    if (threadIdx.x == 0) mask = 0;
+    __syncthreads();
+    unsigned long long m = 0;
+    if (W.nfiles > 0 && W.files[0].n) {
+        const StaReadsDev &R = W.files[0];
+        const uint64_t nb = R.n_bases_total < 65536 ? (uint64_t)R.n_bases_total : 65536ull;
+        for (uint64_t i = threadIdx.x; i < nb; i += blockDim.x) {
+            int q = R.qual[i];
+            if (q < min_baseQ) continue;
+            q = q > 63 ? 63 : q < 4 ? 4 : q;
+            m |= 1ull << q;
+        }
+    }
+    for (int d = 32; d; d >>= 1) m |= __shfl_xor(m, d);
+    if ((threadIdx.x & 63) == 0 && m) atomicOr(&mask, m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nq = __popcll(mask);
+        const float nmax = depth + 3.f * sqrtf(depth) + 2.f;          // entries of a column (Poisson tail)
+        float keys = 2.5f * (float)nq + 2.f;                          // two strands, the column's base and an error or two
+        if (keys > nmax) keys = nmax;
+        *tier = keys <= 12.f ? 0u : keys <= 24.f ? 1u : keys <= 48.f ? 2u : 3u;
     }
 }
 
+size_t sta_glf_redo_bytes(const StaWinDev &w) { const int64_t ncols = (int64_t)w.col_end - w.col_beg; return 64 + (ncols > 0 ? (size_t)((ncols + 63) / 64) : 0); }
+
+// redo: sta_glf_redo_bytes() -- the chosen form (one word, 64 bytes reserved) + one byte per group of 64 columns.
+// STA_GLF_SLOTS = 0 (the byte tile for every column, as before round 6) | 16 | 32 | 64: that form first whatever the sample says
 void sta_launch_glf_cols(hipStream_t s, const StaWinDev &w, int min_baseQ, int capQ, const char *ref, int64_t ref_len,
-                         const double *fk, const double *beta, const double *lhet, void *out)
+                         const double *fk, const double *beta, const double *lhet, void *out, uint8_t *redo, double mean_depth)
 {
     int64_t ncols = (int64_t)w.col_end - w.col_beg;
     if (ncols <= 0) return;
     GlfPar p{ min_baseQ, capQ, ref, ref_len, fk, beta, lhet };
-    hipLaunchKernelGGL(k_glf_cols, dim3((unsigned)((ncols + 63) / 64)), dim3(64), GLF_KEYS * 64, s, w, p, (GlfCol *)out);
+    static const int forced = [] { const char *e = getenv("STA_GLF_SLOTS"); return e && *e ? atoi(e) : -1; }();
+    const dim3 grid((unsigned)((ncols + 63) / 64));
+    if (forced == 0 || !redo) { hipLaunchKernelGGL(k_glf_cols<0>, grid, dim3(64), GLF_KEYS * 64, s, w, p, (GlfCol *)out, (uint8_t *)nullptr, (const uint32_t *)nullptr); return; }
+    uint32_t *tier = reinterpret_cast<uint32_t *>(redo);
+    uint8_t *flags = redo + 64;
+    if (forced == 16 || forced == 32 || forced == 64) { const uint32_t v = forced == 16 ? 0u : forced == 32 ? 1u : 2u; hipMemcpyAsync(tier, &v, 4, hipMemcpyHostToDevice, s); hipStreamSynchronize(s); }
+    else hipLaunchKernelGGL(k_glf_tier, dim3(1), dim3(1024), 0, s, w, min_baseQ, (float)mean_depth, tier);
+    hipLaunchKernelGGL(k_glf_cols<16>, grid, dim3(64), 16 * 64 * 4, s, w, p, (GlfCol *)out, flags, (const uint32_t *)tier);
+    hipLaunchKernelGGL(k_glf_cols<32>, grid, dim3(64), 32 * 64 * 4, s, w, p, (GlfCol *)out, flags, (const uint32_t *)tier);
+    hipLaunchKernelGGL(k_glf_cols<64>, grid, dim3(64), 64 * 64 * 4, s, w, p, (GlfCol *)out, flags, (const uint32_t *)tier);
+    hipLaunchKernelGGL(k_glf_cols<0>, grid, dim3(64), GLF_KEYS * 64, s, w, p, (GlfCol *)out, flags, (const uint32_t *)tier);
 }

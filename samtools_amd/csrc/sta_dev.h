@@ -142,7 +142,8 @@ void sta_launch_plp_fill(hipStream_t s, const StaWinDev &w, const uint64_t *offs
 
 // coverage / bedcov column reductions (kernels_cov.hip)
 void sta_launch_glf_cols(hipStream_t s, const StaWinDev &w, int min_baseQ, int capQ, const char *ref, int64_t ref_len,
-                         const double *fk, const double *beta, const double *lhet, void *out);
+                         const double *fk, const double *beta, const double *lhet, void *out, uint8_t *redo, double mean_depth);
+size_t sta_glf_redo_bytes(const StaWinDev &w);
 void sta_launch_calmd_tag(hipStream_t s, const StaReadsDev &r, int apply, uint8_t *tag_pool, uint8_t *state, const uint8_t *bq_pool);
 void sta_launch_md_len(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int32_t *nm, uint32_t *md_len, uint8_t *state);
 void sta_launch_md_emit(hipStream_t s, const StaReadsDev &r, const StaWinDev &w, int use_equal, int bin_qual, int max_nm,

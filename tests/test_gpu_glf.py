@@ -50,3 +50,29 @@ def test_glf_deep_columns_are_flagged_and_still_agree(tmp_path, oracle_bin, prod
     got, want = run_both(oracle_bin, product_bin, ["-f", fa, sam])
     assert got == want
     assert any(l.split(b"\t")[4] == b"1" for l in want.split(b"\n") if l)
+
+
+@pytest.mark.parametrize("slots", ["auto", "64", "32", "16", "0"])
+def test_glf_columns_with_many_distinct_qualities(tmp_path, oracle_bin, product_bin, slots):
+    """The kernel keeps a column's counters (errmod_cal's sorted multiset of quality / strand / base) in a few LDS slots per column and sends a
+    group of columns whose keys do not fit through the one-byte-per-key form in a second launch (kernels_glf.hip GlfCnt): qualities drawn
+    from 0..60 at depth 90 give most columns more distinct keys than 32 or 64 slots hold; at depth 12 everything fits.  STA_GLF_SLOTS=0 is the
+    second launch's form for every column, 32 / 64 force the first form."""
+    import random
+    rnd = random.Random(77)
+    for depth, tag in ((90, "deep"), (12, "shallow")):
+        sam, fa = write_synth_sam(str(tmp_path), n_ref=2500, depth=depth, read_len=100, seed=33 + depth, paired=False, name="c" + tag)
+        lines = []
+        for l in open(sam):
+            if not l.startswith("@"):
+                f = l.rstrip("\n").split("\t")
+                f[10] = "".join(chr(33 + rnd.randint(0, 60)) for _ in f[9])
+                l = "\t".join(f) + "\n"
+            lines.append(l)
+        open(sam, "w").writelines(lines)
+        env = dict(os.environ)
+        env.pop("STA_GLF_SLOTS", None)
+        if slots != "auto": env["STA_GLF_SLOTS"] = slots            # (auto: k_glf_tier picks the first form from a sample of the qualities)
+        got, want = run_both(oracle_bin, product_bin, ["-Q", "0", "-f", fa, sam], env)
+        assert got == want, (tag, slots)
+        assert want.count(b"\n") > 2000

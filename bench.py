@@ -52,9 +52,14 @@ def _wl(kind, depth, cols, argv, baq=False, bpb=None, gen=None, flags_on=0, flag
 
 _REALN, _REDO_BAQ, _NO_ORPHAN = 1 << 4, 1 << 6, 1 << 3      # STA_MPLP_* (include/samtools_amd.h)
 _PRINT_MAPQ_CHAR, _PRINT_QPOS, _PRINT_QNAME = 1 << 11, 1 << 12, 1 << 13
+PIECE_COLS = 4 << 20        # synthetic inputs above this many columns are assembled from pieces of this size (make_reads)
 WORKLOADS = {
     # BASELINE.json configs[2] (the metric's configuration): mpileup -f, BAQ on, 30x 150 bp
-    "mpileup30": _wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True),
+    # (the headline: bench.py steps a window of 16 M columns -- 503 Mbases, 3.36 M reads, 1.28 GB of text, ~2.5 GB resident with the inputs; the
+    #  parity tests of tests/test_gpu_benchsize_parity.py use `cols` and, for this workload, the stepped window as well.  The class-S BAQ kernel
+    #  is persistent: its tail and the latency-bound list kernels beside it are per window, and at 4 M columns they were 12 % of the step:
+    #  profiles/r06_sessionZ_window_size.log)
+    "mpileup30": dict(_wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True), bench_cols=16 << 20),
     "mpileup30_B": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN),
     # configs[3] shape (deep columns); --gpus N shards it like mpileup30
     "mpileup300": _wl("mpileup", 300, 1 << 19, ["mpileup", "-f", "{fa}", "{sam}"], baq=True),
@@ -246,6 +251,14 @@ def make_reads(wl, ref, chunk_cols, seed_reads=42, chunks=None):
         rd["_abs_pos"] = rd["_abs_pos"].copy()
         return rd
     kw = {k: g[k] for k in ("indel_rate", "trim_rate", "trim_max") if k in g}
+    # a window above PIECE_COLS is assembled from pieces of that size (a multiple of it: bench_cols), built by a few threads; `chunks`
+    # counts in units of chunk_cols (a rank's window)
+    if chunk_cols > PIECE_COLS and chunk_cols % PIECE_COLS == 0:
+        m = chunk_cols // PIECE_COLS
+        if chunks is not None:
+            chunks = [c * m + j for c in chunks for j in range(m)]
+        chunk_cols = PIECE_COLS
+    kw["procs"] = max(1, min(4, (os.cpu_count() or 2) // 2))
     if spec["files"] > 1:
         # one read set per input file, depth / files each, its own seed (single-GPU workloads)
         return [synth_chunked(ref, chunk_cols, depth=spec["depth"] // spec["files"], read_len=150, seed=seed_reads + 1000 * k, chunks=chunks, **kw)
@@ -506,7 +519,7 @@ def run_workload(a, wlname, ctx, secondary=False):
     from synth import synth_ref
 
     spec = WORKLOADS[wlname]
-    kind, depth, def_cols, alg_bpb = spec["kind"], spec["depth"], spec["cols"], spec["bpb"]
+    kind, depth, def_cols, alg_bpb = spec["kind"], spec["depth"], spec.get("bench_cols", spec["cols"]), spec["bpb"]
     if world > 1 and (spec["gen"].get("paired") or spec["gen"].get("hotspot") or spec["files"] > 1):
         raise SystemExit("workload %s is a single-GPU measurement (its generator is not built piecewise)" % wlname)
     cols_per_gpu = a.cols or def_cols

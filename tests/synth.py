@@ -174,25 +174,40 @@ def write_synth_sam(outdir, n_ref=20000, depth=20, read_len=100, seed=7, paired=
 _CONCAT = ("flag", "mapq", "aux", "l_qseq", "mtid", "mpos", "isize", "cigar", "seq", "qual", "names", "_bases", "_quals")
 
 
-def synth_chunked(ref, chunk_cols, depth=30, read_len=150, seed=42, chunks=None, **kw):
+def _piece_job(job):
+    c0, sub, kw = job
+    rd = synth_reads(sub, **kw)
+    rd["_abs_pos"] = rd["_abs_pos"] + c0
+    return rd
+
+
+def synth_chunked(ref, chunk_cols, depth=30, read_len=150, seed=42, chunks=None, procs=1, **kw):
     """ONE long sorted input assembled from pieces: piece k holds the reads STARTING in columns [k * chunk_cols, (k + 1) * chunk_cols)
     (seed + k; they extend into the next piece's columns, so block cuts do split reads), generated independently so that a rank of
     a sharded run only has to build the pieces around its block.  chunks = iterable of piece indices (None: all).  With one piece
-    covering the whole of `ref` the result is synth_reads(ref, seed=seed) itself.  Returns the merged dict (positions absolute)."""
+    covering the whole of `ref` the result is synth_reads(ref, seed=seed) itself.  procs > 1: the pieces are built by that many threads
+    (same result).  Returns the merged dict (positions absolute)."""
     n = len(ref)
     L = read_len
     n_chunks = (n + chunk_cols - 1) // chunk_cols
-    parts = []
+    jobs = []
     for k in (range(n_chunks) if chunks is None else sorted(c for c in chunks if 0 <= c < n_chunks)):
         c0 = k * chunk_cols
         span = min(chunk_cols, n - L + 1 - c0)
         if span <= 0:
             continue
         sub = ref[c0:min(n, c0 + span + L + 16)]
-        rd = synth_reads(sub, depth=depth, read_len=L, seed=seed + k, start_span=span,
-                         n_reads=max(1, int(depth * (n if n_chunks == 1 else min(chunk_cols, n - c0)) / L)), **kw)
-        rd["_abs_pos"] = rd["_abs_pos"] + c0
-        parts.append(rd)
+        jobs.append((c0, sub, dict(depth=depth, read_len=L, seed=seed + k, start_span=span,
+                                   n_reads=max(1, int(depth * (n if n_chunks == 1 else min(chunk_cols, n - c0)) / L)), **kw)))
+    procs = min(int(procs or 1), len(jobs))
+    if procs > 1:
+        # the pieces are independent (own seed, own Generator): built by threads -- the work is large-array numpy calls, which release the
+        # interpreter lock (no worker processes: the caller may hold a GPU context, and the pieces are hundreds of MB to hand back)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(procs) as pool:
+            parts = list(pool.map(_piece_job, jobs))
+    else:
+        parts = [_piece_job(j) for j in jobs]
     if len(parts) == 1:
         out = parts[0]
         out["pos"] = out["_abs_pos"].astype(np.int32)

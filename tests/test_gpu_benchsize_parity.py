@@ -127,6 +127,19 @@ def test_bench_window_text_is_byte_identical_to_the_oracle(wl):
     assert piled > 0
 
 
+@pytest.mark.xdist_group("benchsize_g")
+def test_headline_window_text_is_byte_identical_to_the_oracle():
+    """The window `python bench.py` steps by default (WORKLOADS["mpileup30"]["bench_cols"]: 16 M columns, 503 Mbases, 1.28 GB of text, assembled from
+    4 M-column pieces): the whole text against the oracle's, by sha256 -- the oracle needs ~90 s for it."""
+    import bench
+    n_cols = bench.WORKLOADS["mpileup30"].get("bench_cols", bench.WORKLOADS["mpileup30"]["cols"])
+    want_sha, want_n, _ = _oracle("mpileup30", n_cols)
+    got_sha, got_n, piled = _engine_sha("mpileup30", n_cols)
+    assert got_n == want_n
+    assert got_sha == want_sha
+    assert piled >= 30 * 0.99 * n_cols
+
+
 @pytest.mark.xdist_group("benchsize_d")
 @pytest.mark.parametrize("env", [{"STA_BAQ_SLAB_GIB": "1"}, {"STA_BAQ_NO_SIDE_STREAM": "1"}, {"STA_BAQ_SLAB_GIB": "1", "STA_BAQ_NO_SIDE_STREAM": "1"},
                                  # round 5: the builds of the class-S kernel (baq_band7s.h: 16 = M_LOGTAB, the default; 0 = the MAP quality from the

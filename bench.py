@@ -52,7 +52,6 @@ def _wl(kind, depth, cols, argv, baq=False, bpb=None, gen=None, flags_on=0, flag
 
 _REALN, _REDO_BAQ, _NO_ORPHAN = 1 << 4, 1 << 6, 1 << 3      # STA_MPLP_* (include/samtools_amd.h)
 _PRINT_MAPQ_CHAR, _PRINT_QPOS, _PRINT_QNAME = 1 << 11, 1 << 12, 1 << 13
-PIECE_COLS = 4 << 20        # synthetic inputs above this many columns are assembled from pieces of this size (make_reads)
 WORKLOADS = {
     # BASELINE.json configs[2] (the metric's configuration): mpileup -f, BAQ on, 30x 150 bp
     # (the headline: bench.py steps a window of 16 M columns -- 503 Mbases, 3.36 M reads, 1.28 GB of text, ~2.5 GB resident with the inputs; the
@@ -62,7 +61,7 @@ WORKLOADS = {
     "mpileup30": dict(_wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True), bench_cols=16 << 20),
     "mpileup30_B": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN),
     # configs[3] shape (deep columns); --gpus N shards it like mpileup30
-    "mpileup300": _wl("mpileup", 300, 1 << 19, ["mpileup", "-f", "{fa}", "{sam}"], baq=True),
+    "mpileup300": dict(_wl("mpileup", 300, 1 << 19, ["mpileup", "-f", "{fa}", "{sam}"], baq=True), bench_cols=1 << 21),
     "mpileup300_B": _wl("mpileup", 300, 1 << 19, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN),
     # between the two emit kernels' home grounds
     "mpileup100": _wl("mpileup", 100, 1 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True),
@@ -251,13 +250,14 @@ def make_reads(wl, ref, chunk_cols, seed_reads=42, chunks=None):
         rd["_abs_pos"] = rd["_abs_pos"].copy()
         return rd
     kw = {k: g[k] for k in ("indel_rate", "trim_rate", "trim_max") if k in g}
-    # a window above PIECE_COLS is assembled from pieces of that size (a multiple of it: bench_cols), built by a few threads; `chunks`
-    # counts in units of chunk_cols (a rank's window)
-    if chunk_cols > PIECE_COLS and chunk_cols % PIECE_COLS == 0:
-        m = chunk_cols // PIECE_COLS
+    # a window above the workload's parity-test size (`cols`; `bench_cols` is a multiple of it) is assembled from pieces of that size, built by
+    # a few threads; `chunks` counts in units of chunk_cols (a rank's window)
+    piece = spec["cols"]
+    if chunk_cols > piece and chunk_cols % piece == 0:
+        m = chunk_cols // piece
         if chunks is not None:
             chunks = [c * m + j for c in chunks for j in range(m)]
-        chunk_cols = PIECE_COLS
+        chunk_cols = piece
     kw["procs"] = max(1, min(4, (os.cpu_count() or 2) // 2))
     if spec["files"] > 1:
         # one read set per input file, depth / files each, its own seed (single-GPU workloads)

@@ -83,7 +83,7 @@ extern "C" int sta_main_plpdump(int argc, char **argv)
         int r;
         while ((r = read_cb(&src[0], &b)) >= 0)
             if (sta_bam_plbuf_push(&b, buf) < 0) { ret = 1; break; }
-        if (r < -1) ret = 1;
+        if (r < -1) { fprintf(stderr, "[plpdump] error reading from input file\n"); ret = 1; }
         if (!ret && sta_bam_plbuf_push(nullptr, buf) < 0) ret = 1;
         sta_bam_plbuf_destroy(buf);
         free(b.data);

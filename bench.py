@@ -59,7 +59,7 @@ WORKLOADS = {
     #  is persistent: its tail and the latency-bound list kernels beside it are per window, and at 4 M columns they were 12 % of the step:
     #  profiles/r06_sessionZ_window_size.log)
     "mpileup30": dict(_wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True), bench_cols=16 << 20),
-    "mpileup30_B": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN),
+    "mpileup30_B": dict(_wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN), bench_cols=16 << 20),
     # configs[3] shape (deep columns); --gpus N shards it like mpileup30
     "mpileup300": dict(_wl("mpileup", 300, 1 << 19, ["mpileup", "-f", "{fa}", "{sam}"], baq=True), bench_cols=1 << 21),
     "mpileup300_B": _wl("mpileup", 300, 1 << 19, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN),
@@ -92,7 +92,7 @@ WORKLOADS = {
     "mpileup300_B_s": _wl("mpileup", 300, 1 << 19, ["mpileup", "-B", "-s", "-f", "{fa}", "{sam}"], flags_on=_PRINT_MAPQ_CHAR, flags_off=_REALN),
     "mpileup30_B_s_3files": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-s", "-f", "{fa}", "{sam}"], flags_on=_PRINT_MAPQ_CHAR, flags_off=_REALN, files=3),
     # configs[1]
-    "depth30": _wl("depth", 30, 8 << 20, ["depth", "-a", "{sam}"], bpb=0.21),
+    "depth30": dict(_wl("depth", 30, 8 << 20, ["depth", "-a", "{sam}"], bpb=0.21), bench_cols=32 << 20),
     # rows widened into after the pileup path; single GPU, results stay on the device
     "glf30": _wl("glf", 30, 4 << 20, ["glf", "-f", "{fa}", "{sam}"], bpb=1.5 + 128.0 / 30.0),
     "calmd30": _wl("calmd", 30, 4 << 20, ["calmd", "-r", "{sam}", "{fa}"], bpb=4.0),

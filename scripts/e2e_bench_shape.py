@@ -32,7 +32,10 @@ print("input: %d contigs x %d columns, %.0f Mbases, BAM %.0f MB" % (copies, cols
 # as a user runs it (no timing lines: the process ends as soon as its text is out, driver_capture.cpp driver_exit_now_if_asked), best of three
 big = os.environ.get("STA_E2E_BIG") is not None      # a multi-Gbase input: page-locked staging (the default there) against plain memory, nothing else
 for args in (["depth", "-a", bam], ["mpileup", "-B", "-f", big_fa, bam], ["mpileup", "-f", big_fa, bam]):
-    for env_extra in (({}, {"STA_PIN": "0"}, {"STA_PIN": "0", "STA_PIPE_SLOTS": "3"}) if big else ({}, {"STA_NO_FAST_EXIT": "1"})):
+    variants = ({}, {"STA_PIN": "0"}, {"STA_PIN": "0", "STA_PIPE_SLOTS": "3"}) if big else ({}, {"STA_NO_FAST_EXIT": "1"})
+    if os.environ.get("STA_E2E_VARIANTS"):        # ad-hoc A/B: ';'-separated K=V,K=V sets ("-" = nothing set)
+        variants = tuple(dict(kv.split("=", 1) for kv in v.split(",") if "=" in kv) for v in os.environ["STA_E2E_VARIANTS"].split(";"))
+    for env_extra in variants:
         ts = []
         for rep in range(3):
             t0 = time.perf_counter()
@@ -47,7 +50,7 @@ for env_extra in (({},) if big else ({}, {"STA_FAST_EXIT": "1"}, {"STA_GPU_INFLA
             p = subprocess.run([exe] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
             dt = time.perf_counter() - t0
             tl = [l for l in p.stderr.decode().split("\n") if "driver timing" in l or "driver threads" in l]
-            print(" ".join(args[:3])[:24], env_extra or "", "%.3f s wall = %.0f Mbases/s |" % (dt, mb / dt), " ".join(tl)[:420])
+            print(" ".join(args[:3])[:24], env_extra or "", "%.3f s wall = %.0f Mbases/s |" % (dt, mb / dt), " ".join(tl)[:900])
             if rep == 1:
                 for l in p.stderr.decode().split("\n"):
                     if l.startswith("[timeline]") or l.startswith("[window"): print("     ", l)

@@ -403,11 +403,11 @@ template <int NB, int DEC> __host__ __device__ constexpr size_t baq_rows_lr(int 
 
 template <int BW, int DEC>
 __device__ __forceinline__ void baq_fwd_body(const StaReadsDev &R, const StaWinDev &W, const float *q2p, const uint8_t *refc, int64_t g0, int64_t ngroups, int use_list,
-                                             double *scratch, size_t slot_dbl, int lq_cap)
+                                             double *scratch, size_t slot_dbl, int lq_cap, int64_t vb /* the workgroup's place in the launch's groups (blockIdx.x, or a strided walk) */)
 {
     constexpr int NB = 2 * BW + 1;
     const int lane = threadIdx.x & 63;
-    const int64_t gl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // group within this launch == scratch slot
+    const int64_t gl = vb * 4 + (threadIdx.x >> 6);      // group within this launch == scratch slot
     if (gl >= ngroups) return;
     const int64_t r = baq_pick(R, g0 + gl, lane, use_list, BW);
     if (r < 0) return;
@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(256) k_baq_fwd(StaReadsDev R, StaWinDev W, Baq
                                                  double *scratch, size_t slot_dbl, int lq_cap)
 {
     BAQ_TABLES_INIT()
-    baq_fwd_body<BW, DEC>(R, W, q2p, refc, g0, ngroups, use_list, scratch, slot_dbl, lq_cap);
+    baq_fwd_body<BW, DEC>(R, W, q2p, refc, g0, ngroups, use_list, scratch, slot_dbl, lq_cap, (int64_t)blockIdx.x);
 }
 
 // ---- backward + MAP + apply ----
@@ -549,11 +549,11 @@ __device__ __forceinline__ void baq_cur_seek(BaqCur &cu, const uint32_t *cigar, 
 
 template <int BW, int DEC, bool PLDS>
 __device__ __forceinline__ void baq_bwd_body(const StaReadsDev &R, const StaWinDev &W, const float *q2p, const uint8_t *refc, const double *lt_tab, uint8_t *baq_state, int64_t g0, int64_t ngroups,
-                                             int use_list, double *scratch, size_t slot_dbl, int lq_cap, int lds_rows)
+                                             int use_list, double *scratch, size_t slot_dbl, int lq_cap, int lds_rows, int64_t vb)
 {
     constexpr int NB = 2 * BW + 1;
     const int lane = threadIdx.x & 63;
-    const int64_t gl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t gl = vb * 4 + (threadIdx.x >> 6);
     if (gl >= ngroups) return;
     const int64_t r = baq_pick(R, g0 + gl, lane, use_list, BW);
     if (r < 0) return;
@@ -855,7 +855,7 @@ __global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, 
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t baq_state[];        // PLDS: [wave][row][lane], one byte per row and read
     BAQ_TABLES_INIT()
-    baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, lt_ok ? lt_s : nullptr, baq_state, g0, ngroups, use_list, scratch, slot_dbl, lq_cap, lds_rows);
+    baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, lt_ok ? lt_s : nullptr, baq_state, g0, ngroups, use_list, scratch, slot_dbl, lq_cap, lds_rows, (int64_t)blockIdx.x);
 }
 
 // Both passes of one group in one launch, for the reads that go through the list (a few dozen waves, latency bound): once its waves
@@ -866,14 +866,18 @@ __global__ void __launch_bounds__(256, 2) k_baq_list(StaReadsDev R, StaWinDev W,
                                                      const int32_t *__restrict__ range /* [lo, hi): the list groups that hold this kernel's reads (k_baq_list_partition); NULL: all */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t baq_state[];
-    if (range) {
-        // (a workgroup is four consecutive groups: it leaves when none of them is in the range -- before the tables are loaded)
-        const int64_t gb = (int64_t)blockIdx.x * 4;
-        if (gb + 4 <= range[0] || gb >= range[1]) return;
-    }
+    // The launch holds at most BAQ_LIST_MAX_WG workgroups (sta_launch_baq_list): a workgroup walks the groups of four with the grid's stride.
+    // With one workgroup per four groups the two list kernels of an indel-rich 16 M-column window (650 workgroups each, two fit a CU) took every
+    // register file of the chip for their first 2.4 ms and the persistent class-S kernel -- and the gather in front of it -- waited for them.
+    const int64_t nwg = (ngroups + 3) / 4;
+    int64_t lo = 0, hi = nwg;
+    if (range) { lo = range[0] / 4; hi = (range[1] + 3) / 4; if (hi > nwg) hi = nwg; }      // (the workgroups that hold this kernel's groups)
+    if (lo + (int64_t)blockIdx.x >= hi) return;                                            // before the tables are loaded
     BAQ_TABLES_INIT()
-    baq_fwd_body<BW, DEC>(R, W, q2p, refc, 0, ngroups, 1, scratch, slot_dbl, lq_cap);
-    baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, lt_ok ? lt_s : nullptr, baq_state, 0, ngroups, 1, scratch, slot_dbl, lq_cap, lds_rows);
+    for (int64_t vb = lo + (int64_t)blockIdx.x; vb < hi; vb += (int64_t)gridDim.x) {
+        baq_fwd_body<BW, DEC>(R, W, q2p, refc, 0, ngroups, 1, scratch, slot_dbl, lq_cap, vb);
+        baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, lt_ok ? lt_s : nullptr, baq_state, 0, ngroups, 1, scratch, slot_dbl, lq_cap, lds_rows, vb);
+    }
 }
 
 // The list (R.chain[1 .. 1 + chain[0])) holds the reads of three kernels in the order k_prep_reads' blocks appended them: band width 7
@@ -974,7 +978,10 @@ void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
     if (r.n == 0 || lq_cap <= 0 || ng <= 0) return;
     const BaqTables g_tables = baq_tables();
     const size_t slot = std::max(baq_slot_dbl(lq_cap, 8), baq_slot_dbl(lq_cap, 7));
-    const unsigned nb = (unsigned)((ng + 3) / 4);
+    static const int64_t max_wg = [] { const char *e = getenv("STA_BAQ_LIST_MAX_WG"); const long v = e ? atol(e) : 128; return (int64_t)(v < 1 ? 1 : v); }();
+    // (a list of up to 256 workgroups is launched whole, as before: measured equal at 4 M columns; 650 workgroups per class at 16 M: 27.7 -> 27.0 ms)
+    const int64_t nwg = (ng + 3) / 4;
+    const unsigned nb = (unsigned)(nwg > 2 * max_wg || getenv("STA_BAQ_LIST_MAX_WG") ? std::min<int64_t>(nwg, max_wg) : nwg);      // (k_baq_list walks the rest with the grid's stride)
     const bool plds = lq_cap <= BAQ_LDS_ROWS_MAX;
     const int rows = plds ? (lq_cap + 3) & ~3 : 0;
     const size_t lds = plds ? (size_t)4 * rows * 64 : 0;

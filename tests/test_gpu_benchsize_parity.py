@@ -144,8 +144,10 @@ def test_headline_window_text_is_byte_identical_to_the_oracle():
 @pytest.mark.parametrize("env", [{"STA_BAQ_SLAB_GIB": "1"}, {"STA_BAQ_NO_SIDE_STREAM": "1"}, {"STA_BAQ_SLAB_GIB": "1", "STA_BAQ_NO_SIDE_STREAM": "1"},
                                  # round 5: the builds of the class-S kernel (baq_band7s.h: 16 = M_LOGTAB, the default; 0 = the MAP quality from the
                                  # formula; 1 / 17 = plain instead of non-temporal row stream), the emit kernels without the XCD-aware tile mapping
-                                 {"STA_BAQ7S_MODE": "0"}, {"STA_BAQ7S_MODE": "16"}, {"STA_BAQ7S_MODE": "1"}, {"STA_BAQ7S_MODE": "17"}, {"STA_XCD_MAP": "0"}],
-                         ids=["slab1g", "noside", "slab1g_noside", "baq7s_m0", "baq7s_m16", "baq7s_m1", "baq7s_m17", "no_xcd_map"])
+                                 {"STA_BAQ7S_MODE": "0"}, {"STA_BAQ7S_MODE": "16"}, {"STA_BAQ7S_MODE": "1"}, {"STA_BAQ7S_MODE": "17"}, {"STA_XCD_MAP": "0"},
+                                 # round 6: the list kernels held to a few resident workgroups that walk the list with the grid's stride
+                                 {"STA_BAQ_LIST_MAX_WG": "3"}],
+                         ids=["slab1g", "noside", "slab1g_noside", "baq7s_m0", "baq7s_m16", "baq7s_m1", "baq7s_m17", "no_xcd_map", "list_wg3"])
 def test_env_only_engine_paths(env):
     n_cols = 3 << 18      # 786 432 columns: 157 286 reads, a 6.4 GB one-launch slab -> 7 chunks under STA_BAQ_SLAB_GIB=1
     want_sha, want_n, _ = _oracle("mpileup30", n_cols)

@@ -256,7 +256,10 @@ def make_reads(wl, ref, chunk_cols, seed_reads=42, chunks=None):
     if chunk_cols > piece and chunk_cols % piece == 0:
         m = chunk_cols // piece
         if chunks is not None:
-            chunks = [c * m + j for c in chunks for j in range(m)]
+            # (a rank's own window = all of its pieces; of its neighbours' windows only the adjacent piece: reads reach a few hundred columns)
+            cs = sorted(chunks)
+            mid = cs[len(cs) // 2]
+            chunks = [c * m + j for c in cs for j in (range(m) if c == mid else (m - 1,) if c < mid else (0,))]
         chunk_cols = piece
     kw["procs"] = max(1, min(4, (os.cpu_count() or 2) // 2))
     if spec["files"] > 1:

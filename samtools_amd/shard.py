@@ -236,6 +236,30 @@ def run_sharded_cli(argv: Sequence[str], out=None) -> int:
     dist.all_reduce(rcs, op=dist.ReduceOp.MAX)
     worst = int(rcs.item())
     t1 = time.perf_counter()
+    # STA_SHARD_PWRITE=1 with -o FILE: the text stays sharded -- after the 8-byte size all-gather every rank writes ITS block at its offset of
+    # the file (pwrite), nothing but the sizes crosses the links.  The gather funnels every rank's text through one xGMI link each into rank 0
+    # (76.8 GB/s): fine under BAQ (a 16 M-column step is 23.7 ms for 1.29 GB), seven times too slow for `-B` and `depth`.
+    if os.environ.get("STA_SHARD_PWRITE") and final and out is None:
+        sizes = exchange_sizes(n_local, dev)
+        if worst == 0:
+            if rank == 0:
+                with open(final, "wb") as fh:
+                    fh.truncate(sum(sizes))
+            dist.barrier()
+            data = memoryview(local.cpu().numpy()) if n_local else memoryview(b"")
+            fd = os.open(final, os.O_WRONLY)
+            try:
+                off, done = sum(sizes[:rank]), 0
+                while done < n_local:
+                    done += os.pwrite(fd, data[done:done + (256 << 20)], off + done)
+            finally:
+                os.close(fd)
+            dist.barrier()
+        elif rank == 0:
+            sys.stderr.write("samtools_amd.shard: a rank failed (worst exit status %d): no output written\n" % worst)
+        if os.environ.get("STA_SHARD_TIMING"):
+            sys.stderr.write("[shard %d/%d] driver %.3f s, %d bytes (%s capture); written in place %.3f s\n" % (rank, world, t_drv, n_local, "device" if dev_capture else "host", time.perf_counter() - t1))
+        return worst
     # STA_SHARD_STREAM=1: rank 0 writes every block as it arrives (two 64 MiB receive buffers) instead of staging the whole job's text
     stream = bool(os.environ.get("STA_SHARD_STREAM"))
     if stream:

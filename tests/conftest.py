@@ -26,7 +26,7 @@ def pytest_configure(config):
 
 # tests that need torch device memory, RCCL or bench-size windows: not for the CPU emulation (STA_HIPEMU)
 _NOT_UNDER_HIPEMU = ("test_bench_launch.py", "test_gpu_fullsize.py", "test_gpu_benchsize_parity.py", "test_bulk_entry_through_the_c_abi",
-                     "test_two_processes_one_gather", "test_one_process_over_rccl_with_device_capture",
+                     "test_two_processes_one_gather", "test_three_processes_write_their_blocks_in_place", "test_one_process_over_rccl_with_device_capture",
                      "test_four_processes_unequal_blocks_against_the_oracle", "test_device_capture_is_the_host_capture",
                      "test_throughput_on_bam_like_blocks")
 

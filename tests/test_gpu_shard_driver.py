@@ -121,6 +121,24 @@ def test_two_processes_one_gather(tmp_path, product_bin, pairs, cmd):
     assert open(outp, "rb").read() == want
 
 
+@pytest.mark.parametrize("cmd", [["mpileup", "-B", "-f", "{fa}"], ["depth", "-aa"]], ids=["mpileup_B", "depth"])
+def test_three_processes_write_their_blocks_in_place(tmp_path, product_bin, pairs, cmd):
+    """STA_SHARD_PWRITE=1 with -o FILE: no gather -- the ranks exchange their byte counts and each writes its block at its offset of the file
+    (the shapes without BAQ produce text seven times faster than one xGMI link carries it: DESIGN.md section 6)."""
+    sam, fa = pairs
+    args = [a.format(fa=fa) for a in cmd] + [sam]
+    want = _run(product_bin, args)
+    outp = str(tmp_path / "inplace.txt")
+    open(outp, "wb").write(b"x" * (len(want) + 1000))            # (an older, longer file: it is truncated to the new size)
+    env = dict(os.environ, STA_SHARD_BACKEND="gloo", STA_SHARD_ONE_DEVICE="1", STA_SHARD_PWRITE="1", STA_SHARD_TIMING="1", PYTHONPATH=REPO)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541" if cmd[0] == "mpileup" else "29542", "-m", "samtools_amd.shard"] + args + ["-o", outp],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=REPO)
+    assert p.returncode == 0, p.stderr.decode()[-800:]
+    assert p.stderr.count(b"written in place") == 3
+    assert open(outp, "rb").read() == want
+
+
 @pytest.mark.parametrize("cmd", [["mpileup", "-f", "{fa}"], ["depth", "-aa"]], ids=["mpileup", "depth"])
 def test_one_process_over_rccl_with_device_capture(tmp_path, product_bin, pairs, cmd):
     """The RCCL form of the product launcher on the hardware there is: `torch.distributed.run --nproc-per-node 1 -m samtools_amd.shard`

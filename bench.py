@@ -62,10 +62,10 @@ WORKLOADS = {
     "mpileup30_B": dict(_wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN), bench_cols=16 << 20),
     # configs[3] shape (deep columns); --gpus N shards it like mpileup30
     "mpileup300": dict(_wl("mpileup", 300, 1 << 19, ["mpileup", "-f", "{fa}", "{sam}"], baq=True), bench_cols=1 << 21),
-    "mpileup300_B": _wl("mpileup", 300, 1 << 19, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN),
+    "mpileup300_B": dict(_wl("mpileup", 300, 1 << 19, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN), bench_cols=1 << 21),
     # between the two emit kernels' home grounds
-    "mpileup100": _wl("mpileup", 100, 1 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True),
-    "mpileup100_B": _wl("mpileup", 100, 1 << 20, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN),
+    "mpileup100": dict(_wl("mpileup", 100, 1 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True), bench_cols=4 << 20),
+    "mpileup100_B": dict(_wl("mpileup", 100, 1 << 20, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN), bench_cols=4 << 20),
     # configs[4]: -E -A, BAQ recomputed + mate-overlap resolution on 30x PAIRED reads (99/147 + 83/163, insert ~N(300,30): about a
     # third of the pairs overlap); + 2 B per overlapping base of quality read-modify-write
     "mpileup30_EA_pairs": _wl("mpileup", 30, 4 << 20, ["mpileup", "-E", "-A", "-f", "{fa}", "{sam}"], baq=True, gen={"paired": True},
@@ -75,11 +75,11 @@ WORKLOADS = {
     "mpileup30_hotspot": _wl("mpileup", 30, 4 << 20, ["mpileup", "-d", "100000", "-f", "{fa}", "{sam}"], baq=True, gen={"hotspot": (300, 10000)}, max_depth=100000),
     "mpileup30_B_hotspot": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-d", "100000", "-f", "{fa}", "{sam}"], gen={"hotspot": (300, 10000)}, flags_off=_REALN, max_depth=100000),
     # BAQ with a real indel spectrum: 5 % of the reads carry a 1-3 bp insertion or deletion (band-8 / general-band kernels under load)
-    "mpileup30_indel": _wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True, gen={"indel_rate": 0.05}),
+    "mpileup30_indel": dict(_wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True, gen={"indel_rate": 0.05}), bench_cols=16 << 20),
     # trimmed reads: half of the reads lose 1..50 bases at one end, i.e. fifty-one read lengths side by side (adapter / quality trimming of
     # real data).  Round 4's class-S grouping (64 consecutive reads of ONE length) sent nearly all of them through the list kernels; the
     # per-length dense groups of round 5 keep them in k_baq7s
-    "mpileup30_trim": _wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True, gen={"trim_rate": 0.5}),
+    "mpileup30_trim": dict(_wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True, gen={"trim_rate": 0.5}), bench_cols=16 << 20),
     # three input files, 10x each (the shape of test/dat/mpileup.out.1): the per-file column groups of bam_plcmd.c:669-857 at bench size
     "mpileup30_3files": _wl("mpileup", 30, 4 << 20, ["mpileup", "-f", "{fa}", "{sam}"], baq=True, files=3),
     "mpileup30_B_3files": _wl("mpileup", 30, 4 << 20, ["mpileup", "-B", "-f", "{fa}", "{sam}"], flags_off=_REALN, files=3),

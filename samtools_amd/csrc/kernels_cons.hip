@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) k_cons_walk(Win w, Par o, int64_t n_list,
 
 // The Bayesian caller looks up eleven table entries per read and column (q2p, mqual_pow_1m, nine log-probabilities): the
 // parameter set(s) and the two small tables are copied into LDS once per workgroup (10 KB, 18 KB in the mixed mode).
-template <int KIND> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_cons_col(Win w, Par o, const Tables *t, int64_t n_cols)
+template <int KIND> __global__ void __launch_bounds__(256) k_cons_col(Win w, Par o, const Tables *t, int64_t n_cols)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int32_t c0 = (int32_t)(c & ~63ll), c1 = (int32_t)(c0 + 63 < n_cols ? c0 + 63 : n_cols - 1);      // this wave's columns

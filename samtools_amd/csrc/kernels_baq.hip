@@ -861,7 +861,7 @@ __global__ void __launch_bounds__(256, 2) k_baq_bwd(StaReadsDev R, StaWinDev W, 
 // Both passes of one group in one launch, for the reads that go through the list (a few dozen waves, latency bound): once its waves
 // are placed they run to the end beside the persistent class-S kernel, instead of the second pass queueing behind it for a free slot.
 // A wave's own forward rows are visible to its backward pass in program order; nothing is shared between waves.
-template <int BW, int DEC, bool PLDS>
+template <int BW, int DEC, bool PLDS, bool STRIDED>
 __global__ void __launch_bounds__(256, 2) k_baq_list(StaReadsDev R, StaWinDev W, BaqTables T, int64_t ngroups, double *scratch, size_t slot_dbl, int lq_cap, int lds_rows,
                                                      const int32_t *__restrict__ range /* [lo, hi): the list groups that hold this kernel's reads (k_baq_list_partition); NULL: all */)
 {
@@ -874,6 +874,12 @@ __global__ void __launch_bounds__(256, 2) k_baq_list(StaReadsDev R, StaWinDev W,
     if (range) { lo = range[0] / 4; hi = (range[1] + 3) / 4; if (hi > nwg) hi = nwg; }      // (the workgroups that hold this kernel's groups)
     if (lo + (int64_t)blockIdx.x >= hi) return;                                            // before the tables are loaded
     BAQ_TABLES_INIT()
+    if (!STRIDED) {          // one workgroup per four groups (the loop costs this kernel 19 more spilled registers: its own instantiation)
+        const int64_t vb = lo + (int64_t)blockIdx.x;
+        baq_fwd_body<BW, DEC>(R, W, q2p, refc, 0, ngroups, 1, scratch, slot_dbl, lq_cap, vb);
+        baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, lt_ok ? lt_s : nullptr, baq_state, 0, ngroups, 1, scratch, slot_dbl, lq_cap, lds_rows, vb);
+        return;
+    }
     for (int64_t vb = lo + (int64_t)blockIdx.x; vb < hi; vb += (int64_t)gridDim.x) {
         baq_fwd_body<BW, DEC>(R, W, q2p, refc, 0, ngroups, 1, scratch, slot_dbl, lq_cap, vb);
         baq_bwd_body<BW, DEC, PLDS>(R, W, q2p, refc, lt_ok ? lt_s : nullptr, baq_state, 0, ngroups, 1, scratch, slot_dbl, lq_cap, lds_rows, vb);
@@ -985,7 +991,9 @@ void sta_launch_baq_list(hipStream_t s, const StaReadsDev &r, const StaWinDev &w
     const bool plds = lq_cap <= BAQ_LDS_ROWS_MAX;
     const int rows = plds ? (lq_cap + 3) & ~3 : 0;
     const size_t lds = plds ? (size_t)4 * rows * 64 : 0;
-#define BAQ_LIST_LAUNCH(BW_, DEC_, P_) hipLaunchKernelGGL((k_baq_list<BW_, DEC_, P_>), dim3(nb), dim3(256), lds, s, r, w, g_tables, ng, (double *)scratch, slot, lq_cap, rows, range)
+    const bool strided = (int64_t)nb < nwg;
+#define BAQ_LIST_LAUNCH(BW_, DEC_, P_) do { if (strided) hipLaunchKernelGGL((k_baq_list<BW_, DEC_, P_, true>), dim3(nb), dim3(256), lds, s, r, w, g_tables, ng, (double *)scratch, slot, lq_cap, rows, range); \
+                                            else hipLaunchKernelGGL((k_baq_list<BW_, DEC_, P_, false>), dim3(nb), dim3(256), lds, s, r, w, g_tables, ng, (double *)scratch, slot, lq_cap, rows, range); } while (0)
     if (bw == 7) {
         if (baq_dec_mode() == 2) { if (plds) BAQ_LIST_LAUNCH(7, 2, true); else BAQ_LIST_LAUNCH(7, 2, false); }
         else { if (plds) BAQ_LIST_LAUNCH(7, 1, true); else BAQ_LIST_LAUNCH(7, 1, false); }

@@ -208,9 +208,13 @@ void sta_launch_cons_read_a(hipStream_t s, const Win &w, const Par &o, const Tab
 void sta_launch_cons_prepare(hipStream_t s, const Win &w, const Par &o, const Tables *t, int32_t *gran2read, int64_t n_bases)
 {
     if (w.n_reads > 0 && prepare_is_per_base(o)) {
-        hipMemsetAsync(gran2read, 0xff, (size_t)((n_bases + 7) / 8) * 4, s);
-        hipLaunchKernelGGL(k_cons_granules, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, gran2read);
-        hipLaunchKernelGGL(k_cons_prepare_base, dim3(blocks_for((n_bases + 7) / 8)), dim3(256), 0, s, w, o, gran2read, (n_bases + 7) / 8);
+        // (a window whose records hold no base -- SEQ "*" throughout: five such reads in a row under STA_WINDOW_READS=5 -- has no granules: a grid
+        //  of 0 workgroups is hipErrorInvalidConfiguration and the whole run failed; found on the device by hunt5 / hunt6 in round 6)
+        if (n_bases > 0) {
+            hipMemsetAsync(gran2read, 0xff, (size_t)((n_bases + 7) / 8) * 4, s);
+            hipLaunchKernelGGL(k_cons_granules, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, gran2read);
+            hipLaunchKernelGGL(k_cons_prepare_base, dim3(blocks_for((n_bases + 7) / 8)), dim3(256), 0, s, w, o, gran2read, (n_bases + 7) / 8);
+        }
         hipLaunchKernelGGL(k_cons_prepare_md, dim3(blocks_for(w.n_reads)), dim3(256), 0, s, w, o);
         return;
     }

@@ -57,6 +57,8 @@ hipemu_switch:
     .size hipemu_switch, .-hipemu_switch
 )");
 
+thread_local hipError_t tl_last = hipSuccess;       // what hipGetLastError() hands out next
+
 namespace hipemu {
 
 enum { S_READY = 0, S_WAVE, S_BLOCK, S_DONE };
@@ -445,6 +447,14 @@ void run(const Launch &L)
     const size_t n = (size_t)L.block.x * L.block.y * L.block.z;
     if (!n || n > 1024) die("workgroup size out of range");
     if (g_trace) fprintf(stderr, "hipemu: %s grid %u x %u x %u, workgroup %u, lds %zu\n", L.name, L.grid.x, L.grid.y, L.grid.z, L.block.x, L.shmem);
+    // what the HIP runtime refuses with hipErrorInvalidConfiguration: an empty grid, more than 64 KiB of dynamic LDS without the attribute.
+    // The device build returns the error from hipGetLastError() and runs nothing; so does this one (found on the device by hunt5 / hunt6,
+    // round 6: a consensus window whose reads hold no base launched a grid of 0 workgroups -- the emulation had run "nothing" silently).
+    if ((size_t)L.grid.x * L.grid.y * L.grid.z == 0 || L.shmem > 65536) {
+        if (g_trace || getenv("HIPEMU_STRICT")) fprintf(stderr, "hipemu: %s: invalid configuration (grid %u x %u x %u, lds %zu)\n", L.name, L.grid.x, L.grid.y, L.grid.z, L.shmem);
+        ::tl_last = (hipError_t)9;       // hipErrorInvalidConfiguration
+        return;
+    }
     if (L.shmem > HIPEMU_LDS_BYTES) die("more dynamic LDS than a CU has");
     S.launch = &L; reg_enter();
     {
@@ -490,7 +500,6 @@ extern "C" void __sanitizer_cov_trace_pc()
 // ---- runtime API ----
 namespace {
 const bool g_poison = hipemu::env_long("HIPEMU_POISON", 1) != 0;
-thread_local hipError_t tl_last = hipSuccess;
 struct Ev { double t; };
 double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 }
@@ -506,7 +515,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
     return hipSuccess;
 }
 hipError_t hipGetLastError() { hipError_t e = tl_last; tl_last = hipSuccess; return e; }
-const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory" : "hipemu error"; }
+const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory" : (int)e == 9 ? "invalid configuration argument" : "hipemu error"; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipMallocRaw(void **p, size_t n)
 {

@@ -101,3 +101,28 @@ def test_bulk_entry_through_the_c_abi(oracle_bin, mode):
     assert c == info.n_cols and info.n_kept_reads == n
     assert len(got) == len(rows)
     assert got == rows
+
+
+def test_window_of_reads_without_seq(tmp_path, product_bin, oracle_bin):
+    """A window whose records hold no base at all (SEQ "*" throughout): the per-base preparation has nothing to launch -- a grid of 0 workgroups is
+    hipErrorInvalidConfiguration and failed the whole run (found on the device by scripts/hunt5.py / hunt6.py with 5-read windows in round 6; the CPU
+    emulation of the kernels now refuses such a launch as the HIP runtime does)."""
+    import random
+    rnd = random.Random(3)
+    ref = "".join(rnd.choice("ACGT") for _ in range(600))
+    sam = str(tmp_path / "s.sam")
+    with open(sam, "w") as f:
+        f.write("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c1\tLN:600\n")
+        for i in range(12):
+            f.write("a%d\t0\tc1\t%d\t40\t50M\t*\t0\t0\t%s\t%s\n" % (i, 10 + 3 * i, ref[9 + 3 * i:59 + 3 * i], "F" * 50))
+        for i in range(9):
+            f.write("b%d\t0\tc1\t%d\t40\t40M\t*\t0\t0\t*\t*\n" % (i, 250 + 2 * i))
+        for i in range(12):
+            f.write("c%d\t16\tc1\t%d\t40\t50M\t*\t0\t0\t%s\t%s\n" % (i, 430 + 3 * i, ref[429 + 3 * i:479 + 3 * i], "F" * 50))
+    for opts in (["-f", "pileup", "-d", "3"], ["-f", "fastq", "-a", "--min-MQ", "20", "-C", "30"], ["-m", "simple", "-f", "pileup"]):
+        rc, want, err = _run(oracle_bin, opts + [sam])
+        assert rc == 0, err
+        for env in ({"STA_WINDOW_COLS": "37"}, {"STA_WINDOW_READS": "3", "STA_WINDOW_COLS": "37"}, {"STA_WINDOW_COLS": "100"}, {}):
+            rc2, got, err2 = _run(product_bin, opts + [sam], env)
+            assert rc2 == 0, (opts, env, err2[-300:])
+            assert got == want, (opts, env)

@@ -451,6 +451,7 @@ void run(const Launch &L)
     // The device build returns the error from hipGetLastError() and runs nothing; so does this one (found on the device by hunt5 / hunt6,
     // round 6: a consensus window whose reads hold no base launched a grid of 0 workgroups -- the emulation had run "nothing" silently).
     if ((size_t)L.grid.x * L.grid.y * L.grid.z == 0) {
+        if (const char *lf = getenv("HIPEMU_STRICT_FILE")) { if (FILE *fh = fopen(lf, "a")) { fprintf(fh, "%s grid %u x %u x %u\n", L.name, L.grid.x, L.grid.y, L.grid.z); fclose(fh); } }
         if (g_trace || getenv("HIPEMU_STRICT")) fprintf(stderr, "hipemu: %s: invalid configuration (grid %u x %u x %u, lds %zu)\n", L.name, L.grid.x, L.grid.y, L.grid.z, L.shmem);
         ::tl_last = (hipError_t)9;       // hipErrorInvalidConfiguration
         return;

@@ -1498,6 +1498,7 @@ int sta_bgzf_inflate(int32_t device, const uint8_t *comp, uint64_t comp_bytes, c
         if (blocks[b].comp_off + blocks[b].clen > comp_bytes || blocks[b].out_off + blocks[b].isize > out_bytes) return STA_ERR_ARG;
     if (hipSetDevice(device) != hipSuccess) return STA_ERR_NO_DEVICE;
     if (n_blocks == 0) return STA_OK;
+    (void)hipGetLastError();       // (this thread's last error is sticky: whatever an earlier call of the process left behind is not this call's)
     uint8_t *d_comp = nullptr, *d_out = nullptr; StaBgzfBlock *d_blk = nullptr; uint32_t *d_st = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
     int rc = STA_ERR_HIP;
